@@ -1,0 +1,529 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures in tests/golden/*.npz by RUNNING THE REFERENCE.
+
+This script is the only place that imports /root/reference (read-only).  It
+exists in this container only; on the GPU box the reference is absent and the
+script exits cleanly.  Nothing of the reference is copied: the fixtures hold
+inputs (ours, seeded) and the outputs the reference's functions returned.
+
+How the reference is made importable:
+  * `numba` is not installed -> tests/golden/_numba_shim provides identity
+    decorators (all reference uses are cache=True only);
+  * MPLBACKEND=Agg;
+  * two harness-side injections for the GJK-backed methods, because at HEAD
+    bezier.py never imports gjkNew (bezier.py:21-22 commented out) and
+    `_minDist` builds `Bezier([x, y, z])` from a list (bezier.py:1304) which the
+    constructor rejects (bezier.py:58): `bez.gjkNew = gjk.gjkNew` and a Bezier
+    subclass that coerces list input with the same np.array(..., ndmin=2,
+    dtype=float) the reference's own cpts setter uses (bezier.py:92).
+  * every gjkNew/_minDist call runs under a setitimer alarm and a
+    RecursionError guard; non-terminating inputs are recorded as such.
+
+Usage:  python tests/golden/gen_golden.py            (writes tests/golden/*.npz)
+"""
+import os
+import signal
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+REF = "/root/reference"
+
+if not os.path.isdir(REF):
+    print("reference absent (%s): nothing to do" % REF)
+    sys.exit(0)
+
+os.environ.setdefault("MPLBACKEND", "Agg")
+sys.dont_write_bytecode = True
+sys.path.insert(0, os.path.join(HERE, "_numba_shim"))
+sys.path.insert(0, REF)
+sys.path.insert(0, os.path.join(REF, "Examples"))
+sys.path.insert(0, REPO)
+
+import numpy as np  # noqa: E402
+
+import bezier as bez  # noqa: E402  (reference)
+import optimization as opt  # noqa: E402  (reference)
+from gjk import gjk as G  # noqa: E402  (reference)
+
+from optimalbeziertrajectorygeneration_amd import synth  # noqa: E402  (ours)
+
+# ---------------------------------------------------------------- injections
+bez.gjkNew = G.gjkNew
+_OrigBezier = bez.Bezier
+
+
+class _PB(_OrigBezier):
+    def __init__(self, cpts=None, t0=0.0, tf=1.0, tau=None):
+        if cpts is not None and not isinstance(cpts, np.ndarray):
+            cpts = np.array(cpts, ndmin=2, dtype=float)
+        super().__init__(cpts=cpts, t0=t0, tf=tf, tau=tau)
+
+
+bez.Bezier = _PB
+
+
+class _Timeout(Exception):
+    pass
+
+
+def _alarm(signum, frame):
+    raise _Timeout()
+
+
+signal.signal(signal.SIGALRM, _alarm)
+
+
+def guarded(fn, budget, *a, **k):
+    """-> (status, value); status 0 ok, 1 timeout, 2 RecursionError."""
+    signal.setitimer(signal.ITIMER_REAL, budget)
+    try:
+        v = fn(*a, **k)
+        return 0, v
+    except _Timeout:
+        return 1, None
+    except RecursionError:
+        return 2, None
+    finally:
+        signal.setitimer(signal.ITIMER_REAL, 0)
+
+
+# -------------------------------------------------------- support-index trace
+_trace = []
+_orig_supportPts = G.supportPts
+_cur_polys = [None, None]
+
+
+def _first_row(poly, pt):
+    idx = np.where((poly == pt).all(axis=1))[0]
+    return int(idx[0])
+
+
+def _traced_supportPts(poly1, poly2, direction):
+    newPt, (p1, p2) = _orig_supportPts(poly1, poly2, direction)
+    _trace.append((_first_row(poly1, p1), _first_row(poly2, p2)))
+    return newPt, (p1, p2)
+
+
+G.supportPts = _traced_supportPts
+_gjk_calls = [0]
+_orig_gjkNew = G.gjkNew
+
+
+def _counted_gjkNew(*a, **k):
+    _gjk_calls[0] += 1
+    return _orig_gjkNew(*a, **k)
+
+
+bez.gjkNew = _counted_gjkNew
+
+
+def run_gjk(p1, p2, budget=0.5):
+    """-> dict(status, flag, c1, c2, dist, trace)."""
+    del _trace[:]
+    import io
+    import contextlib
+    with contextlib.redirect_stdout(io.StringIO()):
+        st, v = guarded(_orig_gjkNew, budget, p1, p2)
+    tr = np.array(_trace, dtype=np.int16).reshape(-1, 2)
+    out = dict(status=st, flag=-9, c1=np.full(3, np.nan), c2=np.full(3, np.nan),
+               dist=np.nan, trace=tr)
+    if st == 0:
+        flag, info = v
+        out["flag"] = int(flag)
+        if flag == 1:
+            out["c1"] = np.asarray(info[0], dtype=float)
+            out["c2"] = np.asarray(info[1], dtype=float)
+            out["dist"] = float(info[2])
+    return out
+
+
+def gjk_group(polys, pair_a, pair_b, budget=0.5):
+    pts, off = synth.pack_polys(polys)
+    n = len(pair_a)
+    flag = np.zeros(n, np.int32)
+    status = np.zeros(n, np.int32)
+    c1 = np.zeros((n, 3))
+    c2 = np.zeros((n, 3))
+    dist = np.zeros(n)
+    tr_off = np.zeros(n + 1, np.int32)
+    traces = []
+    for k in range(n):
+        r = run_gjk(polys[pair_a[k]], polys[pair_b[k]], budget)
+        flag[k], status[k] = r["flag"], r["status"]
+        c1[k], c2[k], dist[k] = r["c1"], r["c2"], r["dist"]
+        traces.append(r["trace"])
+        tr_off[k + 1] = tr_off[k] + len(r["trace"])
+    trace = np.concatenate(traces) if traces else np.zeros((0, 2), np.int16)
+    return dict(pts=pts, off=off, pair_a=np.asarray(pair_a, np.int32),
+                pair_b=np.asarray(pair_b, np.int32), flag=flag, status=status,
+                c1=c1, c2=c2, dist=dist, trace=trace.astype(np.int16), trace_off=tr_off)
+
+
+def save(name, **arrs):
+    path = os.path.join(HERE, name)
+    np.savez_compressed(path, **arrs)
+    print("wrote %-28s %8.1f KB" % (name, os.path.getsize(path) / 1024.0))
+
+
+# ==================================================================== tables
+def gen_tables():
+    d = {}
+    for (n, R) in [(10, 0), (10, 10), (20, 0), (20, 30), (20, 100), (10, 1), (30, 0),
+                   (40, 100), (5, 1), (15, 1), (2, 3)]:
+        d["elev_%d_%d" % (n, R)] = bez.elevMatrix(n, R)
+    for n in [3, 5, 10, 15, 20]:
+        d["prod_%d" % n] = bez.bezProductCoefficients(n, n)
+        d["prodT_%d" % n] = bez.prodMatrix(n)
+    for n in [5, 10, 15]:
+        for T in [1.0, 2.4276, 10.0]:
+            d["diff_%d_%s" % (n, repr(T))] = bez.diffMatrix(n, T)
+    save("tables.npz", **d)
+
+
+# =============================================================== Bezier ops
+def gen_ops():
+    rng = np.random.default_rng(42)
+    d = {}
+    case = 0
+    for dim in (1, 2, 3):
+        for n in (5, 10, 15):
+            a = rng.normal(0, 3, size=(dim, n + 1))
+            b = rng.normal(0, 3, size=(dim, n + 1))
+            tf = float(rng.uniform(0.5, 12.0))
+            A = bez.Bezier(a.copy(), tf=tf)
+            Bc = bez.Bezier(b.copy(), tf=tf)
+            pre = "c%d_" % case
+            d[pre + "a"], d[pre + "b"], d[pre + "tf"] = a, b, np.array(tf)
+            d[pre + "elev1"] = A.elev(1).cpts
+            d[pre + "elev7"] = A.elev(7).cpts
+            d[pre + "elev0"] = A.elev(0).cpts
+            Ad = A.diff()
+            d[pre + "diff"] = np.asarray(Ad.cpts)
+            d[pre + "diff_tf"] = np.array(Ad.tf)
+            d[pre + "diff2"] = np.asarray(Ad.diff().cpts)
+            d[pre + "normsq"] = np.asarray(A.normSquare().cpts)
+            d[pre + "mul"] = np.asarray((A * Bc).cpts)
+            d[pre + "sub"] = np.asarray((A - Bc).cpts)
+            d[pre + "add"] = np.asarray((A + Bc).cpts)
+            case += 1
+    d["n_cases"] = np.array(case)
+    save("bezier_ops.npz", **d)
+
+
+# ============================================================ problem layer
+def example1_bezopt():
+    numVeh = 2
+    return opt.BezOptimization(numVeh=numVeh, dimension=2, degree=10, minimizeGoal='TimeOpt',
+                               maxSep=1, maxSpeed=5, maxAngRate=1,
+                               initPoints=[(0, 5), (3, 0)], finalPoints=[(8, 4), (7, 10)],
+                               initSpeeds=[1] * numVeh, finalSpeeds=[1] * numVeh,
+                               initAngs=[0, np.pi / 2], finalAngs=[0, np.pi / 2],
+                               pointObstacles=[[3, 2], [6, 7]])
+
+
+def gen_problem():
+    d = {}
+    rng = np.random.default_rng(7)
+    # --- Example1 (time-optimal, speeds+angles, 2 point obstacles)
+    bo = example1_bezopt()
+    xg = bo.generateGuess(std=0)
+    d["ex1_xguess"] = xg
+    d["ex1_yguess"] = bo.reshapeVector(xg)
+    xr = xg + rng.normal(0, 0.3, size=xg.shape)
+    xr[-1] = 3.7
+    d["ex1_x"] = xr
+    d["ex1_y"] = bo.reshapeVector(xr)
+    xg2 = bo.generateGuess(std=0.5, seed=3)
+    d["ex1_xguess_std"] = xg2
+    for R in (0, 30, 100):
+        opt.DEG_ELEV = R
+        for tag, x in (("g", xg), ("r", xr)):
+            d["ex1_%s_tsep_class_R%d" % (tag, R)] = bo.temporalSeparationConstraints(x)
+            d["ex1_%s_tsep_example_R%d" % (tag, R)] = opt._temporalSeparationConstraints(
+                bo.reshapeVector(x), 2, 2, 1)
+            d["ex1_%s_maxspeed_R%d" % (tag, R)] = bo.maxSpeedConstraints(x)
+            d["ex1_%s_minspeed_R%d" % (tag, R)] = bo.minSpeedConstraints(x)
+            if R <= 30:
+                d["ex1_%s_angrate_R%d" % (tag, R)] = bo.maxAngularRateConstraints(x)
+    opt.DEG_ELEV = 0
+    d["ex1_obj"] = np.array(bo.objectiveFunction(xr))
+
+    # --- Swarm example as written (36 vehicles, 3-D, degree 5, Euclidean)
+    import SwarmOfAerialVehicles as SW
+    numVeh, initPts, finalPts = SW.generatePointsFromImage(SW.CAS_IMG)
+    bs = opt.BezOptimization(numVeh=numVeh, dimension=3, degree=5, minimizeGoal='Euclidean',
+                             maxSep=0.9, initPoints=initPts, finalPoints=finalPts)
+    xs = SW.generate3DGuess(initPts, finalPts, 5)
+    d["sw_init"], d["sw_final"] = initPts, finalPts
+    d["sw_xguess"] = xs
+    d["sw_yguess"] = bs.reshapeVector(xs)
+    xsr = xs + rng.normal(0, 0.2, size=xs.shape)
+    d["sw_x"] = xsr
+    d["sw_y"] = bs.reshapeVector(xsr)
+    d["sw_g_tsep"] = bs.temporalSeparationConstraints(xs)
+    d["sw_r_tsep"] = bs.temporalSeparationConstraints(xsr)
+    d["sw_r_obj"] = np.array(bs.objectiveFunction(xsr))
+    d["sw_genguess"] = bs.generateGuess(std=0)
+
+    # --- fixed-tf model with speeds (not time-optimal), 3 vehicles
+    bf = opt.BezOptimization(numVeh=3, dimension=2, degree=7, minimizeGoal='Euclidean',
+                             maxSep=0.5, maxSpeed=4, minSpeed=0.2, maxAngRate=2,
+                             initPoints=[(0, 0), (1, 5), (9, 2)], finalPoints=[(10, 1), (8, 8), (0, 7)],
+                             initSpeeds=[1, 2, 0.5], finalSpeeds=[1, 1, 2],
+                             initAngs=[0.1, -0.4, 2.0], finalAngs=[0.3, 0.0, 2.5], tf=7.0)
+    xf = bf.generateGuess(std=0.4, seed=11)
+    d["fx_x"] = xf
+    d["fx_y"] = bf.reshapeVector(xf)
+    d["fx_tsep"] = bf.temporalSeparationConstraints(xf)
+    d["fx_maxspeed"] = bf.maxSpeedConstraints(xf)
+    d["fx_minspeed"] = bf.minSpeedConstraints(xf)
+    d["fx_angrate"] = bf.maxAngularRateConstraints(xf)
+    d["fx_obj"] = np.array(bf.objectiveFunction(xf))
+    bfa = opt.BezOptimization(numVeh=3, dimension=2, degree=7, minimizeGoal='Accel',
+                              initPoints=[(0, 0), (1, 5), (9, 2)], finalPoints=[(10, 1), (8, 8), (0, 7)],
+                              initSpeeds=[1, 2, 0.5], finalSpeeds=[1, 1, 2],
+                              initAngs=[0.1, -0.4, 2.0], finalAngs=[0.3, 0.0, 2.5], tf=7.0)
+    d["fx_obj_accel"] = np.array(bfa.objectiveFunction(xf))
+    save("problem.npz", **d)
+
+
+def ref_constraints(Y, N, dim, tf, maxSep, vmax, vmin, wmax, R, ang=True):
+    opt.DEG_ELEV = R
+    out = dict(tsep=opt._temporalSeparationConstraints(Y, N, dim, maxSep),
+               maxspeed=opt._maxSpeedConstraints(Y, N, dim, tf, vmax),
+               minspeed=opt._minSpeedConstraints(Y, N, dim, tf, vmin))
+    if ang and dim == 2:
+        with np.errstate(all="ignore"):
+            out["angrate"] = opt._maxAngularRateConstraints(Y, N, dim, tf, wmax)
+    opt.DEG_ELEV = 0
+    return out
+
+
+def gen_constraints():
+    d = {}
+    cases = [
+        # name, N, d, n, R, tf, seed
+        ("c2", 8, 3, 10, 0, 10.0, 1234),
+        ("c2file_syn", 36, 3, 5, 0, 1.0, 1234),
+        ("c3", 64, 2, 10, 0, 10.0, 1234),
+        ("c3s_R10", 8, 2, 10, 10, 10.0, 1234),
+        ("c3s_R100", 8, 2, 10, 100, 10.0, 1234),
+        ("c4s", 12, 2, 15, 0, 10.0, 1234),
+        ("c4s_R3", 6, 2, 15, 3, 2.5, 99),
+        ("d1", 5, 1, 6, 2, 3.0, 5),
+        ("n20", 4, 2, 20, 5, 4.0, 6),
+        ("n3", 7, 3, 3, 0, 4.0, 8),
+    ]
+    names = []
+    for (name, N, dim, n, R, tf, seed) in cases:
+        Y = synth.swarm_control_points(N, dim, n, seed=seed)
+        r = ref_constraints(Y, N, dim, tf, 0.9, 5.0, 0.3, 1.0, R)
+        d[name + "_Y"] = Y
+        d[name + "_par"] = np.array([N, dim, n, R, tf, 0.9, 5.0, 0.3, 1.0])
+        for k, v in r.items():
+            d[name + "_" + k] = v
+        names.append(name)
+    # inf/nan case: one stationary vehicle (all control points equal) and one
+    # straight constant-speed line -> exact zeros in numerator/denominator
+    Y = synth.swarm_control_points(4, 2, 6, seed=21)
+    Y[0, :] = 3.0
+    Y[1, :] = -2.0
+    Y[2] = np.linspace(0, 6, 7)
+    Y[3] = np.linspace(1, 4, 7)
+    r = ref_constraints(Y, 4, 2, 2.0, 0.9, 5.0, 0.3, 1.0, 0)
+    d["nan_Y"] = Y
+    d["nan_par"] = np.array([4, 2, 6, 0, 2.0, 0.9, 5.0, 0.3, 1.0])
+    for k, v in r.items():
+        d["nan_" + k] = v
+    names.append("nan")
+    d["names"] = np.array(names)
+    save("constraints.npz", **d)
+
+
+# ======================================================================= GJK
+def literal_polys():
+    """Literal test inputs used by the reference's own demos (inputs only):
+    gjk/gjk.py:690-745 (poly1..8), gjk/gjkTests.py:23-46, bezier.py:1794-1804."""
+    P = []
+    P.append([(4, 11, 0), (4, 5, 0), (9, 9, 0)])
+    P.append([(5, 6, 0), (10, 2, 0), (13, 1, 0), (12, 3, 0), (15, 6, 0)])
+    P.append([(4, 11, -1), (4, 5, -1), (9, 9, -1), (7, 8, 3)])
+    P.append([(4, 11, 3), (4, 5, 3), (9, 9, 3), (7, 8, -1)])
+    P.append([(4, 11, -3), (4, 5, -3), (9, 9, -3), (7, 8, -1)])
+    P.append([(4, 11, 0), (4, 5, 1), (9, 9, 2), (7, 8, 3)])
+    P.append([(-1, -1, 0), (1, 1, 0), (1, -1, 0), (-1, 1, 0)])
+    P.append([(-1, -1, -3), (1, 1, -3), (1, -1, -3), (-1, 1, -3), (0, 0, -1)])
+    # dyn4j article pair (gjk/gjkTests.py:23-34)
+    P.append([(4, 11, 0), (4, 5, 0), (9, 9, 0)])
+    P.append([(8, 6, 0), (10, 2, 0), (13, 1, 0), (15, 6, 0)])
+    # 3-D triangle pair (gjk/gjkTests.py:36-46)
+    P.append([(1, 0, -2), (0, 4, -3), (0, 0, 0)])
+    P.append([(3, 8, 1), (5, -4, 1), (0.2, 0, 5)])
+    return [np.array(p, dtype=float) for p in P]
+
+
+def gen_gjk():
+    d = {}
+    polys = literal_polys()
+    n = len(polys)
+    pa, pb = [], []
+    for i in range(n):
+        for j in range(n):
+            if i != j:
+                pa.append(i)
+                pb.append(j)
+    g = gjk_group(polys, pa, pb)
+    for k, v in g.items():
+        d["lit_" + k] = v
+    print("  literal: %d pairs, flags %s, timeouts %d" % (
+        len(pa), np.bincount(g["flag"][g["status"] == 0] + 1, minlength=3), (g["status"] != 0).sum()))
+
+    # C3 2-D swarm: 64 vehicles (degree-10 hulls) + 8 polygons
+    Y = synth.swarm_control_points(64, 2, 10, seed=1234)
+    polys = synth.hulls_from_Y(Y, 2) + synth.polygon_obstacles(8, seed=1234)
+    pa, pb = synth.swarm_pairs(64, 8)
+    g = gjk_group(polys, pa, pb)
+    for k, v in g.items():
+        d["c3_" + k] = v
+    ok = g["status"] == 0
+    print("  c3 2-D: %d pairs, flags(-1,0,1) %s, timeouts %d, mean supports %.2f" % (
+        len(pa), np.bincount(g["flag"][ok] + 1, minlength=3), (~ok).sum(),
+        np.diff(g["trace_off"])[ok].mean()))
+
+    # a denser 2-D swarm in a smaller box so that more pairs collide / touch
+    rng = np.random.default_rng(77)
+    Yd = synth.swarm_control_points(24, 2, 6, seed=77)
+    Yd *= 0.25
+    polys = synth.hulls_from_Y(Yd, 2)
+    pa, pb = synth.swarm_pairs(24, 0)
+    g = gjk_group(polys, pa, pb)
+    for k, v in g.items():
+        d["dense_" + k] = v
+    ok = g["status"] == 0
+    print("  dense 2-D: %d pairs, flags %s, timeouts %d" % (
+        len(pa), np.bincount(g["flag"][ok] + 1, minlength=3), (~ok).sum()))
+
+    # 3-D swarm: 64 vehicles degree 10 (terminating subset + non-terminating ids)
+    Y3 = synth.swarm_control_points(64, 3, 10, seed=1234)
+    polys = synth.hulls_from_Y(Y3, 3)
+    pa, pb = synth.swarm_pairs(64, 0)
+    g = gjk_group(polys, pa, pb, budget=0.4)
+    for k, v in g.items():
+        d["s3d_" + k] = v
+    ok = g["status"] == 0
+    print("  3-D: %d pairs, flags %s, timeouts %d, mean supports %.2f" % (
+        len(pa), np.bincount(g["flag"][ok] + 1, minlength=3), (~ok).sum(),
+        np.diff(g["trace_off"])[ok].mean()))
+    save("gjk.npz", **d)
+
+
+# ==================================================================== minDist
+def run_mindist(c1, c2, budget=5.0):
+    _gjk_calls[0] = 0
+    import io
+    import contextlib
+    with contextlib.redirect_stdout(io.StringIO()):
+        st, v = guarded(bez._minDist, budget, c1, c2)
+    calls = _gjk_calls[0]
+    if st == 0:
+        return st, np.array([float(v[0]), float(v[1]), float(v[2])]), calls
+    return st, np.full(3, np.nan), calls
+
+
+def run_mindist2poly(c1, poly, budget=5.0):
+    _gjk_calls[0] = 0
+    import io
+    import contextlib
+    with contextlib.redirect_stdout(io.StringIO()):
+        st, v = guarded(bez._minDist2Poly, budget, c1, poly)
+    calls = _gjk_calls[0]
+    if st == 0:
+        pt = np.asarray(v[2], dtype=float)
+        if pt.ndim == 0:
+            pt = np.full(3, float(pt))
+        return st, np.array([float(v[0]), float(v[1])]), pt, calls
+    return st, np.full(2, np.nan), np.full(3, np.nan), calls
+
+
+def gen_mindist():
+    d = {}
+    sys.setrecursionlimit(1000)
+    # literal curves of bezier.py:1774-1804 (inputs only)
+    cpts1 = np.array([(0, 1, 2, 3, 4, 5), (1, 2, 0, 0, 2, 1), (0, 1, 2, 3, 4, 5)], dtype=float)
+    cpts2 = np.array([(0, 1, 2, 3, 4, 5), (3, 2, 0, 0, 2, 3), (5, 4, 3, 2, 1, 0)], dtype=float)
+    cpts3 = np.array([(0, 1, 2, 3, 4, 5), (0, 1, 2, 3, 4, 5), (0, 0, 0, 0, 0, 0)], dtype=float)
+    cpts4 = np.array([(5, 4, 3, 2, 1, 0), (0, 1, 2, 3, 4, 5), (0, 0, 0, 0, 0, 0)], dtype=float)
+    cpts4[1, :] -= 1
+    cpts5 = cpts1 + 3
+    poly1 = np.array([(1, 1, 3), (1, 1, 2), (1, 2, 1), (3, 1, 3), (1, 3, 1)], dtype=float)
+    poly2 = np.array([(1, 1, 3), (1, 1, 2), (1, 2, 1), (3, -1, 3), (1, 3, 1)], dtype=float)
+    curves = [cpts1, cpts2, cpts3, cpts4, cpts5]
+    d["lit_curves"] = np.stack(curves)
+    res, stat, calls, pairs = [], [], [], []
+    for i in range(5):
+        for j in range(5):
+            if i == j:
+                continue
+            st, v, nc = run_mindist(bez.Bezier(curves[i].copy()), bez.Bezier(curves[j].copy()))
+            res.append(v); stat.append(st); calls.append(nc); pairs.append((i, j))
+    d["lit_pairs"] = np.array(pairs, np.int32)
+    d["lit_res"] = np.array(res)
+    d["lit_status"] = np.array(stat, np.int32)
+    d["lit_calls"] = np.array(calls, np.int32)
+    print("  literal curve pairs: status", np.bincount(stat, minlength=3), "calls max", max(calls))
+    # curve vs polygon
+    d["lit_polys"] = np.stack([poly1, poly2])
+    r2, p2, s2, c2, pr2 = [], [], [], [], []
+    for i in range(5):
+        for k, poly in enumerate((poly1, poly2)):
+            st, v, pt, nc = run_mindist2poly(bez.Bezier(curves[i].copy()), poly.copy())
+            r2.append(v); p2.append(pt); s2.append(st); c2.append(nc); pr2.append((i, k))
+    d["litp_pairs"] = np.array(pr2, np.int32)
+    d["litp_res"] = np.array(r2)
+    d["litp_pt"] = np.array(p2)
+    d["litp_status"] = np.array(s2, np.int32)
+    d["litp_calls"] = np.array(c2, np.int32)
+    print("  literal curve/poly: status", np.bincount(s2, minlength=3), "calls max", max(c2))
+
+    # seeded C3 pairs: first 60 pairs of a stride through the 2016 list
+    Y = synth.swarm_control_points(64, 2, 10, seed=1234)
+    pa, pb = synth.swarm_pairs(64, 0)
+    sel = np.arange(0, len(pa), len(pa) // 60)[:60]
+    res, stat, calls = [], [], []
+    for k in sel:
+        i, j = int(pa[k]), int(pb[k])
+        st, v, nc = run_mindist(bez.Bezier(Y[2 * i:2 * i + 2].copy()), bez.Bezier(Y[2 * j:2 * j + 2].copy()),
+                                budget=4.0)
+        res.append(v); stat.append(st); calls.append(nc)
+    d["c3_Y"] = Y
+    d["c3_sel"] = sel.astype(np.int32)
+    d["c3_pa"], d["c3_pb"] = pa[sel], pb[sel]
+    d["c3_res"] = np.array(res)
+    d["c3_status"] = np.array(stat, np.int32)
+    d["c3_calls"] = np.array(calls, np.int32)
+    print("  c3 curve pairs: status", np.bincount(stat, minlength=3), "calls median",
+          int(np.median(np.array(calls)[np.array(stat) == 0])), "max", max(calls))
+    # vehicles vs polygons
+    polys = synth.polygon_obstacles(8, seed=1234)
+    r2, p2, s2, c2, pr2 = [], [], [], [], []
+    for i in range(0, 64, 4):
+        for k in range(8):
+            st, v, pt, nc = run_mindist2poly(bez.Bezier(Y[2 * i:2 * i + 2].copy()), polys[k].copy(), budget=3.0)
+            r2.append(v); p2.append(pt); s2.append(st); c2.append(nc); pr2.append((i, k))
+    pts, off = synth.pack_polys(polys)
+    d["c3p_pts"], d["c3p_off"] = pts, off
+    d["c3p_pairs"] = np.array(pr2, np.int32)
+    d["c3p_res"] = np.array(r2)
+    d["c3p_pt"] = np.array(p2)
+    d["c3p_status"] = np.array(s2, np.int32)
+    d["c3p_calls"] = np.array(c2, np.int32)
+    print("  c3 curve/poly: status", np.bincount(s2, minlength=3), "calls max", max(c2))
+    save("mindist.npz", **d)
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["tables", "ops", "problem", "constraints", "gjk", "mindist"]
+    for w in which:
+        print("== " + w)
+        globals()["gen_" + w]()
