@@ -1,0 +1,221 @@
+"""ctypes binding of the CPU oracle (oracle/obtg_oracle.c).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and
+bench.py's cpu_baseline leg -- never by the product package.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libobtg_oracle.so")
+
+_lib = None
+
+DP = np.ctypeslib.ndpointer(dtype=np.float64, flags="C_CONTIGUOUS")
+IP = np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS")
+
+ST_OK, ST_MD_CAP, ST_MAXITER = 0, 1, 2
+MD_OK, MD_NODE_CAP, MD_DEPTH_CAP, MD_GJK_CAP = 0, 1, 2, 3
+
+
+def build(force=False):
+    src = os.path.join(HERE, "obtg_oracle.c")
+    if force or not os.path.exists(LIB_PATH) or os.path.getmtime(LIB_PATH) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", HERE, "-s", "-B", "libobtg_oracle.so"])
+    return LIB_PATH
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            build()
+        _lib = C.CDLL(LIB_PATH)
+        _lib.obtg_oracle_binom.restype = C.c_double
+        _lib.obtg_oracle_euclidean_obj.restype = C.c_double
+        _lib.obtg_oracle_accel_obj.restype = C.c_double
+    return _lib
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def elev_matrix(N, R):
+    T = np.empty((N + 1, N + R + 1))
+    lib().obtg_oracle_elev_matrix(C.c_int(N), C.c_int(R), _p(T))
+    return T
+
+
+def prod_coef(m, n):
+    M = np.empty(((m + 1) * (n + 1), m + n + 1))
+    lib().obtg_oracle_prod_coef(C.c_int(m), C.c_int(n), _p(M))
+    return M
+
+
+def diff_matrix(n, tf):
+    D = np.empty((n + 1, n))
+    lib().obtg_oracle_diff_matrix(C.c_int(n), C.c_double(tf), _p(D))
+    return D
+
+
+def elev(cpts, R):
+    cpts = np.atleast_2d(_f64(cpts))
+    rows, nc = cpts.shape
+    out = np.empty((rows, nc + R))
+    lib().obtg_oracle_elev(_p(cpts), C.c_int(rows), C.c_int(nc - 1), C.c_int(R), _p(out))
+    return out
+
+
+def diff(cpts, T):
+    cpts = np.atleast_2d(_f64(cpts))
+    rows, nc = cpts.shape
+    out = np.empty((rows, nc))
+    lib().obtg_oracle_diff(_p(cpts), C.c_int(rows), C.c_int(nc - 1), C.c_double(T), _p(out))
+    return out
+
+
+def mul(a, b):
+    a = np.atleast_2d(_f64(a))
+    b = np.atleast_2d(_f64(b))
+    rows, mc = a.shape
+    nc = b.shape[1]
+    out = np.empty((rows, mc + nc - 1))
+    lib().obtg_oracle_mul(_p(a), _p(b), C.c_int(rows), C.c_int(mc - 1), C.c_int(nc - 1), _p(out))
+    return out
+
+
+def normsq(x):
+    x = np.atleast_2d(_f64(x))
+    d, nc = x.shape
+    out = np.empty((1, 2 * nc - 1))
+    lib().obtg_oracle_normsq(_p(x), C.c_int(d), C.c_int(nc - 1), _p(out))
+    return out
+
+
+def temporal_sep(Y, nveh, dim, R, max_sep):
+    Y = _f64(Y)
+    n = Y.shape[1] - 1
+    P = nveh * (nveh - 1) // 2
+    out = np.empty(P * (2 * n + R + 1))
+    lib().obtg_oracle_temporal_sep(_p(Y), C.c_int(nveh), C.c_int(dim), C.c_int(n), C.c_int(R),
+                                   C.c_double(max_sep), _p(out))
+    return out
+
+
+def speed(Y, nveh, dim, R, tf, bound, is_max):
+    Y = _f64(Y)
+    n = Y.shape[1] - 1
+    out = np.empty(nveh * (2 * n + R + 1))
+    lib().obtg_oracle_speed(_p(Y), C.c_int(nveh), C.c_int(dim), C.c_int(n), C.c_int(R),
+                            C.c_double(tf), C.c_double(bound), C.c_int(int(is_max)), _p(out))
+    return out
+
+
+def ang_rate(Y, nveh, R, tf, max_rate):
+    Y = _f64(Y)
+    n = Y.shape[1] - 1
+    out = np.empty(nveh * (4 * (n + R) + 1))
+    lib().obtg_oracle_ang_rate(_p(Y), C.c_int(nveh), C.c_int(n), C.c_int(R), C.c_double(tf),
+                               C.c_double(max_rate), _p(out))
+    return out
+
+
+def euclidean_obj(Y, nveh, dim):
+    Y = _f64(Y)
+    return lib().obtg_oracle_euclidean_obj(_p(Y), C.c_int(nveh), C.c_int(dim), C.c_int(Y.shape[1] - 1))
+
+
+def accel_obj(Y, nveh, dim, R, tf):
+    Y = _f64(Y)
+    return lib().obtg_oracle_accel_obj(_p(Y), C.c_int(nveh), C.c_int(dim), C.c_int(Y.shape[1] - 1),
+                                       C.c_int(R), C.c_double(tf))
+
+
+def eval_batch(Yb, tf, nveh, dim, R, max_sep, vmax, wmax, nthreads=1, want=("sep", "speed", "ang")):
+    Yb = _f64(Yb)
+    B = Yb.shape[0]
+    n = Yb.shape[2] - 1
+    tf = _f64(np.broadcast_to(tf, (B,)))
+    P = nveh * (nveh - 1) // 2
+    o_sep = np.empty((B, P * (2 * n + R + 1))) if "sep" in want else None
+    o_sp = np.empty((B, nveh * (2 * n + R + 1))) if "speed" in want else None
+    o_an = np.empty((B, nveh * (4 * (n + R) + 1))) if ("ang" in want and dim == 2) else None
+    lib().obtg_oracle_eval_batch(_p(Yb), _p(tf), C.c_int(B), C.c_int(nveh), C.c_int(dim), C.c_int(n),
+                                 C.c_int(R), C.c_double(max_sep), C.c_double(vmax), C.c_double(wmax),
+                                 _p(o_sep) if o_sep is not None else None,
+                                 _p(o_sp) if o_sp is not None else None,
+                                 _p(o_an) if o_an is not None else None, C.c_int(nthreads))
+    return o_sep, o_sp, o_an
+
+
+def gjk(poly1, poly2, max_iter=128, md_cap=4096, trace_cap=256):
+    """-> dict(flag, c1, c2, dist, trace[n,2], n_support, status)"""
+    p1 = _f64(poly1)
+    p2 = _f64(poly2)
+    flag = C.c_int(0)
+    ns = C.c_int(0)
+    c1 = np.empty(3)
+    c2 = np.empty(3)
+    dist = C.c_double(0)
+    trace = np.zeros((trace_cap, 2), dtype=np.int16)
+    st = lib().obtg_oracle_gjk(_p(p1), C.c_int(p1.shape[0]), _p(p2), C.c_int(p2.shape[0]),
+                               C.c_int(max_iter), C.c_int(md_cap), C.byref(flag), _p(c1), _p(c2),
+                               C.byref(dist), _p(trace), C.c_int(trace_cap), C.byref(ns))
+    return dict(flag=flag.value, c1=c1, c2=c2, dist=dist.value,
+                trace=trace[:min(ns.value, trace_cap)].copy(), n_support=ns.value, status=st)
+
+
+def gjk_pairs(pts, off, pair_a, pair_b, max_iter=128, md_cap=4096, trace_cap=0, nthreads=1):
+    pts = _f64(pts)
+    off = np.ascontiguousarray(off, dtype=np.int32)
+    pa = np.ascontiguousarray(pair_a, dtype=np.int32)
+    pb = np.ascontiguousarray(pair_b, dtype=np.int32)
+    n = pa.shape[0]
+    flag = np.zeros(n, np.int32)
+    status = np.zeros(n, np.int32)
+    nsup = np.zeros(n, np.int32)
+    p1 = np.empty((n, 3))
+    p2 = np.empty((n, 3))
+    dist = np.empty(n)
+    trace = np.zeros((n, trace_cap, 2), dtype=np.int16) if trace_cap else None
+    lib().obtg_oracle_gjk_pairs(_p(pts), _p(off), _p(pa), _p(pb), C.c_int(n), C.c_int(max_iter),
+                                C.c_int(md_cap), _p(flag), _p(p1), _p(p2), _p(dist),
+                                _p(trace) if trace is not None else None, C.c_int(trace_cap),
+                                _p(nsup), _p(status), C.c_int(nthreads))
+    return dict(flag=flag, c1=p1, c2=p2, dist=dist, trace=trace, n_support=nsup, status=status)
+
+
+def min_dist(c1, c2, eps=1e-9, max_iter=128, md_cap=4096, max_depth=900, max_nodes=2000000):
+    c1 = np.atleast_2d(_f64(c1))
+    c2 = np.atleast_2d(_f64(c2))
+    res = np.empty(3)
+    info = np.zeros(4, dtype=np.int64)
+    st = lib().obtg_oracle_min_dist(_p(c1), C.c_int(c1.shape[0]), C.c_int(c1.shape[1]), _p(c2),
+                                    C.c_int(c2.shape[0]), C.c_int(c2.shape[1]), C.c_double(eps),
+                                    C.c_int(max_iter), C.c_int(md_cap), C.c_int(max_depth),
+                                    C.c_long(max_nodes), _p(res), _p(info))
+    return dict(res=res, nodes=int(info[0]), gjk_calls=int(info[1]), depth=int(info[2]), status=st)
+
+
+def min_dist2poly(c1, poly, eps=1e-6, max_iter=128, md_cap=4096, max_depth=900, max_nodes=2000000):
+    c1 = np.atleast_2d(_f64(c1))
+    poly = _f64(poly)
+    res = np.empty(5)
+    info = np.zeros(4, dtype=np.int64)
+    st = lib().obtg_oracle_min_dist2poly(_p(c1), C.c_int(c1.shape[0]), C.c_int(c1.shape[1]), _p(poly),
+                                         C.c_int(poly.shape[0]), C.c_double(eps), C.c_int(max_iter),
+                                         C.c_int(md_cap), C.c_int(max_depth), C.c_long(max_nodes),
+                                         _p(res), _p(info))
+    return dict(res=res, nodes=int(info[0]), gjk_calls=int(info[1]), depth=int(info[2]), status=st)
+
+
+def num_threads():
+    return lib().obtg_oracle_num_threads()

@@ -1,0 +1,27 @@
+"""Shared comparison helpers for the parity tests."""
+import numpy as np
+
+# float64 constraint values must agree within 1e-9 relative (BASELINE.json north_star);
+# "relative" is scale-aware near zero: the scale of a constraint vector is its largest
+# finite magnitude (a Bernstein coefficient vector is a convex-combination family, so
+# absolute errors are governed by the largest coefficient, not by the smallest).
+RTOL = 1e-9
+
+
+def assert_close(got, ref, rtol=RTOL, what=""):
+    got = np.asarray(got, dtype=np.float64).reshape(-1)
+    ref = np.asarray(ref, dtype=np.float64).reshape(-1)
+    assert got.shape == ref.shape, "%s shape %s vs %s" % (what, got.shape, ref.shape)
+    assert (np.isnan(got) == np.isnan(ref)).all(), what + ": NaN pattern differs"
+    inf = np.isinf(ref)
+    assert (np.isinf(got) == inf).all(), what + ": inf pattern differs"
+    assert (got[inf] == ref[inf]).all(), what + ": inf signs differ"
+    fin = np.isfinite(ref)
+    if not fin.any():
+        return 0.0
+    scale = np.abs(ref[fin]).max()
+    err = np.abs(got[fin] - ref[fin])
+    tol = rtol * np.maximum(np.abs(ref[fin]), scale if scale > 0 else 1.0)
+    worst = float((err / np.maximum(tol, 1e-300)).max()) * rtol
+    assert (err <= tol).all(), "%s: max scaled err %.3e > %.1e" % (what, worst, rtol)
+    return worst
