@@ -1,0 +1,212 @@
+/*
+ * obtg.h -- C ABI of libobtg_hip.so: MI355X (gfx950) evaluation of the constraint /
+ * cost hot path that SciPy SLSQP calls on every iteration of the reference
+ * (caslabuiowa/OptimalBezierTrajectoryGeneration).
+ *
+ * The reference has no FFI layer (it is pure Python); the seam this ABI replaces is
+ * the set of Python callables SLSQP invokes.  Each entry point names the reference
+ * function(s) it stands in for (paths relative to the reference checkout).  The
+ * Python look-alikes in optimalbeziertrajectorygeneration_amd/ bind these symbols
+ * with ctypes; INTEGRATION.md shows the reference-side stub.
+ *
+ * Conventions
+ *   - plain C symbols, POD arguments, no exceptions, no global state outside the ctx;
+ *   - all floating point is IEEE binary64; all index / flag arrays are int32 (traces int16);
+ *   - return value: 0 = OBTG_OK, negative = argument / device error (obtg_strerror).
+ *     Per-item algorithmic outcomes (collision, iteration caps) go to flag/status
+ *     arrays, never to the return code;
+ *   - "host" entry points take caller-allocated HOST buffers, block until the result
+ *     is in `out`, and leave the device idle.  "_dev" entry points take DEVICE
+ *     pointers, enqueue on the context's stream and return immediately
+ *     (obtg_sync() or the caller's own stream sync completes them);
+ *   - a context is used by one thread at a time (SLSQP is serial); distinct contexts
+ *     are independent.  There is NO CPU fallback: obtg_ctx_create fails when no
+ *     gfx950 device is usable.
+ *
+ * Shapes: N = n_veh vehicles, d = dim, n = deg (n+1 control points), R = deg_elev,
+ * M = n_point_obs.  One "evaluation row" of control points is
+ *     Y[(N*d)][(n+1)]  row-major float64  (the `y` of reshapeVector, optimization.py:242-285)
+ * and batched calls take B such rows back to back (B = n_x+1 for one SLSQP Jacobian).
+ */
+#ifndef OBTG_H
+#define OBTG_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+#if defined(__GNUC__)
+#pragma GCC visibility push(default)
+#endif
+
+typedef struct obtg_ctx obtg_ctx;
+
+enum {
+    OBTG_OK = 0,
+    OBTG_ERR_ARG = -1,        /* bad argument (null pointer, negative size, unsupported dim ...) */
+    OBTG_ERR_DEVICE = -2,     /* HIP runtime error (see obtg_last_error) */
+    OBTG_ERR_NO_DEVICE = -3,  /* no usable gfx950 device */
+    OBTG_ERR_OOM = -4,        /* device or host allocation failed */
+    OBTG_ERR_UNSUPPORTED = -5 /* degree / size outside what the kernels support */
+};
+
+/* per-item GJK status (status[] arrays) */
+enum {
+    OBTG_ST_OK = 0,
+    OBTG_ST_MD_CAP = 1,  /* minimumDistance's `while True` (gjk/gjk.py:277) exceeded md_cap rounds */
+    OBTG_ST_MAXITER = 2  /* gjkNew exhausted maxIter (flag = -1, gjk/gjk.py:269-270) */
+};
+
+/* per-item minDist status */
+enum {
+    OBTG_MD_OK = 0,
+    OBTG_MD_NODE_CAP = 1,  /* node budget exhausted (reference: runs for seconds / forever) */
+    OBTG_MD_DEPTH_CAP = 2, /* deeper than max_depth (reference: RecursionError / cnt > 1000, bezier.py:1310) */
+    OBTG_MD_GJK_CAP = 3    /* an inner gjkNew hit md_cap */
+};
+
+const char* obtg_strerror(int code);
+/* last HIP error string seen by this context (empty when none) */
+const char* obtg_last_error(const obtg_ctx*);
+/* number of usable gfx950 devices (0 when none / no HIP runtime) */
+int obtg_device_count(void);
+/* every exported symbol, NUL-separated list terminated by an empty string (for load tests) */
+const char* obtg_abi_symbols(void);
+
+/* ---- context -------------------------------------------------------------------------
+ * Replaces: BezOptimization.__init__ (optimization.py:21-63) as far as the constraint
+ * closures need it, plus the class-level matrix caches of bezier.py:48-52 and the
+ * "warm the caches" idiom of the drivers (Examples/Example1_DubinsCarTimeOptimal.py:133-136):
+ * coefficient tables for (deg, deg_elev) are built once here and stay device-resident.
+ * point_obs[M][d] are the pointObstacles that temporalSeparationConstraints appends as
+ * constant curves (optimization.py:86-98).  device = HIP ordinal (>= 0). */
+int obtg_ctx_create(obtg_ctx** out, int n_veh, int dim, int deg, int deg_elev,
+                    int n_point_obs, const double* point_obs, int device);
+void obtg_ctx_destroy(obtg_ctx*);
+/* use an external HIP stream (e.g. torch's current stream) for every later call; NULL = own stream */
+int obtg_ctx_set_stream(obtg_ctx*, void* hip_stream);
+/* DEG_ELEV is a module constant read at call time (optimization.py:17): allow changing it */
+int obtg_ctx_set_deg_elev(obtg_ctx*, int deg_elev);
+int obtg_sync(obtg_ctx*);
+
+/* sizes of one evaluation row's outputs, in doubles */
+int obtg_len_temporal_sep(const obtg_ctx*); /* C(N+M,2) * (2n+R+1) */
+int obtg_len_speed(const obtg_ctx*);        /* N * (2n+R+1)        */
+int obtg_len_ang_rate(const obtg_ctx*);     /* N * (4(n+R)+1)      */
+int obtg_num_pairs(const obtg_ctx*);        /* C(N+M,2)            */
+
+/* ---- Bernstein constraint sweeps (host buffers) ----------------------------------------
+ * obtg_temporal_sep: _temporalSeparationConstraints (optimization.py:311-346) through the
+ *   closure of optimization.py:83-107: for every pair i<j of the N+M objects, in
+ *   lexicographic order, ((v_i - v_j).normSquare().elev(R)).cpts - max_sep^2.
+ *   normSquare keeps the reference's (d/2) factor (bezier.py:884).
+ * obtg_speed: _maxSpeedConstraints / _minSpeedConstraints (optimization.py:349-422):
+ *   per vehicle diff() [derivative then elev(1), bezier.py:497-519], normSquare, elev(R);
+ *   is_max ? bound^2 - cpts : cpts - bound^2.  tf[B]: final time of each row.
+ * obtg_ang_rate: _maxAngularRateConstraints -> _angularRateSqr (optimization.py:425-459,
+ *   578-611), dim must be 2: max_rate^2 - num.cpts/den.cpts element-wise (inf/nan kept). */
+int obtg_temporal_sep(obtg_ctx*, const double* Y, int B, double max_sep, double* out);
+int obtg_speed(obtg_ctx*, const double* Y, const double* tf, int B, double bound, int is_max, double* out);
+int obtg_ang_rate(obtg_ctx*, const double* Y, const double* tf, int B, double max_rate, double* out);
+/* fused per-pair minimum of the elevated separation control points minus max_sep^2
+ * (the `dv.normSquare().min()` variant commented at optimization.py:338 and used by
+ * Examples/SequentialSwarm.py:65): out[B][C(N+M,2)]. */
+int obtg_temporal_sep_min(obtg_ctx*, const double* Y, int B, double max_sep, double* out);
+
+/* ---- same sweeps on DEVICE pointers, asynchronous on the context's stream ---------------
+ * pair_begin/pair_count select a contiguous block of the lexicographic pair list (the
+ * pair-partitioned multi-GPU mode); out rows then hold only that block:
+ * out[B][pair_count*(2n+R+1)].  Pass 0, obtg_num_pairs() for everything. */
+int obtg_temporal_sep_dev(obtg_ctx*, const double* dY, int B, double max_sep,
+                          int pair_begin, int pair_count, double* d_out);
+int obtg_temporal_sep_min_dev(obtg_ctx*, const double* dY, int B, double max_sep,
+                              int pair_begin, int pair_count, double* d_out);
+int obtg_speed_dev(obtg_ctx*, const double* dY, const double* d_tf, int B, double bound, int is_max,
+                   double* d_out);
+int obtg_ang_rate_dev(obtg_ctx*, const double* dY, const double* d_tf, int B, double max_rate,
+                      double* d_out);
+
+/* ---- finite-difference batch on the device --------------------------------------------
+ * Replaces the n_x+1 serial calls SciPy's approx_derivative makes: builds
+ * dY[B][N*d][n+1] with row 0 = Y and row k = Y with the k-th free control point
+ * (interior columns, row-major as x.reshape(numRows,numCols), optimization.py:283)
+ * advanced by h.  n_fixed_cols = columns pinned at each end (1: end points; 2: + speed
+ * columns).  B <= N*d*(n+1-2*n_fixed_cols) + 1. */
+int obtg_fd_batch_dev(obtg_ctx*, const double* dY0, int n_fixed_cols, double h, int B, double* dY);
+
+/* ---- GJK (gjk/gjk.py:230-270 gjkNew, 273-360 minimumDistance) ---------------------------
+ * Generic point sets: pts[n_pts][3], poly_off[n_poly+1]; pair k = (pair_a[k], pair_b[k]).
+ * Outputs per pair: flag in {-1,0,1} (gjk.py:234-237); p1/p2 = closest points on poly1/poly2
+ * and dist when flag == 1 (NaN otherwise); n_support = number of supportPts calls;
+ * support_trace (nullable) [n_pairs][trace_cap][2] int16 = (index into poly1, index into
+ * poly2) of every supportPts call in order (bit-exact parity target); status as OBTG_ST_*.
+ * The reference's decision sequence is followed exactly, including its early exits. */
+int obtg_gjk_pairs(obtg_ctx*, const double* pts, int n_pts, const int* poly_off, int n_poly,
+                   const int* pair_a, const int* pair_b, int n_pairs, int max_iter, int md_cap,
+                   int* flag, double* p1, double* p2, double* dist,
+                   short* support_trace, int trace_cap, int* n_support, int* status);
+
+/* Batched swarm sweep: hulls of the N vehicles of each of the B rows (control polygons,
+ * 2-D padded with z = 0 as bezier.py:1294-1308 does) plus the static polygons registered
+ * with obtg_ctx_set_polygons (object ids N .. N+n_poly-1).  Pair list is device-resident
+ * after obtg_ctx_set_hull_pairs.  Outputs are DEVICE arrays:
+ * d_flag[B][n_pairs] int32, d_p1/d_p2[B][n_pairs][3], d_dist[B][n_pairs],
+ * d_nsup[B][n_pairs] int32 (nullable), d_status[B][n_pairs] int32 (nullable). */
+int obtg_ctx_set_polygons(obtg_ctx*, const double* pts, int n_pts, const int* poly_off, int n_poly);
+int obtg_ctx_set_hull_pairs(obtg_ctx*, const int* pair_a, const int* pair_b, int n_pairs);
+int obtg_gjk_swarm_dev(obtg_ctx*, const double* dY, int B, int max_iter, int md_cap,
+                       int* d_flag, double* d_p1, double* d_p2, double* d_dist,
+                       int* d_nsup, int* d_status);
+/* host-buffer form of the same sweep (B rows of Y in, arrays out) */
+int obtg_gjk_swarm(obtg_ctx*, const double* Y, int B, int max_iter, int md_cap,
+                   int* flag, double* p1, double* p2, double* dist, int* nsup, int* status);
+
+/* ---- curve <-> curve / curve <-> polygon minimum distance --------------------------------
+ * Bezier.minDist -> _minDist (bezier.py:840-852, 1283-1408) and Bezier.minDist2Poly ->
+ * _minDist2Poly (bezier.py:854-857, 1411-1496): branch and bound over de Casteljau
+ * subdivisions with gjkNew lower bounds.  curves[n_curves][3][K] (2-D curves carry a zero
+ * z row).  res[n_pairs][3] = (alpha, t1, t2); for the polygon form res[n_pairs][5] =
+ * (alpha, t1, closest point on polygon[3]).  info[n_pairs][4] (nullable) = nodes visited,
+ * gjkNew calls, max depth, status; status[n_pairs] as OBTG_MD_*. */
+int obtg_min_dist(obtg_ctx*, const double* curves, int n_curves, int K,
+                  const int* pair_a, const int* pair_b, int n_pairs,
+                  double eps, int max_iter, int md_cap, int max_depth, int max_nodes,
+                  double* res, int* info, int* status);
+int obtg_min_dist2poly(obtg_ctx*, const double* curves, int n_curves, int K,
+                       const double* pts, int n_pts, const int* poly_off, int n_poly,
+                       const int* pair_curve, const int* pair_poly, int n_pairs,
+                       double eps, int max_iter, int md_cap, int max_depth, int max_nodes,
+                       double* res, int* info, int* status);
+
+/* ---- single-curve Bernstein algebra (the Bezier object's methods, batched over rows) ----
+ * obtg_bern_elev:   Bezier.elev(R)      bezier.py:469-495   in[rows][n+1]   -> out[rows][n+R+1]
+ * obtg_bern_diff:   Bezier.diff()       bezier.py:497-519   in[rows][n+1]   -> out[rows][n+1]  (T = tf-t0)
+ * obtg_bern_mul:    Bezier.mul          bezier.py:376-432   a[rows][m+1], b[rows][n+1] -> out[rows][m+n+1]
+ * obtg_bern_normsq: Bezier.normSquare() bezier.py:869-889   x[d][n+1]       -> out[2n+1]  ((d/2) quirk kept) */
+int obtg_bern_elev(obtg_ctx*, const double* in, int rows, int n, int R, double* out);
+int obtg_bern_diff(obtg_ctx*, const double* in, int rows, int n, double T, double* out);
+int obtg_bern_mul(obtg_ctx*, const double* a, const double* b, int rows, int m, int n, double* out);
+int obtg_bern_normsq(obtg_ctx*, const double* x, int d, int n, double* out);
+
+/* ---- objectives (optimization.py:462-489 _euclideanObjective, 503-519 _minAccelObjective) */
+int obtg_euclidean_obj(obtg_ctx*, const double* Y, int B, double* out /*[B]*/);
+int obtg_accel_obj(obtg_ctx*, const double* Y, const double* tf, int B, double* out /*[B]*/);
+
+/* ---- instrumentation -------------------------------------------------------------------
+ * When enabled every kernel launch is bracketed by HIP events on the launch stream;
+ * obtg_kernel_stats returns the accumulated device time and launch count per kernel id. */
+enum {
+    OBTG_K_TEMPORAL_SEP = 0, OBTG_K_SPEED = 1, OBTG_K_ANG_RATE = 2, OBTG_K_GJK = 3,
+    OBTG_K_MIN_DIST = 4, OBTG_K_FD_BATCH = 5, OBTG_K_BERN = 6, OBTG_K_COUNT = 7
+};
+int obtg_set_profiling(obtg_ctx*, int on);
+int obtg_kernel_stats(obtg_ctx*, int kernel_id, double* total_ms, long long* launches);
+int obtg_reset_kernel_stats(obtg_ctx*);
+const char* obtg_kernel_name(int kernel_id);
+
+#if defined(__GNUC__)
+#pragma GCC visibility pop
+#endif
+#ifdef __cplusplus
+}
+#endif
+#endif /* OBTG_H */

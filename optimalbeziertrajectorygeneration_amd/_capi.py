@@ -1,0 +1,438 @@
+"""ctypes binding of libobtg_hip.so (include/obtg.h).
+
+This is the ONLY compute path of the package: there is no CPU fallback.  Importing
+works without a GPU (so that host logic can be tested), but creating a `Context`
+raises `RuntimeError` when the library is missing or no gfx950 device is usable.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libobtg_hip.so")
+
+OK = 0
+ST_OK, ST_MD_CAP, ST_MAXITER = 0, 1, 2
+MD_OK, MD_NODE_CAP, MD_DEPTH_CAP, MD_GJK_CAP = 0, 1, 2, 3
+K_TEMPORAL_SEP, K_SPEED, K_ANG_RATE, K_GJK, K_MIN_DIST, K_FD_BATCH, K_BERN, K_COUNT = range(8)
+
+_lib = None
+
+_vp = C.c_void_p
+_i = C.c_int
+_d = C.c_double
+
+# name -> (restype, argtypes); mirrors include/obtg.h one to one
+_SIGNATURES = {
+    "obtg_strerror": (C.c_char_p, [_i]),
+    "obtg_last_error": (C.c_char_p, [_vp]),
+    "obtg_device_count": (_i, []),
+    "obtg_abi_symbols": (_vp, []),
+    "obtg_ctx_create": (_i, [C.POINTER(_vp), _i, _i, _i, _i, _i, _vp, _i]),
+    "obtg_ctx_destroy": (None, [_vp]),
+    "obtg_ctx_set_stream": (_i, [_vp, _vp]),
+    "obtg_ctx_set_deg_elev": (_i, [_vp, _i]),
+    "obtg_sync": (_i, [_vp]),
+    "obtg_len_temporal_sep": (_i, [_vp]),
+    "obtg_len_speed": (_i, [_vp]),
+    "obtg_len_ang_rate": (_i, [_vp]),
+    "obtg_num_pairs": (_i, [_vp]),
+    "obtg_temporal_sep": (_i, [_vp, _vp, _i, _d, _vp]),
+    "obtg_speed": (_i, [_vp, _vp, _vp, _i, _d, _i, _vp]),
+    "obtg_ang_rate": (_i, [_vp, _vp, _vp, _i, _d, _vp]),
+    "obtg_temporal_sep_min": (_i, [_vp, _vp, _i, _d, _vp]),
+    "obtg_temporal_sep_dev": (_i, [_vp, _vp, _i, _d, _i, _i, _vp]),
+    "obtg_temporal_sep_min_dev": (_i, [_vp, _vp, _i, _d, _i, _i, _vp]),
+    "obtg_speed_dev": (_i, [_vp, _vp, _vp, _i, _d, _i, _vp]),
+    "obtg_ang_rate_dev": (_i, [_vp, _vp, _vp, _i, _d, _vp]),
+    "obtg_fd_batch_dev": (_i, [_vp, _vp, _i, _d, _i, _vp]),
+    "obtg_gjk_pairs": (_i, [_vp, _vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp]),
+    "obtg_ctx_set_polygons": (_i, [_vp, _vp, _i, _vp, _i]),
+    "obtg_ctx_set_hull_pairs": (_i, [_vp, _vp, _vp, _i]),
+    "obtg_gjk_swarm_dev": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "obtg_gjk_swarm": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "obtg_min_dist": (_i, [_vp, _vp, _i, _i, _vp, _vp, _i, _d, _i, _i, _i, _i, _vp, _vp, _vp]),
+    "obtg_min_dist2poly": (_i, [_vp, _vp, _i, _i, _vp, _i, _vp, _i, _vp, _vp, _i, _d, _i, _i, _i, _i, _vp, _vp, _vp]),
+    "obtg_bern_elev": (_i, [_vp, _vp, _i, _i, _i, _vp]),
+    "obtg_bern_diff": (_i, [_vp, _vp, _i, _i, _d, _vp]),
+    "obtg_bern_mul": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),
+    "obtg_bern_normsq": (_i, [_vp, _vp, _i, _i, _vp]),
+    "obtg_euclidean_obj": (_i, [_vp, _vp, _i, _vp]),
+    "obtg_accel_obj": (_i, [_vp, _vp, _vp, _i, _vp]),
+    "obtg_set_profiling": (_i, [_vp, _i]),
+    "obtg_kernel_stats": (_i, [_vp, _i, C.POINTER(_d), C.POINTER(C.c_longlong)]),
+    "obtg_reset_kernel_stats": (_i, [_vp]),
+    "obtg_kernel_name": (C.c_char_p, [_i]),
+}
+
+
+def abi_symbol_names():
+    """The symbols include/obtg.h declares (used by the CPU-side load test)."""
+    return sorted(_SIGNATURES)
+
+
+def _preload_torch_hip_runtime():
+    """One HIP runtime per process.  PyTorch-ROCm wheels bundle their own libamdhip64.so
+    (soname libamdhip64.so.7, the same soname /opt/rocm's carries).  If libobtg_hip.so pulled in
+    the system copy and torch later loaded its bundled copy, the process would hold two HIP
+    runtimes and the second would see no GPU.  Loading torch's copy first (by path, without
+    importing torch) makes both libobtg_hip.so (NEEDED libamdhip64.so.7, matched by soname) and
+    a later `import torch` (same file) share it.  Without torch installed the system runtime
+    is used."""
+    if os.environ.get("OBTG_USE_SYSTEM_HIP") == "1":
+        return None
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.submodule_search_locations:
+        return None
+    cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+    if not os.path.exists(cand):
+        return None
+    try:
+        return C.CDLL(cand, mode=C.RTLD_GLOBAL)
+    except OSError:
+        return None
+
+
+_hip_runtime = None
+
+
+def load():
+    """dlopen the in-tree library; loud failure when it has not been built."""
+    global _lib, _hip_runtime
+    if _lib is not None:
+        return _lib
+    _hip_runtime = _preload_torch_hip_runtime()
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            "libobtg_hip.so is missing (%s). Build it with "
+            "`python -m optimalbeziertrajectorygeneration_amd.build`; there is no CPU fallback." % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in _SIGNATURES.items():
+        fn = getattr(lib, name)   # AttributeError here == ABI drift between header and library
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def device_count():
+    return load().obtg_device_count()
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(_vp)
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def _i32(a):
+    return np.ascontiguousarray(a, dtype=np.int32)
+
+
+class ObtgError(RuntimeError):
+    pass
+
+
+class Context(object):
+    """One problem shape on one MI355X: wraps obtg_ctx."""
+
+    def __init__(self, n_veh, dim, deg, deg_elev=0, point_obs=None, device=0):
+        self._lib = load()
+        self._h = _vp()
+        if self._lib.obtg_device_count() <= 0:
+            raise ObtgError("no usable gfx950 (MI355X) device: the HIP path is the only compute path")
+        obs = None
+        n_obs = 0
+        if point_obs is not None and len(point_obs) > 0:
+            obs = _f64(point_obs).reshape(-1, dim)
+            n_obs = obs.shape[0]
+        rc = self._lib.obtg_ctx_create(C.byref(self._h), n_veh, dim, deg, deg_elev, n_obs, _ptr(obs), device)
+        if rc != OK:
+            self._h = _vp()
+            raise ObtgError("obtg_ctx_create: " + self._lib.obtg_strerror(rc).decode())
+        self.n_veh, self.dim, self.deg, self.deg_elev, self.n_obs = n_veh, dim, deg, deg_elev, n_obs
+        self.device = device
+        self.n_hull_pairs = 0
+
+    # -- plumbing
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self._lib.obtg_ctx_destroy(self._h)
+            self._h = _vp()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc, what):
+        if rc != OK:
+            msg = self._lib.obtg_strerror(rc).decode()
+            extra = self._lib.obtg_last_error(self._h)
+            if extra:
+                msg += " (" + extra.decode() + ")"
+            raise ObtgError("%s: %s" % (what, msg))
+
+    @property
+    def handle(self):
+        return self._h
+
+    def set_stream(self, stream_ptr):
+        self._check(self._lib.obtg_ctx_set_stream(self._h, _vp(stream_ptr)), "obtg_ctx_set_stream")
+
+    def set_deg_elev(self, R):
+        self._check(self._lib.obtg_ctx_set_deg_elev(self._h, int(R)), "obtg_ctx_set_deg_elev")
+        self.deg_elev = int(R)
+
+    def sync(self):
+        self._check(self._lib.obtg_sync(self._h), "obtg_sync")
+
+    @property
+    def len_temporal_sep(self):
+        return self._lib.obtg_len_temporal_sep(self._h)
+
+    @property
+    def len_speed(self):
+        return self._lib.obtg_len_speed(self._h)
+
+    @property
+    def len_ang_rate(self):
+        return self._lib.obtg_len_ang_rate(self._h)
+
+    @property
+    def num_pairs(self):
+        return self._lib.obtg_num_pairs(self._h)
+
+    def _rows(self, Y):
+        Y = _f64(Y)
+        per = self.n_veh * self.dim * (self.deg + 1)
+        if Y.size % per != 0 or Y.size == 0:
+            raise ValueError("Y must hold B x (%d x %d) doubles, got %s" % (self.n_veh * self.dim, self.deg + 1, Y.shape))
+        return Y, Y.size // per
+
+    def _tf(self, tf, B):
+        return _f64(np.broadcast_to(np.asarray(tf, dtype=np.float64), (B,)))
+
+    # -- host-buffer sweeps
+    def temporal_sep(self, Y, max_sep):
+        Y, B = self._rows(Y)
+        out = np.empty((B, self.len_temporal_sep))
+        self._check(self._lib.obtg_temporal_sep(self._h, _ptr(Y), B, float(max_sep), _ptr(out)), "obtg_temporal_sep")
+        return out
+
+    def temporal_sep_min(self, Y, max_sep):
+        Y, B = self._rows(Y)
+        out = np.empty((B, self.num_pairs))
+        self._check(self._lib.obtg_temporal_sep_min(self._h, _ptr(Y), B, float(max_sep), _ptr(out)),
+                    "obtg_temporal_sep_min")
+        return out
+
+    def speed(self, Y, tf, bound, is_max):
+        Y, B = self._rows(Y)
+        tf = self._tf(tf, B)
+        out = np.empty((B, self.len_speed))
+        self._check(self._lib.obtg_speed(self._h, _ptr(Y), _ptr(tf), B, float(bound), int(bool(is_max)), _ptr(out)),
+                    "obtg_speed")
+        return out
+
+    def ang_rate(self, Y, tf, max_rate):
+        Y, B = self._rows(Y)
+        tf = self._tf(tf, B)
+        out = np.empty((B, self.len_ang_rate))
+        self._check(self._lib.obtg_ang_rate(self._h, _ptr(Y), _ptr(tf), B, float(max_rate), _ptr(out)),
+                    "obtg_ang_rate")
+        return out
+
+    def euclidean_obj(self, Y):
+        Y, B = self._rows(Y)
+        out = np.empty(B)
+        self._check(self._lib.obtg_euclidean_obj(self._h, _ptr(Y), B, _ptr(out)), "obtg_euclidean_obj")
+        return out
+
+    def accel_obj(self, Y, tf):
+        Y, B = self._rows(Y)
+        tf = self._tf(tf, B)
+        out = np.empty(B)
+        self._check(self._lib.obtg_accel_obj(self._h, _ptr(Y), _ptr(tf), B, _ptr(out)), "obtg_accel_obj")
+        return out
+
+    # -- device-pointer sweeps (pointers are plain ints, e.g. torch.Tensor.data_ptr())
+    def temporal_sep_dev(self, dY, B, max_sep, d_out, pair_begin=0, pair_count=None):
+        if pair_count is None:
+            pair_count = self.num_pairs - pair_begin
+        self._check(self._lib.obtg_temporal_sep_dev(self._h, _vp(dY), B, float(max_sep), pair_begin, pair_count,
+                                                    _vp(d_out)), "obtg_temporal_sep_dev")
+
+    def temporal_sep_min_dev(self, dY, B, max_sep, d_out, pair_begin=0, pair_count=None):
+        if pair_count is None:
+            pair_count = self.num_pairs - pair_begin
+        self._check(self._lib.obtg_temporal_sep_min_dev(self._h, _vp(dY), B, float(max_sep), pair_begin, pair_count,
+                                                        _vp(d_out)), "obtg_temporal_sep_min_dev")
+
+    def speed_dev(self, dY, d_tf, B, bound, is_max, d_out):
+        self._check(self._lib.obtg_speed_dev(self._h, _vp(dY), _vp(d_tf), B, float(bound), int(bool(is_max)),
+                                             _vp(d_out)), "obtg_speed_dev")
+
+    def ang_rate_dev(self, dY, d_tf, B, max_rate, d_out):
+        self._check(self._lib.obtg_ang_rate_dev(self._h, _vp(dY), _vp(d_tf), B, float(max_rate), _vp(d_out)),
+                    "obtg_ang_rate_dev")
+
+    def fd_batch_dev(self, dY0, n_fixed_cols, h, B, dY):
+        self._check(self._lib.obtg_fd_batch_dev(self._h, _vp(dY0), int(n_fixed_cols), float(h), B, _vp(dY)),
+                    "obtg_fd_batch_dev")
+
+    # -- GJK
+    def gjk_pairs(self, pts, off, pair_a, pair_b, max_iter=128, md_cap=4096, trace_cap=0):
+        pts = _f64(pts).reshape(-1, 3)
+        off = _i32(off)
+        pa, pb = _i32(pair_a), _i32(pair_b)
+        n = pa.shape[0]
+        flag = np.zeros(n, np.int32)
+        nsup = np.zeros(n, np.int32)
+        status = np.zeros(n, np.int32)
+        p1 = np.empty((n, 3))
+        p2 = np.empty((n, 3))
+        dist = np.empty(n)
+        trace = np.zeros((n, trace_cap, 2), np.int16) if trace_cap else None
+        self._check(self._lib.obtg_gjk_pairs(self._h, _ptr(pts), pts.shape[0], _ptr(off), off.shape[0] - 1,
+                                             _ptr(pa), _ptr(pb), n, max_iter, md_cap, _ptr(flag), _ptr(p1),
+                                             _ptr(p2), _ptr(dist), _ptr(trace), trace_cap, _ptr(nsup),
+                                             _ptr(status)), "obtg_gjk_pairs")
+        return dict(flag=flag, c1=p1, c2=p2, dist=dist, trace=trace, n_support=nsup, status=status)
+
+    def set_polygons(self, pts, off):
+        if pts is None or len(off) <= 1:
+            self._check(self._lib.obtg_ctx_set_polygons(self._h, None, 0, None, 0), "obtg_ctx_set_polygons")
+            self.n_poly = 0
+            return
+        pts = _f64(pts).reshape(-1, 3)
+        off = _i32(off)
+        self._check(self._lib.obtg_ctx_set_polygons(self._h, _ptr(pts), pts.shape[0], _ptr(off), off.shape[0] - 1),
+                    "obtg_ctx_set_polygons")
+        self.n_poly = off.shape[0] - 1
+
+    def set_hull_pairs(self, pair_a, pair_b):
+        pa, pb = _i32(pair_a), _i32(pair_b)
+        self._check(self._lib.obtg_ctx_set_hull_pairs(self._h, _ptr(pa), _ptr(pb), pa.shape[0]),
+                    "obtg_ctx_set_hull_pairs")
+        self.n_hull_pairs = pa.shape[0]
+
+    def gjk_swarm(self, Y, max_iter=128, md_cap=4096):
+        Y, B = self._rows(Y)
+        n = self.n_hull_pairs
+        flag = np.zeros((B, n), np.int32)
+        nsup = np.zeros((B, n), np.int32)
+        status = np.zeros((B, n), np.int32)
+        p1 = np.empty((B, n, 3))
+        p2 = np.empty((B, n, 3))
+        dist = np.empty((B, n))
+        self._check(self._lib.obtg_gjk_swarm(self._h, _ptr(Y), B, max_iter, md_cap, _ptr(flag), _ptr(p1), _ptr(p2),
+                                             _ptr(dist), _ptr(nsup), _ptr(status)), "obtg_gjk_swarm")
+        return dict(flag=flag, c1=p1, c2=p2, dist=dist, n_support=nsup, status=status)
+
+    def gjk_swarm_dev(self, dY, B, d_flag, d_p1, d_p2, d_dist, d_nsup=None, d_status=None, max_iter=128,
+                      md_cap=4096):
+        self._check(self._lib.obtg_gjk_swarm_dev(self._h, _vp(dY), B, max_iter, md_cap, _vp(d_flag), _vp(d_p1),
+                                                 _vp(d_p2), _vp(d_dist), _vp(d_nsup), _vp(d_status)),
+                    "obtg_gjk_swarm_dev")
+
+    # -- minDist
+    def min_dist(self, curves, pair_a, pair_b, eps=1e-9, max_iter=128, md_cap=4096, max_depth=64,
+                 max_nodes=200000):
+        """curves[n][3][K] (2-D curves: pass a zero z row)."""
+        curves = _f64(curves)
+        n_curves, _, K = curves.shape
+        pa, pb = _i32(pair_a), _i32(pair_b)
+        n = pa.shape[0]
+        res = np.empty((n, 3))
+        info = np.zeros((n, 4), np.int32)
+        status = np.zeros(n, np.int32)
+        self._check(self._lib.obtg_min_dist(self._h, _ptr(curves), n_curves, K, _ptr(pa), _ptr(pb), n, float(eps),
+                                            max_iter, md_cap, max_depth, max_nodes, _ptr(res), _ptr(info),
+                                            _ptr(status)), "obtg_min_dist")
+        return dict(res=res, nodes=info[:, 0], gjk_calls=info[:, 1], depth=info[:, 2], status=status)
+
+    def min_dist2poly(self, curves, pts, off, pair_curve, pair_poly, eps=1e-6, max_iter=128, md_cap=4096,
+                      max_depth=64, max_nodes=200000):
+        curves = _f64(curves)
+        n_curves, _, K = curves.shape
+        pts = _f64(pts).reshape(-1, 3)
+        off = _i32(off)
+        pc, pp = _i32(pair_curve), _i32(pair_poly)
+        n = pc.shape[0]
+        res = np.empty((n, 5))
+        info = np.zeros((n, 4), np.int32)
+        status = np.zeros(n, np.int32)
+        self._check(self._lib.obtg_min_dist2poly(self._h, _ptr(curves), n_curves, K, _ptr(pts), pts.shape[0],
+                                                 _ptr(off), off.shape[0] - 1, _ptr(pc), _ptr(pp), n, float(eps),
+                                                 max_iter, md_cap, max_depth, max_nodes, _ptr(res), _ptr(info),
+                                                 _ptr(status)), "obtg_min_dist2poly")
+        return dict(res=res, nodes=info[:, 0], gjk_calls=info[:, 1], depth=info[:, 2], status=status)
+
+    # -- single-curve algebra
+    def bern_elev(self, cpts, R):
+        a = np.atleast_2d(_f64(cpts))
+        rows, nc = a.shape
+        out = np.empty((rows, nc + R))
+        self._check(self._lib.obtg_bern_elev(self._h, _ptr(a), rows, nc - 1, int(R), _ptr(out)), "obtg_bern_elev")
+        return out
+
+    def bern_diff(self, cpts, T):
+        a = np.atleast_2d(_f64(cpts))
+        rows, nc = a.shape
+        out = np.empty((rows, nc))
+        self._check(self._lib.obtg_bern_diff(self._h, _ptr(a), rows, nc - 1, float(T), _ptr(out)), "obtg_bern_diff")
+        return out
+
+    def bern_mul(self, a, b):
+        a = np.atleast_2d(_f64(a))
+        b = np.atleast_2d(_f64(b))
+        rows, mc = a.shape
+        nc = b.shape[1]
+        out = np.empty((rows, mc + nc - 1))
+        self._check(self._lib.obtg_bern_mul(self._h, _ptr(a), _ptr(b), rows, mc - 1, nc - 1, _ptr(out)),
+                    "obtg_bern_mul")
+        return out
+
+    def bern_normsq(self, x):
+        x = np.atleast_2d(_f64(x))
+        d, nc = x.shape
+        out = np.empty((1, 2 * nc - 1))
+        self._check(self._lib.obtg_bern_normsq(self._h, _ptr(x), d, nc - 1, _ptr(out)), "obtg_bern_normsq")
+        return out
+
+    # -- instrumentation
+    def set_profiling(self, on):
+        self._check(self._lib.obtg_set_profiling(self._h, int(bool(on))), "obtg_set_profiling")
+
+    def reset_kernel_stats(self):
+        self._check(self._lib.obtg_reset_kernel_stats(self._h), "obtg_reset_kernel_stats")
+
+    def kernel_stats(self):
+        out = {}
+        for k in range(K_COUNT):
+            ms = _d(0)
+            n = C.c_longlong(0)
+            self._check(self._lib.obtg_kernel_stats(self._h, k, C.byref(ms), C.byref(n)), "obtg_kernel_stats")
+            out[self._lib.obtg_kernel_name(k).decode()] = (ms.value, n.value)
+        return out
+
+
+_scratch_ctx = None
+
+
+def scratch_context():
+    """A shape-agnostic context for the calls that do not depend on the problem shape
+    (gjkNew on raw point sets, minDist, single-curve Bernstein algebra)."""
+    global _scratch_ctx
+    if _scratch_ctx is None:
+        _scratch_ctx = Context(1, 2, 1, 0)
+    return _scratch_ctx

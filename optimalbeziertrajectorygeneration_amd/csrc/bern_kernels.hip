@@ -1,0 +1,951 @@
+// Bernstein constraint sweeps for gfx950 (MI355X).
+//
+// What is computed (reference file:line in the reference checkout):
+//   temporal separation  optimization.py:311-346   (v_i - v_j).normSquare().elev(R) - maxSep^2
+//   max / min speed      optimization.py:349-422   diff() -> normSquare() -> elev(R)
+//   angular rate         optimization.py:425-459, 578-611
+// through  bezier.py:347-374 (sub), 497-519 (diff = derivative then elev(1)), 869-889 +
+// 1724-1756 (normSquare with the (d/2) factor), 469-495 + 1127-1147 (elev), 376-432 +
+// 1183-1208 (mul).
+//
+// Kernel shape (fast path, k_normsq_elev): the sweep is OUTPUT-bandwidth bound -- one
+// evaluation row at N=64, n=10 reads 11 KB and writes 338 KB -- so the design is about
+// the stores.  One wave (64 lanes) owns 64 consecutive items (pairs or vehicles); each
+// lane keeps its item's source curve (d x (n+1) doubles) and its 2n+1 product
+// coefficients in registers (fully unrolled for the instantiated (n, d)), with the folded
+// product weights / elevation band arriving as wave-uniform scalar loads.  Results are
+// transposed through a per-wave LDS tile so that the wave writes its 64*(2n+R+1) doubles
+// (contiguous in the output because pairs are lexicographic) as 16-byte-per-lane
+// coalesced stores.  The control points of the vehicles a workgroup needs are staged once
+// into LDS (odd pitch => conflict-free ds_read_b64 across lanes).
+//
+// Everything here is float64.  Parity target is 1e-9 relative, so fused multiply-adds and
+// the symmetric folding of the product are allowed in this translation unit.
+#include <algorithm>
+#include <cstdio>
+
+#include "obtg_internal.h"
+
+namespace obtg {
+
+// =====================================================================================
+//  fast path: register-resident product, one item per lane
+// =====================================================================================
+struct NsParams {
+    const double* __restrict__ Y;     // [B][n_veh*DIM][NC]
+    const double* __restrict__ obs;   // [n_obs][DIM]   (pair mode)
+    const double* __restrict__ tf;    // [B]            (vehicle mode)
+    const int2* __restrict__ pairs;   // [P]            (pair mode)
+    const double* __restrict__ W2;    // folded weights [L][NC]
+    const double* __restrict__ Tt;    // elevation table [L+R][L] (R > 0)
+    double* __restrict__ out;
+    int n_veh, n_obj, R;
+    int item_begin, item_count;       // items of this launch (pairs or vehicles)
+    int groups_per_wg, wgs_per_row;
+    int stage_slots;                  // LDS slots reserved for staged objects
+    double sign, offset;              // out = sign * value + offset
+};
+
+constexpr int kTileK = 32;            // k-chunk of the transposition tile when R > 0
+
+template <int NC, int DIM>
+struct NsShape {
+    static constexpr int N = NC - 1;
+    static constexpr int L = 2 * N + 1;
+    static constexpr int VLEN = DIM * NC;
+    static constexpr int VP = (VLEN % 2 == 0) ? VLEN + 1 : VLEN;   // odd pitch (doubles)
+    static constexpr int TPF = (L % 2 == 0) ? L + 1 : L;           // full-tile pitch (R == 0)
+    static constexpr int TPC = kTileK + 1;                          // chunked-tile pitch (R > 0)
+};
+
+// stage objects [lo, lo+cnt) of one evaluation row into LDS slots [slot0, slot0+cnt)
+template <int NC, int DIM>
+__device__ __forceinline__ void stage_objects(double* __restrict__ vl, const double* __restrict__ Yrow,
+                                              const double* __restrict__ obs, int n_veh, int lo,
+                                              int cnt, int slot0, int lane)
+{
+    using S = NsShape<NC, DIM>;
+    const int total = cnt * S::VLEN;
+    for (int e = lane; e < total; e += kWave) {
+        const int v = e / S::VLEN, r = e - v * S::VLEN;
+        const int obj = lo + v;
+        double val;
+        if (obj < n_veh) val = Yrow[(size_t)obj * S::VLEN + r];
+        else val = obs[(obj - n_veh) * DIM + r / NC];   // constant curve (optimization.py:86-98)
+        vl[(slot0 + v) * S::VP + r] = val;
+    }
+}
+
+// (d/2) * sum_q a_q^2 as Bernstein coefficients c[0..L)
+template <int NC, int DIM>
+__device__ __forceinline__ void normsq_coeffs(const double (&a)[DIM][NC], const double* __restrict__ W2,
+                                              double (&c)[2 * NC - 1])
+{
+    constexpr int N = NC - 1, L = 2 * N + 1;
+#pragma unroll
+    for (int k = 0; k < L; ++k) {
+        double s = 0.0;
+#pragma unroll
+        for (int j = (k - N > 0 ? k - N : 0); 2 * j <= k; ++j) {
+            double xa = a[0][j] * a[0][k - j];
+#pragma unroll
+            for (int q = 1; q < DIM; ++q) xa = fma(a[q][j], a[q][k - j], xa);
+            s = fma(W2[k * NC + j], xa, s);
+        }
+        c[k] = s;
+    }
+}
+
+// write a full [n_valid][LR] tile (pitch TP) as one contiguous run of n_valid*LR doubles
+template <int LR, int TP>
+__device__ __forceinline__ void flush_full(const double* __restrict__ tile, double* __restrict__ gout,
+                                           size_t gbase /* element index in out */, int n_valid, int lane)
+{
+    const int total = n_valid * LR;
+    const int shift = (int)(gbase & 1);   // make the 16-byte stores 16-byte aligned
+    const int npairs = (total + shift + 1) >> 1;
+    for (int m = lane; m < npairs; m += kWave) {
+        const int e0 = 2 * m - shift, e1 = e0 + 1;
+        double v0 = 0.0, v1 = 0.0;
+        if (e0 >= 0) { const int pr = e0 / LR, q = e0 - pr * LR; v0 = tile[pr * TP + q]; }
+        if (e1 < total) { const int pr = e1 / LR, q = e1 - pr * LR; v1 = tile[pr * TP + q]; }
+        if (e0 >= 0 && e1 < total) {
+            *reinterpret_cast<double2*>(gout + gbase + e0) = make_double2(v0, v1);
+        } else if (e0 >= 0) {
+            gout[gbase + e0] = v0;
+        } else if (e1 < total) {
+            gout[gbase + e1] = v1;
+        }
+    }
+}
+
+// write chunk columns [k0, k0+kc) of n_valid rows; row r lives at gout[grow + r*LR + ...]
+template <int TP>
+__device__ __forceinline__ void flush_chunk(const double* __restrict__ tile, double* __restrict__ gout,
+                                            size_t grow, int LR, int k0, int kc, int n_valid, int lane)
+{
+    const int total = n_valid * kc;
+    for (int e = lane; e < total; e += kWave) {
+        const int pr = e / kc, q = e - pr * kc;
+        gout[grow + (size_t)pr * LR + k0 + q] = tile[pr * TP + q];
+    }
+}
+
+template <int NC, int DIM, int MODE /*0 = pairs, 1 = vehicles*/, bool MINONLY>
+__global__ __launch_bounds__(kWave) void k_normsq_elev(const NsParams p)
+{
+    using S = NsShape<NC, DIM>;
+    constexpr int N = S::N, L = S::L;
+    extern __shared__ double lds[];
+    const int lane = threadIdx.x;
+    const int b = blockIdx.x / p.wgs_per_row, w = blockIdx.x - b * p.wgs_per_row;
+    const int chunk = kWave * p.groups_per_wg;
+    const int it0 = p.item_begin + w * chunk;
+    const int it_end = min(p.item_begin + p.item_count, it0 + chunk);
+    if (it0 >= it_end) return;
+
+    const int tile_doubles = kWave * ((p.R == 0) ? S::TPF : S::TPC);
+    double* tile = lds;
+    double* vl = lds + (MINONLY ? 0 : tile_doubles);
+
+    // ---- stage the objects this workgroup touches
+    const double* Yrow = p.Y + (size_t)b * p.n_veh * S::VLEN;
+    // A chunk of lexicographic pairs touches rows i0..i0+nI-1 (segment I), the j-range of its
+    // first row (segment A) and the j-range of the later rows (segment B).
+    int i0, nI, a_lo = 0, nA = 0, b_lo = 0, nB = 0;
+    if (MODE == 0) {
+        const int2 f = p.pairs[it0], l = p.pairs[it_end - 1];
+        i0 = f.x; nI = l.x - f.x + 1;
+        a_lo = f.y;
+        nA = (nI == 1) ? (l.y - f.y + 1) : (p.n_obj - f.y);
+        b_lo = i0 + 2;
+        nB = (nI == 1) ? 0 : max(0, ((nI >= 3) ? p.n_obj - 1 : l.y) - b_lo + 1);
+        stage_objects<NC, DIM>(vl, Yrow, p.obs, p.n_veh, i0, nI, 0, lane);
+        stage_objects<NC, DIM>(vl, Yrow, p.obs, p.n_veh, a_lo, nA, nI, lane);
+        stage_objects<NC, DIM>(vl, Yrow, p.obs, p.n_veh, b_lo, nB, nI + nA, lane);
+    } else {
+        i0 = it0; nI = it_end - it0;
+        stage_objects<NC, DIM>(vl, Yrow, p.obs, p.n_veh, i0, nI, 0, lane);
+    }
+    __syncthreads();
+
+    const int LR = L + p.R;
+    for (int g = 0; g < p.groups_per_wg; ++g) {
+        const int itg = it0 + g * kWave;
+        if (itg >= it_end) break;
+        const int n_valid = min(kWave, it_end - itg);
+        const int item = min(itg + lane, it_end - 1);   // idle lanes recompute the last item
+
+        // ---- source curve a[q][c]
+        double a[DIM][NC];
+        if (MODE == 0) {
+            const int2 ij = p.pairs[item];
+            const double* vi = vl + (ij.x - i0) * S::VP;
+            const int sj = (ij.x == i0) ? nI + (ij.y - a_lo) : nI + nA + (ij.y - b_lo);
+            const double* vj = vl + sj * S::VP;
+#pragma unroll
+            for (int q = 0; q < DIM; ++q)
+#pragma unroll
+                for (int c = 0; c < NC; ++c) a[q][c] = vi[q * NC + c] - vj[q * NC + c];
+        } else {
+            // Bezier.diff(): (n/T)(P_{i+1}-P_i), then elev(1) back to degree n (bezier.py:497-519)
+            const double* v = vl + (item - i0) * S::VP;
+            const double val = (double)N / p.tf[b];
+#pragma unroll
+            for (int q = 0; q < DIM; ++q) {
+                double t[NC];
+#pragma unroll
+                for (int c = 0; c < N; ++c) t[c] = v[q * NC + c] * (-val) + v[q * NC + c + 1] * val;
+                a[q][0] = t[0];
+                a[q][N] = t[N - 1];
+#pragma unroll
+                for (int c = 1; c < N; ++c)
+                    a[q][c] = t[c - 1] * ((double)c / (double)N) + t[c] * ((double)(N - c) / (double)N);
+            }
+        }
+
+        double cf[L];
+        normsq_coeffs<NC, DIM>(a, p.W2, cf);
+
+        const size_t row = (size_t)b * p.item_count + (size_t)(itg - p.item_begin);
+        if (p.R == 0) {
+            // elevMatrix(2n, 0) is the identity (bezier.py:1141-1147): the product IS the output
+            if (MINONLY) {
+                double m = cf[0];
+#pragma unroll
+                for (int k = 1; k < L; ++k) m = fmin(m, cf[k]);
+                if (lane < n_valid) p.out[row + lane] = p.sign * m + p.offset;
+            } else {
+#pragma unroll
+                for (int k = 0; k < L; ++k) tile[lane * S::TPF + k] = p.sign * cf[k] + p.offset;
+                __syncthreads();
+                flush_full<L, S::TPF>(tile, p.out, row * L, n_valid, lane);
+                __syncthreads();
+            }
+        } else {
+            double m = INFINITY;
+            for (int k0 = 0; k0 < LR; k0 += kTileK) {
+                const int kc = min(kTileK, LR - k0);
+                for (int kk = 0; kk < kc; ++kk) {
+                    const double* __restrict__ Tr = p.Tt + (size_t)(k0 + kk) * L;
+                    double s = 0.0;
+#pragma unroll
+                    for (int j = 0; j < L; ++j) s = fma(cf[j], Tr[j], s);
+                    if (MINONLY) m = fmin(m, s);
+                    else tile[lane * S::TPC + kk] = p.sign * s + p.offset;
+                }
+                if (!MINONLY) {
+                    __syncthreads();
+                    flush_chunk<S::TPC>(tile, p.out, row * LR, LR, k0, kc, n_valid, lane);
+                    __syncthreads();
+                }
+            }
+            if (MINONLY && lane < n_valid) p.out[row + lane] = p.sign * m + p.offset;
+        }
+    }
+}
+
+// =====================================================================================
+//  angular rate, fast path (R == 0): one vehicle per lane
+// =====================================================================================
+struct AngParams {
+    const double* __restrict__ Y;    // [B][n_veh*2][NC]
+    const double* __restrict__ tf;   // [B]
+    const double* __restrict__ W2n;  // folded weights degree n,   dim factor 1   [2n+1][n+1]
+    const double* __restrict__ W22n; // folded weights degree 2n,  dim factor 1   [4n+1][2n+1]
+    const double* __restrict__ Wn;   // plain weights  degree n                   [2n+1][n+1]
+    double* __restrict__ out;        // [B][n_veh][4n+1]
+    int n_veh, total;                // total = B * n_veh
+    double w2;
+};
+
+template <int NC>
+__device__ __forceinline__ void diff_elev1(const double (&p)[NC], double val, double (&d)[NC])
+{
+    constexpr int N = NC - 1;
+    double t[NC];
+#pragma unroll
+    for (int c = 0; c < N; ++c) t[c] = p[c] * (-val) + p[c + 1] * val;
+    d[0] = t[0];
+    d[N] = t[N - 1];
+#pragma unroll
+    for (int c = 1; c < N; ++c) d[c] = t[c - 1] * ((double)c / (double)N) + t[c] * ((double)(N - c) / (double)N);
+}
+
+template <int NC>
+__global__ __launch_bounds__(kWave) void k_angrate(const AngParams p)
+{
+    constexpr int N = NC - 1, L2 = 2 * N + 1, L4 = 4 * N + 1;
+    constexpr int TP = L4;   // odd
+    extern __shared__ double lds[];
+    const int lane = threadIdx.x;
+    const int it0 = blockIdx.x * kWave;
+    if (it0 >= p.total) return;
+    const int n_valid = min(kWave, p.total - it0);
+    const int item = min(it0 + lane, p.total - 1);
+    const int b = item / p.n_veh;
+    const double* src = p.Y + (size_t)item * 2 * NC;   // rows (b, veh) are contiguous
+    double x[NC], y[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) { x[c] = src[c]; y[c] = src[NC + c]; }
+    const double val = (double)N / p.tf[b];
+    double xD[NC], yD[NC], xDD[NC], yDD[NC];
+    diff_elev1<NC>(x, val, xD);
+    diff_elev1<NC>(y, val, yD);
+    diff_elev1<NC>(xD, val, xDD);
+    diff_elev1<NC>(yD, val, yDD);
+
+    // num1 = yDD*xD - xDD*yD,  den1 = xD*xD + yD*yD     (degree 2n, optimization.py:603-605)
+    double num1[L2], den1[L2];
+#pragma unroll
+    for (int k = 0; k < L2; ++k) {
+        double s1 = 0.0, s2 = 0.0, sd = 0.0;
+#pragma unroll
+        for (int j = (k - N > 0 ? k - N : 0); j <= (N < k ? N : k); ++j) {
+            const double wkj = p.Wn[k * NC + j];
+            s1 = fma(wkj, yDD[j] * xD[k - j], s1);
+            s2 = fma(wkj, xDD[j] * yD[k - j], s2);
+        }
+#pragma unroll
+        for (int j = (k - N > 0 ? k - N : 0); 2 * j <= k; ++j)
+            sd = fma(p.W2n[k * NC + j], fma(xD[j], xD[k - j], yD[j] * yD[k - j]), sd);
+        num1[k] = s1 - s2;
+        den1[k] = sd;
+    }
+    // num = num1^2, den = den1^2 (degree 4n); constraint = w^2 - num.cpts / den.cpts
+#pragma unroll
+    for (int k = 0; k < L4; ++k) {
+        double sn = 0.0, sd = 0.0;
+#pragma unroll
+        for (int j = (k - 2 * N > 0 ? k - 2 * N : 0); 2 * j <= k; ++j) {
+            const double wkj = p.W22n[k * L2 + j];
+            sn = fma(wkj, num1[j] * num1[k - j], sn);
+            sd = fma(wkj, den1[j] * den1[k - j], sd);
+        }
+        lds[lane * TP + k] = p.w2 - sn / sd;
+    }
+    __syncthreads();
+    flush_full<L4, TP>(lds, p.out, (size_t)it0 * L4, n_valid, lane);
+}
+
+// =====================================================================================
+//  generic path: any degree / elevation, one wave per item, operands in LDS, products as
+//  binomially scaled convolutions:  c_k = (1/C(m+n,k)) * sum_j [C(m,j) a_j][C(n,k-j) b_{k-j}]
+// =====================================================================================
+struct GenParams {
+    const double* __restrict__ Y;
+    const double* __restrict__ obs;
+    const double* __restrict__ tf;
+    const int2* __restrict__ pairs;
+    const double* __restrict__ bin;   // concatenated binomial rows
+    double* __restrict__ out;
+    int n_veh, n_obj, dim, n, R;
+    int item_begin, item_count, B;
+    int o_n, o_2n, o_R, o_2nR;        // offsets of rows C(n,.), C(2n,.), C(R,.), C(2n+R,.)
+    int o_m, o_2m, o_4m, o_1m;        // ang-rate: rows for m = n+R, 2m, 4m and C(m-1,.) (unused)
+    double sign, offset;
+    int min_only;
+};
+
+// out[k] (k < L_out, lanes strided) = (1/bo[k]) * sum_j ah[j] * bh[k-j],  ah: la entries, bh: lb entries
+__device__ __forceinline__ double conv_at(const double* ah, int la, const double* bh, int lb, int k)
+{
+    double s = 0.0;
+    const int j0 = max(0, k - (lb - 1)), j1 = min(la - 1, k);
+    for (int j = j0; j <= j1; ++j) s = fma(ah[j], bh[k - j], s);
+    return s;
+}
+
+template <int MODE>
+__global__ __launch_bounds__(kWave) void k_generic_normsq_elev(const GenParams p)
+{
+    extern __shared__ double lds[];
+    const int lane = threadIdx.x;
+    const int n = p.n, nc = n + 1, L = 2 * n + 1, LR = L + p.R, dim = p.dim;
+    const long gi = blockIdx.x;
+    const int b = (int)(gi / p.item_count);
+    const int item = p.item_begin + (int)(gi - (long)b * p.item_count);
+    double* ah = lds;               // [dim][nc]   C(n,j) * a_j
+    double* ch = lds + dim * nc;    // [L]         C(2n,j) * c_j
+    double* tm = ch + L;            // [dim][nc]   scratch (vehicle mode)
+    const double* bn = p.bin + p.o_n;
+    const double* b2n = p.bin + p.o_2n;
+    const double* Yrow = p.Y + (size_t)b * p.n_veh * dim * nc;
+
+    if (MODE == 0) {
+        const int2 ij = p.pairs[item];
+        for (int e = lane; e < dim * nc; e += kWave) {
+            const int q = e / nc, c = e - q * nc;
+            const double vi = ij.x < p.n_veh ? Yrow[(size_t)ij.x * dim * nc + e] : p.obs[(ij.x - p.n_veh) * dim + q];
+            const double vj = ij.y < p.n_veh ? Yrow[(size_t)ij.y * dim * nc + e] : p.obs[(ij.y - p.n_veh) * dim + q];
+            ah[e] = (vi - vj) * bn[c];
+        }
+    } else {
+        const double val = (double)n / p.tf[b];
+        const double* v = Yrow + (size_t)item * dim * nc;
+        for (int e = lane; e < dim * nc; e += kWave) {
+            const int q = e / nc, c = e - q * nc;
+            tm[e] = (c < n) ? v[q * nc + c] * (-val) + v[q * nc + c + 1] * val : 0.0;
+        }
+        __syncthreads();
+        for (int e = lane; e < dim * nc; e += kWave) {
+            const int q = e / nc, c = e - q * nc;
+            double d;
+            if (c == 0) d = tm[q * nc];
+            else if (c == n) d = tm[q * nc + n - 1];
+            else d = tm[q * nc + c - 1] * ((double)c / (double)n) + tm[q * nc + c] * ((double)(n - c) / (double)n);
+            ah[e] = d * bn[c];
+        }
+    }
+    __syncthreads();
+    const size_t row = ((size_t)b * p.item_count + (size_t)(item - p.item_begin));
+    double mloc = INFINITY;
+    for (int k = lane; k < L; k += kWave) {
+        double s = 0.0;
+        for (int q = 0; q < dim; ++q) s += conv_at(ah + q * nc, nc, ah + q * nc, nc, k);
+        const double c = (0.5 * dim) * s / b2n[k];
+        if (p.R == 0) {
+            if (p.min_only) mloc = fmin(mloc, c);
+            else p.out[row * LR + k] = p.sign * c + p.offset;
+        } else ch[k] = c * b2n[k];
+    }
+    if (p.R > 0) {
+        __syncthreads();
+        const double* bR = p.bin + p.o_R;
+        const double* b2nR = p.bin + p.o_2nR;
+        for (int k = lane; k < LR; k += kWave) {
+            const double s = conv_at(ch, L, bR, p.R + 1, k) / b2nR[k];
+            if (p.min_only) mloc = fmin(mloc, s);
+            else p.out[row * LR + k] = p.sign * s + p.offset;
+        }
+    }
+    if (p.min_only) {
+        for (int o = 32; o > 0; o >>= 1) mloc = fmin(mloc, __shfl_down(mloc, o));
+        if (lane == 0) p.out[row] = p.sign * mloc + p.offset;
+    }
+}
+
+// generic angular rate: one wave per (row, vehicle); m = n + R
+__global__ __launch_bounds__(kWave) void k_generic_angrate(const GenParams p)
+{
+    extern __shared__ double lds[];
+    const int lane = threadIdx.x;
+    const int n = p.n, nc = n + 1, m = n + p.R, mc = m + 1, L2 = 2 * m + 1, L4 = 4 * m + 1;
+    const long gi = blockIdx.x;
+    const int b = (int)(gi / p.n_veh), veh = (int)(gi - (long)b * p.n_veh);
+    double* pe = lds;              // [2][mc] elevated position
+    double* d1 = pe + 2 * mc;      // [2][mc] first derivative (plain)
+    double* d2 = d1 + 2 * mc;      // [2][mc] second derivative (plain)
+    double* tm = d2 + 2 * mc;      // [2][mc] scratch
+    double* h1 = tm + 2 * mc;      // [2][mc] C(m,.) * d1
+    double* h2 = h1 + 2 * mc;      // [2][mc] C(m,.) * d2
+    double* nu = h2 + 2 * mc;      // [L2]    C(2m,.) * num1
+    double* de = nu + L2;          // [L2]    C(2m,.) * den1
+    const double* bn = p.bin + p.o_n;
+    const double* bR = p.bin + p.o_R;
+    const double* bm = p.bin + p.o_m;
+    const double* b2m = p.bin + p.o_2m;
+    const double* b4m = p.bin + p.o_4m;
+    const double* v = p.Y + ((size_t)b * p.n_veh + veh) * 2 * nc;
+    const double val = (double)m / p.tf[b];
+
+    // pos.elev(R)  (optimization.py:453)
+    if (p.R == 0) {
+        for (int e = lane; e < 2 * nc; e += kWave) pe[e] = v[e];
+    } else {
+        for (int e = lane; e < 2 * nc; e += kWave) tm[e] = v[e] * bn[e % nc];
+        __syncthreads();
+        for (int e = lane; e < 2 * mc; e += kWave) {
+            const int q = e / mc, k = e - q * mc;
+            pe[e] = conv_at(tm + q * nc, nc, bR, p.R + 1, k) / bm[k];
+        }
+    }
+    __syncthreads();
+    // two diff() passes, each derivative + elev(1)
+    const double* srcs[2] = { pe, d1 };
+    double* dsts[2] = { d1, d2 };
+    for (int pass = 0; pass < 2; ++pass) {
+        const double* s = srcs[pass];
+        double* d = dsts[pass];
+        for (int e = lane; e < 2 * mc; e += kWave) {
+            const int q = e / mc, c = e - q * mc;
+            tm[e] = (c < m) ? s[q * mc + c] * (-val) + s[q * mc + c + 1] * val : 0.0;
+        }
+        __syncthreads();
+        for (int e = lane; e < 2 * mc; e += kWave) {
+            const int q = e / mc, c = e - q * mc;
+            double r;
+            if (c == 0) r = tm[q * mc];
+            else if (c == m) r = tm[q * mc + m - 1];
+            else r = tm[q * mc + c - 1] * ((double)c / (double)m) + tm[q * mc + c] * ((double)(m - c) / (double)m);
+            d[e] = r;
+        }
+        __syncthreads();
+    }
+    for (int e = lane; e < 2 * mc; e += kWave) {
+        h1[e] = d1[e] * bm[e % mc];
+        h2[e] = d2[e] * bm[e % mc];
+    }
+    __syncthreads();
+    const double *xD = h1, *yD = h1 + mc, *xDD = h2, *yDD = h2 + mc;
+    for (int k = lane; k < L2; k += kWave) {
+        const double t1 = conv_at(yDD, mc, xD, mc, k) / b2m[k];
+        const double t2 = conv_at(xDD, mc, yD, mc, k) / b2m[k];
+        const double e1 = conv_at(xD, mc, xD, mc, k) / b2m[k];
+        const double e2 = conv_at(yD, mc, yD, mc, k) / b2m[k];
+        nu[k] = (t1 - t2) * b2m[k];
+        de[k] = (e1 + e2) * b2m[k];
+    }
+    __syncthreads();
+    double* o = p.out + ((size_t)b * p.n_veh + veh) * L4;
+    for (int k = lane; k < L4; k += kWave) {
+        const double num = conv_at(nu, L2, nu, L2, k) / b4m[k];
+        const double den = conv_at(de, L2, de, L2, k) / b4m[k];
+        o[k] = p.offset - num / den;
+    }
+}
+
+// =====================================================================================
+//  single-curve Bernstein algebra (Bezier object methods), one wave per row
+// =====================================================================================
+struct BernParams {
+    const double* __restrict__ a;
+    const double* __restrict__ b;
+    const double* __restrict__ bin;
+    double* __restrict__ out;
+    int rows, m, n, R, d;
+    int o_a, o_b, o_c;   // binomial rows
+    double T;
+};
+
+__global__ __launch_bounds__(kWave) void k_bern_elev(const BernParams p)
+{
+    extern __shared__ double lds[];
+    const int lane = threadIdx.x, r = blockIdx.x, nc = p.n + 1, LR = nc + p.R;
+    const double* bn = p.bin + p.o_a;
+    const double* bR = p.bin + p.o_b;
+    const double* bo = p.bin + p.o_c;
+    if (p.R == 0) {
+        for (int k = lane; k < nc; k += kWave) p.out[(size_t)r * nc + k] = p.a[(size_t)r * nc + k];
+        return;
+    }
+    for (int e = lane; e < nc; e += kWave) lds[e] = p.a[(size_t)r * nc + e] * bn[e];
+    __syncthreads();
+    for (int k = lane; k < LR; k += kWave) p.out[(size_t)r * LR + k] = conv_at(lds, nc, bR, p.R + 1, k) / bo[k];
+}
+
+__global__ __launch_bounds__(kWave) void k_bern_diff(const BernParams p)
+{
+    extern __shared__ double lds[];
+    const int lane = threadIdx.x, r = blockIdx.x, n = p.n, nc = n + 1;
+    const double val = (double)n / p.T;
+    const double* s = p.a + (size_t)r * nc;
+    for (int c = lane; c < n; c += kWave) lds[c] = s[c] * (-val) + s[c + 1] * val;
+    __syncthreads();
+    for (int c = lane; c < nc; c += kWave) {
+        double d;
+        if (c == 0) d = lds[0];
+        else if (c == n) d = lds[n - 1];
+        else d = lds[c - 1] * ((double)c / (double)n) + lds[c] * ((double)(n - c) / (double)n);
+        p.out[(size_t)r * nc + c] = d;
+    }
+}
+
+__global__ __launch_bounds__(kWave) void k_bern_mul(const BernParams p)
+{
+    extern __shared__ double lds[];
+    const int lane = threadIdx.x, r = blockIdx.x, mc = p.m + 1, nc = p.n + 1, L = p.m + p.n + 1;
+    double* ah = lds;
+    double* bh = lds + mc;
+    const double* bm = p.bin + p.o_a;
+    const double* bn = p.bin + p.o_b;
+    const double* bo = p.bin + p.o_c;
+    for (int e = lane; e < mc; e += kWave) ah[e] = p.a[(size_t)r * mc + e] * bm[e];
+    for (int e = lane; e < nc; e += kWave) bh[e] = p.b[(size_t)r * nc + e] * bn[e];
+    __syncthreads();
+    for (int k = lane; k < L; k += kWave) p.out[(size_t)r * L + k] = conv_at(ah, mc, bh, nc, k) / bo[k];
+}
+
+__global__ __launch_bounds__(kWave) void k_bern_normsq(const BernParams p)
+{
+    extern __shared__ double lds[];
+    const int lane = threadIdx.x, nc = p.n + 1, L = 2 * p.n + 1;
+    const double* bn = p.bin + p.o_a;
+    const double* bo = p.bin + p.o_c;
+    for (int e = lane; e < p.d * nc; e += kWave) lds[e] = p.a[e] * bn[e % nc];
+    __syncthreads();
+    for (int k = lane; k < L; k += kWave) {
+        double s = 0.0;
+        for (int q = 0; q < p.d; ++q) s += conv_at(lds + q * nc, nc, lds + q * nc, nc, k);
+        p.out[k] = (0.5 * p.d) * s / bo[k];
+    }
+}
+
+// =====================================================================================
+//  finite-difference batch, objectives
+// =====================================================================================
+__global__ void k_fd_batch(const double* __restrict__ Y0, double* __restrict__ Y, int rows, int nc,
+                           int fixed, double h, int B)
+{
+    const size_t ysz = (size_t)rows * nc;
+    const size_t total = ysz * B;
+    const int free_cols = nc - 2 * fixed;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total;
+         e += (size_t)gridDim.x * blockDim.x) {
+        const int b = (int)(e / ysz);
+        const int r = (int)(e - (size_t)b * ysz);
+        double v = Y0[r];
+        if (b > 0) {
+            const int k = b - 1, pr = k / free_cols, pc = fixed + (k - pr * free_cols);
+            if (r == pr * nc + pc) v += h;
+        }
+        Y[e] = v;
+    }
+}
+
+// optimization.py:462-489: sum over vehicles and segments of |P_{i+1} - P_i| (unused third
+// slot of the reference's np.empty(3) scratch taken as 0 for dim == 2)
+__global__ __launch_bounds__(kWave) void k_euclid(const double* __restrict__ Y, double* __restrict__ out,
+                                                  int n_veh, int dim, int nc)
+{
+    const int lane = threadIdx.x, b = blockIdx.x, n = nc - 1;
+    const double* Yr = Y + (size_t)b * n_veh * dim * nc;
+    double s = 0.0;
+    for (int e = lane; e < n_veh * n; e += kWave) {
+        const int v = e / n, i = e - v * n;
+        double q = 0.0;
+        for (int j = 0; j < dim; ++j) {
+            const double t = Yr[(size_t)(v * dim + j) * nc + i + 1] - Yr[(size_t)(v * dim + j) * nc + i];
+            q = fma(t, t, q);
+        }
+        s += sqrt(q);
+    }
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o);
+    if (lane == 0) out[b] = s;
+}
+
+__global__ __launch_bounds__(kWave) void k_rowsum(const double* __restrict__ in, double* __restrict__ out, int len)
+{
+    const int lane = threadIdx.x, b = blockIdx.x;
+    double s = 0.0;
+    for (int e = lane; e < len; e += kWave) s += in[(size_t)b * len + e];
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o);
+    if (lane == 0) out[b] = s;
+}
+
+// =====================================================================================
+//  launchers
+// =====================================================================================
+template <int NC, int DIM, int MODE, bool MINONLY>
+static size_t ns_lds_bytes(int R, int slots)
+{
+    using S = NsShape<NC, DIM>;
+    size_t tile = MINONLY ? 0 : (size_t)kWave * (R == 0 ? S::TPF : S::TPC);
+    return (tile + (size_t)slots * S::VP) * sizeof(double);
+}
+
+template <int NC, int DIM, int MODE, bool MINONLY>
+static int launch_ns_t(obtg_ctx* c, NsParams p, int B, int kernel_id)
+{
+    size_t lds = ns_lds_bytes<NC, DIM, MODE, MINONLY>(p.R, p.stage_slots);
+    if (lds > 160 * 1024) return OBTG_ERR_UNSUPPORTED;
+    auto kern = k_normsq_elev<NC, DIM, MODE, MINONLY>;
+    if (lds > 48 * 1024)
+        OBTG_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    dim3 grid((unsigned)((size_t)B * p.wgs_per_row));
+    ScopedKernelTimer t(c, kernel_id);
+    hipLaunchKernelGGL(kern, grid, dim3(kWave), lds, c->stream, p);
+    OBTG_HIP(c, hipGetLastError());
+    return OBTG_OK;
+}
+
+template <int MODE, bool MINONLY>
+static int dispatch_ns(obtg_ctx* c, const NsParams& p, int B, int kernel_id)
+{
+    const int nc = c->deg + 1;
+#define OBTG_CASE(NC_, D_) \
+    if (nc == NC_ && c->dim == D_) return launch_ns_t<NC_, D_, MODE, MINONLY>(c, p, B, kernel_id);
+    OBTG_CASE(4, 2) OBTG_CASE(4, 3) OBTG_CASE(6, 2) OBTG_CASE(6, 3) OBTG_CASE(8, 2) OBTG_CASE(8, 3)
+    OBTG_CASE(11, 2) OBTG_CASE(11, 3) OBTG_CASE(16, 2) OBTG_CASE(16, 3) OBTG_CASE(21, 2) OBTG_CASE(21, 3)
+#undef OBTG_CASE
+    return OBTG_ERR_UNSUPPORTED;
+}
+
+static bool fast_shape(const obtg_ctx* c)
+{
+    const int nc = c->deg + 1;
+    const bool ncok = nc == 4 || nc == 6 || nc == 8 || nc == 11 || nc == 16 || nc == 21;
+    return ncok && (c->dim == 2 || c->dim == 3) && c->R <= 512;
+}
+
+static int gen_common(obtg_ctx* c, GenParams& g)
+{
+    // make every binomial row resident BEFORE taking the base pointer
+    const int n = c->deg, R = c->R, m = n + R;
+    int need[] = { n, 2 * n, R, 2 * n + R, m, 2 * m, 4 * m };
+    for (int v : need) { int o = binrow_offset(c, v); if (o < 0) return o; }
+    g.o_n = binrow_offset(c, n); g.o_2n = binrow_offset(c, 2 * n); g.o_R = binrow_offset(c, R);
+    g.o_2nR = binrow_offset(c, 2 * n + R);
+    g.o_m = binrow_offset(c, m); g.o_2m = binrow_offset(c, 2 * m); g.o_4m = binrow_offset(c, 4 * m);
+    g.o_1m = 0;
+    g.bin = c->d_binrows.as<double>();
+    g.n_veh = c->n_veh; g.n_obj = c->n_obj; g.dim = c->dim; g.n = n; g.R = R;
+    g.obs = c->d_obs.as<double>();
+    g.pairs = c->d_pairs.as<int2>();
+    return OBTG_OK;
+}
+
+int launch_temporal_sep(obtg_ctx* c, const double* dY, int B, double max_sep, int pair_begin,
+                        int pair_count, bool min_only, double* d_out)
+{
+    if (B <= 0 || pair_count <= 0) return OBTG_OK;
+    int rc = ensure_tables(c);
+    if (rc) return rc;
+    if (fast_shape(c)) {
+        NsParams p{};
+        p.Y = dY; p.obs = c->d_obs.as<double>(); p.tf = nullptr;
+        p.pairs = c->d_pairs.as<int2>(); p.W2 = c->d_w2.as<double>(); p.Tt = c->d_Tt.as<double>();
+        p.out = d_out; p.n_veh = c->n_veh; p.n_obj = c->n_obj; p.R = c->R;
+        p.item_begin = pair_begin; p.item_count = pair_count;
+        // enough workgroups to fill 256 CUs several times over, but amortise the staging
+        int groups_total = (pair_count + kWave - 1) / kWave;
+        int gpw = 4;
+        while (gpw > 1 && (long)B * ((groups_total + gpw - 1) / gpw) < 4096) gpw >>= 1;
+        p.groups_per_wg = gpw;
+        p.wgs_per_row = (groups_total + gpw - 1) / gpw;
+        // LDS slots: replay the kernel's staging rule over this launch's chunks
+        const int chunk = kWave * gpw;
+        int slots = 0;
+        for (int it0 = pair_begin; it0 < pair_begin + pair_count; it0 += chunk) {
+            const int last = std::min(pair_begin + pair_count, it0 + chunk) - 1;
+            const int fx = c->h_pairs[2 * it0], fy = c->h_pairs[2 * it0 + 1];
+            const int lx = c->h_pairs[2 * last], ly = c->h_pairs[2 * last + 1];
+            const int nI = lx - fx + 1;
+            const int nA = (nI == 1) ? (ly - fy + 1) : (c->n_obj - fy);
+            const int nB = (nI == 1) ? 0 : std::max(0, ((nI >= 3) ? c->n_obj - 1 : ly) - (fx + 2) + 1);
+            slots = std::max(slots, nI + nA + nB);
+        }
+        p.stage_slots = slots;
+        p.sign = 1.0; p.offset = -(max_sep * max_sep);
+        rc = min_only ? dispatch_ns<0, true>(c, p, B, OBTG_K_TEMPORAL_SEP)
+                      : dispatch_ns<0, false>(c, p, B, OBTG_K_TEMPORAL_SEP);
+        if (rc != OBTG_ERR_UNSUPPORTED) return rc;
+    }
+    GenParams g{};
+    rc = gen_common(c, g);
+    if (rc) return rc;
+    if (2 * c->deg + c->R + 1 > kMaxGenericLen) return OBTG_ERR_UNSUPPORTED;
+    g.Y = dY; g.out = d_out; g.item_begin = pair_begin; g.item_count = pair_count; g.B = B;
+    g.sign = 1.0; g.offset = -(max_sep * max_sep); g.min_only = min_only ? 1 : 0;
+    const int nc = c->deg + 1;
+    size_t lds = sizeof(double) * ((size_t)2 * c->dim * nc + 2 * c->deg + 1);
+    ScopedKernelTimer t(c, OBTG_K_TEMPORAL_SEP);
+    hipLaunchKernelGGL(k_generic_normsq_elev<0>, dim3((unsigned)((size_t)B * pair_count)), dim3(kWave), lds,
+                       c->stream, g);
+    OBTG_HIP(c, hipGetLastError());
+    return OBTG_OK;
+}
+
+int launch_speed(obtg_ctx* c, const double* dY, const double* d_tf, int B, double bound, int is_max,
+                 double* d_out)
+{
+    if (B <= 0) return OBTG_OK;
+    int rc = ensure_tables(c);
+    if (rc) return rc;
+    const double b2 = bound * bound;
+    if (fast_shape(c)) {
+        NsParams p{};
+        p.Y = dY; p.obs = nullptr; p.tf = d_tf; p.pairs = nullptr;
+        p.W2 = c->d_w2.as<double>(); p.Tt = c->d_Tt.as<double>(); p.out = d_out;
+        p.n_veh = c->n_veh; p.n_obj = c->n_veh; p.R = c->R;
+        p.item_begin = 0; p.item_count = c->n_veh;
+        p.groups_per_wg = 1;
+        p.wgs_per_row = (c->n_veh + kWave - 1) / kWave;
+        p.stage_slots = std::min(c->n_veh, kWave);
+        p.sign = is_max ? -1.0 : 1.0; p.offset = is_max ? b2 : -b2;
+        rc = dispatch_ns<1, false>(c, p, B, OBTG_K_SPEED);
+        if (rc != OBTG_ERR_UNSUPPORTED) return rc;
+    }
+    GenParams g{};
+    rc = gen_common(c, g);
+    if (rc) return rc;
+    if (2 * c->deg + c->R + 1 > kMaxGenericLen) return OBTG_ERR_UNSUPPORTED;
+    g.Y = dY; g.tf = d_tf; g.out = d_out; g.item_begin = 0; g.item_count = c->n_veh; g.B = B;
+    g.sign = is_max ? -1.0 : 1.0; g.offset = is_max ? b2 : -b2; g.min_only = 0;
+    const int nc = c->deg + 1;
+    size_t lds = sizeof(double) * ((size_t)2 * c->dim * nc + 2 * c->deg + 1);
+    ScopedKernelTimer t(c, OBTG_K_SPEED);
+    hipLaunchKernelGGL(k_generic_normsq_elev<1>, dim3((unsigned)((size_t)B * c->n_veh)), dim3(kWave), lds,
+                       c->stream, g);
+    OBTG_HIP(c, hipGetLastError());
+    return OBTG_OK;
+}
+
+template <int NC>
+static int launch_ang_t(obtg_ctx* c, const AngParams& p)
+{
+    constexpr int L4 = 4 * (NC - 1) + 1;
+    size_t lds = sizeof(double) * kWave * L4;
+    ScopedKernelTimer t(c, OBTG_K_ANG_RATE);
+    hipLaunchKernelGGL(k_angrate<NC>, dim3((unsigned)((p.total + kWave - 1) / kWave)), dim3(kWave), lds,
+                       c->stream, p);
+    OBTG_HIP(c, hipGetLastError());
+    return OBTG_OK;
+}
+
+int launch_ang_rate(obtg_ctx* c, const double* dY, const double* d_tf, int B, double max_rate,
+                    double* d_out)
+{
+    if (c->dim != 2) return OBTG_ERR_ARG;   // optimization.py:590-593 raises for dim != 2
+    if (B <= 0) return OBTG_OK;
+    int rc = ensure_tables(c);
+    if (rc) return rc;
+    const int nc = c->deg + 1;
+    if (c->R == 0 && (nc == 4 || nc == 6 || nc == 8 || nc == 11 || nc == 16)) {
+        AngParams p{};
+        p.Y = dY; p.tf = d_tf; p.out = d_out; p.n_veh = c->n_veh; p.total = B * c->n_veh;
+        p.w2 = max_rate * max_rate;
+        p.W2n = c->d_ang_w2n.as<double>();
+        p.W22n = c->d_ang_w22n.as<double>();
+        p.Wn = c->d_ang_wn.as<double>();
+        switch (nc) {
+            case 4: return launch_ang_t<4>(c, p);
+            case 6: return launch_ang_t<6>(c, p);
+            case 8: return launch_ang_t<8>(c, p);
+            case 11: return launch_ang_t<11>(c, p);
+            case 16: return launch_ang_t<16>(c, p);
+        }
+    }
+    GenParams g{};
+    rc = gen_common(c, g);
+    if (rc) return rc;
+    const int m = c->deg + c->R, mc = m + 1, L2 = 2 * m + 1;
+    if (m > 250) return OBTG_ERR_UNSUPPORTED;   // C(4m,2m) must stay finite in binary64
+    g.Y = dY; g.tf = d_tf; g.out = d_out; g.B = B; g.offset = max_rate * max_rate;
+    size_t lds = sizeof(double) * ((size_t)12 * mc + 2 * L2);
+    if (lds > 160 * 1024) return OBTG_ERR_UNSUPPORTED;
+    if (lds > 48 * 1024)
+        OBTG_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_generic_angrate),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    ScopedKernelTimer t(c, OBTG_K_ANG_RATE);
+    hipLaunchKernelGGL(k_generic_angrate, dim3((unsigned)((size_t)B * c->n_veh)), dim3(kWave), lds, c->stream, g);
+    OBTG_HIP(c, hipGetLastError());
+    return OBTG_OK;
+}
+
+int launch_fd_batch(obtg_ctx* c, const double* dY0, int n_fixed_cols, double h, int B, double* dY)
+{
+    const int rows = c->n_veh * c->dim, nc = c->deg + 1;
+    if (nc - 2 * n_fixed_cols <= 0) return OBTG_ERR_ARG;
+    if (B > rows * (nc - 2 * n_fixed_cols) + 1) return OBTG_ERR_ARG;
+    const size_t total = (size_t)rows * nc * B;
+    unsigned blocks = (unsigned)std::min<size_t>((total + 255) / 256, 256 * 8);
+    ScopedKernelTimer t(c, OBTG_K_FD_BATCH);
+    hipLaunchKernelGGL(k_fd_batch, dim3(blocks), dim3(256), 0, c->stream, dY0, dY, rows, nc, n_fixed_cols, h, B);
+    OBTG_HIP(c, hipGetLastError());
+    return OBTG_OK;
+}
+
+static int bern_rows(obtg_ctx* c, BernParams& p, int ra, int rb, int rc_)
+{
+    int need[] = { ra, rb, rc_ };
+    for (int v : need) if (v >= 0) { int o = binrow_offset(c, v); if (o < 0) return o; }
+    p.o_a = ra >= 0 ? binrow_offset(c, ra) : 0;
+    p.o_b = rb >= 0 ? binrow_offset(c, rb) : 0;
+    p.o_c = rc_ >= 0 ? binrow_offset(c, rc_) : 0;
+    p.bin = c->d_binrows.as<double>();
+    return OBTG_OK;
+}
+
+int launch_bern_elev(obtg_ctx* c, const double* d_in, int rows, int n, int R, double* d_out)
+{
+    if (rows <= 0) return OBTG_OK;
+    if (n < 0 || R < 0 || n + R + 1 > kMaxGenericLen) return OBTG_ERR_UNSUPPORTED;
+    BernParams p{};
+    p.a = d_in; p.out = d_out; p.rows = rows; p.n = n; p.R = R;
+    int rc = bern_rows(c, p, n, R, n + R);
+    if (rc) return rc;
+    ScopedKernelTimer t(c, OBTG_K_BERN);
+    hipLaunchKernelGGL(k_bern_elev, dim3(rows), dim3(kWave), sizeof(double) * (n + 1), c->stream, p);
+    OBTG_HIP(c, hipGetLastError());
+    return OBTG_OK;
+}
+
+int launch_bern_diff(obtg_ctx* c, const double* d_in, int rows, int n, double T, double* d_out)
+{
+    if (rows <= 0) return OBTG_OK;
+    if (n < 1 || n + 1 > kMaxGenericLen) return OBTG_ERR_UNSUPPORTED;
+    BernParams p{};
+    p.a = d_in; p.out = d_out; p.rows = rows; p.n = n; p.T = T;
+    ScopedKernelTimer t(c, OBTG_K_BERN);
+    hipLaunchKernelGGL(k_bern_diff, dim3(rows), dim3(kWave), sizeof(double) * (n + 1), c->stream, p);
+    OBTG_HIP(c, hipGetLastError());
+    return OBTG_OK;
+}
+
+int launch_bern_mul(obtg_ctx* c, const double* d_a, const double* d_b, int rows, int m, int n,
+                    double* d_out)
+{
+    if (rows <= 0) return OBTG_OK;
+    if (m < 0 || n < 0 || m + n + 1 > kMaxGenericLen) return OBTG_ERR_UNSUPPORTED;
+    BernParams p{};
+    p.a = d_a; p.b = d_b; p.out = d_out; p.rows = rows; p.m = m; p.n = n;
+    int rc = bern_rows(c, p, m, n, m + n);
+    if (rc) return rc;
+    ScopedKernelTimer t(c, OBTG_K_BERN);
+    hipLaunchKernelGGL(k_bern_mul, dim3(rows), dim3(kWave), sizeof(double) * (m + n + 2), c->stream, p);
+    OBTG_HIP(c, hipGetLastError());
+    return OBTG_OK;
+}
+
+int launch_bern_normsq(obtg_ctx* c, const double* d_x, int d, int n, double* d_out)
+{
+    if (d <= 0 || n < 0 || 2 * n + 1 > kMaxGenericLen) return OBTG_ERR_UNSUPPORTED;
+    BernParams p{};
+    p.a = d_x; p.out = d_out; p.d = d; p.n = n;
+    int rc = bern_rows(c, p, n, -1, 2 * n);
+    if (rc) return rc;
+    ScopedKernelTimer t(c, OBTG_K_BERN);
+    hipLaunchKernelGGL(k_bern_normsq, dim3(1), dim3(kWave), sizeof(double) * d * (n + 1), c->stream, p);
+    OBTG_HIP(c, hipGetLastError());
+    return OBTG_OK;
+}
+
+int launch_euclidean_obj(obtg_ctx* c, const double* dY, int B, double* d_out)
+{
+    if (B <= 0) return OBTG_OK;
+    ScopedKernelTimer t(c, OBTG_K_BERN);
+    hipLaunchKernelGGL(k_euclid, dim3(B), dim3(kWave), 0, c->stream, dY, d_out, c->n_veh, c->dim, c->deg + 1);
+    OBTG_HIP(c, hipGetLastError());
+    return OBTG_OK;
+}
+
+// optimization.py:503-519: per vehicle pos.diff().diff().normSquare().elev(R), summed
+int launch_accel_obj(obtg_ctx* c, const double* dY, const double* d_tf, int B, double* d_out)
+{
+    if (B <= 0) return OBTG_OK;
+    // d/dt twice on every coordinate row, then the speed-style sweep with sign +1, offset 0
+    const int rows = B * c->n_veh * c->dim, nc = c->deg + 1;
+    int rc = c->ws_misc[3].reserve(sizeof(double) * (size_t)rows * nc);
+    if (rc) return rc;
+    rc = c->ws_misc[4].reserve(sizeof(double) * (size_t)B * c->n_veh * (2 * c->deg + c->R + 1));
+    if (rc) return rc;
+    // first derivative with the per-row tf: launch row-blocks per evaluation row
+    // (tf differs per row only in time-optimal problems; the objective there is x[-1], so a
+    //  single tf per call is all the reference ever uses: optimization.py:294-300)
+    double tf0;
+    OBTG_HIP(c, hipMemcpyAsync(&tf0, d_tf, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    OBTG_HIP(c, hipStreamSynchronize(c->stream));
+    rc = launch_bern_diff(c, dY, rows, c->deg, tf0, c->ws_misc[3].as<double>());
+    if (rc) return rc;
+    rc = launch_speed(c, c->ws_misc[3].as<double>(), d_tf, B, 0.0, 0, c->ws_misc[4].as<double>());
+    if (rc) return rc;
+    ScopedKernelTimer t(c, OBTG_K_BERN);
+    hipLaunchKernelGGL(k_rowsum, dim3(B), dim3(kWave), 0, c->stream, c->ws_misc[4].as<double>(), d_out,
+                       c->n_veh * (2 * c->deg + c->R + 1));
+    OBTG_HIP(c, hipGetLastError());
+    return OBTG_OK;
+}
+
+}  // namespace obtg

@@ -1,0 +1,716 @@
+// C ABI of libobtg_hip.so (include/obtg.h): context, tables, host-buffer entry points.
+// Compiled with hipcc (host code + HIP runtime API); the kernels live in
+// bern_kernels.hip and gjk_kernels.hip.
+#include <cmath>
+#include <cstring>
+#include <new>
+
+#include "obtg_internal.h"
+
+namespace obtg {
+
+int DevBuf::reserve(size_t bytes)
+{
+    if (bytes <= cap && p) return OBTG_OK;
+    if (bytes == 0) bytes = 8;
+    if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
+    // grow geometrically to keep repeated host-entry calls from reallocating
+    size_t want = bytes + bytes / 4;
+    if (hipMalloc(&p, want) != hipSuccess) {
+        (void)hipGetLastError();
+        if (hipMalloc(&p, bytes) != hipSuccess) { p = nullptr; return OBTG_ERR_OOM; }
+        want = bytes;
+    }
+    cap = want;
+    return OBTG_OK;
+}
+
+void DevBuf::release()
+{
+    if (p) (void)hipFree(p);
+    p = nullptr; cap = 0;
+}
+
+int set_error(obtg_ctx* c, hipError_t e, const char* where)
+{
+    if (c) {
+        c->last_error = std::string(hipGetErrorString(e)) + " at " + where;
+    }
+    (void)hipGetLastError();
+    return e == hipErrorOutOfMemory ? OBTG_ERR_OOM : OBTG_ERR_DEVICE;
+}
+
+ScopedKernelTimer::ScopedKernelTimer(obtg_ctx* c_, int id_) : c(c_), id(id_)
+{
+    if (!c->profiling) return;
+    if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) { a = b = nullptr; return; }
+    (void)hipEventRecord(a, c->stream);
+}
+
+ScopedKernelTimer::~ScopedKernelTimer()
+{
+    if (!a || !b) return;
+    (void)hipEventRecord(b, c->stream);
+    c->pending_events.push_back({ id, { a, b } });
+}
+
+void flush_pending_events(obtg_ctx* c)
+{
+    for (auto& pe : c->pending_events) {
+        float ms = 0.f;
+        if (hipEventSynchronize(pe.second.second) == hipSuccess &&
+            hipEventElapsedTime(&ms, pe.second.first, pe.second.second) == hipSuccess) {
+            c->stats[pe.first].ms += ms;
+            c->stats[pe.first].launches += 1;
+        }
+        (void)hipEventDestroy(pe.second.first);
+        (void)hipEventDestroy(pe.second.second);
+    }
+    c->pending_events.clear();
+}
+
+static int upload(obtg_ctx* c, DevBuf& buf, const void* src, size_t bytes)
+{
+    int rc = buf.reserve(bytes);
+    if (rc) return rc;
+    if (bytes) OBTG_HIP(c, hipMemcpyAsync(buf.p, src, bytes, hipMemcpyHostToDevice, c->stream));
+    // the source is usually a temporary: complete the copy before returning
+    OBTG_HIP(c, hipStreamSynchronize(c->stream));
+    return OBTG_OK;
+}
+
+// plain (unfolded) equal-degree product weights w(k,j), layout [2n+1][n+1]
+static std::vector<double> plain_product_weights(int n)
+{
+    int L = 2 * n + 1, nc = n + 1;
+    std::vector<double> W((size_t)L * nc, 0.0);
+    for (int k = 0; k < L; ++k) {
+        double den = binom(2 * n, k);
+        for (int j = (k - n > 0 ? k - n : 0); j <= (n < k ? n : k); ++j)
+            W[(size_t)k * nc + j] = binom(n, j) * binom(n, k - j) / den;
+    }
+    return W;
+}
+
+int ensure_tables(obtg_ctx* c)
+{
+    if (c->tables_R == c->R) return OBTG_OK;
+    const int n = c->deg, L = 2 * n + 1;
+    if (c->tables_R < 0) {
+        auto W2 = folded_product_weights(n, c->dim);
+        int rc = upload(c, c->d_w2, W2.data(), W2.size() * sizeof(double));
+        if (rc) return rc;
+        if (c->dim == 2 && n <= 15) {
+            auto a = folded_product_weights(n, 2);        // factor dim/2 = 1
+            auto b = folded_product_weights(2 * n, 2);
+            auto w = plain_product_weights(n);
+            if ((rc = upload(c, c->d_ang_w2n, a.data(), a.size() * sizeof(double)))) return rc;
+            if ((rc = upload(c, c->d_ang_w22n, b.data(), b.size() * sizeof(double)))) return rc;
+            if ((rc = upload(c, c->d_ang_wn, w.data(), w.size() * sizeof(double)))) return rc;
+        }
+    }
+    if (c->R > 0 && c->R <= 512) {
+        auto Tt = elev_table_T(L, c->R);
+        int rc = upload(c, c->d_Tt, Tt.data(), Tt.size() * sizeof(double));
+        if (rc) return rc;
+    }
+    c->tables_R = c->R;
+    return OBTG_OK;
+}
+
+int binrow_offset(obtg_ctx* c, int n)
+{
+    if (n < 0) return OBTG_ERR_ARG;
+    if (n > 1029) return OBTG_ERR_UNSUPPORTED;   // C(n, n/2) must be finite in binary64
+    if ((int)c->binrow_off.size() <= n) c->binrow_off.resize(n + 1, -1);
+    if (c->binrow_off[n] >= 0) return c->binrow_off[n];
+    auto row = binom_row(n);
+    const int off = (int)c->h_binrows.size();
+    c->h_binrows.insert(c->h_binrows.end(), row.begin(), row.end());
+    // re-upload the whole (small) table; in-flight kernels keep reading the old allocation's
+    // contents only if it is not freed, so drain the stream first
+    if (hipStreamSynchronize(c->stream) != hipSuccess) return OBTG_ERR_DEVICE;
+    int rc = upload(c, c->d_binrows, c->h_binrows.data(), c->h_binrows.size() * sizeof(double));
+    if (rc) return rc;
+    c->binrow_off[n] = off;
+    return off;
+}
+
+static bool check_ctx(const obtg_ctx* c) { return c != nullptr; }
+
+}  // namespace obtg
+
+using namespace obtg;
+
+extern "C" {
+
+const char* obtg_strerror(int code)
+{
+    switch (code) {
+        case OBTG_OK: return "ok";
+        case OBTG_ERR_ARG: return "invalid argument";
+        case OBTG_ERR_DEVICE: return "HIP runtime error";
+        case OBTG_ERR_NO_DEVICE: return "no usable gfx950 device";
+        case OBTG_ERR_OOM: return "out of memory";
+        case OBTG_ERR_UNSUPPORTED: return "degree / size not supported by the kernels";
+        default: return "unknown error";
+    }
+}
+
+const char* obtg_last_error(const obtg_ctx* c) { return c ? c->last_error.c_str() : ""; }
+
+int obtg_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    return n;
+}
+
+const char* obtg_abi_symbols(void)
+{
+    static const char syms[] =
+        "obtg_strerror\0obtg_last_error\0obtg_device_count\0obtg_abi_symbols\0"
+        "obtg_ctx_create\0obtg_ctx_destroy\0obtg_ctx_set_stream\0obtg_ctx_set_deg_elev\0obtg_sync\0"
+        "obtg_len_temporal_sep\0obtg_len_speed\0obtg_len_ang_rate\0obtg_num_pairs\0"
+        "obtg_temporal_sep\0obtg_speed\0obtg_ang_rate\0obtg_temporal_sep_min\0"
+        "obtg_temporal_sep_dev\0obtg_temporal_sep_min_dev\0obtg_speed_dev\0obtg_ang_rate_dev\0"
+        "obtg_fd_batch_dev\0obtg_gjk_pairs\0obtg_ctx_set_polygons\0obtg_ctx_set_hull_pairs\0"
+        "obtg_gjk_swarm_dev\0obtg_gjk_swarm\0obtg_min_dist\0obtg_min_dist2poly\0"
+        "obtg_bern_elev\0obtg_bern_diff\0obtg_bern_mul\0obtg_bern_normsq\0"
+        "obtg_euclidean_obj\0obtg_accel_obj\0"
+        "obtg_set_profiling\0obtg_kernel_stats\0obtg_reset_kernel_stats\0obtg_kernel_name\0";
+    return syms;
+}
+
+int obtg_ctx_create(obtg_ctx** out, int n_veh, int dim, int deg, int deg_elev, int n_point_obs,
+                    const double* point_obs, int device)
+{
+    if (!out) return OBTG_ERR_ARG;
+    *out = nullptr;
+    if (n_veh < 1 || dim < 1 || dim > 3 || deg < 1 || deg_elev < 0 || n_point_obs < 0) return OBTG_ERR_ARG;
+    if (n_point_obs > 0 && !point_obs) return OBTG_ERR_ARG;
+    int ndev = obtg_device_count();
+    if (ndev <= 0 || device < 0 || device >= ndev) return OBTG_ERR_NO_DEVICE;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess) { (void)hipGetLastError(); return OBTG_ERR_NO_DEVICE; }
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) return OBTG_ERR_NO_DEVICE;  // code objects are gfx950 only
+    if (hipSetDevice(device) != hipSuccess) { (void)hipGetLastError(); return OBTG_ERR_NO_DEVICE; }
+    obtg_ctx* c = new (std::nothrow) obtg_ctx();
+    if (!c) return OBTG_ERR_OOM;
+    c->device = device; c->n_veh = n_veh; c->dim = dim; c->deg = deg; c->R = deg_elev;
+    c->n_obs = n_point_obs; c->n_obj = n_veh + n_point_obs;
+    c->n_pairs = c->n_obj * (c->n_obj - 1) / 2;
+    if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) {
+        (void)hipGetLastError(); delete c; return OBTG_ERR_DEVICE;
+    }
+    c->stream = c->own_stream;
+    int rc = OBTG_OK;
+    c->h_pairs.resize((size_t)2 * c->n_pairs);
+    {
+        size_t p = 0;
+        for (int i = 0; i < c->n_obj - 1; ++i)
+            for (int j = i + 1; j < c->n_obj; ++j) { c->h_pairs[p++] = i; c->h_pairs[p++] = j; }
+    }
+    rc = upload(c, c->d_pairs, c->h_pairs.data(), c->h_pairs.size() * sizeof(int));
+    if (!rc) rc = upload(c, c->d_obs, point_obs, sizeof(double) * (size_t)n_point_obs * dim);
+    if (!rc) rc = ensure_tables(c);
+    if (rc) { obtg_ctx_destroy(c); return rc; }
+    *out = c;
+    return OBTG_OK;
+}
+
+void obtg_ctx_destroy(obtg_ctx* c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    flush_pending_events(c);
+    DevBuf* bufs[] = { &c->d_pairs, &c->d_obs, &c->d_w2, &c->d_Tt, &c->d_ang_w2n, &c->d_ang_w22n, &c->d_ang_wn,
+                       &c->d_binrows, &c->d_poly_pts, &c->d_poly_off, &c->d_hp_a, &c->d_hp_b, &c->ws_in,
+                       &c->ws_in2, &c->ws_out };
+    for (DevBuf* b : bufs) b->release();
+    for (auto& b : c->ws_misc) b.release();
+    if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+    delete c;
+}
+
+int obtg_ctx_set_stream(obtg_ctx* c, void* hip_stream)
+{
+    if (!check_ctx(c)) return OBTG_ERR_ARG;
+    OBTG_HIP(c, hipStreamSynchronize(c->stream));
+    c->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : c->own_stream;
+    return OBTG_OK;
+}
+
+int obtg_ctx_set_deg_elev(obtg_ctx* c, int deg_elev)
+{
+    if (!check_ctx(c) || deg_elev < 0) return OBTG_ERR_ARG;
+    if (deg_elev == c->R) return OBTG_OK;
+    OBTG_HIP(c, hipStreamSynchronize(c->stream));
+    c->R = deg_elev;
+    return ensure_tables(c);
+}
+
+int obtg_sync(obtg_ctx* c)
+{
+    if (!check_ctx(c)) return OBTG_ERR_ARG;
+    OBTG_HIP(c, hipStreamSynchronize(c->stream));
+    flush_pending_events(c);
+    return OBTG_OK;
+}
+
+int obtg_len_temporal_sep(const obtg_ctx* c) { return c ? c->n_pairs * (2 * c->deg + c->R + 1) : 0; }
+int obtg_len_speed(const obtg_ctx* c) { return c ? c->n_veh * (2 * c->deg + c->R + 1) : 0; }
+int obtg_len_ang_rate(const obtg_ctx* c) { return c ? c->n_veh * (4 * (c->deg + c->R) + 1) : 0; }
+int obtg_num_pairs(const obtg_ctx* c) { return c ? c->n_pairs : 0; }
+
+// ------------------------------------------------------------------ device-pointer sweeps
+int obtg_temporal_sep_dev(obtg_ctx* c, const double* dY, int B, double max_sep, int pair_begin,
+                          int pair_count, double* d_out)
+{
+    if (!check_ctx(c) || !dY || !d_out || B < 0) return OBTG_ERR_ARG;
+    if (pair_begin < 0 || pair_count < 0 || pair_begin + pair_count > c->n_pairs) return OBTG_ERR_ARG;
+    (void)hipSetDevice(c->device);
+    return launch_temporal_sep(c, dY, B, max_sep, pair_begin, pair_count, false, d_out);
+}
+
+int obtg_temporal_sep_min_dev(obtg_ctx* c, const double* dY, int B, double max_sep, int pair_begin,
+                              int pair_count, double* d_out)
+{
+    if (!check_ctx(c) || !dY || !d_out || B < 0) return OBTG_ERR_ARG;
+    if (pair_begin < 0 || pair_count < 0 || pair_begin + pair_count > c->n_pairs) return OBTG_ERR_ARG;
+    (void)hipSetDevice(c->device);
+    return launch_temporal_sep(c, dY, B, max_sep, pair_begin, pair_count, true, d_out);
+}
+
+int obtg_speed_dev(obtg_ctx* c, const double* dY, const double* d_tf, int B, double bound, int is_max,
+                   double* d_out)
+{
+    if (!check_ctx(c) || !dY || !d_tf || !d_out || B < 0) return OBTG_ERR_ARG;
+    (void)hipSetDevice(c->device);
+    return launch_speed(c, dY, d_tf, B, bound, is_max, d_out);
+}
+
+int obtg_ang_rate_dev(obtg_ctx* c, const double* dY, const double* d_tf, int B, double max_rate, double* d_out)
+{
+    if (!check_ctx(c) || !dY || !d_tf || !d_out || B < 0) return OBTG_ERR_ARG;
+    (void)hipSetDevice(c->device);
+    return launch_ang_rate(c, dY, d_tf, B, max_rate, d_out);
+}
+
+int obtg_fd_batch_dev(obtg_ctx* c, const double* dY0, int n_fixed_cols, double h, int B, double* dY)
+{
+    if (!check_ctx(c) || !dY0 || !dY || B < 1 || n_fixed_cols < 0) return OBTG_ERR_ARG;
+    (void)hipSetDevice(c->device);
+    return launch_fd_batch(c, dY0, n_fixed_cols, h, B, dY);
+}
+
+// ------------------------------------------------------------------ host-buffer sweeps
+static int h2d(obtg_ctx* c, DevBuf& b, const void* src, size_t bytes)
+{
+    int rc = b.reserve(bytes);
+    if (rc) return rc;
+    OBTG_HIP(c, hipMemcpyAsync(b.p, src, bytes, hipMemcpyHostToDevice, c->stream));
+    return OBTG_OK;
+}
+
+static int d2h(obtg_ctx* c, void* dst, const void* src, size_t bytes)
+{
+    OBTG_HIP(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream));
+    OBTG_HIP(c, hipStreamSynchronize(c->stream));
+    flush_pending_events(c);
+    return OBTG_OK;
+}
+
+static size_t ysize(const obtg_ctx* c) { return (size_t)c->n_veh * c->dim * (c->deg + 1); }
+
+static int host_sep(obtg_ctx* c, const double* Y, int B, double max_sep, bool min_only, double* out)
+{
+    if (!check_ctx(c) || !Y || !out || B < 0) return OBTG_ERR_ARG;
+    if (B == 0 || c->n_pairs == 0) return OBTG_OK;
+    (void)hipSetDevice(c->device);
+    const size_t per = min_only ? (size_t)c->n_pairs : (size_t)obtg_len_temporal_sep(c);
+    int rc = h2d(c, c->ws_in, Y, sizeof(double) * ysize(c) * B);
+    if (rc) return rc;
+    if ((rc = c->ws_out.reserve(sizeof(double) * per * B))) return rc;
+    rc = launch_temporal_sep(c, c->ws_in.as<double>(), B, max_sep, 0, c->n_pairs, min_only, c->ws_out.as<double>());
+    if (rc) return rc;
+    return d2h(c, out, c->ws_out.p, sizeof(double) * per * B);
+}
+
+int obtg_temporal_sep(obtg_ctx* c, const double* Y, int B, double max_sep, double* out)
+{
+    return host_sep(c, Y, B, max_sep, false, out);
+}
+
+int obtg_temporal_sep_min(obtg_ctx* c, const double* Y, int B, double max_sep, double* out)
+{
+    return host_sep(c, Y, B, max_sep, true, out);
+}
+
+int obtg_speed(obtg_ctx* c, const double* Y, const double* tf, int B, double bound, int is_max, double* out)
+{
+    if (!check_ctx(c) || !Y || !tf || !out || B < 0) return OBTG_ERR_ARG;
+    if (B == 0) return OBTG_OK;
+    (void)hipSetDevice(c->device);
+    const size_t per = (size_t)obtg_len_speed(c);
+    int rc = h2d(c, c->ws_in, Y, sizeof(double) * ysize(c) * B);
+    if (rc) return rc;
+    if ((rc = h2d(c, c->ws_in2, tf, sizeof(double) * B))) return rc;
+    if ((rc = c->ws_out.reserve(sizeof(double) * per * B))) return rc;
+    rc = launch_speed(c, c->ws_in.as<double>(), c->ws_in2.as<double>(), B, bound, is_max, c->ws_out.as<double>());
+    if (rc) return rc;
+    return d2h(c, out, c->ws_out.p, sizeof(double) * per * B);
+}
+
+int obtg_ang_rate(obtg_ctx* c, const double* Y, const double* tf, int B, double max_rate, double* out)
+{
+    if (!check_ctx(c) || !Y || !tf || !out || B < 0) return OBTG_ERR_ARG;
+    if (c->dim != 2) return OBTG_ERR_ARG;
+    if (B == 0) return OBTG_OK;
+    (void)hipSetDevice(c->device);
+    const size_t per = (size_t)obtg_len_ang_rate(c);
+    int rc = h2d(c, c->ws_in, Y, sizeof(double) * ysize(c) * B);
+    if (rc) return rc;
+    if ((rc = h2d(c, c->ws_in2, tf, sizeof(double) * B))) return rc;
+    if ((rc = c->ws_out.reserve(sizeof(double) * per * B))) return rc;
+    rc = launch_ang_rate(c, c->ws_in.as<double>(), c->ws_in2.as<double>(), B, max_rate, c->ws_out.as<double>());
+    if (rc) return rc;
+    return d2h(c, out, c->ws_out.p, sizeof(double) * per * B);
+}
+
+// ------------------------------------------------------------------ GJK
+// AoS pts[n][3] + offsets -> SoA per polygon (x[K] y[K] z[K])
+static std::vector<double> to_soa(const double* pts, const int* off, int n_poly)
+{
+    std::vector<double> s((size_t)3 * off[n_poly]);
+    for (int a = 0; a < n_poly; ++a) {
+        const int o = off[a], K = off[a + 1] - o;
+        for (int k = 0; k < K; ++k)
+            for (int cdim = 0; cdim < 3; ++cdim) s[(size_t)3 * o + (size_t)cdim * K + k] = pts[(size_t)3 * (o + k) + cdim];
+    }
+    return s;
+}
+
+static int check_polys(const int* off, int n_poly, int n_pts)
+{
+    if (!off || n_poly < 0) return OBTG_ERR_ARG;
+    if (off[0] != 0 || off[n_poly] != n_pts) return OBTG_ERR_ARG;
+    for (int a = 0; a < n_poly; ++a) if (off[a + 1] - off[a] < 1) return OBTG_ERR_ARG;
+    return OBTG_OK;
+}
+
+int obtg_gjk_pairs(obtg_ctx* c, const double* pts, int n_pts, const int* poly_off, int n_poly,
+                   const int* pair_a, const int* pair_b, int n_pairs, int max_iter, int md_cap, int* flag,
+                   double* p1, double* p2, double* dist, short* support_trace, int trace_cap,
+                   int* n_support, int* status)
+{
+    if (!check_ctx(c) || !pts || !pair_a || !pair_b || !flag || !p1 || !p2 || !dist) return OBTG_ERR_ARG;
+    if (n_pairs < 0 || max_iter < 0 || md_cap < 0 || trace_cap < 0) return OBTG_ERR_ARG;
+    int rc = check_polys(poly_off, n_poly, n_pts);
+    if (rc) return rc;
+    for (int k = 0; k < n_pairs; ++k)
+        if (pair_a[k] < 0 || pair_a[k] >= n_poly || pair_b[k] < 0 || pair_b[k] >= n_poly) return OBTG_ERR_ARG;
+    if (n_pairs == 0) return OBTG_OK;
+    (void)hipSetDevice(c->device);
+    auto soa = to_soa(pts, poly_off, n_poly);
+    DevBuf* m = c->ws_misc;
+    if ((rc = h2d(c, c->ws_in, soa.data(), soa.size() * sizeof(double)))) return rc;
+    if ((rc = h2d(c, m[0], poly_off, sizeof(int) * (n_poly + 1)))) return rc;
+    if ((rc = h2d(c, m[1], pair_a, sizeof(int) * n_pairs))) return rc;
+    if ((rc = h2d(c, m[2], pair_b, sizeof(int) * n_pairs))) return rc;
+    // outputs: flag | nsup | status (ints) ; p1 | p2 | dist (doubles) ; trace
+    if ((rc = m[3].reserve(sizeof(int) * 3 * (size_t)n_pairs))) return rc;
+    if ((rc = c->ws_out.reserve(sizeof(double) * 7 * (size_t)n_pairs))) return rc;
+    short* d_trace = nullptr;
+    if (support_trace && trace_cap > 0) {
+        if ((rc = m[4].reserve(sizeof(short) * 2 * (size_t)trace_cap * n_pairs))) return rc;
+        d_trace = m[4].as<short>();
+        OBTG_HIP(c, hipMemsetAsync(d_trace, 0, sizeof(short) * 2 * (size_t)trace_cap * n_pairs, c->stream));
+    }
+    int* d_flag = m[3].as<int>();
+    int* d_nsup = d_flag + n_pairs;
+    int* d_status = d_nsup + n_pairs;
+    double* d_p1 = c->ws_out.as<double>();
+    double* d_p2 = d_p1 + 3 * (size_t)n_pairs;
+    double* d_dist = d_p2 + 3 * (size_t)n_pairs;
+    rc = launch_gjk_pairs(c, c->ws_in.as<double>(), m[0].as<int>(), m[1].as<int>(), m[2].as<int>(), n_pairs,
+                          max_iter, md_cap, d_flag, d_p1, d_p2, d_dist, d_trace, trace_cap, d_nsup, d_status);
+    if (rc) return rc;
+    OBTG_HIP(c, hipMemcpyAsync(flag, d_flag, sizeof(int) * n_pairs, hipMemcpyDeviceToHost, c->stream));
+    if (n_support) OBTG_HIP(c, hipMemcpyAsync(n_support, d_nsup, sizeof(int) * n_pairs, hipMemcpyDeviceToHost, c->stream));
+    if (status) OBTG_HIP(c, hipMemcpyAsync(status, d_status, sizeof(int) * n_pairs, hipMemcpyDeviceToHost, c->stream));
+    OBTG_HIP(c, hipMemcpyAsync(p1, d_p1, sizeof(double) * 3 * n_pairs, hipMemcpyDeviceToHost, c->stream));
+    OBTG_HIP(c, hipMemcpyAsync(p2, d_p2, sizeof(double) * 3 * n_pairs, hipMemcpyDeviceToHost, c->stream));
+    if (d_trace)
+        OBTG_HIP(c, hipMemcpyAsync(support_trace, d_trace, sizeof(short) * 2 * (size_t)trace_cap * n_pairs,
+                                   hipMemcpyDeviceToHost, c->stream));
+    return d2h(c, dist, d_dist, sizeof(double) * n_pairs);
+}
+
+int obtg_ctx_set_polygons(obtg_ctx* c, const double* pts, int n_pts, const int* poly_off, int n_poly)
+{
+    if (!check_ctx(c) || n_poly < 0 || n_pts < 0) return OBTG_ERR_ARG;
+    (void)hipSetDevice(c->device);
+    OBTG_HIP(c, hipStreamSynchronize(c->stream));
+    if (n_poly == 0) {
+        c->n_poly = 0; c->n_poly_pts = 0;
+        int zero = 0;
+        return upload(c, c->d_poly_off, &zero, sizeof(int));
+    }
+    if (!pts) return OBTG_ERR_ARG;
+    int rc = check_polys(poly_off, n_poly, n_pts);
+    if (rc) return rc;
+    auto soa = to_soa(pts, poly_off, n_poly);
+    if ((rc = upload(c, c->d_poly_pts, soa.data(), soa.size() * sizeof(double)))) return rc;
+    if ((rc = upload(c, c->d_poly_off, poly_off, sizeof(int) * (n_poly + 1)))) return rc;
+    c->n_poly = n_poly; c->n_poly_pts = n_pts;
+    c->n_hull_pairs = 0;   // object ids may have changed meaning
+    return OBTG_OK;
+}
+
+int obtg_ctx_set_hull_pairs(obtg_ctx* c, const int* pair_a, const int* pair_b, int n_pairs)
+{
+    if (!check_ctx(c) || n_pairs < 0 || (n_pairs && (!pair_a || !pair_b))) return OBTG_ERR_ARG;
+    const int n_objs = c->n_veh + c->n_poly;
+    for (int k = 0; k < n_pairs; ++k)
+        if (pair_a[k] < 0 || pair_a[k] >= n_objs || pair_b[k] < 0 || pair_b[k] >= n_objs) return OBTG_ERR_ARG;
+    (void)hipSetDevice(c->device);
+    OBTG_HIP(c, hipStreamSynchronize(c->stream));
+    int rc = upload(c, c->d_hp_a, pair_a, sizeof(int) * (size_t)n_pairs);
+    if (rc) return rc;
+    if ((rc = upload(c, c->d_hp_b, pair_b, sizeof(int) * (size_t)n_pairs))) return rc;
+    c->n_hull_pairs = n_pairs;
+    if (c->d_poly_off.p == nullptr) {
+        int zero = 0;
+        if ((rc = upload(c, c->d_poly_off, &zero, sizeof(int)))) return rc;
+    }
+    if (c->d_poly_pts.p == nullptr && (rc = c->d_poly_pts.reserve(8))) return rc;
+    return OBTG_OK;
+}
+
+int obtg_gjk_swarm_dev(obtg_ctx* c, const double* dY, int B, int max_iter, int md_cap, int* d_flag,
+                       double* d_p1, double* d_p2, double* d_dist, int* d_nsup, int* d_status)
+{
+    if (!check_ctx(c) || !dY || !d_flag || !d_p1 || !d_p2 || !d_dist || B < 0) return OBTG_ERR_ARG;
+    if (c->dim < 2) return OBTG_ERR_ARG;   // bezier.py:847-851: curves must be 2-D or 3-D
+    (void)hipSetDevice(c->device);
+    return launch_gjk_swarm(c, dY, B, max_iter, md_cap, d_flag, d_p1, d_p2, d_dist, d_nsup, d_status);
+}
+
+int obtg_gjk_swarm(obtg_ctx* c, const double* Y, int B, int max_iter, int md_cap, int* flag, double* p1,
+                   double* p2, double* dist, int* nsup, int* status)
+{
+    if (!check_ctx(c) || !Y || !flag || !p1 || !p2 || !dist || B < 0) return OBTG_ERR_ARG;
+    if (c->dim < 2) return OBTG_ERR_ARG;
+    const size_t n = (size_t)B * c->n_hull_pairs;
+    if (n == 0) return OBTG_OK;
+    (void)hipSetDevice(c->device);
+    DevBuf* m = c->ws_misc;
+    int rc = h2d(c, c->ws_in, Y, sizeof(double) * ysize(c) * B);
+    if (rc) return rc;
+    if ((rc = m[3].reserve(sizeof(int) * 3 * n))) return rc;
+    if ((rc = c->ws_out.reserve(sizeof(double) * 7 * n))) return rc;
+    int* d_flag = m[3].as<int>();
+    int* d_nsup = d_flag + n;
+    int* d_status = d_nsup + n;
+    double* d_p1 = c->ws_out.as<double>();
+    double* d_p2 = d_p1 + 3 * n;
+    double* d_dist = d_p2 + 3 * n;
+    rc = launch_gjk_swarm(c, c->ws_in.as<double>(), B, max_iter, md_cap, d_flag, d_p1, d_p2, d_dist, d_nsup, d_status);
+    if (rc) return rc;
+    OBTG_HIP(c, hipMemcpyAsync(flag, d_flag, sizeof(int) * n, hipMemcpyDeviceToHost, c->stream));
+    if (nsup) OBTG_HIP(c, hipMemcpyAsync(nsup, d_nsup, sizeof(int) * n, hipMemcpyDeviceToHost, c->stream));
+    if (status) OBTG_HIP(c, hipMemcpyAsync(status, d_status, sizeof(int) * n, hipMemcpyDeviceToHost, c->stream));
+    OBTG_HIP(c, hipMemcpyAsync(p1, d_p1, sizeof(double) * 3 * n, hipMemcpyDeviceToHost, c->stream));
+    OBTG_HIP(c, hipMemcpyAsync(p2, d_p2, sizeof(double) * 3 * n, hipMemcpyDeviceToHost, c->stream));
+    return d2h(c, dist, d_dist, sizeof(double) * n);
+}
+
+// ------------------------------------------------------------------ minDist
+int obtg_min_dist(obtg_ctx* c, const double* curves, int n_curves, int K, const int* pair_a, const int* pair_b,
+                  int n_pairs, double eps, int max_iter, int md_cap, int max_depth, int max_nodes, double* res,
+                  int* info, int* status)
+{
+    if (!check_ctx(c) || !curves || !pair_a || !pair_b || !res || n_curves < 1 || n_pairs < 0) return OBTG_ERR_ARG;
+    if (max_depth < 1 || max_nodes < 1) return OBTG_ERR_ARG;
+    for (int k = 0; k < n_pairs; ++k)
+        if (pair_a[k] < 0 || pair_a[k] >= n_curves || pair_b[k] < 0 || pair_b[k] >= n_curves) return OBTG_ERR_ARG;
+    if (n_pairs == 0) return OBTG_OK;
+    (void)hipSetDevice(c->device);
+    DevBuf* m = c->ws_misc;
+    int rc = h2d(c, c->ws_in, curves, sizeof(double) * 3 * (size_t)K * n_curves);
+    if (rc) return rc;
+    if ((rc = h2d(c, m[1], pair_a, sizeof(int) * n_pairs))) return rc;
+    if ((rc = h2d(c, m[2], pair_b, sizeof(int) * n_pairs))) return rc;
+    if ((rc = m[5].reserve(sizeof(double) * min_dist_stack_doubles(K, max_depth) * n_pairs))) return rc;
+    if ((rc = c->ws_out.reserve(sizeof(double) * 3 * (size_t)n_pairs))) return rc;
+    if ((rc = m[3].reserve(sizeof(int) * 4 * (size_t)n_pairs))) return rc;
+    rc = launch_min_dist(c, c->ws_in.as<double>(), K, m[1].as<int>(), m[2].as<int>(), n_pairs, eps, max_iter,
+                         md_cap, max_depth, max_nodes, m[5].as<double>(), c->ws_out.as<double>(), m[3].as<int>());
+    if (rc) return rc;
+    std::vector<int> hinfo((size_t)4 * n_pairs);
+    OBTG_HIP(c, hipMemcpyAsync(hinfo.data(), m[3].p, sizeof(int) * 4 * n_pairs, hipMemcpyDeviceToHost, c->stream));
+    rc = d2h(c, res, c->ws_out.p, sizeof(double) * 3 * n_pairs);
+    if (rc) return rc;
+    if (info) std::memcpy(info, hinfo.data(), sizeof(int) * 4 * n_pairs);
+    if (status) for (int k = 0; k < n_pairs; ++k) status[k] = hinfo[4 * k + 3];
+    return OBTG_OK;
+}
+
+int obtg_min_dist2poly(obtg_ctx* c, const double* curves, int n_curves, int K, const double* pts, int n_pts,
+                       const int* poly_off, int n_poly, const int* pair_curve, const int* pair_poly, int n_pairs,
+                       double eps, int max_iter, int md_cap, int max_depth, int max_nodes, double* res, int* info,
+                       int* status)
+{
+    if (!check_ctx(c) || !curves || !pts || !pair_curve || !pair_poly || !res || n_curves < 1 || n_pairs < 0)
+        return OBTG_ERR_ARG;
+    if (max_depth < 1 || max_nodes < 1) return OBTG_ERR_ARG;
+    int rc = check_polys(poly_off, n_poly, n_pts);
+    if (rc) return rc;
+    for (int k = 0; k < n_pairs; ++k)
+        if (pair_curve[k] < 0 || pair_curve[k] >= n_curves || pair_poly[k] < 0 || pair_poly[k] >= n_poly)
+            return OBTG_ERR_ARG;
+    if (n_pairs == 0) return OBTG_OK;
+    (void)hipSetDevice(c->device);
+    DevBuf* m = c->ws_misc;
+    auto soa = to_soa(pts, poly_off, n_poly);
+    if ((rc = h2d(c, c->ws_in, curves, sizeof(double) * 3 * (size_t)K * n_curves))) return rc;
+    if ((rc = h2d(c, c->ws_in2, soa.data(), soa.size() * sizeof(double)))) return rc;
+    if ((rc = h2d(c, m[0], poly_off, sizeof(int) * (n_poly + 1)))) return rc;
+    if ((rc = h2d(c, m[1], pair_curve, sizeof(int) * n_pairs))) return rc;
+    if ((rc = h2d(c, m[2], pair_poly, sizeof(int) * n_pairs))) return rc;
+    if ((rc = m[5].reserve(sizeof(double) * min_dist2poly_stack_doubles(K, max_depth) * n_pairs))) return rc;
+    if ((rc = c->ws_out.reserve(sizeof(double) * 5 * (size_t)n_pairs))) return rc;
+    if ((rc = m[3].reserve(sizeof(int) * 4 * (size_t)n_pairs))) return rc;
+    rc = launch_min_dist2poly(c, c->ws_in.as<double>(), K, c->ws_in2.as<double>(), m[0].as<int>(), m[1].as<int>(),
+                              m[2].as<int>(), n_pairs, eps, max_iter, md_cap, max_depth, max_nodes,
+                              m[5].as<double>(), c->ws_out.as<double>(), m[3].as<int>());
+    if (rc) return rc;
+    std::vector<int> hinfo((size_t)4 * n_pairs);
+    OBTG_HIP(c, hipMemcpyAsync(hinfo.data(), m[3].p, sizeof(int) * 4 * n_pairs, hipMemcpyDeviceToHost, c->stream));
+    rc = d2h(c, res, c->ws_out.p, sizeof(double) * 5 * n_pairs);
+    if (rc) return rc;
+    if (info) std::memcpy(info, hinfo.data(), sizeof(int) * 4 * n_pairs);
+    if (status) for (int k = 0; k < n_pairs; ++k) status[k] = hinfo[4 * k + 3];
+    return OBTG_OK;
+}
+
+// ------------------------------------------------------------------ single-curve algebra
+int obtg_bern_elev(obtg_ctx* c, const double* in, int rows, int n, int R, double* out)
+{
+    if (!check_ctx(c) || !in || !out || rows < 0 || n < 0 || R < 0) return OBTG_ERR_ARG;
+    if (rows == 0) return OBTG_OK;
+    (void)hipSetDevice(c->device);
+    int rc = h2d(c, c->ws_in, in, sizeof(double) * (size_t)rows * (n + 1));
+    if (rc) return rc;
+    if ((rc = c->ws_out.reserve(sizeof(double) * (size_t)rows * (n + R + 1)))) return rc;
+    if ((rc = launch_bern_elev(c, c->ws_in.as<double>(), rows, n, R, c->ws_out.as<double>()))) return rc;
+    return d2h(c, out, c->ws_out.p, sizeof(double) * (size_t)rows * (n + R + 1));
+}
+
+int obtg_bern_diff(obtg_ctx* c, const double* in, int rows, int n, double T, double* out)
+{
+    if (!check_ctx(c) || !in || !out || rows < 0 || n < 1) return OBTG_ERR_ARG;
+    if (rows == 0) return OBTG_OK;
+    (void)hipSetDevice(c->device);
+    int rc = h2d(c, c->ws_in, in, sizeof(double) * (size_t)rows * (n + 1));
+    if (rc) return rc;
+    if ((rc = c->ws_out.reserve(sizeof(double) * (size_t)rows * (n + 1)))) return rc;
+    if ((rc = launch_bern_diff(c, c->ws_in.as<double>(), rows, n, T, c->ws_out.as<double>()))) return rc;
+    return d2h(c, out, c->ws_out.p, sizeof(double) * (size_t)rows * (n + 1));
+}
+
+int obtg_bern_mul(obtg_ctx* c, const double* a, const double* b, int rows, int m, int n, double* out)
+{
+    if (!check_ctx(c) || !a || !b || !out || rows < 0 || m < 0 || n < 0) return OBTG_ERR_ARG;
+    if (rows == 0) return OBTG_OK;
+    (void)hipSetDevice(c->device);
+    int rc = h2d(c, c->ws_in, a, sizeof(double) * (size_t)rows * (m + 1));
+    if (rc) return rc;
+    if ((rc = h2d(c, c->ws_in2, b, sizeof(double) * (size_t)rows * (n + 1)))) return rc;
+    if ((rc = c->ws_out.reserve(sizeof(double) * (size_t)rows * (m + n + 1)))) return rc;
+    if ((rc = launch_bern_mul(c, c->ws_in.as<double>(), c->ws_in2.as<double>(), rows, m, n, c->ws_out.as<double>())))
+        return rc;
+    return d2h(c, out, c->ws_out.p, sizeof(double) * (size_t)rows * (m + n + 1));
+}
+
+int obtg_bern_normsq(obtg_ctx* c, const double* x, int d, int n, double* out)
+{
+    if (!check_ctx(c) || !x || !out || d < 1 || n < 0) return OBTG_ERR_ARG;
+    (void)hipSetDevice(c->device);
+    int rc = h2d(c, c->ws_in, x, sizeof(double) * (size_t)d * (n + 1));
+    if (rc) return rc;
+    if ((rc = c->ws_out.reserve(sizeof(double) * (size_t)(2 * n + 1)))) return rc;
+    if ((rc = launch_bern_normsq(c, c->ws_in.as<double>(), d, n, c->ws_out.as<double>()))) return rc;
+    return d2h(c, out, c->ws_out.p, sizeof(double) * (size_t)(2 * n + 1));
+}
+
+// ------------------------------------------------------------------ objectives
+int obtg_euclidean_obj(obtg_ctx* c, const double* Y, int B, double* out)
+{
+    if (!check_ctx(c) || !Y || !out || B < 0) return OBTG_ERR_ARG;
+    if (B == 0) return OBTG_OK;
+    (void)hipSetDevice(c->device);
+    int rc = h2d(c, c->ws_in, Y, sizeof(double) * ysize(c) * B);
+    if (rc) return rc;
+    if ((rc = c->ws_out.reserve(sizeof(double) * B))) return rc;
+    if ((rc = launch_euclidean_obj(c, c->ws_in.as<double>(), B, c->ws_out.as<double>()))) return rc;
+    return d2h(c, out, c->ws_out.p, sizeof(double) * B);
+}
+
+int obtg_accel_obj(obtg_ctx* c, const double* Y, const double* tf, int B, double* out)
+{
+    if (!check_ctx(c) || !Y || !tf || !out || B < 0) return OBTG_ERR_ARG;
+    if (B == 0) return OBTG_OK;
+    (void)hipSetDevice(c->device);
+    int rc = h2d(c, c->ws_in, Y, sizeof(double) * ysize(c) * B);
+    if (rc) return rc;
+    if ((rc = h2d(c, c->ws_in2, tf, sizeof(double) * B))) return rc;
+    if ((rc = c->ws_out.reserve(sizeof(double) * B))) return rc;
+    if ((rc = launch_accel_obj(c, c->ws_in.as<double>(), c->ws_in2.as<double>(), B, c->ws_out.as<double>()))) return rc;
+    return d2h(c, out, c->ws_out.p, sizeof(double) * B);
+}
+
+// ------------------------------------------------------------------ instrumentation
+int obtg_set_profiling(obtg_ctx* c, int on)
+{
+    if (!check_ctx(c)) return OBTG_ERR_ARG;
+    OBTG_HIP(c, hipStreamSynchronize(c->stream));
+    flush_pending_events(c);
+    c->profiling = on != 0;
+    return OBTG_OK;
+}
+
+int obtg_kernel_stats(obtg_ctx* c, int kernel_id, double* total_ms, long long* launches)
+{
+    if (!check_ctx(c) || kernel_id < 0 || kernel_id >= OBTG_K_COUNT) return OBTG_ERR_ARG;
+    flush_pending_events(c);
+    if (total_ms) *total_ms = c->stats[kernel_id].ms;
+    if (launches) *launches = c->stats[kernel_id].launches;
+    return OBTG_OK;
+}
+
+int obtg_reset_kernel_stats(obtg_ctx* c)
+{
+    if (!check_ctx(c)) return OBTG_ERR_ARG;
+    flush_pending_events(c);
+    for (auto& s : c->stats) s = KernelStat{};
+    return OBTG_OK;
+}
+
+const char* obtg_kernel_name(int id)
+{
+    switch (id) {
+        case OBTG_K_TEMPORAL_SEP: return "temporal_sep";
+        case OBTG_K_SPEED: return "speed";
+        case OBTG_K_ANG_RATE: return "ang_rate";
+        case OBTG_K_GJK: return "gjk";
+        case OBTG_K_MIN_DIST: return "min_dist";
+        case OBTG_K_FD_BATCH: return "fd_batch";
+        case OBTG_K_BERN: return "bern";
+        default: return "?";
+    }
+}
+
+}  // extern "C"

@@ -1,0 +1,506 @@
+// GJK convex-hull distance sweeps and the curve<->curve / curve<->polygon branch & bound.
+//
+// Reference: gjk/gjk.py:230-681 (gjkNew and helpers), bezier.py:1283-1558 (_minDist,
+// _minDist2Poly, _upperbound, _upperboundPoly), bezier.py:985-1027 (deCasteljauSplit),
+// optimization.py:109-133 (spatialSeparationConstraints pair loop).
+//
+// This translation unit is compiled with -ffp-contract=off: the reference's branch
+// decisions must be reproduced bit for bit (support indices are the parity target).
+//
+// Work decomposition: one hull pair per lane.  gjkNew is a short, divergent state machine
+// (about five support sweeps over 2(n+1) points); the only expensive step, the support
+// scan, is common to every simplex case, so the loop is shaped "small divergent update,
+// then convergent supportPts".  For the batched swarm sweep a workgroup stages the control
+// polygons of one evaluation row in LDS (structure-of-arrays per vehicle, odd pitch) and
+// its lanes walk consecutive pairs of that row.
+#include <algorithm>
+
+#include "gjk_device.h"
+#include "obtg_internal.h"
+
+namespace obtg {
+
+using gjk::Ctx;
+using gjk::MemGlobal;
+using gjk::MemLds;
+using gjk::Poly;
+using gjk::Result;
+using gjk::V3;
+
+// -------------------------------------------------------------------------------------
+//  generic pair list on global SoA point sets:  poly a = x[K] y[K] z[K] at soa + 3*off[a]
+// -------------------------------------------------------------------------------------
+struct GjkPairsParams {
+    const double* __restrict__ soa;
+    const int* __restrict__ off;
+    const int* __restrict__ pa;
+    const int* __restrict__ pb;
+    int n_pairs, max_iter, md_cap;
+    int* __restrict__ flag;
+    double* __restrict__ p1;
+    double* __restrict__ p2;
+    double* __restrict__ dist;
+    short* trace;
+    int trace_cap;
+    int* nsup;
+    int* status;
+};
+
+__global__ __launch_bounds__(256) void k_gjk_pairs(const GjkPairsParams p)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= p.n_pairs) return;
+    const int a = p.pa[k], b = p.pb[k];
+    Ctx<MemGlobal> g;
+    g.mem = MemGlobal{ p.soa };
+    const int oa = p.off[a], ob = p.off[b];
+    const int Ka = p.off[a + 1] - oa, Kb = p.off[b + 1] - ob;
+    g.P1 = Poly{ 3 * oa, Ka, Ka, 1 };
+    g.P2 = Poly{ 3 * ob, Kb, Kb, 1 };
+    g.trace = p.trace ? p.trace + (size_t)k * p.trace_cap * 2 : nullptr;
+    g.trace_cap = p.trace_cap;
+    g.n_support = 0;
+    Result r;
+    gjk::run(g, p.max_iter, p.md_cap, r);
+    p.flag[k] = r.flag;
+    p.p1[3 * k] = r.c1.x; p.p1[3 * k + 1] = r.c1.y; p.p1[3 * k + 2] = r.c1.z;
+    p.p2[3 * k] = r.c2.x; p.p2[3 * k + 1] = r.c2.y; p.p2[3 * k + 2] = r.c2.z;
+    p.dist[k] = r.dist;
+    if (p.nsup) p.nsup[k] = r.n_support;
+    if (p.status) p.status[k] = r.status;
+}
+
+// -------------------------------------------------------------------------------------
+//  batched swarm sweep: hulls of the vehicles of row b (LDS) + static polygons (LDS)
+// -------------------------------------------------------------------------------------
+struct GjkSwarmParams {
+    const double* __restrict__ Y;      // [B][n_veh*dim][nc]
+    const double* __restrict__ poly;   // SoA polygons
+    const int* __restrict__ poly_off;  // [n_poly+1]
+    const int* __restrict__ pa;
+    const int* __restrict__ pb;
+    int n_veh, dim, nc, n_poly, n_poly_pts, n_pairs, wgs_per_row, vp;
+    int max_iter, md_cap;
+    int* __restrict__ flag;
+    double* __restrict__ p1;
+    double* __restrict__ p2;
+    double* __restrict__ dist;
+    int* nsup;
+    int* status;
+};
+
+__global__ __launch_bounds__(256) void k_gjk_swarm(const GjkSwarmParams p)
+{
+    extern __shared__ double lds[];
+    const int b = blockIdx.x / p.wgs_per_row, w = blockIdx.x - b * p.wgs_per_row;
+    const int vlen = p.dim * p.nc;
+    double* vl = lds;                        // [n_veh][vp]
+    double* pl = lds + p.n_veh * p.vp;       // polygons, SoA, 3*n_poly_pts doubles
+    const double* Yrow = p.Y + (size_t)b * p.n_veh * vlen;
+    for (int e = threadIdx.x; e < p.n_veh * vlen; e += blockDim.x) {
+        const int v = e / vlen, r = e - v * vlen;
+        vl[v * p.vp + r] = Yrow[e];
+    }
+    for (int e = threadIdx.x; e < 3 * p.n_poly_pts; e += blockDim.x) pl[e] = p.poly[e];
+    __syncthreads();
+    const int k = w * blockDim.x + threadIdx.x;
+    if (k >= p.n_pairs) return;
+    const int a = p.pa[k], bb = p.pb[k];
+    Ctx<MemLds> g;
+    g.mem = MemLds{ lds };
+    const int polybase = p.n_veh * p.vp;
+    if (a < p.n_veh) g.P1 = Poly{ a * p.vp, p.nc, p.nc, p.dim == 3 };
+    else { const int o = p.poly_off[a - p.n_veh], K = p.poly_off[a - p.n_veh + 1] - o; g.P1 = Poly{ polybase + 3 * o, K, K, 1 }; }
+    if (bb < p.n_veh) g.P2 = Poly{ bb * p.vp, p.nc, p.nc, p.dim == 3 };
+    else { const int o = p.poly_off[bb - p.n_veh], K = p.poly_off[bb - p.n_veh + 1] - o; g.P2 = Poly{ polybase + 3 * o, K, K, 1 }; }
+    g.trace = nullptr; g.trace_cap = 0; g.n_support = 0;
+    Result r;
+    gjk::run(g, p.max_iter, p.md_cap, r);
+    const size_t o = (size_t)b * p.n_pairs + k;
+    p.flag[o] = r.flag;
+    p.p1[3 * o] = r.c1.x; p.p1[3 * o + 1] = r.c1.y; p.p1[3 * o + 2] = r.c1.z;
+    p.p2[3 * o] = r.c2.x; p.p2[3 * o + 1] = r.c2.y; p.p2[3 * o + 2] = r.c2.z;
+    p.dist[o] = r.dist;
+    if (p.nsup) p.nsup[o] = r.n_support;
+    if (p.status) p.status[o] = r.status;
+}
+
+// -------------------------------------------------------------------------------------
+//  _minDist / _minDist2Poly: depth-first branch & bound with an explicit per-lane stack
+// -------------------------------------------------------------------------------------
+constexpr int kMdMaxK = 32;   // control points per curve supported by the branch & bound kernels
+
+// numpy add.reduce on a contiguous float64 vector: 0 + pairwise_sum (8 partial sums for n >= 8)
+__device__ __forceinline__ double np_sum(const double* a, int n)
+{
+    if (n < 8) {
+        double r = 0.0;
+        for (int i = 0; i < n; ++i) r += a[i];
+        return r;
+    }
+    double r0 = a[0], r1 = a[1], r2 = a[2], r3 = a[3], r4 = a[4], r5 = a[5], r6 = a[6], r7 = a[7];
+    int i;
+    for (i = 8; i < n - (n % 8); i += 8) {
+        r0 += a[i]; r1 += a[i + 1]; r2 += a[i + 2]; r3 += a[i + 3];
+        r4 += a[i + 4]; r5 += a[i + 5]; r6 += a[i + 6]; r7 += a[i + 7];
+    }
+    double res = ((r0 + r1) + (r2 + r3)) + ((r4 + r5) + (r6 + r7));
+    for (; i < n; ++i) res += a[i];
+    return res;
+}
+
+// bezier.py:1320-1351: parameter of a hull closest point on curve c[3][K]
+__device__ double hull_param(const double* c, int K, const V3& cl)
+{
+    for (int i = 0; i < K; ++i)
+        if (c[i] == cl.x && c[K + i] == cl.y && c[2 * K + i] == cl.z) return (double)i / (double)(K - 1);
+    double e[kMdMaxK], q[kMdMaxK], W[kMdMaxK];
+    for (int i = 0; i < K; ++i) {
+        const double dx = cl.x - c[i], dy = cl.y - c[K + i], dz = cl.z - c[2 * K + i];
+        double s = 0.0;
+        s += dx * dx; s += dy * dy; s += dz * dz;
+        e[i] = __builtin_sqrt(s);
+    }
+    for (int i = 0; i < K; ++i) {
+        for (int j = 0; j < i; ++j) q[j] = e[i] / e[j];
+        const double s1 = np_sum(q, i);
+        for (int j = i + 1; j < K; ++j) q[j - i - 1] = e[i] / e[j];
+        const double s2 = np_sum(q, K - i - 1);
+        W[i] = 1 / (1 + s1 + s2);
+    }
+    for (int i = 0; i < K; ++i) q[i] = W[i] * (double)i / (double)K;
+    return np_sum(q, K);
+}
+
+__device__ __forceinline__ double norm_seq(double ax, double ay, double az, double bx, double by, double bz)
+{
+    const double dx = ax - bx, dy = ay - by, dz = az - bz;
+    double s = 0.0;
+    s += dx * dx; s += dy * dy; s += dz * dz;
+    return __builtin_sqrt(s);
+}
+
+// bezier.py:985-1027 deCasteljauSplit on one coordinate row; half = 0: left piece, 1: right piece
+// (the reference reverses the "right" list, bezier.py:563)
+__device__ void split_row(const double* src, int K, double t, int half, double* dst)
+{
+    double tmp[kMdMaxK];
+    for (int i = 0; i < K; ++i) tmp[i] = src[i];
+    int idx = 0;
+    for (int sz = K; sz > 1; --sz) {
+        if (half == 0) dst[idx] = tmp[0]; else dst[K - 1 - idx] = tmp[sz - 1];
+        idx++;
+        for (int i = 0; i < sz - 1; ++i) tmp[i] = (1 - t) * tmp[i] + t * tmp[i + 1];
+    }
+    if (half == 0) dst[K - 1] = tmp[0]; else dst[0] = tmp[0];
+}
+
+// frame layout (doubles): c1[3K] c2[3K] then scalars
+enum { F_T1 = 0, F_T2, F_T1L, F_T1H, F_T2L, F_T2H, F_ALPHA, F_RT1, F_RT2, F_STATE, F_NSCAL };
+
+struct MdParams {
+    const double* __restrict__ curves;   // [n_curves][3][K]
+    const int* __restrict__ pa;
+    const int* __restrict__ pb;
+    int n_pairs, K, max_iter, md_cap, max_depth, max_nodes;
+    double eps;
+    double* stack;                        // [n_pairs][max_depth][frame]
+    double* __restrict__ res;             // [n_pairs][3]
+    int* __restrict__ info;               // [n_pairs][4]
+};
+
+__global__ __launch_bounds__(64) void k_min_dist(const MdParams p)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= p.n_pairs) return;
+    const int K = p.K, FR = 6 * K + F_NSCAL;
+    double* st = p.stack + (size_t)k * p.max_depth * FR;
+    const double* ca = p.curves + (size_t)p.pa[k] * 3 * K;
+    const double* cb = p.curves + (size_t)p.pb[k] * 3 * K;
+    for (int i = 0; i < 3 * K; ++i) { st[i] = ca[i]; st[3 * K + i] = cb[i]; }
+    {
+        double* sc = st + 6 * K;
+        sc[F_T1L] = 0; sc[F_T1H] = 1; sc[F_T2L] = 0; sc[F_T2H] = 1;
+        sc[F_ALPHA] = INFINITY; sc[F_STATE] = 0;
+    }
+    int depth = 0;           // index of the current frame; cnt = depth + 1
+    int nodes = 0, calls = 0, dmax = 0, status = OBTG_MD_OK;
+    double r0 = INFINITY, r1 = -1, r2 = -1;   // value returned by the frame that just finished
+    bool returning = false;
+    for (;;) {
+        double* f = st + (size_t)depth * FR;
+        double* sc = f + 6 * K;
+        int state = (int)sc[F_STATE];
+        if (!returning && state == 0) {
+            // ---- evaluate this node (bezier.py:1310-1374)
+            if (depth + 1 > 1000) { r0 = r1 = r2 = -1; returning = true; depth--; if (depth < 0) break; continue; }
+            if (nodes >= p.max_nodes) { status = OBTG_MD_NODE_CAP; break; }
+            nodes++;
+            if (depth + 1 > dmax) dmax = depth + 1;
+            Ctx<MemGlobal> g;
+            g.mem = MemGlobal{ f };
+            g.P1 = Poly{ 0, K, K, 1 };
+            g.P2 = Poly{ 3 * K, K, K, 1 };
+            g.trace = nullptr; g.trace_cap = 0; g.n_support = 0;
+            Result gr;
+            gjk::run(g, p.max_iter, p.md_cap, gr);
+            calls++;
+            if (gr.status == OBTG_ST_MD_CAP) { status = OBTG_MD_GJK_CAP; break; }
+            double lb, t1, t2;
+            if (gr.flag > 0) {
+                lb = gr.dist;
+                t1 = hull_param(f, K, gr.c1);
+                t2 = hull_param(f + 3 * K, K, gr.c2);
+            } else { t1 = 0.5; t2 = 0.5; lb = p.eps; }
+            // _upperbound (bezier.py:1499-1516)
+            const double* c1 = f; const double* c2 = f + 3 * K;
+            double dd[4];
+            dd[0] = norm_seq(c1[0], c1[K], c1[2 * K], c2[0], c2[K], c2[2 * K]);
+            dd[1] = norm_seq(c1[0], c1[K], c1[2 * K], c2[K - 1], c2[2 * K - 1], c2[3 * K - 1]);
+            dd[2] = norm_seq(c1[K - 1], c1[2 * K - 1], c1[3 * K - 1], c2[0], c2[K], c2[2 * K]);
+            dd[3] = norm_seq(c1[K - 1], c1[2 * K - 1], c1[3 * K - 1], c2[K - 1], c2[2 * K - 1], c2[3 * K - 1]);
+            int am = 0;
+            for (int i = 1; i < 4; ++i) if (dd[i] < dd[am]) am = i;
+            for (int i = 0; i < 4; ++i) if (dd[i] != dd[i]) { am = i; break; }
+            const double ub = dd[am], t1loc = (am >> 1) ? 1.0 : 0.0, t2loc = (am & 1) ? 1.0 : 0.0;
+            double alpha = sc[F_ALPHA], nT1, nT2;
+            if (ub <= alpha) {
+                alpha = ub;
+                nT1 = (1 - t1loc) * sc[F_T1L] + t1loc * sc[F_T1H];
+                nT2 = (1 - t2loc) * sc[F_T2L] + t2loc * sc[F_T2H];
+            } else { nT1 = -1; nT2 = -1; }
+            if (lb >= alpha * (1 - p.eps)) {
+                r0 = alpha; r1 = nT1; r2 = nT2; returning = true; depth--;
+                if (depth < 0) break;
+                continue;
+            }
+            if (depth + 1 >= p.max_depth) { status = OBTG_MD_DEPTH_CAP; r0 = alpha; r1 = nT1; r2 = nT2; break; }
+            if (t1 != t1) t1 = 0;    // Bezier.split: NaN -> 0 (bezier.py:555-557)
+            if (t2 != t2) t2 = 0;
+            sc[F_T1] = t1; sc[F_T2] = t2; sc[F_ALPHA] = alpha; sc[F_RT1] = nT1; sc[F_RT2] = nT2;
+            state = 1; sc[F_STATE] = 1;
+        }
+        if (returning) {
+            // a child of this frame finished: keep the better answer (bezier.py:1384-1406)
+            if (r0 < sc[F_ALPHA]) { sc[F_ALPHA] = r0; sc[F_RT1] = r1; sc[F_RT2] = r2; }
+            returning = false;
+            state = (int)sc[F_STATE];
+        }
+        if (state >= 5) {
+            r0 = sc[F_ALPHA]; r1 = sc[F_RT1]; r2 = sc[F_RT2]; returning = true; depth--;
+            if (depth < 0) break;
+            continue;
+        }
+        // ---- descend into child state-1: (c3,c5) (c3,c6) (c4,c5) (c4,c6)
+        {
+            const int ch = state - 1, h1 = ch >> 1, h2 = ch & 1;
+            const double t1 = sc[F_T1], t2 = sc[F_T2];
+            double* nf = f + FR;
+            for (int c = 0; c < 3; ++c) {
+                split_row(f + c * K, K, t1, h1, nf + c * K);
+                split_row(f + 3 * K + c * K, K, t2, h2, nf + 3 * K + c * K);
+            }
+            double* ns = nf + 6 * K;
+            const double t1len = sc[F_T1H] - sc[F_T1L], t2len = sc[F_T2H] - sc[F_T2L];
+            const double m1 = sc[F_T1L] + t1 * t1len, m2 = sc[F_T2L] + t2 * t2len;
+            ns[F_T1L] = h1 ? m1 : sc[F_T1L]; ns[F_T1H] = h1 ? sc[F_T1H] : m1;
+            ns[F_T2L] = h2 ? m2 : sc[F_T2L]; ns[F_T2H] = h2 ? sc[F_T2H] : m2;
+            ns[F_ALPHA] = sc[F_ALPHA]; ns[F_STATE] = 0;
+            sc[F_STATE] = state + 1;
+            depth++;
+        }
+    }
+    p.res[3 * k] = r0; p.res[3 * k + 1] = r1; p.res[3 * k + 2] = r2;
+    if (p.info) { p.info[4 * k] = nodes; p.info[4 * k + 1] = calls; p.info[4 * k + 2] = dmax; p.info[4 * k + 3] = status; }
+}
+
+// frame layout for the polygon form: c1[3K] then scalars
+enum { G_T1 = 0, G_T1L, G_T1H, G_ALPHA, G_RT1, G_PX, G_PY, G_PZ, G_STATE, G_NSCAL };
+
+struct Md2Params {
+    const double* __restrict__ curves;   // [n_curves][3][K]
+    const double* __restrict__ soa;      // polygons, SoA
+    const int* __restrict__ off;
+    const int* __restrict__ pc;
+    const int* __restrict__ pp;
+    int n_pairs, K, max_iter, md_cap, max_depth, max_nodes;
+    double eps;
+    double* stack;
+    double* __restrict__ res;             // [n_pairs][5]
+    int* __restrict__ info;
+};
+
+constexpr int kPolyBias = 1 << 24;
+struct MemTwo {   // indices below kPolyBias address the stack frame, the rest the polygon table
+    const double* f;
+    const double* __restrict__ g;
+    __device__ __forceinline__ double operator()(int idx) const
+    {
+        return idx < kPolyBias ? f[idx] : g[idx - kPolyBias];
+    }
+};
+
+__global__ __launch_bounds__(64) void k_min_dist2poly(const Md2Params p)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= p.n_pairs) return;
+    const int K = p.K, FR = 3 * K + G_NSCAL;
+    double* st = p.stack + (size_t)k * p.max_depth * FR;
+    const double* ca = p.curves + (size_t)p.pc[k] * 3 * K;
+    const int po = p.off[p.pp[k]], PK = p.off[p.pp[k] + 1] - po;
+    for (int i = 0; i < 3 * K; ++i) st[i] = ca[i];
+    {
+        double* sc = st + 3 * K;
+        sc[G_T1L] = 0; sc[G_T1H] = 1; sc[G_ALPHA] = INFINITY; sc[G_STATE] = 0;
+    }
+    int depth = 0, nodes = 0, calls = 0, dmax = 0, status = OBTG_MD_OK;
+    double r0 = INFINITY, r1 = -1, rx = -1, ry = -1, rz = -1;
+    bool returning = false;
+    for (;;) {
+        double* f = st + (size_t)depth * FR;
+        double* sc = f + 3 * K;
+        int state = (int)sc[G_STATE];
+        if (!returning && state == 0) {
+            if (depth + 1 > 1000) { r0 = r1 = rx = -1; ry = rz = -1; returning = true; depth--; if (depth < 0) break; continue; }
+            if (nodes >= p.max_nodes) { status = OBTG_MD_NODE_CAP; break; }
+            nodes++;
+            if (depth + 1 > dmax) dmax = depth + 1;
+            Ctx<MemTwo> g;
+            g.mem = MemTwo{ f, p.soa };
+            g.P1 = Poly{ 0, K, K, 1 };
+            g.P2 = Poly{ kPolyBias + 3 * po, PK, PK, 1 };
+            g.trace = nullptr; g.trace_cap = 0; g.n_support = 0;
+            Result gr;
+            gjk::run(g, p.max_iter, p.md_cap, gr);
+            calls++;
+            if (gr.status == OBTG_ST_MD_CAP) { status = OBTG_MD_GJK_CAP; break; }
+            double lb, t1, nT1, alpha = sc[G_ALPHA];
+            double cx, cy, cz;
+            if (gr.flag > 0) {
+                lb = gr.dist;
+                t1 = hull_param(f, K, gr.c1);
+                cx = gr.c2.x; cy = gr.c2.y; cz = gr.c2.z;
+                // _upperboundPoly (bezier.py:1535-1547)
+                const double d0 = norm_seq(f[0], f[K], f[2 * K], cx, cy, cz);
+                const double d1 = norm_seq(f[K - 1], f[2 * K - 1], f[3 * K - 1], cx, cy, cz);
+                int am = (d1 < d0) ? 1 : 0;
+                if (d0 != d0) am = 0; else if (d1 != d1) am = 1;
+                const double ub = am ? d1 : d0, t1loc = am ? 1.0 : 0.0;
+                if (ub <= alpha) { alpha = ub; nT1 = (1 - t1loc) * sc[G_T1L] + t1loc * sc[G_T1H]; }
+                else nT1 = -1;
+            } else {
+                t1 = 0.5; nT1 = -1; cx = cy = cz = -1; lb = p.eps * p.eps * p.eps;
+            }
+            if (lb >= alpha * (1 - p.eps)) {
+                r0 = alpha; r1 = nT1; rx = cx; ry = cy; rz = cz; returning = true; depth--;
+                if (depth < 0) break;
+                continue;
+            }
+            if (depth + 1 >= p.max_depth) { status = OBTG_MD_DEPTH_CAP; r0 = alpha; r1 = nT1; rx = cx; ry = cy; rz = cz; break; }
+            if (t1 != t1) t1 = 0;
+            sc[G_T1] = t1; sc[G_ALPHA] = alpha; sc[G_RT1] = nT1; sc[G_PX] = cx; sc[G_PY] = cy; sc[G_PZ] = cz;
+            state = 1; sc[G_STATE] = 1;
+        }
+        if (returning) {
+            if (r0 < sc[G_ALPHA]) { sc[G_ALPHA] = r0; sc[G_RT1] = r1; sc[G_PX] = rx; sc[G_PY] = ry; sc[G_PZ] = rz; }
+            returning = false;
+            state = (int)sc[G_STATE];
+        }
+        if (state >= 3) {
+            r0 = sc[G_ALPHA]; r1 = sc[G_RT1]; rx = sc[G_PX]; ry = sc[G_PY]; rz = sc[G_PZ];
+            returning = true; depth--;
+            if (depth < 0) break;
+            continue;
+        }
+        {
+            const int h1 = state - 1;
+            const double t1 = sc[G_T1];
+            double* nf = f + FR;
+            for (int c = 0; c < 3; ++c) split_row(f + c * K, K, t1, h1, nf + c * K);
+            double* ns = nf + 3 * K;
+            const double t1len = sc[G_T1H] - sc[G_T1L];
+            const double m1 = sc[G_T1L] + t1 * t1len;
+            ns[G_T1L] = h1 ? m1 : sc[G_T1L]; ns[G_T1H] = h1 ? sc[G_T1H] : m1;
+            ns[G_ALPHA] = sc[G_ALPHA]; ns[G_STATE] = 0;
+            sc[G_STATE] = state + 1;
+            depth++;
+        }
+    }
+    p.res[5 * k] = r0; p.res[5 * k + 1] = r1; p.res[5 * k + 2] = rx; p.res[5 * k + 3] = ry; p.res[5 * k + 4] = rz;
+    if (p.info) { p.info[4 * k] = nodes; p.info[4 * k + 1] = calls; p.info[4 * k + 2] = dmax; p.info[4 * k + 3] = status; }
+}
+
+// =====================================================================================
+//  launchers
+// =====================================================================================
+int launch_gjk_pairs(obtg_ctx* c, const double* d_soa, const int* d_off, const int* d_pa,
+                     const int* d_pb, int n_pairs, int max_iter, int md_cap, int* d_flag,
+                     double* d_p1, double* d_p2, double* d_dist, short* d_trace, int trace_cap,
+                     int* d_nsup, int* d_status)
+{
+    if (n_pairs <= 0) return OBTG_OK;
+    GjkPairsParams p{ d_soa, d_off, d_pa, d_pb, n_pairs, max_iter, md_cap, d_flag, d_p1, d_p2, d_dist,
+                      d_trace, trace_cap, d_nsup, d_status };
+    ScopedKernelTimer t(c, OBTG_K_GJK);
+    hipLaunchKernelGGL(k_gjk_pairs, dim3((n_pairs + 255) / 256), dim3(256), 0, c->stream, p);
+    OBTG_HIP(c, hipGetLastError());
+    return OBTG_OK;
+}
+
+int launch_gjk_swarm(obtg_ctx* c, const double* dY, int B, int max_iter, int md_cap, int* d_flag,
+                     double* d_p1, double* d_p2, double* d_dist, int* d_nsup, int* d_status)
+{
+    if (B <= 0 || c->n_hull_pairs <= 0) return OBTG_OK;
+    GjkSwarmParams p{};
+    p.Y = dY; p.poly = c->d_poly_pts.as<double>(); p.poly_off = c->d_poly_off.as<int>();
+    p.pa = c->d_hp_a.as<int>(); p.pb = c->d_hp_b.as<int>();
+    p.n_veh = c->n_veh; p.dim = c->dim; p.nc = c->deg + 1; p.n_poly = c->n_poly;
+    p.n_poly_pts = c->n_poly_pts; p.n_pairs = c->n_hull_pairs;
+    const int vlen = c->dim * (c->deg + 1);
+    p.vp = (vlen % 2 == 0) ? vlen + 1 : vlen;
+    p.wgs_per_row = (c->n_hull_pairs + 255) / 256;
+    p.max_iter = max_iter; p.md_cap = md_cap;
+    p.flag = d_flag; p.p1 = d_p1; p.p2 = d_p2; p.dist = d_dist; p.nsup = d_nsup; p.status = d_status;
+    size_t lds = sizeof(double) * ((size_t)c->n_veh * p.vp + 3 * (size_t)c->n_poly_pts);
+    if (lds > 160 * 1024) return OBTG_ERR_UNSUPPORTED;
+    if (lds > 48 * 1024)
+        OBTG_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_gjk_swarm),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    ScopedKernelTimer t(c, OBTG_K_GJK);
+    hipLaunchKernelGGL(k_gjk_swarm, dim3((unsigned)((size_t)B * p.wgs_per_row)), dim3(256), lds, c->stream, p);
+    OBTG_HIP(c, hipGetLastError());
+    return OBTG_OK;
+}
+
+size_t min_dist_stack_doubles(int K, int max_depth) { return (size_t)max_depth * (6 * K + F_NSCAL); }
+size_t min_dist2poly_stack_doubles(int K, int max_depth) { return (size_t)max_depth * (3 * K + G_NSCAL); }
+
+int launch_min_dist(obtg_ctx* c, const double* d_curves, int K, const int* d_pa, const int* d_pb,
+                    int n_pairs, double eps, int max_iter, int md_cap, int max_depth, int max_nodes,
+                    double* d_stack, double* d_res, int* d_info)
+{
+    if (n_pairs <= 0) return OBTG_OK;
+    if (K < 2 || K > kMdMaxK || max_depth < 1) return OBTG_ERR_UNSUPPORTED;
+    MdParams p{ d_curves, d_pa, d_pb, n_pairs, K, max_iter, md_cap, max_depth, max_nodes, eps, d_stack, d_res, d_info };
+    ScopedKernelTimer t(c, OBTG_K_MIN_DIST);
+    hipLaunchKernelGGL(k_min_dist, dim3((n_pairs + 63) / 64), dim3(64), 0, c->stream, p);
+    OBTG_HIP(c, hipGetLastError());
+    return OBTG_OK;
+}
+
+int launch_min_dist2poly(obtg_ctx* c, const double* d_curves, int K, const double* d_soa,
+                         const int* d_off, const int* d_pc, const int* d_pp, int n_pairs, double eps,
+                         int max_iter, int md_cap, int max_depth, int max_nodes, double* d_stack,
+                         double* d_res, int* d_info)
+{
+    if (n_pairs <= 0) return OBTG_OK;
+    if (K < 2 || K > kMdMaxK || max_depth < 1) return OBTG_ERR_UNSUPPORTED;
+    Md2Params p{ d_curves, d_soa, d_off, d_pc, d_pp, n_pairs, K, max_iter, md_cap, max_depth, max_nodes, eps,
+                 d_stack, d_res, d_info };
+    ScopedKernelTimer t(c, OBTG_K_MIN_DIST);
+    hipLaunchKernelGGL(k_min_dist2poly, dim3((n_pairs + 63) / 64), dim3(64), 0, c->stream, p);
+    OBTG_HIP(c, hipGetLastError());
+    return OBTG_OK;
+}
+
+}  // namespace obtg

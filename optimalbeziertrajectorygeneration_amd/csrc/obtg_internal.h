@@ -1,0 +1,129 @@
+// Internal declarations shared by the translation units of libobtg_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/obtg.h"
+
+namespace obtg {
+
+constexpr int kWave = 64;
+constexpr int kMaxGenericLen = 1024;  // longest Bernstein coefficient vector of the generic kernels
+
+// ---------------------------------------------------------------- host-side tables (tables.cpp)
+double binom(int n, int k);                         // scipy.special.binom on integers (0 outside range)
+std::vector<double> binom_row(int n);               // C(n, 0..n)
+std::vector<double> folded_product_weights(int n, int dim);  // [2n+1][n+1], see bern_kernels.hip
+std::vector<double> elev_table_T(int L_in, int R);  // transposed, zero padded: [L_in+R][L_in]
+
+// ---------------------------------------------------------------- device buffers
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    int reserve(size_t bytes);  // grows (never shrinks); returns OBTG_* code
+    void release();
+    template <class T> T* as() const { return static_cast<T*>(p); }
+};
+
+struct KernelStat {
+    double ms = 0.0;
+    long long launches = 0;
+};
+
+}  // namespace obtg
+
+struct obtg_ctx {
+    int device = 0;
+    int n_veh = 0, dim = 0, deg = 0, R = 0, n_obs = 0;
+    int n_obj = 0, n_pairs = 0;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    std::string last_error;
+
+    // resident tables
+    obtg::DevBuf d_pairs;     // int2[n_pairs]  (i, j) lexicographic, i < j < n_obj
+    obtg::DevBuf d_obs;       // double[n_obs][dim]
+    obtg::DevBuf d_w2;        // folded product weights for (deg, dim)
+    obtg::DevBuf d_Tt;        // elevation table (2*deg -> 2*deg+R), transposed
+    obtg::DevBuf d_ang_w2n, d_ang_w22n, d_ang_wn;  // angular-rate fast path weights
+    std::vector<int> h_pairs; // host copy of the pair table (2 ints per pair)
+    std::vector<double> h_binrows;
+    obtg::DevBuf d_binrows;   // concatenated binomial rows for the generic kernels
+    std::vector<int> binrow_off;   // offset of row C(n, .) inside d_binrows, -1 if absent
+    int tables_R = -1;
+
+    // swarm GJK state
+    obtg::DevBuf d_poly_pts;  // SoA per polygon: x[K], y[K], z[K]
+    obtg::DevBuf d_poly_off;  // int[n_poly+1]
+    int n_poly = 0, n_poly_pts = 0, max_poly_K = 0;
+    obtg::DevBuf d_hp_a, d_hp_b;  // hull pair list
+    int n_hull_pairs = 0;
+
+    // scratch for host-buffer entry points
+    obtg::DevBuf ws_in, ws_in2, ws_out, ws_misc[8];
+
+    // instrumentation
+    bool profiling = false;
+    obtg::KernelStat stats[OBTG_K_COUNT];
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    std::vector<std::pair<int, std::pair<hipEvent_t, hipEvent_t>>> pending_events;
+};
+
+namespace obtg {
+
+int set_error(obtg_ctx* c, hipError_t e, const char* where);
+#define OBTG_HIP(c, call)                                                   \
+    do {                                                                    \
+        hipError_t e__ = (call);                                            \
+        if (e__ != hipSuccess) return ::obtg::set_error((c), e__, #call);   \
+    } while (0)
+
+// bracket a launch with events when profiling
+struct ScopedKernelTimer {
+    obtg_ctx* c;
+    int id;
+    hipEvent_t a = nullptr, b = nullptr;
+    ScopedKernelTimer(obtg_ctx* c_, int id_);
+    ~ScopedKernelTimer();
+};
+void flush_pending_events(obtg_ctx* c);
+
+int ensure_tables(obtg_ctx* c);
+int binrow_offset(obtg_ctx* c, int n);  // ensures row C(n,.) is resident; returns offset (doubles)
+
+// ---------------------------------------------------------------- launchers (bern_kernels.hip)
+int launch_temporal_sep(obtg_ctx* c, const double* dY, int B, double max_sep, int pair_begin,
+                        int pair_count, bool min_only, double* d_out);
+int launch_speed(obtg_ctx* c, const double* dY, const double* d_tf, int B, double bound, int is_max,
+                 double* d_out);
+int launch_ang_rate(obtg_ctx* c, const double* dY, const double* d_tf, int B, double max_rate,
+                    double* d_out);
+int launch_fd_batch(obtg_ctx* c, const double* dY0, int n_fixed_cols, double h, int B, double* dY);
+int launch_bern_elev(obtg_ctx* c, const double* d_in, int rows, int n, int R, double* d_out);
+int launch_bern_diff(obtg_ctx* c, const double* d_in, int rows, int n, double T, double* d_out);
+int launch_bern_mul(obtg_ctx* c, const double* d_a, const double* d_b, int rows, int m, int n,
+                    double* d_out);
+int launch_bern_normsq(obtg_ctx* c, const double* d_x, int d, int n, double* d_out);
+int launch_euclidean_obj(obtg_ctx* c, const double* dY, int B, double* d_out);
+int launch_accel_obj(obtg_ctx* c, const double* dY, const double* d_tf, int B, double* d_out);
+
+// ---------------------------------------------------------------- launchers (gjk_kernels.hip)
+int launch_gjk_pairs(obtg_ctx* c, const double* d_soa, const int* d_off, const int* d_pa,
+                     const int* d_pb, int n_pairs, int max_iter, int md_cap, int* d_flag,
+                     double* d_p1, double* d_p2, double* d_dist, short* d_trace, int trace_cap,
+                     int* d_nsup, int* d_status);
+int launch_gjk_swarm(obtg_ctx* c, const double* dY, int B, int max_iter, int md_cap, int* d_flag,
+                     double* d_p1, double* d_p2, double* d_dist, int* d_nsup, int* d_status);
+int launch_min_dist(obtg_ctx* c, const double* d_curves, int K, const int* d_pa, const int* d_pb,
+                    int n_pairs, double eps, int max_iter, int md_cap, int max_depth, int max_nodes,
+                    double* d_stack, double* d_res, int* d_info);
+int launch_min_dist2poly(obtg_ctx* c, const double* d_curves, int K, const double* d_soa,
+                         const int* d_off, const int* d_pc, const int* d_pp, int n_pairs, double eps,
+                         int max_iter, int md_cap, int max_depth, int max_nodes, double* d_stack,
+                         double* d_res, int* d_info);
+size_t min_dist_stack_doubles(int K, int max_depth);
+size_t min_dist2poly_stack_doubles(int K, int max_depth);
+
+}  // namespace obtg

@@ -1,0 +1,59 @@
+// Host-side coefficient tables (the reference's elevMatrix / prodMatrix / bezProductCoefficients,
+// bezier.py:1127-1208, in the sparse forms the kernels consume).
+#include <cmath>
+
+#include "obtg_internal.h"
+
+namespace obtg {
+
+// scipy.special.binom restricted to integer arguments: 0 outside 0 <= k <= n
+// (the reference relies on that for the band structure, bezier.py:1145).
+double binom(int n, int k)
+{
+    if (k < 0 || k > n) return 0.0;
+    if (k > n - k) k = n - k;
+    long double r = 1.0L;
+    for (int i = 1; i <= k; ++i) r = r * (long double)(n - k + i) / (long double)i;
+    return (double)r;
+}
+
+std::vector<double> binom_row(int n)
+{
+    std::vector<double> r(n + 1);
+    for (int k = 0; k <= n; ++k) r[k] = binom(n, k);
+    return r;
+}
+
+// Equal-degree product weights w(k,j) = C(n,j) C(n,k-j) / C(2n,k) (bezier.py:1183-1208),
+// folded over the symmetry (j, k-j) <-> (k-j, j) and pre-multiplied by the reference's
+// normSquare factor dim/2 (bezier.py:884, 1744-1756).  Layout [2n+1][n+1]; only entries with
+// max(0,k-n) <= j <= k/2 are non-zero:  W2[k][j] = (dim/2) * w(k,j) * (2 if j != k-j else 1).
+std::vector<double> folded_product_weights(int n, int dim)
+{
+    int L = 2 * n + 1, nc = n + 1;
+    std::vector<double> W((size_t)L * nc, 0.0);
+    for (int k = 0; k < L; ++k) {
+        double den = binom(2 * n, k);
+        for (int j = (k - n > 0 ? k - n : 0); 2 * j <= k; ++j) {
+            double w = binom(n, j) * binom(n, k - j) / den;
+            if (j != k - j) w *= 2.0;
+            W[(size_t)k * nc + j] = w * (0.5 * dim);
+        }
+    }
+    return W;
+}
+
+// Degree elevation of an L_in-coefficient curve by R (bezier.py:1127-1147), transposed and
+// dense: Tt[k][j] = C(N,j) C(R,k-j) / C(N+R,k), N = L_in-1, k = 0..N+R, j = 0..N.
+std::vector<double> elev_table_T(int L_in, int R)
+{
+    int N = L_in - 1, Lr = L_in + R;
+    std::vector<double> T((size_t)Lr * L_in, 0.0);
+    for (int k = 0; k < Lr; ++k) {
+        double den = binom(N + R, k);
+        for (int j = 0; j <= N; ++j) T[(size_t)k * L_in + j] = binom(N, j) * binom(R, k - j) / den;
+    }
+    return T;
+}
+
+}  // namespace obtg

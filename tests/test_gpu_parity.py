@@ -1,0 +1,366 @@
+"""Parity of the HIP path (through the C ABI, via ctypes) against the CPU oracle and the
+reference-generated golden fixtures.  Needs a real MI355X: `pytest -m gpu`.
+
+Bars (BASELINE.json north_star): float64 constraint values within 1e-9 relative
+(scale-aware, tests/util.py); GJK flags and support-index sequences BIT-EXACT."""
+import numpy as np
+import pytest
+
+from util import assert_close
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-9
+
+
+@pytest.fixture(scope="module")
+def capi():
+    from optimalbeziertrajectorygeneration_amd import _capi
+    assert _capi.device_count() > 0, "these tests need the GPU"
+    return _capi
+
+
+@pytest.fixture(scope="module")
+def synth():
+    from optimalbeziertrajectorygeneration_amd import synth
+    return synth
+
+
+def _load(golden_dir, name):
+    return np.load(golden_dir + "/" + name)
+
+
+# ----------------------------------------------------------------- Bernstein constraint sweeps
+def test_constraints_golden_and_oracle(capi, oracle, golden_dir):
+    c = _load(golden_dir, "constraints.npz")
+    for name in c["names"]:
+        N, dim, n, R, tf, ms, vmax, vmin, wmax = c[name + "_par"]
+        N, dim, n, R = int(N), int(dim), int(n), int(R)
+        Y = c[name + "_Y"]
+        ctx = capi.Context(N, dim, n, R)
+        got = ctx.temporal_sep(Y, ms)[0]
+        assert_close(got, c[name + "_tsep"], RTOL, name + " tsep vs golden")
+        assert_close(got, oracle.temporal_sep(Y, N, dim, R, ms), RTOL, name + " tsep vs oracle")
+        assert_close(ctx.speed(Y, tf, vmax, True)[0], c[name + "_maxspeed"], RTOL, name + " vmax")
+        assert_close(ctx.speed(Y, tf, vmin, False)[0], c[name + "_minspeed"], RTOL, name + " vmin")
+        if name + "_angrate" in c.files:
+            assert_close(ctx.ang_rate(Y, tf, wmax)[0], c[name + "_angrate"], RTOL, name + " ang")
+        # fused per-pair minimum == min over the elevated control points
+        L = 2 * n + R + 1
+        assert_close(ctx.temporal_sep_min(Y, ms)[0], c[name + "_tsep"].reshape(-1, L).min(axis=1), RTOL,
+                     name + " tsep min")
+        ctx.close()
+
+
+def test_example1_with_point_obstacles(capi, golden_dir):
+    """optimization.py:83-107: point obstacles join the pair loop as constant curves."""
+    p = _load(golden_dir, "problem.npz")
+    obs = [[3.0, 2.0], [6.0, 7.0]]
+    for R in (0, 30, 100):
+        ctx = capi.Context(2, 2, 10, R, point_obs=obs)
+        ctx0 = capi.Context(2, 2, 10, R)
+        for tag in ("g", "r"):
+            x = p["ex1_xguess"] if tag == "g" else p["ex1_x"]
+            y = p["ex1_yguess"] if tag == "g" else p["ex1_y"]
+            assert_close(ctx.temporal_sep(y, 1.0)[0], p["ex1_%s_tsep_class_R%d" % (tag, R)], RTOL)
+            assert_close(ctx0.temporal_sep(y, 1.0)[0], p["ex1_%s_tsep_example_R%d" % (tag, R)], RTOL)
+            assert_close(ctx.speed(y, x[-1], 5.0, True)[0], p["ex1_%s_maxspeed_R%d" % (tag, R)], RTOL)
+            assert_close(ctx.speed(y, x[-1], 0.0, False)[0], p["ex1_%s_minspeed_R%d" % (tag, R)], RTOL)
+            if R <= 30:
+                assert_close(ctx.ang_rate(y, x[-1], 1.0)[0], p["ex1_%s_angrate_R%d" % (tag, R)], RTOL)
+        ctx.close()
+        ctx0.close()
+
+
+def test_swarm_example_and_objectives(capi, golden_dir):
+    p = _load(golden_dir, "problem.npz")
+    ctx = capi.Context(36, 3, 5, 0)
+    assert ctx.len_temporal_sep == 6930
+    assert_close(ctx.temporal_sep(p["sw_yguess"], 0.9)[0], p["sw_g_tsep"], RTOL)
+    assert_close(ctx.temporal_sep(p["sw_y"], 0.9)[0], p["sw_r_tsep"], RTOL)
+    assert abs(ctx.euclidean_obj(p["sw_y"])[0] - float(p["sw_r_obj"])) < 1e-9 * float(p["sw_r_obj"])
+    ctx.close()
+    ctx = capi.Context(3, 2, 7, 0)
+    assert_close(ctx.temporal_sep(p["fx_y"], 0.5)[0], p["fx_tsep"], RTOL)
+    assert_close(ctx.ang_rate(p["fx_y"], 7.0, 2.0)[0], p["fx_angrate"], RTOL)
+    assert abs(ctx.accel_obj(p["fx_y"], 7.0)[0] / float(p["fx_obj_accel"]) - 1) < 1e-9
+    ctx.close()
+
+
+def test_set_deg_elev_switches_tables(capi, oracle, synth):
+    """DEG_ELEV is read at call time (optimization.py:17, 337)."""
+    Y = synth.swarm_control_points(9, 2, 10, seed=3)
+    ctx = capi.Context(9, 2, 10, 0)
+    for R in (0, 5, 0, 40):
+        ctx.set_deg_elev(R)
+        assert ctx.len_temporal_sep == 36 * (21 + R)
+        assert_close(ctx.temporal_sep(Y, 0.9)[0], oracle.temporal_sep(Y, 9, 2, R, 0.9), RTOL)
+        assert_close(ctx.ang_rate(Y, 3.0, 1.0)[0], oracle.ang_rate(Y, 9, R, 3.0, 1.0), RTOL)
+    ctx.close()
+
+
+@pytest.mark.parametrize("N,dim,n,R", [(64, 2, 10, 0), (36, 3, 5, 0), (20, 2, 15, 0), (13, 3, 20, 2),
+                                       (9, 2, 7, 33), (5, 3, 3, 0), (7, 2, 9, 4), (6, 1, 6, 1), (3, 2, 12, 0)])
+def test_fd_batch_rows_vs_oracle(capi, oracle, synth, N, dim, n, R):
+    """A finite-difference batch: every row must match the oracle's row (fast and generic paths,
+    ragged tails: N and B are not multiples of the wave size)."""
+    Y = synth.swarm_control_points(N, dim, n, seed=17)
+    B = 37
+    Yb = synth.fd_batch(Y, B=B)
+    tf = np.linspace(2.0, 9.0, B)
+    ctx = capi.Context(N, dim, n, R)
+    o_sep, o_sp, o_an = oracle.eval_batch(Yb, tf, N, dim, R, 0.9, 5.0, 1.0)
+    assert_close(ctx.temporal_sep(Yb, 0.9), o_sep, RTOL, "tsep batch")
+    assert_close(ctx.speed(Yb, tf, 5.0, True), o_sp, RTOL, "speed batch")
+    if dim == 2:
+        assert_close(ctx.ang_rate(Yb, tf, 1.0), o_an, RTOL, "ang batch")
+    ctx.close()
+
+
+def test_single_object_and_empty_inputs(capi):
+    """optimization.py:345-346: with one object there are no pairs."""
+    ctx = capi.Context(1, 2, 10, 0)
+    assert ctx.num_pairs == 0 and ctx.len_temporal_sep == 0
+    Y = np.arange(22.0).reshape(2, 11)
+    assert ctx.temporal_sep(Y, 0.9).shape == (1, 0)
+    assert ctx.speed(Y, 1.0, 2.0, True).shape == (1, 21)
+    with pytest.raises(ValueError):
+        ctx.speed(np.zeros((3, 11)), 1.0, 2.0, True)
+    ctx.close()
+    with pytest.raises(RuntimeError):
+        capi.Context(2, 4, 5)      # dim 4 is not a thing
+
+
+def test_ang_rate_inf_nan_pattern(capi, golden_dir):
+    """optimization.py:608: element-wise division keeps 0/0 -> nan and x/0 -> inf."""
+    c = _load(golden_dir, "constraints.npz")
+    ctx = capi.Context(4, 2, 6, 0)
+    got = ctx.ang_rate(c["nan_Y"], 2.0, 1.0)[0]
+    ref = c["nan_angrate"]
+    assert np.isnan(ref).any()
+    assert (np.isnan(got) == np.isnan(ref)).all() and (np.isinf(got) == np.isinf(ref)).all()
+    ctx.close()
+
+
+def test_device_pointer_path_and_pair_partition(capi, oracle, synth):
+    """_dev entry points on torch-owned HBM, and the pair-partitioned mode: blocks of the
+    lexicographic pair list computed separately concatenate to the full sweep."""
+    import torch
+    N, dim, n, R = 40, 2, 10, 0
+    Y = synth.swarm_control_points(N, dim, n, seed=5)
+    B = 9
+    Yb = synth.fd_batch(Y, B=B)
+    ctx = capi.Context(N, dim, n, R)
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    dY = torch.from_numpy(Yb).cuda()
+    P, L = ctx.num_pairs, 2 * n + R + 1
+    full = torch.empty((B, P * L), dtype=torch.float64, device="cuda")
+    ctx.temporal_sep_dev(dY.data_ptr(), B, 0.9, full.data_ptr())
+    torch.cuda.synchronize()
+    ref = oracle.eval_batch(Yb, 1.0, N, dim, R, 0.9, 5.0, 1.0, want=("sep",))[0]
+    assert_close(full.cpu().numpy(), ref, RTOL)
+    parts = []
+    cuts = [0, 101, 102, 390, P]
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        o = torch.empty((B, (b - a) * L), dtype=torch.float64, device="cuda")
+        ctx.temporal_sep_dev(dY.data_ptr(), B, 0.9, o.data_ptr(), a, b - a)
+        parts.append(o)
+    torch.cuda.synchronize()
+    glued = torch.cat([q.view(B, -1, L) for q in parts], dim=1).reshape(B, -1)
+    assert torch.equal(glued, full)
+    # device-side FD batch == host-side FD batch, bit for bit
+    d0 = torch.from_numpy(Y).cuda()
+    dfd = torch.empty((B,) + Y.shape, dtype=torch.float64, device="cuda")
+    ctx.fd_batch_dev(d0.data_ptr(), 1, synth.FD_STEP, B, dfd.data_ptr())
+    torch.cuda.synchronize()
+    assert np.array_equal(dfd.cpu().numpy(), Yb)
+    ctx.set_stream(0)
+    ctx.close()
+
+
+# ----------------------------------------------------------------------------- Bezier algebra
+def test_bern_ops_golden(capi, golden_dir):
+    o = _load(golden_dir, "bezier_ops.npz")
+    ctx = capi.scratch_context()
+    for c in range(int(o["n_cases"])):
+        pre = "c%d_" % c
+        a, b, tf = o[pre + "a"], o[pre + "b"], float(o[pre + "tf"])
+        assert_close(ctx.bern_elev(a, 0), o[pre + "elev0"], RTOL)
+        assert_close(ctx.bern_elev(a, 1), o[pre + "elev1"], RTOL)
+        assert_close(ctx.bern_elev(a, 7), o[pre + "elev7"], RTOL)
+        d1 = ctx.bern_diff(a, tf)
+        assert_close(d1, o[pre + "diff"], RTOL)
+        assert_close(ctx.bern_diff(d1, tf), o[pre + "diff2"], RTOL)
+        assert_close(ctx.bern_normsq(a), o[pre + "normsq"], RTOL)
+        assert_close(ctx.bern_mul(a, b), o[pre + "mul"], RTOL)
+
+
+# ------------------------------------------------------------------------------------- GJK
+@pytest.mark.parametrize("grp", ["lit", "c3", "dense", "s3d"])
+def test_gjk_pairs_bit_exact(capi, golden_dir, grp):
+    g = _load(golden_dir, "gjk.npz")
+    ctx = capi.scratch_context()
+    pa, pb = g[grp + "_pair_a"], g[grp + "_pair_b"]
+    r = ctx.gjk_pairs(g[grp + "_pts"], g[grp + "_off"], pa, pb, md_cap=2000, trace_cap=64)
+    ok = g[grp + "_status"] == 0
+    assert (r["flag"][ok] == g[grp + "_flag"][ok]).all()
+    assert (r["status"][ok] == capi.ST_OK).all()
+    assert (r["status"][~ok] == capi.ST_MD_CAP).all()     # reference never returns on these
+    toff, tr = g[grp + "_trace_off"], g[grp + "_trace"]
+    for k in np.where(ok)[0]:
+        n = toff[k + 1] - toff[k]
+        assert r["n_support"][k] == n
+        assert (r["trace"][k, :n] == tr[toff[k]:toff[k + 1]]).all(), "support trace of pair %d" % k
+    sep = ok & (g[grp + "_flag"] == 1)
+    # closest points / distance: 1e-12 relative (the only non-bit-exact step is a**2 in
+    # weightedOriginToPlane, libm pow vs a*a, gjk.py:460)
+    for key in ("dist", "c1", "c2"):
+        got, ref = r[key][sep], g[grp + "_" + key][sep]
+        assert np.max(np.abs(got - ref) / np.maximum(1.0, np.abs(ref))) < 1e-12, key
+    assert np.isnan(r["dist"][ok & (g[grp + "_flag"] == 0)]).all()
+
+
+def test_gjk_swarm_batch_vs_oracle(capi, oracle, synth):
+    N, M = 64, 8
+    Y = synth.swarm_control_points(N, 2, 10, seed=1234)
+    polys = synth.polygon_obstacles(M, seed=1234)
+    ppts, poff = synth.pack_polys(polys)
+    pa, pb = synth.swarm_pairs(N, M)
+    B = 5
+    Yb = synth.fd_batch(Y, B=B)
+    Yb[3] += np.random.default_rng(1).normal(0, 3.0, size=Y.shape)   # a genuinely different row
+    ctx = capi.Context(N, 2, 10, 0)
+    ctx.set_polygons(ppts, poff)
+    ctx.set_hull_pairs(pa, pb)
+    r = ctx.gjk_swarm(Yb, md_cap=2000)
+    for b in range(B):
+        hp, ho = synth.pack_polys(synth.hulls_from_Y(Yb[b], 2) + polys)
+        o = oracle.gjk_pairs(hp, ho, pa, pb, md_cap=2000)
+        assert (r["flag"][b] == o["flag"]).all()
+        assert (r["n_support"][b] == o["n_support"]).all()
+        assert (r["status"][b] == o["status"]).all()
+        sep = o["flag"] == 1
+        for key in ("dist", "c1", "c2"):
+            assert np.max(np.abs(r[key][b][sep] - o[key][sep]) / np.maximum(1.0, np.abs(o[key][sep]))) < 1e-12
+    ctx.close()
+
+
+def test_gjk_swarm_3d(capi, oracle, synth):
+    N = 24
+    Y = synth.swarm_control_points(N, 3, 5, seed=9)
+    pa, pb = synth.swarm_pairs(N, 0)
+    ctx = capi.Context(N, 3, 5, 0)
+    ctx.set_polygons(None, [0])
+    ctx.set_hull_pairs(pa, pb)
+    r = ctx.gjk_swarm(Y, md_cap=500)
+    hp, ho = synth.pack_polys(synth.hulls_from_Y(Y, 3))
+    o = oracle.gjk_pairs(hp, ho, pa, pb, md_cap=500)
+    assert (r["flag"][0] == o["flag"]).all() and (r["n_support"][0] == o["n_support"]).all()
+    assert (r["status"][0] == o["status"]).all()
+    ctx.close()
+
+
+# --------------------------------------------------------------------------------- minDist
+def _pad3(c):
+    c = np.atleast_2d(np.asarray(c, dtype=float))
+    out = np.zeros((3, c.shape[1]))
+    out[:c.shape[0]] = c
+    return out
+
+
+def test_min_dist_golden(capi, oracle, golden_dir):
+    m = _load(golden_dir, "mindist.npz")
+    ctx = capi.scratch_context()
+    cur = m["lit_curves"]
+    pairs = m["lit_pairs"]
+    r = ctx.min_dist(cur, pairs[:, 0], pairs[:, 1], max_depth=64, max_nodes=300000)
+    for k in range(len(pairs)):
+        if m["lit_status"][k] == 0:
+            assert r["status"][k] == capi.MD_OK
+            assert r["gjk_calls"][k] == m["lit_calls"][k]
+            assert_close(r["res"][k], m["lit_res"][k], RTOL)
+        else:
+            assert r["status"][k] != capi.MD_OK
+    Y = m["c3_Y"]
+    curves = np.stack([_pad3(Y[2 * i:2 * i + 2]) for i in range(64)])
+    r = ctx.min_dist(curves, m["c3_pa"], m["c3_pb"], max_depth=64, max_nodes=300000)
+    n_ok = 0
+    for k in range(len(m["c3_pa"])):
+        o = oracle.min_dist(curves[m["c3_pa"][k]], curves[m["c3_pb"][k]], max_depth=64, max_nodes=300000)
+        assert r["status"][k] == o["status"]
+        if o["status"] == oracle.MD_OK:
+            assert r["gjk_calls"][k] == o["gjk_calls"] and r["depth"][k] == o["depth"]
+            assert_close(r["res"][k], o["res"], RTOL)
+        if m["c3_status"][k] == 0:
+            assert r["status"][k] == capi.MD_OK and r["gjk_calls"][k] == m["c3_calls"][k]
+            assert_close(r["res"][k], m["c3_res"][k], RTOL)
+            n_ok += 1
+    assert n_ok >= 30
+
+
+def test_min_dist2poly_golden(capi, golden_dir):
+    m = _load(golden_dir, "mindist.npz")
+    ctx = capi.scratch_context()
+    cur = m["lit_curves"]
+    polys = m["lit_polys"]
+    pts = polys.reshape(-1, 3)
+    off = np.array([0, 5, 10], np.int32)
+    pr = m["litp_pairs"]
+    r = ctx.min_dist2poly(cur, pts, off, pr[:, 0], pr[:, 1], max_depth=64, max_nodes=300000)
+    for k in range(len(pr)):
+        if m["litp_status"][k] == 0:
+            assert r["status"][k] == capi.MD_OK and r["gjk_calls"][k] == m["litp_calls"][k]
+            assert_close(r["res"][k][:2], m["litp_res"][k], RTOL)
+            assert_close(r["res"][k][2:], m["litp_pt"][k], RTOL)
+        else:
+            assert r["status"][k] != capi.MD_OK
+    Y = m["c3_Y"]
+    curves = np.stack([_pad3(Y[2 * i:2 * i + 2]) for i in range(64)])
+    pr = m["c3p_pairs"]
+    r = ctx.min_dist2poly(curves, m["c3p_pts"], m["c3p_off"], pr[:, 0], pr[:, 1], max_depth=64, max_nodes=300000)
+    for k in range(len(pr)):
+        if m["c3p_status"][k] == 0:
+            assert r["status"][k] == capi.MD_OK and r["gjk_calls"][k] == m["c3p_calls"][k]
+            assert_close(r["res"][k][:2], m["c3p_res"][k], RTOL)
+            assert_close(r["res"][k][2:], m["c3p_pt"][k], RTOL)
+        else:
+            assert r["status"][k] != capi.MD_OK
+
+
+# ------------------------------------------------------------- full-size properties (C3)
+def test_c3_full_batch_properties(capi, synth):
+    """BASELINE size (64 vehicles, degree 10, B = n_x + 1 = 1153 rows): size-independent checks.
+    (1) row 0 of the batch equals the single-row call bit for bit; (2) perturbing a control point
+    of vehicle v changes ONLY the N-1 pairs that involve v; (3) the squared separation is
+    translation invariant; (4) min over elevated control points is monotone in R."""
+    import torch
+    N, dim, n = 64, 2, 10
+    Y = synth.swarm_control_points(N, dim, n, seed=1234)
+    ctx = capi.Context(N, dim, n, 0)
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    B = N * dim * (n - 1) + 1
+    d0 = torch.from_numpy(Y).cuda()
+    dY = torch.empty((B,) + Y.shape, dtype=torch.float64, device="cuda")
+    ctx.fd_batch_dev(d0.data_ptr(), 1, 1e-3, B, dY.data_ptr())
+    P, L = ctx.num_pairs, 21
+    out = torch.empty((B, P, L), dtype=torch.float64, device="cuda")
+    ctx.temporal_sep_dev(dY.data_ptr(), B, 0.9, out.data_ptr())
+    torch.cuda.synchronize()
+    single = ctx.temporal_sep(Y, 0.9)[0].reshape(P, L)
+    assert np.array_equal(out[0].cpu().numpy(), single)
+    pa, pb = synth.swarm_pairs(N, 0)
+    changed = (out != out[0:1]).any(dim=2).cpu().numpy()          # [B][P]
+    for b in (1, 2, 577, B - 1):
+        veh = ((b - 1) // (n - 1)) // dim
+        involved = (pa == veh) | (pb == veh)
+        assert changed[b][~involved].sum() == 0
+        assert changed[b][involved].all()
+    shifted = ctx.temporal_sep(Y + 7.25, 0.9)[0].reshape(P, L)
+    assert_close(shifted, single, 1e-9)
+    ctx.set_stream(0)
+    mins = []
+    for R in (0, 5, 20):
+        ctx.set_deg_elev(R)
+        mins.append(ctx.temporal_sep_min(Y, 0.9)[0])
+    assert (mins[1] >= mins[0] - 1e-9).all() and (mins[2] >= mins[1] - 1e-9).all()
+    ctx.close()
