@@ -1,0 +1,235 @@
+#!/usr/bin/env python3
+"""Benchmark of the constraint-evaluation hot path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload C3] [--no-cpu]
+
+Metric (BASELINE.json): constraint-evals/s.  One "constraint-eval" = one evaluation, for
+one optimisation vector x, of every constraint family of the configuration: the temporal
+separation sweep over all vehicle pairs, max-speed, max-angular-rate, and one gjkNew per
+hull pair (vehicle<->vehicle and vehicle<->obstacle).  One "step" = one SLSQP iteration's
+worth of evaluations = the finite-difference batch B = n_x + 1 rows, all resident in HBM.
+
+Workload (config.workload): C3 = 64 vehicles, 2-D, degree 10, DEG_ELEV 0, 8 polygon
+obstacles (BASELINE.json configs[2], the configuration the north-star target is quoted
+on).  Multi-GPU: swarm instances shard over the ranks with no data-path collective (each
+rank evaluates the FD batch of its own seeded swarm) -> "weak" scaling.
+
+Output: ONE JSON line from rank 0 (contract in the task description) carrying also
+  roofline     -- for the kernel that dominates the step's device time: algorithmic bytes
+                  per launch / mean launch duration measured with HIP events on the
+                  launch stream inside the timed region, against the 8 TB/s HBM peak;
+  kernels      -- the same figures for every kernel of the step;
+  cpu_baseline -- the CPU oracle (oracle/, a C port of the reference path) timed on this
+                  box's host on a bounded sample of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="C3", choices=["C2", "C3", "C4", "C5"])
+    ap.add_argument("--batch", type=int, default=0, help="rows per step (default n_x + 1)")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--no-gjk", action="store_true", help="Bernstein sweeps only")
+    return ap.parse_args()
+
+
+def algorithmic_bytes(N, d, n, R, P_t, P_s, sumK):
+    """bytes one evaluation must move (inputs read once, outputs written once)."""
+    L = 2 * n + R + 1
+    by = {
+        "temporal_sep": 8 * N * d * (n + 1) + 8 * P_t * L,
+        "speed": 8 * N * d * (n + 1) + 8 * N * L,
+        "ang_rate": 8 * N * d * (n + 1) + 8 * N * (4 * (n + R) + 1),
+        "gjk": 24 * sumK + 64 * P_s,
+    }
+    # the survey's per-eval total counts the control points once
+    total = 8 * N * d * (n + 1) + 8 * (P_t * L + N * L + N * (4 * (n + R) + 1)) + 24 * sumK + 64 * P_s
+    return by, total
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        args.gpus = world
+
+    import torch
+    import torch.distributed as dist
+    from optimalbeziertrajectorygeneration_amd import _capi, synth
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    cfg = dict(synth.CONFIGS[args.workload])
+    N, d, n, R, M = cfg["N"], cfg["d"], cfg["n"], cfg["R"], cfg.get("n_poly", 0)
+    n_x = N * d * (n - 1)
+    B = args.batch or (n_x + 1)
+    seed = 1234 + 1000 * rank          # every rank its own swarm instance
+    Y = synth.swarm_control_points(N, d, n, seed=seed)
+    polys = synth.polygon_obstacles(M, seed=1234)
+    ppts, poff = synth.pack_polys(polys) if M else (None, [0])
+    pa, pb = synth.swarm_pairs(N, M)
+    use_gjk = (not args.no_gjk) and d >= 2
+    max_sep, vmax, wmax, tfv = 0.9, 5.0, 1.0, 10.0
+
+    ctx = _capi.Context(N, d, n, R, device=local_rank)
+    stream = torch.cuda.current_stream()
+    ctx.set_stream(stream.cuda_stream)
+    if use_gjk:
+        ctx.set_polygons(ppts, poff)
+        ctx.set_hull_pairs(pa, pb)
+    P_t, L = ctx.num_pairs, 2 * n + R + 1
+    P_s = len(pa) if use_gjk else 0
+
+    dev = torch.device("cuda", local_rank)
+    f64 = torch.float64
+    d0 = torch.from_numpy(Y).to(dev)
+    dY = torch.empty((B, N * d, n + 1), dtype=f64, device=dev)
+    ctx.fd_batch_dev(d0.data_ptr(), 1, synth.FD_STEP, B, dY.data_ptr())     # inputs resident in HBM
+    d_tf = torch.full((B,), tfv, dtype=f64, device=dev)
+    o_sep = torch.empty((B, P_t * L), dtype=f64, device=dev)
+    o_sp = torch.empty((B, N * L), dtype=f64, device=dev)
+    o_an = torch.empty((B, N * (4 * (n + R) + 1)), dtype=f64, device=dev) if d == 2 else None
+    if use_gjk:
+        g_flag = torch.empty((B, P_s), dtype=torch.int32, device=dev)
+        g_p1 = torch.empty((B, P_s, 3), dtype=f64, device=dev)
+        g_p2 = torch.empty((B, P_s, 3), dtype=f64, device=dev)
+        g_dist = torch.empty((B, P_s), dtype=f64, device=dev)
+
+    def step():
+        ctx.temporal_sep_dev(dY.data_ptr(), B, max_sep, o_sep.data_ptr())
+        ctx.speed_dev(dY.data_ptr(), d_tf.data_ptr(), B, vmax, True, o_sp.data_ptr())
+        if o_an is not None:
+            ctx.ang_rate_dev(dY.data_ptr(), d_tf.data_ptr(), B, wmax, o_an.data_ptr())
+        if use_gjk:
+            ctx.gjk_swarm_dev(dY.data_ptr(), B, g_flag.data_ptr(), g_p1.data_ptr(), g_p2.data_ptr(),
+                              g_dist.data_ptr(), None, None, 128, 4096)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    ctx.sync()
+    ctx.set_profiling(True)        # HIP events around every launch, on the launch stream
+    ctx.reset_kernel_stats()
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    barrier()
+    t1 = time.perf_counter()
+    elapsed = t1 - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=f64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    stats = ctx.kernel_stats()
+    ctx.set_profiling(False)
+
+    evals = world * B * args.steps
+    value = evals / elapsed
+    ms_per_step = 1e3 * elapsed / args.steps
+
+    sumK = N * (n + 1) + (int(poff[-1]) if M else 0)
+    by, total_bytes = algorithmic_bytes(N, d, n, R, P_t, P_s, sumK)
+    kernels = []
+    for name in ("temporal_sep", "speed", "ang_rate", "gjk"):
+        ms, cnt = stats.get(name, (0.0, 0))
+        if cnt == 0:
+            continue
+        avg_ms = ms / cnt
+        gbs = B * by[name] / (avg_ms * 1e-3) / 1e9
+        kernels.append(dict(kernel=name, launches=cnt, avg_ms=round(avg_ms, 5),
+                            alg_bytes_per_launch=B * by[name], achieved_gbs=round(gbs, 2),
+                            frac=round(gbs / HBM_PEAK_GBS, 5)))
+    dom = max(kernels, key=lambda k: k["avg_ms"])
+    traffic = None
+    tpath = os.path.join(REPO, "profiles", "traffic.json")   # PMC-derived HBM bytes per launch (see profiles/README.md)
+    if os.path.exists(tpath):
+        try:
+            traffic = json.load(open(tpath)).get(args.workload, {}).get(dom["kernel"])
+        except Exception:
+            traffic = None
+    roofline = dict(bound="hbm", kernel=dom["kernel"], achieved=dom["achieved_gbs"], peak=HBM_PEAK_GBS,
+                    unit="GB/s", frac=dom["frac"], traffic=traffic,
+                    step_achieved=round(B * total_bytes / (ms_per_step * 1e-3) / 1e9, 2))
+
+    cpu = None
+    if rank == 0 and not args.no_cpu and args.gpus == 1:
+        cpu = cpu_baseline(args, N, d, n, R, M, Y, polys, pa, pb, use_gjk, max_sep, vmax, wmax, tfv)
+
+    if rank == 0:
+        line = {
+            "metric": "constraint-evals/s (full swarm pairwise min-dist + dynamics) per SLSQP iter",
+            "value": round(value, 2), "unit": "constraint-evals/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "%s: %d vehicles, %d-D, degree %d, DEG_ELEV %d, %d polygon obstacles; "
+                                   "FD batch B=%d rows per GPU per step; families: temporal_sep(%d pairs)"
+                                   "+max_speed+%sgjkNew(%d hull pairs)" % (
+                                       args.workload, N, d, n, R, M, B, P_t,
+                                       "max_ang_rate+" if d == 2 else "", P_s),
+                       "evals_per_step_per_gpu": B, "alg_bytes_per_eval": total_bytes},
+            "roofline": roofline,
+            "kernels": kernels,
+            "cpu_baseline": cpu,
+        }
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(args, N, d, n, R, M, Y, polys, pa, pb, use_gjk, max_sep, vmax, wmax, tfv):
+    """The CPU oracle (C port of the reference path, single thread -- the reference is
+    single-threaded) on a bounded sample of the same FD batch."""
+    from oracle import oracle as O
+    from optimalbeziertrajectorygeneration_amd import synth
+    O.build()
+
+    def run(rows):
+        Yb = synth.fd_batch(Y, B=rows)
+        t0 = time.perf_counter()
+        O.eval_batch(Yb, tfv, N, d, R, max_sep, vmax, wmax, nthreads=1)
+        if use_gjk:
+            for b in range(rows):
+                hp, ho = synth.pack_polys(synth.hulls_from_Y(Yb[b], d) + polys)
+                O.gjk_pairs(hp, ho, pa, pb, nthreads=1)
+        return time.perf_counter() - t0
+
+    probe = run(8)
+    rows = int(max(16, min(20000, args.cpu_seconds / (probe / 8))))
+    dt = run(rows)
+    return {"value": round(rows / dt, 3), "unit": "constraint-evals/s", "cores": 1, "kind": "port",
+            "sample": "%d FD-batch rows of the same %s workload (all families), %.1f s, oracle/obtg_oracle.c -O2"
+                      % (rows, args.workload, dt)}
+
+
+if __name__ == "__main__":
+    main()
