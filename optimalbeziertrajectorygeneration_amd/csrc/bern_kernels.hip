@@ -43,6 +43,9 @@ struct NsParams {
     int item_begin, item_count;       // items of this launch (pairs or vehicles)
     int groups_per_wg, wgs_per_row;
     int stage_slots;                  // LDS slots reserved for staged objects
+    int stage_all;                    // 1: every object of the row is staged, slot == object id
+    int tile_rows;                    // rows of the per-wave transposition tile (64, 32 or 16)
+    int waves;                        // waves per workgroup
     double sign, offset;              // out = sign * value + offset
 };
 
@@ -62,11 +65,11 @@ struct NsShape {
 template <int NC, int DIM>
 __device__ __forceinline__ void stage_objects(double* __restrict__ vl, const double* __restrict__ Yrow,
                                               const double* __restrict__ obs, int n_veh, int lo,
-                                              int cnt, int slot0, int lane)
+                                              int cnt, int slot0, int tid, int nthreads)
 {
     using S = NsShape<NC, DIM>;
     const int total = cnt * S::VLEN;
-    for (int e = lane; e < total; e += kWave) {
+    for (int e = tid; e < total; e += nthreads) {
         const int v = e / S::VLEN, r = e - v * S::VLEN;
         const int obj = lo + v;
         double val;
@@ -131,46 +134,61 @@ __device__ __forceinline__ void flush_chunk(const double* __restrict__ tile, dou
     }
 }
 
+// LDS traffic between the lanes of ONE wave only needs wave-level ordering (a wave's DS
+// operations complete in issue order); a workgroup barrier here would also be unsafe because
+// the waves of a workgroup run different numbers of groups.
+__device__ __forceinline__ void wave_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 template <int NC, int DIM, int MODE /*0 = pairs, 1 = vehicles*/, bool MINONLY>
-__global__ __launch_bounds__(kWave) void k_normsq_elev(const NsParams p)
+__global__ __launch_bounds__(256) void k_normsq_elev(const NsParams p)
 {
     using S = NsShape<NC, DIM>;
     constexpr int N = S::N, L = S::L;
     extern __shared__ double lds[];
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6, n_waves = blockDim.x >> 6;
     const int b = blockIdx.x / p.wgs_per_row, w = blockIdx.x - b * p.wgs_per_row;
     const int chunk = kWave * p.groups_per_wg;
     const int it0 = p.item_begin + w * chunk;
     const int it_end = min(p.item_begin + p.item_count, it0 + chunk);
     if (it0 >= it_end) return;
 
-    const int tile_doubles = kWave * ((p.R == 0) ? S::TPF : S::TPC);
-    double* tile = lds;
-    double* vl = lds + (MINONLY ? 0 : tile_doubles);
+    // LDS: [staged objects: stage_slots * VP][per-wave transposition tiles]
+    double* vl = lds;
+    const int tile_pitch = (p.R == 0) ? S::TPF : S::TPC;
+    double* tile = lds + p.stage_slots * S::VP + wave * (p.tile_rows * tile_pitch);
 
     // ---- stage the objects this workgroup touches
     const double* Yrow = p.Y + (size_t)b * p.n_veh * S::VLEN;
-    // A chunk of lexicographic pairs touches rows i0..i0+nI-1 (segment I), the j-range of its
-    // first row (segment A) and the j-range of the later rows (segment B).
-    int i0, nI, a_lo = 0, nA = 0, b_lo = 0, nB = 0;
-    if (MODE == 0) {
+    // stage_all: slot == object id.  Otherwise a chunk of lexicographic pairs touches rows
+    // i0..i0+nI-1 (segment I), the j-range of its first row (segment A) and the j-range of the
+    // later rows (segment B).
+    int i0 = 0, nI = 0, a_lo = 0, nA = 0, b_lo = 0;
+    if (p.stage_all) {
+        stage_objects<NC, DIM>(vl, Yrow, p.obs, p.n_veh, 0, p.n_obj, 0, threadIdx.x, blockDim.x);
+    } else if (MODE == 0) {
         const int2 f = p.pairs[it0], l = p.pairs[it_end - 1];
         i0 = f.x; nI = l.x - f.x + 1;
         a_lo = f.y;
         nA = (nI == 1) ? (l.y - f.y + 1) : (p.n_obj - f.y);
         b_lo = i0 + 2;
-        nB = (nI == 1) ? 0 : max(0, ((nI >= 3) ? p.n_obj - 1 : l.y) - b_lo + 1);
-        stage_objects<NC, DIM>(vl, Yrow, p.obs, p.n_veh, i0, nI, 0, lane);
-        stage_objects<NC, DIM>(vl, Yrow, p.obs, p.n_veh, a_lo, nA, nI, lane);
-        stage_objects<NC, DIM>(vl, Yrow, p.obs, p.n_veh, b_lo, nB, nI + nA, lane);
+        const int nB = (nI == 1) ? 0 : max(0, ((nI >= 3) ? p.n_obj - 1 : l.y) - b_lo + 1);
+        stage_objects<NC, DIM>(vl, Yrow, p.obs, p.n_veh, i0, nI, 0, threadIdx.x, blockDim.x);
+        stage_objects<NC, DIM>(vl, Yrow, p.obs, p.n_veh, a_lo, nA, nI, threadIdx.x, blockDim.x);
+        stage_objects<NC, DIM>(vl, Yrow, p.obs, p.n_veh, b_lo, nB, nI + nA, threadIdx.x, blockDim.x);
     } else {
         i0 = it0; nI = it_end - it0;
-        stage_objects<NC, DIM>(vl, Yrow, p.obs, p.n_veh, i0, nI, 0, lane);
+        stage_objects<NC, DIM>(vl, Yrow, p.obs, p.n_veh, i0, nI, 0, threadIdx.x, blockDim.x);
     }
     __syncthreads();
 
     const int LR = L + p.R;
-    for (int g = 0; g < p.groups_per_wg; ++g) {
+    const int TR = p.tile_rows;
+    for (int g = wave; g < p.groups_per_wg; g += n_waves) {
         const int itg = it0 + g * kWave;
         if (itg >= it_end) break;
         const int n_valid = min(kWave, it_end - itg);
@@ -180,8 +198,10 @@ __global__ __launch_bounds__(kWave) void k_normsq_elev(const NsParams p)
         double a[DIM][NC];
         if (MODE == 0) {
             const int2 ij = p.pairs[item];
-            const double* vi = vl + (ij.x - i0) * S::VP;
-            const int sj = (ij.x == i0) ? nI + (ij.y - a_lo) : nI + nA + (ij.y - b_lo);
+            int si, sj;
+            if (p.stage_all) { si = ij.x; sj = ij.y; }
+            else { si = ij.x - i0; sj = (ij.x == i0) ? nI + (ij.y - a_lo) : nI + nA + (ij.y - b_lo); }
+            const double* vi = vl + si * S::VP;
             const double* vj = vl + sj * S::VP;
 #pragma unroll
             for (int q = 0; q < DIM; ++q)
@@ -189,7 +209,7 @@ __global__ __launch_bounds__(kWave) void k_normsq_elev(const NsParams p)
                 for (int c = 0; c < NC; ++c) a[q][c] = vi[q * NC + c] - vj[q * NC + c];
         } else {
             // Bezier.diff(): (n/T)(P_{i+1}-P_i), then elev(1) back to degree n (bezier.py:497-519)
-            const double* v = vl + (item - i0) * S::VP;
+            const double* v = vl + (p.stage_all ? item : item - i0) * S::VP;
             const double val = (double)N / p.tf[b];
 #pragma unroll
             for (int q = 0; q < DIM; ++q) {
@@ -216,11 +236,16 @@ __global__ __launch_bounds__(kWave) void k_normsq_elev(const NsParams p)
                 for (int k = 1; k < L; ++k) m = fmin(m, cf[k]);
                 if (lane < n_valid) p.out[row + lane] = p.sign * m + p.offset;
             } else {
+                // transpose TR rows at a time through the wave's tile
+                for (int r0 = 0; r0 < n_valid; r0 += TR) {
+                    if (lane >= r0 && lane < r0 + TR) {
 #pragma unroll
-                for (int k = 0; k < L; ++k) tile[lane * S::TPF + k] = p.sign * cf[k] + p.offset;
-                __syncthreads();
-                flush_full<L, S::TPF>(tile, p.out, row * L, n_valid, lane);
-                __syncthreads();
+                        for (int k = 0; k < L; ++k) tile[(lane - r0) * S::TPF + k] = p.sign * cf[k] + p.offset;
+                    }
+                    wave_sync();
+                    flush_full<L, S::TPF>(tile, p.out, (row + r0) * L, min(TR, n_valid - r0), lane);
+                    wave_sync();
+                }
             }
         } else {
             double m = INFINITY;
@@ -235,9 +260,9 @@ __global__ __launch_bounds__(kWave) void k_normsq_elev(const NsParams p)
                     else tile[lane * S::TPC + kk] = p.sign * s + p.offset;
                 }
                 if (!MINONLY) {
-                    __syncthreads();
+                    wave_sync();
                     flush_chunk<S::TPC>(tile, p.out, row * LR, LR, k0, kc, n_valid, lane);
-                    __syncthreads();
+                    wave_sync();
                 }
             }
             if (MINONLY && lane < n_valid) p.out[row + lane] = p.sign * m + p.offset;
@@ -637,17 +662,22 @@ __global__ __launch_bounds__(kWave) void k_rowsum(const double* __restrict__ in,
 //  launchers
 // =====================================================================================
 template <int NC, int DIM, int MODE, bool MINONLY>
-static size_t ns_lds_bytes(int R, int slots)
-{
-    using S = NsShape<NC, DIM>;
-    size_t tile = MINONLY ? 0 : (size_t)kWave * (R == 0 ? S::TPF : S::TPC);
-    return (tile + (size_t)slots * S::VP) * sizeof(double);
-}
-
-template <int NC, int DIM, int MODE, bool MINONLY>
 static int launch_ns_t(obtg_ctx* c, NsParams p, int B, int kernel_id)
 {
-    size_t lds = ns_lds_bytes<NC, DIM, MODE, MINONLY>(p.R, p.stage_slots);
+    using S = NsShape<NC, DIM>;
+    // the R > 0 path always transposes 64 rows x kTileK columns
+    const size_t budget = 36 * 1024;   // => four workgroups (16 waves) per CU when it can be met
+    const size_t stage = (size_t)p.stage_slots * S::VP * sizeof(double);
+    size_t lds = 0;
+    if (MINONLY) { p.tile_rows = 0; lds = stage; }
+    else if (p.R > 0) { p.tile_rows = kWave; lds = stage + (size_t)p.waves * kWave * S::TPC * sizeof(double); }
+    else {
+        for (int tr = kWave; tr >= 16; tr >>= 1) {
+            p.tile_rows = tr;
+            lds = stage + (size_t)p.waves * tr * S::TPF * sizeof(double);
+            if (lds <= budget) break;
+        }
+    }
     if (lds > 160 * 1024) return OBTG_ERR_UNSUPPORTED;
     auto kern = k_normsq_elev<NC, DIM, MODE, MINONLY>;
     if (lds > 48 * 1024)
@@ -655,7 +685,7 @@ static int launch_ns_t(obtg_ctx* c, NsParams p, int B, int kernel_id)
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     dim3 grid((unsigned)((size_t)B * p.wgs_per_row));
     ScopedKernelTimer t(c, kernel_id);
-    hipLaunchKernelGGL(kern, grid, dim3(kWave), lds, c->stream, p);
+    hipLaunchKernelGGL(kern, grid, dim3(kWave * p.waves), lds, c->stream, p);
     OBTG_HIP(c, hipGetLastError());
     return OBTG_OK;
 }
@@ -708,10 +738,13 @@ int launch_temporal_sep(obtg_ctx* c, const double* dY, int B, double max_sep, in
         p.pairs = c->d_pairs.as<int2>(); p.W2 = c->d_w2.as<double>(); p.Tt = c->d_Tt.as<double>();
         p.out = d_out; p.n_veh = c->n_veh; p.n_obj = c->n_obj; p.R = c->R;
         p.item_begin = pair_begin; p.item_count = pair_count;
-        // enough workgroups to fill 256 CUs several times over, but amortise the staging
+        // workgroup = 4 waves sharing one staging of the row's objects; each wave walks
+        // groups of 64 pairs.  Keep >= ~4k workgroups so that 256 CUs x 4 resident stay fed.
         int groups_total = (pair_count + kWave - 1) / kWave;
-        int gpw = 4;
-        while (gpw > 1 && (long)B * ((groups_total + gpw - 1) / gpw) < 4096) gpw >>= 1;
+        p.waves = groups_total >= 4 ? 4 : groups_total;
+        int gpw = 8;   // groups per workgroup
+        while (gpw > p.waves && (long)B * ((groups_total + gpw - 1) / gpw) < 4096) gpw >>= 1;
+        if (gpw < p.waves) gpw = p.waves;
         p.groups_per_wg = gpw;
         p.wgs_per_row = (groups_total + gpw - 1) / gpw;
         // LDS slots: replay the kernel's staging rule over this launch's chunks
@@ -726,7 +759,8 @@ int launch_temporal_sep(obtg_ctx* c, const double* dY, int B, double max_sep, in
             const int nB = (nI == 1) ? 0 : std::max(0, ((nI >= 3) ? c->n_obj - 1 : ly) - (fx + 2) + 1);
             slots = std::max(slots, nI + nA + nB);
         }
-        p.stage_slots = slots;
+        p.stage_all = c->n_obj <= slots ? 1 : 0;
+        p.stage_slots = p.stage_all ? c->n_obj : slots;
         p.sign = 1.0; p.offset = -(max_sep * max_sep);
         rc = min_only ? dispatch_ns<0, true>(c, p, B, OBTG_K_TEMPORAL_SEP)
                       : dispatch_ns<0, false>(c, p, B, OBTG_K_TEMPORAL_SEP);
@@ -761,8 +795,10 @@ int launch_speed(obtg_ctx* c, const double* dY, const double* d_tf, int B, doubl
         p.n_veh = c->n_veh; p.n_obj = c->n_veh; p.R = c->R;
         p.item_begin = 0; p.item_count = c->n_veh;
         p.groups_per_wg = 1;
+        p.waves = 1;
         p.wgs_per_row = (c->n_veh + kWave - 1) / kWave;
         p.stage_slots = std::min(c->n_veh, kWave);
+        p.stage_all = 0;
         p.sign = is_max ? -1.0 : 1.0; p.offset = is_max ? b2 : -b2;
         rc = dispatch_ns<1, false>(c, p, B, OBTG_K_SPEED);
         if (rc != OBTG_ERR_UNSUPPORTED) return rc;

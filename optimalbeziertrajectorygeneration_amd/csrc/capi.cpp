@@ -406,7 +406,7 @@ int obtg_gjk_pairs(obtg_ctx* c, const double* pts, int n_pts, const int* poly_of
                    int* n_support, int* status)
 {
     if (!check_ctx(c) || !pts || !pair_a || !pair_b || !flag || !p1 || !p2 || !dist) return OBTG_ERR_ARG;
-    if (n_pairs < 0 || max_iter < 0 || md_cap < 0 || trace_cap < 0) return OBTG_ERR_ARG;
+    if (n_pairs < 0 || max_iter < 1 || md_cap < 1 || trace_cap < 0) return OBTG_ERR_ARG;
     int rc = check_polys(poly_off, n_poly, n_pts);
     if (rc) return rc;
     for (int k = 0; k < n_pairs; ++k)
@@ -434,8 +434,11 @@ int obtg_gjk_pairs(obtg_ctx* c, const double* pts, int n_pts, const int* poly_of
     double* d_p1 = c->ws_out.as<double>();
     double* d_p2 = d_p1 + 3 * (size_t)n_pairs;
     double* d_dist = d_p2 + 3 * (size_t)n_pairs;
+    bool planar = true;
+    for (int k = 0; k < n_pts && planar; ++k) planar = pts[3 * (size_t)k + 2] == 0.0;
     rc = launch_gjk_pairs(c, c->ws_in.as<double>(), m[0].as<int>(), m[1].as<int>(), m[2].as<int>(), n_pairs,
-                          max_iter, md_cap, d_flag, d_p1, d_p2, d_dist, d_trace, trace_cap, d_nsup, d_status);
+                          max_iter, md_cap, d_flag, d_p1, d_p2, d_dist, d_trace, trace_cap, d_nsup, d_status,
+                          planar);
     if (rc) return rc;
     OBTG_HIP(c, hipMemcpyAsync(flag, d_flag, sizeof(int) * n_pairs, hipMemcpyDeviceToHost, c->stream));
     if (n_support) OBTG_HIP(c, hipMemcpyAsync(n_support, d_nsup, sizeof(int) * n_pairs, hipMemcpyDeviceToHost, c->stream));
@@ -454,7 +457,7 @@ int obtg_ctx_set_polygons(obtg_ctx* c, const double* pts, int n_pts, const int* 
     (void)hipSetDevice(c->device);
     OBTG_HIP(c, hipStreamSynchronize(c->stream));
     if (n_poly == 0) {
-        c->n_poly = 0; c->n_poly_pts = 0;
+        c->n_poly = 0; c->n_poly_pts = 0; c->polys_planar = true;
         int zero = 0;
         return upload(c, c->d_poly_off, &zero, sizeof(int));
     }
@@ -465,6 +468,8 @@ int obtg_ctx_set_polygons(obtg_ctx* c, const double* pts, int n_pts, const int* 
     if ((rc = upload(c, c->d_poly_pts, soa.data(), soa.size() * sizeof(double)))) return rc;
     if ((rc = upload(c, c->d_poly_off, poly_off, sizeof(int) * (n_poly + 1)))) return rc;
     c->n_poly = n_poly; c->n_poly_pts = n_pts;
+    c->polys_planar = true;
+    for (int k = 0; k < n_pts && c->polys_planar; ++k) c->polys_planar = pts[3 * (size_t)k + 2] == 0.0;
     c->n_hull_pairs = 0;   // object ids may have changed meaning
     return OBTG_OK;
 }
@@ -493,6 +498,7 @@ int obtg_gjk_swarm_dev(obtg_ctx* c, const double* dY, int B, int max_iter, int m
                        double* d_p1, double* d_p2, double* d_dist, int* d_nsup, int* d_status)
 {
     if (!check_ctx(c) || !dY || !d_flag || !d_p1 || !d_p2 || !d_dist || B < 0) return OBTG_ERR_ARG;
+    if (max_iter < 1 || md_cap < 1) return OBTG_ERR_ARG;
     if (c->dim < 2) return OBTG_ERR_ARG;   // bezier.py:847-851: curves must be 2-D or 3-D
     (void)hipSetDevice(c->device);
     return launch_gjk_swarm(c, dY, B, max_iter, md_cap, d_flag, d_p1, d_p2, d_dist, d_nsup, d_status);
@@ -502,6 +508,7 @@ int obtg_gjk_swarm(obtg_ctx* c, const double* Y, int B, int max_iter, int md_cap
                    double* p2, double* dist, int* nsup, int* status)
 {
     if (!check_ctx(c) || !Y || !flag || !p1 || !p2 || !dist || B < 0) return OBTG_ERR_ARG;
+    if (max_iter < 1 || md_cap < 1) return OBTG_ERR_ARG;
     if (c->dim < 2) return OBTG_ERR_ARG;
     const size_t n = (size_t)B * c->n_hull_pairs;
     if (n == 0) return OBTG_OK;

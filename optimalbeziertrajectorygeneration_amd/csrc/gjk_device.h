@@ -76,17 +76,22 @@ __device__ __forceinline__ V3 point(const Mem& mem, const Poly& P, int k)
     return r;
 }
 
-// gjk.py:87-114
-template <class Mem>
-__device__ __forceinline__ int support_idx(const Mem& mem, const Poly& P, const V3& d)
+// The support scan (gjk.py:87-114 `support` with `dot`, gjk.py:174-194): argmax of
+// p.x*d.x + p.y*d.y + p.z*d.z with strict '>' from index 0.
+//
+// PLANAR: every point of both sets has z == 0 (2-D curves padded as bezier.py:1294-1308 does).
+// Then p.z*d.z is +-0 and adding it never changes the value of the two-term sum that the
+// comparison sees (x + (+-0) == x for every x != 0, and +-0 compare equal), so the scan may
+// drop the z term and the z load without changing any index.  Search directions stay planar
+// too: the only out-of-plane direction, +-ABC (gjk.py:620-633), needs ABC.A0 != 0, which is
+// impossible when every z is 0.
+template <class Mem, bool PLANAR>
+__device__ __forceinline__ double sdot(const Mem& mem, const Poly& P, int i, const V3& d)
 {
-    int best = 0;
-    double maxd = dot3(point(mem, P, 0), d);
-    for (int i = 1; i < P.K; ++i) {
-        const double cur = dot3(point(mem, P, i), d);
-        if (cur > maxd) { maxd = cur; best = i; }
-    }
-    return best;
+    const double x = mem(P.base + i), y = mem(P.base + P.cs + i);
+    if (PLANAR) return x * d.x + y * d.y;
+    const double z = P.hasz ? mem(P.base + 2 * P.cs + i) : 0.0;
+    return x * d.x + y * d.y + z * d.z;
 }
 
 template <class Mem>
@@ -98,12 +103,30 @@ struct Ctx {
     int n_support;
 };
 
-// gjk.py:493-501
-template <class Mem>
+// gjk.py:493-501 supportPts: both scans share one loop so that their loads overlap
+template <class Mem, bool PLANAR = false>
 __device__ __forceinline__ void support_pts(Ctx<Mem>& g, const V3& dir, Vert& out)
 {
-    const int i1 = support_idx(g.mem, g.P1, dir);
-    const int i2 = support_idx(g.mem, g.P2, neg(dir));
+    const V3 nd = neg(dir);
+    int i1 = 0, i2 = 0;
+    double m1 = sdot<Mem, PLANAR>(g.mem, g.P1, 0, dir);
+    double m2 = sdot<Mem, PLANAR>(g.mem, g.P2, 0, nd);
+    const int K1 = g.P1.K, K2 = g.P2.K, Kmin = K1 < K2 ? K1 : K2;
+    int i = 1;
+    for (; i < Kmin; ++i) {
+        const double c1 = sdot<Mem, PLANAR>(g.mem, g.P1, i, dir);
+        const double c2 = sdot<Mem, PLANAR>(g.mem, g.P2, i, nd);
+        if (c1 > m1) { m1 = c1; i1 = i; }
+        if (c2 > m2) { m2 = c2; i2 = i; }
+    }
+    for (int j = i; j < K1; ++j) {
+        const double c1 = sdot<Mem, PLANAR>(g.mem, g.P1, j, dir);
+        if (c1 > m1) { m1 = c1; i1 = j; }
+    }
+    for (int j = i; j < K2; ++j) {
+        const double c2 = sdot<Mem, PLANAR>(g.mem, g.P2, j, nd);
+        if (c2 > m2) { m2 = c2; i2 = j; }
+    }
     out.i1 = i1; out.i2 = i2;
     out.v = sub(point(g.mem, g.P1, i1), point(g.mem, g.P2, i2));
     if (g.trace && g.n_support < g.trace_cap) {
@@ -128,9 +151,9 @@ __device__ __forceinline__ double origin_to_line(const V3& A, const V3& B, doubl
     return t;
 }
 
-// gjk.py:565-642
-template <class Mem>
-__device__ __forceinline__ void simplex3(Ctx<Mem>& g, Simplex& s, V3& dir)
+// gjk.py:565-642 simplex3pt WITHOUT its trailing supportPts (every branch ends in one, the
+// caller issues it once so that the scan is convergent code for the whole wave)
+__device__ __forceinline__ void simplex3_update(Simplex& s, V3& dir)
 {
     const V3 A0 = neg(s.A.v), AB = sub(s.B.v, s.A.v), AC = sub(s.C.v, s.A.v);
     const V3 ABC = cross(AB, AC);
@@ -168,21 +191,18 @@ __device__ __forceinline__ void simplex3(Ctx<Mem>& g, Simplex& s, V3& dir)
             s.keys |= kD | kDpts;
         }
     }
-    support_pts(g, dir, s.A);
-    s.keys |= kA;
 }
 
-// gjk.py:505-561, 646-681
-template <class Mem>
-__device__ __forceinline__ void do_simplex(Ctx<Mem>& g, Simplex& s, V3& dir)
+// gjk.py:505-561, 646-681 doSimplex minus the supportPts call; returns whether the case
+// fetches a new support vertex (everything except the 4-point collision exit does)
+__device__ __forceinline__ bool simplex_update(Simplex& s, V3& dir)
 {
     if (!(s.keys & kA)) {
-        support_pts(g, dir, s.A);
-        s.keys |= kA;
+        return true;
     } else if (!(s.keys & kB)) {
         s.B = s.A; s.keys |= kB;
         dir = neg(dir);
-        support_pts(g, dir, s.A);
+        return true;
     } else if (!(s.keys & kC)) {
         double dist;
         const double t = origin_to_line(s.A.v, s.B.v, dist);
@@ -190,25 +210,34 @@ __device__ __forceinline__ void do_simplex(Ctx<Mem>& g, Simplex& s, V3& dir)
         dir.y = -((1 - t) * s.A.v.y + t * s.B.v.y);
         dir.z = -((1 - t) * s.A.v.z + t * s.B.v.z);
         s.C = s.A; s.keys |= kC;
-        support_pts(g, dir, s.A);
+        return true;
     } else if (!(s.keys & kD)) {
-        simplex3(g, s, dir);
+        simplex3_update(s, dir);
+        return true;
+    }
+    const V3 A0 = neg(s.A.v), AB = sub(s.B.v, s.A.v), AC = sub(s.C.v, s.A.v), AD = sub(s.D.v, s.A.v);
+    const V3 ABC = cross(AB, AC), ACD = cross(AC, AD), ADB = cross(AD, AB);
+    if (dotb(ABC, A0) > 0) {
+        s.keys &= ~kD;                       // pop('D') only; 'Dpts' stays (gjk.py:660)
+    } else if (dotb(ACD, A0) > 0) {
+        s.B = s.C; s.C = s.D; s.keys &= ~(kD | kDpts);
+    } else if (dotb(ADB, A0) > 0) {
+        s.C = s.B; s.B = s.D; s.keys &= ~(kD | kDpts);
     } else {
-        const V3 A0 = neg(s.A.v), AB = sub(s.B.v, s.A.v), AC = sub(s.C.v, s.A.v), AD = sub(s.D.v, s.A.v);
-        const V3 ABC = cross(AB, AC), ACD = cross(AC, AD), ADB = cross(AD, AB);
-        if (dotb(ABC, A0) > 0) {
-            s.keys &= ~kD;                       // pop('D') only; 'Dpts' stays (gjk.py:660)
-            simplex3(g, s, dir);
-        } else if (dotb(ACD, A0) > 0) {
-            s.B = s.C; s.C = s.D; s.keys &= ~(kD | kDpts);
-            simplex3(g, s, dir);
-        } else if (dotb(ADB, A0) > 0) {
-            s.C = s.B; s.B = s.D; s.keys &= ~(kD | kDpts);
-            simplex3(g, s, dir);
-        } else {
-            s.keys |= kColl;
-            dir = V3{ 0.0, 0.0, 0.0 };
-        }
+        s.keys |= kColl;
+        dir = V3{ 0.0, 0.0, 0.0 };
+        return false;
+    }
+    simplex3_update(s, dir);
+    return true;
+}
+
+template <class Mem, bool PLANAR = false>
+__device__ __forceinline__ void do_simplex(Ctx<Mem>& g, Simplex& s, V3& dir)
+{
+    if (simplex_update(s, dir)) {
+        support_pts<Mem, PLANAR>(g, dir, s.A);
+        s.keys |= kA;
     }
 }
 
@@ -248,8 +277,12 @@ __device__ __forceinline__ void seg_result(const Ctx<Mem>& g, const Vert& A, con
     r.c2 = V3{ (1 - t) * a2.x + t * o2.x, (1 - t) * a2.y + t * o2.y, (1 - t) * a2.z + t * o2.z };
 }
 
-// gjk.py:230-270 gjkNew + 273-360 minimumDistance
+// gjk.py:299-360: closest points / distance from the converged (restored) simplex
 template <class Mem>
+__device__ __forceinline__ void closest_from_simplex(const Ctx<Mem>& g, const Simplex& s, Result& r);
+
+// gjk.py:230-270 gjkNew + 273-360 minimumDistance
+template <class Mem, bool PLANAR = false>
 __device__ __forceinline__ void run(Ctx<Mem>& g, int max_iter, int md_cap, Result& r)
 {
     Simplex s;
@@ -261,63 +294,208 @@ __device__ __forceinline__ void run(Ctx<Mem>& g, int max_iter, int md_cap, Resul
     r.flag = -1; r.status = OBTG_ST_MAXITER;
     r.c1 = V3{ qnan, qnan, qnan }; r.c2 = r.c1; r.dist = qnan;
     for (int it = 0; it < max_iter; ++it) {
-        do_simplex(g, s, dir);
+        do_simplex<Mem, PLANAR>(g, s, dir);
         if (s.keys & kColl) { r.flag = 0; r.status = OBTG_ST_OK; break; }
         if (dotb(s.A.v, dir) < 0) {
             Simplex old = s;
             bool conv = false;
             for (int rr = 0; rr < md_cap; ++rr) {
                 old = s;
-                do_simplex(g, s, dir);
+                do_simplex<Mem, PLANAR>(g, s, dir);
                 if (matches_old(g, old, s.A.v)) { conv = true; break; }
             }
             r.flag = 1;
             if (!conv) { r.status = OBTG_ST_MD_CAP; break; }
             r.status = OBTG_ST_OK;
-            s = old;
-            if (s.keys & kC) {
-                const V3 A0 = neg(s.A.v), AB = sub(s.B.v, s.A.v), AC = sub(s.C.v, s.A.v);
-                const V3 ABC = cross(AB, AC);
-                if (dotb(cross(ABC, AC), A0) >= 0) {
-                    seg_result(g, s.A, s.C, r);
-                } else if (dotb(cross(AB, ABC), A0) >= 0) {
-                    seg_result(g, s.A, s.B, r);
-                } else {
-                    // gjk.py:440-477 weightedOriginToPlane (a**2 taken as a*a: the reference's
-                    // libm pow(a, 2.0) can differ from it by one ulp of the denominator)
-                    const V3 N = cross(sub(s.B.v, s.A.v), sub(s.C.v, s.A.v));
-                    const double nn = normb(N);
-                    const V3 n{ N.x / nn, N.y / nn, N.z / nn };
-                    const double tq = (n.x * s.A.v.x + n.y * s.A.v.y + n.z * s.A.v.z) /
-                                      (n.x * n.x + n.y * n.y + n.z * n.z);
-                    const V3 cp{ tq * n.x, tq * n.y, tq * n.z };
-                    r.dist = __builtin_sqrt(dot3(cp, cp));
-                    const V3 PA = sub(s.A.v, cp), PB = sub(s.B.v, cp), PC = sub(s.C.v, cp);
-                    const double al = normb(cross(PB, PC)) / nn;
-                    const double be = normb(cross(PC, PA)) / nn;
-                    const double ga = 1 - al - be;
-                    const V3 a1 = point(g.mem, g.P1, s.A.i1), b1 = point(g.mem, g.P1, s.B.i1),
-                             c1 = point(g.mem, g.P1, s.C.i1);
-                    const V3 a2 = point(g.mem, g.P2, s.A.i2), b2 = point(g.mem, g.P2, s.B.i2),
-                             c2 = point(g.mem, g.P2, s.C.i2);
-                    r.c1.x = (al * (s.A.v.x + a2.x) + be * (s.B.v.x + b2.x)) + ga * (s.C.v.x + c2.x);
-                    r.c1.y = (al * (s.A.v.y + a2.y) + be * (s.B.v.y + b2.y)) + ga * (s.C.v.y + c2.y);
-                    r.c1.z = (al * (s.A.v.z + a2.z) + be * (s.B.v.z + b2.z)) + ga * (s.C.v.z + c2.z);
-                    r.c2.x = (al * (a1.x - s.A.v.x) + be * (b1.x - s.B.v.x)) + ga * (c1.x - s.C.v.x);
-                    r.c2.y = (al * (a1.y - s.A.v.y) + be * (b1.y - s.B.v.y)) + ga * (c1.y - s.C.v.y);
-                    r.c2.z = (al * (a1.z - s.A.v.z) + be * (b1.z - s.B.v.z)) + ga * (c1.z - s.C.v.z);
-                }
-            } else if (s.keys & kB) {
-                seg_result(g, s.A, s.B, r);
-            } else {
-                r.dist = normb(s.A.v);
-                r.c1 = point(g.mem, g.P1, s.A.i1);
-                r.c2 = point(g.mem, g.P2, s.A.i2);
-            }
+            closest_from_simplex(g, old, r);
             break;
         }
     }
     r.n_support = g.n_support;
+}
+
+template <class Mem>
+__device__ __forceinline__ void closest_from_simplex(const Ctx<Mem>& g, const Simplex& s, Result& r)
+{
+    if (s.keys & kC) {
+        const V3 A0 = neg(s.A.v), AB = sub(s.B.v, s.A.v), AC = sub(s.C.v, s.A.v);
+        const V3 ABC = cross(AB, AC);
+        if (dotb(cross(ABC, AC), A0) >= 0) {
+            seg_result(g, s.A, s.C, r);
+        } else if (dotb(cross(AB, ABC), A0) >= 0) {
+            seg_result(g, s.A, s.B, r);
+        } else {
+            // gjk.py:440-477 weightedOriginToPlane (a**2 taken as a*a: the reference's
+            // libm pow(a, 2.0) can differ from it by one ulp of the denominator)
+            const V3 N = cross(sub(s.B.v, s.A.v), sub(s.C.v, s.A.v));
+            const double nn = normb(N);
+            const V3 n{ N.x / nn, N.y / nn, N.z / nn };
+            const double tq = (n.x * s.A.v.x + n.y * s.A.v.y + n.z * s.A.v.z) /
+                              (n.x * n.x + n.y * n.y + n.z * n.z);
+            const V3 cp{ tq * n.x, tq * n.y, tq * n.z };
+            r.dist = __builtin_sqrt(dot3(cp, cp));
+            const V3 PA = sub(s.A.v, cp), PB = sub(s.B.v, cp), PC = sub(s.C.v, cp);
+            const double al = normb(cross(PB, PC)) / nn;
+            const double be = normb(cross(PC, PA)) / nn;
+            const double ga = 1 - al - be;
+            const V3 a1 = point(g.mem, g.P1, s.A.i1), b1 = point(g.mem, g.P1, s.B.i1),
+                     c1 = point(g.mem, g.P1, s.C.i1);
+            const V3 a2 = point(g.mem, g.P2, s.A.i2), b2 = point(g.mem, g.P2, s.B.i2),
+                     c2 = point(g.mem, g.P2, s.C.i2);
+            r.c1.x = (al * (s.A.v.x + a2.x) + be * (s.B.v.x + b2.x)) + ga * (s.C.v.x + c2.x);
+            r.c1.y = (al * (s.A.v.y + a2.y) + be * (s.B.v.y + b2.y)) + ga * (s.C.v.y + c2.y);
+            r.c1.z = (al * (s.A.v.z + a2.z) + be * (s.B.v.z + b2.z)) + ga * (s.C.v.z + c2.z);
+            r.c2.x = (al * (a1.x - s.A.v.x) + be * (b1.x - s.B.v.x)) + ga * (c1.x - s.C.v.x);
+            r.c2.y = (al * (a1.y - s.A.v.y) + be * (b1.y - s.B.v.y)) + ga * (c1.y - s.C.v.y);
+            r.c2.z = (al * (a1.z - s.A.v.z) + be * (b1.z - s.B.v.z)) + ga * (c1.z - s.C.v.z);
+        }
+    } else if (s.keys & kB) {
+        seg_result(g, s.A, s.B, r);
+    } else {
+        r.dist = normb(s.A.v);
+        r.c1 = point(g.mem, g.P1, s.A.i1);
+        r.c2 = point(g.mem, g.P2, s.A.i2);
+    }
+}
+
+
+// =====================================================================================
+//  Planar state machine.  When every point of both sets has z == 0 the 3-D arithmetic of
+//  gjk.py degenerates: every cross product is either (+-0, +-0, w) or lies in the plane, the
+//  z terms of every dot product are +-0, and ABC.A0 is always 0, so the tetrahedron cases are
+//  unreachable and "on the ABC plane" (gjk.py:616-618) is the only exit of the third branch.
+//  The formulas below are the surviving non-zero terms of the reference's expressions, in the
+//  reference's operation order: results are identical up to the sign of exact zeros, which no
+//  comparison observes.
+//    cz(a,b)            = a.x*b.y - a.y*b.x              (z of np.cross)
+//    cross((0,0,w), v)  = (-(w*v.y),  w*v.x)
+//    cross(v, (0,0,w))  = (  v.y*w , -(v.x*w))
+//    dotb(a,b)          = fma(a.y,b.y, a.x*b.x);   dot(a,b) = a.x*b.x + a.y*b.y
+// =====================================================================================
+struct V2 { double x, y; };
+struct Vert2 { V2 v; int i1, i2; };
+struct Simplex2 { Vert2 A, B, C; int keys; };
+
+__device__ __forceinline__ double cz(const V2& a, const V2& b) { return a.x * b.y - a.y * b.x; }
+__device__ __forceinline__ double dotb2(const V2& a, const V2& b) { return __builtin_fma(a.y, b.y, a.x * b.x); }
+__device__ __forceinline__ double dot2(const V2& a, const V2& b) { return a.x * b.x + a.y * b.y; }
+__device__ __forceinline__ V2 sub2(const V2& a, const V2& b) { return V2{ a.x - b.x, a.y - b.y }; }
+__device__ __forceinline__ V2 neg2(const V2& a) { return V2{ -a.x, -a.y }; }
+__device__ __forceinline__ bool eq2(const V2& a, const V2& b) { return a.x == b.x && a.y == b.y; }
+
+template <class Mem>
+__device__ __forceinline__ V2 point2(const Mem& mem, const Poly& P, int k)
+{
+    return V2{ mem(P.base + k), mem(P.base + P.cs + k) };
+}
+
+template <class Mem>
+__device__ __forceinline__ void support_pts2(Ctx<Mem>& g, const V2& dir, Vert2& out)
+{
+    const V3 d{ dir.x, dir.y, 0.0 };
+    const V3 nd{ -dir.x, -dir.y, 0.0 };
+    int i1 = 0, i2 = 0;
+    double m1 = sdot<Mem, true>(g.mem, g.P1, 0, d);
+    double m2 = sdot<Mem, true>(g.mem, g.P2, 0, nd);
+    const int K1 = g.P1.K, K2 = g.P2.K, Kmin = K1 < K2 ? K1 : K2;
+    int i = 1;
+    for (; i < Kmin; ++i) {
+        const double c1 = sdot<Mem, true>(g.mem, g.P1, i, d);
+        const double c2 = sdot<Mem, true>(g.mem, g.P2, i, nd);
+        if (c1 > m1) { m1 = c1; i1 = i; }
+        if (c2 > m2) { m2 = c2; i2 = i; }
+    }
+    for (int j = i; j < K1; ++j) {
+        const double c1 = sdot<Mem, true>(g.mem, g.P1, j, d);
+        if (c1 > m1) { m1 = c1; i1 = j; }
+    }
+    for (int j = i; j < K2; ++j) {
+        const double c2 = sdot<Mem, true>(g.mem, g.P2, j, nd);
+        if (c2 > m2) { m2 = c2; i2 = j; }
+    }
+    out.i1 = i1; out.i2 = i2;
+    out.v = sub2(point2(g.mem, g.P1, i1), point2(g.mem, g.P2, i2));
+    if (g.trace && g.n_support < g.trace_cap) {
+        g.trace[2 * g.n_support] = (short)i1;
+        g.trace[2 * g.n_support + 1] = (short)i2;
+    }
+    g.n_support++;
+}
+
+// doSimplex (gjk.py:505-642) for planar inputs, without the trailing supportPts.
+// Every case fetches a support afterwards (the 4-point case cannot occur).
+__device__ __forceinline__ void simplex_update2(Simplex2& s, V2& dir)
+{
+    if (!(s.keys & kA)) {
+        // 0pt: keep direction
+    } else if (!(s.keys & kB)) {
+        s.B = s.A; s.keys |= kB;
+        dir = neg2(dir);
+    } else if (!(s.keys & kC)) {
+        // weightedOriginToLine (gjk.py:397-437)
+        double t = 0.0;
+        if (!eq2(s.A.v, s.B.v)) {
+            const V2 v = sub2(s.B.v, s.A.v);
+            t = -dot2(v, s.A.v) / dot2(v, v);
+            if (t > 1) t = 1; else if (t < 0) t = 0;
+        }
+        dir.x = -((1 - t) * s.A.v.x + t * s.B.v.x);
+        dir.y = -((1 - t) * s.A.v.y + t * s.B.v.y);
+        s.C = s.A; s.keys |= kC;
+    } else {
+        const V2 A0 = neg2(s.A.v), AB = sub2(s.B.v, s.A.v), AC = sub2(s.C.v, s.A.v);
+        const double w = cz(AB, AC);                                   // ABC = (0, 0, w)
+        const V2 t1{ -(w * AC.y), w * AC.x };                          // ABC x AC
+        const V2 t2{ AB.y * w, -(AB.x * w) };                          // AB x ABC
+        const double uab = cz(AB, A0);
+        const V2 dAB{ -(uab * AB.y), uab * AB.x };                     // (AB x A0) x AB
+        const bool ab_pos = dotb2(AB, A0) > 0;
+        if (dotb2(t1, A0) > 0) {
+            if (dotb2(AC, A0) > 0) {
+                const double u = cz(AC, A0);
+                dir = V2{ -(u * AC.y), u * AC.x };                     // (AC x A0) x AC
+                s.B = s.A;
+            } else if (ab_pos) {
+                dir = dAB; s.C = s.A;
+            } else {
+                dir = s.A.v; s.keys = 0;                               // +A (gjk.py:595)
+            }
+        } else if (dotb2(t2, A0) > 0) {
+            if (ab_pos) { dir = dAB; s.C = s.A; }
+            else { dir = neg2(s.A.v); s.keys = 0; }
+        } else {
+            s.keys |= kColl;                                           // ABC.A0 == 0 always
+            dir = V2{ 0.0, 0.0 };
+        }
+    }
+}
+
+template <class Mem>
+__device__ __forceinline__ bool vert_matches2(const Ctx<Mem>& g, const Vert2& o, bool has, const V2& A)
+{
+    if (!has) return false;
+    if (eq2(A, o.v)) return true;
+    return eq2(A, point2(g.mem, g.P1, o.i1)) && eq2(A, point2(g.mem, g.P2, o.i2));
+}
+
+template <class Mem>
+__device__ __forceinline__ bool matches_old2(const Ctx<Mem>& g, const Simplex2& o, const V2& A)
+{
+    if (vert_matches2(g, o.A, o.keys & kA, A)) return true;
+    if (vert_matches2(g, o.B, o.keys & kB, A)) return true;
+    if (vert_matches2(g, o.C, o.keys & kC, A)) return true;
+    return false;   // a 'collision': True value would need A == (1,1,1): impossible with z == 0
+}
+
+__device__ __forceinline__ Simplex lift(const Simplex2& s)
+{
+    Simplex r;
+    r.A = Vert{ V3{ s.A.v.x, s.A.v.y, 0.0 }, s.A.i1, s.A.i2 };
+    r.B = Vert{ V3{ s.B.v.x, s.B.v.y, 0.0 }, s.B.i1, s.B.i2 };
+    r.C = Vert{ V3{ s.C.v.x, s.C.v.y, 0.0 }, s.C.i1, s.C.i2 };
+    r.D = r.A;
+    r.keys = s.keys;
+    return r;
 }
 
 }  // namespace gjk

@@ -28,6 +28,148 @@ using gjk::Result;
 using gjk::V3;
 
 // -------------------------------------------------------------------------------------
+//  The sweep loop.  Every iteration performs ONE doSimplex step for every lane that holds a
+//  pair: a short divergent simplex update, then the support scan as convergent code.  A lane
+//  whose pair finishes (collision, converged minimumDistance, cap) emits its result and pulls
+//  the next pair of the workgroup's chunk from an LDS counter, so lanes stay busy although
+//  gjkNew's trip count varies from 3 to 26 support scans per pair.
+// -------------------------------------------------------------------------------------
+template <class Mem, bool PLANAR, class Setup, class Emit>
+__device__ __forceinline__ void gjk_sweep(int c_end, int* s_next, int max_iter, int md_cap, Setup setup, Emit emit)
+{
+    const int lane = threadIdx.x & (kWave - 1);
+    int k = -1;
+    bool exhausted = false;
+    Ctx<Mem> g;
+    gjk::Simplex s, old;
+    V3 dir{ 1.0, 0.0, 0.0 };
+    int phase = 0, it = 0, rr = 0;
+    s.keys = 0;
+    s.A = gjk::Vert{ V3{ 0, 0, 0 }, 0, 0 };
+    s.B = s.A; s.C = s.A; s.D = s.A; old = s;
+    const double qnan = __builtin_nan("");
+    for (;;) {
+        const unsigned long long want = __ballot(k < 0 && !exhausted);
+        if (want) {
+            const int leader = __ffsll((long long)want) - 1;
+            int base = 0;
+            if (lane == leader) base = atomicAdd(s_next, __popcll(want));
+            base = __shfl(base, leader);
+            if (k < 0 && !exhausted) {
+                const int my = base + __popcll(want & ((1ull << lane) - 1ull));
+                if (my < c_end) {
+                    k = my;
+                    setup(k, g);
+                    g.n_support = 0;
+                    s.keys = 0; dir = V3{ 1.0, 0.0, 0.0 };
+                    phase = 0; it = 0; rr = 0;
+                } else exhausted = true;
+            }
+        }
+        if (__ballot(k >= 0) == 0ull) break;
+        if (k >= 0) {
+            if (phase == 1) old = s;
+            if (gjk::simplex_update(s, dir)) {
+                gjk::support_pts<Mem, PLANAR>(g, dir, s.A);
+                s.keys |= gjk::kA;
+            }
+            bool done = false;
+            Result r;
+            r.c1 = V3{ qnan, qnan, qnan }; r.c2 = r.c1; r.dist = qnan;
+            r.flag = -1; r.status = OBTG_ST_OK;
+            if (phase == 0) {
+                ++it;
+                if (s.keys & gjk::kColl) { r.flag = 0; done = true; }
+                else if (gjk::dotb(s.A.v, dir) < 0) { phase = 1; rr = 0; }
+                else if (it >= max_iter) { r.flag = -1; r.status = OBTG_ST_MAXITER; done = true; }
+            } else {
+                ++rr;
+                if (gjk::matches_old(g, old, s.A.v)) {
+                    gjk::closest_from_simplex(g, old, r);
+                    r.flag = 1; done = true;
+                } else if (rr >= md_cap) { r.flag = 1; r.status = OBTG_ST_MD_CAP; done = true; }
+            }
+            if (done) {
+                r.n_support = g.n_support;
+                emit(k, r);
+                k = -1;
+            }
+        }
+    }
+}
+
+// planar inputs: the same loop on the 2-D state machine of gjk_device.h
+template <class Mem, class Setup, class Emit>
+__device__ __forceinline__ void gjk_sweep_planar(int c_end, int* s_next, int max_iter, int md_cap, Setup setup, Emit emit)
+{
+    const int lane = threadIdx.x & (kWave - 1);
+    int k = -1;
+    bool exhausted = false;
+    Ctx<Mem> g;
+    gjk::Simplex2 s, old;
+    gjk::V2 dir{ 1.0, 0.0 };
+    int phase = 0, it = 0, rr = 0;
+    s.keys = 0;
+    s.A = gjk::Vert2{ gjk::V2{ 0, 0 }, 0, 0 };
+    s.B = s.A; s.C = s.A; old = s;
+    const double qnan = __builtin_nan("");
+    for (;;) {
+        const unsigned long long want = __ballot(k < 0 && !exhausted);
+        if (want) {
+            const int leader = __ffsll((long long)want) - 1;
+            int base = 0;
+            if (lane == leader) base = atomicAdd(s_next, __popcll(want));
+            base = __shfl(base, leader);
+            if (k < 0 && !exhausted) {
+                const int my = base + __popcll(want & ((1ull << lane) - 1ull));
+                if (my < c_end) {
+                    k = my;
+                    setup(k, g);
+                    g.n_support = 0;
+                    s.keys = 0; dir = gjk::V2{ 1.0, 0.0 };
+                    phase = 0; it = 0; rr = 0;
+                } else exhausted = true;
+            }
+        }
+        if (__ballot(k >= 0) == 0ull) break;
+        if (k >= 0) {
+            if (phase == 1) old = s;
+            gjk::simplex_update2(s, dir);
+            gjk::support_pts2(g, dir, s.A);
+            s.keys |= gjk::kA;
+            bool done = false;
+            Result r;
+            r.c1 = V3{ qnan, qnan, qnan }; r.c2 = r.c1; r.dist = qnan;
+            r.flag = -1; r.status = OBTG_ST_OK;
+            if (phase == 0) {
+                ++it;
+                if (s.keys & gjk::kColl) { r.flag = 0; done = true; }
+                else if (gjk::dotb2(s.A.v, dir) < 0) { phase = 1; rr = 0; }
+                else if (it >= max_iter) { r.flag = -1; r.status = OBTG_ST_MAXITER; done = true; }
+            } else {
+                ++rr;
+                if (gjk::matches_old2(g, old, s.A.v)) {
+                    gjk::closest_from_simplex(g, gjk::lift(old), r);
+                    r.flag = 1; done = true;
+                } else if (rr >= md_cap) { r.flag = 1; r.status = OBTG_ST_MD_CAP; done = true; }
+            }
+            if (done) {
+                r.n_support = g.n_support;
+                emit(k, r);
+                k = -1;
+            }
+        }
+    }
+}
+
+template <class Mem, bool PLANAR, class Setup, class Emit>
+__device__ __forceinline__ void gjk_sweep_any(int c_end, int* s_next, int max_iter, int md_cap, Setup setup, Emit emit)
+{
+    if (PLANAR) gjk_sweep_planar<Mem>(c_end, s_next, max_iter, md_cap, setup, emit);
+    else gjk_sweep<Mem, false>(c_end, s_next, max_iter, md_cap, setup, emit);
+}
+
+// -------------------------------------------------------------------------------------
 //  generic pair list on global SoA point sets:  poly a = x[K] y[K] z[K] at soa + 3*off[a]
 // -------------------------------------------------------------------------------------
 struct GjkPairsParams {
@@ -35,7 +177,7 @@ struct GjkPairsParams {
     const int* __restrict__ off;
     const int* __restrict__ pa;
     const int* __restrict__ pb;
-    int n_pairs, max_iter, md_cap;
+    int n_pairs, max_iter, md_cap, chunk;
     int* __restrict__ flag;
     double* __restrict__ p1;
     double* __restrict__ p2;
@@ -46,28 +188,33 @@ struct GjkPairsParams {
     int* status;
 };
 
+template <bool PLANAR>
 __global__ __launch_bounds__(256) void k_gjk_pairs(const GjkPairsParams p)
 {
-    const int k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= p.n_pairs) return;
-    const int a = p.pa[k], b = p.pb[k];
-    Ctx<MemGlobal> g;
-    g.mem = MemGlobal{ p.soa };
-    const int oa = p.off[a], ob = p.off[b];
-    const int Ka = p.off[a + 1] - oa, Kb = p.off[b + 1] - ob;
-    g.P1 = Poly{ 3 * oa, Ka, Ka, 1 };
-    g.P2 = Poly{ 3 * ob, Kb, Kb, 1 };
-    g.trace = p.trace ? p.trace + (size_t)k * p.trace_cap * 2 : nullptr;
-    g.trace_cap = p.trace_cap;
-    g.n_support = 0;
-    Result r;
-    gjk::run(g, p.max_iter, p.md_cap, r);
-    p.flag[k] = r.flag;
-    p.p1[3 * k] = r.c1.x; p.p1[3 * k + 1] = r.c1.y; p.p1[3 * k + 2] = r.c1.z;
-    p.p2[3 * k] = r.c2.x; p.p2[3 * k + 1] = r.c2.y; p.p2[3 * k + 2] = r.c2.z;
-    p.dist[k] = r.dist;
-    if (p.nsup) p.nsup[k] = r.n_support;
-    if (p.status) p.status[k] = r.status;
+    __shared__ int s_next;
+    const int c0 = blockIdx.x * p.chunk, c1 = min(p.n_pairs, c0 + p.chunk);
+    if (threadIdx.x == 0) s_next = c0;
+    __syncthreads();
+    gjk_sweep_any<MemGlobal, PLANAR>(
+        c1, &s_next, p.max_iter, p.md_cap,
+        [&](int k, Ctx<MemGlobal>& g) {
+            const int a = p.pa[k], b = p.pb[k];
+            g.mem = MemGlobal{ p.soa };
+            const int oa = p.off[a], ob = p.off[b];
+            const int Ka = p.off[a + 1] - oa, Kb = p.off[b + 1] - ob;
+            g.P1 = Poly{ 3 * oa, Ka, Ka, 1 };
+            g.P2 = Poly{ 3 * ob, Kb, Kb, 1 };
+            g.trace = p.trace ? p.trace + (size_t)k * p.trace_cap * 2 : nullptr;
+            g.trace_cap = p.trace_cap;
+        },
+        [&](int k, const Result& r) {
+            p.flag[k] = r.flag;
+            p.p1[3 * k] = r.c1.x; p.p1[3 * k + 1] = r.c1.y; p.p1[3 * k + 2] = r.c1.z;
+            p.p2[3 * k] = r.c2.x; p.p2[3 * k + 1] = r.c2.y; p.p2[3 * k + 2] = r.c2.z;
+            p.dist[k] = r.dist;
+            if (p.nsup) p.nsup[k] = r.n_support;
+            if (p.status) p.status[k] = r.status;
+        });
 }
 
 // -------------------------------------------------------------------------------------
@@ -79,7 +226,7 @@ struct GjkSwarmParams {
     const int* __restrict__ poly_off;  // [n_poly+1]
     const int* __restrict__ pa;
     const int* __restrict__ pb;
-    int n_veh, dim, nc, n_poly, n_poly_pts, n_pairs, wgs_per_row, vp;
+    int n_veh, dim, nc, n_poly, n_poly_pts, n_pairs, wgs_per_row, vp, chunk;
     int max_iter, md_cap;
     int* __restrict__ flag;
     double* __restrict__ p1;
@@ -89,9 +236,11 @@ struct GjkSwarmParams {
     int* status;
 };
 
+template <bool PLANAR>
 __global__ __launch_bounds__(256) void k_gjk_swarm(const GjkSwarmParams p)
 {
     extern __shared__ double lds[];
+    __shared__ int s_next;
     const int b = blockIdx.x / p.wgs_per_row, w = blockIdx.x - b * p.wgs_per_row;
     const int vlen = p.dim * p.nc;
     double* vl = lds;                        // [n_veh][vp]
@@ -102,27 +251,31 @@ __global__ __launch_bounds__(256) void k_gjk_swarm(const GjkSwarmParams p)
         vl[v * p.vp + r] = Yrow[e];
     }
     for (int e = threadIdx.x; e < 3 * p.n_poly_pts; e += blockDim.x) pl[e] = p.poly[e];
+    const int c0 = w * p.chunk, c1 = min(p.n_pairs, c0 + p.chunk);
+    if (threadIdx.x == 0) s_next = c0;
     __syncthreads();
-    const int k = w * blockDim.x + threadIdx.x;
-    if (k >= p.n_pairs) return;
-    const int a = p.pa[k], bb = p.pb[k];
-    Ctx<MemLds> g;
-    g.mem = MemLds{ lds };
     const int polybase = p.n_veh * p.vp;
-    if (a < p.n_veh) g.P1 = Poly{ a * p.vp, p.nc, p.nc, p.dim == 3 };
-    else { const int o = p.poly_off[a - p.n_veh], K = p.poly_off[a - p.n_veh + 1] - o; g.P1 = Poly{ polybase + 3 * o, K, K, 1 }; }
-    if (bb < p.n_veh) g.P2 = Poly{ bb * p.vp, p.nc, p.nc, p.dim == 3 };
-    else { const int o = p.poly_off[bb - p.n_veh], K = p.poly_off[bb - p.n_veh + 1] - o; g.P2 = Poly{ polybase + 3 * o, K, K, 1 }; }
-    g.trace = nullptr; g.trace_cap = 0; g.n_support = 0;
-    Result r;
-    gjk::run(g, p.max_iter, p.md_cap, r);
-    const size_t o = (size_t)b * p.n_pairs + k;
-    p.flag[o] = r.flag;
-    p.p1[3 * o] = r.c1.x; p.p1[3 * o + 1] = r.c1.y; p.p1[3 * o + 2] = r.c1.z;
-    p.p2[3 * o] = r.c2.x; p.p2[3 * o + 1] = r.c2.y; p.p2[3 * o + 2] = r.c2.z;
-    p.dist[o] = r.dist;
-    if (p.nsup) p.nsup[o] = r.n_support;
-    if (p.status) p.status[o] = r.status;
+    const size_t obase = (size_t)b * p.n_pairs;
+    gjk_sweep_any<MemLds, PLANAR>(
+        c1, &s_next, p.max_iter, p.md_cap,
+        [&](int k, Ctx<MemLds>& g) {
+            const int a = p.pa[k], bb = p.pb[k];
+            g.mem = MemLds{ lds };
+            if (a < p.n_veh) g.P1 = Poly{ a * p.vp, p.nc, p.nc, p.dim == 3 };
+            else { const int o = p.poly_off[a - p.n_veh], K = p.poly_off[a - p.n_veh + 1] - o; g.P1 = Poly{ polybase + 3 * o, K, K, 1 }; }
+            if (bb < p.n_veh) g.P2 = Poly{ bb * p.vp, p.nc, p.nc, p.dim == 3 };
+            else { const int o = p.poly_off[bb - p.n_veh], K = p.poly_off[bb - p.n_veh + 1] - o; g.P2 = Poly{ polybase + 3 * o, K, K, 1 }; }
+            g.trace = nullptr; g.trace_cap = 0;
+        },
+        [&](int k, const Result& r) {
+            const size_t o = obase + k;
+            p.flag[o] = r.flag;
+            p.p1[3 * o] = r.c1.x; p.p1[3 * o + 1] = r.c1.y; p.p1[3 * o + 2] = r.c1.z;
+            p.p2[3 * o] = r.c2.x; p.p2[3 * o + 1] = r.c2.y; p.p2[3 * o + 2] = r.c2.z;
+            p.dist[o] = r.dist;
+            if (p.nsup) p.nsup[o] = r.n_support;
+            if (p.status) p.status[o] = r.status;
+        });
 }
 
 // -------------------------------------------------------------------------------------
@@ -436,13 +589,17 @@ __global__ __launch_bounds__(64) void k_min_dist2poly(const Md2Params p)
 int launch_gjk_pairs(obtg_ctx* c, const double* d_soa, const int* d_off, const int* d_pa,
                      const int* d_pb, int n_pairs, int max_iter, int md_cap, int* d_flag,
                      double* d_p1, double* d_p2, double* d_dist, short* d_trace, int trace_cap,
-                     int* d_nsup, int* d_status)
+                     int* d_nsup, int* d_status, bool planar)
 {
     if (n_pairs <= 0) return OBTG_OK;
-    GjkPairsParams p{ d_soa, d_off, d_pa, d_pb, n_pairs, max_iter, md_cap, d_flag, d_p1, d_p2, d_dist,
+    int chunk = 1024;
+    while (chunk > 256 && (n_pairs + chunk - 1) / chunk < 1024) chunk >>= 1;
+    GjkPairsParams p{ d_soa, d_off, d_pa, d_pb, n_pairs, max_iter, md_cap, chunk, d_flag, d_p1, d_p2, d_dist,
                       d_trace, trace_cap, d_nsup, d_status };
+    const dim3 grid((n_pairs + chunk - 1) / chunk);
     ScopedKernelTimer t(c, OBTG_K_GJK);
-    hipLaunchKernelGGL(k_gjk_pairs, dim3((n_pairs + 255) / 256), dim3(256), 0, c->stream, p);
+    if (planar) hipLaunchKernelGGL(k_gjk_pairs<true>, grid, dim3(256), 0, c->stream, p);
+    else hipLaunchKernelGGL(k_gjk_pairs<false>, grid, dim3(256), 0, c->stream, p);
     OBTG_HIP(c, hipGetLastError());
     return OBTG_OK;
 }
@@ -458,16 +615,23 @@ int launch_gjk_swarm(obtg_ctx* c, const double* dY, int B, int max_iter, int md_
     p.n_poly_pts = c->n_poly_pts; p.n_pairs = c->n_hull_pairs;
     const int vlen = c->dim * (c->deg + 1);
     p.vp = (vlen % 2 == 0) ? vlen + 1 : vlen;
-    p.wgs_per_row = (c->n_hull_pairs + 255) / 256;
+    // workgroups per row: one staging of the row's hulls serves `chunk` pairs; keep >= ~6k
+    // workgroups in flight-order so that the last wave of workgroups is a small fraction
+    int wgs = 1;
+    while ((long)B * wgs < 6144 && (c->n_hull_pairs + wgs - 1) / wgs > 256) wgs <<= 1;
+    p.chunk = (c->n_hull_pairs + wgs - 1) / wgs;
+    p.wgs_per_row = (c->n_hull_pairs + p.chunk - 1) / p.chunk;
     p.max_iter = max_iter; p.md_cap = md_cap;
     p.flag = d_flag; p.p1 = d_p1; p.p2 = d_p2; p.dist = d_dist; p.nsup = d_nsup; p.status = d_status;
     size_t lds = sizeof(double) * ((size_t)c->n_veh * p.vp + 3 * (size_t)c->n_poly_pts);
-    if (lds > 160 * 1024) return OBTG_ERR_UNSUPPORTED;
+    if (lds > 160 * 1024 - 64) return OBTG_ERR_UNSUPPORTED;
+    const bool planar = c->dim == 2 && c->polys_planar;
+    auto kern = planar ? k_gjk_swarm<true> : k_gjk_swarm<false>;
     if (lds > 48 * 1024)
-        OBTG_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_gjk_swarm),
+        OBTG_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     ScopedKernelTimer t(c, OBTG_K_GJK);
-    hipLaunchKernelGGL(k_gjk_swarm, dim3((unsigned)((size_t)B * p.wgs_per_row)), dim3(256), lds, c->stream, p);
+    hipLaunchKernelGGL(kern, dim3((unsigned)((size_t)B * p.wgs_per_row)), dim3(256), lds, c->stream, p);
     OBTG_HIP(c, hipGetLastError());
     return OBTG_OK;
 }

@@ -58,6 +58,7 @@ struct obtg_ctx {
     obtg::DevBuf d_poly_pts;  // SoA per polygon: x[K], y[K], z[K]
     obtg::DevBuf d_poly_off;  // int[n_poly+1]
     int n_poly = 0, n_poly_pts = 0, max_poly_K = 0;
+    bool polys_planar = true;   // every registered polygon vertex has z == 0
     obtg::DevBuf d_hp_a, d_hp_b;  // hull pair list
     int n_hull_pairs = 0;
 
@@ -113,7 +114,7 @@ int launch_accel_obj(obtg_ctx* c, const double* dY, const double* d_tf, int B, d
 int launch_gjk_pairs(obtg_ctx* c, const double* d_soa, const int* d_off, const int* d_pa,
                      const int* d_pb, int n_pairs, int max_iter, int md_cap, int* d_flag,
                      double* d_p1, double* d_p2, double* d_dist, short* d_trace, int trace_cap,
-                     int* d_nsup, int* d_status);
+                     int* d_nsup, int* d_status, bool planar);
 int launch_gjk_swarm(obtg_ctx* c, const double* dY, int B, int max_iter, int md_cap, int* d_flag,
                      double* d_p1, double* d_p2, double* d_dist, int* d_nsup, int* d_status);
 int launch_min_dist(obtg_ctx* c, const double* d_curves, int K, const int* d_pa, const int* d_pb,
