@@ -187,9 +187,12 @@ int obtg_bern_diff(obtg_ctx*, const double* in, int rows, int n, double T, doubl
 int obtg_bern_mul(obtg_ctx*, const double* a, const double* b, int rows, int m, int n, double* out);
 int obtg_bern_normsq(obtg_ctx*, const double* x, int d, int n, double* out);
 
-/* ---- objectives (optimization.py:462-489 _euclideanObjective, 503-519 _minAccelObjective) */
+/* ---- objectives (optimization.py:462-489 _euclideanObjective, 503-519 _minAccelObjective,
+ * 522-539 _minJerkObjective): sums over vehicles of the elevated |d^k pos/dt^k|^2 control
+ * points, k = 2 (accel) or 3 (jerk); tf[0] is the (single) final time the reference uses. */
 int obtg_euclidean_obj(obtg_ctx*, const double* Y, int B, double* out /*[B]*/);
 int obtg_accel_obj(obtg_ctx*, const double* Y, const double* tf, int B, double* out /*[B]*/);
+int obtg_jerk_obj(obtg_ctx*, const double* Y, const double* tf, int B, double* out /*[B]*/);
 
 /* ---- instrumentation -------------------------------------------------------------------
  * When enabled every kernel launch is bracketed by HIP events on the launch stream;

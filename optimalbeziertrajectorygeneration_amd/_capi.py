@@ -60,6 +60,7 @@ _SIGNATURES = {
     "obtg_bern_normsq": (_i, [_vp, _vp, _i, _i, _vp]),
     "obtg_euclidean_obj": (_i, [_vp, _vp, _i, _vp]),
     "obtg_accel_obj": (_i, [_vp, _vp, _vp, _i, _vp]),
+    "obtg_jerk_obj": (_i, [_vp, _vp, _vp, _i, _vp]),
     "obtg_set_profiling": (_i, [_vp, _i]),
     "obtg_kernel_stats": (_i, [_vp, _i, C.POINTER(_d), C.POINTER(C.c_longlong)]),
     "obtg_reset_kernel_stats": (_i, [_vp]),
@@ -257,12 +258,17 @@ class Context(object):
         self._check(self._lib.obtg_euclidean_obj(self._h, _ptr(Y), B, _ptr(out)), "obtg_euclidean_obj")
         return out
 
-    def accel_obj(self, Y, tf):
+    def deriv_energy_obj(self, Y, tf, order):
+        """order 2: _minAccelObjective, order 3: _minJerkObjective (optimization.py:503-539)."""
         Y, B = self._rows(Y)
         tf = self._tf(tf, B)
         out = np.empty(B)
-        self._check(self._lib.obtg_accel_obj(self._h, _ptr(Y), _ptr(tf), B, _ptr(out)), "obtg_accel_obj")
+        fn = {2: self._lib.obtg_accel_obj, 3: self._lib.obtg_jerk_obj}[int(order)]
+        self._check(fn(self._h, _ptr(Y), _ptr(tf), B, _ptr(out)), "obtg_accel/jerk_obj")
         return out
+
+    def accel_obj(self, Y, tf):
+        return self.deriv_energy_obj(Y, tf, 2)
 
     # -- device-pointer sweeps (pointers are plain ints, e.g. torch.Tensor.data_ptr())
     def temporal_sep_dev(self, dY, B, max_sep, d_out, pair_begin=0, pair_count=None):

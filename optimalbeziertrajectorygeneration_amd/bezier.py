@@ -1,0 +1,236 @@
+"""`bezier.Bezier` look-alike whose arithmetic runs on the MI355X through libobtg_hip.so.
+
+Mirrors the part of the reference's object API that the SLSQP constraint callbacks and the
+drivers use (reference bezier.py:34-270 container, 318-519 add/sub/mul/div/elev/diff,
+840-889 minDist/minDist2Poly/normSquare).  Every method below that computes control points
+calls the C ABI (include/obtg.h); there is no CPU implementation of those in this package.
+
+Differences from the reference, on purpose:
+  * the constructor accepts any array-like (the reference needs an ndarray and crashes on
+    the lists its own `_minDist` passes, bezier.py:58, 1304);
+  * `minDist` / `minDist2Poly` work (at the reference's HEAD they raise because `gjkNew` is
+    never imported, bezier.py:21-22) and report the reference's non-terminating inputs as
+    exceptions instead of hanging;
+  * plotting, sampling on `tau` and temporal alignment of curves with different [t0, tf]
+    are outside the accelerated path and are not provided.
+"""
+import numpy as np
+
+from . import _capi
+
+
+def _ctx():
+    return _capi.scratch_context()
+
+
+class BezierParams(object):
+    """Control points d x (n+1), time span [t0, tf] (reference bezier.py:34-145)."""
+
+    def __init__(self, cpts=None, tau=None, t0=0.0, tf=1.0):
+        self._cpts = None
+        self._dim = None
+        self._deg = None
+        if cpts is not None:
+            self.cpts = cpts
+        if tau is not None:
+            self._t0 = tau[0]
+            self._tf = tau[-1]
+        else:
+            self._t0 = float(t0)
+            self._tf = float(tf)
+        self._tau = tau
+
+    @property
+    def cpts(self):
+        return self._cpts
+
+    @cpts.setter
+    def cpts(self, value):
+        if isinstance(value, np.ndarray) and value.ndim == 2 and value.dtype == np.float64:
+            new = value
+        else:
+            new = np.array(value, ndmin=2, dtype=float)   # bezier.py:92
+        self._dim = new.shape[0]
+        self._deg = new.shape[1] - 1
+        self._cpts = new
+
+    @property
+    def deg(self):
+        return self._deg
+
+    degree = deg
+
+    @property
+    def dim(self):
+        return self._dim
+
+    dimension = dim
+
+    @property
+    def t0(self):
+        return self._t0
+
+    @t0.setter
+    def t0(self, value):
+        self._t0 = float(value)
+        self._tau = None
+
+    @property
+    def tf(self):
+        return self._tf
+
+    @tf.setter
+    def tf(self, value):
+        self._tf = float(value)
+        self._tau = None
+
+    @property
+    def tau(self):
+        if self._tau is None:
+            self._tau = np.linspace(self._t0, self._tf, 1001)
+        elif not isinstance(self._tau, np.ndarray):
+            self._tau = np.array(self._tau)
+        return self._tau
+
+    @tau.setter
+    def tau(self, val):
+        self._t0 = val[0]
+        self._tf = val[-1]
+        self._tau = np.array(val)
+
+
+class Bezier(BezierParams):
+    """Bezier(cpts=None, t0=0.0, tf=1.0, tau=None) -- reference bezier.py:148-166."""
+
+    def __init__(self, cpts=None, t0=0.0, tf=1.0, tau=None):
+        super(Bezier, self).__init__(cpts=cpts, tau=tau, t0=t0, tf=tf)
+
+    def __add__(self, curve):
+        return self.add(curve)
+
+    def __sub__(self, curve):
+        return self.sub(curve)
+
+    def __mul__(self, curve):
+        return self.mul(curve)
+
+    def __truediv__(self, curve):
+        return self.div(curve)
+
+    def __repr__(self):
+        return 'Bezier({}, {}, {})'.format(self.cpts, self.t0, self.tf)
+
+    @property
+    def x(self):
+        return Bezier(self.cpts[0], t0=self.t0, tf=self.tf)
+
+    @property
+    def y(self):
+        return Bezier(self.cpts[1], t0=self.t0, tf=self.tf) if self.dim > 1 else None
+
+    @property
+    def z(self):
+        return Bezier(self.cpts[2], t0=self.t0, tf=self.tf) if self.dim > 2 else None
+
+    def copy(self):
+        return Bezier(self.cpts, self.t0, self.tf)
+
+    # ---- arithmetic (bezier.py:318-374): equal time spans only
+    def _same_span(self, other):
+        if not (self.t0 == other.t0 and self.tf == other.tf):
+            raise NotImplementedError('curves with different [t0, tf] need the reference\'s temporal '
+                                      'alignment (bezier.py:903-941), which is outside the accelerated path')
+
+    def add(self, other):
+        self._same_span(other)
+        if self.t0 >= self.tf:
+            return None
+        return Bezier(self.cpts + other.cpts, t0=self.t0, tf=self.tf)
+
+    def sub(self, other):
+        self._same_span(other)
+        if self.t0 >= self.tf:
+            return None
+        return Bezier(self.cpts - other.cpts, t0=self.t0, tf=self.tf)
+
+    def mul(self, multiplicand):
+        """Product of two curves (bezier.py:376-432), dimension by dimension."""
+        if not isinstance(multiplicand, Bezier):
+            raise TypeError('The multiplicand must be a {} object, not a {}'.format(Bezier, type(multiplicand)))
+        if multiplicand.dim != self.dim:
+            raise ValueError('The dimension of both Bezier curves must be the same.\n'
+                             'The first dimension is {} and the second is {}'.format(self.dim, multiplicand.dim))
+        new = self.copy()
+        new.cpts = _ctx().bern_mul(self.cpts, multiplicand.cpts)
+        return new
+
+    def div(self, denominator):
+        """Rational curve numerator/denominator (bezier.py:434-467): element-wise on control points."""
+        if not isinstance(denominator, Bezier):
+            raise TypeError('The denominator must be a Bezier object, not a {}. '
+                            'Or the module has been reloaded.'.format(type(denominator)))
+        num, den = self.cpts, denominator.cpts
+        with np.errstate(divide='ignore', invalid='ignore'):
+            cpts = np.where(num == 0, 0.0, np.where(den == 0, np.inf, num / den))
+        return RationalBezier(cpts.astype(np.float64), den.astype(np.float64), tau=self.tau, tf=self.tf)
+
+    def elev(self, R=1):
+        """Degree elevation by R (bezier.py:469-495)."""
+        new = self.copy()
+        new.cpts = _ctx().bern_elev(self.cpts, int(R))
+        return new
+
+    def diff(self):
+        """Derivative, elevated back to the original degree (bezier.py:497-519)."""
+        new = self.copy()
+        new.cpts = _ctx().bern_diff(self.cpts, self.tf - self.t0)
+        return new
+
+    def normSquare(self):
+        """(d/2) * |curve|^2 as a 1 x (2n+1) curve -- the reference's factor is kept (bezier.py:869-889)."""
+        new = self.copy()
+        new.cpts = _ctx().bern_normsq(self.cpts)
+        return new
+
+    # ---- distances (bezier.py:840-857)
+    def _padded(self):
+        c = np.zeros((3, self.deg + 1))
+        c[:self.dim] = self.cpts
+        return c
+
+    def minDist(self, otherCurve, eps=1e-9, max_depth=128, max_nodes=4000000):
+        if self.dim < 2 or self.dim > 3 or otherCurve.dim < 2 or otherCurve.dim > 3:
+            raise ValueError('Both curves must be either 2D or 3D, not {}D and {}D.'.format(self.dim, otherCurve.dim))
+        if self.deg != otherCurve.deg:
+            raise ValueError('minDist needs curves of equal degree here (got {} and {})'.format(self.deg, otherCurve.deg))
+        r = _ctx().min_dist(np.stack([self._padded(), otherCurve._padded()]), [0], [1], eps=eps,
+                            max_depth=max_depth, max_nodes=max_nodes)
+        _raise_md(r['status'][0])
+        a, t1, t2 = r['res'][0]
+        return (float(a), float(t1), float(t2))
+
+    def minDist2Poly(self, poly, eps=1e-6, max_depth=128, max_nodes=4000000):
+        poly = np.asarray(poly, dtype=float)
+        r = _ctx().min_dist2poly(self._padded()[None], poly, [0, poly.shape[0]], [0], [0], eps=eps,
+                                 max_depth=max_depth, max_nodes=max_nodes)
+        _raise_md(r['status'][0])
+        res = r['res'][0]
+        return (float(res[0]), float(res[1]), res[2:].copy())
+
+
+def _raise_md(status):
+    if status == _capi.MD_OK:
+        return
+    if status == _capi.MD_DEPTH_CAP:
+        raise RecursionError('minDist: subdivision deeper than max_depth (the reference overflows its stack here)')
+    if status == _capi.MD_NODE_CAP:
+        raise RuntimeError('minDist: node budget exhausted (the reference does not return on this input)')
+    raise RuntimeError('minDist: an inner gjkNew did not converge (the reference loops forever here)')
+
+
+class RationalBezier(BezierParams):
+    """Container for control points + weights (bezier.py:894-900)."""
+
+    def __init__(self, cpts=None, weights=None, tau=None, tf=1.0):
+        super(RationalBezier, self).__init__(cpts=cpts, tau=tau, tf=tf)
+        self._weights = np.array(weights, ndmin=2)

@@ -957,26 +957,30 @@ int launch_euclidean_obj(obtg_ctx* c, const double* dY, int B, double* d_out)
     return OBTG_OK;
 }
 
-// optimization.py:503-519: per vehicle pos.diff().diff().normSquare().elev(R), summed
-int launch_accel_obj(obtg_ctx* c, const double* dY, const double* d_tf, int B, double* d_out)
+// optimization.py:503-539: per vehicle (d/dt)^order pos -> normSquare().elev(R), control points
+// summed.  order-1 plain derivative passes, then the speed-style sweep (one more derivative,
+// product, elevation) with sign +1 and offset 0.
+int launch_deriv_energy_obj(obtg_ctx* c, const double* dY, const double* d_tf, int B, int order, double* d_out)
 {
     if (B <= 0) return OBTG_OK;
-    // d/dt twice on every coordinate row, then the speed-style sweep with sign +1, offset 0
+    if (order < 1 || order > 4) return OBTG_ERR_ARG;
     const int rows = B * c->n_veh * c->dim, nc = c->deg + 1;
     int rc = c->ws_misc[3].reserve(sizeof(double) * (size_t)rows * nc);
     if (rc) return rc;
-    rc = c->ws_misc[4].reserve(sizeof(double) * (size_t)B * c->n_veh * (2 * c->deg + c->R + 1));
-    if (rc) return rc;
-    // first derivative with the per-row tf: launch row-blocks per evaluation row
-    // (tf differs per row only in time-optimal problems; the objective there is x[-1], so a
-    //  single tf per call is all the reference ever uses: optimization.py:294-300)
+    if ((rc = c->ws_misc[6].reserve(sizeof(double) * (size_t)rows * nc))) return rc;
+    if ((rc = c->ws_misc[4].reserve(sizeof(double) * (size_t)B * c->n_veh * (2 * c->deg + c->R + 1)))) return rc;
+    // tf differs per row only in time-optimal problems, whose objective is x[-1]; the reference
+    // passes one model['tf'] (optimization.py:294-308)
     double tf0;
     OBTG_HIP(c, hipMemcpyAsync(&tf0, d_tf, sizeof(double), hipMemcpyDeviceToHost, c->stream));
     OBTG_HIP(c, hipStreamSynchronize(c->stream));
-    rc = launch_bern_diff(c, dY, rows, c->deg, tf0, c->ws_misc[3].as<double>());
-    if (rc) return rc;
-    rc = launch_speed(c, c->ws_misc[3].as<double>(), d_tf, B, 0.0, 0, c->ws_misc[4].as<double>());
-    if (rc) return rc;
+    const double* src = dY;
+    double* bufs[2] = { c->ws_misc[3].as<double>(), c->ws_misc[6].as<double>() };
+    for (int k = 0; k < order - 1; ++k) {
+        if ((rc = launch_bern_diff(c, src, rows, c->deg, tf0, bufs[k & 1]))) return rc;
+        src = bufs[k & 1];
+    }
+    if ((rc = launch_speed(c, src, d_tf, B, 0.0, 0, c->ws_misc[4].as<double>()))) return rc;
     ScopedKernelTimer t(c, OBTG_K_BERN);
     hipLaunchKernelGGL(k_rowsum, dim3(B), dim3(kWave), 0, c->stream, c->ws_misc[4].as<double>(), d_out,
                        c->n_veh * (2 * c->deg + c->R + 1));

@@ -177,7 +177,7 @@ const char* obtg_abi_symbols(void)
         "obtg_fd_batch_dev\0obtg_gjk_pairs\0obtg_ctx_set_polygons\0obtg_ctx_set_hull_pairs\0"
         "obtg_gjk_swarm_dev\0obtg_gjk_swarm\0obtg_min_dist\0obtg_min_dist2poly\0"
         "obtg_bern_elev\0obtg_bern_diff\0obtg_bern_mul\0obtg_bern_normsq\0"
-        "obtg_euclidean_obj\0obtg_accel_obj\0"
+        "obtg_euclidean_obj\0obtg_accel_obj\0obtg_jerk_obj\0"
         "obtg_set_profiling\0obtg_kernel_stats\0obtg_reset_kernel_stats\0obtg_kernel_name\0";
     return syms;
 }
@@ -666,7 +666,7 @@ int obtg_euclidean_obj(obtg_ctx* c, const double* Y, int B, double* out)
     return d2h(c, out, c->ws_out.p, sizeof(double) * B);
 }
 
-int obtg_accel_obj(obtg_ctx* c, const double* Y, const double* tf, int B, double* out)
+static int host_deriv_obj(obtg_ctx* c, const double* Y, const double* tf, int B, int order, double* out)
 {
     if (!check_ctx(c) || !Y || !tf || !out || B < 0) return OBTG_ERR_ARG;
     if (B == 0) return OBTG_OK;
@@ -675,8 +675,19 @@ int obtg_accel_obj(obtg_ctx* c, const double* Y, const double* tf, int B, double
     if (rc) return rc;
     if ((rc = h2d(c, c->ws_in2, tf, sizeof(double) * B))) return rc;
     if ((rc = c->ws_out.reserve(sizeof(double) * B))) return rc;
-    if ((rc = launch_accel_obj(c, c->ws_in.as<double>(), c->ws_in2.as<double>(), B, c->ws_out.as<double>()))) return rc;
+    if ((rc = launch_deriv_energy_obj(c, c->ws_in.as<double>(), c->ws_in2.as<double>(), B, order, c->ws_out.as<double>())))
+        return rc;
     return d2h(c, out, c->ws_out.p, sizeof(double) * B);
+}
+
+int obtg_accel_obj(obtg_ctx* c, const double* Y, const double* tf, int B, double* out)
+{
+    return host_deriv_obj(c, Y, tf, B, 2, out);
+}
+
+int obtg_jerk_obj(obtg_ctx* c, const double* Y, const double* tf, int B, double* out)
+{
+    return host_deriv_obj(c, Y, tf, B, 3, out);
 }
 
 // ------------------------------------------------------------------ instrumentation

@@ -108,7 +108,7 @@ int launch_bern_mul(obtg_ctx* c, const double* d_a, const double* d_b, int rows,
                     double* d_out);
 int launch_bern_normsq(obtg_ctx* c, const double* d_x, int d, int n, double* d_out);
 int launch_euclidean_obj(obtg_ctx* c, const double* dY, int B, double* d_out);
-int launch_accel_obj(obtg_ctx* c, const double* dY, const double* d_tf, int B, double* d_out);
+int launch_deriv_energy_obj(obtg_ctx* c, const double* dY, const double* d_tf, int B, int order, double* d_out);
 
 // ---------------------------------------------------------------- launchers (gjk_kernels.hip)
 int launch_gjk_pairs(obtg_ctx* c, const double* d_soa, const int* d_off, const int* d_pa,

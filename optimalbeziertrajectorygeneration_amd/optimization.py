@@ -1,0 +1,296 @@
+"""`optimization.BezOptimization` look-alike: same constructor, attributes and callback
+signatures as the reference (optimization.py:20-308), with every constraint / cost
+evaluation dispatched to the MI355X through libobtg_hip.so.
+
+A driver script changes only its import lines:
+
+    import optimalbeziertrajectorygeneration_amd.bezier as bez
+    from optimalbeziertrajectorygeneration_amd.optimization import BezOptimization
+
+and hands the same closures to `scipy.optimize.minimize(method='SLSQP')`.  Beyond the
+reference, each constraint has a `...Jacobian` provider that evaluates SciPy's whole
+2-point finite-difference batch (n_x + 1 rows) in ONE launch; pass it as the 'jac' entry of
+the constraint dict to remove the n_x + 1 serial callbacks per iteration.
+"""
+import numpy as np
+
+from . import _capi
+from . import bezier as bez
+
+DEG_ELEV = 0   # module constant read at call time, like optimization.py:17
+
+FD_STEP = 1.4901161193847656e-08   # SciPy '2-point' abs_step (sqrt of machine epsilon)
+
+
+class BezOptimization(object):
+    def __init__(self,
+                 numVeh=1,
+                 dimension=1,
+                 degree=5,
+                 minimizeGoal='Euclidean',
+                 maxSep=0.9,
+                 minSpeed=0,
+                 maxSpeed=1e6,
+                 maxAngRate=1e6,
+                 initPoints=None,
+                 finalPoints=None,
+                 initSpeeds=None,
+                 finalSpeeds=None,
+                 initAngs=None,
+                 finalAngs=None,
+                 tf=1.0,
+                 pointObstacles=None,
+                 shapeObstacles=None,
+                 device=0):
+        self.pointObstacles = pointObstacles
+        self.shapeObstacles = shapeObstacles
+        self._device = device
+
+        self._numCols = degree + 1
+        if initPoints is not None:
+            self._numCols -= 2
+        if initSpeeds is not None:
+            self._numCols -= 2
+
+        self.model = {'numVeh': numVeh,
+                      'dim': dimension,
+                      'deg': degree,
+                      'minGoal': minimizeGoal,
+                      'maxSep': maxSep,
+                      'minSpeed': minSpeed,
+                      'maxSpeed': maxSpeed,
+                      'maxAngRate': maxAngRate,
+                      'initPoints': np.atleast_2d(initPoints),
+                      'finalPoints': np.atleast_2d(finalPoints),
+                      'initSpeeds': np.atleast_1d(initSpeeds),
+                      'finalSpeeds': np.atleast_1d(finalSpeeds),
+                      'initAngs': np.atleast_1d(initAngs),
+                      'finalAngs': np.atleast_1d(finalAngs),
+                      'tf': tf}
+        self._ctxs = {}
+
+    # ------------------------------------------------------------------ device contexts
+    def _ctx(self, with_point_obs):
+        """Context for the current DEG_ELEV (created on first use; the reference's counterpart
+        is the lazily filled class-level matrix caches, bezier.py:48-52)."""
+        key = bool(with_point_obs)
+        c = self._ctxs.get(key)
+        if c is None:
+            obs = self.pointObstacles if with_point_obs else None
+            c = _capi.Context(self.model['numVeh'], self.model['dim'], self.model['deg'], int(DEG_ELEV),
+                              point_obs=obs, device=self._device)
+            self._ctxs[key] = c
+        if c.deg_elev != int(DEG_ELEV):
+            c.set_deg_elev(int(DEG_ELEV))
+        return c
+
+    def _timeopt(self):
+        return self.model['minGoal'].lower() == 'timeopt'
+
+    def _tf_of(self, x):
+        return x[-1] if self._timeopt() else self.model['tf']
+
+    # ------------------------------------------------------------------ objective
+    @property
+    def objectiveFunction(self):
+        minGoal = self.model['minGoal'].lower()
+        objectivesDict = {'euclidean': self.euclideanObjective,
+                          'timeopt': lambda x: x[-1],
+                          'accel': self.accelObjective,
+                          'jerk': self.jerkObjective,
+                          }
+        try:
+            return objectivesDict[minGoal]
+        except KeyError:
+            err = ('The provided minimize goal, {}, is not a valid goal. '
+                   'The available minimize goals are:\n{}'
+                   ).format(minGoal, objectivesDict.keys())
+            raise ValueError(err)
+
+    def euclideanObjective(self, x):
+        return float(self._ctx(False).euclidean_obj(self.reshapeVector(x))[0])
+
+    def accelObjective(self, x):
+        return float(self._ctx(False).deriv_energy_obj(self.reshapeVector(x), self.model['tf'], 2)[0])
+
+    def jerkObjective(self, x):
+        return float(self._ctx(False).deriv_energy_obj(self.reshapeVector(x), self.model['tf'], 3)[0])
+
+    # ------------------------------------------------------------------ constraints
+    @property
+    def temporalSeparationConstraints(self):
+        with_obs = self.pointObstacles is not None
+        nobj = self.model['numVeh'] + (len(self.pointObstacles) if with_obs else 0)
+
+        def wrapper(x):
+            if nobj <= 1:
+                return None                      # optimization.py:345-346
+            y = self.reshapeVector(x)
+            return self._ctx(with_obs).temporal_sep(y, self.model['maxSep'])[0]
+        return wrapper
+
+    @property
+    def minSpeedConstraints(self):
+        def wrapper(x):
+            y = self.reshapeVector(x)
+            return self._ctx(False).speed(y, self._tf_of(x), self.model['minSpeed'], False)[0]
+        return wrapper
+
+    @property
+    def maxSpeedConstraints(self):
+        def wrapper(x):
+            y = self.reshapeVector(x)
+            return self._ctx(False).speed(y, self._tf_of(x), self.model['maxSpeed'], True)[0]
+        return wrapper
+
+    @property
+    def maxAngularRateConstraints(self):
+        def wrapper(x):
+            if self.model['dim'] != 2:
+                msg = ('The input curve must be two dimensional,\n'
+                       'instead it is {} dimensional'.format(self.model['dim']))
+                raise ValueError(msg)            # optimization.py:590-593
+            y = self.reshapeVector(x)
+            return self._ctx(False).ang_rate(y, self._tf_of(x), self.model['maxAngRate'])[0]
+        return wrapper
+
+    def spatialSeparationConstraints(self, x):
+        """All-pairs minDist over vehicles AND shape obstacles (optimization.py:109-133);
+        returns shape (P, 3): (dist, t1, t2) - maxSep, as the reference does."""
+        numVeh, dim, maxSep = self.model['numVeh'], self.model['dim'], self.model['maxSep']
+        y = self.reshapeVector(x)
+        curves = [bez.Bezier(y[i * dim:(i + 1) * dim, :]) for i in range(numVeh)] + list(self.shapeObstacles)
+        n = len(curves)
+        stack = np.stack([c._padded() for c in curves])
+        pa, pb = [], []
+        for i in range(n):
+            for j in range(i + 1, n):
+                pa.append(i)
+                pb.append(j)
+        r = _capi.scratch_context().min_dist(stack, pa, pb, eps=1e-9, max_depth=128, max_nodes=4000000)
+        for st in r['status']:
+            bez._raise_md(st)
+        return r['res'] - maxSep
+
+    # ------------------------------------------------------------------ batched Jacobians (new)
+    def _fd_rows(self, x):
+        """x and its n_x forward-difference neighbours, SciPy-style: rows[k+1] = x + h e_k,
+        dx[k] = (x_k + h) - x_k."""
+        x = np.asarray(x, dtype=float)
+        X = np.repeat(x[None], x.size + 1, axis=0)
+        idx = np.arange(x.size)
+        X[idx + 1, idx] += FD_STEP
+        dx = X[idx + 1, idx] - x
+        return X, dx
+
+    def _jac(self, x, family):
+        X, dx = self._fd_rows(x)
+        Y = self.reshapeVectors(X)
+        if family == 'tsep':
+            with_obs = self.pointObstacles is not None
+            F = self._ctx(with_obs).temporal_sep(Y, self.model['maxSep'])
+        else:
+            tf = X[:, -1] if self._timeopt() else np.full(X.shape[0], self.model['tf'])
+            c = self._ctx(False)
+            if family == 'vmax':
+                F = c.speed(Y, tf, self.model['maxSpeed'], True)
+            elif family == 'vmin':
+                F = c.speed(Y, tf, self.model['minSpeed'], False)
+            else:
+                F = c.ang_rate(Y, tf, self.model['maxAngRate'])
+        return ((F[1:] - F[0:1]) / dx[:, None]).T
+
+    def temporalSeparationJacobian(self, x):
+        return self._jac(x, 'tsep')
+
+    def maxSpeedJacobian(self, x):
+        return self._jac(x, 'vmax')
+
+    def minSpeedJacobian(self, x):
+        return self._jac(x, 'vmin')
+
+    def maxAngularRateJacobian(self, x):
+        return self._jac(x, 'ang')
+
+    # ------------------------------------------------------------------ x <-> y
+    def generateGuess(self, std=0, seed=None):
+        """Straight-line initial guess (optimization.py:189-240)."""
+        dim = self.model['dim']
+        deg = self.model['deg']
+        numVeh = self.model['numVeh']
+        tf = self.model['tf']
+        initPoints = self.model['initPoints']
+        finalPoints = self.model['finalPoints']
+        initSpeeds = self.model['initSpeeds']
+        finalSpeeds = self.model['finalSpeeds']
+        initAngs = self.model['initAngs']
+        finalAngs = self.model['finalAngs']
+
+        np.random.seed(seed)
+        xGuess = []
+        for i in range(numVeh):
+            for j in range(dim):
+                if initSpeeds[0] is None:
+                    line = np.linspace(initPoints[i, j], finalPoints[i, j], deg + 1)
+                    line += np.random.randn(deg + 1) * std
+                else:
+                    if dim != 2:
+                        err = ('The dimension must be 2 for initial and final '
+                               'speeds and angles.')
+                        raise ValueError(err)
+                    initMag = initSpeeds[i] * tf / deg
+                    finalMag = finalSpeeds[i] * tf / deg
+                    if j % 2 == 0:
+                        initPt = initPoints[i, j] + initMag * np.cos(initAngs[i])
+                        finalPt = finalPoints[i, j] - finalMag * np.cos(finalAngs[i])
+                    else:
+                        initPt = initPoints[i, j] + initMag * np.sin(initAngs[i])
+                        finalPt = finalPoints[i, j] - finalMag * np.sin(finalAngs[i])
+                    line = np.linspace(initPt, finalPt, deg + 1 - 2)
+                    line += np.random.randn(deg + 1 - 2) * std
+                xGuess.append(line[1:-1])
+        if self._timeopt():
+            xGuess.append([tf])
+        return np.concatenate(xGuess)
+
+    def reshapeVector(self, x):
+        """x -> y[(numVeh*dim) x (deg+1)] (optimization.py:242-285)."""
+        return self.reshapeVectors(np.asarray(x, dtype=float)[None])[0]
+
+    def reshapeVectors(self, X):
+        """Batched reshapeVector: X[B][n_x] -> Y[B][(numVeh*dim)][deg+1]."""
+        dim = self.model['dim']
+        deg = self.model['deg']
+        numVeh = self.model['numVeh']
+        initPoints = self.model['initPoints']
+        finalPoints = self.model['finalPoints']
+        initSpeeds = self.model['initSpeeds']
+        finalSpeeds = self.model['finalSpeeds']
+        initAngs = self.model['initAngs']
+        finalAngs = self.model['finalAngs']
+        numCols = self._numCols
+        numRows = dim * numVeh
+        X = np.asarray(X, dtype=float)
+        B = X.shape[0]
+        if self._timeopt():
+            tf = X[:, -1]
+            X = X[:, :-1]
+        else:
+            tf = np.full(B, float(self.model['tf']))
+        Y = np.empty((B, numRows, deg + 1))
+        offset = 0
+        if initPoints is not None:
+            offset += 1
+            for i in range(initPoints.shape[0]):
+                Y[:, i * dim:(i + 1) * dim, 0] = initPoints[i]
+                Y[:, i * dim:(i + 1) * dim, -1] = finalPoints[i]
+        if initSpeeds[0] is not None:
+            offset += 1
+            initMag = initSpeeds[None, :] * tf[:, None] / deg
+            finalMag = finalSpeeds[None, :] * tf[:, None] / deg
+            Y[:, ::2, 1] = initPoints[:, 0] + initMag * np.cos(initAngs)        # X
+            Y[:, 1::2, 1] = initPoints[:, 1] + initMag * np.sin(initAngs)       # Y
+            Y[:, ::2, -2] = finalPoints[:, 0] - finalMag * np.cos(finalAngs)    # X
+            Y[:, 1::2, -2] = finalPoints[:, 1] - finalMag * np.sin(finalAngs)   # Y
+        Y[:, :, offset:-offset] = X.reshape((B, numRows, numCols))
+        return Y

@@ -285,6 +285,18 @@ def gen_problem():
                               initSpeeds=[1, 2, 0.5], finalSpeeds=[1, 1, 2],
                               initAngs=[0.1, -0.4, 2.0], finalAngs=[0.3, 0.0, 2.5], tf=7.0)
     d["fx_obj_accel"] = np.array(bfa.objectiveFunction(xf))
+    bfa.model['minGoal'] = 'Jerk'
+    d["fx_obj_jerk"] = np.array(bfa.objectiveFunction(xf))
+    # literal layout check of optimization.py:614-654 (2 vehicles, speeds, deg 5)
+    bm = opt.BezOptimization(numVeh=2, dimension=2, degree=5,
+                             initPoints=np.array([[1, 2], [3, 4]]), finalPoints=np.array([[5, 6], [7, 8]]),
+                             initSpeeds=np.array([3, 3]), finalSpeeds=np.array([10, 10]),
+                             initAngs=np.array([np.pi / 2, np.pi / 2]), finalAngs=np.array([0, 0]),
+                             pointObstacles=[[1, 2], [3, 4]])
+    xm = np.arange(8.0) + 0.5
+    d["main_x"] = xm
+    d["main_y"] = bm.reshapeVector(xm)
+    d["main_guess"] = bm.generateGuess()
     save("problem.npz", **d)
 
 

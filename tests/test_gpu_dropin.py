@@ -1,0 +1,152 @@
+"""The drop-in layer on a real MI355X: the reference's object API (`Bezier`, `BezOptimization`,
+`gjkNew`) backed by the HIP library, and an unchanged SLSQP driver converging to the
+reference's solution.  `pytest -m gpu`."""
+import numpy as np
+import pytest
+
+from util import assert_close
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def P(golden_dir):
+    return np.load(golden_dir + "/problem.npz")
+
+
+def _example1(**kw):
+    from optimalbeziertrajectorygeneration_amd.optimization import BezOptimization
+    args = dict(numVeh=2, dimension=2, degree=10, minimizeGoal='TimeOpt', maxSep=1, maxSpeed=5, maxAngRate=1,
+                initPoints=[(0, 5), (3, 0)], finalPoints=[(8, 4), (7, 10)], initSpeeds=[1] * 2,
+                finalSpeeds=[1] * 2, initAngs=[0, np.pi / 2], finalAngs=[0, np.pi / 2],
+                pointObstacles=[[3, 2], [6, 7]])
+    args.update(kw)
+    return BezOptimization(**args)
+
+
+def test_bezier_methods_match_reference(golden_dir):
+    from optimalbeziertrajectorygeneration_amd.bezier import Bezier
+    o = np.load(golden_dir + "/bezier_ops.npz")
+    for c in range(int(o["n_cases"])):
+        pre = "c%d_" % c
+        a, b, tf = o[pre + "a"], o[pre + "b"], float(o[pre + "tf"])
+        A, B = Bezier(a.copy(), tf=tf), Bezier(b.copy(), tf=tf)
+        assert_close(A.elev(1).cpts, o[pre + "elev1"])
+        assert_close(A.elev(7).cpts, o[pre + "elev7"])
+        Ad = A.diff()
+        assert Ad.tf == float(o[pre + "diff_tf"]) and Ad.deg == A.deg       # derivative is re-elevated
+        assert_close(Ad.cpts, o[pre + "diff"])
+        assert_close(Ad.diff().cpts, o[pre + "diff2"])
+        ns = A.normSquare()
+        assert ns.cpts.shape == (1, 2 * A.deg + 1)
+        assert_close(ns.cpts, o[pre + "normsq"])
+        assert_close((A * B).cpts, o[pre + "mul"])
+        assert np.array_equal((A - B).cpts, o[pre + "sub"]) and np.array_equal((A + B).cpts, o[pre + "add"])
+
+
+def test_mindist_known_answers(golden_dir):
+    """bezier.py:1772-1868 demo inputs; values probed from the reference."""
+    from optimalbeziertrajectorygeneration_amd.bezier import Bezier
+    m = np.load(golden_dir + "/mindist.npz")
+    c = [Bezier(x) for x in m["lit_curves"]]
+    assert c[0].minDist(c[1]) == (0.125, 0.5, 0.5)
+    assert abs(c[2].minDist(c[1])[0] - 1.41421356238) < 1e-10
+    assert c[2].minDist(c[3])[0] < 1e-9
+    d, t1, pt = c[0].minDist2Poly(m["lit_polys"][0])
+    assert abs(d - 0.23517375778) < 1e-10 and abs(t1 - 0.60679671625) < 1e-10 and tuple(pt) == (3.0, 1.0, 3.0)
+    with pytest.raises((RecursionError, RuntimeError)):
+        c[0].minDist(c[4])          # the reference overflows its stack on this pair
+
+
+def test_gjknew_signature_and_values(capsys):
+    from optimalbeziertrajectorygeneration_amd.gjk import gjkNew
+    P_ = lambda *rows: np.array(rows, dtype=float)
+    p1 = P_((4, 11, 0), (4, 5, 0), (9, 9, 0))
+    p2 = P_((5, 6, 0), (10, 2, 0), (13, 1, 0), (12, 3, 0), (15, 6, 0))
+    p5 = P_((4, 11, -3), (4, 5, -3), (9, 9, -3), (7, 8, -1))
+    p6 = P_((4, 11, 0), (4, 5, 1), (9, 9, 2), (7, 8, 3))
+    assert gjkNew(p1, p2) == (0, ())
+    flag, (a, b, dist) = gjkNew(p1, p5)
+    assert flag == 1 and dist == 1.0 and a.shape == (3,) and b.shape == (3,)
+    flag, info = gjkNew(p5, p6)
+    assert flag == 1 and abs(info[2] - 2.3426064283) < 1e-9
+    flag, info = gjkNew(p5, p6, maxIter=1)
+    assert (flag, info) == (-1, ()) and 'Maximum iterations met' in capsys.readouterr().out
+
+
+def test_closures_match_reference(P):
+    from optimalbeziertrajectorygeneration_amd import optimization as opt
+    bo = _example1()
+    try:
+        for R in (0, 30):
+            opt.DEG_ELEV = R           # read at call time, as in the reference
+            for tag in ("g", "r"):
+                x = P["ex1_xguess"] if tag == "g" else P["ex1_x"]
+                assert_close(bo.temporalSeparationConstraints(x), P["ex1_%s_tsep_class_R%d" % (tag, R)])
+                assert_close(bo.maxSpeedConstraints(x), P["ex1_%s_maxspeed_R%d" % (tag, R)])
+                assert_close(bo.minSpeedConstraints(x), P["ex1_%s_minspeed_R%d" % (tag, R)])
+                assert_close(bo.maxAngularRateConstraints(x), P["ex1_%s_angrate_R%d" % (tag, R)])
+    finally:
+        opt.DEG_ELEV = 0
+    from optimalbeziertrajectorygeneration_amd.optimization import BezOptimization
+    bf = BezOptimization(numVeh=3, dimension=2, degree=7, minimizeGoal='Accel', initPoints=[(0, 0), (1, 5), (9, 2)],
+                         finalPoints=[(10, 1), (8, 8), (0, 7)], initSpeeds=[1, 2, 0.5], finalSpeeds=[1, 1, 2],
+                         initAngs=[0.1, -0.4, 2.0], finalAngs=[0.3, 0.0, 2.5], tf=7.0)
+    assert abs(bf.objectiveFunction(P["fx_x"]) / float(P["fx_obj_accel"]) - 1) < 1e-9
+    bf.model['minGoal'] = 'Jerk'
+    assert abs(bf.objectiveFunction(P["fx_x"]) / float(P["fx_obj_jerk"]) - 1) < 1e-9
+    one = BezOptimization(numVeh=1, dimension=2, degree=5, initPoints=[(0, 0)], finalPoints=[(1, 1)])
+    assert one.temporalSeparationConstraints(one.generateGuess()) is None
+    b3 = BezOptimization(numVeh=2, dimension=3, degree=5, initPoints=np.zeros((2, 3)), finalPoints=np.ones((2, 3)))
+    with pytest.raises(ValueError):
+        b3.maxAngularRateConstraints(b3.generateGuess())
+
+
+def test_batched_jacobian_equals_scipy_fd(P):
+    """The one-launch FD Jacobian reproduces scipy's approx_derivative('2-point') on the closure."""
+    from scipy.optimize._numdiff import approx_derivative
+    bo = _example1()
+    x = P["ex1_x"]
+    for fun, jac in ((bo.temporalSeparationConstraints, bo.temporalSeparationJacobian),
+                     (bo.maxSpeedConstraints, bo.maxSpeedJacobian),
+                     (bo.maxAngularRateConstraints, bo.maxAngularRateJacobian)):
+        J_ref = approx_derivative(fun, x, method='2-point', abs_step=1.4901161193847656e-08)
+        J = jac(x)
+        assert J.shape == J_ref.shape
+        assert np.allclose(J, J_ref, rtol=0, atol=2e-6 * max(1.0, np.abs(J_ref).max()))
+
+
+def test_slsqp_driver_converges_to_reference_solution():
+    """Example1's driver with only the import lines changed (Examples/Example1_DubinsCarTimeOptimal.py
+    :128-148): tf* = 2.427643189 with DEG_ELEV 0 under SciPy 1.15."""
+    import scipy.optimize as sop
+    from optimalbeziertrajectorygeneration_amd import bezier as bez   # noqa: F401  (the driver imports it)
+    bo = _example1(pointObstacles=None)        # Example1's own separation function ignores the obstacles
+    xGuess = bo.generateGuess(std=0)
+    cons = [{'type': 'ineq', 'fun': bo.temporalSeparationConstraints},
+            {'type': 'ineq', 'fun': bo.maxSpeedConstraints},
+            {'type': 'ineq', 'fun': bo.maxAngularRateConstraints},
+            {'type': 'ineq', 'fun': lambda x: x[-1]}]
+    res = sop.minimize(bo.objectiveFunction, x0=xGuess, method='SLSQP', constraints=cons,
+                       options={'maxiter': 250, 'disp': False})
+    assert res.success
+    assert abs(res.fun - 2.427643189186796) < 1e-6
+    # same problem, Jacobians from the batched providers (one launch per constraint per iteration)
+    cons_j = [{'type': 'ineq', 'fun': bo.temporalSeparationConstraints, 'jac': bo.temporalSeparationJacobian},
+              {'type': 'ineq', 'fun': bo.maxSpeedConstraints, 'jac': bo.maxSpeedJacobian},
+              {'type': 'ineq', 'fun': bo.maxAngularRateConstraints, 'jac': bo.maxAngularRateJacobian},
+              {'type': 'ineq', 'fun': lambda x: x[-1], 'jac': lambda x: np.eye(1, x.size, x.size - 1)}]
+    res_j = sop.minimize(bo.objectiveFunction, x0=xGuess, method='SLSQP', constraints=cons_j,
+                         options={'maxiter': 250, 'disp': False})
+    assert res_j.success and abs(res_j.fun - 2.427643189186796) < 1e-5
+
+
+def test_spatial_separation_constraints_shape():
+    """optimization.py:109-133: (P, 3) array of (dist, t1, t2) - maxSep over vehicles and shape obstacles."""
+    from optimalbeziertrajectorygeneration_amd.bezier import Bezier
+    from optimalbeziertrajectorygeneration_amd.optimization import BezOptimization
+    obst = [Bezier(np.array([[8., 9, 10, 11, 12, 13], [0., 2, 4, 6, 8, 10]]))]
+    bo = BezOptimization(numVeh=2, dimension=2, degree=5, maxSep=0.5, initPoints=[(0, 0), (0, 4)],
+                         finalPoints=[(5, 1), (5, 6)], shapeObstacles=obst)
+    out = bo.spatialSeparationConstraints(bo.generateGuess(std=0.3, seed=2))
+    assert out.shape == (3, 3) and np.isfinite(out).all()

@@ -1,0 +1,93 @@
+"""Host-side logic of the look-alike problem layer (no GPU needed): x <-> y layout,
+initial guesses, finite-difference row construction -- against values captured from the
+reference (tests/golden/problem.npz)."""
+import numpy as np
+import pytest
+
+
+@pytest.fixture(scope="module")
+def P(golden_dir):
+    return np.load(golden_dir + "/problem.npz")
+
+
+def _example1():
+    from optimalbeziertrajectorygeneration_amd.optimization import BezOptimization
+    return BezOptimization(numVeh=2, dimension=2, degree=10, minimizeGoal='TimeOpt', maxSep=1, maxSpeed=5,
+                           maxAngRate=1, initPoints=[(0, 5), (3, 0)], finalPoints=[(8, 4), (7, 10)],
+                           initSpeeds=[1] * 2, finalSpeeds=[1] * 2, initAngs=[0, np.pi / 2],
+                           finalAngs=[0, np.pi / 2], pointObstacles=[[3, 2], [6, 7]])
+
+
+def test_example1_guess_and_reshape(P):
+    bo = _example1()
+    xg = bo.generateGuess(std=0)
+    assert np.array_equal(xg, P["ex1_xguess"])
+    assert np.array_equal(bo.reshapeVector(xg), P["ex1_yguess"])
+    assert np.array_equal(bo.reshapeVector(P["ex1_x"]), P["ex1_y"])
+    assert np.allclose(bo.reshapeVector(xg)[0, :3], [0, 0.1, 1.075])
+    assert np.array_equal(bo.generateGuess(std=0.5, seed=3), P["ex1_xguess_std"])
+    assert bo.objectiveFunction(P["ex1_x"]) == float(P["ex1_obj"]) == 3.7
+    assert bo.model['numVeh'] == 2 and bo.pointObstacles == [[3, 2], [6, 7]]
+
+
+def test_swarm_and_fixed_tf_layouts(P):
+    from optimalbeziertrajectorygeneration_amd.optimization import BezOptimization
+    bs = BezOptimization(numVeh=36, dimension=3, degree=5, minimizeGoal='Euclidean', maxSep=0.9,
+                         initPoints=P["sw_init"], finalPoints=P["sw_final"])
+    assert np.array_equal(bs.reshapeVector(P["sw_xguess"]), P["sw_yguess"])
+    assert np.array_equal(bs.reshapeVector(P["sw_x"]), P["sw_y"])
+    assert np.array_equal(bs.generateGuess(std=0), P["sw_genguess"])
+    bf = BezOptimization(numVeh=3, dimension=2, degree=7, minimizeGoal='Euclidean', maxSep=0.5, maxSpeed=4,
+                         minSpeed=0.2, maxAngRate=2, initPoints=[(0, 0), (1, 5), (9, 2)],
+                         finalPoints=[(10, 1), (8, 8), (0, 7)], initSpeeds=[1, 2, 0.5], finalSpeeds=[1, 1, 2],
+                         initAngs=[0.1, -0.4, 2.0], finalAngs=[0.3, 0.0, 2.5], tf=7.0)
+    assert np.array_equal(bf.generateGuess(std=0.4, seed=11), P["fx_x"])
+    assert np.array_equal(bf.reshapeVector(P["fx_x"]), P["fx_y"])
+    bm = BezOptimization(numVeh=2, dimension=2, degree=5, initPoints=np.array([[1, 2], [3, 4]]),
+                         finalPoints=np.array([[5, 6], [7, 8]]), initSpeeds=np.array([3, 3]),
+                         finalSpeeds=np.array([10, 10]), initAngs=np.array([np.pi / 2, np.pi / 2]),
+                         finalAngs=np.array([0, 0]), pointObstacles=[[1, 2], [3, 4]])
+    assert np.array_equal(bm.reshapeVector(P["main_x"]), P["main_y"])
+    assert np.array_equal(bm.generateGuess(), P["main_guess"])
+
+
+def test_batched_reshape_equals_rowwise(P):
+    bo = _example1()
+    X, dx = bo._fd_rows(P["ex1_x"])
+    assert X.shape == (30, 29) and np.all(dx > 0)
+    Y = bo.reshapeVectors(X)
+    for k in (0, 1, 17, 29):
+        assert np.array_equal(Y[k], bo.reshapeVector(X[k]))
+    # the tf row moves the speed columns of every vehicle (optimization.py:276-281)
+    assert (Y[29, :, 1] != Y[0, :, 1]).any() and np.array_equal(Y[29, :, 2:-2], Y[0, :, 2:-2])
+
+
+def test_invalid_goal_raises():
+    from optimalbeziertrajectorygeneration_amd.optimization import BezOptimization
+    bo = BezOptimization(numVeh=1, dimension=2, degree=5, minimizeGoal='nope', initPoints=[(0, 0)],
+                         finalPoints=[(1, 1)])
+    with pytest.raises(ValueError):
+        bo.objectiveFunction
+
+
+def test_bezier_container_semantics():
+    from optimalbeziertrajectorygeneration_amd.bezier import Bezier, RationalBezier
+    c = Bezier([[0, 1, 2], [3, 4, 5]], tf=2.5)          # array-likes are accepted
+    assert c.dim == c.dimension == 2 and c.deg == c.degree == 2 and c.t0 == 0.0 and c.tf == 2.5
+    assert c.x.cpts.shape == (1, 3) and c.z is None and np.array_equal(c.y.cpts, [[3, 4, 5]])
+    assert c.tau.shape == (1001,) and c.tau[-1] == 2.5
+    d = Bezier(np.array([1.0, 2.0, 4.0]))                # 1-D input is promoted (bezier.py:58-61)
+    assert d.dim == 1 and d.deg == 2
+    s = c - Bezier(np.ones((2, 3)), tf=2.5)
+    assert np.array_equal(s.cpts, np.array([[-1, 0, 1], [2, 3, 4]], float)) and s.tf == 2.5
+    assert np.array_equal((c + c).cpts, 2 * c.cpts)
+    with pytest.raises(NotImplementedError):
+        c - Bezier(np.ones((2, 3)), tf=1.0)
+    with pytest.raises(TypeError):
+        c.mul(3)
+    with pytest.raises(ValueError):
+        c.mul(d)
+    with pytest.raises(ValueError):
+        d.minDist(d)
+    r = RationalBezier(np.ones((1, 3)), np.ones((1, 3)))
+    assert r.deg == 2
