@@ -1,6 +1,7 @@
 // C ABI of libobtg_hip.so (include/obtg.h): context, tables, host-buffer entry points.
 // Compiled with hipcc (host code + HIP runtime API); the kernels live in
 // bern_kernels.hip and gjk_kernels.hip.
+#include <algorithm>
 #include <cmath>
 #include <cstring>
 #include <new>
@@ -457,7 +458,7 @@ int obtg_ctx_set_polygons(obtg_ctx* c, const double* pts, int n_pts, const int* 
     (void)hipSetDevice(c->device);
     OBTG_HIP(c, hipStreamSynchronize(c->stream));
     if (n_poly == 0) {
-        c->n_poly = 0; c->n_poly_pts = 0; c->polys_planar = true;
+        c->n_poly = 0; c->n_poly_pts = 0; c->polys_planar = true; c->max_poly_K = 0;
         int zero = 0;
         return upload(c, c->d_poly_off, &zero, sizeof(int));
     }
@@ -470,6 +471,8 @@ int obtg_ctx_set_polygons(obtg_ctx* c, const double* pts, int n_pts, const int* 
     c->n_poly = n_poly; c->n_poly_pts = n_pts;
     c->polys_planar = true;
     for (int k = 0; k < n_pts && c->polys_planar; ++k) c->polys_planar = pts[3 * (size_t)k + 2] == 0.0;
+    c->max_poly_K = 0;
+    for (int a = 0; a < n_poly; ++a) c->max_poly_K = std::max(c->max_poly_K, poly_off[a + 1] - poly_off[a]);
     c->n_hull_pairs = 0;   // object ids may have changed meaning
     return OBTG_OK;
 }

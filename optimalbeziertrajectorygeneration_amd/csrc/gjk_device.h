@@ -475,6 +475,9 @@ __device__ __forceinline__ bool vert_matches2(const Ctx<Mem>& g, const Vert2& o,
 {
     if (!has) return false;
     if (eq2(A, o.v)) return true;
+    // A == p1 and A == p2 forces p1 == p2, i.e. the old vertex p1 - p2 is exactly zero: test that
+    // in registers first, the point loads are then needed (almost) never
+    if (o.v.x != 0.0 || o.v.y != 0.0) return false;
     return eq2(A, point2(g.mem, g.P1, o.i1)) && eq2(A, point2(g.mem, g.P2, o.i2));
 }
 

@@ -149,7 +149,9 @@ __device__ __forceinline__ void gjk_sweep_planar(int c_end, int* s_next, int max
             } else {
                 ++rr;
                 if (gjk::matches_old2(g, old, s.A.v)) {
+#ifndef OBTG_EXP_NOFINAL
                     gjk::closest_from_simplex(g, gjk::lift(old), r);
+#endif
                     r.flag = 1; done = true;
                 } else if (rr >= md_cap) { r.flag = 1; r.status = OBTG_ST_MD_CAP; done = true; }
             }
@@ -276,6 +278,176 @@ __global__ __launch_bounds__(256) void k_gjk_swarm(const GjkSwarmParams p)
             if (p.nsup) p.nsup[o] = r.n_support;
             if (p.status) p.status[o] = r.status;
         });
+}
+
+// -------------------------------------------------------------------------------------
+//  Planar swarm sweep, fixed point count: the fast path of the 2-D configurations.
+//  Every object of a row (vehicle hulls AND polygons) is staged in LDS as x[NC] y[NC] with one
+//  odd pitch; polygons with fewer than NC vertices are padded with copies of their vertex 0,
+//  which can never win the strict '>' of the support scan (gjk.py:109), so indices are
+//  unchanged.  The scan is then a fully unrolled 2*NC-point loop with immediate LDS offsets.
+//  Phase 1 runs the state machine and leaves a 16-byte record per pair in LDS (final simplex
+//  as support indices); phase 2 turns records into closest points / distance with one lane
+//  per pair, convergent and with coalesced output stores.
+// -------------------------------------------------------------------------------------
+template <int NC>
+struct PlanarShape {
+    static constexpr int VP = (2 * NC) % 2 == 0 ? 2 * NC + 1 : 2 * NC;   // odd pitch in doubles
+};
+
+template <int NC>
+__device__ __forceinline__ void support_fixed(const double* __restrict__ o1, const double* __restrict__ o2,
+                                              const gjk::V2& d, gjk::Vert2& out)
+{
+    const double ndx = -d.x, ndy = -d.y;
+    int i1 = 0, i2 = 0;
+    double m1 = o1[0] * d.x + o1[NC] * d.y;
+    double m2 = o2[0] * ndx + o2[NC] * ndy;
+#pragma unroll
+    for (int i = 1; i < NC; ++i) {
+        const double c1 = o1[i] * d.x + o1[NC + i] * d.y;
+        const double c2 = o2[i] * ndx + o2[NC + i] * ndy;
+        if (c1 > m1) { m1 = c1; i1 = i; }
+        if (c2 > m2) { m2 = c2; i2 = i; }
+    }
+    out.i1 = i1; out.i2 = i2;
+    out.v = gjk::V2{ o1[i1] - o2[i2], o1[NC + i1] - o2[NC + i2] };
+}
+
+template <int NC>
+__global__ __launch_bounds__(256) void k_gjk_swarm_planar(const GjkSwarmParams p)
+{
+    using gjk::V2;
+    using gjk::Vert2;
+    using gjk::Simplex2;
+    constexpr int VP = PlanarShape<NC>::VP;
+    extern __shared__ double lds[];
+    __shared__ int s_next;
+    const int n_obj = p.n_veh + p.n_poly;
+    const int b = blockIdx.x / p.wgs_per_row, w = blockIdx.x - b * p.wgs_per_row;
+    const int c0 = w * p.chunk, c1 = min(p.n_pairs, c0 + p.chunk);
+    int4* rec = reinterpret_cast<int4*>(lds + ((n_obj * VP + 1) & ~1));     // 16-byte aligned
+
+    // ---- stage vehicles (rows x, y of the evaluation row) and padded polygons
+    const double* Yrow = p.Y + (size_t)b * p.n_veh * 2 * NC;
+    for (int e = threadIdx.x; e < p.n_veh * 2 * NC; e += blockDim.x) {
+        const int v = e / (2 * NC), r = e - v * (2 * NC);
+        lds[v * VP + r] = Yrow[e];
+    }
+    for (int e = threadIdx.x; e < p.n_poly * 2 * NC; e += blockDim.x) {
+        const int o = e / (2 * NC), r = e - o * (2 * NC), q = r / NC, k = r - q * NC;
+        const int off = p.poly_off[o], K = p.poly_off[o + 1] - off;
+        lds[(p.n_veh + o) * VP + r] = p.poly[3 * off + q * K + (k < K ? k : 0)];
+    }
+    if (threadIdx.x == 0) s_next = c0;
+    __syncthreads();
+
+    // ---- phase 1: state machine with lane refill
+    {
+        const int lane = threadIdx.x & (kWave - 1);
+        int k = -1;
+        bool exhausted = false;
+        const double* o1 = lds;
+        const double* o2 = lds;
+        Simplex2 s, old;
+        V2 dir{ 1.0, 0.0 };
+        int phase = 0, it = 0, rr = 0, nsup = 0;
+        s.keys = 0;
+        s.A = Vert2{ V2{ 0, 0 }, 0, 0 };
+        s.B = s.A; s.C = s.A; old = s;
+        for (;;) {
+            const unsigned long long want = __ballot(k < 0 && !exhausted);
+            if (want) {
+                const int leader = __ffsll((long long)want) - 1;
+                int base = 0;
+                if (lane == leader) base = atomicAdd(&s_next, __popcll(want));
+                base = __shfl(base, leader);
+                if (k < 0 && !exhausted) {
+                    const int my = base + __popcll(want & ((1ull << lane) - 1ull));
+                    if (my < c1) {
+                        k = my;
+                        o1 = lds + p.pa[k] * VP;
+                        o2 = lds + p.pb[k] * VP;
+                        s.keys = 0; dir = V2{ 1.0, 0.0 };
+                        phase = 0; it = 0; rr = 0; nsup = 0;
+                    } else exhausted = true;
+                }
+            }
+            if (__ballot(k >= 0) == 0ull) break;
+            if (k >= 0) {
+                if (phase == 1) old = s;
+                gjk::simplex_update2(s, dir);
+                support_fixed<NC>(o1, o2, dir, s.A);
+                s.keys |= gjk::kA;
+                ++nsup;
+                int flag = -2, status = OBTG_ST_OK;       // -2: not finished
+                if (phase == 0) {
+                    ++it;
+                    if (s.keys & gjk::kColl) flag = 0;
+                    else if (gjk::dotb2(s.A.v, dir) < 0) { phase = 1; rr = 0; }
+                    else if (it >= p.max_iter) { flag = -1; status = OBTG_ST_MAXITER; }
+                } else {
+                    ++rr;
+                    // converged iff the new A equals any value of the old dict (gjk.py:281-294)
+                    bool m = false;
+                    if ((old.keys & gjk::kA) && (gjk::eq2(s.A.v, old.A.v) ||
+                        (old.A.v.x == 0.0 && old.A.v.y == 0.0 && s.A.v.x == o1[old.A.i1] && s.A.v.y == o1[NC + old.A.i1] &&
+                         s.A.v.x == o2[old.A.i2] && s.A.v.y == o2[NC + old.A.i2]))) m = true;
+                    if ((old.keys & gjk::kB) && (gjk::eq2(s.A.v, old.B.v) ||
+                        (old.B.v.x == 0.0 && old.B.v.y == 0.0 && s.A.v.x == o1[old.B.i1] && s.A.v.y == o1[NC + old.B.i1] &&
+                         s.A.v.x == o2[old.B.i2] && s.A.v.y == o2[NC + old.B.i2]))) m = true;
+                    if ((old.keys & gjk::kC) && (gjk::eq2(s.A.v, old.C.v) ||
+                        (old.C.v.x == 0.0 && old.C.v.y == 0.0 && s.A.v.x == o1[old.C.i1] && s.A.v.y == o1[NC + old.C.i1] &&
+                         s.A.v.x == o2[old.C.i2] && s.A.v.y == o2[NC + old.C.i2]))) m = true;
+                    if (m) flag = 1;
+                    else if (rr >= p.md_cap) { flag = 1; status = OBTG_ST_MD_CAP; }
+                }
+                if (flag != -2) {
+                    int4 r;
+                    r.x = (flag & 0xff) | (status << 8) | (old.keys << 16);
+                    r.y = nsup;
+                    r.z = old.A.i1 | (old.A.i2 << 8) | (old.B.i1 << 16) | (old.B.i2 << 24);
+                    r.w = old.C.i1 | (old.C.i2 << 8);
+                    rec[k - c0] = r;
+                    k = -1;
+                }
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- phase 2: closest points / distance from the recorded simplices (gjk.py:299-360)
+    const size_t obase = (size_t)b * p.n_pairs;
+    const double qnan = __builtin_nan("");
+    for (int k = c0 + (int)threadIdx.x; k < c1; k += blockDim.x) {
+        const int4 r4 = rec[k - c0];
+        const int flag = (int)(signed char)(r4.x & 0xff), status = (r4.x >> 8) & 0xff, keys = (r4.x >> 16) & 0xff;
+        Result r;
+        r.c1 = V3{ qnan, qnan, qnan }; r.c2 = r.c1; r.dist = qnan;
+        if (flag == 1 && status == OBTG_ST_OK) {
+            Ctx<MemLds> g;
+            g.mem = MemLds{ lds };
+            g.P1 = Poly{ p.pa[k] * VP, NC, NC, 0 };
+            g.P2 = Poly{ p.pb[k] * VP, NC, NC, 0 };
+            g.trace = nullptr; g.trace_cap = 0; g.n_support = 0;
+            gjk::Simplex s;
+            s.keys = keys;
+            const int ia1 = r4.z & 0xff, ia2 = (r4.z >> 8) & 0xff, ib1 = (r4.z >> 16) & 0xff, ib2 = (r4.z >> 24) & 0xff;
+            const int ic1 = r4.w & 0xff, ic2 = (r4.w >> 8) & 0xff;
+            s.A = gjk::Vert{ gjk::sub(gjk::point(g.mem, g.P1, ia1), gjk::point(g.mem, g.P2, ia2)), ia1, ia2 };
+            s.B = gjk::Vert{ gjk::sub(gjk::point(g.mem, g.P1, ib1), gjk::point(g.mem, g.P2, ib2)), ib1, ib2 };
+            s.C = gjk::Vert{ gjk::sub(gjk::point(g.mem, g.P1, ic1), gjk::point(g.mem, g.P2, ic2)), ic1, ic2 };
+            s.D = s.A;
+            gjk::closest_from_simplex(g, s, r);
+        }
+        const size_t o = obase + k;
+        p.flag[o] = flag;
+        p.p1[3 * o] = r.c1.x; p.p1[3 * o + 1] = r.c1.y; p.p1[3 * o + 2] = r.c1.z;
+        p.p2[3 * o] = r.c2.x; p.p2[3 * o + 1] = r.c2.y; p.p2[3 * o + 2] = r.c2.z;
+        p.dist[o] = r.dist;
+        if (p.nsup) p.nsup[o] = r4.y;
+        if (p.status) p.status[o] = status;
+    }
 }
 
 // -------------------------------------------------------------------------------------
@@ -626,6 +798,31 @@ int launch_gjk_swarm(obtg_ctx* c, const double* dY, int B, int max_iter, int md_
     size_t lds = sizeof(double) * ((size_t)c->n_veh * p.vp + 3 * (size_t)c->n_poly_pts);
     if (lds > 160 * 1024 - 64) return OBTG_ERR_UNSUPPORTED;
     const bool planar = c->dim == 2 && c->polys_planar;
+    if (planar && c->max_poly_K <= c->deg + 1 && c->deg + 1 <= 127) {
+        const int nc = c->deg + 1;
+        const int vp2 = 2 * nc + 1;
+        const size_t lds2 = sizeof(double) * (((size_t)(c->n_veh + c->n_poly) * vp2 + 1) & ~(size_t)1) +
+                            sizeof(int4) * (size_t)p.chunk;
+        void (*kp)(const GjkSwarmParams) = nullptr;
+        switch (nc) {
+            case 4: kp = k_gjk_swarm_planar<4>; break;
+            case 6: kp = k_gjk_swarm_planar<6>; break;
+            case 8: kp = k_gjk_swarm_planar<8>; break;
+            case 11: kp = k_gjk_swarm_planar<11>; break;
+            case 16: kp = k_gjk_swarm_planar<16>; break;
+            case 21: kp = k_gjk_swarm_planar<21>; break;
+            default: break;
+        }
+        if (kp && lds2 <= 64 * 1024) {
+            if (lds2 > 48 * 1024)
+                OBTG_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(kp),
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
+            ScopedKernelTimer t(c, OBTG_K_GJK);
+            hipLaunchKernelGGL(kp, dim3((unsigned)((size_t)B * p.wgs_per_row)), dim3(256), lds2, c->stream, p);
+            OBTG_HIP(c, hipGetLastError());
+            return OBTG_OK;
+        }
+    }
     auto kern = planar ? k_gjk_swarm<true> : k_gjk_swarm<false>;
     if (lds > 48 * 1024)
         OBTG_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
