@@ -342,6 +342,26 @@ __global__ __launch_bounds__(256) void k_gjk_swarm_planar(const GjkSwarmParams p
     if (threadIdx.x == 0) s_next = c0;
     __syncthreads();
 
+    // ---- the first two doSimplex steps of every pair use the fixed directions (1,0,0) and
+    // (-1,-0,-0) (gjk.py:247, 544): their support scans depend on one object only, so they are
+    // done once per object and row.  x*1 + y*0 == x and x*(-1) + y*(-0) == -x exactly, hence
+    // "first index of max x" / "first index of min x" are the reference's answers.
+    int* ext = reinterpret_cast<int*>(rec + p.chunk);      // [n_obj][2]: (first argmax x, first argmin x)
+    for (int o = threadIdx.x; o < n_obj; o += blockDim.x) {
+        const double* q = lds + o * VP;
+        int imx = 0, imn = 0;
+        double mx = q[0] * 1.0 + q[NC] * 0.0, mn = q[0] * -1.0 + q[NC] * -0.0;
+#pragma unroll
+        for (int i = 1; i < NC; ++i) {
+            const double c1 = q[i] * 1.0 + q[NC + i] * 0.0, c2 = q[i] * -1.0 + q[NC + i] * -0.0;
+            if (c1 > mx) { mx = c1; imx = i; }
+            if (c2 > mn) { mn = c2; imn = i; }
+        }
+        ext[2 * o] = imx; ext[2 * o + 1] = imn;
+    }
+    __syncthreads();
+    const bool shortcut = p.max_iter >= 3 && p.md_cap >= 2;
+
     // ---- phase 1: state machine with lane refill
     {
         const int lane = threadIdx.x & (kWave - 1);
@@ -366,10 +386,40 @@ __global__ __launch_bounds__(256) void k_gjk_swarm_planar(const GjkSwarmParams p
                     const int my = base + __popcll(want & ((1ull << lane) - 1ull));
                     if (my < c1) {
                         k = my;
-                        o1 = lds + p.pa[k] * VP;
-                        o2 = lds + p.pb[k] * VP;
+                        const int a = p.pa[k], bb = p.pb[k];
+                        o1 = lds + a * VP;
+                        o2 = lds + bb * VP;
                         s.keys = 0; dir = V2{ 1.0, 0.0 };
                         phase = 0; it = 0; rr = 0; nsup = 0;
+                        if (shortcut) {
+                            // state after doSimplex #1 (0pt) and #2 (1pt)
+                            const int ax = ext[2 * a], an = ext[2 * a + 1], bx = ext[2 * bb], bn = ext[2 * bb + 1];
+                            const Vert2 A1{ V2{ o1[ax] - o2[bn], o1[NC + ax] - o2[NC + bn] }, ax, bn };
+                            const Vert2 A2{ V2{ o1[an] - o2[bx], o1[NC + an] - o2[NC + bx] }, an, bx };
+                            const bool md1 = gjk::dotb2(A1.v, dir) < 0;       // exit of iteration 1 (gjk.py:260)
+                            dir = gjk::neg2(dir);
+                            s.B = A1; s.A = A2; s.keys = gjk::kA | gjk::kB;
+                            nsup = 2;
+                            if (!md1) {
+                                it = 2;
+                                if (gjk::dotb2(A2.v, dir) < 0) { phase = 1; rr = 0; }
+                            } else {
+                                // iteration 2 ran inside minimumDistance with old = {A1}
+                                phase = 1; rr = 1;
+                                const bool m = gjk::eq2(A2.v, A1.v) ||
+                                    (A1.v.x == 0.0 && A1.v.y == 0.0 && A2.v.x == o1[ax] && A2.v.y == o1[NC + ax] &&
+                                     A2.v.x == o2[bn] && A2.v.y == o2[NC + bn]);
+                                if (m) {
+                                    int4 r;
+                                    r.x = 1 | (OBTG_ST_OK << 8) | (gjk::kA << 16);
+                                    r.y = nsup;
+                                    r.z = A1.i1 | (A1.i2 << 8);
+                                    r.w = 0;
+                                    rec[k - c0] = r;
+                                    k = -1;
+                                }
+                            }
+                        }
                     } else exhausted = true;
                 }
             }
@@ -802,7 +852,7 @@ int launch_gjk_swarm(obtg_ctx* c, const double* dY, int B, int max_iter, int md_
         const int nc = c->deg + 1;
         const int vp2 = 2 * nc + 1;
         const size_t lds2 = sizeof(double) * (((size_t)(c->n_veh + c->n_poly) * vp2 + 1) & ~(size_t)1) +
-                            sizeof(int4) * (size_t)p.chunk;
+                            sizeof(int4) * (size_t)p.chunk + sizeof(int) * 2 * (size_t)(c->n_veh + c->n_poly);
         void (*kp)(const GjkSwarmParams) = nullptr;
         switch (nc) {
             case 4: kp = k_gjk_swarm_planar<4>; break;
