@@ -120,12 +120,13 @@ def main():
 
     def step():
         ctx.temporal_sep_dev(dY.data_ptr(), B, max_sep, o_sep.data_ptr())
-        ctx.speed_dev(dY.data_ptr(), d_tf.data_ptr(), B, vmax, True, o_sp.data_ptr())
-        if o_an is not None:
-            ctx.ang_rate_dev(dY.data_ptr(), d_tf.data_ptr(), B, wmax, o_an.data_ptr())
+        if o_an is not None:    # speed + angular rate share their derivative curves: one launch
+            ctx.dynamics_dev(dY.data_ptr(), d_tf.data_ptr(), B, vmax, True, wmax, o_sp.data_ptr(), o_an.data_ptr())
+        else:
+            ctx.speed_dev(dY.data_ptr(), d_tf.data_ptr(), B, vmax, True, o_sp.data_ptr())
         if use_gjk:
             ctx.gjk_swarm_dev(dY.data_ptr(), B, g_flag.data_ptr(), g_p1.data_ptr(), g_p2.data_ptr(),
-                              g_dist.data_ptr(), None, None, 128, 4096)
+                              g_dist.data_ptr(), None, None, 128, 256)
 
     def barrier():
         if world > 1:
@@ -160,6 +161,8 @@ def main():
     sumK = N * (n + 1) + (int(poff[-1]) if M else 0)
     by, total_bytes = algorithmic_bytes(N, d, n, R, P_t, P_s, sumK)
     kernels = []
+    if o_an is not None:   # the fused dynamics launch is booked under "ang_rate"
+        by["ang_rate"] = by["ang_rate"] + 8 * N * L
     for name in ("temporal_sep", "speed", "ang_rate", "gjk"):
         ms, cnt = stats.get(name, (0.0, 0))
         if cnt == 0:

@@ -124,6 +124,11 @@ int obtg_speed_dev(obtg_ctx*, const double* dY, const double* d_tf, int B, doubl
                    double* d_out);
 int obtg_ang_rate_dev(obtg_ctx*, const double* dY, const double* d_tf, int B, double max_rate,
                       double* d_out);
+/* speed and angular-rate constraints of the same rows in one launch (they share the derivative
+ * curves: for d = 2 the speed curve is the angular rate's denominator before squaring,
+ * optimization.py:380 vs 605).  Either output may be NULL. */
+int obtg_dynamics_dev(obtg_ctx*, const double* dY, const double* d_tf, int B, double speed_bound,
+                      int speed_is_max, double max_rate, double* d_out_speed, double* d_out_ang);
 
 /* ---- finite-difference batch on the device --------------------------------------------
  * Replaces the n_x+1 serial calls SciPy's approx_derivative makes: builds

@@ -46,6 +46,7 @@ _SIGNATURES = {
     "obtg_temporal_sep_min_dev": (_i, [_vp, _vp, _i, _d, _i, _i, _vp]),
     "obtg_speed_dev": (_i, [_vp, _vp, _vp, _i, _d, _i, _vp]),
     "obtg_ang_rate_dev": (_i, [_vp, _vp, _vp, _i, _d, _vp]),
+    "obtg_dynamics_dev": (_i, [_vp, _vp, _vp, _i, _d, _i, _d, _vp, _vp]),
     "obtg_fd_batch_dev": (_i, [_vp, _vp, _i, _d, _i, _vp]),
     "obtg_gjk_pairs": (_i, [_vp, _vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp]),
     "obtg_ctx_set_polygons": (_i, [_vp, _vp, _i, _vp, _i]),
@@ -290,6 +291,11 @@ class Context(object):
     def ang_rate_dev(self, dY, d_tf, B, max_rate, d_out):
         self._check(self._lib.obtg_ang_rate_dev(self._h, _vp(dY), _vp(d_tf), B, float(max_rate), _vp(d_out)),
                     "obtg_ang_rate_dev")
+
+    def dynamics_dev(self, dY, d_tf, B, speed_bound, speed_is_max, max_rate, d_out_speed, d_out_ang):
+        self._check(self._lib.obtg_dynamics_dev(self._h, _vp(dY), _vp(d_tf), B, float(speed_bound),
+                                                int(bool(speed_is_max)), float(max_rate), _vp(d_out_speed),
+                                                _vp(d_out_ang)), "obtg_dynamics_dev")
 
     def fd_batch_dev(self, dY0, n_fixed_cols, h, B, dY):
         self._check(self._lib.obtg_fd_batch_dev(self._h, _vp(dY0), int(n_fixed_cols), float(h), B, _vp(dY)),

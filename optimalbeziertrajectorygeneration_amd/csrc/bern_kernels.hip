@@ -28,6 +28,29 @@
 
 namespace obtg {
 
+// Read-only coefficient tables are addressed through the CONSTANT address space: their loads
+// have wave-uniform addresses and must become scalar loads (s_load_dwordxN into SGPRs, usable
+// directly as v_fma_f64 operands).  Through a plain global pointer the compiler cannot prove
+// that the kernel's own stores do not clobber the table and falls back to one vector load +
+// s_waitcnt vmcnt(0) per product row -- a serialised L2 round trip per row (measured with
+// s_memtime stamps: 8.5 k cycles for the 200 FMAs of one group, 1.7 k after this change).
+typedef const double __attribute__((address_space(4))) * ctab_t;
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Wold-style-cast"
+__device__ __forceinline__ ctab_t as_ctab(const double* p) { return (ctab_t)p; }
+#pragma clang diagnostic pop
+
+// The constraint vectors are written once and never re-read by these kernels: non-temporal
+// stores keep the 390 MB output stream from evicting the control points from L2 / Infinity
+// Cache (measured: -10 % kernel time on the temporal sweep).
+typedef double d2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void store_nt(double* p, double v) { __builtin_nontemporal_store(v, p); }
+__device__ __forceinline__ void store_nt2(double* p, double v0, double v1)
+{
+    d2_t v; v.x = v0; v.y = v1;
+    __builtin_nontemporal_store(v, reinterpret_cast<d2_t*>(p));
+}
+
 // =====================================================================================
 //  fast path: register-resident product, one item per lane
 // =====================================================================================
@@ -79,9 +102,19 @@ __device__ __forceinline__ void stage_objects(double* __restrict__ vl, const dou
     }
 }
 
+// LDS traffic between the lanes of ONE wave only needs wave-level ordering (a wave's DS
+// operations complete in issue order); a workgroup barrier here would also be unsafe because
+// the waves of a workgroup run different numbers of groups.
+__device__ __forceinline__ void wave_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 // (d/2) * sum_q a_q^2 as Bernstein coefficients c[0..L)
 template <int NC, int DIM>
-__device__ __forceinline__ void normsq_coeffs(const double (&a)[DIM][NC], const double* __restrict__ W2,
+__device__ __forceinline__ void normsq_coeffs(const double (&a)[DIM][NC], ctab_t W2,
                                               double (&c)[2 * NC - 1])
 {
     constexpr int N = NC - 1, L = 2 * N + 1;
@@ -112,13 +145,9 @@ __device__ __forceinline__ void flush_full(const double* __restrict__ tile, doub
         double v0 = 0.0, v1 = 0.0;
         if (e0 >= 0) { const int pr = e0 / LR, q = e0 - pr * LR; v0 = tile[pr * TP + q]; }
         if (e1 < total) { const int pr = e1 / LR, q = e1 - pr * LR; v1 = tile[pr * TP + q]; }
-        if (e0 >= 0 && e1 < total) {
-            *reinterpret_cast<double2*>(gout + gbase + e0) = make_double2(v0, v1);
-        } else if (e0 >= 0) {
-            gout[gbase + e0] = v0;
-        } else if (e1 < total) {
-            gout[gbase + e1] = v1;
-        }
+        if (e0 >= 0 && e1 < total) store_nt2(gout + gbase + e0, v0, v1);
+        else if (e0 >= 0) store_nt(gout + gbase + e0, v0);
+        else if (e1 < total) store_nt(gout + gbase + e1, v1);
     }
 }
 
@@ -130,18 +159,8 @@ __device__ __forceinline__ void flush_chunk(const double* __restrict__ tile, dou
     const int total = n_valid * kc;
     for (int e = lane; e < total; e += kWave) {
         const int pr = e / kc, q = e - pr * kc;
-        gout[grow + (size_t)pr * LR + k0 + q] = tile[pr * TP + q];
+        store_nt(gout + grow + (size_t)pr * LR + k0 + q, tile[pr * TP + q]);
     }
-}
-
-// LDS traffic between the lanes of ONE wave only needs wave-level ordering (a wave's DS
-// operations complete in issue order); a workgroup barrier here would also be unsafe because
-// the waves of a workgroup run different numbers of groups.
-__device__ __forceinline__ void wave_sync()
-{
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
 template <int NC, int DIM, int MODE /*0 = pairs, 1 = vehicles*/, bool MINONLY>
@@ -225,7 +244,7 @@ __global__ __launch_bounds__(256) void k_normsq_elev(const NsParams p)
         }
 
         double cf[L];
-        normsq_coeffs<NC, DIM>(a, p.W2, cf);
+        normsq_coeffs<NC, DIM>(a, as_ctab(p.W2), cf);
 
         const size_t row = (size_t)b * p.item_count + (size_t)(itg - p.item_begin);
         if (p.R == 0) {
@@ -252,7 +271,7 @@ __global__ __launch_bounds__(256) void k_normsq_elev(const NsParams p)
             for (int k0 = 0; k0 < LR; k0 += kTileK) {
                 const int kc = min(kTileK, LR - k0);
                 for (int kk = 0; kk < kc; ++kk) {
-                    const double* __restrict__ Tr = p.Tt + (size_t)(k0 + kk) * L;
+                    const ctab_t Tr = as_ctab(p.Tt) + (size_t)(k0 + kk) * L;
                     double s = 0.0;
 #pragma unroll
                     for (int j = 0; j < L; ++j) s = fma(cf[j], Tr[j], s);
@@ -279,9 +298,11 @@ struct AngParams {
     const double* __restrict__ W2n;  // folded weights degree n,   dim factor 1   [2n+1][n+1]
     const double* __restrict__ W22n; // folded weights degree 2n,  dim factor 1   [4n+1][2n+1]
     const double* __restrict__ Wn;   // plain weights  degree n                   [2n+1][n+1]
-    double* __restrict__ out;        // [B][n_veh][4n+1]
+    double* __restrict__ out;        // [B][n_veh][4n+1]           (nullable)
+    double* __restrict__ out_speed;  // [B][n_veh][2n+1]           (nullable)
     int n_veh, total;                // total = B * n_veh
-    double w2;
+    double w2;                       // max_rate^2
+    double sp_sign, sp_offset;       // speed output = sp_sign * |v|^2 + sp_offset
 };
 
 template <int NC>
@@ -297,15 +318,62 @@ __device__ __forceinline__ void diff_elev1(const double (&p)[NC], double val, do
     for (int c = 1; c < N; ++c) d[c] = t[c - 1] * ((double)c / (double)N) + t[c] * ((double)(N - c) / (double)N);
 }
 
-template <int NC>
-__global__ __launch_bounds__(kWave) void k_angrate(const AngParams p)
+// The degree-4n stage (41 coefficients at n = 10, each a folded product row plus one FP64
+// division) is split over kDynParts waves per group of 64 vehicles; boundaries balance the
+// folded term counts (+ a division's worth per coefficient).
+constexpr int kDynParts = 4;
+constexpr int dyn_cost(int k, int n2) { return k / 2 - (k - n2 > 0 ? k - n2 : 0) + 1 + 6; }
+constexpr int dyn_bound(int n2, int q)
+{
+    const int L = 2 * n2 + 1;
+    long T = 0;
+    for (int k = 0; k < L; ++k) T += dyn_cost(k, n2);
+    const long target = T * q / kDynParts;
+    long cum = 0;
+    for (int k = 0; k < L; ++k) {
+        if (cum >= target) return k;
+        cum += dyn_cost(k, n2);
+    }
+    return L;
+}
+
+template <int NC, int PART>
+__device__ __forceinline__ void dyn_final(const AngParams& p, const double (&num1)[2 * NC - 1],
+                                          const double (&den1)[2 * NC - 1], double* tile, size_t grow,
+                                          int n_valid, int lane)
 {
     constexpr int N = NC - 1, L2 = 2 * N + 1, L4 = 4 * N + 1;
-    constexpr int TP = L4;   // odd
+    constexpr int K0 = dyn_bound(2 * N, PART), K1 = dyn_bound(2 * N, PART + 1);
+    const ctab_t W22n = as_ctab(p.W22n);
+    // num = num1^2, den = den1^2 (degree 4n); constraint = w^2 - num.cpts / den.cpts
+#pragma unroll
+    for (int k = K0; k < K1; ++k) {
+        double sn = 0.0, sd = 0.0;
+#pragma unroll
+        for (int j = (k - 2 * N > 0 ? k - 2 * N : 0); 2 * j <= k; ++j) {
+            const double wkj = W22n[k * L2 + j];
+            sn = fma(wkj, num1[j] * num1[k - j], sn);
+            sd = fma(wkj, den1[j] * den1[k - j], sd);
+        }
+        tile[lane * L4 + (k - K0)] = p.w2 - sn / sd;
+    }
+    wave_sync();
+    flush_chunk<L4>(tile, p.out, grow, L4, K0, K1 - K0, n_valid, lane);
+}
+
+// angular rate (optimization.py:425-459, 578-611) and, from the same derivatives, the speed
+// constraint (optimization.py:349-422): for d = 2 the speed curve (d/2)(xD^2 + yD^2) IS den1.
+template <int NC>
+__global__ __launch_bounds__(kWave) void k_dynamics(const AngParams p)
+{
+    constexpr int N = NC - 1, L2 = 2 * N + 1, L4 = 4 * N + 1;
     extern __shared__ double lds[];
     const int lane = threadIdx.x;
-    const int it0 = blockIdx.x * kWave;
+    const int part = blockIdx.x % kDynParts;
+    const int it0 = (blockIdx.x / kDynParts) * kWave;
     if (it0 >= p.total) return;
+    const bool want_ang = p.out != nullptr;
+    if (!want_ang && part != 0) return;
     const int n_valid = min(kWave, p.total - it0);
     const int item = min(it0 + lane, p.total - 1);
     const int b = item / p.n_veh;
@@ -321,36 +389,40 @@ __global__ __launch_bounds__(kWave) void k_angrate(const AngParams p)
     diff_elev1<NC>(yD, val, yDD);
 
     // num1 = yDD*xD - xDD*yD,  den1 = xD*xD + yD*yD     (degree 2n, optimization.py:603-605)
+    const ctab_t Wn = as_ctab(p.Wn), W2n = as_ctab(p.W2n);
     double num1[L2], den1[L2];
 #pragma unroll
     for (int k = 0; k < L2; ++k) {
         double s1 = 0.0, s2 = 0.0, sd = 0.0;
+        if (want_ang) {
 #pragma unroll
-        for (int j = (k - N > 0 ? k - N : 0); j <= (N < k ? N : k); ++j) {
-            const double wkj = p.Wn[k * NC + j];
-            s1 = fma(wkj, yDD[j] * xD[k - j], s1);
-            s2 = fma(wkj, xDD[j] * yD[k - j], s2);
+            for (int j = (k - N > 0 ? k - N : 0); j <= (N < k ? N : k); ++j) {
+                const double wkj = Wn[k * NC + j];
+                s1 = fma(wkj, yDD[j] * xD[k - j], s1);
+                s2 = fma(wkj, xDD[j] * yD[k - j], s2);
+            }
         }
 #pragma unroll
         for (int j = (k - N > 0 ? k - N : 0); 2 * j <= k; ++j)
-            sd = fma(p.W2n[k * NC + j], fma(xD[j], xD[k - j], yD[j] * yD[k - j]), sd);
+            sd = fma(W2n[k * NC + j], fma(xD[j], xD[k - j], yD[j] * yD[k - j]), sd);
         num1[k] = s1 - s2;
         den1[k] = sd;
     }
-    // num = num1^2, den = den1^2 (degree 4n); constraint = w^2 - num.cpts / den.cpts
+    if (p.out_speed && part == 0) {
 #pragma unroll
-    for (int k = 0; k < L4; ++k) {
-        double sn = 0.0, sd = 0.0;
-#pragma unroll
-        for (int j = (k - 2 * N > 0 ? k - 2 * N : 0); 2 * j <= k; ++j) {
-            const double wkj = p.W22n[k * L2 + j];
-            sn = fma(wkj, num1[j] * num1[k - j], sn);
-            sd = fma(wkj, den1[j] * den1[k - j], sd);
-        }
-        lds[lane * TP + k] = p.w2 - sn / sd;
+        for (int k = 0; k < L2; ++k) lds[lane * L2 + k] = p.sp_sign * den1[k] + p.sp_offset;
+        wave_sync();
+        flush_full<L2, L2>(lds, p.out_speed, (size_t)it0 * L2, n_valid, lane);
+        wave_sync();
     }
-    __syncthreads();
-    flush_full<L4, TP>(lds, p.out, (size_t)it0 * L4, n_valid, lane);
+    if (!want_ang) return;
+    const size_t grow = (size_t)it0 * L4;
+    switch (part) {
+        case 0: dyn_final<NC, 0>(p, num1, den1, lds, grow, n_valid, lane); break;
+        case 1: dyn_final<NC, 1>(p, num1, den1, lds, grow, n_valid, lane); break;
+        case 2: dyn_final<NC, 2>(p, num1, den1, lds, grow, n_valid, lane); break;
+        default: dyn_final<NC, 3>(p, num1, den1, lds, grow, n_valid, lane); break;
+    }
 }
 
 // =====================================================================================
@@ -742,7 +814,7 @@ int launch_temporal_sep(obtg_ctx* c, const double* dY, int B, double max_sep, in
         // groups of 64 pairs.  Keep >= ~4k workgroups so that 256 CUs x 4 resident stay fed.
         int groups_total = (pair_count + kWave - 1) / kWave;
         p.waves = groups_total >= 4 ? 4 : groups_total;
-        int gpw = 8;   // groups per workgroup
+        int gpw = 16;   // groups per workgroup
         while (gpw > p.waves && (long)B * ((groups_total + gpw - 1) / gpw) < 4096) gpw >>= 1;
         if (gpw < p.waves) gpw = p.waves;
         p.groups_per_wg = gpw;
@@ -819,14 +891,52 @@ int launch_speed(obtg_ctx* c, const double* dY, const double* d_tf, int B, doubl
 }
 
 template <int NC>
-static int launch_ang_t(obtg_ctx* c, const AngParams& p)
+static int launch_dyn_t(obtg_ctx* c, const AngParams& p, int kernel_id)
 {
     constexpr int L4 = 4 * (NC - 1) + 1;
     size_t lds = sizeof(double) * kWave * L4;
-    ScopedKernelTimer t(c, OBTG_K_ANG_RATE);
-    hipLaunchKernelGGL(k_angrate<NC>, dim3((unsigned)((p.total + kWave - 1) / kWave)), dim3(kWave), lds,
-                       c->stream, p);
+    const unsigned groups = (unsigned)((p.total + kWave - 1) / kWave);
+    ScopedKernelTimer t(c, kernel_id);
+    hipLaunchKernelGGL(k_dynamics<NC>, dim3(groups * kDynParts), dim3(kWave), lds, c->stream, p);
     OBTG_HIP(c, hipGetLastError());
+    return OBTG_OK;
+}
+
+static bool dyn_fast(const obtg_ctx* c)
+{
+    const int nc = c->deg + 1;
+    return c->dim == 2 && c->R == 0 && (nc == 4 || nc == 6 || nc == 8 || nc == 11 || nc == 16);
+}
+
+// speed and/or angular rate in one launch (either output may be null)
+int launch_dynamics(obtg_ctx* c, const double* dY, const double* d_tf, int B, double bound, int is_max,
+                    double max_rate, double* d_out_speed, double* d_out_ang)
+{
+    if (B <= 0) return OBTG_OK;
+    int rc = ensure_tables(c);
+    if (rc) return rc;
+    if (d_out_ang && c->dim != 2) return OBTG_ERR_ARG;   // optimization.py:590-593 raises for dim != 2
+    if (dyn_fast(c)) {
+        AngParams p{};
+        p.Y = dY; p.tf = d_tf; p.out = d_out_ang; p.out_speed = d_out_speed;
+        p.n_veh = c->n_veh; p.total = B * c->n_veh;
+        p.w2 = max_rate * max_rate;
+        const double b2 = bound * bound;
+        p.sp_sign = is_max ? -1.0 : 1.0; p.sp_offset = is_max ? b2 : -b2;
+        p.W2n = c->d_ang_w2n.as<double>();
+        p.W22n = c->d_ang_w22n.as<double>();
+        p.Wn = c->d_ang_wn.as<double>();
+        const int kid = d_out_ang ? OBTG_K_ANG_RATE : OBTG_K_SPEED;
+        switch (c->deg + 1) {
+            case 4: return launch_dyn_t<4>(c, p, kid);
+            case 6: return launch_dyn_t<6>(c, p, kid);
+            case 8: return launch_dyn_t<8>(c, p, kid);
+            case 11: return launch_dyn_t<11>(c, p, kid);
+            case 16: return launch_dyn_t<16>(c, p, kid);
+        }
+    }
+    if (d_out_speed && (rc = launch_speed(c, dY, d_tf, B, bound, is_max, d_out_speed))) return rc;
+    if (d_out_ang && (rc = launch_ang_rate(c, dY, d_tf, B, max_rate, d_out_ang))) return rc;
     return OBTG_OK;
 }
 
@@ -837,22 +947,7 @@ int launch_ang_rate(obtg_ctx* c, const double* dY, const double* d_tf, int B, do
     if (B <= 0) return OBTG_OK;
     int rc = ensure_tables(c);
     if (rc) return rc;
-    const int nc = c->deg + 1;
-    if (c->R == 0 && (nc == 4 || nc == 6 || nc == 8 || nc == 11 || nc == 16)) {
-        AngParams p{};
-        p.Y = dY; p.tf = d_tf; p.out = d_out; p.n_veh = c->n_veh; p.total = B * c->n_veh;
-        p.w2 = max_rate * max_rate;
-        p.W2n = c->d_ang_w2n.as<double>();
-        p.W22n = c->d_ang_w22n.as<double>();
-        p.Wn = c->d_ang_wn.as<double>();
-        switch (nc) {
-            case 4: return launch_ang_t<4>(c, p);
-            case 6: return launch_ang_t<6>(c, p);
-            case 8: return launch_ang_t<8>(c, p);
-            case 11: return launch_ang_t<11>(c, p);
-            case 16: return launch_ang_t<16>(c, p);
-        }
-    }
+    if (dyn_fast(c)) return launch_dynamics(c, dY, d_tf, B, 0.0, 1, max_rate, nullptr, d_out);
     GenParams g{};
     rc = gen_common(c, g);
     if (rc) return rc;

@@ -174,7 +174,7 @@ const char* obtg_abi_symbols(void)
         "obtg_ctx_create\0obtg_ctx_destroy\0obtg_ctx_set_stream\0obtg_ctx_set_deg_elev\0obtg_sync\0"
         "obtg_len_temporal_sep\0obtg_len_speed\0obtg_len_ang_rate\0obtg_num_pairs\0"
         "obtg_temporal_sep\0obtg_speed\0obtg_ang_rate\0obtg_temporal_sep_min\0"
-        "obtg_temporal_sep_dev\0obtg_temporal_sep_min_dev\0obtg_speed_dev\0obtg_ang_rate_dev\0"
+        "obtg_temporal_sep_dev\0obtg_temporal_sep_min_dev\0obtg_speed_dev\0obtg_ang_rate_dev\0obtg_dynamics_dev\0"
         "obtg_fd_batch_dev\0obtg_gjk_pairs\0obtg_ctx_set_polygons\0obtg_ctx_set_hull_pairs\0"
         "obtg_gjk_swarm_dev\0obtg_gjk_swarm\0obtg_min_dist\0obtg_min_dist2poly\0"
         "obtg_bern_elev\0obtg_bern_diff\0obtg_bern_mul\0obtg_bern_normsq\0"
@@ -297,6 +297,14 @@ int obtg_ang_rate_dev(obtg_ctx* c, const double* dY, const double* d_tf, int B, 
     if (!check_ctx(c) || !dY || !d_tf || !d_out || B < 0) return OBTG_ERR_ARG;
     (void)hipSetDevice(c->device);
     return launch_ang_rate(c, dY, d_tf, B, max_rate, d_out);
+}
+
+int obtg_dynamics_dev(obtg_ctx* c, const double* dY, const double* d_tf, int B, double speed_bound,
+                      int speed_is_max, double max_rate, double* d_out_speed, double* d_out_ang)
+{
+    if (!check_ctx(c) || !dY || !d_tf || B < 0 || (!d_out_speed && !d_out_ang)) return OBTG_ERR_ARG;
+    (void)hipSetDevice(c->device);
+    return launch_dynamics(c, dY, d_tf, B, speed_bound, speed_is_max, max_rate, d_out_speed, d_out_ang);
 }
 
 int obtg_fd_batch_dev(obtg_ctx* c, const double* dY0, int n_fixed_cols, double h, int B, double* dY)

@@ -101,6 +101,8 @@ int launch_speed(obtg_ctx* c, const double* dY, const double* d_tf, int B, doubl
                  double* d_out);
 int launch_ang_rate(obtg_ctx* c, const double* dY, const double* d_tf, int B, double max_rate,
                     double* d_out);
+int launch_dynamics(obtg_ctx* c, const double* dY, const double* d_tf, int B, double bound, int is_max,
+                    double max_rate, double* d_out_speed, double* d_out_ang);
 int launch_fd_batch(obtg_ctx* c, const double* dY0, int n_fixed_cols, double h, int B, double* dY);
 int launch_bern_elev(obtg_ctx* c, const double* d_in, int rows, int n, int R, double* d_out);
 int launch_bern_diff(obtg_ctx* c, const double* d_in, int rows, int n, double T, double* d_out);

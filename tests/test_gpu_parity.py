@@ -364,3 +364,31 @@ def test_c3_full_batch_properties(capi, synth):
         mins.append(ctx.temporal_sep_min(Y, 0.9)[0])
     assert (mins[1] >= mins[0] - 1e-9).all() and (mins[2] >= mins[1] - 1e-9).all()
     ctx.close()
+
+
+def test_fused_dynamics_matches_separate_calls(capi, oracle, synth):
+    """obtg_dynamics_dev: speed and angular rate from one launch == the two separate sweeps."""
+    import torch
+    for (N, n, R) in ((64, 10, 0), (19, 5, 0), (7, 15, 0), (9, 10, 3)):      # last: no fast path
+        Y = synth.swarm_control_points(N, 2, n, seed=11)
+        B = 21
+        Yb = synth.fd_batch(Y, B=B)
+        tf = np.linspace(1.5, 8.0, B)
+        ctx = capi.Context(N, 2, n, R)
+        ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+        dY = torch.from_numpy(Yb).cuda()
+        dtf = torch.from_numpy(tf).cuda()
+        osp = torch.empty((B, ctx.len_speed), dtype=torch.float64, device="cuda")
+        oan = torch.empty((B, ctx.len_ang_rate), dtype=torch.float64, device="cuda")
+        ctx.dynamics_dev(dY.data_ptr(), dtf.data_ptr(), B, 4.0, False, 1.5, osp.data_ptr(), oan.data_ptr())
+        torch.cuda.synchronize()
+        _, o_sp, o_an = oracle.eval_batch(Yb, tf, N, 2, R, 0.9, 4.0, 1.5)
+        # the oracle batch returns the max-speed form 16 - |v|^2; the call above asked for min-speed
+        assert_close(osp.cpu().numpy(), -o_sp, RTOL, "fused speed (min form = -(max form), same bound)")
+        assert_close(oan.cpu().numpy(), o_an, RTOL, "fused ang")
+        only = torch.empty_like(osp)
+        ctx.dynamics_dev(dY.data_ptr(), dtf.data_ptr(), B, 4.0, True, 1.5, only.data_ptr(), 0)
+        torch.cuda.synchronize()
+        assert_close(only.cpu().numpy(), o_sp, RTOL, "speed only through the fused entry")
+        ctx.set_stream(0)
+        ctx.close()
