@@ -69,6 +69,8 @@ struct NsParams {
     int stage_all;                    // 1: every object of the row is staged, slot == object id
     int tile_rows;                    // rows of the per-wave transposition tile (64, 32 or 16)
     int waves;                        // waves per workgroup
+    int tiling;                       // 1: row-window tiles (large swarms), see k_normsq_elev
+    const int2* __restrict__ tiles;   // [wgs_per_row] (first row, first column) of each tile
     double sign, offset;              // out = sign * value + offset
 };
 
@@ -174,7 +176,7 @@ __global__ __launch_bounds__(256) void k_normsq_elev(const NsParams p)
     const int chunk = kWave * p.groups_per_wg;
     const int it0 = p.item_begin + w * chunk;
     const int it_end = min(p.item_begin + p.item_count, it0 + chunk);
-    if (it0 >= it_end) return;
+    if (!p.tiling && it0 >= it_end) return;
 
     // LDS: [staged objects: stage_slots * VP][per-wave transposition tiles]
     double* vl = lds;
@@ -183,12 +185,21 @@ __global__ __launch_bounds__(256) void k_normsq_elev(const NsParams p)
 
     // ---- stage the objects this workgroup touches
     const double* Yrow = p.Y + (size_t)b * p.n_veh * S::VLEN;
-    // stage_all: slot == object id.  Otherwise a chunk of lexicographic pairs touches rows
-    // i0..i0+nI-1 (segment I), the j-range of its first row (segment A) and the j-range of the
-    // later rows (segment B).
-    int i0 = 0, nI = 0, a_lo = 0, nA = 0, b_lo = 0;
+    // three staging schemes:
+    //   stage_all  (small swarms): every object of the row, slot == object id;
+    //   tiling     (large swarms): the workgroup owns rows ti0..ti0+n_waves-1 of the pair
+    //              triangle restricted to the 64-wide column window [tj0, tj0+64): it stages
+    //              n_waves + 64 objects, each wave handles one row segment (contiguous pairs);
+    //   otherwise: a chunk of lexicographic pairs touches rows i0..i0+nI-1 (segment I), the
+    //              j-range of its first row (segment A) and of the later rows (segment B).
+    int i0 = 0, nI = 0, a_lo = 0, nA = 0, b_lo = 0, ti0 = 0, tj0 = 0;
     if (p.stage_all) {
         stage_objects<NC, DIM>(vl, Yrow, p.obs, p.n_veh, 0, p.n_obj, 0, threadIdx.x, blockDim.x);
+    } else if (MODE == 0 && p.tiling) {
+        const int2 t = p.tiles[w];
+        ti0 = t.x; tj0 = t.y;
+        stage_objects<NC, DIM>(vl, Yrow, p.obs, p.n_veh, ti0, min(n_waves, p.n_obj - ti0), 0, threadIdx.x, blockDim.x);
+        stage_objects<NC, DIM>(vl, Yrow, p.obs, p.n_veh, tj0, min(kWave, p.n_obj - tj0), n_waves, threadIdx.x, blockDim.x);
     } else if (MODE == 0) {
         const int2 f = p.pairs[it0], l = p.pairs[it_end - 1];
         i0 = f.x; nI = l.x - f.x + 1;
@@ -208,18 +219,43 @@ __global__ __launch_bounds__(256) void k_normsq_elev(const NsParams p)
     const int LR = L + p.R;
     const int TR = p.tile_rows;
     for (int g = wave; g < p.groups_per_wg; g += n_waves) {
-        const int itg = it0 + g * kWave;
-        if (itg >= it_end) break;
-        const int n_valid = min(kWave, it_end - itg);
-        const int item = min(itg + lane, it_end - 1);   // idle lanes recompute the last item
+        // this wave's group: valid lanes are [lane0, lane0 + n_valid), lane r0 + lane0 owns output
+        // row `row + r0`; si/sj are the LDS slots of the lane's two curves
+        int n_valid, lane0 = 0, si = 0, sj = 0, item = 0;
+        size_t row;
+        if (MODE == 0 && p.tiling) {
+            const int i = ti0 + wave;
+            if (g != wave || i >= p.n_obj - 1) break;
+            const int j = tj0 + lane;
+            const long tri = (long)i * p.n_obj - (long)i * (i + 1) / 2 - i - 1;   // p(i,j) = tri + j
+            const long pidx = tri + j;
+            const bool valid = j > i && j < p.n_obj && pidx >= p.item_begin &&
+                               pidx < (long)p.item_begin + p.item_count;
+            const unsigned long long m = __ballot(valid);
+            if (m == 0ull) break;
+            lane0 = __ffsll((long long)m) - 1;
+            n_valid = __popcll(m);
+            si = wave;
+            sj = n_waves + (min(j, p.n_obj - 1) - tj0);
+            row = (size_t)b * p.item_count + (size_t)(tri + tj0 + lane0 - p.item_begin);
+        } else {
+            const int itg = it0 + g * kWave;
+            if (itg >= it_end) break;
+            n_valid = min(kWave, it_end - itg);
+            item = min(itg + lane, it_end - 1);   // idle lanes recompute the last item
+            row = (size_t)b * p.item_count + (size_t)(itg - p.item_begin);
+            if (MODE == 0) {
+                const int2 ij = p.pairs[item];
+                if (p.stage_all) { si = ij.x; sj = ij.y; }
+                else { si = ij.x - i0; sj = (ij.x == i0) ? nI + (ij.y - a_lo) : nI + nA + (ij.y - b_lo); }
+            } else si = p.stage_all ? item : item - i0;
+        }
+        const int r = lane - lane0;                     // this lane's row inside the group
+        const bool mine = r >= 0 && r < n_valid;
 
         // ---- source curve a[q][c]
         double a[DIM][NC];
         if (MODE == 0) {
-            const int2 ij = p.pairs[item];
-            int si, sj;
-            if (p.stage_all) { si = ij.x; sj = ij.y; }
-            else { si = ij.x - i0; sj = (ij.x == i0) ? nI + (ij.y - a_lo) : nI + nA + (ij.y - b_lo); }
             const double* vi = vl + si * S::VP;
             const double* vj = vl + sj * S::VP;
 #pragma unroll
@@ -228,7 +264,7 @@ __global__ __launch_bounds__(256) void k_normsq_elev(const NsParams p)
                 for (int c = 0; c < NC; ++c) a[q][c] = vi[q * NC + c] - vj[q * NC + c];
         } else {
             // Bezier.diff(): (n/T)(P_{i+1}-P_i), then elev(1) back to degree n (bezier.py:497-519)
-            const double* v = vl + (p.stage_all ? item : item - i0) * S::VP;
+            const double* v = vl + si * S::VP;
             const double val = (double)N / p.tf[b];
 #pragma unroll
             for (int q = 0; q < DIM; ++q) {
@@ -246,20 +282,19 @@ __global__ __launch_bounds__(256) void k_normsq_elev(const NsParams p)
         double cf[L];
         normsq_coeffs<NC, DIM>(a, as_ctab(p.W2), cf);
 
-        const size_t row = (size_t)b * p.item_count + (size_t)(itg - p.item_begin);
         if (p.R == 0) {
             // elevMatrix(2n, 0) is the identity (bezier.py:1141-1147): the product IS the output
             if (MINONLY) {
                 double m = cf[0];
 #pragma unroll
                 for (int k = 1; k < L; ++k) m = fmin(m, cf[k]);
-                if (lane < n_valid) p.out[row + lane] = p.sign * m + p.offset;
+                if (mine) p.out[row + r] = p.sign * m + p.offset;
             } else {
                 // transpose TR rows at a time through the wave's tile
                 for (int r0 = 0; r0 < n_valid; r0 += TR) {
-                    if (lane >= r0 && lane < r0 + TR) {
+                    if (mine && r >= r0 && r < r0 + TR) {
 #pragma unroll
-                        for (int k = 0; k < L; ++k) tile[(lane - r0) * S::TPF + k] = p.sign * cf[k] + p.offset;
+                        for (int k = 0; k < L; ++k) tile[(r - r0) * S::TPF + k] = p.sign * cf[k] + p.offset;
                     }
                     wave_sync();
                     flush_full<L, S::TPF>(tile, p.out, (row + r0) * L, min(TR, n_valid - r0), lane);
@@ -276,7 +311,7 @@ __global__ __launch_bounds__(256) void k_normsq_elev(const NsParams p)
 #pragma unroll
                     for (int j = 0; j < L; ++j) s = fma(cf[j], Tr[j], s);
                     if (MINONLY) m = fmin(m, s);
-                    else tile[lane * S::TPC + kk] = p.sign * s + p.offset;
+                    else if (mine) tile[r * S::TPC + kk] = p.sign * s + p.offset;
                 }
                 if (!MINONLY) {
                     wave_sync();
@@ -284,7 +319,7 @@ __global__ __launch_bounds__(256) void k_normsq_elev(const NsParams p)
                     wave_sync();
                 }
             }
-            if (MINONLY && lane < n_valid) p.out[row + lane] = p.sign * m + p.offset;
+            if (MINONLY && mine) p.out[row + r] = p.sign * m + p.offset;
         }
     }
 }
@@ -812,27 +847,59 @@ int launch_temporal_sep(obtg_ctx* c, const double* dY, int B, double max_sep, in
         p.item_begin = pair_begin; p.item_count = pair_count;
         // workgroup = 4 waves sharing one staging of the row's objects; each wave walks
         // groups of 64 pairs.  Keep >= ~4k workgroups so that 256 CUs x 4 resident stay fed.
+        const int vlen = c->dim * (c->deg + 1), vp = (vlen % 2 == 0) ? vlen + 1 : vlen;
+        const size_t row_bytes = sizeof(double) * (size_t)c->n_obj * vp;
         int groups_total = (pair_count + kWave - 1) / kWave;
-        p.waves = groups_total >= 4 ? 4 : groups_total;
-        int gpw = 16;   // groups per workgroup
-        while (gpw > p.waves && (long)B * ((groups_total + gpw - 1) / gpw) < 4096) gpw >>= 1;
-        if (gpw < p.waves) gpw = p.waves;
-        p.groups_per_wg = gpw;
-        p.wgs_per_row = (groups_total + gpw - 1) / gpw;
-        // LDS slots: replay the kernel's staging rule over this launch's chunks
-        const int chunk = kWave * gpw;
-        int slots = 0;
-        for (int it0 = pair_begin; it0 < pair_begin + pair_count; it0 += chunk) {
-            const int last = std::min(pair_begin + pair_count, it0 + chunk) - 1;
-            const int fx = c->h_pairs[2 * it0], fy = c->h_pairs[2 * it0 + 1];
-            const int lx = c->h_pairs[2 * last], ly = c->h_pairs[2 * last + 1];
-            const int nI = lx - fx + 1;
-            const int nA = (nI == 1) ? (ly - fy + 1) : (c->n_obj - fy);
-            const int nB = (nI == 1) ? 0 : std::max(0, ((nI >= 3) ? c->n_obj - 1 : ly) - (fx + 2) + 1);
-            slots = std::max(slots, nI + nA + nB);
+        if (row_bytes <= 24 * 1024 || c->n_obj <= 2 * kWave) {
+            p.waves = groups_total >= 4 ? 4 : groups_total;
+            int gpw = 16;   // groups per workgroup
+            while (gpw > p.waves && (long)B * ((groups_total + gpw - 1) / gpw) < 4096) gpw >>= 1;
+            if (gpw < p.waves) gpw = p.waves;
+            p.groups_per_wg = gpw;
+            p.wgs_per_row = (groups_total + gpw - 1) / gpw;
+            // LDS slots: replay the kernel's staging rule over this launch's chunks
+            const int chunk = kWave * gpw;
+            int slots = 0;
+            for (int it0 = pair_begin; it0 < pair_begin + pair_count; it0 += chunk) {
+                const int last = std::min(pair_begin + pair_count, it0 + chunk) - 1;
+                const int fx = c->h_pairs[2 * it0], fy = c->h_pairs[2 * it0 + 1];
+                const int lx = c->h_pairs[2 * last], ly = c->h_pairs[2 * last + 1];
+                const int nI = lx - fx + 1;
+                const int nA = (nI == 1) ? (ly - fy + 1) : (c->n_obj - fy);
+                const int nB = (nI == 1) ? 0 : std::max(0, ((nI >= 3) ? c->n_obj - 1 : ly) - (fx + 2) + 1);
+                slots = std::max(slots, nI + nA + nB);
+            }
+            p.stage_all = c->n_obj <= slots ? 1 : 0;
+            p.stage_slots = p.stage_all ? c->n_obj : slots;
+            p.tiling = 0; p.tiles = nullptr;
+        } else {
+            // large swarm: row-window tiles (4 rows x 64 columns of the pair triangle)
+            p.waves = 4; p.groups_per_wg = 4; p.stage_all = 0; p.tiling = 1;
+            p.stage_slots = p.waves + kWave;
+            if (c->tiles_begin != pair_begin || c->tiles_count != pair_count || c->h_tiles.empty()) {
+                c->h_tiles.clear();
+                const long nobj = c->n_obj, pend = (long)pair_begin + pair_count;
+                for (int i0 = 0; i0 < c->n_obj - 1; i0 += p.waves) {
+                    const int i1 = std::min(c->n_obj - 2, i0 + p.waves - 1);
+                    // pair-index span of rows i0..i1
+                    const long lo = (long)i0 * nobj - (long)i0 * (i0 + 1) / 2;
+                    const long hi = (long)i1 * nobj - (long)i1 * (i1 + 1) / 2 + (nobj - 1 - i1 - 1);
+                    if (hi < pair_begin || lo >= pend) continue;
+                    for (int j0 = ((i0 + 1) / kWave) * kWave; j0 < c->n_obj; j0 += kWave) {
+                        c->h_tiles.push_back(i0);
+                        c->h_tiles.push_back(j0);
+                    }
+                }
+                int rc2 = c->d_tiles.reserve(sizeof(int) * c->h_tiles.size());
+                if (rc2) return rc2;
+                OBTG_HIP(c, hipMemcpyAsync(c->d_tiles.p, c->h_tiles.data(), sizeof(int) * c->h_tiles.size(),
+                                           hipMemcpyHostToDevice, c->stream));
+                OBTG_HIP(c, hipStreamSynchronize(c->stream));
+                c->tiles_begin = pair_begin; c->tiles_count = pair_count;
+            }
+            p.tiles = c->d_tiles.as<int2>();
+            p.wgs_per_row = (int)(c->h_tiles.size() / 2);
         }
-        p.stage_all = c->n_obj <= slots ? 1 : 0;
-        p.stage_slots = p.stage_all ? c->n_obj : slots;
         p.sign = 1.0; p.offset = -(max_sep * max_sep);
         rc = min_only ? dispatch_ns<0, true>(c, p, B, OBTG_K_TEMPORAL_SEP)
                       : dispatch_ns<0, false>(c, p, B, OBTG_K_TEMPORAL_SEP);
@@ -870,7 +937,7 @@ int launch_speed(obtg_ctx* c, const double* dY, const double* d_tf, int B, doubl
         p.waves = 1;
         p.wgs_per_row = (c->n_veh + kWave - 1) / kWave;
         p.stage_slots = std::min(c->n_veh, kWave);
-        p.stage_all = 0;
+        p.stage_all = 0; p.tiling = 0; p.tiles = nullptr;
         p.sign = is_max ? -1.0 : 1.0; p.offset = is_max ? b2 : -b2;
         rc = dispatch_ns<1, false>(c, p, B, OBTG_K_SPEED);
         if (rc != OBTG_ERR_UNSUPPORTED) return rc;

@@ -227,7 +227,7 @@ void obtg_ctx_destroy(obtg_ctx* c)
     (void)hipStreamSynchronize(c->stream);
     flush_pending_events(c);
     DevBuf* bufs[] = { &c->d_pairs, &c->d_obs, &c->d_w2, &c->d_Tt, &c->d_ang_w2n, &c->d_ang_w22n, &c->d_ang_wn,
-                       &c->d_binrows, &c->d_poly_pts, &c->d_poly_off, &c->d_hp_a, &c->d_hp_b, &c->ws_in,
+                       &c->d_binrows, &c->d_tiles, &c->d_poly_pts, &c->d_poly_off, &c->d_hp_a, &c->d_hp_b, &c->ws_in,
                        &c->ws_in2, &c->ws_out };
     for (DevBuf* b : bufs) b->release();
     for (auto& b : c->ws_misc) b.release();

@@ -49,6 +49,9 @@ struct obtg_ctx {
     obtg::DevBuf d_Tt;        // elevation table (2*deg -> 2*deg+R), transposed
     obtg::DevBuf d_ang_w2n, d_ang_w22n, d_ang_wn;  // angular-rate fast path weights
     std::vector<int> h_pairs; // host copy of the pair table (2 ints per pair)
+    std::vector<int> h_tiles; // row-window tiles of the current (pair_begin, pair_count)
+    obtg::DevBuf d_tiles;
+    int tiles_begin = -1, tiles_count = -1;
     std::vector<double> h_binrows;
     obtg::DevBuf d_binrows;   // concatenated binomial rows for the generic kernels
     std::vector<int> binrow_off;   // offset of row C(n, .) inside d_binrows, -1 if absent
