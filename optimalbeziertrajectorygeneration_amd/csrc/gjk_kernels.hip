@@ -841,6 +841,7 @@ int launch_gjk_swarm(obtg_ctx* c, const double* dY, int B, int max_iter, int md_
     // workgroups in flight-order so that the last wave of workgroups is a small fraction
     int wgs = 1;
     while ((long)B * wgs < 6144 && (c->n_hull_pairs + wgs - 1) / wgs > 256) wgs <<= 1;
+    while ((c->n_hull_pairs + wgs - 1) / wgs > 1024) wgs <<= 1;   // bounds the per-chunk LDS records
     p.chunk = (c->n_hull_pairs + wgs - 1) / wgs;
     p.wgs_per_row = (c->n_hull_pairs + p.chunk - 1) / p.chunk;
     p.max_iter = max_iter; p.md_cap = md_cap;
@@ -863,10 +864,7 @@ int launch_gjk_swarm(obtg_ctx* c, const double* dY, int B, int max_iter, int md_
             case 21: kp = k_gjk_swarm_planar<21>; break;
             default: break;
         }
-        if (kp && lds2 <= 64 * 1024) {
-            if (lds2 > 48 * 1024)
-                OBTG_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(kp),
-                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
+        if (kp && lds2 <= 48 * 1024) {   // larger rows: the general kernel does better than 1-2 workgroups per CU
             ScopedKernelTimer t(c, OBTG_K_GJK);
             hipLaunchKernelGGL(kp, dim3((unsigned)((size_t)B * p.wgs_per_row)), dim3(256), lds2, c->stream, p);
             OBTG_HIP(c, hipGetLastError());
