@@ -46,6 +46,9 @@ def parse():
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-gjk", action="store_true", help="Bernstein sweeps only")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for rehearsals)")
+    ap.add_argument("--one-device", action="store_true",
+                    help="rehearsal only: every rank uses device 0 (needs --backend gloo)")
     return ap.parse_args()
 
 
@@ -77,10 +80,15 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
+    if args.one_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(args.backend)
 
     cfg = dict(synth.CONFIGS[args.workload])
     N, d, n, R, M = cfg["N"], cfg["d"], cfg["n"], cfg["R"], cfg.get("n_poly", 0)
@@ -184,9 +192,10 @@ def main():
                     unit="GB/s", frac=dom["frac"], traffic=traffic,
                     step_achieved=round(B * total_bytes / (ms_per_step * 1e-3) / 1e9, 2))
 
-    cpu = None
+    cpu = cpu_np = None
     if rank == 0 and not args.no_cpu and args.gpus == 1:
         cpu = cpu_baseline(args, N, d, n, R, M, Y, polys, pa, pb, use_gjk, max_sep, vmax, wmax, tfv)
+        cpu_np = cpu_baseline_numpy(N, d, n, R, Y, max_sep, vmax, wmax, tfv)
 
     if rank == 0:
         line = {
@@ -203,6 +212,7 @@ def main():
             "roofline": roofline,
             "kernels": kernels,
             "cpu_baseline": cpu,
+            "cpu_baseline_numpy": cpu_np,
         }
         print(json.dumps(line))
     if world > 1:
@@ -232,6 +242,32 @@ def cpu_baseline(args, N, d, n, R, M, Y, polys, pa, pb, use_gjk, max_sep, vmax, 
     return {"value": round(rows / dt, 3), "unit": "constraint-evals/s", "cores": 1, "kind": "port",
             "sample": "%d FD-batch rows of the same %s workload (all families), %.1f s, oracle/obtg_oracle.c -O2"
                       % (rows, args.workload, dt)}
+
+
+def cpu_baseline_numpy(N, d, n, R, Y, max_sep, vmax, wmax, tfv):
+    """Reference-shaped NumPy port (oracle/numpy_port.py: the reference's per-pair Python loops and
+    dense coefficient matrices, minus its Bezier objects), Bernstein families only, one thread."""
+    from oracle import numpy_port as P
+    from optimalbeziertrajectorygeneration_amd import synth
+
+    def one(Yr):
+        P.temporal_sep(Yr, N, d, R, max_sep)
+        P.speed(Yr, N, d, R, tfv, vmax, True)
+        if d == 2:
+            P.ang_rate(Yr, N, R, tfv, wmax)
+
+    Yb = synth.fd_batch(Y, B=64)
+    one(Yb[0])                       # builds the coefficient-matrix caches, like the drivers' warm-up
+    t0 = time.perf_counter()
+    rows = 0
+    while rows < 64 and time.perf_counter() - t0 < 4.0:
+        one(Yb[rows])
+        rows += 1
+    dt = time.perf_counter() - t0
+    return {"value": round(rows / dt, 3), "unit": "constraint-evals/s", "cores": 1, "kind": "port",
+            "sample": "%d rows, Bernstein families only (no gjkNew), %.1f s, oracle/numpy_port.py; the real "
+                      "reference measured in the survey container is ~5.6x slower than this port "
+                      "(BASELINE.md section 2)" % (rows, dt)}
 
 
 if __name__ == "__main__":
