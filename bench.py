@@ -46,6 +46,9 @@ def parse():
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-gjk", action="store_true", help="Bernstein sweeps only")
+    ap.add_argument("--fd-dedup", action="store_true",
+                    help="reuse row 0's gjkNew results for bit-identical hull pairs (obtg_ctx_set_fd_dedup); "
+                         "NOT the headline number")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for rehearsals)")
     ap.add_argument("--one-device", action="store_true",
                     help="rehearsal only: every rank uses device 0 (needs --backend gloo)")
@@ -108,6 +111,7 @@ def main():
     if use_gjk:
         ctx.set_polygons(ppts, poff)
         ctx.set_hull_pairs(pa, pb)
+        ctx.set_fd_dedup(args.fd_dedup)
     P_t, L = ctx.num_pairs, 2 * n + R + 1
     P_s = len(pa) if use_gjk else 0
 
@@ -208,7 +212,8 @@ def main():
                                    "+max_speed+%sgjkNew(%d hull pairs)" % (
                                        args.workload, N, d, n, R, M, B, P_t,
                                        "max_ang_rate+" if d == 2 else "", P_s),
-                       "evals_per_step_per_gpu": B, "alg_bytes_per_eval": total_bytes},
+                       "evals_per_step_per_gpu": B, "alg_bytes_per_eval": total_bytes,
+                       "gjk_fd_dedup": bool(args.fd_dedup)},
             "roofline": roofline,
             "kernels": kernels,
             "cpu_baseline": cpu,

@@ -161,6 +161,12 @@ int obtg_ctx_set_hull_pairs(obtg_ctx*, const int* pair_a, const int* pair_b, int
 int obtg_gjk_swarm_dev(obtg_ctx*, const double* dY, int B, int max_iter, int md_cap,
                        int* d_flag, double* d_p1, double* d_p2, double* d_dist,
                        int* d_nsup, int* d_status);
+/* Finite-difference de-duplication (off by default).  The rows of one
+ * SLSQP Jacobian differ from row 0 in ONE vehicle, so all pairs not involving it have row 0's
+ * inputs bit for bit.  When on, obtg_gjk_swarm[_dev] compares every row with row 0 (bitwise, per
+ * vehicle), runs gjkNew only for pairs with a changed hull and copies row 0's outputs for the
+ * rest.  Results are identical to the brute-force sweep for any input. */
+int obtg_ctx_set_fd_dedup(obtg_ctx*, int on);
 /* host-buffer form of the same sweep (B rows of Y in, arrays out) */
 int obtg_gjk_swarm(obtg_ctx*, const double* Y, int B, int max_iter, int md_cap,
                    int* flag, double* p1, double* p2, double* dist, int* nsup, int* status);

@@ -51,6 +51,7 @@ _SIGNATURES = {
     "obtg_gjk_pairs": (_i, [_vp, _vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp]),
     "obtg_ctx_set_polygons": (_i, [_vp, _vp, _i, _vp, _i]),
     "obtg_ctx_set_hull_pairs": (_i, [_vp, _vp, _vp, _i]),
+    "obtg_ctx_set_fd_dedup": (_i, [_vp, _i]),
     "obtg_gjk_swarm_dev": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "obtg_gjk_swarm": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "obtg_min_dist": (_i, [_vp, _vp, _i, _i, _vp, _vp, _i, _d, _i, _i, _i, _i, _vp, _vp, _vp]),
@@ -336,6 +337,9 @@ class Context(object):
         self._check(self._lib.obtg_ctx_set_hull_pairs(self._h, _ptr(pa), _ptr(pb), pa.shape[0]),
                     "obtg_ctx_set_hull_pairs")
         self.n_hull_pairs = pa.shape[0]
+
+    def set_fd_dedup(self, on):
+        self._check(self._lib.obtg_ctx_set_fd_dedup(self._h, int(bool(on))), "obtg_ctx_set_fd_dedup")
 
     def gjk_swarm(self, Y, max_iter=128, md_cap=4096):
         Y, B = self._rows(Y)

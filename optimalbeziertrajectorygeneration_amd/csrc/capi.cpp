@@ -176,7 +176,7 @@ const char* obtg_abi_symbols(void)
         "obtg_temporal_sep\0obtg_speed\0obtg_ang_rate\0obtg_temporal_sep_min\0"
         "obtg_temporal_sep_dev\0obtg_temporal_sep_min_dev\0obtg_speed_dev\0obtg_ang_rate_dev\0obtg_dynamics_dev\0"
         "obtg_fd_batch_dev\0obtg_gjk_pairs\0obtg_ctx_set_polygons\0obtg_ctx_set_hull_pairs\0"
-        "obtg_gjk_swarm_dev\0obtg_gjk_swarm\0obtg_min_dist\0obtg_min_dist2poly\0"
+        "obtg_ctx_set_fd_dedup\0obtg_gjk_swarm_dev\0obtg_gjk_swarm\0obtg_min_dist\0obtg_min_dist2poly\0"
         "obtg_bern_elev\0obtg_bern_diff\0obtg_bern_mul\0obtg_bern_normsq\0"
         "obtg_euclidean_obj\0obtg_accel_obj\0obtg_jerk_obj\0"
         "obtg_set_profiling\0obtg_kernel_stats\0obtg_reset_kernel_stats\0obtg_kernel_name\0";
@@ -502,6 +502,13 @@ int obtg_ctx_set_hull_pairs(obtg_ctx* c, const int* pair_a, const int* pair_b, i
         if ((rc = upload(c, c->d_poly_off, &zero, sizeof(int)))) return rc;
     }
     if (c->d_poly_pts.p == nullptr && (rc = c->d_poly_pts.reserve(8))) return rc;
+    return OBTG_OK;
+}
+
+int obtg_ctx_set_fd_dedup(obtg_ctx* c, int on)
+{
+    if (!check_ctx(c)) return OBTG_ERR_ARG;
+    c->fd_dedup = on != 0;
     return OBTG_OK;
 }
 

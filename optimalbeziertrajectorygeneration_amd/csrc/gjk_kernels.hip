@@ -230,6 +230,7 @@ struct GjkSwarmParams {
     const int* __restrict__ pb;
     int n_veh, dim, nc, n_poly, n_poly_pts, n_pairs, wgs_per_row, vp, chunk;
     int max_iter, md_cap;
+    const unsigned char* chg;          // FIXUP kernels: [B][n_veh], 1 = vehicle differs from row 0
     int* __restrict__ flag;
     double* __restrict__ p1;
     double* __restrict__ p2;
@@ -314,7 +315,12 @@ __device__ __forceinline__ void support_fixed(const double* __restrict__ o1, con
     out.v = gjk::V2{ o1[i1] - o2[i2], o1[NC + i1] - o2[NC + i2] };
 }
 
-template <int NC>
+// FIXUP = false: the sweep proper (blockIdx -> (row, chunk of the pair list)).
+// FIXUP = true : finite-difference de-duplication pass, one workgroup per row b >= 1: only pairs
+//                with a hull that differs from row 0 (mask p.chg) are evaluated; everything else was
+//                filled in beforehand by k_bcast_row0.  The pair list is walked in segments of
+//                p.chunk candidates; the changed ones are compacted into an LDS list.
+template <int NC, bool FIXUP>
 __global__ __launch_bounds__(256) void k_gjk_swarm_planar(const GjkSwarmParams p)
 {
     using gjk::V2;
@@ -324,9 +330,11 @@ __global__ __launch_bounds__(256) void k_gjk_swarm_planar(const GjkSwarmParams p
     extern __shared__ double lds[];
     __shared__ int s_next;
     const int n_obj = p.n_veh + p.n_poly;
-    const int b = blockIdx.x / p.wgs_per_row, w = blockIdx.x - b * p.wgs_per_row;
-    const int c0 = w * p.chunk, c1 = min(p.n_pairs, c0 + p.chunk);
+    const int b = FIXUP ? (int)blockIdx.x + 1 : (int)(blockIdx.x / p.wgs_per_row);
+    const int w = FIXUP ? 0 : (int)(blockIdx.x - b * p.wgs_per_row);
+    int c0 = w * p.chunk, c1 = min(p.n_pairs, c0 + p.chunk);
     int4* rec = reinterpret_cast<int4*>(lds + ((n_obj * VP + 1) & ~1));     // 16-byte aligned
+    __shared__ int s_nlist;
 
     // ---- stage vehicles (rows x, y of the evaluation row) and padded polygons
     const double* Yrow = p.Y + (size_t)b * p.n_veh * 2 * NC;
@@ -339,7 +347,6 @@ __global__ __launch_bounds__(256) void k_gjk_swarm_planar(const GjkSwarmParams p
         const int off = p.poly_off[o], K = p.poly_off[o + 1] - off;
         lds[(p.n_veh + o) * VP + r] = p.poly[3 * off + q * K + (k < K ? k : 0)];
     }
-    if (threadIdx.x == 0) s_next = c0;
     __syncthreads();
 
     // ---- the first two doSimplex steps of every pair use the fixed directions (1,0,0) and
@@ -361,6 +368,25 @@ __global__ __launch_bounds__(256) void k_gjk_swarm_planar(const GjkSwarmParams p
     }
     __syncthreads();
     const bool shortcut = p.max_iter >= 3 && p.md_cap >= 2;
+    int* list = ext + 2 * n_obj;                          // FIXUP: compacted pair indices of a segment
+    const unsigned char* chg = FIXUP ? p.chg + (size_t)b * p.n_veh : nullptr;
+
+    for (int seg0 = 0; seg0 < (FIXUP ? p.n_pairs : 1); seg0 += p.chunk) {
+    if (FIXUP) {
+        if (threadIdx.x == 0) s_nlist = 0;
+        __syncthreads();
+        const int seg1 = min(p.n_pairs, seg0 + p.chunk);
+        for (int q = seg0 + (int)threadIdx.x; q < seg1; q += blockDim.x) {
+            const int a = p.pa[q], bb = p.pb[q];
+            if ((a < p.n_veh && chg[a]) || (bb < p.n_veh && chg[bb])) list[atomicAdd(&s_nlist, 1)] = q;
+        }
+        __syncthreads();
+        c0 = 0; c1 = s_nlist;
+        __syncthreads();
+        if (c1 == 0) continue;                            // uniform: nothing changed in this segment
+    }
+    if (threadIdx.x == 0) s_next = c0;
+    __syncthreads();
 
     // ---- phase 1: state machine with lane refill
     {
@@ -386,7 +412,8 @@ __global__ __launch_bounds__(256) void k_gjk_swarm_planar(const GjkSwarmParams p
                     const int my = base + __popcll(want & ((1ull << lane) - 1ull));
                     if (my < c1) {
                         k = my;
-                        const int a = p.pa[k], bb = p.pb[k];
+                        const int kk = FIXUP ? list[k] : k;
+                        const int a = p.pa[kk], bb = p.pb[kk];
                         o1 = lds + a * VP;
                         o2 = lds + bb * VP;
                         s.keys = 0; dir = V2{ 1.0, 0.0 };
@@ -470,6 +497,7 @@ __global__ __launch_bounds__(256) void k_gjk_swarm_planar(const GjkSwarmParams p
     const size_t obase = (size_t)b * p.n_pairs;
     const double qnan = __builtin_nan("");
     for (int k = c0 + (int)threadIdx.x; k < c1; k += blockDim.x) {
+        const int kk = FIXUP ? list[k] : k;
         const int4 r4 = rec[k - c0];
         const int flag = (int)(signed char)(r4.x & 0xff), status = (r4.x >> 8) & 0xff, keys = (r4.x >> 16) & 0xff;
         Result r;
@@ -477,8 +505,8 @@ __global__ __launch_bounds__(256) void k_gjk_swarm_planar(const GjkSwarmParams p
         if (flag == 1 && status == OBTG_ST_OK) {
             Ctx<MemLds> g;
             g.mem = MemLds{ lds };
-            g.P1 = Poly{ p.pa[k] * VP, NC, NC, 0 };
-            g.P2 = Poly{ p.pb[k] * VP, NC, NC, 0 };
+            g.P1 = Poly{ p.pa[kk] * VP, NC, NC, 0 };
+            g.P2 = Poly{ p.pb[kk] * VP, NC, NC, 0 };
             g.trace = nullptr; g.trace_cap = 0; g.n_support = 0;
             gjk::Simplex s;
             s.keys = keys;
@@ -490,7 +518,7 @@ __global__ __launch_bounds__(256) void k_gjk_swarm_planar(const GjkSwarmParams p
             s.D = s.A;
             gjk::closest_from_simplex(g, s, r);
         }
-        const size_t o = obase + k;
+        const size_t o = obase + kk;
         p.flag[o] = flag;
         p.p1[3 * o] = r.c1.x; p.p1[3 * o + 1] = r.c1.y; p.p1[3 * o + 2] = r.c1.z;
         p.p2[3 * o] = r.c2.x; p.p2[3 * o + 1] = r.c2.y; p.p2[3 * o + 2] = r.c2.z;
@@ -498,6 +526,33 @@ __global__ __launch_bounds__(256) void k_gjk_swarm_planar(const GjkSwarmParams p
         if (p.nsup) p.nsup[o] = r4.y;
         if (p.status) p.status[o] = status;
     }
+    if (FIXUP) __syncthreads();                          // rec / list are reused by the next segment
+    }
+}
+
+
+// which vehicles of row b differ (bitwise) from row 0: chg[b][v]
+__global__ void k_changed_objects(const double* __restrict__ Y, int B, int n_veh, int vlen, unsigned char* __restrict__ chg)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= B * n_veh) return;
+    const int b = t / n_veh, v = t - b * n_veh;
+    const unsigned long long* r0 = reinterpret_cast<const unsigned long long*>(Y) + (size_t)v * vlen;
+    const unsigned long long* rb = r0 + (size_t)b * n_veh * vlen;
+    bool diff = false;
+    for (int i = 0; i < vlen; ++i) diff |= r0[i] != rb[i];
+    chg[t] = diff ? 1 : 0;
+}
+
+// rows 1..B-1 of a [B][row_len] array := row 0 (streaming; blockIdx.y picks a block of 16 rows)
+template <class T>
+__global__ void k_bcast_row0(T* __restrict__ a, size_t row_len, int B)
+{
+    const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= row_len) return;
+    const T v = a[e];
+    const int b0 = 1 + (int)blockIdx.y * 16, b1 = min(B, b0 + 16);
+    for (int b = b0; b < b1; ++b) __builtin_nontemporal_store(v, a + (size_t)b * row_len + e);
 }
 
 // -------------------------------------------------------------------------------------
@@ -855,18 +910,48 @@ int launch_gjk_swarm(obtg_ctx* c, const double* dY, int B, int max_iter, int md_
         const size_t lds2 = sizeof(double) * (((size_t)(c->n_veh + c->n_poly) * vp2 + 1) & ~(size_t)1) +
                             sizeof(int4) * (size_t)p.chunk + sizeof(int) * 2 * (size_t)(c->n_veh + c->n_poly);
         void (*kp)(const GjkSwarmParams) = nullptr;
+        void (*kf)(const GjkSwarmParams) = nullptr;
         switch (nc) {
-            case 4: kp = k_gjk_swarm_planar<4>; break;
-            case 6: kp = k_gjk_swarm_planar<6>; break;
-            case 8: kp = k_gjk_swarm_planar<8>; break;
-            case 11: kp = k_gjk_swarm_planar<11>; break;
-            case 16: kp = k_gjk_swarm_planar<16>; break;
-            case 21: kp = k_gjk_swarm_planar<21>; break;
+            case 4: kp = k_gjk_swarm_planar<4, false>; kf = k_gjk_swarm_planar<4, true>; break;
+            case 6: kp = k_gjk_swarm_planar<6, false>; kf = k_gjk_swarm_planar<6, true>; break;
+            case 8: kp = k_gjk_swarm_planar<8, false>; kf = k_gjk_swarm_planar<8, true>; break;
+            case 11: kp = k_gjk_swarm_planar<11, false>; kf = k_gjk_swarm_planar<11, true>; break;
+            case 16: kp = k_gjk_swarm_planar<16, false>; kf = k_gjk_swarm_planar<16, true>; break;
+            case 21: kp = k_gjk_swarm_planar<21, false>; kf = k_gjk_swarm_planar<21, true>; break;
             default: break;
         }
         if (kp && lds2 <= 48 * 1024) {   // larger rows: the general kernel does better than 1-2 workgroups per CU
             ScopedKernelTimer t(c, OBTG_K_GJK);
-            hipLaunchKernelGGL(kp, dim3((unsigned)((size_t)B * p.wgs_per_row)), dim3(256), lds2, c->stream, p);
+            if (c->fd_dedup && B > 1 && kf) {
+                // Finite-difference de-duplication: row 0 in full, its results broadcast to every
+                // row, then one workgroup per row re-evaluates the pairs whose hulls differ from row 0.
+                int rc = c->ws_misc[7].reserve((size_t)B * c->n_veh);
+                if (rc) return rc;
+                unsigned char* chg = c->ws_misc[7].as<unsigned char>();
+                const int tot = B * c->n_veh;
+                hipLaunchKernelGGL(k_changed_objects, dim3((tot + 255) / 256), dim3(256), 0, c->stream, dY, B,
+                                   c->n_veh, c->dim * (c->deg + 1), chg);
+                hipLaunchKernelGGL(kp, dim3((unsigned)p.wgs_per_row), dim3(256), lds2, c->stream, p);
+                const size_t np = (size_t)c->n_hull_pairs;
+                const dim3 cb(256);
+                const unsigned gy = (unsigned)((B - 1 + 15) / 16);
+                const dim3 g1((unsigned)((np + 255) / 256), gy), g3((unsigned)((3 * np + 255) / 256), gy);
+                hipLaunchKernelGGL(k_bcast_row0<int>, g1, cb, 0, c->stream, d_flag, np, B);
+                hipLaunchKernelGGL(k_bcast_row0<double>, g3, cb, 0, c->stream, d_p1, 3 * np, B);
+                hipLaunchKernelGGL(k_bcast_row0<double>, g3, cb, 0, c->stream, d_p2, 3 * np, B);
+                hipLaunchKernelGGL(k_bcast_row0<double>, g1, cb, 0, c->stream, d_dist, np, B);
+                if (d_nsup) hipLaunchKernelGGL(k_bcast_row0<int>, g1, cb, 0, c->stream, d_nsup, np, B);
+                if (d_status) hipLaunchKernelGGL(k_bcast_row0<int>, g1, cb, 0, c->stream, d_status, np, B);
+                GjkSwarmParams q = p;
+                q.chg = chg;
+                q.chunk = 1024;
+                const size_t ldsf = sizeof(double) * (((size_t)(c->n_veh + c->n_poly) * vp2 + 1) & ~(size_t)1) +
+                                    sizeof(int4) * (size_t)q.chunk + sizeof(int) * 2 * (size_t)(c->n_veh + c->n_poly) +
+                                    sizeof(int) * (size_t)q.chunk;
+                hipLaunchKernelGGL(kf, dim3((unsigned)(B - 1)), dim3(256), ldsf, c->stream, q);
+            } else {
+                hipLaunchKernelGGL(kp, dim3((unsigned)((size_t)B * p.wgs_per_row)), dim3(256), lds2, c->stream, p);
+            }
             OBTG_HIP(c, hipGetLastError());
             return OBTG_OK;
         }

@@ -62,6 +62,7 @@ struct obtg_ctx {
     obtg::DevBuf d_poly_off;  // int[n_poly+1]
     int n_poly = 0, n_poly_pts = 0, max_poly_K = 0;
     bool polys_planar = true;   // every registered polygon vertex has z == 0
+    bool fd_dedup = false;      // reuse row 0's GJK results for bit-identical hull pairs
     obtg::DevBuf d_hp_a, d_hp_b;  // hull pair list
     int n_hull_pairs = 0;
 

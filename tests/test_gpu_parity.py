@@ -439,3 +439,34 @@ def test_pair_partition_large_swarm(capi, synth):
     assert torch.equal(torch.cat(parts, dim=1), full)
     ctx.set_stream(0)
     ctx.close()
+
+
+def test_gjk_fd_dedup_is_bit_identical(capi, synth):
+    """obtg_ctx_set_fd_dedup: reusing row 0's results for bit-identical hull pairs changes nothing,
+    on a finite-difference batch (one vehicle differs per row) and on unrelated rows (nothing reusable)."""
+    N, M = 64, 8
+    Y = synth.swarm_control_points(N, 2, 10, seed=1234)
+    polys = synth.polygon_obstacles(M, seed=1234)
+    ppts, poff = synth.pack_polys(polys)
+    pa, pb = synth.swarm_pairs(N, M)
+    B = 40
+    Yfd = synth.fd_batch(Y, B=B, h=0.37)                  # a visible step: results really change
+    Yrand = np.stack([synth.swarm_control_points(N, 2, 10, seed=s) for s in range(6)])
+    Ymix = Yfd.copy()
+    Ymix[7] = Yrand[3]                                    # one row unrelated to row 0
+    Ymix[9] = Ymix[0]                                     # one row identical to row 0
+    ctx = capi.Context(N, 2, 10, 0)
+    ctx.set_polygons(ppts, poff)
+    ctx.set_hull_pairs(pa, pb)
+    for Yb in (Yfd, Yrand, Ymix):
+        ctx.set_fd_dedup(False)
+        ref = ctx.gjk_swarm(Yb, md_cap=500)
+        ctx.set_fd_dedup(True)
+        got = ctx.gjk_swarm(Yb, md_cap=500)
+        for key in ("flag", "n_support", "status"):
+            assert np.array_equal(got[key], ref[key]), key
+        for key in ("c1", "c2", "dist"):
+            assert np.array_equal(got[key], ref[key], equal_nan=True), key
+    # the FD rows really differ from row 0 somewhere (the test is not vacuous)
+    assert (ref["dist"][1:] != ref["dist"][0:1]).any()
+    ctx.close()
