@@ -111,6 +111,11 @@ int obtg_ang_rate(obtg_ctx*, const double* Y, const double* tf, int B, double ma
  * (the `dv.normSquare().min()` variant commented at optimization.py:338 and used by
  * Examples/SequentialSwarm.py:65): out[B][C(N+M,2)]. */
 int obtg_temporal_sep_min(obtg_ctx*, const double* Y, int B, double max_sep, double* out);
+/* the same restricted to pairs [pair_begin, pair_begin+pair_count) of the lexicographic list:
+ * out[B][pair_count].  With pair_begin = 0, pair_count = N-1 this is the one-vs-many constraint
+ * of Examples/SequentialSwarm.py:43-70 (vehicle 0 against every other one). */
+int obtg_temporal_sep_min_range(obtg_ctx*, const double* Y, int B, double max_sep,
+                                int pair_begin, int pair_count, double* out);
 
 /* ---- same sweeps on DEVICE pointers, asynchronous on the context's stream ---------------
  * pair_begin/pair_count select a contiguous block of the lexicographic pair list (the

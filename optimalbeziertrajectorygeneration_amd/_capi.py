@@ -42,6 +42,7 @@ _SIGNATURES = {
     "obtg_speed": (_i, [_vp, _vp, _vp, _i, _d, _i, _vp]),
     "obtg_ang_rate": (_i, [_vp, _vp, _vp, _i, _d, _vp]),
     "obtg_temporal_sep_min": (_i, [_vp, _vp, _i, _d, _vp]),
+    "obtg_temporal_sep_min_range": (_i, [_vp, _vp, _i, _d, _i, _i, _vp]),
     "obtg_temporal_sep_dev": (_i, [_vp, _vp, _i, _d, _i, _i, _vp]),
     "obtg_temporal_sep_min_dev": (_i, [_vp, _vp, _i, _d, _i, _i, _vp]),
     "obtg_speed_dev": (_i, [_vp, _vp, _vp, _i, _d, _i, _vp]),
@@ -231,11 +232,13 @@ class Context(object):
         self._check(self._lib.obtg_temporal_sep(self._h, _ptr(Y), B, float(max_sep), _ptr(out)), "obtg_temporal_sep")
         return out
 
-    def temporal_sep_min(self, Y, max_sep):
+    def temporal_sep_min(self, Y, max_sep, pair_begin=0, pair_count=None):
         Y, B = self._rows(Y)
-        out = np.empty((B, self.num_pairs))
-        self._check(self._lib.obtg_temporal_sep_min(self._h, _ptr(Y), B, float(max_sep), _ptr(out)),
-                    "obtg_temporal_sep_min")
+        if pair_count is None:
+            pair_count = self.num_pairs - pair_begin
+        out = np.empty((B, pair_count))
+        self._check(self._lib.obtg_temporal_sep_min_range(self._h, _ptr(Y), B, float(max_sep), int(pair_begin),
+                                                          int(pair_count), _ptr(out)), "obtg_temporal_sep_min_range")
         return out
 
     def speed(self, Y, tf, bound, is_max):

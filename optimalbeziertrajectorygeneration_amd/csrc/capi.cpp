@@ -173,7 +173,7 @@ const char* obtg_abi_symbols(void)
         "obtg_strerror\0obtg_last_error\0obtg_device_count\0obtg_abi_symbols\0"
         "obtg_ctx_create\0obtg_ctx_destroy\0obtg_ctx_set_stream\0obtg_ctx_set_deg_elev\0obtg_sync\0"
         "obtg_len_temporal_sep\0obtg_len_speed\0obtg_len_ang_rate\0obtg_num_pairs\0"
-        "obtg_temporal_sep\0obtg_speed\0obtg_ang_rate\0obtg_temporal_sep_min\0"
+        "obtg_temporal_sep\0obtg_speed\0obtg_ang_rate\0obtg_temporal_sep_min\0obtg_temporal_sep_min_range\0"
         "obtg_temporal_sep_dev\0obtg_temporal_sep_min_dev\0obtg_speed_dev\0obtg_ang_rate_dev\0obtg_dynamics_dev\0"
         "obtg_fd_batch_dev\0obtg_gjk_pairs\0obtg_ctx_set_polygons\0obtg_ctx_set_hull_pairs\0"
         "obtg_ctx_set_fd_dedup\0obtg_gjk_swarm_dev\0obtg_gjk_swarm\0obtg_min_dist\0obtg_min_dist2poly\0"
@@ -333,18 +333,29 @@ static int d2h(obtg_ctx* c, void* dst, const void* src, size_t bytes)
 
 static size_t ysize(const obtg_ctx* c) { return (size_t)c->n_veh * c->dim * (c->deg + 1); }
 
-static int host_sep(obtg_ctx* c, const double* Y, int B, double max_sep, bool min_only, double* out)
+static int host_sep(obtg_ctx* c, const double* Y, int B, double max_sep, bool min_only, double* out,
+                    int pair_begin = 0, int pair_count = -1)
 {
     if (!check_ctx(c) || !Y || !out || B < 0) return OBTG_ERR_ARG;
-    if (B == 0 || c->n_pairs == 0) return OBTG_OK;
+    if (pair_count < 0) pair_count = c->n_pairs - pair_begin;
+    if (pair_begin < 0 || pair_begin + pair_count > c->n_pairs) return OBTG_ERR_ARG;
+    if (B == 0 || pair_count == 0) return OBTG_OK;
     (void)hipSetDevice(c->device);
-    const size_t per = min_only ? (size_t)c->n_pairs : (size_t)obtg_len_temporal_sep(c);
+    const size_t per = min_only ? (size_t)pair_count : (size_t)pair_count * (2 * c->deg + c->R + 1);
     int rc = h2d(c, c->ws_in, Y, sizeof(double) * ysize(c) * B);
     if (rc) return rc;
     if ((rc = c->ws_out.reserve(sizeof(double) * per * B))) return rc;
-    rc = launch_temporal_sep(c, c->ws_in.as<double>(), B, max_sep, 0, c->n_pairs, min_only, c->ws_out.as<double>());
+    rc = launch_temporal_sep(c, c->ws_in.as<double>(), B, max_sep, pair_begin, pair_count, min_only,
+                             c->ws_out.as<double>());
     if (rc) return rc;
     return d2h(c, out, c->ws_out.p, sizeof(double) * per * B);
+}
+
+int obtg_temporal_sep_min_range(obtg_ctx* c, const double* Y, int B, double max_sep, int pair_begin,
+                                int pair_count, double* out)
+{
+    if (pair_count < 0) return OBTG_ERR_ARG;
+    return host_sep(c, Y, B, max_sep, true, out, pair_begin, pair_count);
 }
 
 int obtg_temporal_sep(obtg_ctx* c, const double* Y, int B, double max_sep, double* out)
