@@ -503,20 +503,60 @@ __global__ __launch_bounds__(256) void k_gjk_swarm_planar(const GjkSwarmParams p
         Result r;
         r.c1 = V3{ qnan, qnan, qnan }; r.c2 = r.c1; r.dist = qnan;
         if (flag == 1 && status == OBTG_ST_OK) {
-            Ctx<MemLds> g;
-            g.mem = MemLds{ lds };
-            g.P1 = Poly{ p.pa[kk] * VP, NC, NC, 0 };
-            g.P2 = Poly{ p.pb[kk] * VP, NC, NC, 0 };
-            g.trace = nullptr; g.trace_cap = 0; g.n_support = 0;
-            gjk::Simplex s;
-            s.keys = keys;
+            // planar restatement of gjk.py:299-360 (z terms are exact zeros, see gjk_device.h):
+            // pick the partner vertex O of the closest feature, then ONE segment evaluation
+            const double* q1 = lds + p.pa[kk] * VP;
+            const double* q2 = lds + p.pb[kk] * VP;
             const int ia1 = r4.z & 0xff, ia2 = (r4.z >> 8) & 0xff, ib1 = (r4.z >> 16) & 0xff, ib2 = (r4.z >> 24) & 0xff;
             const int ic1 = r4.w & 0xff, ic2 = (r4.w >> 8) & 0xff;
-            s.A = gjk::Vert{ gjk::sub(gjk::point(g.mem, g.P1, ia1), gjk::point(g.mem, g.P2, ia2)), ia1, ia2 };
-            s.B = gjk::Vert{ gjk::sub(gjk::point(g.mem, g.P1, ib1), gjk::point(g.mem, g.P2, ib2)), ib1, ib2 };
-            s.C = gjk::Vert{ gjk::sub(gjk::point(g.mem, g.P1, ic1), gjk::point(g.mem, g.P2, ic2)), ic1, ic2 };
-            s.D = s.A;
-            gjk::closest_from_simplex(g, s, r);
+            const V2 a1{ q1[ia1], q1[NC + ia1] }, a2{ q2[ia2], q2[NC + ia2] };
+            const V2 A = gjk::sub2(a1, a2);
+            int which = 0;                    // 0: point A, 1: segment A-B, 2: segment A-C, 3: plane
+            if (keys & gjk::kC) {
+                const V2 b1{ q1[ib1], q1[NC + ib1] }, b2{ q2[ib2], q2[NC + ib2] };
+                const V2 c1{ q1[ic1], q1[NC + ic1] }, c2{ q2[ic2], q2[NC + ic2] };
+                const V2 B = gjk::sub2(b1, b2), C = gjk::sub2(c1, c2);
+                const V2 A0 = gjk::neg2(A), AB = gjk::sub2(B, A), AC = gjk::sub2(C, A);
+                const double w = gjk::cz(AB, AC);
+                const V2 t1{ -(w * AC.y), w * AC.x };
+                const V2 t2{ AB.y * w, -(AB.x * w) };
+                which = (gjk::dotb2(t1, A0) >= 0) ? 2 : ((gjk::dotb2(t2, A0) >= 0) ? 1 : 3);
+            } else if (keys & gjk::kB) which = 1;
+            if (which == 1 || which == 2) {
+                const int io1 = which == 2 ? ic1 : ib1, io2 = which == 2 ? ic2 : ib2;
+                const V2 o1{ q1[io1], q1[NC + io1] }, o2{ q2[io2], q2[NC + io2] };
+                const V2 O = gjk::sub2(o1, o2);
+                double t = 0.0;               // weightedOriginToLine (gjk.py:397-437)
+                if (gjk::eq2(A, O)) {
+                    r.dist = __builtin_sqrt(gjk::dot2(A, A));
+                } else {
+                    const V2 v = gjk::sub2(O, A);
+                    t = -gjk::dot2(v, A) / gjk::dot2(v, v);
+                    if (t > 1) t = 1; else if (t < 0) t = 0;
+                    const V2 cp{ (1 - t) * A.x + t * O.x, (1 - t) * A.y + t * O.y };
+                    r.dist = __builtin_sqrt(gjk::dot2(cp, cp));
+                }
+                r.c1 = V3{ (1 - t) * a1.x + t * o1.x, (1 - t) * a1.y + t * o1.y, 0.0 };
+                r.c2 = V3{ (1 - t) * a2.x + t * o2.x, (1 - t) * a2.y + t * o2.y, 0.0 };
+            } else if (which == 0) {
+                r.dist = __builtin_sqrt(gjk::dotb2(A, A));         // np.linalg.norm (gjk.py:352)
+                r.c1 = V3{ a1.x, a1.y, 0.0 };
+                r.c2 = V3{ a2.x, a2.y, 0.0 };
+            } else {
+                // origin inside the triangle's plane region (rare): the general 3-D evaluation
+                Ctx<MemLds> g;
+                g.mem = MemLds{ lds };
+                g.P1 = Poly{ p.pa[kk] * VP, NC, NC, 0 };
+                g.P2 = Poly{ p.pb[kk] * VP, NC, NC, 0 };
+                g.trace = nullptr; g.trace_cap = 0; g.n_support = 0;
+                gjk::Simplex s;
+                s.keys = keys;
+                s.A = gjk::Vert{ gjk::sub(gjk::point(g.mem, g.P1, ia1), gjk::point(g.mem, g.P2, ia2)), ia1, ia2 };
+                s.B = gjk::Vert{ gjk::sub(gjk::point(g.mem, g.P1, ib1), gjk::point(g.mem, g.P2, ib2)), ib1, ib2 };
+                s.C = gjk::Vert{ gjk::sub(gjk::point(g.mem, g.P1, ic1), gjk::point(g.mem, g.P2, ic2)), ic1, ic2 };
+                s.D = s.A;
+                gjk::closest_from_simplex(g, s, r);
+            }
         }
         const size_t o = obase + kk;
         p.flag[o] = flag;
