@@ -14,6 +14,7 @@
 // polygons of one evaluation row in LDS (structure-of-arrays per vehicle, odd pitch) and
 // its lanes walk consecutive pairs of that row.
 #include <algorithm>
+#include <cstdlib>
 
 #include "gjk_device.h"
 #include "obtg_internal.h"
@@ -932,11 +933,11 @@ int launch_gjk_swarm(obtg_ctx* c, const double* dY, int B, int max_iter, int md_
     p.n_poly_pts = c->n_poly_pts; p.n_pairs = c->n_hull_pairs;
     const int vlen = c->dim * (c->deg + 1);
     p.vp = (vlen % 2 == 0) ? vlen + 1 : vlen;
-    // workgroups per row: one staging of the row's hulls serves `chunk` pairs; keep >= ~6k
-    // workgroups in flight-order so that the last wave of workgroups is a small fraction
-    int wgs = 1;
-    while ((long)B * wgs < 6144 && (c->n_hull_pairs + wgs - 1) / wgs > 256) wgs <<= 1;
-    while ((c->n_hull_pairs + wgs - 1) / wgs > 1024) wgs <<= 1;   // bounds the per-chunk LDS records
+    // workgroups per row.  Lanes refill from their workgroup's chunk, so a chunk must hold several
+    // pairs per lane (measured at C3: 316 pairs per 256 lanes = 0.281 ms, 1264 pairs = 0.215 ms);
+    // small batches trade that for enough workgroups to fill the chip.
+    int wgs = (c->n_hull_pairs + 1279) / 1280;
+    while ((long)B * wgs < 2048 && (c->n_hull_pairs + wgs - 1) / wgs > 256) wgs <<= 1;
     p.chunk = (c->n_hull_pairs + wgs - 1) / wgs;
     p.wgs_per_row = (c->n_hull_pairs + p.chunk - 1) / p.chunk;
     p.max_iter = max_iter; p.md_cap = md_cap;
@@ -960,7 +961,10 @@ int launch_gjk_swarm(obtg_ctx* c, const double* dY, int B, int max_iter, int md_
             case 21: kp = k_gjk_swarm_planar<21, false>; kf = k_gjk_swarm_planar<21, true>; break;
             default: break;
         }
-        if (kp && lds2 <= 48 * 1024) {   // larger rows: the general kernel does better than 1-2 workgroups per CU
+        if (kp && lds2 <= 64 * 1024) {   // larger rows: the general kernel does better than 1-2 workgroups per CU
+            if (lds2 > 48 * 1024)
+                OBTG_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(kp),
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
             ScopedKernelTimer t(c, OBTG_K_GJK);
             if (c->fd_dedup && B > 1 && kf) {
                 // Finite-difference de-duplication: row 0 in full, its results broadcast to every
@@ -971,7 +975,14 @@ int launch_gjk_swarm(obtg_ctx* c, const double* dY, int B, int max_iter, int md_
                 const int tot = B * c->n_veh;
                 hipLaunchKernelGGL(k_changed_objects, dim3((tot + 255) / 256), dim3(256), 0, c->stream, dY, B,
                                    c->n_veh, c->dim * (c->deg + 1), chg);
-                hipLaunchKernelGGL(kp, dim3((unsigned)p.wgs_per_row), dim3(256), lds2, c->stream, p);
+                {   // row 0 alone: chunk it as a one-row batch (many small workgroups)
+                    GjkSwarmParams r0 = p;
+                    int w0 = (c->n_hull_pairs + 1279) / 1280;
+                    while (w0 < 2048 && (c->n_hull_pairs + w0 - 1) / w0 > 256) w0 <<= 1;
+                    r0.chunk = (c->n_hull_pairs + w0 - 1) / w0;
+                    r0.wgs_per_row = (c->n_hull_pairs + r0.chunk - 1) / r0.chunk;
+                    hipLaunchKernelGGL(kp, dim3((unsigned)r0.wgs_per_row), dim3(256), lds2, c->stream, r0);
+                }
                 const size_t np = (size_t)c->n_hull_pairs;
                 const dim3 cb(256);
                 const unsigned gy = (unsigned)((B - 1 + 15) / 16);
