@@ -353,10 +353,11 @@ __device__ __forceinline__ void diff_elev1(const double (&p)[NC], double val, do
     for (int c = 1; c < N; ++c) d[c] = t[c - 1] * ((double)c / (double)N) + t[c] * ((double)(N - c) / (double)N);
 }
 
-// The degree-4n stage (41 coefficients at n = 10, each a folded product row plus one FP64
-// division) is split over kDynParts waves per group of 64 vehicles; boundaries balance the
-// folded term counts (+ a division's worth per coefficient).
-constexpr int kDynParts = 4;
+// The degree-4n stage can be split over kDynParts waves per group of 64 vehicles (balanced
+// constexpr k-ranges).  Measured at C3 after the tables became scalar loads: 1 part 0.030 ms,
+// 2 parts 0.039 ms, 4 parts 0.043 ms -- every part repeats the derivative / degree-2n stage, and
+// that redundancy costs more than the extra waves hide.  Kept at 1.
+constexpr int kDynParts = 1;
 constexpr int dyn_cost(int k, int n2) { return k / 2 - (k - n2 > 0 ? k - n2 : 0) + 1 + 6; }
 constexpr int dyn_bound(int n2, int q)
 {
