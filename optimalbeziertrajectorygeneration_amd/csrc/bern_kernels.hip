@@ -60,7 +60,10 @@ struct NsParams {
     const double* __restrict__ tf;    // [B]            (vehicle mode)
     const int2* __restrict__ pairs;   // [P]            (pair mode)
     const double* __restrict__ W2;    // folded weights [L][NC]
-    const double* __restrict__ Tt;    // elevation table [L+R][L] (R > 0)
+    const double* __restrict__ Tt;    // elevation tables (R > 0), three rows back to back:
+                                      //   scale[L]      = C(2n, j)
+                                      //   binp[R+2L-1]  = C(R, m) for m = -(L-1) .. R+L-1 (0 outside 0..R)
+                                      //   inv[L+R]      = 1 / C(2n+R, k)
     double* __restrict__ out;
     int n_veh, n_obj, R;
     int item_begin, item_count;       // items of this launch (pairs or vehicles)
@@ -159,6 +162,14 @@ __device__ __forceinline__ void flush_chunk(const double* __restrict__ tile, dou
                                             size_t grow, int LR, int k0, int kc, int n_valid, int lane)
 {
     const int total = n_valid * kc;
+    if (kc == kTileK) {           // full chunk: power-of-two row length, no integer division
+        static_assert((kTileK & (kTileK - 1)) == 0, "kTileK must be a power of two");
+        for (int e = lane; e < total; e += kWave) {
+            const int pr = e / kTileK, q = e & (kTileK - 1);
+            store_nt(gout + grow + (size_t)pr * LR + k0 + q, tile[pr * TP + q]);
+        }
+        return;
+    }
     for (int e = lane; e < total; e += kWave) {
         const int pr = e / kc, q = e - pr * kc;
         store_nt(gout + grow + (size_t)pr * LR + k0 + q, tile[pr * TP + q]);
@@ -302,14 +313,24 @@ __global__ __launch_bounds__(256) void k_normsq_elev(const NsParams p)
                 }
             }
         } else {
+            // elev(R) as a binomially scaled convolution (bezier.py:1127-1147 written out):
+            //   out_k = (1/C(2n+R,k)) * sum_j [C(2n,j) c_j] * C(R, k-j)
+            // the weights depend on k-j only, so the whole table is one padded binomial row of
+            // R+2L-1 doubles that lives in the scalar cache; a dense (2n+R+1) x (2n+1) table (20 KB at
+            // R = 100) thrashed it: 1.31 ms -> see DESIGN.md for the C5 sweep.
+            const ctab_t escale = as_ctab(p.Tt), ebin = escale + L, einv = ebin + (p.R + 2 * L - 1);
+            double ch[L];
+#pragma unroll
+            for (int j = 0; j < L; ++j) ch[j] = cf[j] * escale[j];
             double m = INFINITY;
             for (int k0 = 0; k0 < LR; k0 += kTileK) {
                 const int kc = min(kTileK, LR - k0);
                 for (int kk = 0; kk < kc; ++kk) {
-                    const ctab_t Tr = as_ctab(p.Tt) + (size_t)(k0 + kk) * L;
+                    const ctab_t win = ebin + (k0 + kk);      // win[L-1-j] = C(R, k-j)
                     double s = 0.0;
 #pragma unroll
-                    for (int j = 0; j < L; ++j) s = fma(cf[j], Tr[j], s);
+                    for (int j = 0; j < L; ++j) s = fma(ch[j], win[L - 1 - j], s);
+                    s *= einv[k0 + kk];
                     if (MINONLY) m = fmin(m, s);
                     else if (mine) tile[r * S::TPC + kk] = p.sign * s + p.offset;
                 }

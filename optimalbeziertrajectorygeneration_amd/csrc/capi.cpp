@@ -111,7 +111,7 @@ int ensure_tables(obtg_ctx* c)
         }
     }
     if (c->R > 0 && c->R <= 512) {
-        auto Tt = elev_table_T(L, c->R);
+        auto Tt = elev_conv_tables(L, c->R);
         int rc = upload(c, c->d_Tt, Tt.data(), Tt.size() * sizeof(double));
         if (rc) return rc;
     }

@@ -17,6 +17,7 @@ double binom(int n, int k);                         // scipy.special.binom on in
 std::vector<double> binom_row(int n);               // C(n, 0..n)
 std::vector<double> folded_product_weights(int n, int dim);  // [2n+1][n+1], see bern_kernels.hip
 std::vector<double> elev_table_T(int L_in, int R);  // transposed, zero padded: [L_in+R][L_in]
+std::vector<double> elev_conv_tables(int L_in, int R);  // scale | padded C(R,.) | 1/C(N+R,.)
 
 // ---------------------------------------------------------------- device buffers
 struct DevBuf {
@@ -46,7 +47,7 @@ struct obtg_ctx {
     obtg::DevBuf d_pairs;     // int2[n_pairs]  (i, j) lexicographic, i < j < n_obj
     obtg::DevBuf d_obs;       // double[n_obs][dim]
     obtg::DevBuf d_w2;        // folded product weights for (deg, dim)
-    obtg::DevBuf d_Tt;        // elevation table (2*deg -> 2*deg+R), transposed
+    obtg::DevBuf d_Tt;        // elevation (2*deg -> 2*deg+R) as convolution tables (elev_conv_tables)
     obtg::DevBuf d_ang_w2n, d_ang_w22n, d_ang_wn;  // angular-rate fast path weights
     std::vector<int> h_pairs; // host copy of the pair table (2 ints per pair)
     std::vector<int> h_tiles; // row-window tiles of the current (pair_begin, pair_count)

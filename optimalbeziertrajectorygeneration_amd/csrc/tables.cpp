@@ -56,4 +56,17 @@ std::vector<double> elev_table_T(int L_in, int R)
     return T;
 }
 
+// Degree elevation by R of an L_in-coefficient curve as a scaled convolution: three rows back to back
+//   scale[L_in] = C(N, j);  binp[R + 2 L_in - 1] = C(R, m), m = -(L_in-1) .. R+L_in-1;  inv[L_in+R] = 1/C(N+R, k)
+std::vector<double> elev_conv_tables(int L_in, int R)
+{
+    const int N = L_in - 1;
+    std::vector<double> t;
+    t.reserve((size_t)L_in + R + 2 * L_in - 1 + L_in + R);
+    for (int j = 0; j <= N; ++j) t.push_back(binom(N, j));
+    for (int m = -(L_in - 1); m <= R + L_in - 1; ++m) t.push_back(binom(R, m));
+    for (int k = 0; k <= N + R; ++k) t.push_back(1.0 / binom(N + R, k));
+    return t;
+}
+
 }  // namespace obtg
