@@ -64,6 +64,7 @@ struct NsParams {
                                       //   scale[L]      = C(2n, j)
                                       //   binp[R+2L-1]  = C(R, m) for m = -(L-1) .. R+L-1 (0 outside 0..R)
                                       //   inv[L+R]      = 1 / C(2n+R, k)
+    const double* __restrict__ Td;    // dense elevation table, transposed: Td[k][j] = T[j][k], [L+R][L] (R > 0)
     double* __restrict__ out;
     int n_veh, n_obj, R;
     int item_begin, item_count;       // items of this launch (pairs or vehicles)
@@ -166,17 +167,20 @@ __device__ __forceinline__ void flush_chunk(const double* __restrict__ tile, dou
         static_assert((kTileK & (kTileK - 1)) == 0, "kTileK must be a power of two");
         for (int e = lane; e < total; e += kWave) {
             const int pr = e / kTileK, q = e & (kTileK - 1);
-            store_nt(gout + grow + (size_t)pr * LR + k0 + q, tile[pr * TP + q]);
+            gout[grow + (size_t)pr * LR + k0 + q] = tile[pr * TP + q];
         }
         return;
     }
     for (int e = lane; e < total; e += kWave) {
         const int pr = e / kc, q = e - pr * kc;
-        store_nt(gout + grow + (size_t)pr * LR + k0 + q, tile[pr * TP + q]);
+        gout[grow + (size_t)pr * LR + k0 + q] = tile[pr * TP + q];
     }
 }
 
-template <int NC, int DIM, int MODE /*0 = pairs, 1 = vehicles*/, bool MINONLY>
+// ELEV = false: DEG_ELEV == 0 (the product IS the output); ELEV = true: R > 0.  Separate
+// instantiations so that the R > 0 code (two weight columns in registers) does not cost the
+// R == 0 kernel its occupancy.
+template <int NC, int DIM, int MODE /*0 = pairs, 1 = vehicles*/, bool MINONLY, bool ELEV>
 __global__ __launch_bounds__(256) void k_normsq_elev(const NsParams p)
 {
     using S = NsShape<NC, DIM>;
@@ -191,8 +195,7 @@ __global__ __launch_bounds__(256) void k_normsq_elev(const NsParams p)
 
     // LDS: [staged objects: stage_slots * VP][per-wave transposition tiles]
     double* vl = lds;
-    const int tile_pitch = (p.R == 0) ? S::TPF : S::TPC;
-    double* tile = lds + p.stage_slots * S::VP + wave * (p.tile_rows * tile_pitch);
+    double* tile = lds + p.stage_slots * S::VP + wave * (p.tile_rows * S::TPF);
 
     // ---- stage the objects this workgroup touches
     const double* Yrow = p.Y + (size_t)b * p.n_veh * S::VLEN;
@@ -293,7 +296,7 @@ __global__ __launch_bounds__(256) void k_normsq_elev(const NsParams p)
         double cf[L];
         normsq_coeffs<NC, DIM>(a, as_ctab(p.W2), cf);
 
-        if (p.R == 0) {
+        if (!ELEV) {
             // elevMatrix(2n, 0) is the identity (bezier.py:1141-1147): the product IS the output
             if (MINONLY) {
                 double m = cf[0];
@@ -313,34 +316,59 @@ __global__ __launch_bounds__(256) void k_normsq_elev(const NsParams p)
                 }
             }
         } else {
-            // elev(R) as a binomially scaled convolution (bezier.py:1127-1147 written out):
-            //   out_k = (1/C(2n+R,k)) * sum_j [C(2n,j) c_j] * C(R, k-j)
-            // the weights depend on k-j only, so the whole table is one padded binomial row of
-            // R+2L-1 doubles that lives in the scalar cache; a dense (2n+R+1) x (2n+1) table (20 KB at
-            // R = 100) thrashed it: 1.31 ms -> see DESIGN.md for the C5 sweep.
-            const ctab_t escale = as_ctab(p.Tt), ebin = escale + L, einv = ebin + (p.R + 2 * L - 1);
-            double ch[L];
+            if (MINONLY) {
+                // elev(R) as a binomially scaled convolution (bezier.py:1127-1147 written out):
+                //   out_k = (1/C(2n+R,k)) * sum_j [C(2n,j) c_j] * C(R, k-j)
+                // only the minimum over k leaves the lane
+                const ctab_t escale = as_ctab(p.Tt), ebin = escale + L, einv = ebin + (p.R + 2 * L - 1);
+                double ch[L];
 #pragma unroll
-            for (int j = 0; j < L; ++j) ch[j] = cf[j] * escale[j];
-            double m = INFINITY;
-            for (int k0 = 0; k0 < LR; k0 += kTileK) {
-                const int kc = min(kTileK, LR - k0);
-                for (int kk = 0; kk < kc; ++kk) {
-                    const ctab_t win = ebin + (k0 + kk);      // win[L-1-j] = C(R, k-j)
+                for (int j = 0; j < L; ++j) ch[j] = cf[j] * escale[j];
+                double m = INFINITY;
+                for (int k = 0; k < LR; ++k) {
+                    const ctab_t win = ebin + k;              // win[L-1-j] = C(R, k-j)
                     double s = 0.0;
 #pragma unroll
                     for (int j = 0; j < L; ++j) s = fma(ch[j], win[L - 1 - j], s);
-                    s *= einv[k0 + kk];
-                    if (MINONLY) m = fmin(m, s);
-                    else if (mine) tile[r * S::TPC + kk] = p.sign * s + p.offset;
+                    m = fmin(m, s * einv[k]);
                 }
-                if (!MINONLY) {
-                    wave_sync();
-                    flush_chunk<S::TPC>(tile, p.out, row * LR, LR, k0, kc, n_valid, lane);
-                    wave_sync();
+                if (mine) p.out[row + r] = p.sign * m + p.offset;
+            } else {
+                // Full elevated rows: switch the lane <-> data mapping.  The 2n+1 product coefficients
+                // of the wave's pairs go to the LDS tile; then lane = output column k keeps its column
+                // of the elevation matrix (2n+1 weights) in registers and walks the pairs, reading each
+                // pair's coefficients as LDS broadcasts.  Every store instruction writes 64 consecutive
+                // doubles of one output row: no transposition, no partial rows.  Two columns per lane
+                // (k, k+64) share the broadcasts.
+                if (mine) {
+#pragma unroll
+                    for (int k = 0; k < L; ++k) tile[r * S::TPF + k] = cf[k];
                 }
+                wave_sync();
+                for (int kb = 0; kb < LR; kb += 2 * kWave) {
+                    const int k1 = kb + lane, k2 = kb + kWave + lane;
+                    double w1[L], w2[L];
+#pragma unroll
+                    for (int j = 0; j < L; ++j) {
+                        w1[j] = k1 < LR ? p.Td[(size_t)k1 * L + j] : 0.0;
+                        w2[j] = k2 < LR ? p.Td[(size_t)k2 * L + j] : 0.0;
+                    }
+                    for (int pr = 0; pr < n_valid; ++pr) {
+                        const double* cr = tile + pr * S::TPF;
+                        double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+                        for (int j = 0; j < L; ++j) {
+                            const double cj = cr[j];
+                            s1 = fma(cj, w1[j], s1);
+                            s2 = fma(cj, w2[j], s2);
+                        }
+                        double* orow = p.out + (row + pr) * LR;
+                        if (k1 < LR) store_nt(orow + k1, p.sign * s1 + p.offset);
+                        if (k2 < LR) store_nt(orow + k2, p.sign * s2 + p.offset);
+                    }
+                }
+                wave_sync();
             }
-            if (MINONLY && mine) p.out[row + r] = p.sign * m + p.offset;
         }
     }
 }
@@ -415,7 +443,8 @@ __device__ __forceinline__ void dyn_final(const AngParams& p, const double (&num
         tile[lane * L4 + (k - K0)] = p.w2 - sn / sd;
     }
     wave_sync();
-    flush_chunk<L4>(tile, p.out, grow, L4, K0, K1 - K0, n_valid, lane);
+    if (K0 == 0 && K1 == L4) flush_full<L4, L4>(tile, p.out, grow, n_valid, lane);   // whole rows: contiguous
+    else flush_chunk<L4>(tile, p.out, grow, L4, K0, K1 - K0, n_valid, lane);
 }
 
 // angular rate (optimization.py:425-459, 578-611) and, from the same derivatives, the speed
@@ -799,7 +828,7 @@ static int launch_ns_t(obtg_ctx* c, NsParams p, int B, int kernel_id)
     const size_t stage = (size_t)p.stage_slots * S::VP * sizeof(double);
     size_t lds = 0;
     if (MINONLY) { p.tile_rows = 0; lds = stage; }
-    else if (p.R > 0) { p.tile_rows = kWave; lds = stage + (size_t)p.waves * kWave * S::TPC * sizeof(double); }
+    else if (p.R > 0) { p.tile_rows = kWave; lds = stage + (size_t)p.waves * kWave * S::TPF * sizeof(double); }
     else {
         for (int tr = kWave; tr >= 16; tr >>= 1) {
             p.tile_rows = tr;
@@ -808,7 +837,8 @@ static int launch_ns_t(obtg_ctx* c, NsParams p, int B, int kernel_id)
         }
     }
     if (lds > 160 * 1024) return OBTG_ERR_UNSUPPORTED;
-    auto kern = k_normsq_elev<NC, DIM, MODE, MINONLY>;
+    void (*kern)(const NsParams) = p.R > 0 ? k_normsq_elev<NC, DIM, MODE, MINONLY, true>
+                                           : k_normsq_elev<NC, DIM, MODE, MINONLY, false>;
     if (lds > 48 * 1024)
         OBTG_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -864,7 +894,7 @@ int launch_temporal_sep(obtg_ctx* c, const double* dY, int B, double max_sep, in
     if (fast_shape(c)) {
         NsParams p{};
         p.Y = dY; p.obs = c->d_obs.as<double>(); p.tf = nullptr;
-        p.pairs = c->d_pairs.as<int2>(); p.W2 = c->d_w2.as<double>(); p.Tt = c->d_Tt.as<double>();
+        p.pairs = c->d_pairs.as<int2>(); p.W2 = c->d_w2.as<double>(); p.Tt = c->d_Tt.as<double>(); p.Td = c->d_Td.as<double>();
         p.out = d_out; p.n_veh = c->n_veh; p.n_obj = c->n_obj; p.R = c->R;
         p.item_begin = pair_begin; p.item_count = pair_count;
         // workgroup = 4 waves sharing one staging of the row's objects; each wave walks
@@ -952,7 +982,7 @@ int launch_speed(obtg_ctx* c, const double* dY, const double* d_tf, int B, doubl
     if (fast_shape(c)) {
         NsParams p{};
         p.Y = dY; p.obs = nullptr; p.tf = d_tf; p.pairs = nullptr;
-        p.W2 = c->d_w2.as<double>(); p.Tt = c->d_Tt.as<double>(); p.out = d_out;
+        p.W2 = c->d_w2.as<double>(); p.Tt = c->d_Tt.as<double>(); p.Td = c->d_Td.as<double>(); p.out = d_out;
         p.n_veh = c->n_veh; p.n_obj = c->n_veh; p.R = c->R;
         p.item_begin = 0; p.item_count = c->n_veh;
         p.groups_per_wg = 1;

@@ -114,6 +114,8 @@ int ensure_tables(obtg_ctx* c)
         auto Tt = elev_conv_tables(L, c->R);
         int rc = upload(c, c->d_Tt, Tt.data(), Tt.size() * sizeof(double));
         if (rc) return rc;
+        auto Td = elev_table_T(L, c->R);
+        if ((rc = upload(c, c->d_Td, Td.data(), Td.size() * sizeof(double)))) return rc;
     }
     c->tables_R = c->R;
     return OBTG_OK;
@@ -226,7 +228,7 @@ void obtg_ctx_destroy(obtg_ctx* c)
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     flush_pending_events(c);
-    DevBuf* bufs[] = { &c->d_pairs, &c->d_obs, &c->d_w2, &c->d_Tt, &c->d_ang_w2n, &c->d_ang_w22n, &c->d_ang_wn,
+    DevBuf* bufs[] = { &c->d_pairs, &c->d_obs, &c->d_w2, &c->d_Tt, &c->d_Td, &c->d_ang_w2n, &c->d_ang_w22n, &c->d_ang_wn,
                        &c->d_binrows, &c->d_tiles, &c->d_poly_pts, &c->d_poly_off, &c->d_hp_a, &c->d_hp_b, &c->ws_in,
                        &c->ws_in2, &c->ws_out };
     for (DevBuf* b : bufs) b->release();

@@ -48,6 +48,7 @@ struct obtg_ctx {
     obtg::DevBuf d_obs;       // double[n_obs][dim]
     obtg::DevBuf d_w2;        // folded product weights for (deg, dim)
     obtg::DevBuf d_Tt;        // elevation (2*deg -> 2*deg+R) as convolution tables (elev_conv_tables)
+    obtg::DevBuf d_Td;        // the same elevation as a dense transposed matrix (elev_table_T)
     obtg::DevBuf d_ang_w2n, d_ang_w22n, d_ang_wn;  // angular-rate fast path weights
     std::vector<int> h_pairs; // host copy of the pair table (2 ints per pair)
     std::vector<int> h_tiles; // row-window tiles of the current (pair_begin, pair_count)
