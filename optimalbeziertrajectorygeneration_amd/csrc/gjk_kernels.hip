@@ -150,9 +150,7 @@ __device__ __forceinline__ void gjk_sweep_planar(int c_end, int* s_next, int max
             } else {
                 ++rr;
                 if (gjk::matches_old2(g, old, s.A.v)) {
-#ifndef OBTG_EXP_NOFINAL
                     gjk::closest_from_simplex(g, gjk::lift(old), r);
-#endif
                     r.flag = 1; done = true;
                 } else if (rr >= md_cap) { r.flag = 1; r.status = OBTG_ST_MD_CAP; done = true; }
             }

@@ -22,6 +22,49 @@ DEG_ELEV = 0   # module constant read at call time, like optimization.py:17
 FD_STEP = 1.4901161193847656e-08   # SciPy '2-point' abs_step (sqrt of machine epsilon)
 
 
+# ---------------------------------------------------------------------------------------------
+# module-level evaluators with the reference's private signatures (optimization.py:311-459).
+# Drivers copy / call these directly (Examples/Example1_DubinsCarTimeOptimal.py:19-52 re-implements
+# the first one with a `degElev` argument), so they exist here too; contexts are cached per shape.
+# ---------------------------------------------------------------------------------------------
+_ctx_cache = {}
+
+
+def _shape_ctx(nVeh, dim, deg, R, device=0):
+    key = (int(nVeh), int(dim), int(deg), int(R), int(device))
+    c = _ctx_cache.get(key)
+    if c is None:
+        c = _capi.Context(key[0], key[1], key[2], key[3], device=key[4])
+        _ctx_cache[key] = c
+    return c
+
+
+def _temporalSeparationConstraints(y, nVeh, dim, maxSep, degElev=None):
+    if nVeh <= 1:
+        return None
+    y = np.ascontiguousarray(y, dtype=np.float64)
+    R = DEG_ELEV if degElev is None else degElev
+    return _shape_ctx(nVeh, dim, y.shape[1] - 1, R).temporal_sep(y, maxSep)[0]
+
+
+def _minSpeedConstraints(y, nVeh, dim, tf, minSpeed):
+    y = np.ascontiguousarray(y, dtype=np.float64)
+    return _shape_ctx(nVeh, dim, y.shape[1] - 1, DEG_ELEV).speed(y, tf, minSpeed, False)[0]
+
+
+def _maxSpeedConstraints(y, nVeh, dim, tf, maxSpeed):
+    y = np.ascontiguousarray(y, dtype=np.float64)
+    return _shape_ctx(nVeh, dim, y.shape[1] - 1, DEG_ELEV).speed(y, tf, maxSpeed, True)[0]
+
+
+def _maxAngularRateConstraints(y, nVeh, dim, tf, maxAngRate):
+    if dim != 2:
+        raise ValueError('The input curve must be two dimensional,\n'
+                         'instead it is {} dimensional'.format(dim))
+    y = np.ascontiguousarray(y, dtype=np.float64)
+    return _shape_ctx(nVeh, dim, y.shape[1] - 1, DEG_ELEV).ang_rate(y, tf, maxAngRate)[0]
+
+
 class BezOptimization(object):
     def __init__(self,
                  numVeh=1,
