@@ -49,6 +49,10 @@ def parse():
     ap.add_argument("--fd-dedup", action="store_true",
                     help="reuse row 0's gjkNew results for bit-identical hull pairs (obtg_ctx_set_fd_dedup); "
                          "NOT the headline number")
+    ap.add_argument("--mode", default="batch", choices=["batch", "pairs"],
+                    help="batch: every rank evaluates its own FD batch, no collective (default, the headline); "
+                         "pairs: ONE evaluation batch, the pair list partitioned over the ranks and the per-pair "
+                         "separation minima all-gathered (RCCL) -- the 256-vehicle case of BASELINE.json")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for rehearsals)")
     ap.add_argument("--one-device", action="store_true",
                     help="rehearsal only: every rank uses device 0 (needs --backend gloo)")
@@ -97,7 +101,7 @@ def main():
     N, d, n, R, M = cfg["N"], cfg["d"], cfg["n"], cfg["R"], cfg.get("n_poly", 0)
     n_x = N * d * (n - 1)
     B = args.batch or (n_x + 1)
-    seed = 1234 + 1000 * rank          # every rank its own swarm instance
+    seed = 1234 + (1000 * rank if args.mode == "batch" else 0)   # batch mode: every rank its own swarm instance
     Y = synth.swarm_control_points(N, d, n, seed=seed)
     polys = synth.polygon_obstacles(M, seed=1234)
     ppts, poff = synth.pack_polys(polys) if M else (None, [0])
@@ -143,6 +147,9 @@ def main():
     def barrier():
         if world > 1:
             dist.barrier()
+
+    if args.mode == "pairs":
+        return pairs_mode(args, ctx, dist, world, rank, dev, dY, B, max_sep, barrier)
 
     for _ in range(args.warmup):
         step()
@@ -220,6 +227,45 @@ def main():
             "cpu_baseline_numpy": cpu_np,
         }
         print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def pairs_mode(args, ctx, dist, world, rank, dev, dY, B, max_sep, barrier):
+    """Pair-partitioned temporal separation of ONE batch (same swarm on every rank): each rank sweeps a
+    contiguous block of the lexicographic pair list and the per-pair minima are all-gathered."""
+    import torch
+    from optimalbeziertrajectorygeneration_amd.distributed import PairPartitionedSweep, gpu_temporal_sep_evaluator
+    sweep = PairPartitionedSweep(ctx.num_pairs, 1)
+    evaluate = gpu_temporal_sep_evaluator(ctx, dY, B, max_sep, min_only=True)
+
+    def step():
+        return sweep.run(evaluate, B, dev)
+
+    for _ in range(args.warmup):
+        out = step()
+    torch.cuda.synchronize()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    torch.cuda.synchronize()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    # every rank must hold the full, identical result
+    chk = out.sum().item()
+    if rank == 0:
+        print(json.dumps({
+            "metric": "pair-partitioned separation-minima evals/s (one batch across all GPUs, RCCL all-gather)",
+            "value": round(B * args.steps / elapsed, 2), "unit": "constraint-evals/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 4),
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "%s temporal-separation minima, %d pairs split over %d ranks, B=%d rows"
+                                   % (args.workload, ctx.num_pairs, world, B), "checksum": chk}}))
     if world > 1:
         dist.destroy_process_group()
 
