@@ -367,7 +367,8 @@ __global__ __launch_bounds__(256) void k_gjk_swarm_planar(const GjkSwarmParams p
     }
     __syncthreads();
     const bool shortcut = p.max_iter >= 3 && p.md_cap >= 2;
-    int* list = ext + 2 * n_obj;                          // FIXUP: compacted pair indices of a segment
+    unsigned* plist = reinterpret_cast<unsigned*>(ext + 2 * n_obj);   // [chunk] packed (a | b << 16)
+    int* list = reinterpret_cast<int*>(plist + p.chunk);   // FIXUP: compacted pair indices of a segment
     const unsigned char* chg = FIXUP ? p.chg + (size_t)b * p.n_veh : nullptr;
 
     for (int seg0 = 0; seg0 < (FIXUP ? p.n_pairs : 1); seg0 += p.chunk) {
@@ -383,6 +384,11 @@ __global__ __launch_bounds__(256) void k_gjk_swarm_planar(const GjkSwarmParams p
         c0 = 0; c1 = s_nlist;
         __syncthreads();
         if (c1 == 0) continue;                            // uniform: nothing changed in this segment
+    }
+    // the chunk's (a, b) object ids go to LDS once: the refill path must not wait on global memory
+    for (int q = c0 + (int)threadIdx.x; q < c1; q += blockDim.x) {
+        const int kq = FIXUP ? list[q] : q;
+        plist[q - c0] = (unsigned)p.pa[kq] | ((unsigned)p.pb[kq] << 16);
     }
     if (threadIdx.x == 0) s_next = c0;
     __syncthreads();
@@ -411,8 +417,8 @@ __global__ __launch_bounds__(256) void k_gjk_swarm_planar(const GjkSwarmParams p
                     const int my = base + __popcll(want & ((1ull << lane) - 1ull));
                     if (my < c1) {
                         k = my;
-                        const int kk = FIXUP ? list[k] : k;
-                        const int a = p.pa[kk], bb = p.pb[kk];
+                        const unsigned ab = plist[k - c0];
+                        const int a = (int)(ab & 0xffffu), bb = (int)(ab >> 16);
                         o1 = lds + a * VP;
                         o2 = lds + bb * VP;
                         s.keys = 0; dir = V2{ 1.0, 0.0 };
@@ -947,7 +953,8 @@ int launch_gjk_swarm(obtg_ctx* c, const double* dY, int B, int max_iter, int md_
         const int nc = c->deg + 1;
         const int vp2 = 2 * nc + 1;
         const size_t lds2 = sizeof(double) * (((size_t)(c->n_veh + c->n_poly) * vp2 + 1) & ~(size_t)1) +
-                            sizeof(int4) * (size_t)p.chunk + sizeof(int) * 2 * (size_t)(c->n_veh + c->n_poly);
+                            sizeof(int4) * (size_t)p.chunk + sizeof(int) * 2 * (size_t)(c->n_veh + c->n_poly) +
+                            sizeof(unsigned) * (size_t)p.chunk;
         void (*kp)(const GjkSwarmParams) = nullptr;
         void (*kf)(const GjkSwarmParams) = nullptr;
         switch (nc) {
@@ -996,7 +1003,7 @@ int launch_gjk_swarm(obtg_ctx* c, const double* dY, int B, int max_iter, int md_
                 q.chunk = 1024;
                 const size_t ldsf = sizeof(double) * (((size_t)(c->n_veh + c->n_poly) * vp2 + 1) & ~(size_t)1) +
                                     sizeof(int4) * (size_t)q.chunk + sizeof(int) * 2 * (size_t)(c->n_veh + c->n_poly) +
-                                    sizeof(int) * (size_t)q.chunk;
+                                    2 * sizeof(int) * (size_t)q.chunk;
                 hipLaunchKernelGGL(kf, dim3((unsigned)(B - 1)), dim3(256), ldsf, c->stream, q);
             } else {
                 hipLaunchKernelGGL(kp, dim3((unsigned)((size_t)B * p.wgs_per_row)), dim3(256), lds2, c->stream, p);
