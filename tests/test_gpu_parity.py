@@ -470,3 +470,50 @@ def test_gjk_fd_dedup_is_bit_identical(capi, synth):
     # the FD rows really differ from row 0 somewhere (the test is not vacuous)
     assert (ref["dist"][1:] != ref["dist"][0:1]).any()
     ctx.close()
+
+
+def test_c_abi_error_codes(capi):
+    """Argument errors come back as negative return codes (never exceptions across the C boundary,
+    never a launch with bad shapes): exercised through ctypes directly."""
+    import ctypes as C
+    lib = capi.load()
+    h = C.c_void_p()
+    assert lib.obtg_ctx_create(C.byref(h), 0, 2, 5, 0, 0, None, 0) == -1          # n_veh < 1
+    assert lib.obtg_ctx_create(C.byref(h), 2, 2, 5, -1, 0, None, 0) == -1         # deg_elev < 0
+    assert lib.obtg_ctx_create(C.byref(h), 2, 2, 5, 0, 3, None, 0) == -1          # obstacles without data
+    assert lib.obtg_ctx_create(C.byref(h), 2, 2, 5, 0, 0, None, 99) == -3         # no such device
+    assert lib.obtg_ctx_create(None, 2, 2, 5, 0, 0, None, 0) == -1
+    ctx = capi.Context(6, 2, 5, 0)
+    hh = ctx.handle
+    Y = np.zeros((12, 6))
+    out = np.zeros(15 * 11)
+    p = lambda a: a.ctypes.data_as(C.c_void_p)
+    assert lib.obtg_temporal_sep(hh, None, 1, 0.5, p(out)) == -1
+    assert lib.obtg_temporal_sep(hh, p(Y), -1, 0.5, p(out)) == -1
+    assert lib.obtg_temporal_sep(hh, p(Y), 0, 0.5, p(out)) == 0                   # empty batch is fine
+    assert lib.obtg_temporal_sep_min_range(hh, p(Y), 1, 0.5, 10, 6, p(out)) == -1  # range past the pair list
+    assert lib.obtg_temporal_sep_dev(hh, p(Y), 1, 0.5, -1, 3, p(out)) == -1
+    assert lib.obtg_ctx_set_deg_elev(hh, -3) == -1
+    ia = np.array([0], np.int32)
+    ib = np.array([9], np.int32)
+    assert lib.obtg_ctx_set_hull_pairs(hh, p(ia), p(ib), 1) == -1                  # object id out of range
+    pts = np.zeros((3, 3))
+    off = np.array([0, 3], np.int32)
+    f = np.zeros(1, np.int32)
+    d3 = np.zeros(3)
+    assert lib.obtg_gjk_pairs(hh, p(pts), 3, p(off), 1, p(ia), p(ib), 1, 128, 100, p(f), p(d3), p(d3), p(d3),
+                              None, 0, None, None) == -1                           # pair references polygon 9
+    assert lib.obtg_gjk_pairs(hh, p(pts), 3, p(off), 1, p(ia), p(ia), 1, 0, 100, p(f), p(d3), p(d3), p(d3),
+                              None, 0, None, None) == -1                           # max_iter < 1
+    bad_off = np.array([0, 2], np.int32)
+    assert lib.obtg_gjk_pairs(hh, p(pts), 3, p(bad_off), 1, p(ia), p(ia), 1, 128, 100, p(f), p(d3), p(d3), p(d3),
+                              None, 0, None, None) == -1                           # offsets do not cover the points
+    c3 = capi.Context(2, 3, 5, 0)
+    o3 = np.zeros(2 * 21)
+    tf = np.ones(1)
+    assert lib.obtg_ang_rate(c3.handle, p(np.zeros((6, 6))), p(tf), 1, 1.0, p(o3)) == -1   # 2-D only
+    assert lib.obtg_strerror(-5).decode().startswith("degree")
+    big = capi.Context(2, 2, 600, 0)       # beyond every instantiated / generic size for the products
+    with pytest.raises(RuntimeError):
+        big.ang_rate(np.zeros((4, 601)), 1.0, 1.0)
+    ctx.close(); c3.close(); big.close()
