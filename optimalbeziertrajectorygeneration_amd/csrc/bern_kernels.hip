@@ -608,22 +608,54 @@ __global__ __launch_bounds__(kWave) void k_generic_normsq_elev(const GenParams p
     }
 }
 
+// Register-tiled convolution for the long products of the generic angular-rate kernel.
+// Lane owns 8 consecutive outputs k0..k0+7:  s[i] = sum_t ah[t] * bp[Q - t + i],  Q = pad + k0,
+// where bp is the zero-padded copy of the second operand (`pad` leading zeros) and ah is padded
+// with zeros to a multiple of 8 (la8).  The 8-wide window of bp slides by one element per step and
+// lives in registers as a circular buffer (slot (i - t) mod 8), so a step costs one broadcast LDS
+// read (ah[t]) and one vector LDS read (the new window element) for 8 FMAs -- 0.25 LDS reads per
+// FMA instead of 2 for the one-output-per-lane form.
+__device__ __forceinline__ void conv_tile8(const double* ah, int la8, const double* bp, int pad, int k0,
+                                           double (&s)[8])
+{
+    const double* q = bp + pad + k0;
+    double Rw[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { Rw[i] = q[i]; s[i] = 0.0; }
+    for (int j = 0; j < la8; j += 8) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const double a = ah[j + u];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) s[i] = fma(a, Rw[(i - u) & 7], s[i]);
+            Rw[(-(u + 1)) & 7] = q[-(j + u + 1)];      // window element 0 of step t+1
+        }
+    }
+}
+
 // generic angular rate: one wave per (row, vehicle); m = n + R
 __global__ __launch_bounds__(kWave) void k_generic_angrate(const GenParams p)
 {
     extern __shared__ double lds[];
     const int lane = threadIdx.x;
     const int n = p.n, nc = n + 1, m = n + p.R, mc = m + 1, L2 = 2 * m + 1, L4 = 4 * m + 1;
+    const int mc8 = (mc + 7) & ~7, L28 = (L2 + 7) & ~7;
+    const int padm = mc8, padf = L28;                    // leading zeros of the padded b-operands
+    const int szm = padm + L2 + 16, szf = padf + L4 + 16;
     const long gi = blockIdx.x;
     const int b = (int)(gi / p.n_veh), veh = (int)(gi - (long)b * p.n_veh);
     double* pe = lds;              // [2][mc] elevated position
     double* d1 = pe + 2 * mc;      // [2][mc] first derivative (plain)
     double* d2 = d1 + 2 * mc;      // [2][mc] second derivative (plain)
     double* tm = d2 + 2 * mc;      // [2][mc] scratch
-    double* h1 = tm + 2 * mc;      // [2][mc] C(m,.) * d1
-    double* h2 = h1 + 2 * mc;      // [2][mc] C(m,.) * d2
-    double* nu = h2 + 2 * mc;      // [L2]    C(2m,.) * num1
-    double* de = nu + L2;          // [L2]    C(2m,.) * den1
+    double* h1 = tm + 2 * mc;      // [2][mc8] C(m,.) * d1, zero padded   (a-operands)
+    double* h2 = h1 + 2 * mc8;     // [2][mc8] C(m,.) * d2, zero padded
+    double* xp = h2 + 2 * mc8;     // [szm]  zero-padded C(m,.) * xD      (b-operands)
+    double* yp = xp + szm;         // [szm]  zero-padded C(m,.) * yD
+    double* nu = yp + szm;         // [L28]  C(2m,.) * num1, zero padded
+    double* de = nu + L28;         // [L28]  C(2m,.) * den1, zero padded
+    double* np_ = de + L28;        // [szf]  zero-padded nu
+    double* dp_ = np_ + szf;       // [szf]  zero-padded de
     const double* bn = p.bin + p.o_n;
     const double* bR = p.bin + p.o_R;
     const double* bm = p.bin + p.o_m;
@@ -632,6 +664,8 @@ __global__ __launch_bounds__(kWave) void k_generic_angrate(const GenParams p)
     const double* v = p.Y + ((size_t)b * p.n_veh + veh) * 2 * nc;
     const double val = (double)m / p.tf[b];
 
+    // zero everything that is read as padding
+    for (int e = lane; e < 4 * mc8 + 2 * szm + 2 * L28 + 2 * szf; e += kWave) h1[e] = 0.0;
     // pos.elev(R)  (optimization.py:453)
     if (p.R == 0) {
         for (int e = lane; e < 2 * nc; e += kWave) pe[e] = v[e];
@@ -666,25 +700,43 @@ __global__ __launch_bounds__(kWave) void k_generic_angrate(const GenParams p)
         __syncthreads();
     }
     for (int e = lane; e < 2 * mc; e += kWave) {
-        h1[e] = d1[e] * bm[e % mc];
-        h2[e] = d2[e] * bm[e % mc];
+        const int q = e / mc, c = e - q * mc;
+        const double s1 = d1[e] * bm[c];
+        h1[q * mc8 + c] = s1;
+        h2[q * mc8 + c] = d2[e] * bm[c];
+        (q == 0 ? xp : yp)[padm + c] = s1;
     }
     __syncthreads();
-    const double *xD = h1, *yD = h1 + mc, *xDD = h2, *yDD = h2 + mc;
-    for (int k = lane; k < L2; k += kWave) {
-        const double t1 = conv_at(yDD, mc, xD, mc, k) / b2m[k];
-        const double t2 = conv_at(xDD, mc, yD, mc, k) / b2m[k];
-        const double e1 = conv_at(xD, mc, xD, mc, k) / b2m[k];
-        const double e2 = conv_at(yD, mc, yD, mc, k) / b2m[k];
-        nu[k] = (t1 - t2) * b2m[k];
-        de[k] = (e1 + e2) * b2m[k];
+    const double *xD = h1, *yD = h1 + mc8, *xDD = h2, *yDD = h2 + mc8;
+    // num1 = yDD*xD - xDD*yD, den1 = xD*xD + yD*yD  (degree 2m), 8 coefficients per lane
+    for (int k0 = 8 * lane; k0 < L2; k0 += 8 * kWave) {
+        double t1[8], t2[8], e1[8], e2[8];
+        conv_tile8(yDD, mc8, xp, padm, k0, t1);
+        conv_tile8(xDD, mc8, yp, padm, k0, t2);
+        conv_tile8(xD, mc8, xp, padm, k0, e1);
+        conv_tile8(yD, mc8, yp, padm, k0, e2);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int k = k0 + i;
+            if (k < L2) {
+                const double c = b2m[k];
+                const double nk = (t1[i] / c - t2[i] / c) * c, dk = (e1[i] / c + e2[i] / c) * c;
+                nu[k] = nk; de[k] = dk;
+                np_[padf + k] = nk; dp_[padf + k] = dk;
+            }
+        }
     }
     __syncthreads();
     double* o = p.out + ((size_t)b * p.n_veh + veh) * L4;
-    for (int k = lane; k < L4; k += kWave) {
-        const double num = conv_at(nu, L2, nu, L2, k) / b4m[k];
-        const double den = conv_at(de, L2, de, L2, k) / b4m[k];
-        o[k] = p.offset - num / den;
+    for (int k0 = 8 * lane; k0 < L4; k0 += 8 * kWave) {
+        double sn[8], sd[8];
+        conv_tile8(nu, L28, np_, padf, k0, sn);
+        conv_tile8(de, L28, dp_, padf, k0, sd);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int k = k0 + i;
+            if (k < L4) o[k] = p.offset - (sn[i] / b4m[k]) / (sd[i] / b4m[k]);
+        }
     }
 }
 
@@ -1073,7 +1125,9 @@ int launch_ang_rate(obtg_ctx* c, const double* dY, const double* d_tf, int B, do
     const int m = c->deg + c->R, mc = m + 1, L2 = 2 * m + 1;
     if (m > 250) return OBTG_ERR_UNSUPPORTED;   // C(4m,2m) must stay finite in binary64
     g.Y = dY; g.tf = d_tf; g.out = d_out; g.B = B; g.offset = max_rate * max_rate;
-    size_t lds = sizeof(double) * ((size_t)12 * mc + 2 * L2);
+    const int mc8 = (mc + 7) & ~7, L28 = (L2 + 7) & ~7;
+    size_t lds = sizeof(double) * ((size_t)8 * mc + 4 * mc8 + 2 * (mc8 + L2 + 16) + 2 * L28 +
+                                   2 * (L28 + (4 * m + 1) + 16));
     if (lds > 160 * 1024) return OBTG_ERR_UNSUPPORTED;
     if (lds > 48 * 1024)
         OBTG_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_generic_angrate),
