@@ -229,7 +229,8 @@ void obtg_ctx_destroy(obtg_ctx* c)
     (void)hipStreamSynchronize(c->stream);
     flush_pending_events(c);
     DevBuf* bufs[] = { &c->d_pairs, &c->d_obs, &c->d_w2, &c->d_Tt, &c->d_Td, &c->d_ang_w2n, &c->d_ang_w22n, &c->d_ang_wn,
-                       &c->d_binrows, &c->d_tiles, &c->d_poly_pts, &c->d_poly_off, &c->d_hp_a, &c->d_hp_b, &c->ws_in,
+                       &c->d_binrows, &c->d_tiles, &c->d_poly_pts, &c->d_poly_off, &c->d_hp_a, &c->d_hp_b, &c->d_tile_chunk_off, &c->d_tile_order, &c->d_tile_pslots,
+                       &c->d_tile_cobj_off, &c->d_tile_cobjs, &c->ws_in,
                        &c->ws_in2, &c->ws_out };
     for (DevBuf* b : bufs) b->release();
     for (auto& b : c->ws_misc) b.release();
@@ -495,6 +496,7 @@ int obtg_ctx_set_polygons(obtg_ctx* c, const double* pts, int n_pts, const int* 
     c->max_poly_K = 0;
     for (int a = 0; a < n_poly; ++a) c->max_poly_K = std::max(c->max_poly_K, poly_off[a + 1] - poly_off[a]);
     c->n_hull_pairs = 0;   // object ids may have changed meaning
+    c->tile_valid = false;
     return OBTG_OK;
 }
 
@@ -510,6 +512,9 @@ int obtg_ctx_set_hull_pairs(obtg_ctx* c, const int* pair_a, const int* pair_b, i
     if (rc) return rc;
     if ((rc = upload(c, c->d_hp_b, pair_b, sizeof(int) * (size_t)n_pairs))) return rc;
     c->n_hull_pairs = n_pairs;
+    c->h_hp_a.assign(pair_a, pair_a + n_pairs);
+    c->h_hp_b.assign(pair_b, pair_b + n_pairs);
+    c->tile_valid = false;
     if (c->d_poly_off.p == nullptr) {
         int zero = 0;
         if ((rc = upload(c, c->d_poly_off, &zero, sizeof(int)))) return rc;

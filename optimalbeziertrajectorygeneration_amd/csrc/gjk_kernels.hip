@@ -230,6 +230,13 @@ struct GjkSwarmParams {
     int n_veh, dim, nc, n_poly, n_poly_pts, n_pairs, wgs_per_row, vp, chunk;
     int max_iter, md_cap;
     const unsigned char* chg;          // FIXUP kernels: [B][n_veh], 1 = vehicle differs from row 0
+    // TILED kernels (large rows): host-built chunk metadata, see build_tiles()
+    const int* chunk_off;              // [n_chunks+1] pair ranges in tile-major order
+    const int* order;                  // [n_pairs] original pair index of each sorted position
+    const unsigned* pslots;            // [n_pairs] LDS slots (a | b << 16) of each sorted position
+    const int* cobj_off;               // [n_chunks+1] object-list ranges
+    const int* cobjs;                  // object ids per chunk, slot order
+    int max_objs;                      // most objects any chunk stages
     int* __restrict__ flag;
     double* __restrict__ p1;
     double* __restrict__ p2;
@@ -314,37 +321,61 @@ __device__ __forceinline__ void support_fixed(const double* __restrict__ o1, con
     out.v = gjk::V2{ o1[i1] - o2[i2], o1[NC + i1] - o2[NC + i2] };
 }
 
-// FIXUP = false: the sweep proper (blockIdx -> (row, chunk of the pair list)).
-// FIXUP = true : finite-difference de-duplication pass, one workgroup per row b >= 1: only pairs
-//                with a hull that differs from row 0 (mask p.chg) are evaluated; everything else was
-//                filled in beforehand by k_bcast_row0.  The pair list is walked in segments of
-//                p.chunk candidates; the changed ones are compacted into an LDS list.
-template <int NC, bool FIXUP>
+// MODE 0: the sweep proper (blockIdx -> (row, chunk of the pair list)); every object of the row is
+//         staged, LDS slot == object id.
+// MODE 1: finite-difference de-duplication pass (FIXUP), one workgroup per row b >= 1: only pairs
+//         with a hull that differs from row 0 (mask p.chg) are evaluated; everything else was
+//         filled in beforehand by k_bcast_row0.  The pair list is walked in segments of
+//         p.chunk candidates; the changed ones are compacted into an LDS list.
+// MODE 2: large rows (TILED).  The host has sorted the pair list tile-major (8 x 64 blocks of the
+//         pair matrix) and cut it into chunks that touch at most p.max_objs objects; a workgroup
+//         stages only its chunk's objects (p.cobjs) and the pairs carry LDS slots (p.pslots);
+//         results go to the pairs' original positions (p.order).
+template <int NC, int MODE>
 __global__ __launch_bounds__(256) void k_gjk_swarm_planar(const GjkSwarmParams p)
 {
+    constexpr bool FIXUP = MODE == 1, TILED = MODE == 2;
     using gjk::V2;
     using gjk::Vert2;
     using gjk::Simplex2;
     constexpr int VP = PlanarShape<NC>::VP;
     extern __shared__ double lds[];
     __shared__ int s_next;
-    const int n_obj = p.n_veh + p.n_poly;
     const int b = FIXUP ? (int)blockIdx.x + 1 : (int)(blockIdx.x / p.wgs_per_row);
     const int w = FIXUP ? 0 : (int)(blockIdx.x - b * p.wgs_per_row);
-    int c0 = w * p.chunk, c1 = min(p.n_pairs, c0 + p.chunk);
-    int4* rec = reinterpret_cast<int4*>(lds + ((n_obj * VP + 1) & ~1));     // 16-byte aligned
+    int c0 = TILED ? p.chunk_off[w] : w * p.chunk;
+    int c1 = TILED ? p.chunk_off[w + 1] : min(p.n_pairs, c0 + p.chunk);
+    const int obj0 = TILED ? p.cobj_off[w] : 0;
+    const int n_obj = TILED ? p.cobj_off[w + 1] - obj0 : p.n_veh + p.n_poly;     // staged objects
+    const int cap_obj = TILED ? p.max_objs : n_obj;                                // LDS slots reserved
+    int4* rec = reinterpret_cast<int4*>(lds + ((cap_obj * VP + 1) & ~1));         // 16-byte aligned
     __shared__ int s_nlist;
 
     // ---- stage vehicles (rows x, y of the evaluation row) and padded polygons
     const double* Yrow = p.Y + (size_t)b * p.n_veh * 2 * NC;
-    for (int e = threadIdx.x; e < p.n_veh * 2 * NC; e += blockDim.x) {
-        const int v = e / (2 * NC), r = e - v * (2 * NC);
-        lds[v * VP + r] = Yrow[e];
-    }
-    for (int e = threadIdx.x; e < p.n_poly * 2 * NC; e += blockDim.x) {
-        const int o = e / (2 * NC), r = e - o * (2 * NC), q = r / NC, k = r - q * NC;
-        const int off = p.poly_off[o], K = p.poly_off[o + 1] - off;
-        lds[(p.n_veh + o) * VP + r] = p.poly[3 * off + q * K + (k < K ? k : 0)];
+    if (TILED) {
+        for (int e = threadIdx.x; e < n_obj * 2 * NC; e += blockDim.x) {
+            const int sl = e / (2 * NC), r = e - sl * (2 * NC);
+            const int obj = p.cobjs[obj0 + sl];
+            double val;
+            if (obj < p.n_veh) val = Yrow[(size_t)obj * 2 * NC + r];
+            else {
+                const int o = obj - p.n_veh, q = r / NC, k = r - q * NC;
+                const int off = p.poly_off[o], K = p.poly_off[o + 1] - off;
+                val = p.poly[3 * off + q * K + (k < K ? k : 0)];
+            }
+            lds[sl * VP + r] = val;
+        }
+    } else {
+        for (int e = threadIdx.x; e < p.n_veh * 2 * NC; e += blockDim.x) {
+            const int v = e / (2 * NC), r = e - v * (2 * NC);
+            lds[v * VP + r] = Yrow[e];
+        }
+        for (int e = threadIdx.x; e < p.n_poly * 2 * NC; e += blockDim.x) {
+            const int o = e / (2 * NC), r = e - o * (2 * NC), q = r / NC, k = r - q * NC;
+            const int off = p.poly_off[o], K = p.poly_off[o + 1] - off;
+            lds[(p.n_veh + o) * VP + r] = p.poly[3 * off + q * K + (k < K ? k : 0)];
+        }
     }
     __syncthreads();
 
@@ -367,7 +398,7 @@ __global__ __launch_bounds__(256) void k_gjk_swarm_planar(const GjkSwarmParams p
     }
     __syncthreads();
     const bool shortcut = p.max_iter >= 3 && p.md_cap >= 2;
-    unsigned* plist = reinterpret_cast<unsigned*>(ext + 2 * n_obj);   // [chunk] packed (a | b << 16)
+    unsigned* plist = reinterpret_cast<unsigned*>(ext + 2 * cap_obj);   // [chunk] packed slots (a | b << 16)
     int* list = reinterpret_cast<int*>(plist + p.chunk);   // FIXUP: compacted pair indices of a segment
     const unsigned char* chg = FIXUP ? p.chg + (size_t)b * p.n_veh : nullptr;
 
@@ -387,8 +418,11 @@ __global__ __launch_bounds__(256) void k_gjk_swarm_planar(const GjkSwarmParams p
     }
     // the chunk's (a, b) object ids go to LDS once: the refill path must not wait on global memory
     for (int q = c0 + (int)threadIdx.x; q < c1; q += blockDim.x) {
-        const int kq = FIXUP ? list[q] : q;
-        plist[q - c0] = (unsigned)p.pa[kq] | ((unsigned)p.pb[kq] << 16);
+        if (TILED) plist[q - c0] = p.pslots[q];
+        else {
+            const int kq = FIXUP ? list[q] : q;
+            plist[q - c0] = (unsigned)p.pa[kq] | ((unsigned)p.pb[kq] << 16);
+        }
     }
     if (threadIdx.x == 0) s_next = c0;
     __syncthreads();
@@ -502,7 +536,9 @@ __global__ __launch_bounds__(256) void k_gjk_swarm_planar(const GjkSwarmParams p
     const size_t obase = (size_t)b * p.n_pairs;
     const double qnan = __builtin_nan("");
     for (int k = c0 + (int)threadIdx.x; k < c1; k += blockDim.x) {
-        const int kk = FIXUP ? list[k] : k;
+        const int kk = TILED ? p.order[k] : (FIXUP ? list[k] : k);
+        const unsigned ab2 = plist[k - c0];
+        const int sa = (int)(ab2 & 0xffffu), sb = (int)(ab2 >> 16);
         const int4 r4 = rec[k - c0];
         const int flag = (int)(signed char)(r4.x & 0xff), status = (r4.x >> 8) & 0xff, keys = (r4.x >> 16) & 0xff;
         Result r;
@@ -510,8 +546,8 @@ __global__ __launch_bounds__(256) void k_gjk_swarm_planar(const GjkSwarmParams p
         if (flag == 1 && status == OBTG_ST_OK) {
             // planar restatement of gjk.py:299-360 (z terms are exact zeros, see gjk_device.h):
             // pick the partner vertex O of the closest feature, then ONE segment evaluation
-            const double* q1 = lds + p.pa[kk] * VP;
-            const double* q2 = lds + p.pb[kk] * VP;
+            const double* q1 = lds + sa * VP;
+            const double* q2 = lds + sb * VP;
             const int ia1 = r4.z & 0xff, ia2 = (r4.z >> 8) & 0xff, ib1 = (r4.z >> 16) & 0xff, ib2 = (r4.z >> 24) & 0xff;
             const int ic1 = r4.w & 0xff, ic2 = (r4.w >> 8) & 0xff;
             const V2 a1{ q1[ia1], q1[NC + ia1] }, a2{ q2[ia2], q2[NC + ia2] };
@@ -551,8 +587,8 @@ __global__ __launch_bounds__(256) void k_gjk_swarm_planar(const GjkSwarmParams p
                 // origin inside the triangle's plane region (rare): the general 3-D evaluation
                 Ctx<MemLds> g;
                 g.mem = MemLds{ lds };
-                g.P1 = Poly{ p.pa[kk] * VP, NC, NC, 0 };
-                g.P2 = Poly{ p.pb[kk] * VP, NC, NC, 0 };
+                g.P1 = Poly{ sa * VP, NC, NC, 0 };
+                g.P2 = Poly{ sb * VP, NC, NC, 0 };
                 g.trace = nullptr; g.trace_cap = 0; g.n_support = 0;
                 gjk::Simplex s;
                 s.keys = keys;
@@ -926,6 +962,68 @@ int launch_gjk_pairs(obtg_ctx* c, const double* d_soa, const int* d_off, const i
     return OBTG_OK;
 }
 
+// Tile-major chunking of the hull pair list for rows that do not fit LDS (MODE 2 above).
+// Pairs are bucketed by (a / 8, b / 64); a chunk is one bucket (<= 512 pairs, <= 72 objects when the
+// list is the usual all-pairs sweep; arbitrary lists are handled by cutting buckets at kMaxPairs /
+// kMaxObjs).  Cached in the context until the pair list or the polygons change.
+static int build_tiles(obtg_ctx* c, int /*vp*/)
+{
+    if (c->tile_valid) return OBTG_OK;
+    constexpr int TA = 8, TB = 64, kMaxPairs = 512, kMaxObjs = 96;
+    const int np = c->n_hull_pairs, nobj = c->n_veh + c->n_poly;
+    if (nobj > 65535) return OBTG_ERR_UNSUPPORTED;
+    const std::vector<int>& pa = c->h_hp_a;
+    const std::vector<int>& pb = c->h_hp_b;
+    if ((int)pa.size() != np) return OBTG_ERR_UNSUPPORTED;
+    const int nbb = (nobj + TB - 1) / TB;
+    std::vector<int> order(np);
+    for (int i = 0; i < np; ++i) order[i] = i;
+    auto key = [&](int i) { return (long)(pa[i] / TA) * nbb + pb[i] / TB; };
+    std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return key(x) < key(y); });
+    std::vector<int> chunk_off{ 0 }, cobj_off{ 0 }, cobjs;
+    std::vector<unsigned> pslots(np);
+    std::vector<int> slot_of(nobj, -1), touched;
+    int max_objs = 0, max_pairs = 0, start = 0;
+    auto close_chunk = [&](int end) {
+        for (int o : touched) slot_of[o] = -1;
+        max_objs = std::max(max_objs, (int)touched.size());
+        max_pairs = std::max(max_pairs, end - start);
+        cobjs.insert(cobjs.end(), touched.begin(), touched.end());
+        cobj_off.push_back((int)cobjs.size());
+        chunk_off.push_back(end);
+        touched.clear();
+        start = end;
+    };
+    for (int s2 = 0; s2 < np; ++s2) {
+        const int i = order[s2];
+        int need = (slot_of[pa[i]] < 0) + (slot_of[pb[i]] < 0 && pb[i] != pa[i]);
+        const bool new_bucket = s2 > start && key(i) != key(order[s2 - 1]);
+        if (s2 > start && (new_bucket || s2 - start >= kMaxPairs || (int)touched.size() + need > kMaxObjs))
+            close_chunk(s2);
+        for (int o : { pa[i], pb[i] })
+            if (slot_of[o] < 0) { slot_of[o] = (int)touched.size(); touched.push_back(o); }
+        pslots[s2] = (unsigned)slot_of[pa[i]] | ((unsigned)slot_of[pb[i]] << 16);
+    }
+    if (np > start) close_chunk(np);
+    auto up = [&](DevBuf& d, const void* src, size_t bytes) -> int {
+        int rc = d.reserve(bytes);
+        if (rc) return rc;
+        if (hipMemcpyAsync(d.p, src, bytes, hipMemcpyHostToDevice, c->stream) != hipSuccess) return OBTG_ERR_DEVICE;
+        return OBTG_OK;
+    };
+    int rc;
+    if ((rc = up(c->d_tile_chunk_off, chunk_off.data(), chunk_off.size() * sizeof(int)))) return rc;
+    if ((rc = up(c->d_tile_order, order.data(), order.size() * sizeof(int)))) return rc;
+    if ((rc = up(c->d_tile_pslots, pslots.data(), pslots.size() * sizeof(unsigned)))) return rc;
+    if ((rc = up(c->d_tile_cobj_off, cobj_off.data(), cobj_off.size() * sizeof(int)))) return rc;
+    if ((rc = up(c->d_tile_cobjs, cobjs.data(), cobjs.size() * sizeof(int)))) return rc;
+    if (hipStreamSynchronize(c->stream) != hipSuccess) return OBTG_ERR_DEVICE;   // sources are locals
+    c->tile_n_chunks = (int)chunk_off.size() - 1;
+    c->tile_max_objs = max_objs; c->tile_max_pairs = max_pairs;
+    c->tile_valid = true;
+    return OBTG_OK;
+}
+
 int launch_gjk_swarm(obtg_ctx* c, const double* dY, int B, int max_iter, int md_cap, int* d_flag,
                      double* d_p1, double* d_p2, double* d_dist, int* d_nsup, int* d_status)
 {
@@ -957,14 +1055,36 @@ int launch_gjk_swarm(obtg_ctx* c, const double* dY, int B, int max_iter, int md_
                             sizeof(unsigned) * (size_t)p.chunk;
         void (*kp)(const GjkSwarmParams) = nullptr;
         void (*kf)(const GjkSwarmParams) = nullptr;
+        void (*kt)(const GjkSwarmParams) = nullptr;
+#define OBTG_GJK_CASE(NC_) \
+    case NC_: kp = k_gjk_swarm_planar<NC_, 0>; kf = k_gjk_swarm_planar<NC_, 1>; kt = k_gjk_swarm_planar<NC_, 2>; break;
         switch (nc) {
-            case 4: kp = k_gjk_swarm_planar<4, false>; kf = k_gjk_swarm_planar<4, true>; break;
-            case 6: kp = k_gjk_swarm_planar<6, false>; kf = k_gjk_swarm_planar<6, true>; break;
-            case 8: kp = k_gjk_swarm_planar<8, false>; kf = k_gjk_swarm_planar<8, true>; break;
-            case 11: kp = k_gjk_swarm_planar<11, false>; kf = k_gjk_swarm_planar<11, true>; break;
-            case 16: kp = k_gjk_swarm_planar<16, false>; kf = k_gjk_swarm_planar<16, true>; break;
-            case 21: kp = k_gjk_swarm_planar<21, false>; kf = k_gjk_swarm_planar<21, true>; break;
+            OBTG_GJK_CASE(4) OBTG_GJK_CASE(6) OBTG_GJK_CASE(8) OBTG_GJK_CASE(11) OBTG_GJK_CASE(16) OBTG_GJK_CASE(21)
             default: break;
+        }
+#undef OBTG_GJK_CASE
+        if (kt && lds2 > 48 * 1024) {
+            // large rows: tile-major chunks, each staging only the objects it touches
+            int rc = build_tiles(c, 2 * nc + 1);
+            if (rc == OBTG_OK) {
+                GjkSwarmParams q = p;
+                q.chunk_off = c->d_tile_chunk_off.as<int>(); q.order = c->d_tile_order.as<int>();
+                q.pslots = c->d_tile_pslots.as<unsigned>(); q.cobj_off = c->d_tile_cobj_off.as<int>();
+                q.cobjs = c->d_tile_cobjs.as<int>(); q.max_objs = c->tile_max_objs;
+                q.chunk = c->tile_max_pairs; q.wgs_per_row = c->tile_n_chunks;
+                const size_t ldst = sizeof(double) * (((size_t)q.max_objs * vp2 + 1) & ~(size_t)1) +
+                                    sizeof(int4) * (size_t)q.chunk + sizeof(int) * 2 * (size_t)q.max_objs +
+                                    sizeof(unsigned) * (size_t)q.chunk;
+                if (ldst <= 64 * 1024) {
+                    if (ldst > 48 * 1024)
+                        OBTG_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(kt),
+                                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldst));
+                    ScopedKernelTimer t(c, OBTG_K_GJK);
+                    hipLaunchKernelGGL(kt, dim3((unsigned)((size_t)B * q.wgs_per_row)), dim3(256), ldst, c->stream, q);
+                    OBTG_HIP(c, hipGetLastError());
+                    return OBTG_OK;
+                }
+            } else if (rc != OBTG_ERR_UNSUPPORTED) return rc;
         }
         if (kp && lds2 <= 64 * 1024) {   // larger rows: the general kernel does better than 1-2 workgroups per CU
             if (lds2 > 48 * 1024)

@@ -66,6 +66,10 @@ struct obtg_ctx {
     bool polys_planar = true;   // every registered polygon vertex has z == 0
     bool fd_dedup = false;      // reuse row 0's GJK results for bit-identical hull pairs
     obtg::DevBuf d_hp_a, d_hp_b;  // hull pair list
+    std::vector<int> h_hp_a, h_hp_b;   // host copy (tile-major chunking of large rows)
+    obtg::DevBuf d_tile_chunk_off, d_tile_order, d_tile_pslots, d_tile_cobj_off, d_tile_cobjs;
+    bool tile_valid = false;
+    int tile_n_chunks = 0, tile_max_objs = 0, tile_max_pairs = 0;
     int n_hull_pairs = 0;
 
     // scratch for host-buffer entry points

@@ -517,3 +517,35 @@ def test_c_abi_error_codes(capi):
     with pytest.raises(RuntimeError):
         big.ang_rate(np.zeros((4, 601)), 1.0, 1.0)
     ctx.close(); c3.close(); big.close()
+
+
+def test_gjk_swarm_large_rows_tiled(capi, oracle, synth):
+    """Rows whose hulls do not fit LDS (C4's shape: 256 vehicles, degree 15, plus polygons) go
+    through the tile-major chunking; every pair must still match the oracle bit for bit."""
+    N, n, M = 256, 15, 5
+    Y = synth.swarm_control_points(N, 2, n, seed=1234)
+    polys = synth.polygon_obstacles(M, seed=3)
+    ppts, poff = synth.pack_polys(polys)
+    pa, pb = synth.swarm_pairs(N, M)
+    Yb = synth.fd_batch(Y, B=2, h=0.8)
+    ctx = capi.Context(N, 2, n, 0)
+    ctx.set_polygons(ppts, poff)
+    ctx.set_hull_pairs(pa, pb)
+    r = ctx.gjk_swarm(Yb, md_cap=500)
+    for b in range(2):
+        hp, ho = synth.pack_polys(synth.hulls_from_Y(Yb[b], 2) + polys)
+        o = oracle.gjk_pairs(hp, ho, pa, pb, md_cap=500, nthreads=8)
+        assert (r["flag"][b] == o["flag"]).all()
+        assert (r["n_support"][b] == o["n_support"]).all()
+        assert (r["status"][b] == o["status"]).all()
+        sep = o["flag"] == 1
+        for key in ("dist", "c1", "c2"):
+            assert np.max(np.abs(r[key][b][sep] - o[key][sep]) / np.maximum(1.0, np.abs(o[key][sep]))) < 1e-12
+    # an arbitrary (shuffled, partial) pair list takes the same path
+    rng = np.random.default_rng(0)
+    sel = rng.permutation(len(pa))[:5000]
+    ctx.set_hull_pairs(pa[sel], pb[sel])
+    r2 = ctx.gjk_swarm(Yb[:1], md_cap=500)
+    assert (r2["flag"][0] == r["flag"][0][sel]).all()
+    assert np.array_equal(r2["dist"][0], r["dist"][0][sel], equal_nan=True)
+    ctx.close()
