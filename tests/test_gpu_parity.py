@@ -549,3 +549,36 @@ def test_gjk_swarm_large_rows_tiled(capi, oracle, synth):
     assert (r2["flag"][0] == r["flag"][0][sel]).all()
     assert np.array_equal(r2["dist"][0], r["dist"][0][sel], equal_nan=True)
     ctx.close()
+
+
+@pytest.mark.parametrize("planar", [True, False])
+def test_gjk_random_point_sets_bit_exact(capi, oracle, planar):
+    """20 000 random polygon pairs (3..12 vertices, overlapping and separated, 2-D and 3-D): flags,
+    statuses, support counts and full support-index traces must equal the oracle's exactly."""
+    rng = np.random.default_rng(11 if planar else 12)
+    polys = []
+    for _ in range(400):
+        K = int(rng.integers(3, 13))
+        c = rng.uniform(-10, 10, size=3)
+        P = c + rng.normal(0, rng.uniform(0.5, 4.0), size=(K, 3))
+        if planar:
+            P[:, 2] = 0.0
+        polys.append(P)
+    pa = rng.integers(0, 400, size=20000).astype(np.int32)
+    pb = rng.integers(0, 400, size=20000).astype(np.int32)
+    off = np.zeros(401, np.int32)
+    off[1:] = np.cumsum([p.shape[0] for p in polys])
+    pts = np.vstack(polys)
+    ctx = capi.scratch_context()
+    r = ctx.gjk_pairs(pts, off, pa, pb, md_cap=300, trace_cap=48)
+    o = oracle.gjk_pairs(pts, off, pa, pb, md_cap=300, trace_cap=48, nthreads=8)
+    assert (r["flag"] == o["flag"]).all()
+    assert (r["status"] == o["status"]).all()
+    assert (r["n_support"] == o["n_support"]).all()
+    n = np.minimum(o["n_support"], 48)
+    mask = np.arange(48)[None, :] < n[:, None]
+    assert (r["trace"][mask] == o["trace"][mask]).all()
+    ok = (o["flag"] == 1) & (o["status"] == 0)
+    assert ok.sum() > 1000 and (o["flag"] == 0).sum() > 1000
+    for key in ("dist", "c1", "c2"):
+        assert np.max(np.abs(r[key][ok] - o[key][ok]) / np.maximum(1.0, np.abs(o[key][ok]))) < 1e-12
