@@ -1,0 +1,20 @@
+#!/bin/bash
+# Collect the judged evidence for one round on the GPU box (run through gpurun):
+#   tools/collect_profiles.sh r01_d
+# Writes gpurun_out/<tag>/{stats,fetch,write}/ + bench lines; tools/parse_profiles.py then copies
+# the summaries into profiles/ (run that in the container after gpurun merged gpurun_out/ back).
+set -e -o pipefail
+TAG=${1:-rXX}
+OUT=gpurun_out/$TAG
+mkdir -p $OUT
+export TMPDIR=/tmp
+python3 bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err
+echo "default bench done" > $OUT/progress.log
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o run -- python3 bench.py --steps 20 --warmup 3 --no-cpu > $OUT/bench_stats.json 2> $OUT/stats.err
+echo "kernel stats done" >> $OUT/progress.log
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_dedup -o run -- python3 bench.py --steps 20 --warmup 3 --no-cpu --fd-dedup > $OUT/bench_stats_dedup.json 2> $OUT/stats_dedup.err
+echo "dedup stats done" >> $OUT/progress.log
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -o run -- python3 bench.py --steps 3 --warmup 1 --no-cpu > $OUT/bench_fetch.json 2> $OUT/fetch.err
+echo "fetch pmc done" >> $OUT/progress.log
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/write -o run -- python3 bench.py --steps 3 --warmup 1 --no-cpu > $OUT/bench_write.json 2> $OUT/write.err
+echo "write pmc done" >> $OUT/progress.log
