@@ -53,7 +53,11 @@ enum {
 enum {
     OBTG_ST_OK = 0,
     OBTG_ST_MD_CAP = 1,  /* minimumDistance's `while True` (gjk/gjk.py:277) exceeded md_cap rounds */
-    OBTG_ST_MAXITER = 2  /* gjkNew exhausted maxIter (flag = -1, gjk/gjk.py:269-270) */
+    OBTG_ST_MAXITER = 2, /* gjkNew exhausted maxIter (flag = -1, gjk/gjk.py:269-270) */
+    OBTG_ST_CYCLE = 3    /* minimumDistance returned exactly to an earlier (simplex, direction) state: the
+                          * reference's loop depends on nothing else, so it never exits on this input.
+                          * Reported by the 3-D state machine (any z != 0, and the curve-distance entry
+                          * points); all-z-zero input runs on the 2-D machine, guarded by md_cap alone. */
 };
 
 /* per-item minDist status */

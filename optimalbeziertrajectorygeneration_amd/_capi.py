@@ -13,7 +13,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libobtg_hip.so")
 
 OK = 0
-ST_OK, ST_MD_CAP, ST_MAXITER = 0, 1, 2
+ST_OK, ST_MD_CAP, ST_MAXITER, ST_CYCLE = 0, 1, 2, 3
 MD_OK, MD_NODE_CAP, MD_DEPTH_CAP, MD_GJK_CAP = 0, 1, 2, 3
 K_TEMPORAL_SEP, K_SPEED, K_ANG_RATE, K_GJK, K_MIN_DIST, K_FD_BATCH, K_BERN, K_COUNT = range(8)
 

@@ -261,6 +261,38 @@ __device__ __forceinline__ bool matches_old(const Ctx<Mem>& g, const Simplex& o,
     return false;
 }
 
+// Brent cycle detector for minimumDistance's `while True` (gjk.py:277): the loop body is a function
+// of (live simplex entries, search direction) alone, so an exact return to a checkpointed state
+// proves that the reference never exits.  One checkpoint, refreshed after 1, 2, 4, ... rounds.
+struct Checkpoint {
+    int keys, power, lam;
+    int a1, a2, b1, b2, c1, c2, d1, d2;
+    V3 dir;
+    __device__ __forceinline__ void take(const Simplex& s, const V3& d)
+    {
+        keys = s.keys; dir = d;
+        a1 = s.A.i1; a2 = s.A.i2; b1 = s.B.i1; b2 = s.B.i2;
+        c1 = s.C.i1; c2 = s.C.i2; d1 = s.D.i1; d2 = s.D.i2;
+    }
+    __device__ __forceinline__ void start(const Simplex& s, const V3& d) { take(s, d); power = 1; lam = 0; }
+    __device__ __forceinline__ bool same(const Simplex& s, const V3& d) const
+    {
+        if (s.keys != keys || !eq(d, dir)) return false;
+        if ((keys & kA) && (s.A.i1 != a1 || s.A.i2 != a2)) return false;
+        if ((keys & kB) && (s.B.i1 != b1 || s.B.i2 != b2)) return false;
+        if ((keys & kC) && (s.C.i1 != c1 || s.C.i2 != c2)) return false;
+        if ((keys & (kD | kDpts)) && (s.D.i1 != d1 || s.D.i2 != d2)) return false;
+        return true;
+    }
+    // after one round that did not converge: true = the state repeats
+    __device__ __forceinline__ bool step(const Simplex& s, const V3& d)
+    {
+        if (same(s, d)) return true;
+        if (++lam == power) { take(s, d); power *= 2; lam = 0; }
+        return false;
+    }
+};
+
 struct Result {
     int flag, status, n_support;
     V3 c1, c2;
@@ -298,14 +330,17 @@ __device__ __forceinline__ void run(Ctx<Mem>& g, int max_iter, int md_cap, Resul
         if (s.keys & kColl) { r.flag = 0; r.status = OBTG_ST_OK; break; }
         if (dotb(s.A.v, dir) < 0) {
             Simplex old = s;
-            bool conv = false;
+            Checkpoint chk;
+            chk.start(s, dir);
+            bool conv = false, cycle = false;
             for (int rr = 0; rr < md_cap; ++rr) {
                 old = s;
                 do_simplex<Mem, PLANAR>(g, s, dir);
                 if (matches_old(g, old, s.A.v)) { conv = true; break; }
+                if (chk.step(s, dir)) { cycle = true; break; }
             }
             r.flag = 1;
-            if (!conv) { r.status = OBTG_ST_MD_CAP; break; }
+            if (!conv) { r.status = cycle ? OBTG_ST_CYCLE : OBTG_ST_MD_CAP; break; }
             r.status = OBTG_ST_OK;
             closest_from_simplex(g, old, r);
             break;

@@ -43,10 +43,12 @@ __device__ __forceinline__ void gjk_sweep(int c_end, int* s_next, int max_iter, 
     bool exhausted = false;
     Ctx<Mem> g;
     gjk::Simplex s, old;
+    gjk::Checkpoint chk;
     V3 dir{ 1.0, 0.0, 0.0 };
     int phase = 0, it = 0, rr = 0;
     s.keys = 0;
     s.A = gjk::Vert{ V3{ 0, 0, 0 }, 0, 0 };
+    chk.start(s, dir);
     s.B = s.A; s.C = s.A; s.D = s.A; old = s;
     const double qnan = __builtin_nan("");
     for (;;) {
@@ -81,14 +83,15 @@ __device__ __forceinline__ void gjk_sweep(int c_end, int* s_next, int max_iter, 
             if (phase == 0) {
                 ++it;
                 if (s.keys & gjk::kColl) { r.flag = 0; done = true; }
-                else if (gjk::dotb(s.A.v, dir) < 0) { phase = 1; rr = 0; }
+                else if (gjk::dotb(s.A.v, dir) < 0) { phase = 1; rr = 0; chk.start(s, dir); }
                 else if (it >= max_iter) { r.flag = -1; r.status = OBTG_ST_MAXITER; done = true; }
             } else {
                 ++rr;
                 if (gjk::matches_old(g, old, s.A.v)) {
                     gjk::closest_from_simplex(g, old, r);
                     r.flag = 1; done = true;
-                } else if (rr >= md_cap) { r.flag = 1; r.status = OBTG_ST_MD_CAP; done = true; }
+                } else if (chk.step(s, dir)) { r.flag = 1; r.status = OBTG_ST_CYCLE; done = true; }
+                else if (rr >= md_cap) { r.flag = 1; r.status = OBTG_ST_MD_CAP; done = true; }
             }
             if (done) {
                 r.n_support = g.n_support;
@@ -756,7 +759,7 @@ __global__ __launch_bounds__(64) void k_min_dist(const MdParams p)
             Result gr;
             gjk::run(g, p.max_iter, p.md_cap, gr);
             calls++;
-            if (gr.status == OBTG_ST_MD_CAP) { status = OBTG_MD_GJK_CAP; break; }
+            if (gr.status == OBTG_ST_MD_CAP || gr.status == OBTG_ST_CYCLE) { status = OBTG_MD_GJK_CAP; break; }
             double lb, t1, t2;
             if (gr.flag > 0) {
                 lb = gr.dist;
@@ -884,7 +887,7 @@ __global__ __launch_bounds__(64) void k_min_dist2poly(const Md2Params p)
             Result gr;
             gjk::run(g, p.max_iter, p.md_cap, gr);
             calls++;
-            if (gr.status == OBTG_ST_MD_CAP) { status = OBTG_MD_GJK_CAP; break; }
+            if (gr.status == OBTG_ST_MD_CAP || gr.status == OBTG_ST_CYCLE) { status = OBTG_MD_GJK_CAP; break; }
             double lb, t1, nT1, alpha = sc[G_ALPHA];
             double cx, cy, cz;
             if (gr.flag > 0) {

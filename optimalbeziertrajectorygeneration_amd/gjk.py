@@ -6,7 +6,8 @@ flag -1: maximum iterations met, 0: collision, 1: separated with
 info = (point on poly1, point on poly2, distance); info == () otherwise.  The reference's
 decision sequence is reproduced exactly (support indices are bit-identical), including its
 habit of stopping at a non-minimal distance.  Inputs on which the reference's
-`minimumDistance` loops forever (gjk.py:277) raise RuntimeError here after `md_cap` rounds.
+`minimumDistance` loops forever (gjk.py:277) raise RuntimeError here: as soon as the loop's state
+repeats (3-D input) or after `md_cap` rounds.
 """
 import numpy as np
 
@@ -20,6 +21,8 @@ def gjkNew(poly1, poly2, maxIter=128, verbose=False, md_cap=4096):
     off = [0, p1.shape[0], p1.shape[0] + p2.shape[0]]
     r = _capi.scratch_context().gjk_pairs(pts, off, [0], [1], max_iter=int(maxIter), md_cap=md_cap)
     flag, status = int(r['flag'][0]), int(r['status'][0])
+    if status == _capi.ST_CYCLE:
+        raise RuntimeError('gjkNew: minimumDistance cycles (the reference loops forever on this input)')
     if status == _capi.ST_MD_CAP:
         raise RuntimeError('gjkNew: minimumDistance did not converge in %d rounds '
                            '(the reference loops forever on this input)' % md_cap)

@@ -518,14 +518,36 @@ static int matches_old(const gjk_ctx_t *g, const simplex_t *old, const double *A
 #define ST_OK 0
 #define ST_MD_CAP 1      /* minimumDistance (gjk.py:277 `while True`) exceeded md_cap rounds */
 #define ST_MAXITER 2     /* gjkNew exhausted maxIter (flag -1, gjk.py:269-270) */
+#define ST_CYCLE 3       /* minimumDistance came back to an earlier (simplex, direction) state: its
+                          * `while True` is a function of that state alone, so the reference never
+                          * returns on this input */
+
+/* Cycle detector of the 3-D state machine (Brent: one checkpoint, refreshed after 1, 2, 4, ...
+ * rounds).  Only live dict entries take part, so stale slots cannot delay or fake a match.
+ * mode 0 off, 1 on, 2 auto = on unless every z of the input is 0 (the library runs such input
+ * on its 2-D machine, which keeps md_cap as the only guard). */
+static int g_cycle_mode = 2;
+EXPORT void obtg_oracle_set_cycle_detect(int mode) { g_cycle_mode = mode; }
+
+static int state_eq(const simplex_t *a, const double *da, const simplex_t *b, const double *db)
+{
+    if (a->hasA != b->hasA || a->hasB != b->hasB || a->hasC != b->hasC || a->hasD != b->hasD ||
+        a->hasDpts != b->hasDpts || a->collision != b->collision) return 0;
+    if (!(da[0] == db[0] && da[1] == db[1] && da[2] == db[2])) return 0;
+    if (a->hasA && (a->A.i1 != b->A.i1 || a->A.i2 != b->A.i2)) return 0;
+    if (a->hasB && (a->B.i1 != b->B.i1 || a->B.i2 != b->B.i2)) return 0;
+    if (a->hasC && (a->C.i1 != b->C.i1 || a->C.i2 != b->C.i2)) return 0;
+    if ((a->hasD || a->hasDpts) && (a->D.i1 != b->D.i1 || a->D.i2 != b->D.i2)) return 0;
+    return 1;
+}
 
 /* gjk/gjk.py:230-270 gjkNew + 273-360 minimumDistance.
  * poly1[K1][3], poly2[K2][3].  Outputs: *flag in {-1,0,1}; c1,c2,dist when flag==1.
  * trace (nullable) receives (i1,i2) of every supportPts call, *n_support their count.
  * Returns status. */
-EXPORT int obtg_oracle_gjk(const double *poly1, int K1, const double *poly2, int K2, int max_iter,
-                           int md_cap, int *flag, double *c1, double *c2, double *dist,
-                           short *trace, int trace_cap, int *n_support)
+static int gjk_impl(const double *poly1, int K1, const double *poly2, int K2, int max_iter,
+                    int md_cap, int *flag, double *c1, double *c2, double *dist,
+                    short *trace, int trace_cap, int *n_support, int cyc)
 {
     gjk_ctx_t g = { poly1, poly2, K1, K2, trace, trace_cap, 0 };
     simplex_t s; simplex_clear(&s);
@@ -538,15 +560,23 @@ EXPORT int obtg_oracle_gjk(const double *poly1, int K1, const double *poly2, int
         if (s.collision) { *flag = 0; *n_support = g.n_support; return ST_OK; }
         if (dotb(s.A.v, dir) < 0) {
             /* minimumDistance */
-            simplex_t old;
-            int conv = 0;
+            simplex_t old, chk = s;
+            double chk_dir[3] = { dir[0], dir[1], dir[2] };
+            int conv = 0, cycle = 0, power = 1, lam = 0;
             for (int r = 0; r < md_cap; ++r) {
                 old = s;
                 do_simplex(&g, &s, dir);
                 if (matches_old(&g, &old, s.A.v)) { conv = 1; break; }
+                if (cyc) {
+                    if (state_eq(&s, dir, &chk, chk_dir)) { cycle = 1; break; }
+                    if (++lam == power) {
+                        chk = s; chk_dir[0] = dir[0]; chk_dir[1] = dir[1]; chk_dir[2] = dir[2];
+                        power *= 2; lam = 0;
+                    }
+                }
             }
             *n_support = g.n_support;
-            if (!conv) { *flag = 1; return ST_MD_CAP; }
+            if (!conv) { *flag = 1; return cycle ? ST_CYCLE : ST_MD_CAP; }
             s = old;
             const double *P1 = g.p1, *P2 = g.p2;
             if (s.hasC) {
@@ -609,6 +639,20 @@ EXPORT int obtg_oracle_gjk(const double *poly1, int K1, const double *poly2, int
     return ST_MAXITER;
 }
 
+static int all_z_zero(const double *p, int K)
+{
+    for (int i = 0; i < K; ++i) if (p[3 * i + 2] != 0.0) return 0;
+    return 1;
+}
+
+EXPORT int obtg_oracle_gjk(const double *poly1, int K1, const double *poly2, int K2, int max_iter,
+                           int md_cap, int *flag, double *c1, double *c2, double *dist,
+                           short *trace, int trace_cap, int *n_support)
+{
+    int cyc = g_cycle_mode == 1 || (g_cycle_mode == 2 && !(all_z_zero(poly1, K1) && all_z_zero(poly2, K2)));
+    return gjk_impl(poly1, K1, poly2, K2, max_iter, md_cap, flag, c1, c2, dist, trace, trace_cap, n_support, cyc);
+}
+
 /* Pair-list sweep used by tests and by the CPU baseline. pts[n_pts][3],
  * poly_off[n_poly+1]; trace (nullable) is [n_pairs][trace_cap][2]. */
 EXPORT void obtg_oracle_gjk_pairs(const double *pts, const int *poly_off, const int *pair_a,
@@ -617,14 +661,21 @@ EXPORT void obtg_oracle_gjk_pairs(const double *pts, const int *poly_off, const 
                                   int trace_cap, int *n_support, int *status, int nthreads)
 {
     (void)nthreads;
+    /* the library picks its machine per call from ALL points handed over (capi.cpp obtg_gjk_pairs) */
+    int n_poly = 0;
+    for (int k = 0; k < n_pairs; ++k) {
+        if (pair_a[k] + 1 > n_poly) n_poly = pair_a[k] + 1;
+        if (pair_b[k] + 1 > n_poly) n_poly = pair_b[k] + 1;
+    }
+    const int cyc = g_cycle_mode == 1 || (g_cycle_mode == 2 && !all_z_zero(pts, n_poly ? poly_off[n_poly] : 0));
 #pragma omp parallel for schedule(dynamic, 16) num_threads(nthreads > 0 ? nthreads : 1)
     for (int k = 0; k < n_pairs; ++k) {
         int a = pair_a[k], b = pair_b[k];
-        status[k] = obtg_oracle_gjk(pts + 3 * poly_off[a], poly_off[a + 1] - poly_off[a],
+        status[k] = gjk_impl(pts + 3 * poly_off[a], poly_off[a + 1] - poly_off[a],
                                     pts + 3 * poly_off[b], poly_off[b + 1] - poly_off[b], max_iter,
                                     md_cap, flag + k, p1 + 3 * k, p2 + 3 * k, dist + k,
                                     trace ? trace + (long)k * trace_cap * 2 : 0, trace_cap,
-                                    n_support + k);
+                                    n_support + k, cyc);
     }
 }
 
@@ -721,9 +772,9 @@ static void min_dist_rec(md_ctx_t *m, const double *c1, const double *c2, int cn
     if (cnt > m->depth_seen) m->depth_seen = cnt;
     int flag, nsup;
     double cl1[3], cl2[3], lb, t1, t2;
-    int st = obtg_oracle_gjk(poly1, K1, poly2, K2, m->max_iter, m->md_cap, &flag, cl1, cl2, &lb, 0, 0, &nsup);
+    int st = gjk_impl(poly1, K1, poly2, K2, m->max_iter, m->md_cap, &flag, cl1, cl2, &lb, 0, 0, &nsup, g_cycle_mode != 0);
     m->gjk_calls++;
-    if (st == ST_MD_CAP) { m->status = MD_GJK_CAP; ret[0] = alpha; ret[1] = ret[2] = -1; return; }
+    if (st == ST_MD_CAP || st == ST_CYCLE) { m->status = MD_GJK_CAP; ret[0] = alpha; ret[1] = ret[2] = -1; return; }
     if (flag > 0) {
         t1 = hull_param(poly1, K1, cl1);
         t2 = hull_param(poly2, K2, cl2);
@@ -803,9 +854,9 @@ static void min_dist_poly_rec(md_ctx_t *m, const double *c1, const double *poly2
     if (cnt > m->depth_seen) m->depth_seen = cnt;
     int flag, nsup;
     double cl1[3], cl2[3], lb, t1, nT1;
-    int st = obtg_oracle_gjk(poly1, K1, poly2, K2, m->max_iter, m->md_cap, &flag, cl1, cl2, &lb, 0, 0, &nsup);
+    int st = gjk_impl(poly1, K1, poly2, K2, m->max_iter, m->md_cap, &flag, cl1, cl2, &lb, 0, 0, &nsup, g_cycle_mode != 0);
     m->gjk_calls++;
-    if (st == ST_MD_CAP) { m->status = MD_GJK_CAP; ret[0] = alpha; ret[1] = -1; ret[2] = ret[3] = ret[4] = -1; return; }
+    if (st == ST_MD_CAP || st == ST_CYCLE) { m->status = MD_GJK_CAP; ret[0] = alpha; ret[1] = -1; ret[2] = ret[3] = ret[4] = -1; return; }
     if (flag > 0) {
         t1 = hull_param(poly1, K1, cl1);
         /* bezier.py:1535-1547 _upperboundPoly */

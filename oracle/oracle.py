@@ -17,7 +17,7 @@ _lib = None
 DP = np.ctypeslib.ndpointer(dtype=np.float64, flags="C_CONTIGUOUS")
 IP = np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS")
 
-ST_OK, ST_MD_CAP, ST_MAXITER = 0, 1, 2
+ST_OK, ST_MD_CAP, ST_MAXITER, ST_CYCLE = 0, 1, 2, 3
 MD_OK, MD_NODE_CAP, MD_DEPTH_CAP, MD_GJK_CAP = 0, 1, 2, 3
 
 
@@ -173,8 +173,13 @@ def gjk(poly1, poly2, max_iter=128, md_cap=4096, trace_cap=256):
                 trace=trace[:min(ns.value, trace_cap)].copy(), n_support=ns.value, status=st)
 
 
-def gjk_pairs(pts, off, pair_a, pair_b, max_iter=128, md_cap=4096, trace_cap=0, nthreads=1):
+def gjk_pairs(pts, off, pair_a, pair_b, max_iter=128, md_cap=4096, trace_cap=0, nthreads=1, cycle_detect=None):
+    """cycle_detect None = the library's rule: the 3-D machine (with its cycle detector, status ST_CYCLE)
+    unless every z handed over is 0."""
     pts = _f64(pts)
+    if cycle_detect is None:
+        cycle_detect = bool(np.any(pts.reshape(-1, 3)[:, 2] != 0.0))
+    lib().obtg_oracle_set_cycle_detect(C.c_int(1 if cycle_detect else 0))
     off = np.ascontiguousarray(off, dtype=np.int32)
     pa = np.ascontiguousarray(pair_a, dtype=np.int32)
     pb = np.ascontiguousarray(pair_b, dtype=np.int32)
@@ -190,6 +195,7 @@ def gjk_pairs(pts, off, pair_a, pair_b, max_iter=128, md_cap=4096, trace_cap=0, 
                                 C.c_int(md_cap), _p(flag), _p(p1), _p(p2), _p(dist),
                                 _p(trace) if trace is not None else None, C.c_int(trace_cap),
                                 _p(nsup), _p(status), C.c_int(nthreads))
+    lib().obtg_oracle_set_cycle_detect(C.c_int(2))
     return dict(flag=flag, c1=p1, c2=p2, dist=dist, trace=trace, n_support=nsup, status=status)
 
 

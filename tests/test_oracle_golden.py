@@ -104,14 +104,20 @@ def test_problem_layer_constraints(oracle, golden_dir):
 @pytest.mark.parametrize("grp", ["lit", "c3", "dense", "s3d"])
 def test_gjk_bit_exact(oracle, golden_dir, grp):
     """flag, support-index sequence, closest points and distance: BIT-EXACT on every
-    input where the reference terminates; non-terminating inputs hit the md cap."""
+    input where the reference terminates; on the others (the generator's timer fired) the cycle
+    detector proves that minimumDistance's loop can never exit."""
     g = _load(golden_dir, "gjk.npz")
     pa, pb = g[grp + "_pair_a"], g[grp + "_pair_b"]
     r = oracle.gjk_pairs(g[grp + "_pts"], g[grp + "_off"], pa, pb, trace_cap=64, md_cap=2000)
     ok = g[grp + "_status"] == 0
     assert (r["flag"][ok] == g[grp + "_flag"][ok]).all()
     assert (r["status"][ok] == oracle.ST_OK).all()
-    assert (r["status"][~ok] == oracle.ST_MD_CAP).all()
+    assert (r["status"][~ok] == oracle.ST_CYCLE).all()
+    if (~ok).any():         # detector off: the same inputs spin until the cap, the others do not change
+        r0 = oracle.gjk_pairs(g[grp + "_pts"], g[grp + "_off"], pa, pb, trace_cap=64, md_cap=300, cycle_detect=False)
+        assert (r0["status"][~ok] == oracle.ST_MD_CAP).all() and (r0["status"][ok] == oracle.ST_OK).all()
+        assert (r0["n_support"][ok] == r["n_support"][ok]).all()
+        assert r["n_support"][~ok].max() < 64
     toff, tr = g[grp + "_trace_off"], g[grp + "_trace"]
     for k in np.where(ok)[0]:
         n = toff[k + 1] - toff[k]
