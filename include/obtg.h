@@ -176,6 +176,12 @@ int obtg_gjk_swarm_dev(obtg_ctx*, const double* dY, int B, int max_iter, int md_
  * vehicle), runs gjkNew only for pairs with a changed hull and copies row 0's outputs for the
  * rest.  Results are identical to the brute-force sweep for any input. */
 int obtg_ctx_set_fd_dedup(obtg_ctx*, int on);
+/* Trip-count history of the planar sweep (on by default).  Each obtg_gjk_swarm[_dev] call keeps one
+ * byte per (row, pair): the number of support scans gjkNew took.  The next call evaluates every
+ * workgroup's pairs in descending order of that count, so that the lanes of a wavefront finish and
+ * refill together (SLSQP's consecutive calls see nearly the same geometry).  Scheduling only:
+ * every pair is evaluated in full and the outputs do not depend on the order.  Off = list order. */
+int obtg_ctx_set_gjk_history(obtg_ctx*, int on);
 /* host-buffer form of the same sweep (B rows of Y in, arrays out) */
 int obtg_gjk_swarm(obtg_ctx*, const double* Y, int B, int max_iter, int md_cap,
                    int* flag, double* p1, double* p2, double* dist, int* nsup, int* status);

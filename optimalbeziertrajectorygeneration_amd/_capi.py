@@ -10,7 +10,7 @@ import os
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libobtg_hip.so")
+LIB_PATH = os.environ.get("OBTG_LIB") or os.path.join(HERE, "libobtg_hip.so")   # OBTG_LIB: experimental builds (tools/build_variant.sh)
 
 OK = 0
 ST_OK, ST_MD_CAP, ST_MAXITER, ST_CYCLE = 0, 1, 2, 3
@@ -53,6 +53,7 @@ _SIGNATURES = {
     "obtg_ctx_set_polygons": (_i, [_vp, _vp, _i, _vp, _i]),
     "obtg_ctx_set_hull_pairs": (_i, [_vp, _vp, _vp, _i]),
     "obtg_ctx_set_fd_dedup": (_i, [_vp, _i]),
+    "obtg_ctx_set_gjk_history": (_i, [_vp, _i]),
     "obtg_gjk_swarm_dev": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "obtg_gjk_swarm": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "obtg_min_dist": (_i, [_vp, _vp, _i, _i, _vp, _vp, _i, _d, _i, _i, _i, _i, _vp, _vp, _vp]),
@@ -343,6 +344,9 @@ class Context(object):
 
     def set_fd_dedup(self, on):
         self._check(self._lib.obtg_ctx_set_fd_dedup(self._h, int(bool(on))), "obtg_ctx_set_fd_dedup")
+
+    def set_gjk_history(self, on):
+        self._check(self._lib.obtg_ctx_set_gjk_history(self._h, int(bool(on))), "obtg_ctx_set_gjk_history")
 
     def gjk_swarm(self, Y, max_iter=128, md_cap=4096):
         Y, B = self._rows(Y)

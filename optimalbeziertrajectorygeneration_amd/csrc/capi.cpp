@@ -178,7 +178,7 @@ const char* obtg_abi_symbols(void)
         "obtg_temporal_sep\0obtg_speed\0obtg_ang_rate\0obtg_temporal_sep_min\0obtg_temporal_sep_min_range\0"
         "obtg_temporal_sep_dev\0obtg_temporal_sep_min_dev\0obtg_speed_dev\0obtg_ang_rate_dev\0obtg_dynamics_dev\0"
         "obtg_fd_batch_dev\0obtg_gjk_pairs\0obtg_ctx_set_polygons\0obtg_ctx_set_hull_pairs\0"
-        "obtg_ctx_set_fd_dedup\0obtg_gjk_swarm_dev\0obtg_gjk_swarm\0obtg_min_dist\0obtg_min_dist2poly\0"
+        "obtg_ctx_set_fd_dedup\0obtg_ctx_set_gjk_history\0obtg_gjk_swarm_dev\0obtg_gjk_swarm\0obtg_min_dist\0obtg_min_dist2poly\0"
         "obtg_bern_elev\0obtg_bern_diff\0obtg_bern_mul\0obtg_bern_normsq\0"
         "obtg_euclidean_obj\0obtg_accel_obj\0obtg_jerk_obj\0"
         "obtg_set_profiling\0obtg_kernel_stats\0obtg_reset_kernel_stats\0obtg_kernel_name\0";
@@ -234,6 +234,7 @@ void obtg_ctx_destroy(obtg_ctx* c)
                        &c->ws_in2, &c->ws_out };
     for (DevBuf* b : bufs) b->release();
     for (auto& b : c->ws_misc) b.release();
+    for (auto& b : c->d_gjk_len) b.release();
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
 }
@@ -497,6 +498,7 @@ int obtg_ctx_set_polygons(obtg_ctx* c, const double* pts, int n_pts, const int* 
     for (int a = 0; a < n_poly; ++a) c->max_poly_K = std::max(c->max_poly_K, poly_off[a + 1] - poly_off[a]);
     c->n_hull_pairs = 0;   // object ids may have changed meaning
     c->tile_valid = false;
+    c->gjk_len_rows = 0;
     return OBTG_OK;
 }
 
@@ -515,6 +517,7 @@ int obtg_ctx_set_hull_pairs(obtg_ctx* c, const int* pair_a, const int* pair_b, i
     c->h_hp_a.assign(pair_a, pair_a + n_pairs);
     c->h_hp_b.assign(pair_b, pair_b + n_pairs);
     c->tile_valid = false;
+    c->gjk_len_rows = 0;
     if (c->d_poly_off.p == nullptr) {
         int zero = 0;
         if ((rc = upload(c, c->d_poly_off, &zero, sizeof(int)))) return rc;
@@ -527,6 +530,14 @@ int obtg_ctx_set_fd_dedup(obtg_ctx* c, int on)
 {
     if (!check_ctx(c)) return OBTG_ERR_ARG;
     c->fd_dedup = on != 0;
+    return OBTG_OK;
+}
+
+int obtg_ctx_set_gjk_history(obtg_ctx* c, int on)
+{
+    if (!check_ctx(c)) return OBTG_ERR_ARG;
+    c->gjk_history = on != 0;
+    c->gjk_len_rows = 0;
     return OBTG_OK;
 }
 

@@ -240,6 +240,11 @@ struct GjkSwarmParams {
     const int* cobj_off;               // [n_chunks+1] object-list ranges
     const int* cobjs;                  // object ids per chunk, slot order
     int max_objs;                      // most objects any chunk stages
+    // plain sweep (MODE 0): trip-count history used to order each workgroup's pairs, see the kernel
+    int B;
+    const unsigned char* len_in;       // nullable, [.][n_pairs] support-scan counts of the previous sweep
+    int len_in_stride;                 // n_pairs (same batch shape as last time) or 0 (every row reads row 0)
+    unsigned char* len_out;            // nullable, [B][n_pairs]
     int* __restrict__ flag;
     double* __restrict__ p1;
     double* __restrict__ p2;
@@ -324,8 +329,20 @@ __device__ __forceinline__ void support_fixed(const double* __restrict__ o1, con
     out.v = gjk::V2{ o1[i1] - o2[i2], o1[NC + i1] - o2[NC + i2] };
 }
 
-// MODE 0: the sweep proper (blockIdx -> (row, chunk of the pair list)); every object of the row is
-//         staged, LDS slot == object id.
+// MODE 0: the sweep proper.  Workgroup w of a row owns the pairs k = w, w + W, w + 2W, ... (W =
+//         workgroups per row); every object of the row is staged, LDS slot == object id.
+//         * Scheduling by history: gjkNew's trip count per pair varies 3..26 support scans, and a wave
+//           pays for the refill path whenever ANY lane finishes.  The previous sweep leaves its
+//           per-pair scan counts in p.len_in (SLSQP evaluates f(x) right before the finite-difference
+//           batch around x, and consecutive iterates are close, so the counts carry over); each
+//           workgroup counting-sorts its pairs by descending count, so the lanes of a wave start
+//           pairs of equal length together, finish together, refill together, and the longest pairs
+//           are not left for the tail.  Only the ORDER of evaluation changes: results are written
+//           per pair and are identical for any order.
+//         * XCD-aware ids: consecutive workgroup ids go round-robin to the 8 XCDs (one L2 each).  The
+//           W workgroups of a row read the same staged row and interleave their output records, so
+//           id -> (row, w) keeps a row on one XCD: rows 8g .. 8g+7 take ids 8gW .. 8(g+1)W-1 with
+//           row = 8g + id % 8, w = (id / 8) % W.
 // MODE 1: finite-difference de-duplication pass (FIXUP), one workgroup per row b >= 1: only pairs
 //         with a hull that differs from row 0 (mask p.chg) are evaluated; everything else was
 //         filled in beforehand by k_bcast_row0.  The pair list is walked in segments of
@@ -334,25 +351,69 @@ __device__ __forceinline__ void support_fixed(const double* __restrict__ o1, con
 //         pair matrix) and cut it into chunks that touch at most p.max_objs objects; a workgroup
 //         stages only its chunk's objects (p.cobjs) and the pairs carry LDS slots (p.pslots);
 //         results go to the pairs' original positions (p.order).
-template <int NC, int MODE>
-__global__ __launch_bounds__(256) void k_gjk_swarm_planar(const GjkSwarmParams p)
+template <int MODE>
+__host__ __device__ constexpr size_t planar_lds_bytes(int cap_obj, int vp, int chunk)
 {
-    constexpr bool FIXUP = MODE == 1, TILED = MODE == 2;
+    // objects | r01 int2[chunk], plist int[chunk] | ext int[2 cap_obj] | MODE 0, 1: list int[chunk] | r2 u16[chunk] | MODE 0: ord u16[chunk]
+    return sizeof(double) * (((size_t)cap_obj * vp + 1) & ~(size_t)1) + 12 * (size_t)chunk + 8 * (size_t)cap_obj +
+           (MODE != 2 ? 4 * (size_t)chunk : 0) + 2 * (size_t)chunk + (MODE == 0 ? 2 * (size_t)chunk : 0);
+}
+
+#ifdef OBTG_X_WG512
+#define OBTG_SWEEP_THREADS 512
+#else
+#define OBTG_SWEEP_THREADS 256
+#endif
+template <int NC, int MODE>
+__global__ __launch_bounds__(MODE == 0 ? OBTG_SWEEP_THREADS : 256) void k_gjk_swarm_planar(const GjkSwarmParams p)
+{
+    constexpr bool SWEEP = MODE == 0, FIXUP = MODE == 1, TILED = MODE == 2;
     using gjk::V2;
     using gjk::Vert2;
     using gjk::Simplex2;
     constexpr int VP = PlanarShape<NC>::VP;
     extern __shared__ double lds[];
     __shared__ int s_next;
-    const int b = FIXUP ? (int)blockIdx.x + 1 : (int)(blockIdx.x / p.wgs_per_row);
-    const int w = FIXUP ? 0 : (int)(blockIdx.x - b * p.wgs_per_row);
-    int c0 = TILED ? p.chunk_off[w] : w * p.chunk;
-    int c1 = TILED ? p.chunk_off[w + 1] : min(p.n_pairs, c0 + p.chunk);
+    __shared__ int s_nlist;
+    __shared__ int s_hist[256];
+    int b, w;
+    if (SWEEP) {
+#ifdef OBTG_X_PLAINMAP
+        b = (int)blockIdx.x / p.wgs_per_row; w = (int)blockIdx.x - b * p.wgs_per_row;
+#else
+        const int per = 8 * p.wgs_per_row;
+        const int grp = (int)blockIdx.x / per, g = (int)blockIdx.x - grp * per;
+        b = grp * 8 + (g & 7);
+        w = g >> 3;
+#endif
+        if (b >= p.B) return;
+    } else if (FIXUP) {
+        b = (int)blockIdx.x + 1; w = 0;
+    } else {
+        b = (int)(blockIdx.x / p.wgs_per_row); w = (int)(blockIdx.x - b * p.wgs_per_row);
+    }
+    // c0 .. c1: positions this workgroup walks (MODE 0: local indices l, pair k = w + l W)
+    int c0 = SWEEP ? 0 : (TILED ? p.chunk_off[w] : w * p.chunk);
+#ifdef OBTG_X_CONTIG
+#define OWN(w_, l_, W_) ((w_) * p.chunk + (l_))
+    int c1 = SWEEP ? max(0, min(p.n_pairs - w * p.chunk, p.chunk))
+#else
+#define OWN(w_, l_, W_) ((w_) + (l_) * (W_))
+    int c1 = SWEEP ? (p.n_pairs - w + p.wgs_per_row - 1) / p.wgs_per_row
+#endif
+                   : (TILED ? p.chunk_off[w + 1] : min(p.n_pairs, c0 + p.chunk));
     const int obj0 = TILED ? p.cobj_off[w] : 0;
     const int n_obj = TILED ? p.cobj_off[w + 1] - obj0 : p.n_veh + p.n_poly;     // staged objects
     const int cap_obj = TILED ? p.max_objs : n_obj;                                // LDS slots reserved
-    int4* rec = reinterpret_cast<int4*>(lds + ((cap_obj * VP + 1) & ~1));         // 16-byte aligned
-    __shared__ int s_nlist;
+    // per-pair records of phase 1 -> phase 2:  r01.x = (flag+1) | status << 2 | keys << 4 | n_support << 8,
+    // r01.y = A.i1 | A.i2 << 8 | B.i1 << 16 | B.i2 << 24,  r2 = C.i1 | C.i2 << 8
+    int2* r01 = reinterpret_cast<int2*>(lds + ((cap_obj * VP + 1) & ~1));
+    unsigned* plist = reinterpret_cast<unsigned*>(r01 + p.chunk);   // [chunk] packed slots (a | b << 16) per position
+    int* ext = reinterpret_cast<int*>(plist + p.chunk);            // [cap_obj][2]: (first argmax x, first argmin x)
+    int* list = ext + 2 * cap_obj;                                  // FIXUP: compacted pair indices of a segment
+    unsigned* pnat = reinterpret_cast<unsigned*>(list);           // MODE 0: packed slots per local index l
+    unsigned short* r2 = reinterpret_cast<unsigned short*>(TILED ? list : list + p.chunk);
+    unsigned short* ord = r2 + p.chunk;                            // MODE 0: position -> local index l
 
     // ---- stage vehicles (rows x, y of the evaluation row) and padded polygons
     const double* Yrow = p.Y + (size_t)b * p.n_veh * 2 * NC;
@@ -386,7 +447,6 @@ __global__ __launch_bounds__(256) void k_gjk_swarm_planar(const GjkSwarmParams p
     // (-1,-0,-0) (gjk.py:247, 544): their support scans depend on one object only, so they are
     // done once per object and row.  x*1 + y*0 == x and x*(-1) + y*(-0) == -x exactly, hence
     // "first index of max x" / "first index of min x" are the reference's answers.
-    int* ext = reinterpret_cast<int*>(rec + p.chunk);      // [n_obj][2]: (first argmax x, first argmin x)
     for (int o = threadIdx.x; o < n_obj; o += blockDim.x) {
         const double* q = lds + o * VP;
         int imx = 0, imn = 0;
@@ -401,8 +461,6 @@ __global__ __launch_bounds__(256) void k_gjk_swarm_planar(const GjkSwarmParams p
     }
     __syncthreads();
     const bool shortcut = p.max_iter >= 3 && p.md_cap >= 2;
-    unsigned* plist = reinterpret_cast<unsigned*>(ext + 2 * cap_obj);   // [chunk] packed slots (a | b << 16)
-    int* list = reinterpret_cast<int*>(plist + p.chunk);   // FIXUP: compacted pair indices of a segment
     const unsigned char* chg = FIXUP ? p.chg + (size_t)b * p.n_veh : nullptr;
 
     for (int seg0 = 0; seg0 < (FIXUP ? p.n_pairs : 1); seg0 += p.chunk) {
@@ -420,11 +478,52 @@ __global__ __launch_bounds__(256) void k_gjk_swarm_planar(const GjkSwarmParams p
         if (c1 == 0) continue;                            // uniform: nothing changed in this segment
     }
     // the chunk's (a, b) object ids go to LDS once: the refill path must not wait on global memory
-    for (int q = c0 + (int)threadIdx.x; q < c1; q += blockDim.x) {
-        if (TILED) plist[q - c0] = p.pslots[q];
-        else {
-            const int kq = FIXUP ? list[q] : q;
-            plist[q - c0] = (unsigned)p.pa[kq] | ((unsigned)p.pb[kq] << 16);
+    if (SWEEP) {
+        const int W = p.wgs_per_row;
+        if (p.len_in) {
+            // counting sort of this workgroup's pairs by descending scan count of the previous sweep
+            const unsigned char* len = p.len_in + (size_t)b * p.len_in_stride;
+            if (threadIdx.x < 256) s_hist[threadIdx.x] = 0;
+            __syncthreads();
+            for (int l = threadIdx.x; l < c1; l += blockDim.x) atomicAdd(&s_hist[255 - len[OWN(w, l, W)]], 1);
+            __syncthreads();
+            if (threadIdx.x < kWave) {
+                const int lane = threadIdx.x;
+                const int v0 = s_hist[4 * lane], v1 = s_hist[4 * lane + 1], v2 = s_hist[4 * lane + 2], v3 = s_hist[4 * lane + 3];
+                const int sum = v0 + v1 + v2 + v3;
+                int incl = sum;
+#pragma unroll
+                for (int d = 1; d < kWave; d <<= 1) {
+                    const int t = __shfl_up(incl, d);
+                    if (lane >= d) incl += t;
+                }
+                const int excl = incl - sum;
+                s_hist[4 * lane] = excl; s_hist[4 * lane + 1] = excl + v0;
+                s_hist[4 * lane + 2] = excl + v0 + v1; s_hist[4 * lane + 3] = excl + v0 + v1 + v2;
+            }
+            __syncthreads();
+            for (int l = threadIdx.x; l < c1; l += blockDim.x) {
+                const int kq = OWN(w, l, W);
+                const int pos = atomicAdd(&s_hist[255 - len[kq]], 1);
+                const unsigned ab = (unsigned)p.pa[kq] | ((unsigned)p.pb[kq] << 16);
+                ord[pos] = (unsigned short)l;
+                plist[pos] = ab;
+                pnat[l] = ab;
+            }
+        } else {
+            for (int l = threadIdx.x; l < c1; l += blockDim.x) {
+                const int kq = OWN(w, l, W);
+                ord[l] = (unsigned short)l;
+                plist[l] = pnat[l] = (unsigned)p.pa[kq] | ((unsigned)p.pb[kq] << 16);
+            }
+        }
+    } else {
+        for (int q = c0 + (int)threadIdx.x; q < c1; q += blockDim.x) {
+            if (TILED) plist[q - c0] = p.pslots[q];
+            else {
+                const int kq = FIXUP ? list[q] : q;
+                plist[q - c0] = (unsigned)p.pa[kq] | ((unsigned)p.pb[kq] << 16);
+            }
         }
     }
     if (threadIdx.x == 0) s_next = c0;
@@ -433,7 +532,7 @@ __global__ __launch_bounds__(256) void k_gjk_swarm_planar(const GjkSwarmParams p
     // ---- phase 1: state machine with lane refill
     {
         const int lane = threadIdx.x & (kWave - 1);
-        int k = -1;
+        int k = -1, slot = 0;
         bool exhausted = false;
         const double* o1 = lds;
         const double* o2 = lds;
@@ -454,6 +553,7 @@ __global__ __launch_bounds__(256) void k_gjk_swarm_planar(const GjkSwarmParams p
                     const int my = base + __popcll(want & ((1ull << lane) - 1ull));
                     if (my < c1) {
                         k = my;
+                        slot = SWEEP ? (int)ord[k] : k - c0;
                         const unsigned ab = plist[k - c0];
                         const int a = (int)(ab & 0xffffu), bb = (int)(ab >> 16);
                         o1 = lds + a * VP;
@@ -479,12 +579,9 @@ __global__ __launch_bounds__(256) void k_gjk_swarm_planar(const GjkSwarmParams p
                                     (A1.v.x == 0.0 && A1.v.y == 0.0 && A2.v.x == o1[ax] && A2.v.y == o1[NC + ax] &&
                                      A2.v.x == o2[bn] && A2.v.y == o2[NC + bn]);
                                 if (m) {
-                                    int4 r;
-                                    r.x = 1 | (OBTG_ST_OK << 8) | (gjk::kA << 16);
-                                    r.y = nsup;
-                                    r.z = A1.i1 | (A1.i2 << 8);
-                                    r.w = 0;
-                                    rec[k - c0] = r;
+                                    r01[slot] = make_int2((1 + 1) | (OBTG_ST_OK << 2) | (gjk::kA << 4) | (nsup << 8),
+                                                          A1.i1 | (A1.i2 << 8));
+                                    r2[slot] = 0;
                                     k = -1;
                                 }
                             }
@@ -522,12 +619,9 @@ __global__ __launch_bounds__(256) void k_gjk_swarm_planar(const GjkSwarmParams p
                     else if (rr >= p.md_cap) { flag = 1; status = OBTG_ST_MD_CAP; }
                 }
                 if (flag != -2) {
-                    int4 r;
-                    r.x = (flag & 0xff) | (status << 8) | (old.keys << 16);
-                    r.y = nsup;
-                    r.z = old.A.i1 | (old.A.i2 << 8) | (old.B.i1 << 16) | (old.B.i2 << 24);
-                    r.w = old.C.i1 | (old.C.i2 << 8);
-                    rec[k - c0] = r;
+                    r01[slot] = make_int2((flag + 1) | (status << 2) | ((old.keys & 7) << 4) | (min(nsup, 0xffffff) << 8),
+                                          old.A.i1 | (old.A.i2 << 8) | (old.B.i1 << 16) | (old.B.i2 << 24));
+                    r2[slot] = (unsigned short)(old.C.i1 | (old.C.i2 << 8));
                     k = -1;
                 }
             }
@@ -539,11 +633,12 @@ __global__ __launch_bounds__(256) void k_gjk_swarm_planar(const GjkSwarmParams p
     const size_t obase = (size_t)b * p.n_pairs;
     const double qnan = __builtin_nan("");
     for (int k = c0 + (int)threadIdx.x; k < c1; k += blockDim.x) {
-        const int kk = TILED ? p.order[k] : (FIXUP ? list[k] : k);
-        const unsigned ab2 = plist[k - c0];
+        const int kk = SWEEP ? OWN(w, k, p.wgs_per_row) : (TILED ? p.order[k] : (FIXUP ? list[k] : k));
+        const unsigned ab2 = SWEEP ? pnat[k] : plist[k - c0];
         const int sa = (int)(ab2 & 0xffffu), sb = (int)(ab2 >> 16);
-        const int4 r4 = rec[k - c0];
-        const int flag = (int)(signed char)(r4.x & 0xff), status = (r4.x >> 8) & 0xff, keys = (r4.x >> 16) & 0xff;
+        const int2 rq = r01[k - c0];
+        const int rq0 = rq.x, rq1 = rq.y, rq2 = (int)r2[k - c0];
+        const int flag = (rq0 & 3) - 1, status = (rq0 >> 2) & 3, keys = (rq0 >> 4) & 7, n_scans = (int)((unsigned)rq0 >> 8);
         Result r;
         r.c1 = V3{ qnan, qnan, qnan }; r.c2 = r.c1; r.dist = qnan;
         if (flag == 1 && status == OBTG_ST_OK) {
@@ -551,8 +646,8 @@ __global__ __launch_bounds__(256) void k_gjk_swarm_planar(const GjkSwarmParams p
             // pick the partner vertex O of the closest feature, then ONE segment evaluation
             const double* q1 = lds + sa * VP;
             const double* q2 = lds + sb * VP;
-            const int ia1 = r4.z & 0xff, ia2 = (r4.z >> 8) & 0xff, ib1 = (r4.z >> 16) & 0xff, ib2 = (r4.z >> 24) & 0xff;
-            const int ic1 = r4.w & 0xff, ic2 = (r4.w >> 8) & 0xff;
+            const int ia1 = rq1 & 0xff, ia2 = (rq1 >> 8) & 0xff, ib1 = (rq1 >> 16) & 0xff, ib2 = (rq1 >> 24) & 0xff;
+            const int ic1 = rq2 & 0xff, ic2 = (rq2 >> 8) & 0xff;
             const V2 a1{ q1[ia1], q1[NC + ia1] }, a2{ q2[ia2], q2[NC + ia2] };
             const V2 A = gjk::sub2(a1, a2);
             int which = 0;                    // 0: point A, 1: segment A-B, 2: segment A-C, 3: plane
@@ -607,8 +702,9 @@ __global__ __launch_bounds__(256) void k_gjk_swarm_planar(const GjkSwarmParams p
         p.p1[3 * o] = r.c1.x; p.p1[3 * o + 1] = r.c1.y; p.p1[3 * o + 2] = r.c1.z;
         p.p2[3 * o] = r.c2.x; p.p2[3 * o + 1] = r.c2.y; p.p2[3 * o + 2] = r.c2.z;
         p.dist[o] = r.dist;
-        if (p.nsup) p.nsup[o] = r4.y;
+        if (p.nsup) p.nsup[o] = n_scans;
         if (p.status) p.status[o] = status;
+        if (SWEEP && p.len_out) p.len_out[o] = (unsigned char)min(n_scans, 255);
     }
     if (FIXUP) __syncthreads();                          // rec / list are reused by the next segment
     }
@@ -1042,6 +1138,9 @@ int launch_gjk_swarm(obtg_ctx* c, const double* dY, int B, int max_iter, int md_
     // pairs per lane (measured at C3: 316 pairs per 256 lanes = 0.281 ms, 1264 pairs = 0.215 ms);
     // small batches trade that for enough workgroups to fill the chip.
     int wgs = (c->n_hull_pairs + 1279) / 1280;
+#ifdef OBTG_X_WG512
+    wgs = (c->n_hull_pairs + 2559) / 2560;
+#endif
     while ((long)B * wgs < 2048 && (c->n_hull_pairs + wgs - 1) / wgs > 256) wgs <<= 1;
     p.chunk = (c->n_hull_pairs + wgs - 1) / wgs;
     p.wgs_per_row = (c->n_hull_pairs + p.chunk - 1) / p.chunk;
@@ -1053,9 +1152,7 @@ int launch_gjk_swarm(obtg_ctx* c, const double* dY, int B, int max_iter, int md_
     if (planar && c->max_poly_K <= c->deg + 1 && c->deg + 1 <= 127) {
         const int nc = c->deg + 1;
         const int vp2 = 2 * nc + 1;
-        const size_t lds2 = sizeof(double) * (((size_t)(c->n_veh + c->n_poly) * vp2 + 1) & ~(size_t)1) +
-                            sizeof(int4) * (size_t)p.chunk + sizeof(int) * 2 * (size_t)(c->n_veh + c->n_poly) +
-                            sizeof(unsigned) * (size_t)p.chunk;
+        const size_t lds2 = planar_lds_bytes<0>(c->n_veh + c->n_poly, vp2, p.chunk);
         void (*kp)(const GjkSwarmParams) = nullptr;
         void (*kf)(const GjkSwarmParams) = nullptr;
         void (*kt)(const GjkSwarmParams) = nullptr;
@@ -1066,7 +1163,12 @@ int launch_gjk_swarm(obtg_ctx* c, const double* dY, int B, int max_iter, int md_
             default: break;
         }
 #undef OBTG_GJK_CASE
-        if (kt && lds2 > 48 * 1024) {
+#ifdef OBTG_X_WG512
+        constexpr size_t kTileAbove = 80 * 1024, kSweepMax = 80 * 1024;
+#else
+        constexpr size_t kTileAbove = 48 * 1024, kSweepMax = 64 * 1024;
+#endif
+        if (kt && lds2 > kTileAbove) {
             // large rows: tile-major chunks, each staging only the objects it touches
             int rc = build_tiles(c, 2 * nc + 1);
             if (rc == OBTG_OK) {
@@ -1075,9 +1177,7 @@ int launch_gjk_swarm(obtg_ctx* c, const double* dY, int B, int max_iter, int md_
                 q.pslots = c->d_tile_pslots.as<unsigned>(); q.cobj_off = c->d_tile_cobj_off.as<int>();
                 q.cobjs = c->d_tile_cobjs.as<int>(); q.max_objs = c->tile_max_objs;
                 q.chunk = c->tile_max_pairs; q.wgs_per_row = c->tile_n_chunks;
-                const size_t ldst = sizeof(double) * (((size_t)q.max_objs * vp2 + 1) & ~(size_t)1) +
-                                    sizeof(int4) * (size_t)q.chunk + sizeof(int) * 2 * (size_t)q.max_objs +
-                                    sizeof(unsigned) * (size_t)q.chunk;
+                const size_t ldst = planar_lds_bytes<2>(q.max_objs, vp2, q.chunk);
                 if (ldst <= 64 * 1024) {
                     if (ldst > 48 * 1024)
                         OBTG_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(kt),
@@ -1089,7 +1189,7 @@ int launch_gjk_swarm(obtg_ctx* c, const double* dY, int B, int max_iter, int md_
                 }
             } else if (rc != OBTG_ERR_UNSUPPORTED) return rc;
         }
-        if (kp && lds2 <= 64 * 1024) {   // larger rows: the general kernel does better than 1-2 workgroups per CU
+        if (kp && lds2 <= kSweepMax) {   // larger rows: the general kernel does better than 1-2 workgroups per CU
             if (lds2 > 48 * 1024)
                 OBTG_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(kp),
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
@@ -1109,7 +1209,9 @@ int launch_gjk_swarm(obtg_ctx* c, const double* dY, int B, int max_iter, int md_
                     while (w0 < 2048 && (c->n_hull_pairs + w0 - 1) / w0 > 256) w0 <<= 1;
                     r0.chunk = (c->n_hull_pairs + w0 - 1) / w0;
                     r0.wgs_per_row = (c->n_hull_pairs + r0.chunk - 1) / r0.chunk;
-                    hipLaunchKernelGGL(kp, dim3((unsigned)r0.wgs_per_row), dim3(256), lds2, c->stream, r0);
+                    r0.B = 1;
+                    hipLaunchKernelGGL(kp, dim3((unsigned)(8 * r0.wgs_per_row)), dim3(OBTG_SWEEP_THREADS),
+                                       planar_lds_bytes<0>(c->n_veh + c->n_poly, vp2, r0.chunk), c->stream, r0);
                 }
                 const size_t np = (size_t)c->n_hull_pairs;
                 const dim3 cb(256);
@@ -1124,12 +1226,22 @@ int launch_gjk_swarm(obtg_ctx* c, const double* dY, int B, int max_iter, int md_
                 GjkSwarmParams q = p;
                 q.chg = chg;
                 q.chunk = 1024;
-                const size_t ldsf = sizeof(double) * (((size_t)(c->n_veh + c->n_poly) * vp2 + 1) & ~(size_t)1) +
-                                    sizeof(int4) * (size_t)q.chunk + sizeof(int) * 2 * (size_t)(c->n_veh + c->n_poly) +
-                                    2 * sizeof(int) * (size_t)q.chunk;
+                const size_t ldsf = planar_lds_bytes<1>(c->n_veh + c->n_poly, vp2, q.chunk);
                 hipLaunchKernelGGL(kf, dim3((unsigned)(B - 1)), dim3(256), ldsf, c->stream, q);
             } else {
-                hipLaunchKernelGGL(kp, dim3((unsigned)((size_t)B * p.wgs_per_row)), dim3(256), lds2, c->stream, p);
+                // trip-count history: this sweep orders its pairs by the counts the previous one left
+                // behind (same batch shape: row by row; otherwise every row follows the old row 0)
+                const size_t np = (size_t)c->n_hull_pairs;
+                obtg::DevBuf& hist_out = c->d_gjk_len[c->gjk_len_cur ^ 1];
+                if (int rc = hist_out.reserve((size_t)B * np)) return rc;
+                p.B = B;
+                p.len_in = (c->gjk_history && c->gjk_len_rows > 0) ? c->d_gjk_len[c->gjk_len_cur].as<unsigned char>() : nullptr;
+                p.len_in_stride = c->gjk_len_rows == B ? (int)np : 0;
+                p.len_out = c->gjk_history ? hist_out.as<unsigned char>() : nullptr;
+                const unsigned grid = (unsigned)(((size_t)B + 7) / 8 * 8 * p.wgs_per_row);
+                hipLaunchKernelGGL(kp, dim3(grid), dim3(OBTG_SWEEP_THREADS), lds2, c->stream, p);
+                c->gjk_len_cur ^= 1;
+                c->gjk_len_rows = B;
             }
             OBTG_HIP(c, hipGetLastError());
             return OBTG_OK;

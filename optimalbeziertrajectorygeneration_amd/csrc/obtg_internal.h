@@ -71,6 +71,9 @@ struct obtg_ctx {
     bool tile_valid = false;
     int tile_n_chunks = 0, tile_max_objs = 0, tile_max_pairs = 0;
     int n_hull_pairs = 0;
+    obtg::DevBuf d_gjk_len[2];   // per-pair support-scan counts of the last planar sweep (scheduling history)
+    bool gjk_history = true;
+    int gjk_len_cur = 0, gjk_len_rows = 0;   // buffer holding the latest counts, and how many rows of them
 
     // scratch for host-buffer entry points
     obtg::DevBuf ws_in, ws_in2, ws_out, ws_misc[8];

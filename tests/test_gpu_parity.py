@@ -582,3 +582,41 @@ def test_gjk_random_point_sets_bit_exact(capi, oracle, planar):
     assert ok.sum() > 1000 and (o["flag"] == 0).sum() > 1000
     for key in ("dist", "c1", "c2"):
         assert np.max(np.abs(r[key][ok] - o[key][ok]) / np.maximum(1.0, np.abs(o[key][ok]))) < 1e-12
+
+
+def test_gjk_swarm_history_order_does_not_change_results(capi, oracle, synth):
+    """The planar sweep orders each workgroup's pairs by the previous call's trip counts (scheduling
+    only).  Cold call, warm calls, a different batch shape in between, a moved swarm and history off
+    must all give bit-identical outputs, equal to the oracle's."""
+    N, d, n, M = 24, 2, 10, 5
+    Y = synth.swarm_control_points(N, d, n, seed=5)
+    polys = synth.polygon_obstacles(M, seed=9)
+    ppts, poff = synth.pack_polys(polys)
+    pa, pb = synth.swarm_pairs(N, M)
+    ctx = capi.Context(N, d, n, 0)
+    ctx.set_polygons(ppts, poff)
+    ctx.set_hull_pairs(pa, pb)
+    Yb = synth.fd_batch(Y, B=40)
+    Yb[7] += np.random.default_rng(2).normal(0, 3.0, size=Y.shape)                                      # one row with different geometry / trip counts
+    keys = ("flag", "c1", "c2", "dist", "n_support", "status")
+
+    def same(a, b):
+        return all(np.array_equal(a[k], b[k], equal_nan=True) for k in keys)
+
+    cold = ctx.gjk_swarm(Yb, md_cap=500)               # no history yet: list order
+    warm = ctx.gjk_swarm(Yb, md_cap=500)               # per-row history
+    assert same(cold, warm)
+    one = ctx.gjk_swarm(Yb[:1], md_cap=500)            # other batch shape: history of row 0 only
+    assert all(np.array_equal(one[k][0], cold[k][0], equal_nan=True) for k in keys)
+    again = ctx.gjk_swarm(Yb, md_cap=500)              # B changed back: every row follows the old row 0
+    assert same(cold, again)
+    moved = ctx.gjk_swarm(Yb[::-1].copy(), md_cap=500)  # history now belongs to other rows
+    assert all(np.array_equal(moved[k][::-1], cold[k], equal_nan=True) for k in keys)
+    ctx.set_gjk_history(False)
+    off = ctx.gjk_swarm(Yb, md_cap=500)
+    assert same(cold, off)
+    hp, ho = synth.pack_polys(synth.hulls_from_Y(Yb[7], 2) + polys)
+    o = oracle.gjk_pairs(hp, ho, pa, pb, md_cap=500)
+    assert (cold["flag"][7] == o["flag"]).all() and (cold["n_support"][7] == o["n_support"]).all()
+    assert len(np.unique(cold["n_support"][7])) > 3     # the ordering had something to sort
+    ctx.close()
