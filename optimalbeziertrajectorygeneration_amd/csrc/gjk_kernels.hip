@@ -307,26 +307,43 @@ __global__ __launch_bounds__(256) void k_gjk_swarm(const GjkSwarmParams p)
 // -------------------------------------------------------------------------------------
 template <int NC>
 struct PlanarShape {
-    static constexpr int VP = (2 * NC) % 2 == 0 ? 2 * NC + 1 : 2 * NC;   // odd pitch in doubles
+    static constexpr int VPQ = NC | 1;   // object pitch in (x, y) points of 16 bytes, odd
 };
 
+// LDS image of the staged objects as the general closest-point code addresses it (gjk_device.h
+// `point`: coordinate c of point k of a set at `base` is mem(base + c*cs + k)): cs = 1 << 24
+struct MemLdsXY {
+    const double* l;
+    __device__ __forceinline__ double operator()(int idx) const { return l[((idx & 0xffffff) << 1) | (idx >> 24)]; }
+};
+
+// The support scan over two staged objects.  Points are (x, y) pairs of 16 bytes, so one
+// ds_read_b128 fetches a point (ds_read2_b64, which the compiler picks for two separate doubles,
+// moves half the bytes per LDS cycle).  Value and index of the running maximum are tracked
+// separately: `c > m` decides the index exactly as gjk.py:109 does, max() carries the value
+// (equal up to the sign of zero, which no comparison sees).
 template <int NC>
-__device__ __forceinline__ void support_fixed(const double* __restrict__ o1, const double* __restrict__ o2,
+__device__ __forceinline__ void support_fixed(const double2* __restrict__ o1, const double2* __restrict__ o2,
                                               const gjk::V2& d, gjk::Vert2& out)
 {
     const double ndx = -d.x, ndy = -d.y;
     int i1 = 0, i2 = 0;
-    double m1 = o1[0] * d.x + o1[NC] * d.y;
-    double m2 = o2[0] * ndx + o2[NC] * ndy;
+    const double2 f1 = o1[0], f2 = o2[0];
+    double m1 = f1.x * d.x + f1.y * d.y;
+    double m2 = f2.x * ndx + f2.y * ndy;
 #pragma unroll
     for (int i = 1; i < NC; ++i) {
-        const double c1 = o1[i] * d.x + o1[NC + i] * d.y;
-        const double c2 = o2[i] * ndx + o2[NC + i] * ndy;
-        if (c1 > m1) { m1 = c1; i1 = i; }
-        if (c2 > m2) { m2 = c2; i2 = i; }
+        const double2 q1 = o1[i], q2 = o2[i];
+        const double c1 = q1.x * d.x + q1.y * d.y;
+        const double c2 = q2.x * ndx + q2.y * ndy;
+        i1 = c1 > m1 ? i : i1;
+        i2 = c2 > m2 ? i : i2;
+        m1 = __builtin_fmax(m1, c1);
+        m2 = __builtin_fmax(m2, c2);
     }
     out.i1 = i1; out.i2 = i2;
-    out.v = gjk::V2{ o1[i1] - o2[i2], o1[NC + i1] - o2[NC + i2] };
+    const double2 w1 = o1[i1], w2 = o2[i2];
+    out.v = gjk::V2{ w1.x - w2.x, w1.y - w2.y };
 }
 
 // MODE 0: the sweep proper.  Workgroup w of a row owns the pairs k = w, w + W, w + 2W, ... (W =
@@ -352,10 +369,10 @@ __device__ __forceinline__ void support_fixed(const double* __restrict__ o1, con
 //         stages only its chunk's objects (p.cobjs) and the pairs carry LDS slots (p.pslots);
 //         results go to the pairs' original positions (p.order).
 template <int MODE>
-__host__ __device__ constexpr size_t planar_lds_bytes(int cap_obj, int vp, int chunk)
+__host__ __device__ constexpr size_t planar_lds_bytes(int cap_obj, int vpq, int chunk)
 {
     // objects | r01 int2[chunk], plist int[chunk] | ext int[2 cap_obj] | MODE 0, 1: list int[chunk] | r2 u16[chunk] | MODE 0: ord u16[chunk]
-    return sizeof(double) * (((size_t)cap_obj * vp + 1) & ~(size_t)1) + 12 * (size_t)chunk + 8 * (size_t)cap_obj +
+    return 16 * (size_t)cap_obj * vpq + 12 * (size_t)chunk + 8 * (size_t)cap_obj +
            (MODE != 2 ? 4 * (size_t)chunk : 0) + 2 * (size_t)chunk + (MODE == 0 ? 2 * (size_t)chunk : 0);
 }
 
@@ -371,8 +388,9 @@ __global__ __launch_bounds__(MODE == 0 ? OBTG_SWEEP_THREADS : 256) void k_gjk_sw
     using gjk::V2;
     using gjk::Vert2;
     using gjk::Simplex2;
-    constexpr int VP = PlanarShape<NC>::VP;
-    extern __shared__ double lds[];
+    constexpr int VPQ = PlanarShape<NC>::VPQ;
+    extern __shared__ double2 xy[];                                // [cap_obj][VPQ] points
+    double* lds = reinterpret_cast<double*>(xy);
     __shared__ int s_next;
     __shared__ int s_nlist;
     __shared__ int s_hist[256];
@@ -407,7 +425,7 @@ __global__ __launch_bounds__(MODE == 0 ? OBTG_SWEEP_THREADS : 256) void k_gjk_sw
     const int cap_obj = TILED ? p.max_objs : n_obj;                                // LDS slots reserved
     // per-pair records of phase 1 -> phase 2:  r01.x = (flag+1) | status << 2 | keys << 4 | n_support << 8,
     // r01.y = A.i1 | A.i2 << 8 | B.i1 << 16 | B.i2 << 24,  r2 = C.i1 | C.i2 << 8
-    int2* r01 = reinterpret_cast<int2*>(lds + ((cap_obj * VP + 1) & ~1));
+    int2* r01 = reinterpret_cast<int2*>(xy + cap_obj * VPQ);
     unsigned* plist = reinterpret_cast<unsigned*>(r01 + p.chunk);   // [chunk] packed slots (a | b << 16) per position
     int* ext = reinterpret_cast<int*>(plist + p.chunk);            // [cap_obj][2]: (first argmax x, first argmin x)
     int* list = ext + 2 * cap_obj;                                  // FIXUP: compacted pair indices of a segment
@@ -417,28 +435,29 @@ __global__ __launch_bounds__(MODE == 0 ? OBTG_SWEEP_THREADS : 256) void k_gjk_sw
 
     // ---- stage vehicles (rows x, y of the evaluation row) and padded polygons
     const double* Yrow = p.Y + (size_t)b * p.n_veh * 2 * NC;
+    // (rows x[NC], y[NC] in memory -> point-major (x, y) in LDS)
     if (TILED) {
         for (int e = threadIdx.x; e < n_obj * 2 * NC; e += blockDim.x) {
-            const int sl = e / (2 * NC), r = e - sl * (2 * NC);
+            const int sl = e / (2 * NC), r = e - sl * (2 * NC), q = r / NC, k = r - q * NC;
             const int obj = p.cobjs[obj0 + sl];
             double val;
             if (obj < p.n_veh) val = Yrow[(size_t)obj * 2 * NC + r];
             else {
-                const int o = obj - p.n_veh, q = r / NC, k = r - q * NC;
+                const int o = obj - p.n_veh;
                 const int off = p.poly_off[o], K = p.poly_off[o + 1] - off;
                 val = p.poly[3 * off + q * K + (k < K ? k : 0)];
             }
-            lds[sl * VP + r] = val;
+            lds[2 * (sl * VPQ + k) + q] = val;
         }
     } else {
         for (int e = threadIdx.x; e < p.n_veh * 2 * NC; e += blockDim.x) {
-            const int v = e / (2 * NC), r = e - v * (2 * NC);
-            lds[v * VP + r] = Yrow[e];
+            const int v = e / (2 * NC), r = e - v * (2 * NC), q = r / NC, k = r - q * NC;
+            lds[2 * (v * VPQ + k) + q] = Yrow[e];
         }
         for (int e = threadIdx.x; e < p.n_poly * 2 * NC; e += blockDim.x) {
             const int o = e / (2 * NC), r = e - o * (2 * NC), q = r / NC, k = r - q * NC;
             const int off = p.poly_off[o], K = p.poly_off[o + 1] - off;
-            lds[(p.n_veh + o) * VP + r] = p.poly[3 * off + q * K + (k < K ? k : 0)];
+            lds[2 * ((p.n_veh + o) * VPQ + k) + q] = p.poly[3 * off + q * K + (k < K ? k : 0)];
         }
     }
     __syncthreads();
@@ -448,12 +467,12 @@ __global__ __launch_bounds__(MODE == 0 ? OBTG_SWEEP_THREADS : 256) void k_gjk_sw
     // done once per object and row.  x*1 + y*0 == x and x*(-1) + y*(-0) == -x exactly, hence
     // "first index of max x" / "first index of min x" are the reference's answers.
     for (int o = threadIdx.x; o < n_obj; o += blockDim.x) {
-        const double* q = lds + o * VP;
+        const double2* q = xy + o * VPQ;
         int imx = 0, imn = 0;
-        double mx = q[0] * 1.0 + q[NC] * 0.0, mn = q[0] * -1.0 + q[NC] * -0.0;
+        double mx = q[0].x * 1.0 + q[0].y * 0.0, mn = q[0].x * -1.0 + q[0].y * -0.0;
 #pragma unroll
         for (int i = 1; i < NC; ++i) {
-            const double c1 = q[i] * 1.0 + q[NC + i] * 0.0, c2 = q[i] * -1.0 + q[NC + i] * -0.0;
+            const double c1 = q[i].x * 1.0 + q[i].y * 0.0, c2 = q[i].x * -1.0 + q[i].y * -0.0;
             if (c1 > mx) { mx = c1; imx = i; }
             if (c2 > mn) { mn = c2; imn = i; }
         }
@@ -534,8 +553,8 @@ __global__ __launch_bounds__(MODE == 0 ? OBTG_SWEEP_THREADS : 256) void k_gjk_sw
         const int lane = threadIdx.x & (kWave - 1);
         int k = -1, slot = 0;
         bool exhausted = false;
-        const double* o1 = lds;
-        const double* o2 = lds;
+        const double2* o1 = xy;
+        const double2* o2 = xy;
         Simplex2 s, old;
         V2 dir{ 1.0, 0.0 };
         int phase = 0, it = 0, rr = 0, nsup = 0;
@@ -556,15 +575,16 @@ __global__ __launch_bounds__(MODE == 0 ? OBTG_SWEEP_THREADS : 256) void k_gjk_sw
                         slot = SWEEP ? (int)ord[k] : k - c0;
                         const unsigned ab = plist[k - c0];
                         const int a = (int)(ab & 0xffffu), bb = (int)(ab >> 16);
-                        o1 = lds + a * VP;
-                        o2 = lds + bb * VP;
+                        o1 = xy + a * VPQ;
+                        o2 = xy + bb * VPQ;
                         s.keys = 0; dir = V2{ 1.0, 0.0 };
                         phase = 0; it = 0; rr = 0; nsup = 0;
                         if (shortcut) {
                             // state after doSimplex #1 (0pt) and #2 (1pt)
                             const int ax = ext[2 * a], an = ext[2 * a + 1], bx = ext[2 * bb], bn = ext[2 * bb + 1];
-                            const Vert2 A1{ V2{ o1[ax] - o2[bn], o1[NC + ax] - o2[NC + bn] }, ax, bn };
-                            const Vert2 A2{ V2{ o1[an] - o2[bx], o1[NC + an] - o2[NC + bx] }, an, bx };
+                            const double2 pax = o1[ax], pbn = o2[bn], pan = o1[an], pbx = o2[bx];
+                            const Vert2 A1{ V2{ pax.x - pbn.x, pax.y - pbn.y }, ax, bn };
+                            const Vert2 A2{ V2{ pan.x - pbx.x, pan.y - pbx.y }, an, bx };
                             const bool md1 = gjk::dotb2(A1.v, dir) < 0;       // exit of iteration 1 (gjk.py:260)
                             dir = gjk::neg2(dir);
                             s.B = A1; s.A = A2; s.keys = gjk::kA | gjk::kB;
@@ -576,8 +596,8 @@ __global__ __launch_bounds__(MODE == 0 ? OBTG_SWEEP_THREADS : 256) void k_gjk_sw
                                 // iteration 2 ran inside minimumDistance with old = {A1}
                                 phase = 1; rr = 1;
                                 const bool m = gjk::eq2(A2.v, A1.v) ||
-                                    (A1.v.x == 0.0 && A1.v.y == 0.0 && A2.v.x == o1[ax] && A2.v.y == o1[NC + ax] &&
-                                     A2.v.x == o2[bn] && A2.v.y == o2[NC + bn]);
+                                    (A1.v.x == 0.0 && A1.v.y == 0.0 && A2.v.x == pax.x && A2.v.y == pax.y &&
+                                     A2.v.x == pbn.x && A2.v.y == pbn.y);
                                 if (m) {
                                     r01[slot] = make_int2((1 + 1) | (OBTG_ST_OK << 2) | (gjk::kA << 4) | (nsup << 8),
                                                           A1.i1 | (A1.i2 << 8));
@@ -607,14 +627,14 @@ __global__ __launch_bounds__(MODE == 0 ? OBTG_SWEEP_THREADS : 256) void k_gjk_sw
                     // converged iff the new A equals any value of the old dict (gjk.py:281-294)
                     bool m = false;
                     if ((old.keys & gjk::kA) && (gjk::eq2(s.A.v, old.A.v) ||
-                        (old.A.v.x == 0.0 && old.A.v.y == 0.0 && s.A.v.x == o1[old.A.i1] && s.A.v.y == o1[NC + old.A.i1] &&
-                         s.A.v.x == o2[old.A.i2] && s.A.v.y == o2[NC + old.A.i2]))) m = true;
+                        (old.A.v.x == 0.0 && old.A.v.y == 0.0 && s.A.v.x == o1[old.A.i1].x && s.A.v.y == o1[old.A.i1].y &&
+                         s.A.v.x == o2[old.A.i2].x && s.A.v.y == o2[old.A.i2].y))) m = true;
                     if ((old.keys & gjk::kB) && (gjk::eq2(s.A.v, old.B.v) ||
-                        (old.B.v.x == 0.0 && old.B.v.y == 0.0 && s.A.v.x == o1[old.B.i1] && s.A.v.y == o1[NC + old.B.i1] &&
-                         s.A.v.x == o2[old.B.i2] && s.A.v.y == o2[NC + old.B.i2]))) m = true;
+                        (old.B.v.x == 0.0 && old.B.v.y == 0.0 && s.A.v.x == o1[old.B.i1].x && s.A.v.y == o1[old.B.i1].y &&
+                         s.A.v.x == o2[old.B.i2].x && s.A.v.y == o2[old.B.i2].y))) m = true;
                     if ((old.keys & gjk::kC) && (gjk::eq2(s.A.v, old.C.v) ||
-                        (old.C.v.x == 0.0 && old.C.v.y == 0.0 && s.A.v.x == o1[old.C.i1] && s.A.v.y == o1[NC + old.C.i1] &&
-                         s.A.v.x == o2[old.C.i2] && s.A.v.y == o2[NC + old.C.i2]))) m = true;
+                        (old.C.v.x == 0.0 && old.C.v.y == 0.0 && s.A.v.x == o1[old.C.i1].x && s.A.v.y == o1[old.C.i1].y &&
+                         s.A.v.x == o2[old.C.i2].x && s.A.v.y == o2[old.C.i2].y))) m = true;
                     if (m) flag = 1;
                     else if (rr >= p.md_cap) { flag = 1; status = OBTG_ST_MD_CAP; }
                 }
@@ -644,16 +664,16 @@ __global__ __launch_bounds__(MODE == 0 ? OBTG_SWEEP_THREADS : 256) void k_gjk_sw
         if (flag == 1 && status == OBTG_ST_OK) {
             // planar restatement of gjk.py:299-360 (z terms are exact zeros, see gjk_device.h):
             // pick the partner vertex O of the closest feature, then ONE segment evaluation
-            const double* q1 = lds + sa * VP;
-            const double* q2 = lds + sb * VP;
+            const double2* q1 = xy + sa * VPQ;
+            const double2* q2 = xy + sb * VPQ;
             const int ia1 = rq1 & 0xff, ia2 = (rq1 >> 8) & 0xff, ib1 = (rq1 >> 16) & 0xff, ib2 = (rq1 >> 24) & 0xff;
             const int ic1 = rq2 & 0xff, ic2 = (rq2 >> 8) & 0xff;
-            const V2 a1{ q1[ia1], q1[NC + ia1] }, a2{ q2[ia2], q2[NC + ia2] };
+            const V2 a1{ q1[ia1].x, q1[ia1].y }, a2{ q2[ia2].x, q2[ia2].y };
             const V2 A = gjk::sub2(a1, a2);
             int which = 0;                    // 0: point A, 1: segment A-B, 2: segment A-C, 3: plane
             if (keys & gjk::kC) {
-                const V2 b1{ q1[ib1], q1[NC + ib1] }, b2{ q2[ib2], q2[NC + ib2] };
-                const V2 c1{ q1[ic1], q1[NC + ic1] }, c2{ q2[ic2], q2[NC + ic2] };
+                const V2 b1{ q1[ib1].x, q1[ib1].y }, b2{ q2[ib2].x, q2[ib2].y };
+                const V2 c1{ q1[ic1].x, q1[ic1].y }, c2{ q2[ic2].x, q2[ic2].y };
                 const V2 B = gjk::sub2(b1, b2), C = gjk::sub2(c1, c2);
                 const V2 A0 = gjk::neg2(A), AB = gjk::sub2(B, A), AC = gjk::sub2(C, A);
                 const double w = gjk::cz(AB, AC);
@@ -663,7 +683,7 @@ __global__ __launch_bounds__(MODE == 0 ? OBTG_SWEEP_THREADS : 256) void k_gjk_sw
             } else if (keys & gjk::kB) which = 1;
             if (which == 1 || which == 2) {
                 const int io1 = which == 2 ? ic1 : ib1, io2 = which == 2 ? ic2 : ib2;
-                const V2 o1{ q1[io1], q1[NC + io1] }, o2{ q2[io2], q2[NC + io2] };
+                const V2 o1{ q1[io1].x, q1[io1].y }, o2{ q2[io2].x, q2[io2].y };
                 const V2 O = gjk::sub2(o1, o2);
                 double t = 0.0;               // weightedOriginToLine (gjk.py:397-437)
                 if (gjk::eq2(A, O)) {
@@ -683,10 +703,10 @@ __global__ __launch_bounds__(MODE == 0 ? OBTG_SWEEP_THREADS : 256) void k_gjk_sw
                 r.c2 = V3{ a2.x, a2.y, 0.0 };
             } else {
                 // origin inside the triangle's plane region (rare): the general 3-D evaluation
-                Ctx<MemLds> g;
-                g.mem = MemLds{ lds };
-                g.P1 = Poly{ sa * VP, NC, NC, 0 };
-                g.P2 = Poly{ sb * VP, NC, NC, 0 };
+                Ctx<MemLdsXY> g;
+                g.mem = MemLdsXY{ lds };
+                g.P1 = Poly{ sa * VPQ, 1 << 24, NC, 0 };
+                g.P2 = Poly{ sb * VPQ, 1 << 24, NC, 0 };
                 g.trace = nullptr; g.trace_cap = 0; g.n_support = 0;
                 gjk::Simplex s;
                 s.keys = keys;
@@ -1151,7 +1171,7 @@ int launch_gjk_swarm(obtg_ctx* c, const double* dY, int B, int max_iter, int md_
     const bool planar = c->dim == 2 && c->polys_planar;
     if (planar && c->max_poly_K <= c->deg + 1 && c->deg + 1 <= 127) {
         const int nc = c->deg + 1;
-        const int vp2 = 2 * nc + 1;
+        const int vp2 = nc | 1;                    // object pitch in 16-byte points (PlanarShape<NC>::VPQ)
         const size_t lds2 = planar_lds_bytes<0>(c->n_veh + c->n_poly, vp2, p.chunk);
         void (*kp)(const GjkSwarmParams) = nullptr;
         void (*kf)(const GjkSwarmParams) = nullptr;
@@ -1170,7 +1190,7 @@ int launch_gjk_swarm(obtg_ctx* c, const double* dY, int B, int max_iter, int md_
 #endif
         if (kt && lds2 > kTileAbove) {
             // large rows: tile-major chunks, each staging only the objects it touches
-            int rc = build_tiles(c, 2 * nc + 1);
+            int rc = build_tiles(c, vp2);
             if (rc == OBTG_OK) {
                 GjkSwarmParams q = p;
                 q.chunk_off = c->d_tile_chunk_off.as<int>(); q.order = c->d_tile_order.as<int>();
