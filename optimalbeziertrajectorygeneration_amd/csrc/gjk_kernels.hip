@@ -346,8 +346,8 @@ __device__ __forceinline__ void support_fixed(const double2* __restrict__ o1, co
     out.v = gjk::V2{ w1.x - w2.x, w1.y - w2.y };
 }
 
-// MODE 0: the sweep proper.  Workgroup w of a row owns the pairs k = w, w + W, w + 2W, ... (W =
-//         workgroups per row); every object of the row is staged, LDS slot == object id.
+// MODE 0: the sweep proper.  Workgroup w of a row owns the pairs [w*chunk, (w+1)*chunk) of the list;
+//         every object of the row is staged, LDS slot == object id.
 //         * Scheduling by history: gjkNew's trip count per pair varies 3..26 support scans, and a wave
 //           pays for the refill path whenever ANY lane finishes.  The previous sweep leaves its
 //           per-pair scan counts in p.len_in (SLSQP evaluates f(x) right before the finite-difference
@@ -357,7 +357,7 @@ __device__ __forceinline__ void support_fixed(const double2* __restrict__ o1, co
 //           are not left for the tail.  Only the ORDER of evaluation changes: results are written
 //           per pair and are identical for any order.
 //         * XCD-aware ids: consecutive workgroup ids go round-robin to the 8 XCDs (one L2 each).  The
-//           W workgroups of a row read the same staged row and interleave their output records, so
+//           W workgroups of a row stage the same row and write neighbouring output ranges, so
 //           id -> (row, w) keeps a row on one XCD: rows 8g .. 8g+7 take ids 8gW .. 8(g+1)W-1 with
 //           row = 8g + id % 8, w = (id / 8) % W.
 // MODE 1: finite-difference de-duplication pass (FIXUP), one workgroup per row b >= 1: only pairs
@@ -396,29 +396,20 @@ __global__ __launch_bounds__(MODE == 0 ? OBTG_SWEEP_THREADS : 256) void k_gjk_sw
     __shared__ int s_hist[256];
     int b, w;
     if (SWEEP) {
-#ifdef OBTG_X_PLAINMAP
-        b = (int)blockIdx.x / p.wgs_per_row; w = (int)blockIdx.x - b * p.wgs_per_row;
-#else
         const int per = 8 * p.wgs_per_row;
         const int grp = (int)blockIdx.x / per, g = (int)blockIdx.x - grp * per;
         b = grp * 8 + (g & 7);
         w = g >> 3;
-#endif
         if (b >= p.B) return;
     } else if (FIXUP) {
         b = (int)blockIdx.x + 1; w = 0;
     } else {
         b = (int)(blockIdx.x / p.wgs_per_row); w = (int)(blockIdx.x - b * p.wgs_per_row);
     }
-    // c0 .. c1: positions this workgroup walks (MODE 0: local indices l, pair k = w + l W)
+    // c0 .. c1: positions this workgroup walks (MODE 0: local indices l, pair k = w * chunk + l)
     int c0 = SWEEP ? 0 : (TILED ? p.chunk_off[w] : w * p.chunk);
-#ifdef OBTG_X_CONTIG
 #define OWN(w_, l_, W_) ((w_) * p.chunk + (l_))
     int c1 = SWEEP ? max(0, min(p.n_pairs - w * p.chunk, p.chunk))
-#else
-#define OWN(w_, l_, W_) ((w_) + (l_) * (W_))
-    int c1 = SWEEP ? (p.n_pairs - w + p.wgs_per_row - 1) / p.wgs_per_row
-#endif
                    : (TILED ? p.chunk_off[w + 1] : min(p.n_pairs, c0 + p.chunk));
     const int obj0 = TILED ? p.cobj_off[w] : 0;
     const int n_obj = TILED ? p.cobj_off[w + 1] - obj0 : p.n_veh + p.n_poly;     // staged objects
