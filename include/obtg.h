@@ -227,7 +227,14 @@ enum {
     OBTG_K_TEMPORAL_SEP = 0, OBTG_K_SPEED = 1, OBTG_K_ANG_RATE = 2, OBTG_K_GJK = 3,
     OBTG_K_MIN_DIST = 4, OBTG_K_FD_BATCH = 5, OBTG_K_BERN = 6, OBTG_K_COUNT = 7
 };
+/* on: 0 = off, 1 = every kernel, OBTG_PROFILE_ONLY(id) = only launches of that kernel id (two
+ * events per launch drain the queue between kernels: 15 % of a 0.25 ms step when all three
+ * launches of the step carry them, hence the selective form for timed regions). */
+#define OBTG_PROFILE_ONLY_FLAG 0x100
+#define OBTG_PROFILE_ONLY(kernel_id) (OBTG_PROFILE_ONLY_FLAG | (kernel_id))
 int obtg_set_profiling(obtg_ctx*, int on);
+/* sample: events on every `every`-th eligible launch of each kernel id (1 = all, the default) */
+int obtg_set_profile_period(obtg_ctx*, int every);
 int obtg_kernel_stats(obtg_ctx*, int kernel_id, double* total_ms, long long* launches);
 int obtg_reset_kernel_stats(obtg_ctx*);
 const char* obtg_kernel_name(int kernel_id);

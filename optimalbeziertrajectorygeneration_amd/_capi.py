@@ -66,6 +66,7 @@ _SIGNATURES = {
     "obtg_accel_obj": (_i, [_vp, _vp, _vp, _i, _vp]),
     "obtg_jerk_obj": (_i, [_vp, _vp, _vp, _i, _vp]),
     "obtg_set_profiling": (_i, [_vp, _i]),
+    "obtg_set_profile_period": (_i, [_vp, _i]),
     "obtg_kernel_stats": (_i, [_vp, _i, C.POINTER(_d), C.POINTER(C.c_longlong)]),
     "obtg_reset_kernel_stats": (_i, [_vp]),
     "obtg_kernel_name": (C.c_char_p, [_i]),
@@ -433,8 +434,16 @@ class Context(object):
         return out
 
     # -- instrumentation
-    def set_profiling(self, on):
-        self._check(self._lib.obtg_set_profiling(self._h, int(bool(on))), "obtg_set_profiling")
+    def set_profiling(self, on, only=None):
+        """on: events around every kernel launch; only='gjk' (a kernel name): around that kernel alone."""
+        mode = int(bool(on))
+        if on and only is not None:
+            names = [self._lib.obtg_kernel_name(k).decode() for k in range(K_COUNT)]
+            mode = 0x100 | names.index(only)
+        self._check(self._lib.obtg_set_profiling(self._h, mode), "obtg_set_profiling")
+
+    def set_profile_period(self, every):
+        self._check(self._lib.obtg_set_profile_period(self._h, int(every)), "obtg_set_profile_period")
 
     def reset_kernel_stats(self):
         self._check(self._lib.obtg_reset_kernel_stats(self._h), "obtg_reset_kernel_stats")

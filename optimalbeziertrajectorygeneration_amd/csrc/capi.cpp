@@ -43,8 +43,13 @@ int set_error(obtg_ctx* c, hipError_t e, const char* where)
 
 ScopedKernelTimer::ScopedKernelTimer(obtg_ctx* c_, int id_) : c(c_), id(id_)
 {
-    if (!c->profiling) return;
-    if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) { a = b = nullptr; return; }
+    if (!c->profiling || !((c->profile_mask >> id) & 1u)) return;
+    if (c->profile_period > 1 && (c->profile_seen[id]++ % c->profile_period) != 0) return;
+    auto take = [&](hipEvent_t& e) {
+        if (!c->event_pool.empty()) { e = c->event_pool.back(); c->event_pool.pop_back(); return true; }
+        return hipEventCreate(&e) == hipSuccess;
+    };
+    if (!take(a) || !take(b)) { a = b = nullptr; return; }
     (void)hipEventRecord(a, c->stream);
 }
 
@@ -64,8 +69,8 @@ void flush_pending_events(obtg_ctx* c)
             c->stats[pe.first].ms += ms;
             c->stats[pe.first].launches += 1;
         }
-        (void)hipEventDestroy(pe.second.first);
-        (void)hipEventDestroy(pe.second.second);
+        c->event_pool.push_back(pe.second.first);
+        c->event_pool.push_back(pe.second.second);
     }
     c->pending_events.clear();
 }
@@ -181,7 +186,7 @@ const char* obtg_abi_symbols(void)
         "obtg_ctx_set_fd_dedup\0obtg_ctx_set_gjk_history\0obtg_gjk_swarm_dev\0obtg_gjk_swarm\0obtg_min_dist\0obtg_min_dist2poly\0"
         "obtg_bern_elev\0obtg_bern_diff\0obtg_bern_mul\0obtg_bern_normsq\0"
         "obtg_euclidean_obj\0obtg_accel_obj\0obtg_jerk_obj\0"
-        "obtg_set_profiling\0obtg_kernel_stats\0obtg_reset_kernel_stats\0obtg_kernel_name\0";
+        "obtg_set_profiling\0obtg_set_profile_period\0obtg_kernel_stats\0obtg_reset_kernel_stats\0obtg_kernel_name\0";
     return syms;
 }
 
@@ -228,6 +233,7 @@ void obtg_ctx_destroy(obtg_ctx* c)
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     flush_pending_events(c);
+    for (hipEvent_t e : c->event_pool) (void)hipEventDestroy(e);
     DevBuf* bufs[] = { &c->d_pairs, &c->d_obs, &c->d_w2, &c->d_Tt, &c->d_Td, &c->d_ang_w2n, &c->d_ang_w22n, &c->d_ang_wn,
                        &c->d_binrows, &c->d_tiles, &c->d_poly_pts, &c->d_poly_off, &c->d_hp_a, &c->d_hp_b, &c->d_tile_chunk_off, &c->d_tile_order, &c->d_tile_pslots,
                        &c->d_tile_cobj_off, &c->d_tile_cobjs, &c->ws_in,
@@ -744,6 +750,16 @@ int obtg_set_profiling(obtg_ctx* c, int on)
     OBTG_HIP(c, hipStreamSynchronize(c->stream));
     flush_pending_events(c);
     c->profiling = on != 0;
+    c->profile_mask = (on & OBTG_PROFILE_ONLY_FLAG) ? (1u << (on & 0xff)) : ~0u;
+    if ((on & OBTG_PROFILE_ONLY_FLAG) && (on & 0xff) >= OBTG_K_COUNT) return OBTG_ERR_ARG;
+    return OBTG_OK;
+}
+
+int obtg_set_profile_period(obtg_ctx* c, int every)
+{
+    if (!check_ctx(c) || every < 1) return OBTG_ERR_ARG;
+    c->profile_period = every;
+    for (auto& n : c->profile_seen) n = 0;
     return OBTG_OK;
 }
 

@@ -80,6 +80,10 @@ struct obtg_ctx {
 
     // instrumentation
     bool profiling = false;
+    int profile_period = 1;               // events on every n-th eligible launch of a kernel id
+    long long profile_seen[OBTG_K_COUNT] = {};
+    unsigned profile_mask = ~0u;          // kernel ids that get events while profiling
+    std::vector<hipEvent_t> event_pool;   // recycled events
     obtg::KernelStat stats[OBTG_K_COUNT];
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     std::vector<std::pair<int, std::pair<hipEvent_t, hipEvent_t>>> pending_events;

@@ -10,9 +10,9 @@ mkdir -p $OUT
 export TMPDIR=/tmp
 python3 bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err
 echo "default bench done" > $OUT/progress.log
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o run -- python3 bench.py --steps 20 --warmup 3 --no-cpu > $OUT/bench_stats.json 2> $OUT/stats.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o run -- python3 bench.py --no-cpu > $OUT/bench_stats.json 2> $OUT/stats.err
 echo "kernel stats done" >> $OUT/progress.log
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_dedup -o run -- python3 bench.py --steps 20 --warmup 3 --no-cpu --fd-dedup > $OUT/bench_stats_dedup.json 2> $OUT/stats_dedup.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_dedup -o run -- python3 bench.py --no-cpu --fd-dedup > $OUT/bench_stats_dedup.json 2> $OUT/stats_dedup.err
 echo "dedup stats done" >> $OUT/progress.log
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -o run -- python3 bench.py --steps 3 --warmup 1 --no-cpu > $OUT/bench_fetch.json 2> $OUT/fetch.err
 echo "fetch pmc done" >> $OUT/progress.log
