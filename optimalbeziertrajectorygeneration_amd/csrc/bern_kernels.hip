@@ -511,6 +511,120 @@ __global__ __launch_bounds__(kWave) void k_dynamics(const AngParams p)
     }
 }
 
+// Two-wave form of k_dynamics for the angular-rate case.  One lane per (row, vehicle) leaves the
+// chip with about one wavefront per SIMD (C3: 1153 groups of 64 items), so every scalar table load
+// and every dependent FMA chain is exposed.  Here a workgroup of two waves shares a group: wave 0
+// takes the denominator side (den1 = xD^2 + yD^2, the speed constraint, den = den1^2), wave 1 the
+// numerator side (num1 = yDD xD - xDD yD, num = num1^2); they swap what the other needs for its
+// share of the 4n+1 quotients through LDS.  Only the derivative stage is computed twice.
+template <int NC>
+__global__ __launch_bounds__(2 * kWave) void k_dynamics2(const AngParams p)
+{
+    constexpr int N = NC - 1, L2 = 2 * N + 1, L4 = 4 * N + 1;
+    constexpr int KS = (L4 * 5) / 8;           // wave 0 divides k < KS, wave 1 the rest (wave 1 has the dearer products)
+    extern __shared__ double lds[];
+    double* tile = lds;                        // [kWave][L4]: exchange, then the output rows
+    double* tile_sp = lds + kWave * L4;        // [kWave][L2]: speed rows (wave 0)
+    const int lane = threadIdx.x & (kWave - 1);
+    const int role = threadIdx.x >> 6;         // wave-uniform
+    const int it0 = blockIdx.x * kWave;
+    const int n_valid = min(kWave, p.total - it0);
+    const int item = min(it0 + lane, p.total - 1);
+    const int b = item / p.n_veh;
+    const double* src = p.Y + (size_t)item * 2 * NC;
+    double x[NC], y[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) { x[c] = src[c]; y[c] = src[NC + c]; }
+    const double val = (double)N / p.tf[b];
+    double xD[NC], yD[NC];
+    diff_elev1<NC>(x, val, xD);
+    diff_elev1<NC>(y, val, yD);
+    const ctab_t W22n = as_ctab(p.W22n);
+    double sq[L4];                             // den (wave 0) or num (wave 1), degree 4n
+    if (role == 0) {
+        const ctab_t W2n = as_ctab(p.W2n);
+        double den1[L2];
+#pragma unroll
+        for (int k = 0; k < L2; ++k) {
+            double sd = 0.0;
+#pragma unroll
+            for (int j = (k - N > 0 ? k - N : 0); 2 * j <= k; ++j)
+                sd = fma(W2n[k * NC + j], fma(xD[j], xD[k - j], yD[j] * yD[k - j]), sd);
+            den1[k] = sd;
+        }
+        if (p.out_speed) {
+#pragma unroll
+            for (int k = 0; k < L2; ++k) tile_sp[lane * L2 + k] = p.sp_sign * den1[k] + p.sp_offset;
+            wave_sync();
+            flush_full<L2, L2>(tile_sp, p.out_speed, (size_t)it0 * L2, n_valid, lane);
+        }
+#pragma unroll
+        for (int k = 0; k < L4; ++k) {
+            double s = 0.0;
+#pragma unroll
+            for (int j = (k - 2 * N > 0 ? k - 2 * N : 0); 2 * j <= k; ++j) s = fma(W22n[k * L2 + j], den1[j] * den1[k - j], s);
+            sq[k] = s;
+        }
+#pragma unroll
+        for (int k = KS; k < L4; ++k) tile[lane * L4 + k] = sq[k];
+    } else {
+        const ctab_t Wn = as_ctab(p.Wn);
+        double xDD[NC], yDD[NC], num1[L2];
+        diff_elev1<NC>(xD, val, xDD);
+        diff_elev1<NC>(yD, val, yDD);
+#pragma unroll
+        for (int k = 0; k < L2; ++k) {
+            double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+            for (int j = (k - N > 0 ? k - N : 0); j <= (N < k ? N : k); ++j) {
+                const double wkj = Wn[k * NC + j];
+                s1 = fma(wkj, yDD[j] * xD[k - j], s1);
+                s2 = fma(wkj, xDD[j] * yD[k - j], s2);
+            }
+            num1[k] = s1 - s2;
+        }
+#pragma unroll
+        for (int k = 0; k < L4; ++k) {
+            double s = 0.0;
+#pragma unroll
+            for (int j = (k - 2 * N > 0 ? k - 2 * N : 0); 2 * j <= k; ++j) s = fma(W22n[k * L2 + j], num1[j] * num1[k - j], s);
+            sq[k] = s;
+        }
+#pragma unroll
+        for (int k = 0; k < KS; ++k) tile[lane * L4 + k] = sq[k];
+    }
+    __syncthreads();
+    // constraint = w^2 - num.cpts / den.cpts (optimization.py:608), each wave its share of k
+    double q[L4];
+    if (role == 0) {
+#pragma unroll
+        for (int k = 0; k < KS; ++k) q[k] = p.w2 - tile[lane * L4 + k] / sq[k];
+    } else {
+#pragma unroll
+        for (int k = KS; k < L4; ++k) q[k] = p.w2 - sq[k] / tile[lane * L4 + k];
+    }
+    __syncthreads();
+    if (role == 0) {
+#pragma unroll
+        for (int k = 0; k < KS; ++k) tile[lane * L4 + k] = q[k];
+    } else {
+#pragma unroll
+        for (int k = KS; k < L4; ++k) tile[lane * L4 + k] = q[k];
+    }
+    __syncthreads();
+    // rows of consecutive items are contiguous in the output: one linear copy by both waves
+    const size_t grow = (size_t)it0 * L4;
+    const int total = n_valid * L4;
+    const int shift = (int)(grow & 1);
+    const int npairs = (total + shift + 1) >> 1;
+    for (int m = threadIdx.x; m < npairs; m += 2 * kWave) {
+        const int e0 = 2 * m - shift, e1 = e0 + 1;
+        if (e0 >= 0 && e1 < total) store_nt2(p.out + grow + e0, tile[e0], tile[e1]);
+        else if (e0 >= 0) store_nt(p.out + grow + e0, tile[e0]);
+        else if (e1 < total) store_nt(p.out + grow + e1, tile[e1]);
+    }
+}
+
 // =====================================================================================
 //  generic path: any degree / elevation, one wave per item, operands in LDS, products as
 //  binomially scaled convolutions:  c_k = (1/C(m+n,k)) * sum_j [C(m,j) a_j][C(n,k-j) b_{k-j}]
@@ -1064,10 +1178,15 @@ int launch_speed(obtg_ctx* c, const double* dY, const double* d_tf, int B, doubl
 template <int NC>
 static int launch_dyn_t(obtg_ctx* c, const AngParams& p, int kernel_id)
 {
-    constexpr int L4 = 4 * (NC - 1) + 1;
+    constexpr int L4 = 4 * (NC - 1) + 1, L2 = 2 * (NC - 1) + 1;
     size_t lds = sizeof(double) * kWave * L4;
     const unsigned groups = (unsigned)((p.total + kWave - 1) / kWave);
     ScopedKernelTimer t(c, kernel_id);
+    if (p.out) {   // angular rate (with or without the speed rows): two waves per group
+        hipLaunchKernelGGL(k_dynamics2<NC>, dim3(groups), dim3(2 * kWave), lds + sizeof(double) * kWave * L2, c->stream, p);
+        OBTG_HIP(c, hipGetLastError());
+        return OBTG_OK;
+    }
     hipLaunchKernelGGL(k_dynamics<NC>, dim3(groups * kDynParts), dim3(kWave), lds, c->stream, p);
     OBTG_HIP(c, hipGetLastError());
     return OBTG_OK;
