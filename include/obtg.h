@@ -121,6 +121,20 @@ int obtg_temporal_sep_min(obtg_ctx*, const double* Y, int B, double max_sep, dou
 int obtg_temporal_sep_min_range(obtg_ctx*, const double* Y, int B, double max_sep,
                                 int pair_begin, int pair_count, double* out);
 
+/* Structured finite differences of the temporal-separation family (the `jac`
+ * entry a driver adds next to optimization.py:83-107).  Perturbation t sets element (pert_row[t],
+ * pert_col[t]) of the evaluation row Y0[(n_veh*dim)][deg+1] to pert_val[t] -- one control-point
+ * coordinate of vehicle v_t = pert_row[t] / dim -- so only the n_obj-1 pairs containing v_t change.
+ * out_blk[n_pert][n_obj-1][2n+R+1]: block t holds, for the partners u = 0..n_obj-1, u != v_t in
+ * increasing order, the constraint values of pair {v_t, u} under perturbation t; they equal the
+ * corresponding entries of obtg_temporal_sep on the fully perturbed row bit for bit, the rest of
+ * that row equals the unperturbed evaluation.  n_x (N-1) pair evaluations instead of n_x C(N,2).
+ * OBTG_ERR_UNSUPPORTED for shapes outside the specialised kernels (use the batch form then). */
+int obtg_temporal_sep_fd(obtg_ctx*, const double* Y0, int n_pert, const int* pert_row, const int* pert_col,
+                         const double* pert_val, double max_sep, double* out_blk);
+int obtg_temporal_sep_fd_dev(obtg_ctx*, const double* dY0, int n_pert, const int* d_pert_row,
+                             const int* d_pert_col, const double* d_pert_val, double max_sep, double* d_out_blk);
+
 /* ---- same sweeps on DEVICE pointers, asynchronous on the context's stream ---------------
  * pair_begin/pair_count select a contiguous block of the lexicographic pair list (the
  * pair-partitioned multi-GPU mode); out rows then hold only that block:

@@ -43,6 +43,8 @@ _SIGNATURES = {
     "obtg_ang_rate": (_i, [_vp, _vp, _vp, _i, _d, _vp]),
     "obtg_temporal_sep_min": (_i, [_vp, _vp, _i, _d, _vp]),
     "obtg_temporal_sep_min_range": (_i, [_vp, _vp, _i, _d, _i, _i, _vp]),
+    "obtg_temporal_sep_fd": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _d, _vp]),
+    "obtg_temporal_sep_fd_dev": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _d, _vp]),
     "obtg_temporal_sep_dev": (_i, [_vp, _vp, _i, _d, _i, _i, _vp]),
     "obtg_temporal_sep_min_dev": (_i, [_vp, _vp, _i, _d, _i, _i, _vp]),
     "obtg_speed_dev": (_i, [_vp, _vp, _vp, _i, _d, _i, _vp]),
@@ -434,6 +436,23 @@ class Context(object):
         return out
 
     # -- instrumentation
+    def temporal_sep_fd(self, Y0, pert_row, pert_col, pert_val, max_sep):
+        """Structured finite differences: -> blk[n_pert][n_obj-1][2n+R+1] (include/obtg.h obtg_temporal_sep_fd)."""
+        Y0 = _f64(Y0).reshape(self.n_veh * self.dim, self.deg + 1)
+        pr = np.ascontiguousarray(pert_row, dtype=np.int32)
+        pc = np.ascontiguousarray(pert_col, dtype=np.int32)
+        pv = _f64(pert_val)
+        n = pr.shape[0]
+        out = np.empty((n, max(self.n_veh + self.n_obs - 1, 0), 2 * self.deg + self.deg_elev + 1))
+        self._check(self._lib.obtg_temporal_sep_fd(self._h, _ptr(Y0), n, _ptr(pr), _ptr(pc), _ptr(pv),
+                                                   float(max_sep), _ptr(out)), "obtg_temporal_sep_fd")
+        return out
+
+    def temporal_sep_fd_dev(self, dY0, n_pert, d_row, d_col, d_val, max_sep, d_out):
+        self._check(self._lib.obtg_temporal_sep_fd_dev(self._h, _vp(dY0), int(n_pert), _vp(d_row), _vp(d_col),
+                                                       _vp(d_val), float(max_sep), _vp(d_out)),
+                    "obtg_temporal_sep_fd_dev")
+
     def set_profiling(self, on, only=None):
         """on: events around every kernel launch; only='gjk' (a kernel name): around that kernel alone."""
         mode = int(bool(on))

@@ -374,6 +374,68 @@ __global__ __launch_bounds__(256) void k_normsq_elev(const NsParams p)
 }
 
 // =====================================================================================
+//  Structured finite differences of the temporal-separation family.
+//  Perturbation t replaces ONE element of the evaluation row, i.e. one control point coordinate of
+//  vehicle v_t; only the n_obj - 1 pairs that contain v_t change (optimization.py:311-346 is a sum over
+//  pairs).  Item = (t, partner): one lane evaluates that pair exactly as k_normsq_elev does (same
+//  difference, same product weights, same elevation sums in the same order), so block t of the
+//  output equals the corresponding entries of the brute-force finite-difference row bit for bit.
+// =====================================================================================
+struct TsepFdParams {
+    const double* __restrict__ Y0;     // [n_veh*DIM][NC] the evaluation row
+    const double* __restrict__ obs;    // [n_obj - n_veh][DIM] point obstacles (constant curves)
+    const double* __restrict__ W2;     // folded product weights
+    const double* __restrict__ Td;     // dense elevation table [L+R][L]
+    const int* __restrict__ prow;      // [n_pert] row of Y0 that perturbation t touches
+    const int* __restrict__ pcol;      // [n_pert] column
+    const double* __restrict__ pval;   // [n_pert] the perturbed value itself (x_k + h as the caller rounds it)
+    double* __restrict__ out;          // [n_pert][n_obj-1][L+R]
+    int n_veh, n_obj, R, n_pert;
+    double sign, offset;
+};
+
+template <int NC, int DIM>
+__global__ __launch_bounds__(kWave) void k_tsep_fd(const TsepFdParams p)
+{
+    using S = NsShape<NC, DIM>;
+    constexpr int L = S::L;
+    const long item = (long)blockIdx.x * kWave + threadIdx.x;
+    const int partners = p.n_obj - 1;
+    if (item >= (long)p.n_pert * partners) return;
+    const int t = (int)(item / partners), uu = (int)(item - (long)t * partners);
+    const int r = p.prow[t], cc = p.pcol[t];
+    const double val = p.pval[t];
+    const int v = r / DIM, rq = r - v * DIM;
+    const int u = uu < v ? uu : uu + 1;
+    double a[DIM][NC];
+#pragma unroll
+    for (int q = 0; q < DIM; ++q)
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            double xv = p.Y0[(size_t)(v * DIM + q) * NC + c];
+            if (q == rq && c == cc) xv = val;
+            const double xu = u < p.n_veh ? p.Y0[(size_t)(u * DIM + q) * NC + c] : p.obs[(u - p.n_veh) * DIM + q];
+            a[q][c] = v < u ? xv - xu : xu - xv;      // pairs are (i, j) with i < j: v_i - v_j
+        }
+    double cf[L];
+    normsq_coeffs<NC, DIM>(a, as_ctab(p.W2), cf);
+    const int LR = L + p.R;
+    double* o = p.out + (size_t)item * LR;
+    if (p.R == 0) {
+#pragma unroll
+        for (int k = 0; k < L; ++k) o[k] = p.sign * cf[k] + p.offset;
+    } else {
+        for (int k = 0; k < LR; ++k) {
+            const double* w = p.Td + (size_t)k * L;
+            double s1 = 0.0;
+#pragma unroll
+            for (int j = 0; j < L; ++j) s1 = fma(cf[j], w[j], s1);
+            o[k] = p.sign * s1 + p.offset;
+        }
+    }
+}
+
+// =====================================================================================
 //  angular rate, fast path (R == 0): one vehicle per lane
 // =====================================================================================
 struct AngParams {
@@ -1199,6 +1261,33 @@ static bool dyn_fast(const obtg_ctx* c)
 }
 
 // speed and/or angular rate in one launch (either output may be null)
+int launch_temporal_sep_fd(obtg_ctx* c, const double* dY0, int n_pert, const int* d_prow, const int* d_pcol,
+                           const double* d_pval, double max_sep, double* d_out)
+{
+    if (n_pert <= 0 || c->n_obj < 2) return OBTG_OK;
+    int rc = ensure_tables(c);
+    if (rc) return rc;
+    if (!fast_shape(c)) return OBTG_ERR_UNSUPPORTED;
+    TsepFdParams p{};
+    p.Y0 = dY0; p.obs = c->d_obs.as<double>(); p.W2 = c->d_w2.as<double>(); p.Td = c->d_Td.as<double>();
+    p.prow = d_prow; p.pcol = d_pcol; p.pval = d_pval; p.out = d_out;
+    p.n_veh = c->n_veh; p.n_obj = c->n_obj; p.R = c->R; p.n_pert = n_pert;
+    p.sign = 1.0; p.offset = -(max_sep * max_sep);
+    const long items = (long)n_pert * (c->n_obj - 1);
+    const dim3 grid((unsigned)((items + kWave - 1) / kWave));
+    const int nc = c->deg + 1;
+    void (*kern)(const TsepFdParams) = nullptr;
+#define OBTG_CASE(NC_, D_) if (nc == NC_ && c->dim == D_) kern = k_tsep_fd<NC_, D_>;
+    OBTG_CASE(4, 2) OBTG_CASE(4, 3) OBTG_CASE(6, 2) OBTG_CASE(6, 3) OBTG_CASE(8, 2) OBTG_CASE(8, 3)
+    OBTG_CASE(11, 2) OBTG_CASE(11, 3) OBTG_CASE(16, 2) OBTG_CASE(16, 3) OBTG_CASE(21, 2) OBTG_CASE(21, 3)
+#undef OBTG_CASE
+    if (!kern) return OBTG_ERR_UNSUPPORTED;
+    ScopedKernelTimer t(c, OBTG_K_TEMPORAL_SEP);
+    hipLaunchKernelGGL(kern, grid, dim3(kWave), 0, c->stream, p);
+    OBTG_HIP(c, hipGetLastError());
+    return OBTG_OK;
+}
+
 int launch_dynamics(obtg_ctx* c, const double* dY, const double* d_tf, int B, double bound, int is_max,
                     double max_rate, double* d_out_speed, double* d_out_ang)
 {

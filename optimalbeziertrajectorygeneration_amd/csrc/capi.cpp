@@ -181,6 +181,7 @@ const char* obtg_abi_symbols(void)
         "obtg_ctx_create\0obtg_ctx_destroy\0obtg_ctx_set_stream\0obtg_ctx_set_deg_elev\0obtg_sync\0"
         "obtg_len_temporal_sep\0obtg_len_speed\0obtg_len_ang_rate\0obtg_num_pairs\0"
         "obtg_temporal_sep\0obtg_speed\0obtg_ang_rate\0obtg_temporal_sep_min\0obtg_temporal_sep_min_range\0"
+        "obtg_temporal_sep_fd\0obtg_temporal_sep_fd_dev\0"
         "obtg_temporal_sep_dev\0obtg_temporal_sep_min_dev\0obtg_speed_dev\0obtg_ang_rate_dev\0obtg_dynamics_dev\0"
         "obtg_fd_batch_dev\0obtg_gjk_pairs\0obtg_ctx_set_polygons\0obtg_ctx_set_hull_pairs\0"
         "obtg_ctx_set_fd_dedup\0obtg_ctx_set_gjk_history\0obtg_gjk_swarm_dev\0obtg_gjk_swarm\0obtg_min_dist\0obtg_min_dist2poly\0"
@@ -376,6 +377,44 @@ int obtg_temporal_sep(obtg_ctx* c, const double* Y, int B, double max_sep, doubl
 int obtg_temporal_sep_min(obtg_ctx* c, const double* Y, int B, double max_sep, double* out)
 {
     return host_sep(c, Y, B, max_sep, true, out);
+}
+
+static int check_perts(const obtg_ctx* c, int n_pert, const int* prow, const int* pcol)
+{
+    for (int t = 0; t < n_pert; ++t)
+        if (prow[t] < 0 || prow[t] >= c->n_veh * c->dim || pcol[t] < 0 || pcol[t] > c->deg) return OBTG_ERR_ARG;
+    return OBTG_OK;
+}
+
+int obtg_temporal_sep_fd(obtg_ctx* c, const double* Y0, int n_pert, const int* pert_row, const int* pert_col,
+                         const double* pert_val, double max_sep, double* out_blk)
+{
+    if (!check_ctx(c) || n_pert < 0) return OBTG_ERR_ARG;
+    if (n_pert == 0 || c->n_obj < 2) return OBTG_OK;
+    if (!Y0 || !pert_row || !pert_col || !pert_val || !out_blk) return OBTG_ERR_ARG;
+    if (int rc = check_perts(c, n_pert, pert_row, pert_col)) return rc;
+    (void)hipSetDevice(c->device);
+    const size_t per = (size_t)(c->n_obj - 1) * (2 * c->deg + c->R + 1);
+    int rc = h2d(c, c->ws_in, Y0, sizeof(double) * ysize(c));
+    if (rc) return rc;
+    if ((rc = h2d(c, c->ws_misc[0], pert_row, sizeof(int) * (size_t)n_pert))) return rc;
+    if ((rc = h2d(c, c->ws_misc[1], pert_col, sizeof(int) * (size_t)n_pert))) return rc;
+    if ((rc = h2d(c, c->ws_in2, pert_val, sizeof(double) * (size_t)n_pert))) return rc;
+    if ((rc = c->ws_out.reserve(sizeof(double) * per * n_pert))) return rc;
+    rc = launch_temporal_sep_fd(c, c->ws_in.as<double>(), n_pert, c->ws_misc[0].as<int>(), c->ws_misc[1].as<int>(),
+                                c->ws_in2.as<double>(), max_sep, c->ws_out.as<double>());
+    if (rc) return rc;
+    return d2h(c, out_blk, c->ws_out.p, sizeof(double) * per * n_pert);
+}
+
+int obtg_temporal_sep_fd_dev(obtg_ctx* c, const double* dY0, int n_pert, const int* d_pert_row,
+                             const int* d_pert_col, const double* d_pert_val, double max_sep, double* d_out_blk)
+{
+    if (!check_ctx(c) || n_pert < 0) return OBTG_ERR_ARG;
+    if (n_pert == 0 || c->n_obj < 2) return OBTG_OK;
+    if (!dY0 || !d_pert_row || !d_pert_col || !d_pert_val || !d_out_blk) return OBTG_ERR_ARG;
+    (void)hipSetDevice(c->device);
+    return launch_temporal_sep_fd(c, dY0, n_pert, d_pert_row, d_pert_col, d_pert_val, max_sep, d_out_blk);
 }
 
 int obtg_speed(obtg_ctx* c, const double* Y, const double* tf, int B, double bound, int is_max, double* out)

@@ -114,6 +114,8 @@ int binrow_offset(obtg_ctx* c, int n);  // ensures row C(n,.) is resident; retur
 // ---------------------------------------------------------------- launchers (bern_kernels.hip)
 int launch_temporal_sep(obtg_ctx* c, const double* dY, int B, double max_sep, int pair_begin,
                         int pair_count, bool min_only, double* d_out);
+int launch_temporal_sep_fd(obtg_ctx* c, const double* dY0, int n_pert, const int* d_prow, const int* d_pcol,
+                           const double* d_pval, double max_sep, double* d_out);
 int launch_speed(obtg_ctx* c, const double* dY, const double* d_tf, int B, double bound, int is_max,
                  double* d_out);
 int launch_ang_rate(obtg_ctx* c, const double* dY, const double* d_tf, int B, double max_rate,

@@ -243,8 +243,47 @@ class BezOptimization(object):
                 F = c.ang_rate(Y, tf, self.model['maxAngRate'])
         return ((F[1:] - F[0:1]) / dx[:, None]).T
 
-    def temporalSeparationJacobian(self, x):
-        return self._jac(x, 'tsep')
+    def temporalSeparationJacobian(self, x, structured=True):
+        """d(temporalSeparationConstraints)/dx by SciPy-style forward differences.
+
+        structured=True: a variable of vehicle v only moves the N-1 pairs
+        that contain v, so only those pairs are re-evaluated (obtg_temporal_sep_fd) and the dense
+        matrix is assembled from them; every entry equals the brute-force batch's
+        (structured=False) bit for bit.  Variables that move every vehicle (tf with prescribed
+        speeds) and shapes outside the specialised kernels take the batch path."""
+        if not structured:
+            return self._jac(x, 'tsep')
+        x = np.asarray(x, dtype=float)
+        X, dx = self._fd_rows(x)
+        with_obs = self.pointObstacles is not None
+        ctx = self._ctx(with_obs)
+        n_obj = ctx.n_veh + ctx.n_obs
+        if n_obj < 2:
+            return self._jac(x, 'tsep')
+        dim, numCols = self.model['dim'], self._numCols
+        n_pts = self.model['numVeh'] * dim * numCols          # control-point variables; a trailing tf is not one
+        offset = (self.model['deg'] + 1 - numCols) // 2
+        Y0 = self.reshapeVectors(x[None])[0]
+        k = np.arange(n_pts)
+        prow, pcol = k // numCols, offset + k % numCols
+        try:
+            blk = ctx.temporal_sep_fd(Y0, prow, pcol, X[k + 1, k], self.model['maxSep'])
+        except _capi.ObtgError:
+            return self._jac(x, 'tsep')
+        F0 = ctx.temporal_sep(Y0[None], self.model['maxSep'])[0]
+        LR = blk.shape[2]
+        J = np.zeros((F0.size, x.size))
+        veh = prow // dim
+        partners = np.arange(n_obj - 1)[None, :] + (np.arange(n_obj - 1)[None, :] >= veh[:, None])   # [n_pts][n_obj-1]
+        lo, hi = np.minimum(veh[:, None], partners), np.maximum(veh[:, None], partners)
+        pidx = lo * n_obj - lo * (lo + 1) // 2 + (hi - lo - 1)                                        # lexicographic pair index
+        rows = pidx[:, :, None] * LR + np.arange(LR)[None, None, :]
+        J[rows.reshape(n_pts, -1), k[:, None]] = (blk - F0[rows]).reshape(n_pts, -1) / dx[:n_pts, None]
+        if x.size > n_pts:      # tf: moves columns 1 / -2 of every vehicle when speeds are prescribed
+            Yt = self.reshapeVectors(X[n_pts + 1:])
+            Ft = ctx.temporal_sep(Yt, self.model['maxSep'])
+            J[:, n_pts:] = ((Ft - F0[None]) / dx[n_pts:, None]).T
+        return J
 
     def maxSpeedJacobian(self, x):
         return self._jac(x, 'vmax')

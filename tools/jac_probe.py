@@ -1,0 +1,37 @@
+"""Temporal-separation Jacobian at a configuration: brute-force FD batch vs structured FD (obtg_temporal_sep_fd_dev).
+    python tools/jac_probe.py [C3]"""
+import sys, time, numpy as np, torch
+sys.path.insert(0, '.')
+from optimalbeziertrajectorygeneration_amd import _capi, synth
+name = sys.argv[1] if len(sys.argv) > 1 else 'C3'
+cfg = synth.CONFIGS[name]
+N, d, n, R = cfg['N'], cfg['d'], cfg['n'], cfg['R']
+Y = synth.swarm_control_points(N, d, n); n_x = N * d * (n - 1); B = n_x + 1
+dev = torch.device('cuda'); f64 = torch.float64
+c = _capi.Context(N, d, n, R); c.set_stream(torch.cuda.current_stream().cuda_stream)
+P, L = c.num_pairs, 2 * n + R + 1
+d0 = torch.from_numpy(Y).to(dev); dY = torch.empty((B, N * d, n + 1), dtype=f64, device=dev)
+c.fd_batch_dev(d0.data_ptr(), 1, synth.FD_STEP, B, dY.data_ptr())
+o_full = torch.empty((B, P * L), dtype=f64, device=dev)
+k = np.arange(n_x); prow = k // (n - 1); pcol = 1 + k % (n - 1)
+pval = Y[prow, pcol] + synth.FD_STEP
+d_row = torch.from_numpy(prow.astype(np.int32)).to(dev); d_col = torch.from_numpy(pcol.astype(np.int32)).to(dev)
+d_val = torch.from_numpy(pval).to(dev)
+o_blk = torch.empty((n_x, N - 1, L), dtype=f64, device=dev); o_base = torch.empty((1, P * L), dtype=f64, device=dev)
+def brute(): c.temporal_sep_dev(dY.data_ptr(), B, 0.9, o_full.data_ptr())
+def struct():
+    c.temporal_sep_dev(d0.data_ptr(), 1, 0.9, o_base.data_ptr())
+    c.temporal_sep_fd_dev(d0.data_ptr(), n_x, d_row.data_ptr(), d_col.data_ptr(), d_val.data_ptr(), 0.9, o_blk.data_ptr())
+def timed(f, reps=100):
+    for _ in range(5): f()
+    torch.cuda.synchronize(); t = time.perf_counter()
+    for _ in range(reps): f()
+    torch.cuda.synchronize(); return (time.perf_counter() - t) / reps * 1e3
+tb, ts = timed(brute), timed(struct)
+# spot check: block of variable 7 against the brute-force row 8
+full = o_full.cpu().numpy(); blk = o_blk.cpu().numpy()
+v = prow[7] // d; partners = [u for u in range(N) if u != v]
+pidx = [min(u, v) * N - min(u, v) * (min(u, v) + 1) // 2 + (max(u, v) - min(u, v) - 1) for u in partners]
+same = all(np.array_equal(full[8, p * L:(p + 1) * L], blk[7, i]) for i, p in enumerate(pidx))
+print('%s: brute-force FD batch %.4f ms (%d pair evaluations, %.1f MB out); structured %.4f ms (%d pair evaluations, %.1f MB out); ratio %.1fx; spot check identical: %s'
+      % (name, tb, B * P, B * P * L * 8 / 1e6, ts, P + n_x * (N - 1), (P + n_x * (N - 1)) * L * 8 / 1e6, tb / ts, same))
