@@ -127,6 +127,17 @@ class BezOptimization(object):
             c.set_deg_elev(int(DEG_ELEV))
         return c
 
+    def _ctx_one(self):
+        """A one-vehicle context of the same degree: the per-vehicle families evaluated on a compact
+        batch of single vehicles (structured Jacobians)."""
+        c = self._ctxs.get('one')
+        if c is None:
+            c = _capi.Context(1, self.model['dim'], self.model['deg'], int(DEG_ELEV), device=self._device)
+            self._ctxs['one'] = c
+        if c.deg_elev != int(DEG_ELEV):
+            c.set_deg_elev(int(DEG_ELEV))
+        return c
+
     def _timeopt(self):
         return self.model['minGoal'].lower() == 'timeopt'
 
@@ -285,14 +296,54 @@ class BezOptimization(object):
             J[:, n_pts:] = ((Ft - F0[None]) / dx[n_pts:, None]).T
         return J
 
-    def maxSpeedJacobian(self, x):
-        return self._jac(x, 'vmax')
+    def _jac_vehicle(self, x, family, structured=True):
+        """Per-vehicle families (speed, angular rate): the Jacobian is block diagonal -- a control
+        point of vehicle v only moves v's own rows.  structured=True evaluates, per variable, that one
+        vehicle (a compact batch on a one-vehicle context: n_x vehicle evaluations instead of
+        n_x N); entries equal the brute-force batch's bit for bit.  A trailing tf moves everything and
+        takes the batch path."""
+        if not structured:
+            return self._jac(x, family)
+        x = np.asarray(x, dtype=float)
+        X, dx = self._fd_rows(x)
+        dim, numCols, numVeh = self.model['dim'], self._numCols, self.model['numVeh']
+        n_pts = numVeh * dim * numCols
+        offset = (self.model['deg'] + 1 - numCols) // 2
+        Y0 = self.reshapeVectors(x[None])[0]
+        tf0 = float(self._tf_of(x))
 
-    def minSpeedJacobian(self, x):
-        return self._jac(x, 'vmin')
+        def evaluate(ctx, Y, tf):
+            if family == 'vmax':
+                return ctx.speed(Y, tf, self.model['maxSpeed'], True)
+            if family == 'vmin':
+                return ctx.speed(Y, tf, self.model['minSpeed'], False)
+            return ctx.ang_rate(Y, tf, self.model['maxAngRate'])
 
-    def maxAngularRateJacobian(self, x):
-        return self._jac(x, 'ang')
+        F0 = evaluate(self._ctx(False), Y0[None], np.array([tf0]))[0]
+        per = F0.size // numVeh
+        k = np.arange(n_pts)
+        prow, pcol = k // numCols, offset + k % numCols
+        veh = prow // dim
+        Yc = Y0.reshape(numVeh, dim, -1)[veh].copy()              # [n_pts][dim][deg+1]: the touched vehicle of each variable
+        Yc[k, prow % dim, pcol] = X[k + 1, k]
+        Fc = evaluate(self._ctx_one(), Yc, np.full(n_pts, tf0))   # [n_pts][per]
+        J = np.zeros((F0.size, x.size))
+        rows = veh[:, None] * per + np.arange(per)[None, :]
+        J[rows, k[:, None]] = (Fc - F0[rows]) / dx[:n_pts, None]
+        if x.size > n_pts:
+            Xt = X[n_pts + 1:]
+            Ft = evaluate(self._ctx(False), self.reshapeVectors(Xt), Xt[:, -1])
+            J[:, n_pts:] = ((Ft - F0[None]) / dx[n_pts:, None]).T
+        return J
+
+    def maxSpeedJacobian(self, x, structured=True):
+        return self._jac_vehicle(x, 'vmax', structured)
+
+    def minSpeedJacobian(self, x, structured=True):
+        return self._jac_vehicle(x, 'vmin', structured)
+
+    def maxAngularRateJacobian(self, x, structured=True):
+        return self._jac_vehicle(x, 'ang', structured)
 
     # ------------------------------------------------------------------ x <-> y
     def generateGuess(self, std=0, seed=None):

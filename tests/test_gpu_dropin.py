@@ -216,3 +216,14 @@ def test_structured_jacobian_is_bit_identical_to_brute_force(case):
     assert J_s.shape == J_b.shape and J_s.shape[1] == x.size
     assert np.array_equal(J_s, J_b)
     assert np.count_nonzero(J_b) > 0 and np.count_nonzero(J_b) < J_b.size // 2      # sparse and not trivial
+    # per-vehicle families: block-diagonal Jacobians from a compact one-vehicle batch
+    fams = [bo.maxSpeedJacobian, bo.minSpeedJacobian] + ([bo.maxAngularRateJacobian] if bo.model['dim'] == 2 else [])
+    if case == "example1":
+        bo.model['minSpeed'] = 0.2
+    elif case != "elevated":
+        bo.model['maxSpeed'], bo.model['minSpeed'], bo.model['maxAngRate'] = 5.0, 0.2, 1.0
+    if case == "elevated":
+        return
+    for jac in fams:
+        Js, Jb = jac(x), jac(x, structured=False)
+        assert np.array_equal(Js, Jb, equal_nan=True) and np.count_nonzero(Jb) > 0
