@@ -217,8 +217,12 @@ def main():
             traffic = json.load(open(tpath)).get(args.workload, {}).get(dom["kernel"])
         except Exception:
             traffic = None
+    note = None
+    if dom["kernel"] == "gjk":
+        note = ("gjkNew sweep: VALU-issue bound by nature (PMC at C3: ~85 % VALU busy, LDS 34 %), reported against "
+                "HBM as the contract asks; see DESIGN.md 4.3")
     roofline = dict(bound="hbm", kernel=dom["kernel"], achieved=dom["achieved_gbs"], peak=HBM_PEAK_GBS,
-                    unit="GB/s", frac=dom["frac"], traffic=traffic,
+                    unit="GB/s", frac=dom["frac"], traffic=traffic, note=note,
                     step_achieved=round(B * total_bytes / (ms_per_step * 1e-3) / 1e9, 2))
 
     cpu = cpu_np = None
