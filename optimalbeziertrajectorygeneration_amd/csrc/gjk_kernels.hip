@@ -381,8 +381,15 @@ __host__ __device__ constexpr size_t planar_lds_bytes(int cap_obj, int vpq, int 
 #else
 #define OBTG_SWEEP_THREADS 256
 #endif
+// Occupancy: the sweep is sensitive to waves per SIMD (C3: 2 / 3 / 4 / 5 waves = 0.58 / 0.17 / 0.153 /
+// 0.146 ms).  Five waves need <= 96 VGPRs (7 spilled at NC = 11) and <= 32 KB of LDS per workgroup,
+// hence 864-pair chunks; six waves (80 VGPRs, 24 spilled) lose again.
+#ifndef OBTG_X_SWEEP_WAVES
+#define OBTG_X_SWEEP_WAVES 5
+#endif
 template <int NC, int MODE>
-__global__ __launch_bounds__(MODE == 0 ? OBTG_SWEEP_THREADS : 256) void k_gjk_swarm_planar(const GjkSwarmParams p)
+__global__ __launch_bounds__(MODE == 0 ? OBTG_SWEEP_THREADS : 256, (MODE == 0 && NC <= 11) ? OBTG_X_SWEEP_WAVES : 1)
+void k_gjk_swarm_planar(const GjkSwarmParams p)
 {
     constexpr bool SWEEP = MODE == 0, FIXUP = MODE == 1, TILED = MODE == 2;
     using gjk::V2;
@@ -489,13 +496,12 @@ __global__ __launch_bounds__(MODE == 0 ? OBTG_SWEEP_THREADS : 256) void k_gjk_sw
     }
     // the chunk's (a, b) object ids go to LDS once: the refill path must not wait on global memory
     if (SWEEP) {
-        const int W = p.wgs_per_row;
         if (p.len_in) {
             // counting sort of this workgroup's pairs by descending scan count of the previous sweep
             const unsigned char* len = p.len_in + (size_t)b * p.len_in_stride;
             if (threadIdx.x < 256) s_hist[threadIdx.x] = 0;
             __syncthreads();
-            for (int l = threadIdx.x; l < c1; l += blockDim.x) atomicAdd(&s_hist[255 - len[OWN(w, l, W)]], 1);
+            for (int l = threadIdx.x; l < c1; l += blockDim.x) atomicAdd(&s_hist[255 - len[OWN(w, l, 0)]], 1);
             __syncthreads();
             if (threadIdx.x < kWave) {
                 const int lane = threadIdx.x;
@@ -513,7 +519,7 @@ __global__ __launch_bounds__(MODE == 0 ? OBTG_SWEEP_THREADS : 256) void k_gjk_sw
             }
             __syncthreads();
             for (int l = threadIdx.x; l < c1; l += blockDim.x) {
-                const int kq = OWN(w, l, W);
+                const int kq = OWN(w, l, 0);
                 const int pos = atomicAdd(&s_hist[255 - len[kq]], 1);
                 const unsigned ab = (unsigned)p.pa[kq] | ((unsigned)p.pb[kq] << 16);
                 ord[pos] = (unsigned short)l;
@@ -522,7 +528,7 @@ __global__ __launch_bounds__(MODE == 0 ? OBTG_SWEEP_THREADS : 256) void k_gjk_sw
             }
         } else {
             for (int l = threadIdx.x; l < c1; l += blockDim.x) {
-                const int kq = OWN(w, l, W);
+                const int kq = OWN(w, l, 0);
                 ord[l] = (unsigned short)l;
                 plist[l] = pnat[l] = (unsigned)p.pa[kq] | ((unsigned)p.pb[kq] << 16);
             }
@@ -1146,9 +1152,13 @@ int launch_gjk_swarm(obtg_ctx* c, const double* dY, int B, int max_iter, int md_
     const int vlen = c->dim * (c->deg + 1);
     p.vp = (vlen % 2 == 0) ? vlen + 1 : vlen;
     // workgroups per row.  Lanes refill from their workgroup's chunk, so a chunk must hold several
-    // pairs per lane (measured at C3: 316 pairs per 256 lanes = 0.281 ms, 1264 pairs = 0.215 ms);
-    // small batches trade that for enough workgroups to fill the chip.
-    int wgs = (c->n_hull_pairs + 1279) / 1280;
+    // pairs per lane (measured at C3 in list order: 316 pairs per 256 lanes = 0.281 ms, 1264 pairs =
+    // 0.215 ms); with the history order 864-pair chunks do as well as 1264 and leave LDS for a fifth
+    // workgroup per CU.  Small batches trade chunk size for enough workgroups to fill the chip.
+#ifndef OBTG_X_CHUNK
+#define OBTG_X_CHUNK 864
+#endif
+    int wgs = (c->n_hull_pairs + OBTG_X_CHUNK - 1) / OBTG_X_CHUNK;
 #ifdef OBTG_X_WG512
     wgs = (c->n_hull_pairs + 2559) / 2560;
 #endif
@@ -1163,7 +1173,11 @@ int launch_gjk_swarm(obtg_ctx* c, const double* dY, int B, int max_iter, int md_
     if (planar && c->max_poly_K <= c->deg + 1 && c->deg + 1 <= 127) {
         const int nc = c->deg + 1;
         const int vp2 = nc | 1;                    // object pitch in 16-byte points (PlanarShape<NC>::VPQ)
+#ifdef OBTG_X_GJKLDSPAD
+        const size_t lds2 = planar_lds_bytes<0>(c->n_veh + c->n_poly, vp2, p.chunk) + OBTG_X_GJKLDSPAD;
+#else
         const size_t lds2 = planar_lds_bytes<0>(c->n_veh + c->n_poly, vp2, p.chunk);
+#endif
         void (*kp)(const GjkSwarmParams) = nullptr;
         void (*kf)(const GjkSwarmParams) = nullptr;
         void (*kt)(const GjkSwarmParams) = nullptr;
