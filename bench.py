@@ -39,6 +39,8 @@ HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--separate", action="store_true",
+                    help="temporal separation and the gjkNew sweep as two launches instead of the one-launch pair sweep")
     ap.add_argument("--steps", type=int, default=500)
     ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--workload", default="C3", choices=["C2", "C3", "C4", "C5"])
@@ -134,13 +136,19 @@ def main():
         g_p2 = torch.empty((B, P_s, 3), dtype=f64, device=dev)
         g_dist = torch.empty((B, P_s), dtype=f64, device=dev)
 
+    one_launch = use_gjk and not args.separate   # the N x N pair sweeps (temporal separation + gjkNew) as one grid
+
     def step():
-        ctx.temporal_sep_dev(dY.data_ptr(), B, max_sep, o_sep.data_ptr())
+        if one_launch:
+            ctx.pair_sweep_dev(dY.data_ptr(), B, max_sep, o_sep.data_ptr(), g_flag.data_ptr(), g_p1.data_ptr(),
+                               g_p2.data_ptr(), g_dist.data_ptr(), None, None, 128, 256)
+        else:
+            ctx.temporal_sep_dev(dY.data_ptr(), B, max_sep, o_sep.data_ptr())
         if o_an is not None:    # speed + angular rate share their derivative curves: one launch
             ctx.dynamics_dev(dY.data_ptr(), d_tf.data_ptr(), B, vmax, True, wmax, o_sp.data_ptr(), o_an.data_ptr())
         else:
             ctx.speed_dev(dY.data_ptr(), d_tf.data_ptr(), B, vmax, True, o_sp.data_ptr())
-        if use_gjk:
+        if use_gjk and not one_launch:
             ctx.gjk_swarm_dev(dY.data_ptr(), B, g_flag.data_ptr(), g_p1.data_ptr(), g_p2.data_ptr(),
                               g_dist.data_ptr(), None, None, 128, 256)
 
@@ -159,7 +167,8 @@ def main():
     torch.cuda.synchronize()
     ctx.sync()
     wstats = ctx.kernel_stats()
-    dom_name = max(("temporal_sep", "speed", "ang_rate", "gjk"), key=lambda k: wstats.get(k, (0.0, 0))[0])
+    KNAMES = ("pair_sweep", "temporal_sep", "speed", "ang_rate", "gjk")
+    dom_name = max(KNAMES, key=lambda k: wstats.get(k, (0.0, 0))[0])
     # timed region: HIP events (launch stream) around the dominant kernel only, on every 4th step --
     # an event pair drains the queue around its launch (events on all three launches of every step
     # cost 15 % of a 0.25 ms step)
@@ -200,7 +209,8 @@ def main():
     kernels = []
     if o_an is not None:   # the fused dynamics launch is booked under "ang_rate"
         by["ang_rate"] = by["ang_rate"] + 8 * N * L
-    for name in ("temporal_sep", "speed", "ang_rate", "gjk"):
+    by["pair_sweep"] = by["temporal_sep"] + by["gjk"]    # when a shape falls back to two launches they report separately
+    for name in KNAMES:
         ms, cnt = stats.get(name, (0.0, 0))
         if cnt == 0:
             continue
@@ -218,6 +228,9 @@ def main():
         except Exception:
             traffic = None
     note = None
+    if dom["kernel"] == "pair_sweep":
+        note = ("one launch: the gjkNew sweep's workgroups (VALU bound) also write their row's temporal-separation "
+                "block (HBM-write bound); bytes = both families' algorithmic bytes; see DESIGN.md 4.7")
     if dom["kernel"] == "gjk":
         note = ("gjkNew sweep: VALU-issue bound by nature (PMC at C3: ~85 % VALU busy, LDS 34 %), reported against "
                 "HBM as the contract asks; see DESIGN.md 4.3")

@@ -184,6 +184,16 @@ int obtg_ctx_set_hull_pairs(obtg_ctx*, const int* pair_a, const int* pair_b, int
 int obtg_gjk_swarm_dev(obtg_ctx*, const double* dY, int B, int max_iter, int md_cap,
                        int* d_flag, double* d_p1, double* d_p2, double* d_dist,
                        int* d_nsup, int* d_status);
+/* The N x N pair sweep of a batch in ONE launch: obtg_temporal_sep_dev (all pairs) and
+ * obtg_gjk_swarm_dev for the same B rows.  The workgroups of the planar gjkNew sweep have the row's
+ * control points in LDS anyway; each also writes its share of the row's temporal-separation block
+ * (part before, part after its gjkNew phases, staggered between workgroups), whose HBM stores then
+ * drain under the VALU-bound gjkNew work of the other wavefronts.  Outputs are those of the two
+ * separate calls, bit for bit.  Shapes without that kernel (3-D, DEG_ELEV > 0, point obstacles,
+ * large rows, de-duplication on) fall back to the two launches. */
+int obtg_pair_sweep_dev(obtg_ctx*, const double* dY, int B, double max_sep, double* d_out_sep,
+                        int max_iter, int md_cap, int* d_flag, double* d_p1, double* d_p2,
+                        double* d_dist, int* d_nsup, int* d_status);
 /* Finite-difference de-duplication (off by default).  The rows of one
  * SLSQP Jacobian differ from row 0 in ONE vehicle, so all pairs not involving it have row 0's
  * inputs bit for bit.  When on, obtg_gjk_swarm[_dev] compares every row with row 0 (bitwise, per
@@ -239,7 +249,7 @@ int obtg_jerk_obj(obtg_ctx*, const double* Y, const double* tf, int B, double* o
  * obtg_kernel_stats returns the accumulated device time and launch count per kernel id. */
 enum {
     OBTG_K_TEMPORAL_SEP = 0, OBTG_K_SPEED = 1, OBTG_K_ANG_RATE = 2, OBTG_K_GJK = 3,
-    OBTG_K_MIN_DIST = 4, OBTG_K_FD_BATCH = 5, OBTG_K_BERN = 6, OBTG_K_COUNT = 7
+    OBTG_K_MIN_DIST = 4, OBTG_K_FD_BATCH = 5, OBTG_K_BERN = 6, OBTG_K_PAIR_SWEEP = 7, OBTG_K_COUNT = 8
 };
 /* on: 0 = off, 1 = every kernel, OBTG_PROFILE_ONLY(id) = only launches of that kernel id (two
  * events per launch drain the queue between kernels: 15 % of a 0.25 ms step when all three

@@ -15,7 +15,7 @@ LIB_PATH = os.environ.get("OBTG_LIB") or os.path.join(HERE, "libobtg_hip.so")   
 OK = 0
 ST_OK, ST_MD_CAP, ST_MAXITER, ST_CYCLE = 0, 1, 2, 3
 MD_OK, MD_NODE_CAP, MD_DEPTH_CAP, MD_GJK_CAP = 0, 1, 2, 3
-K_TEMPORAL_SEP, K_SPEED, K_ANG_RATE, K_GJK, K_MIN_DIST, K_FD_BATCH, K_BERN, K_COUNT = range(8)
+K_TEMPORAL_SEP, K_SPEED, K_ANG_RATE, K_GJK, K_MIN_DIST, K_FD_BATCH, K_BERN, K_PAIR_SWEEP, K_COUNT = range(9)
 
 _lib = None
 
@@ -56,6 +56,7 @@ _SIGNATURES = {
     "obtg_ctx_set_hull_pairs": (_i, [_vp, _vp, _vp, _i]),
     "obtg_ctx_set_fd_dedup": (_i, [_vp, _i]),
     "obtg_ctx_set_gjk_history": (_i, [_vp, _i]),
+    "obtg_pair_sweep_dev": (_i, [_vp, _vp, _i, _d, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "obtg_gjk_swarm_dev": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "obtg_gjk_swarm": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "obtg_min_dist": (_i, [_vp, _vp, _i, _i, _vp, _vp, _i, _d, _i, _i, _i, _i, _vp, _vp, _vp]),
@@ -371,6 +372,14 @@ class Context(object):
                     "obtg_gjk_swarm_dev")
 
     # -- minDist
+    def pair_sweep_dev(self, dY, B, max_sep, d_out_sep, d_flag, d_p1, d_p2, d_dist, d_nsup=None, d_status=None,
+                       max_iter=128, md_cap=4096):
+        """temporal separation + gjkNew hull sweep of the same rows in one launch (obtg_pair_sweep_dev)."""
+        self._check(self._lib.obtg_pair_sweep_dev(self._h, _vp(dY), B, float(max_sep), _vp(d_out_sep), max_iter,
+                                                  md_cap, _vp(d_flag), _vp(d_p1), _vp(d_p2), _vp(d_dist),
+                                                  _vp(d_nsup) if d_nsup else None,
+                                                  _vp(d_status) if d_status else None), "obtg_pair_sweep_dev")
+
     def min_dist(self, curves, pair_a, pair_b, eps=1e-9, max_iter=128, md_cap=4096, max_depth=64,
                  max_nodes=200000):
         """curves[n][3][K] (2-D curves: pass a zero z row)."""

@@ -1,0 +1,423 @@
+// Device side of the Bernstein sweeps (fast path): shared by bern_kernels.hip (stand-alone
+// kernels) and gjk_kernels.hip (the one-launch pair sweep).  Floating-point contraction is the
+// including translation unit's business: gjk_kernels.hip brackets this header with
+// `#pragma clang fp contract(fast)` so that both units generate the same arithmetic.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "obtg_internal.h"
+
+namespace obtg {
+
+// Read-only coefficient tables are addressed through the CONSTANT address space: their loads
+// have wave-uniform addresses and must become scalar loads (s_load_dwordxN into SGPRs, usable
+// directly as v_fma_f64 operands).  Through a plain global pointer the compiler cannot prove
+// that the kernel's own stores do not clobber the table and falls back to one vector load +
+// s_waitcnt vmcnt(0) per product row -- a serialised L2 round trip per row (measured with
+// s_memtime stamps: 8.5 k cycles for the 200 FMAs of one group, 1.7 k after this change).
+typedef const double __attribute__((address_space(4))) * ctab_t;
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Wold-style-cast"
+__device__ __forceinline__ ctab_t as_ctab(const double* p) { return (ctab_t)p; }
+#pragma clang diagnostic pop
+
+// The constraint vectors are written once and never re-read by these kernels: non-temporal
+// stores keep the 390 MB output stream from evicting the control points from L2 / Infinity
+// Cache (measured: -10 % kernel time on the temporal sweep).
+typedef double d2_t __attribute__((ext_vector_type(2)));
+#ifdef OBTG_X_PLAINSTORE
+__device__ __forceinline__ void store_nt(double* p, double v) { *p = v; }
+__device__ __forceinline__ void store_nt2(double* p, double v0, double v1)
+{
+    d2_t v; v.x = v0; v.y = v1;
+    *reinterpret_cast<d2_t*>(p) = v;
+}
+#else
+__device__ __forceinline__ void store_nt(double* p, double v) { __builtin_nontemporal_store(v, p); }
+__device__ __forceinline__ void store_nt2(double* p, double v0, double v1)
+{
+    d2_t v; v.x = v0; v.y = v1;
+    __builtin_nontemporal_store(v, reinterpret_cast<d2_t*>(p));
+}
+#endif
+
+// =====================================================================================
+//  fast path: register-resident product, one item per lane
+// =====================================================================================
+struct NsParams {
+    const double* __restrict__ Y;     // [B][n_veh*DIM][NC]
+    const double* __restrict__ obs;   // [n_obs][DIM]   (pair mode)
+    const double* __restrict__ tf;    // [B]            (vehicle mode)
+    const int2* __restrict__ pairs;   // [P]            (pair mode)
+    const double* __restrict__ W2;    // folded weights [L][NC]
+    const double* __restrict__ Tt;    // elevation tables (R > 0), three rows back to back:
+                                      //   scale[L]      = C(2n, j)
+                                      //   binp[R+2L-1]  = C(R, m) for m = -(L-1) .. R+L-1 (0 outside 0..R)
+                                      //   inv[L+R]      = 1 / C(2n+R, k)
+    const double* __restrict__ Td;    // dense elevation table, transposed: Td[k][j] = T[j][k], [L+R][L] (R > 0)
+    double* __restrict__ out;
+    int n_veh, n_obj, R;
+    int item_begin, item_count;       // items of this launch (pairs or vehicles)
+    int groups_per_wg, wgs_per_row;
+    int stage_slots;                  // LDS slots reserved for staged objects
+    int stage_all;                    // 1: every object of the row is staged, slot == object id
+    int tile_rows;                    // rows of the per-wave transposition tile (64, 32 or 16)
+    int waves;                        // waves per workgroup
+    int tiling;                       // 1: row-window tiles (large swarms), see k_normsq_elev
+    const int2* __restrict__ tiles;   // [wgs_per_row] (first row, first column) of each tile
+    double sign, offset;              // out = sign * value + offset
+};
+
+constexpr int kTileK = 32;            // k-chunk of the transposition tile when R > 0
+
+template <int NC, int DIM>
+struct NsShape {
+    static constexpr int N = NC - 1;
+    static constexpr int L = 2 * N + 1;
+    static constexpr int VLEN = DIM * NC;
+    static constexpr int VP = (VLEN % 2 == 0) ? VLEN + 1 : VLEN;   // odd pitch (doubles)
+    static constexpr int TPF = (L % 2 == 0) ? L + 1 : L;           // full-tile pitch (R == 0)
+    static constexpr int TPC = kTileK + 1;                          // chunked-tile pitch (R > 0)
+};
+
+// stage objects [lo, lo+cnt) of one evaluation row into LDS slots [slot0, slot0+cnt)
+template <int NC, int DIM>
+__device__ __forceinline__ void stage_objects(double* __restrict__ vl, const double* __restrict__ Yrow,
+                                              const double* __restrict__ obs, int n_veh, int lo,
+                                              int cnt, int slot0, int tid, int nthreads)
+{
+    using S = NsShape<NC, DIM>;
+    const int total = cnt * S::VLEN;
+    for (int e = tid; e < total; e += nthreads) {
+        const int v = e / S::VLEN, r = e - v * S::VLEN;
+        const int obj = lo + v;
+        double val;
+        if (obj < n_veh) val = Yrow[(size_t)obj * S::VLEN + r];
+        else val = obs[(obj - n_veh) * DIM + r / NC];   // constant curve (optimization.py:86-98)
+        vl[(slot0 + v) * S::VP + r] = val;
+    }
+}
+
+// LDS traffic between the lanes of ONE wave only needs wave-level ordering (a wave's DS
+// operations complete in issue order); a workgroup barrier here would also be unsafe because
+// the waves of a workgroup run different numbers of groups.
+__device__ __forceinline__ void wave_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// (d/2) * sum_q a_q^2 as Bernstein coefficients c[0..L)
+template <int NC, int DIM>
+__device__ __forceinline__ void normsq_coeffs(const double (&a)[DIM][NC], ctab_t W2,
+                                              double (&c)[2 * NC - 1])
+{
+    constexpr int N = NC - 1, L = 2 * N + 1;
+#pragma unroll
+    for (int k = 0; k < L; ++k) {
+        double s = 0.0;
+#pragma unroll
+        for (int j = (k - N > 0 ? k - N : 0); 2 * j <= k; ++j) {
+            double xa = a[0][j] * a[0][k - j];
+#pragma unroll
+            for (int q = 1; q < DIM; ++q) xa = fma(a[q][j], a[q][k - j], xa);
+            s = fma(W2[k * NC + j], xa, s);
+        }
+        c[k] = s;
+    }
+}
+
+// write a full [n_valid][LR] tile (pitch TP) as one contiguous run of n_valid*LR doubles
+template <int LR, int TP>
+__device__ __forceinline__ void flush_full(const double* __restrict__ tile, double* __restrict__ gout,
+                                           size_t gbase /* element index in out */, int n_valid, int lane)
+{
+    const int total = n_valid * LR;
+    const int shift = (int)(gbase & 1);   // make the 16-byte stores 16-byte aligned
+    const int npairs = (total + shift + 1) >> 1;
+    for (int m = lane; m < npairs; m += kWave) {
+        const int e0 = 2 * m - shift, e1 = e0 + 1;
+        double v0 = 0.0, v1 = 0.0;
+        if (e0 >= 0) { const int pr = e0 / LR, q = e0 - pr * LR; v0 = tile[pr * TP + q]; }
+        if (e1 < total) { const int pr = e1 / LR, q = e1 - pr * LR; v1 = tile[pr * TP + q]; }
+        if (e0 >= 0 && e1 < total) store_nt2(gout + gbase + e0, v0, v1);
+        else if (e0 >= 0) store_nt(gout + gbase + e0, v0);
+        else if (e1 < total) store_nt(gout + gbase + e1, v1);
+    }
+}
+
+// write chunk columns [k0, k0+kc) of n_valid rows; row r lives at gout[grow + r*LR + ...]
+template <int TP>
+__device__ __forceinline__ void flush_chunk(const double* __restrict__ tile, double* __restrict__ gout,
+                                            size_t grow, int LR, int k0, int kc, int n_valid, int lane)
+{
+    const int total = n_valid * kc;
+    if (kc == kTileK) {           // full chunk: power-of-two row length, no integer division
+        static_assert((kTileK & (kTileK - 1)) == 0, "kTileK must be a power of two");
+        for (int e = lane; e < total; e += kWave) {
+            const int pr = e / kTileK, q = e & (kTileK - 1);
+            gout[grow + (size_t)pr * LR + k0 + q] = tile[pr * TP + q];
+        }
+        return;
+    }
+    for (int e = lane; e < total; e += kWave) {
+        const int pr = e / kc, q = e - pr * kc;
+        gout[grow + (size_t)pr * LR + k0 + q] = tile[pr * TP + q];
+    }
+}
+
+// ELEV = false: DEG_ELEV == 0 (the product IS the output); ELEV = true: R > 0.  Separate
+// instantiations so that the R > 0 code (two weight columns in registers) does not cost the
+// R == 0 kernel its occupancy.
+// Temporal separation (optimization.py:311-346, R == 0, d == 2, no point obstacles) of one evaluation
+// row whose vehicles are ALREADY staged point-major in LDS -- (x_c, y_c) pairs with object pitch
+// `vpq`, the layout of the planar GJK sweep -- so that the GJK workgroups of a row can write the
+// row's separation block themselves (gjk_kernels.hip, pair sweep): same differences, weights and
+// output transform as k_normsq_elev<NC, 2, 0, false, false>, hence the same bits.
+// The calling workgroup takes the 64-pair groups g = g_first + (wave + it*n_waves)*g_step, it = 0, 1, ...
+struct TsepXYParams {
+    const int2* __restrict__ pairs;   // [n_pairs] lexicographic (i, j), i < j < n_veh
+    const double* __restrict__ W2;    // folded product weights of (deg, dim = 2)
+    double* __restrict__ out;         // [B][n_pairs][2n+1]; nullptr = no temporal work
+    int n_pairs;
+    double sign, offset;
+};
+
+template <int NC>
+__device__ __forceinline__ void tsep_groups_from_xy(const TsepXYParams& t, const double2* xy, const int vpq,
+                                                    const int b, const int g_first, const int g_step,
+                                                    double* tile_base, const int TR, const int it_lo, const int it_hi)
+{
+    using S = NsShape<NC, 2>;
+    constexpr int L = S::L;
+    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6, n_waves = blockDim.x >> 6;
+    double* tile = tile_base + wave * (TR * S::TPF);
+    const int n_groups = (t.n_pairs + kWave - 1) / kWave;
+    // a wave's it-th group is g_first + (wave + it * n_waves) * g_step; this call does it_lo <= it < it_hi
+    for (int it = it_lo; it < it_hi; ++it) {
+        const int g = g_first + (wave + it * n_waves) * g_step;
+        if (g >= n_groups) break;
+        const int itg = g * kWave;
+        const int n_valid = min(kWave, t.n_pairs - itg);
+        const int item = min(itg + lane, t.n_pairs - 1);      // idle lanes recompute the last item
+        const int2 ij = t.pairs[item];
+        const double2* vi = xy + ij.x * vpq;
+        const double2* vj = xy + ij.y * vpq;
+        double a[2][NC];
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const double2 pi = vi[c], pj = vj[c];
+            a[0][c] = pi.x - pj.x;
+            a[1][c] = pi.y - pj.y;
+        }
+        double cf[L];
+        normsq_coeffs<NC, 2>(a, as_ctab(t.W2), cf);
+        const size_t row = (size_t)b * t.n_pairs + (size_t)itg;
+        for (int r0 = 0; r0 < n_valid; r0 += TR) {
+            if (lane >= r0 && lane < r0 + TR && lane < n_valid) {
+#pragma unroll
+                for (int k = 0; k < L; ++k) tile[(lane - r0) * S::TPF + k] = t.sign * cf[k] + t.offset;
+            }
+            wave_sync();
+            flush_full<L, S::TPF>(tile, t.out, (row + r0) * L, min(TR, n_valid - r0), lane);
+            wave_sync();
+        }
+    }
+}
+
+// (b, w) = evaluation row and workgroup index inside the row; lds = the workgroup's dynamic LDS.
+// A device function so that the pair sweep can run it next to the GJK workgroups in ONE launch
+// (gjk_kernels.hip k_pair_sweep); k_normsq_elev below is the stand-alone kernel.
+template <int NC, int DIM, int MODE /*0 = pairs, 1 = vehicles*/, bool MINONLY, bool ELEV>
+__device__ __forceinline__ void normsq_elev_body(const NsParams& p, const int b, const int w, double* lds)
+{
+    using S = NsShape<NC, DIM>;
+    constexpr int N = S::N, L = S::L;
+    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6, n_waves = blockDim.x >> 6;
+    const int chunk = kWave * p.groups_per_wg;
+    const int it0 = p.item_begin + w * chunk;
+    const int it_end = min(p.item_begin + p.item_count, it0 + chunk);
+    if (!p.tiling && it0 >= it_end) return;
+
+    // LDS: [staged objects: stage_slots * VP][per-wave transposition tiles]
+    double* vl = lds;
+    double* tile = lds + p.stage_slots * S::VP + wave * (p.tile_rows * S::TPF);
+
+    // ---- stage the objects this workgroup touches
+    const double* Yrow = p.Y + (size_t)b * p.n_veh * S::VLEN;
+    // three staging schemes:
+    //   stage_all  (small swarms): every object of the row, slot == object id;
+    //   tiling     (large swarms): the workgroup owns rows ti0..ti0+n_waves-1 of the pair
+    //              triangle restricted to the 64-wide column window [tj0, tj0+64): it stages
+    //              n_waves + 64 objects, each wave handles one row segment (contiguous pairs);
+    //   otherwise: a chunk of lexicographic pairs touches rows i0..i0+nI-1 (segment I), the
+    //              j-range of its first row (segment A) and of the later rows (segment B).
+    int i0 = 0, nI = 0, a_lo = 0, nA = 0, b_lo = 0, ti0 = 0, tj0 = 0;
+    if (p.stage_all) {
+        stage_objects<NC, DIM>(vl, Yrow, p.obs, p.n_veh, 0, p.n_obj, 0, threadIdx.x, blockDim.x);
+    } else if (MODE == 0 && p.tiling) {
+        const int2 t = p.tiles[w];
+        ti0 = t.x; tj0 = t.y;
+        stage_objects<NC, DIM>(vl, Yrow, p.obs, p.n_veh, ti0, min(n_waves, p.n_obj - ti0), 0, threadIdx.x, blockDim.x);
+        stage_objects<NC, DIM>(vl, Yrow, p.obs, p.n_veh, tj0, min(kWave, p.n_obj - tj0), n_waves, threadIdx.x, blockDim.x);
+    } else if (MODE == 0) {
+        const int2 f = p.pairs[it0], l = p.pairs[it_end - 1];
+        i0 = f.x; nI = l.x - f.x + 1;
+        a_lo = f.y;
+        nA = (nI == 1) ? (l.y - f.y + 1) : (p.n_obj - f.y);
+        b_lo = i0 + 2;
+        const int nB = (nI == 1) ? 0 : max(0, ((nI >= 3) ? p.n_obj - 1 : l.y) - b_lo + 1);
+        stage_objects<NC, DIM>(vl, Yrow, p.obs, p.n_veh, i0, nI, 0, threadIdx.x, blockDim.x);
+        stage_objects<NC, DIM>(vl, Yrow, p.obs, p.n_veh, a_lo, nA, nI, threadIdx.x, blockDim.x);
+        stage_objects<NC, DIM>(vl, Yrow, p.obs, p.n_veh, b_lo, nB, nI + nA, threadIdx.x, blockDim.x);
+    } else {
+        i0 = it0; nI = it_end - it0;
+        stage_objects<NC, DIM>(vl, Yrow, p.obs, p.n_veh, i0, nI, 0, threadIdx.x, blockDim.x);
+    }
+    __syncthreads();
+
+    const int LR = L + p.R;
+    const int TR = p.tile_rows;
+    for (int g = wave; g < p.groups_per_wg; g += n_waves) {
+        // this wave's group: valid lanes are [lane0, lane0 + n_valid), lane r0 + lane0 owns output
+        // row `row + r0`; si/sj are the LDS slots of the lane's two curves
+        int n_valid, lane0 = 0, si = 0, sj = 0, item = 0;
+        size_t row;
+        if (MODE == 0 && p.tiling) {
+            const int i = ti0 + wave;
+            if (g != wave || i >= p.n_obj - 1) break;
+            const int j = tj0 + lane;
+            const long tri = (long)i * p.n_obj - (long)i * (i + 1) / 2 - i - 1;   // p(i,j) = tri + j
+            const long pidx = tri + j;
+            const bool valid = j > i && j < p.n_obj && pidx >= p.item_begin &&
+                               pidx < (long)p.item_begin + p.item_count;
+            const unsigned long long m = __ballot(valid);
+            if (m == 0ull) break;
+            lane0 = __ffsll((long long)m) - 1;
+            n_valid = __popcll(m);
+            si = wave;
+            sj = n_waves + (min(j, p.n_obj - 1) - tj0);
+            row = (size_t)b * p.item_count + (size_t)(tri + tj0 + lane0 - p.item_begin);
+        } else {
+            const int itg = it0 + g * kWave;
+            if (itg >= it_end) break;
+            n_valid = min(kWave, it_end - itg);
+            item = min(itg + lane, it_end - 1);   // idle lanes recompute the last item
+            row = (size_t)b * p.item_count + (size_t)(itg - p.item_begin);
+            if (MODE == 0) {
+                const int2 ij = p.pairs[item];
+                if (p.stage_all) { si = ij.x; sj = ij.y; }
+                else { si = ij.x - i0; sj = (ij.x == i0) ? nI + (ij.y - a_lo) : nI + nA + (ij.y - b_lo); }
+            } else si = p.stage_all ? item : item - i0;
+        }
+        const int r = lane - lane0;                     // this lane's row inside the group
+        const bool mine = r >= 0 && r < n_valid;
+
+        // ---- source curve a[q][c]
+        double a[DIM][NC];
+        if (MODE == 0) {
+            const double* vi = vl + si * S::VP;
+            const double* vj = vl + sj * S::VP;
+#pragma unroll
+            for (int q = 0; q < DIM; ++q)
+#pragma unroll
+                for (int c = 0; c < NC; ++c) a[q][c] = vi[q * NC + c] - vj[q * NC + c];
+        } else {
+            // Bezier.diff(): (n/T)(P_{i+1}-P_i), then elev(1) back to degree n (bezier.py:497-519)
+            const double* v = vl + si * S::VP;
+            const double val = (double)N / p.tf[b];
+#pragma unroll
+            for (int q = 0; q < DIM; ++q) {
+                double t[NC];
+#pragma unroll
+                for (int c = 0; c < N; ++c) t[c] = v[q * NC + c] * (-val) + v[q * NC + c + 1] * val;
+                a[q][0] = t[0];
+                a[q][N] = t[N - 1];
+#pragma unroll
+                for (int c = 1; c < N; ++c)
+                    a[q][c] = t[c - 1] * ((double)c / (double)N) + t[c] * ((double)(N - c) / (double)N);
+            }
+        }
+
+        double cf[L];
+        normsq_coeffs<NC, DIM>(a, as_ctab(p.W2), cf);
+
+        if (!ELEV) {
+            // elevMatrix(2n, 0) is the identity (bezier.py:1141-1147): the product IS the output
+            if (MINONLY) {
+                double m = cf[0];
+#pragma unroll
+                for (int k = 1; k < L; ++k) m = fmin(m, cf[k]);
+                if (mine) p.out[row + r] = p.sign * m + p.offset;
+            } else {
+                // transpose TR rows at a time through the wave's tile
+                for (int r0 = 0; r0 < n_valid; r0 += TR) {
+                    if (mine && r >= r0 && r < r0 + TR) {
+#pragma unroll
+                        for (int k = 0; k < L; ++k) tile[(r - r0) * S::TPF + k] = p.sign * cf[k] + p.offset;
+                    }
+                    wave_sync();
+                    flush_full<L, S::TPF>(tile, p.out, (row + r0) * L, min(TR, n_valid - r0), lane);
+                    wave_sync();
+                }
+            }
+        } else {
+            if (MINONLY) {
+                // elev(R) as a binomially scaled convolution (bezier.py:1127-1147 written out):
+                //   out_k = (1/C(2n+R,k)) * sum_j [C(2n,j) c_j] * C(R, k-j)
+                // only the minimum over k leaves the lane
+                const ctab_t escale = as_ctab(p.Tt), ebin = escale + L, einv = ebin + (p.R + 2 * L - 1);
+                double ch[L];
+#pragma unroll
+                for (int j = 0; j < L; ++j) ch[j] = cf[j] * escale[j];
+                double m = INFINITY;
+                for (int k = 0; k < LR; ++k) {
+                    const ctab_t win = ebin + k;              // win[L-1-j] = C(R, k-j)
+                    double s = 0.0;
+#pragma unroll
+                    for (int j = 0; j < L; ++j) s = fma(ch[j], win[L - 1 - j], s);
+                    m = fmin(m, s * einv[k]);
+                }
+                if (mine) p.out[row + r] = p.sign * m + p.offset;
+            } else {
+                // Full elevated rows: switch the lane <-> data mapping.  The 2n+1 product coefficients
+                // of the wave's pairs go to the LDS tile; then lane = output column k keeps its column
+                // of the elevation matrix (2n+1 weights) in registers and walks the pairs, reading each
+                // pair's coefficients as LDS broadcasts.  Every store instruction writes 64 consecutive
+                // doubles of one output row: no transposition, no partial rows.  Two columns per lane
+                // (k, k+64) share the broadcasts.
+                if (mine) {
+#pragma unroll
+                    for (int k = 0; k < L; ++k) tile[r * S::TPF + k] = cf[k];
+                }
+                wave_sync();
+                for (int kb = 0; kb < LR; kb += 2 * kWave) {
+                    const int k1 = kb + lane, k2 = kb + kWave + lane;
+                    double w1[L], w2[L];
+#pragma unroll
+                    for (int j = 0; j < L; ++j) {
+                        w1[j] = k1 < LR ? p.Td[(size_t)k1 * L + j] : 0.0;
+                        w2[j] = k2 < LR ? p.Td[(size_t)k2 * L + j] : 0.0;
+                    }
+                    for (int pr = 0; pr < n_valid; ++pr) {
+                        const double* cr = tile + pr * S::TPF;
+                        double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+                        for (int j = 0; j < L; ++j) {
+                            const double cj = cr[j];
+                            s1 = fma(cj, w1[j], s1);
+                            s2 = fma(cj, w2[j], s2);
+                        }
+                        double* orow = p.out + (row + pr) * LR;
+                        if (k1 < LR) store_nt(orow + k1, p.sign * s1 + p.offset);
+                        if (k2 < LR) store_nt(orow + k2, p.sign * s2 + p.offset);
+                    }
+                }
+                wave_sync();
+            }
+        }
+    }
+}
+
+}  // namespace obtg

@@ -184,7 +184,7 @@ const char* obtg_abi_symbols(void)
         "obtg_temporal_sep_fd\0obtg_temporal_sep_fd_dev\0"
         "obtg_temporal_sep_dev\0obtg_temporal_sep_min_dev\0obtg_speed_dev\0obtg_ang_rate_dev\0obtg_dynamics_dev\0"
         "obtg_fd_batch_dev\0obtg_gjk_pairs\0obtg_ctx_set_polygons\0obtg_ctx_set_hull_pairs\0"
-        "obtg_ctx_set_fd_dedup\0obtg_ctx_set_gjk_history\0obtg_gjk_swarm_dev\0obtg_gjk_swarm\0obtg_min_dist\0obtg_min_dist2poly\0"
+        "obtg_ctx_set_fd_dedup\0obtg_ctx_set_gjk_history\0obtg_pair_sweep_dev\0obtg_gjk_swarm_dev\0obtg_gjk_swarm\0obtg_min_dist\0obtg_min_dist2poly\0"
         "obtg_bern_elev\0obtg_bern_diff\0obtg_bern_mul\0obtg_bern_normsq\0"
         "obtg_euclidean_obj\0obtg_accel_obj\0obtg_jerk_obj\0"
         "obtg_set_profiling\0obtg_set_profile_period\0obtg_kernel_stats\0obtg_reset_kernel_stats\0obtg_kernel_name\0";
@@ -578,6 +578,17 @@ int obtg_ctx_set_fd_dedup(obtg_ctx* c, int on)
     return OBTG_OK;
 }
 
+int obtg_pair_sweep_dev(obtg_ctx* c, const double* dY, int B, double max_sep, double* d_out_sep, int max_iter,
+                        int md_cap, int* d_flag, double* d_p1, double* d_p2, double* d_dist, int* d_nsup,
+                        int* d_status)
+{
+    if (!check_ctx(c) || !dY || !d_out_sep || !d_flag || !d_p1 || !d_p2 || !d_dist || B < 0 || max_iter < 1 ||
+        md_cap < 1) return OBTG_ERR_ARG;
+    (void)hipSetDevice(c->device);
+    return launch_pair_sweep(c, dY, B, max_sep, d_out_sep, max_iter, md_cap, d_flag, d_p1, d_p2, d_dist, d_nsup,
+                             d_status);
+}
+
 int obtg_ctx_set_gjk_history(obtg_ctx* c, int on)
 {
     if (!check_ctx(c)) return OBTG_ERR_ARG;
@@ -829,6 +840,7 @@ const char* obtg_kernel_name(int id)
         case OBTG_K_MIN_DIST: return "min_dist";
         case OBTG_K_FD_BATCH: return "fd_batch";
         case OBTG_K_BERN: return "bern";
+        case OBTG_K_PAIR_SWEEP: return "pair_sweep";
         default: return "?";
     }
 }

@@ -18,6 +18,15 @@
 
 #include "gjk_device.h"
 #include "obtg_internal.h"
+// the Bernstein sweep body that k_pair_sweep runs beside the GJK workgroups: same contraction
+// setting as in bern_kernels.hip, so that both units produce the same arithmetic
+#pragma clang fp contract(fast)
+#include "bern_device.h"
+#pragma clang fp contract(off)
+
+#ifndef OBTG_X_CHUNK
+#define OBTG_X_CHUNK 864     // hull pairs per workgroup of the planar sweep (see launch_gjk_swarm)
+#endif
 
 namespace obtg {
 
@@ -245,6 +254,8 @@ struct GjkSwarmParams {
     const unsigned char* len_in;       // nullable, [.][n_pairs] support-scan counts of the previous sweep
     int len_in_stride;                 // n_pairs (same batch shape as last time) or 0 (every row reads row 0)
     unsigned char* len_out;            // nullable, [B][n_pairs]
+    TsepXYParams ts;                   // pair sweep: the row's temporal-separation block (ts.out != nullptr)
+    int ts_tile_rows;
     int* __restrict__ flag;
     double* __restrict__ p1;
     double* __restrict__ p2;
@@ -387,22 +398,24 @@ __host__ __device__ constexpr size_t planar_lds_bytes(int cap_obj, int vpq, int 
 #ifndef OBTG_X_SWEEP_WAVES
 #define OBTG_X_SWEEP_WAVES 5
 #endif
+// (b_in, w_in): row / workgroup-in-row when the caller has already decoded them (>= 0: the one-launch
+// pair sweep), else decoded from blockIdx here.
 template <int NC, int MODE>
-__global__ __launch_bounds__(MODE == 0 ? OBTG_SWEEP_THREADS : 256, (MODE == 0 && NC <= 11) ? OBTG_X_SWEEP_WAVES : 1)
-void k_gjk_swarm_planar(const GjkSwarmParams p)
+__device__ __forceinline__ void gjk_planar_body(const GjkSwarmParams& p, double2* xy, const int b_in, const int w_in)
 {
     constexpr bool SWEEP = MODE == 0, FIXUP = MODE == 1, TILED = MODE == 2;
     using gjk::V2;
     using gjk::Vert2;
     using gjk::Simplex2;
     constexpr int VPQ = PlanarShape<NC>::VPQ;
-    extern __shared__ double2 xy[];                                // [cap_obj][VPQ] points
-    double* lds = reinterpret_cast<double*>(xy);
+    double* lds = reinterpret_cast<double*>(xy);                   // xy: [cap_obj][VPQ] points
     __shared__ int s_next;
     __shared__ int s_nlist;
     __shared__ int s_hist[256];
     int b, w;
-    if (SWEEP) {
+    if (b_in >= 0) {
+        b = b_in; w = w_in;
+    } else if (SWEEP) {
         const int per = 8 * p.wgs_per_row;
         const int grp = (int)blockIdx.x / per, g = (int)blockIdx.x - grp * per;
         b = grp * 8 + (g & 7);
@@ -459,6 +472,19 @@ void k_gjk_swarm_planar(const GjkSwarmParams p)
         }
     }
     __syncthreads();
+
+    // ---- pair sweep: this workgroup's share of the row's temporal-separation block, from the objects
+    // just staged.  Its stores are not waited for: they drain while the lanes run gjkNew below (the
+    // Bernstein block is HBM-write bound, gjkNew VALU bound).  The transposition tile borrows the
+    // LDS that phase 1 uses afterwards.
+    // Workgroups differ in how much of their share they write before computing (0..3 groups per wave,
+    // the rest afterwards), so that every CU has both kinds of work at all times.
+    const int ts_before = (b + w) & 3;      // groups per wave written before the gjkNew phases (0..3), the rest after
+    if (SWEEP && p.ts.out != nullptr && ts_before > 0) {
+        tsep_groups_from_xy<NC>(p.ts, xy, VPQ, b, w, p.wgs_per_row, reinterpret_cast<double*>(r01), p.ts_tile_rows,
+                                0, ts_before);
+        __syncthreads();
+    }
 
     // ---- the first two doSimplex steps of every pair use the fixed directions (1,0,0) and
     // (-1,-0,-0) (gjk.py:247, 544): their support scans depend on one object only, so they are
@@ -725,8 +751,20 @@ void k_gjk_swarm_planar(const GjkSwarmParams p)
     }
     if (FIXUP) __syncthreads();                          // rec / list are reused by the next segment
     }
+    if (SWEEP && p.ts.out != nullptr) {
+        __syncthreads();                                     // phase 2 has read the records the tile overwrites
+        tsep_groups_from_xy<NC>(p.ts, xy, VPQ, b, w, p.wgs_per_row, reinterpret_cast<double*>(r01), p.ts_tile_rows,
+                                ts_before, 1 << 30);
+    }
 }
 
+template <int NC, int MODE>
+__global__ __launch_bounds__(MODE == 0 ? OBTG_SWEEP_THREADS : 256, (MODE == 0 && NC <= 11) ? OBTG_X_SWEEP_WAVES : 1)
+void k_gjk_swarm_planar(const GjkSwarmParams p)
+{
+    extern __shared__ double2 xy_dyn[];
+    gjk_planar_body<NC, MODE>(p, xy_dyn, -1, -1);
+}
 
 // which vehicles of row b differ (bitwise) from row 0: chg[b][v]
 __global__ void k_changed_objects(const double* __restrict__ Y, int B, int n_veh, int vlen, unsigned char* __restrict__ chg)
@@ -1155,9 +1193,6 @@ int launch_gjk_swarm(obtg_ctx* c, const double* dY, int B, int max_iter, int md_
     // pairs per lane (measured at C3 in list order: 316 pairs per 256 lanes = 0.281 ms, 1264 pairs =
     // 0.215 ms); with the history order 864-pair chunks do as well as 1264 and leave LDS for a fifth
     // workgroup per CU.  Small batches trade chunk size for enough workgroups to fill the chip.
-#ifndef OBTG_X_CHUNK
-#define OBTG_X_CHUNK 864
-#endif
     int wgs = (c->n_hull_pairs + OBTG_X_CHUNK - 1) / OBTG_X_CHUNK;
 #ifdef OBTG_X_WG512
     wgs = (c->n_hull_pairs + 2559) / 2560;
@@ -1278,6 +1313,74 @@ int launch_gjk_swarm(obtg_ctx* c, const double* dY, int B, int max_iter, int md_
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     ScopedKernelTimer t(c, OBTG_K_GJK);
     hipLaunchKernelGGL(kern, dim3((unsigned)((size_t)B * p.wgs_per_row)), dim3(256), lds, c->stream, p);
+    OBTG_HIP(c, hipGetLastError());
+    return OBTG_OK;
+}
+
+// The pair sweeps of a batch as one launch: the planar GJK sweep whose workgroups also write their
+// row's temporal-separation block (GjkSwarmParams::ts).  Shapes outside that kernel: two launches.
+int launch_pair_sweep(obtg_ctx* c, const double* dY, int B, double max_sep, double* d_out_sep, int max_iter,
+                      int md_cap, int* d_flag, double* d_p1, double* d_p2, double* d_dist, int* d_nsup, int* d_status)
+{
+    if (B <= 0) return OBTG_OK;
+    const int nc = c->deg + 1;
+    void (*kern)(const GjkSwarmParams) = nullptr;
+    switch (nc) {
+        case 4: kern = k_gjk_swarm_planar<4, 0>; break;
+        case 6: kern = k_gjk_swarm_planar<6, 0>; break;
+        case 8: kern = k_gjk_swarm_planar<8, 0>; break;
+        case 11: kern = k_gjk_swarm_planar<11, 0>; break;
+        case 16: kern = k_gjk_swarm_planar<16, 0>; break;
+        default: break;
+    }
+    bool fused = kern && c->dim == 2 && c->polys_planar && c->max_poly_K <= nc && c->n_hull_pairs > 0 &&
+                 !c->fd_dedup && c->R == 0 && c->n_obs == 0 && c->n_pairs > 0;
+    GjkSwarmParams p{};
+    size_t lds = 0;
+    if (fused) {
+        int rc = ensure_tables(c);
+        if (rc) return rc;
+        p.Y = dY; p.poly = c->d_poly_pts.as<double>(); p.poly_off = c->d_poly_off.as<int>();
+        p.pa = c->d_hp_a.as<int>(); p.pb = c->d_hp_b.as<int>();
+        p.n_veh = c->n_veh; p.dim = c->dim; p.nc = nc; p.n_poly = c->n_poly;
+        p.n_poly_pts = c->n_poly_pts; p.n_pairs = c->n_hull_pairs;
+        int wgs = (c->n_hull_pairs + OBTG_X_CHUNK - 1) / OBTG_X_CHUNK;
+        while ((long)B * wgs < 2048 && (c->n_hull_pairs + wgs - 1) / wgs > 256) wgs <<= 1;
+        p.chunk = (c->n_hull_pairs + wgs - 1) / wgs;
+        p.wgs_per_row = (c->n_hull_pairs + p.chunk - 1) / p.chunk;
+        p.max_iter = max_iter; p.md_cap = md_cap;
+        p.flag = d_flag; p.p1 = d_p1; p.p2 = d_p2; p.dist = d_dist; p.nsup = d_nsup; p.status = d_status;
+        const int n_obj = c->n_veh + c->n_poly, vpq = nc | 1;
+        lds = planar_lds_bytes<0>(n_obj, vpq, p.chunk);
+        // the transposition tile (4 waves x TR rows x odd(2n+1) doubles) borrows the LDS behind the objects
+        const int L = 2 * c->deg + 1, tpf = (L % 2 == 0) ? L + 1 : L;
+        const size_t behind = lds - (size_t)16 * n_obj * vpq;
+        int tr = 64;
+        while (tr >= 8 && (size_t)4 * tr * tpf * sizeof(double) > behind) tr >>= 1;
+        fused = tr >= 8 && lds <= 48 * 1024;
+        p.ts.pairs = c->d_pairs.as<int2>(); p.ts.W2 = c->d_w2.as<double>(); p.ts.out = d_out_sep;
+        p.ts.n_pairs = c->n_pairs; p.ts.sign = 1.0; p.ts.offset = -(max_sep * max_sep);
+        p.ts_tile_rows = tr;
+    }
+    if (!fused) {
+        int rc = launch_temporal_sep(c, dY, B, max_sep, 0, c->n_pairs, false, d_out_sep);
+        if (rc) return rc;
+        return launch_gjk_swarm(c, dY, B, max_iter, md_cap, d_flag, d_p1, d_p2, d_dist, d_nsup, d_status);
+    }
+    const size_t np = (size_t)c->n_hull_pairs;
+    obtg::DevBuf& hist_out = c->d_gjk_len[c->gjk_len_cur ^ 1];
+    if (int rc = hist_out.reserve((size_t)B * np)) return rc;
+    p.B = B;
+    p.len_in = (c->gjk_history && c->gjk_len_rows > 0) ? c->d_gjk_len[c->gjk_len_cur].as<unsigned char>() : nullptr;
+    p.len_in_stride = c->gjk_len_rows == B ? (int)np : 0;
+    p.len_out = c->gjk_history ? hist_out.as<unsigned char>() : nullptr;
+    const unsigned grid = (unsigned)(((size_t)B + 7) / 8 * 8 * p.wgs_per_row);
+    {
+        ScopedKernelTimer tm(c, OBTG_K_PAIR_SWEEP);
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(OBTG_SWEEP_THREADS), lds, c->stream, p);
+    }
+    c->gjk_len_cur ^= 1;
+    c->gjk_len_rows = B;
     OBTG_HIP(c, hipGetLastError());
     return OBTG_OK;
 }

@@ -114,6 +114,11 @@ int binrow_offset(obtg_ctx* c, int n);  // ensures row C(n,.) is resident; retur
 // ---------------------------------------------------------------- launchers (bern_kernels.hip)
 int launch_temporal_sep(obtg_ctx* c, const double* dY, int B, double max_sep, int pair_begin,
                         int pair_count, bool min_only, double* d_out);
+struct NsParams;
+int plan_temporal_sep(obtg_ctx* c, const double* dY, int B, int pair_begin, int pair_count, double* d_out, NsParams& p);
+size_t temporal_sep_lds_bytes(const obtg_ctx* c, NsParams& p, size_t budget);
+int launch_pair_sweep(obtg_ctx* c, const double* dY, int B, double max_sep, double* d_out_sep, int max_iter,
+                      int md_cap, int* d_flag, double* d_p1, double* d_p2, double* d_dist, int* d_nsup, int* d_status);
 int launch_temporal_sep_fd(obtg_ctx* c, const double* dY0, int n_pert, const int* d_prow, const int* d_pcol,
                            const double* d_pval, double max_sep, double* d_out);
 int launch_speed(obtg_ctx* c, const double* dY, const double* d_tf, int B, double bound, int is_max,

@@ -620,3 +620,51 @@ def test_gjk_swarm_history_order_does_not_change_results(capi, oracle, synth):
     assert (cold["flag"][7] == o["flag"]).all() and (cold["n_support"][7] == o["n_support"]).all()
     assert len(np.unique(cold["n_support"][7])) > 3     # the ordering had something to sort
     ctx.close()
+
+
+@pytest.mark.parametrize("shape", ["C3", "small_deg7", "fallback_3d"])
+def test_pair_sweep_one_launch_equals_separate_kernels(capi, synth, shape):
+    """obtg_pair_sweep_dev (temporal separation + gjkNew sweep as ONE grid) returns what the two
+    separate entry points return, bit for bit; shapes without the fused instantiation fall back."""
+    import torch
+    if shape == "C3":
+        N, d, n, M, B = 64, 2, 10, 8, 37
+    elif shape == "small_deg7":
+        N, d, n, M, B = 9, 2, 7, 3, 21
+    else:
+        N, d, n, M, B = 6, 3, 5, 0, 5
+    Y = synth.swarm_control_points(N, d, n, seed=21)
+    Yb = synth.fd_batch(Y, B=B, h=0.01)
+    Yb[B // 2] += np.random.default_rng(4).normal(0, 2.0, size=Y.shape)
+    pa, pb = synth.swarm_pairs(N, M)
+    ctx = capi.Context(N, d, n, 0)
+    if M:
+        ctx.set_polygons(*synth.pack_polys(synth.polygon_obstacles(M, seed=8)))
+    ctx.set_hull_pairs(pa, pb)
+    dev = torch.device("cuda")
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    dY = torch.from_numpy(Yb).to(dev)
+    P, L, Ps = ctx.num_pairs, 2 * n + 1, len(pa)
+
+    def bufs():
+        return dict(sep=torch.full((B, P * L), np.nan, dtype=torch.float64, device=dev),
+                    flag=torch.full((B, Ps), -7, dtype=torch.int32, device=dev),
+                    p1=torch.full((B, Ps, 3), -1.0, dtype=torch.float64, device=dev),
+                    p2=torch.full((B, Ps, 3), -1.0, dtype=torch.float64, device=dev),
+                    dist=torch.full((B, Ps), -1.0, dtype=torch.float64, device=dev),
+                    nsup=torch.zeros((B, Ps), dtype=torch.int32, device=dev),
+                    status=torch.full((B, Ps), -7, dtype=torch.int32, device=dev))
+    a, b = bufs(), bufs()
+    for _ in range(2):          # second round: with trip-count history
+        ctx.temporal_sep_dev(dY.data_ptr(), B, 0.9, a["sep"].data_ptr())
+        ctx.gjk_swarm_dev(dY.data_ptr(), B, a["flag"].data_ptr(), a["p1"].data_ptr(), a["p2"].data_ptr(),
+                          a["dist"].data_ptr(), a["nsup"].data_ptr(), a["status"].data_ptr(), 128, 500)
+        ctx.pair_sweep_dev(dY.data_ptr(), B, 0.9, b["sep"].data_ptr(), b["flag"].data_ptr(), b["p1"].data_ptr(),
+                           b["p2"].data_ptr(), b["dist"].data_ptr(), b["nsup"].data_ptr(), b["status"].data_ptr(),
+                           128, 500)
+        torch.cuda.synchronize()
+        for k in a:
+            assert np.array_equal(a[k].cpu().numpy(), b[k].cpu().numpy(), equal_nan=True), k
+    assert not torch.isnan(b["sep"]).any() and (b["flag"] != -7).all()
+    ctx.set_stream(0)
+    ctx.close()
