@@ -766,6 +766,16 @@ void k_gjk_swarm_planar(const GjkSwarmParams p)
     gjk_planar_body<NC, MODE>(p, xy_dyn, -1, -1);
 }
 
+// the same grid when it also writes the temporal-separation blocks (p.ts.out set): own symbol, so that
+// profiles tell the pair sweep from the plain GJK sweep
+template <int NC>
+__global__ __launch_bounds__(OBTG_SWEEP_THREADS, NC <= 11 ? OBTG_X_SWEEP_WAVES : 1)
+void k_pair_sweep(const GjkSwarmParams p)
+{
+    extern __shared__ double2 xy_dyn[];
+    gjk_planar_body<NC, 0>(p, xy_dyn, -1, -1);
+}
+
 // which vehicles of row b differ (bitwise) from row 0: chg[b][v]
 __global__ void k_changed_objects(const double* __restrict__ Y, int B, int n_veh, int vlen, unsigned char* __restrict__ chg)
 {
@@ -1326,11 +1336,11 @@ int launch_pair_sweep(obtg_ctx* c, const double* dY, int B, double max_sep, doub
     const int nc = c->deg + 1;
     void (*kern)(const GjkSwarmParams) = nullptr;
     switch (nc) {
-        case 4: kern = k_gjk_swarm_planar<4, 0>; break;
-        case 6: kern = k_gjk_swarm_planar<6, 0>; break;
-        case 8: kern = k_gjk_swarm_planar<8, 0>; break;
-        case 11: kern = k_gjk_swarm_planar<11, 0>; break;
-        case 16: kern = k_gjk_swarm_planar<16, 0>; break;
+        case 4: kern = k_pair_sweep<4>; break;
+        case 6: kern = k_pair_sweep<6>; break;
+        case 8: kern = k_pair_sweep<8>; break;
+        case 11: kern = k_pair_sweep<11>; break;
+        case 16: kern = k_pair_sweep<16>; break;
         default: break;
     }
     bool fused = kern && c->dim == 2 && c->polys_planar && c->max_poly_K <= nc && c->n_hull_pairs > 0 &&
