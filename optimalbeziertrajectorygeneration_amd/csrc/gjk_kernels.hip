@@ -742,8 +742,12 @@ __device__ __forceinline__ void gjk_planar_body(const GjkSwarmParams& p, double2
         }
         const size_t o = obase + kk;
         p.flag[o] = flag;
-        p.p1[3 * o] = r.c1.x; p.p1[3 * o + 1] = r.c1.y; p.p1[3 * o + 2] = r.c1.z;
-        p.p2[3 * o] = r.c2.x; p.p2[3 * o + 1] = r.c2.y; p.p2[3 * o + 2] = r.c2.z;
+        // 24-byte records: one 16-byte (8-byte aligned) and one 8-byte store each
+        typedef double d2u_t __attribute__((ext_vector_type(2), aligned(8)));
+        d2u_t xy1, xy2;
+        xy1.x = r.c1.x; xy1.y = r.c1.y; xy2.x = r.c2.x; xy2.y = r.c2.y;
+        *reinterpret_cast<d2u_t*>(p.p1 + 3 * o) = xy1; p.p1[3 * o + 2] = r.c1.z;
+        *reinterpret_cast<d2u_t*>(p.p2 + 3 * o) = xy2; p.p2[3 * o + 2] = r.c2.z;
         p.dist[o] = r.dist;
         if (p.nsup) p.nsup[o] = n_scans;
         if (p.status) p.status[o] = status;

@@ -1,4 +1,4 @@
-"""Do the HBM-bound Bernstein kernels and the VALU-bound GJK sweep overlap when issued on two streams?"""
+"""Does the dynamics launch overlap with the pair sweep when issued on a second stream?"""
 import sys, time, numpy as np, torch
 sys.path.insert(0,'.')
 from optimalbeziertrajectorygeneration_amd import _capi, synth
@@ -16,14 +16,13 @@ d_tf=torch.full((B,),10.0,dtype=f64,device=dev)
 P=cA.num_pairs; L=21; Ps=len(pa)
 o_sep=torch.empty((B,P*L),dtype=f64,device=dev); o_sp=torch.empty((B,N*L),dtype=f64,device=dev); o_an=torch.empty((B,N*41),dtype=f64,device=dev)
 g_flag=torch.empty((B,Ps),dtype=torch.int32,device=dev); g_p1=torch.empty((B,Ps,3),dtype=f64,device=dev); g_p2=torch.empty((B,Ps,3),dtype=f64,device=dev); g_dist=torch.empty((B,Ps),dtype=f64,device=dev)
-def gjk(c): c.gjk_swarm_dev(dY.data_ptr(),B,g_flag.data_ptr(),g_p1.data_ptr(),g_p2.data_ptr(),g_dist.data_ptr(),None,None,128,256)
+def gjk(c): c.pair_sweep_dev(dY.data_ptr(),B,0.9,o_sep.data_ptr(),g_flag.data_ptr(),g_p1.data_ptr(),g_p2.data_ptr(),g_dist.data_ptr(),None,None,128,256)
 def bern(c):
-    c.temporal_sep_dev(dY.data_ptr(),B,0.9,o_sep.data_ptr())
     c.dynamics_dev(dY.data_ptr(),d_tf.data_ptr(),B,5.0,True,1.0,o_sp.data_ptr(),o_an.data_ptr())
-def run(two,K=50):
+def run(two,K=300):
     cA.set_stream(s1.cuda_stream); cB.set_stream(s2.cuda_stream if two else s1.cuda_stream)
-    for _ in range(5): gjk(cA); bern(cB)
+    for _ in range(20): bern(cB); gjk(cA)
     torch.cuda.synchronize(); t=time.perf_counter()
-    for _ in range(K): gjk(cA); bern(cB)
+    for _ in range(K): bern(cB); gjk(cA)
     torch.cuda.synchronize(); return (time.perf_counter()-t)/K*1e3
 for m in (False,True,False,True): print('two streams' if m else 'one stream ', '%.4f ms/step'%run(m))
