@@ -382,9 +382,9 @@ __device__ __forceinline__ void support_fixed(const double2* __restrict__ o1, co
 template <int MODE>
 __host__ __device__ constexpr size_t planar_lds_bytes(int cap_obj, int vpq, int chunk)
 {
-    // objects | r01 int2[chunk], plist int[chunk] | ext int[2 cap_obj] | MODE 0, 1: list int[chunk] | r2 u16[chunk] | MODE 0: ord u16[chunk]
+    // objects | r01 int2[chunk], plist int[chunk] | ext int[2 cap_obj] | list / pnat int[chunk] | r2 u16[chunk] | MODE 0, 2: ord u16[chunk]
     return 16 * (size_t)cap_obj * vpq + 12 * (size_t)chunk + 8 * (size_t)cap_obj +
-           (MODE != 2 ? 4 * (size_t)chunk : 0) + 2 * (size_t)chunk + (MODE == 0 ? 2 * (size_t)chunk : 0);
+           4 * (size_t)chunk + 2 * (size_t)chunk + (MODE != 1 ? 2 * (size_t)chunk : 0);
 }
 
 #ifdef OBTG_X_WG512
@@ -440,9 +440,9 @@ __device__ __forceinline__ void gjk_planar_body(const GjkSwarmParams& p, double2
     unsigned* plist = reinterpret_cast<unsigned*>(r01 + p.chunk);   // [chunk] packed slots (a | b << 16) per position
     int* ext = reinterpret_cast<int*>(plist + p.chunk);            // [cap_obj][2]: (first argmax x, first argmin x)
     int* list = ext + 2 * cap_obj;                                  // FIXUP: compacted pair indices of a segment
-    unsigned* pnat = reinterpret_cast<unsigned*>(list);           // MODE 0: packed slots per local index l
-    unsigned short* r2 = reinterpret_cast<unsigned short*>(TILED ? list : list + p.chunk);
-    unsigned short* ord = r2 + p.chunk;                            // MODE 0: position -> local index l
+    unsigned* pnat = reinterpret_cast<unsigned*>(list);           // MODE 0, 2: packed slots per local index l
+    unsigned short* r2 = reinterpret_cast<unsigned short*>(list + p.chunk);
+    unsigned short* ord = r2 + p.chunk;                            // MODE 0, 2: position -> local index l
 
     // ---- stage vehicles (rows x, y of the evaluation row) and padded polygons
     const double* Yrow = p.Y + (size_t)b * p.n_veh * 2 * NC;
@@ -521,13 +521,19 @@ __device__ __forceinline__ void gjk_planar_body(const GjkSwarmParams& p, double2
         if (c1 == 0) continue;                            // uniform: nothing changed in this segment
     }
     // the chunk's (a, b) object ids go to LDS once: the refill path must not wait on global memory
-    if (SWEEP) {
+    if (SWEEP || TILED) {
+        // local index l = position - c0 in list order; pair id (history / output index) and packed slots of l
+        const int n_loc = c1 - c0;
+        auto pair_of = [&](int l) { return SWEEP ? OWN(w, l, 0) : p.order[c0 + l]; };
+        auto slots_of = [&](int l, int kq) {
+            return SWEEP ? ((unsigned)p.pa[kq] | ((unsigned)p.pb[kq] << 16)) : p.pslots[c0 + l];
+        };
         if (p.len_in) {
             // counting sort of this workgroup's pairs by descending scan count of the previous sweep
             const unsigned char* len = p.len_in + (size_t)b * p.len_in_stride;
             if (threadIdx.x < 256) s_hist[threadIdx.x] = 0;
             __syncthreads();
-            for (int l = threadIdx.x; l < c1; l += blockDim.x) atomicAdd(&s_hist[255 - len[OWN(w, l, 0)]], 1);
+            for (int l = threadIdx.x; l < n_loc; l += blockDim.x) atomicAdd(&s_hist[255 - len[pair_of(l)]], 1);
             __syncthreads();
             if (threadIdx.x < kWave) {
                 const int lane = threadIdx.x;
@@ -544,28 +550,24 @@ __device__ __forceinline__ void gjk_planar_body(const GjkSwarmParams& p, double2
                 s_hist[4 * lane + 2] = excl + v0 + v1; s_hist[4 * lane + 3] = excl + v0 + v1 + v2;
             }
             __syncthreads();
-            for (int l = threadIdx.x; l < c1; l += blockDim.x) {
-                const int kq = OWN(w, l, 0);
+            for (int l = threadIdx.x; l < n_loc; l += blockDim.x) {
+                const int kq = pair_of(l);
                 const int pos = atomicAdd(&s_hist[255 - len[kq]], 1);
-                const unsigned ab = (unsigned)p.pa[kq] | ((unsigned)p.pb[kq] << 16);
+                const unsigned ab = slots_of(l, kq);
                 ord[pos] = (unsigned short)l;
                 plist[pos] = ab;
                 pnat[l] = ab;
             }
         } else {
-            for (int l = threadIdx.x; l < c1; l += blockDim.x) {
-                const int kq = OWN(w, l, 0);
+            for (int l = threadIdx.x; l < n_loc; l += blockDim.x) {
                 ord[l] = (unsigned short)l;
-                plist[l] = pnat[l] = (unsigned)p.pa[kq] | ((unsigned)p.pb[kq] << 16);
+                plist[l] = pnat[l] = slots_of(l, pair_of(l));
             }
         }
     } else {
         for (int q = c0 + (int)threadIdx.x; q < c1; q += blockDim.x) {
-            if (TILED) plist[q - c0] = p.pslots[q];
-            else {
-                const int kq = FIXUP ? list[q] : q;
-                plist[q - c0] = (unsigned)p.pa[kq] | ((unsigned)p.pb[kq] << 16);
-            }
+            const int kq = list[q];
+            plist[q - c0] = (unsigned)p.pa[kq] | ((unsigned)p.pb[kq] << 16);
         }
     }
     if (threadIdx.x == 0) s_next = c0;
@@ -595,7 +597,7 @@ __device__ __forceinline__ void gjk_planar_body(const GjkSwarmParams& p, double2
                     const int my = base + __popcll(want & ((1ull << lane) - 1ull));
                     if (my < c1) {
                         k = my;
-                        slot = SWEEP ? (int)ord[k] : k - c0;
+                        slot = (SWEEP || TILED) ? (int)ord[k - c0] : k - c0;
                         const unsigned ab = plist[k - c0];
                         const int a = (int)(ab & 0xffffu), bb = (int)(ab >> 16);
                         o1 = xy + a * VPQ;
@@ -677,7 +679,7 @@ __device__ __forceinline__ void gjk_planar_body(const GjkSwarmParams& p, double2
     const double qnan = __builtin_nan("");
     for (int k = c0 + (int)threadIdx.x; k < c1; k += blockDim.x) {
         const int kk = SWEEP ? OWN(w, k, p.wgs_per_row) : (TILED ? p.order[k] : (FIXUP ? list[k] : k));
-        const unsigned ab2 = SWEEP ? pnat[k] : plist[k - c0];
+        const unsigned ab2 = (SWEEP || TILED) ? pnat[k - c0] : plist[k - c0];
         const int sa = (int)(ab2 & 0xffffu), sb = (int)(ab2 >> 16);
         const int2 rq = r01[k - c0];
         const int rq0 = rq.x, rq1 = rq.y, rq2 = (int)r2[k - c0];
@@ -751,7 +753,7 @@ __device__ __forceinline__ void gjk_planar_body(const GjkSwarmParams& p, double2
         p.dist[o] = r.dist;
         if (p.nsup) p.nsup[o] = n_scans;
         if (p.status) p.status[o] = status;
-        if (SWEEP && p.len_out) p.len_out[o] = (unsigned char)min(n_scans, 255);
+        if ((SWEEP || TILED) && p.len_out) p.len_out[o] = (unsigned char)min(n_scans, 255);
     }
     if (FIXUP) __syncthreads();                          // rec / list are reused by the next segment
     }
@@ -1253,6 +1255,14 @@ int launch_gjk_swarm(obtg_ctx* c, const double* dY, int B, int max_iter, int md_
                 q.chunk = c->tile_max_pairs; q.wgs_per_row = c->tile_n_chunks;
                 const size_t ldst = planar_lds_bytes<2>(q.max_objs, vp2, q.chunk);
                 if (ldst <= 64 * 1024) {
+                    const size_t npairs = (size_t)c->n_hull_pairs;
+                    obtg::DevBuf& hist_out = c->d_gjk_len[c->gjk_len_cur ^ 1];
+                    if (c->gjk_history) { if (int rc2 = hist_out.reserve((size_t)B * npairs)) return rc2; }
+                    q.B = B;
+                    q.len_in = (c->gjk_history && c->gjk_len_rows > 0) ? c->d_gjk_len[c->gjk_len_cur].as<unsigned char>() : nullptr;
+                    q.len_in_stride = c->gjk_len_rows == B ? (int)npairs : 0;
+                    q.len_out = c->gjk_history ? hist_out.as<unsigned char>() : nullptr;
+                    if (c->gjk_history) { c->gjk_len_cur ^= 1; c->gjk_len_rows = B; }
                     if (ldst > 48 * 1024)
                         OBTG_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(kt),
                                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldst));

@@ -541,6 +541,12 @@ def test_gjk_swarm_large_rows_tiled(capi, oracle, synth):
         sep = o["flag"] == 1
         for key in ("dist", "c1", "c2"):
             assert np.max(np.abs(r[key][b][sep] - o[key][sep]) / np.maximum(1.0, np.abs(o[key][sep]))) < 1e-12
+    # second and third call: the chunks are now walked in trip-count order (history of the call before,
+    # row by row, then of row 0 only): nothing may change
+    for Yw in (Yb, Yb[:1]):
+        rw = ctx.gjk_swarm(Yw, md_cap=500)
+        for key in ("flag", "n_support", "status", "dist", "c1", "c2"):
+            assert np.array_equal(rw[key], r[key][:Yw.shape[0]], equal_nan=True), key
     # an arbitrary (shuffled, partial) pair list takes the same path
     rng = np.random.default_rng(0)
     sel = rng.permutation(len(pa))[:5000]
