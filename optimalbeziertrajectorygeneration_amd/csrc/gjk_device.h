@@ -136,6 +136,42 @@ __device__ __forceinline__ void support_pts(Ctx<Mem>& g, const V3& dir, Vert& ou
     g.n_support++;
 }
 
+// supportPts with the scan spread over the wavefront: every lane holds the same direction (the state
+// machine runs redundantly in all 64 lanes, with wave-uniform control flow), lanes 0..K1-1 take the
+// points of poly1 and lanes 32..32+K2-1 those of poly2 (K <= 32), and the two half-waves reduce to
+// "largest value, lowest index among equals" -- which is what the serial scan with its strict '>'
+// from index 0 returns (gjk.py:87-114).  The per-point products are the serial scan's own, so the
+// indices and the Minkowski vertex are identical to support_pts'.
+template <class Mem>
+__device__ __forceinline__ void support_pts_wave(Ctx<Mem>& g, const V3& dir, Vert& out)
+{
+    const int lane = threadIdx.x & 63, half = lane >> 5, li = lane & 31;
+    const Poly& P = half ? g.P2 : g.P1;
+    const V3 d = half ? neg(dir) : dir;
+    const bool have = li < P.K;
+    double v = have ? sdot<Mem, false>(g.mem, P, li, d) : -__builtin_inf();
+    const double v0 = __shfl(v, half << 5);                // value of point 0 of this half
+    if (v != v) v = -__builtin_inf();                      // `cur > maxd` is false for NaN: never selected
+    int idx = have ? li : 0x7fffffff;
+#pragma unroll
+    for (int m = 16; m >= 1; m >>= 1) {
+        const double ov = __shfl_xor(v, m);
+        const int oi = __shfl_xor(idx, m);
+        const bool take = ov > v || (ov == v && oi < idx);
+        v = take ? ov : v;
+        idx = take ? oi : idx;
+    }
+    if (v0 != v0) idx = 0;                                 // maxd starts as NaN: nothing is ever greater
+    const int i1 = __shfl(idx, 0), i2 = __shfl(idx, 32);
+    out.i1 = i1; out.i2 = i2;
+    out.v = sub(point(g.mem, g.P1, i1), point(g.mem, g.P2, i2));
+    if (g.trace && g.n_support < g.trace_cap && lane == 0) {
+        g.trace[2 * g.n_support] = (short)i1;
+        g.trace[2 * g.n_support + 1] = (short)i2;
+    }
+    g.n_support++;
+}
+
 // gjk.py:397-437 weightedOriginToLine
 __device__ __forceinline__ double origin_to_line(const V3& A, const V3& B, double& dist)
 {
@@ -232,11 +268,12 @@ __device__ __forceinline__ bool simplex_update(Simplex& s, V3& dir)
     return true;
 }
 
-template <class Mem, bool PLANAR = false>
+template <class Mem, bool PLANAR = false, bool WAVE = false>
 __device__ __forceinline__ void do_simplex(Ctx<Mem>& g, Simplex& s, V3& dir)
 {
     if (simplex_update(s, dir)) {
-        support_pts<Mem, PLANAR>(g, dir, s.A);
+        if (WAVE) support_pts_wave<Mem>(g, dir, s.A);
+        else support_pts<Mem, PLANAR>(g, dir, s.A);
         s.keys |= kA;
     }
 }
@@ -314,7 +351,8 @@ template <class Mem>
 __device__ __forceinline__ void closest_from_simplex(const Ctx<Mem>& g, const Simplex& s, Result& r);
 
 // gjk.py:230-270 gjkNew + 273-360 minimumDistance
-template <class Mem, bool PLANAR = false>
+// WAVE: one pair per wavefront, see support_pts_wave
+template <class Mem, bool PLANAR = false, bool WAVE = false>
 __device__ __forceinline__ void run(Ctx<Mem>& g, int max_iter, int md_cap, Result& r)
 {
     Simplex s;
@@ -326,7 +364,7 @@ __device__ __forceinline__ void run(Ctx<Mem>& g, int max_iter, int md_cap, Resul
     r.flag = -1; r.status = OBTG_ST_MAXITER;
     r.c1 = V3{ qnan, qnan, qnan }; r.c2 = r.c1; r.dist = qnan;
     for (int it = 0; it < max_iter; ++it) {
-        do_simplex<Mem, PLANAR>(g, s, dir);
+        do_simplex<Mem, PLANAR, WAVE>(g, s, dir);
         if (s.keys & kColl) { r.flag = 0; r.status = OBTG_ST_OK; break; }
         if (dotb(s.A.v, dir) < 0) {
             Simplex old = s;
@@ -335,7 +373,7 @@ __device__ __forceinline__ void run(Ctx<Mem>& g, int max_iter, int md_cap, Resul
             bool conv = false, cycle = false;
             for (int rr = 0; rr < md_cap; ++rr) {
                 old = s;
-                do_simplex<Mem, PLANAR>(g, s, dir);
+                do_simplex<Mem, PLANAR, WAVE>(g, s, dir);
                 if (matches_old(g, old, s.A.v)) { conv = true; break; }
                 if (chk.step(s, dir)) { cycle = true; break; }
             }

@@ -765,7 +765,11 @@ __device__ __forceinline__ void gjk_planar_body(const GjkSwarmParams& p, double2
 }
 
 template <int NC, int MODE>
-__global__ __launch_bounds__(MODE == 0 ? OBTG_SWEEP_THREADS : 256, (MODE == 0 && NC <= 11) ? OBTG_X_SWEEP_WAVES : 1)
+#ifndef OBTG_X_TILED_WAVES
+#define OBTG_X_TILED_WAVES 1
+#endif
+__global__ __launch_bounds__(MODE == 0 ? OBTG_SWEEP_THREADS : 256,
+                             (MODE == 0 && NC <= 11) ? OBTG_X_SWEEP_WAVES : (MODE == 2 ? OBTG_X_TILED_WAVES : 1))
 void k_gjk_swarm_planar(const GjkSwarmParams p)
 {
     extern __shared__ double2 xy_dyn[];
@@ -993,6 +997,214 @@ __global__ __launch_bounds__(64) void k_min_dist(const MdParams p)
     }
     p.res[3 * k] = r0; p.res[3 * k + 1] = r1; p.res[3 * k + 2] = r2;
     if (p.info) { p.info[4 * k] = nodes; p.info[4 * k + 1] = calls; p.info[4 * k + 2] = dmax; p.info[4 * k + 3] = status; }
+}
+
+// -------------------------------------------------------------------------------------
+//  _minDist with one pair per WAVEFRONT.  The recursion of bezier.py:1283-1408 is sequential per pair
+//  (every child is pruned against the alpha its elder siblings returned), so the parallelism inside a
+//  pair is inside a node: the support scans of gjkNew (support_pts_wave), the two closest-point
+//  parameters (one curve per half-wave, one hull point per lane) and the six de Casteljau rows of a
+//  child.  Everything else runs redundantly in all lanes with wave-uniform control flow, on the same
+//  device functions as k_min_dist, so results, node and GJK-call counts are those of the one-lane form.
+//  LDS per pair: current node's curves, the next child's curves, the scalar part of every stack frame;
+//  the curve part of the frames stays in the global stack (written once per child, re-read when the
+//  walk comes back to a node to split its next child).
+// -------------------------------------------------------------------------------------
+// np_sum over q(0..n-1) without materialising the vector (same association as np_sum above)
+template <class F>
+__device__ __forceinline__ double np_sum_f(int n, F q)
+{
+    if (n < 8) {
+        double r = 0.0;
+        for (int i = 0; i < n; ++i) r += q(i);
+        return r;
+    }
+    double r0 = q(0), r1 = q(1), r2 = q(2), r3 = q(3), r4 = q(4), r5 = q(5), r6 = q(6), r7 = q(7);
+    int i;
+    for (i = 8; i < n - (n % 8); i += 8) {
+        r0 += q(i); r1 += q(i + 1); r2 += q(i + 2); r3 += q(i + 3);
+        r4 += q(i + 4); r5 += q(i + 5); r6 += q(i + 6); r7 += q(i + 7);
+    }
+    double res = ((r0 + r1) + (r2 + r3)) + ((r4 + r5) + (r6 + r7));
+    for (; i < n; ++i) res += q(i);
+    return res;
+}
+
+// split_row on LDS rows: `work` (K doubles) is the lane's scratch row, so nothing goes to private memory
+__device__ __forceinline__ void split_row_lds(const double* src, int K, double t, int half, double* dst, double* work)
+{
+    for (int i = 0; i < K; ++i) work[i] = src[i];
+    int idx = 0;
+    for (int sz = K; sz > 1; --sz) {
+        if (half == 0) dst[idx] = work[0]; else dst[K - 1 - idx] = work[sz - 1];
+        idx++;
+        for (int i = 0; i < sz - 1; ++i) work[i] = (1 - t) * work[i] + t * work[i + 1];
+    }
+    if (half == 0) dst[K - 1] = work[0]; else dst[0] = work[0];
+}
+
+__device__ __forceinline__ double hull_param_wave(const double* c, int K, const V3& cl, double* sh_e, double* sh_q, int li)
+{
+    // exact row match first (bezier.py:1320-1333): lowest matching index
+    const bool hit = li < K && c[li] == cl.x && c[K + li] == cl.y && c[2 * K + li] == cl.z;
+    const unsigned long long mall = __ballot(hit);
+    const unsigned m = (threadIdx.x & 32) ? (unsigned)(mall >> 32) : (unsigned)mall;
+    if (m) return (double)(__ffs((int)m) - 1) / (double)(K - 1);
+    if (li < K) {
+        const double dx = cl.x - c[li], dy = cl.y - c[K + li], dz = cl.z - c[2 * K + li];
+        double s = 0.0;
+        s += dx * dx; s += dy * dy; s += dz * dz;
+        sh_e[li] = __builtin_sqrt(s);
+    }
+    wave_sync();
+    if (li < K) {
+        const double ei = sh_e[li];
+        const double s1 = np_sum_f(li, [&](int j) { return ei / sh_e[j]; });
+        const double s2 = np_sum_f(K - li - 1, [&](int j) { return ei / sh_e[li + 1 + j]; });
+        const double W = 1 / (1 + s1 + s2);
+        sh_q[li] = W * (double)li / (double)K;
+    }
+    wave_sync();
+    return np_sum(sh_q, K);
+}
+
+__global__ __launch_bounds__(64) void k_min_dist_wave(const MdParams p)
+{
+    extern __shared__ double md_lds[];
+    const int k = blockIdx.x, lane = threadIdx.x, half = lane >> 5, li = lane & 31;
+    const int K = p.K, FR = 6 * K + F_NSCAL;
+    double* cur = md_lds;                       // [6K] curves of the node being evaluated
+    double* nxt = cur + 6 * K;                  // [6K] curves of the child being built
+    double* sh_e = nxt + 6 * K;                 // [2][kMdMaxK]; with sh_q also the six scratch rows of a split
+    double* sh_q = sh_e + 2 * kMdMaxK;          // [2][kMdMaxK] (+ 2 more rows so that 6 K doubles fit)
+    double* scs = sh_q + 4 * kMdMaxK;           // [max_depth][F_NSCAL] frame scalars
+    double* st = p.stack + (size_t)k * p.max_depth * FR;
+    const double* ca = p.curves + (size_t)p.pa[k] * 3 * K;
+    const double* cb = p.curves + (size_t)p.pb[k] * 3 * K;
+    for (int i = lane; i < 3 * K; i += kWave) {
+        const double a = ca[i], bq = cb[i];
+        st[i] = a; st[3 * K + i] = bq; cur[i] = a; cur[3 * K + i] = bq;
+    }
+    if (lane == 0) {
+        scs[F_T1L] = 0; scs[F_T1H] = 1; scs[F_T2L] = 0; scs[F_T2H] = 1;
+        scs[F_ALPHA] = INFINITY; scs[F_STATE] = 0;
+    }
+    __syncthreads();
+    int depth = 0, cur_depth = 0;     // cur_depth: which frame's curves `cur` holds
+    int nodes = 0, calls = 0, dmax = 0, status = OBTG_MD_OK;
+    double r0 = INFINITY, r1 = -1, r2 = -1;
+    bool returning = false;
+    for (;;) {
+        double* f = st + (size_t)depth * FR;
+        double* sc = scs + depth * F_NSCAL;
+        int state = (int)sc[F_STATE];
+        if (!returning && state == 0) {
+            if (depth + 1 > 1000) { r0 = r1 = r2 = -1; returning = true; depth--; if (depth < 0) break; continue; }
+            if (nodes >= p.max_nodes) { status = OBTG_MD_NODE_CAP; break; }
+            nodes++;
+            if (depth + 1 > dmax) dmax = depth + 1;
+            // `cur` holds this frame: frame 0 from the prologue, every other one from the descend step
+            Ctx<MemLds> g;
+            g.mem = MemLds{ cur };
+            g.P1 = Poly{ 0, K, K, 1 };
+            g.P2 = Poly{ 3 * K, K, K, 1 };
+            g.trace = nullptr; g.trace_cap = 0; g.n_support = 0;
+            Result gr;
+            gjk::run<MemLds, false, true>(g, p.max_iter, p.md_cap, gr);
+            calls++;
+            if (gr.status == OBTG_ST_MD_CAP || gr.status == OBTG_ST_CYCLE) { status = OBTG_MD_GJK_CAP; break; }
+            double lb, t1, t2;
+            if (gr.flag > 0) {
+                lb = gr.dist;
+                const double tp = hull_param_wave(cur + half * 3 * K, K, half ? gr.c2 : gr.c1, sh_e + half * kMdMaxK,
+                                                  sh_q + half * kMdMaxK, li);
+                t1 = __shfl(tp, 0); t2 = __shfl(tp, 32);
+            } else { t1 = 0.5; t2 = 0.5; lb = p.eps; }
+            const double* c1 = cur; const double* c2 = cur + 3 * K;
+            double dd[4];
+            dd[0] = norm_seq(c1[0], c1[K], c1[2 * K], c2[0], c2[K], c2[2 * K]);
+            dd[1] = norm_seq(c1[0], c1[K], c1[2 * K], c2[K - 1], c2[2 * K - 1], c2[3 * K - 1]);
+            dd[2] = norm_seq(c1[K - 1], c1[2 * K - 1], c1[3 * K - 1], c2[0], c2[K], c2[2 * K]);
+            dd[3] = norm_seq(c1[K - 1], c1[2 * K - 1], c1[3 * K - 1], c2[K - 1], c2[2 * K - 1], c2[3 * K - 1]);
+            int am = 0;
+            for (int i = 1; i < 4; ++i) if (dd[i] < dd[am]) am = i;
+            for (int i = 0; i < 4; ++i) if (dd[i] != dd[i]) { am = i; break; }
+            const double ub = dd[am], t1loc = (am >> 1) ? 1.0 : 0.0, t2loc = (am & 1) ? 1.0 : 0.0;
+            double alpha = sc[F_ALPHA], nT1, nT2;
+            if (ub <= alpha) {
+                alpha = ub;
+                nT1 = (1 - t1loc) * sc[F_T1L] + t1loc * sc[F_T1H];
+                nT2 = (1 - t2loc) * sc[F_T2L] + t2loc * sc[F_T2H];
+            } else { nT1 = -1; nT2 = -1; }
+            if (lb >= alpha * (1 - p.eps)) {
+                r0 = alpha; r1 = nT1; r2 = nT2; returning = true; depth--;
+                if (depth < 0) break;
+                continue;
+            }
+            if (depth + 1 >= p.max_depth) { status = OBTG_MD_DEPTH_CAP; r0 = alpha; r1 = nT1; r2 = nT2; break; }
+            if (t1 != t1) t1 = 0;
+            if (t2 != t2) t2 = 0;
+            wave_sync();
+            if (lane == 0) {
+                sc[F_T1] = t1; sc[F_T2] = t2; sc[F_ALPHA] = alpha; sc[F_RT1] = nT1; sc[F_RT2] = nT2; sc[F_STATE] = 1;
+            }
+            wave_sync();
+            state = 1;
+        }
+        if (returning) {
+            if (r0 < sc[F_ALPHA]) {
+                wave_sync();
+                if (lane == 0) { sc[F_ALPHA] = r0; sc[F_RT1] = r1; sc[F_RT2] = r2; }
+                wave_sync();
+            }
+            returning = false;
+            state = (int)sc[F_STATE];
+        }
+        if (state >= 5) {
+            r0 = sc[F_ALPHA]; r1 = sc[F_RT1]; r2 = sc[F_RT2]; returning = true; depth--;
+            if (depth < 0) break;
+            continue;
+        }
+        // ---- descend into child state-1: (c3,c5) (c3,c6) (c4,c5) (c4,c6)
+        {
+            if (cur_depth != depth) {            // the walk came back up: fetch this frame's curves again
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");   // other lanes' stores of this frame have landed
+                for (int i = lane; i < 6 * K; i += kWave) cur[i] = f[i];
+                cur_depth = depth;
+                wave_sync();
+            }
+            const int ch = state - 1, h1 = ch >> 1, h2 = ch & 1;
+            const double t1 = sc[F_T1], t2 = sc[F_T2];
+            double* nf = f + FR;
+            if (lane < 6) {                       // rows 0..2: curve 1 (x, y, z), rows 3..5: curve 2
+                const bool second = lane >= 3;
+                split_row_lds(cur + lane * K, K, second ? t2 : t1, second ? h2 : h1, nxt + lane * K, sh_e + lane * K);
+            }
+            wave_sync();
+            for (int i = lane; i < 6 * K; i += kWave) nf[i] = nxt[i];
+            const double t1len = sc[F_T1H] - sc[F_T1L], t2len = sc[F_T2H] - sc[F_T2L];
+            const double m1 = sc[F_T1L] + t1 * t1len, m2 = sc[F_T2L] + t2 * t2len;
+            const double a_in = sc[F_ALPHA];
+            const double n1l = h1 ? m1 : sc[F_T1L], n1h = h1 ? sc[F_T1H] : m1;
+            const double n2l = h2 ? m2 : sc[F_T2L], n2h = h2 ? sc[F_T2H] : m2;
+            wave_sync();
+            if (lane == 0) {
+                double* ns = sc + F_NSCAL;
+                ns[F_T1L] = n1l; ns[F_T1H] = n1h; ns[F_T2L] = n2l; ns[F_T2H] = n2h;
+                ns[F_ALPHA] = a_in; ns[F_STATE] = 0;
+                sc[F_STATE] = state + 1;
+            }
+            // the child is evaluated next: its curves become `cur`
+            double* tsw = cur; cur = nxt; nxt = tsw;
+            depth++;
+            cur_depth = depth;
+            wave_sync();
+        }
+    }
+    if (lane == 0) {
+        p.res[3 * k] = r0; p.res[3 * k + 1] = r1; p.res[3 * k + 2] = r2;
+        if (p.info) { p.info[4 * k] = nodes; p.info[4 * k + 1] = calls; p.info[4 * k + 2] = dmax; p.info[4 * k + 3] = status; }
+    }
 }
 
 // frame layout for the polygon form: c1[3K] then scalars
@@ -1420,7 +1632,11 @@ int launch_min_dist(obtg_ctx* c, const double* d_curves, int K, const int* d_pa,
     if (K < 2 || K > kMdMaxK || max_depth < 1) return OBTG_ERR_UNSUPPORTED;
     MdParams p{ d_curves, d_pa, d_pb, n_pairs, K, max_iter, md_cap, max_depth, max_nodes, eps, d_stack, d_res, d_info };
     ScopedKernelTimer t(c, OBTG_K_MIN_DIST);
-    hipLaunchKernelGGL(k_min_dist, dim3((n_pairs + 63) / 64), dim3(64), 0, c->stream, p);
+    const size_t lds_w = sizeof(double) * ((size_t)12 * K + 6 * kMdMaxK + (size_t)max_depth * F_NSCAL);
+    if (lds_w <= 48 * 1024)    // one pair per wavefront
+        hipLaunchKernelGGL(k_min_dist_wave, dim3((unsigned)n_pairs), dim3(kWave), lds_w, c->stream, p);
+    else
+        hipLaunchKernelGGL(k_min_dist, dim3((n_pairs + 63) / 64), dim3(64), 0, c->stream, p);
     OBTG_HIP(c, hipGetLastError());
     return OBTG_OK;
 }
