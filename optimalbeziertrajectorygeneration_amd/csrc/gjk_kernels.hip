@@ -706,26 +706,32 @@ __device__ __forceinline__ void gjk_planar_body(const GjkSwarmParams& p, double2
                 const V2 t2{ AB.y * w, -(AB.x * w) };
                 which = (gjk::dotb2(t1, A0) >= 0) ? 2 : ((gjk::dotb2(t2, A0) >= 0) ? 1 : 3);
             } else if (keys & gjk::kB) which = 1;
-            if (which == 1 || which == 2) {
-                const int io1 = which == 2 ? ic1 : ib1, io2 = which == 2 ? ic2 : ib2;
-                const V2 o1{ q1[io1].x, q1[io1].y }, o2{ q2[io2].x, q2[io2].y };
-                const V2 O = gjk::sub2(o1, o2);
-                double t = 0.0;               // weightedOriginToLine (gjk.py:397-437)
-                if (gjk::eq2(A, O)) {
-                    r.dist = __builtin_sqrt(gjk::dot2(A, A));
-                } else {
-                    const V2 v = gjk::sub2(O, A);
-                    t = -gjk::dot2(v, A) / gjk::dot2(v, v);
-                    if (t > 1) t = 1; else if (t < 0) t = 0;
-                    const V2 cp{ (1 - t) * A.x + t * O.x, (1 - t) * A.y + t * O.y };
-                    r.dist = __builtin_sqrt(gjk::dot2(cp, cp));
+            if (which != 3) {
+                // point A (which == 0) or segment A-O: one radicand per lane, ONE square root for the wave
+                // (the three exits of gjk.py:343-358 / 397-437 differ in what is under the root only)
+                double t = 0.0, rad = gjk::dotb2(A, A);                  // np.linalg.norm(A) (gjk.py:352)
+                V2 o1 = a1, o2 = a2;
+                if (which != 0) {
+                    const int io1 = which == 2 ? ic1 : ib1, io2 = which == 2 ? ic2 : ib2;
+                    o1 = V2{ q1[io1].x, q1[io1].y }; o2 = V2{ q2[io2].x, q2[io2].y };
+                    const V2 O = gjk::sub2(o1, o2);
+                    rad = gjk::dot2(A, A);                                  // identical points (gjk.py:417-419)
+                    if (!gjk::eq2(A, O)) {                                  // weightedOriginToLine (gjk.py:397-437)
+                        const V2 v = gjk::sub2(O, A);
+                        t = -gjk::dot2(v, A) / gjk::dot2(v, v);
+                        if (t > 1) t = 1; else if (t < 0) t = 0;
+                        const V2 cp{ (1 - t) * A.x + t * O.x, (1 - t) * A.y + t * O.y };
+                        rad = gjk::dot2(cp, cp);
+                    }
                 }
-                r.c1 = V3{ (1 - t) * a1.x + t * o1.x, (1 - t) * a1.y + t * o1.y, 0.0 };
-                r.c2 = V3{ (1 - t) * a2.x + t * o2.x, (1 - t) * a2.y + t * o2.y, 0.0 };
-            } else if (which == 0) {
-                r.dist = __builtin_sqrt(gjk::dotb2(A, A));         // np.linalg.norm (gjk.py:352)
-                r.c1 = V3{ a1.x, a1.y, 0.0 };
-                r.c2 = V3{ a2.x, a2.y, 0.0 };
+                r.dist = __builtin_sqrt(rad);
+                if (which == 0) {
+                    r.c1 = V3{ a1.x, a1.y, 0.0 };
+                    r.c2 = V3{ a2.x, a2.y, 0.0 };
+                } else {
+                    r.c1 = V3{ (1 - t) * a1.x + t * o1.x, (1 - t) * a1.y + t * o1.y, 0.0 };
+                    r.c2 = V3{ (1 - t) * a2.x + t * o2.x, (1 - t) * a2.y + t * o2.y, 0.0 };
+                }
             } else {
                 // origin inside the triangle's plane region (rare): the general 3-D evaluation
                 Ctx<MemLdsXY> g;
