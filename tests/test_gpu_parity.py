@@ -674,3 +674,27 @@ def test_pair_sweep_one_launch_equals_separate_kernels(capi, synth, shape):
     assert not torch.isnan(b["sep"]).any() and (b["flag"] != -7).all()
     ctx.set_stream(0)
     ctx.close()
+
+
+@pytest.mark.parametrize("R", [0, 7])
+def test_temporal_sep_is_the_sampled_squared_distance(capi, synth, R):
+    """The reference's own eyeball check (temp.py:20-37), made numerical and independent of the oracle:
+    the Bernstein polynomial with the returned control points equals (d/2) |v_i(t) - v_j(t)|^2 - maxSep^2
+    at sampled t, for every pair of the 64-vehicle swarm (the d/2 factor: bezier.py:884, 1744-1756)."""
+    from scipy.special import comb
+    N, dim, n = 64, 2, 10
+    Y = synth.swarm_control_points(N, dim, n, seed=77)
+    ctx = capi.Context(N, dim, n, R)
+    out = ctx.temporal_sep(Y, 0.9)[0].reshape(ctx.num_pairs, 2 * n + R + 1)
+    t = np.linspace(0.0, 1.0, 17)
+
+    def basis(deg):
+        k = np.arange(deg + 1)
+        return comb(deg, k)[None, :] * t[:, None] ** k[None, :] * (1 - t[:, None]) ** (deg - k[None, :])   # [t][k]
+
+    curves = Y.reshape(N, dim, n + 1) @ basis(n).T                       # [N][dim][t]
+    pa, pb = synth.swarm_pairs(N, 0)
+    direct = (dim / 2.0) * ((curves[pa] - curves[pb]) ** 2).sum(axis=1) - 0.9 ** 2     # [P][t]
+    from_cpts = out @ basis(2 * n + R).T
+    assert_close(from_cpts, direct, 1e-9)
+    ctx.close()
