@@ -210,6 +210,16 @@ int obtg_ctx_set_gjk_history(obtg_ctx*, int on);
 int obtg_gjk_swarm(obtg_ctx*, const double* Y, int B, int max_iter, int md_cap,
                    int* flag, double* p1, double* p2, double* dist, int* nsup, int* status);
 
+/* Robust curve <-> curve minimum distance (NOT the reference's algorithm): breadth-first
+ * branch & bound on the parameter square with bounds that are valid for the curves themselves -- upper: distances
+ * between end points of sub-curves; lower: gap of the two control polygons projected on the direction between the
+ * sub-curves' mid points.  res[n_pairs][3] = (dist, t1, t2) with dist within a relative eps of the true minimum, or
+ * below eps x (largest coordinate) when the curves touch, when status == OBTG_MD_OK; OBTG_MD_NODE_CAP (node budget max_nodes or the internal frontier of 1024 nodes per
+ * pair exhausted) and OBTG_MD_DEPTH_CAP (level 48) return the best distance found so far, an upper bound.
+ * info[n_pairs][4] = (nodes, levels, largest frontier, status).  Use where `_minDist`'s known defects matter
+ * (bezier.py:1283-1408 on gjkNew: non-minimal hull distances used as lower bounds, unbounded loops). */
+int obtg_min_dist_robust(obtg_ctx*, const double* curves, int n_curves, int K, const int* pair_a, const int* pair_b,
+                         int n_pairs, double eps, int max_nodes, double* res, int* info, int* status);
 /* ---- curve <-> curve / curve <-> polygon minimum distance --------------------------------
  * Bezier.minDist -> _minDist (bezier.py:840-852, 1283-1408) and Bezier.minDist2Poly ->
  * _minDist2Poly (bezier.py:854-857, 1411-1496): branch and bound over de Casteljau

@@ -60,6 +60,7 @@ _SIGNATURES = {
     "obtg_gjk_swarm_dev": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "obtg_gjk_swarm": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "obtg_min_dist": (_i, [_vp, _vp, _i, _i, _vp, _vp, _i, _d, _i, _i, _i, _i, _vp, _vp, _vp]),
+    "obtg_min_dist_robust": (_i, [_vp, _vp, _i, _i, _vp, _vp, _i, _d, _i, _vp, _vp, _vp]),
     "obtg_min_dist2poly": (_i, [_vp, _vp, _i, _i, _vp, _i, _vp, _i, _vp, _vp, _i, _d, _i, _i, _i, _i, _vp, _vp, _vp]),
     "obtg_bern_elev": (_i, [_vp, _vp, _i, _i, _i, _vp]),
     "obtg_bern_diff": (_i, [_vp, _vp, _i, _i, _d, _vp]),
@@ -394,6 +395,20 @@ class Context(object):
                                             max_iter, md_cap, max_depth, max_nodes, _ptr(res), _ptr(info),
                                             _ptr(status)), "obtg_min_dist")
         return dict(res=res, nodes=info[:, 0], gjk_calls=info[:, 1], depth=info[:, 2], status=status)
+
+    def min_dist_robust(self, curves, pair_a, pair_b, eps=1e-9, max_nodes=200000):
+        """Robust branch & bound (obtg_min_dist_robust): true minimum within relative eps when status == MD_OK."""
+        curves = _f64(curves)
+        n_curves, _, K = curves.shape
+        pa, pb = _i32(pair_a), _i32(pair_b)
+        n = pa.shape[0]
+        res = np.empty((n, 3))
+        info = np.zeros((n, 4), np.int32)
+        status = np.zeros(n, np.int32)
+        self._check(self._lib.obtg_min_dist_robust(self._h, _ptr(curves), n_curves, K, _ptr(pa), _ptr(pb), n, float(eps),
+                                                   int(max_nodes), _ptr(res), _ptr(info), _ptr(status)),
+                    "obtg_min_dist_robust")
+        return dict(res=res, nodes=info[:, 0], levels=info[:, 1], frontier=info[:, 2], status=status)
 
     def min_dist2poly(self, curves, pts, off, pair_curve, pair_poly, eps=1e-6, max_iter=128, md_cap=4096,
                       max_depth=64, max_nodes=200000):

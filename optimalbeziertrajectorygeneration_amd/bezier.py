@@ -198,11 +198,21 @@ class Bezier(BezierParams):
         c[:self.dim] = self.cpts
         return c
 
-    def minDist(self, otherCurve, eps=1e-9, max_depth=128, max_nodes=4000000):
+    def minDist(self, otherCurve, eps=1e-9, max_depth=128, max_nodes=4000000, robust=False):
+        """(dist, t1, t2).  Default: the reference's `_minDist` step for step (bezier.py:1283-1408), including
+        its non-minimal answers.  robust=True: obtg_min_dist_robust, the true minimum within relative eps."""
         if self.dim < 2 or self.dim > 3 or otherCurve.dim < 2 or otherCurve.dim > 3:
             raise ValueError('Both curves must be either 2D or 3D, not {}D and {}D.'.format(self.dim, otherCurve.dim))
         if self.deg != otherCurve.deg:
             raise ValueError('minDist needs curves of equal degree here (got {} and {})'.format(self.deg, otherCurve.deg))
+        if robust:
+            r = _ctx().min_dist_robust(np.stack([self._padded(), otherCurve._padded()]), [0], [1], eps=eps,
+                                       max_nodes=max_nodes)
+            if r['status'][0] != _capi.MD_OK:
+                raise RuntimeError('minDist(robust): search budget exhausted (curves coincide over a stretch?); '
+                                   'best distance so far %g' % r['res'][0][0])
+            a, t1, t2 = r['res'][0]
+            return (float(a), float(t1), float(t2))
         r = _ctx().min_dist(np.stack([self._padded(), otherCurve._padded()]), [0], [1], eps=eps,
                             max_depth=max_depth, max_nodes=max_nodes)
         _raise_md(r['status'][0])

@@ -184,7 +184,7 @@ const char* obtg_abi_symbols(void)
         "obtg_temporal_sep_fd\0obtg_temporal_sep_fd_dev\0"
         "obtg_temporal_sep_dev\0obtg_temporal_sep_min_dev\0obtg_speed_dev\0obtg_ang_rate_dev\0obtg_dynamics_dev\0"
         "obtg_fd_batch_dev\0obtg_gjk_pairs\0obtg_ctx_set_polygons\0obtg_ctx_set_hull_pairs\0"
-        "obtg_ctx_set_fd_dedup\0obtg_ctx_set_gjk_history\0obtg_pair_sweep_dev\0obtg_gjk_swarm_dev\0obtg_gjk_swarm\0obtg_min_dist\0obtg_min_dist2poly\0"
+        "obtg_ctx_set_fd_dedup\0obtg_ctx_set_gjk_history\0obtg_pair_sweep_dev\0obtg_gjk_swarm_dev\0obtg_gjk_swarm\0obtg_min_dist\0obtg_min_dist_robust\0obtg_min_dist2poly\0"
         "obtg_bern_elev\0obtg_bern_diff\0obtg_bern_mul\0obtg_bern_normsq\0"
         "obtg_euclidean_obj\0obtg_accel_obj\0obtg_jerk_obj\0"
         "obtg_set_profiling\0obtg_set_profile_period\0obtg_kernel_stats\0obtg_reset_kernel_stats\0obtg_kernel_name\0";
@@ -658,6 +658,36 @@ int obtg_min_dist(obtg_ctx* c, const double* curves, int n_curves, int K, const 
     if ((rc = m[3].reserve(sizeof(int) * 4 * (size_t)n_pairs))) return rc;
     rc = launch_min_dist(c, c->ws_in.as<double>(), K, m[1].as<int>(), m[2].as<int>(), n_pairs, eps, max_iter,
                          md_cap, max_depth, max_nodes, m[5].as<double>(), c->ws_out.as<double>(), m[3].as<int>());
+    if (rc) return rc;
+    std::vector<int> hinfo((size_t)4 * n_pairs);
+    OBTG_HIP(c, hipMemcpyAsync(hinfo.data(), m[3].p, sizeof(int) * 4 * n_pairs, hipMemcpyDeviceToHost, c->stream));
+    rc = d2h(c, res, c->ws_out.p, sizeof(double) * 3 * n_pairs);
+    if (rc) return rc;
+    if (info) std::memcpy(info, hinfo.data(), sizeof(int) * 4 * n_pairs);
+    if (status) for (int k = 0; k < n_pairs; ++k) status[k] = hinfo[4 * k + 3];
+    return OBTG_OK;
+}
+
+int obtg_min_dist_robust(obtg_ctx* c, const double* curves, int n_curves, int K, const int* pair_a, const int* pair_b,
+                         int n_pairs, double eps, int max_nodes, double* res, int* info, int* status)
+{
+    if (!check_ctx(c) || !curves || !pair_a || !pair_b || !res || n_curves < 1 || n_pairs < 0) return OBTG_ERR_ARG;
+    if (max_nodes < 1 || !(eps > 0)) return OBTG_ERR_ARG;
+    for (int k = 0; k < n_pairs; ++k)
+        if (pair_a[k] < 0 || pair_a[k] >= n_curves || pair_b[k] < 0 || pair_b[k] >= n_curves) return OBTG_ERR_ARG;
+    if (n_pairs == 0) return OBTG_OK;
+    (void)hipSetDevice(c->device);
+    constexpr int kCap = 1024, kMaxLevel = 48;
+    DevBuf* m = c->ws_misc;
+    int rc = h2d(c, c->ws_in, curves, sizeof(double) * 3 * (size_t)K * n_curves);
+    if (rc) return rc;
+    if ((rc = h2d(c, m[1], pair_a, sizeof(int) * n_pairs))) return rc;
+    if ((rc = h2d(c, m[2], pair_b, sizeof(int) * n_pairs))) return rc;
+    if ((rc = m[5].reserve(sizeof(double) * 2 * kCap * 3 * (size_t)n_pairs))) return rc;
+    if ((rc = c->ws_out.reserve(sizeof(double) * 3 * (size_t)n_pairs))) return rc;
+    if ((rc = m[3].reserve(sizeof(int) * 4 * (size_t)n_pairs))) return rc;
+    rc = launch_min_dist_robust(c, c->ws_in.as<double>(), K, m[1].as<int>(), m[2].as<int>(), n_pairs, eps, max_nodes,
+                                kMaxLevel, kCap, m[5].as<double>(), c->ws_out.as<double>(), m[3].as<int>());
     if (rc) return rc;
     std::vector<int> hinfo((size_t)4 * n_pairs);
     OBTG_HIP(c, hipMemcpyAsync(hinfo.data(), m[3].p, sizeof(int) * 4 * n_pairs, hipMemcpyDeviceToHost, c->stream));

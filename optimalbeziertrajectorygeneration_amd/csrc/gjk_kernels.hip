@@ -1213,6 +1213,163 @@ __global__ __launch_bounds__(64) void k_min_dist_wave(const MdParams p)
     }
 }
 
+// -------------------------------------------------------------------------------------
+//  Robust curve <-> curve minimum distance: an opt-in replacement for
+//  _minDist that does not inherit gjkNew's non-minimal distances and unbounded loops (SURVEY.md 8(a)
+//  G2/G3: 458 of 1499 reference distances are not minimal; some pairs never return).
+//  Breadth-first branch & bound on the parameter square, one pair per wavefront, one node per lane:
+//    node      = [t1, t1 + 2^-l] x [t2, t2 + 2^-l]; its two sub-curves come from the originals by two
+//                de Casteljau splits per coordinate (nothing but (t1, t2, l) is stored);
+//    upper     = distances between the four end-point pairs of the two sub-curves (points ON the
+//                curves): alpha = wave minimum;
+//    lower     = gap of the two control polygons projected on d = (mid-point difference): a valid bound
+//                on the distance of the convex hulls, hence of the sub-curves, that closes
+//                quadratically with the node size near a regular minimum;
+//    a node survives while lower < alpha (1 - eps) and is then cut into its four children.
+//  When the frontier empties, alpha is within a relative eps of the true minimum, or below eps times the
+//  largest coordinate (the curves touch) (status OK); the node
+//  budget / frontier capacity / level cap end the search with the best alpha so far and a status.
+// -------------------------------------------------------------------------------------
+struct MdrParams {
+    const double* __restrict__ curves;   // [n_curves][3][K]
+    const int* __restrict__ pa;
+    const int* __restrict__ pb;
+    int n_pairs, K, max_nodes, max_level, cap;
+    double eps;
+    double* frontier;                     // [n_pairs][2][cap][3]  (t1, t2, level)
+    double* __restrict__ res;             // [n_pairs][3]  (dist, t1, t2)
+    int* __restrict__ info;               // [n_pairs][4]  (nodes, levels, max frontier, status)
+};
+
+// sub-curve of one coordinate row on [a, a + w]: left part of a split at b = a + w, then the right
+// part of that at a / b; row in/out through `x` (K doubles, lane-private LDS)
+__device__ __forceinline__ void subcurve_row(double* x, int K, double a, double w)
+{
+    const double b = a + w;
+    if (b < 1.0) {                                   // keep the left part [0, b]
+        for (int sz = K; sz > 1; --sz)
+            for (int i = K - 1; i >= K - sz + 1; --i) x[i] = (1 - b) * x[i - 1] + b * x[i];
+    }
+    if (a > 0.0) {                                   // of that, the right part [a / b, 1]
+        const double u = a / b;
+        for (int sz = K; sz > 1; --sz)
+            for (int i = 0; i < sz - 1; ++i) x[i] = (1 - u) * x[i] + u * x[i + 1];
+    }
+}
+
+__global__ __launch_bounds__(64) void k_min_dist_robust(const MdrParams p)
+{
+    extern __shared__ double mr_lds[];
+    __shared__ int s_count;
+    const int k = blockIdx.x, lane = threadIdx.x, K = p.K;
+    const int pitch = (3 * K) | 1;
+    double* orig = mr_lds;                         // [2][3][K]
+    double* work = orig + 6 * K + lane * pitch;    // per lane: row scratch [K], projections [2][K]
+    const double* ca = p.curves + (size_t)p.pa[k] * 3 * K;
+    const double* cb = p.curves + (size_t)p.pb[k] * 3 * K;
+    double scale = 0.0;
+    for (int i = lane; i < 3 * K; i += kWave) {
+        const double a = ca[i], bq = cb[i];
+        orig[i] = a; orig[3 * K + i] = bq;
+        scale = fmax(scale, fmax(__builtin_fabs(a), __builtin_fabs(bq)));
+    }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) scale = fmax(scale, __shfl_xor(scale, m));
+    const double abs_tol = p.eps * scale;          // "the curves touch": a relative criterion cannot close on distance 0
+    double* fa = p.frontier + (size_t)k * 2 * p.cap * 3;
+    double* fb = fa + (size_t)p.cap * 3;
+    if (lane == 0) { fa[0] = 0.0; fa[1] = 0.0; fa[2] = 0.0; }
+    __syncthreads();
+    int n_a = 1, nodes = 0, levels = 0, front_max = 1, status = OBTG_MD_OK;
+    double alpha = INFINITY, bt1 = -1, bt2 = -1;
+    while (n_a > 0) {
+        if (lane == 0) s_count = 0;
+        __syncthreads();
+        for (int base = 0; base < n_a; base += kWave) {
+            const bool valid = base + lane < n_a;
+            const int ni = valid ? base + lane : base;
+            const double t1 = fa[3 * ni], t2 = fa[3 * ni + 1];
+            const int lev = (int)fa[3 * ni + 2];
+            const double w = __builtin_ldexp(1.0, -lev);
+            // pass A: end points and a middle control point of both sub-curves
+            double e[2][2][3], mid[2][3];
+            for (int cv = 0; cv < 2; ++cv)
+                for (int q = 0; q < 3; ++q) {
+                    for (int i = 0; i < K; ++i) work[i] = orig[(cv * 3 + q) * K + i];
+                    subcurve_row(work, K, cv ? t2 : t1, w);
+                    e[cv][0][q] = work[0]; e[cv][1][q] = work[K - 1];
+                    mid[cv][q] = 0.5 * (work[0] + work[K - 1]);
+                }
+            double best = INFINITY, b1 = -1, b2 = -1;
+            for (int i1 = 0; i1 < 2; ++i1)
+                for (int i2 = 0; i2 < 2; ++i2) {
+                    const double dx = e[0][i1][0] - e[1][i2][0], dy = e[0][i1][1] - e[1][i2][1], dz = e[0][i1][2] - e[1][i2][2];
+                    const double dd = __builtin_sqrt(dx * dx + dy * dy + dz * dz);
+                    if (dd < best) { best = dd; b1 = t1 + i1 * w; b2 = t2 + i2 * w; }
+                }
+            if (!valid) best = INFINITY;
+            // wave minimum of the upper bounds (lowest lane among equals)
+            double wb = best;
+#pragma unroll
+            for (int m = 32; m >= 1; m >>= 1) wb = fmin(wb, __shfl_xor(wb, m));
+            if (wb < alpha) {
+                const unsigned long long who = __ballot(best == wb);
+                const int src = __ffsll((long long)who) - 1;
+                alpha = wb; bt1 = __shfl(b1, src); bt2 = __shfl(b2, src);
+            }
+            // pass B: projections of both control polygons on d = mid1 - mid2
+            double d[3] = { mid[0][0] - mid[1][0], mid[0][1] - mid[1][1], mid[0][2] - mid[1][2] };
+            const double dn = __builtin_sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+            double lb = 0.0;
+            if (dn > 0.0) {
+                double* pr = work + K;                  // [2][K]
+                for (int i = 0; i < 2 * K; ++i) pr[i] = 0.0;
+                for (int cv = 0; cv < 2; ++cv)
+                    for (int q = 0; q < 3; ++q) {
+                        for (int i = 0; i < K; ++i) work[i] = orig[(cv * 3 + q) * K + i];
+                        subcurve_row(work, K, cv ? t2 : t1, w);
+                        const double dq = d[q] / dn;
+                        for (int i = 0; i < K; ++i) pr[cv * K + i] += dq * work[i];
+                    }
+                double lo1 = INFINITY, hi2 = -INFINITY;
+                for (int i = 0; i < K; ++i) { lo1 = fmin(lo1, pr[i]); hi2 = fmax(hi2, pr[K + i]); }
+                lb = fmax(0.0, (lo1 - hi2) * (1.0 - 1e-12));
+            }
+            const bool keep = valid && lb < alpha * (1 - p.eps) && alpha > abs_tol;
+            if (keep) {
+                if (lev + 1 > p.max_level) status = OBTG_MD_DEPTH_CAP;
+                else {
+                    const int pos = atomicAdd(&s_count, 4);
+                    if (pos + 4 <= p.cap) {
+                        const double h = 0.5 * w;
+                        for (int c4 = 0; c4 < 4; ++c4) {
+                            fb[3 * (pos + c4)] = t1 + (c4 >> 1) * h;
+                            fb[3 * (pos + c4) + 1] = t2 + (c4 & 1) * h;
+                            fb[3 * (pos + c4) + 2] = (double)(lev + 1);
+                        }
+                    } else status = OBTG_MD_NODE_CAP;
+                }
+            }
+        }
+        nodes += n_a;
+        levels++;
+        __syncthreads();
+        // statuses are per lane: any lane hitting a cap ends the search with the best alpha so far
+        const unsigned long long capped = __ballot(status != OBTG_MD_OK);
+        if (capped) { status = __shfl(status, __ffsll((long long)capped) - 1); break; }
+        n_a = min(s_count, p.cap);
+        if (n_a > front_max) front_max = n_a;
+        if (nodes + n_a > p.max_nodes && n_a > 0) { status = OBTG_MD_NODE_CAP; break; }
+        double* tsw = fa; fa = fb; fb = tsw;
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+        __syncthreads();
+    }
+    if (lane == 0) {
+        p.res[3 * k] = alpha; p.res[3 * k + 1] = bt1; p.res[3 * k + 2] = bt2;
+        if (p.info) { p.info[4 * k] = nodes; p.info[4 * k + 1] = levels; p.info[4 * k + 2] = front_max; p.info[4 * k + 3] = status; }
+    }
+}
+
 // frame layout for the polygon form: c1[3K] then scalars
 enum { G_T1 = 0, G_T1L, G_T1H, G_ALPHA, G_RT1, G_PX, G_PY, G_PZ, G_STATE, G_NSCAL };
 
@@ -1643,6 +1800,19 @@ int launch_min_dist(obtg_ctx* c, const double* d_curves, int K, const int* d_pa,
         hipLaunchKernelGGL(k_min_dist_wave, dim3((unsigned)n_pairs), dim3(kWave), lds_w, c->stream, p);
     else
         hipLaunchKernelGGL(k_min_dist, dim3((n_pairs + 63) / 64), dim3(64), 0, c->stream, p);
+    OBTG_HIP(c, hipGetLastError());
+    return OBTG_OK;
+}
+
+int launch_min_dist_robust(obtg_ctx* c, const double* d_curves, int K, const int* d_pa, const int* d_pb, int n_pairs,
+                           double eps, int max_nodes, int max_level, int cap, double* d_frontier, double* d_res, int* d_info)
+{
+    if (n_pairs <= 0) return OBTG_OK;
+    if (K < 2 || K > kMdMaxK || cap < 4 || max_level < 1 || max_level > 50) return OBTG_ERR_UNSUPPORTED;
+    MdrParams p{ d_curves, d_pa, d_pb, n_pairs, K, max_nodes, max_level, cap, eps, d_frontier, d_res, d_info };
+    const size_t lds = sizeof(double) * ((size_t)6 * K + (size_t)kWave * ((3 * K) | 1));
+    ScopedKernelTimer t(c, OBTG_K_MIN_DIST);
+    hipLaunchKernelGGL(k_min_dist_robust, dim3((unsigned)n_pairs), dim3(kWave), lds, c->stream, p);
     OBTG_HIP(c, hipGetLastError());
     return OBTG_OK;
 }

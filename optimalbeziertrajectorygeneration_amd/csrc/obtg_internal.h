@@ -146,6 +146,8 @@ int launch_gjk_swarm(obtg_ctx* c, const double* dY, int B, int max_iter, int md_
 int launch_min_dist(obtg_ctx* c, const double* d_curves, int K, const int* d_pa, const int* d_pb,
                     int n_pairs, double eps, int max_iter, int md_cap, int max_depth, int max_nodes,
                     double* d_stack, double* d_res, int* d_info);
+int launch_min_dist_robust(obtg_ctx* c, const double* d_curves, int K, const int* d_pa, const int* d_pb, int n_pairs,
+                           double eps, int max_nodes, int max_level, int cap, double* d_frontier, double* d_res, int* d_info);
 int launch_min_dist2poly(obtg_ctx* c, const double* d_curves, int K, const double* d_soa,
                          const int* d_off, const int* d_pc, const int* d_pp, int n_pairs, double eps,
                          int max_iter, int md_cap, int max_depth, int max_nodes, double* d_stack,

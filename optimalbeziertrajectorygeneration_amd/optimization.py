@@ -208,9 +208,11 @@ class BezOptimization(object):
             return self._ctx(False).ang_rate(y, self._tf_of(x), self.model['maxAngRate'])[0]
         return wrapper
 
-    def spatialSeparationConstraints(self, x):
+    def spatialSeparationConstraints(self, x, robust=False):
         """All-pairs minDist over vehicles AND shape obstacles (optimization.py:109-133);
-        returns shape (P, 3): (dist, t1, t2) - maxSep, as the reference does."""
+        returns shape (P, 3): (dist, t1, t2) - maxSep, as the reference does.
+        robust=True: true minimum distances (obtg_min_dist_robust) instead of the reference's `_minDist`;
+        pairs whose search budget runs out (curves coinciding over a stretch) report their best upper bound."""
         numVeh, dim, maxSep = self.model['numVeh'], self.model['dim'], self.model['maxSep']
         y = self.reshapeVector(x)
         curves = [bez.Bezier(y[i * dim:(i + 1) * dim, :]) for i in range(numVeh)] + list(self.shapeObstacles)
@@ -221,6 +223,8 @@ class BezOptimization(object):
             for j in range(i + 1, n):
                 pa.append(i)
                 pb.append(j)
+        if robust:
+            return _capi.scratch_context().min_dist_robust(stack, pa, pb, eps=1e-9, max_nodes=400000)['res'] - maxSep
         r = _capi.scratch_context().min_dist(stack, pa, pb, eps=1e-9, max_depth=128, max_nodes=4000000)
         for st in r['status']:
             bez._raise_md(st)

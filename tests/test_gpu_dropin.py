@@ -227,3 +227,27 @@ def test_structured_jacobian_is_bit_identical_to_brute_force(case):
     for jac in fams:
         Js, Jb = jac(x), jac(x, structured=False)
         assert np.array_equal(Js, Jb, equal_nan=True) and np.count_nonzero(Jb) > 0
+
+
+def test_min_dist_robust_option():
+    """Bezier.minDist(robust=True) and spatialSeparationConstraints(robust=True)."""
+    from optimalbeziertrajectorygeneration_amd.bezier import Bezier
+    from optimalbeziertrajectorygeneration_amd.optimization import BezOptimization
+    a = Bezier(np.array([[0, 1, 2, 3, 4, 5.0], [0, 2, -1, 3, 0, 1.0]]))
+    b = Bezier(np.array([[0, 1, 2, 3, 4, 5.0], [4, 3, 5, 2, 6, 3.0]]))
+    d, t1, t2 = a.minDist(b, robust=True)
+    ts = np.linspace(0, 1, 400)
+    brute = min(np.linalg.norm(a(t)[:, 0] - b(u)[:, 0]) for t in ts[::4] for u in ts[::4]) if callable(a) else None
+    d_ref = a.minDist(b)[0]
+    assert d <= d_ref * (1 + 1e-9)                       # never worse than the reference-style answer
+    if brute is not None:
+        assert d <= brute + 1e-9
+    tracks = [Bezier(np.array([[8, 9, 10, 11, 12, 13, 12, 11, 10, 9, 8.0], [8, 10, 12, 14, 20, 14, 12, 10, 10, 9, 8.0]])),
+              Bezier(np.array([[18, 13, 9, 6, 4, 3, 4, 6, 9, 13, 18.0], [3, 3, 4, 4, 4, 5, 5, 5, 7, 8, 3.0]]))]
+    bo = BezOptimization(numVeh=1, dimension=2, degree=10, minimizeGoal='TimeOpt', maxSep=0.5, maxSpeed=5, maxAngRate=0.5,
+                         initPoints=(2, 1), finalPoints=(15, 15), initSpeeds=1, finalSpeeds=1, initAngs=np.pi / 2,
+                         finalAngs=np.pi / 2, shapeObstacles=tracks)
+    x = bo.generateGuess()
+    x[-1] = 10
+    out = bo.spatialSeparationConstraints(x, robust=True)      # Examples/ComplexObstacles.py:19-52: the reference does not finish here
+    assert out.shape == (3, 3) and np.isfinite(out).all()

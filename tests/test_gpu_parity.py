@@ -698,3 +698,46 @@ def test_temporal_sep_is_the_sampled_squared_distance(capi, synth, R):
     from_cpts = out @ basis(2 * n + R).T
     assert_close(from_cpts, direct, 1e-9)
     ctx.close()
+
+
+def test_min_dist_robust_finds_the_true_minimum(capi, synth, golden_dir):
+    """obtg_min_dist_robust against a ground truth that shares no code with it:
+    dense sampling of both curves followed by a bounded local minimisation (SciPy).  Also the literal
+    curves of bezier.py:1772-1868: the known answers of the reference where it is right (0.125;
+    sqrt(2); crossing curves), and a finite answer on the pair that overflows the reference's stack."""
+    from scipy.optimize import minimize
+    from scipy.special import comb
+    N, n = 24, 10
+    Y = synth.swarm_control_points(N, 2, n, seed=99)
+    curves = np.zeros((N, 3, n + 1))
+    curves[:, :2, :] = Y.reshape(N, 2, n + 1)
+    curves[:, 2, :] = np.random.default_rng(5).normal(0, 3.0, size=(N, n + 1))      # genuinely 3-D
+    pa, pb = np.triu_indices(N, 1)
+    ctx = capi.scratch_context()
+    r = ctx.min_dist_robust(curves, pa, pb, eps=1e-9, max_nodes=400000)
+    assert (r["status"] == capi.MD_OK).all(), np.bincount(r["status"])
+    k = np.arange(n + 1)
+
+    def point(c, t):
+        b = comb(n, k) * t ** k * (1 - t) ** (n - k)
+        return c @ b
+
+    ts = np.linspace(0, 1, 201)
+    Bm = comb(n, k)[None, :] * ts[:, None] ** k[None, :] * (1 - ts[:, None]) ** (n - k[None, :])
+    samples = curves @ Bm.T                                                        # [N][3][201]
+    rng = np.random.default_rng(0)
+    for q in rng.choice(len(pa), 40, replace=False):
+        a, b = curves[pa[q]], curves[pb[q]]
+        D = np.linalg.norm(samples[pa[q]][:, :, None] - samples[pb[q]][:, None, :], axis=0)
+        i, j = np.unravel_index(np.argmin(D), D.shape)
+        f = lambda x: np.linalg.norm(point(a, x[0]) - point(b, x[1]))             # noqa: E731
+        best = min((minimize(f, [ts[i], ts[j]], bounds=[(0, 1), (0, 1)], method="L-BFGS-B", tol=1e-14).fun, D[i, j]))
+        got, t1, t2 = r["res"][q]
+        assert got <= best * (1 + 1e-7) + 1e-9, (q, got, best)                     # never worse than the ground truth
+        assert got >= best * (1 - 1e-5) - 1e-9, (q, got, best)                     # and it IS a distance of the curves
+        assert abs(f([t1, t2]) - got) <= 1e-9 * max(1.0, got)                      # reported parameters reproduce it
+    m = np.load(golden_dir + "/mindist.npz")
+    lit = m["lit_curves"]
+    rl = ctx.min_dist_robust(lit, [0, 2, 2, 0], [1, 1, 3, 4], eps=1e-9, max_nodes=400000)
+    assert abs(rl["res"][0][0] - 0.125) < 1e-9 and abs(rl["res"][1][0] - np.sqrt(2)) < 1e-8
+    assert rl["res"][2][0] < 1e-6 and np.isfinite(rl["res"][3][0])

@@ -14,3 +14,13 @@ for cap in (2000, 200000):
     st = np.bincount(r['status'], minlength=4)
     print('max_nodes %d: %d pairs in %.3f s; status counts ok/depth/nodes/gjk = %s; gjk calls total %d, median %d, max %d'
           % (cap, len(pa), dt, st.tolist(), r['gjk_calls'].sum(), np.median(r['gjk_calls']), r['gjk_calls'].max()))
+t = time.perf_counter()
+rr = ctx.min_dist_robust(curves, pa, pb, eps=1e-9, max_nodes=400000)
+dt = time.perf_counter() - t
+ok = r['status'] == 0
+both = ok & (rr['status'] == 0)
+worse = (r['res'][both, 0] > rr['res'][both, 0] * (1 + 1e-6)).sum()
+print('robust: %d pairs in %.3f s; status counts ok/nodes/depth = %s; nodes total %d, median %d, max %d; largest frontier %d; '
+      'reference-style answer non-minimal on %d of the %d pairs both finish (max ratio %.2f)'
+      % (len(pa), dt, np.bincount(rr['status'], minlength=3).tolist(), rr['nodes'].sum(), np.median(rr['nodes']), rr['nodes'].max(),
+         rr['frontier'].max(), worse, both.sum(), np.max(np.where(rr['res'][both, 0] > 1e-6, r['res'][both, 0] / np.maximum(rr['res'][both, 0], 1e-6), 1.0))))
