@@ -15,3 +15,19 @@ for B in (1, 1153):
         ctx.temporal_sep(Yb, 0.9); ctx.speed(Yb, tf, 5.0, True); ctx.ang_rate(Yb, tf, 1.0)
     dt = (time.perf_counter() - t) / K
     print("B=%d: %.3f ms per (tsep+speed+ang) host call set -> %.1f evals/s" % (B, dt * 1e3, B / dt))
+
+# the same Jacobian content through the structured entry points: only what a variable touches crosses PCIe
+k = np.arange(N * d * (n - 1)); prow = k // (n - 1); pcol = 1 + k % (n - 1)
+pval = Y[prow, pcol] + synth.FD_STEP
+one = _capi.Context(1, d, n, 0)
+Yc = Y.reshape(N, d, n + 1)[prow // d].copy(); Yc[k, prow % d, pcol] = pval
+tfc = np.full(len(k), 10.0)
+def structured():
+    ctx.temporal_sep(Y[None], 0.9); ctx.temporal_sep_fd(Y, prow, pcol, pval, 0.9)
+    ctx.speed(Y[None], np.array([10.0]), 5.0, True); one.speed(Yc, tfc, 5.0, True)
+    ctx.ang_rate(Y[None], np.array([10.0]), 1.0); one.ang_rate(Yc, tfc, 1.0)
+for _ in range(3): structured()
+t = time.perf_counter()
+for _ in range(20): structured()
+dt = (time.perf_counter() - t) / 20
+print("structured FD (same Jacobians, %d variables): %.3f ms per set -> %.1f Jacobian-row equivalents/s" % (len(k), dt * 1e3, (len(k) + 1) / dt))
