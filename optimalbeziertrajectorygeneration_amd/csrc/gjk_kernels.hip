@@ -792,6 +792,291 @@ void k_pair_sweep(const GjkSwarmParams p)
     gjk_planar_body<NC, 0>(p, xy_dyn, -1, -1);
 }
 
+// -------------------------------------------------------------------------------------
+//  3-D swarm sweep, fixed point count (the SwarmOfAerialVehicles shapes: every object has <= NC
+//  points, any z).  Same organisation as the planar sweep -- objects staged point-major, unrolled
+//  support scan, lane refill in trip-count order of the previous sweep, XCD-aware ids, phase 1
+//  leaves records, phase 2 evaluates the closest points convergently -- on the full 3-D state machine
+//  of gjk_device.h (simplex_update, the Brent cycle detector, closest_from_simplex).
+//  LDS point = (x, y, z, 0): 32 bytes, object pitch 4 NC + 2 doubles (odd in 16-byte units).
+// -------------------------------------------------------------------------------------
+template <int NC>
+__device__ __forceinline__ void support_fixed3(const double* __restrict__ o1, const double* __restrict__ o2, const V3& d,
+                                               gjk::Vert& out)
+{
+    const double ndx = -d.x, ndy = -d.y, ndz = -d.z;
+    int i1 = 0, i2 = 0;
+    double m1 = o1[0] * d.x + o1[1] * d.y + o1[2] * d.z;
+    double m2 = o2[0] * ndx + o2[1] * ndy + o2[2] * ndz;
+#pragma unroll
+    for (int i = 1; i < NC; ++i) {
+        const double2 a = *reinterpret_cast<const double2*>(o1 + 4 * i), bq = *reinterpret_cast<const double2*>(o2 + 4 * i);
+        const double c1 = a.x * d.x + a.y * d.y + o1[4 * i + 2] * d.z;
+        const double c2 = bq.x * ndx + bq.y * ndy + o2[4 * i + 2] * ndz;
+        i1 = c1 > m1 ? i : i1;
+        i2 = c2 > m2 ? i : i2;
+        m1 = __builtin_fmax(m1, c1);
+        m2 = __builtin_fmax(m2, c2);
+    }
+    out.i1 = i1; out.i2 = i2;
+    out.v = V3{ o1[4 * i1] - o2[4 * i2], o1[4 * i1 + 1] - o2[4 * i2 + 1], o1[4 * i1 + 2] - o2[4 * i2 + 2] };
+}
+
+__host__ __device__ constexpr size_t sweep3d_lds_bytes(int n_obj, int nc, int chunk)
+{
+    // objects | r0 r1 r2 int[chunk] each | plist, pnat int[chunk] | ext int[2 n_obj] | ord u16[chunk]
+    return 8 * (size_t)n_obj * (4 * nc + 2) + 20 * (size_t)chunk + 8 * (size_t)n_obj + 2 * (size_t)chunk + 16;
+}
+
+template <int NC>
+__global__ __launch_bounds__(256) void k_gjk_swarm_3d(const GjkSwarmParams p)
+{
+    using gjk::Simplex;
+    using gjk::Vert;
+    constexpr int PITCH = 4 * NC + 2;
+    extern __shared__ double2 xyz_dyn[];
+    double* lds = reinterpret_cast<double*>(xyz_dyn);
+    __shared__ int s_next;
+    __shared__ int s_hist[256];
+    const int per = 8 * p.wgs_per_row;
+    const int grp = (int)blockIdx.x / per, g8 = (int)blockIdx.x - grp * per;
+    const int b = grp * 8 + (g8 & 7), w = g8 >> 3;
+    if (b >= p.B) return;
+    const int n_obj = p.n_veh + p.n_poly;
+    const int c1 = max(0, min(p.n_pairs - w * p.chunk, p.chunk));
+    int* r0 = reinterpret_cast<int*>(lds + n_obj * PITCH);
+    int* r1 = r0 + p.chunk;
+    int* r2 = r1 + p.chunk;
+    unsigned* plist = reinterpret_cast<unsigned*>(r2 + p.chunk);
+    unsigned* pnat = plist + p.chunk;
+    int* ext = reinterpret_cast<int*>(pnat + p.chunk);
+    unsigned short* ord = reinterpret_cast<unsigned short*>(ext + 2 * n_obj);
+
+    // ---- stage: vehicles (rows x, y[, z] of the evaluation row) and padded polygons, point-major
+    const int vlen = p.dim * NC;
+    const double* Yrow = p.Y + (size_t)b * p.n_veh * vlen;
+    for (int e = threadIdx.x; e < n_obj * 4 * NC; e += blockDim.x) {
+        const int o = e / (4 * NC), r = e - o * (4 * NC), k = r >> 2, q = r & 3;
+        double val = 0.0;
+        if (o < p.n_veh) {
+            if (q < p.dim) val = Yrow[(size_t)o * vlen + q * NC + k];
+        } else if (q < 3) {
+            const int off = p.poly_off[o - p.n_veh], K = p.poly_off[o - p.n_veh + 1] - off;
+            val = p.poly[3 * off + q * K + (k < K ? k : 0)];       // padded with copies of vertex 0
+        }
+        lds[o * PITCH + r] = val;
+    }
+    __syncthreads();
+    // first two doSimplex steps: supports along (1,0,0) and (-1,-0,-0) depend on one object only
+    for (int o = threadIdx.x; o < n_obj; o += blockDim.x) {
+        const double* q = lds + o * PITCH;
+        int imx = 0, imn = 0;
+        double mx = q[0] * 1.0 + q[1] * 0.0 + q[2] * 0.0, mn = q[0] * -1.0 + q[1] * -0.0 + q[2] * -0.0;
+#pragma unroll
+        for (int i = 1; i < NC; ++i) {
+            const double v1 = q[4 * i] * 1.0 + q[4 * i + 1] * 0.0 + q[4 * i + 2] * 0.0;
+            const double v2 = q[4 * i] * -1.0 + q[4 * i + 1] * -0.0 + q[4 * i + 2] * -0.0;
+            if (v1 > mx) { mx = v1; imx = i; }
+            if (v2 > mn) { mn = v2; imn = i; }
+        }
+        ext[2 * o] = imx; ext[2 * o + 1] = imn;
+    }
+    // pair slots, in trip-count order of the previous sweep
+    {
+        auto slots_of = [&](int l) { const int kq = w * p.chunk + l; return (unsigned)p.pa[kq] | ((unsigned)p.pb[kq] << 16); };
+        if (p.len_in) {
+            const unsigned char* len = p.len_in + (size_t)b * p.len_in_stride + (size_t)w * p.chunk;
+            s_hist[threadIdx.x] = 0;
+            __syncthreads();
+            for (int l = threadIdx.x; l < c1; l += blockDim.x) atomicAdd(&s_hist[255 - len[l]], 1);
+            __syncthreads();
+            if (threadIdx.x < kWave) {
+                const int lane = threadIdx.x;
+                const int v0 = s_hist[4 * lane], v1 = s_hist[4 * lane + 1], v2 = s_hist[4 * lane + 2], v3 = s_hist[4 * lane + 3];
+                const int sum = v0 + v1 + v2 + v3;
+                int incl = sum;
+#pragma unroll
+                for (int dd = 1; dd < kWave; dd <<= 1) {
+                    const int t = __shfl_up(incl, dd);
+                    if (lane >= dd) incl += t;
+                }
+                const int excl = incl - sum;
+                s_hist[4 * lane] = excl; s_hist[4 * lane + 1] = excl + v0;
+                s_hist[4 * lane + 2] = excl + v0 + v1; s_hist[4 * lane + 3] = excl + v0 + v1 + v2;
+            }
+            __syncthreads();
+            for (int l = threadIdx.x; l < c1; l += blockDim.x) {
+                const int pos = atomicAdd(&s_hist[255 - len[l]], 1);
+                const unsigned ab = slots_of(l);
+                ord[pos] = (unsigned short)l; plist[pos] = ab; pnat[l] = ab;
+            }
+        } else {
+            for (int l = threadIdx.x; l < c1; l += blockDim.x) { ord[l] = (unsigned short)l; plist[l] = pnat[l] = slots_of(l); }
+        }
+    }
+    if (threadIdx.x == 0) s_next = 0;
+    __syncthreads();
+    const bool shortcut = p.max_iter >= 3 && p.md_cap >= 2;
+
+    // ---- phase 1
+    {
+        const int lane = threadIdx.x & (kWave - 1);
+        int k = -1, slot = 0, sa = 0, sb = 0;
+        bool exhausted = false;
+        const double* o1 = lds;
+        const double* o2 = lds;
+        Simplex s, old;
+        gjk::Checkpoint chk;
+        V3 dir{ 1.0, 0.0, 0.0 };
+        int phase = 0, it = 0, rr = 0, nsup = 0;
+        s.keys = 0;
+        s.A = Vert{ V3{ 0, 0, 0 }, 0, 0 };
+        s.B = s.A; s.C = s.A; s.D = s.A; old = s;
+        chk.start(s, dir);
+        for (;;) {
+            const unsigned long long want = __ballot(k < 0 && !exhausted);
+            if (want) {
+                const int leader = __ffsll((long long)want) - 1;
+                int base = 0;
+                if (lane == leader) base = atomicAdd(&s_next, __popcll(want));
+                base = __shfl(base, leader);
+                if (k < 0 && !exhausted) {
+                    const int my = base + __popcll(want & ((1ull << lane) - 1ull));
+                    if (my < c1) {
+                        k = my;
+                        slot = (int)ord[k];
+                        const unsigned ab = plist[k];
+                        sa = (int)(ab & 0xffffu); sb = (int)(ab >> 16);
+                        o1 = lds + sa * PITCH; o2 = lds + sb * PITCH;
+                        s.keys = 0; dir = V3{ 1.0, 0.0, 0.0 };
+                        phase = 0; it = 0; rr = 0; nsup = 0;
+                        if (shortcut) {
+                            const int ax = ext[2 * sa], an = ext[2 * sa + 1], bx = ext[2 * sb], bn = ext[2 * sb + 1];
+                            const Vert A1{ V3{ o1[4 * ax] - o2[4 * bn], o1[4 * ax + 1] - o2[4 * bn + 1], o1[4 * ax + 2] - o2[4 * bn + 2] }, ax, bn };
+                            const Vert A2{ V3{ o1[4 * an] - o2[4 * bx], o1[4 * an + 1] - o2[4 * bx + 1], o1[4 * an + 2] - o2[4 * bx + 2] }, an, bx };
+                            const bool md1 = gjk::dotb(A1.v, dir) < 0;
+                            dir = gjk::neg(dir);
+                            s.B = A1; s.A = A2; s.keys = gjk::kA | gjk::kB;
+                            nsup = 2;
+                            if (!md1) {
+                                it = 2;
+                                if (gjk::dotb(A2.v, dir) < 0) { phase = 1; rr = 0; chk.start(s, dir); }
+                            } else {
+                                // iteration 2 ran inside minimumDistance with old = {A: A1}
+                                phase = 1; rr = 1;
+                                const bool m = gjk::eq(A2.v, A1.v) ||
+                                    (A1.v.x == 0.0 && A1.v.y == 0.0 && A1.v.z == 0.0 &&
+                                     A2.v.x == o1[4 * ax] && A2.v.y == o1[4 * ax + 1] && A2.v.z == o1[4 * ax + 2] &&
+                                     A2.v.x == o2[4 * bn] && A2.v.y == o2[4 * bn + 1] && A2.v.z == o2[4 * bn + 2]);
+                                if (m) {
+                                    r0[slot] = (1 + 1) | (OBTG_ST_OK << 2) | (gjk::kA << 4) | (nsup << 10);
+                                    r1[slot] = A1.i1 | (A1.i2 << 8);
+                                    r2[slot] = 0;
+                                    k = -1;
+                                } else {
+                                    // the checkpoint of minimumDistance is the state at its entry: {A: A1}, dir (1,0,0)
+                                    Simplex e1; e1.keys = gjk::kA; e1.A = A1; e1.B = A1; e1.C = A1; e1.D = A1;
+                                    chk.start(e1, V3{ 1.0, 0.0, 0.0 });
+                                    if (chk.step(s, dir)) {   // cannot repeat after one round; keeps the counters aligned
+                                        r0[slot] = (1 + 1) | (OBTG_ST_CYCLE << 2) | (nsup << 10); r1[slot] = 0; r2[slot] = 0; k = -1;
+                                    }
+                                }
+                            }
+                        }
+                    } else exhausted = true;
+                }
+            }
+            if (__ballot(k >= 0) == 0ull) break;
+            if (k >= 0) {
+                if (phase == 1) old = s;
+                int flag = -2, status = OBTG_ST_OK;
+                if (gjk::simplex_update(s, dir)) {
+                    support_fixed3<NC>(o1, o2, dir, s.A);
+                    s.keys |= gjk::kA;
+                    ++nsup;
+                }
+                if (phase == 0) {
+                    ++it;
+                    if (s.keys & gjk::kColl) flag = 0;
+                    else if (gjk::dotb(s.A.v, dir) < 0) { phase = 1; rr = 0; chk.start(s, dir); }
+                    else if (it >= p.max_iter) { flag = -1; status = OBTG_ST_MAXITER; }
+                } else {
+                    ++rr;
+                    // matches_old through per-object bases: the stored indices address o1 / o2 directly
+                    auto pts_eq = [&](const Vert& ov, bool has, bool haspts) {
+                        if (has && gjk::eq(s.A.v, ov.v)) return true;
+                        return haspts && s.A.v.x == o1[4 * ov.i1] && s.A.v.y == o1[4 * ov.i1 + 1] && s.A.v.z == o1[4 * ov.i1 + 2] &&
+                               s.A.v.x == o2[4 * ov.i2] && s.A.v.y == o2[4 * ov.i2 + 1] && s.A.v.z == o2[4 * ov.i2 + 2];
+                    };
+                    const bool m = pts_eq(old.A, old.keys & gjk::kA, old.keys & gjk::kA) ||
+                                   pts_eq(old.B, old.keys & gjk::kB, old.keys & gjk::kB) ||
+                                   pts_eq(old.C, old.keys & gjk::kC, old.keys & gjk::kC) ||
+                                   pts_eq(old.D, old.keys & gjk::kD, old.keys & gjk::kDpts) ||
+                                   ((old.keys & gjk::kColl) && s.A.v.x == 1.0 && s.A.v.y == 1.0 && s.A.v.z == 1.0);
+                    if (m) flag = 1;
+                    else if (chk.step(s, dir)) { flag = 1; status = OBTG_ST_CYCLE; }
+                    else if (rr >= p.md_cap) { flag = 1; status = OBTG_ST_MD_CAP; }
+                }
+                if (flag != -2) {
+                    r0[slot] = (flag + 1) | (status << 2) | ((old.keys & 63) << 4) | (min(nsup, 0x3fffff) << 10);
+                    r1[slot] = old.A.i1 | (old.A.i2 << 8) | (old.B.i1 << 16) | (old.B.i2 << 24);
+                    r2[slot] = old.C.i1 | (old.C.i2 << 8) | (old.D.i1 << 16) | (old.D.i2 << 24);
+                    k = -1;
+                }
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- phase 2: closest points / distance from the recorded simplices (gjk.py:299-360), one lane per pair
+    const size_t obase = (size_t)b * p.n_pairs + (size_t)w * p.chunk;
+    const double qnan = __builtin_nan("");
+    for (int l = threadIdx.x; l < c1; l += blockDim.x) {
+        const unsigned ab2 = pnat[l];
+        const double* q1 = lds + (int)(ab2 & 0xffffu) * PITCH;
+        const double* q2 = lds + (int)(ab2 >> 16) * PITCH;
+        const int w0 = r0[l], w1 = r1[l], w2 = r2[l];
+        const int flag = (w0 & 3) - 1, status = (w0 >> 2) & 3, keys = (w0 >> 4) & 63, n_scans = (int)((unsigned)w0 >> 10);
+        Result r;
+        r.c1 = V3{ qnan, qnan, qnan }; r.c2 = r.c1; r.dist = qnan;
+        if (flag == 1 && status == OBTG_ST_OK) {
+            // gjk_device.h addresses coordinate c of point k of a set at `base` as mem(base + c*cs + k): with
+            // cs = 1 << 24 and bit 23 of the base telling the two objects apart, both resolve into LDS
+            struct MemTwo {
+                const double* a; const double* b2;
+                __device__ __forceinline__ double operator()(int idx) const
+                {
+                    const int kpt = idx & 0x7fffff, c = (idx >> 24) & 3;
+                    return (idx & 0x800000) ? b2[4 * kpt + c] : a[4 * kpt + c];
+                }
+            };
+            Ctx<MemTwo> g;
+            g.mem = MemTwo{ q1, q2 };
+            g.P1 = Poly{ 0, 1 << 24, NC, 1 };
+            g.P2 = Poly{ 0x800000, 1 << 24, NC, 1 };
+            g.trace = nullptr; g.trace_cap = 0; g.n_support = 0;
+            auto vert = [&](int i1, int i2) {
+                return Vert{ V3{ q1[4 * i1] - q2[4 * i2], q1[4 * i1 + 1] - q2[4 * i2 + 1], q1[4 * i1 + 2] - q2[4 * i2 + 2] }, i1, i2 };
+            };
+            Simplex s;
+            s.keys = keys;
+            s.A = vert(w1 & 0xff, (w1 >> 8) & 0xff);
+            s.B = vert((w1 >> 16) & 0xff, (w1 >> 24) & 0xff);
+            s.C = vert(w2 & 0xff, (w2 >> 8) & 0xff);
+            s.D = vert((w2 >> 16) & 0xff, (w2 >> 24) & 0xff);
+            gjk::closest_from_simplex(g, s, r);
+        }
+        const size_t o = obase + l;
+        p.flag[o] = flag;
+        p.p1[3 * o] = r.c1.x; p.p1[3 * o + 1] = r.c1.y; p.p1[3 * o + 2] = r.c1.z;
+        p.p2[3 * o] = r.c2.x; p.p2[3 * o + 1] = r.c2.y; p.p2[3 * o + 2] = r.c2.z;
+        p.dist[o] = r.dist;
+        if (p.nsup) p.nsup[o] = n_scans;
+        if (p.status) p.status[o] = status;
+        if (p.len_out) p.len_out[o] = (unsigned char)min(n_scans, 255);
+    }
+}
+
 // which vehicles of row b differ (bitwise) from row 0: chg[b][v]
 __global__ void k_changed_objects(const double* __restrict__ Y, int B, int n_veh, int vlen, unsigned char* __restrict__ chg)
 {
@@ -1702,6 +1987,50 @@ int launch_gjk_swarm(obtg_ctx* c, const double* dY, int B, int max_iter, int md_
                 c->gjk_len_cur ^= 1;
                 c->gjk_len_rows = B;
             }
+            OBTG_HIP(c, hipGetLastError());
+            return OBTG_OK;
+        }
+    }
+    if (!planar && !c->fd_dedup && c->max_poly_K <= c->deg + 1) {
+        // 3-D (or non-planar polygons): the fixed-point-count 3-D sweep when it is instantiated and fits
+        const int nc = c->deg + 1, n_obj = c->n_veh + c->n_poly;
+        void (*k3)(const GjkSwarmParams) = nullptr;
+        switch (nc) {
+            case 4: k3 = k_gjk_swarm_3d<4>; break;
+            case 6: k3 = k_gjk_swarm_3d<6>; break;
+            case 8: k3 = k_gjk_swarm_3d<8>; break;
+            case 11: k3 = k_gjk_swarm_3d<11>; break;
+            case 16: k3 = k_gjk_swarm_3d<16>; break;
+            default: break;
+        }
+        // Chunks: a pair of the 3-D machine can take 50 scans (cycling pairs run until the detector fires), and a
+        // workgroup lasts as long as its longest pair whatever its size -- so few large workgroups (one round of
+        // the chip) beat many small ones; split rows only for very small batches.
+        {
+            int wgs3 = (c->n_hull_pairs + OBTG_X_CHUNK - 1) / OBTG_X_CHUNK;
+            while ((long)B * wgs3 < 512 && (c->n_hull_pairs + wgs3 - 1) / wgs3 > 256) wgs3 <<= 1;
+            p.chunk = (c->n_hull_pairs + wgs3 - 1) / wgs3;
+            p.wgs_per_row = (c->n_hull_pairs + p.chunk - 1) / p.chunk;
+        }
+        const size_t lds3 = sweep3d_lds_bytes(n_obj, nc, p.chunk);
+        if (k3 && lds3 <= 64 * 1024 && p.chunk <= 65535) {
+            if (lds3 > 48 * 1024)
+                OBTG_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k3),
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3));
+            const size_t np = (size_t)c->n_hull_pairs;
+            obtg::DevBuf& hist_out = c->d_gjk_len[c->gjk_len_cur ^ 1];
+            if (int rc2 = hist_out.reserve((size_t)B * np)) return rc2;
+            p.B = B;
+            p.len_in = (c->gjk_history && c->gjk_len_rows > 0) ? c->d_gjk_len[c->gjk_len_cur].as<unsigned char>() : nullptr;
+            p.len_in_stride = c->gjk_len_rows == B ? (int)np : 0;
+            p.len_out = c->gjk_history ? hist_out.as<unsigned char>() : nullptr;
+            const unsigned grid = (unsigned)(((size_t)B + 7) / 8 * 8 * p.wgs_per_row);
+            {
+                ScopedKernelTimer t(c, OBTG_K_GJK);
+                hipLaunchKernelGGL(k3, dim3(grid), dim3(256), lds3, c->stream, p);
+            }
+            c->gjk_len_cur ^= 1;
+            c->gjk_len_rows = B;
             OBTG_HIP(c, hipGetLastError());
             return OBTG_OK;
         }
