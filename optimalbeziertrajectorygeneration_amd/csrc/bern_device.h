@@ -25,21 +25,12 @@ __device__ __forceinline__ ctab_t as_ctab(const double* p) { return (ctab_t)p; }
 // stores keep the 390 MB output stream from evicting the control points from L2 / Infinity
 // Cache (measured: -10 % kernel time on the temporal sweep).
 typedef double d2_t __attribute__((ext_vector_type(2)));
-#ifdef OBTG_X_PLAINSTORE
-__device__ __forceinline__ void store_nt(double* p, double v) { *p = v; }
-__device__ __forceinline__ void store_nt2(double* p, double v0, double v1)
-{
-    d2_t v; v.x = v0; v.y = v1;
-    *reinterpret_cast<d2_t*>(p) = v;
-}
-#else
 __device__ __forceinline__ void store_nt(double* p, double v) { __builtin_nontemporal_store(v, p); }
 __device__ __forceinline__ void store_nt2(double* p, double v0, double v1)
 {
     d2_t v; v.x = v0; v.y = v1;
     __builtin_nontemporal_store(v, reinterpret_cast<d2_t*>(p));
 }
-#endif
 
 // =====================================================================================
 //  fast path: register-resident product, one item per lane

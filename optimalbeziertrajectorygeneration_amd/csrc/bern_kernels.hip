@@ -27,9 +27,7 @@
 #include "obtg_internal.h"
 #include "bern_device.h"
 
-#ifndef OBTG_X_NSBUDGET
-#define OBTG_X_NSBUDGET (36 * 1024)   // LDS per workgroup of the temporal sweep: four workgroups per CU
-#endif
+constexpr size_t kNsLdsBudget = 36 * 1024;   // LDS per workgroup of the temporal sweep: four workgroups per CU
 
 namespace obtg {
 
@@ -720,7 +718,7 @@ static int launch_ns_t(obtg_ctx* c, NsParams p, int B, int kernel_id)
 {
     using S = NsShape<NC, DIM>;
     // the R > 0 path always transposes 64 rows x kTileK columns
-    const size_t budget = OBTG_X_NSBUDGET;   // => four workgroups (16 waves) per CU when it can be met
+    const size_t budget = kNsLdsBudget;   // => four workgroups (16 waves) per CU when it can be met
     const size_t stage = (size_t)p.stage_slots * S::VP * sizeof(double);
     size_t lds = 0;
     if (MINONLY) { p.tile_rows = 0; lds = stage; }

@@ -24,9 +24,7 @@
 #include "bern_device.h"
 #pragma clang fp contract(off)
 
-#ifndef OBTG_X_CHUNK
-#define OBTG_X_CHUNK 864     // hull pairs per workgroup of the planar sweep (see launch_gjk_swarm)
-#endif
+constexpr int kSweepChunk = 864;   // hull pairs per workgroup of the planar sweep (see launch_gjk_swarm)
 
 namespace obtg {
 
@@ -387,17 +385,11 @@ __host__ __device__ constexpr size_t planar_lds_bytes(int cap_obj, int vpq, int 
            4 * (size_t)chunk + 2 * (size_t)chunk + (MODE != 1 ? 2 * (size_t)chunk : 0);
 }
 
-#ifdef OBTG_X_WG512
-#define OBTG_SWEEP_THREADS 512
-#else
-#define OBTG_SWEEP_THREADS 256
-#endif
+#define OBTG_SWEEP_THREADS 256      // 512-thread workgroups (half as many stagings per row) measured no faster
 // Occupancy: the sweep is sensitive to waves per SIMD (C3: 2 / 3 / 4 / 5 waves = 0.58 / 0.17 / 0.153 /
 // 0.146 ms).  Five waves need <= 96 VGPRs (7 spilled at NC = 11) and <= 32 KB of LDS per workgroup,
 // hence 864-pair chunks; six waves (80 VGPRs, 24 spilled) lose again.
-#ifndef OBTG_X_SWEEP_WAVES
-#define OBTG_X_SWEEP_WAVES 5
-#endif
+constexpr int kSweepWavesPerSimd = 5;
 // (b_in, w_in): row / workgroup-in-row when the caller has already decoded them (>= 0: the one-launch
 // pair sweep), else decoded from blockIdx here.
 template <int NC, int MODE>
@@ -771,11 +763,8 @@ __device__ __forceinline__ void gjk_planar_body(const GjkSwarmParams& p, double2
 }
 
 template <int NC, int MODE>
-#ifndef OBTG_X_TILED_WAVES
-#define OBTG_X_TILED_WAVES 1
-#endif
 __global__ __launch_bounds__(MODE == 0 ? OBTG_SWEEP_THREADS : 256,
-                             (MODE == 0 && NC <= 11) ? OBTG_X_SWEEP_WAVES : (MODE == 2 ? OBTG_X_TILED_WAVES : 1))
+                             (MODE == 0 && NC <= 11) ? kSweepWavesPerSimd : 1)
 void k_gjk_swarm_planar(const GjkSwarmParams p)
 {
     extern __shared__ double2 xy_dyn[];
@@ -785,7 +774,7 @@ void k_gjk_swarm_planar(const GjkSwarmParams p)
 // the same grid when it also writes the temporal-separation blocks (p.ts.out set): own symbol, so that
 // profiles tell the pair sweep from the plain GJK sweep
 template <int NC>
-__global__ __launch_bounds__(OBTG_SWEEP_THREADS, NC <= 11 ? OBTG_X_SWEEP_WAVES : 1)
+__global__ __launch_bounds__(OBTG_SWEEP_THREADS, NC <= 11 ? kSweepWavesPerSimd : 1)
 void k_pair_sweep(const GjkSwarmParams p)
 {
     extern __shared__ double2 xy_dyn[];
@@ -1869,10 +1858,7 @@ int launch_gjk_swarm(obtg_ctx* c, const double* dY, int B, int max_iter, int md_
     // pairs per lane (measured at C3 in list order: 316 pairs per 256 lanes = 0.281 ms, 1264 pairs =
     // 0.215 ms); with the history order 864-pair chunks do as well as 1264 and leave LDS for a fifth
     // workgroup per CU.  Small batches trade chunk size for enough workgroups to fill the chip.
-    int wgs = (c->n_hull_pairs + OBTG_X_CHUNK - 1) / OBTG_X_CHUNK;
-#ifdef OBTG_X_WG512
-    wgs = (c->n_hull_pairs + 2559) / 2560;
-#endif
+    int wgs = (c->n_hull_pairs + kSweepChunk - 1) / kSweepChunk;
     while ((long)B * wgs < 2048 && (c->n_hull_pairs + wgs - 1) / wgs > 256) wgs <<= 1;
     p.chunk = (c->n_hull_pairs + wgs - 1) / wgs;
     p.wgs_per_row = (c->n_hull_pairs + p.chunk - 1) / p.chunk;
@@ -1884,11 +1870,7 @@ int launch_gjk_swarm(obtg_ctx* c, const double* dY, int B, int max_iter, int md_
     if (planar && c->max_poly_K <= c->deg + 1 && c->deg + 1 <= 127) {
         const int nc = c->deg + 1;
         const int vp2 = nc | 1;                    // object pitch in 16-byte points (PlanarShape<NC>::VPQ)
-#ifdef OBTG_X_GJKLDSPAD
-        const size_t lds2 = planar_lds_bytes<0>(c->n_veh + c->n_poly, vp2, p.chunk) + OBTG_X_GJKLDSPAD;
-#else
         const size_t lds2 = planar_lds_bytes<0>(c->n_veh + c->n_poly, vp2, p.chunk);
-#endif
         void (*kp)(const GjkSwarmParams) = nullptr;
         void (*kf)(const GjkSwarmParams) = nullptr;
         void (*kt)(const GjkSwarmParams) = nullptr;
@@ -1899,11 +1881,7 @@ int launch_gjk_swarm(obtg_ctx* c, const double* dY, int B, int max_iter, int md_
             default: break;
         }
 #undef OBTG_GJK_CASE
-#ifdef OBTG_X_WG512
-        constexpr size_t kTileAbove = 80 * 1024, kSweepMax = 80 * 1024;
-#else
         constexpr size_t kTileAbove = 48 * 1024, kSweepMax = 64 * 1024;
-#endif
         if (kt && lds2 > kTileAbove) {
             // large rows: tile-major chunks, each staging only the objects it touches
             int rc = build_tiles(c, vp2);
@@ -2007,7 +1985,7 @@ int launch_gjk_swarm(obtg_ctx* c, const double* dY, int B, int max_iter, int md_
         // workgroup lasts as long as its longest pair whatever its size -- so few large workgroups (one round of
         // the chip) beat many small ones; split rows only for very small batches.
         {
-            int wgs3 = (c->n_hull_pairs + OBTG_X_CHUNK - 1) / OBTG_X_CHUNK;
+            int wgs3 = (c->n_hull_pairs + kSweepChunk - 1) / kSweepChunk;
             while ((long)B * wgs3 < 512 && (c->n_hull_pairs + wgs3 - 1) / wgs3 > 256) wgs3 <<= 1;
             p.chunk = (c->n_hull_pairs + wgs3 - 1) / wgs3;
             p.wgs_per_row = (c->n_hull_pairs + p.chunk - 1) / p.chunk;
@@ -2072,7 +2050,7 @@ int launch_pair_sweep(obtg_ctx* c, const double* dY, int B, double max_sep, doub
         p.pa = c->d_hp_a.as<int>(); p.pb = c->d_hp_b.as<int>();
         p.n_veh = c->n_veh; p.dim = c->dim; p.nc = nc; p.n_poly = c->n_poly;
         p.n_poly_pts = c->n_poly_pts; p.n_pairs = c->n_hull_pairs;
-        int wgs = (c->n_hull_pairs + OBTG_X_CHUNK - 1) / OBTG_X_CHUNK;
+        int wgs = (c->n_hull_pairs + kSweepChunk - 1) / kSweepChunk;
         while ((long)B * wgs < 2048 && (c->n_hull_pairs + wgs - 1) / wgs > 256) wgs <<= 1;
         p.chunk = (c->n_hull_pairs + wgs - 1) / wgs;
         p.wgs_per_row = (c->n_hull_pairs + p.chunk - 1) / p.chunk;
