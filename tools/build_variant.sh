@@ -1,6 +1,7 @@
 #!/bin/bash
 # Build an experimental variant of libobtg_hip.so with extra -D flags for gjk_kernels.hip / bern_kernels.hip:
-#   tools/build_variant.sh NAME -DOBTG_X_FOO ...   ->  optimalbeziertrajectorygeneration_amd/exp_NAME.so
+#   tools/build_variant.sh NAME -DSOME_SWITCH=1 ...   ->  optimalbeziertrajectorygeneration_amd/exp_NAME.so
+# (for A/B experiments: put the switch in the source under #ifdef, build both, run the probes with OBTG_LIB set)
 # Select it at run time with OBTG_LIB=optimalbeziertrajectorygeneration_amd/exp_NAME.so (see _capi.py).
 set -e
 NAME=$1; shift
