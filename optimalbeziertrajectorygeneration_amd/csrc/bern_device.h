@@ -127,6 +127,15 @@ __device__ __forceinline__ void flush_full(const double* __restrict__ tile, doub
     const int total = n_valid * LR;
     const int shift = (int)(gbase & 1);   // make the 16-byte stores 16-byte aligned
     const int npairs = (total + shift + 1) >> 1;
+    if (LR == TP) {                       // the tile is the output run itself: no row / column arithmetic
+        for (int m = lane; m < npairs; m += kWave) {
+            const int e0 = 2 * m - shift, e1 = e0 + 1;
+            if (e0 >= 0 && e1 < total) store_nt2(gout + gbase + e0, tile[e0], tile[e1]);
+            else if (e0 >= 0) store_nt(gout + gbase + e0, tile[e0]);
+            else if (e1 < total) store_nt(gout + gbase + e1, tile[e1]);
+        }
+        return;
+    }
     for (int m = lane; m < npairs; m += kWave) {
         const int e0 = 2 * m - shift, e1 = e0 + 1;
         double v0 = 0.0, v1 = 0.0;
