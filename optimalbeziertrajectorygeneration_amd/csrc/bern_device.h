@@ -128,6 +128,12 @@ __device__ __forceinline__ void flush_full(const double* __restrict__ tile, doub
     const int shift = (int)(gbase & 1);   // make the 16-byte stores 16-byte aligned
     const int npairs = (total + shift + 1) >> 1;
     if (LR == TP) {                       // the tile is the output run itself: no row / column arithmetic
+        if (shift == 0 && (total & 1) == 0 && (reinterpret_cast<size_t>(tile) & 15) == 0) {
+            const d2_t* t2 = reinterpret_cast<const d2_t*>(tile);
+            d2_t* g2 = reinterpret_cast<d2_t*>(gout + gbase);
+            for (int m = lane; m < (total >> 1); m += kWave) __builtin_nontemporal_store(t2[m], g2 + m);
+            return;
+        }
         for (int m = lane; m < npairs; m += kWave) {
             const int e0 = 2 * m - shift, e1 = e0 + 1;
             if (e0 >= 0 && e1 < total) store_nt2(gout + gbase + e0, tile[e0], tile[e1]);
