@@ -2061,8 +2061,8 @@ int launch_pair_sweep(obtg_ctx* c, const double* dY, int B, double max_sep, doub
         // the transposition tile (4 waves x TR rows x odd(2n+1) doubles) borrows the LDS behind the objects
         const int L = 2 * c->deg + 1, tpf = (L % 2 == 0) ? L + 1 : L;
         const size_t behind = lds - (size_t)16 * n_obj * vpq;
-        int tr = 64;
-        while (tr >= 8 && (size_t)4 * tr * tpf * sizeof(double) > behind) tr >>= 1;
+        int tr = 64;                       // rows per transposition pass: the largest multiple of 8 that fits
+        while (tr >= 8 && (size_t)4 * tr * tpf * sizeof(double) > behind) tr -= 8;
         fused = tr >= 8 && lds <= 48 * 1024;
         p.ts.pairs = c->d_pairs.as<int2>(); p.ts.W2 = c->d_w2.as<double>(); p.ts.out = d_out_sep;
         p.ts.n_pairs = c->n_pairs; p.ts.sign = 1.0; p.ts.offset = -(max_sep * max_sep);
