@@ -715,6 +715,8 @@ int obtg_min_dist2poly(obtg_ctx* c, const double* curves, int n_curves, int K, c
     (void)hipSetDevice(c->device);
     DevBuf* m = c->ws_misc;
     auto soa = to_soa(pts, poly_off, n_poly);
+    int max_K = 0;
+    for (int a = 0; a < n_poly; ++a) max_K = std::max(max_K, poly_off[a + 1] - poly_off[a]);
     if ((rc = h2d(c, c->ws_in, curves, sizeof(double) * 3 * (size_t)K * n_curves))) return rc;
     if ((rc = h2d(c, c->ws_in2, soa.data(), soa.size() * sizeof(double)))) return rc;
     if ((rc = h2d(c, m[0], poly_off, sizeof(int) * (n_poly + 1)))) return rc;
@@ -725,7 +727,7 @@ int obtg_min_dist2poly(obtg_ctx* c, const double* curves, int n_curves, int K, c
     if ((rc = m[3].reserve(sizeof(int) * 4 * (size_t)n_pairs))) return rc;
     rc = launch_min_dist2poly(c, c->ws_in.as<double>(), K, c->ws_in2.as<double>(), m[0].as<int>(), m[1].as<int>(),
                               m[2].as<int>(), n_pairs, eps, max_iter, md_cap, max_depth, max_nodes,
-                              m[5].as<double>(), c->ws_out.as<double>(), m[3].as<int>());
+                              m[5].as<double>(), c->ws_out.as<double>(), m[3].as<int>(), max_K);
     if (rc) return rc;
     std::vector<int> hinfo((size_t)4 * n_pairs);
     OBTG_HIP(c, hipMemcpyAsync(hinfo.data(), m[3].p, sizeof(int) * 4 * n_pairs, hipMemcpyDeviceToHost, c->stream));

@@ -2111,6 +2111,128 @@ int launch_min_dist(obtg_ctx* c, const double* d_curves, int K, const int* d_pa,
     return OBTG_OK;
 }
 
+// _minDist2Poly with one (curve, polygon) pair per wavefront: as k_min_dist_wave, with the polygon (<= 32
+// vertices) copied to LDS once and only the curve in the frames.
+__global__ __launch_bounds__(64) void k_min_dist2poly_wave(const Md2Params p)
+{
+    extern __shared__ double m2_lds[];
+    const int k = blockIdx.x, lane = threadIdx.x, li = lane & 31;
+    const int K = p.K, FR = 3 * K + G_NSCAL;
+    const int po = p.off[p.pp[k]], PK = p.off[p.pp[k] + 1] - po;
+    double* cur = m2_lds;                       // [3K] curve of the node being evaluated
+    double* nxt = cur + 3 * K;                  // [3K] the child being built
+    double* pol = nxt + 3 * K;                  // [3][32] polygon, SoA
+    double* sh_e = pol + 3 * kMdMaxK;           // [kMdMaxK] (+ the three scratch rows of a split, with sh_q)
+    double* sh_q = sh_e + kMdMaxK;              // [kMdMaxK] + 2 rows
+    double* scs = sh_q + 3 * kMdMaxK;           // [max_depth][G_NSCAL]
+    double* st = p.stack + (size_t)k * p.max_depth * FR;
+    const double* ca = p.curves + (size_t)p.pc[k] * 3 * K;
+    for (int i = lane; i < 3 * K; i += kWave) { const double a = ca[i]; st[i] = a; cur[i] = a; }
+    for (int i = lane; i < 3 * PK; i += kWave) pol[(i / PK) * kMdMaxK + (i % PK)] = p.soa[3 * po + i];
+    if (lane == 0) { scs[G_T1L] = 0; scs[G_T1H] = 1; scs[G_ALPHA] = INFINITY; scs[G_STATE] = 0; }
+    __syncthreads();
+    int depth = 0, cur_depth = 0, nodes = 0, calls = 0, dmax = 0, status = OBTG_MD_OK;
+    double r0 = INFINITY, r1 = -1, rx = -1, ry = -1, rz = -1;
+    bool returning = false;
+    for (;;) {
+        double* f = st + (size_t)depth * FR;
+        double* sc = scs + depth * G_NSCAL;
+        int state = (int)sc[G_STATE];
+        if (!returning && state == 0) {
+            if (depth + 1 > 1000) { r0 = r1 = rx = -1; ry = rz = -1; returning = true; depth--; if (depth < 0) break; continue; }
+            if (nodes >= p.max_nodes) { status = OBTG_MD_NODE_CAP; break; }
+            nodes++;
+            if (depth + 1 > dmax) dmax = depth + 1;
+            Ctx<MemLds> g;
+            g.mem = MemLds{ m2_lds };
+            g.P1 = Poly{ (int)(cur - m2_lds), K, K, 1 };
+            g.P2 = Poly{ (int)(pol - m2_lds), kMdMaxK, PK, 1 };
+            g.trace = nullptr; g.trace_cap = 0; g.n_support = 0;
+            Result gr;
+            gjk::run<MemLds, false, true>(g, p.max_iter, p.md_cap, gr);
+            calls++;
+            if (gr.status == OBTG_ST_MD_CAP || gr.status == OBTG_ST_CYCLE) { status = OBTG_MD_GJK_CAP; break; }
+            double lb, t1, nT1, alpha = sc[G_ALPHA];
+            double cx, cy, cz;
+            if (gr.flag > 0) {
+                lb = gr.dist;
+                const double tp = hull_param_wave(cur, K, gr.c1, sh_e, sh_q, lane < 32 ? li : kMdMaxK);
+                t1 = __shfl(tp, 0);
+                cx = gr.c2.x; cy = gr.c2.y; cz = gr.c2.z;
+                const double d0 = norm_seq(cur[0], cur[K], cur[2 * K], cx, cy, cz);
+                const double d1 = norm_seq(cur[K - 1], cur[2 * K - 1], cur[3 * K - 1], cx, cy, cz);
+                int am = (d1 < d0) ? 1 : 0;
+                if (d0 != d0) am = 0; else if (d1 != d1) am = 1;
+                const double ub = am ? d1 : d0, t1loc = am ? 1.0 : 0.0;
+                if (ub <= alpha) { alpha = ub; nT1 = (1 - t1loc) * sc[G_T1L] + t1loc * sc[G_T1H]; }
+                else nT1 = -1;
+            } else {
+                t1 = 0.5; nT1 = -1; cx = cy = cz = -1; lb = p.eps * p.eps * p.eps;
+            }
+            if (lb >= alpha * (1 - p.eps)) {
+                r0 = alpha; r1 = nT1; rx = cx; ry = cy; rz = cz; returning = true; depth--;
+                if (depth < 0) break;
+                continue;
+            }
+            if (depth + 1 >= p.max_depth) { status = OBTG_MD_DEPTH_CAP; r0 = alpha; r1 = nT1; rx = cx; ry = cy; rz = cz; break; }
+            if (t1 != t1) t1 = 0;
+            wave_sync();
+            if (lane == 0) {
+                sc[G_T1] = t1; sc[G_ALPHA] = alpha; sc[G_RT1] = nT1; sc[G_PX] = cx; sc[G_PY] = cy; sc[G_PZ] = cz; sc[G_STATE] = 1;
+            }
+            wave_sync();
+            state = 1;
+        }
+        if (returning) {
+            if (r0 < sc[G_ALPHA]) {
+                wave_sync();
+                if (lane == 0) { sc[G_ALPHA] = r0; sc[G_RT1] = r1; sc[G_PX] = rx; sc[G_PY] = ry; sc[G_PZ] = rz; }
+                wave_sync();
+            }
+            returning = false;
+            state = (int)sc[G_STATE];
+        }
+        if (state >= 3) {
+            r0 = sc[G_ALPHA]; r1 = sc[G_RT1]; rx = sc[G_PX]; ry = sc[G_PY]; rz = sc[G_PZ];
+            returning = true; depth--;
+            if (depth < 0) break;
+            continue;
+        }
+        {
+            if (cur_depth != depth) {
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+                for (int i = lane; i < 3 * K; i += kWave) cur[i] = f[i];
+                cur_depth = depth;
+                wave_sync();
+            }
+            const int h1 = state - 1;
+            const double t1 = sc[G_T1];
+            double* nf = f + FR;
+            if (lane < 3) split_row_lds(cur + lane * K, K, t1, h1, nxt + lane * K, sh_e + lane * kMdMaxK);
+            wave_sync();
+            for (int i = lane; i < 3 * K; i += kWave) nf[i] = nxt[i];
+            const double t1len = sc[G_T1H] - sc[G_T1L];
+            const double m1 = sc[G_T1L] + t1 * t1len;
+            const double a_in = sc[G_ALPHA];
+            const double n1l = h1 ? m1 : sc[G_T1L], n1h = h1 ? sc[G_T1H] : m1;
+            wave_sync();
+            if (lane == 0) {
+                double* ns = sc + G_NSCAL;
+                ns[G_T1L] = n1l; ns[G_T1H] = n1h; ns[G_ALPHA] = a_in; ns[G_STATE] = 0;
+                sc[G_STATE] = state + 1;
+            }
+            double* tsw = cur; cur = nxt; nxt = tsw;
+            depth++;
+            cur_depth = depth;
+            wave_sync();
+        }
+    }
+    if (lane == 0) {
+        p.res[5 * k] = r0; p.res[5 * k + 1] = r1; p.res[5 * k + 2] = rx; p.res[5 * k + 3] = ry; p.res[5 * k + 4] = rz;
+        if (p.info) { p.info[4 * k] = nodes; p.info[4 * k + 1] = calls; p.info[4 * k + 2] = dmax; p.info[4 * k + 3] = status; }
+    }
+}
+
 int launch_min_dist_robust(obtg_ctx* c, const double* d_curves, int K, const int* d_pa, const int* d_pb, int n_pairs,
                            double eps, int max_nodes, int max_level, int cap, double* d_frontier, double* d_res, int* d_info)
 {
@@ -2127,14 +2249,18 @@ int launch_min_dist_robust(obtg_ctx* c, const double* d_curves, int K, const int
 int launch_min_dist2poly(obtg_ctx* c, const double* d_curves, int K, const double* d_soa,
                          const int* d_off, const int* d_pc, const int* d_pp, int n_pairs, double eps,
                          int max_iter, int md_cap, int max_depth, int max_nodes, double* d_stack,
-                         double* d_res, int* d_info)
+                         double* d_res, int* d_info, int max_poly_K)
 {
     if (n_pairs <= 0) return OBTG_OK;
     if (K < 2 || K > kMdMaxK || max_depth < 1) return OBTG_ERR_UNSUPPORTED;
     Md2Params p{ d_curves, d_soa, d_off, d_pc, d_pp, n_pairs, K, max_iter, md_cap, max_depth, max_nodes, eps,
                  d_stack, d_res, d_info };
     ScopedKernelTimer t(c, OBTG_K_MIN_DIST);
-    hipLaunchKernelGGL(k_min_dist2poly, dim3((n_pairs + 63) / 64), dim3(64), 0, c->stream, p);
+    const size_t lds_w = sizeof(double) * ((size_t)6 * K + 8 * kMdMaxK + (size_t)max_depth * G_NSCAL);
+    if (lds_w <= 48 * 1024 && max_poly_K <= kMdMaxK)      // one pair per wavefront
+        hipLaunchKernelGGL(k_min_dist2poly_wave, dim3((unsigned)n_pairs), dim3(kWave), lds_w, c->stream, p);
+    else
+        hipLaunchKernelGGL(k_min_dist2poly, dim3((n_pairs + 63) / 64), dim3(64), 0, c->stream, p);
     OBTG_HIP(c, hipGetLastError());
     return OBTG_OK;
 }

@@ -151,7 +151,7 @@ int launch_min_dist_robust(obtg_ctx* c, const double* d_curves, int K, const int
 int launch_min_dist2poly(obtg_ctx* c, const double* d_curves, int K, const double* d_soa,
                          const int* d_off, const int* d_pc, const int* d_pp, int n_pairs, double eps,
                          int max_iter, int md_cap, int max_depth, int max_nodes, double* d_stack,
-                         double* d_res, int* d_info);
+                         double* d_res, int* d_info, int max_poly_K);
 size_t min_dist_stack_doubles(int K, int max_depth);
 size_t min_dist2poly_stack_doubles(int K, int max_depth);
 
