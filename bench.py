@@ -51,7 +51,7 @@ def parse():
     ap.add_argument("--fd-dedup", action="store_true",
                     help="reuse row 0's gjkNew results for bit-identical hull pairs (obtg_ctx_set_fd_dedup); "
                          "NOT the headline number")
-    ap.add_argument("--mode", default="batch", choices=["batch", "pairs"],
+    ap.add_argument("--mode", default="batch", choices=["batch", "pairs", "mindist"],
                     help="batch: every rank evaluates its own FD batch, no collective (default, the headline); "
                          "pairs: ONE evaluation batch, the pair list partitioned over the ranks and the per-pair "
                          "separation minima all-gathered (RCCL) -- the 256-vehicle case of BASELINE.json")
@@ -158,6 +158,8 @@ def main():
 
     if args.mode == "pairs":
         return pairs_mode(args, ctx, dist, world, rank, dev, dY, B, max_sep, barrier)
+    if args.mode == "mindist":
+        return mindist_mode(args, rank)
 
     # warm-up, with events around every launch: finds the dominant kernel of this workload
     ctx.set_profiling(True)
@@ -303,6 +305,38 @@ def pairs_mode(args, ctx, dist, world, rank, dev, dY, B, max_sep, barrier):
                                    % (args.workload, ctx.num_pairs, world, B), "checksum": chk}}))
     if world > 1:
         dist.destroy_process_group()
+
+
+def mindist_mode(args, rank):
+    """The `_minDist` variant of the pair sweep, reported separately: one evaluation of
+    spatialSeparationConstraints (optimization.py:109-133) at the ComplexObstacles-style size of C5 -- all
+    C(96, 2) pairs of 64 vehicles and 32 curve obstacles -- through the host-buffer entry points, in the
+    reference's own algorithm (obtg_min_dist, node budget 2000 per pair: a fifth of the pairs would not
+    finish in the reference either) and in the robust one (obtg_min_dist_robust)."""
+    from optimalbeziertrajectorygeneration_amd import _capi, synth
+    N, M, n = 64, 32, 10
+    Yc = synth.swarm_control_points(N + M, 2, n, seed=1234)
+    curves = np.zeros((N + M, 3, n + 1))
+    curves[:, :2, :] = Yc.reshape(N + M, 2, n + 1)
+    pa, pb = np.triu_indices(N + M, 1)
+    ctx = _capi.scratch_context()
+    out = {}
+    for name, f in (("reference_algorithm", lambda: ctx.min_dist(curves, pa, pb, eps=1e-9, max_depth=128, max_nodes=2000)),
+                    ("robust", lambda: ctx.min_dist_robust(curves, pa, pb, eps=1e-9, max_nodes=400000))):
+        for _ in range(max(args.warmup // 10, 2)):
+            r = f()
+        reps = max(args.steps // 50, 5)
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            r = f()
+        ms = 1e3 * (time.perf_counter() - t0) / reps
+        out[name] = dict(ms_per_eval=round(ms, 3), evals_per_s=round(1e3 / ms, 2), pairs_per_s=round(len(pa) * 1e3 / ms, 1),
+                         status_counts=np.bincount(r["status"], minlength=4).tolist())
+    if rank == 0:
+        print(json.dumps({"metric": "spatial-separation (_minDist) evals/s, host buffers in and out", "value": out["reference_algorithm"]["evals_per_s"],
+                          "unit": "constraint-evals/s", "n_gpus": 1, "higher_is_better": True, "dtype": "f64", "data": "synthetic",
+                          "vs_baseline": None, "config": {"workload": "C5-style: 64 vehicles + 32 curve obstacles, degree 10, 4560 curve pairs per evaluation"},
+                          "variants": out}))
 
 
 def cpu_baseline(args, N, d, n, R, M, Y, polys, pa, pb, use_gjk, max_sep, vmax, wmax, tfv):
