@@ -741,3 +741,94 @@ def test_min_dist_robust_finds_the_true_minimum(capi, synth, golden_dir):
     rl = ctx.min_dist_robust(lit, [0, 2, 2, 0], [1, 1, 3, 4], eps=1e-9, max_nodes=400000)
     assert abs(rl["res"][0][0] - 0.125) < 1e-9 and abs(rl["res"][1][0] - np.sqrt(2)) < 1e-8
     assert rl["res"][2][0] < 1e-6 and np.isfinite(rl["res"][3][0])
+
+
+def test_pair_sweep_random_shapes(capi, synth):
+    """The one-launch pair sweep against the separate entry points over random swarm sizes, degrees with a
+    specialised kernel, polygon counts, batch sizes and pair-list lengths (odd counts, partial last groups,
+    rows that start on odd output offsets, one-row batches): every output bit-identical, twice (the second
+    launch runs in trip-count order)."""
+    import torch
+    rng = np.random.default_rng(2024)
+    dev = torch.device("cuda")
+    for trial in range(14):
+        n = int(rng.choice([3, 5, 7, 10]))
+        N = int(rng.integers(2, 70))
+        M = int(rng.integers(0, 7))
+        B = int(rng.choice([1, 2, 3, 9, 16, 33]))
+        Y = synth.swarm_control_points(N, 2, n, seed=100 + trial)
+        Yb = synth.fd_batch(Y, B=B, h=0.05) if B > 1 else Y[None].copy()
+        pa, pb = synth.swarm_pairs(N, M)
+        if len(pa) > 3 and trial % 3 == 0:                     # an arbitrary sub-list in shuffled order
+            sel = rng.permutation(len(pa))[:max(1, len(pa) * 2 // 3)]
+            pa, pb = pa[sel], pb[sel]
+        ctx = capi.Context(N, 2, n, 0)
+        if M:
+            polys = synth.polygon_obstacles(M, seed=trial)
+            polys = [p_[:min(len(p_), n + 1)] for p_ in polys]   # the planar kernel wants <= n+1 vertices
+            ctx.set_polygons(*synth.pack_polys(polys))
+        ctx.set_hull_pairs(pa, pb)
+        ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+        dY = torch.from_numpy(Yb).to(dev)
+        P, L, Ps = ctx.num_pairs, 2 * n + 1, len(pa)
+
+        def bufs():
+            return [torch.full((B, max(P, 1) * L), np.nan, dtype=torch.float64, device=dev),
+                    torch.full((B, Ps), -7, dtype=torch.int32, device=dev),
+                    torch.full((B, Ps, 3), -1.0, dtype=torch.float64, device=dev),
+                    torch.full((B, Ps, 3), -1.0, dtype=torch.float64, device=dev),
+                    torch.full((B, Ps), -1.0, dtype=torch.float64, device=dev),
+                    torch.zeros((B, Ps), dtype=torch.int32, device=dev),
+                    torch.full((B, Ps), -7, dtype=torch.int32, device=dev)]
+        a, b = bufs(), bufs()
+        for rnd in range(2):
+            if P:
+                ctx.temporal_sep_dev(dY.data_ptr(), B, 0.9, a[0].data_ptr())
+            ctx.gjk_swarm_dev(dY.data_ptr(), B, a[1].data_ptr(), a[2].data_ptr(), a[3].data_ptr(), a[4].data_ptr(),
+                              a[5].data_ptr(), a[6].data_ptr(), 128, 300)
+            ctx.pair_sweep_dev(dY.data_ptr(), B, 0.9, b[0].data_ptr(), b[1].data_ptr(), b[2].data_ptr(), b[3].data_ptr(),
+                               b[4].data_ptr(), b[5].data_ptr(), b[6].data_ptr(), 128, 300)
+            torch.cuda.synchronize()
+            for i, (x, y) in enumerate(zip(a, b)):
+                assert np.array_equal(x.cpu().numpy(), y.cpu().numpy(), equal_nan=True), (trial, rnd, i, N, n, M, B, Ps)
+        ctx.set_stream(0)
+        ctx.close()
+
+
+def test_gjk_swarm_3d_random_shapes(capi, oracle, synth):
+    """The 3-D sweep kernel (k_gjk_swarm_3d) against the oracle over random 3-D swarms with 3-D polygon
+    obstacles (padded to n+1 points), several rows, twice (second call in trip-count order): flags, statuses
+    (incl. the cycle detector's) and support counts exact, distances / closest points to 1e-12."""
+    rng = np.random.default_rng(77)
+    for trial in range(8):
+        n = int(rng.choice([3, 5, 7, 10]))
+        N = int(rng.integers(2, 40))
+        M = int(rng.integers(0, 5))
+        B = int(rng.choice([1, 2, 5]))
+        Y = synth.swarm_control_points(N, 3, n, seed=300 + trial)
+        Yb = synth.fd_batch(Y, B=B, h=0.3) if B > 1 else Y[None].copy()
+        polys = []
+        for _ in range(M):
+            K = int(rng.integers(3, n + 2))
+            polys.append(rng.uniform(0, 100, size=(1, 3)) + rng.normal(0, 6.0, size=(K, 3)))
+        pa, pb = synth.swarm_pairs(N, M)
+        ctx = capi.Context(N, 3, n, 0)
+        if M:
+            ctx.set_polygons(*synth.pack_polys(polys))
+        else:
+            ctx.set_polygons(None, [0])
+        ctx.set_hull_pairs(pa, pb)
+        for rnd in range(2):
+            r = ctx.gjk_swarm(Yb, md_cap=400)
+            for b in range(B):
+                hp, ho = synth.pack_polys(synth.hulls_from_Y(Yb[b], 3) + polys)
+                o = oracle.gjk_pairs(hp, ho, pa, pb, md_cap=400, nthreads=8)
+                tag = (trial, rnd, b, N, n, M)
+                assert (r["flag"][b] == o["flag"]).all(), tag
+                assert (r["status"][b] == o["status"]).all(), tag
+                assert (r["n_support"][b] == o["n_support"]).all(), tag
+                sep = (o["flag"] == 1) & (o["status"] == 0)
+                for key in ("dist", "c1", "c2"):
+                    if sep.any():
+                        assert np.max(np.abs(r[key][b][sep] - o[key][sep]) / np.maximum(1.0, np.abs(o[key][sep]))) < 1e-12, tag
+        ctx.close()
