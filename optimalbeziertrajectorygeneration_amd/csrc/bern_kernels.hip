@@ -22,6 +22,7 @@
 // Everything here is float64.  Parity target is 1e-9 relative, so fused multiply-adds and
 // the symmetric folding of the product are allowed in this translation unit.
 #include <algorithm>
+#include <type_traits>
 #include <cstdio>
 
 #include "obtg_internal.h"
@@ -457,22 +458,28 @@ __global__ __launch_bounds__(kWave) void k_generic_normsq_elev(const GenParams p
 // lives in registers as a circular buffer (slot (i - t) mod 8), so a step costs one broadcast LDS
 // read (ah[t]) and one vector LDS read (the new window element) for 8 FMAs -- 0.25 LDS reads per
 // FMA instead of 2 for the one-output-per-lane form.
-__device__ __forceinline__ void conv_tile8(const double* ah, int la8, const double* bp, int pad, int k0,
-                                           double (&s)[8])
+template <int T = 8>
+__device__ __forceinline__ void conv_tile(const double* ah, int la8, const double* bp, int pad, int k0,
+                                          double (&s)[T])
 {
+    static_assert(T == 4 || T == 8, "window sizes with a cheap modulus");
     const double* q = bp + pad + k0;
-    double Rw[8];
+    double Rw[T];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) { Rw[i] = q[i]; s[i] = 0.0; }
-    for (int j = 0; j < la8; j += 8) {
+    for (int i = 0; i < T; ++i) { Rw[i] = q[i]; s[i] = 0.0; }
+    for (int j = 0; j < la8; j += T) {          // la8 is a multiple of 8
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
+        for (int u = 0; u < T; ++u) {
             const double a = ah[j + u];
 #pragma unroll
-            for (int i = 0; i < 8; ++i) s[i] = fma(a, Rw[(i - u) & 7], s[i]);
-            Rw[(-(u + 1)) & 7] = q[-(j + u + 1)];      // window element 0 of step t+1
+            for (int i = 0; i < T; ++i) s[i] = fma(a, Rw[(i - u) & (T - 1)], s[i]);
+            Rw[(-(u + 1)) & (T - 1)] = q[-(j + u + 1)];      // window element 0 of step t+1
         }
     }
+}
+__device__ __forceinline__ void conv_tile8(const double* ah, int la8, const double* bp, int pad, int k0, double (&s)[8])
+{
+    conv_tile<8>(ah, la8, bp, pad, k0, s);
 }
 
 // generic angular rate: one wave per (row, vehicle); m = n + R
@@ -551,23 +558,29 @@ __global__ __launch_bounds__(kWave) void k_generic_angrate(const GenParams p)
     __syncthreads();
     const double *xD = h1, *yD = h1 + mc8, *xDD = h2, *yDD = h2 + mc8;
     // num1 = yDD*xD - xDD*yD, den1 = xD*xD + yD*yD  (degree 2m), 8 coefficients per lane
-    for (int k0 = 8 * lane; k0 < L2; k0 += 8 * kWave) {
-        double t1[8], t2[8], e1[8], e2[8];
-        conv_tile8(yDD, mc8, xp, padm, k0, t1);
-        conv_tile8(xDD, mc8, yp, padm, k0, t2);
-        conv_tile8(xD, mc8, xp, padm, k0, e1);
-        conv_tile8(yD, mc8, yp, padm, k0, e2);
+    // (4 per lane while that keeps more lanes busy: 2m+1 outputs are 28 lanes' worth of 8 at m = 110)
+    auto stage2 = [&](auto tile_tag) {
+        constexpr int T = decltype(tile_tag)::value;
+        for (int k0 = T * lane; k0 < L2; k0 += T * kWave) {
+            double t1[T], t2[T], e1[T], e2[T];
+            conv_tile<T>(yDD, mc8, xp, padm, k0, t1);
+            conv_tile<T>(xDD, mc8, yp, padm, k0, t2);
+            conv_tile<T>(xD, mc8, xp, padm, k0, e1);
+            conv_tile<T>(yD, mc8, yp, padm, k0, e2);
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int k = k0 + i;
-            if (k < L2) {
-                const double c = b2m[k];
-                const double nk = (t1[i] / c - t2[i] / c) * c, dk = (e1[i] / c + e2[i] / c) * c;
-                nu[k] = nk; de[k] = dk;
-                np_[padf + k] = nk; dp_[padf + k] = dk;
+            for (int i = 0; i < T; ++i) {
+                const int k = k0 + i;
+                if (k < L2) {
+                    const double c = b2m[k];
+                    const double nk = (t1[i] / c - t2[i] / c) * c, dk = (e1[i] / c + e2[i] / c) * c;
+                    nu[k] = nk; de[k] = dk;
+                    np_[padf + k] = nk; dp_[padf + k] = dk;
+                }
             }
         }
-    }
+    };
+    if (L2 <= 4 * kWave) stage2(std::integral_constant<int, 4>{});
+    else stage2(std::integral_constant<int, 8>{});
     __syncthreads();
     double* o = p.out + ((size_t)b * p.n_veh + veh) * L4;
     for (int k0 = 8 * lane; k0 < L4; k0 += 8 * kWave) {
