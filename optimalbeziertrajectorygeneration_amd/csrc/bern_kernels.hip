@@ -482,6 +482,13 @@ __device__ __forceinline__ void conv_tile8(const double* ah, int la8, const doub
     conv_tile<8>(ah, la8, bp, pad, k0, s);
 }
 
+// the squares of the generic angular rate take the balanced schedule when their 8-output tiles pair up
+__host__ __device__ inline bool angrate_balanced(int m)
+{
+    const int T = (4 * m + 1 + 7) / 8;
+    return T % 4 == 0 && T / 2 <= 32;
+}
+
 // generic angular rate: one wave per (row, vehicle); m = n + R
 __global__ __launch_bounds__(kWave) void k_generic_angrate(const GenParams p)
 {
@@ -489,22 +496,25 @@ __global__ __launch_bounds__(kWave) void k_generic_angrate(const GenParams p)
     const int lane = threadIdx.x;
     const int n = p.n, nc = n + 1, m = n + p.R, mc = m + 1, L2 = 2 * m + 1, L4 = 4 * m + 1;
     const int mc8 = (mc + 7) & ~7, L28 = (L2 + 7) & ~7;
-    const int padm = mc8, padf = L28;                    // leading zeros of the padded b-operands
+    // leading zeros of the padded b-operands: a whole operand length for the plain sliding-window products; the
+    // balanced schedule of the squares never reaches further back than one tile
+    const bool balanced = angrate_balanced(m);
+    const int padm = mc8, padf = balanced ? 8 : L28;
     const int szm = padm + L2 + 16, szf = padf + L4 + 16;
     const long gi = blockIdx.x;
     const int b = (int)(gi / p.n_veh), veh = (int)(gi - (long)b * p.n_veh);
-    double* pe = lds;              // [2][mc] elevated position
-    double* d1 = pe + 2 * mc;      // [2][mc] first derivative (plain)
+    // LDS (the occupancy of this kernel is set by it: 18 KB per item at m = 110, two waves per SIMD):
+    //   h2 | xp | yp | np_ | dp_ ; the elevation / derivative scratch lives inside np_/dp_, which are not
+    //   needed before the degree-2m products have been read out of h2 / xp / yp.
+    double* h2 = lds;              // [2][mc8] C(m,.) * d2, zero padded   (a-operands xDD, yDD)
+    double* xp = h2 + 2 * mc8;     // [szm]  zero-padded C(m,.) * xD      (b-operand; xp + padm is the a-operand xD)
+    double* yp = xp + szm;         // [szm]  zero-padded C(m,.) * yD
+    double* np_ = yp + szm;        // [szf]  zero-padded C(2m,.) * num1   (np_ + padf is the a-operand of the square)
+    double* dp_ = np_ + szf;       // [szf]  zero-padded C(2m,.) * den1
+    double* pe = np_;              // [2][mc] elevated position           } scratch of the first stage,
+    double* d1 = pe + 2 * mc;      // [2][mc] first derivative (plain)    } 8 mc <= 2 szf doubles
     double* d2 = d1 + 2 * mc;      // [2][mc] second derivative (plain)
     double* tm = d2 + 2 * mc;      // [2][mc] scratch
-    double* h1 = tm + 2 * mc;      // [2][mc8] C(m,.) * d1, zero padded   (a-operands)
-    double* h2 = h1 + 2 * mc8;     // [2][mc8] C(m,.) * d2, zero padded
-    double* xp = h2 + 2 * mc8;     // [szm]  zero-padded C(m,.) * xD      (b-operands)
-    double* yp = xp + szm;         // [szm]  zero-padded C(m,.) * yD
-    double* nu = yp + szm;         // [L28]  C(2m,.) * num1, zero padded
-    double* de = nu + L28;         // [L28]  C(2m,.) * den1, zero padded
-    double* np_ = de + L28;        // [szf]  zero-padded nu
-    double* dp_ = np_ + szf;       // [szf]  zero-padded de
     const double* bn = p.bin + p.o_n;
     const double* bR = p.bin + p.o_R;
     const double* bm = p.bin + p.o_m;
@@ -513,8 +523,8 @@ __global__ __launch_bounds__(kWave) void k_generic_angrate(const GenParams p)
     const double* v = p.Y + ((size_t)b * p.n_veh + veh) * 2 * nc;
     const double val = (double)m / p.tf[b];
 
-    // zero everything that is read as padding
-    for (int e = lane; e < 4 * mc8 + 2 * szm + 2 * L28 + 2 * szf; e += kWave) h1[e] = 0.0;
+    // zero everything that is read as padding (np_/dp_ are cleared after the first stage has used them)
+    for (int e = lane; e < 2 * mc8 + 2 * szm; e += kWave) h2[e] = 0.0;
     // pos.elev(R)  (optimization.py:453)
     if (p.R == 0) {
         for (int e = lane; e < 2 * nc; e += kWave) pe[e] = v[e];
@@ -550,13 +560,14 @@ __global__ __launch_bounds__(kWave) void k_generic_angrate(const GenParams p)
     }
     for (int e = lane; e < 2 * mc; e += kWave) {
         const int q = e / mc, c = e - q * mc;
-        const double s1 = d1[e] * bm[c];
-        h1[q * mc8 + c] = s1;
         h2[q * mc8 + c] = d2[e] * bm[c];
-        (q == 0 ? xp : yp)[padm + c] = s1;
+        (q == 0 ? xp : yp)[padm + c] = d1[e] * bm[c];
     }
     __syncthreads();
-    const double *xD = h1, *yD = h1 + mc8, *xDD = h2, *yDD = h2 + mc8;
+    for (int e = lane; e < 2 * szf; e += kWave) np_[e] = 0.0;      // the scratch is dead: now the padded squares' operands
+    __syncthreads();
+    const double *xD = xp + padm, *yD = yp + padm, *xDD = h2, *yDD = h2 + mc8;
+    const double *nu = np_ + padf, *de = dp_ + padf;
     // num1 = yDD*xD - xDD*yD, den1 = xD*xD + yD*yD  (degree 2m), 8 coefficients per lane
     // (4 per lane while that keeps more lanes busy: 2m+1 outputs are 28 lanes' worth of 8 at m = 110)
     auto stage2 = [&](auto tile_tag) {
@@ -573,7 +584,6 @@ __global__ __launch_bounds__(kWave) void k_generic_angrate(const GenParams p)
                 if (k < L2) {
                     const double c = b2m[k];
                     const double nk = (t1[i] / c - t2[i] / c) * c, dk = (e1[i] / c + e2[i] / c) * c;
-                    nu[k] = nk; de[k] = dk;
                     np_[padf + k] = nk; dp_[padf + k] = dk;
                 }
             }
@@ -583,6 +593,68 @@ __global__ __launch_bounds__(kWave) void k_generic_angrate(const GenParams p)
     else stage2(std::integral_constant<int, 8>{});
     __syncthreads();
     double* o = p.out + ((size_t)b * p.n_veh + veh) * L4;
+    const int T = (L4 + 7) / 8, H = T / 2;              // output tiles of 8; the index range of a square is a triangle:
+    if (balanced) {                                      // tile t needs j in [lo(t), hi(t)), longest in the middle
+        // Balanced schedule: tiles (t, H-1-t) and (H+t, T-1-t) have complementary lengths, so a lane that walks
+        // such a pair in ONE loop does ~(la8 + 8) steps whatever t is -- half the lanes of the plain scheme for
+        // the same time -- and the two squares run side by side: lanes 0..H-1 on num1^2, lanes 32..32+H-1 on
+        // den1^2.  Every tile is summed by one lane in ascending j, exactly as conv_tile does.
+        const int side = lane >> 5, slot = lane & 31;
+        const bool active = slot < H;
+        const bool rising = slot < H / 2;
+        const int i0 = rising ? slot : slot - H / 2;
+        const int ta = rising ? i0 : T - 1 - i0;         // the short tile first
+        const int tb = rising ? H - 1 - i0 : H + i0;
+        auto lo_of = [&](int t) { const int v = 8 * t - (L2 - 1); return v > 0 ? (v & ~7) : 0; };
+        auto hi_of = [&](int t) { return min(L28, 8 * t + 8); };
+        const int ja0 = lo_of(ta), la = active ? hi_of(ta) - ja0 : 0;
+        const int jb0 = lo_of(tb), lb = active ? hi_of(tb) - jb0 : 0;
+        int total = la + lb;
+#pragma unroll
+        for (int msk = 32; msk >= 1; msk >>= 1) total = max(total, __shfl_xor(total, msk));   // wave-uniform trip count
+        const double* ah = side ? de : nu;
+        const double* bq = (side ? dp_ : np_) + padf;
+        double s8[8], first[8], Rw[8];
+        const double* q = bq + 8 * ta;
+        int j = ja0, left = la;                          // current segment: tile pointer q, next j, steps left
+        bool second = false;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { Rw[i] = q[i - j]; s8[i] = 0.0; first[i] = 0.0; }
+        for (int v = 0; v < total; v += 8) {
+            if (left == 0 && !second) {                  // switch to the long tile
+#pragma unroll
+                for (int i = 0; i < 8; ++i) { first[i] = s8[i]; s8[i] = 0.0; }
+                q = bq + 8 * tb; j = jb0; left = lb; second = true;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) Rw[i] = q[i - j];
+            }
+            if (left > 0) {
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const double a = ah[j + u];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) s8[i] = fma(a, Rw[(i - u) & 7], s8[i]);
+                    Rw[(-(u + 1)) & 7] = q[-(j + u + 1)];
+                }
+                j += 8; left -= 8;
+            }
+        }
+        if (!second) {                                   // la == total cannot happen (lb > 0), kept for safety
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { first[i] = s8[i]; s8[i] = 0.0; }
+        }
+        // quotients: the num lane of a slot takes den's sums from lane + 32
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const double da = __shfl(first[i], (lane & 31) + 32), db = __shfl(s8[i], (lane & 31) + 32);
+            if (side == 0 && active) {
+                const int ka = 8 * ta + i, kb = 8 * tb + i;
+                if (ka < L4) o[ka] = p.offset - (first[i] / b4m[ka]) / (da / b4m[ka]);
+                if (kb < L4) o[kb] = p.offset - (s8[i] / b4m[kb]) / (db / b4m[kb]);
+            }
+        }
+        return;
+    }
     for (int k0 = 8 * lane; k0 < L4; k0 += 8 * kWave) {
         double sn[8], sd[8];
         conv_tile8(nu, L28, np_, padf, k0, sn);
@@ -1039,8 +1111,9 @@ int launch_ang_rate(obtg_ctx* c, const double* dY, const double* d_tf, int B, do
     if (m > 250) return OBTG_ERR_UNSUPPORTED;   // C(4m,2m) must stay finite in binary64
     g.Y = dY; g.tf = d_tf; g.out = d_out; g.B = B; g.offset = max_rate * max_rate;
     const int mc8 = (mc + 7) & ~7, L28 = (L2 + 7) & ~7;
-    size_t lds = sizeof(double) * ((size_t)8 * mc + 4 * mc8 + 2 * (mc8 + L2 + 16) + 2 * L28 +
-                                   2 * (L28 + (4 * m + 1) + 16));
+    const int padf = angrate_balanced(m) ? 8 : L28;
+    size_t lds = sizeof(double) * ((size_t)2 * mc8 + 2 * (mc8 + L2 + 16) + 2 * (padf + (4 * m + 1) + 16));
+    if ((size_t)8 * mc > (size_t)2 * (padf + (4 * m + 1) + 16)) return OBTG_ERR_UNSUPPORTED;   // first-stage scratch lives in there
     if (lds > 160 * 1024) return OBTG_ERR_UNSUPPORTED;
     if (lds > 48 * 1024)
         OBTG_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_generic_angrate),
