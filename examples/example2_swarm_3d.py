@@ -1,0 +1,54 @@
+#!/usr/bin/env python3
+"""The flow of the reference's swarm driver (Examples/SwarmOfAerialVehicles.py:137-170: 3-D, degree 5,
+Euclidean objective, temporal separation as the only constraint, SLSQP) on the MI355X path, on a
+synthetic crossing swarm instead of the image-derived targets.  Solved twice: with SciPy's own finite
+differences over the callback, and with the structured Jacobian provider (one `jac` key more).
+
+    python examples/example2_swarm_3d.py [numVeh]
+"""
+import os
+import sys
+import time
+
+import numpy as np
+import scipy.optimize as sop
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from optimalbeziertrajectorygeneration_amd.optimization import BezOptimization  # was: from optimization import ...
+
+
+def crossing_swarm(numVeh, seed=3):
+    """Vehicles start on a line at z = 0 and end on the mirrored line at z = 10: every straight path crosses the others'."""
+    rng = np.random.default_rng(seed)
+    xs = np.arange(numVeh) * 2.0
+    init = np.stack([xs, np.zeros(numVeh), np.zeros(numVeh)], axis=1)
+    final = np.stack([xs[::-1], np.full(numVeh, 1.0), np.full(numVeh, 10.0)], axis=1)
+    return init + rng.normal(0, 0.05, init.shape), final + rng.normal(0, 0.05, final.shape)
+
+
+def solve(numVeh=5, with_jac=True, maxiter=400):
+    init, final = crossing_swarm(numVeh)
+    bezopt = BezOptimization(numVeh=numVeh, dimension=3, degree=5, minimizeGoal='Euclidean', maxSep=0.9,
+                             initPoints=init, finalPoints=final)
+    x0 = bezopt.generateGuess(std=0.2, seed=1)
+    con = {'type': 'ineq', 'fun': bezopt.temporalSeparationConstraints}
+    if with_jac:
+        con['jac'] = bezopt.temporalSeparationJacobian
+    t0 = time.time()
+    res = sop.minimize(bezopt.objectiveFunction, x0=x0, method='SLSQP', constraints=[con],
+                       options={'maxiter': maxiter, 'disp': False})
+    return bezopt, res, time.time() - t0
+
+
+def main():
+    numVeh = int(sys.argv[1]) if len(sys.argv) > 1 else 5
+    for with_jac in (False, True):
+        bezopt, res, dt = solve(numVeh, with_jac)
+        sep = bezopt.temporalSeparationConstraints(res.x)
+        print('%-28s objective %.6f  nit %3d  nfev %5d  converged %s  min separation margin %+.2e  %.2f s'
+              % ('structured Jacobian provider' if with_jac else 'SciPy finite differences', res.fun, res.nit, res.nfev,
+                 res.success, sep.min(), dt))
+
+
+if __name__ == '__main__':
+    main()

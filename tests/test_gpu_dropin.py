@@ -251,3 +251,22 @@ def test_min_dist_robust_option():
     x[-1] = 10
     out = bo.spatialSeparationConstraints(x, robust=True)      # Examples/ComplexObstacles.py:19-52: the reference does not finish here
     assert out.shape == (3, 3) and np.isfinite(out).all()
+
+
+def test_swarm_3d_driver_flow():
+    """examples/example2_swarm_3d.py: the reference swarm driver's flow (3-D, degree 5, Euclidean objective,
+    temporal separation) converges to a feasible solution, and handing SLSQP the structured Jacobian
+    provider leads to the same optimum as SciPy's finite differences over the callback."""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location(
+        "example2", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples", "example2_swarm_3d.py"))
+    ex = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ex)
+    bo, r_fd, _ = ex.solve(5, with_jac=False)
+    _, r_j, _ = ex.solve(5, with_jac=True)
+    assert r_fd.success and r_j.success
+    assert bo.temporalSeparationConstraints(r_fd.x).min() > -1e-6 and bo.temporalSeparationConstraints(r_j.x).min() > -1e-6
+    assert abs(r_fd.fun - r_j.fun) < 1e-4 * max(1.0, abs(r_fd.fun))
+    # the straight-line guess is infeasible (the paths cross): the constraint did real work
+    assert bo.temporalSeparationConstraints(bo.generateGuess(std=0)).min() < 0
