@@ -482,12 +482,70 @@ __device__ __forceinline__ void conv_tile8(const double* ah, int la8, const doub
     conv_tile<8>(ah, la8, bp, pad, k0, s);
 }
 
-// the squares of the generic angular rate take the balanced schedule when their 8-output tiles pair up
-__host__ __device__ inline bool angrate_balanced(int m)
+// Balanced schedule of a product  c = a * b  with len(a) = len(b) = L data entries (zero beyond).  Output tile t
+// (T consecutive coefficients) needs j in [lo(t), hi(t)) -- a triangle over t, longest in the middle -- and
+// tiles (t, H-1-t), (H+t, Tn-1-t) have complementary lengths (Tn tiles, H = Tn / 2), so a lane that walks such
+// a pair in ONE loop does about len(a) + T steps whatever t is: half the lanes of "one tile per lane" for the
+// same time, and no multiplications by padding zeros.  Lanes 0..H-1 of a half-wave take the H pairs; the two
+// half-waves run two products side by side.  Every tile is summed by one lane in ascending j, as conv_tile does.
+// b is addressed as bq[k - j] and must be readable (zeros) for T entries before its start.
+__host__ __device__ inline bool conv_pairs_ok(int n_out, int T)
 {
-    const int T = (4 * m + 1 + 7) / 8;
-    return T % 4 == 0 && T / 2 <= 32;
+    const int Tn = (n_out + T - 1) / T;
+    return Tn % 4 == 0 && Tn / 2 <= 32;
 }
+
+template <int T>
+__device__ __forceinline__ void conv_pairs(const double* ah, const double* bq, int L, int La8, int n_out, int slot,
+                                           int& ta, int& tb, double (&first)[T], double (&second)[T])
+{
+    const int Tn = (n_out + T - 1) / T, H = Tn / 2;
+    const bool active = slot < H;
+    const bool rising = slot < H / 2;
+    const int i0 = rising ? slot : slot - H / 2;
+    ta = rising ? i0 : Tn - 1 - i0;                    // the short tile first
+    tb = rising ? H - 1 - i0 : H + i0;
+    auto lo_of = [&](int t) { const int v = T * t - (L - 1); return v > 0 ? (v & ~(T - 1)) : 0; };
+    auto hi_of = [&](int t) { return min(La8, T * t + T); };
+    const int ja0 = lo_of(ta), la = active ? hi_of(ta) - ja0 : 0;
+    const int jb0 = lo_of(tb), lb = active ? hi_of(tb) - jb0 : 0;
+    int total = la + lb;
+#pragma unroll
+    for (int msk = 32; msk >= 1; msk >>= 1) total = max(total, __shfl_xor(total, msk));   // wave-uniform trip count
+    double Rw[T];
+    const double* q = bq + T * ta;
+    int j = ja0, left = la;                            // current segment: tile pointer q, next j, steps left
+    bool on_second = false;
+#pragma unroll
+    for (int i = 0; i < T; ++i) { Rw[i] = q[i - j]; second[i] = 0.0; first[i] = 0.0; }
+    for (int v = 0; v < total; v += T) {
+        if (left == 0 && !on_second) {                 // switch to the long tile
+#pragma unroll
+            for (int i = 0; i < T; ++i) { first[i] = second[i]; second[i] = 0.0; }
+            q = bq + T * tb; j = jb0; left = lb; on_second = true;
+#pragma unroll
+            for (int i = 0; i < T; ++i) Rw[i] = q[i - j];
+        }
+        if (left > 0) {
+#pragma unroll
+            for (int u = 0; u < T; ++u) {
+                const double a = ah[j + u];
+#pragma unroll
+                for (int i = 0; i < T; ++i) second[i] = fma(a, Rw[(i - u) & (T - 1)], second[i]);
+                Rw[(-(u + 1)) & (T - 1)] = q[-(j + u + 1)];
+            }
+            j += T; left -= T;
+        }
+    }
+    if (!on_second) {
+#pragma unroll
+        for (int i = 0; i < T; ++i) { first[i] = second[i]; second[i] = 0.0; }
+    }
+}
+
+// the products of the generic angular rate that take the balanced schedule
+__host__ __device__ inline bool angrate_balanced(int m) { return conv_pairs_ok(4 * m + 1, 8); }
+__host__ __device__ inline bool angrate_balanced2(int m) { return conv_pairs_ok(2 * m + 1, 4) && 2 * m + 1 <= 4 * 64; }
 
 // generic angular rate: one wave per (row, vehicle); m = n + R
 __global__ __launch_bounds__(kWave) void k_generic_angrate(const GenParams p)
@@ -498,8 +556,8 @@ __global__ __launch_bounds__(kWave) void k_generic_angrate(const GenParams p)
     const int mc8 = (mc + 7) & ~7, L28 = (L2 + 7) & ~7;
     // leading zeros of the padded b-operands: a whole operand length for the plain sliding-window products; the
     // balanced schedule of the squares never reaches further back than one tile
-    const bool balanced = angrate_balanced(m);
-    const int padm = mc8, padf = balanced ? 8 : L28;
+    const bool balanced = angrate_balanced(m), balanced2 = angrate_balanced2(m);
+    const int padm = balanced2 ? 8 : mc8, padf = balanced ? 8 : L28;
     const int szm = padm + L2 + 16, szf = padf + L4 + 16;
     const long gi = blockIdx.x;
     const int b = (int)(gi / p.n_veh), veh = (int)(gi - (long)b * p.n_veh);
@@ -589,68 +647,48 @@ __global__ __launch_bounds__(kWave) void k_generic_angrate(const GenParams p)
             }
         }
     };
-    if (L2 <= 4 * kWave) stage2(std::integral_constant<int, 4>{});
+    if (balanced2) {
+        // two products side by side per pass: (yDD * xD | xDD * yD) -> num1, then (xD * xD | yD * yD) -> den1
+        const int side = lane >> 5, slot = lane & 31;
+        const int Hn = ((L2 + 3) / 4) / 2;
+        for (int pass = 0; pass < 2; ++pass) {
+            const double* ah = pass == 0 ? (side ? xDD : yDD) : (side ? yD : xD);
+            const double* bq = (pass == 0 ? (side ? yp : xp) : (side ? yp : xp)) + padm;
+            double fa[4], fb[4];
+            int ta, tb;
+            conv_pairs<4>(ah, bq, mc, mc8, L2, slot, ta, tb, fa, fb);
+            double* dst = pass == 0 ? np_ : dp_;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const double oa = __shfl(fa[i], slot + 32), ob = __shfl(fb[i], slot + 32);
+                if (side == 0 && slot < Hn) {
+                    const int ka = 4 * ta + i, kb = 4 * tb + i;
+                    // the sums are C(2m,k) times the Bernstein coefficients, which is the scaling the next
+                    // product wants: no division by C(2m,k) and multiplication back
+                    if (ka < L2) dst[padf + ka] = pass == 0 ? fa[i] - oa : fa[i] + oa;
+                    if (kb < L2) dst[padf + kb] = pass == 0 ? fb[i] - ob : fb[i] + ob;
+                }
+            }
+        }
+    } else if (L2 <= 4 * kWave) stage2(std::integral_constant<int, 4>{});
     else stage2(std::integral_constant<int, 8>{});
     __syncthreads();
     double* o = p.out + ((size_t)b * p.n_veh + veh) * L4;
-    const int T = (L4 + 7) / 8, H = T / 2;              // output tiles of 8; the index range of a square is a triangle:
-    if (balanced) {                                      // tile t needs j in [lo(t), hi(t)), longest in the middle
-        // Balanced schedule: tiles (t, H-1-t) and (H+t, T-1-t) have complementary lengths, so a lane that walks
-        // such a pair in ONE loop does ~(la8 + 8) steps whatever t is -- half the lanes of the plain scheme for
-        // the same time -- and the two squares run side by side: lanes 0..H-1 on num1^2, lanes 32..32+H-1 on
-        // den1^2.  Every tile is summed by one lane in ascending j, exactly as conv_tile does.
+    if (balanced) {
         const int side = lane >> 5, slot = lane & 31;
-        const bool active = slot < H;
-        const bool rising = slot < H / 2;
-        const int i0 = rising ? slot : slot - H / 2;
-        const int ta = rising ? i0 : T - 1 - i0;         // the short tile first
-        const int tb = rising ? H - 1 - i0 : H + i0;
-        auto lo_of = [&](int t) { const int v = 8 * t - (L2 - 1); return v > 0 ? (v & ~7) : 0; };
-        auto hi_of = [&](int t) { return min(L28, 8 * t + 8); };
-        const int ja0 = lo_of(ta), la = active ? hi_of(ta) - ja0 : 0;
-        const int jb0 = lo_of(tb), lb = active ? hi_of(tb) - jb0 : 0;
-        int total = la + lb;
-#pragma unroll
-        for (int msk = 32; msk >= 1; msk >>= 1) total = max(total, __shfl_xor(total, msk));   // wave-uniform trip count
-        const double* ah = side ? de : nu;
-        const double* bq = (side ? dp_ : np_) + padf;
-        double s8[8], first[8], Rw[8];
-        const double* q = bq + 8 * ta;
-        int j = ja0, left = la;                          // current segment: tile pointer q, next j, steps left
-        bool second = false;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) { Rw[i] = q[i - j]; s8[i] = 0.0; first[i] = 0.0; }
-        for (int v = 0; v < total; v += 8) {
-            if (left == 0 && !second) {                  // switch to the long tile
-#pragma unroll
-                for (int i = 0; i < 8; ++i) { first[i] = s8[i]; s8[i] = 0.0; }
-                q = bq + 8 * tb; j = jb0; left = lb; second = true;
-#pragma unroll
-                for (int i = 0; i < 8; ++i) Rw[i] = q[i - j];
-            }
-            if (left > 0) {
-#pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const double a = ah[j + u];
-#pragma unroll
-                    for (int i = 0; i < 8; ++i) s8[i] = fma(a, Rw[(i - u) & 7], s8[i]);
-                    Rw[(-(u + 1)) & 7] = q[-(j + u + 1)];
-                }
-                j += 8; left -= 8;
-            }
-        }
-        if (!second) {                                   // la == total cannot happen (lb > 0), kept for safety
-#pragma unroll
-            for (int i = 0; i < 8; ++i) { first[i] = s8[i]; s8[i] = 0.0; }
-        }
+        const int H = ((L4 + 7) / 8) / 2;
+        double first[8], s8[8];
+        int ta, tb;
+        conv_pairs<8>(side ? de : nu, (side ? dp_ : np_) + padf, L2, L28, L4, slot, ta, tb, first, s8);
         // quotients: the num lane of a slot takes den's sums from lane + 32
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-            const double da = __shfl(first[i], (lane & 31) + 32), db = __shfl(s8[i], (lane & 31) + 32);
-            if (side == 0 && active) {
+            const double da = __shfl(first[i], slot + 32), db = __shfl(s8[i], slot + 32);
+            if (side == 0 && slot < H) {
                 const int ka = 8 * ta + i, kb = 8 * tb + i;
-                if (ka < L4) o[ka] = p.offset - (first[i] / b4m[ka]) / (da / b4m[ka]);
-                if (kb < L4) o[kb] = p.offset - (s8[i] / b4m[kb]) / (db / b4m[kb]);
+                // num.cpts / den.cpts element-wise (optimization.py:608): the common factor C(4m,k) cancels
+                if (ka < L4) o[ka] = p.offset - first[i] / da;
+                if (kb < L4) o[kb] = p.offset - s8[i] / db;
             }
         }
         return;
@@ -1111,8 +1149,8 @@ int launch_ang_rate(obtg_ctx* c, const double* dY, const double* d_tf, int B, do
     if (m > 250) return OBTG_ERR_UNSUPPORTED;   // C(4m,2m) must stay finite in binary64
     g.Y = dY; g.tf = d_tf; g.out = d_out; g.B = B; g.offset = max_rate * max_rate;
     const int mc8 = (mc + 7) & ~7, L28 = (L2 + 7) & ~7;
-    const int padf = angrate_balanced(m) ? 8 : L28;
-    size_t lds = sizeof(double) * ((size_t)2 * mc8 + 2 * (mc8 + L2 + 16) + 2 * (padf + (4 * m + 1) + 16));
+    const int padf = angrate_balanced(m) ? 8 : L28, padm = angrate_balanced2(m) ? 8 : mc8;
+    size_t lds = sizeof(double) * ((size_t)2 * mc8 + 2 * (padm + L2 + 16) + 2 * (padf + (4 * m + 1) + 16));
     if ((size_t)8 * mc > (size_t)2 * (padf + (4 * m + 1) + 16)) return OBTG_ERR_UNSUPPORTED;   // first-stage scratch lives in there
     if (lds > 160 * 1024) return OBTG_ERR_UNSUPPORTED;
     if (lds > 48 * 1024)
