@@ -558,7 +558,9 @@ __global__ __launch_bounds__(kWave) void k_generic_angrate(const GenParams p)
     // balanced schedule of the squares never reaches further back than one tile
     const bool balanced = angrate_balanced(m), balanced2 = angrate_balanced2(m);
     const int padm = balanced2 ? 8 : mc8, padf = balanced ? 8 : L28;
-    const int szm = padm + L2 + 16, szf = padf + L4 + 16;
+    // b-operand buffers: the plain sliding window reads zeros up to the product's length, the balanced schedule
+    // only within one tile of the data
+    const int szm = padm + (balanced2 ? mc : L2) + 16, szf = padf + (balanced ? L2 : L4) + 16;
     const long gi = blockIdx.x;
     const int b = (int)(gi / p.n_veh), veh = (int)(gi - (long)b * p.n_veh);
     // LDS (the occupancy of this kernel is set by it: 18 KB per item at m = 110, two waves per SIMD):
@@ -1149,9 +1151,11 @@ int launch_ang_rate(obtg_ctx* c, const double* dY, const double* d_tf, int B, do
     if (m > 250) return OBTG_ERR_UNSUPPORTED;   // C(4m,2m) must stay finite in binary64
     g.Y = dY; g.tf = d_tf; g.out = d_out; g.B = B; g.offset = max_rate * max_rate;
     const int mc8 = (mc + 7) & ~7, L28 = (L2 + 7) & ~7;
-    const int padf = angrate_balanced(m) ? 8 : L28, padm = angrate_balanced2(m) ? 8 : mc8;
-    size_t lds = sizeof(double) * ((size_t)2 * mc8 + 2 * (padm + L2 + 16) + 2 * (padf + (4 * m + 1) + 16));
-    if ((size_t)8 * mc > (size_t)2 * (padf + (4 * m + 1) + 16)) return OBTG_ERR_UNSUPPORTED;   // first-stage scratch lives in there
+    const bool bal = angrate_balanced(m), bal2 = angrate_balanced2(m);
+    const int padf = bal ? 8 : L28, padm = bal2 ? 8 : mc8;
+    const size_t szm = padm + (bal2 ? mc : L2) + 16, szf = padf + (bal ? L2 : 4 * m + 1) + 16;
+    // the first stage's scratch (8 mc doubles) starts where the squares' operands (2 szf) will live
+    size_t lds = sizeof(double) * ((size_t)2 * mc8 + 2 * szm + std::max((size_t)2 * szf, (size_t)8 * mc));
     if (lds > 160 * 1024) return OBTG_ERR_UNSUPPORTED;
     if (lds > 48 * 1024)
         OBTG_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_generic_angrate),
