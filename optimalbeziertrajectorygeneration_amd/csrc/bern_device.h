@@ -254,7 +254,7 @@ __device__ __forceinline__ void normsq_elev_body(const NsParams& p, const int b,
     const double* Yrow = p.Y + (size_t)b * p.n_veh * S::VLEN;
     // three staging schemes:
     //   stage_all  (small swarms): every object of the row, slot == object id;
-    //   tiling     (large swarms): the workgroup owns rows ti0..ti0+n_waves-1 of the pair
+    //   tiling     (large swarms): the workgroup owns rows ti0..ti0+groups_per_wg-1 of the pair
     //              triangle restricted to the 64-wide column window [tj0, tj0+64): it stages
     //              n_waves + 64 objects, each wave handles one row segment (contiguous pairs);
     //   otherwise: a chunk of lexicographic pairs touches rows i0..i0+nI-1 (segment I), the
@@ -265,8 +265,8 @@ __device__ __forceinline__ void normsq_elev_body(const NsParams& p, const int b,
     } else if (MODE == 0 && p.tiling) {
         const int2 t = p.tiles[w];
         ti0 = t.x; tj0 = t.y;
-        stage_objects<NC, DIM>(vl, Yrow, p.obs, p.n_veh, ti0, min(n_waves, p.n_obj - ti0), 0, threadIdx.x, blockDim.x);
-        stage_objects<NC, DIM>(vl, Yrow, p.obs, p.n_veh, tj0, min(kWave, p.n_obj - tj0), n_waves, threadIdx.x, blockDim.x);
+        stage_objects<NC, DIM>(vl, Yrow, p.obs, p.n_veh, ti0, min(p.groups_per_wg, p.n_obj - ti0), 0, threadIdx.x, blockDim.x);
+        stage_objects<NC, DIM>(vl, Yrow, p.obs, p.n_veh, tj0, min(kWave, p.n_obj - tj0), p.groups_per_wg, threadIdx.x, blockDim.x);
     } else if (MODE == 0) {
         const int2 f = p.pairs[it0], l = p.pairs[it_end - 1];
         i0 = f.x; nI = l.x - f.x + 1;
@@ -291,19 +291,19 @@ __device__ __forceinline__ void normsq_elev_body(const NsParams& p, const int b,
         int n_valid, lane0 = 0, si = 0, sj = 0, item = 0;
         size_t row;
         if (MODE == 0 && p.tiling) {
-            const int i = ti0 + wave;
-            if (g != wave || i >= p.n_obj - 1) break;
+            const int i = ti0 + g;                        // group g of the tile = its row g
+            if (i >= p.n_obj - 1) break;
             const int j = tj0 + lane;
             const long tri = (long)i * p.n_obj - (long)i * (i + 1) / 2 - i - 1;   // p(i,j) = tri + j
             const long pidx = tri + j;
             const bool valid = j > i && j < p.n_obj && pidx >= p.item_begin &&
                                pidx < (long)p.item_begin + p.item_count;
             const unsigned long long m = __ballot(valid);
-            if (m == 0ull) break;
+            if (m == 0ull) continue;                      // (a later row of the tile may still be inside a partition's pair range)
             lane0 = __ffsll((long long)m) - 1;
             n_valid = __popcll(m);
-            si = wave;
-            sj = n_waves + (min(j, p.n_obj - 1) - tj0);
+            si = g;
+            sj = p.groups_per_wg + (min(j, p.n_obj - 1) - tj0);
             row = (size_t)b * p.item_count + (size_t)(tri + tj0 + lane0 - p.item_begin);
         } else {
             const int itg = it0 + g * kWave;
