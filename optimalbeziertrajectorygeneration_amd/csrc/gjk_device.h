@@ -446,7 +446,14 @@ __device__ __forceinline__ void closest_from_simplex(const Ctx<Mem>& g, const Si
 //    dotb(a,b)          = fma(a.y,b.y, a.x*b.x);   dot(a,b) = a.x*b.x + a.y*b.y
 // =====================================================================================
 struct V2 { double x, y; };
-struct Vert2 { V2 v; int i1, i2; };
+// support indices packed i1 | i2 << 16 (one register per vertex: the planar sweeps copy simplices every step)
+struct Vert2 {
+    V2 v;
+    int ii;
+    __device__ __forceinline__ int i1() const { return ii & 0xffff; }
+    __device__ __forceinline__ int i2() const { return (int)((unsigned)ii >> 16); }
+};
+__device__ __forceinline__ int pack_ii(int i1, int i2) { return i1 | (i2 << 16); }
 struct Simplex2 { Vert2 A, B, C; int keys; };
 
 __device__ __forceinline__ double cz(const V2& a, const V2& b) { return a.x * b.y - a.y * b.x; }
@@ -486,7 +493,7 @@ __device__ __forceinline__ void support_pts2(Ctx<Mem>& g, const V2& dir, Vert2& 
         const double c2 = sdot<Mem, true>(g.mem, g.P2, j, nd);
         if (c2 > m2) { m2 = c2; i2 = j; }
     }
-    out.i1 = i1; out.i2 = i2;
+    out.ii = pack_ii(i1, i2);
     out.v = sub2(point2(g.mem, g.P1, i1), point2(g.mem, g.P2, i2));
     if (g.trace && g.n_support < g.trace_cap) {
         g.trace[2 * g.n_support] = (short)i1;
@@ -551,7 +558,7 @@ __device__ __forceinline__ bool vert_matches2(const Ctx<Mem>& g, const Vert2& o,
     // A == p1 and A == p2 forces p1 == p2, i.e. the old vertex p1 - p2 is exactly zero: test that
     // in registers first, the point loads are then needed (almost) never
     if (o.v.x != 0.0 || o.v.y != 0.0) return false;
-    return eq2(A, point2(g.mem, g.P1, o.i1)) && eq2(A, point2(g.mem, g.P2, o.i2));
+    return eq2(A, point2(g.mem, g.P1, o.i1())) && eq2(A, point2(g.mem, g.P2, o.i2()));
 }
 
 template <class Mem>
@@ -566,9 +573,9 @@ __device__ __forceinline__ bool matches_old2(const Ctx<Mem>& g, const Simplex2& 
 __device__ __forceinline__ Simplex lift(const Simplex2& s)
 {
     Simplex r;
-    r.A = Vert{ V3{ s.A.v.x, s.A.v.y, 0.0 }, s.A.i1, s.A.i2 };
-    r.B = Vert{ V3{ s.B.v.x, s.B.v.y, 0.0 }, s.B.i1, s.B.i2 };
-    r.C = Vert{ V3{ s.C.v.x, s.C.v.y, 0.0 }, s.C.i1, s.C.i2 };
+    r.A = Vert{ V3{ s.A.v.x, s.A.v.y, 0.0 }, s.A.i1(), s.A.i2() };
+    r.B = Vert{ V3{ s.B.v.x, s.B.v.y, 0.0 }, s.B.i1(), s.B.i2() };
+    r.C = Vert{ V3{ s.C.v.x, s.C.v.y, 0.0 }, s.C.i1(), s.C.i2() };
     r.D = r.A;
     r.keys = s.keys;
     return r;

@@ -121,7 +121,7 @@ __device__ __forceinline__ void gjk_sweep_planar(int c_end, int* s_next, int max
     gjk::V2 dir{ 1.0, 0.0 };
     int phase = 0, it = 0, rr = 0;
     s.keys = 0;
-    s.A = gjk::Vert2{ gjk::V2{ 0, 0 }, 0, 0 };
+    s.A = gjk::Vert2{ gjk::V2{ 0, 0 }, 0 };
     s.B = s.A; s.C = s.A; old = s;
     const double qnan = __builtin_nan("");
     for (;;) {
@@ -350,7 +350,7 @@ __device__ __forceinline__ void support_fixed(const double2* __restrict__ o1, co
         m1 = __builtin_fmax(m1, c1);
         m2 = __builtin_fmax(m2, c2);
     }
-    out.i1 = i1; out.i2 = i2;
+    out.ii = gjk::pack_ii(i1, i2);
     const double2 w1 = o1[i1], w2 = o2[i2];
     out.v = gjk::V2{ w1.x - w2.x, w1.y - w2.y };
 }
@@ -390,6 +390,9 @@ __host__ __device__ constexpr size_t planar_lds_bytes(int cap_obj, int vpq, int 
 // 0.146 ms).  Five waves need <= 96 VGPRs (7 spilled at NC = 11) and <= 32 KB of LDS per workgroup,
 // hence 864-pair chunks; six waves (80 VGPRs, 24 spilled) lose again.
 constexpr int kSweepWavesPerSimd = 5;
+// packed support indices (i1 | i2 << 16) as the 16-bit record form i1 | i2 << 8 (indices < 128 here)
+__device__ __forceinline__ int rec8(int ii) { return (ii & 0xff) | ((ii >> 8) & 0xff00); }
+
 // (b_in, w_in): row / workgroup-in-row when the caller has already decoded them (>= 0: the one-launch
 // pair sweep), else decoded from blockIdx here.
 template <int NC, int MODE>
@@ -576,7 +579,7 @@ __device__ __forceinline__ void gjk_planar_body(const GjkSwarmParams& p, double2
         V2 dir{ 1.0, 0.0 };
         int phase = 0, it = 0, rr = 0, nsup = 0;
         s.keys = 0;
-        s.A = Vert2{ V2{ 0, 0 }, 0, 0 };
+        s.A = Vert2{ V2{ 0, 0 }, 0 };
         s.B = s.A; s.C = s.A; old = s;
         for (;;) {
             const unsigned long long want = __ballot(k < 0 && !exhausted);
@@ -600,8 +603,8 @@ __device__ __forceinline__ void gjk_planar_body(const GjkSwarmParams& p, double2
                             // state after doSimplex #1 (0pt) and #2 (1pt)
                             const int ax = ext[2 * a], an = ext[2 * a + 1], bx = ext[2 * bb], bn = ext[2 * bb + 1];
                             const double2 pax = o1[ax], pbn = o2[bn], pan = o1[an], pbx = o2[bx];
-                            const Vert2 A1{ V2{ pax.x - pbn.x, pax.y - pbn.y }, ax, bn };
-                            const Vert2 A2{ V2{ pan.x - pbx.x, pan.y - pbx.y }, an, bx };
+                            const Vert2 A1{ V2{ pax.x - pbn.x, pax.y - pbn.y }, gjk::pack_ii(ax, bn) };
+                            const Vert2 A2{ V2{ pan.x - pbx.x, pan.y - pbx.y }, gjk::pack_ii(an, bx) };
                             const bool md1 = gjk::dotb2(A1.v, dir) < 0;       // exit of iteration 1 (gjk.py:260)
                             dir = gjk::neg2(dir);
                             s.B = A1; s.A = A2; s.keys = gjk::kA | gjk::kB;
@@ -617,7 +620,7 @@ __device__ __forceinline__ void gjk_planar_body(const GjkSwarmParams& p, double2
                                      A2.v.x == pbn.x && A2.v.y == pbn.y);
                                 if (m) {
                                     r01[slot] = make_int2((1 + 1) | (OBTG_ST_OK << 2) | (gjk::kA << 4) | (nsup << 8),
-                                                          A1.i1 | (A1.i2 << 8));
+                                                          rec8(A1.ii));
                                     r2[slot] = 0;
                                     k = -1;
                                 }
@@ -644,21 +647,21 @@ __device__ __forceinline__ void gjk_planar_body(const GjkSwarmParams& p, double2
                     // converged iff the new A equals any value of the old dict (gjk.py:281-294)
                     bool m = false;
                     if ((old.keys & gjk::kA) && (gjk::eq2(s.A.v, old.A.v) ||
-                        (old.A.v.x == 0.0 && old.A.v.y == 0.0 && s.A.v.x == o1[old.A.i1].x && s.A.v.y == o1[old.A.i1].y &&
-                         s.A.v.x == o2[old.A.i2].x && s.A.v.y == o2[old.A.i2].y))) m = true;
+                        (old.A.v.x == 0.0 && old.A.v.y == 0.0 && s.A.v.x == o1[old.A.i1()].x && s.A.v.y == o1[old.A.i1()].y &&
+                         s.A.v.x == o2[old.A.i2()].x && s.A.v.y == o2[old.A.i2()].y))) m = true;
                     if ((old.keys & gjk::kB) && (gjk::eq2(s.A.v, old.B.v) ||
-                        (old.B.v.x == 0.0 && old.B.v.y == 0.0 && s.A.v.x == o1[old.B.i1].x && s.A.v.y == o1[old.B.i1].y &&
-                         s.A.v.x == o2[old.B.i2].x && s.A.v.y == o2[old.B.i2].y))) m = true;
+                        (old.B.v.x == 0.0 && old.B.v.y == 0.0 && s.A.v.x == o1[old.B.i1()].x && s.A.v.y == o1[old.B.i1()].y &&
+                         s.A.v.x == o2[old.B.i2()].x && s.A.v.y == o2[old.B.i2()].y))) m = true;
                     if ((old.keys & gjk::kC) && (gjk::eq2(s.A.v, old.C.v) ||
-                        (old.C.v.x == 0.0 && old.C.v.y == 0.0 && s.A.v.x == o1[old.C.i1].x && s.A.v.y == o1[old.C.i1].y &&
-                         s.A.v.x == o2[old.C.i2].x && s.A.v.y == o2[old.C.i2].y))) m = true;
+                        (old.C.v.x == 0.0 && old.C.v.y == 0.0 && s.A.v.x == o1[old.C.i1()].x && s.A.v.y == o1[old.C.i1()].y &&
+                         s.A.v.x == o2[old.C.i2()].x && s.A.v.y == o2[old.C.i2()].y))) m = true;
                     if (m) flag = 1;
                     else if (rr >= p.md_cap) { flag = 1; status = OBTG_ST_MD_CAP; }
                 }
                 if (flag != -2) {
                     r01[slot] = make_int2((flag + 1) | (status << 2) | ((old.keys & 7) << 4) | (min(nsup, 0xffffff) << 8),
-                                          old.A.i1 | (old.A.i2 << 8) | (old.B.i1 << 16) | (old.B.i2 << 24));
-                    r2[slot] = (unsigned short)(old.C.i1 | (old.C.i2 << 8));
+                                          rec8(old.A.ii) | (rec8(old.B.ii) << 16));
+                    r2[slot] = (unsigned short)rec8(old.C.ii);
                     k = -1;
                 }
             }
