@@ -161,6 +161,13 @@ def main():
     if args.mode == "mindist":
         return mindist_mode(args, rank)
 
+    # spin-up: the clocks of an idle MI355X need a few hundred ms of work to settle (at C3 a step reads 0.257 ms
+    # straight after start and 0.205 ms once they have); untimed, before the W warm-up steps
+    t_spin = time.perf_counter()
+    while time.perf_counter() - t_spin < 0.4:
+        for _ in range(20):
+            step()
+        torch.cuda.synchronize()
     # warm-up, with events around every launch: finds the dominant kernel of this workload
     ctx.set_profiling(True)
     ctx.reset_kernel_stats()
