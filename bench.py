@@ -6,25 +6,36 @@
 Metric (BASELINE.json): constraint-evals/s.  One "constraint-eval" = one evaluation, for
 one optimisation vector x, of every constraint family of the configuration: the temporal
 separation sweep over all vehicle pairs, max-speed, max-angular-rate, and one gjkNew per
-hull pair (vehicle<->vehicle and vehicle<->obstacle).  One "step" = one SLSQP iteration's
-worth of evaluations = the finite-difference batch B = n_x + 1 rows, all resident in HBM.
+hull pair (vehicle<->vehicle and vehicle<->obstacle; for the curve-obstacle configuration C5
+every pair of the 64 + 32 objects, as spatialSeparationConstraints pairs them).  One "step" =
+one SLSQP iteration's worth of evaluations: the finite-difference batch B = n_x + 1 rows is
+built on the device from x's control points (obtg_fd_batch_dev) and every family is evaluated
+on it, all resident in HBM.
 
 Workload (config.workload): C3 = 64 vehicles, 2-D, degree 10, DEG_ELEV 0, 8 polygon
 obstacles (BASELINE.json configs[2], the configuration the north-star target is quoted
-on).  Multi-GPU: swarm instances shard over the ranks with no data-path collective (each
-rank evaluates the FD batch of its own seeded swarm) -> "weak" scaling.
+on).  Multi-GPU (`--gpus N`): this script starts N rank processes itself (or runs as one
+rank under torchrun when RANK/WORLD_SIZE are set); swarm instances shard over the ranks with
+no data-path collective (each rank evaluates the FD batch of its own seeded swarm) -> "weak"
+scaling.  `--mode pairs` is the partitioned form: ONE batch, the pair lists split over the
+ranks, one RCCL all-gather of the per-pair minima.
 
 Output: ONE JSON line from rank 0 (contract in the task description) carrying also
   roofline     -- for the kernel that dominates the step's device time: algorithmic bytes
                   per launch / mean launch duration measured with HIP events on the
-                  launch stream inside the timed region, against the 8 TB/s HBM peak;
+                  launch stream inside the timed region, against the 8 TB/s HBM peak and
+                  against this box's measured copy / fill bandwidth;
   kernels      -- the same figures for every kernel of the step;
+  parity_check -- the device buffers of the last timed step against the CPU oracle on a sample
+                  of rows (first, last, one per XCD residue);
   cpu_baseline -- the CPU oracle (oracle/, a C port of the reference path) timed on this
                   box's host on a bounded sample of the same workload.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -43,9 +54,9 @@ def parse():
                     help="temporal separation and the gjkNew sweep as two launches instead of the one-launch pair sweep")
     ap.add_argument("--steps", type=int, default=500)
     ap.add_argument("--warmup", type=int, default=50)
-    ap.add_argument("--workload", default="C3", choices=["C2", "C3", "C4", "C5"])
+    ap.add_argument("--workload", default="C3", choices=["C2", "C2_file", "C3", "C4", "C5"])
     ap.add_argument("--batch", type=int, default=0, help="rows per step (default n_x + 1)")
-    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline and parity_check legs")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-gjk", action="store_true", help="Bernstein sweeps only")
     ap.add_argument("--fd-dedup", action="store_true",
@@ -53,12 +64,46 @@ def parse():
                          "NOT the headline number")
     ap.add_argument("--mode", default="batch", choices=["batch", "pairs", "mindist"],
                     help="batch: every rank evaluates its own FD batch, no collective (default, the headline); "
-                         "pairs: ONE evaluation batch, the pair list partitioned over the ranks and the per-pair "
-                         "separation minima all-gathered (RCCL) -- the 256-vehicle case of BASELINE.json")
+                         "pairs: ONE evaluation batch, the pair lists (temporal separation AND gjkNew hull pairs) "
+                         "partitioned over the ranks and the per-pair minima all-gathered (RCCL) -- the 256-vehicle "
+                         "case of BASELINE.json")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for rehearsals)")
     ap.add_argument("--one-device", action="store_true",
                     help="rehearsal only: every rank uses device 0 (needs --backend gloo)")
     return ap.parse_args()
+
+
+# ---------------------------------------------------------------------------------------------
+# launcher: `python bench.py --gpus N` starts the N ranks itself.  The parent never touches the GPU
+# (no torch import, no HIP call) and never re-execs: it only starts fresh children and waits.
+# ---------------------------------------------------------------------------------------------
+def spawn_ranks(args):
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ)
+        env.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    live = list(procs)
+    while live:
+        time.sleep(0.2)
+        for p in list(live):
+            code = p.poll()
+            if code is None:
+                continue
+            live.remove(p)
+            if code != 0 and rc == 0:
+                rc = code
+                for q in live:          # one rank failed: the others would wait in a barrier forever
+                    q.terminate()
+    if rc:
+        sys.stderr.write("bench.py: a rank exited with code %d\n" % rc)
+    return rc
 
 
 def algorithmic_bytes(N, d, n, R, P_t, P_s, sumK):
@@ -69,19 +114,46 @@ def algorithmic_bytes(N, d, n, R, P_t, P_s, sumK):
         "speed": 8 * N * d * (n + 1) + 8 * N * L,
         "ang_rate": 8 * N * d * (n + 1) + 8 * N * (4 * (n + R) + 1),
         "gjk": 24 * sumK + 64 * P_s,
+        "fd_batch": 2 * 8 * N * d * (n + 1),
     }
     # the survey's per-eval total counts the control points once
     total = 8 * N * d * (n + 1) + 8 * (P_t * L + N * L + N * (4 * (n + R) + 1)) + 24 * sumK + 64 * P_s
     return by, total
 
 
+def measured_peaks(torch, dev):
+    """This box's achievable HBM rates with stock kernels (tools/bw_probe.py): device copy (read + write
+    bytes) and fill (write only), 1 GiB each -- well past the 256 MB Infinity Cache."""
+    n = (1 << 30) // 8
+    x = torch.empty(n, dtype=torch.float64, device=dev)
+    y = torch.empty_like(x)
+
+    def t(f, k=10):
+        for _ in range(3):
+            f()
+        torch.cuda.synchronize()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(k):
+            f()
+        b.record()
+        torch.cuda.synchronize()
+        return a.elapsed_time(b) * 1e-3 / k
+    tc, tw = t(lambda: y.copy_(x)), t(lambda: x.fill_(1.0))
+    del x, y
+    return 2 * n * 8 / tc / 1e9, n * 8 / tw / 1e9
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:
+        sys.exit(spawn_ranks(args))
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        args.gpus = world
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d: refusing to print a %d-GPU line from %d rank(s)"
+                         % (args.gpus, world, args.gpus, world))
 
     import torch
     import torch.distributed as dist
@@ -98,16 +170,21 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(args.backend)
+        if dist.get_world_size() != args.gpus:
+            raise SystemExit("bench.py: process group of %d ranks for --gpus %d" % (dist.get_world_size(), args.gpus))
+
+    if args.mode == "mindist":
+        return mindist_mode(args, rank)
 
     cfg = dict(synth.CONFIGS[args.workload])
-    N, d, n, R, M = cfg["N"], cfg["d"], cfg["n"], cfg["R"], cfg.get("n_poly", 0)
+    N, d, n, R = cfg["N"], cfg["d"], cfg["n"], cfg["R"]
     n_x = N * d * (n - 1)
     B = args.batch or (n_x + 1)
     seed = 1234 + (1000 * rank if args.mode == "batch" else 0)   # batch mode: every rank its own swarm instance
     Y = synth.swarm_control_points(N, d, n, seed=seed)
-    polys = synth.polygon_obstacles(M, seed=1234)
-    ppts, poff = synth.pack_polys(polys) if M else (None, [0])
-    pa, pb = synth.swarm_pairs(N, M)
+    statics, pa, pb = synth.config_hull_sweep(args.workload, seed=1234)
+    M = len(statics)
+    ppts, poff = synth.pack_polys(statics) if M else (None, [0])
     use_gjk = (not args.no_gjk) and d >= 2
     max_sep, vmax, wmax, tfv = 0.9, 5.0, 1.0, 10.0
 
@@ -126,6 +203,14 @@ def main():
     d0 = torch.from_numpy(Y).to(dev)
     dY = torch.empty((B, N * d, n + 1), dtype=f64, device=dev)
     ctx.fd_batch_dev(d0.data_ptr(), 1, synth.FD_STEP, B, dY.data_ptr())     # inputs resident in HBM
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    if args.mode == "pairs":
+        return pairs_mode(args, ctx, dist, world, rank, dev, dY, B, max_sep, barrier, pa, pb, use_gjk)
+
     d_tf = torch.full((B,), tfv, dtype=f64, device=dev)
     o_sep = torch.empty((B, P_t * L), dtype=f64, device=dev)
     o_sp = torch.empty((B, N * L), dtype=f64, device=dev)
@@ -135,13 +220,16 @@ def main():
         g_p1 = torch.empty((B, P_s, 3), dtype=f64, device=dev)
         g_p2 = torch.empty((B, P_s, 3), dtype=f64, device=dev)
         g_dist = torch.empty((B, P_s), dtype=f64, device=dev)
+        g_stat = torch.empty((B, P_s), dtype=torch.int32, device=dev)
 
     one_launch = use_gjk and not args.separate   # the N x N pair sweeps (temporal separation + gjkNew) as one grid
 
     def step():
+        # B0: the FD batch of this SLSQP iteration, built on the device from x's control points
+        ctx.fd_batch_dev(d0.data_ptr(), 1, synth.FD_STEP, B, dY.data_ptr())
         if one_launch:
             ctx.pair_sweep_dev(dY.data_ptr(), B, max_sep, o_sep.data_ptr(), g_flag.data_ptr(), g_p1.data_ptr(),
-                               g_p2.data_ptr(), g_dist.data_ptr(), None, None, 128, 256)
+                               g_p2.data_ptr(), g_dist.data_ptr(), None, g_stat.data_ptr(), 128, 256)
         else:
             ctx.temporal_sep_dev(dY.data_ptr(), B, max_sep, o_sep.data_ptr())
         if o_an is not None:    # speed + angular rate share their derivative curves: one launch
@@ -150,16 +238,7 @@ def main():
             ctx.speed_dev(dY.data_ptr(), d_tf.data_ptr(), B, vmax, True, o_sp.data_ptr())
         if use_gjk and not one_launch:
             ctx.gjk_swarm_dev(dY.data_ptr(), B, g_flag.data_ptr(), g_p1.data_ptr(), g_p2.data_ptr(),
-                              g_dist.data_ptr(), None, None, 128, 256)
-
-    def barrier():
-        if world > 1:
-            dist.barrier()
-
-    if args.mode == "pairs":
-        return pairs_mode(args, ctx, dist, world, rank, dev, dY, B, max_sep, barrier)
-    if args.mode == "mindist":
-        return mindist_mode(args, rank)
+                              g_dist.data_ptr(), None, g_stat.data_ptr(), 128, 256)
 
     # spin-up: the clocks of an idle MI355X need a few hundred ms of work to settle (at C3 a step reads 0.257 ms
     # straight after start and 0.205 ms once they have); untimed, before the W warm-up steps
@@ -176,7 +255,7 @@ def main():
     torch.cuda.synchronize()
     ctx.sync()
     wstats = ctx.kernel_stats()
-    KNAMES = ("pair_sweep", "temporal_sep", "speed", "ang_rate", "gjk")
+    KNAMES = ("pair_sweep", "temporal_sep", "speed", "ang_rate", "gjk", "fd_batch")
     dom_name = max(KNAMES, key=lambda k: wstats.get(k, (0.0, 0))[0])
     # timed region: HIP events (launch stream) around the dominant kernel only, on every 4th step --
     # an event pair drains the queue around its launch (events on all three launches of every step
@@ -198,6 +277,14 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     stats_timed = ctx.kernel_stats()
+    # sample rows of the buffers the last timed step left behind, for the parity check (before anything rewrites them)
+    status_nonok = int((g_stat != 0).sum().item()) if use_gjk else 0
+    snap = None
+    if rank == 0 and not args.no_cpu and args.gpus == 1:
+        dev_out = dict(Y=dY, sep=o_sep, speed=o_sp, ang=o_an)
+        if use_gjk:
+            dev_out.update(flag=g_flag, dist=g_dist, p1=g_p1)
+        snap = parity_snapshot(dev_out, B)
     # the other kernels: the same steps once more with events on every launch, outside the timed region
     ctx.set_profiling(True)
     ctx.set_profile_period(1)
@@ -243,50 +330,116 @@ def main():
     if dom["kernel"] == "gjk":
         note = ("gjkNew sweep: VALU-issue bound by nature (PMC at C3: ~85 % VALU busy, LDS 34 %), reported against "
                 "HBM as the contract asks; see DESIGN.md 4.3")
+    copy_gbs, fill_gbs = measured_peaks(torch, dev)
     roofline = dict(bound="hbm", kernel=dom["kernel"], achieved=dom["achieved_gbs"], peak=HBM_PEAK_GBS,
-                    unit="GB/s", frac=dom["frac"], traffic=traffic, note=note,
-                    step_achieved=round(B * total_bytes / (ms_per_step * 1e-3) / 1e9, 2))
+                    unit="GB/s", frac=dom["frac"], traffic=traffic,
+                    peak_measured=round(copy_gbs, 1), frac_measured=round(dom["achieved_gbs"] / copy_gbs, 5),
+                    peak_measured_write_only=round(fill_gbs, 1),
+                    peak_measured_note="this box, torch copy_ (read+write bytes) / fill_ of 1 GiB, HIP events",
+                    note=note, step_achieved=round(B * total_bytes / (ms_per_step * 1e-3) / 1e9, 2))
 
-    cpu = cpu_np = None
+    cpu = cpu_np = parity = None
     if rank == 0 and not args.no_cpu and args.gpus == 1:
-        cpu = cpu_baseline(args, N, d, n, R, M, Y, polys, pa, pb, use_gjk, max_sep, vmax, wmax, tfv)
-        cpu_np = cpu_baseline_numpy(N, d, n, R, Y, max_sep, vmax, wmax, tfv)
+        parity = parity_check(snap, N, d, n, R, statics, pa, pb, use_gjk, max_sep, vmax, wmax, tfv)
+        parity["status_nonok"] = status_nonok
+        cpu = cpu_baseline(args, N, d, n, R, Y, statics, pa, pb, use_gjk, max_sep, vmax, wmax, tfv)
+        cpu_np = cpu_baseline_numpy(N, d, n, R, Y, statics, pa, pb, use_gjk, max_sep, vmax, wmax, tfv)
 
     if rank == 0:
+        obst = ("%d curve obstacles (shapeObstacles)" % M) if cfg.get("n_curve_obs") else ("%d polygon obstacles" % M)
         line = {
             "metric": "constraint-evals/s (full swarm pairwise min-dist + dynamics) per SLSQP iter",
             "value": round(value, 2), "unit": "constraint-evals/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "%s: %d vehicles, %d-D, degree %d, DEG_ELEV %d, %d polygon obstacles; "
-                                   "FD batch B=%d rows per GPU per step; families: temporal_sep(%d pairs)"
-                                   "+max_speed+%sgjkNew(%d hull pairs)" % (
-                                       args.workload, N, d, n, R, M, B, P_t,
+            "config": {"workload": "%s: %d vehicles, %d-D, degree %d, DEG_ELEV %d, %s; "
+                                   "FD batch B=%d rows per GPU per step (built on the device each step); families: "
+                                   "temporal_sep(%d pairs)+max_speed+%sgjkNew(%d hull pairs)" % (
+                                       args.workload, N, d, n, R, obst, B, P_t,
                                        "max_ang_rate+" if d == 2 else "", P_s),
                        "evals_per_step_per_gpu": B, "alg_bytes_per_eval": total_bytes,
-                       "gjk_fd_dedup": bool(args.fd_dedup)},
+                       "gjk_fd_dedup": bool(args.fd_dedup), "gjk_status_nonok_last_step": status_nonok},
             "roofline": roofline,
             "kernels": kernels,
+            "parity_check": parity,
             "cpu_baseline": cpu,
             "cpu_baseline_numpy": cpu_np,
         }
         print(json.dumps(line))
+        sys.stdout.flush()
     if world > 1:
         dist.destroy_process_group()
+    if parity is not None and not parity["ok"]:
+        raise SystemExit("bench.py: the timed step's device buffers DISAGREE with the oracle: %s" % json.dumps(parity))
 
 
-def pairs_mode(args, ctx, dist, world, rank, dev, dY, B, max_sep, barrier):
-    """Pair-partitioned temporal separation of ONE batch (same swarm on every rank): each rank sweeps a
-    contiguous block of the lexicographic pair list and the per-pair minima are all-gathered."""
+def parity_snapshot(dev_out, B):
+    """Host copies of a sample of rows of the step's device buffers: first, last, and rows of every residue
+    mod 8 (consecutive rows of a launch go to the 8 XCDs round-robin)."""
+    rows = sorted(set([0, B - 1] + [min(B - 1, (k * (B - 1)) // 9 // 8 * 8 + k % 8) for k in range(1, 9)]))
+    snap = {k: (v[rows].cpu().numpy() if v is not None else None) for k, v in dev_out.items()}
+    snap["rows"] = rows
+    return snap
+
+
+def parity_check(dev_out, N, d, n, R, statics, pa, pb, use_gjk, max_sep, vmax, wmax, tfv):
+    """The sampled rows of the buffers the LAST TIMED step left on the device against the CPU oracle.  The oracle
+    sees the device's own FD batch rows.  Bars as in tests/: 1e-9 scale-aware on constraint values, flags
+    identical, closest-point distances 1e-12."""
+    from oracle import oracle as O
+    from optimalbeziertrajectorygeneration_amd import synth
+    O.build()
+    rows = dev_out["rows"]
+    Yr = dev_out["Y"]
+    o_sep, o_sp, o_an = O.eval_batch(Yr, tfv, N, d, R, max_sep, vmax, wmax, nthreads=1)
+
+    def rel(got, ref):
+        fin = np.isfinite(ref)
+        if (np.isfinite(got) != fin).any():
+            return float("inf")
+        if not fin.any():
+            return 0.0
+        return float((np.abs(got[fin] - ref[fin]) / np.maximum(np.abs(ref[fin]), np.abs(ref[fin]).max())).max())
+
+    worst = {"temporal_sep": rel(dev_out["sep"], o_sep), "speed": rel(dev_out["speed"], o_sp)}
+    if dev_out.get("ang") is not None:
+        worst["ang_rate"] = rel(dev_out["ang"], o_an)
+    flags_equal, dist_rel = True, 0.0
+    if use_gjk:
+        fl, di, p1 = dev_out["flag"], dev_out["dist"], dev_out["p1"]
+        for k, r in enumerate(rows):
+            hp, ho = synth.pack_polys(synth.hulls_from_Y(Yr[k], d) + statics)
+            o = O.gjk_pairs(hp, ho, pa, pb, md_cap=256)
+            flags_equal = flags_equal and bool((fl[k] == o["flag"]).all())
+            sep = o["flag"] == 1
+            if sep.any():
+                dist_rel = max(dist_rel, float((np.abs(di[k][sep] - o["dist"][sep]) / np.maximum(1.0, np.abs(o["dist"][sep]))).max()),
+                               float((np.abs(p1[k][sep] - o["c1"][sep]) / np.maximum(1.0, np.abs(o["c1"][sep]))).max()))
+    max_rel = max(worst.values())
+    ok = bool(max_rel <= 1e-9 and flags_equal and dist_rel <= 1e-12)
+    return {"rows": len(rows), "row_ids": rows, "max_rel": max_rel, "per_family": worst, "flags_equal": flags_equal,
+            "gjk_dist_max_rel": dist_rel, "ok": ok,
+            "against": "oracle/obtg_oracle.c on the device's own FD rows; buffers of the LAST timed step"}
+
+
+def pairs_mode(args, ctx, dist, world, rank, dev, dY, B, max_sep, barrier, pa, pb, use_gjk):
+    """Pair-partitioned evaluation of ONE batch (same swarm on every rank): each rank sweeps a contiguous block of
+    the lexicographic temporal-separation pair list and of the gjkNew hull pair list; ONE all-gather returns the
+    per-pair separation minima and gjkNew's (dist, flag) to every rank."""
     import torch
-    from optimalbeziertrajectorygeneration_amd.distributed import PairPartitionedSweep, gpu_temporal_sep_evaluator
+    from optimalbeziertrajectorygeneration_amd.distributed import (GpuHullPairSweep, PairPartitionedSweep,
+                                                                   all_gather_pair_blocks, gpu_temporal_sep_evaluator)
     sweep = PairPartitionedSweep(ctx.num_pairs, 1)
     evaluate = gpu_temporal_sep_evaluator(ctx, dY, B, max_sep, min_only=True)
+    hull = GpuHullPairSweep(ctx, pa, pb) if use_gjk else None
 
     def step():
-        return sweep.run(evaluate, B, dev)
+        parts = [(evaluate(*sweep.my_block), sweep.blocks, 1)]
+        if hull is not None:
+            parts += hull.parts(dY, B)
+        return all_gather_pair_blocks(parts)
 
-    for _ in range(args.warmup):
+    for _ in range(max(args.warmup, 1)):
         out = step()
     torch.cuda.synchronize()
     barrier()
@@ -301,15 +454,20 @@ def pairs_mode(args, ctx, dist, world, rank, dev, dY, B, max_sep, barrier):
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     # every rank must hold the full, identical result
-    chk = out.sum().item()
+    chk = {"sep_min_sum": out[0].sum().item()}
+    if hull is not None:
+        chk["gjk_dist_nansum"] = torch.nansum(out[1]).item()
+        chk["gjk_flag_sum"] = int(out[2].sum().item())
     if rank == 0:
         print(json.dumps({
-            "metric": "pair-partitioned separation-minima evals/s (one batch across all GPUs, RCCL all-gather)",
+            "metric": "pair-partitioned evals/s (one batch across all GPUs: separation minima + gjkNew dist/flag, "
+                      "one RCCL all-gather)",
             "value": round(B * args.steps / elapsed, 2), "unit": "constraint-evals/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 4),
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "%s temporal-separation minima, %d pairs split over %d ranks, B=%d rows"
-                                   % (args.workload, ctx.num_pairs, world, B), "checksum": chk}}))
+            "config": {"workload": "%s: %d temporal-separation pairs + %d gjkNew hull pairs split over %d ranks, "
+                                   "B=%d rows" % (args.workload, ctx.num_pairs, len(pa) if use_gjk else 0, world, B),
+                       "checksum": chk}}))
     if world > 1:
         dist.destroy_process_group()
 
@@ -322,10 +480,10 @@ def mindist_mode(args, rank):
     finish in the reference either) and in the robust one (obtg_min_dist_robust)."""
     from optimalbeziertrajectorygeneration_amd import _capi, synth
     N, M, n = 64, 32, 10
-    Yc = synth.swarm_control_points(N + M, 2, n, seed=1234)
+    Yc = np.vstack((synth.swarm_control_points(N, 2, n, seed=1234), synth.curve_obstacles(M, 2, n, seed=1234)))
     curves = np.zeros((N + M, 3, n + 1))
     curves[:, :2, :] = Yc.reshape(N + M, 2, n + 1)
-    pa, pb = np.triu_indices(N + M, 1)
+    pa, pb = synth.all_pairs(N + M)
     ctx = _capi.scratch_context()
     out = {}
     for name, f in (("reference_algorithm", lambda: ctx.min_dist(curves, pa, pb, eps=1e-9, max_depth=128, max_nodes=2000)),
@@ -346,7 +504,7 @@ def mindist_mode(args, rank):
                           "variants": out}))
 
 
-def cpu_baseline(args, N, d, n, R, M, Y, polys, pa, pb, use_gjk, max_sep, vmax, wmax, tfv):
+def cpu_baseline(args, N, d, n, R, Y, statics, pa, pb, use_gjk, max_sep, vmax, wmax, tfv):
     """The CPU oracle (C port of the reference path, single thread -- the reference is
     single-threaded) on a bounded sample of the same FD batch."""
     from oracle import oracle as O
@@ -356,7 +514,7 @@ def cpu_baseline(args, N, d, n, R, M, Y, polys, pa, pb, use_gjk, max_sep, vmax, 
     def run(rows, nthreads, passes=1):
         """time only the oracle calls; inputs (FD rows, packed hulls) are prepared before"""
         Yb = synth.fd_batch(Y, B=rows)
-        hulls = [synth.pack_polys(synth.hulls_from_Y(Yb[b], d) + polys) for b in range(rows)] if use_gjk else []
+        hulls = [synth.pack_polys(synth.hulls_from_Y(Yb[b], d) + statics) for b in range(rows)] if use_gjk else []
         t0 = time.perf_counter()
         for _ in range(passes):
             O.eval_batch(Yb, tfv, N, d, R, max_sep, vmax, wmax, nthreads=nthreads)
@@ -386,9 +544,10 @@ def cpu_baseline(args, N, d, n, R, M, Y, polys, pa, pb, use_gjk, max_sep, vmax, 
     return out
 
 
-def cpu_baseline_numpy(N, d, n, R, Y, max_sep, vmax, wmax, tfv):
-    """Reference-shaped NumPy port (oracle/numpy_port.py: the reference's per-pair Python loops and
-    dense coefficient matrices, minus its Bezier objects), Bernstein families only, one thread."""
+def cpu_baseline_numpy(N, d, n, R, Y, statics, pa, pb, use_gjk, max_sep, vmax, wmax, tfv):
+    """Reference-shaped NumPy port (oracle/numpy_port.py: the reference's per-pair Python loops, dense
+    coefficient matrices and dict-simplex gjkNew, minus its Bezier objects), EVERY family of the evaluation, one
+    thread -- the figure the >= 50x target is quoted against."""
     from oracle import numpy_port as P
     from optimalbeziertrajectorygeneration_amd import synth
 
@@ -397,19 +556,26 @@ def cpu_baseline_numpy(N, d, n, R, Y, max_sep, vmax, wmax, tfv):
         P.speed(Yr, N, d, R, tfv, vmax, True)
         if d == 2:
             P.ang_rate(Yr, N, R, tfv, wmax)
+        if use_gjk:
+            polys = synth.hulls_from_Y(Yr, d) + statics
+            for a, b in zip(pa, pb):
+                P.gjk_new(polys[a], polys[b])
 
-    Yb = synth.fd_batch(Y, B=64)
-    one(Yb[0])                       # builds the coefficient-matrix caches, like the drivers' warm-up
+    Yb = synth.fd_batch(Y, B=16)
+    P.temporal_sep(Yb[0], N, d, R, max_sep)      # builds the coefficient-matrix caches, like the drivers' warm-up
+    P.speed(Yb[0], N, d, R, tfv, vmax, True)
+    if d == 2:
+        P.ang_rate(Yb[0], N, R, tfv, wmax)
     t0 = time.perf_counter()
     rows = 0
-    while rows < 64 and time.perf_counter() - t0 < 4.0:
+    while rows < 16 and (rows == 0 or time.perf_counter() - t0 < 6.0):
         one(Yb[rows])
         rows += 1
     dt = time.perf_counter() - t0
     return {"value": round(rows / dt, 3), "unit": "constraint-evals/s", "cores": 1, "kind": "port",
-            "sample": "%d rows, Bernstein families only (no gjkNew), %.1f s, oracle/numpy_port.py; the real "
-                      "reference measured in the survey container is ~5.6x slower than this port "
-                      "(BASELINE.md section 2)" % (rows, dt)}
+            "sample": "%d rows, all families (Bernstein sweeps%s), %.1f s, oracle/numpy_port.py; the real "
+                      "reference measured in the survey container is ~5.6x slower than this port on the Bernstein "
+                      "families (BASELINE.md section 2)" % (rows, " + one gjkNew per hull pair" if use_gjk else "", dt)}
 
 
 if __name__ == "__main__":

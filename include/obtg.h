@@ -178,7 +178,9 @@ int obtg_gjk_pairs(obtg_ctx*, const double* pts, int n_pts, const int* poly_off,
  * with obtg_ctx_set_polygons (object ids N .. N+n_poly-1).  Pair list is device-resident
  * after obtg_ctx_set_hull_pairs.  Outputs are DEVICE arrays:
  * d_flag[B][n_pairs] int32, d_p1/d_p2[B][n_pairs][3], d_dist[B][n_pairs],
- * d_nsup[B][n_pairs] int32 (nullable), d_status[B][n_pairs] int32 (nullable). */
+ * d_nsup[B][n_pairs] int32 (nullable), d_status[B][n_pairs] int32 (nullable).
+ * obtg_ctx_set_polygons drops the pair list (object ids change meaning): the sweeps return OBTG_ERR_ARG until
+ * obtg_ctx_set_hull_pairs has been called again. */
 int obtg_ctx_set_polygons(obtg_ctx*, const double* pts, int n_pts, const int* poly_off, int n_poly);
 int obtg_ctx_set_hull_pairs(obtg_ctx*, const int* pair_a, const int* pair_b, int n_pairs);
 int obtg_gjk_swarm_dev(obtg_ctx*, const double* dY, int B, int max_iter, int md_cap,
@@ -249,7 +251,8 @@ int obtg_bern_normsq(obtg_ctx*, const double* x, int d, int n, double* out);
 
 /* ---- objectives (optimization.py:462-489 _euclideanObjective, 503-519 _minAccelObjective,
  * 522-539 _minJerkObjective): sums over vehicles of the elevated |d^k pos/dt^k|^2 control
- * points, k = 2 (accel) or 3 (jerk); tf[0] is the (single) final time the reference uses. */
+ * points, k = 2 (accel) or 3 (jerk); tf[B] must hold ONE final time B times, as the reference has a single
+ * model['tf'] for these objectives (a batch with differing tf is OBTG_ERR_ARG). */
 int obtg_euclidean_obj(obtg_ctx*, const double* Y, int B, double* out /*[B]*/);
 int obtg_accel_obj(obtg_ctx*, const double* Y, const double* tf, int B, double* out /*[B]*/);
 int obtg_jerk_obj(obtg_ctx*, const double* Y, const double* tf, int B, double* out /*[B]*/);

@@ -169,7 +169,8 @@ class Context(object):
             raise ObtgError("obtg_ctx_create: " + self._lib.obtg_strerror(rc).decode())
         self.n_veh, self.dim, self.deg, self.deg_elev, self.n_obs = n_veh, dim, deg, deg_elev, n_obs
         self.device = device
-        self.n_hull_pairs = 0
+        self.n_poly = 0
+        self.n_hull_pairs = None      # no hull pair list registered yet
 
     # -- plumbing
     def close(self):
@@ -334,12 +335,18 @@ class Context(object):
         if pts is None or len(off) <= 1:
             self._check(self._lib.obtg_ctx_set_polygons(self._h, None, 0, None, 0), "obtg_ctx_set_polygons")
             self.n_poly = 0
+            self.n_hull_pairs = None      # object ids changed meaning: the library dropped the pair list too
             return
         pts = _f64(pts).reshape(-1, 3)
         off = _i32(off)
         self._check(self._lib.obtg_ctx_set_polygons(self._h, _ptr(pts), pts.shape[0], _ptr(off), off.shape[0] - 1),
                     "obtg_ctx_set_polygons")
         self.n_poly = off.shape[0] - 1
+        self.n_hull_pairs = None
+
+    def _need_hull_pairs(self, what):
+        if self.n_hull_pairs is None:
+            raise ObtgError("%s: no hull pair list registered -- call set_hull_pairs() (again) after set_polygons()" % what)
 
     def set_hull_pairs(self, pair_a, pair_b):
         pa, pb = _i32(pair_a), _i32(pair_b)
@@ -354,20 +361,22 @@ class Context(object):
         self._check(self._lib.obtg_ctx_set_gjk_history(self._h, int(bool(on))), "obtg_ctx_set_gjk_history")
 
     def gjk_swarm(self, Y, max_iter=128, md_cap=4096):
+        self._need_hull_pairs("gjk_swarm")
         Y, B = self._rows(Y)
         n = self.n_hull_pairs
         flag = np.zeros((B, n), np.int32)
         nsup = np.zeros((B, n), np.int32)
         status = np.zeros((B, n), np.int32)
-        p1 = np.empty((B, n, 3))
-        p2 = np.empty((B, n, 3))
-        dist = np.empty((B, n))
+        p1 = np.full((B, n, 3), np.nan)
+        p2 = np.full((B, n, 3), np.nan)
+        dist = np.full((B, n), np.nan)
         self._check(self._lib.obtg_gjk_swarm(self._h, _ptr(Y), B, max_iter, md_cap, _ptr(flag), _ptr(p1), _ptr(p2),
                                              _ptr(dist), _ptr(nsup), _ptr(status)), "obtg_gjk_swarm")
         return dict(flag=flag, c1=p1, c2=p2, dist=dist, n_support=nsup, status=status)
 
     def gjk_swarm_dev(self, dY, B, d_flag, d_p1, d_p2, d_dist, d_nsup=None, d_status=None, max_iter=128,
                       md_cap=4096):
+        self._need_hull_pairs("gjk_swarm_dev")
         self._check(self._lib.obtg_gjk_swarm_dev(self._h, _vp(dY), B, max_iter, md_cap, _vp(d_flag), _vp(d_p1),
                                                  _vp(d_p2), _vp(d_dist), _vp(d_nsup), _vp(d_status)),
                     "obtg_gjk_swarm_dev")
@@ -376,6 +385,7 @@ class Context(object):
     def pair_sweep_dev(self, dY, B, max_sep, d_out_sep, d_flag, d_p1, d_p2, d_dist, d_nsup=None, d_status=None,
                        max_iter=128, md_cap=4096):
         """temporal separation + gjkNew hull sweep of the same rows in one launch (obtg_pair_sweep_dev)."""
+        self._need_hull_pairs("pair_sweep_dev")
         self._check(self._lib.obtg_pair_sweep_dev(self._h, _vp(dY), B, float(max_sep), _vp(d_out_sep), max_iter,
                                                   md_cap, _vp(d_flag), _vp(d_p1), _vp(d_p2), _vp(d_dist),
                                                   _vp(d_nsup) if d_nsup else None,

@@ -1258,7 +1258,7 @@ int launch_euclidean_obj(obtg_ctx* c, const double* dY, int B, double* d_out)
 // optimization.py:503-539: per vehicle (d/dt)^order pos -> normSquare().elev(R), control points
 // summed.  order-1 plain derivative passes, then the speed-style sweep (one more derivative,
 // product, elevation) with sign +1 and offset 0.
-int launch_deriv_energy_obj(obtg_ctx* c, const double* dY, const double* d_tf, int B, int order, double* d_out)
+int launch_deriv_energy_obj(obtg_ctx* c, const double* dY, const double* d_tf, double tf0, int B, int order, double* d_out)
 {
     if (B <= 0) return OBTG_OK;
     if (order < 1 || order > 4) return OBTG_ERR_ARG;
@@ -1267,11 +1267,8 @@ int launch_deriv_energy_obj(obtg_ctx* c, const double* dY, const double* d_tf, i
     if (rc) return rc;
     if ((rc = c->ws_misc[6].reserve(sizeof(double) * (size_t)rows * nc))) return rc;
     if ((rc = c->ws_misc[4].reserve(sizeof(double) * (size_t)B * c->n_veh * (2 * c->deg + c->R + 1)))) return rc;
-    // tf differs per row only in time-optimal problems, whose objective is x[-1]; the reference
-    // passes one model['tf'] (optimization.py:294-308)
-    double tf0;
-    OBTG_HIP(c, hipMemcpyAsync(&tf0, d_tf, sizeof(double), hipMemcpyDeviceToHost, c->stream));
-    OBTG_HIP(c, hipStreamSynchronize(c->stream));
+    // the reference passes ONE model['tf'] (optimization.py:294-308; tf differs per row only in time-optimal
+    // problems, whose objective is x[-1]): tf0 is that value, d_tf[B] holds it B times (checked by the caller)
     const double* src = dY;
     double* bufs[2] = { c->ws_misc[3].as<double>(), c->ws_misc[6].as<double>() };
     for (int k = 0; k < order - 1; ++k) {

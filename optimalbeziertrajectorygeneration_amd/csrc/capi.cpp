@@ -527,6 +527,7 @@ int obtg_ctx_set_polygons(obtg_ctx* c, const double* pts, int n_pts, const int* 
     OBTG_HIP(c, hipStreamSynchronize(c->stream));
     if (n_poly == 0) {
         c->n_poly = 0; c->n_poly_pts = 0; c->polys_planar = true; c->max_poly_K = 0;
+        c->n_hull_pairs = 0; c->hull_pairs_set = false; c->tile_valid = false; c->gjk_len_rows = 0;
         int zero = 0;
         return upload(c, c->d_poly_off, &zero, sizeof(int));
     }
@@ -542,6 +543,7 @@ int obtg_ctx_set_polygons(obtg_ctx* c, const double* pts, int n_pts, const int* 
     c->max_poly_K = 0;
     for (int a = 0; a < n_poly; ++a) c->max_poly_K = std::max(c->max_poly_K, poly_off[a + 1] - poly_off[a]);
     c->n_hull_pairs = 0;   // object ids may have changed meaning
+    c->hull_pairs_set = false;
     c->tile_valid = false;
     c->gjk_len_rows = 0;
     return OBTG_OK;
@@ -559,6 +561,7 @@ int obtg_ctx_set_hull_pairs(obtg_ctx* c, const int* pair_a, const int* pair_b, i
     if (rc) return rc;
     if ((rc = upload(c, c->d_hp_b, pair_b, sizeof(int) * (size_t)n_pairs))) return rc;
     c->n_hull_pairs = n_pairs;
+    c->hull_pairs_set = true;
     c->h_hp_a.assign(pair_a, pair_a + n_pairs);
     c->h_hp_b.assign(pair_b, pair_b + n_pairs);
     c->tile_valid = false;
@@ -584,6 +587,7 @@ int obtg_pair_sweep_dev(obtg_ctx* c, const double* dY, int B, double max_sep, do
 {
     if (!check_ctx(c) || !dY || !d_out_sep || !d_flag || !d_p1 || !d_p2 || !d_dist || B < 0 || max_iter < 1 ||
         md_cap < 1) return OBTG_ERR_ARG;
+    if (!c->hull_pairs_set) return OBTG_ERR_ARG;   // no pair list registered (or invalidated by obtg_ctx_set_polygons)
     (void)hipSetDevice(c->device);
     return launch_pair_sweep(c, dY, B, max_sep, d_out_sep, max_iter, md_cap, d_flag, d_p1, d_p2, d_dist, d_nsup,
                              d_status);
@@ -603,6 +607,7 @@ int obtg_gjk_swarm_dev(obtg_ctx* c, const double* dY, int B, int max_iter, int m
     if (!check_ctx(c) || !dY || !d_flag || !d_p1 || !d_p2 || !d_dist || B < 0) return OBTG_ERR_ARG;
     if (max_iter < 1 || md_cap < 1) return OBTG_ERR_ARG;
     if (c->dim < 2) return OBTG_ERR_ARG;   // bezier.py:847-851: curves must be 2-D or 3-D
+    if (!c->hull_pairs_set) return OBTG_ERR_ARG;   // no pair list registered (or invalidated by obtg_ctx_set_polygons)
     (void)hipSetDevice(c->device);
     return launch_gjk_swarm(c, dY, B, max_iter, md_cap, d_flag, d_p1, d_p2, d_dist, d_nsup, d_status);
 }
@@ -612,7 +617,7 @@ int obtg_gjk_swarm(obtg_ctx* c, const double* Y, int B, int max_iter, int md_cap
 {
     if (!check_ctx(c) || !Y || !flag || !p1 || !p2 || !dist || B < 0) return OBTG_ERR_ARG;
     if (max_iter < 1 || md_cap < 1) return OBTG_ERR_ARG;
-    if (c->dim < 2) return OBTG_ERR_ARG;
+    if (c->dim < 2 || !c->hull_pairs_set) return OBTG_ERR_ARG;
     const size_t n = (size_t)B * c->n_hull_pairs;
     if (n == 0) return OBTG_OK;
     (void)hipSetDevice(c->device);
@@ -643,7 +648,7 @@ int obtg_min_dist(obtg_ctx* c, const double* curves, int n_curves, int K, const 
                   int* info, int* status)
 {
     if (!check_ctx(c) || !curves || !pair_a || !pair_b || !res || n_curves < 1 || n_pairs < 0) return OBTG_ERR_ARG;
-    if (max_depth < 1 || max_nodes < 1) return OBTG_ERR_ARG;
+    if (K < 2 || max_iter < 1 || md_cap < 1 || max_depth < 1 || max_nodes < 1) return OBTG_ERR_ARG;
     for (int k = 0; k < n_pairs; ++k)
         if (pair_a[k] < 0 || pair_a[k] >= n_curves || pair_b[k] < 0 || pair_b[k] >= n_curves) return OBTG_ERR_ARG;
     if (n_pairs == 0) return OBTG_OK;
@@ -672,7 +677,7 @@ int obtg_min_dist_robust(obtg_ctx* c, const double* curves, int n_curves, int K,
                          int n_pairs, double eps, int max_nodes, double* res, int* info, int* status)
 {
     if (!check_ctx(c) || !curves || !pair_a || !pair_b || !res || n_curves < 1 || n_pairs < 0) return OBTG_ERR_ARG;
-    if (max_nodes < 1 || !(eps > 0)) return OBTG_ERR_ARG;
+    if (K < 2 || max_nodes < 1 || !(eps > 0)) return OBTG_ERR_ARG;
     for (int k = 0; k < n_pairs; ++k)
         if (pair_a[k] < 0 || pair_a[k] >= n_curves || pair_b[k] < 0 || pair_b[k] >= n_curves) return OBTG_ERR_ARG;
     if (n_pairs == 0) return OBTG_OK;
@@ -705,7 +710,7 @@ int obtg_min_dist2poly(obtg_ctx* c, const double* curves, int n_curves, int K, c
 {
     if (!check_ctx(c) || !curves || !pts || !pair_curve || !pair_poly || !res || n_curves < 1 || n_pairs < 0)
         return OBTG_ERR_ARG;
-    if (max_depth < 1 || max_nodes < 1) return OBTG_ERR_ARG;
+    if (K < 2 || max_iter < 1 || md_cap < 1 || max_depth < 1 || max_nodes < 1) return OBTG_ERR_ARG;
     int rc = check_polys(poly_off, n_poly, n_pts);
     if (rc) return rc;
     for (int k = 0; k < n_pairs; ++k)
@@ -805,12 +810,14 @@ static int host_deriv_obj(obtg_ctx* c, const double* Y, const double* tf, int B,
 {
     if (!check_ctx(c) || !Y || !tf || !out || B < 0) return OBTG_ERR_ARG;
     if (B == 0) return OBTG_OK;
+    // one final time for the whole batch, as the reference's objectives have (optimization.py:294-308)
+    for (int b = 1; b < B; ++b) if (!(tf[b] == tf[0])) return OBTG_ERR_ARG;
     (void)hipSetDevice(c->device);
     int rc = h2d(c, c->ws_in, Y, sizeof(double) * ysize(c) * B);
     if (rc) return rc;
     if ((rc = h2d(c, c->ws_in2, tf, sizeof(double) * B))) return rc;
     if ((rc = c->ws_out.reserve(sizeof(double) * B))) return rc;
-    if ((rc = launch_deriv_energy_obj(c, c->ws_in.as<double>(), c->ws_in2.as<double>(), B, order, c->ws_out.as<double>())))
+    if ((rc = launch_deriv_energy_obj(c, c->ws_in.as<double>(), c->ws_in2.as<double>(), tf[0], B, order, c->ws_out.as<double>())))
         return rc;
     return d2h(c, out, c->ws_out.p, sizeof(double) * B);
 }
@@ -829,11 +836,11 @@ int obtg_jerk_obj(obtg_ctx* c, const double* Y, const double* tf, int B, double*
 int obtg_set_profiling(obtg_ctx* c, int on)
 {
     if (!check_ctx(c)) return OBTG_ERR_ARG;
+    if ((on & OBTG_PROFILE_ONLY_FLAG) && (on & 0xff) >= OBTG_K_COUNT) return OBTG_ERR_ARG;
     OBTG_HIP(c, hipStreamSynchronize(c->stream));
     flush_pending_events(c);
     c->profiling = on != 0;
     c->profile_mask = (on & OBTG_PROFILE_ONLY_FLAG) ? (1u << (on & 0xff)) : ~0u;
-    if ((on & OBTG_PROFILE_ONLY_FLAG) && (on & 0xff) >= OBTG_K_COUNT) return OBTG_ERR_ARG;
     return OBTG_OK;
 }
 

@@ -71,6 +71,7 @@ struct obtg_ctx {
     bool tile_valid = false;
     int tile_n_chunks = 0, tile_max_objs = 0, tile_max_pairs = 0;
     int n_hull_pairs = 0;
+    bool hull_pairs_set = false;  // obtg_ctx_set_hull_pairs since the last obtg_ctx_set_polygons
     obtg::DevBuf d_gjk_len[2];   // per-pair support-scan counts of the last planar sweep (scheduling history)
     bool gjk_history = true;
     int gjk_len_cur = 0, gjk_len_rows = 0;   // buffer holding the latest counts, and how many rows of them
@@ -134,7 +135,7 @@ int launch_bern_mul(obtg_ctx* c, const double* d_a, const double* d_b, int rows,
                     double* d_out);
 int launch_bern_normsq(obtg_ctx* c, const double* d_x, int d, int n, double* d_out);
 int launch_euclidean_obj(obtg_ctx* c, const double* dY, int B, double* d_out);
-int launch_deriv_energy_obj(obtg_ctx* c, const double* dY, const double* d_tf, int B, int order, double* d_out);
+int launch_deriv_energy_obj(obtg_ctx* c, const double* dY, const double* d_tf, double tf0, int B, int order, double* d_out);
 
 // ---------------------------------------------------------------- launchers (gjk_kernels.hip)
 int launch_gjk_pairs(obtg_ctx* c, const double* d_soa, const int* d_off, const int* d_pa,

@@ -8,14 +8,16 @@ Two independent ways to shard:
     the host as Jacobian column blocks.  `shard_rows`.
   * pair partitioning (one evaluation across GPUs, the 256-vehicle case): every rank holds
     all control points (65 KB), owns a contiguous balanced block of the lexicographic pair
-    list, and ONE all-gather assembles either the full constraint vector or only the
-    per-pair minima.  On a fully connected 8-GPU xGMI node each rank pushes its shard to 7
-    peers concurrently, so the collective is latency-bound at these sizes (1 MB shards).
-    `PairPartitionedSweep`.
+    list -- and of the gjkNew hull pair list, "GJK pairs partition the same way" -- and ONE
+    all-gather assembles either the full constraint vector or only the per-pair minima
+    (separation minima of the Bernstein family, gjkNew's distance and flag of the hull family).
+    On a fully connected 8-GPU xGMI node each rank pushes its shard to 7 peers concurrently, so
+    the collective is latency-bound at these sizes (1 MB shards).  `PairPartitionedSweep`,
+    `all_gather_pair_blocks`.
 
 The compute itself is injected (`evaluate(pair_begin, pair_count) -> tensor[B, count*width]`)
-so that the orchestration can be rehearsed on CPU with gloo; on GPUs the evaluator is a
-closure over `Context.temporal_sep_dev`.
+so that the orchestration can be rehearsed on CPU with gloo; on GPUs the evaluators are
+closures over `Context.temporal_sep[_min]_dev` / `Context.gjk_swarm_dev`.
 """
 import torch
 import torch.distributed as dist
@@ -38,13 +40,52 @@ def shard_rows(B, world, rank):
     return partition(B, world)[rank]
 
 
+def _world_rank(group=None):
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_world_size(group), dist.get_rank(group)
+    return 1, 0
+
+
+def all_gather_pair_blocks(parts, group=None):
+    """ONE all-gather for several partitioned results.
+
+    parts: list of (mine, blocks, width): `mine` is this rank's tensor [B, count_r*width] (any
+    dtype), `blocks` the [(begin, count)] partition of that result's pair list over the ranks.
+    The blocks of all parts are padded to their largest count, byte-packed (8-byte items first so
+    that every segment stays aligned) and exchanged with a single `all_gather_into_tensor`;
+    returns the assembled [B, n_pairs*width] tensors, identical on every rank."""
+    world, rank = _world_rank(group)
+    if world == 1:
+        return [p[0] for p in parts]
+    order = sorted(range(len(parts)), key=lambda i: -parts[i][0].element_size())
+    segs, meta = [], []
+    for i in order:
+        mine, blocks, w = parts[i]
+        B = mine.shape[0]
+        cmax = max(c for _, c in blocks)
+        pad = torch.zeros((B, cmax * w), dtype=mine.dtype, device=mine.device)
+        pad[:, :mine.shape[1]] = mine
+        segs.append(pad.view(torch.uint8).reshape(-1))
+        meta.append((i, B, cmax, w, mine.dtype, blocks))
+    send = torch.cat(segs)
+    recv = torch.empty((world, send.numel()), dtype=torch.uint8, device=send.device)
+    dist.all_gather_into_tensor(recv.view(-1), send, group=group)
+    out = [None] * len(parts)
+    off = 0
+    for (i, B, cmax, w, dtype, blocks) in meta:
+        nbytes = B * cmax * w * torch.empty((), dtype=dtype).element_size()
+        seg = recv[:, off:off + nbytes].contiguous().view(dtype).view(world, B, cmax * w)
+        out[i] = torch.cat([seg[r, :, :c * w] for r, (_, c) in enumerate(blocks)], dim=1).contiguous()
+        off += nbytes
+    return out
+
+
 class PairPartitionedSweep(object):
     """All-gather of per-rank pair blocks into the full [B, n_pairs*width] result."""
 
     def __init__(self, n_pairs, width, group=None):
         self.group = group
-        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
-        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.world, self.rank = _world_rank(group)
         self.n_pairs, self.width = n_pairs, width
         self.blocks = partition(n_pairs, self.world)
         self.max_count = max(c for _, c in self.blocks)
@@ -60,15 +101,7 @@ class PairPartitionedSweep(object):
         mine = evaluate(begin, count)
         if self.world == 1:
             return mine
-        w = self.width
-        # equal-sized shards for all_gather_into_tensor: pad the short blocks by one pair
-        send = torch.zeros((self.max_count * w, B), dtype=dtype, device=device)
-        send[:count * w] = mine.t()
-        recv = torch.empty((self.world * self.max_count * w, B), dtype=dtype, device=device)
-        dist.all_gather_into_tensor(recv, send, group=self.group)
-        recv = recv.view(self.world, self.max_count * w, B)
-        parts = [recv[r, :c * w] for r, (_, c) in enumerate(self.blocks)]
-        return torch.cat(parts, dim=0).t().contiguous()
+        return all_gather_pair_blocks([(mine, self.blocks, self.width)], group=self.group)[0]
 
 
 def gpu_temporal_sep_evaluator(ctx, dY, B, max_sep, min_only=False):
@@ -83,3 +116,44 @@ def gpu_temporal_sep_evaluator(ctx, dY, B, max_sep, min_only=False):
             fn(dY.data_ptr(), B, max_sep, out.data_ptr(), begin, count)
         return out
     return evaluate
+
+
+class GpuHullPairSweep(object):
+    """The gjkNew hull sweep with its pair list partitioned over the ranks ("GJK pairs
+    partition the same way").  Every rank holds all control points and static objects, registers ITS
+    contiguous block of the hull pair list with the context (`obtg_ctx_set_hull_pairs`), sweeps it, and
+    one all-gather returns (dist[B, P_s] float64, flag[B, P_s] int32) on every rank -- gjkNew's separation
+    distance (NaN where flag != 1) and flag per pair."""
+
+    def __init__(self, ctx, pair_a, pair_b, group=None, max_iter=128, md_cap=256):
+        self.ctx, self.group = ctx, group
+        self.world, self.rank = _world_rank(group)
+        self.n_pairs = len(pair_a)
+        self.blocks = partition(self.n_pairs, self.world)
+        b, c = self.blocks[self.rank]
+        ctx.set_hull_pairs(pair_a[b:b + c], pair_b[b:b + c])
+        self.count = c
+        self.max_iter, self.md_cap = max_iter, md_cap
+        self._buf = None
+
+    def evaluate(self, dY, B):
+        """-> (dist[B, count], flag[B, count]) of this rank's block (device tensors)."""
+        c = self.count
+        if self._buf is None or self._buf[0].shape[0] != B:
+            dev = dY.device
+            self._buf = (torch.empty((B, c), dtype=torch.float64, device=dev),
+                         torch.empty((B, c), dtype=torch.int32, device=dev),
+                         torch.empty((B, c, 3), dtype=torch.float64, device=dev),
+                         torch.empty((B, c, 3), dtype=torch.float64, device=dev))
+        d_dist, d_flag, d_p1, d_p2 = self._buf
+        if c:
+            self.ctx.gjk_swarm_dev(dY.data_ptr(), B, d_flag.data_ptr(), d_p1.data_ptr(), d_p2.data_ptr(),
+                                   d_dist.data_ptr(), None, None, self.max_iter, self.md_cap)
+        return d_dist, d_flag
+
+    def parts(self, dY, B):
+        d_dist, d_flag = self.evaluate(dY, B)
+        return [(d_dist, self.blocks, 1), (d_flag, self.blocks, 1)]
+
+    def run(self, dY, B):
+        return all_gather_pair_blocks(self.parts(dY, B), group=self.group)

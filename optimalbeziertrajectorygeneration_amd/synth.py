@@ -19,6 +19,9 @@ CONFIGS = {
     "C2": dict(N=8, d=3, n=10, R=0, n_poly=0),
     "C3": dict(N=64, d=2, n=10, R=0, n_poly=8),
     "C4": dict(N=256, d=2, n=15, R=0, n_poly=0),
+    # ComplexObstacles.py-style (Examples/ComplexObstacles.py:19-40): the obstacles are Bezier curves
+    # ("tracks") handed over as shapeObstacles; spatialSeparationConstraints (optimization.py:109-133)
+    # pairs every object with every other one, so the hull sweep covers C(64+32, 2) = 4560 pairs.
     "C5": dict(N=64, d=2, n=10, R=100, n_poly=0, n_curve_obs=32),
 }
 
@@ -59,6 +62,35 @@ def polygon_obstacles(n_poly, seed=1234):
         P[:, 1] = c[1] + rad * np.sin(ang)
         polys.append(P)
     return polys
+
+
+def curve_obstacles(n_curves, d, n, seed=1234):
+    """Curve ("track") obstacles of the C5 configuration: degree-n curves from the same generator
+    as the vehicles, own seed stream.  -> Y_obs[(n_curves*d), n+1]."""
+    return swarm_control_points(n_curves, d, n, seed=seed + 15485863)
+
+
+def all_pairs(n_obj):
+    """Every unordered pair i<j of n_obj objects, lexicographic: the pair loop of
+    spatialSeparationConstraints (optimization.py:127-130) over vehicles AND obstacles."""
+    a, b = np.triu_indices(n_obj, 1)
+    return a.astype(np.int32), b.astype(np.int32)
+
+
+def config_hull_sweep(name, seed=1234):
+    """The gjkNew hull sweep of a named configuration: static objects registered behind the
+    vehicles and the pair list.  -> (static_polys [list of (K,3)], pair_a, pair_b)."""
+    cfg = CONFIGS[name]
+    N, d, n = cfg["N"], cfg["d"], cfg["n"]
+    M = cfg.get("n_curve_obs", 0)
+    if M:
+        statics = hulls_from_Y(curve_obstacles(M, d, n, seed=seed), d)
+        pa, pb = all_pairs(N + M)
+        return statics, pa, pb
+    Mp = cfg.get("n_poly", 0)
+    statics = polygon_obstacles(Mp, seed=seed)
+    pa, pb = swarm_pairs(N, Mp)
+    return statics, pa, pb
 
 
 def fd_batch(Y, B=None, h=FD_STEP):

@@ -534,8 +534,90 @@ def gen_mindist():
     save("mindist.npz", **d)
 
 
+# ========================================================================= C5
+def gen_c5():
+    """BASELINE config 5 (ComplexObstacles.py-style): 64 vehicles + 32 curve obstacles, degree 10.
+    gjkNew over all C(96,2) = 4560 hull pairs of the seeded set, and `_minDist` on a strided subset
+    of the same pair list (status, result, gjkNew-call count)."""
+    d = {}
+    N, M, n = 64, 32, 10
+    Y = synth.swarm_control_points(N, 2, n, seed=1234)
+    Yo = synth.curve_obstacles(M, 2, n, seed=1234)
+    polys = synth.hulls_from_Y(Y, 2) + synth.hulls_from_Y(Yo, 2)
+    pa, pb = synth.all_pairs(N + M)
+    g = gjk_group(polys, pa, pb)
+    for k, v in g.items():
+        d["gjk_" + k] = v
+    ok = g["status"] == 0
+    print("  c5 hulls: %d pairs, flags(-1,0,1) %s, timeouts %d, mean supports %.2f" % (
+        len(pa), np.bincount(g["flag"][ok] + 1, minlength=3), (~ok).sum(), np.diff(g["trace_off"])[ok].mean()))
+    d["Y"], d["Yobs"] = Y, Yo
+    sys.setrecursionlimit(1000)
+    Yall = np.vstack((Y, Yo))
+    sel = np.arange(0, len(pa), len(pa) // 60)[:60]
+    res, stat, calls = [], [], []
+    for k in sel:
+        i, j = int(pa[k]), int(pb[k])
+        st, v, nc = run_mindist(bez.Bezier(Yall[2 * i:2 * i + 2].copy()), bez.Bezier(Yall[2 * j:2 * j + 2].copy()),
+                                budget=4.0)
+        res.append(v); stat.append(st); calls.append(nc)
+    d["md_sel"] = sel.astype(np.int32)
+    d["md_pa"], d["md_pb"] = pa[sel], pb[sel]
+    d["md_res"] = np.array(res)
+    d["md_status"] = np.array(stat, np.int32)
+    d["md_calls"] = np.array(calls, np.int32)
+    print("  c5 curve pairs: status", np.bincount(stat, minlength=3), "calls median",
+          int(np.median(np.array(calls)[np.array(stat) == 0])), "max", max(calls))
+    save("c5.npz", **d)
+
+
+# ==================================================== spatialSeparationConstraints
+def spatial_problem(dim, deg, seed, nveh=2):
+    """Inputs (ours, seeded) of one small spatial-separation problem: nveh vehicles + 1 curve obstacle."""
+    rng = np.random.default_rng(seed)
+    ip = rng.uniform(0, 10, size=(nveh, dim))
+    fp = rng.uniform(0, 10, size=(nveh, dim))
+    obs = rng.uniform(0, 10, size=(dim, deg + 1))
+    return ip, fp, obs
+
+
+def gen_spatial():
+    """BezOptimization.spatialSeparationConstraints (optimization.py:109-133) on small problems the
+    reference finishes: the assembled (P,3) array (maxSep subtracted from dist, t1 AND t2), pair order,
+    and the total number of gjkNew calls."""
+    import io
+    import contextlib
+    sys.setrecursionlimit(1000)
+    d = {}
+    names = []
+    for (dim, deg, seed) in [(2, 5, 10), (2, 5, 11), (3, 5, 0), (3, 5, 2), (3, 5, 6), (3, 5, 9)]:
+        ip, fp, obs = spatial_problem(dim, deg, seed)
+        bo = opt.BezOptimization(numVeh=2, dimension=dim, degree=deg, minimizeGoal='Euclidean', maxSep=0.5,
+                                 initPoints=ip, finalPoints=fp, shapeObstacles=[bez.Bezier(obs.copy())])
+        x = bo.generateGuess(std=0.7, seed=seed)
+        _gjk_calls[0] = 0
+        with contextlib.redirect_stdout(io.StringIO()):
+            st, v = guarded(bo.spatialSeparationConstraints, 60.0, x)
+        if st != 0:
+            print("  spatial (%d,%d,%d): reference did not finish (status %d), skipped" % (dim, deg, seed, st))
+            continue
+        name = "s%dd_%d" % (dim, seed)
+        names.append(name)
+        d[name + "_par"] = np.array([2, dim, deg, 0.5])
+        d[name + "_init"], d[name + "_final"], d[name + "_obs"] = ip, fp, obs
+        d[name + "_x"] = x
+        d[name + "_y"] = bo.reshapeVector(x)
+        d[name + "_out"] = np.asarray(v, dtype=float)
+        d[name + "_calls"] = np.array(_gjk_calls[0])
+        print("  spatial %s: out %s, %d gjkNew calls" % (name, np.asarray(v).shape, _gjk_calls[0]))
+    d["names"] = np.array(names)
+    save("spatial.npz", **d)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["tables", "ops", "problem", "constraints", "gjk", "mindist"]
+    which = sys.argv[1:] or ["tables", "ops", "problem", "constraints", "gjk", "mindist", "c5", "spatial"]
     for w in which:
+        if w == "none":          # import-only (exploration)
+            continue
         print("== " + w)
         globals()["gen_" + w]()

@@ -1,0 +1,96 @@
+"""Multi-rank paths on the one-GPU box: the HIP evaluators behind the pair-partitioned sweeps (world_size 1), and
+`bench.py --gpus 2` starting its own two ranks (gloo, both on device 0: a rehearsal of the launcher and of the
+collective path, not a scaling measurement).  `pytest -m gpu`."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_pair_partitioned_sweeps_with_hip_evaluators(oracle):
+    """distributed.PairPartitionedSweep over gpu_temporal_sep_evaluator and GpuHullPairSweep with the HIP library as
+    the evaluator: blocks of a 3-way partition glue to the unpartitioned result, and that equals the oracle."""
+    import torch
+    from optimalbeziertrajectorygeneration_amd import _capi, synth
+    from optimalbeziertrajectorygeneration_amd.distributed import (GpuHullPairSweep, PairPartitionedSweep,
+                                                                   gpu_temporal_sep_evaluator, partition)
+    N, d, n, M, B = 20, 2, 10, 4, 6
+    Y = synth.swarm_control_points(N, d, n, seed=5)
+    Yb = synth.fd_batch(Y, B=B)
+    polys = synth.polygon_obstacles(M, seed=5)
+    pa, pb = synth.swarm_pairs(N, M)
+    ctx = _capi.Context(N, d, n, 0)
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    ctx.set_polygons(*synth.pack_polys(polys))
+    dY = torch.from_numpy(Yb).cuda()
+    P, L = ctx.num_pairs, 2 * n + 1
+    o_sep = np.stack([oracle.temporal_sep(Yb[b], N, d, 0, 0.9) for b in range(B)])
+    for min_only in (False, True):
+        ev = gpu_temporal_sep_evaluator(ctx, dY, B, 0.9, min_only=min_only)
+        full = PairPartitionedSweep(P, 1 if min_only else L).run(ev, B, dY.device)      # world_size 1: the whole list
+        torch.cuda.synchronize()
+        w = 1 if min_only else L
+        glued = torch.cat([ev(b0, c) for (b0, c) in partition(P, 3)], dim=1)
+        torch.cuda.synchronize()
+        assert torch.equal(glued, full) and full.shape == (B, P * w)
+        ref = o_sep.reshape(B, P, L).min(axis=2) if min_only else o_sep
+        assert np.abs(full.cpu().numpy() - ref).max() <= 1e-9 * np.abs(ref).max()
+    hull = GpuHullPairSweep(ctx, pa, pb, md_cap=500)
+    dist_, flag = hull.run(dY, B)
+    torch.cuda.synchronize()
+    dist_, flag = dist_.cpu().numpy().copy(), flag.cpu().numpy().copy()
+    for b in range(B):
+        o = oracle.gjk_pairs(*synth.pack_polys(synth.hulls_from_Y(Yb[b], d) + polys), pa, pb, md_cap=500)
+        assert (flag[b] == o["flag"]).all()
+        sep = o["flag"] == 1
+        assert np.abs(dist_[b][sep] - o["dist"][sep]).max() <= 1e-12 * max(1.0, np.abs(o["dist"][sep]).max())
+        assert np.isnan(dist_[b][~sep]).all()
+    # a rank's block alone (what rank 1 of 3 would register and sweep)
+    b0, c = partition(len(pa), 3)[1]
+    ctx.set_hull_pairs(pa[b0:b0 + c], pb[b0:b0 + c])
+    r = ctx.gjk_swarm(Yb, md_cap=500)
+    assert np.array_equal(r["flag"], flag[:, b0:b0 + c]) and np.array_equal(r["dist"], dist_[:, b0:b0 + c], equal_nan=True)
+    ctx.set_stream(0)
+    ctx.close()
+
+
+def _bench(args, timeout=600):
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py")] + args, env=env, stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, timeout=timeout, universal_newlines=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    return json.loads(lines[0])
+
+
+def test_bench_starts_its_own_ranks():
+    """`python bench.py --gpus 2` (no torchrun): two child ranks, one JSON line from rank 0 with n_gpus == 2 and the
+    whole-job rate (2 x B rows per step)."""
+    common = ["--steps", "6", "--warmup", "2", "--no-cpu", "--workload", "C2", "--backend", "gloo", "--one-device"]
+    one = _bench(["--gpus", "1", "--steps", "6", "--warmup", "2", "--no-cpu", "--workload", "C2"])
+    two = _bench(["--gpus", "2"] + common)
+    assert one["n_gpus"] == 1 and two["n_gpus"] == 2 and two["scaling"] == "weak"
+    B = two["config"]["evals_per_step_per_gpu"]
+    assert abs(two["value"] - 2 * B * two["steps"] / (two["ms_per_step"] * 1e-3 * two["steps"])) < 1e-3 * two["value"]
+
+
+def test_bench_pairs_mode_two_ranks_equals_one_rank():
+    """--mode pairs: temporal-separation minima AND gjkNew (dist, flag) of one batch, pair lists split over two
+    ranks + one all-gather == the single-rank sweep (identical checksums)."""
+    args = ["--mode", "pairs", "--workload", "C3", "--batch", "9", "--steps", "2", "--warmup", "1", "--no-cpu"]
+    one = _bench(["--gpus", "1"] + args)
+    two = _bench(["--gpus", "2", "--backend", "gloo", "--one-device"] + args)
+    assert two["n_gpus"] == 2 and two["scaling"] == "strong"
+    c1, c2 = one["config"]["checksum"], two["config"]["checksum"]
+    assert c1["gjk_flag_sum"] == c2["gjk_flag_sum"]
+    assert c1["sep_min_sum"] == c2["sep_min_sum"] and c1["gjk_dist_nansum"] == c2["gjk_dist_nansum"]

@@ -196,9 +196,14 @@ def test_bern_ops_golden(capi, golden_dir):
 
 
 # ------------------------------------------------------------------------------------- GJK
-@pytest.mark.parametrize("grp", ["lit", "c3", "dense", "s3d"])
+@pytest.mark.parametrize("grp", ["lit", "c3", "dense", "s3d", "c5"])
 def test_gjk_pairs_bit_exact(capi, golden_dir, grp):
-    g = _load(golden_dir, "gjk.npz")
+    if grp == "c5":       # BASELINE config 5: 64 vehicles + 32 curve obstacles, all C(96,2) hull pairs
+        c5 = _load(golden_dir, "c5.npz")
+        g = {"c5_" + k[4:]: c5[k] for k in c5.files if k.startswith("gjk_")}
+        assert len(g["c5_pair_a"]) == 4560
+    else:
+        g = _load(golden_dir, "gjk.npz")
     ctx = capi.scratch_context()
     pa, pb = g[grp + "_pair_a"], g[grp + "_pair_b"]
     r = ctx.gjk_pairs(g[grp + "_pts"], g[grp + "_off"], pa, pb, md_cap=2000, trace_cap=64)
@@ -832,3 +837,177 @@ def test_gjk_swarm_3d_random_shapes(capi, oracle, synth):
                     if sep.any():
                         assert np.max(np.abs(r[key][b][sep] - o[key][sep]) / np.maximum(1.0, np.abs(o[key][sep]))) < 1e-12, tag
         ctx.close()
+
+
+# ------------------------------------------------------------- BASELINE config 5 (curve obstacles)
+def test_c5_hull_sweep_with_curve_obstacles(capi, oracle, synth, golden_dir):
+    """64 vehicles + 32 curve obstacles (ComplexObstacles.py-style, Examples/ComplexObstacles.py:19-40): the batched
+    sweep with the obstacle hulls registered as static objects, all C(96,2) = 4560 pairs that
+    spatialSeparationConstraints visits (optimization.py:127-130, obstacle<->obstacle included).  Row 0 against the
+    reference's fixture, perturbed rows against the oracle; one launch (device pointers) == host entry."""
+    import torch
+    g = _load(golden_dir, "c5.npz")
+    cfg = synth.CONFIGS["C5"]
+    N, d, n, M = cfg["N"], cfg["d"], cfg["n"], cfg["n_curve_obs"]
+    Y = synth.swarm_control_points(N, d, n, seed=1234)
+    statics, pa, pb = synth.config_hull_sweep("C5", seed=1234)
+    assert np.array_equal(Y, g["Y"]) and len(statics) == M and len(pa) == 4560
+    assert np.array_equal(pa, g["gjk_pair_a"]) and np.array_equal(pb, g["gjk_pair_b"])
+    ppts, poff = synth.pack_polys(statics)
+    B = 4
+    Yb = synth.fd_batch(Y, B=B)
+    Yb[2] += np.random.default_rng(5).normal(0, 2.0, size=Y.shape)
+    ctx = capi.Context(N, d, n, cfg["R"])
+    ctx.set_polygons(ppts, poff)
+    ctx.set_hull_pairs(pa, pb)
+    r = ctx.gjk_swarm(Yb, md_cap=2000)
+    assert (r["flag"][0] == g["gjk_flag"]).all() and (r["status"][0] == capi.ST_OK).all()
+    assert (r["n_support"][0] == np.diff(g["gjk_trace_off"])).all()
+    sep = g["gjk_flag"] == 1
+    for key in ("dist", "c1", "c2"):
+        ref = g["gjk_" + key][sep]
+        assert np.max(np.abs(r[key][0][sep] - ref) / np.maximum(1.0, np.abs(ref))) < 1e-12, key
+    for b in range(1, B):
+        hp, ho = synth.pack_polys(synth.hulls_from_Y(Yb[b], d) + statics)
+        o = oracle.gjk_pairs(hp, ho, pa, pb, md_cap=2000)
+        assert (r["flag"][b] == o["flag"]).all() and (r["n_support"][b] == o["n_support"]).all()
+        assert (r["status"][b] == o["status"]).all()
+        sp = o["flag"] == 1
+        for key in ("dist", "c1", "c2"):
+            assert np.max(np.abs(r[key][b][sp] - o[key][sp]) / np.maximum(1.0, np.abs(o[key][sp]))) < 1e-12
+    # device-pointer form (what bench.py --workload C5 times), second call = history-ordered schedule
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    dY = torch.from_numpy(Yb).cuda()
+    Ps = len(pa)
+    t_flag = torch.empty((B, Ps), dtype=torch.int32, device="cuda")
+    t_p1 = torch.empty((B, Ps, 3), dtype=torch.float64, device="cuda")
+    t_p2 = torch.empty((B, Ps, 3), dtype=torch.float64, device="cuda")
+    t_dist = torch.empty((B, Ps), dtype=torch.float64, device="cuda")
+    t_ns = torch.empty((B, Ps), dtype=torch.int32, device="cuda")
+    t_st = torch.empty((B, Ps), dtype=torch.int32, device="cuda")
+    for _ in range(2):
+        ctx.gjk_swarm_dev(dY.data_ptr(), B, t_flag.data_ptr(), t_p1.data_ptr(), t_p2.data_ptr(), t_dist.data_ptr(),
+                          t_ns.data_ptr(), t_st.data_ptr(), 128, 2000)
+        torch.cuda.synchronize()
+        assert np.array_equal(t_flag.cpu().numpy(), r["flag"]) and np.array_equal(t_ns.cpu().numpy(), r["n_support"])
+        assert np.array_equal(t_dist.cpu().numpy(), r["dist"], equal_nan=True)
+        assert np.array_equal(t_p1.cpu().numpy(), r["c1"], equal_nan=True)
+    ctx.set_stream(0)
+    ctx.close()
+
+
+def test_c5_min_dist_pairs(capi, oracle, synth, golden_dir):
+    """`_minDist` on config 5's pair list: the strided subset the reference was run on (fixture: result and gjkNew-call
+    count where it finished) and the whole 4560-pair list against the oracle (status, node and call counts, result)."""
+    g = _load(golden_dir, "c5.npz")
+    Yall = np.vstack((g["Y"], g["Yobs"]))
+    curves = np.stack([_pad3(Yall[2 * i:2 * i + 2]) for i in range(96)])
+    ctx = capi.scratch_context()
+    r = ctx.min_dist(curves, g["md_pa"], g["md_pb"], max_depth=64, max_nodes=300000)
+    n_ok = 0
+    for k in range(len(g["md_pa"])):
+        if g["md_status"][k] == 0:
+            assert r["status"][k] == capi.MD_OK and r["gjk_calls"][k] == g["md_calls"][k]
+            assert_close(r["res"][k], g["md_res"][k], RTOL)
+            n_ok += 1
+        elif g["md_status"][k] == 2:
+            assert r["status"][k] != capi.MD_OK      # RecursionError in the reference
+    assert n_ok >= 25
+    pa, pb = synth.all_pairs(96)
+    r = ctx.min_dist(curves, pa, pb, max_depth=64, max_nodes=2000)
+    n_fin = 0
+    for k in range(0, len(pa), 7):              # every 7th pair of the full list against the oracle
+        o = oracle.min_dist(curves[pa[k]], curves[pb[k]], max_depth=64, max_nodes=2000)
+        assert r["status"][k] == o["status"], k
+        if o["status"] == oracle.MD_OK:
+            assert r["gjk_calls"][k] == o["gjk_calls"] and r["nodes"][k] == o["nodes"] and r["depth"][k] == o["depth"]
+            assert_close(r["res"][k], o["res"], RTOL)
+            n_fin += 1
+    assert n_fin > 300
+
+
+def test_pair_sweep_at_bench_shape_vs_oracle(capi, oracle, synth):
+    """The launch bench.py times -- obtg_pair_sweep_dev (k_pair_sweep<11>) at C3, B = n_x + 1 = 1153 rows built by
+    obtg_fd_batch_dev -- against the ORACLE directly (not against the separate kernels): first row, last row and one
+    row of every residue mod 8 (consecutive rows go to the 8 XCDs round-robin), all pairs of those rows; a second
+    launch (history-ordered schedule) must reproduce the first bit for bit; statuses all OK."""
+    import torch
+    cfg = synth.CONFIGS["C3"]
+    N, d, n = cfg["N"], cfg["d"], cfg["n"]
+    Y = synth.swarm_control_points(N, d, n, seed=1234)
+    statics, pa, pb = synth.config_hull_sweep("C3", seed=1234)
+    B = N * d * (n - 1) + 1
+    ctx = capi.Context(N, d, n, 0)
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    ctx.set_polygons(*synth.pack_polys(statics))
+    ctx.set_hull_pairs(pa, pb)
+    d0 = torch.from_numpy(Y).cuda()
+    dY = torch.empty((B,) + Y.shape, dtype=torch.float64, device="cuda")
+    ctx.fd_batch_dev(d0.data_ptr(), 1, synth.FD_STEP, B, dY.data_ptr())
+    P, L, Ps = ctx.num_pairs, 2 * n + 1, len(pa)
+    outs = []
+    for _ in range(2):
+        o_sep = torch.empty((B, P * L), dtype=torch.float64, device="cuda")
+        g_flag = torch.empty((B, Ps), dtype=torch.int32, device="cuda")
+        g_p1 = torch.empty((B, Ps, 3), dtype=torch.float64, device="cuda")
+        g_p2 = torch.empty((B, Ps, 3), dtype=torch.float64, device="cuda")
+        g_dist = torch.empty((B, Ps), dtype=torch.float64, device="cuda")
+        g_ns = torch.empty((B, Ps), dtype=torch.int32, device="cuda")
+        g_st = torch.full((B, Ps), -7, dtype=torch.int32, device="cuda")
+        ctx.pair_sweep_dev(dY.data_ptr(), B, 0.9, o_sep.data_ptr(), g_flag.data_ptr(), g_p1.data_ptr(), g_p2.data_ptr(),
+                           g_dist.data_ptr(), g_ns.data_ptr(), g_st.data_ptr(), 128, 256)
+        torch.cuda.synchronize()
+        outs.append((o_sep, g_flag, g_p1, g_p2, g_dist, g_ns, g_st))
+    for a, b in zip(*outs):
+        assert torch.equal(a.view(torch.uint8), b.view(torch.uint8))           # bit for bit, NaNs included
+    o_sep, g_flag, g_p1, g_p2, g_dist, g_ns, g_st = outs[0]
+    assert int((g_st != 0).sum().item()) == 0
+    rows = sorted(set([0, B - 1] + [(k * (B - 1)) // 9 // 8 * 8 + k % 8 for k in range(1, 9)]))
+    assert sorted(set(r % 8 for r in rows)) == list(range(8))
+    Yr = dY[rows].cpu().numpy()
+    assert np.array_equal(Yr, synth.fd_batch(Y, B=B)[rows])                     # B0: device FD batch == host FD batch
+    ref_sep, _, _ = oracle.eval_batch(Yr, 10.0, N, d, 0, 0.9, 5.0, 1.0, want=("sep",))
+    assert_close(o_sep[rows].cpu().numpy(), ref_sep, RTOL, "separation block at the bench shape")
+    fl, ns, di = g_flag[rows].cpu().numpy(), g_ns[rows].cpu().numpy(), g_dist[rows].cpu().numpy()
+    c1, c2 = g_p1[rows].cpu().numpy(), g_p2[rows].cpu().numpy()
+    for k in range(len(rows)):
+        o = oracle.gjk_pairs(*synth.pack_polys(synth.hulls_from_Y(Yr[k], d) + statics), pa, pb, md_cap=256)
+        assert (fl[k] == o["flag"]).all() and (ns[k] == o["n_support"]).all() and (o["status"] == 0).all()
+        sep = o["flag"] == 1
+        for got, ref in ((di[k], o["dist"]), (c1[k], o["c1"]), (c2[k], o["c2"])):
+            assert np.max(np.abs(got[sep] - ref[sep]) / np.maximum(1.0, np.abs(ref[sep]))) < 1e-12
+    ctx.set_stream(0)
+    ctx.close()
+
+
+def test_set_polygons_invalidates_the_hull_pair_list(capi, synth):
+    """obtg_ctx_set_polygons changes what object ids mean and drops the pair list: a sweep without a fresh
+    set_hull_pairs must fail loudly, on the Python side and at the C ABI, instead of returning stale-sized or
+    uninitialised arrays."""
+    import ctypes as C
+    N = 6
+    Y = synth.swarm_control_points(N, 2, 5, seed=3)
+    ctx = capi.Context(N, 2, 5, 0)
+    with pytest.raises(capi.ObtgError):
+        ctx.gjk_swarm(Y)                                  # never registered
+    pa, pb = synth.swarm_pairs(N, 0)
+    ctx.set_polygons(None, [0])
+    ctx.set_hull_pairs(pa, pb)
+    assert ctx.gjk_swarm(Y)["flag"].shape == (1, 15)
+    ctx.set_polygons(*synth.pack_polys(synth.polygon_obstacles(2, seed=1)))
+    with pytest.raises(capi.ObtgError):
+        ctx.gjk_swarm(Y)
+    lib = capi.load()
+    buf = np.zeros(64)
+    ibuf = np.zeros(64, np.int32)
+    vp = lambda a: a.ctypes.data_as(C.c_void_p)
+    rc = lib.obtg_gjk_swarm(ctx.handle, vp(np.ascontiguousarray(Y)), 1, 128, 256, vp(ibuf), vp(buf), vp(buf), vp(buf), None, None)
+    assert rc == -1                                       # OBTG_ERR_ARG
+    ctx.set_hull_pairs(*synth.swarm_pairs(N, 2))
+    assert ctx.gjk_swarm(Y)["flag"].shape == (1, 15 + 12)
+    # objectives: one final time per batch, as the reference has (a batch with differing tf is refused)
+    Yb = synth.fd_batch(Y, B=3)
+    assert ctx.deriv_energy_obj(Yb, 4.0, 2).shape == (3,)
+    with pytest.raises(capi.ObtgError):
+        ctx.deriv_energy_obj(Yb, np.array([4.0, 4.0, 5.0]), 2)
+    ctx.close()

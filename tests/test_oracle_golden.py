@@ -206,3 +206,82 @@ def test_numpy_reference_shaped_port_matches_oracle(oracle):
         assert_close(P.speed(Y, N, d, R, 3.0, 5.0, True), oracle.speed(Y, N, d, R, 3.0, 5.0, 1), 1e-12)
         if d == 2:
             assert_close(P.ang_rate(Y, N, R, 3.0, 1.0), oracle.ang_rate(Y, N, R, 3.0, 1.0), 1e-9)
+
+
+# ------------------------------------------------------------------ BASELINE config 5 / row G4
+def test_c5_hull_sweep_bit_exact(oracle, golden_dir):
+    """64 vehicles + 32 curve obstacles: gjkNew over all C(96,2) = 4560 hull pairs
+    (optimization.py:127-130 pairs every object with every other one)."""
+    g = _load(golden_dir, "c5.npz")
+    pa, pb = g["gjk_pair_a"], g["gjk_pair_b"]
+    assert len(pa) == 4560
+    r = oracle.gjk_pairs(g["gjk_pts"], g["gjk_off"], pa, pb, trace_cap=64, md_cap=2000)
+    assert (g["gjk_status"] == 0).all()
+    assert (r["flag"] == g["gjk_flag"]).all() and (r["status"] == oracle.ST_OK).all()
+    toff, tr = g["gjk_trace_off"], g["gjk_trace"]
+    assert (r["n_support"] == np.diff(toff)).all()
+    for k in range(len(pa)):
+        assert (r["trace"][k, :toff[k + 1] - toff[k]] == tr[toff[k]:toff[k + 1]]).all(), "support trace of pair %d" % k
+    sep = g["gjk_flag"] == 1
+    assert (r["dist"][sep] == g["gjk_dist"][sep]).all()
+    assert (r["c1"][sep] == g["gjk_c1"][sep]).all() and (r["c2"][sep] == g["gjk_c2"][sep]).all()
+
+
+def test_c5_min_dist_subset(oracle, golden_dir):
+    g = _load(golden_dir, "c5.npz")
+    Yall = np.vstack((g["Y"], g["Yobs"]))
+    n_ok = 0
+    for k in range(len(g["md_sel"])):
+        i, j = int(g["md_pa"][k]), int(g["md_pb"][k])
+        r = oracle.min_dist(Yall[2 * i:2 * i + 2], Yall[2 * j:2 * j + 2], max_nodes=300000)
+        if g["md_status"][k] == 1 and r["status"] == oracle.MD_OK:
+            continue   # the generator's wall-clock budget fired on a finite (long) search
+        _check_md(oracle, g["md_status"][k], g["md_res"][k], g["md_calls"][k], r)
+        n_ok += g["md_status"][k] == 0
+    assert n_ok >= 25
+
+
+def spatial_from_oracle(O, y, obs, dim, max_sep):
+    """spatialSeparationConstraints (optimization.py:109-133) restated over the oracle's _minDist:
+    vehicles then obstacles, all pairs i<j, np.array(list of 3-tuples) - maxSep."""
+    nveh = y.shape[0] // dim
+    curves = [y[i * dim:(i + 1) * dim] for i in range(nveh)] + list(obs)
+    out, calls = [], 0
+    for i in range(len(curves)):
+        for j in range(i + 1, len(curves)):
+            r = O.min_dist(curves[i], curves[j], max_nodes=2000000)
+            assert r["status"] == O.MD_OK
+            out.append(r["res"])
+            calls += r["gjk_calls"]
+    return np.array(out) - max_sep, calls
+
+
+def test_spatial_separation_constraints(oracle, golden_dir):
+    """Row G4: the assembled (P,3) array -- maxSep is subtracted from t1 and t2 as well."""
+    s = _load(golden_dir, "spatial.npz")
+    assert len(s["names"]) >= 4
+    for name in s["names"]:
+        nveh, dim, deg, max_sep = s[name + "_par"]
+        out, calls = spatial_from_oracle(oracle, s[name + "_y"], [s[name + "_obs"]], int(dim), float(max_sep))
+        ref = s[name + "_out"]
+        assert out.shape == ref.shape == (3, 3)
+        assert calls == int(s[name + "_calls"]), name
+        assert_close(out, ref, 1e-12, name)
+
+
+def test_numpy_port_gjk_matches_oracle(oracle, golden_dir):
+    """oracle/numpy_port.gjk_new (the dict-simplex, reference-shaped gjkNew behind bench.py's cpu_baseline_numpy):
+    flag, number of supportPts calls and distance identical to the C oracle, hence to the reference's fixtures."""
+    from oracle import numpy_port as P
+    g = _load(golden_dir, "gjk.npz")
+    for grp, stride in (("lit", 1), ("c3", 9), ("dense", 3), ("s3d", 11)):
+        pts, off = g[grp + "_pts"], g[grp + "_off"]
+        polys = [pts[off[i]:off[i + 1]] for i in range(len(off) - 1)]
+        pa, pb = g[grp + "_pair_a"][::stride], g[grp + "_pair_b"][::stride]
+        ok = g[grp + "_status"][::stride] == 0
+        o = oracle.gjk_pairs(pts, off, pa, pb, md_cap=2000)
+        for k in np.where(ok)[0]:
+            flag, info, nsup = P.gjk_new(polys[pa[k]], polys[pb[k]])
+            assert flag == o["flag"][k] == g[grp + "_flag"][::stride][k] and nsup == o["n_support"][k]
+            if flag == 1:
+                assert info[2] == o["dist"][k] and (info[0] == o["c1"][k]).all() and (info[1] == o["c2"][k]).all()
