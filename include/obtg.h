@@ -90,6 +90,13 @@ void obtg_ctx_destroy(obtg_ctx*);
 int obtg_ctx_set_stream(obtg_ctx*, void* hip_stream);
 /* DEG_ELEV is a module constant read at call time (optimization.py:17): allow changing it */
 int obtg_ctx_set_deg_elev(obtg_ctx*, int deg_elev);
+/* Angular rate with DEG_ELEV > 0 (optimization.py:578-611).  The reference elevates the position by R first and
+ * forms every product at degree n+R (a degree-4(n+R) square: 441 coefficients from degree-220 operands at R = 100).
+ * Elevation commutes with diff/mul/add, so by default (elevate_first = 0) the library forms numerator and
+ * denominator at degree 4n from the original control points and elevates both by 4R before the element-wise
+ * quotient -- the same control points up to rounding (within the 1e-9 bar on every reference fixture), an order of
+ * magnitude less arithmetic.  elevate_first = 1 keeps the reference's order of operations (generic kernel). */
+int obtg_ctx_set_ang_rate_order(obtg_ctx*, int elevate_first);
 int obtg_sync(obtg_ctx*);
 
 /* sizes of one evaluation row's outputs, in doubles */
@@ -243,11 +250,15 @@ int obtg_min_dist2poly(obtg_ctx*, const double* curves, int n_curves, int K,
  * obtg_bern_elev:   Bezier.elev(R)      bezier.py:469-495   in[rows][n+1]   -> out[rows][n+R+1]
  * obtg_bern_diff:   Bezier.diff()       bezier.py:497-519   in[rows][n+1]   -> out[rows][n+1]  (T = tf-t0)
  * obtg_bern_mul:    Bezier.mul          bezier.py:376-432   a[rows][m+1], b[rows][n+1] -> out[rows][m+n+1]
- * obtg_bern_normsq: Bezier.normSquare() bezier.py:869-889   x[d][n+1]       -> out[2n+1]  ((d/2) quirk kept) */
+ * obtg_bern_normsq: Bezier.normSquare() bezier.py:869-889   x[d][n+1]       -> out[2n+1]  ((d/2) quirk kept)
+ * obtg_bern_split:  Bezier.split(tDiv)  bezier.py:533-572 -> deCasteljauSplit 985-1027   in[rows][n+1] ->
+ *                   left[rows][n+1], right[rows][n+1] at z = (tDiv - t0)/(tf - t0); `right` is in the curve's own
+ *                   orientation (the reference reverses deCasteljauSplit's second array, bezier.py:563) */
 int obtg_bern_elev(obtg_ctx*, const double* in, int rows, int n, int R, double* out);
 int obtg_bern_diff(obtg_ctx*, const double* in, int rows, int n, double T, double* out);
 int obtg_bern_mul(obtg_ctx*, const double* a, const double* b, int rows, int m, int n, double* out);
 int obtg_bern_normsq(obtg_ctx*, const double* x, int d, int n, double* out);
+int obtg_bern_split(obtg_ctx*, const double* in, int rows, int n, double z, double* left, double* right);
 
 /* ---- objectives (optimization.py:462-489 _euclideanObjective, 503-519 _minAccelObjective,
  * 522-539 _minJerkObjective): sums over vehicles of the elevated |d^k pos/dt^k|^2 control

@@ -33,6 +33,7 @@ _SIGNATURES = {
     "obtg_ctx_destroy": (None, [_vp]),
     "obtg_ctx_set_stream": (_i, [_vp, _vp]),
     "obtg_ctx_set_deg_elev": (_i, [_vp, _i]),
+    "obtg_ctx_set_ang_rate_order": (_i, [_vp, _i]),
     "obtg_sync": (_i, [_vp]),
     "obtg_len_temporal_sep": (_i, [_vp]),
     "obtg_len_speed": (_i, [_vp]),
@@ -66,6 +67,7 @@ _SIGNATURES = {
     "obtg_bern_diff": (_i, [_vp, _vp, _i, _i, _d, _vp]),
     "obtg_bern_mul": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),
     "obtg_bern_normsq": (_i, [_vp, _vp, _i, _i, _vp]),
+    "obtg_bern_split": (_i, [_vp, _vp, _i, _i, _d, _vp, _vp]),
     "obtg_euclidean_obj": (_i, [_vp, _vp, _i, _vp]),
     "obtg_accel_obj": (_i, [_vp, _vp, _vp, _i, _vp]),
     "obtg_jerk_obj": (_i, [_vp, _vp, _vp, _i, _vp]),
@@ -202,6 +204,11 @@ class Context(object):
     def set_deg_elev(self, R):
         self._check(self._lib.obtg_ctx_set_deg_elev(self._h, int(R)), "obtg_ctx_set_deg_elev")
         self.deg_elev = int(R)
+
+    def set_ang_rate_order(self, elevate_first):
+        """DEG_ELEV > 0: False (default) = products at degree 4n, then elevation by 4R; True = the reference's
+        order of operations (include/obtg.h obtg_ctx_set_ang_rate_order)."""
+        self._check(self._lib.obtg_ctx_set_ang_rate_order(self._h, int(bool(elevate_first))), "obtg_ctx_set_ang_rate_order")
 
     def sync(self):
         self._check(self._lib.obtg_sync(self._h), "obtg_sync")
@@ -468,6 +475,15 @@ class Context(object):
         out = np.empty((1, 2 * nc - 1))
         self._check(self._lib.obtg_bern_normsq(self._h, _ptr(x), d, nc - 1, _ptr(out)), "obtg_bern_normsq")
         return out
+
+    def bern_split(self, cpts, z):
+        """de Casteljau split of every row at parameter z in [0, 1] -> (left, right), each rows x (n+1)."""
+        a = np.atleast_2d(_f64(cpts))
+        rows, nc = a.shape
+        left, right = np.empty((rows, nc)), np.empty((rows, nc))
+        self._check(self._lib.obtg_bern_split(self._h, _ptr(a), rows, nc - 1, float(z), _ptr(left), _ptr(right)),
+                    "obtg_bern_split")
+        return left, right
 
     # -- instrumentation
     def temporal_sep_fd(self, Y0, pert_row, pert_col, pert_val, max_sep):

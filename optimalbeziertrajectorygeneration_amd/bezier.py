@@ -186,6 +186,15 @@ class Bezier(BezierParams):
         new.cpts = _ctx().bern_diff(self.cpts, self.tf - self.t0)
         return new
 
+    def split(self, tDiv):
+        """Two curves, before and after tDiv (bezier.py:533-572): de Casteljau at (tDiv - t0)/(tf - t0); the
+        pieces keep the original span's ends, [t0, tDiv] and [tDiv, tf]."""
+        if np.isnan(tDiv):
+            print('[!] Warning, tDiv is {}, changing to 0.'.format(tDiv))
+            tDiv = 0
+        left, right = _ctx().bern_split(self.cpts, (tDiv - self.t0) / (self.tf - self.t0))
+        return Bezier(left, t0=self.t0, tf=tDiv), Bezier(right, t0=tDiv, tf=self.tf)
+
     def normSquare(self):
         """(d/2) * |curve|^2 as a 1 x (2n+1) curve -- the reference's factor is kept (bezier.py:869-889)."""
         new = self.copy()

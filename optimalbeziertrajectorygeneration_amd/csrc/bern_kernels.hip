@@ -354,6 +354,177 @@ __global__ __launch_bounds__(2 * kWave) void k_dynamics2(const AngParams p)
     }
 }
 
+// Angular rate (and speed) with DEG_ELEV = R > 0 (optimization.py:425-459, 578-611 after `pos.elev(R)`).
+// The reference elevates the position to degree m = n + R first and forms every product at the elevated
+// degree (4m + 1 = 441 coefficients at R = 100, from degree-2m operands).  Degree elevation commutes with diff(),
+// mul() and add(): the degree-4m control points of num and den are elev(., 4R) of the degree-4n control points the
+// R = 0 kernel forms from the ORIGINAL control points, and the speed rows are elev(den1, R).  So: phase A = the
+// degree-4n num / den of k_dynamics2 (lane = item, everything in registers), phase B = two banded elevations and
+// the element-wise quotient.  Elevation is a binomially scaled convolution,
+//     elev(a, Q)_k = (1 / C(P+Q, k)) sum_j [C(P, j) a_j] C(Q, k-j),
+// so all output columns share ONE weight row C(Q, .): a block of 8 columns walks a window of that row with one
+// wave-uniform scalar per step (8 + 8 independent FMA chains), instead of fetching 4n+1 weights per column; in the
+// quotient num_k / den_k the factor 1 / C(P+Q, k) cancels and is never applied.  2 (4n+1) FMAs per output value
+// against the generic kernel's degree-4m convolutions.  A workgroup is four waves on the same 64 items; each
+// repeats phase A (8 % of its work) and takes every fourth 32-column chunk, transposed through a per-wave LDS tile
+// so that stores are 256-byte runs.
+struct AngElevParams {
+    AngParams a;
+    const double* __restrict__ cv4;  // scale[4n+1] = C(4n, j) | padded row C(4R, m) 2^-e, m = -(4n) .. 4R+4n+8
+    const double* __restrict__ cv2;  // scale[2n+1] = C(2n, j) | padded row C(R, m), m = -(2n) .. R+2n+8 | 1/C(2n+R, k) (+8)
+    int R;
+};
+
+constexpr int kElevChunk = 32;
+constexpr int kElevBlock = 8;
+
+template <int LIN>
+__device__ __forceinline__ void elev_store_chunk(const double* __restrict__ tile, double* __restrict__ gout, size_t grow,
+                                                 int LR, int k0, int kc, int n_valid, int lane)
+{
+    constexpr int TP = kElevChunk + 1;
+    if (kc == kElevChunk) {
+        for (int e = lane; e < n_valid * kElevChunk; e += kWave) {
+            const int pr = e / kElevChunk, q = e & (kElevChunk - 1);
+            store_nt(gout + grow + (size_t)pr * LR + k0 + q, tile[pr * TP + q]);
+        }
+        return;
+    }
+    for (int e = lane; e < n_valid * kc; e += kWave) {
+        const int pr = e / kc, q = e - pr * kc;
+        store_nt(gout + grow + (size_t)pr * LR + k0 + q, tile[pr * TP + q]);
+    }
+}
+
+// sa[i] = sum_j a[j] c[(k0+i) - j], i < kElevBlock, with cp = (padded row) + k0: cp[m] = c[k0 - (LIN-1) + m]
+template <int LIN>
+__device__ __forceinline__ void conv_block2(const ctab_t cp, const double (&a)[LIN], const double (&b)[LIN],
+                                            double (&sa)[kElevBlock], double (&sb)[kElevBlock])
+{
+#pragma unroll
+    for (int i = 0; i < kElevBlock; ++i) sa[i] = sb[i] = 0.0;
+#pragma unroll
+    for (int m = 0; m < LIN - 1 + kElevBlock; ++m) {
+        const double c = cp[m];
+#pragma unroll
+        for (int i = 0; i < kElevBlock; ++i) {
+            const int j = i + LIN - 1 - m;
+            if (j >= 0 && j < LIN) { sa[i] = fma(c, a[j], sa[i]); sb[i] = fma(c, b[j], sb[i]); }
+        }
+    }
+}
+
+template <int LIN>
+__device__ __forceinline__ void conv_block1(const ctab_t cp, const double (&a)[LIN], double (&sa)[kElevBlock])
+{
+#pragma unroll
+    for (int i = 0; i < kElevBlock; ++i) sa[i] = 0.0;
+#pragma unroll
+    for (int m = 0; m < LIN - 1 + kElevBlock; ++m) {
+        const double c = cp[m];
+#pragma unroll
+        for (int i = 0; i < kElevBlock; ++i) {
+            const int j = i + LIN - 1 - m;
+            if (j >= 0 && j < LIN) sa[i] = fma(c, a[j], sa[i]);
+        }
+    }
+}
+
+template <int NC>
+__global__ __launch_bounds__(4 * kWave, (NC > 11 ? 1 : 2)) void k_dynamics_elev(const AngElevParams q)
+{
+    constexpr int N = NC - 1, L2 = 2 * N + 1, L4 = 4 * N + 1, TP = kElevChunk + 1;
+    const AngParams& p = q.a;
+    extern __shared__ double lds[];
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform: table reads become scalar loads
+    double* tile = lds + wave * (kWave * TP);
+    const int it0 = blockIdx.x * kWave;
+    const int n_valid = min(kWave, p.total - it0);
+    const int item = min(it0 + lane, p.total - 1);
+    const int b = item / p.n_veh;
+    const double* src = p.Y + (size_t)item * 2 * NC;
+    double num[L4], den[L4];
+    {   // ---- phase A: degree-4n numerator and denominator from the original control points (as k_dynamics2)
+        double x[NC], y[NC];
+#pragma unroll
+        for (int c = 0; c < NC; ++c) { x[c] = src[c]; y[c] = src[NC + c]; }
+        const double val = (double)N / p.tf[b];
+        double xD[NC], yD[NC], xDD[NC], yDD[NC];
+        diff_elev1<NC>(x, val, xD);
+        diff_elev1<NC>(y, val, yD);
+        diff_elev1<NC>(xD, val, xDD);
+        diff_elev1<NC>(yD, val, yDD);
+        const ctab_t Wn = as_ctab(p.Wn), W2n = as_ctab(p.W2n), W22n = as_ctab(p.W22n);
+        double num1[L2], den1[L2];
+#pragma unroll
+        for (int k = 0; k < L2; ++k) {
+            double s1 = 0.0, s2 = 0.0, sd = 0.0;
+#pragma unroll
+            for (int j = (k - N > 0 ? k - N : 0); j <= (N < k ? N : k); ++j) {
+                const double wkj = Wn[k * NC + j];
+                s1 = fma(wkj, yDD[j] * xD[k - j], s1);
+                s2 = fma(wkj, xDD[j] * yD[k - j], s2);
+            }
+#pragma unroll
+            for (int j = (k - N > 0 ? k - N : 0); 2 * j <= k; ++j)
+                sd = fma(W2n[k * NC + j], fma(xD[j], xD[k - j], yD[j] * yD[k - j]), sd);
+            num1[k] = s1 - s2;
+            den1[k] = sd;
+        }
+        // speed rows = elev(den1, R): this wave's share of their 32-column chunks, while den1 is still live
+        if (p.out_speed) {
+            const int L2R = L2 + q.R;
+            const ctab_t sc2 = as_ctab(q.cv2), row2 = sc2 + L2, inv2 = row2 + (q.R + 1 + 2 * (L2 - 1) + kElevBlock);
+            double dh[L2];
+#pragma unroll
+            for (int j = 0; j < L2; ++j) dh[j] = sc2[j] * den1[j];
+            for (int k0 = wave * kElevChunk; k0 < L2R; k0 += 4 * kElevChunk) {
+                const int kc = min(kElevChunk, L2R - k0);
+                for (int kb = 0; kb < kc; kb += kElevBlock) {
+                    double sa[kElevBlock];
+                    conv_block1<L2>(row2 + k0 + kb, dh, sa);
+#pragma unroll
+                    for (int i = 0; i < kElevBlock; ++i)
+                        tile[lane * TP + kb + i] = p.sp_sign * (sa[i] * inv2[k0 + kb + i]) + p.sp_offset;
+                }
+                wave_sync();
+                elev_store_chunk<L2>(tile, p.out_speed, (size_t)it0 * L2R, L2R, k0, kc, n_valid, lane);
+                wave_sync();
+            }
+        }
+        const ctab_t sc4 = as_ctab(q.cv4);
+#pragma unroll
+        for (int k = 0; k < L4; ++k) {
+            double sn = 0.0, sd = 0.0;
+#pragma unroll
+            for (int j = (k - 2 * N > 0 ? k - 2 * N : 0); 2 * j <= k; ++j) {
+                const double wkj = W22n[k * L2 + j];
+                sn = fma(wkj, num1[j] * num1[k - j], sn);
+                sd = fma(wkj, den1[j] * den1[k - j], sd);
+            }
+            const double sck = sc4[k];          // C(4n, k): the convolution form's pre-scaling
+            num[k] = sck * sn;
+            den[k] = sck * sd;
+        }
+    }
+    // ---- phase B: elevate both by 4R and divide, 32 output columns at a time; chunk t belongs to wave t mod 4
+    const int L4R = L4 + 4 * q.R;
+    const ctab_t row4 = as_ctab(q.cv4) + L4;
+    for (int k0 = wave * kElevChunk; k0 < L4R; k0 += 4 * kElevChunk) {
+        const int kc = min(kElevChunk, L4R - k0);
+        for (int kb = 0; kb < kc; kb += kElevBlock) {
+            double sn[kElevBlock], sd[kElevBlock];
+            conv_block2<L4>(row4 + k0 + kb, num, den, sn, sd);
+#pragma unroll
+            for (int i = 0; i < kElevBlock; ++i) tile[lane * TP + kb + i] = p.w2 - sn[i] / sd[i];
+        }
+        wave_sync();
+        elev_store_chunk<L4>(tile, p.out, (size_t)it0 * L4R, L4R, k0, kc, n_valid, lane);
+        wave_sync();
+    }
+}
+
 // =====================================================================================
 //  generic path: any degree / elevation, one wave per item, operands in LDS, products as
 //  binomially scaled convolutions:  c_k = (1/C(m+n,k)) * sum_j [C(m,j) a_j][C(n,k-j) b_{k-j}]
@@ -783,6 +954,31 @@ __global__ __launch_bounds__(kWave) void k_bern_normsq(const BernParams p)
     }
 }
 
+// Bezier.split (bezier.py:533-572) -> deCasteljauSplit (bezier.py:985-1027): the de Casteljau triangle at
+// z = (tDiv - t0) / (tf - t0), one wave per row, the row in LDS.  Level by level every lane forms
+// (1-z) c_i + z c_{i+1} from the previous level; left[k] is the first element of level k, right[k] (already in
+// the curve's own orientation, i.e. the reference's `right[::-1]`) the last element of level n-k.
+__global__ __launch_bounds__(kWave) void k_bern_split(const BernParams p, double* __restrict__ right)
+{
+    extern __shared__ double lds[];
+    const int lane = threadIdx.x, r = blockIdx.x, n = p.n, nc = n + 1;
+    double* cur = lds;
+    double* nxt = lds + nc;
+    const double z = p.T, w = 1.0 - z;
+    for (int e = lane; e < nc; e += kWave) cur[e] = p.a[(size_t)r * nc + e];
+    __syncthreads();
+    double* L = p.out + (size_t)r * nc;
+    double* Rt = right + (size_t)r * nc;
+    for (int lev = 0; lev < n; ++lev) {
+        const int len = nc - lev;
+        if (lane == 0) { L[lev] = cur[0]; Rt[n - lev] = cur[len - 1]; }
+        for (int i = lane; i < len - 1; i += kWave) nxt[i] = w * cur[i] + z * cur[i + 1];
+        __syncthreads();
+        double* t = cur; cur = nxt; nxt = t;
+    }
+    if (lane == 0) { L[n] = cur[0]; Rt[0] = cur[0]; }
+}
+
 // =====================================================================================
 //  finite-difference batch, objectives
 // =====================================================================================
@@ -1073,6 +1269,29 @@ static int launch_dyn_t(obtg_ctx* c, const AngParams& p, int kernel_id)
     return OBTG_OK;
 }
 
+template <int NC>
+static int launch_dyn_elev_t(obtg_ctx* c, const AngElevParams& q, int kernel_id)
+{
+    const size_t lds = sizeof(double) * 4 * kWave * (kElevChunk + 1);
+    const unsigned groups = (unsigned)((q.a.total + kWave - 1) / kWave);
+    if (lds > 48 * 1024)
+        OBTG_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_dynamics_elev<NC>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    ScopedKernelTimer t(c, kernel_id);
+    hipLaunchKernelGGL(k_dynamics_elev<NC>, dim3(groups), dim3(4 * kWave), lds, c->stream, q);
+    OBTG_HIP(c, hipGetLastError());
+    return OBTG_OK;
+}
+
+// DEG_ELEV > 0, angular rate wanted: products at degree 4n, then elevation by 4R (k_dynamics_elev).
+// obtg_ctx_set_ang_rate_order(ctx, 1) keeps the reference's order of operations (generic kernel) instead.
+static bool dyn_fast_elev(const obtg_ctx* c)
+{
+    const int nc = c->deg + 1;
+    return c->dim == 2 && c->R > 0 && !c->ang_elevate_first && c->d_ang_T4.p != nullptr && c->d_ang_cv2.p != nullptr &&
+           (nc == 4 || nc == 6 || nc == 8 || nc == 11 || nc == 16);
+}
+
 static bool dyn_fast(const obtg_ctx* c)
 {
     const int nc = c->deg + 1;
@@ -1133,6 +1352,26 @@ int launch_dynamics(obtg_ctx* c, const double* dY, const double* d_tf, int B, do
             case 16: return launch_dyn_t<16>(c, p, kid);
         }
     }
+    if (d_out_ang && dyn_fast_elev(c)) {
+        AngElevParams q{};
+        AngParams& p = q.a;
+        p.Y = dY; p.tf = d_tf; p.out = d_out_ang; p.out_speed = d_out_speed;
+        p.n_veh = c->n_veh; p.total = B * c->n_veh;
+        p.w2 = max_rate * max_rate;
+        const double b2 = bound * bound;
+        p.sp_sign = is_max ? -1.0 : 1.0; p.sp_offset = is_max ? b2 : -b2;
+        p.W2n = c->d_ang_w2n.as<double>();
+        p.W22n = c->d_ang_w22n.as<double>();
+        p.Wn = c->d_ang_wn.as<double>();
+        q.cv4 = c->d_ang_T4.as<double>(); q.cv2 = c->d_ang_cv2.as<double>(); q.R = c->R;
+        switch (c->deg + 1) {
+            case 4: return launch_dyn_elev_t<4>(c, q, OBTG_K_ANG_RATE);
+            case 6: return launch_dyn_elev_t<6>(c, q, OBTG_K_ANG_RATE);
+            case 8: return launch_dyn_elev_t<8>(c, q, OBTG_K_ANG_RATE);
+            case 11: return launch_dyn_elev_t<11>(c, q, OBTG_K_ANG_RATE);
+            case 16: return launch_dyn_elev_t<16>(c, q, OBTG_K_ANG_RATE);
+        }
+    }
     if (d_out_speed && (rc = launch_speed(c, dY, d_tf, B, bound, is_max, d_out_speed))) return rc;
     if (d_out_ang && (rc = launch_ang_rate(c, dY, d_tf, B, max_rate, d_out_ang))) return rc;
     return OBTG_OK;
@@ -1145,7 +1384,7 @@ int launch_ang_rate(obtg_ctx* c, const double* dY, const double* d_tf, int B, do
     if (B <= 0) return OBTG_OK;
     int rc = ensure_tables(c);
     if (rc) return rc;
-    if (dyn_fast(c)) return launch_dynamics(c, dY, d_tf, B, 0.0, 1, max_rate, nullptr, d_out);
+    if (dyn_fast(c) || dyn_fast_elev(c)) return launch_dynamics(c, dY, d_tf, B, 0.0, 1, max_rate, nullptr, d_out);
     GenParams g{};
     rc = gen_common(c, g);
     if (rc) return rc;
@@ -1214,6 +1453,18 @@ int launch_bern_diff(obtg_ctx* c, const double* d_in, int rows, int n, double T,
     p.a = d_in; p.out = d_out; p.rows = rows; p.n = n; p.T = T;
     ScopedKernelTimer t(c, OBTG_K_BERN);
     hipLaunchKernelGGL(k_bern_diff, dim3(rows), dim3(kWave), sizeof(double) * (n + 1), c->stream, p);
+    OBTG_HIP(c, hipGetLastError());
+    return OBTG_OK;
+}
+
+int launch_bern_split(obtg_ctx* c, const double* d_in, int rows, int n, double z, double* d_left, double* d_right)
+{
+    if (rows <= 0) return OBTG_OK;
+    if (n < 0 || n + 1 > kMaxGenericLen) return OBTG_ERR_UNSUPPORTED;
+    BernParams p{};
+    p.a = d_in; p.out = d_left; p.rows = rows; p.n = n; p.T = z;
+    ScopedKernelTimer t(c, OBTG_K_BERN);
+    hipLaunchKernelGGL(k_bern_split, dim3(rows), dim3(kWave), sizeof(double) * 2 * (n + 1), c->stream, p, d_right);
     OBTG_HIP(c, hipGetLastError());
     return OBTG_OK;
 }

@@ -122,6 +122,15 @@ int ensure_tables(obtg_ctx* c)
         auto Td = elev_table_T(L, c->R);
         if ((rc = upload(c, c->d_Td, Td.data(), Td.size() * sizeof(double)))) return rc;
     }
+    c->d_ang_T4.release();
+    c->d_ang_cv2.release();
+    if (c->R > 0 && c->dim == 2 && n <= 15 && 4 * c->R <= 1000) {   // C(4R, .) and C(2n+R, .) finite in binary64
+        auto cv4 = elev_conv_padded(4 * n + 1, 4 * c->R, 8, true, false);
+        auto cv2 = elev_conv_padded(2 * n + 1, c->R, 8, false, true);
+        int rc = upload(c, c->d_ang_T4, cv4.data(), cv4.size() * sizeof(double));
+        if (rc) return rc;
+        if ((rc = upload(c, c->d_ang_cv2, cv2.data(), cv2.size() * sizeof(double)))) return rc;
+    }
     c->tables_R = c->R;
     return OBTG_OK;
 }
@@ -178,14 +187,14 @@ const char* obtg_abi_symbols(void)
 {
     static const char syms[] =
         "obtg_strerror\0obtg_last_error\0obtg_device_count\0obtg_abi_symbols\0"
-        "obtg_ctx_create\0obtg_ctx_destroy\0obtg_ctx_set_stream\0obtg_ctx_set_deg_elev\0obtg_sync\0"
+        "obtg_ctx_create\0obtg_ctx_destroy\0obtg_ctx_set_stream\0obtg_ctx_set_deg_elev\0obtg_ctx_set_ang_rate_order\0obtg_sync\0"
         "obtg_len_temporal_sep\0obtg_len_speed\0obtg_len_ang_rate\0obtg_num_pairs\0"
         "obtg_temporal_sep\0obtg_speed\0obtg_ang_rate\0obtg_temporal_sep_min\0obtg_temporal_sep_min_range\0"
         "obtg_temporal_sep_fd\0obtg_temporal_sep_fd_dev\0"
         "obtg_temporal_sep_dev\0obtg_temporal_sep_min_dev\0obtg_speed_dev\0obtg_ang_rate_dev\0obtg_dynamics_dev\0"
         "obtg_fd_batch_dev\0obtg_gjk_pairs\0obtg_ctx_set_polygons\0obtg_ctx_set_hull_pairs\0"
         "obtg_ctx_set_fd_dedup\0obtg_ctx_set_gjk_history\0obtg_pair_sweep_dev\0obtg_gjk_swarm_dev\0obtg_gjk_swarm\0obtg_min_dist\0obtg_min_dist_robust\0obtg_min_dist2poly\0"
-        "obtg_bern_elev\0obtg_bern_diff\0obtg_bern_mul\0obtg_bern_normsq\0"
+        "obtg_bern_elev\0obtg_bern_diff\0obtg_bern_mul\0obtg_bern_normsq\0obtg_bern_split\0"
         "obtg_euclidean_obj\0obtg_accel_obj\0obtg_jerk_obj\0"
         "obtg_set_profiling\0obtg_set_profile_period\0obtg_kernel_stats\0obtg_reset_kernel_stats\0obtg_kernel_name\0";
     return syms;
@@ -235,7 +244,7 @@ void obtg_ctx_destroy(obtg_ctx* c)
     (void)hipStreamSynchronize(c->stream);
     flush_pending_events(c);
     for (hipEvent_t e : c->event_pool) (void)hipEventDestroy(e);
-    DevBuf* bufs[] = { &c->d_pairs, &c->d_obs, &c->d_w2, &c->d_Tt, &c->d_Td, &c->d_ang_w2n, &c->d_ang_w22n, &c->d_ang_wn,
+    DevBuf* bufs[] = { &c->d_pairs, &c->d_obs, &c->d_w2, &c->d_Tt, &c->d_Td, &c->d_ang_w2n, &c->d_ang_w22n, &c->d_ang_wn, &c->d_ang_T4, &c->d_ang_cv2,
                        &c->d_binrows, &c->d_tiles, &c->d_poly_pts, &c->d_poly_off, &c->d_hp_a, &c->d_hp_b, &c->d_tile_chunk_off, &c->d_tile_order, &c->d_tile_pslots,
                        &c->d_tile_cobj_off, &c->d_tile_cobjs, &c->ws_in,
                        &c->ws_in2, &c->ws_out };
@@ -261,6 +270,13 @@ int obtg_ctx_set_deg_elev(obtg_ctx* c, int deg_elev)
     OBTG_HIP(c, hipStreamSynchronize(c->stream));
     c->R = deg_elev;
     return ensure_tables(c);
+}
+
+int obtg_ctx_set_ang_rate_order(obtg_ctx* c, int elevate_first)
+{
+    if (!check_ctx(c)) return OBTG_ERR_ARG;
+    c->ang_elevate_first = elevate_first != 0;
+    return OBTG_OK;
 }
 
 int obtg_sync(obtg_ctx* c)
@@ -766,6 +782,21 @@ int obtg_bern_diff(obtg_ctx* c, const double* in, int rows, int n, double T, dou
     if ((rc = c->ws_out.reserve(sizeof(double) * (size_t)rows * (n + 1)))) return rc;
     if ((rc = launch_bern_diff(c, c->ws_in.as<double>(), rows, n, T, c->ws_out.as<double>()))) return rc;
     return d2h(c, out, c->ws_out.p, sizeof(double) * (size_t)rows * (n + 1));
+}
+
+int obtg_bern_split(obtg_ctx* c, const double* in, int rows, int n, double z, double* left, double* right)
+{
+    if (!check_ctx(c) || !in || !left || !right || rows < 0 || n < 0) return OBTG_ERR_ARG;
+    if (rows == 0) return OBTG_OK;
+    (void)hipSetDevice(c->device);
+    const size_t len = (size_t)rows * (n + 1);
+    int rc = h2d(c, c->ws_in, in, sizeof(double) * len);
+    if (rc) return rc;
+    if ((rc = c->ws_out.reserve(sizeof(double) * 2 * len))) return rc;
+    double* dl = c->ws_out.as<double>();
+    if ((rc = launch_bern_split(c, c->ws_in.as<double>(), rows, n, z, dl, dl + len))) return rc;
+    OBTG_HIP(c, hipMemcpyAsync(left, dl, sizeof(double) * len, hipMemcpyDeviceToHost, c->stream));
+    return d2h(c, right, dl + len, sizeof(double) * len);
 }
 
 int obtg_bern_mul(obtg_ctx* c, const double* a, const double* b, int rows, int m, int n, double* out)

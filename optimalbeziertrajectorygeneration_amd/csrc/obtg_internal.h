@@ -18,6 +18,7 @@ std::vector<double> binom_row(int n);               // C(n, 0..n)
 std::vector<double> folded_product_weights(int n, int dim);  // [2n+1][n+1], see bern_kernels.hip
 std::vector<double> elev_table_T(int L_in, int R);  // transposed, zero padded: [L_in+R][L_in]
 std::vector<double> elev_conv_tables(int L_in, int R);  // scale | padded C(R,.) | 1/C(N+R,.)
+std::vector<double> elev_conv_padded(int L_in, int R, int extra, bool normalise, bool with_inv);
 
 // ---------------------------------------------------------------- device buffers
 struct DevBuf {
@@ -50,6 +51,9 @@ struct obtg_ctx {
     obtg::DevBuf d_Tt;        // elevation (2*deg -> 2*deg+R) as convolution tables (elev_conv_tables)
     obtg::DevBuf d_Td;        // the same elevation as a dense transposed matrix (elev_table_T)
     obtg::DevBuf d_ang_w2n, d_ang_w22n, d_ang_wn;  // angular-rate fast path weights
+    obtg::DevBuf d_ang_T4;    // angular rate, R > 0: elevation 4*deg -> 4*(deg+R) as a scaled convolution (elev_conv_padded)
+    obtg::DevBuf d_ang_cv2;   // the same for the speed rows, 2*deg -> 2*deg+R, with the 1/C(2n+R, k) row
+    bool ang_elevate_first = false;   // true: the reference's order (elevate, then products at degree n+R; generic kernel)
     std::vector<int> h_pairs; // host copy of the pair table (2 ints per pair)
     std::vector<int> h_tiles; // row-window tiles of the current (pair_begin, pair_count)
     obtg::DevBuf d_tiles;
@@ -131,6 +135,7 @@ int launch_dynamics(obtg_ctx* c, const double* dY, const double* d_tf, int B, do
 int launch_fd_batch(obtg_ctx* c, const double* dY0, int n_fixed_cols, double h, int B, double* dY);
 int launch_bern_elev(obtg_ctx* c, const double* d_in, int rows, int n, int R, double* d_out);
 int launch_bern_diff(obtg_ctx* c, const double* d_in, int rows, int n, double T, double* d_out);
+int launch_bern_split(obtg_ctx* c, const double* d_in, int rows, int n, double z, double* d_left, double* d_right);
 int launch_bern_mul(obtg_ctx* c, const double* d_a, const double* d_b, int rows, int m, int n,
                     double* d_out);
 int launch_bern_normsq(obtg_ctx* c, const double* d_x, int d, int n, double* d_out);

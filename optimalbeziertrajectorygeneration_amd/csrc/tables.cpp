@@ -69,4 +69,22 @@ std::vector<double> elev_conv_tables(int L_in, int R)
     return t;
 }
 
+// The same elevation for kernels that walk a window of the binomial row (k_dynamics_elev):
+//   scale[L_in] = C(N, j) | row[(L_in-1) + (R+1) + (L_in-1) + extra] = C(R, m) for m = -(L_in-1) .. , zero outside 0..R
+//   | (with_inv) inv[L_in + R + extra] = 1 / C(N+R, k), zero past the end.
+// normalise: the row is divided by the power of two below its largest entry (a quotient of two elevations does not
+// see the factor; keeps C(4R, .) x C(4n, .) x values far from overflow).
+std::vector<double> elev_conv_padded(int L_in, int R, int extra, bool normalise, bool with_inv)
+{
+    const int N = L_in - 1;
+    std::vector<double> t;
+    for (int j = 0; j <= N; ++j) t.push_back(binom(N, j));
+    int e = 0;
+    if (normalise) (void)std::frexp(binom(R, R / 2), &e);
+    for (int m = -(L_in - 1); m <= R + (L_in - 1) + extra; ++m) t.push_back(std::ldexp(binom(R, m), -e));
+    if (with_inv)
+        for (int k = 0; k < L_in + R + extra; ++k) t.push_back(k <= N + R ? 1.0 / binom(N + R, k) : 0.0);
+    return t;
+}
+
 }  // namespace obtg

@@ -351,44 +351,30 @@ class BezOptimization(object):
 
     # ------------------------------------------------------------------ x <-> y
     def generateGuess(self, std=0, seed=None):
-        """Straight-line initial guess (optimization.py:189-240)."""
-        dim = self.model['dim']
-        deg = self.model['deg']
-        numVeh = self.model['numVeh']
-        tf = self.model['tf']
-        initPoints = self.model['initPoints']
-        finalPoints = self.model['finalPoints']
-        initSpeeds = self.model['initSpeeds']
-        finalSpeeds = self.model['finalSpeeds']
-        initAngs = self.model['initAngs']
-        finalAngs = self.model['finalAngs']
-
+        """Straight-line initial guess with N(0, std^2) noise (optimization.py:189-240), all vehicles at once.
+        One `randn` draw of numVeh*dim*len values consumes NumPy's legacy stream in the order the reference's
+        per-row draws do, so a given `seed` yields the reference's guess."""
+        m = self.model
+        numVeh, dim, deg = m['numVeh'], m['dim'], m['deg']
+        start = np.asarray(m['initPoints'], dtype=float)[:numVeh]
+        stop = np.asarray(m['finalPoints'], dtype=float)[:numVeh]
+        npts = deg + 1
+        if m['initSpeeds'][0] is not None:
+            if dim != 2:
+                raise ValueError('The dimension must be 2 for initial and final speeds and angles.')
+            # prescribed speeds pin the second and the second-to-last control point: the line runs between those
+            heading0 = np.stack((np.cos(m['initAngs']), np.sin(m['initAngs'])), axis=1)
+            heading1 = np.stack((np.cos(m['finalAngs']), np.sin(m['finalAngs'])), axis=1)
+            start = start + (np.asarray(m['initSpeeds'], dtype=float) * m['tf'] / deg)[:, None] * heading0
+            stop = stop - (np.asarray(m['finalSpeeds'], dtype=float) * m['tf'] / deg)[:, None] * heading1
+            npts = deg - 1
         np.random.seed(seed)
-        xGuess = []
-        for i in range(numVeh):
-            for j in range(dim):
-                if initSpeeds[0] is None:
-                    line = np.linspace(initPoints[i, j], finalPoints[i, j], deg + 1)
-                    line += np.random.randn(deg + 1) * std
-                else:
-                    if dim != 2:
-                        err = ('The dimension must be 2 for initial and final '
-                               'speeds and angles.')
-                        raise ValueError(err)
-                    initMag = initSpeeds[i] * tf / deg
-                    finalMag = finalSpeeds[i] * tf / deg
-                    if j % 2 == 0:
-                        initPt = initPoints[i, j] + initMag * np.cos(initAngs[i])
-                        finalPt = finalPoints[i, j] - finalMag * np.cos(finalAngs[i])
-                    else:
-                        initPt = initPoints[i, j] + initMag * np.sin(initAngs[i])
-                        finalPt = finalPoints[i, j] - finalMag * np.sin(finalAngs[i])
-                    line = np.linspace(initPt, finalPt, deg + 1 - 2)
-                    line += np.random.randn(deg + 1 - 2) * std
-                xGuess.append(line[1:-1])
-        if self._timeopt():
-            xGuess.append([tf])
-        return np.concatenate(xGuess)
+        # row by row: np.linspace with array end points switches formula when ANY row has start == stop, which
+        # would move the other rows' last bits away from the reference's scalar calls
+        lines = np.array([np.linspace(a, b, npts) for a, b in zip(start.ravel(), stop.ravel())])
+        lines += np.random.randn(numVeh * dim, npts) * std
+        guess = lines[:, 1:-1].reshape(-1)
+        return np.append(guess, m['tf']) if self._timeopt() else guess
 
     def reshapeVector(self, x):
         """x -> y[(numVeh*dim) x (deg+1)] (optimization.py:242-285)."""

@@ -714,6 +714,18 @@ static void decasteljau_split(const double *cpts, int K, double t, double *left,
     left[K - 1] = right_rev[K - 1] = tmp[0];
 }
 
+/* bezier.py:533-572 Bezier.split(tDiv): per row deCasteljauSplit at z = (tDiv-t0)/(tf-t0); the second curve takes
+ * the reversed right array (bezier.py:563).  left/right: rows x (n+1). */
+EXPORT void obtg_oracle_split(const double *cpts, int rows, int n, double z, double *left, double *right)
+{
+    int K = n + 1;
+    double rr[K];
+    for (int r = 0; r < rows; ++r) {
+        decasteljau_split(cpts + (long)r * K, K, z, left + (long)r * K, rr);
+        for (int i = 0; i < K; ++i) right[(long)r * K + i] = rr[K - 1 - i];
+    }
+}
+
 /* bezier.py:1320-1351: curve parameter of a hull closest point */
 static double hull_param(const double *poly, int K, const double *closest)
 {

@@ -92,6 +92,14 @@ def mul(a, b):
     return out
 
 
+def split(cpts, z):
+    cpts = np.atleast_2d(_f64(cpts))
+    rows, nc = cpts.shape
+    left, right = np.empty((rows, nc)), np.empty((rows, nc))
+    lib().obtg_oracle_split(_p(cpts), C.c_int(rows), C.c_int(nc - 1), C.c_double(z), _p(left), _p(right))
+    return left, right
+
+
 def normsq(x):
     x = np.atleast_2d(_f64(x))
     d, nc = x.shape

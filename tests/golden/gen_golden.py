@@ -206,6 +206,11 @@ def gen_ops():
             d[pre + "mul"] = np.asarray((A * Bc).cpts)
             d[pre + "sub"] = np.asarray((A - Bc).cpts)
             d[pre + "add"] = np.asarray((A + Bc).cpts)
+            for q, frac in enumerate((0.3, 0.5, 0.875)):       # Bezier.split (bezier.py:533-572)
+                c1, c2 = A.split(frac * tf)
+                d[pre + "split%d_t" % q] = np.array(frac * tf)
+                d[pre + "split%d_l" % q], d[pre + "split%d_r" % q] = np.asarray(c1.cpts), np.asarray(c2.cpts)
+                d[pre + "split%d_span" % q] = np.array([c1.t0, c1.tf, c2.t0, c2.tf])
             case += 1
     d["n_cases"] = np.array(case)
     save("bezier_ops.npz", **d)

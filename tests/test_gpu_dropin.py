@@ -42,6 +42,11 @@ def test_bezier_methods_match_reference(golden_dir):
         assert_close(ns.cpts, o[pre + "normsq"])
         assert_close((A * B).cpts, o[pre + "mul"])
         assert np.array_equal((A - B).cpts, o[pre + "sub"]) and np.array_equal((A + B).cpts, o[pre + "add"])
+        for q in range(3):                                     # Bezier.split (bezier.py:533-572)
+            c1, c2 = A.split(float(o[pre + "split%d_t" % q]))
+            assert_close(c1.cpts, o[pre + "split%d_l" % q])
+            assert_close(c2.cpts, o[pre + "split%d_r" % q])
+            assert [c1.t0, c1.tf, c2.t0, c2.tf] == o[pre + "split%d_span" % q].tolist()
 
 
 def test_mindist_known_answers(golden_dir):
@@ -291,3 +296,39 @@ def test_swarm_3d_driver_flow():
     assert abs(r_fd.fun - r_j.fun) < 1e-4 * max(1.0, abs(r_fd.fun))
     # the straight-line guess is infeasible (the paths cross): the constraint did real work
     assert bo.temporalSeparationConstraints(bo.generateGuess(std=0)).min() < 0
+
+
+def test_integration_md_binding_stub_runs(golden_dir):
+    """INTEGRATION.md section 2 shows the ctypes stub a maintainer of the reference would drop beside
+    optimization.py.  Execute that very text (library name resolved to the in-tree build, a stand-in `optimization`
+    module carrying DEG_ELEV) and hold its functions to the reference's fixtures."""
+    import os
+    import re
+    import sys
+    import types
+    from optimalbeziertrajectorygeneration_amd import _capi
+    _capi.load()                                   # one HIP runtime per process (see _capi._preload_torch_hip_runtime)
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    text = open(os.path.join(repo, "INTEGRATION.md")).read()
+    m = re.search(r"```python\n(# obtg_binding\.py.*?)```", text, re.S)
+    assert m, "the binding stub is missing from INTEGRATION.md"
+    code = m.group(1).replace('"libobtg_hip.so"', repr(_capi.LIB_PATH))
+    fake = types.ModuleType("optimization")
+    saved = sys.modules.get("optimization")
+    sys.modules["optimization"] = fake
+    try:
+        ns = {}
+        exec(compile(code, "INTEGRATION.md:obtg_binding.py", "exec"), ns)
+        c = np.load(golden_dir + "/constraints.npz")
+        for name in ("c3s_R10", "c2", "n20"):
+            N, dim, n, R, tf, ms, vmax, vmin, wmax = c[name + "_par"]
+            fake.DEG_ELEV = int(R)
+            Y = c[name + "_Y"]
+            assert_close(ns["_temporalSeparationConstraints"](Y, int(N), int(dim), ms), c[name + "_tsep"])
+            assert_close(ns["_maxSpeedConstraints"](Y, int(N), int(dim), tf, vmax), c[name + "_maxspeed"])
+        assert ns["_temporalSeparationConstraints"](c["c2_Y"][:3], 1, 3, 0.9) is None       # optimization.py:345-346
+    finally:
+        if saved is None:
+            del sys.modules["optimization"]
+        else:
+            sys.modules["optimization"] = saved

@@ -1011,3 +1011,51 @@ def test_set_polygons_invalidates_the_hull_pair_list(capi, synth):
     with pytest.raises(capi.ObtgError):
         ctx.deriv_energy_obj(Yb, np.array([4.0, 4.0, 5.0]), 2)
     ctx.close()
+
+
+def test_ang_rate_with_elevation_both_orders(capi, oracle, synth, golden_dir):
+    """DEG_ELEV > 0: the default path forms num / den at degree 4n and elevates both by 4R (k_dynamics_elev);
+    obtg_ctx_set_ang_rate_order(1) keeps the reference's order of operations (elevate first, generic kernel).
+    Both against the reference's fixtures and the oracle at 1e-9 scale-aware; the fused speed + angular-rate launch
+    with R > 0 equals the separate entry points; inf/nan pattern of an exactly degenerate vehicle."""
+    import torch
+    c = _load(golden_dir, "constraints.npz")
+    for name in ("c3s_R10", "c3s_R100", "c4s_R3"):
+        N, dim, n, R, tf, ms, vmax, vmin, wmax = c[name + "_par"]
+        N, n, R = int(N), int(n), int(R)
+        Y = c[name + "_Y"]
+        ctx = capi.Context(N, 2, n, R)
+        fast = ctx.ang_rate(Y, tf, wmax)[0]
+        ctx.set_ang_rate_order(True)
+        ref_order = ctx.ang_rate(Y, tf, wmax)[0]
+        ctx.set_ang_rate_order(False)
+        assert_close(fast, c[name + "_angrate"], RTOL, name + " fast vs golden")
+        assert_close(ref_order, c[name + "_angrate"], RTOL, name + " reference order vs golden")
+        assert_close(fast, oracle.ang_rate(Y, N, R, tf, wmax), RTOL, name + " fast vs oracle")
+        # fused launch (obtg_dynamics_dev) on a perturbed batch with per-row tf
+        B = 7
+        Yb = synth.fd_batch(Y, B=B)
+        tfs = np.linspace(2.0, 9.0, B)
+        ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+        dY, dtf = torch.from_numpy(Yb).cuda(), torch.from_numpy(tfs).cuda()
+        osp = torch.empty((B, ctx.len_speed), dtype=torch.float64, device="cuda")
+        oan = torch.empty((B, ctx.len_ang_rate), dtype=torch.float64, device="cuda")
+        ctx.dynamics_dev(dY.data_ptr(), dtf.data_ptr(), B, vmax, True, wmax, osp.data_ptr(), oan.data_ptr())
+        torch.cuda.synchronize()
+        ctx.set_stream(0)
+        _, o_sp, o_an = oracle.eval_batch(Yb, tfs, N, 2, R, 0.9, vmax, wmax)
+        assert_close(osp.cpu().numpy(), o_sp, RTOL, name + " fused speed")
+        assert_close(oan.cpu().numpy(), o_an, RTOL, name + " fused ang")
+        assert_close(ctx.speed(Yb, tfs, vmax, True), o_sp, RTOL, name + " speed entry")
+        ctx.close()
+    # ragged group (N * B not a multiple of 64) and an exactly stationary vehicle: 0/0 -> NaN in every column
+    Y = synth.swarm_control_points(5, 2, 10, seed=4)
+    Y[2:4, :] = np.array([[3.0], [-2.0]])
+    ctx = capi.Context(5, 2, 10, 12)
+    got = ctx.ang_rate(synth.fd_batch(Y, B=3), 4.0, 1.0)
+    L = 4 * (10 + 12) + 1
+    assert got.shape == (3, 5 * L)
+    assert np.isnan(got[0].reshape(5, L)[1]).all() and np.isfinite(got[0].reshape(5, L)[[0, 2, 3, 4]]).all()
+    ref = oracle.ang_rate(Y, 5, 12, 4.0, 1.0).reshape(5, L)
+    assert_close(got[0].reshape(5, L)[[0, 2, 3, 4]], ref[[0, 2, 3, 4]], RTOL, "regular vehicles beside a degenerate one")
+    ctx.close()

@@ -43,6 +43,10 @@ def test_bezier_ops(oracle, golden_dir):
         assert_close(oracle.normsq(a), o[pre + "normsq"], 1e-13, pre + "normsq")
         assert_close(oracle.mul(a, b), o[pre + "mul"], 1e-13, pre + "mul")
         assert (a - b == o[pre + "sub"]).all() and (a + b == o[pre + "add"]).all()
+        for q in range(3):
+            left, right = oracle.split(a, float(o[pre + "split%d_t" % q]) / tf)
+            assert_close(left, o[pre + "split%d_l" % q], 1e-13, pre + "split left")
+            assert_close(right, o[pre + "split%d_r" % q], 1e-13, pre + "split right")
 
 
 def test_normsq_is_d_over_2_quirk(oracle):
