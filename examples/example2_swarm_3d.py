@@ -26,10 +26,10 @@ def crossing_swarm(numVeh, seed=3):
     return init + rng.normal(0, 0.05, init.shape), final + rng.normal(0, 0.05, final.shape)
 
 
-def solve(numVeh=5, with_jac=True, maxiter=400):
+def solve(numVeh=5, with_jac=True, maxiter=400, separationRows='all'):
     init, final = crossing_swarm(numVeh)
     bezopt = BezOptimization(numVeh=numVeh, dimension=3, degree=5, minimizeGoal='Euclidean', maxSep=0.9,
-                             initPoints=init, finalPoints=final)
+                             initPoints=init, finalPoints=final, separationRows=separationRows)
     x0 = bezopt.generateGuess(std=0.2, seed=1)
     con = {'type': 'ineq', 'fun': bezopt.temporalSeparationConstraints}
     if with_jac:
@@ -42,12 +42,12 @@ def solve(numVeh=5, with_jac=True, maxiter=400):
 
 def main():
     numVeh = int(sys.argv[1]) if len(sys.argv) > 1 else 5
-    for with_jac in (False, True):
-        bezopt, res, dt = solve(numVeh, with_jac)
+    for with_jac, rows in ((False, 'all'), (True, 'all'), (True, 'min')):
+        bezopt, res, dt = solve(numVeh, with_jac, separationRows=rows)
         sep = bezopt.temporalSeparationConstraints(res.x)
-        print('%-28s objective %.6f  nit %3d  nfev %5d  converged %s  min separation margin %+.2e  %.2f s'
-              % ('structured Jacobian provider' if with_jac else 'SciPy finite differences', res.fun, res.nit, res.nfev,
-                 res.success, sep.min(), dt))
+        what = ('structured Jacobian provider' if with_jac else 'SciPy finite differences') + (', one row per pair' if rows == 'min' else '')
+        print('%-46s objective %.6f  nit %3d  nfev %5d  converged %s  min separation margin %+.2e  %4d rows  %.2f s'
+              % (what, res.fun, res.nit, res.nfev, res.success, sep.min(), sep.size, dt))
 
 
 if __name__ == '__main__':

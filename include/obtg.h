@@ -31,6 +31,8 @@
 #ifndef OBTG_H
 #define OBTG_H
 
+#include <stddef.h>
+
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -75,6 +77,12 @@ const char* obtg_last_error(const obtg_ctx*);
 int obtg_device_count(void);
 /* every exported symbol, NUL-separated list terminated by an empty string (for load tests) */
 const char* obtg_abi_symbols(void);
+
+/* Pinned (page-locked) host memory.  The host-buffer entry points accept any host pointer; buffers from
+ * obtg_host_alloc are DMA targets as they are (PCIe rate), pageable buffers (e.g. a plain NumPy array) are staged
+ * through a pinned ring inside the context, chunk by chunk, overlapped with the transfer. */
+int obtg_host_alloc(size_t bytes, void** out);
+int obtg_host_free(void* p);
 
 /* ---- context -------------------------------------------------------------------------
  * Replaces: BezOptimization.__init__ (optimization.py:21-63) as far as the constraint

@@ -6,6 +6,7 @@ raises `RuntimeError` when the library is missing or no gfx950 device is usable.
 """
 import ctypes as C
 import os
+import weakref
 
 import numpy as np
 
@@ -29,6 +30,8 @@ _SIGNATURES = {
     "obtg_last_error": (C.c_char_p, [_vp]),
     "obtg_device_count": (_i, []),
     "obtg_abi_symbols": (_vp, []),
+    "obtg_host_alloc": (_i, [C.c_size_t, C.POINTER(_vp)]),
+    "obtg_host_free": (_i, [_vp]),
     "obtg_ctx_create": (_i, [C.POINTER(_vp), _i, _i, _i, _i, _i, _vp, _i]),
     "obtg_ctx_destroy": (None, [_vp]),
     "obtg_ctx_set_stream": (_i, [_vp, _vp]),
@@ -152,6 +155,57 @@ class ObtgError(RuntimeError):
     pass
 
 
+class _PinnedPool(object):
+    """Page-locked host blocks for the large result arrays of the host-buffer entry points.
+
+    The device writes such an array by DMA at PCIe rate; a pageable NumPy array would be staged chunk by chunk
+    (include/obtg.h, obtg_host_alloc).  Blocks are recycled: pinning costs milliseconds per 100 MB, an SLSQP
+    driver asks for the same shapes on every iteration.  An array keeps its block alive through its buffer
+    object; when the last view dies the block returns to the pool (at most `cap` bytes stay cached)."""
+
+    MIN_BYTES = 1 << 20
+
+    def __init__(self, cap=4 << 30):
+        self.cap, self.cached, self.free = cap, 0, {}
+
+    def _release(self, size, ptr):
+        if self.cached + size <= self.cap:
+            self.free.setdefault(size, []).append(ptr)
+            self.cached += size
+        elif _lib is not None:
+            _lib.obtg_host_free(_vp(ptr))
+
+    def empty(self, shape, dtype=np.float64):
+        dtype = np.dtype(dtype)
+        count = int(np.prod(shape))
+        nbytes = count * dtype.itemsize
+        if nbytes < self.MIN_BYTES:
+            return np.empty(shape, dtype)
+        size = 1 << (nbytes - 1).bit_length()
+        if size > (1 << 28):                      # above 256 MB: 64 MB granularity instead of powers of two
+            size = -(-nbytes // (64 << 20)) * (64 << 20)
+        blocks = self.free.get(size)
+        if blocks:
+            ptr = blocks.pop()
+            self.cached -= size
+        else:
+            h = _vp()
+            if load().obtg_host_alloc(size, C.byref(h)) != OK or not h.value:
+                return np.empty(shape, dtype)     # no pinned memory left: a pageable array still works (staged)
+            ptr = h.value
+        buf = (C.c_char * nbytes).from_address(ptr)
+        weakref.finalize(buf, self._release, size, ptr)
+        return np.frombuffer(buf, dtype=dtype, count=count).reshape(shape)
+
+
+_pinned = _PinnedPool()
+
+
+def pinned_empty(shape, dtype=np.float64):
+    """An uninitialised array in page-locked host memory (falls back to np.empty for small sizes)."""
+    return _pinned.empty(shape, dtype)
+
+
 class Context(object):
     """One problem shape on one MI355X: wraps obtg_ctx."""
 
@@ -242,7 +296,7 @@ class Context(object):
     # -- host-buffer sweeps
     def temporal_sep(self, Y, max_sep):
         Y, B = self._rows(Y)
-        out = np.empty((B, self.len_temporal_sep))
+        out = pinned_empty((B, self.len_temporal_sep))
         self._check(self._lib.obtg_temporal_sep(self._h, _ptr(Y), B, float(max_sep), _ptr(out)), "obtg_temporal_sep")
         return out
 
@@ -250,7 +304,7 @@ class Context(object):
         Y, B = self._rows(Y)
         if pair_count is None:
             pair_count = self.num_pairs - pair_begin
-        out = np.empty((B, pair_count))
+        out = pinned_empty((B, pair_count))
         self._check(self._lib.obtg_temporal_sep_min_range(self._h, _ptr(Y), B, float(max_sep), int(pair_begin),
                                                           int(pair_count), _ptr(out)), "obtg_temporal_sep_min_range")
         return out
@@ -258,7 +312,7 @@ class Context(object):
     def speed(self, Y, tf, bound, is_max):
         Y, B = self._rows(Y)
         tf = self._tf(tf, B)
-        out = np.empty((B, self.len_speed))
+        out = pinned_empty((B, self.len_speed))
         self._check(self._lib.obtg_speed(self._h, _ptr(Y), _ptr(tf), B, float(bound), int(bool(is_max)), _ptr(out)),
                     "obtg_speed")
         return out
@@ -266,7 +320,7 @@ class Context(object):
     def ang_rate(self, Y, tf, max_rate):
         Y, B = self._rows(Y)
         tf = self._tf(tf, B)
-        out = np.empty((B, self.len_ang_rate))
+        out = pinned_empty((B, self.len_ang_rate))
         self._check(self._lib.obtg_ang_rate(self._h, _ptr(Y), _ptr(tf), B, float(max_rate), _ptr(out)),
                     "obtg_ang_rate")
         return out
@@ -371,12 +425,10 @@ class Context(object):
         self._need_hull_pairs("gjk_swarm")
         Y, B = self._rows(Y)
         n = self.n_hull_pairs
-        flag = np.zeros((B, n), np.int32)
-        nsup = np.zeros((B, n), np.int32)
-        status = np.zeros((B, n), np.int32)
-        p1 = np.full((B, n, 3), np.nan)
-        p2 = np.full((B, n, 3), np.nan)
-        dist = np.full((B, n), np.nan)
+        flag, nsup, status = (pinned_empty((B, n), np.int32) for _ in range(3))
+        p1, p2, dist = pinned_empty((B, n, 3)), pinned_empty((B, n, 3)), pinned_empty((B, n))
+        for a, v in ((flag, 0), (nsup, 0), (status, 0), (p1, np.nan), (p2, np.nan), (dist, np.nan)):
+            a.fill(v)
         self._check(self._lib.obtg_gjk_swarm(self._h, _ptr(Y), B, max_iter, md_cap, _ptr(flag), _ptr(p1), _ptr(p2),
                                              _ptr(dist), _ptr(nsup), _ptr(status)), "obtg_gjk_swarm")
         return dict(flag=flag, c1=p1, c2=p2, dist=dist, n_support=nsup, status=status)
@@ -493,7 +545,7 @@ class Context(object):
         pc = np.ascontiguousarray(pert_col, dtype=np.int32)
         pv = _f64(pert_val)
         n = pr.shape[0]
-        out = np.empty((n, max(self.n_veh + self.n_obs - 1, 0), 2 * self.deg + self.deg_elev + 1))
+        out = pinned_empty((n, max(self.n_veh + self.n_obs - 1, 0), 2 * self.deg + self.deg_elev + 1))
         self._check(self._lib.obtg_temporal_sep_fd(self._h, _ptr(Y0), n, _ptr(pr), _ptr(pc), _ptr(pv),
                                                    float(max_sep), _ptr(out)), "obtg_temporal_sep_fd")
         return out

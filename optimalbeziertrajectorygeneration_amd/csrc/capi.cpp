@@ -186,7 +186,7 @@ int obtg_device_count(void)
 const char* obtg_abi_symbols(void)
 {
     static const char syms[] =
-        "obtg_strerror\0obtg_last_error\0obtg_device_count\0obtg_abi_symbols\0"
+        "obtg_strerror\0obtg_last_error\0obtg_device_count\0obtg_abi_symbols\0obtg_host_alloc\0obtg_host_free\0"
         "obtg_ctx_create\0obtg_ctx_destroy\0obtg_ctx_set_stream\0obtg_ctx_set_deg_elev\0obtg_ctx_set_ang_rate_order\0obtg_sync\0"
         "obtg_len_temporal_sep\0obtg_len_speed\0obtg_len_ang_rate\0obtg_num_pairs\0"
         "obtg_temporal_sep\0obtg_speed\0obtg_ang_rate\0obtg_temporal_sep_min\0obtg_temporal_sep_min_range\0"
@@ -251,6 +251,10 @@ void obtg_ctx_destroy(obtg_ctx* c)
     for (DevBuf* b : bufs) b->release();
     for (auto& b : c->ws_misc) b.release();
     for (auto& b : c->d_gjk_len) b.release();
+    if (c->ring) {
+        (void)hipHostFree(c->ring);
+        for (hipEvent_t e : c->ring_ev) if (e) (void)hipEventDestroy(e);
+    }
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
 }
@@ -270,6 +274,22 @@ int obtg_ctx_set_deg_elev(obtg_ctx* c, int deg_elev)
     OBTG_HIP(c, hipStreamSynchronize(c->stream));
     c->R = deg_elev;
     return ensure_tables(c);
+}
+
+int obtg_host_alloc(size_t bytes, void** out)
+{
+    if (!out) return OBTG_ERR_ARG;
+    *out = nullptr;
+    if (bytes == 0) bytes = 8;
+    if (hipHostMalloc(out, bytes, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); *out = nullptr; return OBTG_ERR_OOM; }
+    return OBTG_OK;
+}
+
+int obtg_host_free(void* p)
+{
+    if (!p) return OBTG_OK;
+    if (hipHostFree(p) != hipSuccess) { (void)hipGetLastError(); return OBTG_ERR_ARG; }
+    return OBTG_OK;
 }
 
 int obtg_ctx_set_ang_rate_order(obtg_ctx* c, int elevate_first)
@@ -342,18 +362,107 @@ int obtg_fd_batch_dev(obtg_ctx* c, const double* dY0, int n_fixed_cols, double h
 }
 
 // ------------------------------------------------------------------ host-buffer sweeps
+// Host <-> device copies of the host-buffer entry points.  A caller's NumPy array is pageable memory; handing it
+// to hipMemcpyAsync makes the runtime bounce it through its own staging at ~10 GB/s (measured: 427 MB D2H in
+// 41 ms).  Instead: (a) buffers the caller allocated with obtg_host_alloc (pinned) are DMA targets as they are;
+// (b) pageable buffers go through the context's pinned ring in chunks, the DMA of chunk i+1 running while the host
+// copies chunk i out of (into) the ring.
+constexpr size_t kRingChunk = 4u << 20;     // bytes per ring slot
+constexpr int kRingSlots = 4;
+constexpr size_t kRingMin = 256u << 10;     // smaller copies: one pageable hipMemcpyAsync is as fast
+
+static bool is_pinned(const void* p)
+{
+    hipPointerAttribute_t a;
+    if (hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return false; }
+    return a.type == hipMemoryTypeHost;
+}
+
+static int ensure_ring(obtg_ctx* c)
+{
+    if (c->ring) return OBTG_OK;
+    if (hipHostMalloc(&c->ring, kRingChunk * kRingSlots, hipHostMallocDefault) != hipSuccess) {
+        (void)hipGetLastError(); c->ring = nullptr; return OBTG_ERR_OOM;
+    }
+    for (int i = 0; i < kRingSlots; ++i)
+        if (hipEventCreateWithFlags(&c->ring_ev[i], hipEventDisableTiming) != hipSuccess) return OBTG_ERR_DEVICE;
+    return OBTG_OK;
+}
+
+// wait until the DMA that last used ring slot `sl` is done (the CPU is about to touch the slot)
+static int ring_slot_ready(obtg_ctx* c, int sl)
+{
+    if (c->ring_pending[sl]) {
+        OBTG_HIP(c, hipEventSynchronize(c->ring_ev[sl]));
+        c->ring_pending[sl] = false;
+    }
+    return OBTG_OK;
+}
+
 static int h2d(obtg_ctx* c, DevBuf& b, const void* src, size_t bytes)
 {
     int rc = b.reserve(bytes);
     if (rc) return rc;
-    OBTG_HIP(c, hipMemcpyAsync(b.p, src, bytes, hipMemcpyHostToDevice, c->stream));
+    if (bytes < kRingMin || is_pinned(src) || ensure_ring(c) != OBTG_OK) {
+        OBTG_HIP(c, hipMemcpyAsync(b.p, src, bytes, hipMemcpyHostToDevice, c->stream));
+        return OBTG_OK;
+    }
+    char* ring = static_cast<char*>(c->ring);
+    for (size_t off = 0; off < bytes; off += kRingChunk) {
+        const int sl = c->ring_next;
+        c->ring_next = (c->ring_next + 1) % kRingSlots;
+        const size_t nb = std::min(kRingChunk, bytes - off);
+        if ((rc = ring_slot_ready(c, sl))) return rc;
+        std::memcpy(ring + sl * kRingChunk, static_cast<const char*>(src) + off, nb);
+        OBTG_HIP(c, hipMemcpyAsync(static_cast<char*>(b.p) + off, ring + sl * kRingChunk, nb, hipMemcpyHostToDevice, c->stream));
+        OBTG_HIP(c, hipEventRecord(c->ring_ev[sl], c->stream));
+        c->ring_pending[sl] = true;
+    }
     return OBTG_OK;
 }
 
+// device -> host, complete on return for THIS array (the stream may still hold other work)
+static int d2h_copy(obtg_ctx* c, void* dst, const void* src, size_t bytes)
+{
+    if (bytes == 0) return OBTG_OK;
+    if (bytes < kRingMin || is_pinned(dst) || ensure_ring(c) != OBTG_OK) {
+        OBTG_HIP(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream));
+        return OBTG_OK;
+    }
+    char* ring = static_cast<char*>(c->ring);
+    const size_t n_chunks = (bytes + kRingChunk - 1) / kRingChunk;
+    int slot_of[kRingSlots];
+    int rc;
+    auto issue = [&](size_t i) -> int {
+        const size_t off = i * kRingChunk, nb = std::min(kRingChunk, bytes - off);
+        const int sl = c->ring_next;
+        c->ring_next = (c->ring_next + 1) % kRingSlots;
+        slot_of[i % kRingSlots] = sl;
+        // a pending H2D out of this slot precedes us on the same stream: DMA order is safe, only CPU access waits
+        OBTG_HIP(c, hipMemcpyAsync(ring + sl * kRingChunk, static_cast<const char*>(src) + off, nb, hipMemcpyDeviceToHost, c->stream));
+        OBTG_HIP(c, hipEventRecord(c->ring_ev[sl], c->stream));
+        c->ring_pending[sl] = true;
+        return OBTG_OK;
+    };
+    size_t issued = 0;
+    for (; issued < n_chunks && issued < (size_t)kRingSlots; ++issued) if ((rc = issue(issued))) return rc;
+    for (size_t i = 0; i < n_chunks; ++i) {
+        const int sl = slot_of[i % kRingSlots];
+        if ((rc = ring_slot_ready(c, sl))) return rc;
+        const size_t off = i * kRingChunk, nb = std::min(kRingChunk, bytes - off);
+        std::memcpy(static_cast<char*>(dst) + off, ring + sl * kRingChunk, nb);
+        if (issued < n_chunks) { if ((rc = issue(issued))) return rc; ++issued; }   // the slot just emptied is next in the rotation
+    }
+    return OBTG_OK;
+}
+
+// the last output of a host entry point: copy, then leave the device idle
 static int d2h(obtg_ctx* c, void* dst, const void* src, size_t bytes)
 {
-    OBTG_HIP(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream));
+    int rc = d2h_copy(c, dst, src, bytes);
+    if (rc) return rc;
     OBTG_HIP(c, hipStreamSynchronize(c->stream));
+    for (bool& f : c->ring_pending) f = false;
     flush_pending_events(c);
     return OBTG_OK;
 }
@@ -525,11 +634,11 @@ int obtg_gjk_pairs(obtg_ctx* c, const double* pts, int n_pts, const int* poly_of
                           max_iter, md_cap, d_flag, d_p1, d_p2, d_dist, d_trace, trace_cap, d_nsup, d_status,
                           planar);
     if (rc) return rc;
-    OBTG_HIP(c, hipMemcpyAsync(flag, d_flag, sizeof(int) * n_pairs, hipMemcpyDeviceToHost, c->stream));
-    if (n_support) OBTG_HIP(c, hipMemcpyAsync(n_support, d_nsup, sizeof(int) * n_pairs, hipMemcpyDeviceToHost, c->stream));
-    if (status) OBTG_HIP(c, hipMemcpyAsync(status, d_status, sizeof(int) * n_pairs, hipMemcpyDeviceToHost, c->stream));
-    OBTG_HIP(c, hipMemcpyAsync(p1, d_p1, sizeof(double) * 3 * n_pairs, hipMemcpyDeviceToHost, c->stream));
-    OBTG_HIP(c, hipMemcpyAsync(p2, d_p2, sizeof(double) * 3 * n_pairs, hipMemcpyDeviceToHost, c->stream));
+    if ((rc = d2h_copy(c, flag, d_flag, sizeof(int) * n_pairs))) return rc;
+    if (n_support) if ((rc = d2h_copy(c, n_support, d_nsup, sizeof(int) * n_pairs))) return rc;
+    if (status) if ((rc = d2h_copy(c, status, d_status, sizeof(int) * n_pairs))) return rc;
+    if ((rc = d2h_copy(c, p1, d_p1, sizeof(double) * 3 * n_pairs))) return rc;
+    if ((rc = d2h_copy(c, p2, d_p2, sizeof(double) * 3 * n_pairs))) return rc;
     if (d_trace)
         OBTG_HIP(c, hipMemcpyAsync(support_trace, d_trace, sizeof(short) * 2 * (size_t)trace_cap * n_pairs,
                                    hipMemcpyDeviceToHost, c->stream));
@@ -650,11 +759,11 @@ int obtg_gjk_swarm(obtg_ctx* c, const double* Y, int B, int max_iter, int md_cap
     double* d_dist = d_p2 + 3 * n;
     rc = launch_gjk_swarm(c, c->ws_in.as<double>(), B, max_iter, md_cap, d_flag, d_p1, d_p2, d_dist, d_nsup, d_status);
     if (rc) return rc;
-    OBTG_HIP(c, hipMemcpyAsync(flag, d_flag, sizeof(int) * n, hipMemcpyDeviceToHost, c->stream));
-    if (nsup) OBTG_HIP(c, hipMemcpyAsync(nsup, d_nsup, sizeof(int) * n, hipMemcpyDeviceToHost, c->stream));
-    if (status) OBTG_HIP(c, hipMemcpyAsync(status, d_status, sizeof(int) * n, hipMemcpyDeviceToHost, c->stream));
-    OBTG_HIP(c, hipMemcpyAsync(p1, d_p1, sizeof(double) * 3 * n, hipMemcpyDeviceToHost, c->stream));
-    OBTG_HIP(c, hipMemcpyAsync(p2, d_p2, sizeof(double) * 3 * n, hipMemcpyDeviceToHost, c->stream));
+    if ((rc = d2h_copy(c, flag, d_flag, sizeof(int) * n))) return rc;
+    if (nsup) if ((rc = d2h_copy(c, nsup, d_nsup, sizeof(int) * n))) return rc;
+    if (status) if ((rc = d2h_copy(c, status, d_status, sizeof(int) * n))) return rc;
+    if ((rc = d2h_copy(c, p1, d_p1, sizeof(double) * 3 * n))) return rc;
+    if ((rc = d2h_copy(c, p2, d_p2, sizeof(double) * 3 * n))) return rc;
     return d2h(c, dist, d_dist, sizeof(double) * n);
 }
 
@@ -681,7 +790,7 @@ int obtg_min_dist(obtg_ctx* c, const double* curves, int n_curves, int K, const 
                          md_cap, max_depth, max_nodes, m[5].as<double>(), c->ws_out.as<double>(), m[3].as<int>());
     if (rc) return rc;
     std::vector<int> hinfo((size_t)4 * n_pairs);
-    OBTG_HIP(c, hipMemcpyAsync(hinfo.data(), m[3].p, sizeof(int) * 4 * n_pairs, hipMemcpyDeviceToHost, c->stream));
+    if ((rc = d2h_copy(c, hinfo.data(), m[3].p, sizeof(int) * 4 * n_pairs))) return rc;
     rc = d2h(c, res, c->ws_out.p, sizeof(double) * 3 * n_pairs);
     if (rc) return rc;
     if (info) std::memcpy(info, hinfo.data(), sizeof(int) * 4 * n_pairs);
@@ -711,7 +820,7 @@ int obtg_min_dist_robust(obtg_ctx* c, const double* curves, int n_curves, int K,
                                 kMaxLevel, kCap, m[5].as<double>(), c->ws_out.as<double>(), m[3].as<int>());
     if (rc) return rc;
     std::vector<int> hinfo((size_t)4 * n_pairs);
-    OBTG_HIP(c, hipMemcpyAsync(hinfo.data(), m[3].p, sizeof(int) * 4 * n_pairs, hipMemcpyDeviceToHost, c->stream));
+    if ((rc = d2h_copy(c, hinfo.data(), m[3].p, sizeof(int) * 4 * n_pairs))) return rc;
     rc = d2h(c, res, c->ws_out.p, sizeof(double) * 3 * n_pairs);
     if (rc) return rc;
     if (info) std::memcpy(info, hinfo.data(), sizeof(int) * 4 * n_pairs);
@@ -751,7 +860,7 @@ int obtg_min_dist2poly(obtg_ctx* c, const double* curves, int n_curves, int K, c
                               m[5].as<double>(), c->ws_out.as<double>(), m[3].as<int>(), max_K);
     if (rc) return rc;
     std::vector<int> hinfo((size_t)4 * n_pairs);
-    OBTG_HIP(c, hipMemcpyAsync(hinfo.data(), m[3].p, sizeof(int) * 4 * n_pairs, hipMemcpyDeviceToHost, c->stream));
+    if ((rc = d2h_copy(c, hinfo.data(), m[3].p, sizeof(int) * 4 * n_pairs))) return rc;
     rc = d2h(c, res, c->ws_out.p, sizeof(double) * 5 * n_pairs);
     if (rc) return rc;
     if (info) std::memcpy(info, hinfo.data(), sizeof(int) * 4 * n_pairs);
@@ -795,7 +904,7 @@ int obtg_bern_split(obtg_ctx* c, const double* in, int rows, int n, double z, do
     if ((rc = c->ws_out.reserve(sizeof(double) * 2 * len))) return rc;
     double* dl = c->ws_out.as<double>();
     if ((rc = launch_bern_split(c, c->ws_in.as<double>(), rows, n, z, dl, dl + len))) return rc;
-    OBTG_HIP(c, hipMemcpyAsync(left, dl, sizeof(double) * len, hipMemcpyDeviceToHost, c->stream));
+    if ((rc = d2h_copy(c, left, dl, sizeof(double) * len))) return rc;
     return d2h(c, right, dl + len, sizeof(double) * len);
 }
 

@@ -82,6 +82,10 @@ struct obtg_ctx {
 
     // scratch for host-buffer entry points
     obtg::DevBuf ws_in, ws_in2, ws_out, ws_misc[8];
+    void* ring = nullptr;                 // pinned staging ring for pageable caller buffers (capi.cpp h2d / d2h)
+    hipEvent_t ring_ev[4] = {};
+    bool ring_pending[4] = {};            // slot's event recorded and not waited for yet
+    int ring_next = 0;                    // next slot of the rotation
 
     // instrumentation
     bool profiling = false;

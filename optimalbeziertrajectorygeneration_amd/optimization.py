@@ -84,10 +84,20 @@ class BezOptimization(object):
                  tf=1.0,
                  pointObstacles=None,
                  shapeObstacles=None,
-                 device=0):
+                 device=0,
+                 separationRows='all'):
+        """Beyond the reference's keywords: `device` (HIP ordinal) and `separationRows` --
+        'all': temporalSeparationConstraints returns every elevated control point of every pair, as the
+        reference does (optimization.py:337); 'min': one row per pair, the smallest of them -- the
+        `dv.normSquare().min()` form the reference leaves commented at optimization.py:338 and uses in
+        Examples/SequentialSwarm.py:65 -- which hands SLSQP 2n+R+1 times fewer rows (SURVEY.md 8(f) item 4:
+        its dense least-squares step is what dominates an iteration once the callbacks are fast)."""
+        if separationRows not in ('all', 'min'):
+            raise ValueError("separationRows must be 'all' or 'min', not {!r}".format(separationRows))
         self.pointObstacles = pointObstacles
         self.shapeObstacles = shapeObstacles
         self._device = device
+        self.separationRows = separationRows
 
         self._numCols = degree + 1
         if initPoints is not None:
@@ -180,6 +190,8 @@ class BezOptimization(object):
             if nobj <= 1:
                 return None                      # optimization.py:345-346
             y = self.reshapeVector(x)
+            if self.separationRows == 'min':     # per-pair minimum, reduced on the device (obtg_temporal_sep_min)
+                return self._ctx(with_obs).temporal_sep_min(y, self.model['maxSep'])[0]
             return self._ctx(with_obs).temporal_sep(y, self.model['maxSep'])[0]
         return wrapper
 
@@ -246,7 +258,10 @@ class BezOptimization(object):
         Y = self.reshapeVectors(X)
         if family == 'tsep':
             with_obs = self.pointObstacles is not None
-            F = self._ctx(with_obs).temporal_sep(Y, self.model['maxSep'])
+            if self.separationRows == 'min':
+                F = self._ctx(with_obs).temporal_sep_min(Y, self.model['maxSep'])
+            else:
+                F = self._ctx(with_obs).temporal_sep(Y, self.model['maxSep'])
         else:
             tf = X[:, -1] if self._timeopt() else np.full(X.shape[0], self.model['tf'])
             c = self._ctx(False)
@@ -287,6 +302,13 @@ class BezOptimization(object):
             return self._jac(x, 'tsep')
         F0 = ctx.temporal_sep(Y0[None], self.model['maxSep'])[0]
         LR = blk.shape[2]
+        reduced = self.separationRows == 'min'
+        if reduced:
+            # forward differences of the per-pair minimum itself: min over the perturbed pair's control points minus
+            # min over the unperturbed ones -- exactly what SciPy would form from n_x + 1 calls of the 'min' closure
+            blk = blk.min(axis=2, keepdims=True)
+            F0 = F0.reshape(-1, LR).min(axis=1)
+            LR = 1
         J = np.zeros((F0.size, x.size))
         veh = prow // dim
         partners = np.arange(n_obj - 1)[None, :] + (np.arange(n_obj - 1)[None, :] >= veh[:, None])   # [n_pts][n_obj-1]
@@ -296,7 +318,7 @@ class BezOptimization(object):
         J[rows.reshape(n_pts, -1), k[:, None]] = (blk - F0[rows]).reshape(n_pts, -1) / dx[:n_pts, None]
         if x.size > n_pts:      # tf: moves columns 1 / -2 of every vehicle when speeds are prescribed
             Yt = self.reshapeVectors(X[n_pts + 1:])
-            Ft = ctx.temporal_sep(Yt, self.model['maxSep'])
+            Ft = ctx.temporal_sep_min(Yt, self.model['maxSep']) if reduced else ctx.temporal_sep(Yt, self.model['maxSep'])
             J[:, n_pts:] = ((Ft - F0[None]) / dx[n_pts:, None]).T
         return J
 

@@ -332,3 +332,45 @@ def test_integration_md_binding_stub_runs(golden_dir):
             del sys.modules["optimization"]
         else:
             sys.modules["optimization"] = saved
+
+
+def test_reduced_separation_rows_option():
+    """BezOptimization(separationRows='min') hands SLSQP one row per pair -- the smallest
+    elevated control point (the reference's commented `.min()` form, optimization.py:338; Examples/SequentialSwarm.py:65).
+    The closure equals the row-wise minimum of the full closure, its structured Jacobian equals SciPy's finite
+    differences of the closure, and the solvers land on the same optimum as with every row (Example1, 3-D swarm)."""
+    import importlib.util
+    import os
+    import scipy.optimize as sop
+    from scipy.optimize._numdiff import approx_derivative
+    full, red = _example1(), _example1(separationRows='min')
+    x = full.generateGuess(std=0.3, seed=5)
+    f_all, f_min = full.temporalSeparationConstraints(x), red.temporalSeparationConstraints(x)
+    assert f_min.shape == (6,) and np.array_equal(f_min, f_all.reshape(6, -1).min(axis=1))      # 2 vehicles + 2 point obstacles
+    J_s = red.temporalSeparationJacobian(x)
+    J_b = red.temporalSeparationJacobian(x, structured=False)
+    J_sp = approx_derivative(red.temporalSeparationConstraints, x, method='2-point', abs_step=1.4901161193847656e-08)
+    assert np.array_equal(J_s, J_b) and J_s.shape == (6, x.size)
+    assert np.allclose(J_s, J_sp, rtol=0, atol=2e-6 * max(1.0, np.abs(J_sp).max()))
+    with pytest.raises(ValueError):
+        _example1(separationRows='some')
+
+    def solve(bo):
+        cons = [{'type': 'ineq', 'fun': bo.temporalSeparationConstraints, 'jac': bo.temporalSeparationJacobian},
+                {'type': 'ineq', 'fun': bo.maxSpeedConstraints, 'jac': bo.maxSpeedJacobian},
+                {'type': 'ineq', 'fun': bo.maxAngularRateConstraints, 'jac': bo.maxAngularRateJacobian},
+                {'type': 'ineq', 'fun': lambda x: x[-1], 'jac': lambda x: np.eye(1, x.size, x.size - 1)}]
+        return sop.minimize(bo.objectiveFunction, x0=bo.generateGuess(std=0), method='SLSQP', constraints=cons,
+                            options={'maxiter': 250, 'disp': False})
+    r_all, r_min = solve(_example1(pointObstacles=None)), solve(_example1(pointObstacles=None, separationRows='min'))
+    assert r_all.success and r_min.success and abs(r_all.fun - r_min.fun) < 1e-5 and abs(r_min.fun - 2.427643189) < 1e-5
+    spec = importlib.util.spec_from_file_location(
+        "example2", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples", "example2_swarm_3d.py"))
+    ex = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ex)
+    bo_a, s_all, _ = ex.solve(5, with_jac=True)
+    bo_m, s_min, _ = ex.solve(5, with_jac=True, separationRows='min')
+    assert s_all.success and s_min.success
+    assert bo_m.temporalSeparationConstraints(s_min.x).shape == (10,)
+    assert bo_a.temporalSeparationConstraints(s_min.x).min() > -1e-6          # feasible for the full constraint set too
+    assert abs(s_all.fun - s_min.fun) < 1e-3 * max(1.0, abs(s_all.fun))
