@@ -68,6 +68,12 @@ def parse():
                          "partitioned over the ranks and the per-pair minima all-gathered (RCCL) -- the 256-vehicle "
                          "case of BASELINE.json")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for rehearsals)")
+    ap.add_argument("--materialise", action="store_true",
+                    help="write the finite-difference batch to HBM every step (obtg_fd_batch_dev) even when the sweeps "
+                         "can form its rows while staging them (obtg_*_fd_dev)")
+    ap.add_argument("--streams", type=int, default=2, choices=[1, 2],
+                    help="2 (default): the dynamics launch (speed + angular rate, latency bound) runs on a second HIP "
+                         "stream beside the pair sweep (VALU bound); 1: every launch on one stream")
     ap.add_argument("--one-device", action="store_true",
                     help="rehearsal only: every rank uses device 0 (needs --backend gloo)")
     return ap.parse_args()
@@ -223,9 +229,26 @@ def main():
         g_stat = torch.empty((B, P_s), dtype=torch.int32, device=dev)
 
     one_launch = use_gjk and not args.separate   # the N x N pair sweeps (temporal separation + gjkNew) as one grid
+    # B0, the FD batch of this SLSQP iteration: formed from x's control points INSIDE the sweeps while they stage their
+    # rows (obtg_*_fd_dev) when both launches of the step have that form, else written to HBM by obtg_fd_batch_dev
+    fly_sweep, fly_dyn = ctx.fd_forms_on_the_fly()
+    on_the_fly = one_launch and o_an is not None and fly_sweep and fly_dyn and not args.materialise and B <= n_x + 1
+    # the dynamics launch is latency bound (one or two wavefronts per SIMD), the pair sweep VALU bound: on two streams
+    # the first hides under the second.  A context owns one stream, so the dynamics launch gets a context of its own.
+    two_streams = args.streams == 2 and on_the_fly
+    ctx_dyn = ctx
+    if two_streams:
+        stream2 = torch.cuda.Stream(device=dev)
+        ctx_dyn = _capi.Context(N, d, n, R, device=local_rank)
+        ctx_dyn.set_stream(stream2.cuda_stream)
 
     def step():
-        # B0: the FD batch of this SLSQP iteration, built on the device from x's control points
+        if on_the_fly:
+            ctx_dyn.dynamics_fd_dev(d0.data_ptr(), 1, synth.FD_STEP, d_tf.data_ptr(), B, vmax, True, wmax,
+                                    o_sp.data_ptr(), o_an.data_ptr())
+            ctx.pair_sweep_fd_dev(d0.data_ptr(), 1, synth.FD_STEP, B, max_sep, o_sep.data_ptr(), g_flag.data_ptr(),
+                                  g_p1.data_ptr(), g_p2.data_ptr(), g_dist.data_ptr(), None, g_stat.data_ptr(), 128, 256)
+            return
         ctx.fd_batch_dev(d0.data_ptr(), 1, synth.FD_STEP, B, dY.data_ptr())
         if one_launch:
             ctx.pair_sweep_dev(dY.data_ptr(), B, max_sep, o_sep.data_ptr(), g_flag.data_ptr(), g_p1.data_ptr(),
@@ -247,22 +270,35 @@ def main():
         for _ in range(20):
             step()
         torch.cuda.synchronize()
+    ctxs = [ctx] + ([ctx_dyn] if ctx_dyn is not ctx else [])
+
+    def prof(on, only=None, period=1):
+        for cx in ctxs:
+            cx.set_profiling(on, only=only) if only else cx.set_profiling(on)
+            cx.set_profile_period(period)
+            cx.reset_kernel_stats()
+
+    def kstats():
+        out = {}
+        for cx in ctxs:
+            cx.sync()
+            for kname, (ms, cnt) in cx.kernel_stats().items():
+                a = out.get(kname, (0.0, 0))
+                out[kname] = (a[0] + ms, a[1] + cnt)
+        return out
+
     # warm-up, with events around every launch: finds the dominant kernel of this workload
-    ctx.set_profiling(True)
-    ctx.reset_kernel_stats()
+    prof(True)
     for _ in range(max(args.warmup, 1)):
         step()
     torch.cuda.synchronize()
-    ctx.sync()
-    wstats = ctx.kernel_stats()
+    wstats = kstats()
     KNAMES = ("pair_sweep", "temporal_sep", "speed", "ang_rate", "gjk", "fd_batch")
     dom_name = max(KNAMES, key=lambda k: wstats.get(k, (0.0, 0))[0])
     # timed region: HIP events (launch stream) around the dominant kernel only, on every 4th step --
     # an event pair drains the queue around its launch (events on all three launches of every step
     # cost 15 % of a 0.25 ms step)
-    ctx.set_profiling(True, only=dom_name)
-    ctx.set_profile_period(4 if args.steps >= 8 else 1)
-    ctx.reset_kernel_stats()
+    prof(True, only=dom_name, period=4 if args.steps >= 8 else 1)
     barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -276,7 +312,7 @@ def main():
         tt = torch.tensor([elapsed], dtype=f64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
-    stats_timed = ctx.kernel_stats()
+    stats_timed = kstats()
     # sample rows of the buffers the last timed step left behind, for the parity check (before anything rewrites them)
     status_nonok = int((g_stat != 0).sum().item()) if use_gjk else 0
     snap = None
@@ -286,15 +322,13 @@ def main():
             dev_out.update(flag=g_flag, dist=g_dist, p1=g_p1)
         snap = parity_snapshot(dev_out, B)
     # the other kernels: the same steps once more with events on every launch, outside the timed region
-    ctx.set_profiling(True)
-    ctx.set_profile_period(1)
-    ctx.reset_kernel_stats()
+    prof(True)
     for _ in range(args.steps):
         step()
     torch.cuda.synchronize()
-    stats = ctx.kernel_stats()
+    stats = kstats()
     stats[dom_name] = stats_timed[dom_name]
-    ctx.set_profiling(False)
+    prof(False)
 
     evals = world * B * args.steps
     value = evals / elapsed
@@ -353,10 +387,13 @@ def main():
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "%s: %d vehicles, %d-D, degree %d, DEG_ELEV %d, %s; "
-                                   "FD batch B=%d rows per GPU per step (built on the device each step); families: "
+                                   "FD batch B=%d rows per GPU per step (%s); families: "
                                    "temporal_sep(%d pairs)+max_speed+%sgjkNew(%d hull pairs)" % (
-                                       args.workload, N, d, n, R, obst, B, P_t,
+                                       args.workload, N, d, n, R, obst, B,
+                                       "formed from x's control points inside the sweeps" if on_the_fly
+                                       else "written to HBM by obtg_fd_batch_dev each step", P_t,
                                        "max_ang_rate+" if d == 2 else "", P_s),
+                       "launches_per_step": 2 if on_the_fly else len([k for k in kernels]), "streams": 2 if two_streams else 1,
                        "evals_per_step_per_gpu": B, "alg_bytes_per_eval": total_bytes,
                        "gjk_fd_dedup": bool(args.fd_dedup), "gjk_status_nonok_last_step": status_nonok},
             "roofline": roofline,

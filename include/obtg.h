@@ -176,6 +176,19 @@ int obtg_dynamics_dev(obtg_ctx*, const double* dY, const double* d_tf, int B, do
  * columns).  B <= N*d*(n+1-2*n_fixed_cols) + 1. */
 int obtg_fd_batch_dev(obtg_ctx*, const double* dY0, int n_fixed_cols, double h, int B, double* dY);
 
+/* The same batch WITHOUT writing it: obtg_pair_sweep_dev / obtg_dynamics_dev on a virtual finite-difference batch.
+ * dY0 is ONE evaluation row; evaluation row 0 is dY0 and row b >= 1 is dY0 with its (b-1)-th free control point
+ * advanced by h -- bit for bit the rows obtg_fd_batch_dev(dY0, n_fixed_cols, h, B) writes -- formed while the kernels
+ * stage their inputs, so that the B x 11 KB batch never travels through HBM and a step of an SLSQP iteration is
+ * two launches.  Shapes whose kernels have no on-the-fly form (obtg_fd_forms_on_the_fly: bit 0 = pair sweep, bit 1 =
+ * dynamics) materialise the batch in a context buffer first; results are identical either way. */
+int obtg_fd_forms_on_the_fly(const obtg_ctx*);
+int obtg_pair_sweep_fd_dev(obtg_ctx*, const double* dY0, int n_fixed_cols, double h, int B, double max_sep,
+                           double* d_out_sep, int max_iter, int md_cap, int* d_flag, double* d_p1, double* d_p2,
+                           double* d_dist, int* d_nsup, int* d_status);
+int obtg_dynamics_fd_dev(obtg_ctx*, const double* dY0, int n_fixed_cols, double h, const double* d_tf, int B,
+                         double speed_bound, int speed_is_max, double max_rate, double* d_out_speed, double* d_out_ang);
+
 /* ---- GJK (gjk/gjk.py:230-270 gjkNew, 273-360 minimumDistance) ---------------------------
  * Generic point sets: pts[n_pts][3], poly_off[n_poly+1]; pair k = (pair_a[k], pair_b[k]).
  * Outputs per pair: flag in {-1,0,1} (gjk.py:234-237); p1/p2 = closest points on poly1/poly2

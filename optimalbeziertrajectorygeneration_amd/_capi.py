@@ -55,6 +55,9 @@ _SIGNATURES = {
     "obtg_ang_rate_dev": (_i, [_vp, _vp, _vp, _i, _d, _vp]),
     "obtg_dynamics_dev": (_i, [_vp, _vp, _vp, _i, _d, _i, _d, _vp, _vp]),
     "obtg_fd_batch_dev": (_i, [_vp, _vp, _i, _d, _i, _vp]),
+    "obtg_fd_forms_on_the_fly": (_i, [_vp]),
+    "obtg_pair_sweep_fd_dev": (_i, [_vp, _vp, _i, _d, _i, _d, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "obtg_dynamics_fd_dev": (_i, [_vp, _vp, _i, _d, _vp, _i, _d, _i, _d, _vp, _vp]),
     "obtg_gjk_pairs": (_i, [_vp, _vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp]),
     "obtg_ctx_set_polygons": (_i, [_vp, _vp, _i, _vp, _i]),
     "obtg_ctx_set_hull_pairs": (_i, [_vp, _vp, _vp, _i]),
@@ -372,6 +375,25 @@ class Context(object):
     def fd_batch_dev(self, dY0, n_fixed_cols, h, B, dY):
         self._check(self._lib.obtg_fd_batch_dev(self._h, _vp(dY0), int(n_fixed_cols), float(h), B, _vp(dY)),
                     "obtg_fd_batch_dev")
+
+    def fd_forms_on_the_fly(self):
+        """(pair sweep, dynamics): does the _fd_dev form build the finite-difference rows while staging them?"""
+        m = self._lib.obtg_fd_forms_on_the_fly(self._h)
+        return bool(m & 1), bool(m & 2)
+
+    def pair_sweep_fd_dev(self, dY0, n_fixed_cols, h, B, max_sep, d_out_sep, d_flag, d_p1, d_p2, d_dist, d_nsup=None,
+                          d_status=None, max_iter=128, md_cap=4096):
+        """obtg_pair_sweep_dev on the virtual FD batch of ONE row dY0 (include/obtg.h obtg_pair_sweep_fd_dev)."""
+        self._need_hull_pairs("pair_sweep_fd_dev")
+        self._check(self._lib.obtg_pair_sweep_fd_dev(self._h, _vp(dY0), int(n_fixed_cols), float(h), B, float(max_sep),
+                                                     _vp(d_out_sep), max_iter, md_cap, _vp(d_flag), _vp(d_p1), _vp(d_p2),
+                                                     _vp(d_dist), _vp(d_nsup) if d_nsup else None,
+                                                     _vp(d_status) if d_status else None), "obtg_pair_sweep_fd_dev")
+
+    def dynamics_fd_dev(self, dY0, n_fixed_cols, h, d_tf, B, speed_bound, speed_is_max, max_rate, d_out_speed, d_out_ang):
+        self._check(self._lib.obtg_dynamics_fd_dev(self._h, _vp(dY0), int(n_fixed_cols), float(h), _vp(d_tf), B,
+                                                   float(speed_bound), int(bool(speed_is_max)), float(max_rate),
+                                                   _vp(d_out_speed), _vp(d_out_ang)), "obtg_dynamics_fd_dev")
 
     # -- GJK
     def gjk_pairs(self, pts, off, pair_a, pair_b, max_iter=128, md_cap=4096, trace_cap=0):

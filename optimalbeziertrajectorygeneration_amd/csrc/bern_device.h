@@ -43,8 +43,8 @@ struct NsParams {
     const double* __restrict__ W2;    // folded weights [L][NC]
     const double* __restrict__ Tt;    // elevation tables (R > 0), three rows back to back:
                                       //   scale[L]      = C(2n, j)
-                                      //   binp[R+2L-1]  = C(R, m) for m = -(L-1) .. R+L-1 (0 outside 0..R)
-                                      //   inv[L+R]      = 1 / C(2n+R, k)
+                                      //   binp[R+2L-1+8] = C(R, m) for m = -(L-1) .. R+L-1+8 (0 outside 0..R)
+                                      //   inv[L+R+8]    = 1 / C(2n+R, k) (0 past the end)
     const double* __restrict__ Td;    // dense elevation table, transposed: Td[k][j] = T[j][k], [L+R][L] (R > 0)
     double* __restrict__ out;
     int n_veh, n_obj, R;
@@ -173,6 +173,67 @@ __device__ __forceinline__ void flush_chunk(const double* __restrict__ tile, dou
     }
 }
 
+// ---- degree elevation as a binomially scaled convolution, lane = item -----------------------------------------
+//     elev(a, Q)_k = (1 / C(P+Q, k)) sum_j [C(P, j) a_j] C(Q, k-j)
+// All output columns share ONE weight row C(Q, .): a block of kElevBlock columns walks a window of that row with
+// one wave-uniform scalar per step (kElevBlock independent FMA chains) instead of fetching P+1 weights per column.
+// Outputs leave through a per-wave LDS tile of kElevChunk columns so that stores are 256-byte runs.
+constexpr int kConvPad = 8;           // zero entries behind the padded binomial row and the 1/C(P+Q, .) row
+constexpr int kElevChunk = 32;
+constexpr int kElevBlock = 8;
+
+template <int LIN>
+__device__ __forceinline__ void elev_store_chunk(const double* __restrict__ tile, double* __restrict__ gout, size_t grow,
+                                                 int LR, int k0, int kc, int n_valid, int lane)
+{
+    constexpr int TP = kElevChunk + 1;
+    if (kc == kElevChunk) {
+        for (int e = lane; e < n_valid * kElevChunk; e += kWave) {
+            const int pr = e / kElevChunk, q = e & (kElevChunk - 1);
+            store_nt(gout + grow + (size_t)pr * LR + k0 + q, tile[pr * TP + q]);
+        }
+        return;
+    }
+    for (int e = lane; e < n_valid * kc; e += kWave) {
+        const int pr = e / kc, q = e - pr * kc;
+        store_nt(gout + grow + (size_t)pr * LR + k0 + q, tile[pr * TP + q]);
+    }
+}
+
+// sa[i] = sum_j a[j] c[(k0+i) - j], i < kElevBlock, with cp = (padded row) + k0: cp[m] = c[k0 - (LIN-1) + m]
+template <int LIN>
+__device__ __forceinline__ void conv_block2(const ctab_t cp, const double (&a)[LIN], const double (&b)[LIN],
+                                            double (&sa)[kElevBlock], double (&sb)[kElevBlock])
+{
+#pragma unroll
+    for (int i = 0; i < kElevBlock; ++i) sa[i] = sb[i] = 0.0;
+#pragma unroll
+    for (int m = 0; m < LIN - 1 + kElevBlock; ++m) {
+        const double c = cp[m];
+#pragma unroll
+        for (int i = 0; i < kElevBlock; ++i) {
+            const int j = i + LIN - 1 - m;
+            if (j >= 0 && j < LIN) { sa[i] = fma(c, a[j], sa[i]); sb[i] = fma(c, b[j], sb[i]); }
+        }
+    }
+}
+
+template <int LIN>
+__device__ __forceinline__ void conv_block1(const ctab_t cp, const double (&a)[LIN], double (&sa)[kElevBlock])
+{
+#pragma unroll
+    for (int i = 0; i < kElevBlock; ++i) sa[i] = 0.0;
+#pragma unroll
+    for (int m = 0; m < LIN - 1 + kElevBlock; ++m) {
+        const double c = cp[m];
+#pragma unroll
+        for (int i = 0; i < kElevBlock; ++i) {
+            const int j = i + LIN - 1 - m;
+            if (j >= 0 && j < LIN) sa[i] = fma(c, a[j], sa[i]);
+        }
+    }
+}
+
 // ELEV = false: DEG_ELEV == 0 (the product IS the output); ELEV = true: R > 0.  Separate
 // instantiations so that the R > 0 code (two weight columns in registers) does not cost the
 // R == 0 kernel its occupancy.
@@ -248,7 +309,7 @@ __device__ __forceinline__ void normsq_elev_body(const NsParams& p, const int b,
 
     // LDS: [staged objects: stage_slots * VP][per-wave transposition tiles]
     double* vl = lds;
-    double* tile = lds + p.stage_slots * S::VP + wave * (p.tile_rows * S::TPF);
+    double* tile = lds + p.stage_slots * S::VP + wave * (ELEV ? kWave * (kElevChunk + 1) : p.tile_rows * S::TPF);
 
     // ---- stage the objects this workgroup touches
     const double* Yrow = p.Y + (size_t)b * p.n_veh * S::VLEN;
@@ -373,7 +434,7 @@ __device__ __forceinline__ void normsq_elev_body(const NsParams& p, const int b,
                 // elev(R) as a binomially scaled convolution (bezier.py:1127-1147 written out):
                 //   out_k = (1/C(2n+R,k)) * sum_j [C(2n,j) c_j] * C(R, k-j)
                 // only the minimum over k leaves the lane
-                const ctab_t escale = as_ctab(p.Tt), ebin = escale + L, einv = ebin + (p.R + 2 * L - 1);
+                const ctab_t escale = as_ctab(p.Tt), ebin = escale + L, einv = ebin + (p.R + 2 * L - 1 + kConvPad);
                 double ch[L];
 #pragma unroll
                 for (int j = 0; j < L; ++j) ch[j] = cf[j] * escale[j];
@@ -387,40 +448,29 @@ __device__ __forceinline__ void normsq_elev_body(const NsParams& p, const int b,
                 }
                 if (mine) p.out[row + r] = p.sign * m + p.offset;
             } else {
-                // Full elevated rows: switch the lane <-> data mapping.  The 2n+1 product coefficients
-                // of the wave's pairs go to the LDS tile; then lane = output column k keeps its column
-                // of the elevation matrix (2n+1 weights) in registers and walks the pairs, reading each
-                // pair's coefficients as LDS broadcasts.  Every store instruction writes 64 consecutive
-                // doubles of one output row: no transposition, no partial rows.  Two columns per lane
-                // (k, k+64) share the broadcasts.
-                if (mine) {
+                // Full elevated rows, lane = item: the elevation as a sliding-window convolution (above), 32 output
+                // columns at a time through the wave's transposition tile.  No LDS traffic in the FMA loop (the
+                // earlier form -- lane = output column, the pair's coefficients as LDS broadcasts -- was bound by
+                // the LDS pipe: C5 0.65 ms for 2.26 GB of output).
+                const ctab_t escale = as_ctab(p.Tt), ebin = escale + L, einv = ebin + (p.R + 2 * L - 1 + kConvPad);
+                double ch[L];
 #pragma unroll
-                    for (int k = 0; k < L; ++k) tile[r * S::TPF + k] = cf[k];
-                }
-                wave_sync();
-                for (int kb = 0; kb < LR; kb += 2 * kWave) {
-                    const int k1 = kb + lane, k2 = kb + kWave + lane;
-                    double w1[L], w2[L];
+                for (int j = 0; j < L; ++j) ch[j] = cf[j] * escale[j];
+                for (int k0 = 0; k0 < LR; k0 += kElevChunk) {
+                    const int kc = min(kElevChunk, LR - k0);
+                    for (int kb = 0; kb < kc; kb += kElevBlock) {
+                        double sa[kElevBlock];
+                        conv_block1<L>(ebin + k0 + kb, ch, sa);
+                        if (mine) {
 #pragma unroll
-                    for (int j = 0; j < L; ++j) {
-                        w1[j] = k1 < LR ? p.Td[(size_t)k1 * L + j] : 0.0;
-                        w2[j] = k2 < LR ? p.Td[(size_t)k2 * L + j] : 0.0;
-                    }
-                    for (int pr = 0; pr < n_valid; ++pr) {
-                        const double* cr = tile + pr * S::TPF;
-                        double s1 = 0.0, s2 = 0.0;
-#pragma unroll
-                        for (int j = 0; j < L; ++j) {
-                            const double cj = cr[j];
-                            s1 = fma(cj, w1[j], s1);
-                            s2 = fma(cj, w2[j], s2);
+                            for (int i = 0; i < kElevBlock; ++i)
+                                tile[r * (kElevChunk + 1) + kb + i] = p.sign * (sa[i] * einv[k0 + kb + i]) + p.offset;
                         }
-                        double* orow = p.out + (row + pr) * LR;
-                        if (k1 < LR) store_nt(orow + k1, p.sign * s1 + p.offset);
-                        if (k2 < LR) store_nt(orow + k2, p.sign * s2 + p.offset);
                     }
+                    wave_sync();
+                    elev_store_chunk<L>(tile, p.out, row * LR, LR, k0, kc, n_valid, lane);
+                    wave_sync();
                 }
-                wave_sync();
             }
         }
     }

@@ -116,7 +116,34 @@ struct AngParams {
     int n_veh, total;                // total = B * n_veh
     double w2;                       // max_rate^2
     double sp_sign, sp_offset;       // speed output = sp_sign * |v|^2 + sp_offset
+    int fd, fd_fixed;                // fd != 0: Y is ONE row [n_veh*2][NC]; row b >= 1 = Y with its (b-1)-th free
+    double fd_h;                     //          control point advanced by fd_h (the rows obtg_fd_batch_dev writes)
 };
+
+// control points of item (b, veh) of a 2-D batch: from the materialised batch, or formed on the fly (p.fd)
+template <int NC>
+__device__ __forceinline__ void load_item_xy(const AngParams& p, int item, int b, double (&x)[NC], double (&y)[NC])
+{
+    if (!p.fd) {
+        const double* src = p.Y + (size_t)item * 2 * NC;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) { x[c] = src[c]; y[c] = src[NC + c]; }
+        return;
+    }
+    const int veh = item - b * p.n_veh;
+    const double* src = p.Y + (size_t)veh * 2 * NC;
+    int pl = -1;                                           // perturbed element inside this vehicle's 2 NC values
+    if (b > 0) {
+        const int free_cols = NC - 2 * p.fd_fixed, kq = b - 1, pr = kq / free_cols, pc = p.fd_fixed + (kq - pr * free_cols);
+        pl = pr * NC + pc - veh * 2 * NC;
+    }
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        const double vx = src[c], vy = src[NC + c];
+        x[c] = (c == pl) ? vx + p.fd_h : vx;
+        y[c] = (NC + c == pl) ? vy + p.fd_h : vy;
+    }
+}
 
 template <int NC>
 __device__ __forceinline__ void diff_elev1(const double (&p)[NC], double val, double (&d)[NC])
@@ -192,10 +219,8 @@ __global__ __launch_bounds__(kWave) void k_dynamics(const AngParams p)
     const int n_valid = min(kWave, p.total - it0);
     const int item = min(it0 + lane, p.total - 1);
     const int b = item / p.n_veh;
-    const double* src = p.Y + (size_t)item * 2 * NC;   // rows (b, veh) are contiguous
     double x[NC], y[NC];
-#pragma unroll
-    for (int c = 0; c < NC; ++c) { x[c] = src[c]; y[c] = src[NC + c]; }
+    load_item_xy<NC>(p, item, b, x, y);                // rows (b, veh) are contiguous
     const double val = (double)N / p.tf[b];
     double xD[NC], yD[NC], xDD[NC], yDD[NC];
     diff_elev1<NC>(x, val, xD);
@@ -260,10 +285,8 @@ __global__ __launch_bounds__(2 * kWave) void k_dynamics2(const AngParams p)
     const int n_valid = min(kWave, p.total - it0);
     const int item = min(it0 + lane, p.total - 1);
     const int b = item / p.n_veh;
-    const double* src = p.Y + (size_t)item * 2 * NC;
     double x[NC], y[NC];
-#pragma unroll
-    for (int c = 0; c < NC; ++c) { x[c] = src[c]; y[c] = src[NC + c]; }
+    load_item_xy<NC>(p, item, b, x, y);
     const double val = (double)N / p.tf[b];
     double xD[NC], yD[NC];
     diff_elev1<NC>(x, val, xD);
@@ -375,61 +398,6 @@ struct AngElevParams {
     int R;
 };
 
-constexpr int kElevChunk = 32;
-constexpr int kElevBlock = 8;
-
-template <int LIN>
-__device__ __forceinline__ void elev_store_chunk(const double* __restrict__ tile, double* __restrict__ gout, size_t grow,
-                                                 int LR, int k0, int kc, int n_valid, int lane)
-{
-    constexpr int TP = kElevChunk + 1;
-    if (kc == kElevChunk) {
-        for (int e = lane; e < n_valid * kElevChunk; e += kWave) {
-            const int pr = e / kElevChunk, q = e & (kElevChunk - 1);
-            store_nt(gout + grow + (size_t)pr * LR + k0 + q, tile[pr * TP + q]);
-        }
-        return;
-    }
-    for (int e = lane; e < n_valid * kc; e += kWave) {
-        const int pr = e / kc, q = e - pr * kc;
-        store_nt(gout + grow + (size_t)pr * LR + k0 + q, tile[pr * TP + q]);
-    }
-}
-
-// sa[i] = sum_j a[j] c[(k0+i) - j], i < kElevBlock, with cp = (padded row) + k0: cp[m] = c[k0 - (LIN-1) + m]
-template <int LIN>
-__device__ __forceinline__ void conv_block2(const ctab_t cp, const double (&a)[LIN], const double (&b)[LIN],
-                                            double (&sa)[kElevBlock], double (&sb)[kElevBlock])
-{
-#pragma unroll
-    for (int i = 0; i < kElevBlock; ++i) sa[i] = sb[i] = 0.0;
-#pragma unroll
-    for (int m = 0; m < LIN - 1 + kElevBlock; ++m) {
-        const double c = cp[m];
-#pragma unroll
-        for (int i = 0; i < kElevBlock; ++i) {
-            const int j = i + LIN - 1 - m;
-            if (j >= 0 && j < LIN) { sa[i] = fma(c, a[j], sa[i]); sb[i] = fma(c, b[j], sb[i]); }
-        }
-    }
-}
-
-template <int LIN>
-__device__ __forceinline__ void conv_block1(const ctab_t cp, const double (&a)[LIN], double (&sa)[kElevBlock])
-{
-#pragma unroll
-    for (int i = 0; i < kElevBlock; ++i) sa[i] = 0.0;
-#pragma unroll
-    for (int m = 0; m < LIN - 1 + kElevBlock; ++m) {
-        const double c = cp[m];
-#pragma unroll
-        for (int i = 0; i < kElevBlock; ++i) {
-            const int j = i + LIN - 1 - m;
-            if (j >= 0 && j < LIN) sa[i] = fma(c, a[j], sa[i]);
-        }
-    }
-}
-
 template <int NC>
 __global__ __launch_bounds__(4 * kWave, (NC > 11 ? 1 : 2)) void k_dynamics_elev(const AngElevParams q)
 {
@@ -443,12 +411,10 @@ __global__ __launch_bounds__(4 * kWave, (NC > 11 ? 1 : 2)) void k_dynamics_elev(
     const int n_valid = min(kWave, p.total - it0);
     const int item = min(it0 + lane, p.total - 1);
     const int b = item / p.n_veh;
-    const double* src = p.Y + (size_t)item * 2 * NC;
     double num[L4], den[L4];
     {   // ---- phase A: degree-4n numerator and denominator from the original control points (as k_dynamics2)
         double x[NC], y[NC];
-#pragma unroll
-        for (int c = 0; c < NC; ++c) { x[c] = src[c]; y[c] = src[NC + c]; }
+        load_item_xy<NC>(p, item, b, x, y);
         const double val = (double)N / p.tf[b];
         double xD[NC], yD[NC], xDD[NC], yDD[NC];
         diff_elev1<NC>(x, val, xD);
@@ -1043,7 +1009,7 @@ static int launch_ns_t(obtg_ctx* c, NsParams p, int B, int kernel_id)
     const size_t stage = (size_t)p.stage_slots * S::VP * sizeof(double);
     size_t lds = 0;
     if (MINONLY) { p.tile_rows = 0; lds = stage; }
-    else if (p.R > 0) { p.tile_rows = kWave; lds = stage + (size_t)p.waves * kWave * S::TPF * sizeof(double); }
+    else if (p.R > 0) { p.tile_rows = kWave; lds = stage + (size_t)p.waves * kWave * (kElevChunk + 1) * sizeof(double); }
     else {
         for (int tr = kWave; tr >= 16; tr >>= 1) {
             p.tile_rows = tr;
@@ -1298,6 +1264,9 @@ static bool dyn_fast(const obtg_ctx* c)
     return c->dim == 2 && c->R == 0 && (nc == 4 || nc == 6 || nc == 8 || nc == 11 || nc == 16);
 }
 
+// shapes whose dynamics kernels form a virtual finite-difference batch on the fly (see obtg_ctx::fd)
+bool dynamics_fd_on_the_fly(const obtg_ctx* c, bool want_ang) { return dyn_fast(c) || (want_ang && dyn_fast_elev(c)); }
+
 // speed and/or angular rate in one launch (either output may be null)
 int launch_temporal_sep_fd(obtg_ctx* c, const double* dY0, int n_pert, const int* d_prow, const int* d_pcol,
                            const double* d_pval, double max_sep, double* d_out)
@@ -1343,6 +1312,7 @@ int launch_dynamics(obtg_ctx* c, const double* dY, const double* d_tf, int B, do
         p.W2n = c->d_ang_w2n.as<double>();
         p.W22n = c->d_ang_w22n.as<double>();
         p.Wn = c->d_ang_wn.as<double>();
+        if (c->fd.Y0) { p.Y = c->fd.Y0; p.fd = 1; p.fd_fixed = c->fd.fixed; p.fd_h = c->fd.h; }
         const int kid = d_out_ang ? OBTG_K_ANG_RATE : OBTG_K_SPEED;
         switch (c->deg + 1) {
             case 4: return launch_dyn_t<4>(c, p, kid);
@@ -1363,6 +1333,7 @@ int launch_dynamics(obtg_ctx* c, const double* dY, const double* d_tf, int B, do
         p.W2n = c->d_ang_w2n.as<double>();
         p.W22n = c->d_ang_w22n.as<double>();
         p.Wn = c->d_ang_wn.as<double>();
+        if (c->fd.Y0) { p.Y = c->fd.Y0; p.fd = 1; p.fd_fixed = c->fd.fixed; p.fd_h = c->fd.h; }
         q.cv4 = c->d_ang_T4.as<double>(); q.cv2 = c->d_ang_cv2.as<double>(); q.R = c->R;
         switch (c->deg + 1) {
             case 4: return launch_dyn_elev_t<4>(c, q, OBTG_K_ANG_RATE);

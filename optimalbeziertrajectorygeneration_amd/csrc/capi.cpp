@@ -192,7 +192,7 @@ const char* obtg_abi_symbols(void)
         "obtg_temporal_sep\0obtg_speed\0obtg_ang_rate\0obtg_temporal_sep_min\0obtg_temporal_sep_min_range\0"
         "obtg_temporal_sep_fd\0obtg_temporal_sep_fd_dev\0"
         "obtg_temporal_sep_dev\0obtg_temporal_sep_min_dev\0obtg_speed_dev\0obtg_ang_rate_dev\0obtg_dynamics_dev\0"
-        "obtg_fd_batch_dev\0obtg_gjk_pairs\0obtg_ctx_set_polygons\0obtg_ctx_set_hull_pairs\0"
+        "obtg_fd_batch_dev\0obtg_fd_forms_on_the_fly\0obtg_pair_sweep_fd_dev\0obtg_dynamics_fd_dev\0obtg_gjk_pairs\0obtg_ctx_set_polygons\0obtg_ctx_set_hull_pairs\0"
         "obtg_ctx_set_fd_dedup\0obtg_ctx_set_gjk_history\0obtg_pair_sweep_dev\0obtg_gjk_swarm_dev\0obtg_gjk_swarm\0obtg_min_dist\0obtg_min_dist_robust\0obtg_min_dist2poly\0"
         "obtg_bern_elev\0obtg_bern_diff\0obtg_bern_mul\0obtg_bern_normsq\0obtg_bern_split\0"
         "obtg_euclidean_obj\0obtg_accel_obj\0obtg_jerk_obj\0"
@@ -247,7 +247,7 @@ void obtg_ctx_destroy(obtg_ctx* c)
     DevBuf* bufs[] = { &c->d_pairs, &c->d_obs, &c->d_w2, &c->d_Tt, &c->d_Td, &c->d_ang_w2n, &c->d_ang_w22n, &c->d_ang_wn, &c->d_ang_T4, &c->d_ang_cv2,
                        &c->d_binrows, &c->d_tiles, &c->d_poly_pts, &c->d_poly_off, &c->d_hp_a, &c->d_hp_b, &c->d_tile_chunk_off, &c->d_tile_order, &c->d_tile_pslots,
                        &c->d_tile_cobj_off, &c->d_tile_cobjs, &c->ws_in,
-                       &c->ws_in2, &c->ws_out };
+                       &c->ws_in2, &c->ws_out, &c->ws_fd };
     for (DevBuf* b : bufs) b->release();
     for (auto& b : c->ws_misc) b.release();
     for (auto& b : c->d_gjk_len) b.release();
@@ -352,6 +352,65 @@ int obtg_dynamics_dev(obtg_ctx* c, const double* dY, const double* d_tf, int B, 
     if (!check_ctx(c) || !dY || !d_tf || B < 0 || (!d_out_speed && !d_out_ang)) return OBTG_ERR_ARG;
     (void)hipSetDevice(c->device);
     return launch_dynamics(c, dY, d_tf, B, speed_bound, speed_is_max, max_rate, d_out_speed, d_out_ang);
+}
+
+// The finite-difference batch without ever writing it: the sweeps below take ONE row of control points and form row
+// b >= 1 (that row with its (b-1)-th free control point advanced by h) while staging it.  Shapes whose kernels
+// have no on-the-fly form get the batch materialised in a context buffer first -- same results either way.
+static int fd_args_ok(const obtg_ctx* c, int n_fixed_cols, int B)
+{
+    const int rows = c->n_veh * c->dim, nc = c->deg + 1;
+    if (n_fixed_cols < 0 || nc - 2 * n_fixed_cols <= 0) return OBTG_ERR_ARG;
+    if (B < 1 || B > rows * (nc - 2 * n_fixed_cols) + 1) return OBTG_ERR_ARG;
+    return OBTG_OK;
+}
+
+static int fd_materialise(obtg_ctx* c, const double* dY0, int n_fixed_cols, double h, int B)
+{
+    int rc = c->ws_fd.reserve(sizeof(double) * (size_t)B * c->n_veh * c->dim * (c->deg + 1));
+    if (rc) return rc;
+    return launch_fd_batch(c, dY0, n_fixed_cols, h, B, c->ws_fd.as<double>());
+}
+
+int obtg_fd_forms_on_the_fly(const obtg_ctx* c)
+{
+    if (!c) return 0;
+    return (pair_sweep_is_one_launch(c) ? 1 : 0) | ((c->dim == 2 && dynamics_fd_on_the_fly(c, true)) ? 2 : 0);
+}
+
+int obtg_pair_sweep_fd_dev(obtg_ctx* c, const double* dY0, int n_fixed_cols, double h, int B, double max_sep,
+                           double* d_out_sep, int max_iter, int md_cap, int* d_flag, double* d_p1, double* d_p2,
+                           double* d_dist, int* d_nsup, int* d_status)
+{
+    if (!check_ctx(c) || !dY0 || !d_out_sep || !d_flag || !d_p1 || !d_p2 || !d_dist || max_iter < 1 || md_cap < 1)
+        return OBTG_ERR_ARG;
+    if (!c->hull_pairs_set) return OBTG_ERR_ARG;
+    if (int rc = fd_args_ok(c, n_fixed_cols, B)) return rc;
+    (void)hipSetDevice(c->device);
+    c->fd.Y0 = dY0; c->fd.h = h; c->fd.fixed = n_fixed_cols;
+    int rc = launch_pair_sweep(c, dY0, B, max_sep, d_out_sep, max_iter, md_cap, d_flag, d_p1, d_p2, d_dist, d_nsup, d_status);
+    c->fd.Y0 = nullptr;
+    if (rc != OBTG_ERR_UNSUPPORTED) return rc;
+    if ((rc = fd_materialise(c, dY0, n_fixed_cols, h, B))) return rc;
+    return launch_pair_sweep(c, c->ws_fd.as<double>(), B, max_sep, d_out_sep, max_iter, md_cap, d_flag, d_p1, d_p2, d_dist,
+                             d_nsup, d_status);
+}
+
+int obtg_dynamics_fd_dev(obtg_ctx* c, const double* dY0, int n_fixed_cols, double h, const double* d_tf, int B,
+                         double speed_bound, int speed_is_max, double max_rate, double* d_out_speed, double* d_out_ang)
+{
+    if (!check_ctx(c) || !dY0 || !d_tf || (!d_out_speed && !d_out_ang)) return OBTG_ERR_ARG;
+    if (int rc = fd_args_ok(c, n_fixed_cols, B)) return rc;
+    (void)hipSetDevice(c->device);
+    if (int rc = ensure_tables(c)) return rc;
+    if (c->dim == 2 && dynamics_fd_on_the_fly(c, d_out_ang != nullptr)) {
+        c->fd.Y0 = dY0; c->fd.h = h; c->fd.fixed = n_fixed_cols;
+        const int rc = launch_dynamics(c, dY0, d_tf, B, speed_bound, speed_is_max, max_rate, d_out_speed, d_out_ang);
+        c->fd.Y0 = nullptr;
+        return rc;
+    }
+    if (int rc = fd_materialise(c, dY0, n_fixed_cols, h, B)) return rc;
+    return launch_dynamics(c, c->ws_fd.as<double>(), d_tf, B, speed_bound, speed_is_max, max_rate, d_out_speed, d_out_ang);
 }
 
 int obtg_fd_batch_dev(obtg_ctx* c, const double* dY0, int n_fixed_cols, double h, int B, double* dY)

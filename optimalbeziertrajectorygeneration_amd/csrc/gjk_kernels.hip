@@ -252,6 +252,8 @@ struct GjkSwarmParams {
     const unsigned char* len_in;       // nullable, [.][n_pairs] support-scan counts of the previous sweep
     int len_in_stride;                 // n_pairs (same batch shape as last time) or 0 (every row reads row 0)
     unsigned char* len_out;            // nullable, [B][n_pairs]
+    int fd, fd_fixed;                  // fd != 0: Y is ONE row; row b >= 1 = Y with its (b-1)-th free control point
+    double fd_h;                       //          advanced by fd_h (the rows obtg_fd_batch_dev writes), formed while staging
     TsepXYParams ts;                   // pair sweep: the row's temporal-separation block (ts.out != nullptr)
     int ts_tile_rows;
     int* __restrict__ flag;
@@ -440,14 +442,19 @@ __device__ __forceinline__ void gjk_planar_body(const GjkSwarmParams& p, double2
     unsigned short* ord = r2 + p.chunk;                            // MODE 0, 2: position -> local index l
 
     // ---- stage vehicles (rows x, y of the evaluation row) and padded polygons
-    const double* Yrow = p.Y + (size_t)b * p.n_veh * 2 * NC;
+    const double* Yrow = p.fd ? p.Y : p.Y + (size_t)b * p.n_veh * 2 * NC;
+    int fd_e = -1;                       // element of the row that this evaluation row advances by fd_h
+    if (p.fd && b > 0) {
+        const int free_cols = NC - 2 * p.fd_fixed, kq = b - 1, pr = kq / free_cols;
+        fd_e = pr * NC + p.fd_fixed + (kq - pr * free_cols);
+    }
     // (rows x[NC], y[NC] in memory -> point-major (x, y) in LDS)
     if (TILED) {
         for (int e = threadIdx.x; e < n_obj * 2 * NC; e += blockDim.x) {
             const int sl = e / (2 * NC), r = e - sl * (2 * NC), q = r / NC, k = r - q * NC;
             const int obj = p.cobjs[obj0 + sl];
             double val;
-            if (obj < p.n_veh) val = Yrow[(size_t)obj * 2 * NC + r];
+            if (obj < p.n_veh) { const int ee = obj * 2 * NC + r; val = Yrow[ee]; if (ee == fd_e) val += p.fd_h; }
             else {
                 const int o = obj - p.n_veh;
                 const int off = p.poly_off[o], K = p.poly_off[o + 1] - off;
@@ -458,7 +465,8 @@ __device__ __forceinline__ void gjk_planar_body(const GjkSwarmParams& p, double2
     } else {
         for (int e = threadIdx.x; e < p.n_veh * 2 * NC; e += blockDim.x) {
             const int v = e / (2 * NC), r = e - v * (2 * NC), q = r / NC, k = r - q * NC;
-            lds[2 * (v * VPQ + k) + q] = Yrow[e];
+            const double val = Yrow[e];
+            lds[2 * (v * VPQ + k) + q] = (e == fd_e) ? val + p.fd_h : val;
         }
         for (int e = threadIdx.x; e < p.n_poly * 2 * NC; e += blockDim.x) {
             const int o = e / (2 * NC), r = e - o * (2 * NC), q = r / NC, k = r - q * NC;
@@ -2028,9 +2036,27 @@ int launch_gjk_swarm(obtg_ctx* c, const double* dY, int B, int max_iter, int md_
 
 // The pair sweeps of a batch as one launch: the planar GJK sweep whose workgroups also write their
 // row's temporal-separation block (GjkSwarmParams::ts).  Shapes outside that kernel: two launches.
+// does obtg_pair_sweep_dev run as ONE launch for this context (large batch)?  Mirrors launch_pair_sweep's decision.
+bool pair_sweep_is_one_launch(const obtg_ctx* c)
+{
+    const int nc = c->deg + 1;
+    if (!(nc == 4 || nc == 6 || nc == 8 || nc == 11 || nc == 16)) return false;
+    if (!(c->dim == 2 && c->polys_planar && c->max_poly_K <= nc && c->n_hull_pairs > 0 && !c->fd_dedup && c->R == 0 &&
+          c->n_obs == 0 && c->n_pairs > 0)) return false;
+    const int wgs = (c->n_hull_pairs + kSweepChunk - 1) / kSweepChunk;
+    const int chunk = (c->n_hull_pairs + wgs - 1) / wgs;
+    const int n_obj = c->n_veh + c->n_poly, vpq = nc | 1;
+    const size_t lds = planar_lds_bytes<0>(n_obj, vpq, chunk);
+    const int L = 2 * c->deg + 1, tpf = (L % 2 == 0) ? L + 1 : L;
+    const size_t behind = lds - (size_t)16 * n_obj * vpq;
+    return (size_t)4 * 8 * tpf * sizeof(double) <= behind && lds <= 48 * 1024;
+}
+
 int launch_pair_sweep(obtg_ctx* c, const double* dY, int B, double max_sep, double* d_out_sep, int max_iter,
                       int md_cap, int* d_flag, double* d_p1, double* d_p2, double* d_dist, int* d_nsup, int* d_status)
 {
+    // with a virtual finite-difference batch (c->fd) only the one-launch kernel applies: it forms the rows while
+    // staging them; OBTG_ERR_UNSUPPORTED tells the caller to materialise the batch instead
     if (B <= 0) return OBTG_OK;
     const int nc = c->deg + 1;
     void (*kern)(const GjkSwarmParams) = nullptr;
@@ -2070,8 +2096,10 @@ int launch_pair_sweep(obtg_ctx* c, const double* dY, int B, double max_sep, doub
         p.ts.pairs = c->d_pairs.as<int2>(); p.ts.W2 = c->d_w2.as<double>(); p.ts.out = d_out_sep;
         p.ts.n_pairs = c->n_pairs; p.ts.sign = 1.0; p.ts.offset = -(max_sep * max_sep);
         p.ts_tile_rows = tr;
+        if (c->fd.Y0) { p.Y = c->fd.Y0; p.fd = 1; p.fd_fixed = c->fd.fixed; p.fd_h = c->fd.h; }
     }
     if (!fused) {
+        if (c->fd.Y0) return OBTG_ERR_UNSUPPORTED;   // caller materialises the batch (pair_sweep_fd_on_the_fly)
         int rc = launch_temporal_sep(c, dY, B, max_sep, 0, c->n_pairs, false, d_out_sep);
         if (rc) return rc;
         return launch_gjk_swarm(c, dY, B, max_iter, md_cap, d_flag, d_p1, d_p2, d_dist, d_nsup, d_status);

@@ -80,6 +80,11 @@ struct obtg_ctx {
     bool gjk_history = true;
     int gjk_len_cur = 0, gjk_len_rows = 0;   // buffer holding the latest counts, and how many rows of them
 
+    // Virtual finite-difference batch (obtg_*_fd_dev): rows are formed on the fly from ONE row of control points,
+    // row b >= 1 = Y0 with its (b-1)-th free control point advanced by h (exactly obtg_fd_batch_dev's rows).
+    struct FdView { const double* Y0 = nullptr; double h = 0.0; int fixed = 0; } fd;
+    obtg::DevBuf ws_fd;                   // materialised batch for shapes whose kernels have no on-the-fly form
+
     // scratch for host-buffer entry points
     obtg::DevBuf ws_in, ws_in2, ws_out, ws_misc[8];
     void* ring = nullptr;                 // pinned staging ring for pageable caller buffers (capi.cpp h2d / d2h)
@@ -137,6 +142,8 @@ int launch_ang_rate(obtg_ctx* c, const double* dY, const double* d_tf, int B, do
 int launch_dynamics(obtg_ctx* c, const double* dY, const double* d_tf, int B, double bound, int is_max,
                     double max_rate, double* d_out_speed, double* d_out_ang);
 int launch_fd_batch(obtg_ctx* c, const double* dY0, int n_fixed_cols, double h, int B, double* dY);
+bool dynamics_fd_on_the_fly(const obtg_ctx* c, bool want_ang);
+bool pair_sweep_is_one_launch(const obtg_ctx* c);
 int launch_bern_elev(obtg_ctx* c, const double* d_in, int rows, int n, int R, double* d_out);
 int launch_bern_diff(obtg_ctx* c, const double* d_in, int rows, int n, double T, double* d_out);
 int launch_bern_split(obtg_ctx* c, const double* d_in, int rows, int n, double z, double* d_left, double* d_right);

@@ -57,16 +57,11 @@ std::vector<double> elev_table_T(int L_in, int R)
 }
 
 // Degree elevation by R of an L_in-coefficient curve as a scaled convolution: three rows back to back
-//   scale[L_in] = C(N, j);  binp[R + 2 L_in - 1] = C(R, m), m = -(L_in-1) .. R+L_in-1;  inv[L_in+R] = 1/C(N+R, k)
+//   scale[L_in] = C(N, j);  binp[R + 2 L_in - 1 + 8] = C(R, m), m = -(L_in-1) .. R+L_in-1+8;  inv[L_in+R+8] = 1/C(N+R, k)
+// (8 = kConvPad of bern_device.h: kernels that produce blocks of 8 output columns read that far past the end)
 std::vector<double> elev_conv_tables(int L_in, int R)
 {
-    const int N = L_in - 1;
-    std::vector<double> t;
-    t.reserve((size_t)L_in + R + 2 * L_in - 1 + L_in + R);
-    for (int j = 0; j <= N; ++j) t.push_back(binom(N, j));
-    for (int m = -(L_in - 1); m <= R + L_in - 1; ++m) t.push_back(binom(R, m));
-    for (int k = 0; k <= N + R; ++k) t.push_back(1.0 / binom(N + R, k));
-    return t;
+    return elev_conv_padded(L_in, R, 8, false, true);
 }
 
 // The same elevation for kernels that walk a window of the binomial row (k_dynamics_elev):

@@ -1059,3 +1059,60 @@ def test_ang_rate_with_elevation_both_orders(capi, oracle, synth, golden_dir):
     ref = oracle.ang_rate(Y, 5, 12, 4.0, 1.0).reshape(5, L)
     assert_close(got[0].reshape(5, L)[[0, 2, 3, 4]], ref[[0, 2, 3, 4]], RTOL, "regular vehicles beside a degenerate one")
     ctx.close()
+
+
+@pytest.mark.parametrize("shape", ["C3", "deg7", "elevated", "space3d"])
+def test_fd_forms_equal_the_materialised_batch(capi, synth, shape):
+    """obtg_pair_sweep_fd_dev / obtg_dynamics_fd_dev take ONE row of control points and form the finite-difference
+    rows while staging them (C3, deg7: on the fly; elevated: dynamics on the fly, pair sweep through the fallback;
+    space3d: both through the fallback, which materialises the batch).  Every output must equal, bit for bit, what
+    obtg_fd_batch_dev + obtg_pair_sweep_dev / obtg_dynamics_dev produce."""
+    import torch
+    N, d, n, R, M, fixed = {"C3": (64, 2, 10, 0, 8, 1), "deg7": (9, 2, 7, 0, 2, 2), "elevated": (8, 2, 10, 6, 3, 1),
+                            "space3d": (7, 3, 5, 0, 0, 1)}[shape]
+    Y = synth.swarm_control_points(N, d, n, seed=12)
+    polys = synth.polygon_obstacles(M, seed=12)
+    pa, pb = synth.swarm_pairs(N, M)
+    B = N * d * (n + 1 - 2 * fixed) + 1 if shape != "C3" else 300
+    ctx = capi.Context(N, d, n, R)
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    ctx.set_polygons(*(synth.pack_polys(polys) if M else (None, [0])))
+    ctx.set_hull_pairs(pa, pb)
+    on_fly = ctx.fd_forms_on_the_fly()
+    assert on_fly == {"C3": (True, True), "deg7": (True, True), "elevated": (False, True), "space3d": (False, False)}[shape]
+    h = 1e-3
+    d0 = torch.from_numpy(Y).cuda()
+    dY = torch.empty((B,) + Y.shape, dtype=torch.float64, device="cuda")
+    ctx.fd_batch_dev(d0.data_ptr(), fixed, h, B, dY.data_ptr())
+    P, L, Ps = ctx.num_pairs, 2 * n + R + 1, len(pa)
+    dtf = torch.from_numpy(np.linspace(3.0, 9.0, B)).cuda()
+
+    def bufs():
+        f64, i32 = torch.float64, torch.int32
+        return dict(sep=torch.empty((B, P * L), dtype=f64, device="cuda"), flag=torch.empty((B, Ps), dtype=i32, device="cuda"),
+                    p1=torch.empty((B, Ps, 3), dtype=f64, device="cuda"), p2=torch.empty((B, Ps, 3), dtype=f64, device="cuda"),
+                    dist=torch.empty((B, Ps), dtype=f64, device="cuda"), ns=torch.empty((B, Ps), dtype=i32, device="cuda"),
+                    st=torch.empty((B, Ps), dtype=i32, device="cuda"),
+                    sp=torch.empty((B, ctx.len_speed), dtype=f64, device="cuda"),
+                    an=torch.empty((B, max(ctx.len_ang_rate, 1)), dtype=f64, device="cuda"))
+    a, b = bufs(), bufs()
+    an_a = a["an"].data_ptr() if d == 2 else 0
+    an_b = b["an"].data_ptr() if d == 2 else 0
+    ctx.pair_sweep_dev(dY.data_ptr(), B, 0.9, a["sep"].data_ptr(), a["flag"].data_ptr(), a["p1"].data_ptr(), a["p2"].data_ptr(),
+                       a["dist"].data_ptr(), a["ns"].data_ptr(), a["st"].data_ptr(), 128, 500)
+    ctx.dynamics_dev(dY.data_ptr(), dtf.data_ptr(), B, 4.0, True, 1.5, a["sp"].data_ptr(), an_a)
+    ctx.pair_sweep_fd_dev(d0.data_ptr(), fixed, h, B, 0.9, b["sep"].data_ptr(), b["flag"].data_ptr(), b["p1"].data_ptr(),
+                          b["p2"].data_ptr(), b["dist"].data_ptr(), b["ns"].data_ptr(), b["st"].data_ptr(), 128, 500)
+    ctx.dynamics_fd_dev(d0.data_ptr(), fixed, h, dtf.data_ptr(), B, 4.0, True, 1.5, b["sp"].data_ptr(), an_b)
+    torch.cuda.synchronize()
+    for key in a:
+        if key == "an" and d != 2:
+            continue
+        assert torch.equal(a[key].view(torch.uint8), b[key].view(torch.uint8)), key
+    assert int((a["flag"][1:] != a["flag"][:1]).sum().item()) > 0 or shape == "space3d"     # the batch really varies
+    # argument checks of the fd forms
+    with pytest.raises(capi.ObtgError):
+        ctx.dynamics_fd_dev(d0.data_ptr(), fixed, h, dtf.data_ptr(), N * d * (n + 1 - 2 * fixed) + 2, 4.0, True, 1.5,
+                            b["sp"].data_ptr(), an_b)
+    ctx.set_stream(0)
+    ctx.close()
