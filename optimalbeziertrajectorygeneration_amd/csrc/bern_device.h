@@ -187,6 +187,22 @@ __device__ __forceinline__ void elev_store_chunk(const double* __restrict__ tile
                                                  int LR, int k0, int kc, int n_valid, int lane)
 {
     constexpr int TP = kElevChunk + 1;
+    if (kc == kElevChunk && n_valid == kWave) {
+        // full tile: 32 store instructions of 2 x 256-byte runs; the LDS reads go out eight at a time (one read,
+        // one wait, one store per trip left the loop bound by the LDS latency: 32 x ~100 cycles per chunk)
+        const int q = lane & (kElevChunk - 1), half = lane >> 5;
+        const double* t = tile + half * TP + q;
+        double* g = gout + grow + (size_t)half * LR + k0 + q;
+#pragma unroll
+        for (int it0 = 0; it0 < kWave / 2; it0 += 8) {
+            double v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = t[(it0 + u) * 2 * TP];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) store_nt(g + (size_t)(it0 + u) * 2 * LR, v[u]);
+        }
+        return;
+    }
     if (kc == kElevChunk) {
         for (int e = lane; e < n_valid * kElevChunk; e += kWave) {
             const int pr = e / kElevChunk, q = e & (kElevChunk - 1);
@@ -214,6 +230,23 @@ __device__ __forceinline__ void conv_block2(const ctab_t cp, const double (&a)[L
         for (int i = 0; i < kElevBlock; ++i) {
             const int j = i + LIN - 1 - m;
             if (j >= 0 && j < LIN) { sa[i] = fma(c, a[j], sa[i]); sb[i] = fma(c, b[j], sb[i]); }
+        }
+    }
+}
+
+// the same walk with the window in registers (per-lane column block): w[m] = c[k0 - (LIN-1) + m]
+template <int LIN>
+__device__ __forceinline__ void conv_block1_reg(const double (&w)[LIN - 1 + kElevBlock], const double (&a)[LIN],
+                                                double (&sa)[kElevBlock])
+{
+#pragma unroll
+    for (int i = 0; i < kElevBlock; ++i) sa[i] = 0.0;
+#pragma unroll
+    for (int m = 0; m < LIN - 1 + kElevBlock; ++m) {
+#pragma unroll
+        for (int i = 0; i < kElevBlock; ++i) {
+            const int j = i + LIN - 1 - m;
+            if (j >= 0 && j < LIN) sa[i] = fma(w[m], a[j], sa[i]);
         }
     }
 }
@@ -309,7 +342,7 @@ __device__ __forceinline__ void normsq_elev_body(const NsParams& p, const int b,
 
     // LDS: [staged objects: stage_slots * VP][per-wave transposition tiles]
     double* vl = lds;
-    double* tile = lds + p.stage_slots * S::VP + wave * (ELEV ? kWave * (kElevChunk + 1) : p.tile_rows * S::TPF);
+    double* tile = lds + p.stage_slots * S::VP + wave * (ELEV ? kWave * (S::L + kElevBlock + 1) : p.tile_rows * S::TPF);
 
     // ---- stage the objects this workgroup touches
     const double* Yrow = p.Y + (size_t)b * p.n_veh * S::VLEN;
@@ -448,28 +481,64 @@ __device__ __forceinline__ void normsq_elev_body(const NsParams& p, const int b,
                 }
                 if (mine) p.out[row + r] = p.sign * m + p.offset;
             } else {
-                // Full elevated rows, lane = item: the elevation as a sliding-window convolution (above), 32 output
-                // columns at a time through the wave's transposition tile.  No LDS traffic in the FMA loop (the
-                // earlier form -- lane = output column, the pair's coefficients as LDS broadcasts -- was bound by
-                // the LDS pipe: C5 0.65 ms for 2.26 GB of output).
-                const ctab_t escale = as_ctab(p.Tt), ebin = escale + L, einv = ebin + (p.R + 2 * L - 1 + kConvPad);
-                double ch[L];
+                // Full elevated rows.  The wave's pre-scaled product coefficients go to LDS (64 x L); then the lane <->
+                // data mapping changes to lane = (row of a pass, block of 8 output columns): a pass covers `rpp` = 64 /
+                // nb2 rows x all columns, the lane keeps the window of the binomial row its 8 columns need in registers
+                // for the whole kernel and reads its row's L coefficients as LDS broadcasts -- 8 FMAs per LDS operand --
+                // and a pass's rows, contiguous in the output, leave through a small tile as ONE linear run of 16-byte
+                // stores.  (Earlier forms: lane = output column with 2 columns per lane was bound by the LDS pipe, 0.65 ms
+                // at C5; lane = item with 32-column chunks wrote 256-byte pieces of 968-byte rows: 0.87-1.24 ms.)
+                const ctab_t escale = as_ctab(p.Tt);
+                const double* ebin_g = p.Tt + L;
+                const double* einv_g = ebin_g + (p.R + 2 * L - 1 + kConvPad);
+                const int nblk = (LR + kElevBlock - 1) / kElevBlock;
+                int nb2 = 1;
+                while (nb2 < nblk && nb2 < kWave) nb2 <<= 1;
+                const int rpp = kWave / nb2;                       // rows per pass
+                const int cb = lane & (nb2 - 1), rs = lane / nb2;
+                double* chT = tile;                                // [64][L]
+                // output tile of a pass: row q, column block c, column i of the block at q * opitch + c * 9 + i -- the
+                // pitch of 9 doubles per 8-column block keeps the 16 lanes of a row on 16 different bank pairs (at
+                // pitch 8 they fall on 4: PMC showed 60 % of the LDS cycles of this loop as bank conflicts).
+                // Ordinary write-back stores: a row is 8 LR bytes, not a multiple of the 128-byte line, so neighbouring
+                // store instructions share lines and the L2 has to merge them -- with non-temporal stores the same loop
+                // ran 0.65 instead of 0.55 ms at C5 (2.26 GB of output per launch).
+                constexpr int BP = kElevBlock + 1;
+                double* otile = tile + kWave * L;                  // [rpp][nb2 * 9]
+                const int opitch = nb2 * BP;
+                if (mine) {
 #pragma unroll
-                for (int j = 0; j < L; ++j) ch[j] = cf[j] * escale[j];
-                for (int k0 = 0; k0 < LR; k0 += kElevChunk) {
-                    const int kc = min(kElevChunk, LR - k0);
-                    for (int kb = 0; kb < kc; kb += kElevBlock) {
-                        double sa[kElevBlock];
-                        conv_block1<L>(ebin + k0 + kb, ch, sa);
-                        if (mine) {
+                    for (int j = 0; j < L; ++j) chT[r * L + j] = cf[j] * escale[j];
+                }
+                wave_sync();
+                for (int cg = 0; cg < nblk; cg += nb2) {            // column groups (one unless LR > 512)
+                    const int blk = cg + cb;
+                    const bool colv = blk < nblk;
+                    double w[L - 1 + kElevBlock], inv8[kElevBlock];
 #pragma unroll
-                            for (int i = 0; i < kElevBlock; ++i)
-                                tile[r * (kElevChunk + 1) + kb + i] = p.sign * (sa[i] * einv[k0 + kb + i]) + p.offset;
+                    for (int m = 0; m < L - 1 + kElevBlock; ++m) w[m] = colv ? ebin_g[blk * kElevBlock + m] : 0.0;
+#pragma unroll
+                    for (int i = 0; i < kElevBlock; ++i) inv8[i] = colv ? einv_g[blk * kElevBlock + i] : 0.0;
+                    const int c_lo = cg * kElevBlock, c_n = min(LR - c_lo, nb2 * kElevBlock);   // columns of this group
+                    for (int r0 = 0; r0 < n_valid; r0 += rpp) {
+                        const int rr = r0 + rs;
+                        if (rr < n_valid && colv) {
+                            double ch[L], sa[kElevBlock];
+#pragma unroll
+                            for (int j = 0; j < L; ++j) ch[j] = chT[rr * L + j];
+                            conv_block1_reg<L>(w, ch, sa);
+                            double* o = otile + rs * opitch + cb * BP;
+#pragma unroll
+                            for (int i = 0; i < kElevBlock; ++i) o[i] = p.sign * (sa[i] * inv8[i]) + p.offset;
                         }
+                        wave_sync();
+                        const int rows = min(rpp, n_valid - r0);
+                        for (int q = 0; q < rows; ++q) {            // each row: a run of c_n doubles, 512 bytes per store instruction
+                            double* g = p.out + (row + r0 + q) * LR + c_lo;
+                            for (int kc = lane; kc < c_n; kc += kWave) g[kc] = otile[q * opitch + (kc >> 3) * BP + (kc & 7)];
+                        }
+                        wave_sync();
                     }
-                    wave_sync();
-                    elev_store_chunk<L>(tile, p.out, row * LR, LR, k0, kc, n_valid, lane);
-                    wave_sync();
                 }
             }
         }

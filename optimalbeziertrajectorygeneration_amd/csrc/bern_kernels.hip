@@ -52,7 +52,7 @@ struct TsepFdParams {
     const double* __restrict__ Y0;     // [n_veh*DIM][NC] the evaluation row
     const double* __restrict__ obs;    // [n_obj - n_veh][DIM] point obstacles (constant curves)
     const double* __restrict__ W2;     // folded product weights
-    const double* __restrict__ Td;     // dense elevation table [L+R][L]
+    const double* __restrict__ Tt;     // elevation as a scaled convolution (NsParams::Tt)
     const int* __restrict__ prow;      // [n_pert] row of Y0 that perturbation t touches
     const int* __restrict__ pcol;      // [n_pert] column
     const double* __restrict__ pval;   // [n_pert] the perturbed value itself (x_k + h as the caller rounds it)
@@ -92,12 +92,17 @@ __global__ __launch_bounds__(kWave) void k_tsep_fd(const TsepFdParams p)
 #pragma unroll
         for (int k = 0; k < L; ++k) o[k] = p.sign * cf[k] + p.offset;
     } else {
-        for (int k = 0; k < LR; ++k) {
-            const double* w = p.Td + (size_t)k * L;
-            double s1 = 0.0;
+        // the elevation exactly as normsq_elev_body forms it (same pre-scaling, same window walk, same order)
+        const ctab_t escale = as_ctab(p.Tt), ebin = escale + L, einv = ebin + (p.R + 2 * L - 1 + kConvPad);
+        double ch[L];
 #pragma unroll
-            for (int j = 0; j < L; ++j) s1 = fma(cf[j], w[j], s1);
-            o[k] = p.sign * s1 + p.offset;
+        for (int j = 0; j < L; ++j) ch[j] = cf[j] * escale[j];
+        for (int k = 0; k < LR; k += kElevBlock) {
+            double sa[kElevBlock];
+            conv_block1<L>(ebin + k, ch, sa);
+#pragma unroll
+            for (int i = 0; i < kElevBlock; ++i)
+                if (k + i < LR) o[k + i] = p.sign * (sa[i] * einv[k + i]) + p.offset;
         }
     }
 }
@@ -1009,7 +1014,7 @@ static int launch_ns_t(obtg_ctx* c, NsParams p, int B, int kernel_id)
     const size_t stage = (size_t)p.stage_slots * S::VP * sizeof(double);
     size_t lds = 0;
     if (MINONLY) { p.tile_rows = 0; lds = stage; }
-    else if (p.R > 0) { p.tile_rows = kWave; lds = stage + (size_t)p.waves * kWave * (kElevChunk + 1) * sizeof(double); }
+    else if (p.R > 0) { p.tile_rows = kWave; lds = stage + (size_t)p.waves * kWave * (S::L + kElevBlock + 1) * sizeof(double); }
     else {
         for (int tr = kWave; tr >= 16; tr >>= 1) {
             p.tile_rows = tr;
@@ -1276,7 +1281,7 @@ int launch_temporal_sep_fd(obtg_ctx* c, const double* dY0, int n_pert, const int
     if (rc) return rc;
     if (!fast_shape(c)) return OBTG_ERR_UNSUPPORTED;
     TsepFdParams p{};
-    p.Y0 = dY0; p.obs = c->d_obs.as<double>(); p.W2 = c->d_w2.as<double>(); p.Td = c->d_Td.as<double>();
+    p.Y0 = dY0; p.obs = c->d_obs.as<double>(); p.W2 = c->d_w2.as<double>(); p.Tt = c->d_Tt.as<double>();
     p.prow = d_prow; p.pcol = d_pcol; p.pval = d_pval; p.out = d_out;
     p.n_veh = c->n_veh; p.n_obj = c->n_obj; p.R = c->R; p.n_pert = n_pert;
     p.sign = 1.0; p.offset = -(max_sep * max_sep);
