@@ -250,6 +250,22 @@ int obtg_gjk_swarm(obtg_ctx*, const double* Y, int B, int max_iter, int md_cap,
  * (bezier.py:1283-1408 on gjkNew: non-minimal hull distances used as lower bounds, unbounded loops). */
 int obtg_min_dist_robust(obtg_ctx*, const double* curves, int n_curves, int K, const int* pair_a, const int* pair_b,
                          int n_pairs, double eps, int max_nodes, double* res, int* info, int* status);
+/* The curve <-> polygon form of the robust search (NOT the reference's `_minDist2Poly`, bezier.py:1411-1496): branch &
+ * bound on the curve parameter with bounds that hold for the curve itself -- upper: true distances from sub-curve end
+ * points to the polygon's convex hull; lower: the certified lower bound of the true distance between the sub-curve's
+ * control hull and the polygon's hull (obtg_gjk_true_pairs' algorithm).  res[n_pairs][5] = (dist, t, closest point on the
+ * polygon's hull[3]); info / status as obtg_min_dist_robust. */
+int obtg_min_dist2poly_robust(obtg_ctx*, const double* curves, int n_curves, int K, const double* pts, int n_pts,
+                              const int* poly_off, int n_poly, const int* pair_curve, const int* pair_poly, int n_pairs,
+                              double eps, int max_nodes, double* res, int* info, int* status);
+/* True distance between the convex hulls of two point sets (opt-in; NOT gjkNew, which stops at a non-minimal distance
+ * on ~30 % of separated pairs and never exits on some 3-D inputs -- SURVEY.md 8(a) G2): a textbook GJK whose exit test
+ * is a certificate, dist >= hull distance >= lower with dist - lower <= eps * dist.  Same point-set / pair conventions as
+ * obtg_gjk_pairs.  flag 1 separated (p1 / p2 = closest points, dist), 0 intersecting or touching (dist 0);
+ * lower, iters, status (0 converged, 1 iteration cap) are nullable. */
+int obtg_gjk_true_pairs(obtg_ctx*, const double* pts, int n_pts, const int* poly_off, int n_poly,
+                        const int* pair_a, const int* pair_b, int n_pairs, double eps, int max_iter,
+                        int* flag, double* p1, double* p2, double* dist, double* lower, int* iters, int* status);
 /* ---- curve <-> curve / curve <-> polygon minimum distance --------------------------------
  * Bezier.minDist -> _minDist (bezier.py:840-852, 1283-1408) and Bezier.minDist2Poly ->
  * _minDist2Poly (bezier.py:854-857, 1411-1496): branch and bound over de Casteljau

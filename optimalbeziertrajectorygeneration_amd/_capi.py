@@ -69,6 +69,8 @@ _SIGNATURES = {
     "obtg_min_dist": (_i, [_vp, _vp, _i, _i, _vp, _vp, _i, _d, _i, _i, _i, _i, _vp, _vp, _vp]),
     "obtg_min_dist_robust": (_i, [_vp, _vp, _i, _i, _vp, _vp, _i, _d, _i, _vp, _vp, _vp]),
     "obtg_min_dist2poly": (_i, [_vp, _vp, _i, _i, _vp, _i, _vp, _i, _vp, _vp, _i, _d, _i, _i, _i, _i, _vp, _vp, _vp]),
+    "obtg_min_dist2poly_robust": (_i, [_vp, _vp, _i, _i, _vp, _i, _vp, _i, _vp, _vp, _i, _d, _i, _vp, _vp, _vp]),
+    "obtg_gjk_true_pairs": (_i, [_vp, _vp, _i, _vp, _i, _vp, _vp, _i, _d, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "obtg_bern_elev": (_i, [_vp, _vp, _i, _i, _i, _vp]),
     "obtg_bern_diff": (_i, [_vp, _vp, _i, _i, _d, _vp]),
     "obtg_bern_mul": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),
@@ -517,6 +519,35 @@ class Context(object):
                                                  max_iter, md_cap, max_depth, max_nodes, _ptr(res), _ptr(info),
                                                  _ptr(status)), "obtg_min_dist2poly")
         return dict(res=res, nodes=info[:, 0], gjk_calls=info[:, 1], depth=info[:, 2], status=status)
+
+    def min_dist2poly_robust(self, curves, pts, off, pair_curve, pair_poly, eps=1e-9, max_nodes=200000):
+        """Robust curve <-> polygon distance (obtg_min_dist2poly_robust): true minimum within relative eps when MD_OK."""
+        curves = _f64(curves)
+        n_curves, _, K = curves.shape
+        pts = _f64(pts).reshape(-1, 3)
+        off = _i32(off)
+        pc, pp = _i32(pair_curve), _i32(pair_poly)
+        n = pc.shape[0]
+        res = np.empty((n, 5))
+        info = np.zeros((n, 4), np.int32)
+        status = np.zeros(n, np.int32)
+        self._check(self._lib.obtg_min_dist2poly_robust(self._h, _ptr(curves), n_curves, K, _ptr(pts), pts.shape[0], _ptr(off),
+                                                        off.shape[0] - 1, _ptr(pc), _ptr(pp), n, float(eps), int(max_nodes),
+                                                        _ptr(res), _ptr(info), _ptr(status)), "obtg_min_dist2poly_robust")
+        return dict(res=res, nodes=info[:, 0], levels=info[:, 1], frontier=info[:, 2], status=status)
+
+    def gjk_true_pairs(self, pts, off, pair_a, pair_b, eps=1e-10, max_iter=64):
+        """True hull distances (obtg_gjk_true_pairs; not gjkNew): dist with the certificate dist - lower <= eps * dist."""
+        pts = _f64(pts).reshape(-1, 3)
+        off = _i32(off)
+        pa, pb = _i32(pair_a), _i32(pair_b)
+        n = pa.shape[0]
+        flag, iters, status = np.zeros(n, np.int32), np.zeros(n, np.int32), np.zeros(n, np.int32)
+        p1, p2, dist, lower = np.empty((n, 3)), np.empty((n, 3)), np.empty(n), np.empty(n)
+        self._check(self._lib.obtg_gjk_true_pairs(self._h, _ptr(pts), pts.shape[0], _ptr(off), off.shape[0] - 1, _ptr(pa), _ptr(pb),
+                                                  n, float(eps), int(max_iter), _ptr(flag), _ptr(p1), _ptr(p2), _ptr(dist),
+                                                  _ptr(lower), _ptr(iters), _ptr(status)), "obtg_gjk_true_pairs")
+        return dict(flag=flag, c1=p1, c2=p2, dist=dist, lower=lower, iters=iters, status=status)
 
     # -- single-curve algebra
     def bern_elev(self, cpts, R):

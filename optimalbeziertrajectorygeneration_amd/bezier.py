@@ -228,8 +228,17 @@ class Bezier(BezierParams):
         a, t1, t2 = r['res'][0]
         return (float(a), float(t1), float(t2))
 
-    def minDist2Poly(self, poly, eps=1e-6, max_depth=128, max_nodes=4000000):
+    def minDist2Poly(self, poly, eps=1e-6, max_depth=128, max_nodes=4000000, robust=False):
+        """(dist, t, closest point on the polygon).  Default: the reference's `_minDist2Poly` step for step
+        (bezier.py:1411-1496).  robust=True: obtg_min_dist2poly_robust, the true minimum within relative eps."""
         poly = np.asarray(poly, dtype=float)
+        if robust:
+            r = _ctx().min_dist2poly_robust(self._padded()[None], poly, [0, poly.shape[0]], [0], [0], eps=min(eps, 1e-9),
+                                            max_nodes=max_nodes)
+            if r['status'][0] != _capi.MD_OK:
+                raise RuntimeError('minDist2Poly(robust): search budget exhausted; best distance so far %g' % r['res'][0][0])
+            res = r['res'][0]
+            return (float(res[0]), float(res[1]), res[2:].copy())
         r = _ctx().min_dist2poly(self._padded()[None], poly, [0, poly.shape[0]], [0], [0], eps=eps,
                                  max_depth=max_depth, max_nodes=max_nodes)
         _raise_md(r['status'][0])

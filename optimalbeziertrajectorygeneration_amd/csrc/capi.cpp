@@ -193,7 +193,7 @@ const char* obtg_abi_symbols(void)
         "obtg_temporal_sep_fd\0obtg_temporal_sep_fd_dev\0"
         "obtg_temporal_sep_dev\0obtg_temporal_sep_min_dev\0obtg_speed_dev\0obtg_ang_rate_dev\0obtg_dynamics_dev\0"
         "obtg_fd_batch_dev\0obtg_fd_forms_on_the_fly\0obtg_pair_sweep_fd_dev\0obtg_dynamics_fd_dev\0obtg_gjk_pairs\0obtg_ctx_set_polygons\0obtg_ctx_set_hull_pairs\0"
-        "obtg_ctx_set_fd_dedup\0obtg_ctx_set_gjk_history\0obtg_pair_sweep_dev\0obtg_gjk_swarm_dev\0obtg_gjk_swarm\0obtg_min_dist\0obtg_min_dist_robust\0obtg_min_dist2poly\0"
+        "obtg_ctx_set_fd_dedup\0obtg_ctx_set_gjk_history\0obtg_pair_sweep_dev\0obtg_gjk_swarm_dev\0obtg_gjk_swarm\0obtg_min_dist\0obtg_min_dist_robust\0obtg_min_dist2poly\0obtg_min_dist2poly_robust\0obtg_gjk_true_pairs\0"
         "obtg_bern_elev\0obtg_bern_diff\0obtg_bern_mul\0obtg_bern_normsq\0obtg_bern_split\0"
         "obtg_euclidean_obj\0obtg_accel_obj\0obtg_jerk_obj\0"
         "obtg_set_profiling\0obtg_set_profile_period\0obtg_kernel_stats\0obtg_reset_kernel_stats\0obtg_kernel_name\0";
@@ -702,6 +702,85 @@ int obtg_gjk_pairs(obtg_ctx* c, const double* pts, int n_pts, const int* poly_of
         OBTG_HIP(c, hipMemcpyAsync(support_trace, d_trace, sizeof(short) * 2 * (size_t)trace_cap * n_pairs,
                                    hipMemcpyDeviceToHost, c->stream));
     return d2h(c, dist, d_dist, sizeof(double) * n_pairs);
+}
+
+int obtg_gjk_true_pairs(obtg_ctx* c, const double* pts, int n_pts, const int* poly_off, int n_poly, const int* pair_a,
+                        const int* pair_b, int n_pairs, double eps, int max_iter, int* flag, double* p1, double* p2,
+                        double* dist, double* lower, int* iters, int* status)
+{
+    if (!check_ctx(c) || !pts || !pair_a || !pair_b || !flag || !p1 || !p2 || !dist) return OBTG_ERR_ARG;
+    if (n_pairs < 0 || max_iter < 1 || !(eps > 0)) return OBTG_ERR_ARG;
+    int rc = check_polys(poly_off, n_poly, n_pts);
+    if (rc) return rc;
+    for (int k = 0; k < n_pairs; ++k)
+        if (pair_a[k] < 0 || pair_a[k] >= n_poly || pair_b[k] < 0 || pair_b[k] >= n_poly) return OBTG_ERR_ARG;
+    if (n_pairs == 0) return OBTG_OK;
+    (void)hipSetDevice(c->device);
+    auto soa = to_soa(pts, poly_off, n_poly);
+    DevBuf* m = c->ws_misc;
+    if ((rc = h2d(c, c->ws_in, soa.data(), soa.size() * sizeof(double)))) return rc;
+    if ((rc = h2d(c, m[0], poly_off, sizeof(int) * (n_poly + 1)))) return rc;
+    if ((rc = h2d(c, m[1], pair_a, sizeof(int) * n_pairs))) return rc;
+    if ((rc = h2d(c, m[2], pair_b, sizeof(int) * n_pairs))) return rc;
+    if ((rc = m[3].reserve(sizeof(int) * 3 * (size_t)n_pairs))) return rc;
+    if ((rc = c->ws_out.reserve(sizeof(double) * 8 * (size_t)n_pairs))) return rc;
+    int* d_flag = m[3].as<int>();
+    int* d_iters = d_flag + n_pairs;
+    int* d_status = d_iters + n_pairs;
+    double* d_p1 = c->ws_out.as<double>();
+    double* d_p2 = d_p1 + 3 * (size_t)n_pairs;
+    double* d_dist = d_p2 + 3 * (size_t)n_pairs;
+    double* d_lower = d_dist + n_pairs;
+    rc = launch_gjk_true_pairs(c, c->ws_in.as<double>(), m[0].as<int>(), m[1].as<int>(), m[2].as<int>(), n_pairs, eps,
+                               max_iter, d_flag, d_p1, d_p2, d_dist, d_lower, d_iters, d_status);
+    if (rc) return rc;
+    if ((rc = d2h_copy(c, flag, d_flag, sizeof(int) * n_pairs))) return rc;
+    if (iters && (rc = d2h_copy(c, iters, d_iters, sizeof(int) * n_pairs))) return rc;
+    if (status && (rc = d2h_copy(c, status, d_status, sizeof(int) * n_pairs))) return rc;
+    if ((rc = d2h_copy(c, p1, d_p1, sizeof(double) * 3 * n_pairs))) return rc;
+    if ((rc = d2h_copy(c, p2, d_p2, sizeof(double) * 3 * n_pairs))) return rc;
+    if (lower && (rc = d2h_copy(c, lower, d_lower, sizeof(double) * n_pairs))) return rc;
+    return d2h(c, dist, d_dist, sizeof(double) * n_pairs);
+}
+
+int obtg_min_dist2poly_robust(obtg_ctx* c, const double* curves, int n_curves, int K, const double* pts, int n_pts,
+                              const int* poly_off, int n_poly, const int* pair_curve, const int* pair_poly, int n_pairs,
+                              double eps, int max_nodes, double* res, int* info, int* status)
+{
+    if (!check_ctx(c) || !curves || !pts || !pair_curve || !pair_poly || !res || n_curves < 1 || n_pairs < 0)
+        return OBTG_ERR_ARG;
+    if (K < 2 || max_nodes < 1 || !(eps > 0)) return OBTG_ERR_ARG;
+    int rc = check_polys(poly_off, n_poly, n_pts);
+    if (rc) return rc;
+    for (int k = 0; k < n_pairs; ++k)
+        if (pair_curve[k] < 0 || pair_curve[k] >= n_curves || pair_poly[k] < 0 || pair_poly[k] >= n_poly)
+            return OBTG_ERR_ARG;
+    if (n_pairs == 0) return OBTG_OK;
+    (void)hipSetDevice(c->device);
+    constexpr int kCap = 1024, kMaxLevel = 48;
+    DevBuf* m = c->ws_misc;
+    auto soa = to_soa(pts, poly_off, n_poly);
+    int max_K = 0;
+    for (int a = 0; a < n_poly; ++a) max_K = std::max(max_K, poly_off[a + 1] - poly_off[a]);
+    if ((rc = h2d(c, c->ws_in, curves, sizeof(double) * 3 * (size_t)K * n_curves))) return rc;
+    if ((rc = h2d(c, c->ws_in2, soa.data(), soa.size() * sizeof(double)))) return rc;
+    if ((rc = h2d(c, m[0], poly_off, sizeof(int) * (n_poly + 1)))) return rc;
+    if ((rc = h2d(c, m[1], pair_curve, sizeof(int) * n_pairs))) return rc;
+    if ((rc = h2d(c, m[2], pair_poly, sizeof(int) * n_pairs))) return rc;
+    if ((rc = m[5].reserve(sizeof(double) * 2 * kCap * 2 * (size_t)n_pairs))) return rc;
+    if ((rc = c->ws_out.reserve(sizeof(double) * 5 * (size_t)n_pairs))) return rc;
+    if ((rc = m[3].reserve(sizeof(int) * 4 * (size_t)n_pairs))) return rc;
+    rc = launch_min_dist2poly_robust(c, c->ws_in.as<double>(), K, c->ws_in2.as<double>(), m[0].as<int>(), m[1].as<int>(),
+                                     m[2].as<int>(), n_pairs, eps, max_nodes, kMaxLevel, kCap, max_K, m[5].as<double>(),
+                                     c->ws_out.as<double>(), m[3].as<int>());
+    if (rc) return rc;
+    std::vector<int> hinfo((size_t)4 * n_pairs);
+    if ((rc = d2h_copy(c, hinfo.data(), m[3].p, sizeof(int) * 4 * n_pairs))) return rc;
+    rc = d2h(c, res, c->ws_out.p, sizeof(double) * 5 * n_pairs);
+    if (rc) return rc;
+    if (info) std::memcpy(info, hinfo.data(), sizeof(int) * 4 * n_pairs);
+    if (status) for (int k = 0; k < n_pairs; ++k) status[k] = hinfo[4 * k + 3];
+    return OBTG_OK;
 }
 
 int obtg_ctx_set_polygons(obtg_ctx* c, const double* pts, int n_pts, const int* poly_off, int n_poly)

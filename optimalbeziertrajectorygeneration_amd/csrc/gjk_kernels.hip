@@ -17,6 +17,7 @@
 #include <cstdlib>
 
 #include "gjk_device.h"
+#include "gjk_true.h"
 #include "obtg_internal.h"
 // the Bernstein sweep body that k_pair_sweep runs beside the GJK workgroups: same contraction
 // setting as in bern_kernels.hip, so that both units produce the same arithmetic
@@ -1655,6 +1656,196 @@ __global__ __launch_bounds__(64) void k_min_dist_robust(const MdrParams p)
     }
 }
 
+
+// -------------------------------------------------------------------------------------
+//  True hull distance (gjk_true.h; NOT the reference's gjkNew): one pair per lane, point sets in global memory
+//  (SoA per polygon as for k_gjk_pairs).  Per pair: flag (1 separated / 0 intersecting), closest points, distance
+//  = the hull distance within a relative eps, `lower` = the proven lower bound at exit, iterations, status.
+// -------------------------------------------------------------------------------------
+struct GjkTrueParams {
+    const double* __restrict__ soa;
+    const int* __restrict__ off;
+    const int* __restrict__ pa;
+    const int* __restrict__ pb;
+    int n_pairs, max_iter;
+    double eps;
+    int* __restrict__ flag;
+    double* __restrict__ p1;
+    double* __restrict__ p2;
+    double* __restrict__ dist;
+    double* __restrict__ lower;
+    int* iters;
+    int* status;
+};
+
+struct SoaSet {          // one polygon of the SoA table: x[K] y[K] z[K]
+    const double* b;
+    int K;
+    __device__ __forceinline__ tgjk::P3 operator()(int i) const { return tgjk::P3{ b[i], b[K + i], b[2 * K + i] }; }
+};
+
+template <class S1, class S2>
+struct SupportScan {
+    S1 s1; S2 s2; int K1, K2;
+    __device__ __forceinline__ void operator()(const tgjk::P3& d, int& i1, int& i2) const
+    {
+        i1 = 0; i2 = 0;
+        double m1 = tgjk::dot(s1(0), d), m2 = -tgjk::dot(s2(0), d);
+        for (int i = 1; i < K1; ++i) { const double c = tgjk::dot(s1(i), d); if (c > m1) { m1 = c; i1 = i; } }
+        for (int i = 1; i < K2; ++i) { const double c = -tgjk::dot(s2(i), d); if (c > m2) { m2 = c; i2 = i; } }
+    }
+};
+
+__global__ __launch_bounds__(256) void k_gjk_true_pairs(const GjkTrueParams p)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= p.n_pairs) return;
+    const int a = p.pa[k], b = p.pb[k];
+    const int oa = p.off[a], ob = p.off[b];
+    const SoaSet s1{ p.soa + 3 * oa, p.off[a + 1] - oa }, s2{ p.soa + 3 * ob, p.off[b + 1] - ob };
+    double scale = 0.0;
+    for (int i = 0; i < 3 * s1.K; ++i) scale = fmax(scale, __builtin_fabs(s1.b[i]));
+    for (int i = 0; i < 3 * s2.K; ++i) scale = fmax(scale, __builtin_fabs(s2.b[i]));
+    const SupportScan<SoaSet, SoaSet> sup{ s1, s2, s1.K, s2.K };
+    const tgjk::Result r = tgjk::true_distance(sup, s1, s2, p.eps, p.eps * scale, p.max_iter);
+    p.flag[k] = r.flag;
+    p.p1[3 * k] = r.c1.x; p.p1[3 * k + 1] = r.c1.y; p.p1[3 * k + 2] = r.c1.z;
+    p.p2[3 * k] = r.c2.x; p.p2[3 * k + 1] = r.c2.y; p.p2[3 * k + 2] = r.c2.z;
+    p.dist[k] = r.dist;
+    if (p.lower) p.lower[k] = r.lower;
+    if (p.iters) p.iters[k] = r.iters;
+    if (p.status) p.status[k] = r.status;
+}
+
+// -------------------------------------------------------------------------------------
+//  Robust curve <-> polygon minimum distance (NOT the reference's `_minDist2Poly`, which
+//  inherits gjkNew's non-minimal distances as "lower bounds" and its unbounded loops, bezier.py:1411-1496).
+//  Breadth-first branch & bound on the curve parameter, one pair per wavefront, one node per lane.  A node is a
+//  sub-curve [t, t + 2^-level]; with the true hull distance of gjk_true.h both bounds are valid for the curve itself:
+//    upper = distance from the sub-curve's two end points (points ON the curve) to the polygon's hull,
+//    lower = the certified lower bound of the distance between the sub-curve's control hull and the polygon's hull.
+//  Survivors (lower < alpha (1 - eps)) are halved into a ping-pong frontier in global memory.  Ends when the
+//  frontier is empty or alpha <= eps x (largest coordinate) (the curve touches the polygon); caps return the best
+//  upper bound with a status.
+// -------------------------------------------------------------------------------------
+struct Md2rParams {
+    const double* __restrict__ curves;   // [n_curves][3][K]
+    const double* __restrict__ soa;      // polygons, SoA
+    const int* __restrict__ off;
+    const int* __restrict__ pc;
+    const int* __restrict__ pp;
+    int n_pairs, K, max_nodes, max_level, cap;
+    double eps;
+    double* frontier;                     // [n_pairs][2][cap][2]  (t, level)
+    double* __restrict__ res;             // [n_pairs][5]  (dist, t, closest point on the polygon[3])
+    int* __restrict__ info;               // [n_pairs][4]  (nodes, levels, max frontier, status)
+};
+
+struct LdsRows {         // a lane's sub-curve: rows x[K] y[K] z[K] in LDS
+    const double* b;
+    int K;
+    __device__ __forceinline__ tgjk::P3 operator()(int i) const { return tgjk::P3{ b[i], b[K + i], b[2 * K + i] }; }
+};
+
+struct OnePoint {
+    tgjk::P3 q;
+    __device__ __forceinline__ tgjk::P3 operator()(int) const { return q; }
+};
+
+__global__ __launch_bounds__(64) void k_min_dist2poly_robust(const Md2rParams p)
+{
+    extern __shared__ double mr_lds[];
+    __shared__ int s_count;
+    const int k = blockIdx.x, lane = threadIdx.x, K = p.K;
+    const int pitch = (3 * K) | 1;
+    const int po = p.off[p.pp[k]], Kp = p.off[p.pp[k] + 1] - po;
+    double* orig = mr_lds;                         // [3][K]
+    double* poly = orig + 3 * K;                   // [3][Kp]
+    double* work = poly + 3 * Kp + lane * pitch;   // per lane: the node's sub-curve [3][K]
+    const double* cc = p.curves + (size_t)p.pc[k] * 3 * K;
+    double scale = 0.0;
+    for (int i = lane; i < 3 * K; i += kWave) { const double a = cc[i]; orig[i] = a; scale = fmax(scale, __builtin_fabs(a)); }
+    for (int i = lane; i < 3 * Kp; i += kWave) { const double a = p.soa[3 * po + i]; poly[i] = a; scale = fmax(scale, __builtin_fabs(a)); }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) scale = fmax(scale, __shfl_xor(scale, m));
+    const double abs_tol = p.eps * scale;
+    double* fa = p.frontier + (size_t)k * 2 * p.cap * 2;
+    double* fb = fa + (size_t)p.cap * 2;
+    if (lane == 0) { fa[0] = 0.0; fa[1] = 0.0; }
+    __syncthreads();
+    const LdsRows pset{ poly, Kp };
+    int n_a = 1, nodes = 0, levels = 0, front_max = 1, status = OBTG_MD_OK;
+    double alpha = INFINITY, bt = -1, bx = 0, by = 0, bz = 0;
+    while (n_a > 0) {
+        if (lane == 0) s_count = 0;
+        __syncthreads();
+        for (int base = 0; base < n_a; base += kWave) {
+            const bool valid = base + lane < n_a;
+            const int ni = valid ? base + lane : base;
+            const double t = fa[2 * ni];
+            const int lev = (int)fa[2 * ni + 1];
+            const double w = __builtin_ldexp(1.0, -lev);
+            for (int q = 0; q < 3; ++q) {
+                for (int i = 0; i < K; ++i) work[q * K + i] = orig[q * K + i];
+                subcurve_row(work + q * K, K, t, w);
+            }
+            // upper bounds: the sub-curve's end points against the polygon's hull
+            double best = INFINITY, bt_l = -1;
+            tgjk::P3 bc{ 0, 0, 0 };
+            for (int e = 0; e < 2; ++e) {
+                const int ie = e ? K - 1 : 0;
+                const OnePoint one{ tgjk::P3{ work[ie], work[K + ie], work[2 * K + ie] } };
+                const SupportScan<OnePoint, LdsRows> sup{ one, pset, 1, Kp };
+                const tgjk::Result r = tgjk::true_distance(sup, one, pset, 1e-13, abs_tol, 64);
+                if (r.dist < best) { best = r.dist; bt_l = t + e * w; bc = r.c2; }
+            }
+            if (!valid) best = INFINITY;
+            double wb = best;
+#pragma unroll
+            for (int m = 32; m >= 1; m >>= 1) wb = fmin(wb, __shfl_xor(wb, m));
+            if (wb < alpha) {
+                const unsigned long long who = __ballot(best == wb);
+                const int src = __ffsll((long long)who) - 1;
+                alpha = wb; bt = __shfl(bt_l, src);
+                bx = __shfl(bc.x, src); by = __shfl(bc.y, src); bz = __shfl(bc.z, src);
+            }
+            // lower bound: control hull of the sub-curve against the polygon's hull
+            const LdsRows cset{ work, K };
+            const SupportScan<LdsRows, LdsRows> sup2{ cset, pset, K, Kp };
+            const tgjk::Result rl = tgjk::true_distance(sup2, cset, pset, 1e-6, abs_tol, 64);
+            const double lb = rl.flag ? rl.lower * (1.0 - 1e-12) : 0.0;
+            const bool keep = valid && lb < alpha * (1 - p.eps) && alpha > abs_tol;
+            if (keep) {
+                if (lev + 1 > p.max_level) status = OBTG_MD_DEPTH_CAP;
+                else {
+                    const int pos = atomicAdd(&s_count, 2);
+                    if (pos + 2 <= p.cap) {
+                        const double h = 0.5 * w;
+                        fb[2 * pos] = t; fb[2 * pos + 1] = (double)(lev + 1);
+                        fb[2 * pos + 2] = t + h; fb[2 * pos + 3] = (double)(lev + 1);
+                    } else status = OBTG_MD_NODE_CAP;
+                }
+            }
+        }
+        nodes += n_a;
+        levels++;
+        __syncthreads();
+        const unsigned long long capped = __ballot(status != OBTG_MD_OK);
+        if (capped) { status = __shfl(status, __ffsll((long long)capped) - 1); break; }
+        n_a = min(s_count, p.cap);
+        if (n_a > front_max) front_max = n_a;
+        if (nodes + n_a > p.max_nodes && n_a > 0) { status = OBTG_MD_NODE_CAP; break; }
+        double* tsw = fa; fa = fb; fb = tsw;
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+        __syncthreads();
+    }
+    if (lane == 0) {
+        double* o = p.res + 5 * (size_t)k;
+        o[0] = alpha; o[1] = bt; o[2] = bx; o[3] = by; o[4] = bz;
+        if (p.info) { p.info[4 * k] = nodes; p.info[4 * k + 1] = levels; p.info[4 * k + 2] = front_max; p.info[4 * k + 3] = status; }
+    }
+}
+
 // frame layout for the polygon form: c1[3K] then scalars
 enum { G_T1 = 0, G_T1L, G_T1H, G_ALPHA, G_RT1, G_PX, G_PY, G_PZ, G_STATE, G_NSCAL };
 
@@ -2273,6 +2464,36 @@ int launch_min_dist_robust(obtg_ctx* c, const double* d_curves, int K, const int
     const size_t lds = sizeof(double) * ((size_t)6 * K + (size_t)kWave * ((3 * K) | 1));
     ScopedKernelTimer t(c, OBTG_K_MIN_DIST);
     hipLaunchKernelGGL(k_min_dist_robust, dim3((unsigned)n_pairs), dim3(kWave), lds, c->stream, p);
+    OBTG_HIP(c, hipGetLastError());
+    return OBTG_OK;
+}
+
+int launch_gjk_true_pairs(obtg_ctx* c, const double* d_soa, const int* d_off, const int* d_pa, const int* d_pb, int n_pairs,
+                          double eps, int max_iter, int* d_flag, double* d_p1, double* d_p2, double* d_dist, double* d_lower,
+                          int* d_iters, int* d_status)
+{
+    if (n_pairs <= 0) return OBTG_OK;
+    GjkTrueParams p{ d_soa, d_off, d_pa, d_pb, n_pairs, max_iter, eps, d_flag, d_p1, d_p2, d_dist, d_lower, d_iters, d_status };
+    ScopedKernelTimer t(c, OBTG_K_GJK);
+    hipLaunchKernelGGL(k_gjk_true_pairs, dim3((n_pairs + 255) / 256), dim3(256), 0, c->stream, p);
+    OBTG_HIP(c, hipGetLastError());
+    return OBTG_OK;
+}
+
+int launch_min_dist2poly_robust(obtg_ctx* c, const double* d_curves, int K, const double* d_soa, const int* d_off,
+                                const int* d_pc, const int* d_pp, int n_pairs, double eps, int max_nodes, int max_level,
+                                int cap, int max_poly_K, double* d_frontier, double* d_res, int* d_info)
+{
+    if (n_pairs <= 0) return OBTG_OK;
+    if (K < 2 || K > kMdMaxK || max_poly_K > 4 * kMdMaxK || cap < 2 || max_level < 1 || max_level > 50) return OBTG_ERR_UNSUPPORTED;
+    Md2rParams p{ d_curves, d_soa, d_off, d_pc, d_pp, n_pairs, K, max_nodes, max_level, cap, eps, d_frontier, d_res, d_info };
+    const size_t lds = sizeof(double) * ((size_t)3 * K + (size_t)3 * max_poly_K + (size_t)kWave * ((3 * K) | 1));
+    if (lds > 64 * 1024) return OBTG_ERR_UNSUPPORTED;
+    if (lds > 48 * 1024)
+        OBTG_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_min_dist2poly_robust),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    ScopedKernelTimer t(c, OBTG_K_MIN_DIST);
+    hipLaunchKernelGGL(k_min_dist2poly_robust, dim3((unsigned)n_pairs), dim3(kWave), lds, c->stream, p);
     OBTG_HIP(c, hipGetLastError());
     return OBTG_OK;
 }

@@ -169,6 +169,12 @@ int launch_min_dist2poly(obtg_ctx* c, const double* d_curves, int K, const doubl
                          const int* d_off, const int* d_pc, const int* d_pp, int n_pairs, double eps,
                          int max_iter, int md_cap, int max_depth, int max_nodes, double* d_stack,
                          double* d_res, int* d_info, int max_poly_K);
+int launch_gjk_true_pairs(obtg_ctx* c, const double* d_soa, const int* d_off, const int* d_pa, const int* d_pb, int n_pairs,
+                          double eps, int max_iter, int* d_flag, double* d_p1, double* d_p2, double* d_dist, double* d_lower,
+                          int* d_iters, int* d_status);
+int launch_min_dist2poly_robust(obtg_ctx* c, const double* d_curves, int K, const double* d_soa, const int* d_off,
+                                const int* d_pc, const int* d_pp, int n_pairs, double eps, int max_nodes, int max_level,
+                                int cap, int max_poly_K, double* d_frontier, double* d_res, int* d_info);
 size_t min_dist_stack_doubles(int K, int max_depth);
 size_t min_dist2poly_stack_doubles(int K, int max_depth);
 
