@@ -122,7 +122,7 @@ def algorithmic_bytes(N, d, n, R, P_t, P_s, sumK):
         "speed": 8 * N * d * (n + 1) + 8 * N * L,
         "ang_rate": 8 * N * d * (n + 1) + 8 * N * (4 * (n + R) + 1),
         "gjk": 24 * sumK + 64 * P_s,
-        "fd_batch": 2 * 8 * N * d * (n + 1),
+        "fd_batch": 8 * N * d * (n + 1),      # one row written per evaluation (the one source row stays in cache)
     }
     # the survey's per-eval total counts the control points once
     total = 8 * N * d * (n + 1) + 8 * (P_t * L + N * L + N * (4 * (n + R) + 1)) + 24 * sumK + 64 * P_s

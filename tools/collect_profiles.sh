@@ -1,6 +1,6 @@
 #!/bin/bash
 # Collect the judged evidence for one round on the GPU box (run through gpurun):
-#   tools/collect_profiles.sh r01_d
+#   tools/collect_profiles.sh r02_a
 # Writes gpurun_out/<tag>/{stats,fetch,write}/ + bench lines; tools/parse_profiles.py then copies
 # the summaries into profiles/ (run that in the container after gpurun merged gpurun_out/ back).
 set -e -o pipefail
@@ -12,9 +12,17 @@ python3 bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err
 echo "default bench done" > $OUT/progress.log
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o run -- python3 bench.py --no-cpu > $OUT/bench_stats.json 2> $OUT/stats.err
 echo "kernel stats done" >> $OUT/progress.log
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_2s -o run -- python3 bench.py --no-cpu --streams 2 > $OUT/bench_stats_2s.json 2> $OUT/stats_2s.err
+echo "two-stream stats done" >> $OUT/progress.log
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_dedup -o run -- python3 bench.py --no-cpu --fd-dedup > $OUT/bench_stats_dedup.json 2> $OUT/stats_dedup.err
 echo "dedup stats done" >> $OUT/progress.log
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -o run -- python3 bench.py --steps 3 --warmup 1 --no-cpu > $OUT/bench_fetch.json 2> $OUT/fetch.err
 echo "fetch pmc done" >> $OUT/progress.log
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/write -o run -- python3 bench.py --steps 3 --warmup 1 --no-cpu > $OUT/bench_write.json 2> $OUT/write.err
 echo "write pmc done" >> $OUT/progress.log
+# C5: its own stats + traffic passes (different dominant kernel)
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_c5 -o run -- python3 bench.py --no-cpu --workload C5 --steps 50 --warmup 5 > $OUT/bench_stats_c5.json 2> $OUT/stats_c5.err
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/fetch_c5 -o run -- python3 bench.py --workload C5 --steps 3 --warmup 1 --no-cpu > $OUT/bench_fetch_c5.json 2> $OUT/fetch_c5.err
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/write_c5 -o run -- python3 bench.py --workload C5 --steps 3 --warmup 1 --no-cpu > $OUT/bench_write_c5.json 2> $OUT/write_c5.err
+echo "c5 done" >> $OUT/progress.log
+cat $OUT/progress.log

@@ -32,31 +32,34 @@ def main():
     workload = sys.argv[sys.argv.index("--workload") + 1] if "--workload" in sys.argv else "C3"
     src = os.path.join(REPO, "gpurun_out", tag)
     dst = os.path.join(REPO, "profiles")
-    for sub, name in (("stats", f"{tag}_kernel_stats.csv"), ("stats_dedup", f"{tag}_fd_dedup_kernel_stats.csv")):
+    for sub, name in (("stats", f"{tag}_kernel_stats.csv"), ("stats_dedup", f"{tag}_fd_dedup_kernel_stats.csv"),
+                      ("stats_2s", f"{tag}_two_streams_kernel_stats.csv"), ("stats_c5", f"{tag}_C5_kernel_stats.csv")):
         hits = glob.glob(os.path.join(src, sub, "**", "*kernel_stats.csv"), recursive=True)
         if hits:
             shutil.copy(hits[0], os.path.join(dst, name))
-    for a, b in (("bench_stats.json", f"{tag}_bench.json"), ("bench_default.json", f"{tag}_bench_with_cpu_baseline.json")):
+    for a, b in (("bench_stats.json", f"{tag}_bench.json"), ("bench_default.json", f"{tag}_bench_with_cpu_baseline.json"),
+                 ("bench_stats_2s.json", f"{tag}_two_streams_bench.json"), ("bench_stats_c5.json", f"{tag}_C5_bench.json")):
         if os.path.exists(os.path.join(src, a)):
             shutil.copy(os.path.join(src, a), os.path.join(dst, b))
-    fetch = pmc_mean(os.path.join(src, "fetch"), "FETCH_SIZE")
-    write = pmc_mean(os.path.join(src, "write"), "WRITE_SIZE")
     tpath = os.path.join(dst, "traffic.json")
     traffic = json.load(open(tpath)) if os.path.exists(tpath) else {}
-    per, detail = {}, {}
-    for fam, needle in FAMILY:
-        for k in fetch:
-            if needle in k and k in write and fam not in per:
-                b = int(round((2.0 * fetch[k] + write[k]) * 1024))
-                per[fam] = b
-                detail[fam] = dict(kernel=k, FETCH_SIZE_KB=round(fetch[k], 1), WRITE_SIZE_KB=round(write[k], 1),
-                                   hbm_bytes_per_launch=b)
-    if per:
-        traffic[workload] = per
-        traffic.setdefault("_detail", {})[workload] = detail
-        traffic["_source"] = tag
-        json.dump(traffic, open(tpath, "w"), indent=1)
-    print(json.dumps(detail, indent=1))
+    for wl, suffix in ((workload, ""), ("C5", "_c5")):
+        fetch = pmc_mean(os.path.join(src, "fetch" + suffix), "FETCH_SIZE")
+        write = pmc_mean(os.path.join(src, "write" + suffix), "WRITE_SIZE")
+        per, detail = {}, {}
+        for fam, needle in FAMILY:
+            for k in fetch:
+                if needle in k and k in write and fam not in per:
+                    b = int(round((2.0 * fetch[k] + write[k]) * 1024))
+                    per[fam] = b
+                    detail[fam] = dict(kernel=k, FETCH_SIZE_KB=round(fetch[k], 1), WRITE_SIZE_KB=round(write[k], 1),
+                                       hbm_bytes_per_launch=b)
+        if per:
+            traffic[wl] = per
+            traffic.setdefault("_detail", {})[wl] = detail
+            traffic["_source"] = tag
+        print(wl, json.dumps(detail, indent=1))
+    json.dump(traffic, open(tpath, "w"), indent=1)
 
 
 if __name__ == "__main__":
