@@ -76,6 +76,9 @@ def parse():
                          "kernel alone; 2: the dynamics launch (speed + angular rate, latency bound) runs on a second HIP "
                          "stream beside the pair sweep (VALU bound) -- about 5 %% more evals/s, but the sweep's measured "
                          "duration then includes the co-running launch")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="rehearsal: initialise torch.distributed and run the collectives even with one rank "
+                         "(exercises the RCCL path on a one-GPU box)")
     ap.add_argument("--one-device", action="store_true",
                     help="rehearsal only: every rank uses device 0 (needs --backend gloo)")
     return ap.parse_args()
@@ -172,8 +175,12 @@ def main():
     if args.one_device:
         local_rank = 0
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29517")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         if args.backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
@@ -213,11 +220,11 @@ def main():
     ctx.fd_batch_dev(d0.data_ptr(), 1, synth.FD_STEP, B, dY.data_ptr())     # inputs resident in HBM
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
 
     if args.mode == "pairs":
-        return pairs_mode(args, ctx, dist, world, rank, dev, dY, B, max_sep, barrier, pa, pb, use_gjk)
+        return pairs_mode(args, ctx, dist, world, rank, dev, dY, B, max_sep, barrier, pa, pb, use_gjk, use_dist)
 
     d_tf = torch.full((B,), tfv, dtype=f64, device=dev)
     o_sep = torch.empty((B, P_t * L), dtype=f64, device=dev)
@@ -310,7 +317,7 @@ def main():
     barrier()
     t1 = time.perf_counter()
     elapsed = t1 - t0
-    if world > 1:
+    if use_dist:
         tt = torch.tensor([elapsed], dtype=f64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
@@ -406,7 +413,7 @@ def main():
         }
         print(json.dumps(line))
         sys.stdout.flush()
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
     if parity is not None and not parity["ok"]:
         raise SystemExit("bench.py: the timed step's device buffers DISAGREE with the oracle: %s" % json.dumps(parity))
@@ -461,7 +468,7 @@ def parity_check(dev_out, N, d, n, R, statics, pa, pb, use_gjk, max_sep, vmax, w
             "against": "oracle/obtg_oracle.c on the device's own FD rows; buffers of the LAST timed step"}
 
 
-def pairs_mode(args, ctx, dist, world, rank, dev, dY, B, max_sep, barrier, pa, pb, use_gjk):
+def pairs_mode(args, ctx, dist, world, rank, dev, dY, B, max_sep, barrier, pa, pb, use_gjk, use_dist=False):
     """Pair-partitioned evaluation of ONE batch (same swarm on every rank): each rank sweeps a contiguous block of
     the lexicographic temporal-separation pair list and of the gjkNew hull pair list; ONE all-gather returns the
     per-pair separation minima and gjkNew's (dist, flag) to every rank."""
@@ -476,7 +483,7 @@ def pairs_mode(args, ctx, dist, world, rank, dev, dY, B, max_sep, barrier, pa, p
         parts = [(evaluate(*sweep.my_block), sweep.blocks, 1)]
         if hull is not None:
             parts += hull.parts(dY, B)
-        return all_gather_pair_blocks(parts)
+        return all_gather_pair_blocks(parts, force=args.force_dist)
 
     for _ in range(max(args.warmup, 1)):
         out = step()
@@ -488,7 +495,7 @@ def pairs_mode(args, ctx, dist, world, rank, dev, dY, B, max_sep, barrier, pa, p
     torch.cuda.synchronize()
     barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
@@ -507,7 +514,7 @@ def pairs_mode(args, ctx, dist, world, rank, dev, dY, B, max_sep, barrier, pa, p
             "config": {"workload": "%s: %d temporal-separation pairs + %d gjkNew hull pairs split over %d ranks, "
                                    "B=%d rows" % (args.workload, ctx.num_pairs, len(pa) if use_gjk else 0, world, B),
                        "checksum": chk}}))
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

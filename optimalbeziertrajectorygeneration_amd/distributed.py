@@ -46,7 +46,7 @@ def _world_rank(group=None):
     return 1, 0
 
 
-def all_gather_pair_blocks(parts, group=None):
+def all_gather_pair_blocks(parts, group=None, force=False):
     """ONE all-gather for several partitioned results.
 
     parts: list of (mine, blocks, width): `mine` is this rank's tensor [B, count_r*width] (any
@@ -55,7 +55,7 @@ def all_gather_pair_blocks(parts, group=None):
     that every segment stays aligned) and exchanged with a single `all_gather_into_tensor`;
     returns the assembled [B, n_pairs*width] tensors, identical on every rank."""
     world, rank = _world_rank(group)
-    if world == 1:
+    if world == 1 and not (force and dist.is_initialized()):      # force: run the collective even alone (rehearsals)
         return [p[0] for p in parts]
     order = sorted(range(len(parts)), key=lambda i: -parts[i][0].element_size())
     segs, meta = [], []

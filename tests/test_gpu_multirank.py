@@ -94,3 +94,15 @@ def test_bench_pairs_mode_two_ranks_equals_one_rank():
     c1, c2 = one["config"]["checksum"], two["config"]["checksum"]
     assert c1["gjk_flag_sum"] == c2["gjk_flag_sum"]
     assert c1["sep_min_sum"] == c2["sep_min_sum"] and c1["gjk_dist_nansum"] == c2["gjk_dist_nansum"]
+
+
+def test_rccl_path_with_one_rank():
+    """The backend the multi-GPU runs use (`nccl` == RCCL), exercised on the one-GPU box: process-group init with a device
+    id, barrier, the MAX all-reduce of the timing and -- in pairs mode -- the packed all-gather on device tensors, with a
+    single rank (`--force-dist`).  Same checksums as the run without torch.distributed."""
+    args = ["--mode", "pairs", "--workload", "C3", "--batch", "9", "--steps", "2", "--warmup", "1", "--no-cpu"]
+    plain = _bench(["--gpus", "1"] + args)
+    rccl = _bench(["--gpus", "1", "--force-dist", "--backend", "nccl"] + args)
+    assert plain["config"]["checksum"] == rccl["config"]["checksum"]
+    line = _bench(["--gpus", "1", "--force-dist", "--backend", "nccl", "--steps", "4", "--warmup", "2", "--no-cpu", "--workload", "C2"])
+    assert line["n_gpus"] == 1 and line["value"] > 0
