@@ -36,7 +36,7 @@ def solve(numVeh=5, with_jac=True, maxiter=400, separationRows='all'):
         con['jac'] = bezopt.temporalSeparationJacobian
     t0 = time.time()
     res = sop.minimize(bezopt.objectiveFunction, x0=x0, method='SLSQP', constraints=[con],
-                       options={'maxiter': maxiter, 'disp': False})
+                       jac=bezopt.objectiveGradient if with_jac else None, options={'maxiter': maxiter, 'disp': False})
     return bezopt, res, time.time() - t0
 
 

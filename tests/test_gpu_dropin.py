@@ -121,6 +121,22 @@ def test_batched_jacobian_equals_scipy_fd(P):
         assert np.allclose(J, J_ref, rtol=0, atol=2e-6 * max(1.0, np.abs(J_ref).max()))
 
 
+def test_objective_gradient_equals_scipy_fd(P):
+    """objectiveGradient: SciPy's 2-point gradient of objectiveFunction from one batched evaluation."""
+    from scipy.optimize._numdiff import approx_derivative
+    from optimalbeziertrajectorygeneration_amd.optimization import BezOptimization
+    rng = np.random.default_rng(2)
+    for goal in ('Euclidean', 'Accel', 'Jerk', 'TimeOpt'):
+        kw = dict(initSpeeds=[1, 2, 0.5], finalSpeeds=[1, 1, 2], initAngs=[0.1, -0.4, 2.0], finalAngs=[0.3, 0.0, 2.5]) \
+            if goal == 'TimeOpt' else {}
+        bo = BezOptimization(numVeh=3, dimension=2, degree=7, minimizeGoal=goal, initPoints=[(0, 0), (1, 5), (9, 2)],
+                             finalPoints=[(10, 1), (8, 8), (0, 7)], tf=7.0, **kw)
+        x = bo.generateGuess(std=0.4, seed=11)
+        g = bo.objectiveGradient(x)
+        ref = approx_derivative(bo.objectiveFunction, x, method='2-point', abs_step=1.4901161193847656e-08)
+        assert g.shape == x.shape and np.allclose(g, ref, rtol=0, atol=2e-6 * max(1.0, np.abs(ref).max())), goal
+
+
 def test_slsqp_driver_converges_to_reference_solution():
     """Example1's driver with only the import lines changed (Examples/Example1_DubinsCarTimeOptimal.py
     :128-148): tf* = 2.427643189 with DEG_ELEV 0 under SciPy 1.15."""

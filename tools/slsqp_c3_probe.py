@@ -67,10 +67,11 @@ def main():
         return
     cons = [{'type': 'ineq', 'fun': funs[k], 'jac': jacs[k]} for k, _, _ in fams]
     stamps = [time.perf_counter()]
-    res = sop.minimize(obj, x0=x0, method='SLSQP', constraints=cons, callback=lambda xk: stamps.append(time.perf_counter()),
+    grad = Timed(bo.objectiveGradient)
+    res = sop.minimize(obj, x0=x0, jac=grad, method='SLSQP', constraints=cons, callback=lambda xk: stamps.append(time.perf_counter()),
                        options={'maxiter': args.iters, 'disp': False})
     total = time.perf_counter() - stamps[0]
-    t_cb = sum(t.t for t in funs.values()) + sum(t.t for t in jacs.values()) + obj.t
+    t_cb = sum(t.t for t in funs.values()) + sum(t.t for t in jacs.values()) + obj.t + grad.t
     its = max(1, len(stamps) - 1)
     out.update({"iterations": int(res.nit), "status": int(res.status), "message": str(res.message),
                 "total_s": total, "s_per_iteration": total / its,
