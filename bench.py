@@ -238,10 +238,12 @@ def main():
         g_stat = torch.empty((B, P_s), dtype=torch.int32, device=dev)
 
     one_launch = use_gjk and not args.separate   # the N x N pair sweeps (temporal separation + gjkNew) as one grid
-    # B0, the FD batch of this SLSQP iteration: formed from x's control points INSIDE the sweeps while they stage their
-    # rows (obtg_*_fd_dev) when both launches of the step have that form, else written to HBM by obtg_fd_batch_dev
+    # B0, the FD batch of this SLSQP iteration: never written when every sweep of the step can form its rows while it
+    # stages them -- an obtg_fd_view over x's control points, the sweeps called with dY = NULL; kernels without that
+    # form make the library write the batch once per step (what --materialise forces for all of them)
     fly_sweep, fly_dyn = ctx.fd_forms_on_the_fly()
-    on_the_fly = one_launch and o_an is not None and fly_sweep and fly_dyn and not args.materialise and B <= n_x + 1
+    use_view = not args.materialise and B <= n_x + 1
+    on_the_fly = use_view and one_launch and o_an is not None and fly_sweep and fly_dyn      # two launches, nothing written
     # the dynamics launch is latency bound (one or two wavefronts per SIMD), the pair sweep VALU bound: on two streams
     # the first hides under the second.  A context owns one stream, so the dynamics launch gets a context of its own.
     two_streams = args.streams == 2 and on_the_fly
@@ -250,27 +252,31 @@ def main():
         stream2 = torch.cuda.Stream(device=dev)
         ctx_dyn = _capi.Context(N, d, n, R, device=local_rank)
         ctx_dyn.set_stream(stream2.cuda_stream)
+    Yp = None if use_view else dY.data_ptr()
 
-    def step():
-        if on_the_fly:
-            ctx_dyn.dynamics_fd_dev(d0.data_ptr(), 1, synth.FD_STEP, d_tf.data_ptr(), B, vmax, True, wmax,
-                                    o_sp.data_ptr(), o_an.data_ptr())
-            ctx.pair_sweep_fd_dev(d0.data_ptr(), 1, synth.FD_STEP, B, max_sep, o_sep.data_ptr(), g_flag.data_ptr(),
-                                  g_p1.data_ptr(), g_p2.data_ptr(), g_dist.data_ptr(), None, g_stat.data_ptr(), 128, 256)
-            return
-        ctx.fd_batch_dev(d0.data_ptr(), 1, synth.FD_STEP, B, dY.data_ptr())
+    def sweeps():
         if one_launch:
-            ctx.pair_sweep_dev(dY.data_ptr(), B, max_sep, o_sep.data_ptr(), g_flag.data_ptr(), g_p1.data_ptr(),
+            ctx.pair_sweep_dev(Yp, B, max_sep, o_sep.data_ptr(), g_flag.data_ptr(), g_p1.data_ptr(),
                                g_p2.data_ptr(), g_dist.data_ptr(), None, g_stat.data_ptr(), 128, 256)
         else:
-            ctx.temporal_sep_dev(dY.data_ptr(), B, max_sep, o_sep.data_ptr())
+            ctx.temporal_sep_dev(Yp, B, max_sep, o_sep.data_ptr())
         if o_an is not None:    # speed + angular rate share their derivative curves: one launch
-            ctx.dynamics_dev(dY.data_ptr(), d_tf.data_ptr(), B, vmax, True, wmax, o_sp.data_ptr(), o_an.data_ptr())
+            ctx_dyn.dynamics_dev(Yp, d_tf.data_ptr(), B, vmax, True, wmax, o_sp.data_ptr(), o_an.data_ptr())
         else:
-            ctx.speed_dev(dY.data_ptr(), d_tf.data_ptr(), B, vmax, True, o_sp.data_ptr())
+            ctx.speed_dev(Yp, d_tf.data_ptr(), B, vmax, True, o_sp.data_ptr())
         if use_gjk and not one_launch:
-            ctx.gjk_swarm_dev(dY.data_ptr(), B, g_flag.data_ptr(), g_p1.data_ptr(), g_p2.data_ptr(),
+            ctx.gjk_swarm_dev(Yp, B, g_flag.data_ptr(), g_p1.data_ptr(), g_p2.data_ptr(),
                               g_dist.data_ptr(), None, g_stat.data_ptr(), 128, 256)
+
+    def step():
+        if not use_view:
+            ctx.fd_batch_dev(d0.data_ptr(), 1, synth.FD_STEP, B, dY.data_ptr())
+            return sweeps()
+        for cx in ([ctx, ctx_dyn] if ctx_dyn is not ctx else [ctx]):
+            cx.fd_view_begin(d0.data_ptr(), 1, synth.FD_STEP, B)
+        sweeps()
+        for cx in ([ctx, ctx_dyn] if ctx_dyn is not ctx else [ctx]):
+            cx.fd_view_end()
 
     # spin-up: the clocks of an idle MI355X need a few hundred ms of work to settle (at C3 a step reads 0.257 ms
     # straight after start and 0.205 ms once they have); untimed, before the W warm-up steps
@@ -400,9 +406,11 @@ def main():
                                    "temporal_sep(%d pairs)+max_speed+%sgjkNew(%d hull pairs)" % (
                                        args.workload, N, d, n, R, obst, B,
                                        "formed from x's control points inside the sweeps" if on_the_fly
-                                       else "written to HBM by obtg_fd_batch_dev each step", P_t,
+                                       else ("a view over x's control points: formed inside the sweeps that can, written "
+                                             "once per step for the others" if use_view
+                                             else "written to HBM by obtg_fd_batch_dev each step"), P_t,
                                        "max_ang_rate+" if d == 2 else "", P_s),
-                       "launches_per_step": 2 if on_the_fly else len([k for k in kernels]), "streams": 2 if two_streams else 1,
+                       "launches_per_step": len(kernels), "streams": 2 if two_streams else 1,
                        "evals_per_step_per_gpu": B, "alg_bytes_per_eval": total_bytes,
                        "gjk_fd_dedup": bool(args.fd_dedup), "gjk_status_nonok_last_step": status_nonok},
             "roofline": roofline,

@@ -176,12 +176,16 @@ int obtg_dynamics_dev(obtg_ctx*, const double* dY, const double* d_tf, int B, do
  * columns).  B <= N*d*(n+1-2*n_fixed_cols) + 1. */
 int obtg_fd_batch_dev(obtg_ctx*, const double* dY0, int n_fixed_cols, double h, int B, double* dY);
 
-/* The same batch WITHOUT writing it: obtg_pair_sweep_dev / obtg_dynamics_dev on a virtual finite-difference batch.
- * dY0 is ONE evaluation row; evaluation row 0 is dY0 and row b >= 1 is dY0 with its (b-1)-th free control point
- * advanced by h -- bit for bit the rows obtg_fd_batch_dev(dY0, n_fixed_cols, h, B) writes -- formed while the kernels
- * stage their inputs, so that the B x 11 KB batch never travels through HBM and a step of an SLSQP iteration is
- * two launches.  Shapes whose kernels have no on-the-fly form (obtg_fd_forms_on_the_fly: bit 0 = pair sweep, bit 1 =
- * dynamics) materialise the batch in a context buffer first; results are identical either way. */
+/* The same batch WITHOUT writing it: a VIEW.  Between obtg_fd_view_begin and obtg_fd_view_end every `_dev` sweep
+ * (temporal_sep[_min], speed, ang_rate, dynamics, gjk_swarm, pair_sweep) may be called with dY = NULL and the view's B:
+ * it then evaluates the virtual batch whose row 0 is dY0 and whose row b >= 1 is dY0 with its (b-1)-th free control point
+ * advanced by h -- bit for bit the rows obtg_fd_batch_dev(dY0, n_fixed_cols, h, B) writes.  Kernels with an on-the-fly
+ * form build the rows while staging their inputs (the B x 11 KB batch never travels through HBM); for the others the
+ * batch is written to a context buffer, once per view.  Results are identical either way.  dY0 must stay valid until the
+ * view ends.  obtg_pair_sweep_fd_dev / obtg_dynamics_fd_dev are the one-call forms (a view around a single sweep);
+ * obtg_fd_forms_on_the_fly: bit 0 = the pair sweep is one launch forming its rows itself, bit 1 = the dynamics launch. */
+int obtg_fd_view_begin(obtg_ctx*, const double* dY0, int n_fixed_cols, double h, int B);
+int obtg_fd_view_end(obtg_ctx*);
 int obtg_fd_forms_on_the_fly(const obtg_ctx*);
 int obtg_pair_sweep_fd_dev(obtg_ctx*, const double* dY0, int n_fixed_cols, double h, int B, double max_sep,
                            double* d_out_sep, int max_iter, int md_cap, int* d_flag, double* d_p1, double* d_p2,

@@ -55,6 +55,8 @@ _SIGNATURES = {
     "obtg_ang_rate_dev": (_i, [_vp, _vp, _vp, _i, _d, _vp]),
     "obtg_dynamics_dev": (_i, [_vp, _vp, _vp, _i, _d, _i, _d, _vp, _vp]),
     "obtg_fd_batch_dev": (_i, [_vp, _vp, _i, _d, _i, _vp]),
+    "obtg_fd_view_begin": (_i, [_vp, _vp, _i, _d, _i]),
+    "obtg_fd_view_end": (_i, [_vp]),
     "obtg_fd_forms_on_the_fly": (_i, [_vp]),
     "obtg_pair_sweep_fd_dev": (_i, [_vp, _vp, _i, _d, _i, _d, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "obtg_dynamics_fd_dev": (_i, [_vp, _vp, _i, _d, _vp, _i, _d, _i, _d, _vp, _vp]),
@@ -377,6 +379,14 @@ class Context(object):
     def fd_batch_dev(self, dY0, n_fixed_cols, h, B, dY):
         self._check(self._lib.obtg_fd_batch_dev(self._h, _vp(dY0), int(n_fixed_cols), float(h), B, _vp(dY)),
                     "obtg_fd_batch_dev")
+
+    def fd_view_begin(self, dY0, n_fixed_cols, h, B):
+        """Open a virtual finite-difference batch over the ONE device row dY0 (include/obtg.h obtg_fd_view_begin): until
+        fd_view_end() the `_dev` sweeps take dY = None."""
+        self._check(self._lib.obtg_fd_view_begin(self._h, _vp(dY0), int(n_fixed_cols), float(h), int(B)), "obtg_fd_view_begin")
+
+    def fd_view_end(self):
+        self._check(self._lib.obtg_fd_view_end(self._h), "obtg_fd_view_end")
 
     def fd_forms_on_the_fly(self):
         """(pair sweep, dynamics): does the _fd_dev form build the finite-difference rows while staging them?"""

@@ -57,7 +57,17 @@ struct NsParams {
     int tiling;                       // 1: row-window tiles (large swarms), see k_normsq_elev
     const int2* __restrict__ tiles;   // [wgs_per_row] (first row, first column) of each tile
     double sign, offset;              // out = sign * value + offset
+    int fd, fd_fixed;                 // fd != 0: Y is ONE row; evaluation row b >= 1 = Y with its (b-1)-th free control point
+    double fd_h;                      //          advanced by fd_h (obtg_fd_batch_dev's rows), formed while staging
 };
+
+// element of an evaluation row [n_rows][nc] that row b of a virtual finite-difference batch advances (-1: none)
+__device__ __forceinline__ int fd_element(int fd, int fixed, int nc, int b)
+{
+    if (!fd || b <= 0) return -1;
+    const int free_cols = nc - 2 * fixed, kq = b - 1, pr = kq / free_cols;
+    return pr * nc + fixed + (kq - pr * free_cols);
+}
 
 constexpr int kTileK = 32;            // k-chunk of the transposition tile when R > 0
 
@@ -75,7 +85,7 @@ struct NsShape {
 template <int NC, int DIM>
 __device__ __forceinline__ void stage_objects(double* __restrict__ vl, const double* __restrict__ Yrow,
                                               const double* __restrict__ obs, int n_veh, int lo,
-                                              int cnt, int slot0, int tid, int nthreads)
+                                              int cnt, int slot0, int tid, int nthreads, int fd_e = -1, double fd_h = 0.0)
 {
     using S = NsShape<NC, DIM>;
     const int total = cnt * S::VLEN;
@@ -83,7 +93,7 @@ __device__ __forceinline__ void stage_objects(double* __restrict__ vl, const dou
         const int v = e / S::VLEN, r = e - v * S::VLEN;
         const int obj = lo + v;
         double val;
-        if (obj < n_veh) val = Yrow[(size_t)obj * S::VLEN + r];
+        if (obj < n_veh) { const int ee = obj * S::VLEN + r; val = Yrow[ee]; if (ee == fd_e) val += fd_h; }
         else val = obs[(obj - n_veh) * DIM + r / NC];   // constant curve (optimization.py:86-98)
         vl[(slot0 + v) * S::VP + r] = val;
     }
@@ -345,7 +355,8 @@ __device__ __forceinline__ void normsq_elev_body(const NsParams& p, const int b,
     double* tile = lds + p.stage_slots * S::VP + wave * (ELEV ? kWave * (S::L + kElevBlock + 1) : p.tile_rows * S::TPF);
 
     // ---- stage the objects this workgroup touches
-    const double* Yrow = p.Y + (size_t)b * p.n_veh * S::VLEN;
+    const double* Yrow = p.fd ? p.Y : p.Y + (size_t)b * p.n_veh * S::VLEN;
+    const int fd_e = fd_element(p.fd, p.fd_fixed, NC, b);
     // three staging schemes:
     //   stage_all  (small swarms): every object of the row, slot == object id;
     //   tiling     (large swarms): the workgroup owns rows ti0..ti0+groups_per_wg-1 of the pair
@@ -355,12 +366,12 @@ __device__ __forceinline__ void normsq_elev_body(const NsParams& p, const int b,
     //              j-range of its first row (segment A) and of the later rows (segment B).
     int i0 = 0, nI = 0, a_lo = 0, nA = 0, b_lo = 0, ti0 = 0, tj0 = 0;
     if (p.stage_all) {
-        stage_objects<NC, DIM>(vl, Yrow, p.obs, p.n_veh, 0, p.n_obj, 0, threadIdx.x, blockDim.x);
+        stage_objects<NC, DIM>(vl, Yrow, p.obs, p.n_veh, 0, p.n_obj, 0, threadIdx.x, blockDim.x, fd_e, p.fd_h);
     } else if (MODE == 0 && p.tiling) {
         const int2 t = p.tiles[w];
         ti0 = t.x; tj0 = t.y;
-        stage_objects<NC, DIM>(vl, Yrow, p.obs, p.n_veh, ti0, min(p.groups_per_wg, p.n_obj - ti0), 0, threadIdx.x, blockDim.x);
-        stage_objects<NC, DIM>(vl, Yrow, p.obs, p.n_veh, tj0, min(kWave, p.n_obj - tj0), p.groups_per_wg, threadIdx.x, blockDim.x);
+        stage_objects<NC, DIM>(vl, Yrow, p.obs, p.n_veh, ti0, min(p.groups_per_wg, p.n_obj - ti0), 0, threadIdx.x, blockDim.x, fd_e, p.fd_h);
+        stage_objects<NC, DIM>(vl, Yrow, p.obs, p.n_veh, tj0, min(kWave, p.n_obj - tj0), p.groups_per_wg, threadIdx.x, blockDim.x, fd_e, p.fd_h);
     } else if (MODE == 0) {
         const int2 f = p.pairs[it0], l = p.pairs[it_end - 1];
         i0 = f.x; nI = l.x - f.x + 1;
@@ -368,12 +379,12 @@ __device__ __forceinline__ void normsq_elev_body(const NsParams& p, const int b,
         nA = (nI == 1) ? (l.y - f.y + 1) : (p.n_obj - f.y);
         b_lo = i0 + 2;
         const int nB = (nI == 1) ? 0 : max(0, ((nI >= 3) ? p.n_obj - 1 : l.y) - b_lo + 1);
-        stage_objects<NC, DIM>(vl, Yrow, p.obs, p.n_veh, i0, nI, 0, threadIdx.x, blockDim.x);
-        stage_objects<NC, DIM>(vl, Yrow, p.obs, p.n_veh, a_lo, nA, nI, threadIdx.x, blockDim.x);
-        stage_objects<NC, DIM>(vl, Yrow, p.obs, p.n_veh, b_lo, nB, nI + nA, threadIdx.x, blockDim.x);
+        stage_objects<NC, DIM>(vl, Yrow, p.obs, p.n_veh, i0, nI, 0, threadIdx.x, blockDim.x, fd_e, p.fd_h);
+        stage_objects<NC, DIM>(vl, Yrow, p.obs, p.n_veh, a_lo, nA, nI, threadIdx.x, blockDim.x, fd_e, p.fd_h);
+        stage_objects<NC, DIM>(vl, Yrow, p.obs, p.n_veh, b_lo, nB, nI + nA, threadIdx.x, blockDim.x, fd_e, p.fd_h);
     } else {
         i0 = it0; nI = it_end - it0;
-        stage_objects<NC, DIM>(vl, Yrow, p.obs, p.n_veh, i0, nI, 0, threadIdx.x, blockDim.x);
+        stage_objects<NC, DIM>(vl, Yrow, p.obs, p.n_veh, i0, nI, 0, threadIdx.x, blockDim.x, fd_e, p.fd_h);
     }
     __syncthreads();
 

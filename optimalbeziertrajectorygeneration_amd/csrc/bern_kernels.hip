@@ -1167,10 +1167,12 @@ int launch_temporal_sep(obtg_ctx* c, const double* dY, int B, double max_sep, in
     if (rc != OBTG_OK && rc != OBTG_ERR_UNSUPPORTED) return rc;
     if (rc == OBTG_OK) {
         p.sign = 1.0; p.offset = -(max_sep * max_sep);
+        if (c->fd.Y0) { p.Y = c->fd.Y0; p.fd = 1; p.fd_fixed = c->fd.fixed; p.fd_h = c->fd.h; }
         rc = min_only ? dispatch_ns<0, true>(c, p, B, OBTG_K_TEMPORAL_SEP)
                       : dispatch_ns<0, false>(c, p, B, OBTG_K_TEMPORAL_SEP);
         if (rc != OBTG_ERR_UNSUPPORTED) return rc;
     }
+    if (c->fd.Y0) return kNeedBatch;          // the generic kernel reads its rows from memory
     GenParams g{};
     rc = gen_common(c, g);
     if (rc) return rc;
@@ -1205,9 +1207,11 @@ int launch_speed(obtg_ctx* c, const double* dY, const double* d_tf, int B, doubl
         p.stage_slots = std::min(c->n_veh, kWave);
         p.stage_all = 0; p.tiling = 0; p.tiles = nullptr;
         p.sign = is_max ? -1.0 : 1.0; p.offset = is_max ? b2 : -b2;
+        if (c->fd.Y0) { p.Y = c->fd.Y0; p.fd = 1; p.fd_fixed = c->fd.fixed; p.fd_h = c->fd.h; }
         rc = dispatch_ns<1, false>(c, p, B, OBTG_K_SPEED);
         if (rc != OBTG_ERR_UNSUPPORTED) return rc;
     }
+    if (c->fd.Y0) return kNeedBatch;
     GenParams g{};
     rc = gen_common(c, g);
     if (rc) return rc;
@@ -1361,6 +1365,7 @@ int launch_ang_rate(obtg_ctx* c, const double* dY, const double* d_tf, int B, do
     int rc = ensure_tables(c);
     if (rc) return rc;
     if (dyn_fast(c) || dyn_fast_elev(c)) return launch_dynamics(c, dY, d_tf, B, 0.0, 1, max_rate, nullptr, d_out);
+    if (c->fd.Y0) return kNeedBatch;
     GenParams g{};
     rc = gen_common(c, g);
     if (rc) return rc;

@@ -192,7 +192,7 @@ const char* obtg_abi_symbols(void)
         "obtg_temporal_sep\0obtg_speed\0obtg_ang_rate\0obtg_temporal_sep_min\0obtg_temporal_sep_min_range\0"
         "obtg_temporal_sep_fd\0obtg_temporal_sep_fd_dev\0"
         "obtg_temporal_sep_dev\0obtg_temporal_sep_min_dev\0obtg_speed_dev\0obtg_ang_rate_dev\0obtg_dynamics_dev\0"
-        "obtg_fd_batch_dev\0obtg_fd_forms_on_the_fly\0obtg_pair_sweep_fd_dev\0obtg_dynamics_fd_dev\0obtg_gjk_pairs\0obtg_ctx_set_polygons\0obtg_ctx_set_hull_pairs\0"
+        "obtg_fd_batch_dev\0obtg_fd_view_begin\0obtg_fd_view_end\0obtg_fd_forms_on_the_fly\0obtg_pair_sweep_fd_dev\0obtg_dynamics_fd_dev\0obtg_gjk_pairs\0obtg_ctx_set_polygons\0obtg_ctx_set_hull_pairs\0"
         "obtg_ctx_set_fd_dedup\0obtg_ctx_set_gjk_history\0obtg_pair_sweep_dev\0obtg_gjk_swarm_dev\0obtg_gjk_swarm\0obtg_min_dist\0obtg_min_dist_robust\0obtg_min_dist2poly\0obtg_min_dist2poly_robust\0obtg_gjk_true_pairs\0"
         "obtg_bern_elev\0obtg_bern_diff\0obtg_bern_mul\0obtg_bern_normsq\0obtg_bern_split\0"
         "obtg_euclidean_obj\0obtg_accel_obj\0obtg_jerk_obj\0"
@@ -312,57 +312,99 @@ int obtg_len_speed(const obtg_ctx* c) { return c ? c->n_veh * (2 * c->deg + c->R
 int obtg_len_ang_rate(const obtg_ctx* c) { return c ? c->n_veh * (4 * (c->deg + c->R) + 1) : 0; }
 int obtg_num_pairs(const obtg_ctx* c) { return c ? c->n_pairs : 0; }
 
-// ------------------------------------------------------------------ device-pointer sweeps
-int obtg_temporal_sep_dev(obtg_ctx* c, const double* dY, int B, double max_sep, int pair_begin,
-                          int pair_count, double* d_out)
-{
-    if (!check_ctx(c) || !dY || !d_out || B < 0) return OBTG_ERR_ARG;
-    if (pair_begin < 0 || pair_count < 0 || pair_begin + pair_count > c->n_pairs) return OBTG_ERR_ARG;
-    (void)hipSetDevice(c->device);
-    return launch_temporal_sep(c, dY, B, max_sep, pair_begin, pair_count, false, d_out);
-}
+// ------------------------------------------------------------------ virtual finite-difference batch
+// dY == NULL in a `_dev` sweep means "the batch of the open view" (obtg_fd_view_begin): the launcher gets the view's
+// single row with c->fd set; kernels that form the rows while staging them use it, the others answer kNeedBatch and
+// the batch is written to a context buffer -- once per view -- and handed over instead.
+static int fd_materialise(obtg_ctx* c, const double* dY0, int n_fixed_cols, double h, int B);
 
-int obtg_temporal_sep_min_dev(obtg_ctx* c, const double* dY, int B, double max_sep, int pair_begin,
-                              int pair_count, double* d_out)
+extern "C++" {
+template <class Launch>
+static int with_batch(obtg_ctx* c, const double* dY, int B, Launch launch)
 {
-    if (!check_ctx(c) || !dY || !d_out || B < 0) return OBTG_ERR_ARG;
-    if (pair_begin < 0 || pair_count < 0 || pair_begin + pair_count > c->n_pairs) return OBTG_ERR_ARG;
-    (void)hipSetDevice(c->device);
-    return launch_temporal_sep(c, dY, B, max_sep, pair_begin, pair_count, true, d_out);
+    if (dY) return launch(dY);
+    if (!c->view.Y0 || B != c->view.B) return OBTG_ERR_ARG;
+    int rc = kNeedBatch;
+    if (!c->view.materialised) {
+        c->fd.Y0 = c->view.Y0; c->fd.h = c->view.h; c->fd.fixed = c->view.fixed;
+        rc = launch(c->view.Y0);
+        c->fd.Y0 = nullptr;
+    }
+    if (rc != kNeedBatch) return rc;
+    if (!c->view.materialised) {
+        if ((rc = fd_materialise(c, c->view.Y0, c->view.fixed, c->view.h, c->view.B))) return rc;
+        c->view.materialised = true;
+    }
+    return launch(c->ws_fd.as<double>());
 }
+}  // extern "C++"
 
-int obtg_speed_dev(obtg_ctx* c, const double* dY, const double* d_tf, int B, double bound, int is_max,
-                   double* d_out)
-{
-    if (!check_ctx(c) || !dY || !d_tf || !d_out || B < 0) return OBTG_ERR_ARG;
-    (void)hipSetDevice(c->device);
-    return launch_speed(c, dY, d_tf, B, bound, is_max, d_out);
-}
-
-int obtg_ang_rate_dev(obtg_ctx* c, const double* dY, const double* d_tf, int B, double max_rate, double* d_out)
-{
-    if (!check_ctx(c) || !dY || !d_tf || !d_out || B < 0) return OBTG_ERR_ARG;
-    (void)hipSetDevice(c->device);
-    return launch_ang_rate(c, dY, d_tf, B, max_rate, d_out);
-}
-
-int obtg_dynamics_dev(obtg_ctx* c, const double* dY, const double* d_tf, int B, double speed_bound,
-                      int speed_is_max, double max_rate, double* d_out_speed, double* d_out_ang)
-{
-    if (!check_ctx(c) || !dY || !d_tf || B < 0 || (!d_out_speed && !d_out_ang)) return OBTG_ERR_ARG;
-    (void)hipSetDevice(c->device);
-    return launch_dynamics(c, dY, d_tf, B, speed_bound, speed_is_max, max_rate, d_out_speed, d_out_ang);
-}
-
-// The finite-difference batch without ever writing it: the sweeps below take ONE row of control points and form row
-// b >= 1 (that row with its (b-1)-th free control point advanced by h) while staging it.  Shapes whose kernels
-// have no on-the-fly form get the batch materialised in a context buffer first -- same results either way.
 static int fd_args_ok(const obtg_ctx* c, int n_fixed_cols, int B)
 {
     const int rows = c->n_veh * c->dim, nc = c->deg + 1;
     if (n_fixed_cols < 0 || nc - 2 * n_fixed_cols <= 0) return OBTG_ERR_ARG;
     if (B < 1 || B > rows * (nc - 2 * n_fixed_cols) + 1) return OBTG_ERR_ARG;
     return OBTG_OK;
+}
+
+int obtg_fd_view_begin(obtg_ctx* c, const double* dY0, int n_fixed_cols, double h, int B)
+{
+    if (!check_ctx(c) || !dY0) return OBTG_ERR_ARG;
+    if (int rc = fd_args_ok(c, n_fixed_cols, B)) return rc;
+    c->view.Y0 = dY0; c->view.h = h; c->view.fixed = n_fixed_cols; c->view.B = B; c->view.materialised = false;
+    return OBTG_OK;
+}
+
+int obtg_fd_view_end(obtg_ctx* c)
+{
+    if (!check_ctx(c)) return OBTG_ERR_ARG;
+    c->view.Y0 = nullptr; c->view.B = 0; c->view.materialised = false;
+    return OBTG_OK;
+}
+
+// ------------------------------------------------------------------ device-pointer sweeps
+int obtg_temporal_sep_dev(obtg_ctx* c, const double* dY, int B, double max_sep, int pair_begin,
+                          int pair_count, double* d_out)
+{
+    if (!check_ctx(c) || !d_out || B < 0) return OBTG_ERR_ARG;
+    if (pair_begin < 0 || pair_count < 0 || pair_begin + pair_count > c->n_pairs) return OBTG_ERR_ARG;
+    (void)hipSetDevice(c->device);
+    return with_batch(c, dY, B, [&](const double* src) {
+        return launch_temporal_sep(c, src, B, max_sep, pair_begin, pair_count, false, d_out); });
+}
+
+int obtg_temporal_sep_min_dev(obtg_ctx* c, const double* dY, int B, double max_sep, int pair_begin,
+                              int pair_count, double* d_out)
+{
+    if (!check_ctx(c) || !d_out || B < 0) return OBTG_ERR_ARG;
+    if (pair_begin < 0 || pair_count < 0 || pair_begin + pair_count > c->n_pairs) return OBTG_ERR_ARG;
+    (void)hipSetDevice(c->device);
+    return with_batch(c, dY, B, [&](const double* src) {
+        return launch_temporal_sep(c, src, B, max_sep, pair_begin, pair_count, true, d_out); });
+}
+
+int obtg_speed_dev(obtg_ctx* c, const double* dY, const double* d_tf, int B, double bound, int is_max,
+                   double* d_out)
+{
+    if (!check_ctx(c) || !d_tf || !d_out || B < 0) return OBTG_ERR_ARG;
+    (void)hipSetDevice(c->device);
+    return with_batch(c, dY, B, [&](const double* src) { return launch_speed(c, src, d_tf, B, bound, is_max, d_out); });
+}
+
+int obtg_ang_rate_dev(obtg_ctx* c, const double* dY, const double* d_tf, int B, double max_rate, double* d_out)
+{
+    if (!check_ctx(c) || !d_tf || !d_out || B < 0) return OBTG_ERR_ARG;
+    (void)hipSetDevice(c->device);
+    return with_batch(c, dY, B, [&](const double* src) { return launch_ang_rate(c, src, d_tf, B, max_rate, d_out); });
+}
+
+int obtg_dynamics_dev(obtg_ctx* c, const double* dY, const double* d_tf, int B, double speed_bound,
+                      int speed_is_max, double max_rate, double* d_out_speed, double* d_out_ang)
+{
+    if (!check_ctx(c) || !d_tf || B < 0 || (!d_out_speed && !d_out_ang)) return OBTG_ERR_ARG;
+    (void)hipSetDevice(c->device);
+    return with_batch(c, dY, B, [&](const double* src) {
+        return launch_dynamics(c, src, d_tf, B, speed_bound, speed_is_max, max_rate, d_out_speed, d_out_ang); });
 }
 
 static int fd_materialise(obtg_ctx* c, const double* dY0, int n_fixed_cols, double h, int B)
@@ -378,39 +420,26 @@ int obtg_fd_forms_on_the_fly(const obtg_ctx* c)
     return (pair_sweep_is_one_launch(c) ? 1 : 0) | ((c->dim == 2 && dynamics_fd_on_the_fly(c, true)) ? 2 : 0);
 }
 
+// one-call forms: a view around a single sweep
 int obtg_pair_sweep_fd_dev(obtg_ctx* c, const double* dY0, int n_fixed_cols, double h, int B, double max_sep,
                            double* d_out_sep, int max_iter, int md_cap, int* d_flag, double* d_p1, double* d_p2,
                            double* d_dist, int* d_nsup, int* d_status)
 {
-    if (!check_ctx(c) || !dY0 || !d_out_sep || !d_flag || !d_p1 || !d_p2 || !d_dist || max_iter < 1 || md_cap < 1)
-        return OBTG_ERR_ARG;
-    if (!c->hull_pairs_set) return OBTG_ERR_ARG;
-    if (int rc = fd_args_ok(c, n_fixed_cols, B)) return rc;
-    (void)hipSetDevice(c->device);
-    c->fd.Y0 = dY0; c->fd.h = h; c->fd.fixed = n_fixed_cols;
-    int rc = launch_pair_sweep(c, dY0, B, max_sep, d_out_sep, max_iter, md_cap, d_flag, d_p1, d_p2, d_dist, d_nsup, d_status);
-    c->fd.Y0 = nullptr;
-    if (rc != OBTG_ERR_UNSUPPORTED) return rc;
-    if ((rc = fd_materialise(c, dY0, n_fixed_cols, h, B))) return rc;
-    return launch_pair_sweep(c, c->ws_fd.as<double>(), B, max_sep, d_out_sep, max_iter, md_cap, d_flag, d_p1, d_p2, d_dist,
-                             d_nsup, d_status);
+    int rc = obtg_fd_view_begin(c, dY0, n_fixed_cols, h, B);
+    if (rc) return rc;
+    rc = obtg_pair_sweep_dev(c, nullptr, B, max_sep, d_out_sep, max_iter, md_cap, d_flag, d_p1, d_p2, d_dist, d_nsup, d_status);
+    (void)obtg_fd_view_end(c);
+    return rc;
 }
 
 int obtg_dynamics_fd_dev(obtg_ctx* c, const double* dY0, int n_fixed_cols, double h, const double* d_tf, int B,
                          double speed_bound, int speed_is_max, double max_rate, double* d_out_speed, double* d_out_ang)
 {
-    if (!check_ctx(c) || !dY0 || !d_tf || (!d_out_speed && !d_out_ang)) return OBTG_ERR_ARG;
-    if (int rc = fd_args_ok(c, n_fixed_cols, B)) return rc;
-    (void)hipSetDevice(c->device);
-    if (int rc = ensure_tables(c)) return rc;
-    if (c->dim == 2 && dynamics_fd_on_the_fly(c, d_out_ang != nullptr)) {
-        c->fd.Y0 = dY0; c->fd.h = h; c->fd.fixed = n_fixed_cols;
-        const int rc = launch_dynamics(c, dY0, d_tf, B, speed_bound, speed_is_max, max_rate, d_out_speed, d_out_ang);
-        c->fd.Y0 = nullptr;
-        return rc;
-    }
-    if (int rc = fd_materialise(c, dY0, n_fixed_cols, h, B)) return rc;
-    return launch_dynamics(c, c->ws_fd.as<double>(), d_tf, B, speed_bound, speed_is_max, max_rate, d_out_speed, d_out_ang);
+    int rc = obtg_fd_view_begin(c, dY0, n_fixed_cols, h, B);
+    if (rc) return rc;
+    rc = obtg_dynamics_dev(c, nullptr, d_tf, B, speed_bound, speed_is_max, max_rate, d_out_speed, d_out_ang);
+    (void)obtg_fd_view_end(c);
+    return rc;
 }
 
 int obtg_fd_batch_dev(obtg_ctx* c, const double* dY0, int n_fixed_cols, double h, int B, double* dY)
@@ -848,12 +877,12 @@ int obtg_pair_sweep_dev(obtg_ctx* c, const double* dY, int B, double max_sep, do
                         int md_cap, int* d_flag, double* d_p1, double* d_p2, double* d_dist, int* d_nsup,
                         int* d_status)
 {
-    if (!check_ctx(c) || !dY || !d_out_sep || !d_flag || !d_p1 || !d_p2 || !d_dist || B < 0 || max_iter < 1 ||
+    if (!check_ctx(c) || !d_out_sep || !d_flag || !d_p1 || !d_p2 || !d_dist || B < 0 || max_iter < 1 ||
         md_cap < 1) return OBTG_ERR_ARG;
     if (!c->hull_pairs_set) return OBTG_ERR_ARG;   // no pair list registered (or invalidated by obtg_ctx_set_polygons)
     (void)hipSetDevice(c->device);
-    return launch_pair_sweep(c, dY, B, max_sep, d_out_sep, max_iter, md_cap, d_flag, d_p1, d_p2, d_dist, d_nsup,
-                             d_status);
+    return with_batch(c, dY, B, [&](const double* src) {
+        return launch_pair_sweep(c, src, B, max_sep, d_out_sep, max_iter, md_cap, d_flag, d_p1, d_p2, d_dist, d_nsup, d_status); });
 }
 
 int obtg_ctx_set_gjk_history(obtg_ctx* c, int on)
@@ -867,12 +896,13 @@ int obtg_ctx_set_gjk_history(obtg_ctx* c, int on)
 int obtg_gjk_swarm_dev(obtg_ctx* c, const double* dY, int B, int max_iter, int md_cap, int* d_flag,
                        double* d_p1, double* d_p2, double* d_dist, int* d_nsup, int* d_status)
 {
-    if (!check_ctx(c) || !dY || !d_flag || !d_p1 || !d_p2 || !d_dist || B < 0) return OBTG_ERR_ARG;
+    if (!check_ctx(c) || !d_flag || !d_p1 || !d_p2 || !d_dist || B < 0) return OBTG_ERR_ARG;
     if (max_iter < 1 || md_cap < 1) return OBTG_ERR_ARG;
     if (c->dim < 2) return OBTG_ERR_ARG;   // bezier.py:847-851: curves must be 2-D or 3-D
     if (!c->hull_pairs_set) return OBTG_ERR_ARG;   // no pair list registered (or invalidated by obtg_ctx_set_polygons)
     (void)hipSetDevice(c->device);
-    return launch_gjk_swarm(c, dY, B, max_iter, md_cap, d_flag, d_p1, d_p2, d_dist, d_nsup, d_status);
+    return with_batch(c, dY, B, [&](const double* src) {
+        return launch_gjk_swarm(c, src, B, max_iter, md_cap, d_flag, d_p1, d_p2, d_dist, d_nsup, d_status); });
 }
 
 int obtg_gjk_swarm(obtg_ctx* c, const double* Y, int B, int max_iter, int md_cap, int* flag, double* p1,

@@ -274,10 +274,12 @@ __global__ __launch_bounds__(256) void k_gjk_swarm(const GjkSwarmParams p)
     const int vlen = p.dim * p.nc;
     double* vl = lds;                        // [n_veh][vp]
     double* pl = lds + p.n_veh * p.vp;       // polygons, SoA, 3*n_poly_pts doubles
-    const double* Yrow = p.Y + (size_t)b * p.n_veh * vlen;
+    const double* Yrow = p.fd ? p.Y : p.Y + (size_t)b * p.n_veh * vlen;
+    const int fd_e = fd_element(p.fd, p.fd_fixed, p.nc, b);
     for (int e = threadIdx.x; e < p.n_veh * vlen; e += blockDim.x) {
         const int v = e / vlen, r = e - v * vlen;
-        vl[v * p.vp + r] = Yrow[e];
+        const double val = Yrow[e];
+        vl[v * p.vp + r] = (e == fd_e) ? val + p.fd_h : val;
     }
     for (int e = threadIdx.x; e < 3 * p.n_poly_pts; e += blockDim.x) pl[e] = p.poly[e];
     const int c0 = w * p.chunk, c1 = min(p.n_pairs, c0 + p.chunk);
@@ -444,11 +446,7 @@ __device__ __forceinline__ void gjk_planar_body(const GjkSwarmParams& p, double2
 
     // ---- stage vehicles (rows x, y of the evaluation row) and padded polygons
     const double* Yrow = p.fd ? p.Y : p.Y + (size_t)b * p.n_veh * 2 * NC;
-    int fd_e = -1;                       // element of the row that this evaluation row advances by fd_h
-    if (p.fd && b > 0) {
-        const int free_cols = NC - 2 * p.fd_fixed, kq = b - 1, pr = kq / free_cols;
-        fd_e = pr * NC + p.fd_fixed + (kq - pr * free_cols);
-    }
+    const int fd_e = fd_element(p.fd, p.fd_fixed, NC, b);   // element of the row that this evaluation row advances by fd_h
     // (rows x[NC], y[NC] in memory -> point-major (x, y) in LDS)
     if (TILED) {
         for (int e = threadIdx.x; e < n_obj * 2 * NC; e += blockDim.x) {
@@ -855,12 +853,13 @@ __global__ __launch_bounds__(256) void k_gjk_swarm_3d(const GjkSwarmParams p)
 
     // ---- stage: vehicles (rows x, y[, z] of the evaluation row) and padded polygons, point-major
     const int vlen = p.dim * NC;
-    const double* Yrow = p.Y + (size_t)b * p.n_veh * vlen;
+    const double* Yrow = p.fd ? p.Y : p.Y + (size_t)b * p.n_veh * vlen;
+    const int fd_e = fd_element(p.fd, p.fd_fixed, NC, b);
     for (int e = threadIdx.x; e < n_obj * 4 * NC; e += blockDim.x) {
         const int o = e / (4 * NC), r = e - o * (4 * NC), k = r >> 2, q = r & 3;
         double val = 0.0;
         if (o < p.n_veh) {
-            if (q < p.dim) val = Yrow[(size_t)o * vlen + q * NC + k];
+            if (q < p.dim) { const int ee = o * vlen + q * NC + k; val = Yrow[ee]; if (ee == fd_e) val += p.fd_h; }
         } else if (q < 3) {
             const int off = p.poly_off[o - p.n_veh], K = p.poly_off[o - p.n_veh + 1] - off;
             val = p.poly[3 * off + q * K + (k < K ? k : 0)];       // padded with copies of vertex 0
@@ -2066,6 +2065,10 @@ int launch_gjk_swarm(obtg_ctx* c, const double* dY, int B, int max_iter, int md_
     p.wgs_per_row = (c->n_hull_pairs + p.chunk - 1) / p.chunk;
     p.max_iter = max_iter; p.md_cap = md_cap;
     p.flag = d_flag; p.p1 = d_p1; p.p2 = d_p2; p.dist = d_dist; p.nsup = d_nsup; p.status = d_status;
+    if (c->fd.Y0) {
+        if (c->fd_dedup) return kNeedBatch;      // the de-duplication mask compares rows in memory
+        p.Y = c->fd.Y0; p.fd = 1; p.fd_fixed = c->fd.fixed; p.fd_h = c->fd.h;
+    }
     size_t lds = sizeof(double) * ((size_t)c->n_veh * p.vp + 3 * (size_t)c->n_poly_pts);
     if (lds > 160 * 1024 - 64) return OBTG_ERR_UNSUPPORTED;
     const bool planar = c->dim == 2 && c->polys_planar;
@@ -2289,8 +2292,7 @@ int launch_pair_sweep(obtg_ctx* c, const double* dY, int B, double max_sep, doub
         p.ts_tile_rows = tr;
         if (c->fd.Y0) { p.Y = c->fd.Y0; p.fd = 1; p.fd_fixed = c->fd.fixed; p.fd_h = c->fd.h; }
     }
-    if (!fused) {
-        if (c->fd.Y0) return OBTG_ERR_UNSUPPORTED;   // caller materialises the batch (pair_sweep_fd_on_the_fly)
+    if (!fused) {      // two launches; each forms the virtual batch's rows itself or asks for the batch (kNeedBatch)
         int rc = launch_temporal_sep(c, dY, B, max_sep, 0, c->n_pairs, false, d_out_sep);
         if (rc) return rc;
         return launch_gjk_swarm(c, dY, B, max_iter, md_cap, d_flag, d_p1, d_p2, d_dist, d_nsup, d_status);

@@ -10,6 +10,7 @@
 namespace obtg {
 
 constexpr int kWave = 64;
+constexpr int kNeedBatch = 1077;      // internal launcher result: "this kernel needs the finite-difference batch in memory"
 constexpr int kMaxGenericLen = 1024;  // longest Bernstein coefficient vector of the generic kernels
 
 // ---------------------------------------------------------------- host-side tables (tables.cpp)
@@ -82,8 +83,11 @@ struct obtg_ctx {
 
     // Virtual finite-difference batch (obtg_*_fd_dev): rows are formed on the fly from ONE row of control points,
     // row b >= 1 = Y0 with its (b-1)-th free control point advanced by h (exactly obtg_fd_batch_dev's rows).
+    // `fd` is set for the duration of ONE launcher call; launchers whose kernel cannot form the rows return
+    // obtg::kNeedBatch before launching anything and the caller materialises the batch (once per view) instead.
     struct FdView { const double* Y0 = nullptr; double h = 0.0; int fixed = 0; } fd;
-    obtg::DevBuf ws_fd;                   // materialised batch for shapes whose kernels have no on-the-fly form
+    struct { const double* Y0 = nullptr; double h = 0.0; int fixed = 0; int B = 0; bool materialised = false; } view;   // obtg_fd_view_begin .. _end
+    obtg::DevBuf ws_fd;                   // the view's batch, written only when some kernel needs it
 
     // scratch for host-buffer entry points
     obtg::DevBuf ws_in, ws_in2, ws_out, ws_misc[8];

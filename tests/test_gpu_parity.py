@@ -1061,7 +1061,7 @@ def test_ang_rate_with_elevation_both_orders(capi, oracle, synth, golden_dir):
     ctx.close()
 
 
-@pytest.mark.parametrize("shape", ["C3", "deg7", "elevated", "space3d"])
+@pytest.mark.parametrize("shape", ["C3", "deg7", "elevated", "space3d", "generic"])
 def test_fd_forms_equal_the_materialised_batch(capi, synth, shape):
     """obtg_pair_sweep_fd_dev / obtg_dynamics_fd_dev take ONE row of control points and form the finite-difference
     rows while staging them (C3, deg7: on the fly; elevated: dynamics on the fly, pair sweep through the fallback;
@@ -1069,7 +1069,7 @@ def test_fd_forms_equal_the_materialised_batch(capi, synth, shape):
     obtg_fd_batch_dev + obtg_pair_sweep_dev / obtg_dynamics_dev produce."""
     import torch
     N, d, n, R, M, fixed = {"C3": (64, 2, 10, 0, 8, 1), "deg7": (20, 2, 7, 0, 2, 2), "elevated": (8, 2, 10, 6, 3, 1),
-                            "space3d": (7, 3, 5, 0, 0, 1)}[shape]
+                            "space3d": (7, 3, 5, 0, 0, 1), "generic": (5, 2, 12, 2, 2, 1)}[shape]
     Y = synth.swarm_control_points(N, d, n, seed=12)
     polys = synth.polygon_obstacles(M, seed=12)
     pa, pb = synth.swarm_pairs(N, M)
@@ -1079,7 +1079,8 @@ def test_fd_forms_equal_the_materialised_batch(capi, synth, shape):
     ctx.set_polygons(*(synth.pack_polys(polys) if M else (None, [0])))
     ctx.set_hull_pairs(pa, pb)
     on_fly = ctx.fd_forms_on_the_fly()
-    assert on_fly == {"C3": (True, True), "deg7": (True, True), "elevated": (False, True), "space3d": (False, False)}[shape]
+    assert on_fly == {"C3": (True, True), "deg7": (True, True), "elevated": (False, True), "space3d": (False, False),
+                      "generic": (False, False)}[shape]      # generic: degree 12 has no specialised kernel at all
     h = 1e-3
     d0 = torch.from_numpy(Y).cuda()
     dY = torch.empty((B,) + Y.shape, dtype=torch.float64, device="cuda")
@@ -1110,6 +1111,33 @@ def test_fd_forms_equal_the_materialised_batch(capi, synth, shape):
             continue
         assert torch.equal(a[key].view(torch.uint8), b[key].view(torch.uint8)), key
     assert int((a["sep"][1:] != a["sep"][:1]).any(dim=1).sum().item()) == B - 1              # every row really differs from row 0
+    # the view: every `_dev` sweep with dY = None between fd_view_begin and fd_view_end (kernels that can form the rows do,
+    # for the others the library writes the batch once) -- again bit for bit the materialised results
+    v = bufs()
+    mn_a = torch.empty((B, P), dtype=torch.float64, device="cuda")
+    mn_v = torch.empty((B, P), dtype=torch.float64, device="cuda")
+    ctx.temporal_sep_min_dev(dY.data_ptr(), B, 0.9, mn_a.data_ptr())
+    # (the separate speed / angular-rate entry points round differently from the fused dynamics launch: like with like)
+    ctx.speed_dev(dY.data_ptr(), dtf.data_ptr(), B, 4.0, True, a["sp"].data_ptr())
+    if d == 2:
+        ctx.ang_rate_dev(dY.data_ptr(), dtf.data_ptr(), B, 1.5, a["an"].data_ptr())
+    ctx.fd_view_begin(d0.data_ptr(), fixed, h, B)
+    ctx.temporal_sep_dev(None, B, 0.9, v["sep"].data_ptr())
+    ctx.temporal_sep_min_dev(None, B, 0.9, mn_v.data_ptr())
+    ctx.speed_dev(None, dtf.data_ptr(), B, 4.0, True, v["sp"].data_ptr())
+    if d == 2:
+        ctx.ang_rate_dev(None, dtf.data_ptr(), B, 1.5, v["an"].data_ptr())
+    ctx.gjk_swarm_dev(None, B, v["flag"].data_ptr(), v["p1"].data_ptr(), v["p2"].data_ptr(), v["dist"].data_ptr(),
+                      v["ns"].data_ptr(), v["st"].data_ptr(), 128, 500)
+    ctx.fd_view_end()
+    torch.cuda.synchronize()
+    for key in a:
+        if key == "an" and d != 2:
+            continue
+        assert torch.equal(a[key].view(torch.uint8), v[key].view(torch.uint8)), "view: " + key
+    assert torch.equal(mn_a, mn_v)
+    with pytest.raises(capi.ObtgError):
+        ctx.speed_dev(None, dtf.data_ptr(), B, 4.0, True, v["sp"].data_ptr())        # no view open
     # argument checks of the fd forms
     with pytest.raises(capi.ObtgError):
         ctx.dynamics_fd_dev(d0.data_ptr(), fixed, h, dtf.data_ptr(), N * d * (n + 1 - 2 * fixed) + 2, 4.0, True, 1.5,
