@@ -254,7 +254,14 @@ def main():
         ctx_dyn.set_stream(stream2.cuda_stream)
     Yp = None if use_view else dY.data_ptr()
 
+    everything = one_launch and o_an is not None and not two_streams
+
     def sweeps():
+        if everything:       # all four families through one call (two launches at C3: pair sweep, dynamics)
+            ctx.constraint_sweep_dev(Yp, d_tf.data_ptr(), B, max_sep, o_sep.data_ptr(), vmax, True, wmax, o_sp.data_ptr(),
+                                     o_an.data_ptr(), g_flag.data_ptr(), g_p1.data_ptr(), g_p2.data_ptr(), g_dist.data_ptr(),
+                                     None, g_stat.data_ptr(), 128, 256)
+            return
         if one_launch:
             ctx.pair_sweep_dev(Yp, B, max_sep, o_sep.data_ptr(), g_flag.data_ptr(), g_p1.data_ptr(),
                                g_p2.data_ptr(), g_dist.data_ptr(), None, g_stat.data_ptr(), 128, 256)

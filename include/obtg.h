@@ -228,6 +228,14 @@ int obtg_gjk_swarm_dev(obtg_ctx*, const double* dY, int B, int max_iter, int md_
 int obtg_pair_sweep_dev(obtg_ctx*, const double* dY, int B, double max_sep, double* d_out_sep,
                         int max_iter, int md_cap, int* d_flag, double* d_p1, double* d_p2,
                         double* d_dist, int* d_nsup, int* d_status);
+/* EVERY constraint family of the batch in one call: obtg_pair_sweep_dev (temporal separation + gjkNew hull sweep) and
+ * obtg_dynamics_dev (max/min speed + angular rate; d_out_ang may be NULL) of the same B rows -- what one evaluation of an
+ * SLSQP step needs, as the library's best launch sequence for the shape (two launches where the one-launch pair sweep
+ * applies).  Outputs are those of the two separate calls, bit for bit.  dY may be NULL inside an obtg_fd_view. */
+int obtg_constraint_sweep_dev(obtg_ctx*, const double* dY, const double* d_tf, int B, double max_sep, double* d_out_sep,
+                              double speed_bound, int speed_is_max, double max_rate, double* d_out_speed,
+                              double* d_out_ang, int max_iter, int md_cap, int* d_flag, double* d_p1, double* d_p2,
+                              double* d_dist, int* d_nsup, int* d_status);
 /* Finite-difference de-duplication (off by default).  The rows of one
  * SLSQP Jacobian differ from row 0 in ONE vehicle, so all pairs not involving it have row 0's
  * inputs bit for bit.  When on, obtg_gjk_swarm[_dev] compares every row with row 0 (bitwise, per

@@ -67,6 +67,7 @@ _SIGNATURES = {
     "obtg_ctx_set_gjk_history": (_i, [_vp, _i]),
     "obtg_pair_sweep_dev": (_i, [_vp, _vp, _i, _d, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "obtg_gjk_swarm_dev": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "obtg_constraint_sweep_dev": (_i, [_vp, _vp, _vp, _i, _d, _vp, _d, _i, _d, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "obtg_gjk_swarm": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "obtg_min_dist": (_i, [_vp, _vp, _i, _i, _vp, _vp, _i, _d, _i, _i, _i, _i, _vp, _vp, _vp]),
     "obtg_min_dist_robust": (_i, [_vp, _vp, _i, _i, _vp, _vp, _i, _d, _i, _vp, _vp, _vp]),
@@ -483,6 +484,16 @@ class Context(object):
                                                   md_cap, _vp(d_flag), _vp(d_p1), _vp(d_p2), _vp(d_dist),
                                                   _vp(d_nsup) if d_nsup else None,
                                                   _vp(d_status) if d_status else None), "obtg_pair_sweep_dev")
+
+    def constraint_sweep_dev(self, dY, d_tf, B, max_sep, d_out_sep, speed_bound, speed_is_max, max_rate, d_out_speed,
+                             d_out_ang, d_flag, d_p1, d_p2, d_dist, d_nsup=None, d_status=None, max_iter=128, md_cap=4096):
+        """Every constraint family of the batch in one call (obtg_constraint_sweep_dev)."""
+        self._need_hull_pairs("constraint_sweep_dev")
+        self._check(self._lib.obtg_constraint_sweep_dev(self._h, _vp(dY), _vp(d_tf), B, float(max_sep), _vp(d_out_sep),
+                                                        float(speed_bound), int(bool(speed_is_max)), float(max_rate),
+                                                        _vp(d_out_speed), _vp(d_out_ang), max_iter, md_cap, _vp(d_flag),
+                                                        _vp(d_p1), _vp(d_p2), _vp(d_dist), _vp(d_nsup) if d_nsup else None,
+                                                        _vp(d_status) if d_status else None), "obtg_constraint_sweep_dev")
 
     def min_dist(self, curves, pair_a, pair_b, eps=1e-9, max_iter=128, md_cap=4096, max_depth=64,
                  max_nodes=200000):

@@ -556,4 +556,168 @@ __device__ __forceinline__ void normsq_elev_body(const NsParams& p, const int b,
     }
 }
 
+// =====================================================================================
+//  angular rate + speed, fast path (R == 0, d == 2): shared by bern_kernels.hip and the pair sweep
+// =====================================================================================
+struct AngParams {
+    const double* __restrict__ Y;    // [B][n_veh*2][NC]
+    const double* __restrict__ tf;   // [B]
+    const double* __restrict__ W2n;  // folded weights degree n,   dim factor 1   [2n+1][n+1]
+    const double* __restrict__ W22n; // folded weights degree 2n,  dim factor 1   [4n+1][2n+1]
+    const double* __restrict__ Wn;   // plain weights  degree n                   [2n+1][n+1]
+    double* __restrict__ out;        // [B][n_veh][4n+1]           (nullable)
+    double* __restrict__ out_speed;  // [B][n_veh][2n+1]           (nullable)
+    int n_veh, total;                // total = B * n_veh
+    double w2;                       // max_rate^2
+    double sp_sign, sp_offset;       // speed output = sp_sign * |v|^2 + sp_offset
+    int fd, fd_fixed;                // fd != 0: Y is ONE row [n_veh*2][NC]; row b >= 1 = Y with its (b-1)-th free
+    double fd_h;                     //          control point advanced by fd_h (the rows obtg_fd_batch_dev writes)
+};
+
+// control points of item (b, veh) of a 2-D batch: from the materialised batch, or formed on the fly (p.fd)
+template <int NC>
+__device__ __forceinline__ void load_item_xy(const AngParams& p, int item, int b, double (&x)[NC], double (&y)[NC])
+{
+    if (!p.fd) {
+        const double* src = p.Y + (size_t)item * 2 * NC;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) { x[c] = src[c]; y[c] = src[NC + c]; }
+        return;
+    }
+    const int veh = item - b * p.n_veh;
+    const double* src = p.Y + (size_t)veh * 2 * NC;
+    int pl = -1;                                           // perturbed element inside this vehicle's 2 NC values
+    if (b > 0) {
+        const int free_cols = NC - 2 * p.fd_fixed, kq = b - 1, pr = kq / free_cols, pc = p.fd_fixed + (kq - pr * free_cols);
+        pl = pr * NC + pc - veh * 2 * NC;
+    }
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        const double vx = src[c], vy = src[NC + c];
+        x[c] = (c == pl) ? vx + p.fd_h : vx;
+        y[c] = (NC + c == pl) ? vy + p.fd_h : vy;
+    }
+}
+
+template <int NC>
+__device__ __forceinline__ void diff_elev1(const double (&p)[NC], double val, double (&d)[NC])
+{
+    constexpr int N = NC - 1;
+    double t[NC];
+#pragma unroll
+    for (int c = 0; c < N; ++c) t[c] = p[c] * (-val) + p[c + 1] * val;
+    d[0] = t[0];
+    d[N] = t[N - 1];
+#pragma unroll
+    for (int c = 1; c < N; ++c) d[c] = t[c - 1] * ((double)c / (double)N) + t[c] * ((double)(N - c) / (double)N);
+}
+
+// Two waves (threads 0..127 of the workgroup) on the 64 items of `group`; the other waves of a larger workgroup must
+// have returned before the call (the barriers below count the surviving waves).  k_dynamics2 is this on its own grid;
+// the pair sweep runs it in workgroups of its own grid (gjk_kernels.hip k_pair_sweep<NC, true>).
+template <int NC>
+__device__ __forceinline__ void dynamics2_group(const AngParams& p, double* lds, const int group)
+{
+    constexpr int N = NC - 1, L2 = 2 * N + 1, L4 = 4 * N + 1;
+    constexpr int KS = (L4 * 5) / 8;           // wave 0 divides k < KS, wave 1 the rest (wave 1 has the dearer products)
+    double* tile = lds;                        // [kWave][L4]: exchange, then the output rows
+    double* tile_sp = lds + kWave * L4;        // [kWave][L2]: speed rows (wave 0)
+    const int lane = threadIdx.x & (kWave - 1);
+    const int role = threadIdx.x >> 6;         // wave-uniform
+    const int it0 = group * kWave;
+    const int n_valid = min(kWave, p.total - it0);
+    const int item = min(it0 + lane, p.total - 1);
+    const int b = item / p.n_veh;
+    double x[NC], y[NC];
+    load_item_xy<NC>(p, item, b, x, y);
+    const double val = (double)N / p.tf[b];
+    double xD[NC], yD[NC];
+    diff_elev1<NC>(x, val, xD);
+    diff_elev1<NC>(y, val, yD);
+    const ctab_t W22n = as_ctab(p.W22n);
+    double sq[L4];                             // den (wave 0) or num (wave 1), degree 4n
+    if (role == 0) {
+        const ctab_t W2n = as_ctab(p.W2n);
+        double den1[L2];
+#pragma unroll
+        for (int k = 0; k < L2; ++k) {
+            double sd = 0.0;
+#pragma unroll
+            for (int j = (k - N > 0 ? k - N : 0); 2 * j <= k; ++j)
+                sd = fma(W2n[k * NC + j], fma(xD[j], xD[k - j], yD[j] * yD[k - j]), sd);
+            den1[k] = sd;
+        }
+        if (p.out_speed) {
+#pragma unroll
+            for (int k = 0; k < L2; ++k) tile_sp[lane * L2 + k] = p.sp_sign * den1[k] + p.sp_offset;
+            wave_sync();
+            flush_full<L2, L2>(tile_sp, p.out_speed, (size_t)it0 * L2, n_valid, lane);
+        }
+#pragma unroll
+        for (int k = 0; k < L4; ++k) {
+            double s = 0.0;
+#pragma unroll
+            for (int j = (k - 2 * N > 0 ? k - 2 * N : 0); 2 * j <= k; ++j) s = fma(W22n[k * L2 + j], den1[j] * den1[k - j], s);
+            sq[k] = s;
+        }
+#pragma unroll
+        for (int k = KS; k < L4; ++k) tile[lane * L4 + k] = sq[k];
+    } else {
+        const ctab_t Wn = as_ctab(p.Wn);
+        double xDD[NC], yDD[NC], num1[L2];
+        diff_elev1<NC>(xD, val, xDD);
+        diff_elev1<NC>(yD, val, yDD);
+#pragma unroll
+        for (int k = 0; k < L2; ++k) {
+            double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+            for (int j = (k - N > 0 ? k - N : 0); j <= (N < k ? N : k); ++j) {
+                const double wkj = Wn[k * NC + j];
+                s1 = fma(wkj, yDD[j] * xD[k - j], s1);
+                s2 = fma(wkj, xDD[j] * yD[k - j], s2);
+            }
+            num1[k] = s1 - s2;
+        }
+#pragma unroll
+        for (int k = 0; k < L4; ++k) {
+            double s = 0.0;
+#pragma unroll
+            for (int j = (k - 2 * N > 0 ? k - 2 * N : 0); 2 * j <= k; ++j) s = fma(W22n[k * L2 + j], num1[j] * num1[k - j], s);
+            sq[k] = s;
+        }
+#pragma unroll
+        for (int k = 0; k < KS; ++k) tile[lane * L4 + k] = sq[k];
+    }
+    __syncthreads();
+    // constraint = w^2 - num.cpts / den.cpts (optimization.py:608), each wave its share of k
+    double q[L4];
+    if (role == 0) {
+#pragma unroll
+        for (int k = 0; k < KS; ++k) q[k] = p.w2 - tile[lane * L4 + k] / sq[k];
+    } else {
+#pragma unroll
+        for (int k = KS; k < L4; ++k) q[k] = p.w2 - sq[k] / tile[lane * L4 + k];
+    }
+    __syncthreads();
+    if (role == 0) {
+#pragma unroll
+        for (int k = 0; k < KS; ++k) tile[lane * L4 + k] = q[k];
+    } else {
+#pragma unroll
+        for (int k = KS; k < L4; ++k) tile[lane * L4 + k] = q[k];
+    }
+    __syncthreads();
+    // rows of consecutive items are contiguous in the output: one linear copy by both waves
+    const size_t grow = (size_t)it0 * L4;
+    const int total = n_valid * L4;
+    const int shift = (int)(grow & 1);
+    const int npairs = (total + shift + 1) >> 1;
+    for (int m = threadIdx.x; m < npairs; m += 2 * kWave) {
+        const int e0 = 2 * m - shift, e1 = e0 + 1;
+        if (e0 >= 0 && e1 < total) store_nt2(p.out + grow + e0, tile[e0], tile[e1]);
+        else if (e0 >= 0) store_nt(p.out + grow + e0, tile[e0]);
+        else if (e1 < total) store_nt(p.out + grow + e1, tile[e1]);
+    }
+}
+
 }  // namespace obtg

@@ -193,7 +193,7 @@ const char* obtg_abi_symbols(void)
         "obtg_temporal_sep_fd\0obtg_temporal_sep_fd_dev\0"
         "obtg_temporal_sep_dev\0obtg_temporal_sep_min_dev\0obtg_speed_dev\0obtg_ang_rate_dev\0obtg_dynamics_dev\0"
         "obtg_fd_batch_dev\0obtg_fd_view_begin\0obtg_fd_view_end\0obtg_fd_forms_on_the_fly\0obtg_pair_sweep_fd_dev\0obtg_dynamics_fd_dev\0obtg_gjk_pairs\0obtg_ctx_set_polygons\0obtg_ctx_set_hull_pairs\0"
-        "obtg_ctx_set_fd_dedup\0obtg_ctx_set_gjk_history\0obtg_pair_sweep_dev\0obtg_gjk_swarm_dev\0obtg_gjk_swarm\0obtg_min_dist\0obtg_min_dist_robust\0obtg_min_dist2poly\0obtg_min_dist2poly_robust\0obtg_gjk_true_pairs\0"
+        "obtg_ctx_set_fd_dedup\0obtg_ctx_set_gjk_history\0obtg_pair_sweep_dev\0obtg_constraint_sweep_dev\0obtg_gjk_swarm_dev\0obtg_gjk_swarm\0obtg_min_dist\0obtg_min_dist_robust\0obtg_min_dist2poly\0obtg_min_dist2poly_robust\0obtg_gjk_true_pairs\0"
         "obtg_bern_elev\0obtg_bern_diff\0obtg_bern_mul\0obtg_bern_normsq\0obtg_bern_split\0"
         "obtg_euclidean_obj\0obtg_accel_obj\0obtg_jerk_obj\0"
         "obtg_set_profiling\0obtg_set_profile_period\0obtg_kernel_stats\0obtg_reset_kernel_stats\0obtg_kernel_name\0";
@@ -883,6 +883,23 @@ int obtg_pair_sweep_dev(obtg_ctx* c, const double* dY, int B, double max_sep, do
     (void)hipSetDevice(c->device);
     return with_batch(c, dY, B, [&](const double* src) {
         return launch_pair_sweep(c, src, B, max_sep, d_out_sep, max_iter, md_cap, d_flag, d_p1, d_p2, d_dist, d_nsup, d_status); });
+}
+
+int obtg_constraint_sweep_dev(obtg_ctx* c, const double* dY, const double* d_tf, int B, double max_sep, double* d_out_sep,
+                              double speed_bound, int speed_is_max, double max_rate, double* d_out_speed,
+                              double* d_out_ang, int max_iter, int md_cap, int* d_flag, double* d_p1, double* d_p2,
+                              double* d_dist, int* d_nsup, int* d_status)
+{
+    if (!check_ctx(c) || !d_tf || !d_out_sep || !d_out_speed || !d_flag || !d_p1 || !d_p2 || !d_dist || B < 0 ||
+        max_iter < 1 || md_cap < 1) return OBTG_ERR_ARG;
+    if (!c->hull_pairs_set) return OBTG_ERR_ARG;
+    if (d_out_ang && c->dim != 2) return OBTG_ERR_ARG;
+    (void)hipSetDevice(c->device);
+    return with_batch(c, dY, B, [&](const double* src) {
+        int rc = launch_pair_sweep(c, src, B, max_sep, d_out_sep, max_iter, md_cap, d_flag, d_p1, d_p2, d_dist, d_nsup, d_status);
+        if (rc) return rc;
+        return launch_dynamics(c, src, d_tf, B, speed_bound, speed_is_max, max_rate, d_out_speed, d_out_ang);
+    });
 }
 
 int obtg_ctx_set_gjk_history(obtg_ctx* c, int on)

@@ -1215,3 +1215,58 @@ def test_min_dist2poly_robust(capi, synth, golden_dir, host_gjk):
     d_rob, t_rob, pt = c1.minDist2Poly(m["lit_polys"][0], robust=True)
     d_ref = c1.minDist2Poly(m["lit_polys"][0])[0]
     assert d_rob <= d_ref * (1 + 1e-9) and pt.shape == (3,)
+
+
+@pytest.mark.parametrize("shape", ["C3", "deg7_ragged", "elevated_fallback"])
+def test_constraint_sweep_equals_separate_calls(capi, synth, shape):
+    """obtg_constraint_sweep_dev: all four families of a batch in one call, against the separate entry points (pair
+    sweep + fused dynamics), bit for bit; on a materialised batch and inside an FD view."""
+    import torch
+    N, n, R, M, B = {"C3": (64, 10, 0, 8, 700), "deg7_ragged": (40, 7, 0, 3, 11), "elevated_fallback": (8, 10, 5, 2, 9)}[shape]
+    Y = synth.swarm_control_points(N, 2, n, seed=21)
+    polys = synth.polygon_obstacles(M, seed=21)
+    pa, pb = synth.swarm_pairs(N, M)
+    ctx = capi.Context(N, 2, n, R)
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    ctx.set_polygons(*synth.pack_polys(polys))
+    ctx.set_hull_pairs(pa, pb)
+    h = 1e-3
+    d0 = torch.from_numpy(Y).cuda()
+    dY = torch.empty((B,) + Y.shape, dtype=torch.float64, device="cuda")
+    ctx.fd_batch_dev(d0.data_ptr(), 1, h, B, dY.data_ptr())
+    dY[B // 2] += torch.randn_like(dY[B // 2])                       # one genuinely different row (materialised form only)
+    dtf = torch.from_numpy(np.linspace(3.0, 9.0, B)).cuda()
+    P, L, Ps = ctx.num_pairs, 2 * n + R + 1, len(pa)
+
+    def bufs():
+        f64, i32 = torch.float64, torch.int32
+        return dict(sep=torch.empty((B, P * L), dtype=f64, device="cuda"), flag=torch.empty((B, Ps), dtype=i32, device="cuda"),
+                    p1=torch.empty((B, Ps, 3), dtype=f64, device="cuda"), p2=torch.empty((B, Ps, 3), dtype=f64, device="cuda"),
+                    dist=torch.empty((B, Ps), dtype=f64, device="cuda"), ns=torch.empty((B, Ps), dtype=i32, device="cuda"),
+                    st=torch.empty((B, Ps), dtype=i32, device="cuda"), sp=torch.empty((B, ctx.len_speed), dtype=f64, device="cuda"),
+                    an=torch.empty((B, ctx.len_ang_rate), dtype=f64, device="cuda"))
+
+    def separate(src, o):
+        ctx.pair_sweep_dev(src, B, 0.9, o["sep"].data_ptr(), o["flag"].data_ptr(), o["p1"].data_ptr(), o["p2"].data_ptr(),
+                           o["dist"].data_ptr(), o["ns"].data_ptr(), o["st"].data_ptr(), 128, 500)
+        ctx.dynamics_dev(src, dtf.data_ptr(), B, 4.0, True, 1.5, o["sp"].data_ptr(), o["an"].data_ptr())
+
+    def fused(src, o):
+        ctx.constraint_sweep_dev(src, dtf.data_ptr(), B, 0.9, o["sep"].data_ptr(), 4.0, True, 1.5, o["sp"].data_ptr(),
+                                 o["an"].data_ptr(), o["flag"].data_ptr(), o["p1"].data_ptr(), o["p2"].data_ptr(),
+                                 o["dist"].data_ptr(), o["ns"].data_ptr(), o["st"].data_ptr(), 128, 500)
+    for view in (False, True):
+        a, b = bufs(), bufs()
+        if view:
+            ctx.fd_view_begin(d0.data_ptr(), 1, h, B)
+        src = None if view else dY.data_ptr()
+        separate(src, a)
+        fused(src, b)
+        fused(src, b)                                                # second call: history-ordered schedule
+        if view:
+            ctx.fd_view_end()
+        torch.cuda.synchronize()
+        for key in a:
+            assert torch.equal(a[key].view(torch.uint8), b[key].view(torch.uint8)), (key, view)
+    ctx.set_stream(0)
+    ctx.close()
