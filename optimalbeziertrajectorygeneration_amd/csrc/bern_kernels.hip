@@ -28,7 +28,9 @@
 #include "obtg_internal.h"
 #include "bern_device.h"
 
-constexpr size_t kNsLdsBudget = 36 * 1024;   // LDS per workgroup of the temporal sweep: four workgroups per CU
+// LDS per workgroup of the temporal sweep: room for 64-row transposition tiles (one pass per 64-pair group) at two
+// workgroups per CU.  36 KB (16- / 32-row tiles, four workgroups): C3 0.083 ms, C4 15.4 ms; 76 KB: 0.077 / 14.3 ms.
+constexpr size_t kNsLdsBudget = 76 * 1024;
 
 namespace obtg {
 
@@ -858,7 +860,7 @@ static int launch_ns_t(obtg_ctx* c, NsParams p, int B, int kernel_id)
 {
     using S = NsShape<NC, DIM>;
     // the R > 0 path always transposes 64 rows x kTileK columns
-    const size_t budget = kNsLdsBudget;   // => four workgroups (16 waves) per CU when it can be met
+    const size_t budget = kNsLdsBudget;
     const size_t stage = (size_t)p.stage_slots * S::VP * sizeof(double);
     size_t lds = 0;
     if (MINONLY) { p.tile_rows = 0; lds = stage; }

@@ -572,7 +572,7 @@ __device__ __forceinline__ void gjk_planar_body(const GjkSwarmParams& p, double2
             plist[q - c0] = (unsigned)p.pa[kq] | ((unsigned)p.pb[kq] << 16);
         }
     }
-    if (threadIdx.x == 0) s_next = c0;
+    if (threadIdx.x == 0) { s_next = c0; if (SWEEP || TILED) s_nlist = 0; }
     __syncthreads();
 
     // ---- phase 1: state machine with lane refill
@@ -677,10 +677,47 @@ __device__ __forceinline__ void gjk_planar_body(const GjkSwarmParams& p, double2
     __syncthreads();
 
     // ---- phase 2: closest points / distance from the recorded simplices (gjk.py:299-360)
+    // The rare exit "origin over the triangle's interior" needs the general 3-D evaluation (about three times the
+    // instructions of the other exits together); about one pair in a hundred takes it, i.e. every other wave would
+    // pay for it.  Those pairs are set aside (their local index goes to `ord`, which phase 1 no longer needs) and
+    // evaluated afterwards, densely packed.
+    constexpr bool DEFER = SWEEP || TILED;
     const size_t obase = (size_t)b * p.n_pairs;
     const double qnan = __builtin_nan("");
+    auto emit = [&](int kk, int flag, int status, int n_scans, const Result& r) {
+        const size_t o = obase + kk;
+        p.flag[o] = flag;
+        // 24-byte records: one 16-byte (8-byte aligned) and one 8-byte store each
+        typedef double d2u_t __attribute__((ext_vector_type(2), aligned(8)));
+        d2u_t xy1, xy2;
+        xy1.x = r.c1.x; xy1.y = r.c1.y; xy2.x = r.c2.x; xy2.y = r.c2.y;
+        *reinterpret_cast<d2u_t*>(p.p1 + 3 * o) = xy1; p.p1[3 * o + 2] = r.c1.z;
+        *reinterpret_cast<d2u_t*>(p.p2 + 3 * o) = xy2; p.p2[3 * o + 2] = r.c2.z;
+        p.dist[o] = r.dist;
+        if (p.nsup) p.nsup[o] = n_scans;
+        if (p.status) p.status[o] = status;
+        if ((SWEEP || TILED) && p.len_out) p.len_out[o] = (unsigned char)min(n_scans, 255);
+    };
+    auto pair_id = [&](int k) { return SWEEP ? OWN(w, k, p.wgs_per_row) : (TILED ? p.order[k] : (FIXUP ? list[k] : k)); };
+    // the general evaluation of a recorded three-point simplex
+    auto general_exit = [&](int sa, int sb, int keys, int rq1, int rq2, Result& r) {
+        const int ia1 = rq1 & 0xff, ia2 = (rq1 >> 8) & 0xff, ib1 = (rq1 >> 16) & 0xff, ib2 = (rq1 >> 24) & 0xff;
+        const int ic1 = rq2 & 0xff, ic2 = (rq2 >> 8) & 0xff;
+        Ctx<MemLdsXY> g;
+        g.mem = MemLdsXY{ lds };
+        g.P1 = Poly{ sa * VPQ, 1 << 24, NC, 0 };
+        g.P2 = Poly{ sb * VPQ, 1 << 24, NC, 0 };
+        g.trace = nullptr; g.trace_cap = 0; g.n_support = 0;
+        gjk::Simplex s;
+        s.keys = keys;
+        s.A = gjk::Vert{ gjk::sub(gjk::point(g.mem, g.P1, ia1), gjk::point(g.mem, g.P2, ia2)), ia1, ia2 };
+        s.B = gjk::Vert{ gjk::sub(gjk::point(g.mem, g.P1, ib1), gjk::point(g.mem, g.P2, ib2)), ib1, ib2 };
+        s.C = gjk::Vert{ gjk::sub(gjk::point(g.mem, g.P1, ic1), gjk::point(g.mem, g.P2, ic2)), ic1, ic2 };
+        s.D = s.A;
+        gjk::closest_from_simplex(g, s, r);
+    };
     for (int k = c0 + (int)threadIdx.x; k < c1; k += blockDim.x) {
-        const int kk = SWEEP ? OWN(w, k, p.wgs_per_row) : (TILED ? p.order[k] : (FIXUP ? list[k] : k));
+        const int kk = pair_id(k);
         const unsigned ab2 = (SWEEP || TILED) ? pnat[k - c0] : plist[k - c0];
         const int sa = (int)(ab2 & 0xffffu), sb = (int)(ab2 >> 16);
         const int2 rq = r01[k - c0];
@@ -734,34 +771,27 @@ __device__ __forceinline__ void gjk_planar_body(const GjkSwarmParams& p, double2
                     r.c1 = V3{ (1 - t) * a1.x + t * o1.x, (1 - t) * a1.y + t * o1.y, 0.0 };
                     r.c2 = V3{ (1 - t) * a2.x + t * o2.x, (1 - t) * a2.y + t * o2.y, 0.0 };
                 }
+            } else if (DEFER) {
+                ord[atomicAdd(&s_nlist, 1)] = (unsigned short)(k - c0);
+                continue;
             } else {
-                // origin inside the triangle's plane region (rare): the general 3-D evaluation
-                Ctx<MemLdsXY> g;
-                g.mem = MemLdsXY{ lds };
-                g.P1 = Poly{ sa * VPQ, 1 << 24, NC, 0 };
-                g.P2 = Poly{ sb * VPQ, 1 << 24, NC, 0 };
-                g.trace = nullptr; g.trace_cap = 0; g.n_support = 0;
-                gjk::Simplex s;
-                s.keys = keys;
-                s.A = gjk::Vert{ gjk::sub(gjk::point(g.mem, g.P1, ia1), gjk::point(g.mem, g.P2, ia2)), ia1, ia2 };
-                s.B = gjk::Vert{ gjk::sub(gjk::point(g.mem, g.P1, ib1), gjk::point(g.mem, g.P2, ib2)), ib1, ib2 };
-                s.C = gjk::Vert{ gjk::sub(gjk::point(g.mem, g.P1, ic1), gjk::point(g.mem, g.P2, ic2)), ic1, ic2 };
-                s.D = s.A;
-                gjk::closest_from_simplex(g, s, r);
+                general_exit(sa, sb, keys, rq1, rq2, r);
             }
         }
-        const size_t o = obase + kk;
-        p.flag[o] = flag;
-        // 24-byte records: one 16-byte (8-byte aligned) and one 8-byte store each
-        typedef double d2u_t __attribute__((ext_vector_type(2), aligned(8)));
-        d2u_t xy1, xy2;
-        xy1.x = r.c1.x; xy1.y = r.c1.y; xy2.x = r.c2.x; xy2.y = r.c2.y;
-        *reinterpret_cast<d2u_t*>(p.p1 + 3 * o) = xy1; p.p1[3 * o + 2] = r.c1.z;
-        *reinterpret_cast<d2u_t*>(p.p2 + 3 * o) = xy2; p.p2[3 * o + 2] = r.c2.z;
-        p.dist[o] = r.dist;
-        if (p.nsup) p.nsup[o] = n_scans;
-        if (p.status) p.status[o] = status;
-        if ((SWEEP || TILED) && p.len_out) p.len_out[o] = (unsigned char)min(n_scans, 255);
+        emit(kk, flag, status, n_scans, r);
+    }
+    if (DEFER) {
+        __syncthreads();
+        const int n_def = s_nlist;
+        for (int q = (int)threadIdx.x; q < n_def; q += blockDim.x) {
+            const int l = (int)ord[q], k = c0 + l;
+            const unsigned ab2 = pnat[l];
+            const int2 rq = r01[l];
+            Result r;
+            r.c1 = V3{ qnan, qnan, qnan }; r.c2 = r.c1; r.dist = qnan;
+            general_exit((int)(ab2 & 0xffffu), (int)(ab2 >> 16), (rq.x >> 4) & 7, rq.y, (int)r2[l], r);
+            emit(pair_id(k), 1, OBTG_ST_OK, (int)((unsigned)rq.x >> 8), r);
+        }
     }
     if (FIXUP) __syncthreads();                          // rec / list are reused by the next segment
     }
@@ -1994,10 +2024,23 @@ int launch_gjk_pairs(obtg_ctx* c, const double* d_soa, const int* d_off, const i
 // Pairs are bucketed by (a / 8, b / 64); a chunk is one bucket (<= 512 pairs, <= 72 objects when the
 // list is the usual all-pairs sweep; arbitrary lists are handled by cutting buckets at kMaxPairs /
 // kMaxObjs).  Cached in the context until the pair list or the polygons change.
+// Tiles are TA x 64 blocks of the pair matrix.  A workgroup's lanes refill from its tile only, so the taller the tile
+// the fewer lanes idle at its end -- as long as the four workgroups a CU can hold (register bound of the tiled
+// kernels) still fit its 160 KB of LDS.  C4 (16 points): TA = 8 / 12 / 13 / 14 -> 17.96 / 14.25 / 13.80 /
+// 16.11 ms per sweep (14 costs a workgroup per CU).
+static int tile_height(int nc)
+{
+    const int vpq = nc | 1, occ = 4;
+    const size_t budget = (size_t)160 * 1024 / occ - 1280;          // 1040 bytes of static LDS per workgroup
+    int ta = 8;
+    while (ta < 32 && planar_lds_bytes<2>(ta + 1 + 64, vpq, (ta + 1) * 64) <= budget) ++ta;
+    return ta;
+}
+
 static int build_tiles(obtg_ctx* c, int /*vp*/)
 {
     if (c->tile_valid) return OBTG_OK;
-    constexpr int TA = 8, TB = 64, kMaxPairs = 512, kMaxObjs = 96;
+    const int TA = tile_height(c->deg + 1), TB = 64, kMaxPairs = TA * TB, kMaxObjs = TA + TB;
     const int np = c->n_hull_pairs, nobj = c->n_veh + c->n_poly;
     if (nobj > 65535) return OBTG_ERR_UNSUPPORTED;
     const std::vector<int>& pa = c->h_hp_a;
