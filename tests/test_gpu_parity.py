@@ -524,10 +524,10 @@ def test_c_abi_error_codes(capi):
     ctx.close(); c3.close(); big.close()
 
 
-def test_gjk_swarm_large_rows_tiled(capi, oracle, synth):
-    """Rows whose hulls do not fit LDS (C4's shape: 256 vehicles, degree 15, plus polygons) go
-    through the tile-major chunking; every pair must still match the oracle bit for bit."""
-    N, n, M = 256, 15, 5
+@pytest.mark.parametrize("N,n,M", [(256, 15, 5), (600, 5, 3)])
+def test_gjk_swarm_large_rows_tiled(capi, oracle, synth, N, n, M):
+    """Rows whose hulls do not fit LDS (C4's shape: 256 vehicles, degree 15, plus polygons; 600 vehicles of degree 5,
+    whose tiles are taller) go through the tile-major chunking; every pair must still match the oracle bit for bit."""
     Y = synth.swarm_control_points(N, 2, n, seed=1234)
     polys = synth.polygon_obstacles(M, seed=3)
     ppts, poff = synth.pack_polys(polys)
