@@ -635,36 +635,26 @@ __device__ __forceinline__ void dynamics2_group(const AngParams& p, double* lds,
     diff_elev1<NC>(x, val, xD);
     diff_elev1<NC>(y, val, yD);
     const ctab_t W22n = as_ctab(p.W22n);
-    double sq[L4];                             // den (wave 0) or num (wave 1), degree 4n
+    double q1[L2];                             // den1 (wave 0) or num1 (wave 1), degree 2n
     if (role == 0) {
         const ctab_t W2n = as_ctab(p.W2n);
-        double den1[L2];
 #pragma unroll
         for (int k = 0; k < L2; ++k) {
             double sd = 0.0;
 #pragma unroll
             for (int j = (k - N > 0 ? k - N : 0); 2 * j <= k; ++j)
                 sd = fma(W2n[k * NC + j], fma(xD[j], xD[k - j], yD[j] * yD[k - j]), sd);
-            den1[k] = sd;
+            q1[k] = sd;
         }
         if (p.out_speed) {
 #pragma unroll
-            for (int k = 0; k < L2; ++k) tile_sp[lane * L2 + k] = p.sp_sign * den1[k] + p.sp_offset;
+            for (int k = 0; k < L2; ++k) tile_sp[lane * L2 + k] = p.sp_sign * q1[k] + p.sp_offset;
             wave_sync();
             flush_full<L2, L2>(tile_sp, p.out_speed, (size_t)it0 * L2, n_valid, lane);
         }
-#pragma unroll
-        for (int k = 0; k < L4; ++k) {
-            double s = 0.0;
-#pragma unroll
-            for (int j = (k - 2 * N > 0 ? k - 2 * N : 0); 2 * j <= k; ++j) s = fma(W22n[k * L2 + j], den1[j] * den1[k - j], s);
-            sq[k] = s;
-        }
-#pragma unroll
-        for (int k = KS; k < L4; ++k) tile[lane * L4 + k] = sq[k];
     } else {
         const ctab_t Wn = as_ctab(p.Wn);
-        double xDD[NC], yDD[NC], num1[L2];
+        double xDD[NC], yDD[NC];
         diff_elev1<NC>(xD, val, xDD);
         diff_elev1<NC>(yD, val, yDD);
 #pragma unroll
@@ -676,15 +666,22 @@ __device__ __forceinline__ void dynamics2_group(const AngParams& p, double* lds,
                 s1 = fma(wkj, yDD[j] * xD[k - j], s1);
                 s2 = fma(wkj, xDD[j] * yD[k - j], s2);
             }
-            num1[k] = s1 - s2;
+            q1[k] = s1 - s2;
         }
+    }
+    // the square (degree 4n) of either side: one copy of the code for both waves
+    double sq[L4];
 #pragma unroll
-        for (int k = 0; k < L4; ++k) {
-            double s = 0.0;
+    for (int k = 0; k < L4; ++k) {
+        double s = 0.0;
 #pragma unroll
-            for (int j = (k - 2 * N > 0 ? k - 2 * N : 0); 2 * j <= k; ++j) s = fma(W22n[k * L2 + j], num1[j] * num1[k - j], s);
-            sq[k] = s;
-        }
+        for (int j = (k - 2 * N > 0 ? k - 2 * N : 0); 2 * j <= k; ++j) s = fma(W22n[k * L2 + j], q1[j] * q1[k - j], s);
+        sq[k] = s;
+    }
+    if (role == 0) {
+#pragma unroll
+        for (int k = KS; k < L4; ++k) tile[lane * L4 + k] = sq[k];
+    } else {
 #pragma unroll
         for (int k = 0; k < KS; ++k) tile[lane * L4 + k] = sq[k];
     }
