@@ -3,6 +3,7 @@
 // bern_kernels.hip and gjk_kernels.hip.
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 
@@ -10,26 +11,42 @@
 
 namespace obtg {
 
-int DevBuf::reserve(size_t bytes)
+int DevBuf::reserve(size_t bytes, bool zero_copy)
 {
-    if (bytes <= cap && p) return OBTG_OK;
+    if (io && zero_copy && bytes <= kZeroCopyBytes && !host_failed) {
+        if (!host) {
+            if (hipHostMalloc(&host, kZeroCopyBytes, hipHostMallocMapped) != hipSuccess ||
+                hipHostGetDevicePointer(&host_dev, host, 0) != hipSuccess) {
+                (void)hipGetLastError();
+                if (host) (void)hipHostFree(host);
+                host = nullptr; host_dev = nullptr; host_failed = true;
+            }
+        }
+        if (host) { p = host_dev; cap = kZeroCopyBytes; on_host = true; return OBTG_OK; }
+    }
+    on_host = false;
+    if (bytes <= dev_cap && dev) { p = dev; cap = dev_cap; return OBTG_OK; }
     if (bytes == 0) bytes = 8;
-    if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
+    if (dev) { (void)hipFree(dev); dev = nullptr; dev_cap = 0; }
+    p = nullptr; cap = 0;
     // grow geometrically to keep repeated host-entry calls from reallocating
     size_t want = bytes + bytes / 4;
-    if (hipMalloc(&p, want) != hipSuccess) {
+    if (hipMalloc(&dev, want) != hipSuccess) {
         (void)hipGetLastError();
-        if (hipMalloc(&p, bytes) != hipSuccess) { p = nullptr; return OBTG_ERR_OOM; }
+        if (hipMalloc(&dev, bytes) != hipSuccess) { dev = nullptr; return OBTG_ERR_OOM; }
         want = bytes;
     }
-    cap = want;
+    dev_cap = want;
+    p = dev; cap = dev_cap;
     return OBTG_OK;
 }
 
 void DevBuf::release()
 {
-    if (p) (void)hipFree(p);
-    p = nullptr; cap = 0;
+    if (dev) (void)hipFree(dev);
+    if (host) (void)hipHostFree(host);
+    dev = nullptr; dev_cap = 0; host = nullptr; host_dev = nullptr;
+    p = nullptr; cap = 0; on_host = false;
 }
 
 int set_error(obtg_ctx* c, hipError_t e, const char* where)
@@ -222,6 +239,8 @@ int obtg_ctx_create(obtg_ctx** out, int n_veh, int dim, int deg, int deg_elev, i
         (void)hipGetLastError(); delete c; return OBTG_ERR_DEVICE;
     }
     c->stream = c->own_stream;
+    // OBTG_ZERO_COPY=0 keeps every staging buffer in device memory (the path for large batches)
+    { const char* e = getenv("OBTG_ZERO_COPY"); const bool zc = !(e && e[0] == '0'); c->ws_in.io = c->ws_in2.io = c->ws_out.io = zc; }
     int rc = OBTG_OK;
     c->h_pairs.resize((size_t)2 * c->n_pairs);
     {
@@ -487,10 +506,17 @@ static int ring_slot_ready(obtg_ctx* c, int sl)
     return OBTG_OK;
 }
 
-static int h2d(obtg_ctx* c, DevBuf& b, const void* src, size_t bytes)
+// zero_copy: inputs of up to kZeroCopyIn bytes may stay in mapped host memory (the kernel fetches them across PCIe:
+// a one-row call of 64 vehicles, 11 KB read by several workgroups, is already slower that way than one DMA transfer)
+constexpr size_t kZeroCopyIn = 8u << 10;
+static int h2d(obtg_ctx* c, DevBuf& b, const void* src, size_t bytes, bool zero_copy = false)
 {
-    int rc = b.reserve(bytes);
+    int rc = b.reserve(bytes, zero_copy && bytes <= kZeroCopyIn);
     if (rc) return rc;
+    if (b.on_host) {        // mapped host block: the device is idle between host entry points, nothing can be reading it
+        std::memcpy(b.host, src, bytes);
+        return OBTG_OK;
+    }
     if (bytes < kRingMin || is_pinned(src) || ensure_ring(c) != OBTG_OK) {
         OBTG_HIP(c, hipMemcpyAsync(b.p, src, bytes, hipMemcpyHostToDevice, c->stream));
         return OBTG_OK;
@@ -510,9 +536,26 @@ static int h2d(obtg_ctx* c, DevBuf& b, const void* src, size_t bytes)
 }
 
 // device -> host, complete on return for THIS array (the stream may still hold other work)
+// the CPU address of `src` when it lies in the mapped host block of a staging buffer, else nullptr
+static const void* mapped_alias(const obtg_ctx* c, const void* src)
+{
+    for (const DevBuf* b : { &c->ws_in, &c->ws_in2, &c->ws_out }) {
+        if (!b->host) continue;
+        const char* lo = static_cast<const char*>(b->host_dev);
+        const char* q = static_cast<const char*>(src);
+        if (q >= lo && q < lo + kZeroCopyBytes) return static_cast<const char*>(b->host) + (q - lo);
+    }
+    return nullptr;
+}
+
 static int d2h_copy(obtg_ctx* c, void* dst, const void* src, size_t bytes)
 {
     if (bytes == 0) return OBTG_OK;
+    if (const void* h = mapped_alias(c, src)) {     // the kernel wrote host memory itself: wait for it, then a plain copy
+        OBTG_HIP(c, hipStreamSynchronize(c->stream));
+        std::memcpy(dst, h, bytes);
+        return OBTG_OK;
+    }
     if (bytes < kRingMin || is_pinned(dst) || ensure_ring(c) != OBTG_OK) {
         OBTG_HIP(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream));
         return OBTG_OK;
@@ -566,9 +609,9 @@ static int host_sep(obtg_ctx* c, const double* Y, int B, double max_sep, bool mi
     if (B == 0 || pair_count == 0) return OBTG_OK;
     (void)hipSetDevice(c->device);
     const size_t per = min_only ? (size_t)pair_count : (size_t)pair_count * (2 * c->deg + c->R + 1);
-    int rc = h2d(c, c->ws_in, Y, sizeof(double) * ysize(c) * B);
+    int rc = h2d(c, c->ws_in, Y, sizeof(double) * ysize(c) * B, true);
     if (rc) return rc;
-    if ((rc = c->ws_out.reserve(sizeof(double) * per * B))) return rc;
+    if ((rc = c->ws_out.reserve(sizeof(double) * per * B, true))) return rc;
     rc = launch_temporal_sep(c, c->ws_in.as<double>(), B, max_sep, pair_begin, pair_count, min_only,
                              c->ws_out.as<double>());
     if (rc) return rc;
@@ -636,10 +679,10 @@ int obtg_speed(obtg_ctx* c, const double* Y, const double* tf, int B, double bou
     if (B == 0) return OBTG_OK;
     (void)hipSetDevice(c->device);
     const size_t per = (size_t)obtg_len_speed(c);
-    int rc = h2d(c, c->ws_in, Y, sizeof(double) * ysize(c) * B);
+    int rc = h2d(c, c->ws_in, Y, sizeof(double) * ysize(c) * B, true);
     if (rc) return rc;
-    if ((rc = h2d(c, c->ws_in2, tf, sizeof(double) * B))) return rc;
-    if ((rc = c->ws_out.reserve(sizeof(double) * per * B))) return rc;
+    if ((rc = h2d(c, c->ws_in2, tf, sizeof(double) * B, true))) return rc;
+    if ((rc = c->ws_out.reserve(sizeof(double) * per * B, true))) return rc;
     rc = launch_speed(c, c->ws_in.as<double>(), c->ws_in2.as<double>(), B, bound, is_max, c->ws_out.as<double>());
     if (rc) return rc;
     return d2h(c, out, c->ws_out.p, sizeof(double) * per * B);
@@ -652,10 +695,10 @@ int obtg_ang_rate(obtg_ctx* c, const double* Y, const double* tf, int B, double 
     if (B == 0) return OBTG_OK;
     (void)hipSetDevice(c->device);
     const size_t per = (size_t)obtg_len_ang_rate(c);
-    int rc = h2d(c, c->ws_in, Y, sizeof(double) * ysize(c) * B);
+    int rc = h2d(c, c->ws_in, Y, sizeof(double) * ysize(c) * B, true);
     if (rc) return rc;
-    if ((rc = h2d(c, c->ws_in2, tf, sizeof(double) * B))) return rc;
-    if ((rc = c->ws_out.reserve(sizeof(double) * per * B))) return rc;
+    if ((rc = h2d(c, c->ws_in2, tf, sizeof(double) * B, true))) return rc;
+    if ((rc = c->ws_out.reserve(sizeof(double) * per * B, true))) return rc;
     rc = launch_ang_rate(c, c->ws_in.as<double>(), c->ws_in2.as<double>(), B, max_rate, c->ws_out.as<double>());
     if (rc) return rc;
     return d2h(c, out, c->ws_out.p, sizeof(double) * per * B);
@@ -1124,9 +1167,9 @@ int obtg_euclidean_obj(obtg_ctx* c, const double* Y, int B, double* out)
     if (!check_ctx(c) || !Y || !out || B < 0) return OBTG_ERR_ARG;
     if (B == 0) return OBTG_OK;
     (void)hipSetDevice(c->device);
-    int rc = h2d(c, c->ws_in, Y, sizeof(double) * ysize(c) * B);
+    int rc = h2d(c, c->ws_in, Y, sizeof(double) * ysize(c) * B, true);
     if (rc) return rc;
-    if ((rc = c->ws_out.reserve(sizeof(double) * B))) return rc;
+    if ((rc = c->ws_out.reserve(sizeof(double) * B, true))) return rc;
     if ((rc = launch_euclidean_obj(c, c->ws_in.as<double>(), B, c->ws_out.as<double>()))) return rc;
     return d2h(c, out, c->ws_out.p, sizeof(double) * B);
 }
@@ -1138,10 +1181,10 @@ static int host_deriv_obj(obtg_ctx* c, const double* Y, const double* tf, int B,
     // one final time for the whole batch, as the reference's objectives have (optimization.py:294-308)
     for (int b = 1; b < B; ++b) if (!(tf[b] == tf[0])) return OBTG_ERR_ARG;
     (void)hipSetDevice(c->device);
-    int rc = h2d(c, c->ws_in, Y, sizeof(double) * ysize(c) * B);
+    int rc = h2d(c, c->ws_in, Y, sizeof(double) * ysize(c) * B, true);
     if (rc) return rc;
-    if ((rc = h2d(c, c->ws_in2, tf, sizeof(double) * B))) return rc;
-    if ((rc = c->ws_out.reserve(sizeof(double) * B))) return rc;
+    if ((rc = h2d(c, c->ws_in2, tf, sizeof(double) * B, true))) return rc;
+    if ((rc = c->ws_out.reserve(sizeof(double) * B, true))) return rc;
     if ((rc = launch_deriv_energy_obj(c, c->ws_in.as<double>(), c->ws_in2.as<double>(), tf[0], B, order, c->ws_out.as<double>())))
         return rc;
     return d2h(c, out, c->ws_out.p, sizeof(double) * B);

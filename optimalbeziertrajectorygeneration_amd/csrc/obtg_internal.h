@@ -22,10 +22,24 @@ std::vector<double> elev_conv_tables(int L_in, int R);  // scale | padded C(R,.)
 std::vector<double> elev_conv_padded(int L_in, int R, int extra, bool normalise, bool with_inv);
 
 // ---------------------------------------------------------------- device buffers
+// Device buffer that grows.  A staging buffer of the host entry points (`io`) serves requests of up to kZeroCopyBytes
+// from mapped pinned HOST memory instead: the kernel reads its few hundred bytes of control points and writes its few
+// KB of results across PCIe itself, and a one-row SLSQP callback is memcpy + ONE launch + synchronize + memcpy instead
+// of two DMA transfers around the launch (tools/latency_probe.py: 30 -> 15 us per call at Example1's size).
+constexpr size_t kZeroCopyBytes = 64u << 10;
 struct DevBuf {
-    void* p = nullptr;
-    size_t cap = 0;
-    int reserve(size_t bytes);  // grows (never shrinks); returns OBTG_* code
+    void* p = nullptr;          // the address kernels use for the current request
+    size_t cap = 0;             // capacity behind p
+    bool io = false;            // a staging buffer of the host entry points (set once, at context creation)
+    bool on_host = false;       // p is the mapped host block
+    void* dev = nullptr;        // device allocation (grows, never shrinks)
+    size_t dev_cap = 0;
+    void* host = nullptr;       // CPU address of the mapped block (kZeroCopyBytes), host_dev its device address
+    void* host_dev = nullptr;
+    bool host_failed = false;
+    // returns OBTG_* code.  zero_copy: this request may be served from the mapped host block -- only for data a kernel
+    // touches once (control points staged to LDS or registers, results written once)
+    int reserve(size_t bytes, bool zero_copy = false);
     void release();
     template <class T> T* as() const { return static_cast<T*>(p); }
 };

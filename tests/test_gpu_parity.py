@@ -1270,3 +1270,31 @@ def test_constraint_sweep_equals_separate_calls(capi, synth, shape):
             assert torch.equal(a[key].view(torch.uint8), b[key].view(torch.uint8)), (key, view)
     ctx.set_stream(0)
     ctx.close()
+
+
+@pytest.mark.gpu
+def test_small_host_calls_through_mapped_memory_equal_the_staged_path(capi, synth, monkeypatch):
+    """One-row host calls keep their control points and results in mapped pinned host memory (the kernel reads and
+    writes across PCIe itself; capi.cpp DevBuf::reserve).  Same bits as the device-staged path (OBTG_ZERO_COPY=0), for
+    shapes on both sides of the size limits (8 KB in, 64 KB out), and when small and large calls alternate on one
+    context (the staging buffers switch between the mapped block and device memory)."""
+    tf1 = np.array([7.5])
+    for (N, d, n, R) in [(2, 2, 10, 30), (8, 3, 10, 0), (36, 3, 5, 0), (46, 2, 10, 0), (47, 2, 10, 0), (64, 2, 10, 0)]:
+        Y = synth.swarm_control_points(N, d, n, seed=N + n)
+        Yb = synth.fd_batch(Y, B=40)
+        monkeypatch.setenv("OBTG_ZERO_COPY", "0")
+        ref = capi.Context(N, d, n, R)
+        monkeypatch.delenv("OBTG_ZERO_COPY")
+        ctx = capi.Context(N, d, n, R)
+        tfb = np.full(40, 7.5)
+        for _ in range(2):                                  # small, large, small, large
+            pairs = [(ctx.temporal_sep(Y, 0.9), ref.temporal_sep(Y, 0.9)), (ctx.speed(Y, tf1, 5.0, True), ref.speed(Y, tf1, 5.0, True)),
+                     (ctx.temporal_sep_min(Y, 0.9), ref.temporal_sep_min(Y, 0.9)),
+                     (ctx.temporal_sep(Yb, 0.9), ref.temporal_sep(Yb, 0.9)), (ctx.speed(Yb, tfb, 5.0, False), ref.speed(Yb, tfb, 5.0, False))]
+            if d == 2:
+                pairs += [(ctx.ang_rate(Y, tf1, 1.0), ref.ang_rate(Y, tf1, 1.0)), (ctx.ang_rate(Yb, tfb, 1.0), ref.ang_rate(Yb, tfb, 1.0))]
+            pairs += [(ctx.euclidean_obj(Y), ref.euclidean_obj(Y)), (ctx.deriv_energy_obj(Y, tf1, 2), ref.deriv_energy_obj(Y, tf1, 2))]
+            for got, want in pairs:
+                assert np.array_equal(np.asarray(got), np.asarray(want), equal_nan=True)
+        ctx.close()
+        ref.close()

@@ -33,3 +33,32 @@ if __name__ == "__main__":
         out[tag] = probe(*shape)
         print(tag, out[tag], flush=True)
     print(json.dumps({"unit": "us per call, B = 1", "latency": out}))
+
+
+def raw_probe(N=2, d=2, n=10, R=30, calls=5000):
+    """The same call without the Python wrapper (pre-allocated arrays, bare ctypes): what the C side costs."""
+    import ctypes as C
+    ctx = _capi.Context(N, d, n, R)
+    lib = ctx._lib
+    Y = np.ascontiguousarray(synth.swarm_control_points(N, d, n, seed=1))
+    out = _capi.pinned_empty((1, ctx.len_temporal_sep))
+    outp = np.empty((1, ctx.len_temporal_sep))
+    res = {}
+    for tag, o in (("pinned result", out), ("pageable result", outp)):
+        yp, op = Y.ctypes.data_as(C.c_void_p), o.ctypes.data_as(C.c_void_p)
+        for _ in range(200):
+            lib.obtg_temporal_sep(ctx._h, yp, 1, C.c_double(0.9), op)
+        t0 = time.perf_counter()
+        for _ in range(calls):
+            lib.obtg_temporal_sep(ctx._h, yp, 1, C.c_double(0.9), op)
+        res[tag] = round((time.perf_counter() - t0) / calls * 1e6, 2)
+    t0 = time.perf_counter()
+    for _ in range(calls):
+        lib.obtg_len_temporal_sep(ctx._h)
+    res["bare ctypes call"] = round((time.perf_counter() - t0) / calls * 1e6, 2)
+    ctx.close()
+    return res
+
+
+if __name__ == "__main__":
+    print("raw obtg_temporal_sep, example1 shape:", raw_probe())
