@@ -232,6 +232,7 @@ int obtg_ctx_create(obtg_ctx** out, int n_veh, int dim, int deg, int deg_elev, i
     if (hipSetDevice(device) != hipSuccess) { (void)hipGetLastError(); return OBTG_ERR_NO_DEVICE; }
     obtg_ctx* c = new (std::nothrow) obtg_ctx();
     if (!c) return OBTG_ERR_OOM;
+    c->n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     c->device = device; c->n_veh = n_veh; c->dim = dim; c->deg = deg; c->R = deg_elev;
     c->n_obs = n_point_obs; c->n_obj = n_veh + n_point_obs;
     c->n_pairs = c->n_obj * (c->n_obj - 1) / 2;

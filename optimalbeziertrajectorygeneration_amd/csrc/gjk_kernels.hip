@@ -2248,9 +2248,19 @@ int launch_gjk_swarm(obtg_ctx* c, const double* dY, int B, int max_iter, int md_
         // Chunks: a pair of the 3-D machine can take 50 scans (cycling pairs run until the detector fires), and a
         // workgroup lasts as long as its longest pair whatever its size -- so few large workgroups (one round of
         // the chip) beat many small ones; split rows only for very small batches.
+        // ... up to what the chip holds at once (160 VGPRs: three workgroups per CU, 768).  C2_file, 433 rows: two
+        // workgroups per row are 866 -- a second round for the last 98, 0.243 ms; one per row is one round, 0.177 ms.
         {
+            long resident = 256 * 3;
+            if (k3) {
+                int per_cu = 0;
+                if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(k3), 256,
+                                                                 sweep3d_lds_bytes(n_obj, nc, 256)) == hipSuccess && per_cu > 0)
+                    resident = (long)per_cu * c->n_cus;
+                else (void)hipGetLastError();
+            }
             int wgs3 = (c->n_hull_pairs + kSweepChunk - 1) / kSweepChunk;
-            while ((long)B * wgs3 < 512 && (c->n_hull_pairs + wgs3 - 1) / wgs3 > 256) wgs3 <<= 1;
+            while ((long)B * wgs3 * 2 <= resident && (c->n_hull_pairs + wgs3 - 1) / wgs3 > 256) wgs3 <<= 1;
             p.chunk = (c->n_hull_pairs + wgs3 - 1) / wgs3;
             p.wgs_per_row = (c->n_hull_pairs + p.chunk - 1) / p.chunk;
         }

@@ -53,6 +53,7 @@ struct KernelStat {
 
 struct obtg_ctx {
     int device = 0;
+    int n_cus = 256;          // compute units of the device (hipDeviceProp_t::multiProcessorCount)
     int n_veh = 0, dim = 0, deg = 0, R = 0, n_obs = 0;
     int n_obj = 0, n_pairs = 0;
     hipStream_t own_stream = nullptr;
