@@ -233,13 +233,13 @@ __device__ __forceinline__ void simplex3_update(Simplex& s, V3& dir)
 // fetches a new support vertex (everything except the 4-point collision exit does)
 __device__ __forceinline__ bool simplex_update(Simplex& s, V3& dir)
 {
-    if (!(s.keys & kA)) {
-        return true;
-    } else if (!(s.keys & kB)) {
+    if (!(s.keys & kA)) return true;
+    if (!(s.keys & kB)) {
         s.B = s.A; s.keys |= kB;
         dir = neg(dir);
         return true;
-    } else if (!(s.keys & kC)) {
+    }
+    if (!(s.keys & kC)) {
         double dist;
         const double t = origin_to_line(s.A.v, s.B.v, dist);
         dir.x = -((1 - t) * s.A.v.x + t * s.B.v.x);
@@ -247,22 +247,23 @@ __device__ __forceinline__ bool simplex_update(Simplex& s, V3& dir)
         dir.z = -((1 - t) * s.A.v.z + t * s.B.v.z);
         s.C = s.A; s.keys |= kC;
         return true;
-    } else if (!(s.keys & kD)) {
-        simplex3_update(s, dir);
-        return true;
     }
-    const V3 A0 = neg(s.A.v), AB = sub(s.B.v, s.A.v), AC = sub(s.C.v, s.A.v), AD = sub(s.D.v, s.A.v);
-    const V3 ABC = cross(AB, AC), ACD = cross(AC, AD), ADB = cross(AD, AB);
-    if (dotb(ABC, A0) > 0) {
-        s.keys &= ~kD;                       // pop('D') only; 'Dpts' stays (gjk.py:660)
-    } else if (dotb(ACD, A0) > 0) {
-        s.B = s.C; s.C = s.D; s.keys &= ~(kD | kDpts);
-    } else if (dotb(ADB, A0) > 0) {
-        s.C = s.B; s.B = s.D; s.keys &= ~(kD | kDpts);
-    } else {
-        s.keys |= kColl;
-        dir = V3{ 0.0, 0.0, 0.0 };
-        return false;
+    if (s.keys & kD) {
+        // four points: pick the face the origin is in front of (gjk.py:646-681), then the three-point case below --
+        // ONE copy of it for both kinds of lanes (a wave usually holds both)
+        const V3 A0 = neg(s.A.v), AB = sub(s.B.v, s.A.v), AC = sub(s.C.v, s.A.v), AD = sub(s.D.v, s.A.v);
+        const V3 ABC = cross(AB, AC), ACD = cross(AC, AD), ADB = cross(AD, AB);
+        if (dotb(ABC, A0) > 0) {
+            s.keys &= ~kD;                       // pop('D') only; 'Dpts' stays (gjk.py:660)
+        } else if (dotb(ACD, A0) > 0) {
+            s.B = s.C; s.C = s.D; s.keys &= ~(kD | kDpts);
+        } else if (dotb(ADB, A0) > 0) {
+            s.C = s.B; s.B = s.D; s.keys &= ~(kD | kDpts);
+        } else {
+            s.keys |= kColl;
+            dir = V3{ 0.0, 0.0, 0.0 };
+            return false;
+        }
     }
     simplex3_update(s, dir);
     return true;
