@@ -336,6 +336,58 @@ __device__ __forceinline__ void tsep_groups_from_xy(const TsepXYParams& t, const
     }
 }
 
+// The same for the TILED sweep (large rows): the workgroup has staged the vehicles of one TA x 64 tile of the pair
+// matrix -- rows ti0 .. ti0+ta-1 at LDS slots rowslot[.], columns tj0 .. tj0+63 at colslot[.] -- and writes the
+// separation rows of that tile's pairs: row i's pairs (i, j), j in the window, are one contiguous run of the output
+// (normsq_elev_body's `tiling` arrangement on the point-major layout).  n_veh == n_obj (no point obstacles).
+// Wave `wave` takes the tile rows g = wave + it * n_waves, it_lo <= it < it_hi.
+template <int NC>
+__device__ __forceinline__ void tsep_tile_from_xy(const TsepXYParams& t, const double2* xy, const int vpq, const int b,
+                                                  const int n_veh, const int ti0, const int tj0, const int ta,
+                                                  const unsigned short* rowslot, const unsigned short* colslot,
+                                                  double* tile_base, const int TR, const int it_lo, const int it_hi)
+{
+    using S = NsShape<NC, 2>;
+    constexpr int L = S::L;
+    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6, n_waves = blockDim.x >> 6;
+    double* tile = tile_base + wave * (TR * S::TPF);
+    for (int it = it_lo; it < it_hi; ++it) {
+        const int g = wave + it * n_waves;
+        if (g >= ta) break;
+        const int i = ti0 + g;
+        if (i >= n_veh - 1) break;
+        const int j = tj0 + lane;
+        const bool valid = j > i && j < n_veh;
+        const unsigned long long m = __ballot(valid);
+        if (m == 0ull) continue;
+        const int lane0 = __ffsll((long long)m) - 1, n_valid = __popcll(m);   // valid lanes are [lane0, lane0 + n_valid)
+        const int jj = min(max(j, i + 1), n_veh - 1);                        // idle lanes recompute a valid pair
+        const double2* vi = xy + (int)rowslot[g] * vpq;
+        const double2* vj = xy + (int)colslot[jj - tj0] * vpq;
+        double a[2][NC];
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const double2 pi = vi[c], pj = vj[c];
+            a[0][c] = pi.x - pj.x;
+            a[1][c] = pi.y - pj.y;
+        }
+        double cf[L];
+        normsq_coeffs<NC, 2>(a, as_ctab(t.W2), cf);
+        const long tri = (long)i * n_veh - (long)i * (i + 1) / 2 - i - 1;    // pair index of (i, j) = tri + j
+        const size_t row = (size_t)b * t.n_pairs + (size_t)(tri + tj0 + lane0);
+        const int r = lane - lane0;
+        for (int r0 = 0; r0 < n_valid; r0 += TR) {
+            if (valid && r >= r0 && r < r0 + TR) {
+#pragma unroll
+                for (int k = 0; k < L; ++k) tile[(r - r0) * S::TPF + k] = t.sign * cf[k] + t.offset;
+            }
+            wave_sync();
+            flush_full<L, S::TPF>(tile, t.out, (row + r0) * L, min(TR, n_valid - r0), lane);
+            wave_sync();
+        }
+    }
+}
+
 // (b, w) = evaluation row and workgroup index inside the row; lds = the workgroup's dynamic LDS.
 // A device function so that the pair sweep can run it next to the GJK workgroups in ONE launch
 // (gjk_kernels.hip k_pair_sweep); k_normsq_elev below is the stand-alone kernel.

@@ -266,7 +266,7 @@ void obtg_ctx_destroy(obtg_ctx* c)
     for (hipEvent_t e : c->event_pool) (void)hipEventDestroy(e);
     DevBuf* bufs[] = { &c->d_pairs, &c->d_obs, &c->d_w2, &c->d_Tt, &c->d_Td, &c->d_ang_w2n, &c->d_ang_w22n, &c->d_ang_wn, &c->d_ang_T4, &c->d_ang_cv2,
                        &c->d_binrows, &c->d_tiles, &c->d_poly_pts, &c->d_poly_off, &c->d_hp_a, &c->d_hp_b, &c->d_tile_chunk_off, &c->d_tile_order, &c->d_tile_pslots,
-                       &c->d_tile_cobj_off, &c->d_tile_cobjs, &c->ws_in,
+                       &c->d_tile_cobj_off, &c->d_tile_cobjs, &c->d_tile_ij, &c->ws_in,
                        &c->ws_in2, &c->ws_out, &c->ws_fd };
     for (DevBuf* b : bufs) b->release();
     for (auto& b : c->ws_misc) b.release();

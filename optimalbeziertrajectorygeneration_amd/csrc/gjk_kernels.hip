@@ -248,6 +248,8 @@ struct GjkSwarmParams {
     const int* cobj_off;               // [n_chunks+1] object-list ranges
     const int* cobjs;                  // object ids per chunk, slot order
     int max_objs;                      // most objects any chunk stages
+    const int2* chunk_ij;              // [n_chunks] pair sweep: origin (ti0, tj0) of the tile whose separation rows the chunk writes, ti0 < 0: none
+    int tile_a;                        // tile height
     // plain sweep (MODE 0): trip-count history used to order each workgroup's pairs, see the kernel
     int B;
     const unsigned char* len_in;       // nullable, [.][n_pairs] support-scan counts of the previous sweep
@@ -400,7 +402,8 @@ __device__ __forceinline__ int rec8(int ii) { return (ii & 0xff) | ((ii >> 8) & 
 
 // (b_in, w_in): row / workgroup-in-row when the caller has already decoded them (>= 0: the one-launch
 // pair sweep), else decoded from blockIdx here.
-template <int NC, int MODE>
+// TS: the kernel also writes temporal-separation rows (the pair sweeps); the plain sweeps compile without that code
+template <int NC, int MODE, bool TS = false>
 __device__ __forceinline__ void gjk_planar_body(const GjkSwarmParams& p, double2* xy, const int b_in, const int w_in)
 {
     constexpr bool SWEEP = MODE == 0, FIXUP = MODE == 1, TILED = MODE == 2;
@@ -413,10 +416,11 @@ __device__ __forceinline__ void gjk_planar_body(const GjkSwarmParams& p, double2
     // Bernstein phases (whose stores drain in the background) at 0, so a SIMD that holds both kinds of waves feeds the
     // state machines first.  Pair sweep 1 - 2.5 % faster in interleaved runs on one box (0.1736 -> 0.1720 ms, 0.1763 ->
     // 0.1718 ms on another); the reverse assignment changes nothing.
-    if (SWEEP) __builtin_amdgcn_s_setprio(3);
+    if (TS) __builtin_amdgcn_s_setprio(3);
     __shared__ int s_next;
     __shared__ int s_nlist;
     __shared__ int s_hist[256];
+    __shared__ unsigned short s_rowslot[32], s_colslot[kWave];   // TILED pair sweep: LDS slots of the tile's row / column vehicles
     int b, w;
     if (b_in >= 0) {
         b = b_in; w = w_in;
@@ -457,6 +461,13 @@ __device__ __forceinline__ void gjk_planar_body(const GjkSwarmParams& p, double2
         for (int e = threadIdx.x; e < n_obj * 2 * NC; e += blockDim.x) {
             const int sl = e / (2 * NC), r = e - sl * (2 * NC), q = r / NC, k = r - q * NC;
             const int obj = p.cobjs[obj0 + sl];
+            if (TS && r == 0 && p.ts.out != nullptr) {
+                const int2 ij = p.chunk_ij[w];
+                if (ij.x >= 0) {
+                    if (obj >= ij.x && obj < ij.x + p.tile_a) s_rowslot[obj - ij.x] = (unsigned short)sl;
+                    if (obj >= ij.y && obj < ij.y + kWave) s_colslot[obj - ij.y] = (unsigned short)sl;
+                }
+            }
             double val;
             if (obj < p.n_veh) { const int ee = obj * 2 * NC + r; val = Yrow[ee]; if (ee == fd_e) val += p.fd_h; }
             else {
@@ -487,7 +498,15 @@ __device__ __forceinline__ void gjk_planar_body(const GjkSwarmParams& p, double2
     // Workgroups differ in how much of their share they write before computing (0..3 groups per wave,
     // the rest afterwards), so that every CU has both kinds of work at all times.
     const int ts_before = (b + w) & 3;      // groups per wave written before the gjkNew phases (0..3), the rest after
-    if (SWEEP && p.ts.out != nullptr && ts_before > 0) {
+    const int2 ts_ij = (TS && TILED && p.ts.out != nullptr) ? p.chunk_ij[w] : make_int2(-1, -1);
+    if (TS && TILED && ts_ij.x >= 0 && ts_before > 0) {
+        __builtin_amdgcn_s_setprio(0);
+        tsep_tile_from_xy<NC>(p.ts, xy, VPQ, b, p.n_veh, ts_ij.x, ts_ij.y, p.tile_a, s_rowslot, s_colslot,
+                              reinterpret_cast<double*>(r01), p.ts_tile_rows, 0, ts_before);
+        __builtin_amdgcn_s_setprio(3);
+        __syncthreads();
+    }
+    if (TS && SWEEP && p.ts.out != nullptr && ts_before > 0) {
         __builtin_amdgcn_s_setprio(0);
         tsep_groups_from_xy<NC>(p.ts, xy, VPQ, b, w, p.wgs_per_row, reinterpret_cast<double*>(r01), p.ts_tile_rows,
                                 0, ts_before);
@@ -802,7 +821,13 @@ __device__ __forceinline__ void gjk_planar_body(const GjkSwarmParams& p, double2
     }
     if (FIXUP) __syncthreads();                          // rec / list are reused by the next segment
     }
-    if (SWEEP && p.ts.out != nullptr) {
+    if (TS && TILED && ts_ij.x >= 0) {
+        __syncthreads();                                     // phase 2 has read the records the tile overwrites
+        __builtin_amdgcn_s_setprio(0);
+        tsep_tile_from_xy<NC>(p.ts, xy, VPQ, b, p.n_veh, ts_ij.x, ts_ij.y, p.tile_a, s_rowslot, s_colslot,
+                              reinterpret_cast<double*>(r01), p.ts_tile_rows, ts_before, 1 << 30);
+    }
+    if (TS && SWEEP && p.ts.out != nullptr) {
         __syncthreads();                                     // phase 2 has read the records the tile overwrites
         __builtin_amdgcn_s_setprio(0);
         tsep_groups_from_xy<NC>(p.ts, xy, VPQ, b, w, p.wgs_per_row, reinterpret_cast<double*>(r01), p.ts_tile_rows,
@@ -812,7 +837,7 @@ __device__ __forceinline__ void gjk_planar_body(const GjkSwarmParams& p, double2
 
 template <int NC, int MODE>
 __global__ __launch_bounds__(MODE == 0 ? OBTG_SWEEP_THREADS : 256,
-                             (MODE == 0 && NC <= 11) ? kSweepWavesPerSimd : 1)
+                             (MODE == 0 && NC <= 11) ? kSweepWavesPerSimd : (MODE == 2 ? 4 : 1))   // tiled: four waves per SIMD (tile_height() counts on it)
 void k_gjk_swarm_planar(const GjkSwarmParams p)
 {
     extern __shared__ double2 xy_dyn[];
@@ -834,7 +859,17 @@ __global__ __launch_bounds__(OBTG_SWEEP_THREADS, NC <= 11 ? kSweepWavesPerSimd :
 void k_pair_sweep(const GjkSwarmParams p)
 {
     extern __shared__ double2 xy_dyn[];
-    gjk_planar_body<NC, 0>(p, xy_dyn, -1, -1);
+    gjk_planar_body<NC, 0, true>(p, xy_dyn, -1, -1);
+}
+
+// The pair sweep of LARGE rows (hulls of a row beyond 48 KB of LDS, C4) as one launch: the tiled sweep whose chunks
+// also write the temporal-separation rows of their TA x 64 tile of the pair matrix (tsep_tile_from_xy) -- a chunk has
+// exactly that tile's vehicles staged.  Needs a hull pair list that holds every vehicle pair (build_tiles checks).
+template <int NC>
+__global__ __launch_bounds__(256, 4) void k_pair_sweep_tiled(const GjkSwarmParams p)
+{
+    extern __shared__ double2 xy_dyn[];
+    gjk_planar_body<NC, 2, true>(p, xy_dyn, -1, -1);
 }
 
 // -------------------------------------------------------------------------------------
@@ -2059,11 +2094,20 @@ static int build_tiles(obtg_ctx* c, int /*vp*/)
     for (int i = 0; i < np; ++i) order[i] = i;
     auto key = [&](int i) { return (long)(pa[i] / TA) * nbb + pb[i] / TB; };
     std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return key(x) < key(y); });
-    std::vector<int> chunk_off{ 0 }, cobj_off{ 0 }, cobjs;
+    std::vector<int> chunk_off{ 0 }, cobj_off{ 0 }, cobjs, chunk_ij;
     std::vector<unsigned> pslots(np);
     std::vector<int> slot_of(nobj, -1), touched;
     int max_objs = 0, max_pairs = 0, start = 0;
+    long last_key = -1;
     auto close_chunk = [&](int end) {
+        // the first chunk of a tile writes the tile's temporal-separation rows in the one-launch pair sweep
+        const int i0 = order[start];
+        const long k0 = key(i0);
+        const int ti0 = pa[i0] / TA * TA, tj0 = pb[i0] / TB * TB;
+        const bool first = k0 != last_key && ti0 < c->n_veh - 1 && tj0 < c->n_veh;
+        chunk_ij.push_back(first ? ti0 : -1);
+        chunk_ij.push_back(tj0);
+        last_key = k0;
         for (int o : touched) slot_of[o] = -1;
         max_objs = std::max(max_objs, (int)touched.size());
         max_pairs = std::max(max_pairs, end - start);
@@ -2096,6 +2140,21 @@ static int build_tiles(obtg_ctx* c, int /*vp*/)
     if ((rc = up(c->d_tile_pslots, pslots.data(), pslots.size() * sizeof(unsigned)))) return rc;
     if ((rc = up(c->d_tile_cobj_off, cobj_off.data(), cobj_off.size() * sizeof(int)))) return rc;
     if ((rc = up(c->d_tile_cobjs, cobjs.data(), cobjs.size() * sizeof(int)))) return rc;
+    if ((rc = up(c->d_tile_ij, chunk_ij.data(), chunk_ij.size() * sizeof(int)))) return rc;
+    {   // does the list hold every vehicle pair (i < j)?  Then every tile's vehicles are staged by the tile's chunk.
+        const long nv = c->n_veh, want = nv * (nv - 1) / 2;
+        std::vector<char> seen((size_t)std::max(want, 1L), 0);
+        long have = 0;
+        for (int i = 0; i < np; ++i) {
+            const long a = pa[i], bb = pb[i];
+            if (a < bb && bb < nv) {
+                const long idx = a * nv - a * (a + 1) / 2 - a - 1 + bb;
+                if (!seen[(size_t)idx]) { seen[(size_t)idx] = 1; ++have; }
+            }
+        }
+        c->tile_ts_ok = want > 0 && have == want && TA <= 32;
+    }
+    c->tile_a = TA;
     if (hipStreamSynchronize(c->stream) != hipSuccess) return OBTG_ERR_DEVICE;   // sources are locals
     c->tile_n_chunks = (int)chunk_off.size() - 1;
     c->tile_max_objs = max_objs; c->tile_max_pairs = max_pairs;
@@ -2360,6 +2419,53 @@ int launch_pair_sweep(obtg_ctx* c, const double* dY, int B, double max_sep, doub
         p.ts.n_pairs = c->n_pairs; p.ts.sign = 1.0; p.ts.offset = -(max_sep * max_sep);
         p.ts_tile_rows = tr;
         if (c->fd.Y0) { p.Y = c->fd.Y0; p.fd = 1; p.fd_fixed = c->fd.fixed; p.fd_h = c->fd.h; }
+    }
+    if (!fused && kern && c->dim == 2 && c->polys_planar && c->max_poly_K <= nc && c->n_hull_pairs > 0 && !c->fd_dedup &&
+        c->R == 0 && c->n_obs == 0 && c->n_pairs > 0 && lds > 48 * 1024) {
+        // large rows: the tiled sweep, its chunks writing their tile's separation rows
+        void (*kt)(const GjkSwarmParams) = nullptr;
+        switch (nc) {
+            case 4: kt = k_pair_sweep_tiled<4>; break;
+            case 6: kt = k_pair_sweep_tiled<6>; break;
+            case 8: kt = k_pair_sweep_tiled<8>; break;
+            case 11: kt = k_pair_sweep_tiled<11>; break;
+            case 16: kt = k_pair_sweep_tiled<16>; break;
+            default: break;
+        }
+        const int vpq = nc | 1;
+        int rc = build_tiles(c, vpq);
+        if (rc != OBTG_OK && rc != OBTG_ERR_UNSUPPORTED) return rc;
+        if (rc == OBTG_OK && kt && c->tile_ts_ok) {
+            GjkSwarmParams q = p;
+            q.chunk_off = c->d_tile_chunk_off.as<int>(); q.order = c->d_tile_order.as<int>();
+            q.pslots = c->d_tile_pslots.as<unsigned>(); q.cobj_off = c->d_tile_cobj_off.as<int>();
+            q.cobjs = c->d_tile_cobjs.as<int>(); q.max_objs = c->tile_max_objs;
+            q.chunk_ij = c->d_tile_ij.as<int2>(); q.tile_a = c->tile_a;
+            q.chunk = c->tile_max_pairs; q.wgs_per_row = c->tile_n_chunks;
+            const size_t ldst = planar_lds_bytes<2>(q.max_objs, vpq, q.chunk);
+            const int L = 2 * c->deg + 1, tpf = (L % 2 == 0) ? L + 1 : L;
+            const size_t behind = ldst - (size_t)16 * q.max_objs * vpq;
+            int tr = 64;
+            while (tr >= 8 && (size_t)4 * tr * tpf * sizeof(double) > behind) tr -= 8;
+            if (tr >= 8 && ldst <= 64 * 1024) {
+                q.ts_tile_rows = tr;
+                const size_t npairs = (size_t)c->n_hull_pairs;
+                obtg::DevBuf& hist_out = c->d_gjk_len[c->gjk_len_cur ^ 1];
+                if (c->gjk_history) { if (int rc2 = hist_out.reserve((size_t)B * npairs)) return rc2; }
+                q.B = B;
+                q.len_in = (c->gjk_history && c->gjk_len_rows > 0) ? c->d_gjk_len[c->gjk_len_cur].as<unsigned char>() : nullptr;
+                q.len_in_stride = c->gjk_len_rows == B ? (int)npairs : 0;
+                q.len_out = c->gjk_history ? hist_out.as<unsigned char>() : nullptr;
+                if (c->gjk_history) { c->gjk_len_cur ^= 1; c->gjk_len_rows = B; }
+                if (ldst > 48 * 1024)
+                    OBTG_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(kt),
+                                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldst));
+                ScopedKernelTimer tm(c, OBTG_K_PAIR_SWEEP);
+                hipLaunchKernelGGL(kt, dim3((unsigned)((size_t)B * q.wgs_per_row)), dim3(256), ldst, c->stream, q);
+                OBTG_HIP(c, hipGetLastError());
+                return OBTG_OK;
+            }
+        }
     }
     if (!fused) {      // two launches; each forms the virtual batch's rows itself or asks for the batch (kNeedBatch)
         int rc = launch_temporal_sep(c, dY, B, max_sep, 0, c->n_pairs, false, d_out_sep);

@@ -87,7 +87,10 @@ struct obtg_ctx {
     bool fd_dedup = false;      // reuse row 0's GJK results for bit-identical hull pairs
     obtg::DevBuf d_hp_a, d_hp_b;  // hull pair list
     std::vector<int> h_hp_a, h_hp_b;   // host copy (tile-major chunking of large rows)
-    obtg::DevBuf d_tile_chunk_off, d_tile_order, d_tile_pslots, d_tile_cobj_off, d_tile_cobjs;
+    obtg::DevBuf d_tile_chunk_off, d_tile_order, d_tile_pslots, d_tile_cobj_off, d_tile_cobjs, d_tile_ij;
+    bool tile_ts_ok = false;  // every chunk's tile origin is recorded and the hull pair list holds every vehicle pair: the tiled
+                              // sweep can write the temporal-separation rows of its tiles (one-launch pair sweep of large rows)
+    int tile_a = 8;           // tile height the chunks were cut for
     bool tile_valid = false;
     int tile_n_chunks = 0, tile_max_objs = 0, tile_max_pairs = 0;
     int n_hull_pairs = 0;

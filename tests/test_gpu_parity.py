@@ -633,7 +633,7 @@ def test_gjk_swarm_history_order_does_not_change_results(capi, oracle, synth):
     ctx.close()
 
 
-@pytest.mark.parametrize("shape", ["C3", "small_deg7", "fallback_3d"])
+@pytest.mark.parametrize("shape", ["C3", "small_deg7", "fallback_3d", "tiled_C4", "tiled_deg5"])
 def test_pair_sweep_one_launch_equals_separate_kernels(capi, synth, shape):
     """obtg_pair_sweep_dev (temporal separation + gjkNew sweep as ONE grid) returns what the two
     separate entry points return, bit for bit; shapes without the fused instantiation fall back."""
@@ -642,6 +642,10 @@ def test_pair_sweep_one_launch_equals_separate_kernels(capi, synth, shape):
         N, d, n, M, B = 64, 2, 10, 8, 37
     elif shape == "small_deg7":
         N, d, n, M, B = 9, 2, 7, 3, 21
+    elif shape == "tiled_C4":         # rows beyond 48 KB of LDS: the tiled sweep writes its tiles' separation rows
+        N, d, n, M, B = 256, 2, 15, 5, 3
+    elif shape == "tiled_deg5":       # taller tiles, a ragged last row / column block
+        N, d, n, M, B = 603, 2, 5, 2, 2
     else:
         N, d, n, M, B = 6, 3, 5, 0, 5
     Y = synth.swarm_control_points(N, d, n, seed=21)
