@@ -633,7 +633,7 @@ def test_gjk_swarm_history_order_does_not_change_results(capi, oracle, synth):
     ctx.close()
 
 
-@pytest.mark.parametrize("shape", ["C3", "small_deg7", "fallback_3d", "tiled_C4", "tiled_deg5"])
+@pytest.mark.parametrize("shape", ["C3", "small_deg7", "fallback_3d", "tiled_C4", "tiled_deg5", "tiled_partial"])
 def test_pair_sweep_one_launch_equals_separate_kernels(capi, synth, shape):
     """obtg_pair_sweep_dev (temporal separation + gjkNew sweep as ONE grid) returns what the two
     separate entry points return, bit for bit; shapes without the fused instantiation fall back."""
@@ -644,7 +644,7 @@ def test_pair_sweep_one_launch_equals_separate_kernels(capi, synth, shape):
         N, d, n, M, B = 9, 2, 7, 3, 21
     elif shape == "tiled_C4":         # rows beyond 48 KB of LDS: the tiled sweep writes its tiles' separation rows
         N, d, n, M, B = 256, 2, 15, 5, 3
-    elif shape == "tiled_deg5":       # taller tiles, a ragged last row / column block
+    elif shape in ("tiled_deg5", "tiled_partial"):       # taller tiles, a ragged last row / column block
         N, d, n, M, B = 603, 2, 5, 2, 2
     else:
         N, d, n, M, B = 6, 3, 5, 0, 5
@@ -652,6 +652,9 @@ def test_pair_sweep_one_launch_equals_separate_kernels(capi, synth, shape):
     Yb = synth.fd_batch(Y, B=B, h=0.01)
     Yb[B // 2] += np.random.default_rng(4).normal(0, 2.0, size=Y.shape)
     pa, pb = synth.swarm_pairs(N, M)
+    if shape == "tiled_partial":      # a hull pair list that misses vehicle pairs: the tiles cannot carry the separation rows
+        keep = np.random.default_rng(5).random(len(pa)) < 0.7
+        pa, pb = pa[keep], pb[keep]
     ctx = capi.Context(N, d, n, 0)
     if M:
         ctx.set_polygons(*synth.pack_polys(synth.polygon_obstacles(M, seed=8)))
