@@ -633,7 +633,7 @@ def test_gjk_swarm_history_order_does_not_change_results(capi, oracle, synth):
     ctx.close()
 
 
-@pytest.mark.parametrize("shape", ["C3", "small_deg7", "fallback_3d", "tiled_C4", "tiled_deg5", "tiled_partial"])
+@pytest.mark.parametrize("shape", ["C3", "small_deg7", "fallback_3d", "tiled_C4", "tiled_deg5", "tiled_deg10", "tiled_partial"])
 def test_pair_sweep_one_launch_equals_separate_kernels(capi, synth, shape):
     """obtg_pair_sweep_dev (temporal separation + gjkNew sweep as ONE grid) returns what the two
     separate entry points return, bit for bit; shapes without the fused instantiation fall back."""
@@ -646,6 +646,8 @@ def test_pair_sweep_one_launch_equals_separate_kernels(capi, synth, shape):
         N, d, n, M, B = 256, 2, 15, 5, 3
     elif shape in ("tiled_deg5", "tiled_partial"):       # taller tiles, a ragged last row / column block
         N, d, n, M, B = 603, 2, 5, 2, 2
+    elif shape == "tiled_deg10":
+        N, d, n, M, B = 301, 2, 10, 0, 2
     else:
         N, d, n, M, B = 6, 3, 5, 0, 5
     Y = synth.swarm_control_points(N, d, n, seed=21)
