@@ -2162,6 +2162,23 @@ static int build_tiles(obtg_ctx* c, int /*vp*/)
     return OBTG_OK;
 }
 
+// Workgroups per row of the plain planar sweep: kSweepChunk pairs each, more for small batches (enough workgroups to
+// fill the chip), and more again when the row's objects leave less LDS than that: up to 11 points per hull the kernel
+// runs five workgroups per CU only while a workgroup stays under 160 KB / 5 (C5: 96 objects, 760-pair chunks were
+// 33.5 KB = four per CU; 652-pair chunks are 31.2 KB).
+static int sweep_wgs_per_row(const obtg_ctx* c, int B, int nc)
+{
+    const int np = c->n_hull_pairs, n_obj = c->n_veh + c->n_poly, vpq = nc | 1;
+    int wgs = (np + kSweepChunk - 1) / kSweepChunk;
+    while ((long)B * wgs < 2048 && (np + wgs - 1) / wgs > 256) wgs <<= 1;
+    if (nc <= 11) {
+        const size_t budget = (size_t)160 * 1024 / kSweepWavesPerSimd - 1280;
+        while ((np + wgs - 1) / wgs > 256 && planar_lds_bytes<0>(n_obj, vpq, (np + wgs - 1) / wgs) > budget &&
+               planar_lds_bytes<0>(n_obj, vpq, 256) <= budget) ++wgs;
+    }
+    return wgs;
+}
+
 int launch_gjk_swarm(obtg_ctx* c, const double* dY, int B, int max_iter, int md_cap, int* d_flag,
                      double* d_p1, double* d_p2, double* d_dist, int* d_nsup, int* d_status)
 {
@@ -2177,8 +2194,7 @@ int launch_gjk_swarm(obtg_ctx* c, const double* dY, int B, int max_iter, int md_
     // pairs per lane (measured at C3 in list order: 316 pairs per 256 lanes = 0.281 ms, 1264 pairs =
     // 0.215 ms); with the history order 864-pair chunks do as well as 1264 and leave LDS for a fifth
     // workgroup per CU.  Small batches trade chunk size for enough workgroups to fill the chip.
-    int wgs = (c->n_hull_pairs + kSweepChunk - 1) / kSweepChunk;
-    while ((long)B * wgs < 2048 && (c->n_hull_pairs + wgs - 1) / wgs > 256) wgs <<= 1;
+    const int wgs = sweep_wgs_per_row(c, B, c->deg + 1);
     p.chunk = (c->n_hull_pairs + wgs - 1) / wgs;
     p.wgs_per_row = (c->n_hull_pairs + p.chunk - 1) / p.chunk;
     p.max_iter = max_iter; p.md_cap = md_cap;
@@ -2365,7 +2381,7 @@ bool pair_sweep_is_one_launch(const obtg_ctx* c)
     if (!(nc == 4 || nc == 6 || nc == 8 || nc == 11 || nc == 16)) return false;
     if (!(c->dim == 2 && c->polys_planar && c->max_poly_K <= nc && c->n_hull_pairs > 0 && !c->fd_dedup && c->R == 0 &&
           c->n_obs == 0 && c->n_pairs > 0)) return false;
-    const int wgs = (c->n_hull_pairs + kSweepChunk - 1) / kSweepChunk;
+    const int wgs = sweep_wgs_per_row(c, 1 << 20, nc);
     const int chunk = (c->n_hull_pairs + wgs - 1) / wgs;
     const int n_obj = c->n_veh + c->n_poly, vpq = nc | 1;
     const size_t lds = planar_lds_bytes<0>(n_obj, vpq, chunk);
@@ -2401,8 +2417,7 @@ int launch_pair_sweep(obtg_ctx* c, const double* dY, int B, double max_sep, doub
         p.pa = c->d_hp_a.as<int>(); p.pb = c->d_hp_b.as<int>();
         p.n_veh = c->n_veh; p.dim = c->dim; p.nc = nc; p.n_poly = c->n_poly;
         p.n_poly_pts = c->n_poly_pts; p.n_pairs = c->n_hull_pairs;
-        int wgs = (c->n_hull_pairs + kSweepChunk - 1) / kSweepChunk;
-        while ((long)B * wgs < 2048 && (c->n_hull_pairs + wgs - 1) / wgs > 256) wgs <<= 1;
+        const int wgs = sweep_wgs_per_row(c, B, nc);
         p.chunk = (c->n_hull_pairs + wgs - 1) / wgs;
         p.wgs_per_row = (c->n_hull_pairs + p.chunk - 1) / p.chunk;
         p.max_iter = max_iter; p.md_cap = md_cap;
