@@ -2204,7 +2204,6 @@ int launch_gjk_swarm(obtg_ctx* c, const double* dY, int B, int max_iter, int md_
         p.Y = c->fd.Y0; p.fd = 1; p.fd_fixed = c->fd.fixed; p.fd_h = c->fd.h;
     }
     size_t lds = sizeof(double) * ((size_t)c->n_veh * p.vp + 3 * (size_t)c->n_poly_pts);
-    if (lds > 160 * 1024 - 64) return OBTG_ERR_UNSUPPORTED;
     const bool planar = c->dim == 2 && c->polys_planar;
     if (planar && c->max_poly_K <= c->deg + 1 && c->deg + 1 <= 127) {
         const int nc = c->deg + 1;
@@ -2362,6 +2361,7 @@ int launch_gjk_swarm(obtg_ctx* c, const double* dY, int B, int max_iter, int md_
             return OBTG_OK;
         }
     }
+    if (lds > 160 * 1024 - 64) return OBTG_ERR_UNSUPPORTED;      // the general kernel stages the whole row (the tiled sweep above does not)
     auto kern = planar ? k_gjk_swarm<true> : k_gjk_swarm<false>;
     if (lds > 48 * 1024)
         OBTG_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(kern),

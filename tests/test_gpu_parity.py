@@ -524,7 +524,7 @@ def test_c_abi_error_codes(capi):
     ctx.close(); c3.close(); big.close()
 
 
-@pytest.mark.parametrize("N,n,M", [(256, 15, 5), (600, 5, 3)])
+@pytest.mark.parametrize("N,n,M", [(256, 15, 5), (600, 5, 3), (700, 15, 2)])     # the last: a row of 184 KB, more than a CU's LDS
 def test_gjk_swarm_large_rows_tiled(capi, oracle, synth, N, n, M):
     """Rows whose hulls do not fit LDS (C4's shape: 256 vehicles, degree 15, plus polygons; 600 vehicles of degree 5,
     whose tiles are taller) go through the tile-major chunking; every pair must still match the oracle bit for bit."""
