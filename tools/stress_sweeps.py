@@ -78,5 +78,86 @@ def main():
     print("stress ok: %d trials" % trials)
 
 
+def families(trials, seed):
+    """Bernstein families (temporal separation, speed, angular rate; any DEG_ELEV, with and without point obstacles)
+    and the 3-D sweep, random shapes, against the oracle."""
+    rng = np.random.default_rng(seed)
+    t0 = time.time()
+    for trial in range(trials):
+        d = int(rng.choice([2, 2, 3]))
+        n = int(rng.choice([3, 4, 5, 7, 9, 10, 12, 15, 20]))
+        R = int(rng.choice([0, 0, 1, 3, 10, 30, 100]))
+        N = int(rng.integers(1, 90))
+        n_obs = int(rng.choice([0, 0, 3]))
+        B = int(rng.choice([1, 2, 7]))
+        Y = synth.swarm_control_points(N, d, n, seed=500 + trial)
+        Yb = synth.fd_batch(Y, B=B, h=0.25) if B > 1 else Y[None].copy()
+        obs = rng.uniform(0, 100, size=(n_obs, d)) if n_obs else None
+        tf = rng.uniform(5, 20, size=B)
+        ctx = capi.Context(N, d, n, R, point_obs=obs)
+        Yo = Yb if not n_obs else np.concatenate([Yb, np.broadcast_to(np.repeat(obs.reshape(-1)[:, None], n + 1, 1)[None], (B, n_obs * d, n + 1))], axis=1)
+        nveh_o = N + n_obs
+        r_sep, _, _ = oracle.eval_batch(Yo, tf, nveh_o, d, R, 0.9, 5.0, 1.0, want=("sep",), nthreads=8) if nveh_o > 1 else (None, None, None)
+        _, r_sp, r_an = oracle.eval_batch(Yb, tf, N, d, R, 0.9, 5.0, 1.0, want=("speed", "ang") if d == 2 else ("speed",), nthreads=8)
+
+        def close(got, ref, what):
+            got, ref = np.asarray(got), np.asarray(ref)
+            assert got.shape == ref.shape, (what, got.shape, ref.shape)
+            fin = np.isfinite(ref)
+            assert np.array_equal(np.isnan(got), np.isnan(ref)) and np.array_equal(np.isinf(got), np.isinf(ref)), (what, trial)
+            if fin.any():
+                err = np.max(np.abs(got[fin] - ref[fin]) / np.maximum(1.0, np.abs(ref[fin])))
+                assert err < 1e-9, (what, trial, err, N, d, n, R)
+        if nveh_o > 1:
+            close(ctx.temporal_sep(Yb, 0.9), r_sep, "sep")
+        close(ctx.speed(Yb, tf, 5.0, True), r_sp, "speed")
+        if d == 2:
+            close(ctx.ang_rate(Yb, tf, 1.0), r_an, "ang")
+        ctx.close()
+        print("families trial %d ok: N=%d d=%d n=%d R=%d obs=%d B=%d (%.0f s)" % (trial, N, d, n, R, n_obs, B, time.time() - t0), flush=True)
+    print("families ok: %d trials" % trials)
+
+
+def gjk3d(trials, seed):
+    """The 3-D sweep (and, for shapes outside it, the general kernel) on random 3-D swarms with 3-D polygons against
+    the oracle: flags, statuses (incl. the cycle detector's), support counts exact; distances to 1e-12."""
+    rng = np.random.default_rng(seed)
+    t0 = time.time()
+    for trial in range(trials):
+        n = int(rng.choice([3, 5, 7, 10, 15, 4, 9]))
+        N = int(rng.integers(2, 60))
+        M = int(rng.integers(0, 5))
+        B = int(rng.choice([1, 2, 5, 40]))
+        Y = synth.swarm_control_points(N, 3, n, seed=900 + trial)
+        Yb = synth.fd_batch(Y, B=B, h=0.3) if B > 1 else Y[None].copy()
+        polys = []
+        for _ in range(M):
+            K = int(rng.integers(3, n + 2))
+            polys.append(rng.uniform(0, 100, size=(1, 3)) + rng.normal(0, 6.0, size=(K, 3)))
+        pa, pb = synth.swarm_pairs(N, M)
+        ctx = capi.Context(N, 3, n, 0)
+        if M:
+            ctx.set_polygons(*synth.pack_polys(polys))
+        ctx.set_hull_pairs(pa, pb)
+        for rnd in range(2):
+            r = ctx.gjk_swarm(Yb, md_cap=300)
+            for b in range(0, B, max(1, B // 3)):
+                o = oracle.gjk_pairs(*synth.pack_polys(synth.hulls_from_Y(Yb[b], 3) + polys), pa, pb, md_cap=300, nthreads=8)
+                assert (r["flag"][b] == o["flag"]).all() and (r["n_support"][b] == o["n_support"]).all() and \
+                       (r["status"][b] == o["status"]).all(), ("gjk3d", trial, rnd, N, n, M, B)
+                sep = (o["flag"] == 1) & (o["status"] == 0)
+                for key in ("dist", "c1", "c2"):
+                    if sep.any():
+                        assert np.max(np.abs(r[key][b][sep] - o[key][sep]) / np.maximum(1.0, np.abs(o[key][sep]))) < 1e-12, (key, trial)
+        ctx.close()
+        print("gjk3d trial %d ok: N=%d n=%d M=%d B=%d (%.0f s)" % (trial, N, n, M, B, time.time() - t0), flush=True)
+    print("gjk3d ok: %d trials" % trials)
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "gjk3d":
+        gjk3d(int(sys.argv[2]) if len(sys.argv) > 2 else 40, int(sys.argv[3]) if len(sys.argv) > 3 else 11)
+    elif len(sys.argv) > 1 and sys.argv[1] == "families":
+        families(int(sys.argv[2]) if len(sys.argv) > 2 else 40, int(sys.argv[3]) if len(sys.argv) > 3 else 7)
+    else:
+        main()
