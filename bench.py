@@ -254,12 +254,13 @@ def main():
         ctx_dyn.set_stream(stream2.cuda_stream)
     Yp = None if use_view else dY.data_ptr()
 
-    everything = one_launch and o_an is not None and not two_streams
+    everything = one_launch and not two_streams       # (3-D rows: no angular rate; the 3-D sweep's launch then takes the speed rows too)
 
     def sweeps():
         if everything:       # all four families through one call (two launches at C3: pair sweep, dynamics)
             ctx.constraint_sweep_dev(Yp, d_tf.data_ptr(), B, max_sep, o_sep.data_ptr(), vmax, True, wmax, o_sp.data_ptr(),
-                                     o_an.data_ptr(), g_flag.data_ptr(), g_p1.data_ptr(), g_p2.data_ptr(), g_dist.data_ptr(),
+                                     o_an.data_ptr() if o_an is not None else None, g_flag.data_ptr(), g_p1.data_ptr(),
+                                     g_p2.data_ptr(), g_dist.data_ptr(),
                                      None, g_stat.data_ptr(), 128, 256)
             return
         if one_launch:
@@ -362,6 +363,8 @@ def main():
     if o_an is not None:   # the fused dynamics launch is booked under "ang_rate"
         by["ang_rate"] = by["ang_rate"] + 8 * N * L
     by["pair_sweep"] = by["temporal_sep"] + by["gjk"]    # when a shape falls back to two launches they report separately
+    if stats.get("pair_sweep", (0.0, 0))[1] > 0 and stats.get("speed", (0.0, 0))[1] == 0 and o_an is None:
+        by["pair_sweep"] += by["speed"]             # 3-D rows: the sweep's launch wrote the speed rows as well
     for name in KNAMES:
         ms, cnt = stats.get(name, (0.0, 0))
         if cnt == 0:

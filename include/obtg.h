@@ -225,8 +225,10 @@ int obtg_gjk_swarm_dev(obtg_ctx*, const double* dY, int B, int max_iter, int md_
  * drain under the VALU-bound gjkNew work of the other wavefronts.  Outputs are those of the two
  * separate calls, bit for bit.  Rows whose hulls exceed 48 KB of LDS (256 vehicles of degree 15) take the
  * tiled form of the same idea when the hull pair list holds every vehicle pair: a chunk of the tiled sweep
- * stages one TA x 64 tile of the pair matrix and writes that tile's separation rows.  Shapes without
- * either kernel (3-D, DEG_ELEV > 0, point obstacles, de-duplication on) fall back to the two launches. */
+ * stages one TA x 64 tile of the pair matrix and writes that tile's separation rows.  3-D rows: the 3-D
+ * sweep's workgroups run their part of the separation block first (obtg_constraint_sweep_dev: and of the
+ * speed rows), one launch as well.  Shapes without such a kernel (DEG_ELEV > 0, point obstacles,
+ * de-duplication on) fall back to the two launches. */
 int obtg_pair_sweep_dev(obtg_ctx*, const double* dY, int B, double max_sep, double* d_out_sep,
                         int max_iter, int md_cap, int* d_flag, double* d_p1, double* d_p2,
                         double* d_dist, int* d_nsup, int* d_status);

@@ -909,13 +909,11 @@ __host__ __device__ constexpr size_t sweep3d_lds_bytes(int n_obj, int nc, int ch
 }
 
 template <int NC>
-__global__ __launch_bounds__(256) void k_gjk_swarm_3d(const GjkSwarmParams p)
+__device__ __forceinline__ void gjk_swarm3d_body(const GjkSwarmParams& p, double* lds)
 {
     using gjk::Simplex;
     using gjk::Vert;
     constexpr int PITCH = 4 * NC + 2;
-    extern __shared__ double2 xyz_dyn[];
-    double* lds = reinterpret_cast<double*>(xyz_dyn);
     __shared__ int s_next;
     __shared__ int s_hist[256];
     const int per = 8 * p.wgs_per_row;
@@ -1156,6 +1154,35 @@ __global__ __launch_bounds__(256) void k_gjk_swarm_3d(const GjkSwarmParams p)
         if (p.status) p.status[o] = status;
         if (p.len_out) p.len_out[o] = (unsigned char)min(n_scans, 255);
     }
+}
+
+template <int NC>
+__global__ __launch_bounds__(256) void k_gjk_swarm_3d(const GjkSwarmParams p)
+{
+    extern __shared__ double2 xyz_dyn[];
+    gjk_swarm3d_body<NC>(p, reinterpret_cast<double*>(xyz_dyn));
+}
+
+// The 3-D sweep as the ONE launch of an evaluation batch (the SwarmOfAerialVehicles shapes: a step is otherwise three
+// launch-latency-sized kernels).  Workgroup (row b, part w) first runs its part of the row's temporal-separation block
+// and of its speed rows -- normsq_elev_body, the stand-alone kernels' code on its own staging area behind the sweep's
+// LDS, hence the same bits -- and then the gjkNew sweep; the Bernstein stores drain meanwhile.
+template <int NC>
+__global__ __launch_bounds__(256) void k_pair_sweep_3d(const GjkSwarmParams p, const NsParams ts, const NsParams sp,
+                                                       const int ns_offset /* doubles */)
+{
+    extern __shared__ double2 xyz_dyn[];
+    double* lds = reinterpret_cast<double*>(xyz_dyn);
+    const int per = 8 * p.wgs_per_row;
+    const int grp = (int)blockIdx.x / per, g8 = (int)blockIdx.x - grp * per;
+    const int b = grp * 8 + (g8 & 7), w = g8 >> 3;
+    if (b >= p.B) return;
+    if (ts.out != nullptr) normsq_elev_body<NC, 3, 0, false, false>(ts, b, w, lds + ns_offset);
+    if (sp.out != nullptr) {
+        __syncthreads();
+        normsq_elev_body<NC, 3, 1, false, false>(sp, b, w, lds + ns_offset);
+    }
+    gjk_swarm3d_body<NC>(p, lds);
 }
 
 // which vehicles of row b differ (bitwise) from row 0: chg[b][v]
@@ -2180,7 +2207,7 @@ static int sweep_wgs_per_row(const obtg_ctx* c, int B, int nc)
 }
 
 int launch_gjk_swarm(obtg_ctx* c, const double* dY, int B, int max_iter, int md_cap, int* d_flag,
-                     double* d_p1, double* d_p2, double* d_dist, int* d_nsup, int* d_status)
+                     double* d_p1, double* d_p2, double* d_dist, int* d_nsup, int* d_status, SweepFold* fold)
 {
     if (B <= 0 || c->n_hull_pairs <= 0) return OBTG_OK;
     GjkSwarmParams p{};
@@ -2351,7 +2378,56 @@ int launch_gjk_swarm(obtg_ctx* c, const double* dY, int B, int max_iter, int md_
             p.len_in_stride = c->gjk_len_rows == B ? (int)np : 0;
             p.len_out = c->gjk_history ? hist_out.as<unsigned char>() : nullptr;
             const unsigned grid = (unsigned)(((size_t)B + 7) / 8 * 8 * p.wgs_per_row);
-            {
+            // one launch for the batch: fold the row's temporal-separation block (and speed rows) into the sweep
+            bool folded = false;
+            if (fold && fold->d_out_sep && c->dim == 3 && c->R == 0 && c->n_obs == 0 && c->n_pairs > 0 && !c->fd_dedup) {
+                void (*kf3)(const GjkSwarmParams, const NsParams, const NsParams, int) = nullptr;
+                switch (nc) {
+                    case 4: kf3 = k_pair_sweep_3d<4>; break;
+                    case 6: kf3 = k_pair_sweep_3d<6>; break;
+                    case 8: kf3 = k_pair_sweep_3d<8>; break;
+                    case 11: kf3 = k_pair_sweep_3d<11>; break;
+                    case 16: kf3 = k_pair_sweep_3d<16>; break;
+                    default: break;
+                }
+                int rc2 = ensure_tables(c);
+                if (rc2) return rc2;
+                const int W = p.wgs_per_row, vlen3 = 3 * nc, vp3 = (vlen3 % 2 == 0) ? vlen3 + 1 : vlen3;
+                const int L = 2 * c->deg + 1, tpf = (L % 2 == 0) ? L + 1 : L, tr = 16;
+                NsParams ts{}, sp{};
+                ts.Y = p.Y; ts.obs = nullptr; ts.pairs = c->d_pairs.as<int2>(); ts.W2 = c->d_w2.as<double>();
+                ts.Tt = c->d_Tt.as<double>(); ts.Td = c->d_Td.as<double>(); ts.out = fold->d_out_sep;
+                ts.n_veh = c->n_veh; ts.n_obj = c->n_obj; ts.R = 0; ts.item_begin = 0; ts.item_count = c->n_pairs;
+                const int groups_t = (c->n_pairs + kWave - 1) / kWave;
+                ts.groups_per_wg = (groups_t + W - 1) / W; ts.wgs_per_row = W; ts.waves = 4;
+                ts.stage_all = 1; ts.stage_slots = c->n_obj; ts.tile_rows = tr; ts.tiling = 0; ts.tiles = nullptr;
+                ts.sign = 1.0; ts.offset = -(fold->max_sep * fold->max_sep);
+                ts.fd = p.fd; ts.fd_fixed = p.fd_fixed; ts.fd_h = p.fd_h;
+                size_t ns_bytes = sizeof(double) * ((size_t)ts.stage_slots * vp3 + (size_t)4 * tr * tpf);
+                if (fold->d_out_speed && fold->d_tf) {
+                    sp = ts;
+                    sp.pairs = nullptr; sp.tf = fold->d_tf; sp.out = fold->d_out_speed; sp.n_obj = c->n_veh;
+                    sp.item_count = c->n_veh;
+                    const int groups_s = (c->n_veh + kWave - 1) / kWave;
+                    sp.groups_per_wg = (groups_s + W - 1) / W;
+                    sp.stage_all = 0; sp.stage_slots = std::min(c->n_veh, kWave * sp.groups_per_wg);
+                    const double b2 = fold->speed_bound * fold->speed_bound;
+                    sp.sign = fold->speed_is_max ? -1.0 : 1.0; sp.offset = fold->speed_is_max ? b2 : -b2;
+                    ns_bytes = std::max(ns_bytes, sizeof(double) * ((size_t)sp.stage_slots * vp3 + (size_t)4 * tr * tpf));
+                }
+                const size_t lds_a = (lds3 + 15) / 16 * 16;
+                if (kf3 && lds_a + ns_bytes <= 64 * 1024) {
+                    if (lds_a + ns_bytes > 48 * 1024)
+                        OBTG_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(kf3),
+                                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds_a + ns_bytes)));
+                    ScopedKernelTimer t(c, OBTG_K_PAIR_SWEEP);
+                    hipLaunchKernelGGL(kf3, dim3(grid), dim3(256), lds_a + ns_bytes, c->stream, p, ts, sp, (int)(lds_a / sizeof(double)));
+                    folded = true;
+                    fold->did_sep = true;
+                    fold->did_speed = sp.out != nullptr;
+                }
+            }
+            if (!folded) {
                 ScopedKernelTimer t(c, OBTG_K_GJK);
                 hipLaunchKernelGGL(k3, dim3(grid), dim3(256), lds3, c->stream, p);
             }
@@ -2391,7 +2467,8 @@ bool pair_sweep_is_one_launch(const obtg_ctx* c)
 }
 
 int launch_pair_sweep(obtg_ctx* c, const double* dY, int B, double max_sep, double* d_out_sep, int max_iter,
-                      int md_cap, int* d_flag, double* d_p1, double* d_p2, double* d_dist, int* d_nsup, int* d_status)
+                      int md_cap, int* d_flag, double* d_p1, double* d_p2, double* d_dist, int* d_nsup, int* d_status,
+                      SweepFold* speed)
 {
     // with a virtual finite-difference batch (c->fd) only the one-launch kernel applies: it forms the rows while
     // staging them; OBTG_ERR_UNSUPPORTED tells the caller to materialise the batch instead
@@ -2482,10 +2559,17 @@ int launch_pair_sweep(obtg_ctx* c, const double* dY, int B, double max_sep, doub
             }
         }
     }
-    if (!fused) {      // two launches; each forms the virtual batch's rows itself or asks for the batch (kNeedBatch)
-        int rc = launch_temporal_sep(c, dY, B, max_sep, 0, c->n_pairs, false, d_out_sep);
+    if (!fused) {
+        // the 3-D sweep takes the separation block (and speed rows) into its launch where it can; otherwise two
+        // launches, each forming the virtual batch's rows itself or asking for the batch (kNeedBatch)
+        SweepFold f;
+        if (speed) f = *speed;
+        f.max_sep = max_sep; f.d_out_sep = d_out_sep; f.did_sep = f.did_speed = false;
+        int rc = launch_gjk_swarm(c, dY, B, max_iter, md_cap, d_flag, d_p1, d_p2, d_dist, d_nsup, d_status, &f);
         if (rc) return rc;
-        return launch_gjk_swarm(c, dY, B, max_iter, md_cap, d_flag, d_p1, d_p2, d_dist, d_nsup, d_status);
+        if (speed) speed->did_speed = f.did_speed;
+        if (f.did_sep) return OBTG_OK;
+        return launch_temporal_sep(c, dY, B, max_sep, 0, c->n_pairs, false, d_out_sep);
     }
     const size_t np = (size_t)c->n_hull_pairs;
     obtg::DevBuf& hist_out = c->d_gjk_len[c->gjk_len_cur ^ 1];

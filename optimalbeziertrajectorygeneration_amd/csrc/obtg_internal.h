@@ -151,10 +151,24 @@ int binrow_offset(obtg_ctx* c, int n);  // ensures row C(n,.) is resident; retur
 int launch_temporal_sep(obtg_ctx* c, const double* dY, int B, double max_sep, int pair_begin,
                         int pair_count, bool min_only, double* d_out);
 struct NsParams;
+// What launch_gjk_swarm may fold into its 3-D sweep launch (k_pair_sweep_3d): the row's temporal-separation block and,
+// when d_out_speed is set, its speed rows.  did_* report what the launch took over.
+struct SweepFold {
+    double max_sep = 0.0;
+    double* d_out_sep = nullptr;
+    const double* d_tf = nullptr;
+    double speed_bound = 0.0;
+    int speed_is_max = 1;
+    double* d_out_speed = nullptr;
+    bool did_sep = false, did_speed = false;
+};
 int plan_temporal_sep(obtg_ctx* c, const double* dY, int B, int pair_begin, int pair_count, double* d_out, NsParams& p);
 size_t temporal_sep_lds_bytes(const obtg_ctx* c, NsParams& p, size_t budget);
+// speed (optional): the speed rows of the same batch, folded into the launch where a kernel does that (3-D sweeps);
+// speed->did_speed tells the caller whether they still have to be launched
 int launch_pair_sweep(obtg_ctx* c, const double* dY, int B, double max_sep, double* d_out_sep, int max_iter,
-                      int md_cap, int* d_flag, double* d_p1, double* d_p2, double* d_dist, int* d_nsup, int* d_status);
+                      int md_cap, int* d_flag, double* d_p1, double* d_p2, double* d_dist, int* d_nsup, int* d_status,
+                      SweepFold* speed = nullptr);
 int launch_temporal_sep_fd(obtg_ctx* c, const double* dY0, int n_pert, const int* d_prow, const int* d_pcol,
                            const double* d_pval, double max_sep, double* d_out);
 int launch_speed(obtg_ctx* c, const double* dY, const double* d_tf, int B, double bound, int is_max,
@@ -181,7 +195,7 @@ int launch_gjk_pairs(obtg_ctx* c, const double* d_soa, const int* d_off, const i
                      double* d_p1, double* d_p2, double* d_dist, short* d_trace, int trace_cap,
                      int* d_nsup, int* d_status, bool planar);
 int launch_gjk_swarm(obtg_ctx* c, const double* dY, int B, int max_iter, int md_cap, int* d_flag,
-                     double* d_p1, double* d_p2, double* d_dist, int* d_nsup, int* d_status);
+                     double* d_p1, double* d_p2, double* d_dist, int* d_nsup, int* d_status, SweepFold* fold = nullptr);
 int launch_min_dist(obtg_ctx* c, const double* d_curves, int K, const int* d_pa, const int* d_pb,
                     int n_pairs, double eps, int max_iter, int md_cap, int max_depth, int max_nodes,
                     double* d_stack, double* d_res, int* d_info);

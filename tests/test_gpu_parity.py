@@ -1307,3 +1307,69 @@ def test_small_host_calls_through_mapped_memory_equal_the_staged_path(capi, synt
                 assert np.array_equal(np.asarray(got), np.asarray(want), equal_nan=True)
         ctx.close()
         ref.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N,n,M,B", [(8, 10, 0, 217), (36, 5, 2, 40), (70, 7, 3, 3), (130, 3, 0, 2)])
+def test_3d_sweep_as_one_launch_equals_separate_calls(capi, synth, N, n, M, B):
+    """3-D rows: obtg_constraint_sweep_dev is ONE launch (k_pair_sweep_3d: the sweep's workgroups first run their part of
+    the row's temporal-separation block and speed rows with the stand-alone kernels' code) -- the same bits as
+    obtg_temporal_sep_dev, obtg_speed_dev and obtg_gjk_swarm_dev; on a materialised batch and inside an FD view; rows
+    split over several workgroups (small B) and more than 64 vehicles (two speed groups) included."""
+    import torch
+    rng = np.random.default_rng(N)
+    Y = synth.swarm_control_points(N, 3, n, seed=N)
+    polys = [rng.uniform(0, 100, size=(1, 3)) + rng.normal(0, 6.0, size=(int(rng.integers(3, n + 2)), 3)) for _ in range(M)]
+    pa, pb = synth.swarm_pairs(N, M)
+    ctx = capi.Context(N, 3, n, 0)
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    if M:
+        ctx.set_polygons(*synth.pack_polys(polys))
+    ctx.set_hull_pairs(pa, pb)
+    h = 1e-3
+    d0 = torch.from_numpy(Y).cuda()
+    Bv = min(B, N * 3 * (n - 1) + 1)
+    dY = torch.empty((B,) + Y.shape, dtype=torch.float64, device="cuda")
+    ctx.fd_batch_dev(d0.data_ptr(), 1, h, min(B, Bv), dY.data_ptr())
+    dtf = torch.from_numpy(np.linspace(3.0, 9.0, B)).cuda()
+    P, L, Ps = ctx.num_pairs, 2 * n + 1, len(pa)
+
+    def bufs():
+        f64, i32 = torch.float64, torch.int32
+        return dict(sep=torch.full((B, P * L), np.nan, dtype=f64, device="cuda"), flag=torch.full((B, Ps), -7, dtype=i32, device="cuda"),
+                    p1=torch.zeros((B, Ps, 3), dtype=f64, device="cuda"), p2=torch.zeros((B, Ps, 3), dtype=f64, device="cuda"),
+                    dist=torch.zeros((B, Ps), dtype=f64, device="cuda"), ns=torch.zeros((B, Ps), dtype=i32, device="cuda"),
+                    st=torch.zeros((B, Ps), dtype=i32, device="cuda"), sp=torch.full((B, ctx.len_speed), np.nan, dtype=f64, device="cuda"))
+
+    def separate(src, o):
+        ctx.temporal_sep_dev(src, B, 0.9, o["sep"].data_ptr())
+        ctx.speed_dev(src, dtf.data_ptr(), B, 4.0, True, o["sp"].data_ptr())
+        ctx.gjk_swarm_dev(src, B, o["flag"].data_ptr(), o["p1"].data_ptr(), o["p2"].data_ptr(), o["dist"].data_ptr(),
+                          o["ns"].data_ptr(), o["st"].data_ptr(), 128, 500)
+
+    def fused(src, o):
+        ctx.constraint_sweep_dev(src, dtf.data_ptr(), B, 0.9, o["sep"].data_ptr(), 4.0, True, 1.5, o["sp"].data_ptr(), None,
+                                 o["flag"].data_ptr(), o["p1"].data_ptr(), o["p2"].data_ptr(), o["dist"].data_ptr(),
+                                 o["ns"].data_ptr(), o["st"].data_ptr(), 128, 500)
+    for view in (False, True):
+        if view and B > Bv:
+            continue
+        a, b = bufs(), bufs()
+        if view:
+            ctx.fd_view_begin(d0.data_ptr(), 1, h, B)
+        src = None if view else dY.data_ptr()
+        separate(src, a)
+        ctx.reset_kernel_stats(); ctx.set_profiling(True)
+        fused(src, b)
+        fused(src, b)
+        if view:
+            ctx.fd_view_end()
+        torch.cuda.synchronize()
+        ks = ctx.kernel_stats()
+        ctx.set_profiling(False)
+        assert ks.get("pair_sweep", (0.0, 0))[1] == 2 and ks.get("speed", (0.0, 0))[1] == 0 and ks.get("temporal_sep", (0.0, 0))[1] == 0, ks
+        for key in a:
+            assert torch.equal(a[key].view(torch.uint8), b[key].view(torch.uint8)), (key, view)
+        assert not torch.isnan(b["sep"]).any() and not torch.isnan(b["sp"]).any()
+    ctx.set_stream(0)
+    ctx.close()
