@@ -23,10 +23,10 @@ std::vector<double> elev_conv_padded(int L_in, int R, int extra, bool normalise,
 
 // ---------------------------------------------------------------- device buffers
 // Device buffer that grows.  A staging buffer of the host entry points (`io`) serves requests of up to kZeroCopyBytes
-// from mapped pinned HOST memory instead: the kernel reads its few hundred bytes of control points and writes its few
-// KB of results across PCIe itself, and a one-row SLSQP callback is memcpy + ONE launch + synchronize + memcpy instead
+// from mapped pinned HOST memory instead: the kernel reads its few hundred bytes of control points and writes its
+// results (up to one 64-vehicle row of separation rows, 339 KB) across PCIe itself, and a one-row SLSQP callback is memcpy + ONE launch + synchronize + memcpy instead
 // of two DMA transfers around the launch (tools/latency_probe.py: 30 -> 15 us per call at Example1's size).
-constexpr size_t kZeroCopyBytes = 64u << 10;
+constexpr size_t kZeroCopyBytes = 512u << 10;
 struct DevBuf {
     void* p = nullptr;          // the address kernels use for the current request
     size_t cap = 0;             // capacity behind p

@@ -1285,7 +1285,7 @@ def test_constraint_sweep_equals_separate_calls(capi, synth, shape):
 def test_small_host_calls_through_mapped_memory_equal_the_staged_path(capi, synth, monkeypatch):
     """One-row host calls keep their control points and results in mapped pinned host memory (the kernel reads and
     writes across PCIe itself; capi.cpp DevBuf::reserve).  Same bits as the device-staged path (OBTG_ZERO_COPY=0), for
-    shapes on both sides of the size limits (8 KB in, 64 KB out), and when small and large calls alternate on one
+    shapes on both sides of the size limits (8 KB in, 512 KB out), and when small and large calls alternate on one
     context (the staging buffers switch between the mapped block and device memory)."""
     tf1 = np.array([7.5])
     for (N, d, n, R) in [(2, 2, 10, 30), (8, 3, 10, 0), (36, 3, 5, 0), (46, 2, 10, 0), (47, 2, 10, 0), (64, 2, 10, 0)]:
