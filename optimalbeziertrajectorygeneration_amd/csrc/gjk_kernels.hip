@@ -2126,11 +2126,13 @@ static int build_tiles(obtg_ctx* c, int /*vp*/)
     std::vector<int> slot_of(nobj, -1), touched;
     int max_objs = 0, max_pairs = 0, start = 0;
     long last_key = -1;
+    bool tile_split = false;        // a tile cut into several chunks (duplicate pairs): no chunk holds all of its vehicles
     auto close_chunk = [&](int end) {
         // the first chunk of a tile writes the tile's temporal-separation rows in the one-launch pair sweep
         const int i0 = order[start];
         const long k0 = key(i0);
         const int ti0 = pa[i0] / TA * TA, tj0 = pb[i0] / TB * TB;
+        if (k0 == last_key) tile_split = true;
         const bool first = k0 != last_key && ti0 < c->n_veh - 1 && tj0 < c->n_veh;
         chunk_ij.push_back(first ? ti0 : -1);
         chunk_ij.push_back(tj0);
@@ -2179,7 +2181,7 @@ static int build_tiles(obtg_ctx* c, int /*vp*/)
                 if (!seen[(size_t)idx]) { seen[(size_t)idx] = 1; ++have; }
             }
         }
-        c->tile_ts_ok = want > 0 && have == want && TA <= 32;
+        c->tile_ts_ok = want > 0 && have == want && TA <= 32 && !tile_split;
     }
     c->tile_a = TA;
     if (hipStreamSynchronize(c->stream) != hipSuccess) return OBTG_ERR_DEVICE;   // sources are locals

@@ -633,7 +633,7 @@ def test_gjk_swarm_history_order_does_not_change_results(capi, oracle, synth):
     ctx.close()
 
 
-@pytest.mark.parametrize("shape", ["C3", "small_deg7", "fallback_3d", "tiled_C4", "tiled_deg5", "tiled_deg10", "tiled_partial"])
+@pytest.mark.parametrize("shape", ["C3", "small_deg7", "fallback_3d", "tiled_C4", "tiled_deg5", "tiled_deg10", "tiled_partial", "tiled_dups"])
 def test_pair_sweep_one_launch_equals_separate_kernels(capi, synth, shape):
     """obtg_pair_sweep_dev (temporal separation + gjkNew sweep as ONE grid) returns what the two
     separate entry points return, bit for bit; shapes without the fused instantiation fall back."""
@@ -644,7 +644,7 @@ def test_pair_sweep_one_launch_equals_separate_kernels(capi, synth, shape):
         N, d, n, M, B = 9, 2, 7, 3, 21
     elif shape == "tiled_C4":         # rows beyond 48 KB of LDS: the tiled sweep writes its tiles' separation rows
         N, d, n, M, B = 256, 2, 15, 5, 3
-    elif shape in ("tiled_deg5", "tiled_partial"):       # taller tiles, a ragged last row / column block
+    elif shape in ("tiled_deg5", "tiled_partial", "tiled_dups"):       # taller tiles, a ragged last row / column block
         N, d, n, M, B = 603, 2, 5, 2, 2
     elif shape == "tiled_deg10":
         N, d, n, M, B = 301, 2, 10, 0, 2
@@ -654,6 +654,8 @@ def test_pair_sweep_one_launch_equals_separate_kernels(capi, synth, shape):
     Yb = synth.fd_batch(Y, B=B, h=0.01)
     Yb[B // 2] += np.random.default_rng(4).normal(0, 2.0, size=Y.shape)
     pa, pb = synth.swarm_pairs(N, M)
+    if shape == "tiled_dups":         # pairs listed twice: a tile overflows into a second chunk, no chunk stages all its vehicles
+        pa, pb = np.concatenate([pa, pa[:4000]]), np.concatenate([pb, pb[:4000]])
     if shape == "tiled_partial":      # a hull pair list that misses vehicle pairs: the tiles cannot carry the separation rows
         keep = np.random.default_rng(5).random(len(pa)) < 0.7
         pa, pb = pa[keep], pb[keep]
