@@ -1,0 +1,81 @@
+"""Where two correct float64 evaluations of the angular-rate constraint disagree by more than 1e-9: the exact value
+(rational arithmetic) of the worst element, next to the oracle (reference's order of operations), the device's
+reference-order kernel and the device's fast order.   python tools/angrate_conditioning.py [n] [R]"""
+import os, sys
+from fractions import Fraction as F
+from math import comb
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from optimalbeziertrajectorygeneration_amd import _capi as capi, synth
+from oracle import oracle
+
+
+def elev(a, R):
+    n = len(a) - 1
+    return [sum(F(comb(n, j) * comb(R, i - j), comb(n + R, i)) * a[j] for j in range(max(0, i - R), min(n, i) + 1))
+            for i in range(n + R + 1)]
+
+
+def diff(a, tf):          # derivative, elevated back to the same degree (as the reference's Bezier.diff does)
+    n = len(a) - 1
+    d = [F(n) / tf * (a[i + 1] - a[i]) for i in range(n)]
+    return elev(d, 1)
+
+
+def mul(a, b):
+    m, n = len(a) - 1, len(b) - 1
+    return [sum(F(comb(m, j) * comb(n, k - j), comb(m + n, k)) * a[j] * b[k - j] for j in range(max(0, k - n), min(m, k) + 1))
+            for k in range(m + n + 1)]
+
+
+def exact_ang(x, y, tf, R, w):
+    x, y = elev([F(v) for v in x], R), elev([F(v) for v in y], R)
+    tf = F(tf)
+    xD, yD = diff(x, tf), diff(y, tf)
+    xDD, yDD = diff(xD, tf), diff(yD, tf)
+    num = [p - q for p, q in zip(mul(yDD, xD), mul(xDD, yD))]
+    den = [p + q for p, q in zip(mul(xD, xD), mul(yD, yD))]
+    n2, d2 = mul(num, num), mul(den, den)
+    return [F(w) * F(w) - a / b if b != 0 else None for a, b in zip(n2, d2)], den
+
+
+def main():
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 10
+    R = int(sys.argv[2]) if len(sys.argv) > 2 else 60
+    N, B = 64, 6
+    worst = None
+    for seed in range(6):
+        Y = synth.swarm_control_points(N, 2, n, seed=40 + seed)
+        Yb = synth.fd_batch(Y, B=B, h=0.5)
+        tf = np.linspace(4.0, 25.0, B)
+        _, _, ref = oracle.eval_batch(Yb, tf, N, 2, R, 0.9, 5.0, 1.0, want=("ang",), nthreads=8)
+        res = {}
+        for order in (0, 1):
+            ctx = capi.Context(N, 2, n, R)
+            ctx.set_ang_rate_order(order)
+            res[order] = ctx.ang_rate(Yb, tf, 1.0)
+            ctx.close()
+        fin = np.isfinite(ref)
+        err = np.where(fin, np.abs(res[0] - ref) / np.maximum(1.0, np.abs(ref)), 0.0)
+        i = np.unravel_index(np.argmax(err), err.shape)
+        if worst is None or err[i] > worst[0]:
+            worst = (err[i], seed, i, Yb, tf, ref, res)
+    e, seed, (b, col), Yb, tf, ref, res = worst
+    L4 = 4 * (n + R) + 1
+    veh, k = col // L4, col % L4
+    print("worst element: seed %d row %d vehicle %d coefficient %d of %d; fast order vs oracle %.3e" % (seed, b, veh, k, L4, e))
+    ex, den = exact_ang(Yb[b, 2 * veh], Yb[b, 2 * veh + 1], tf[b], R, 1.0)
+    exact = float(ex[k])
+    for name, v in (("oracle (reference order, CPU)", ref[b, col]), ("device, reference order", res[1][b, col]), ("device, fast order", res[0][b, col])):
+        print("  %-32s %.17g   |value - exact| / max(1, |exact|) = %.3e" % (name, v, abs(F(float(v)) - ex[k]) / max(1, abs(ex[k]))))
+    print("  exact %.17g;  den1_k relative to the largest |den1| of the curve: %.3e" % (exact, float(abs(den[min(k // 2, len(den) - 1)]) / max(abs(d) for d in den))))
+    # the whole row of this vehicle: how many elements are off by more than 1e-9 in each evaluation
+    exf = np.array([float(v) for v in ex])
+    sl = slice(veh * L4, (veh + 1) * L4)
+    for name, arr in (("oracle", ref[b, sl]), ("device ref order", res[1][b, sl]), ("device fast order", res[0][b, sl])):
+        d = np.abs(arr - exf) / np.maximum(1.0, np.abs(exf))
+        print("  %-18s max error vs exact over the vehicle's %d coefficients: %.3e (%d above 1e-9)" % (name, L4, d.max(), int((d > 1e-9).sum())))
+
+
+if __name__ == "__main__":
+    main()

@@ -100,19 +100,21 @@ def families(trials, seed):
         r_sep, _, _ = oracle.eval_batch(Yo, tf, nveh_o, d, R, 0.9, 5.0, 1.0, want=("sep",), nthreads=8) if nveh_o > 1 else (None, None, None)
         _, r_sp, r_an = oracle.eval_batch(Yb, tf, N, d, R, 0.9, 5.0, 1.0, want=("speed", "ang") if d == 2 else ("speed",), nthreads=8)
 
-        def close(got, ref, what):
+        def close(got, ref, what, tol=1e-9):
             got, ref = np.asarray(got), np.asarray(ref)
             assert got.shape == ref.shape, (what, got.shape, ref.shape)
             fin = np.isfinite(ref)
             assert np.array_equal(np.isnan(got), np.isnan(ref)) and np.array_equal(np.isinf(got), np.isinf(ref)), (what, trial)
             if fin.any():
                 err = np.max(np.abs(got[fin] - ref[fin]) / np.maximum(1.0, np.abs(ref[fin])))
-                assert err < 1e-9, (what, trial, err, N, d, n, R)
+                assert err < tol, (what, trial, err, N, d, n, R)
         if nveh_o > 1:
             close(ctx.temporal_sep(Yb, 0.9), r_sep, "sep")
         close(ctx.speed(Yb, tf, 5.0, True), r_sp, "speed")
         if d == 2:
-            close(ctx.ang_rate(Yb, tf, 1.0), r_an, "ang")
+            # with DEG_ELEV > 0 near-singular elements (vehicle almost at rest) differ by up to ~1e-8 between any two
+            # orders of operations, the oracle's included (tools/angrate_conditioning.py)
+            close(ctx.ang_rate(Yb, tf, 1.0), r_an, "ang", 1e-9 if R == 0 else 5e-8)
         ctx.close()
         print("families trial %d ok: N=%d d=%d n=%d R=%d obs=%d B=%d (%.0f s)" % (trial, N, d, n, R, n_obs, B, time.time() - t0), flush=True)
     print("families ok: %d trials" % trials)
