@@ -365,6 +365,10 @@ def main():
     by["pair_sweep"] = by["temporal_sep"] + by["gjk"]    # when a shape falls back to two launches they report separately
     if stats.get("pair_sweep", (0.0, 0))[1] > 0 and stats.get("speed", (0.0, 0))[1] == 0 and o_an is None:
         by["pair_sweep"] += by["speed"]             # 3-D rows: the sweep's launch wrote the speed rows as well
+    one_launch_step = (stats.get("pair_sweep", (0.0, 0))[1] > 0 and stats.get("ang_rate", (0.0, 0))[1] == 0 and
+                       stats.get("speed", (0.0, 0))[1] == 0 and o_an is not None)
+    if one_launch_step:
+        by["pair_sweep"] += by["ang_rate"]          # planar rows: the speed / angular-rate groups ran as the grid's last workgroups
     for name in KNAMES:
         ms, cnt = stats.get(name, (0.0, 0))
         if cnt == 0:
@@ -386,6 +390,10 @@ def main():
     if dom["kernel"] == "pair_sweep":
         note = ("one launch: the gjkNew sweep's workgroups (VALU bound) also write their row's temporal-separation "
                 "block (HBM-write bound); bytes = both families' algorithmic bytes; see DESIGN.md 4.7")
+        if one_launch_step:
+            note = ("the whole step is this one launch: the gjkNew sweep's workgroups also write their row's temporal-"
+                    "separation block, and the speed / angular-rate groups run as the grid's last workgroups; bytes = "
+                    "all four families' algorithmic bytes; see DESIGN.md 4.7")
     if dom["kernel"] == "gjk":
         note = ("gjkNew sweep: VALU-issue bound by nature (PMC at C3: ~85 % VALU busy, LDS 34 %), reported against "
                 "HBM as the contract asks; see DESIGN.md 4.3")

@@ -667,7 +667,8 @@ __device__ __forceinline__ void diff_elev1(const double (&p)[NC], double val, do
 // Two waves (threads 0..127 of the workgroup) on the 64 items of `group`; the other waves of a larger workgroup must
 // have returned before the call (the barriers below count the surviving waves).  k_dynamics2 is this on its own grid;
 // the pair sweep runs it in workgroups of its own grid (gjk_kernels.hip k_pair_sweep<NC, true>).
-template <int NC>
+// HALF_SP: the speed rows leave through a 32-row tile in two halves (5.4 KB less LDS: the form the pair sweep's grid runs)
+template <int NC, bool HALF_SP = false>
 __device__ __forceinline__ void dynamics2_group(const AngParams& p, double* lds, const int group)
 {
     constexpr int N = NC - 1, L2 = 2 * N + 1, L4 = 4 * N + 1;
@@ -698,11 +699,22 @@ __device__ __forceinline__ void dynamics2_group(const AngParams& p, double* lds,
                 sd = fma(W2n[k * NC + j], fma(xD[j], xD[k - j], yD[j] * yD[k - j]), sd);
             q1[k] = sd;
         }
-        if (p.out_speed) {
+        if (p.out_speed && !HALF_SP) {
 #pragma unroll
             for (int k = 0; k < L2; ++k) tile_sp[lane * L2 + k] = p.sp_sign * q1[k] + p.sp_offset;
             wave_sync();
             flush_full<L2, L2>(tile_sp, p.out_speed, (size_t)it0 * L2, n_valid, lane);
+        }
+        if (p.out_speed && HALF_SP) {
+            for (int h0 = 0; h0 < n_valid; h0 += kWave / 2) {
+                if (lane >= h0 && lane < h0 + kWave / 2) {
+#pragma unroll
+                    for (int k = 0; k < L2; ++k) tile_sp[(lane - h0) * L2 + k] = p.sp_sign * q1[k] + p.sp_offset;
+                }
+                wave_sync();
+                flush_full<L2, L2>(tile_sp, p.out_speed, ((size_t)it0 + h0) * L2, min(kWave / 2, n_valid - h0), lane);
+                wave_sync();
+            }
         }
     } else {
         const ctab_t Wn = as_ctab(p.Wn);

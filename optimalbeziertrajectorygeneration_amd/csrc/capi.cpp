@@ -942,10 +942,10 @@ int obtg_constraint_sweep_dev(obtg_ctx* c, const double* dY, const double* d_tf,
     return with_batch(c, dY, B, [&](const double* src) {
         SweepFold sp;
         sp.d_tf = d_tf; sp.speed_bound = speed_bound; sp.speed_is_max = speed_is_max;
-        sp.d_out_speed = d_out_ang ? nullptr : d_out_speed;        // with an angular-rate output the dynamics launch writes both
+        sp.d_out_speed = d_out_speed; sp.d_out_ang = d_out_ang; sp.max_rate = max_rate;
         int rc = launch_pair_sweep(c, src, B, max_sep, d_out_sep, max_iter, md_cap, d_flag, d_p1, d_p2, d_dist, d_nsup, d_status, &sp);
         if (rc) return rc;
-        if (sp.did_speed) return (int)OBTG_OK;
+        if (sp.did_dynamics || (sp.did_speed && !d_out_ang)) return (int)OBTG_OK;
         return launch_dynamics(c, src, d_tf, B, speed_bound, speed_is_max, max_rate, d_out_speed, d_out_ang);
     });
 }

@@ -258,6 +258,8 @@ struct GjkSwarmParams {
     int fd, fd_fixed;                  // fd != 0: Y is ONE row; row b >= 1 = Y with its (b-1)-th free control point
     double fd_h;                       //          advanced by fd_h (the rows obtg_fd_batch_dev writes), formed while staging
     TsepXYParams ts;                   // pair sweep: the row's temporal-separation block (ts.out != nullptr)
+    AngParams dyn;                     // pair sweep: speed / angular-rate groups run by the grid's LAST workgroups (dyn.out != nullptr)
+    int dyn_first_block;               //             first of them
     int ts_tile_rows;
     int* __restrict__ flag;
     double* __restrict__ p1;
@@ -859,6 +861,15 @@ __global__ __launch_bounds__(OBTG_SWEEP_THREADS, NC <= 11 ? kSweepWavesPerSimd :
 void k_pair_sweep(const GjkSwarmParams p)
 {
     extern __shared__ double2 xy_dyn[];
+    if (p.dyn.out != nullptr && (int)blockIdx.x >= p.dyn_first_block) {
+        // the speed / angular-rate evaluation of the batch, one 64-vehicle group per workgroup, on the grid's last
+        // block ids: they are dispatched as the sweep's workgroups drain and fill the slots the tail leaves empty
+        // (on the FIRST block ids the launch takes 0.201 instead of 0.187 ms).  Under the sweep's 96-VGPR bound this
+        // body spills (43 dwords); the gjkNew loop is not touched by it (no scratch access at all in this build).
+        if (threadIdx.x >= 2 * kWave) return;
+        dynamics2_group<NC, true>(p.dyn, reinterpret_cast<double*>(xy_dyn), (int)blockIdx.x - p.dyn_first_block);
+        return;
+    }
     gjk_planar_body<NC, 0, true>(p, xy_dyn, -1, -1);
 }
 
@@ -2580,7 +2591,29 @@ int launch_pair_sweep(obtg_ctx* c, const double* dY, int B, double max_sep, doub
     p.len_in = (c->gjk_history && c->gjk_len_rows > 0) ? c->d_gjk_len[c->gjk_len_cur].as<unsigned char>() : nullptr;
     p.len_in_stride = c->gjk_len_rows == B ? (int)np : 0;
     p.len_out = c->gjk_history ? hist_out.as<unsigned char>() : nullptr;
-    const unsigned grid = (unsigned)(((size_t)B + 7) / 8 * 8 * p.wgs_per_row);
+    unsigned grid = (unsigned)(((size_t)B + 7) / 8 * 8 * p.wgs_per_row);
+    // the speed / angular-rate groups of the batch as the grid's last workgroups (they fill the slots the sweep's tail
+    // leaves empty): when the caller wants them and their 26 KB of LDS fit the sweep's allocation class
+    static const bool fold_dyn = !(getenv("OBTG_FOLD_DYNAMICS") && getenv("OBTG_FOLD_DYNAMICS")[0] == '0');
+    if (fold_dyn && speed && speed->d_out_ang && speed->d_out_speed && speed->d_tf && c->d_ang_w22n.p != nullptr) {
+        const int L4 = 4 * c->deg + 1, L2 = 2 * c->deg + 1;
+        const size_t lds_dyn = sizeof(double) * ((size_t)kWave * L4 + (size_t)(kWave / 2) * L2);
+        const size_t budget = (size_t)160 * 1024 / kSweepWavesPerSimd - 1280;
+        if (nc <= 11 && std::max(lds, lds_dyn) <= budget) {
+            AngParams& d = p.dyn;
+            d.Y = p.Y; d.tf = speed->d_tf; d.out = speed->d_out_ang; d.out_speed = speed->d_out_speed;
+            d.n_veh = c->n_veh; d.total = B * c->n_veh;
+            d.w2 = speed->max_rate * speed->max_rate;
+            const double b2 = speed->speed_bound * speed->speed_bound;
+            d.sp_sign = speed->speed_is_max ? -1.0 : 1.0; d.sp_offset = speed->speed_is_max ? b2 : -b2;
+            d.W2n = c->d_ang_w2n.as<double>(); d.W22n = c->d_ang_w22n.as<double>(); d.Wn = c->d_ang_wn.as<double>();
+            d.fd = p.fd; d.fd_fixed = p.fd_fixed; d.fd_h = p.fd_h;
+            p.dyn_first_block = (int)grid;
+            grid += (unsigned)((d.total + kWave - 1) / kWave);
+            lds = std::max(lds, lds_dyn);
+            speed->did_dynamics = true;
+        }
+    }
     {
         ScopedKernelTimer tm(c, OBTG_K_PAIR_SWEEP);
         hipLaunchKernelGGL(kern, dim3(grid), dim3(OBTG_SWEEP_THREADS), lds, c->stream, p);

@@ -160,7 +160,9 @@ struct SweepFold {
     double speed_bound = 0.0;
     int speed_is_max = 1;
     double* d_out_speed = nullptr;
-    bool did_sep = false, did_speed = false;
+    double max_rate = 0.0;          // planar rows: with d_out_ang the speed / angular-rate groups may join the sweep's grid
+    double* d_out_ang = nullptr;
+    bool did_sep = false, did_speed = false, did_dynamics = false;
 };
 int plan_temporal_sep(obtg_ctx* c, const double* dY, int B, int pair_begin, int pair_count, double* d_out, NsParams& p);
 size_t temporal_sep_lds_bytes(const obtg_ctx* c, NsParams& p, size_t budget);

@@ -1272,11 +1272,16 @@ def test_constraint_sweep_equals_separate_calls(capi, synth, shape):
             ctx.fd_view_begin(d0.data_ptr(), 1, h, B)
         src = None if view else dY.data_ptr()
         separate(src, a)
+        ctx.reset_kernel_stats(); ctx.set_profiling(True)
         fused(src, b)
         fused(src, b)                                                # second call: history-ordered schedule
         if view:
             ctx.fd_view_end()
         torch.cuda.synchronize()
+        ks = ctx.kernel_stats()
+        ctx.set_profiling(False)
+        if shape == "C3":       # the whole step is ONE launch: the dynamics groups are the grid's last workgroups
+            assert ks.get("pair_sweep", (0.0, 0))[1] == 2 and ks.get("ang_rate", (0.0, 0))[1] == 0, ks
         for key in a:
             assert torch.equal(a[key].view(torch.uint8), b[key].view(torch.uint8)), (key, view)
     ctx.set_stream(0)
