@@ -57,6 +57,21 @@ def main():
             torch.cuda.synchronize()
             for i, (x, y) in enumerate(zip(a, b)):
                 assert np.array_equal(x.cpu().numpy(), y.cpu().numpy(), equal_nan=True), ("fused != separate", trial, rnd, i, N, n, M, B, Ps)
+        # every family in one call (planar rows: the dynamics groups inside the sweep's grid) against the separate launches
+        dtf = torch.from_numpy(np.linspace(3.0, 9.0, B)).to(dev)
+        sp_a = torch.full((B, ctx.len_speed), np.nan, dtype=torch.float64, device=dev)
+        an_a = torch.full((B, ctx.len_ang_rate), np.nan, dtype=torch.float64, device=dev)
+        sp_b, an_b = torch.full_like(sp_a, np.nan), torch.full_like(an_a, np.nan)
+        ctx.dynamics_dev(dY.data_ptr(), dtf.data_ptr(), B, 4.0, True, 1.5, sp_a.data_ptr(), an_a.data_ptr())
+        c = bufs()
+        ctx.constraint_sweep_dev(dY.data_ptr(), dtf.data_ptr(), B, 0.9, c[0].data_ptr(), 4.0, True, 1.5, sp_b.data_ptr(), an_b.data_ptr(),
+                                 c[1].data_ptr(), c[2].data_ptr(), c[3].data_ptr(), c[4].data_ptr(), c[5].data_ptr(), c[6].data_ptr(), 128, 300)
+        torch.cuda.synchronize()
+        for i, (x, y) in enumerate(zip(a, c)):
+            if i == 0 and not P:
+                continue
+            assert np.array_equal(x.cpu().numpy(), y.cpu().numpy(), equal_nan=True), ("constraint sweep != separate", trial, i, N, n, M, B)
+        assert torch.equal(sp_a.view(torch.uint8), sp_b.view(torch.uint8)) and torch.equal(an_a.view(torch.uint8), an_b.view(torch.uint8)), ("dynamics", trial, N, n)
         fl, ns, st, di = (a[1].cpu().numpy(), a[5].cpu().numpy(), a[6].cpu().numpy(), a[4].cpu().numpy())
         c1, c2 = a[2].cpu().numpy(), a[3].cpu().numpy()
         for r in range(B):
