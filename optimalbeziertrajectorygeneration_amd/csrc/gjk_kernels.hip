@@ -848,14 +848,10 @@ void k_gjk_swarm_planar(const GjkSwarmParams p)
 
 // the same grid when it also writes the temporal-separation blocks (p.ts.out set): own symbol, so that
 // profiles tell the pair sweep from the plain GJK sweep.
-// DYN: the whole constraint evaluation of the batch in ONE launch.  Every row gets one more workgroup, whose first two
-// waves run the speed / angular-rate evaluation of 64 vehicles (dynamics2_group, bern_device.h: latency bound, one
-// wave per SIMD on its own grid) while the other workgroups of the CU keep the VALU busy with gjkNew.  id -> (row, w)
-// as in gjk_planar_body with W + 1 workgroups per row; w == W is the dynamics workgroup.
-// Tried and not kept: the speed / angular-rate evaluation in the SAME grid (one more workgroup per row running
-// bern_device.h's dynamics2_group beside the sweep's workgroups).  Under the sweep's 96-VGPR budget that body spills
-// (121 registers inlined, which also cost the gjkNew loop 16 more scratch accesses: 0.268 ms for the launch; out of
-// line: 0.283 ms) -- against 0.183 + 0.024 ms as two launches, or 0.194 ms for both on two streams.
+// With p.dyn set the launch is the whole constraint evaluation of the batch: its last workgroups run the speed /
+// angular-rate groups (see below).  Round 1 tried a dynamics workgroup per ROW inside the rows' id range: under the
+// 96-VGPR bound the inlined body cost the gjkNew loop 16 scratch accesses (0.268 ms for the launch; out of line:
+// 0.283 ms) against 0.183 + 0.024 ms as two launches.
 template <int NC>
 __global__ __launch_bounds__(OBTG_SWEEP_THREADS, NC <= 11 ? kSweepWavesPerSimd : 1)
 void k_pair_sweep(const GjkSwarmParams p)
