@@ -25,7 +25,8 @@
 #include "bern_device.h"
 #pragma clang fp contract(off)
 
-constexpr int kSweepChunk = 864;   // hull pairs per workgroup of the planar sweep (see launch_gjk_swarm)
+constexpr int kSweepChunk = 864;       // hull pairs per workgroup of the plain planar sweep (see launch_gjk_swarm)
+constexpr int kPairSweepChunk = 1280;  // ... and of the one-launch pair sweep (see kPairSweepWavesPerSimd)
 
 namespace obtg {
 
@@ -399,6 +400,11 @@ __host__ __device__ constexpr size_t planar_lds_bytes(int cap_obj, int vpq, int 
 // 0.146 ms).  Five waves need <= 96 VGPRs (7 spilled at NC = 11) and <= 32 KB of LDS per workgroup,
 // hence 864-pair chunks; six waves (80 VGPRs, 24 spilled) lose again.
 constexpr int kSweepWavesPerSimd = 5;
+// The one-launch pair sweep (separation block, dynamics groups in its tail) does better at FOUR waves per SIMD and two
+// workgroups per C3 row: 128 VGPRs (no spills, also none in the dynamics groups), a third fewer stagings and sorts per
+// row, 32-row transposition passes.  Interleaved runs on one box: 5 waves / 864-pair chunks 0.1872 ms, 4 / 864
+// 0.1855, 4 / 1280 0.1819 -- while the plain gjkNew sweep still prefers five (0.129 against 0.142 ms).
+constexpr int kPairSweepWavesPerSimd = 4;
 // packed support indices (i1 | i2 << 16) as the 16-bit record form i1 | i2 << 8 (indices < 128 here)
 __device__ __forceinline__ int rec8(int ii) { return (ii & 0xff) | ((ii >> 8) & 0xff00); }
 
@@ -853,7 +859,7 @@ void k_gjk_swarm_planar(const GjkSwarmParams p)
 // 96-VGPR bound the inlined body cost the gjkNew loop 16 scratch accesses (0.268 ms for the launch; out of line:
 // 0.283 ms) against 0.183 + 0.024 ms as two launches.
 template <int NC>
-__global__ __launch_bounds__(OBTG_SWEEP_THREADS, NC <= 11 ? kSweepWavesPerSimd : 1)
+__global__ __launch_bounds__(OBTG_SWEEP_THREADS, NC <= 11 ? kPairSweepWavesPerSimd : 1)
 void k_pair_sweep(const GjkSwarmParams p)
 {
     extern __shared__ double2 xy_dyn[];
@@ -2202,13 +2208,13 @@ static int build_tiles(obtg_ctx* c, int /*vp*/)
 // fill the chip), and more again when the row's objects leave less LDS than that: up to 11 points per hull the kernel
 // runs five workgroups per CU only while a workgroup stays under 160 KB / 5 (C5: 96 objects, 760-pair chunks were
 // 33.5 KB = four per CU; 652-pair chunks are 31.2 KB).
-static int sweep_wgs_per_row(const obtg_ctx* c, int B, int nc)
+static int sweep_wgs_per_row(const obtg_ctx* c, int B, int nc, int chunk_pairs = kSweepChunk, int waves_per_simd = kSweepWavesPerSimd)
 {
     const int np = c->n_hull_pairs, n_obj = c->n_veh + c->n_poly, vpq = nc | 1;
-    int wgs = (np + kSweepChunk - 1) / kSweepChunk;
+    int wgs = (np + chunk_pairs - 1) / chunk_pairs;
     while ((long)B * wgs < 2048 && (np + wgs - 1) / wgs > 256) wgs <<= 1;
     if (nc <= 11) {
-        const size_t budget = (size_t)160 * 1024 / kSweepWavesPerSimd - 1280;
+        const size_t budget = (size_t)160 * 1024 / waves_per_simd - 1280;
         while ((np + wgs - 1) / wgs > 256 && planar_lds_bytes<0>(n_obj, vpq, (np + wgs - 1) / wgs) > budget &&
                planar_lds_bytes<0>(n_obj, vpq, 256) <= budget) ++wgs;
     }
@@ -2466,7 +2472,7 @@ bool pair_sweep_is_one_launch(const obtg_ctx* c)
     if (!(nc == 4 || nc == 6 || nc == 8 || nc == 11 || nc == 16)) return false;
     if (!(c->dim == 2 && c->polys_planar && c->max_poly_K <= nc && c->n_hull_pairs > 0 && !c->fd_dedup && c->R == 0 &&
           c->n_obs == 0 && c->n_pairs > 0)) return false;
-    const int wgs = sweep_wgs_per_row(c, 1 << 20, nc);
+    const int wgs = sweep_wgs_per_row(c, 1 << 20, nc, kPairSweepChunk, kPairSweepWavesPerSimd);
     const int chunk = (c->n_hull_pairs + wgs - 1) / wgs;
     const int n_obj = c->n_veh + c->n_poly, vpq = nc | 1;
     const size_t lds = planar_lds_bytes<0>(n_obj, vpq, chunk);
@@ -2503,7 +2509,7 @@ int launch_pair_sweep(obtg_ctx* c, const double* dY, int B, double max_sep, doub
         p.pa = c->d_hp_a.as<int>(); p.pb = c->d_hp_b.as<int>();
         p.n_veh = c->n_veh; p.dim = c->dim; p.nc = nc; p.n_poly = c->n_poly;
         p.n_poly_pts = c->n_poly_pts; p.n_pairs = c->n_hull_pairs;
-        const int wgs = sweep_wgs_per_row(c, B, nc);
+        const int wgs = sweep_wgs_per_row(c, B, nc, kPairSweepChunk, kPairSweepWavesPerSimd);
         p.chunk = (c->n_hull_pairs + wgs - 1) / wgs;
         p.wgs_per_row = (c->n_hull_pairs + p.chunk - 1) / p.chunk;
         p.max_iter = max_iter; p.md_cap = md_cap;
@@ -2594,7 +2600,7 @@ int launch_pair_sweep(obtg_ctx* c, const double* dY, int B, double max_sep, doub
     if (fold_dyn && speed && speed->d_out_ang && speed->d_out_speed && speed->d_tf && c->d_ang_w22n.p != nullptr) {
         const int L4 = 4 * c->deg + 1, L2 = 2 * c->deg + 1;
         const size_t lds_dyn = sizeof(double) * ((size_t)kWave * L4 + (size_t)(kWave / 2) * L2);
-        const size_t budget = (size_t)160 * 1024 / kSweepWavesPerSimd - 1280;
+        const size_t budget = (size_t)160 * 1024 / kPairSweepWavesPerSimd - 1280;
         if (nc <= 11 && std::max(lds, lds_dyn) <= budget) {
             AngParams& d = p.dyn;
             d.Y = p.Y; d.tf = speed->d_tf; d.out = speed->d_out_ang; d.out_speed = speed->d_out_speed;
