@@ -106,3 +106,24 @@ def test_rccl_path_with_one_rank():
     assert plain["config"]["checksum"] == rccl["config"]["checksum"]
     line = _bench(["--gpus", "1", "--force-dist", "--backend", "nccl", "--steps", "4", "--warmup", "2", "--no-cpu", "--workload", "C2"])
     assert line["n_gpus"] == 1 and line["value"] > 0
+
+
+def test_default_bench_line_keeps_the_contract():
+    """`python bench.py` as the driver runs it (shortened): ONE JSON line with the contract's keys, the C3 workload as one
+    launch per step, `roofline` and `cpu_baseline` objects complete, and the bench's own check of its device buffers
+    against the oracle green."""
+    d = _bench(["--steps", "12", "--warmup", "3", "--cpu-seconds", "1.5"])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 12 and d["warmup"] == 3 and d["higher_is_better"] is True
+    assert d["unit"] == "constraint-evals/s" and d["dtype"] == "f64" and d["vs_baseline"] is None
+    assert d["config"]["workload"].startswith("C3") and d["config"]["launches_per_step"] == 1
+    assert abs(d["value"] - d["config"]["evals_per_step_per_gpu"] / (d["ms_per_step"] * 1e-3)) < 2e-3 * d["value"]
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0 and r["kernel"] == "pair_sweep"
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-4 and 0.2 < r["frac"] < 1.0 and "traffic" in r
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["cores"] == 1 and c["value"] > 0 and c["unit"] == d["unit"] and c["sample"]
+    p = d["parity_check"]
+    assert p["ok"] is True and p["flags_equal"] is True and p["status_nonok"] == 0 and p["max_rel"] < 1e-9
