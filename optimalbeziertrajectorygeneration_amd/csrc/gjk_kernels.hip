@@ -14,7 +14,9 @@
 // polygons of one evaluation row in LDS (structure-of-arrays per vehicle, odd pitch) and
 // its lanes walk consecutive pairs of that row.
 #include <algorithm>
+#include <cstdio>
 #include <cstdlib>
+#include <vector>
 
 #include "gjk_device.h"
 #include "gjk_true.h"
@@ -25,8 +27,7 @@
 #include "bern_device.h"
 #pragma clang fp contract(off)
 
-constexpr int kSweepChunk = 864;       // hull pairs per workgroup of the plain planar sweep (see launch_gjk_swarm)
-constexpr int kPairSweepChunk = 1280;  // ... and of the one-launch pair sweep (see kPairSweepWavesPerSimd)
+constexpr int kSweepChunk = 864;       // hull pairs per workgroup of the general sweeps (the fixed-count sweeps: sweep_shape())
 
 namespace obtg {
 
@@ -262,12 +263,15 @@ struct GjkSwarmParams {
     AngParams dyn;                     // pair sweep: speed / angular-rate groups run by the grid's LAST workgroups (dyn.out != nullptr)
     int dyn_first_block;               //             first of them
     int ts_tile_rows;
+    unsigned long long* timeline;      // diagnostics (OBTG_TIMELINE): per workgroup [start, end, hw id, -] on the 100 MHz clock
     int* __restrict__ flag;
     double* __restrict__ p1;
     double* __restrict__ p2;
     double* __restrict__ dist;
     int* nsup;
     int* status;
+    int refill_min = 1;                // planar sweeps: idle lanes of a wave wait until this many can refill together
+    int passes = 1;                    // MODE 0: chunks a workgroup takes one after the other (w-th workgroup of a row: chunks w*passes ..)
 };
 
 template <bool PLANAR>
@@ -390,9 +394,9 @@ __device__ __forceinline__ void support_fixed(const double2* __restrict__ o1, co
 template <int MODE>
 __host__ __device__ constexpr size_t planar_lds_bytes(int cap_obj, int vpq, int chunk)
 {
-    // objects | r01 int2[chunk], plist int[chunk] | ext int[2 cap_obj] | list / pnat int[chunk] | r2 u16[chunk] | MODE 0, 2: ord u16[chunk]
-    return 16 * (size_t)cap_obj * vpq + 12 * (size_t)chunk + 8 * (size_t)cap_obj +
-           4 * (size_t)chunk + 2 * (size_t)chunk + (MODE != 1 ? 2 * (size_t)chunk : 0);
+    // objects | rec int2[chunk], plist u32[chunk] | ext int[2 cap_obj] | MODE 1: list int[chunk]; MODE 0, 2: ord u16[chunk]
+    // (14 bytes per pair for the sweeps: five workgroups of 1264 pairs and 72 objects per CU)
+    return 16 * (size_t)cap_obj * vpq + 12 * (size_t)chunk + 8 * (size_t)cap_obj + (MODE == 1 ? 4 : 2) * (size_t)chunk;
 }
 
 #define OBTG_SWEEP_THREADS 256      // 512-thread workgroups (half as many stagings per row) measured no faster
@@ -404,9 +408,12 @@ constexpr int kSweepWavesPerSimd = 5;
 // workgroups per C3 row: 128 VGPRs (no spills, also none in the dynamics groups), a third fewer stagings and sorts per
 // row, 32-row transposition passes.  Interleaved runs on one box: 5 waves / 864-pair chunks 0.1872 ms, 4 / 864
 // 0.1855, 4 / 1280 0.1819 -- while the plain gjkNew sweep still prefers five (0.129 against 0.142 ms).
-constexpr int kPairSweepWavesPerSimd = 4;
-// packed support indices (i1 | i2 << 16) as the 16-bit record form i1 | i2 << 8 (indices < 128 here)
-__device__ __forceinline__ int rec8(int ii) { return (ii & 0xff) | ((ii >> 8) & 0xff00); }
+#ifndef OBTG_PS_WAVES
+#define OBTG_PS_WAVES 5
+#endif
+constexpr int kPairSweepWavesPerSimd = OBTG_PS_WAVES;
+// packed support indices (i1 | i2 << 16) as the 10-bit record form i1 | i2 << 5 (indices < 32 in the fixed-count sweeps)
+__device__ __forceinline__ int rec5(int ii) { return (ii & 31) | ((ii >> 11) & (31 << 5)); }
 
 // (b_in, w_in): row / workgroup-in-row when the caller has already decoded them (>= 0: the one-launch
 // pair sweep), else decoded from blockIdx here.
@@ -443,23 +450,22 @@ __device__ __forceinline__ void gjk_planar_body(const GjkSwarmParams& p, double2
     } else {
         b = (int)(blockIdx.x / p.wgs_per_row); w = (int)(blockIdx.x - b * p.wgs_per_row);
     }
-    // c0 .. c1: positions this workgroup walks (MODE 0: local indices l, pair k = w * chunk + l)
+    // c0 .. c1: positions this workgroup walks (MODE 0: local indices l of its current pass, pair k = cbase + l)
     int c0 = SWEEP ? 0 : (TILED ? p.chunk_off[w] : w * p.chunk);
-#define OWN(w_, l_, W_) ((w_) * p.chunk + (l_))
-    int c1 = SWEEP ? max(0, min(p.n_pairs - w * p.chunk, p.chunk))
-                   : (TILED ? p.chunk_off[w + 1] : min(p.n_pairs, c0 + p.chunk));
+    int cbase = 0;                                  // MODE 0: first pair of the chunk in hand (see the pass loop)
+#define OWN(w_, l_, W_) (cbase + (l_))
+    int c1 = SWEEP ? 0 : (TILED ? p.chunk_off[w + 1] : min(p.n_pairs, c0 + p.chunk));
     const int obj0 = TILED ? p.cobj_off[w] : 0;
     const int n_obj = TILED ? p.cobj_off[w + 1] - obj0 : p.n_veh + p.n_poly;     // staged objects
     const int cap_obj = TILED ? p.max_objs : n_obj;                                // LDS slots reserved
-    // per-pair records of phase 1 -> phase 2:  r01.x = (flag+1) | status << 2 | keys << 4 | n_support << 8,
-    // r01.y = A.i1 | A.i2 << 8 | B.i1 << 16 | B.i2 << 24,  r2 = C.i1 | C.i2 << 8
+    // per-pair records of phase 1 -> phase 2 (8 bytes):  r01.x = (flag+1) | status << 2 | keys << 4 | n_support << 8,
+    // r01.y = the final simplex as support indices, five bits each: A.i1 | A.i2 << 5 | B.i1 << 10 | B.i2 << 15 | C.i1 << 20 | C.i2 << 25
+    static_assert(NC <= 32, "five-bit support indices in the phase-1 records");
     int2* r01 = reinterpret_cast<int2*>(xy + cap_obj * VPQ);
     unsigned* plist = reinterpret_cast<unsigned*>(r01 + p.chunk);   // [chunk] packed slots (a | b << 16) per position
     int* ext = reinterpret_cast<int*>(plist + p.chunk);            // [cap_obj][2]: (first argmax x, first argmin x)
     int* list = ext + 2 * cap_obj;                                  // FIXUP: compacted pair indices of a segment
-    unsigned* pnat = reinterpret_cast<unsigned*>(list);           // MODE 0, 2: packed slots per local index l
-    unsigned short* r2 = reinterpret_cast<unsigned short*>(list + p.chunk);
-    unsigned short* ord = r2 + p.chunk;                            // MODE 0, 2: position -> local index l
+    unsigned short* ord = reinterpret_cast<unsigned short*>(list);  // MODE 0, 2: position -> local index l
 
     // ---- stage vehicles (rows x, y of the evaluation row) and padded polygons
     const double* Yrow = p.fd ? p.Y : p.Y + (size_t)b * p.n_veh * 2 * NC;
@@ -542,7 +548,14 @@ __device__ __forceinline__ void gjk_planar_body(const GjkSwarmParams& p, double2
     const bool shortcut = p.max_iter >= 3 && p.md_cap >= 2;
     const unsigned char* chg = FIXUP ? p.chg + (size_t)b * p.n_veh : nullptr;
 
-    for (int seg0 = 0; seg0 < (FIXUP ? p.n_pairs : 1); seg0 += p.chunk) {
+    // MODE 0: a workgroup takes p.passes chunks of its row one after the other on the one staging of the row (fewer,
+    // longer workgroups: the launch is a whole number of rounds of the chip, see sweep_shape())
+    for (int seg0 = 0; seg0 < (FIXUP ? p.n_pairs : (SWEEP ? p.passes * p.chunk : 1)); seg0 += p.chunk) {
+    if (SWEEP) {
+        cbase = w * p.passes * p.chunk + seg0;
+        c1 = max(0, min(p.n_pairs - cbase, p.chunk));
+        if (c1 == 0) break;                               // uniform
+    }
     if (FIXUP) {
         if (threadIdx.x == 0) s_nlist = 0;
         __syncthreads();
@@ -589,15 +602,13 @@ __device__ __forceinline__ void gjk_planar_body(const GjkSwarmParams& p, double2
             for (int l = threadIdx.x; l < n_loc; l += blockDim.x) {
                 const int kq = pair_of(l);
                 const int pos = atomicAdd(&s_hist[255 - len[kq]], 1);
-                const unsigned ab = slots_of(l, kq);
                 ord[pos] = (unsigned short)l;
-                plist[pos] = ab;
-                pnat[l] = ab;
+                plist[pos] = slots_of(l, kq);
             }
         } else {
             for (int l = threadIdx.x; l < n_loc; l += blockDim.x) {
                 ord[l] = (unsigned short)l;
-                plist[l] = pnat[l] = slots_of(l, pair_of(l));
+                plist[l] = slots_of(l, pair_of(l));
             }
         }
     } else {
@@ -624,7 +635,10 @@ __device__ __forceinline__ void gjk_planar_body(const GjkSwarmParams& p, double2
         s.B = s.A; s.C = s.A; old = s;
         for (;;) {
             const unsigned long long want = __ballot(k < 0 && !exhausted);
-            if (want) {
+            // Refill in batches: the refill path and the two-point step that every fresh pair starts with are paid by
+            // the whole wave whenever ANY lane refills, so idle lanes wait until p.refill_min of them are idle (or
+            // nothing else runs); see tools/refill_sim.py for the trade against idle lane-rounds.
+            if (want && (__popcll(want) >= p.refill_min || __ballot(k >= 0) == 0ull)) {
                 const int leader = __ffsll((long long)want) - 1;
                 int base = 0;
                 if (lane == leader) base = atomicAdd(&s_next, __popcll(want));
@@ -661,8 +675,7 @@ __device__ __forceinline__ void gjk_planar_body(const GjkSwarmParams& p, double2
                                      A2.v.x == pbn.x && A2.v.y == pbn.y);
                                 if (m) {
                                     r01[slot] = make_int2((1 + 1) | (OBTG_ST_OK << 2) | (gjk::kA << 4) | (nsup << 8),
-                                                          rec8(A1.ii));
-                                    r2[slot] = 0;
+                                                          rec5(A1.ii));
                                     k = -1;
                                 }
                             }
@@ -701,8 +714,7 @@ __device__ __forceinline__ void gjk_planar_body(const GjkSwarmParams& p, double2
                 }
                 if (flag != -2) {
                     r01[slot] = make_int2((flag + 1) | (status << 2) | ((old.keys & 7) << 4) | (min(nsup, 0xffffff) << 8),
-                                          rec8(old.A.ii) | (rec8(old.B.ii) << 16));
-                    r2[slot] = (unsigned short)rec8(old.C.ii);
+                                          rec5(old.A.ii) | (rec5(old.B.ii) << 10) | (rec5(old.C.ii) << 20));
                     k = -1;
                 }
             }
@@ -734,9 +746,16 @@ __device__ __forceinline__ void gjk_planar_body(const GjkSwarmParams& p, double2
     };
     auto pair_id = [&](int k) { return SWEEP ? OWN(w, k, p.wgs_per_row) : (TILED ? p.order[k] : (FIXUP ? list[k] : k)); };
     // the general evaluation of a recorded three-point simplex
-    auto general_exit = [&](int sa, int sb, int keys, int rq1, int rq2, Result& r) {
-        const int ia1 = rq1 & 0xff, ia2 = (rq1 >> 8) & 0xff, ib1 = (rq1 >> 16) & 0xff, ib2 = (rq1 >> 24) & 0xff;
-        const int ic1 = rq2 & 0xff, ic2 = (rq2 >> 8) & 0xff;
+    // slots of local index l in list order (phase 2 is convergent: the sweeps read them from the lists again instead of
+    // keeping a second LDS copy)
+    auto slots_nat = [&](int l) {
+        if (SWEEP) { const int kq = cbase + l; return (unsigned)p.pa[kq] | ((unsigned)p.pb[kq] << 16); }
+        if (TILED) return p.pslots[c0 + l];
+        return plist[l];
+    };
+    auto general_exit = [&](int sa, int sb, int keys, int rq1, Result& r) {
+        const int ia1 = rq1 & 31, ia2 = (rq1 >> 5) & 31, ib1 = (rq1 >> 10) & 31, ib2 = (rq1 >> 15) & 31;
+        const int ic1 = (rq1 >> 20) & 31, ic2 = (rq1 >> 25) & 31;
         Ctx<MemLdsXY> g;
         g.mem = MemLdsXY{ lds };
         g.P1 = Poly{ sa * VPQ, 1 << 24, NC, 0 };
@@ -752,10 +771,10 @@ __device__ __forceinline__ void gjk_planar_body(const GjkSwarmParams& p, double2
     };
     for (int k = c0 + (int)threadIdx.x; k < c1; k += blockDim.x) {
         const int kk = pair_id(k);
-        const unsigned ab2 = (SWEEP || TILED) ? pnat[k - c0] : plist[k - c0];
+        const unsigned ab2 = slots_nat(k - c0);
         const int sa = (int)(ab2 & 0xffffu), sb = (int)(ab2 >> 16);
         const int2 rq = r01[k - c0];
-        const int rq0 = rq.x, rq1 = rq.y, rq2 = (int)r2[k - c0];
+        const int rq0 = rq.x, rq1 = rq.y;
         const int flag = (rq0 & 3) - 1, status = (rq0 >> 2) & 3, keys = (rq0 >> 4) & 7, n_scans = (int)((unsigned)rq0 >> 8);
         Result r;
         r.c1 = V3{ qnan, qnan, qnan }; r.c2 = r.c1; r.dist = qnan;
@@ -764,8 +783,8 @@ __device__ __forceinline__ void gjk_planar_body(const GjkSwarmParams& p, double2
             // pick the partner vertex O of the closest feature, then ONE segment evaluation
             const double2* q1 = xy + sa * VPQ;
             const double2* q2 = xy + sb * VPQ;
-            const int ia1 = rq1 & 0xff, ia2 = (rq1 >> 8) & 0xff, ib1 = (rq1 >> 16) & 0xff, ib2 = (rq1 >> 24) & 0xff;
-            const int ic1 = rq2 & 0xff, ic2 = (rq2 >> 8) & 0xff;
+            const int ia1 = rq1 & 31, ia2 = (rq1 >> 5) & 31, ib1 = (rq1 >> 10) & 31, ib2 = (rq1 >> 15) & 31;
+            const int ic1 = (rq1 >> 20) & 31, ic2 = (rq1 >> 25) & 31;
             const V2 a1{ q1[ia1].x, q1[ia1].y }, a2{ q2[ia2].x, q2[ia2].y };
             const V2 A = gjk::sub2(a1, a2);
             int which = 0;                    // 0: point A, 1: segment A-B, 2: segment A-C, 3: plane
@@ -809,7 +828,7 @@ __device__ __forceinline__ void gjk_planar_body(const GjkSwarmParams& p, double2
                 ord[atomicAdd(&s_nlist, 1)] = (unsigned short)(k - c0);
                 continue;
             } else {
-                general_exit(sa, sb, keys, rq1, rq2, r);
+                general_exit(sa, sb, keys, rq1, r);
             }
         }
         emit(kk, flag, status, n_scans, r);
@@ -819,15 +838,15 @@ __device__ __forceinline__ void gjk_planar_body(const GjkSwarmParams& p, double2
         const int n_def = s_nlist;
         for (int q = (int)threadIdx.x; q < n_def; q += blockDim.x) {
             const int l = (int)ord[q], k = c0 + l;
-            const unsigned ab2 = pnat[l];
+            const unsigned ab2 = slots_nat(l);
             const int2 rq = r01[l];
             Result r;
             r.c1 = V3{ qnan, qnan, qnan }; r.c2 = r.c1; r.dist = qnan;
-            general_exit((int)(ab2 & 0xffffu), (int)(ab2 >> 16), (rq.x >> 4) & 7, rq.y, (int)r2[l], r);
+            general_exit((int)(ab2 & 0xffffu), (int)(ab2 >> 16), (rq.x >> 4) & 7, rq.y, r);
             emit(pair_id(k), 1, OBTG_ST_OK, (int)((unsigned)rq.x >> 8), r);
         }
     }
-    if (FIXUP) __syncthreads();                          // rec / list are reused by the next segment
+    if (FIXUP || SWEEP) __syncthreads();                 // records / lists are reused by the next segment or pass
     }
     if (TS && TILED && ts_ij.x >= 0) {
         __syncthreads();                                     // phase 2 has read the records the tile overwrites
@@ -852,6 +871,28 @@ void k_gjk_swarm_planar(const GjkSwarmParams p)
     gjk_planar_body<NC, MODE>(p, xy_dyn, -1, -1);
 }
 
+// Diagnostics (OBTG_TIMELINE=<file>, launch_pair_sweep): when each workgroup of a launch started and when its last wave
+// left, on the constant 100 MHz clock, and where it ran (HW_ID: CU / SE, XCC_ID) -- the picture of the grid's rounds
+// and of its tail.  One scalar branch per workgroup when off.
+struct TimelineScope {
+    unsigned long long* t;
+    __device__ __forceinline__ explicit TimelineScope(unsigned long long* base) : t(base)
+    {
+        if (t) {
+            t += 4 * (size_t)blockIdx.x;
+            if (threadIdx.x == 0) {
+                t[0] = wall_clock64();
+                t[2] = (unsigned long long)__builtin_amdgcn_s_getreg((4 /*HW_ID*/) | (0 << 6) | (31 << 11)) |
+                       ((unsigned long long)__builtin_amdgcn_s_getreg((20 /*XCC_ID*/) | (0 << 6) | (31 << 11)) << 32);
+            }
+        }
+    }
+    __device__ __forceinline__ ~TimelineScope()
+    {
+        if (t && (threadIdx.x & (kWave - 1)) == 0) atomicMax(t + 1, wall_clock64());
+    }
+};
+
 // the same grid when it also writes the temporal-separation blocks (p.ts.out set): own symbol, so that
 // profiles tell the pair sweep from the plain GJK sweep.
 // With p.dyn set the launch is the whole constraint evaluation of the batch: its last workgroups run the speed /
@@ -863,6 +904,7 @@ __global__ __launch_bounds__(OBTG_SWEEP_THREADS, NC <= 11 ? kPairSweepWavesPerSi
 void k_pair_sweep(const GjkSwarmParams p)
 {
     extern __shared__ double2 xy_dyn[];
+    TimelineScope tl(p.timeline);
     if (p.dyn.out != nullptr && (int)blockIdx.x >= p.dyn_first_block) {
         // the speed / angular-rate evaluation of the batch, one 64-vehicle group per workgroup, on the grid's last
         // block ids: they are dispatched as the sweep's workgroups drain and fill the slots the tail leaves empty
@@ -2204,21 +2246,63 @@ static int build_tiles(obtg_ctx* c, int /*vp*/)
     return OBTG_OK;
 }
 
-// Workgroups per row of the plain planar sweep: kSweepChunk pairs each, more for small batches (enough workgroups to
-// fill the chip), and more again when the row's objects leave less LDS than that: up to 11 points per hull the kernel
-// runs five workgroups per CU only while a workgroup stays under 160 KB / 5 (C5: 96 objects, 760-pair chunks were
-// 33.5 KB = four per CU; 652-pair chunks are 31.2 KB).
-static int sweep_wgs_per_row(const obtg_ctx* c, int B, int nc, int chunk_pairs = kSweepChunk, int waves_per_simd = kSweepWavesPerSimd)
+// Shape of a MODE 0 sweep's grid: workgroups per row, chunks a workgroup takes one after the other (passes), pairs per
+// chunk.  What the workgroup timeline (OBTG_TIMELINE, tools/timeline_report.py; profiles/r03_experiments) shows at C3:
+// a workgroup lasts 55 - 60 us whether it shares its CU with three others or runs alone -- it is a chain of dependent
+// state-machine rounds, not a share of the CU's issue slots -- so a launch takes (rounds of the chip) x (duration of a
+// workgroup), and 2306 workgroups on 4 x 256 slots were THREE rounds, the last one a quarter full.  Hence:
+//  * records of 14 bytes per pair, so that five workgroups of 1264 pairs and 72 objects fit a CU's LDS (1280 slots);
+//  * fewer, longer workgroups: a workgroup stages its row once and sweeps `passes` chunks on that staging, and
+//    (wgs, passes) minimise rounds x duration with duration = F + passes x (S + chunk x t) (fitted to the timeline: fixed
+//    part 18 us, per pass 6 us, 25 ns per pair).  C3, 1153 rows: one workgroup per row, two passes -- ONE round.
+// Small batches end up with many small workgroups (one round, shortest duration), as before.
+static int sweep_refill_min()
+{
+    static const int v = getenv("OBTG_REFILL_MIN") ? std::max(1, std::min(64, atoi(getenv("OBTG_REFILL_MIN")))) : 32;
+    return v;
+}
+
+struct SweepShape {
+    int wgs = 1, passes = 1, chunk = 0, per_cu = 1;
+    size_t lds = 0;
+};
+static SweepShape sweep_shape(const obtg_ctx* c, int B, int nc, int waves_per_simd)
 {
     const int np = c->n_hull_pairs, n_obj = c->n_veh + c->n_poly, vpq = nc | 1;
-    int wgs = (np + chunk_pairs - 1) / chunk_pairs;
-    while ((long)B * wgs < 2048 && (np + wgs - 1) / wgs > 256) wgs <<= 1;
-    if (nc <= 11) {
-        const size_t budget = (size_t)160 * 1024 / waves_per_simd - 1280;
-        while ((np + wgs - 1) / wgs > 256 && planar_lds_bytes<0>(n_obj, vpq, (np + wgs - 1) / wgs) > budget &&
-               planar_lds_bytes<0>(n_obj, vpq, 256) <= budget) ++wgs;
+    const size_t fixed = planar_lds_bytes<0>(n_obj, vpq, 0);
+    SweepShape best;
+    // workgroups per CU: what the kernel's registers allow, fewer while the row's objects leave no room for 256 pairs
+    int per_cu = nc <= 11 ? waves_per_simd : 1;
+    size_t budget = 0;
+    for (; per_cu >= 1; --per_cu) {
+        budget = (size_t)160 * 1024 / per_cu - 1280;
+        if (per_cu == 1) budget = 64 * 1024;                       // one workgroup per CU: the launch limit
+        if (fixed + 14 * 256 <= budget) break;
     }
-    return wgs;
+    if (per_cu < 1) { per_cu = 1; }
+    int chunk_max = fixed + 14 * 256 <= budget ? (int)std::min<size_t>((budget - fixed) / 14, 65535) : 256;
+    if (const char* e = getenv("OBTG_SWEEP_CHUNK_MAX")) chunk_max = std::max(64, std::min(chunk_max, atoi(e)));
+    const long slots = (long)c->n_cus * per_cu;
+    double best_cost = 1e300;
+    const int force_w = getenv("OBTG_SWEEP_WGS") ? atoi(getenv("OBTG_SWEEP_WGS")) : 0;
+    for (int W = 1; W <= std::max(1, np / 64); ++W) {
+        const int per_wg = (np + W - 1) / W;
+        const int Q = (per_wg + chunk_max - 1) / chunk_max;
+        const int chunk = (per_wg + Q - 1) / Q;
+        if (W > 1 && chunk < 256 && !force_w) break;
+        const long rounds = ((long)B * W + slots - 1) / slots;
+        const double cost = (double)rounds * (18.0 + Q * (6.0 + 0.025 * chunk));
+        if ((force_w ? W == force_w : cost < best_cost - 1e-9)) {
+            best_cost = cost;
+            best.wgs = W; best.passes = Q; best.chunk = chunk;
+        }
+        if (force_w && W == force_w) break;
+    }
+    // the grid covers ceil(np / (passes * chunk)) workgroups per row
+    best.wgs = (np + best.passes * best.chunk - 1) / (best.passes * best.chunk);
+    best.per_cu = per_cu;
+    best.lds = planar_lds_bytes<0>(n_obj, vpq, best.chunk);
+    return best;
 }
 
 int launch_gjk_swarm(obtg_ctx* c, const double* dY, int B, int max_iter, int md_cap, int* d_flag,
@@ -2236,10 +2320,11 @@ int launch_gjk_swarm(obtg_ctx* c, const double* dY, int B, int max_iter, int md_
     // pairs per lane (measured at C3 in list order: 316 pairs per 256 lanes = 0.281 ms, 1264 pairs =
     // 0.215 ms); with the history order 864-pair chunks do as well as 1264 and leave LDS for a fifth
     // workgroup per CU.  Small batches trade chunk size for enough workgroups to fill the chip.
-    const int wgs = sweep_wgs_per_row(c, B, c->deg + 1);
+    const int wgs = std::max(1, (c->n_hull_pairs + kSweepChunk - 1) / kSweepChunk);     // the general kernels' chunking
     p.chunk = (c->n_hull_pairs + wgs - 1) / wgs;
     p.wgs_per_row = (c->n_hull_pairs + p.chunk - 1) / p.chunk;
     p.max_iter = max_iter; p.md_cap = md_cap;
+    p.refill_min = sweep_refill_min();
     p.flag = d_flag; p.p1 = d_p1; p.p2 = d_p2; p.dist = d_dist; p.nsup = d_nsup; p.status = d_status;
     if (c->fd.Y0) {
         if (c->fd_dedup) return kNeedBatch;      // the de-duplication mask compares rows in memory
@@ -2250,7 +2335,9 @@ int launch_gjk_swarm(obtg_ctx* c, const double* dY, int B, int max_iter, int md_
     if (planar && c->max_poly_K <= c->deg + 1 && c->deg + 1 <= 127) {
         const int nc = c->deg + 1;
         const int vp2 = nc | 1;                    // object pitch in 16-byte points (PlanarShape<NC>::VPQ)
-        const size_t lds2 = planar_lds_bytes<0>(c->n_veh + c->n_poly, vp2, p.chunk);
+        const SweepShape shape = sweep_shape(c, B, nc, kSweepWavesPerSimd);
+        p.chunk = shape.chunk; p.wgs_per_row = shape.wgs; p.passes = shape.passes;
+        const size_t lds2 = shape.lds;
         void (*kp)(const GjkSwarmParams) = nullptr;
         void (*kf)(const GjkSwarmParams) = nullptr;
         void (*kt)(const GjkSwarmParams) = nullptr;
@@ -2270,7 +2357,7 @@ int launch_gjk_swarm(obtg_ctx* c, const double* dY, int B, int max_iter, int md_
                 q.chunk_off = c->d_tile_chunk_off.as<int>(); q.order = c->d_tile_order.as<int>();
                 q.pslots = c->d_tile_pslots.as<unsigned>(); q.cobj_off = c->d_tile_cobj_off.as<int>();
                 q.cobjs = c->d_tile_cobjs.as<int>(); q.max_objs = c->tile_max_objs;
-                q.chunk = c->tile_max_pairs; q.wgs_per_row = c->tile_n_chunks;
+                q.chunk = c->tile_max_pairs; q.wgs_per_row = c->tile_n_chunks; q.passes = 1;
                 const size_t ldst = planar_lds_bytes<2>(q.max_objs, vp2, q.chunk);
                 if (ldst <= 64 * 1024) {
                     const size_t npairs = (size_t)c->n_hull_pairs;
@@ -2311,7 +2398,7 @@ int launch_gjk_swarm(obtg_ctx* c, const double* dY, int B, int max_iter, int md_
                     while (w0 < 2048 && (c->n_hull_pairs + w0 - 1) / w0 > 256) w0 <<= 1;
                     r0.chunk = (c->n_hull_pairs + w0 - 1) / w0;
                     r0.wgs_per_row = (c->n_hull_pairs + r0.chunk - 1) / r0.chunk;
-                    r0.B = 1;
+                    r0.B = 1; r0.passes = 1;
                     hipLaunchKernelGGL(kp, dim3((unsigned)(8 * r0.wgs_per_row)), dim3(OBTG_SWEEP_THREADS),
                                        planar_lds_bytes<0>(c->n_veh + c->n_poly, vp2, r0.chunk), c->stream, r0);
                 }
@@ -2327,7 +2414,7 @@ int launch_gjk_swarm(obtg_ctx* c, const double* dY, int B, int max_iter, int md_
                 if (d_status) hipLaunchKernelGGL(k_bcast_row0<int>, g1, cb, 0, c->stream, d_status, np, B);
                 GjkSwarmParams q = p;
                 q.chg = chg;
-                q.chunk = 1024;
+                q.chunk = 1024; q.passes = 1;
                 const size_t ldsf = planar_lds_bytes<1>(c->n_veh + c->n_poly, vp2, q.chunk);
                 hipLaunchKernelGGL(kf, dim3((unsigned)(B - 1)), dim3(256), ldsf, c->stream, q);
             } else {
@@ -2453,6 +2540,8 @@ int launch_gjk_swarm(obtg_ctx* c, const double* dY, int B, int max_iter, int md_
         }
     }
     if (lds > 160 * 1024 - 64) return OBTG_ERR_UNSUPPORTED;      // the general kernel stages the whole row (the tiled sweep above does not)
+    p.chunk = (c->n_hull_pairs + wgs - 1) / wgs;                  // (the fixed-count branches above may have reshaped the grid)
+    p.wgs_per_row = (c->n_hull_pairs + p.chunk - 1) / p.chunk; p.passes = 1;
     auto kern = planar ? k_gjk_swarm<true> : k_gjk_swarm<false>;
     if (lds > 48 * 1024)
         OBTG_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -2466,19 +2555,30 @@ int launch_gjk_swarm(obtg_ctx* c, const double* dY, int B, int max_iter, int md_
 // The pair sweeps of a batch as one launch: the planar GJK sweep whose workgroups also write their
 // row's temporal-separation block (GjkSwarmParams::ts).  Shapes outside that kernel: two launches.
 // does obtg_pair_sweep_dev run as ONE launch for this context (large batch)?  Mirrors launch_pair_sweep's decision.
+// Rows per pass of the separation block's transposition tile (4 waves x rows x odd(2n+1) doubles), which borrows the LDS
+// behind the staged objects; small rows get a larger allocation so that 16 rows fit.  0: no room.
+static int pair_sweep_tile_rows(const obtg_ctx* c, int nc, size_t& lds)
+{
+    const int n_obj = c->n_veh + c->n_poly, vpq = nc | 1;
+    const int L = 2 * c->deg + 1, tpf = (L % 2 == 0) ? L + 1 : L;
+    const size_t objects = (size_t)16 * n_obj * vpq;
+    auto tile = [&](int rows) { return (size_t)4 * rows * tpf * sizeof(double); };
+    int tr = 64;                       // the largest multiple of 8 that fits
+    while (tr >= 8 && objects + tile(tr) > lds) tr -= 8;
+    const size_t budget = (size_t)160 * 1024 / kPairSweepWavesPerSimd - 1280;
+    for (int want = 16; want >= 8 && tr < want; want -= 8)
+        if (objects + tile(want) <= budget) { lds = std::max(lds, objects + tile(want)); tr = want; }
+    return tr >= 8 ? tr : 0;
+}
+
 bool pair_sweep_is_one_launch(const obtg_ctx* c)
 {
     const int nc = c->deg + 1;
     if (!(nc == 4 || nc == 6 || nc == 8 || nc == 11 || nc == 16)) return false;
     if (!(c->dim == 2 && c->polys_planar && c->max_poly_K <= nc && c->n_hull_pairs > 0 && !c->fd_dedup && c->R == 0 &&
           c->n_obs == 0 && c->n_pairs > 0)) return false;
-    const int wgs = sweep_wgs_per_row(c, 1 << 20, nc, kPairSweepChunk, kPairSweepWavesPerSimd);
-    const int chunk = (c->n_hull_pairs + wgs - 1) / wgs;
-    const int n_obj = c->n_veh + c->n_poly, vpq = nc | 1;
-    const size_t lds = planar_lds_bytes<0>(n_obj, vpq, chunk);
-    const int L = 2 * c->deg + 1, tpf = (L % 2 == 0) ? L + 1 : L;
-    const size_t behind = lds - (size_t)16 * n_obj * vpq;
-    return (size_t)4 * 8 * tpf * sizeof(double) <= behind && lds <= 48 * 1024;
+    size_t lds = sweep_shape(c, 1 << 20, nc, kPairSweepWavesPerSimd).lds;
+    return pair_sweep_tile_rows(c, nc, lds) > 0 && lds <= 48 * 1024;
 }
 
 int launch_pair_sweep(obtg_ctx* c, const double* dY, int B, double max_sep, double* d_out_sep, int max_iter,
@@ -2509,19 +2609,14 @@ int launch_pair_sweep(obtg_ctx* c, const double* dY, int B, double max_sep, doub
         p.pa = c->d_hp_a.as<int>(); p.pb = c->d_hp_b.as<int>();
         p.n_veh = c->n_veh; p.dim = c->dim; p.nc = nc; p.n_poly = c->n_poly;
         p.n_poly_pts = c->n_poly_pts; p.n_pairs = c->n_hull_pairs;
-        const int wgs = sweep_wgs_per_row(c, B, nc, kPairSweepChunk, kPairSweepWavesPerSimd);
-        p.chunk = (c->n_hull_pairs + wgs - 1) / wgs;
-        p.wgs_per_row = (c->n_hull_pairs + p.chunk - 1) / p.chunk;
+        const SweepShape shape = sweep_shape(c, B, nc, kPairSweepWavesPerSimd);
+        p.chunk = shape.chunk; p.wgs_per_row = shape.wgs; p.passes = shape.passes;
         p.max_iter = max_iter; p.md_cap = md_cap;
+        p.refill_min = sweep_refill_min();
         p.flag = d_flag; p.p1 = d_p1; p.p2 = d_p2; p.dist = d_dist; p.nsup = d_nsup; p.status = d_status;
-        const int n_obj = c->n_veh + c->n_poly, vpq = nc | 1;
-        lds = planar_lds_bytes<0>(n_obj, vpq, p.chunk);
-        // the transposition tile (4 waves x TR rows x odd(2n+1) doubles) borrows the LDS behind the objects
-        const int L = 2 * c->deg + 1, tpf = (L % 2 == 0) ? L + 1 : L;
-        const size_t behind = lds - (size_t)16 * n_obj * vpq;
-        int tr = 64;                       // rows per transposition pass: the largest multiple of 8 that fits
-        while (tr >= 8 && (size_t)4 * tr * tpf * sizeof(double) > behind) tr -= 8;
-        fused = tr >= 8 && lds <= 48 * 1024;
+        lds = shape.lds;
+        const int tr = pair_sweep_tile_rows(c, nc, lds);      // the transposition tile borrows the LDS behind the objects
+        fused = tr > 0 && lds <= 48 * 1024;
         p.ts.pairs = c->d_pairs.as<int2>(); p.ts.W2 = c->d_w2.as<double>(); p.ts.out = d_out_sep;
         p.ts.n_pairs = c->n_pairs; p.ts.sign = 1.0; p.ts.offset = -(max_sep * max_sep);
         p.ts_tile_rows = tr;
@@ -2616,9 +2711,35 @@ int launch_pair_sweep(obtg_ctx* c, const double* dY, int B, double max_sep, doub
             speed->did_dynamics = true;
         }
     }
+    // OBTG_TIMELINE=<file>: the 20th (OBTG_TIMELINE_AT) one-launch sweep of the process leaves its workgroup timeline
+    // there (text: block, start and end in 10 ns ticks from the first start, HW_ID, XCC_ID; tools/timeline_report.py)
+    static const char* tl_path = getenv("OBTG_TIMELINE");
+    static const int tl_at = getenv("OBTG_TIMELINE_AT") ? atoi(getenv("OBTG_TIMELINE_AT")) : 20;
+    static int tl_count = 0;
+    const bool tl_now = tl_path && tl_path[0] && ++tl_count == tl_at;
+    if (tl_now) {
+        if (int rc = c->ws_misc[6].reserve((size_t)grid * 4 * sizeof(unsigned long long))) return rc;
+        OBTG_HIP(c, hipMemsetAsync(c->ws_misc[6].p, 0, (size_t)grid * 4 * sizeof(unsigned long long), c->stream));
+        p.timeline = c->ws_misc[6].as<unsigned long long>();
+    }
     {
         ScopedKernelTimer tm(c, OBTG_K_PAIR_SWEEP);
         hipLaunchKernelGGL(kern, dim3(grid), dim3(OBTG_SWEEP_THREADS), lds, c->stream, p);
+    }
+    if (tl_now) {
+        std::vector<unsigned long long> h((size_t)grid * 4);
+        OBTG_HIP(c, hipMemcpyAsync(h.data(), p.timeline, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
+        OBTG_HIP(c, hipStreamSynchronize(c->stream));
+        if (FILE* f = fopen(tl_path, "w")) {
+            unsigned long long t0 = ~0ull;
+            for (unsigned i = 0; i < grid; ++i) if (h[4 * i] && h[4 * i] < t0) t0 = h[4 * i];
+            fprintf(f, "# grid %u sweep_blocks %d wgs_per_row %d passes %d chunk %d B %d\n", grid,
+                    p.dyn.out ? p.dyn_first_block : (int)grid, p.wgs_per_row, p.passes, p.chunk, B);
+            for (unsigned i = 0; i < grid; ++i)
+                fprintf(f, "%u %llu %llu %llu %llu\n", i, h[4 * i] ? h[4 * i] - t0 : 0ull, h[4 * i + 1] ? h[4 * i + 1] - t0 : 0ull,
+                        h[4 * i + 2] & 0xffffffffull, h[4 * i + 2] >> 32);
+            fclose(f);
+        }
     }
     c->gjk_len_cur ^= 1;
     c->gjk_len_rows = B;
