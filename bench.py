@@ -89,29 +89,66 @@ def parse():
 # (no torch import, no HIP call) and never re-execs: it only starts fresh children and waits.
 # ---------------------------------------------------------------------------------------------
 def spawn_ranks(args):
+    import signal
     with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     procs = []
-    for r in range(args.gpus):
-        env = dict(os.environ)
-        env.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
-                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+
+    def stop_all(grace=5.0):
+        """terminate every live rank, then kill what ignores it: a rank left in a barrier would hold its GPU"""
+        live = [p for p in procs if p.poll() is None]
+        for p in live:
+            try:
+                os.killpg(p.pid, signal.SIGTERM)
+            except (ProcessLookupError, PermissionError):
+                pass
+        t_end = time.time() + grace
+        while time.time() < t_end and any(p.poll() is None for p in live):
+            time.sleep(0.1)
+        for p in live:
+            if p.poll() is None:
+                try:
+                    os.killpg(p.pid, signal.SIGKILL)
+                except (ProcessLookupError, PermissionError):
+                    pass
+        for p in live:
+            try:
+                p.wait(timeout=5)
+            except subprocess.TimeoutExpired:
+                pass
+
+    def on_signal(signum, _frame):
+        stop_all()
+        sys.exit(128 + signum)
+
+    old = {sig: signal.signal(sig, on_signal) for sig in (signal.SIGTERM, signal.SIGINT)}
     rc = 0
-    live = list(procs)
-    while live:
-        time.sleep(0.2)
-        for p in list(live):
-            code = p.poll()
-            if code is None:
-                continue
-            live.remove(p)
-            if code != 0 and rc == 0:
-                rc = code
-                for q in live:          # one rank failed: the others would wait in a barrier forever
-                    q.terminate()
+    try:
+        for r in range(args.gpus):
+            env = dict(os.environ)
+            env.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
+                       MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+            env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+            # own process group per rank: a signal to the launcher reaches the ranks through stop_all() only
+            procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                          start_new_session=True))
+        live = list(procs)
+        while live:
+            time.sleep(0.2)
+            for p in list(live):
+                code = p.poll()
+                if code is None:
+                    continue
+                live.remove(p)
+                if code != 0 and rc == 0:
+                    rc = code
+                    stop_all()              # one rank failed: the others would wait in a barrier forever
+                    live = []
+    finally:
+        stop_all()
+        for sig, h in old.items():
+            signal.signal(sig, h)
     if rc:
         sys.stderr.write("bench.py: a rank exited with code %d\n" % rc)
     return rc
@@ -321,7 +358,8 @@ def main():
     # timed region: HIP events (launch stream) around the dominant kernel only, on every 4th step --
     # an event pair drains the queue around its launch (events on all three launches of every step
     # cost 15 % of a 0.25 ms step)
-    prof(True, only=dom_name, period=4 if args.steps >= 8 else 1)
+    # (short runs -- the driver's --steps 20 -- put them on every launch, so that the average has >= 20 samples)
+    prof(True, only=dom_name, period=4 if args.steps >= 100 else 1)
     barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -353,6 +391,53 @@ def main():
     stats[dom_name] = stats_timed[dom_name]
     prof(False)
 
+    # ---- variants, beside -- never as -- `value`: the same step (a) with the trip-count history off (pairs swept in
+    # list order), (b) with x MOVING between steps the way SLSQP moves it: every step evaluates the FD batch around a
+    # new x, one N(0, 1e-2) step of a random walk on the free control points away from the previous one, so the history
+    # the sweep orders its pairs by comes from a different point each time (identical replays are its best case).
+    variants = None
+    if use_view and use_gjk and args.mode == "batch":
+        def timed(nsteps, fn):
+            for _ in range(10):
+                fn(0)
+            torch.cuda.synchronize()
+            a = time.perf_counter()
+            for i in range(nsteps):
+                fn(i)
+            torch.cuda.synchronize()
+            return 1e3 * (time.perf_counter() - a) / nsteps
+
+        def step_at(ptr):
+            for cx in ctxs:
+                cx.fd_view_begin(ptr, 1, synth.FD_STEP, B)
+            sweeps()
+            for cx in ctxs:
+                cx.fd_view_end()
+
+        nv = min(args.steps, 200)
+        variants = {}
+        ctx.set_gjk_history(False)
+        variants["history_off"] = {"ms_per_step": round(timed(nv, lambda i: step_at(d0.data_ptr())), 4),
+                                   "what": "obtg_ctx_set_gjk_history(0): pairs swept in list order"}
+        ctx.set_gjk_history(True)
+        rng = np.random.default_rng(99)
+        walk = [Y.copy()]
+        for _ in range(31):
+            nxt = walk[-1].copy()
+            nxt[:, 1:-1] += rng.normal(0.0, 1e-2, size=(N * d, n - 1))
+            walk.append(nxt)
+        d_walk = [torch.from_numpy(w).to(dev) for w in walk]
+        seq = list(range(32)) + list(range(30, 0, -1))          # there and back: consecutive steps are one move apart
+        variants["moving_x"] = {"ms_per_step": round(timed(nv, lambda i: step_at(d_walk[seq[i % len(seq)]].data_ptr())), 4),
+                                "what": "x advanced between steps by N(0, 1e-2) on every free control point (random walk, "
+                                        "32 positions there and back); history from the previous position"}
+        ctx.set_gjk_history(False)
+        variants["moving_x_history_off"] = {
+            "ms_per_step": round(timed(nv, lambda i: step_at(d_walk[seq[i % len(seq)]].data_ptr())), 4)}
+        ctx.set_gjk_history(True)
+        for v in variants.values():
+            v["evals_per_s"] = round(B / (v["ms_per_step"] * 1e-3), 1)
+
     evals = world * B * args.steps
     value = evals / elapsed
     ms_per_step = 1e3 * elapsed / args.steps
@@ -368,7 +453,9 @@ def main():
     one_launch_step = (stats.get("pair_sweep", (0.0, 0))[1] > 0 and stats.get("ang_rate", (0.0, 0))[1] == 0 and
                        stats.get("speed", (0.0, 0))[1] == 0 and o_an is not None)
     if one_launch_step:
-        by["pair_sweep"] += by["ang_rate"]          # planar rows: the speed / angular-rate groups ran as the grid's last workgroups
+        # planar rows: the speed / angular-rate groups ran as the grid's last workgroups -- the launch IS the evaluation,
+        # its algorithmic bytes are SURVEY.md 8(d)'s per-eval figure (control points counted once) x B
+        by["pair_sweep"] = total_bytes
     for name in KNAMES:
         ms, cnt = stats.get(name, (0.0, 0))
         if cnt == 0:
@@ -412,6 +499,18 @@ def main():
         cpu = cpu_baseline(args, N, d, n, R, Y, statics, pa, pb, use_gjk, max_sep, vmax, wmax, tfv)
         cpu_np = cpu_baseline_numpy(N, d, n, R, Y, statics, pa, pb, use_gjk, max_sep, vmax, wmax, tfv)
 
+    # proof of ranks: what the process group itself reports, and the device every rank ran on
+    ranks_seen = dist.get_world_size() if use_dist else 1
+    devices = [torch.cuda.get_device_name(local_rank) + " #%d" % local_rank]
+    if use_dist:
+        gathered = [None] * ranks_seen
+        dist.all_gather_object(gathered, "%s #%d pid %d" % (torch.cuda.get_device_name(local_rank), local_rank, os.getpid()))
+        devices = gathered
+    status_note = None
+    if status_nonok:
+        status_note = ("%d of the last step's %d gjkNew evaluations ended with a status other than OK (cycle detected / "
+                       "minimumDistance cap): inputs on which the reference's own gjkNew never returns; they are "
+                       "evaluated, flagged per pair and counted in evals/s" % (status_nonok, B * P_s))
     if rank == 0:
         obst = ("%d curve obstacles (shapeObstacles)" % M) if cfg.get("n_curve_obs") else ("%d polygon obstacles" % M)
         line = {
@@ -429,10 +528,13 @@ def main():
                                              else "written to HBM by obtg_fd_batch_dev each step"), P_t,
                                        "max_ang_rate+" if d == 2 else "", P_s),
                        "launches_per_step": len(kernels), "streams": 2 if two_streams else 1,
+                       "ranks_seen": ranks_seen, "backend": (args.backend if use_dist else None), "devices": devices,
+                       "gjk_status_note": status_note,
                        "evals_per_step_per_gpu": B, "alg_bytes_per_eval": total_bytes,
                        "gjk_fd_dedup": bool(args.fd_dedup), "gjk_status_nonok_last_step": status_nonok},
             "roofline": roofline,
             "kernels": kernels,
+            "variants": variants,
             "parity_check": parity,
             "cpu_baseline": cpu,
             "cpu_baseline_numpy": cpu_np,
@@ -473,9 +575,20 @@ def parity_check(dev_out, N, d, n, R, statics, pa, pb, use_gjk, max_sep, vmax, w
             return 0.0
         return float((np.abs(got[fin] - ref[fin]) / np.maximum(np.abs(ref[fin]), np.abs(ref[fin]).max())).max())
 
+    def rel_elem(got, ref):
+        """largest |got - ref| / |ref| over the elements that are not tiny against their vector (|ref| > 1e-6 x scale)"""
+        fin = np.isfinite(ref)
+        if not fin.any():
+            return 0.0
+        scale = np.abs(ref[fin]).max()
+        m = fin & (np.abs(ref) > 1e-6 * scale)
+        return float((np.abs(got[m] - ref[m]) / np.abs(ref[m])).max()) if m.any() else 0.0
+
     worst = {"temporal_sep": rel(dev_out["sep"], o_sep), "speed": rel(dev_out["speed"], o_sp)}
+    elem = {"temporal_sep": rel_elem(dev_out["sep"], o_sep), "speed": rel_elem(dev_out["speed"], o_sp)}
     if dev_out.get("ang") is not None:
         worst["ang_rate"] = rel(dev_out["ang"], o_an)
+        elem["ang_rate"] = rel_elem(dev_out["ang"], o_an)
     flags_equal, dist_rel = True, 0.0
     if use_gjk:
         fl, di, p1 = dev_out["flag"], dev_out["dist"], dev_out["p1"]
@@ -489,7 +602,10 @@ def parity_check(dev_out, N, d, n, R, statics, pa, pb, use_gjk, max_sep, vmax, w
                                float((np.abs(p1[k][sep] - o["c1"][sep]) / np.maximum(1.0, np.abs(o["c1"][sep]))).max()))
     max_rel = max(worst.values())
     ok = bool(max_rel <= 1e-9 and flags_equal and dist_rel <= 1e-12)
-    return {"rows": len(rows), "row_ids": rows, "max_rel": max_rel, "per_family": worst, "flags_equal": flags_equal,
+    return {"rows": len(rows), "row_ids": rows, "max_rel": max_rel, "per_family": worst,
+            "max_rel_elementwise": max(elem.values()), "per_family_elementwise": elem,
+            "elementwise_note": "|got - ref| / |ref| over elements with |ref| > 1e-6 x the vector's largest magnitude",
+            "flags_equal": flags_equal,
             "gjk_dist_max_rel": dist_rel, "ok": ok,
             "against": "oracle/obtg_oracle.c on the device's own FD rows; buffers of the LAST timed step"}
 

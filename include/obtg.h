@@ -167,6 +167,12 @@ int obtg_ang_rate_dev(obtg_ctx*, const double* dY, const double* d_tf, int B, do
  * optimization.py:380 vs 605).  Either output may be NULL. */
 int obtg_dynamics_dev(obtg_ctx*, const double* dY, const double* d_tf, int B, double speed_bound,
                       int speed_is_max, double max_rate, double* d_out_speed, double* d_out_ang);
+/* BOTH speed bounds from one pass.  The reference exposes minSpeedConstraints and maxSpeedConstraints
+ * (optimization.py:135-169, 349-422): the same elevated |v|^2 curve, once as cpts - vmin^2 and once as vmax^2 - cpts.
+ * While d_out2 is set (device, [B][N*(2n+R+1)]; NULL = off), every pass that writes speed rows through
+ * obtg_dynamics[_fd]_dev or obtg_constraint_sweep_dev also writes the rows of this second bound from the curve it
+ * has in registers -- no second launch, no second evaluation of the derivative curves. */
+int obtg_ctx_set_second_speed_bound(obtg_ctx*, double bound, int is_max, double* d_out2);
 
 /* ---- finite-difference batch on the device --------------------------------------------
  * Replaces the n_x+1 serial calls SciPy's approx_derivative makes: builds

@@ -37,6 +37,7 @@ _SIGNATURES = {
     "obtg_ctx_set_stream": (_i, [_vp, _vp]),
     "obtg_ctx_set_deg_elev": (_i, [_vp, _i]),
     "obtg_ctx_set_ang_rate_order": (_i, [_vp, _i]),
+    "obtg_ctx_set_second_speed_bound": (_i, [_vp, _d, _i, _vp]),
     "obtg_sync": (_i, [_vp]),
     "obtg_len_temporal_sep": (_i, [_vp]),
     "obtg_len_speed": (_i, [_vp]),
@@ -380,6 +381,14 @@ class Context(object):
     def fd_batch_dev(self, dY0, n_fixed_cols, h, B, dY):
         self._check(self._lib.obtg_fd_batch_dev(self._h, _vp(dY0), int(n_fixed_cols), float(h), B, _vp(dY)),
                     "obtg_fd_batch_dev")
+
+    def set_second_speed_bound(self, bound, is_max, d_out2):
+        """Both speed bounds from one dynamics pass (include/obtg.h obtg_ctx_set_second_speed_bound): while d_out2 (a
+        device pointer, [B][N*(2n+R+1)]) is set, dynamics_dev / constraint_sweep_dev also write this bound's rows.
+        d_out2 = None switches it off."""
+        self._check(self._lib.obtg_ctx_set_second_speed_bound(self._h, float(bound), int(bool(is_max)),
+                                                               _vp(d_out2) if d_out2 else None),
+                    "obtg_ctx_set_second_speed_bound")
 
     def fd_view_begin(self, dY0, n_fixed_cols, h, B):
         """Open a virtual finite-difference batch over the ONE device row dY0 (include/obtg.h obtg_fd_view_begin): until

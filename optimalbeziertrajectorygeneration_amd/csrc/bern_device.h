@@ -622,6 +622,8 @@ struct AngParams {
     int n_veh, total;                // total = B * n_veh
     double w2;                       // max_rate^2
     double sp_sign, sp_offset;       // speed output = sp_sign * |v|^2 + sp_offset
+    double* __restrict__ out_speed2; // the OTHER speed bound's rows from the same curve (obtg_ctx_set_second_speed_bound;
+    double sp2_sign, sp2_offset;     // optimization.py:135-169 exposes min AND max speed); nullable, needs out_speed
     int fd, fd_fixed;                // fd != 0: Y is ONE row [n_veh*2][NC]; row b >= 1 = Y with its (b-1)-th free
     double fd_h;                     //          control point advanced by fd_h (the rows obtg_fd_batch_dev writes)
 };
@@ -699,21 +701,25 @@ __device__ __forceinline__ void dynamics2_group(const AngParams& p, double* lds,
                 sd = fma(W2n[k * NC + j], fma(xD[j], xD[k - j], yD[j] * yD[k - j]), sd);
             q1[k] = sd;
         }
-        if (p.out_speed && !HALF_SP) {
+        for (int which = 0; which < (p.out_speed ? (p.out_speed2 ? 2 : 1) : 0); ++which) {
+            double* const dst = which ? p.out_speed2 : p.out_speed;
+            const double sgn = which ? p.sp2_sign : p.sp_sign, off = which ? p.sp2_offset : p.sp_offset;
+            if (which) wave_sync();
+            if (!HALF_SP) {
 #pragma unroll
-            for (int k = 0; k < L2; ++k) tile_sp[lane * L2 + k] = p.sp_sign * q1[k] + p.sp_offset;
-            wave_sync();
-            flush_full<L2, L2>(tile_sp, p.out_speed, (size_t)it0 * L2, n_valid, lane);
-        }
-        if (p.out_speed && HALF_SP) {
-            for (int h0 = 0; h0 < n_valid; h0 += kWave / 2) {
-                if (lane >= h0 && lane < h0 + kWave / 2) {
+                for (int k = 0; k < L2; ++k) tile_sp[lane * L2 + k] = sgn * q1[k] + off;
+                wave_sync();
+                flush_full<L2, L2>(tile_sp, dst, (size_t)it0 * L2, n_valid, lane);
+            } else {
+                for (int h0 = 0; h0 < n_valid; h0 += kWave / 2) {
+                    if (lane >= h0 && lane < h0 + kWave / 2) {
 #pragma unroll
-                    for (int k = 0; k < L2; ++k) tile_sp[(lane - h0) * L2 + k] = p.sp_sign * q1[k] + p.sp_offset;
+                        for (int k = 0; k < L2; ++k) tile_sp[(lane - h0) * L2 + k] = sgn * q1[k] + off;
+                    }
+                    wave_sync();
+                    flush_full<L2, L2>(tile_sp, dst, ((size_t)it0 + h0) * L2, min(kWave / 2, n_valid - h0), lane);
+                    wave_sync();
                 }
-                wave_sync();
-                flush_full<L2, L2>(tile_sp, p.out_speed, ((size_t)it0 + h0) * L2, min(kWave / 2, n_valid - h0), lane);
-                wave_sync();
             }
         }
     } else {

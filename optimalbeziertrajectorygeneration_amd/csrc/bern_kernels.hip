@@ -202,11 +202,12 @@ __global__ __launch_bounds__(kWave) void k_dynamics(const AngParams p)
         num1[k] = s1 - s2;
         den1[k] = sd;
     }
-    if (p.out_speed && part == 0) {
+    for (int which = 0; which < ((p.out_speed && part == 0) ? (p.out_speed2 ? 2 : 1) : 0); ++which) {
+        const double sgn = which ? p.sp2_sign : p.sp_sign, off = which ? p.sp2_offset : p.sp_offset;
 #pragma unroll
-        for (int k = 0; k < L2; ++k) lds[lane * L2 + k] = p.sp_sign * den1[k] + p.sp_offset;
+        for (int k = 0; k < L2; ++k) lds[lane * L2 + k] = sgn * den1[k] + off;
         wave_sync();
-        flush_full<L2, L2>(lds, p.out_speed, (size_t)it0 * L2, n_valid, lane);
+        flush_full<L2, L2>(lds, which ? p.out_speed2 : p.out_speed, (size_t)it0 * L2, n_valid, lane);
         wave_sync();
     }
     if (!want_ang) return;
@@ -302,16 +303,21 @@ __global__ __launch_bounds__(4 * kWave, (NC > 11 ? 1 : 2)) void k_dynamics_elev(
             for (int j = 0; j < L2; ++j) dh[j] = sc2[j] * den1[j];
             for (int k0 = wave * kElevChunk; k0 < L2R; k0 += 4 * kElevChunk) {
                 const int kc = min(kElevChunk, L2R - k0);
-                for (int kb = 0; kb < kc; kb += kElevBlock) {
-                    double sa[kElevBlock];
-                    conv_block1<L2>(row2 + k0 + kb, dh, sa);
+                // one pass per requested bound (the second one, obtg_ctx_set_second_speed_bound, repeats the chunk's
+                // convolution: the degree-2n curve is what the two share)
+                for (int which = 0; which < (p.out_speed2 ? 2 : 1); ++which) {
+                    const double sgn = which ? p.sp2_sign : p.sp_sign, off = which ? p.sp2_offset : p.sp_offset;
+                    for (int kb = 0; kb < kc; kb += kElevBlock) {
+                        double sa[kElevBlock];
+                        conv_block1<L2>(row2 + k0 + kb, dh, sa);
 #pragma unroll
-                    for (int i = 0; i < kElevBlock; ++i)
-                        tile[lane * TP + kb + i] = p.sp_sign * (sa[i] * inv2[k0 + kb + i]) + p.sp_offset;
+                        for (int i = 0; i < kElevBlock; ++i)
+                            tile[lane * TP + kb + i] = sgn * (sa[i] * inv2[k0 + kb + i]) + off;
+                    }
+                    wave_sync();
+                    elev_store_chunk<L2>(tile, which ? p.out_speed2 : p.out_speed, (size_t)it0 * L2R, L2R, k0, kc, n_valid, lane);
+                    wave_sync();
                 }
-                wave_sync();
-                elev_store_chunk<L2>(tile, p.out_speed, (size_t)it0 * L2R, L2R, k0, kc, n_valid, lane);
-                wave_sync();
             }
         }
         const ctab_t sc4 = as_ctab(q.cv4);
@@ -1125,6 +1131,16 @@ static bool dyn_fast(const obtg_ctx* c)
 
 // shapes whose dynamics kernels form a virtual finite-difference batch on the fly (see obtg_ctx::fd)
 bool dynamics_fd_on_the_fly(const obtg_ctx* c, bool want_ang) { return dyn_fast(c) || (want_ang && dyn_fast_elev(c)); }
+bool bernstein_fd_on_the_fly(const obtg_ctx* c) { return fast_shape(c); }
+
+// the other speed bound's rows of the same pass (obtg_ctx_set_second_speed_bound)
+static void second_speed_rows(const obtg_ctx* c, AngParams& p)
+{
+    if (!c->speed2.d_out || !p.out_speed) return;
+    const double b2 = c->speed2.bound * c->speed2.bound;
+    p.out_speed2 = c->speed2.d_out;
+    p.sp2_sign = c->speed2.is_max ? -1.0 : 1.0; p.sp2_offset = c->speed2.is_max ? b2 : -b2;
+}
 
 // speed and/or angular rate in one launch (either output may be null)
 int launch_temporal_sep_fd(obtg_ctx* c, const double* dY0, int n_pert, const int* d_prow, const int* d_pcol,
@@ -1171,6 +1187,7 @@ int launch_dynamics(obtg_ctx* c, const double* dY, const double* d_tf, int B, do
         p.W2n = c->d_ang_w2n.as<double>();
         p.W22n = c->d_ang_w22n.as<double>();
         p.Wn = c->d_ang_wn.as<double>();
+        second_speed_rows(c, p);
         if (c->fd.Y0) { p.Y = c->fd.Y0; p.fd = 1; p.fd_fixed = c->fd.fixed; p.fd_h = c->fd.h; }
         const int kid = d_out_ang ? OBTG_K_ANG_RATE : OBTG_K_SPEED;
         switch (c->deg + 1) {
@@ -1192,6 +1209,7 @@ int launch_dynamics(obtg_ctx* c, const double* dY, const double* d_tf, int B, do
         p.W2n = c->d_ang_w2n.as<double>();
         p.W22n = c->d_ang_w22n.as<double>();
         p.Wn = c->d_ang_wn.as<double>();
+        second_speed_rows(c, p);
         if (c->fd.Y0) { p.Y = c->fd.Y0; p.fd = 1; p.fd_fixed = c->fd.fixed; p.fd_h = c->fd.h; }
         q.cv4 = c->d_ang_T4.as<double>(); q.cv2 = c->d_ang_cv2.as<double>(); q.R = c->R;
         switch (c->deg + 1) {
@@ -1203,6 +1221,8 @@ int launch_dynamics(obtg_ctx* c, const double* dY, const double* d_tf, int B, do
         }
     }
     if (d_out_speed && (rc = launch_speed(c, dY, d_tf, B, bound, is_max, d_out_speed))) return rc;
+    if (d_out_speed && c->speed2.d_out &&
+        (rc = launch_speed(c, dY, d_tf, B, c->speed2.bound, c->speed2.is_max, c->speed2.d_out))) return rc;
     if (d_out_ang && (rc = launch_ang_rate(c, dY, d_tf, B, max_rate, d_out_ang))) return rc;
     return OBTG_OK;
 }

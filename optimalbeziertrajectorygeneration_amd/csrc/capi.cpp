@@ -204,7 +204,7 @@ const char* obtg_abi_symbols(void)
 {
     static const char syms[] =
         "obtg_strerror\0obtg_last_error\0obtg_device_count\0obtg_abi_symbols\0obtg_host_alloc\0obtg_host_free\0"
-        "obtg_ctx_create\0obtg_ctx_destroy\0obtg_ctx_set_stream\0obtg_ctx_set_deg_elev\0obtg_ctx_set_ang_rate_order\0obtg_sync\0"
+        "obtg_ctx_create\0obtg_ctx_destroy\0obtg_ctx_set_stream\0obtg_ctx_set_deg_elev\0obtg_ctx_set_ang_rate_order\0obtg_ctx_set_second_speed_bound\0obtg_sync\0"
         "obtg_len_temporal_sep\0obtg_len_speed\0obtg_len_ang_rate\0obtg_num_pairs\0"
         "obtg_temporal_sep\0obtg_speed\0obtg_ang_rate\0obtg_temporal_sep_min\0obtg_temporal_sep_min_range\0"
         "obtg_temporal_sep_fd\0obtg_temporal_sep_fd_dev\0"
@@ -319,6 +319,13 @@ int obtg_ctx_set_ang_rate_order(obtg_ctx* c, int elevate_first)
     return OBTG_OK;
 }
 
+int obtg_ctx_set_second_speed_bound(obtg_ctx* c, double bound, int is_max, double* d_out)
+{
+    if (!check_ctx(c)) return OBTG_ERR_ARG;
+    c->speed2.bound = bound; c->speed2.is_max = is_max != 0; c->speed2.d_out = d_out;
+    return OBTG_OK;
+}
+
 int obtg_sync(obtg_ctx* c)
 {
     if (!check_ctx(c)) return OBTG_ERR_ARG;
@@ -339,13 +346,30 @@ int obtg_num_pairs(const obtg_ctx* c) { return c ? c->n_pairs : 0; }
 static int fd_materialise(obtg_ctx* c, const double* dY0, int n_fixed_cols, double h, int B);
 
 extern "C++" {
+// can_fd: can EVERY kernel of this call form the view's rows itself?  Decided before anything is launched, so that a
+// call of several launches never runs its first ones twice (a launcher answering kNeedBatch after an earlier launch of
+// the same call had gone out used to make the whole call run again on the materialised batch: right results, twice
+// the work, two flips of the sweep's trip-count history).
+// launch_dynamics is one launch on the specialised shapes; otherwise a speed launch and / or a generic angular-rate one
+static bool dynamics_can_fd(const obtg_ctx* c, bool want_speed, bool want_ang)
+{
+    if (dynamics_fd_on_the_fly(c, want_ang)) return true;
+    return !want_ang && want_speed && bernstein_fd_on_the_fly(c);
+}
+// launch_pair_sweep: one launch, or a gjkNew sweep (forms the rows itself unless it de-duplicates) + the separate
+// temporal-separation kernel
+static bool pair_sweep_can_fd(const obtg_ctx* c)
+{
+    return pair_sweep_is_one_launch(c) || (!c->fd_dedup && bernstein_fd_on_the_fly(c));
+}
+
 template <class Launch>
-static int with_batch(obtg_ctx* c, const double* dY, int B, Launch launch)
+static int with_batch(obtg_ctx* c, const double* dY, int B, bool can_fd, Launch launch)
 {
     if (dY) return launch(dY);
     if (!c->view.Y0 || B != c->view.B) return OBTG_ERR_ARG;
     int rc = kNeedBatch;
-    if (!c->view.materialised) {
+    if (!c->view.materialised && can_fd) {
         c->fd.Y0 = c->view.Y0; c->fd.h = c->view.h; c->fd.fixed = c->view.fixed;
         rc = launch(c->view.Y0);
         c->fd.Y0 = nullptr;
@@ -389,7 +413,7 @@ int obtg_temporal_sep_dev(obtg_ctx* c, const double* dY, int B, double max_sep, 
     if (!check_ctx(c) || !d_out || B < 0) return OBTG_ERR_ARG;
     if (pair_begin < 0 || pair_count < 0 || pair_begin + pair_count > c->n_pairs) return OBTG_ERR_ARG;
     (void)hipSetDevice(c->device);
-    return with_batch(c, dY, B, [&](const double* src) {
+    return with_batch(c, dY, B, true, [&](const double* src) {
         return launch_temporal_sep(c, src, B, max_sep, pair_begin, pair_count, false, d_out); });
 }
 
@@ -399,7 +423,7 @@ int obtg_temporal_sep_min_dev(obtg_ctx* c, const double* dY, int B, double max_s
     if (!check_ctx(c) || !d_out || B < 0) return OBTG_ERR_ARG;
     if (pair_begin < 0 || pair_count < 0 || pair_begin + pair_count > c->n_pairs) return OBTG_ERR_ARG;
     (void)hipSetDevice(c->device);
-    return with_batch(c, dY, B, [&](const double* src) {
+    return with_batch(c, dY, B, true, [&](const double* src) {
         return launch_temporal_sep(c, src, B, max_sep, pair_begin, pair_count, true, d_out); });
 }
 
@@ -408,14 +432,14 @@ int obtg_speed_dev(obtg_ctx* c, const double* dY, const double* d_tf, int B, dou
 {
     if (!check_ctx(c) || !d_tf || !d_out || B < 0) return OBTG_ERR_ARG;
     (void)hipSetDevice(c->device);
-    return with_batch(c, dY, B, [&](const double* src) { return launch_speed(c, src, d_tf, B, bound, is_max, d_out); });
+    return with_batch(c, dY, B, true, [&](const double* src) { return launch_speed(c, src, d_tf, B, bound, is_max, d_out); });
 }
 
 int obtg_ang_rate_dev(obtg_ctx* c, const double* dY, const double* d_tf, int B, double max_rate, double* d_out)
 {
     if (!check_ctx(c) || !d_tf || !d_out || B < 0) return OBTG_ERR_ARG;
     (void)hipSetDevice(c->device);
-    return with_batch(c, dY, B, [&](const double* src) { return launch_ang_rate(c, src, d_tf, B, max_rate, d_out); });
+    return with_batch(c, dY, B, true, [&](const double* src) { return launch_ang_rate(c, src, d_tf, B, max_rate, d_out); });
 }
 
 int obtg_dynamics_dev(obtg_ctx* c, const double* dY, const double* d_tf, int B, double speed_bound,
@@ -423,7 +447,7 @@ int obtg_dynamics_dev(obtg_ctx* c, const double* dY, const double* d_tf, int B, 
 {
     if (!check_ctx(c) || !d_tf || B < 0 || (!d_out_speed && !d_out_ang)) return OBTG_ERR_ARG;
     (void)hipSetDevice(c->device);
-    return with_batch(c, dY, B, [&](const double* src) {
+    return with_batch(c, dY, B, dynamics_can_fd(c, d_out_speed != nullptr, d_out_ang != nullptr), [&](const double* src) {
         return launch_dynamics(c, src, d_tf, B, speed_bound, speed_is_max, max_rate, d_out_speed, d_out_ang); });
 }
 
@@ -493,7 +517,15 @@ static int ensure_ring(obtg_ctx* c)
         (void)hipGetLastError(); c->ring = nullptr; return OBTG_ERR_OOM;
     }
     for (int i = 0; i < kRingSlots; ++i)
-        if (hipEventCreateWithFlags(&c->ring_ev[i], hipEventDisableTiming) != hipSuccess) return OBTG_ERR_DEVICE;
+        if (hipEventCreateWithFlags(&c->ring_ev[i], hipEventDisableTiming) != hipSuccess) {
+            // partial failure: leave no half-built ring behind (the next call would take it for a complete one)
+            (void)hipGetLastError();
+            for (int j = 0; j < i; ++j) { (void)hipEventDestroy(c->ring_ev[j]); c->ring_ev[j] = nullptr; }
+            c->ring_ev[i] = nullptr;
+            (void)hipHostFree(c->ring);
+            c->ring = nullptr;
+            return OBTG_ERR_DEVICE;
+        }
     return OBTG_OK;
 }
 
@@ -925,7 +957,7 @@ int obtg_pair_sweep_dev(obtg_ctx* c, const double* dY, int B, double max_sep, do
         md_cap < 1) return OBTG_ERR_ARG;
     if (!c->hull_pairs_set) return OBTG_ERR_ARG;   // no pair list registered (or invalidated by obtg_ctx_set_polygons)
     (void)hipSetDevice(c->device);
-    return with_batch(c, dY, B, [&](const double* src) {
+    return with_batch(c, dY, B, pair_sweep_can_fd(c), [&](const double* src) {
         return launch_pair_sweep(c, src, B, max_sep, d_out_sep, max_iter, md_cap, d_flag, d_p1, d_p2, d_dist, d_nsup, d_status); });
 }
 
@@ -939,7 +971,7 @@ int obtg_constraint_sweep_dev(obtg_ctx* c, const double* dY, const double* d_tf,
     if (!c->hull_pairs_set) return OBTG_ERR_ARG;
     if (d_out_ang && c->dim != 2) return OBTG_ERR_ARG;
     (void)hipSetDevice(c->device);
-    return with_batch(c, dY, B, [&](const double* src) {
+    return with_batch(c, dY, B, pair_sweep_can_fd(c) && dynamics_can_fd(c, true, d_out_ang != nullptr), [&](const double* src) {
         SweepFold sp;
         sp.d_tf = d_tf; sp.speed_bound = speed_bound; sp.speed_is_max = speed_is_max;
         sp.d_out_speed = d_out_speed; sp.d_out_ang = d_out_ang; sp.max_rate = max_rate;
@@ -966,7 +998,7 @@ int obtg_gjk_swarm_dev(obtg_ctx* c, const double* dY, int B, int max_iter, int m
     if (c->dim < 2) return OBTG_ERR_ARG;   // bezier.py:847-851: curves must be 2-D or 3-D
     if (!c->hull_pairs_set) return OBTG_ERR_ARG;   // no pair list registered (or invalidated by obtg_ctx_set_polygons)
     (void)hipSetDevice(c->device);
-    return with_batch(c, dY, B, [&](const double* src) {
+    return with_batch(c, dY, B, true, [&](const double* src) {
         return launch_gjk_swarm(c, src, B, max_iter, md_cap, d_flag, d_p1, d_p2, d_dist, d_nsup, d_status); });
 }
 

@@ -2506,7 +2506,7 @@ int launch_gjk_swarm(obtg_ctx* c, const double* dY, int B, int max_iter, int md_
                 ts.sign = 1.0; ts.offset = -(fold->max_sep * fold->max_sep);
                 ts.fd = p.fd; ts.fd_fixed = p.fd_fixed; ts.fd_h = p.fd_h;
                 size_t ns_bytes = sizeof(double) * ((size_t)ts.stage_slots * vp3 + (size_t)4 * tr * tpf);
-                if (fold->d_out_speed && fold->d_tf) {
+                if (fold->d_out_speed && fold->d_tf && !c->speed2.d_out) {      // (a second speed bound: the dynamics launch writes both)
                     sp = ts;
                     sp.pairs = nullptr; sp.tf = fold->d_tf; sp.out = fold->d_out_speed; sp.n_obj = c->n_veh;
                     sp.item_count = c->n_veh;
@@ -2703,6 +2703,11 @@ int launch_pair_sweep(obtg_ctx* c, const double* dY, int B, double max_sep, doub
             d.w2 = speed->max_rate * speed->max_rate;
             const double b2 = speed->speed_bound * speed->speed_bound;
             d.sp_sign = speed->speed_is_max ? -1.0 : 1.0; d.sp_offset = speed->speed_is_max ? b2 : -b2;
+            if (c->speed2.d_out) {
+                const double c2 = c->speed2.bound * c->speed2.bound;
+                d.out_speed2 = c->speed2.d_out;
+                d.sp2_sign = c->speed2.is_max ? -1.0 : 1.0; d.sp2_offset = c->speed2.is_max ? c2 : -c2;
+            }
             d.W2n = c->d_ang_w2n.as<double>(); d.W22n = c->d_ang_w22n.as<double>(); d.Wn = c->d_ang_wn.as<double>();
             d.fd = p.fd; d.fd_fixed = p.fd_fixed; d.fd_h = p.fd_h;
             p.dyn_first_block = (int)grid;

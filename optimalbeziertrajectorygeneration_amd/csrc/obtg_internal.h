@@ -70,6 +70,8 @@ struct obtg_ctx {
     obtg::DevBuf d_ang_T4;    // angular rate, R > 0: elevation 4*deg -> 4*(deg+R) as a scaled convolution (elev_conv_padded)
     obtg::DevBuf d_ang_cv2;   // the same for the speed rows, 2*deg -> 2*deg+R, with the 1/C(2n+R, k) row
     bool ang_elevate_first = false;   // true: the reference's order (elevate, then products at degree n+R; generic kernel)
+    // obtg_ctx_set_second_speed_bound: every dynamics pass that writes speed rows also writes the other bound's rows
+    struct { double bound = 0.0; int is_max = 0; double* d_out = nullptr; } speed2;
     std::vector<int> h_pairs; // host copy of the pair table (2 ints per pair)
     std::vector<int> h_tiles; // row-window tiles of the current (pair_begin, pair_count)
     obtg::DevBuf d_tiles;
@@ -181,6 +183,7 @@ int launch_dynamics(obtg_ctx* c, const double* dY, const double* d_tf, int B, do
                     double max_rate, double* d_out_speed, double* d_out_ang);
 int launch_fd_batch(obtg_ctx* c, const double* dY0, int n_fixed_cols, double h, int B, double* dY);
 bool dynamics_fd_on_the_fly(const obtg_ctx* c, bool want_ang);
+bool bernstein_fd_on_the_fly(const obtg_ctx* c);      // the separate temporal-separation / speed kernels form a view's rows themselves
 bool pair_sweep_is_one_launch(const obtg_ctx* c);
 int launch_bern_elev(obtg_ctx* c, const double* d_in, int rows, int n, int R, double* d_out);
 int launch_bern_diff(obtg_ctx* c, const double* d_in, int rows, int n, double T, double* d_out);

@@ -27,15 +27,25 @@ FD_STEP = 1.4901161193847656e-08   # SciPy '2-point' abs_step (sqrt of machine e
 # Drivers copy / call these directly (Examples/Example1_DubinsCarTimeOptimal.py:19-52 re-implements
 # the first one with a `degElev` argument), so they exist here too; contexts are cached per shape.
 # ---------------------------------------------------------------------------------------------
-_ctx_cache = {}
+import collections
+
+_CTX_CACHE_MAX = 8              # device contexts kept; the least recently used one is closed beyond that
+_ctx_cache = collections.OrderedDict()
 
 
 def _shape_ctx(nVeh, dim, deg, R, device=0):
+    """A device context per (shape, DEG_ELEV): least-recently-used eviction, so that a driver sweeping degElev or the
+    degree (Examples/Example1_DubinsCarTimeOptimal.py:19-52 takes degElev as an argument) does not pile up contexts."""
     key = (int(nVeh), int(dim), int(deg), int(R), int(device))
     c = _ctx_cache.get(key)
     if c is None:
         c = _capi.Context(key[0], key[1], key[2], key[3], device=key[4])
         _ctx_cache[key] = c
+        while len(_ctx_cache) > _CTX_CACHE_MAX:
+            _, old = _ctx_cache.popitem(last=False)
+            old.close()
+    else:
+        _ctx_cache.move_to_end(key)
     return c
 
 

@@ -102,6 +102,67 @@ def test_pair_partition_and_batch_sharding_world2():
         assert blocks == [(0, 28), (28, 27)]
 
 
+def _worker8(rank, world, port, q):
+    """world_size 8 on C4's list sizes: 32 640 temporal-separation pairs + a 32 640-pair hull list, synthetic per-pair
+    values (this test is about the partition and the packed all-gather, not about the evaluators), and a short list of
+    5 pairs that leaves three ranks with EMPTY blocks."""
+    import sys
+    sys.path.insert(0, REPO)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from optimalbeziertrajectorygeneration_amd.distributed import (PairPartitionedSweep, all_gather_pair_blocks, partition,
+                                                                       shard_rows)
+        B, P = 3, 32640
+        rng = np.random.default_rng(5)
+        mins = rng.normal(size=(B, P))
+        g_dist = rng.uniform(0.0, 9.0, size=(B, P)); g_dist[:, ::7] = np.nan
+        g_flag = rng.integers(-1, 2, size=(B, P)).astype(np.int32)
+        tiny = rng.normal(size=(B, 5))                              # 5 pairs over 8 ranks: ranks 5..7 own nothing
+        sweep = PairPartitionedSweep(P, 1)
+        hb, tb = partition(P, world), partition(5, world)
+        s0, sc = sweep.my_block
+        h0, hc = hb[rank]
+        t0, tc = tb[rank]
+        parts = [(torch.from_numpy(mins[:, s0:s0 + sc].copy()), sweep.blocks, 1),
+                 (torch.from_numpy(g_dist[:, h0:h0 + hc].copy()), hb, 1),
+                 (torch.from_numpy(g_flag[:, h0:h0 + hc].copy()), hb, 1),
+                 (torch.from_numpy(tiny[:, t0:t0 + tc].copy()), tb, 1)]
+        a_min, a_dist, a_flag, a_tiny = all_gather_pair_blocks(parts)
+        ok = bool(np.array_equal(a_min.numpy(), mins) and np.array_equal(a_dist.numpy(), g_dist, equal_nan=True)
+                  and np.array_equal(a_flag.numpy(), g_flag) and np.array_equal(a_tiny.numpy(), tiny))
+        # width > 1 through PairPartitionedSweep.run, ragged: 31 doubles per pair as at C4 (degree 15)
+        full = rng.normal(size=(2, 1000 * 31))
+        sw = PairPartitionedSweep(1000, 31)
+        got = sw.run(lambda b, c: torch.from_numpy(full.reshape(2, 1000, 31)[:, b:b + c].reshape(2, -1).copy()), 2,
+                     torch.device("cpu"))
+        ok = ok and bool(np.array_equal(got.numpy(), full))
+        q.put((rank, ok, sweep.blocks[rank], tb[rank], shard_rows(7169, world, rank)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_pair_partition_world8_with_empty_blocks():
+    """The first real 8-GPU run must not be the first 8-way run: partition + packed all-gather at world size 8."""
+    world = 8
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker8, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=300) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(ok for _, ok, _, _, _ in res)
+    assert [b for _, _, b, _, _ in res] == [(4080 * r, 4080) for r in range(8)]
+    assert [t for _, _, _, t, _ in res] == [(0, 1), (1, 1), (2, 1), (3, 1), (4, 1), (5, 0), (5, 0), (5, 0)]
+    rows = [s for _, _, _, _, s in res]
+    assert sum(c for _, c in rows) == 7169 and rows[0] == (0, 897) and rows[7][0] + rows[7][1] == 7169
+
+
 def _run_bench(args, env_extra=None, timeout=300):
     import subprocess
     import sys

@@ -80,6 +80,7 @@ def test_bench_starts_its_own_ranks():
     one = _bench(["--gpus", "1", "--steps", "6", "--warmup", "2", "--no-cpu", "--workload", "C2"])
     two = _bench(["--gpus", "2"] + common)
     assert one["n_gpus"] == 1 and two["n_gpus"] == 2 and two["scaling"] == "weak"
+    assert two["config"]["ranks_seen"] == 2 and two["config"]["backend"] == "gloo" and len(two["config"]["devices"]) == 2
     B = two["config"]["evals_per_step_per_gpu"]
     assert abs(two["value"] - 2 * B * two["steps"] / (two["ms_per_step"] * 1e-3 * two["steps"])) < 1e-3 * two["value"]
 
@@ -127,3 +128,11 @@ def test_default_bench_line_keeps_the_contract():
     assert c["kind"] == "port" and c["cores"] == 1 and c["value"] > 0 and c["unit"] == d["unit"] and c["sample"]
     p = d["parity_check"]
     assert p["ok"] is True and p["flags_equal"] is True and p["status_nonok"] == 0 and p["max_rel"] < 1e-9
+    assert p["max_rel_elementwise"] < 1e-6 and set(p["per_family_elementwise"]) == set(p["per_family"])
+    # roofline.frac follows SURVEY 8(d): the one launch's bytes are the per-eval figure x rows
+    k = [k for k in d["kernels"] if k["kernel"] == "pair_sweep"][0]
+    assert k["alg_bytes_per_launch"] == d["config"]["alg_bytes_per_eval"] * d["config"]["evals_per_step_per_gpu"]
+    assert k["launches"] >= 12                      # short runs: events on every launch of the dominant kernel
+    assert d["config"]["ranks_seen"] == 1 and len(d["config"]["devices"]) == 1
+    v = d["variants"]
+    assert set(v) >= {"history_off", "moving_x", "moving_x_history_off"} and all(x["ms_per_step"] > 0 for x in v.values())

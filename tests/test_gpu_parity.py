@@ -1289,6 +1289,68 @@ def test_constraint_sweep_equals_separate_calls(capi, synth, shape):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("shape", ["C3_one_launch", "planar", "elevated", "space3d", "generic"])
+def test_both_speed_bounds_from_one_pass(capi, synth, oracle, shape):
+    """minSpeedConstraints AND maxSpeedConstraints (optimization.py:135-169) from one dynamics pass
+    (obtg_ctx_set_second_speed_bound): the second bound's rows equal, bit for bit, what a pass of its own writes, and the
+    first bound's rows are untouched; through obtg_dynamics_dev and through the one-launch constraint sweep."""
+    import torch
+    N, d, n, R, M, B = {"C3_one_launch": (64, 2, 10, 0, 8, 40), "planar": (9, 2, 7, 0, 0, 13), "elevated": (8, 2, 10, 6, 0, 9),
+                        "space3d": (7, 3, 5, 0, 0, 6), "generic": (5, 2, 12, 2, 0, 4)}[shape]
+    Y = synth.fd_batch(synth.swarm_control_points(N, d, n, seed=33), B=B, h=1e-3)
+    ctx = capi.Context(N, d, n, R)
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    dY = torch.from_numpy(Y).cuda()
+    dtf = torch.from_numpy(np.linspace(3.0, 9.0, B)).cuda()
+    vmin, vmax, wmax = 0.7, 4.0, 1.5
+    f64 = torch.float64
+    want_ang = d == 2
+
+    def new(nl):
+        return torch.full((B, nl), float("nan"), dtype=f64, device="cuda")
+    ref_max, ref_min, ref_an = new(ctx.len_speed), new(ctx.len_speed), (new(ctx.len_ang_rate) if want_ang else None)
+    ctx.dynamics_dev(dY.data_ptr(), dtf.data_ptr(), B, vmax, True, wmax, ref_max.data_ptr(), ref_an.data_ptr() if want_ang else None)
+    # (the reference pass of the second bound asks for the angular rate as well, so that it runs the same kernel: the
+    # speed-only fallbacks of the elevated shapes are a different kernel with its own rounding)
+    scratch_an = new(ctx.len_ang_rate) if want_ang else None
+    ctx.dynamics_dev(dY.data_ptr(), dtf.data_ptr(), B, vmin, False, wmax, ref_min.data_ptr(), scratch_an.data_ptr() if want_ang else None)
+    got_max, got_min, got_an = new(ctx.len_speed), new(ctx.len_speed), (new(ctx.len_ang_rate) if want_ang else None)
+    ctx.set_second_speed_bound(vmin, False, got_min.data_ptr())
+    ctx.reset_kernel_stats(); ctx.set_profiling(True)
+    if shape == "C3_one_launch":
+        polys = synth.polygon_obstacles(M, seed=33)
+        pa, pb = synth.swarm_pairs(N, M)
+        ctx.set_polygons(*synth.pack_polys(polys))
+        ctx.set_hull_pairs(pa, pb)
+        P, L, Ps = ctx.num_pairs, 2 * n + 1, len(pa)
+        sep = torch.empty((B, P * L), dtype=f64, device="cuda")
+        flag = torch.empty((B, Ps), dtype=torch.int32, device="cuda")
+        p1, p2 = torch.empty((B, Ps, 3), dtype=f64, device="cuda"), torch.empty((B, Ps, 3), dtype=f64, device="cuda")
+        dist = torch.empty((B, Ps), dtype=f64, device="cuda")
+        ctx.constraint_sweep_dev(dY.data_ptr(), dtf.data_ptr(), B, 0.9, sep.data_ptr(), vmax, True, wmax, got_max.data_ptr(),
+                                 got_an.data_ptr(), flag.data_ptr(), p1.data_ptr(), p2.data_ptr(), dist.data_ptr(), None, None, 128, 500)
+    else:
+        ctx.dynamics_dev(dY.data_ptr(), dtf.data_ptr(), B, vmax, True, wmax, got_max.data_ptr(), got_an.data_ptr() if want_ang else None)
+    ctx.set_second_speed_bound(0.0, False, None)
+    torch.cuda.synchronize()
+    ks = {k: v[1] for k, v in ctx.kernel_stats().items() if v[1]}
+    ctx.set_profiling(False)
+    if shape == "C3_one_launch":
+        assert ks == {"pair_sweep": 1}, ks            # still the one launch
+    if shape in ("planar", "elevated"):
+        assert ks == {"ang_rate": 1}, ks              # one dynamics launch wrote all three outputs
+    for got, ref, what in ((got_max, ref_max, "first bound"), (got_min, ref_min, "second bound"), (got_an, ref_an, "angular rate")):
+        if ref is not None:
+            assert torch.equal(got.view(torch.int64), ref.view(torch.int64)), (shape, what)
+    # and both against the oracle (its speed rows are the max-speed form vmax^2 - |v|^2)
+    o_max = oracle.eval_batch(Y, np.linspace(3.0, 9.0, B), N, d, R, 0.9, vmax, wmax)[1]
+    assert_close(got_max.cpu().numpy(), o_max, RTOL, shape + " max speed vs oracle")
+    assert_close(got_min.cpu().numpy(), (vmax ** 2 - o_max) - vmin ** 2, 1e-9, shape + " min speed vs oracle")
+    ctx.set_stream(0)
+    ctx.close()
+
+
+@pytest.mark.gpu
 def test_small_host_calls_through_mapped_memory_equal_the_staged_path(capi, synth, monkeypatch):
     """One-row host calls keep their control points and results in mapped pinned host memory (the kernel reads and
     writes across PCIe itself; capi.cpp DevBuf::reserve).  Same bits as the device-staged path (OBTG_ZERO_COPY=0), for

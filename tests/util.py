@@ -25,3 +25,15 @@ def assert_close(got, ref, rtol=RTOL, what=""):
     worst = float((err / np.maximum(tol, 1e-300)).max()) * rtol
     assert (err <= tol).all(), "%s: max scaled err %.3e > %.1e" % (what, worst, rtol)
     return worst
+
+
+def elementwise_rel(got, ref, floor=1e-6):
+    """Largest |got - ref| / |ref| over the finite elements that are not tiny against their own vector
+    (|ref| > floor x the vector's largest magnitude): the figure the scale-aware bound above does not show."""
+    got = np.asarray(got, dtype=np.float64).reshape(-1)
+    ref = np.asarray(ref, dtype=np.float64).reshape(-1)
+    fin = np.isfinite(ref)
+    if not fin.any():
+        return 0.0
+    m = fin & (np.abs(ref) > floor * np.abs(ref[fin]).max())
+    return float((np.abs(got[m] - ref[m]) / np.abs(ref[m])).max()) if m.any() else 0.0
