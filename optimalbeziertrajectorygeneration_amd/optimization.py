@@ -95,7 +95,8 @@ class BezOptimization(object):
                  pointObstacles=None,
                  shapeObstacles=None,
                  device=0,
-                 separationRows='all'):
+                 separationRows='all',
+                 angRateOrder='fast'):
         """Beyond the reference's keywords: `device` (HIP ordinal) and `separationRows` --
         'all': temporalSeparationConstraints returns every elevated control point of every pair, as the
         reference does (optimization.py:337); 'min': one row per pair, the smallest of them -- the
@@ -104,6 +105,12 @@ class BezOptimization(object):
         its dense least-squares step is what dominates an iteration once the callbacks are fast)."""
         if separationRows not in ('all', 'min'):
             raise ValueError("separationRows must be 'all' or 'min', not {!r}".format(separationRows))
+        # DEG_ELEV > 0 only: 'fast' forms the angular rate's products at degree 4n and elevates them (0.2 ms at C5);
+        # 'reference' elevates the position first as optimization.py:597 does (1.8 ms) -- closer to the exact value on
+        # vehicles that nearly stop (tests/test_gpu_parity.py::test_near_stop_angular_rate_on_device, DESIGN.md 4.2b)
+        if angRateOrder not in ('fast', 'reference'):
+            raise ValueError("angRateOrder must be 'fast' or 'reference', not {!r}".format(angRateOrder))
+        self.angRateOrder = angRateOrder
         self.pointObstacles = pointObstacles
         self.shapeObstacles = shapeObstacles
         self._device = device
@@ -142,6 +149,7 @@ class BezOptimization(object):
             obs = self.pointObstacles if with_point_obs else None
             c = _capi.Context(self.model['numVeh'], self.model['dim'], self.model['deg'], int(DEG_ELEV),
                               point_obs=obs, device=self._device)
+            c.set_ang_rate_order(self.angRateOrder == 'reference')
             self._ctxs[key] = c
         if c.deg_elev != int(DEG_ELEV):
             c.set_deg_elev(int(DEG_ELEV))
@@ -153,6 +161,7 @@ class BezOptimization(object):
         c = self._ctxs.get('one')
         if c is None:
             c = _capi.Context(1, self.model['dim'], self.model['deg'], int(DEG_ELEV), device=self._device)
+            c.set_ang_rate_order(self.angRateOrder == 'reference')
             self._ctxs['one'] = c
         if c.deg_elev != int(DEG_ELEV):
             c.set_deg_elev(int(DEG_ELEV))

@@ -619,8 +619,33 @@ def gen_spatial():
     save("spatial.npz", **d)
 
 
+def gen_nearstop():
+    """Angular rate with DEG_ELEV > 0 on vehicles that nearly stop (round 3).  A random-shape stress run of round 2
+    (tools/stress_sweeps.py families, trial 28: 48 vehicles, degree 15, DEG_ELEV 100,
+    synth.swarm_control_points(48, 2, 15, seed=528)) found one element 1.45e-8 (scale-aware) from the oracle in the
+    default order of operations.  Its worst-conditioned vehicles -- the four whose elevated |v|^2 control points come
+    closest to zero (some cross it) -- go through the REFERENCE here, at two final times, so that the suite can state
+    what each order of operations achieves against the reference itself."""
+    N, n, R = 48, 15, 100
+    Yall = synth.swarm_control_points(N, 2, n, seed=528)
+    veh = [9, 41, 42, 32]
+    Y = np.concatenate([Yall[2 * v:2 * v + 2] for v in veh])
+    d = {"Y": Y, "veh": np.array(veh), "par": np.array([len(veh), 2, n, R, 1.0])}
+    for tf in (10.0, 14.3):
+        opt.DEG_ELEV = R
+        with np.errstate(all="ignore"):
+            a = opt._maxAngularRateConstraints(Y, len(veh), 2, tf, 1.0)
+        sp = opt._maxSpeedConstraints(Y, len(veh), 2, tf, 5.0)
+        opt.DEG_ELEV = 0
+        d["angrate_tf%g" % tf] = np.asarray(a, dtype=float)
+        d["maxspeed_tf%g" % tf] = np.asarray(sp, dtype=float)
+        print("  nearstop tf=%g: angrate %s, |max| %.3e" % (tf, np.asarray(a).shape, np.nanmax(np.abs(a))))
+    d["tfs"] = np.array([10.0, 14.3])
+    save("nearstop.npz", **d)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["tables", "ops", "problem", "constraints", "gjk", "mindist", "c5", "spatial"]
+    which = sys.argv[1:] or ["tables", "ops", "problem", "constraints", "gjk", "mindist", "c5", "spatial", "nearstop"]
     for w in which:
         if w == "none":          # import-only (exploration)
             continue

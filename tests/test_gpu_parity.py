@@ -1024,6 +1024,47 @@ def test_set_polygons_invalidates_the_hull_pair_list(capi, synth):
     ctx.close()
 
 
+def test_near_stop_angular_rate_on_device(capi, oracle, golden_dir, capsys):
+    """The DEG_ELEV > 0 angular rate on near-stop vehicles (tests/golden/nearstop.npz: the REFERENCE's output on the
+    worst-conditioned vehicles of round 2's stress shape -- the run that showed 1.45e-8 -- plus exact rational values).
+    Three of the four vehicles are well conditioned: both orders of operations hold 1e-9 against the reference.  On the
+    fourth (|v|^2 control points crossing zero, quotients to 3.5e5) the reference itself is 3.0e-9 from the exact value
+    and its C restatement 1.2e-8 from the reference (tests/test_oracle_golden.py), so the bar there is stated against
+    the EXACT value: each order's worst element is recorded and bounded explicitly -- no silent exception."""
+    g = _load(golden_dir, "nearstop.npz")
+    Y = g["Y"]
+    N, n, R = int(g["par"][0]), int(g["par"][2]), int(g["par"][3])
+    L4 = 4 * (n + R) + 1
+
+    def err(a, b, v):
+        return float((np.abs(a[v] - b[v]) / np.maximum(np.abs(b[v]), np.abs(b[v]).max())).max())
+    report = []
+    for tf in g["tfs"]:
+        ref = g["angrate_tf%g" % tf].reshape(N, L4)
+        exact = g["exact_tf%g" % tf].reshape(N, L4)
+        for order, name in ((0, "default order"), (1, "reference order")):
+            ctx = capi.Context(N, 2, n, R)
+            ctx.set_ang_rate_order(order)
+            got = ctx.ang_rate(Y, float(tf), 1.0)[0].reshape(N, L4)
+            ctx.close()
+            for v in (1, 2, 3):
+                assert err(got, ref, v) <= 1e-9, (name, tf, v, err(got, ref, v))
+            e_ref, e_exact = err(got, ref, 0), err(got, exact, 0)
+            report.append("tf %g %s: near-stop vehicle %.2e from the reference, %.2e from the exact value "
+                          "(the reference: %.2e from exact)" % (tf, name, e_ref, e_exact, err(ref, exact, 0)))
+            assert e_exact <= NEAR_STOP_BOUND_EXACT[order], (name, tf, e_exact)
+            assert e_ref <= NEAR_STOP_BOUND_REF[order], (name, tf, e_ref)
+    with capsys.disabled():
+        print("\n" + "\n".join(report))
+
+
+# achieved bounds on the near-stop vehicle (scale-aware, per vehicle): [default order, reference order]
+# measured on MI355X (round 3): default order 3.1e-10 / 5.2e-10 from the exact value at tf = 10 / 14.3 (the reference
+# itself: 3.0e-9 / 7.2e-10), reference order 1.6e-9 / 3.1e-9; against the reference 3.4e-9 / 2.1e-10 and 4.6e-9 / 2.4e-9
+NEAR_STOP_BOUND_EXACT = (2e-9, 1e-8)
+NEAR_STOP_BOUND_REF = (1e-8, 1e-8)
+
+
 def test_ang_rate_with_elevation_both_orders(capi, oracle, synth, golden_dir):
     """DEG_ELEV > 0: the default path forms num / den at degree 4n and elevates both by 4R (k_dynamics_elev);
     obtg_ctx_set_ang_rate_order(1) keeps the reference's order of operations (elevate first, generic kernel).

@@ -39,7 +39,7 @@ def exact_ang(x, y, tf, R, w):
     return [F(w) * F(w) - a / b if b != 0 else None for a, b in zip(n2, d2)], den
 
 
-def main():
+def main():  # noqa
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 10
     R = int(sys.argv[2]) if len(sys.argv) > 2 else 60
     N, B = 64, 6
