@@ -1,0 +1,45 @@
+#!/usr/bin/env python3
+"""The flow of the reference's sequential planner (Examples/SequentialSwarm.py:157-192: 3-D, degree 3, vehicles planned
+one after the other against the trajectories already fixed, SLSQP with the separation constraint only) on the MI355X
+path.  Seeded targets stand in for the example's logo CSV: every vehicle climbs from the z = 0 face to a point of the
+z = volume face a random few metres to the side of where it started, so neighbours get in each other's way without the
+whole swarm crossing (the constraint -- every elevated control point of the squared distance above dsafe^2 -- is a
+sufficient condition and is far from tight for head-on crossings at elev(10)).
+
+    python examples/example3_sequential_swarm.py [numVeh]
+
+Runs the plan three ways: the reference's pairing through plain callbacks (SciPy's own finite differences), the same
+with the one-call Jacobian, and the new vehicle against ALL fixed ones (what the example's docstrings describe).
+"""
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from optimalbeziertrajectorygeneration_amd import sequential as SS  # was: the functions of Examples/SequentialSwarm.py
+
+
+def climb_targets(inipts, volume, seed=5, sigma=6.0):
+    rng = np.random.default_rng(seed)
+    return np.clip(inipts[:, :2] + rng.normal(0.0, sigma, size=(inipts.shape[0], 2)), 0.0, volume)
+
+
+def main():
+    nveh = int(sys.argv[1]) if len(sys.argv) > 1 else 50
+    NDIM, DEG, VOLUME, DSAFE = 3, 3, 100, 1          # SequentialSwarm.py:158-162
+    params = SS.Parameters(nveh, NDIM, DEG, VOLUME, DSAFE, seed=3)
+    params = SS.Parameters(nveh, NDIM, DEG, VOLUME, DSAFE, finalpts=climb_targets(params.inipts, VOLUME), seed=3)
+    for pairing, with_jac in (('reference', False), ('reference', True), ('new_vs_all', True)):
+        traj, results, dt = SS.plan(params, pairing=pairing, with_jac=with_jac)
+        # feasibility of the finished plan: every vehicle against every earlier one
+        worst = np.inf
+        for i in range(1, nveh):
+            worst = min(worst, float(SS.new_vs_all(traj[i * NDIM:(i + 1) * NDIM], traj[:i * NDIM], NDIM, DSAFE).min()))
+        print('%-10s %-22s %3d vehicles in %6.2f s  (%d SLSQP iterations, %d not converged)  worst pair margin %+.3e'
+              % (pairing, 'one-call Jacobian' if with_jac else "SciPy's differences", nveh, dt,
+                 sum(r.nit for r in results), sum(not r.success for r in results), worst))
+
+
+if __name__ == '__main__':
+    main()

@@ -150,6 +150,17 @@ int obtg_temporal_sep_fd(obtg_ctx*, const double* Y0, int n_pert, const int* per
 int obtg_temporal_sep_fd_dev(obtg_ctx*, const double* dY0, int n_pert, const int* d_pert_row,
                              const int* d_pert_col, const double* d_pert_val, double max_sep, double* d_out_blk);
 
+/* ---- one curve against K others (Examples/SequentialSwarm.py:43-70, the sequential planner's constraint) ----------
+ * out[b][k] = min over the elevated control points of |one_b - many_k|^2 (normSquare's (d/2) factor kept), minus
+ * max_sep^2: `dv = vehTraj - tempTraj; dv.normSquare().elev(DEG_ELEV).cpts.min() - maxSep**2` (the example hard-codes
+ * elev(10); here DEG_ELEV is the context's).  one[B][dim][deg+1] are B candidates of the one curve (B = 1 for a plain
+ * callback, n_x + 1 for a finite-difference batch of the vehicle being planned), many[K][dim][deg+1] the curves it is
+ * checked against.  No pair table: the context fixes (dim, deg, DEG_ELEV) only -- its vehicle count is not used -- and K
+ * may differ from call to call (the planner's K grows by one per vehicle).  Degrees with a specialised kernel
+ * (deg + 1 in {4, 6, 8, 11, 16, 21}), others OBTG_ERR_UNSUPPORTED. */
+int obtg_one_vs_many_min(obtg_ctx*, const double* one, int B, const double* many, int K, double max_sep, double* out /*[B][K]*/);
+int obtg_one_vs_many_min_dev(obtg_ctx*, const double* d_one, int B, const double* d_many, int K, double max_sep, double* d_out);
+
 /* ---- same sweeps on DEVICE pointers, asynchronous on the context's stream ---------------
  * pair_begin/pair_count select a contiguous block of the lexicographic pair list (the
  * pair-partitioned multi-GPU mode); out rows then hold only that block:

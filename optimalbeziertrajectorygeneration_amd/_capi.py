@@ -38,6 +38,8 @@ _SIGNATURES = {
     "obtg_ctx_set_deg_elev": (_i, [_vp, _i]),
     "obtg_ctx_set_ang_rate_order": (_i, [_vp, _i]),
     "obtg_ctx_set_second_speed_bound": (_i, [_vp, _d, _i, _vp]),
+    "obtg_one_vs_many_min": (_i, [_vp, _vp, _i, _vp, _i, _d, _vp]),
+    "obtg_one_vs_many_min_dev": (_i, [_vp, _vp, _i, _vp, _i, _d, _vp]),
     "obtg_sync": (_i, [_vp]),
     "obtg_len_temporal_sep": (_i, [_vp]),
     "obtg_len_speed": (_i, [_vp]),
@@ -381,6 +383,23 @@ class Context(object):
     def fd_batch_dev(self, dY0, n_fixed_cols, h, B, dY):
         self._check(self._lib.obtg_fd_batch_dev(self._h, _vp(dY0), int(n_fixed_cols), float(h), B, _vp(dY)),
                     "obtg_fd_batch_dev")
+
+    def one_vs_many_min(self, one, many, max_sep):
+        """Examples/SequentialSwarm.py:43-70: one[B][dim][deg+1] (or [dim][deg+1]) against many[K][dim][deg+1] ->
+        out[B][K], the per-pair minimum of the elevated squared-distance control points minus max_sep^2
+        (include/obtg.h obtg_one_vs_many_min)."""
+        nc = self.deg + 1
+        one = np.ascontiguousarray(one, dtype=np.float64).reshape(-1, self.dim, nc)
+        many = np.ascontiguousarray(many, dtype=np.float64).reshape(-1, self.dim, nc)
+        B, K = one.shape[0], many.shape[0]
+        out = np.empty((B, K))
+        self._check(self._lib.obtg_one_vs_many_min(self._h, _ptr(one), B, _ptr(many), K, float(max_sep), _ptr(out)),
+                    "obtg_one_vs_many_min")
+        return out
+
+    def one_vs_many_min_dev(self, d_one, B, d_many, K, max_sep, d_out):
+        self._check(self._lib.obtg_one_vs_many_min_dev(self._h, _vp(d_one), int(B), _vp(d_many), int(K), float(max_sep),
+                                                       _vp(d_out)), "obtg_one_vs_many_min_dev")
 
     def set_second_speed_bound(self, bound, is_max, d_out2):
         """Both speed bounds from one dynamics pass (include/obtg.h obtg_ctx_set_second_speed_bound): while d_out2 (a

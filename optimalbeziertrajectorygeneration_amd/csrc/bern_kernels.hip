@@ -110,6 +110,63 @@ __global__ __launch_bounds__(kWave) void k_tsep_fd(const TsepFdParams p)
 }
 
 // =====================================================================================
+//  One-vs-many separation minima (Examples/SequentialSwarm.py:43-70): the sequential planner's constraint pairs
+//  ONE curve with K others -- `dv = vehTraj - tempTraj; dv.normSquare().elev(10).cpts.min() - maxSep**2` -- so there
+//  is no C(N,2) pair table and K grows by one per planned vehicle.  Item = (b, k): candidate b of the `one` curves
+//  against curve k of the `many`; one lane evaluates the pair exactly as k_normsq_elev's MINONLY form does (same
+//  difference, product weights and elevation sums in the same order) and keeps the minimum in the lane.
+// =====================================================================================
+struct OneManyParams {
+    const double* __restrict__ one;    // [B][DIM][NC]
+    const double* __restrict__ many;   // [K][DIM][NC]
+    const double* __restrict__ W2;     // folded product weights
+    const double* __restrict__ Tt;     // elevation as a scaled convolution (NsParams::Tt)
+    double* __restrict__ out;          // [B][K]
+    int B, K, R;
+    double sign, offset;
+};
+
+template <int NC, int DIM>
+__global__ __launch_bounds__(256) void k_one_vs_many(const OneManyParams p)
+{
+    using S = NsShape<NC, DIM>;
+    constexpr int L = S::L;
+    const long item = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (item >= (long)p.B * p.K) return;
+    const int b = (int)(item / p.K), k = (int)(item - (long)b * p.K);
+    const double* o = p.one + (size_t)b * DIM * NC;
+    const double* m = p.many + (size_t)k * DIM * NC;
+    double a[DIM][NC];
+#pragma unroll
+    for (int q = 0; q < DIM; ++q)
+#pragma unroll
+        for (int c = 0; c < NC; ++c) a[q][c] = o[q * NC + c] - m[q * NC + c];
+    double cf[L];
+    normsq_coeffs<NC, DIM>(a, as_ctab(p.W2), cf);
+    double mn;
+    if (p.R == 0) {
+        mn = cf[0];
+#pragma unroll
+        for (int j = 1; j < L; ++j) mn = fmin(mn, cf[j]);
+    } else {
+        const int LR = L + p.R;
+        const ctab_t escale = as_ctab(p.Tt), ebin = escale + L, einv = ebin + (p.R + 2 * L - 1 + kConvPad);
+        double ch[L];
+#pragma unroll
+        for (int j = 0; j < L; ++j) ch[j] = cf[j] * escale[j];
+        mn = INFINITY;
+        for (int kk = 0; kk < LR; ++kk) {
+            const ctab_t win = ebin + kk;              // win[L-1-j] = C(R, kk-j)
+            double s = 0.0;
+#pragma unroll
+            for (int j = 0; j < L; ++j) s = fma(ch[j], win[L - 1 - j], s);
+            mn = fmin(mn, s * einv[kk]);
+        }
+    }
+    p.out[item] = p.sign * mn + p.offset;
+}
+
+// =====================================================================================
 //  angular rate, fast path (R == 0): one vehicle per lane
 // =====================================================================================
 // The degree-4n stage can be split over kDynParts waves per group of 64 vehicles (balanced
@@ -1166,6 +1223,32 @@ int launch_temporal_sep_fd(obtg_ctx* c, const double* dY0, int n_pert, const int
     if (!kern) return OBTG_ERR_UNSUPPORTED;
     ScopedKernelTimer t(c, OBTG_K_TEMPORAL_SEP);
     hipLaunchKernelGGL(kern, grid, dim3(kWave), 0, c->stream, p);
+    OBTG_HIP(c, hipGetLastError());
+    return OBTG_OK;
+}
+
+int launch_one_vs_many_min(obtg_ctx* c, const double* d_one, int B, const double* d_many, int K, double max_sep, double* d_out)
+{
+    if (B <= 0 || K <= 0) return OBTG_OK;
+    int rc = ensure_tables(c);
+    if (rc) return rc;
+    if (!fast_shape(c)) return OBTG_ERR_UNSUPPORTED;
+    OneManyParams p{};
+    p.one = d_one; p.many = d_many; p.W2 = c->d_w2.as<double>(); p.Tt = c->d_Tt.as<double>(); p.out = d_out;
+    p.B = B; p.K = K; p.R = c->R;
+    p.sign = 1.0; p.offset = -(max_sep * max_sep);
+    const long items = (long)B * K;
+    const int nc = c->deg + 1;
+    void (*kern)(const OneManyParams) = nullptr;
+#define OBTG_CASE(NC_, D_) if (nc == NC_ && c->dim == D_) kern = k_one_vs_many<NC_, D_>;
+    OBTG_CASE(4, 2) OBTG_CASE(4, 3) OBTG_CASE(6, 2) OBTG_CASE(6, 3) OBTG_CASE(8, 2) OBTG_CASE(8, 3)
+    OBTG_CASE(11, 2) OBTG_CASE(11, 3) OBTG_CASE(16, 2) OBTG_CASE(16, 3) OBTG_CASE(21, 2) OBTG_CASE(21, 3)
+#undef OBTG_CASE
+    if (!kern) return OBTG_ERR_UNSUPPORTED;
+    // small problems: 64-lane workgroups spread a few hundred items over more CUs
+    const int threads = items >= 16384 ? 256 : 64;
+    ScopedKernelTimer t(c, OBTG_K_TEMPORAL_SEP);
+    hipLaunchKernelGGL(kern, dim3((unsigned)((items + threads - 1) / threads)), dim3(threads), 0, c->stream, p);
     OBTG_HIP(c, hipGetLastError());
     return OBTG_OK;
 }

@@ -207,7 +207,7 @@ const char* obtg_abi_symbols(void)
         "obtg_ctx_create\0obtg_ctx_destroy\0obtg_ctx_set_stream\0obtg_ctx_set_deg_elev\0obtg_ctx_set_ang_rate_order\0obtg_ctx_set_second_speed_bound\0obtg_sync\0"
         "obtg_len_temporal_sep\0obtg_len_speed\0obtg_len_ang_rate\0obtg_num_pairs\0"
         "obtg_temporal_sep\0obtg_speed\0obtg_ang_rate\0obtg_temporal_sep_min\0obtg_temporal_sep_min_range\0"
-        "obtg_temporal_sep_fd\0obtg_temporal_sep_fd_dev\0"
+        "obtg_temporal_sep_fd\0obtg_temporal_sep_fd_dev\0obtg_one_vs_many_min\0obtg_one_vs_many_min_dev\0"
         "obtg_temporal_sep_dev\0obtg_temporal_sep_min_dev\0obtg_speed_dev\0obtg_ang_rate_dev\0obtg_dynamics_dev\0"
         "obtg_fd_batch_dev\0obtg_fd_view_begin\0obtg_fd_view_end\0obtg_fd_forms_on_the_fly\0obtg_pair_sweep_fd_dev\0obtg_dynamics_fd_dev\0obtg_gjk_pairs\0obtg_ctx_set_polygons\0obtg_ctx_set_hull_pairs\0"
         "obtg_ctx_set_fd_dedup\0obtg_ctx_set_gjk_history\0obtg_pair_sweep_dev\0obtg_constraint_sweep_dev\0obtg_gjk_swarm_dev\0obtg_gjk_swarm\0obtg_min_dist\0obtg_min_dist_robust\0obtg_min_dist2poly\0obtg_min_dist2poly_robust\0obtg_gjk_true_pairs\0"
@@ -666,6 +666,32 @@ int obtg_temporal_sep(obtg_ctx* c, const double* Y, int B, double max_sep, doubl
 int obtg_temporal_sep_min(obtg_ctx* c, const double* Y, int B, double max_sep, double* out)
 {
     return host_sep(c, Y, B, max_sep, true, out);
+}
+
+// Examples/SequentialSwarm.py:43-70: one curve against K others, per-pair minimum of the elevated control points
+int obtg_one_vs_many_min_dev(obtg_ctx* c, const double* d_one, int B, const double* d_many, int K, double max_sep, double* d_out)
+{
+    if (!check_ctx(c) || B < 0 || K < 0) return OBTG_ERR_ARG;
+    if (B == 0 || K == 0) return OBTG_OK;
+    if (!d_one || !d_many || !d_out) return OBTG_ERR_ARG;
+    (void)hipSetDevice(c->device);
+    return launch_one_vs_many_min(c, d_one, B, d_many, K, max_sep, d_out);
+}
+
+int obtg_one_vs_many_min(obtg_ctx* c, const double* one, int B, const double* many, int K, double max_sep, double* out)
+{
+    if (!check_ctx(c) || B < 0 || K < 0) return OBTG_ERR_ARG;
+    if (B == 0 || K == 0) return OBTG_OK;
+    if (!one || !many || !out) return OBTG_ERR_ARG;
+    (void)hipSetDevice(c->device);
+    const size_t curve = sizeof(double) * (size_t)c->dim * (c->deg + 1);
+    int rc = h2d(c, c->ws_in, one, curve * B, true);
+    if (rc) return rc;
+    // the planned trajectories grow by one curve per vehicle: the staging buffer grows with them, nothing else does
+    if ((rc = h2d(c, c->ws_in2, many, curve * K))) return rc;
+    if ((rc = c->ws_out.reserve(sizeof(double) * (size_t)B * K, true))) return rc;
+    if ((rc = launch_one_vs_many_min(c, c->ws_in.as<double>(), B, c->ws_in2.as<double>(), K, max_sep, c->ws_out.as<double>()))) return rc;
+    return d2h(c, out, c->ws_out.p, sizeof(double) * (size_t)B * K);
 }
 
 static int check_perts(const obtg_ctx* c, int n_pert, const int* prow, const int* pcol)

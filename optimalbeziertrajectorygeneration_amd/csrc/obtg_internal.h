@@ -175,6 +175,7 @@ int launch_pair_sweep(obtg_ctx* c, const double* dY, int B, double max_sep, doub
                       SweepFold* speed = nullptr);
 int launch_temporal_sep_fd(obtg_ctx* c, const double* dY0, int n_pert, const int* d_prow, const int* d_pcol,
                            const double* d_pval, double max_sep, double* d_out);
+int launch_one_vs_many_min(obtg_ctx* c, const double* d_one, int B, const double* d_many, int K, double max_sep, double* d_out);
 int launch_speed(obtg_ctx* c, const double* dY, const double* d_tf, int B, double bound, int is_max,
                  double* d_out);
 int launch_ang_rate(obtg_ctx* c, const double* dY, const double* d_tf, int B, double max_rate,

@@ -1,36 +1,172 @@
-"""One-vs-many separation constraint of the reference's sequential swarm planner
-(Examples/SequentialSwarm.py:43-70): the trajectory in rows 0..ndim-1 of `y` against every other
-trajectory, reduced to the minimum elevated control point per pair:
+"""The reference's sequential swarm planner (Examples/SequentialSwarm.py) on the MI355X path: vehicles are planned
+one after the other, each by an SLSQP run whose only constraint is the separation from trajectories that are
+already fixed.  Same function names, argument meaning and return values as the example:
 
-    distVeh[i-1] = (y_0 - y_i).normSquare().elev(10).cpts.min()  ->  distVeh - maxSep**2
+    temporalSeparationConstraints(y, nveh, ndim, maxSep)   SequentialSwarm.py:43-70
+    nonlcon(x, vidx, traj, nveh, params)                   :19-40
+    cost(x, vidx, params)                                  :72-78
+    reshape(x, traj, ndim, inipt, finalpt)                 :81-116
+    initguess(vidx, params)                                :119-136
+    Parameters(nveh, ndim, deg, volume, dsafe)             :139-163   (final points passed in; the example reads a CSV)
+    plan(params, ...)                                      :176-192   (the vehicle-after-vehicle loop of `__main__`)
 
-On the MI355X this is the fused per-pair minimum sweep (`obtg_temporal_sep_min`) restricted to the
-first nveh-1 pairs of the lexicographic pair list -- the pairs (0, i).  Nothing of the
-(nveh-1) x (2n+R+1) intermediate leaves the chip.
+The constraint pairs ONE trajectory with K others and keeps the smallest elevated control point of each pair's squared
+distance.  On the device that is `obtg_one_vs_many_min` (include/obtg.h): one lane per (candidate, other trajectory),
+minimum kept in the lane, no pair table, and K simply grows by one per planned vehicle on ONE context per
+(dimension, degree, elevation).
+
+Pairing.  The example's `reshape` appends the vehicle being planned BEHIND the fixed trajectories while its constraint
+takes rows 0..ndim-1 as "the" vehicle, so what the reference evaluates is trajectory 0 against everyone else (of which
+only the last row moves with x).  `pairing='reference'` keeps exactly that; `pairing='new_vs_all'` is what the
+docstrings describe -- the new vehicle against every fixed one -- and what a planner wants.
 """
+import time
+
 import numpy as np
+import scipy.optimize as sop
 
 from . import _capi
+
+FD_STEP = 1.4901161193847656e-08   # SciPy '2-point' abs_step
 
 _ctx_cache = {}
 
 
-def _context(nveh, ndim, deg, deg_elev):
-    key = (nveh, ndim, deg, deg_elev)
+def _context(ndim, deg, deg_elev, device=0):
+    """One context per (dimension, degree, elevation): the number of trajectories is an argument of every call."""
+    key = (int(ndim), int(deg), int(deg_elev), int(device))
     c = _ctx_cache.get(key)
     if c is None:
-        if len(_ctx_cache) > 8:          # planning vehicle after vehicle changes nveh every call
-            _ctx_cache.pop(next(iter(_ctx_cache))).close()
-        c = _capi.Context(nveh, ndim, deg, deg_elev)
+        c = _capi.Context(1, key[0], key[1], key[2], device=key[3])
         _ctx_cache[key] = c
     return c
 
 
 def temporalSeparationConstraints(y, nveh, ndim, maxSep, degElev=10):
-    """Same signature as Examples/SequentialSwarm.py:43 (the elevation, hard-coded to 10 there,
-    is a keyword here)."""
+    """Examples/SequentialSwarm.py:43-70 (the elevation, hard-coded to 10 there, is a keyword here): trajectory 0
+    (rows 0..ndim-1 of y) against trajectories 1..nveh-1 -> float64[nveh-1]."""
     if nveh <= 1:
         return np.atleast_1d(0.0)                     # SequentialSwarm.py:69-70
     y = np.ascontiguousarray(y, dtype=np.float64)
-    ctx = _context(nveh, ndim, y.shape[1] - 1, int(degElev))
-    return ctx.temporal_sep_min(y[None], maxSep, pair_begin=0, pair_count=nveh - 1)[0]
+    ctx = _context(ndim, y.shape[1] - 1, degElev)
+    return ctx.one_vs_many_min(y[0:ndim], y[ndim:nveh * ndim], maxSep)[0]
+
+
+def new_vs_all(ynew, traj, ndim, maxSep, degElev=10):
+    """The candidate trajectories ynew[B][ndim][deg+1] (or one, [ndim][deg+1]) against every fixed trajectory of
+    traj[(K*ndim), deg+1] -> float64[B][K]: the planner's constraint as its docstrings describe it, for a whole
+    finite-difference batch of the new vehicle in one launch."""
+    traj = np.ascontiguousarray(traj, dtype=np.float64)
+    ynew = np.ascontiguousarray(ynew, dtype=np.float64)
+    ctx = _context(ndim, traj.shape[1] - 1, degElev)
+    return ctx.one_vs_many_min(ynew, traj, maxSep)
+
+
+def reshape(x, traj, ndim, inipt, finalpt):
+    """SequentialSwarm.py:81-116: x = the interior control points of the vehicle being planned, dimension after
+    dimension; returns the fixed trajectories with the new one (end points added) appended as the LAST ndim rows."""
+    x = np.asarray(x, dtype=np.float64)
+    y = np.concatenate((np.atleast_2d(inipt).reshape((-1, 1)), x.reshape((ndim, -1)),
+                        np.atleast_2d(finalpt).reshape((-1, 1))), axis=1)
+    traj = np.asarray(traj)
+    return np.concatenate((traj, y)) if traj.size > 0 else y
+
+
+def initguess(vidx, params):
+    """SequentialSwarm.py:119-136: straight line between the vehicle's end points."""
+    x0 = np.empty((params.deg - 1) * params.ndim)
+    for d in range(params.ndim):
+        idx = d * (params.deg - 1)
+        x0[idx:idx + params.deg - 1] = np.linspace(params.inipts[vidx, d], params.finalpts[vidx, d], params.deg + 1)[1:-1]
+    return x0
+
+
+def cost(x, vidx, params):
+    """SequentialSwarm.py:72-78: the example plans for feasibility only."""
+    return 0
+
+
+def nonlcon(x, vidx, traj, nveh, params, pairing='reference', degElev=10):
+    """SequentialSwarm.py:19-40."""
+    if pairing == 'reference':
+        y = reshape(x, traj, params.ndim, params.inipts[vidx, :], params.finalpts[vidx, :])
+        return np.concatenate([temporalSeparationConstraints(y, nveh, params.ndim, params.dsafe, degElev)])
+    traj = np.asarray(traj)
+    if traj.size == 0:
+        return np.atleast_1d(0.0)
+    ynew = reshape(x, np.atleast_2d([]), params.ndim, params.inipts[vidx, :], params.finalpts[vidx, :])
+    return new_vs_all(ynew, traj, params.ndim, params.dsafe, degElev)[0]
+
+
+def nonlcon_jac(x, vidx, traj, nveh, params, pairing='reference', degElev=10):
+    """SciPy's 2-point Jacobian of `nonlcon` from ONE device call: the n_x + 1 candidates x, x + h e_k of the vehicle
+    being planned against the trajectories its rows depend on (all K fixed ones for 'new_vs_all'; trajectory 0 alone
+    for the reference's pairing, whose other rows do not move with x).  Entry for entry what approx_derivative builds
+    from n_x + 1 calls of `nonlcon`."""
+    x = np.asarray(x, dtype=np.float64)
+    traj = np.asarray(traj)
+    nx = x.size
+    if traj.size == 0:
+        return np.zeros((1, nx))
+    X = np.repeat(x[None], nx + 1, axis=0)
+    X[np.arange(1, nx + 1), np.arange(nx)] += FD_STEP
+    nc = params.deg + 1
+    Yc = np.empty((nx + 1, params.ndim, nc))
+    Yc[:, :, 0] = params.inipts[vidx]
+    Yc[:, :, -1] = params.finalpts[vidx]
+    Yc[:, :, 1:-1] = X.reshape(nx + 1, params.ndim, nc - 2)
+    if pairing == 'reference':
+        K = traj.shape[0] // params.ndim
+        J = np.zeros((K, nx))                   # rows: trajectory 0 vs trajectories 1..K-1 (constant) and vs the new one
+        F = new_vs_all(Yc, traj[0:params.ndim], params.ndim, params.dsafe, degElev)[:, 0]
+        J[K - 1] = (F[1:] - F[0]) / ((X[np.arange(1, nx + 1), np.arange(nx)]) - x)
+        return J
+    F = new_vs_all(Yc, traj, params.ndim, params.dsafe, degElev)
+    return ((F[1:] - F[0]) / ((X[np.arange(1, nx + 1), np.arange(nx)]) - x)[:, None]).T
+
+
+class Parameters(object):
+    """SequentialSwarm.py:139-163.  Initial points random in the z = 0 face of the control volume (seeded here); final
+    points are handed in -- the example reads Examples/HawksLogo_1000pts.csv -- or drawn in the z = volume face."""
+
+    def __init__(self, nveh, ndim, deg, volume, dsafe, finalpts=None, seed=3):
+        self.nveh, self.ndim, self.deg, self.volume, self.dsafe = nveh, ndim, deg, volume, dsafe
+        rng = np.random.default_rng(seed)
+        self.inipts = volume * np.concatenate([rng.random((nveh, ndim - 1)), np.zeros((nveh, 1))], axis=1)
+        if finalpts is None:
+            finalpts = volume * np.concatenate([rng.random((nveh, ndim - 1)), np.ones((nveh, 1))], axis=1)
+        finalpts = np.asarray(finalpts, dtype=np.float64)
+        if finalpts.shape[1] == ndim - 1:            # the CSV holds the in-plane coordinates only (:159-161)
+            finalpts = np.concatenate((finalpts, volume * np.ones((nveh, 1))), axis=1)
+        self.finalpts = np.ascontiguousarray(finalpts[:nveh])
+
+
+def plan(params, nveh=None, pairing='reference', with_jac=True, degElev=10, maxiter=250, verbose=False, objective=None):
+    """The loop of SequentialSwarm.py:176-192: plan vehicle i by SLSQP against the trajectories fixed so far, append
+    it, go on.  -> (traj[(nveh*ndim), deg+1], per-vehicle OptimizeResult list, seconds).
+    objective: 'feasibility' is the example's constant cost (SequentialSwarm.py:72-74; the default for its own pairing);
+    'deviation' = squared distance of the interior control points from the straight-line guess, which gives SLSQP a
+    well-posed problem when the new vehicle is tied to EVERY fixed trajectory (the default for 'new_vs_all')."""
+    nveh = params.nveh if nveh is None else nveh
+    if objective is None:
+        objective = 'feasibility' if pairing == 'reference' else 'deviation'
+    traj = np.atleast_2d([])
+    results = []
+    t0 = time.time()
+    for i in range(nveh):
+        x0 = initguess(i, params)
+        cons = {'type': 'ineq', 'fun': lambda x, i=i, traj=traj: nonlcon(x, i, traj, i + 1, params, pairing, degElev)}
+        if with_jac:
+            cons['jac'] = lambda x, i=i, traj=traj: nonlcon_jac(x, i, traj, i + 1, params, pairing, degElev)
+        if objective == 'deviation':
+            fun, grad = (lambda x, x0=x0: float(np.dot(x - x0, x - x0))), (lambda x, x0=x0: 2.0 * (x - x0))
+        else:
+            fun, grad = (lambda x, i=i: cost(x, i, params)), (lambda x: np.zeros_like(x))
+        res = sop.minimize(fun, x0, constraints=[cons], method='SLSQP', jac=grad if with_jac else None,
+                           options={'maxiter': maxiter, 'disp': False, 'iprint': 0})
+        results.append(res)
+        xi = res.x if np.all(np.isfinite(res.x)) else x0
+        traj = reshape(xi, traj, params.ndim, params.inipts[i, :], params.finalpts[i, :])
+        if verbose:
+            print('vehicle %d: nit %d, feasible margin %+.3e' % (i, res.nit, float(np.min(cons['fun'](xi)))))
+    return traj, results, time.time() - t0

@@ -644,8 +644,52 @@ def gen_nearstop():
     save("nearstop.npz", **d)
 
 
+def gen_sequential():
+    """The sequential planner's constraint (Examples/SequentialSwarm.py:43-70) through the REFERENCE's own function:
+    vehicle 0 against every other vehicle, min of the elevated (by 10, hard-coded there) squared-distance control
+    points minus maxSep^2 -- all K = nveh - 1 pairs of each shape.  `hawks`: the example's own shape (3-D, degree 3)
+    with its final points from Examples/HawksLogo_1000pts.csv (stored as input data) and straight-line-plus-noise
+    interiors; the module imports cleanly (its work is under `if __name__ == '__main__'`)."""
+    import pandas as pd
+    import SequentialSwarm as SS
+    d = {}
+    names = []
+    for name, nveh, dim, deg, seed in (("v37_3d_deg5", 37, 3, 5, 71), ("v1000_2d_deg5", 1000, 2, 5, 72)):
+        y = synth.swarm_control_points(nveh, dim, deg, seed=seed)
+        out = SS.temporalSeparationConstraints(y, nveh, dim, 1.0)
+        d[name + "_y"], d[name + "_out"] = y, np.asarray(out, dtype=float)
+        d[name + "_par"] = np.array([nveh, dim, deg, 10, 1.0])
+        names.append(name)
+        print("  sequential %s: %s, min %.4f" % (name, out.shape, out.min()))
+    df = pd.read_csv(os.path.join(REF, "Examples", "HawksLogo_1000pts.csv"))
+    fin2 = np.ascontiguousarray(df.values, dtype=float)
+    nveh, dim, deg, volume = fin2.shape[0], 3, 3, 100.0
+    rng = np.random.default_rng(73)
+    ini = volume * np.concatenate([rng.random((nveh, dim - 1)), np.zeros((nveh, 1))], axis=1)
+    fin = np.concatenate((fin2, volume * np.ones((nveh, 1))), axis=1)
+    s = np.linspace(0.0, 1.0, deg + 1)
+    y = (ini[:, :, None] + (fin - ini)[:, :, None] * s[None, None, :]).reshape(nveh * dim, deg + 1)
+    y[:, 1:-1] += rng.normal(0.0, 2.0, size=(nveh * dim, deg - 1))
+    out = SS.temporalSeparationConstraints(y, nveh, dim, 1.0)
+    d["hawks_y"], d["hawks_out"], d["hawks_finalpts"] = y, np.asarray(out, dtype=float), fin
+    d["hawks_par"] = np.array([nveh, dim, deg, 10, 1.0])
+    names.append("hawks")
+    print("  sequential hawks: %s, min %.4f" % (out.shape, out.min()))
+    # nveh == 1: the function's own answer
+    d["single_out"] = np.asarray(SS.temporalSeparationConstraints(y[:dim], 1, dim, 1.0), dtype=float)
+    # reshape / initguess of the example (layout of x and of the trajectory matrix)
+    P = type("P", (), {})()
+    P.ndim, P.deg, P.inipts, P.finalpts = dim, deg, ini, fin
+    x0 = SS.initguess(5, P)
+    d["hawks_x0_v5"] = x0
+    d["hawks_reshape_v5"] = SS.reshape(x0, y[:2 * dim], dim, ini[5], fin[5])
+    d["hawks_inipts"] = ini
+    d["names"] = np.array(names)
+    save("sequential.npz", **d)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["tables", "ops", "problem", "constraints", "gjk", "mindist", "c5", "spatial", "nearstop"]
+    which = sys.argv[1:] or ["tables", "ops", "problem", "constraints", "gjk", "mindist", "c5", "spatial", "nearstop", "sequential"]
     for w in which:
         if w == "none":          # import-only (exploration)
             continue

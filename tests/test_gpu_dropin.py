@@ -211,24 +211,66 @@ def test_spatial_separation_constraints_golden(golden_dir):
         assert_close(out, s[name + "_out"], 1e-9, name)
 
 
-def test_sequential_swarm_one_vs_many(oracle):
-    """Examples/SequentialSwarm.py:43-70: trajectory 0 against all others, min of the elev(10) control
-    points per pair (fused on the device), including a 1000-vehicle row like the example's full run."""
-    from optimalbeziertrajectorygeneration_amd import synth
-    from optimalbeziertrajectorygeneration_amd.sequential import temporalSeparationConstraints
-    for (nveh, ndim, deg) in ((2, 2, 5), (37, 3, 5), (1000, 2, 5)):
-        y = synth.swarm_control_points(nveh, ndim, deg, seed=31)
-        got = temporalSeparationConstraints(y, nveh, ndim, 0.5)
-        assert got.shape == (nveh - 1,)
-        L = 2 * deg + 10 + 1
-        # oracle: elevated control points of the pairs (0, i) only -> use a 2-vehicle restatement per pair
-        ref = np.empty(nveh - 1)
-        for i in range(1, min(nveh, 60)):
-            yy = np.vstack((y[0:ndim], y[i * ndim:(i + 1) * ndim]))
-            ref[i - 1] = oracle.temporal_sep(yy, 2, ndim, 10, 0.5).reshape(1, L).min()
-        m = min(nveh, 60) - 1
-        assert_close(got[:m], ref[:m])
-    assert temporalSeparationConstraints(y[:2], 1, 2, 0.5).tolist() == [0.0]
+def test_sequential_swarm_one_vs_many(oracle, golden_dir):
+    """Examples/SequentialSwarm.py:43-70 through obtg_one_vs_many_min against the REFERENCE's own function
+    (tests/golden/sequential.npz: trajectory 0 against all others, elev(10), EVERY pair of 37 3-D degree-5 vehicles, of
+    1000 2-D degree-5 vehicles and of the example's own shape -- 1000 3-D degree-3 vehicles towards the logo points),
+    and against the oracle's elevated control points of the same pairs."""
+    from optimalbeziertrajectorygeneration_amd import sequential as SS
+    g = np.load(golden_dir + "/sequential.npz")
+    for name in g["names"]:
+        nveh, ndim, deg, R, ms = g[name + "_par"]
+        nveh, ndim, deg, R = int(nveh), int(ndim), int(deg), int(R)
+        y = g[name + "_y"]
+        got = SS.temporalSeparationConstraints(y, nveh, ndim, ms)
+        assert got.shape == g[name + "_out"].shape == (nveh - 1,)
+        assert_close(got, g[name + "_out"], 1e-9, str(name) + " vs the reference, all %d pairs" % (nveh - 1))
+        L = 2 * deg + R + 1
+        ref = oracle.temporal_sep(y, nveh, ndim, R, ms).reshape(-1, L)[:nveh - 1].min(axis=1)     # pairs (0, j) come first
+        assert_close(got, ref, 1e-9, str(name) + " vs the oracle")
+    assert np.array_equal(SS.temporalSeparationConstraints(y[:ndim], 1, ndim, 1.0), g["single_out"])
+    # layout helpers of the example
+    P = type("P", (), {})()
+    P.ndim, P.deg, P.inipts, P.finalpts = 3, 3, g["hawks_inipts"], g["hawks_finalpts"]
+    assert np.array_equal(SS.initguess(5, P), g["hawks_x0_v5"])
+    assert np.array_equal(SS.reshape(g["hawks_x0_v5"], g["hawks_y"][:6], 3, P.inipts[5], P.finalpts[5]), g["hawks_reshape_v5"])
+    # B candidates x K fixed trajectories in one call == row by row; K changes between calls on the same context
+    y = g["v37_3d_deg5_y"]
+    cand = y.reshape(37, 3, 6)[30:37]
+    for K in (1, 5, 29):
+        full = SS.new_vs_all(cand, y[:3 * K], 3, 1.0)
+        assert full.shape == (7, K)
+        for b in range(7):
+            assert np.array_equal(full[b], SS.new_vs_all(cand[b], y[:3 * K], 3, 1.0)[0])
+
+
+def test_sequential_planner_flow():
+    """The vehicle-after-vehicle loop of SequentialSwarm.py:176-192 on seeded targets: the one-call Jacobian equals
+    SciPy's own finite differences of the callback (both pairings), and the plan of 12 vehicles is feasible."""
+    import scipy.optimize as sop
+    from scipy.optimize._numdiff import approx_derivative
+    from optimalbeziertrajectorygeneration_amd import sequential as SS
+    nveh = 12
+    rng = np.random.default_rng(2)
+    fin = 100.0 * np.concatenate([0.35 + 0.3 * rng.random((nveh, 2)), np.ones((nveh, 1))], axis=1)
+    params = SS.Parameters(nveh, 3, 3, 100.0, 2.5, finalpts=fin, seed=4)
+    params.inipts[:, :2] = 35.0 + 30.0 * rng.random((nveh, 2))          # a crowded volume: the constraint is active
+    traj, results, _ = SS.plan(params, pairing='new_vs_all', with_jac=True)
+    assert traj.shape == (nveh * 3, 4)
+    ok = [r.success for r in results]
+    assert sum(ok) >= nveh - 2, [r.message for r in results if not r.success]
+    for i in range(1, nveh):
+        if ok[i]:                                                       # a converged vehicle clears every earlier one
+            assert SS.new_vs_all(traj[3 * i:3 * i + 3], traj[:3 * i], 3, params.dsafe).min() >= -1e-6
+    x = SS.initguess(7, params) + rng.normal(0, 0.5, 6)
+    for pairing in ('reference', 'new_vs_all'):
+        J = SS.nonlcon_jac(x, 7, traj[:21], 8, params, pairing)
+        Jn = approx_derivative(lambda z: SS.nonlcon(z, 7, traj[:21], 8, params, pairing), x, method='2-point',
+                               abs_step=SS.FD_STEP)
+        assert J.shape == Jn.shape == (7, 6) and np.array_equal(J, Jn), pairing
+    # the reference's pairing plans too (its constraint only ties the new vehicle to trajectory 0)
+    traj_r, res_r, _ = SS.plan(params, nveh=5, pairing='reference', with_jac=False)
+    assert traj_r.shape == (15, 4) and sum(r.success for r in res_r) >= 4
 
 
 @pytest.mark.parametrize("case", ["points2d", "elevated", "example1", "space3d"])
