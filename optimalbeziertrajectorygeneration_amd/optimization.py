@@ -283,6 +283,68 @@ class BezOptimization(object):
             bez._raise_md(st)
         return r['res'] - maxSep
 
+    def spatialSeparationJacobian(self, x, robust=False, column=None, on_cap='raise'):
+        """SciPy's 2-point Jacobian of `spatialSeparationConstraints` from ONE device call.  The reference hands the
+        constraint to SLSQP as it is (Examples/ComplexObstacles.py:49-63), so SciPy evaluates it n_x + 1 times, each an
+        all-pairs `_minDist` sweep.  A variable of vehicle v moves only the pairs that contain v: the call carries the
+        base evaluation's C(N+M, 2) pairs plus, per variable, the N+M-1 pairs of its perturbed vehicle (a trailing tf
+        that moves the speed columns of every vehicle takes all their pairs) as extra curves of the same
+        `obtg_min_dist` launch.  Entry for entry what n_x + 1 calls of the closure give: shape (3 P, n_x), rows in the
+        order of `spatialSeparationConstraints(x).ravel()`; column=0 keeps the distance rows only, shape (P, n_x) --
+        the 1-D constraint a driver would hand to SLSQP.  Statuses are treated as by the closure: a pair on which the
+        reference's search does not end (depth / node caps; the reference itself recurses until Python gives up) raises;
+        on_cap='nan' marks the entries of such pairs NaN instead (max_depth 128, 4 000 000 nodes per pair as in the
+        closure)."""
+        numVeh, dim, maxSep = self.model['numVeh'], self.model['dim'], self.model['maxSep']
+        X, dx = self._fd_rows(x)
+        Y = self.reshapeVectors(X)                                  # [n_x + 1][numVeh*dim][deg+1]
+        nx = X.shape[1]
+        obstacles = list(self.shapeObstacles) if self.shapeObstacles is not None else []
+        n = numVeh + len(obstacles)
+        base = [bez.Bezier(Y[0, i * dim:(i + 1) * dim, :])._padded() for i in range(numVeh)] + [c._padded() for c in obstacles]
+        curves = list(base)
+        pa, pb = [], []
+        for i in range(n):
+            for j in range(i + 1, n):
+                pa.append(i)
+                pb.append(j)
+        P = len(pa)
+        pair_index = {(pa[q], pb[q]): q for q in range(P)}
+        touched = []                                               # per variable: (row of the base list, position in the call)
+        Yv = Y.reshape(nx + 1, numVeh, dim, -1)
+        changed = np.any(Yv[1:] != Yv[0], axis=(2, 3))             # [n_x][numVeh]
+        for k in range(nx):
+            mine = {}
+            for v in np.nonzero(changed[k])[0]:
+                mine[int(v)] = len(curves)
+                curves.append(bez.Bezier(Y[k + 1, v * dim:(v + 1) * dim, :])._padded())
+            rows = []
+            for (i, j), q in pair_index.items():
+                if i in mine or j in mine:
+                    rows.append((q, len(pa)))
+                    pa.append(mine.get(i, i))
+                    pb.append(mine.get(j, j))
+            touched.append(rows)
+        stack = np.stack(curves)
+        if robust:
+            res = _capi.scratch_context().min_dist_robust(stack, pa, pb, eps=1e-9, max_nodes=400000)['res']
+        else:
+            r = _capi.scratch_context().min_dist(stack, pa, pb, eps=1e-9, max_depth=128, max_nodes=4000000)
+            res = r['res']
+            if on_cap == 'nan':
+                res = np.where((r['status'] != 0)[:, None], np.nan, res)
+            else:
+                for st in r['status']:
+                    bez._raise_md(st)
+        F0 = res[:P] - maxSep
+        J = np.zeros((P, 3, nx))
+        for k in range(nx):
+            for q, pos in touched[k]:
+                J[q, :, k] = ((res[pos] - maxSep) - F0[q]) / dx[k]
+        if column is not None:
+            return J[:, column, :]
+        return J.reshape(3 * P, nx)
+
     # ------------------------------------------------------------------ batched Jacobians (new)
     def _fd_rows(self, x):
         """x and its n_x forward-difference neighbours, SciPy-style: rows[k+1] = x + h e_k,

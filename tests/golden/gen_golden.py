@@ -688,8 +688,44 @@ def gen_sequential():
     save("sequential.npz", **d)
 
 
+def gen_spatial_fd():
+    """Finite-difference rows of spatialSeparationConstraints through the REFERENCE (round 3): for two of spatial.npz's
+    problems (one 2-D, one 3-D) the closure at x + h e_k for every variable k -- what SciPy's approx_derivative calls when
+    the constraint is handed to SLSQP as Examples/ComplexObstacles.py:49-63 does.  Rows the reference does not finish
+    within its time budget are marked (mask 0) and skipped by the test."""
+    import contextlib
+    import io
+    sp = np.load(os.path.join(HERE, "spatial.npz"))
+    h = 1.4901161193847656e-08
+    d = {}
+    names = []
+    for name in ("s2d_11", "s3d_9"):
+        nveh, dim, deg, max_sep = sp[name + "_par"]
+        dim, deg = int(dim), int(deg)
+        bo = opt.BezOptimization(numVeh=2, dimension=dim, degree=deg, minimizeGoal='Euclidean', maxSep=float(max_sep),
+                                 initPoints=sp[name + "_init"], finalPoints=sp[name + "_final"],
+                                 shapeObstacles=[bez.Bezier(sp[name + "_obs"].copy())])
+        x = sp[name + "_x"]
+        rows = np.full((x.size, 3, 3), np.nan)
+        mask = np.zeros(x.size, dtype=np.int32)
+        for k in range(x.size):
+            xk = x.copy()
+            xk[k] += h
+            with contextlib.redirect_stdout(io.StringIO()):
+                st, v = guarded(bo.spatialSeparationConstraints, 60.0, xk)
+            if st == 0:
+                rows[k] = np.asarray(v, dtype=float)
+                mask[k] = 1
+        d[name + "_rows"], d[name + "_mask"] = rows, mask
+        names.append(name)
+        print("  spatial_fd %s: %d of %d rows finished" % (name, int(mask.sum()), x.size))
+    d["names"] = np.array(names)
+    d["h"] = np.array(h)
+    save("spatial_fd.npz", **d)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["tables", "ops", "problem", "constraints", "gjk", "mindist", "c5", "spatial", "nearstop", "sequential"]
+    which = sys.argv[1:] or ["tables", "ops", "problem", "constraints", "gjk", "mindist", "c5", "spatial", "nearstop", "sequential", "spatial_fd"]
     for w in which:
         if w == "none":          # import-only (exploration)
             continue
