@@ -257,6 +257,20 @@ int obtg_constraint_sweep_dev(obtg_ctx*, const double* dY, const double* d_tf, i
                               double speed_bound, int speed_is_max, double max_rate, double* d_out_speed,
                               double* d_out_ang, int max_iter, int md_cap, int* d_flag, double* d_p1, double* d_p2,
                               double* d_dist, int* d_nsup, int* d_status);
+/* The whole finite-difference step as ONE launch that does not repeat row 0's work (SURVEY.md 8(f) item 1 for every
+ * family; what SciPy's approx_derivative needs from optimization.py:83-187 per SLSQP iteration).  The rows of the view
+ * (dY0, n_fixed_cols, h, B) differ from row 0 in ONE vehicle each: the launch evaluates row 0 in full and streams its
+ * results into all B rows, while one workgroup per row evaluates only the N-1 separation pairs, the hull pairs and the
+ * vehicle its advanced control point touches.  Outputs are those of obtg_constraint_sweep_dev inside the same view,
+ * bit for bit (the same device functions evaluate every pair); the launch is bound by its stores instead of by gjkNew.
+ * Planar shapes of the one-launch sweep (deg + 1 in {4, 6, 8, 11}, DEG_ELEV 0, no point obstacles, angular rate wanted):
+ * OBTG_ERR_UNSUPPORTED otherwise -- the brute-force call gives the same numbers.  A different evaluation strategy from
+ * "every row in full": bench.py reports it as variants.fd_structured, never as its headline value. */
+int obtg_constraint_sweep_fd_structured_dev(obtg_ctx*, const double* dY0, int n_fixed_cols, double h, const double* d_tf,
+                                            int B, double max_sep, double* d_out_sep, double speed_bound, int speed_is_max,
+                                            double max_rate, double* d_out_speed, double* d_out_ang, int max_iter, int md_cap,
+                                            int* d_flag, double* d_p1, double* d_p2, double* d_dist, int* d_nsup,
+                                            int* d_status);
 /* Finite-difference de-duplication (off by default).  The rows of one
  * SLSQP Jacobian differ from row 0 in ONE vehicle, so all pairs not involving it have row 0's
  * inputs bit for bit.  When on, obtg_gjk_swarm[_dev] compares every row with row 0 (bitwise, per

@@ -336,6 +336,66 @@ __device__ __forceinline__ void tsep_groups_from_xy(const TsepXYParams& t, const
     }
 }
 
+// Structured finite-difference step (gjk_kernels.hip k_step_fd_structured), row 0's part: ONE wave evaluates the 64-pair
+// group g of the staged row into `tile`, laid out as the output run itself ([pair][2n+1], no padding); returns the
+// number of pairs in the group.  Arithmetic as above.
+template <int NC>
+__device__ __forceinline__ int tsep_group_to_tile(const TsepXYParams& t, const double2* xy, const int vpq, const int g, double* tile)
+{
+    using S = NsShape<NC, 2>;
+    constexpr int L = S::L;
+    const int lane = threadIdx.x & (kWave - 1);
+    const int itg = g * kWave;
+    const int n_valid = min(kWave, t.n_pairs - itg);
+    const int item = min(itg + lane, t.n_pairs - 1);
+    const int2 ij = t.pairs[item];
+    const double2* vi = xy + ij.x * vpq;
+    const double2* vj = xy + ij.y * vpq;
+    double a[2][NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        const double2 pi = vi[c], pj = vj[c];
+        a[0][c] = pi.x - pj.x;
+        a[1][c] = pi.y - pj.y;
+    }
+    double cf[L];
+    normsq_coeffs<NC, 2>(a, as_ctab(t.W2), cf);
+    if (lane < n_valid) {
+#pragma unroll
+        for (int k = 0; k < L; ++k) tile[lane * L + k] = t.sign * cf[k] + t.offset;
+    }
+    return n_valid;
+}
+
+// ... and a perturbed row's part: the separation rows of every pair that contains vehicle v of row b, one pair per
+// lane, each lane writing its own 8 (2n+1)-byte run (n_veh - 1 pairs per row: a hundredth of the block).
+template <int NC>
+__device__ __forceinline__ void tsep_rows_of_vehicle(const TsepXYParams& t, const double2* xy, const int vpq, const int b,
+                                                     const int n_veh, const int v)
+{
+    using S = NsShape<NC, 2>;
+    constexpr int L = S::L;
+    for (int u0 = threadIdx.x; u0 < n_veh - 1; u0 += blockDim.x) {
+        const int u = u0 < v ? u0 : u0 + 1;
+        const int i = min(u, v), j = max(u, v);
+        const int q = i * (2 * n_veh - i - 1) / 2 + (j - i - 1);        // position of (i, j) in the lexicographic pair list
+        const double2* vi = xy + i * vpq;
+        const double2* vj = xy + j * vpq;
+        double a[2][NC];
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const double2 pi = vi[c], pj = vj[c];
+            a[0][c] = pi.x - pj.x;
+            a[1][c] = pi.y - pj.y;
+        }
+        double cf[L];
+        normsq_coeffs<NC, 2>(a, as_ctab(t.W2), cf);
+        double* o = t.out + ((size_t)b * t.n_pairs + q) * L;
+#pragma unroll
+        for (int k = 0; k < L; ++k) o[k] = t.sign * cf[k] + t.offset;
+    }
+}
+
 // The same for the TILED sweep (large rows): the workgroup has staged the vehicles of one TA x 64 tile of the pair
 // matrix -- rows ti0 .. ti0+ta-1 at LDS slots rowslot[.], columns tj0 .. tj0+63 at colslot[.] -- and writes the
 // separation rows of that tile's pairs: row i's pairs (i, j), j in the window, are one contiguous run of the output

@@ -210,7 +210,7 @@ const char* obtg_abi_symbols(void)
         "obtg_temporal_sep_fd\0obtg_temporal_sep_fd_dev\0obtg_one_vs_many_min\0obtg_one_vs_many_min_dev\0"
         "obtg_temporal_sep_dev\0obtg_temporal_sep_min_dev\0obtg_speed_dev\0obtg_ang_rate_dev\0obtg_dynamics_dev\0"
         "obtg_fd_batch_dev\0obtg_fd_view_begin\0obtg_fd_view_end\0obtg_fd_forms_on_the_fly\0obtg_pair_sweep_fd_dev\0obtg_dynamics_fd_dev\0obtg_gjk_pairs\0obtg_ctx_set_polygons\0obtg_ctx_set_hull_pairs\0"
-        "obtg_ctx_set_fd_dedup\0obtg_ctx_set_gjk_history\0obtg_pair_sweep_dev\0obtg_constraint_sweep_dev\0obtg_gjk_swarm_dev\0obtg_gjk_swarm\0obtg_min_dist\0obtg_min_dist_robust\0obtg_min_dist2poly\0obtg_min_dist2poly_robust\0obtg_gjk_true_pairs\0"
+        "obtg_ctx_set_fd_dedup\0obtg_ctx_set_gjk_history\0obtg_pair_sweep_dev\0obtg_constraint_sweep_dev\0obtg_constraint_sweep_fd_structured_dev\0obtg_gjk_swarm_dev\0obtg_gjk_swarm\0obtg_min_dist\0obtg_min_dist_robust\0obtg_min_dist2poly\0obtg_min_dist2poly_robust\0obtg_gjk_true_pairs\0"
         "obtg_bern_elev\0obtg_bern_diff\0obtg_bern_mul\0obtg_bern_normsq\0obtg_bern_split\0"
         "obtg_euclidean_obj\0obtg_accel_obj\0obtg_jerk_obj\0"
         "obtg_set_profiling\0obtg_set_profile_period\0obtg_kernel_stats\0obtg_reset_kernel_stats\0obtg_kernel_name\0";
@@ -958,6 +958,22 @@ int obtg_ctx_set_hull_pairs(obtg_ctx* c, const int* pair_a, const int* pair_b, i
     c->hull_pairs_set = true;
     c->h_hp_a.assign(pair_a, pair_a + n_pairs);
     c->h_hp_b.assign(pair_b, pair_b + n_pairs);
+    {   // which pairs contain vehicle v (list order): what a finite-difference row that moves v has to re-evaluate
+        std::vector<int> off(c->n_veh + 1, 0), idx;
+        for (int k = 0; k < n_pairs; ++k) {
+            if (pair_a[k] < c->n_veh) ++off[pair_a[k] + 1];
+            if (pair_b[k] < c->n_veh && pair_b[k] != pair_a[k]) ++off[pair_b[k] + 1];
+        }
+        for (int v = 0; v < c->n_veh; ++v) off[v + 1] += off[v];
+        idx.resize((size_t)off[c->n_veh] + 1);
+        std::vector<int> fill(off.begin(), off.end() - 1);
+        for (int k = 0; k < n_pairs; ++k) {
+            if (pair_a[k] < c->n_veh) idx[fill[pair_a[k]]++] = k;
+            if (pair_b[k] < c->n_veh && pair_b[k] != pair_a[k]) idx[fill[pair_b[k]]++] = k;
+        }
+        if ((rc = upload(c, c->d_vp_off, off.data(), sizeof(int) * off.size()))) return rc;
+        if ((rc = upload(c, c->d_vp_idx, idx.data(), sizeof(int) * idx.size()))) return rc;
+    }
     c->tile_valid = false;
     c->gjk_len_rows = 0;
     if (c->d_poly_off.p == nullptr) {
@@ -1006,6 +1022,27 @@ int obtg_constraint_sweep_dev(obtg_ctx* c, const double* dY, const double* d_tf,
         if (sp.did_dynamics || (sp.did_speed && !d_out_ang)) return (int)OBTG_OK;
         return launch_dynamics(c, src, d_tf, B, speed_bound, speed_is_max, max_rate, d_out_speed, d_out_ang);
     });
+}
+
+int obtg_constraint_sweep_fd_structured_dev(obtg_ctx* c, const double* dY0, int n_fixed_cols, double h, const double* d_tf, int B,
+                                            double max_sep, double* d_out_sep, double speed_bound, int speed_is_max, double max_rate,
+                                            double* d_out_speed, double* d_out_ang, int max_iter, int md_cap, int* d_flag,
+                                            double* d_p1, double* d_p2, double* d_dist, int* d_nsup, int* d_status)
+{
+    if (!check_ctx(c) || !dY0 || !d_tf || !d_out_sep || !d_out_speed || !d_out_ang || !d_flag || !d_p1 || !d_p2 || !d_dist ||
+        B < 1 || max_iter < 1 || md_cap < 1) return OBTG_ERR_ARG;
+    if (!c->hull_pairs_set || c->dim != 2) return OBTG_ERR_ARG;
+    int rc = obtg_fd_view_begin(c, dY0, n_fixed_cols, h, B);
+    if (rc) return rc;
+    (void)hipSetDevice(c->device);
+    SweepFold sp;
+    sp.d_tf = d_tf; sp.speed_bound = speed_bound; sp.speed_is_max = speed_is_max;
+    sp.d_out_speed = d_out_speed; sp.d_out_ang = d_out_ang; sp.max_rate = max_rate;
+    c->fd.Y0 = c->view.Y0; c->fd.h = c->view.h; c->fd.fixed = c->view.fixed;
+    rc = launch_step_fd_structured(c, B, max_sep, d_out_sep, max_iter, md_cap, d_flag, d_p1, d_p2, d_dist, d_nsup, d_status, &sp);
+    c->fd.Y0 = nullptr;
+    (void)obtg_fd_view_end(c);
+    return rc;
 }
 
 int obtg_ctx_set_gjk_history(obtg_ctx* c, int on)

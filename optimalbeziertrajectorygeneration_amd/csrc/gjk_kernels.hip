@@ -270,6 +270,10 @@ struct GjkSwarmParams {
     double* __restrict__ dist;
     int* nsup;
     int* status;
+    int chg_from_fd = 0;               // MODE 1: the changed vehicle of row b is the one the view's row b advances (no mask array):
+    const int* vp_off = nullptr;       //         its pairs come from the per-vehicle lists (obtg_ctx::d_vp_off / d_vp_idx)
+    const int* vp_idx = nullptr;
+    int emit_scalar = 0;               // results may go to LDS through generic pointers: 8-byte stores only
     int refill_min = 1;                // planar sweeps: idle lanes of a wave wait until this many can refill together
     int passes = 1;                    // MODE 0: chunks a workgroup takes one after the other (w-th workgroup of a row: chunks w*passes ..)
 };
@@ -546,11 +550,14 @@ __device__ __forceinline__ void gjk_planar_body(const GjkSwarmParams& p, double2
     }
     __syncthreads();
     const bool shortcut = p.max_iter >= 3 && p.md_cap >= 2;
-    const unsigned char* chg = FIXUP ? p.chg + (size_t)b * p.n_veh : nullptr;
+    const unsigned char* chg = (FIXUP && !p.chg_from_fd) ? p.chg + (size_t)b * p.n_veh : nullptr;
+    const int fd_veh = fd_e >= 0 ? fd_e / (2 * NC) : -1;          // the vehicle row b's advanced control point belongs to
 
     // MODE 0: a workgroup takes p.passes chunks of its row one after the other on the one staging of the row (fewer,
     // longer workgroups: the launch is a whole number of rounds of the chip, see sweep_shape())
-    for (int seg0 = 0; seg0 < (FIXUP ? p.n_pairs : (SWEEP ? p.passes * p.chunk : 1)); seg0 += p.chunk) {
+    const int fix_base = (FIXUP && p.chg_from_fd && fd_veh >= 0) ? p.vp_off[fd_veh] : 0;
+    const int fix_count = FIXUP ? (p.chg_from_fd ? (fd_veh >= 0 ? p.vp_off[fd_veh + 1] - fix_base : 0) : p.n_pairs) : 0;
+    for (int seg0 = 0; seg0 < (FIXUP ? fix_count : (SWEEP ? p.passes * p.chunk : 1)); seg0 += p.chunk) {
     if (SWEEP) {
         cbase = w * p.passes * p.chunk + seg0;
         c1 = max(0, min(p.n_pairs - cbase, p.chunk));
@@ -559,10 +566,16 @@ __device__ __forceinline__ void gjk_planar_body(const GjkSwarmParams& p, double2
     if (FIXUP) {
         if (threadIdx.x == 0) s_nlist = 0;
         __syncthreads();
-        const int seg1 = min(p.n_pairs, seg0 + p.chunk);
-        for (int q = seg0 + (int)threadIdx.x; q < seg1; q += blockDim.x) {
-            const int a = p.pa[q], bb = p.pb[q];
-            if ((a < p.n_veh && chg[a]) || (bb < p.n_veh && chg[bb])) list[atomicAdd(&s_nlist, 1)] = q;
+        const int seg1 = min(fix_count, seg0 + p.chunk);
+        if (p.chg_from_fd) {
+            // the pairs of the row's vehicle, straight from its list
+            for (int q = seg0 + (int)threadIdx.x; q < seg1; q += blockDim.x) list[q - seg0] = p.vp_idx[fix_base + q];
+            if (threadIdx.x == 0) s_nlist = seg1 - seg0;
+        } else {
+            for (int q = seg0 + (int)threadIdx.x; q < seg1; q += blockDim.x) {
+                const int a = p.pa[q], bb = p.pb[q];
+                if ((a < p.n_veh && chg[a]) || (bb < p.n_veh && chg[bb])) list[atomicAdd(&s_nlist, 1)] = q;
+            }
         }
         __syncthreads();
         c0 = 0; c1 = s_nlist;
@@ -735,10 +748,15 @@ __device__ __forceinline__ void gjk_planar_body(const GjkSwarmParams& p, double2
         p.flag[o] = flag;
         // 24-byte records: one 16-byte (8-byte aligned) and one 8-byte store each
         typedef double d2u_t __attribute__((ext_vector_type(2), aligned(8)));
-        d2u_t xy1, xy2;
-        xy1.x = r.c1.x; xy1.y = r.c1.y; xy2.x = r.c2.x; xy2.y = r.c2.y;
-        *reinterpret_cast<d2u_t*>(p.p1 + 3 * o) = xy1; p.p1[3 * o + 2] = r.c1.z;
-        *reinterpret_cast<d2u_t*>(p.p2 + 3 * o) = xy2; p.p2[3 * o + 2] = r.c2.z;
+        if (p.emit_scalar) {
+            p.p1[3 * o] = r.c1.x; p.p1[3 * o + 1] = r.c1.y; p.p1[3 * o + 2] = r.c1.z;
+            p.p2[3 * o] = r.c2.x; p.p2[3 * o + 1] = r.c2.y; p.p2[3 * o + 2] = r.c2.z;
+        } else {
+            d2u_t xy1, xy2;
+            xy1.x = r.c1.x; xy1.y = r.c1.y; xy2.x = r.c2.x; xy2.y = r.c2.y;
+            *reinterpret_cast<d2u_t*>(p.p1 + 3 * o) = xy1; p.p1[3 * o + 2] = r.c1.z;
+            *reinterpret_cast<d2u_t*>(p.p2 + 3 * o) = xy2; p.p2[3 * o + 2] = r.c2.z;
+        }
         p.dist[o] = r.dist;
         if (p.nsup) p.nsup[o] = n_scans;
         if (p.status) p.status[o] = status;
@@ -915,6 +933,157 @@ void k_pair_sweep(const GjkSwarmParams p)
         return;
     }
     gjk_planar_body<NC, 0, true>(p, xy_dyn, -1, -1);
+}
+
+// -------------------------------------------------------------------------------------
+//  Structured finite-difference step in ONE launch (SURVEY.md 8(f) item 1 for the whole step; obtg_constraint_sweep_fd_structured_dev).
+//  The rows of an SLSQP finite-difference batch are ONE row of control points with one element advanced: row b >= 1
+//  differs from row 0 in one vehicle, so all but N-1 of its separation pairs, N-1+M of its hull pairs and one of its
+//  vehicles repeat row 0's results bit for bit.  Inside an FD view the rows are DEFINED that way (row b = the view's row
+//  with its (b-1)-th free control point advanced), so which entries repeat is known without comparing anything, and the
+//  step becomes four kinds of workgroups in one grid with no dependency between them:
+//    S  (group g, row range): evaluates the 64-pair group g of ROW 0's separation block once and streams it into every
+//       row of its range, leaving out the entries of pairs that contain the row's own vehicle;
+//    G  (chunk c, row range): runs gjkNew on chunk c of ROW 0's hull pairs (results in LDS) and streams flag / closest
+//       points / distance / status (/ scan count) into every row of its range, with the same exception;
+//    F  (row b >= 1): stages row b, evaluates exactly the pairs the streams left out -- the hull pairs of its vehicle
+//       (the de-duplication pass of the plain sweep, its mask computed from b) and that vehicle's separation rows;
+//    D  the speed / angular-rate groups of the whole batch, as in k_pair_sweep (36 MB of a 611 MB step: not worth a stream).
+//  Every output element is written exactly once, by the workgroup kind that owns it: the result equals the brute-force
+//  sweep's bit for bit (same device functions per pair), the launch is bound by its 611 MB of stores.
+// -------------------------------------------------------------------------------------
+struct StructuredParams {
+    GjkSwarmParams g;                  // the sweep's parameters inside the view (g.fd set, g.Y = the view's row)
+    int n_sep_groups, sep_rows_per;    // S: groups of the separation block, rows per range
+    int gjk_chunks, gjk_chunk_pairs, gjk_rows_per;   // G
+    int fix_chunk;                     // F: candidates per segment of the fix-up pass
+    int n_kind[4];                     // workgroups of each kind (S, F, G, D).  The grid interleaves them: of every 16 block ids,
+    int per16[4];                      // per16[k] belong to kind k, in the order pat[] (host: shares by expected work), so that
+    unsigned char pat[16], rank[16];   // streams (HBM bound) and state machines (latency bound) share the CUs all along
+};
+
+template <int NC>
+__global__ __launch_bounds__(256, 4) void k_step_fd_structured(const StructuredParams sp)
+{
+    extern __shared__ double2 xy_dyn[];
+    constexpr int VPQ = PlanarShape<NC>::VPQ;
+    constexpr int L = 2 * NC - 1;
+    const GjkSwarmParams& p = sp.g;
+    TimelineScope tl(p.timeline);
+    const int n_obj = p.n_veh + p.n_poly;
+    double* lds = reinterpret_cast<double*>(xy_dyn);
+    // kind (0 S, 1 F, 2 G, 3 D) and index inside the kind from the block id
+    const int grp = (int)blockIdx.x >> 4, slot = (int)blockIdx.x & 15;
+    const int kind = sp.pat[slot];
+    const int id = grp * sp.per16[kind] + sp.rank[slot];
+    if (id >= sp.n_kind[kind]) return;
+    if (kind == 3) {
+        if (threadIdx.x >= 2 * kWave) return;
+        dynamics2_group<NC, true>(p.dyn, lds, id);
+        return;
+    }
+    if (kind == 1) {
+        // ---- F: row b's own pairs
+        const int b = id + 1;
+        GjkSwarmParams q = p;
+        q.chunk = sp.fix_chunk; q.chg_from_fd = 1; q.passes = 1; q.len_in = nullptr; q.len_out = nullptr;
+        gjk_planar_body<NC, 1, false>(q, xy_dyn, b, 0);
+        __syncthreads();
+        const int fd_e = fd_element(p.fd, p.fd_fixed, NC, b);
+        if (fd_e >= 0) tsep_rows_of_vehicle<NC>(p.ts, xy_dyn, VPQ, b, p.n_veh, fd_e / (2 * NC));
+        return;
+    }
+    if (kind == 2) {
+        // ---- G: chunk c of row 0's hull pairs, streamed into the rows of range r
+        const int t = id, c = t % sp.gjk_chunks, r = t / sp.gjk_chunks;
+        const int cp = sp.gjk_chunk_pairs;
+        const int k0 = c * cp, n_valid = max(0, min(cp, p.n_pairs - k0));
+        // results in LDS behind the body's own arrays
+        char* base = reinterpret_cast<char*>(xy_dyn) + ((planar_lds_bytes<0>(n_obj, VPQ, cp) + 15) / 16) * 16;
+        double* r_p1 = reinterpret_cast<double*>(base);
+        double* r_p2 = r_p1 + 3 * cp;
+        double* r_dist = r_p2 + 3 * cp;
+        int* r_flag = reinterpret_cast<int*>(r_dist + cp);
+        int* r_stat = r_flag + cp;
+        int* r_nsup = r_stat + cp;
+        GjkSwarmParams q = p;
+        q.fd = 0; q.B = 1; q.chunk = cp; q.passes = 1; q.wgs_per_row = sp.gjk_chunks; q.len_in = nullptr; q.len_out = nullptr;
+        q.emit_scalar = 1;
+        q.flag = r_flag - k0; q.p1 = r_p1 - 3 * (size_t)k0; q.p2 = r_p2 - 3 * (size_t)k0; q.dist = r_dist - k0;
+        q.status = r_stat - k0; q.nsup = r_nsup - k0;
+        gjk_planar_body<NC, 0, false>(q, xy_dyn, 0, c);
+        __syncthreads();
+        const int b0 = r * sp.gjk_rows_per, b1 = min(p.B, b0 + sp.gjk_rows_per);
+        // every thread streams one pair into every n_sub-th row of the range
+        const int n_sub = max(1, (int)blockDim.x / max(n_valid, 1));
+        for (int t = (int)threadIdx.x; t < n_valid * n_sub; t += (int)blockDim.x) {
+            const int l = t % n_valid, sub = t / n_valid;
+            const int kq = k0 + l;
+            const int a = p.pa[kq], bb = p.pb[kq];
+            const int fl = r_flag[l], st = r_stat[l], ns = r_nsup[l];
+            const double di = r_dist[l];
+            const double p1x = r_p1[3 * l], p1y = r_p1[3 * l + 1], p1z = r_p1[3 * l + 2];
+            const double p2x = r_p2[3 * l], p2y = r_p2[3 * l + 1], p2z = r_p2[3 * l + 2];
+            for (int b = b0 + sub; b < b1; b += n_sub) {
+                const int fd_e = fd_element(p.fd, p.fd_fixed, NC, b);
+                const int vb = fd_e >= 0 ? fd_e / (2 * NC) : -1;
+                if (a == vb || bb == vb) continue;                   // row b's own workgroup evaluates this pair
+                const size_t o = (size_t)b * p.n_pairs + kq;
+                p.flag[o] = fl;
+                p.p1[3 * o] = p1x; p.p1[3 * o + 1] = p1y; p.p1[3 * o + 2] = p1z;
+                p.p2[3 * o] = p2x; p.p2[3 * o + 1] = p2y; p.p2[3 * o + 2] = p2z;
+                p.dist[o] = di;
+                if (p.nsup) p.nsup[o] = ns;
+                if (p.status) p.status[o] = st;
+            }
+        }
+        return;
+    }
+    // ---- S: group g of row 0's separation block, streamed into the rows of range r
+    {
+        const int g = id % sp.n_sep_groups, r = id / sp.n_sep_groups;
+        for (int e = threadIdx.x; e < p.n_veh * 2 * NC; e += blockDim.x) {
+            const int v = e / (2 * NC), rr = e - v * (2 * NC), qd = rr / NC, k = rr - qd * NC;
+            lds[2 * (v * VPQ + k) + qd] = p.Y[e];
+        }
+        __syncthreads();
+        double* tile = reinterpret_cast<double*>(xy_dyn + n_obj * VPQ);     // [64][L]: the output run of the group
+        __shared__ int s_nv;
+        if (threadIdx.x < kWave) {
+            const int nv = tsep_group_to_tile<NC>(p.ts, xy_dyn, VPQ, g, tile);
+            if (threadIdx.x == 0) s_nv = nv;
+        }
+        __syncthreads();
+        const int n_el = s_nv * L;                                   // doubles in the run
+        constexpr int kSlots = (kWave * L / 2 + 255) / 256;          // 16-byte pieces per thread
+        double v0[kSlots], v1[kSlots];
+        int pr0[kSlots], pr1[kSlots];                                // (i | j << 16) of the pair each element belongs to, -1: none
+#pragma unroll
+        for (int s = 0; s < kSlots; ++s) {
+            const int m = (int)threadIdx.x + 256 * s, e0 = 2 * m, e1 = e0 + 1;
+            v0[s] = v1[s] = 0.0; pr0[s] = pr1[s] = -1;
+            if (e0 < n_el) { const int2 ij = p.ts.pairs[g * kWave + e0 / L]; pr0[s] = ij.x | (ij.y << 16); v0[s] = tile[e0]; }
+            if (e1 < n_el) { const int2 ij = p.ts.pairs[g * kWave + e1 / L]; pr1[s] = ij.x | (ij.y << 16); v1[s] = tile[e1]; }
+        }
+        const int b0 = r * sp.sep_rows_per, b1 = min(p.B, b0 + sp.sep_rows_per);
+        for (int b = b0; b < b1; ++b) {
+            const int fd_e = fd_element(p.fd, p.fd_fixed, NC, b);
+            const int vb = fd_e >= 0 ? fd_e / (2 * NC) : -1;
+            const size_t ob = ((size_t)b * p.ts.n_pairs + (size_t)g * kWave) * L;
+            double* o = p.ts.out + ob;
+            const bool aligned = (ob & 1) == 0;                     // rows of an odd length start on odd elements
+#pragma unroll
+            for (int s = 0; s < kSlots; ++s) {
+                const int m = (int)threadIdx.x + 256 * s;
+                const bool w0 = pr0[s] >= 0 && (pr0[s] & 0xffff) != vb && (pr0[s] >> 16) != vb;
+                const bool w1 = pr1[s] >= 0 && (pr1[s] & 0xffff) != vb && (pr1[s] >> 16) != vb;
+                if (w0 && w1 && aligned) store_nt2(o + 2 * m, v0[s], v1[s]);
+                else if (w0 && w1) { store_nt(o + 2 * m, v0[s]); store_nt(o + 2 * m + 1, v1[s]); }
+                else if (w0) store_nt(o + 2 * m, v0[s]);
+                else if (w1) store_nt(o + 2 * m + 1, v1[s]);
+            }
+        }
+    }
 }
 
 // The pair sweep of LARGE rows (hulls of a row beyond 48 KB of LDS, C4) as one launch: the tiled sweep whose chunks
@@ -2256,6 +2425,45 @@ static int build_tiles(obtg_ctx* c, int /*vp*/)
 //    (wgs, passes) minimise rounds x duration with duration = F + passes x (S + chunk x t) (fitted to the timeline: fixed
 //    part 18 us, per pass 6 us, 25 ns per pair).  C3, 1153 rows: one workgroup per row, two passes -- ONE round.
 // Small batches end up with many small workgroups (one round, shortest duration), as before.
+// OBTG_TIMELINE=<file>: the 20th (OBTG_TIMELINE_AT) instrumented launch of the process leaves its workgroup timeline
+// there (text: block, start and end in 10 ns ticks from the first start, HW_ID, XCC_ID; tools/timeline_report.py)
+struct TimelineDump {
+    obtg_ctx* c;
+    unsigned grid;
+    unsigned long long* dev = nullptr;
+    int rc = OBTG_OK;
+    TimelineDump(obtg_ctx* c_, unsigned grid_, unsigned long long*& slot) : c(c_), grid(grid_)
+    {
+        static const char* path = getenv("OBTG_TIMELINE");
+        static const int at = getenv("OBTG_TIMELINE_AT") ? atoi(getenv("OBTG_TIMELINE_AT")) : 20;
+        static int count = 0;
+        if (!(path && path[0] && ++count == at)) return;
+        if ((rc = c->ws_misc[6].reserve((size_t)grid * 4 * sizeof(unsigned long long)))) return;
+        if (hipMemsetAsync(c->ws_misc[6].p, 0, (size_t)grid * 4 * sizeof(unsigned long long), c->stream) != hipSuccess) {
+            rc = OBTG_ERR_DEVICE; return;
+        }
+        dev = c->ws_misc[6].as<unsigned long long>();
+        slot = dev;
+    }
+    int finish(const char* header)
+    {
+        if (!dev) return OBTG_OK;
+        std::vector<unsigned long long> h((size_t)grid * 4);
+        OBTG_HIP(c, hipMemcpyAsync(h.data(), dev, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
+        OBTG_HIP(c, hipStreamSynchronize(c->stream));
+        if (FILE* f = fopen(getenv("OBTG_TIMELINE"), "w")) {
+            unsigned long long t0 = ~0ull;
+            for (unsigned i = 0; i < grid; ++i) if (h[4 * i] && h[4 * i] < t0) t0 = h[4 * i];
+            fprintf(f, "%s\n", header);
+            for (unsigned i = 0; i < grid; ++i)
+                fprintf(f, "%u %llu %llu %llu %llu\n", i, h[4 * i] ? h[4 * i] - t0 : 0ull, h[4 * i + 1] ? h[4 * i + 1] - t0 : 0ull,
+                        h[4 * i + 2] & 0xffffffffull, h[4 * i + 2] >> 32);
+            fclose(f);
+        }
+        return OBTG_OK;
+    }
+};
+
 static int sweep_refill_min()
 {
     static const int v = getenv("OBTG_REFILL_MIN") ? std::max(1, std::min(64, atoi(getenv("OBTG_REFILL_MIN")))) : 32;
@@ -2716,40 +2924,140 @@ int launch_pair_sweep(obtg_ctx* c, const double* dY, int B, double max_sep, doub
             speed->did_dynamics = true;
         }
     }
-    // OBTG_TIMELINE=<file>: the 20th (OBTG_TIMELINE_AT) one-launch sweep of the process leaves its workgroup timeline
-    // there (text: block, start and end in 10 ns ticks from the first start, HW_ID, XCC_ID; tools/timeline_report.py)
-    static const char* tl_path = getenv("OBTG_TIMELINE");
-    static const int tl_at = getenv("OBTG_TIMELINE_AT") ? atoi(getenv("OBTG_TIMELINE_AT")) : 20;
-    static int tl_count = 0;
-    const bool tl_now = tl_path && tl_path[0] && ++tl_count == tl_at;
-    if (tl_now) {
-        if (int rc = c->ws_misc[6].reserve((size_t)grid * 4 * sizeof(unsigned long long))) return rc;
-        OBTG_HIP(c, hipMemsetAsync(c->ws_misc[6].p, 0, (size_t)grid * 4 * sizeof(unsigned long long), c->stream));
-        p.timeline = c->ws_misc[6].as<unsigned long long>();
-    }
+    TimelineDump tl(c, grid, p.timeline);
+    if (tl.rc) return tl.rc;
     {
         ScopedKernelTimer tm(c, OBTG_K_PAIR_SWEEP);
         hipLaunchKernelGGL(kern, dim3(grid), dim3(OBTG_SWEEP_THREADS), lds, c->stream, p);
     }
-    if (tl_now) {
-        std::vector<unsigned long long> h((size_t)grid * 4);
-        OBTG_HIP(c, hipMemcpyAsync(h.data(), p.timeline, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
-        OBTG_HIP(c, hipStreamSynchronize(c->stream));
-        if (FILE* f = fopen(tl_path, "w")) {
-            unsigned long long t0 = ~0ull;
-            for (unsigned i = 0; i < grid; ++i) if (h[4 * i] && h[4 * i] < t0) t0 = h[4 * i];
-            fprintf(f, "# grid %u sweep_blocks %d wgs_per_row %d passes %d chunk %d B %d\n", grid,
-                    p.dyn.out ? p.dyn_first_block : (int)grid, p.wgs_per_row, p.passes, p.chunk, B);
-            for (unsigned i = 0; i < grid; ++i)
-                fprintf(f, "%u %llu %llu %llu %llu\n", i, h[4 * i] ? h[4 * i] - t0 : 0ull, h[4 * i + 1] ? h[4 * i + 1] - t0 : 0ull,
-                        h[4 * i + 2] & 0xffffffffull, h[4 * i + 2] >> 32);
-            fclose(f);
-        }
+    {
+        char hdr[256];
+        snprintf(hdr, sizeof hdr, "# grid %u sweep_blocks %d wgs_per_row %d passes %d chunk %d B %d", grid,
+                 p.dyn.out ? p.dyn_first_block : (int)grid, p.wgs_per_row, p.passes, p.chunk, B);
+        if (int rc = tl.finish(hdr)) return rc;
     }
     c->gjk_len_cur ^= 1;
     c->gjk_len_rows = B;
     OBTG_HIP(c, hipGetLastError());
     return OBTG_OK;
+}
+
+// obtg_constraint_sweep_fd_structured_dev: the whole step of an FD view as ONE launch that evaluates row 0 in full and,
+// per perturbed row, only what its vehicle touches (k_step_fd_structured).  OBTG_ERR_UNSUPPORTED for shapes outside the
+// one-launch planar sweep (the caller uses the brute-force sweep, whose results are the same).
+int launch_step_fd_structured(obtg_ctx* c, int B, double max_sep, double* d_out_sep, int max_iter, int md_cap, int* d_flag,
+                              double* d_p1, double* d_p2, double* d_dist, int* d_nsup, int* d_status, SweepFold* speed)
+{
+    if (B <= 0) return OBTG_OK;
+    if (!c->fd.Y0) return OBTG_ERR_ARG;
+    const int nc = c->deg + 1;
+    void (*kern)(const StructuredParams) = nullptr;
+    switch (nc) {
+        case 4: kern = k_step_fd_structured<4>; break;
+        case 6: kern = k_step_fd_structured<6>; break;
+        case 8: kern = k_step_fd_structured<8>; break;
+        case 11: kern = k_step_fd_structured<11>; break;
+        default: break;
+    }
+    const bool ok = kern && c->dim == 2 && c->polys_planar && c->max_poly_K <= nc && c->n_hull_pairs > 0 && !c->fd_dedup &&
+                    c->R == 0 && c->n_obs == 0 && c->n_pairs > 0 && speed && speed->d_out_ang && speed->d_out_speed &&
+                    speed->d_tf && d_out_sep && c->n_veh < 65536;
+    if (!ok) return OBTG_ERR_UNSUPPORTED;
+    int rc = ensure_tables(c);
+    if (rc) return rc;
+    if (c->d_ang_w22n.p == nullptr) return OBTG_ERR_UNSUPPORTED;
+    StructuredParams sp{};
+    GjkSwarmParams& p = sp.g;
+    p.Y = c->fd.Y0; p.fd = 1; p.fd_fixed = c->fd.fixed; p.fd_h = c->fd.h;
+    p.poly = c->d_poly_pts.as<double>(); p.poly_off = c->d_poly_off.as<int>();
+    p.pa = c->d_hp_a.as<int>(); p.pb = c->d_hp_b.as<int>();
+    p.n_veh = c->n_veh; p.dim = c->dim; p.nc = nc; p.n_poly = c->n_poly;
+    p.n_poly_pts = c->n_poly_pts; p.n_pairs = c->n_hull_pairs;
+    p.max_iter = max_iter; p.md_cap = md_cap; p.refill_min = sweep_refill_min();
+    p.flag = d_flag; p.p1 = d_p1; p.p2 = d_p2; p.dist = d_dist; p.nsup = d_nsup; p.status = d_status;
+    p.B = B; p.chunk = 256; p.wgs_per_row = 1; p.passes = 1;
+    p.ts.pairs = c->d_pairs.as<int2>(); p.ts.W2 = c->d_w2.as<double>(); p.ts.out = d_out_sep;
+    p.ts.n_pairs = c->n_pairs; p.ts.sign = 1.0; p.ts.offset = -(max_sep * max_sep);
+    {
+        AngParams& d = p.dyn;
+        d.Y = p.Y; d.tf = speed->d_tf; d.out = speed->d_out_ang; d.out_speed = speed->d_out_speed;
+        d.n_veh = c->n_veh; d.total = B * c->n_veh;
+        d.w2 = speed->max_rate * speed->max_rate;
+        const double b2 = speed->speed_bound * speed->speed_bound;
+        d.sp_sign = speed->speed_is_max ? -1.0 : 1.0; d.sp_offset = speed->speed_is_max ? b2 : -b2;
+        if (c->speed2.d_out) {
+            const double c2 = c->speed2.bound * c->speed2.bound;
+            d.out_speed2 = c->speed2.d_out;
+            d.sp2_sign = c->speed2.is_max ? -1.0 : 1.0; d.sp2_offset = c->speed2.is_max ? c2 : -c2;
+        }
+        d.W2n = c->d_ang_w2n.as<double>(); d.W22n = c->d_ang_w22n.as<double>(); d.Wn = c->d_ang_wn.as<double>();
+        d.fd = 1; d.fd_fixed = p.fd_fixed; d.fd_h = p.fd_h;
+    }
+    const int n_obj = c->n_veh + c->n_poly, vpq = nc | 1, L = 2 * c->deg + 1;
+    // S: one workgroup per (64-pair group, row range); about two thousand workgroups of streams
+    sp.n_sep_groups = (c->n_pairs + kWave - 1) / kWave;
+    int s_ranges = std::max(1, std::min(B, 2048 / std::max(1, sp.n_sep_groups)));
+    sp.sep_rows_per = (B + s_ranges - 1) / s_ranges;
+    s_ranges = (B + sp.sep_rows_per - 1) / sp.sep_rows_per;
+    // G: chunks of ~80 hull pairs (one short gjkNew phase per workgroup), row ranges for ~512 workgroups
+    sp.gjk_chunk_pairs = 80;
+    sp.gjk_chunks = (c->n_hull_pairs + sp.gjk_chunk_pairs - 1) / sp.gjk_chunk_pairs;
+    int g_ranges = std::max(1, std::min(B, 1024 / std::max(1, sp.gjk_chunks)));
+    sp.gjk_rows_per = (B + g_ranges - 1) / g_ranges;
+    g_ranges = (B + sp.gjk_rows_per - 1) / sp.gjk_rows_per;
+    sp.fix_chunk = 256;
+    p.vp_off = c->d_vp_off.as<int>(); p.vp_idx = c->d_vp_idx.as<int>();
+    sp.n_kind[0] = sp.n_sep_groups * s_ranges;
+    sp.n_kind[1] = B - 1;
+    sp.n_kind[2] = sp.gjk_chunks * g_ranges;
+    sp.n_kind[3] = (p.dyn.total + kWave - 1) / kWave;
+    unsigned grid = 0;
+    {
+        // shares of every 16 block ids by expected work (workgroups x duration on the C3 timeline: S 12.5, F 15.2, G 20.2, D 10.7 us)
+        const double cost[4] = { 12.5, 15.2, 20.2, 10.7 };
+        double w[4], tot = 0.0;
+        for (int k = 0; k < 4; ++k) { w[k] = sp.n_kind[k] * cost[k]; tot += w[k]; }
+        int sum = 0;
+        for (int k = 0; k < 4; ++k) { sp.per16[k] = sp.n_kind[k] > 0 ? std::max(1, (int)(16.0 * w[k] / tot + 0.5)) : 0; sum += sp.per16[k]; }
+        while (sum != 16) {             // give to / take from the kind with the largest share
+            int kmax = 0;
+            for (int k = 1; k < 4; ++k) if (sp.per16[k] > sp.per16[kmax]) kmax = k;
+            sp.per16[kmax] += sum < 16 ? 1 : -1;
+            sum += sum < 16 ? 1 : -1;
+        }
+        // spread each kind's slots evenly over the 16
+        struct Slot { double pos; int kind; };
+        std::vector<Slot> slots;
+        for (int k = 0; k < 4; ++k)
+            for (int j = 0; j < sp.per16[k]; ++j) slots.push_back({ (j + 0.5) / sp.per16[k] + 1e-3 * k, k });
+        std::sort(slots.begin(), slots.end(), [](const Slot& a, const Slot& b) { return a.pos < b.pos; });
+        int seen[4] = { 0, 0, 0, 0 };
+        int groups = 0;
+        for (int i = 0; i < 16; ++i) { sp.pat[i] = (unsigned char)slots[i].kind; sp.rank[i] = (unsigned char)seen[slots[i].kind]++; }
+        for (int k = 0; k < 4; ++k)
+            if (sp.per16[k] > 0) groups = std::max(groups, (sp.n_kind[k] + sp.per16[k] - 1) / sp.per16[k]);
+        grid = (unsigned)groups * 16u;
+    }
+    p.dyn_first_block = 0;
+    const size_t lds_s = (size_t)16 * n_obj * vpq + sizeof(double) * kWave * L;
+    const size_t lds_g = (planar_lds_bytes<0>(n_obj, vpq, sp.gjk_chunk_pairs) + 15) / 16 * 16 + (size_t)sp.gjk_chunk_pairs * 68 + 16;
+    const size_t lds_f = planar_lds_bytes<1>(n_obj, vpq, sp.fix_chunk);
+    const size_t lds_d = sizeof(double) * ((size_t)kWave * (4 * c->deg + 1) + (size_t)(kWave / 2) * L);
+    const size_t lds = std::max(std::max(lds_s, lds_g), std::max(lds_f, lds_d));
+    if (lds > 40 * 1024) return OBTG_ERR_UNSUPPORTED;
+    TimelineDump tl(c, grid, p.timeline);
+    if (tl.rc) return tl.rc;
+    {
+        ScopedKernelTimer tm(c, OBTG_K_PAIR_SWEEP);
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, c->stream, sp);
+    }
+    OBTG_HIP(c, hipGetLastError());
+    char hdr[256];
+    snprintf(hdr, sizeof hdr, "# grid %u structured n_S %d n_F %d n_G %d n_D %d per16 %d %d %d %d pat %d%d%d%d%d%d%d%d%d%d%d%d%d%d%d%d B %d",
+             grid, sp.n_kind[0], sp.n_kind[1], sp.n_kind[2], sp.n_kind[3], sp.per16[0], sp.per16[1], sp.per16[2], sp.per16[3],
+             sp.pat[0], sp.pat[1], sp.pat[2], sp.pat[3], sp.pat[4], sp.pat[5], sp.pat[6], sp.pat[7], sp.pat[8], sp.pat[9], sp.pat[10],
+             sp.pat[11], sp.pat[12], sp.pat[13], sp.pat[14], sp.pat[15], B);
+    return tl.finish(hdr);
 }
 
 size_t min_dist_stack_doubles(int K, int max_depth) { return (size_t)max_depth * (6 * K + F_NSCAL); }

@@ -88,6 +88,7 @@ struct obtg_ctx {
     bool polys_planar = true;   // every registered polygon vertex has z == 0
     bool fd_dedup = false;      // reuse row 0's GJK results for bit-identical hull pairs
     obtg::DevBuf d_hp_a, d_hp_b;  // hull pair list
+    obtg::DevBuf d_vp_off, d_vp_idx;   // per vehicle: the positions of the hull pairs that contain it (CSR; structured FD step)
     std::vector<int> h_hp_a, h_hp_b;   // host copy (tile-major chunking of large rows)
     obtg::DevBuf d_tile_chunk_off, d_tile_order, d_tile_pslots, d_tile_cobj_off, d_tile_cobjs, d_tile_ij;
     bool tile_ts_ok = false;  // every chunk's tile origin is recorded and the hull pair list holds every vehicle pair: the tiled
@@ -173,6 +174,8 @@ size_t temporal_sep_lds_bytes(const obtg_ctx* c, NsParams& p, size_t budget);
 int launch_pair_sweep(obtg_ctx* c, const double* dY, int B, double max_sep, double* d_out_sep, int max_iter,
                       int md_cap, int* d_flag, double* d_p1, double* d_p2, double* d_dist, int* d_nsup, int* d_status,
                       SweepFold* speed = nullptr);
+int launch_step_fd_structured(obtg_ctx* c, int B, double max_sep, double* d_out_sep, int max_iter, int md_cap, int* d_flag,
+                              double* d_p1, double* d_p2, double* d_dist, int* d_nsup, int* d_status, SweepFold* speed);
 int launch_temporal_sep_fd(obtg_ctx* c, const double* dY0, int n_pert, const int* d_prow, const int* d_pcol,
                            const double* d_pval, double max_sep, double* d_out);
 int launch_one_vs_many_min(obtg_ctx* c, const double* d_one, int B, const double* d_many, int K, double max_sep, double* d_out);

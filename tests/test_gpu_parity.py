@@ -1392,6 +1392,60 @@ def test_both_speed_bounds_from_one_pass(capi, synth, oracle, shape):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("shape", ["C3_full_batch", "deg7_two_fixed", "three_vehicles", "deg5_no_polys"])
+def test_structured_fd_step_is_bit_identical_to_the_brute_force_sweep(capi, synth, shape):
+    """obtg_constraint_sweep_fd_structured_dev: the finite-difference step as ONE launch that evaluates row 0 in full and
+    per perturbed row only what its vehicle touches, against the brute-force one-launch sweep of the same view
+    (obtg_constraint_sweep_dev, itself oracle-pinned at these shapes): every output array equal bit for bit, at C3 with
+    the full SLSQP batch B = n_x + 1 = 1153, with two fixed columns per end, with an odd row length (3 vehicles) and
+    without polygons; with the second speed bound on."""
+    import torch
+    N, n, M, fixed = {"C3_full_batch": (64, 10, 8, 1), "deg7_two_fixed": (20, 7, 2, 2), "three_vehicles": (3, 10, 1, 1),
+                      "deg5_no_polys": (12, 5, 0, 1)}[shape]
+    Y = synth.swarm_control_points(N, 2, n, seed=41)
+    pa, pb = synth.swarm_pairs(N, M)
+    B = N * 2 * (n + 1 - 2 * fixed) + 1
+    ctx = capi.Context(N, 2, n, 0)
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    ctx.set_polygons(*(synth.pack_polys(synth.polygon_obstacles(M, seed=41)) if M else (None, [0])))
+    ctx.set_hull_pairs(pa, pb)
+    h = synth.FD_STEP if shape == "C3_full_batch" else 1e-3
+    d0 = torch.from_numpy(Y).cuda()
+    dtf = torch.from_numpy(np.linspace(3.0, 9.0, B)).cuda()
+    P, L, Ps = ctx.num_pairs, 2 * n + 1, len(pa)
+
+    def bufs():
+        f64, i32 = torch.float64, torch.int32
+        def nan(*sh):
+            return torch.full(sh, float("nan"), dtype=f64, device="cuda")
+        return dict(sep=nan(B, P * L), flag=torch.full((B, Ps), -7, dtype=i32, device="cuda"), p1=nan(B, Ps, 3), p2=nan(B, Ps, 3),
+                    dist=nan(B, Ps), ns=torch.full((B, Ps), -7, dtype=i32, device="cuda"),
+                    st=torch.full((B, Ps), -7, dtype=i32, device="cuda"), sp=nan(B, ctx.len_speed), sp2=nan(B, ctx.len_speed),
+                    an=nan(B, ctx.len_ang_rate))
+    a, b = bufs(), bufs()
+    ctx.set_second_speed_bound(0.4, False, a["sp2"].data_ptr())
+    ctx.fd_view_begin(d0.data_ptr(), fixed, h, B)
+    ctx.constraint_sweep_dev(None, dtf.data_ptr(), B, 0.9, a["sep"].data_ptr(), 4.0, True, 1.5, a["sp"].data_ptr(),
+                             a["an"].data_ptr(), a["flag"].data_ptr(), a["p1"].data_ptr(), a["p2"].data_ptr(),
+                             a["dist"].data_ptr(), a["ns"].data_ptr(), a["st"].data_ptr(), 128, 500)
+    ctx.fd_view_end()
+    ctx.set_second_speed_bound(0.4, False, b["sp2"].data_ptr())
+    ctx.reset_kernel_stats(); ctx.set_profiling(True)
+    ctx.constraint_sweep_fd_structured_dev(d0.data_ptr(), fixed, h, dtf.data_ptr(), B, 0.9, b["sep"].data_ptr(), 4.0, True, 1.5,
+                                           b["sp"].data_ptr(), b["an"].data_ptr(), b["flag"].data_ptr(), b["p1"].data_ptr(),
+                                           b["p2"].data_ptr(), b["dist"].data_ptr(), b["ns"].data_ptr(), b["st"].data_ptr(), 128, 500)
+    torch.cuda.synchronize()
+    ks = {k: v[1] for k, v in ctx.kernel_stats().items() if v[1]}
+    ctx.set_profiling(False)
+    ctx.set_second_speed_bound(0.0, False, None)
+    assert ks == {"pair_sweep": 1}, ks                                     # ONE launch
+    for key in a:
+        assert torch.equal(a[key].view(torch.uint8), b[key].view(torch.uint8)), (shape, key)
+    ctx.set_stream(0)
+    ctx.close()
+
+
+@pytest.mark.gpu
 def test_small_host_calls_through_mapped_memory_equal_the_staged_path(capi, synth, monkeypatch):
     """One-row host calls keep their control points and results in mapped pinned host memory (the kernel reads and
     writes across PCIe itself; capi.cpp DevBuf::reserve).  Same bits as the device-staged path (OBTG_ZERO_COPY=0), for
