@@ -309,7 +309,9 @@ int obtg_min_dist2poly_robust(obtg_ctx*, const double* curves, int n_curves, int
  * on ~30 % of separated pairs and never exits on some 3-D inputs -- SURVEY.md 8(a) G2): a textbook GJK whose exit test
  * is a certificate, dist >= hull distance >= lower with dist - lower <= eps * dist.  Same point-set / pair conventions as
  * obtg_gjk_pairs.  flag 1 separated (p1 / p2 = closest points, dist), 0 intersecting or touching (dist 0);
- * lower, iters, status (0 converged, 1 iteration cap) are nullable. */
+ * lower, iters, status are nullable; status 0 = converged with that certificate, 1 = iteration cap, 2 = stalled at
+ * rounding level before the certificate closed (dist is still a distance between hull points, `lower` still a proven
+ * lower bound: compare the two). */
 int obtg_gjk_true_pairs(obtg_ctx*, const double* pts, int n_pts, const int* poly_off, int n_poly,
                         const int* pair_a, const int* pair_b, int n_pairs, double eps, int max_iter,
                         int* flag, double* p1, double* p2, double* dist, double* lower, int* iters, int* status);

@@ -174,12 +174,30 @@ class _PinnedPool(object):
     The device writes such an array by DMA at PCIe rate; a pageable NumPy array would be staged chunk by chunk
     (include/obtg.h, obtg_host_alloc).  Blocks are recycled: pinning costs milliseconds per 100 MB, an SLSQP
     driver asks for the same shapes on every iteration.  An array keeps its block alive through its buffer
-    object; when the last view dies the block returns to the pool (at most `cap` bytes stay cached)."""
+    object; when the last view dies the block returns to the pool.  At most `cap` bytes stay cached -- 1 GiB by
+    default (two Jacobian-sized result arrays of the 64-vehicle configuration), OBTG_PINNED_CACHE_MB overrides it --
+    and `trim()` (module function `pinned_trim`) hands every cached block back to the driver."""
 
     MIN_BYTES = 1 << 20
 
-    def __init__(self, cap=4 << 30):
+    def __init__(self, cap=None):
+        if cap is None:
+            cap = int(os.environ.get("OBTG_PINNED_CACHE_MB", "1024")) << 20
         self.cap, self.cached, self.free = cap, 0, {}
+
+    def trim(self, keep_bytes=0):
+        """Free cached blocks (largest first) until at most keep_bytes stay cached; returns the bytes released."""
+        released = 0
+        for size in sorted(self.free, reverse=True):
+            blocks = self.free[size]
+            while blocks and self.cached > keep_bytes:
+                ptr = blocks.pop()
+                self.cached -= size
+                released += size
+                if _lib is not None:
+                    _lib.obtg_host_free(_vp(ptr))
+        self.free = {k: v for k, v in self.free.items() if v}
+        return released
 
     def _release(self, size, ptr):
         if self.cached + size <= self.cap:
@@ -212,6 +230,11 @@ class _PinnedPool(object):
 
 
 _pinned = _PinnedPool()
+
+
+def pinned_trim(keep_bytes=0):
+    """Release the page-locked blocks the result-array pool has cached (all of them by default)."""
+    return _pinned.trim(keep_bytes)
 
 
 def pinned_empty(shape, dtype=np.float64):
@@ -600,7 +623,9 @@ class Context(object):
         return dict(res=res, nodes=info[:, 0], levels=info[:, 1], frontier=info[:, 2], status=status)
 
     def gjk_true_pairs(self, pts, off, pair_a, pair_b, eps=1e-10, max_iter=64):
-        """True hull distances (obtg_gjk_true_pairs; not gjkNew): dist with the certificate dist - lower <= eps * dist."""
+        """True hull distances (obtg_gjk_true_pairs; not gjkNew).  status 0: converged with the certificate
+        dist - lower <= eps * dist; 1: iteration cap; 2: stalled at rounding level before the certificate closed -- dist is
+        then still a distance between hull points and `lower` a proven lower bound: check `lower` (or status)."""
         pts = _f64(pts).reshape(-1, 3)
         off = _i32(off)
         pa, pb = _i32(pair_a), _i32(pair_b)

@@ -135,7 +135,10 @@ struct Result {
     P3 c1, c2;          // closest points on hull 1 / hull 2
     int flag;           // 1 separated, 0 intersecting / touching
     int iters;
-    int status;         // 0 converged, 1 iteration cap (dist is still an upper bound: a distance between hull points)
+    int status;         // 0 converged WITH the certificate dist - lower <= eps * dist; 1 iteration cap; 2 stalled at rounding
+                        // level (a support point repeated, or the simplex step did not get closer) before the certificate
+                        // closed.  In every case dist is a distance between hull points (an upper bound) and `lower` a
+                        // proven lower bound: callers that need the certificate check status == 0 or compare the two.
 };
 
 // Sup(dir, i1, i2): indices of the support points of set 1 in direction dir and of set 2 in direction -dir;
@@ -163,14 +166,14 @@ OBTG_HD Result true_distance(Sup sup, Pt1 pt1, Pt2 pt2, double eps, double abs_t
         if (vv - vw <= eps * vv) { r.status = 0; break; }                 // upper and lower bound agree
         bool dup = false;
         for (int q = 0; q < S.n; ++q) dup = dup || (S.s[q].i1 == i1 && S.s[q].i2 == i2);
-        if (dup) { r.status = 0; break; }                                  // no new vertex: v is optimal to rounding
+        if (dup) { r.status = 2; break; }                                  // no new vertex, certificate not closed: stalled
+        const Simplex S_before = S;
         S.s[S.n].v = w; S.s[S.n].i1 = i1; S.s[S.n].i2 = i2;
         S.n++;
         P3 nv;
         if (!closest_on_simplex(S, nv)) { v = nv; r.flag = 0; r.status = 0; break; }
-        const bool progress = dot(nv, nv) < vv;
+        if (!(dot(nv, nv) < vv)) { S = S_before; r.status = 2; break; }    // no closer: keep the better v and its simplex
         v = nv;                                                            // (S and its weights describe nv)
-        if (!progress) { r.status = 0; break; }                           // stalled at rounding level
     }
     if (r.flag == 0) {
         r.dist = 0.0; r.lower = 0.0;

