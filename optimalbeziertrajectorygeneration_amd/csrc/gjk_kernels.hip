@@ -1093,6 +1093,13 @@ template <int NC>
 __global__ __launch_bounds__(256, 4) void k_pair_sweep_tiled(const GjkSwarmParams p)
 {
     extern __shared__ double2 xy_dyn[];
+    if (p.dyn.out != nullptr && (int)blockIdx.x >= p.dyn_first_block) {
+        // the speed / angular-rate groups of the batch as the grid's last workgroups, as in k_pair_sweep: the whole
+        // evaluation of a large swarm (C4) is this one launch
+        if (threadIdx.x >= 2 * kWave) return;
+        dynamics2_group<NC, true>(p.dyn, reinterpret_cast<double*>(xy_dyn), (int)blockIdx.x - p.dyn_first_block);
+        return;
+    }
     gjk_planar_body<NC, 2, true>(p, xy_dyn, -1, -1);
 }
 
@@ -2328,6 +2335,7 @@ static int tile_height(int nc)
     const size_t budget = (size_t)160 * 1024 / occ - 1280;          // 1040 bytes of static LDS per workgroup
     int ta = 8;
     while (ta < 32 && planar_lds_bytes<2>(ta + 1 + 64, vpq, (ta + 1) * 64) <= budget) ++ta;
+    if (const char* e = getenv("OBTG_TILE_A")) ta = std::max(4, std::min(32, atoi(e)));     // (experiments)
     return ta;
 }
 
@@ -2867,11 +2875,37 @@ int launch_pair_sweep(obtg_ctx* c, const double* dY, int B, double max_sep, doub
                 q.len_in_stride = c->gjk_len_rows == B ? (int)npairs : 0;
                 q.len_out = c->gjk_history ? hist_out.as<unsigned char>() : nullptr;
                 if (c->gjk_history) { c->gjk_len_cur ^= 1; c->gjk_len_rows = B; }
-                if (ldst > 48 * 1024)
+                unsigned grid_t = (unsigned)((size_t)B * q.wgs_per_row);
+                size_t lds_t = ldst;
+                static const bool fold_dyn_t = !(getenv("OBTG_FOLD_DYNAMICS") && getenv("OBTG_FOLD_DYNAMICS")[0] == '0');
+                if (fold_dyn_t && speed && speed->d_out_ang && speed->d_out_speed && speed->d_tf && c->d_ang_w22n.p != nullptr) {
+                    const int L4 = 4 * c->deg + 1;
+                    const size_t lds_dyn = sizeof(double) * ((size_t)kWave * L4 + (size_t)(kWave / 2) * L);
+                    if (std::max(ldst, lds_dyn) <= (size_t)160 * 1024 / 4 - 1280) {       // still four workgroups per CU
+                        AngParams& d = q.dyn;
+                        d.Y = q.Y; d.tf = speed->d_tf; d.out = speed->d_out_ang; d.out_speed = speed->d_out_speed;
+                        d.n_veh = c->n_veh; d.total = B * c->n_veh;
+                        d.w2 = speed->max_rate * speed->max_rate;
+                        const double b2 = speed->speed_bound * speed->speed_bound;
+                        d.sp_sign = speed->speed_is_max ? -1.0 : 1.0; d.sp_offset = speed->speed_is_max ? b2 : -b2;
+                        if (c->speed2.d_out) {
+                            const double c2 = c->speed2.bound * c->speed2.bound;
+                            d.out_speed2 = c->speed2.d_out;
+                            d.sp2_sign = c->speed2.is_max ? -1.0 : 1.0; d.sp2_offset = c->speed2.is_max ? c2 : -c2;
+                        }
+                        d.W2n = c->d_ang_w2n.as<double>(); d.W22n = c->d_ang_w22n.as<double>(); d.Wn = c->d_ang_wn.as<double>();
+                        d.fd = q.fd; d.fd_fixed = q.fd_fixed; d.fd_h = q.fd_h;
+                        q.dyn_first_block = (int)grid_t;
+                        grid_t += (unsigned)((d.total + kWave - 1) / kWave);
+                        lds_t = std::max(ldst, lds_dyn);
+                        speed->did_dynamics = true;
+                    }
+                }
+                if (lds_t > 48 * 1024)
                     OBTG_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(kt),
-                                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldst));
+                                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_t));
                 ScopedKernelTimer tm(c, OBTG_K_PAIR_SWEEP);
-                hipLaunchKernelGGL(kt, dim3((unsigned)((size_t)B * q.wgs_per_row)), dim3(256), ldst, c->stream, q);
+                hipLaunchKernelGGL(kt, dim3(grid_t), dim3(256), lds_t, c->stream, q);
                 OBTG_HIP(c, hipGetLastError());
                 return OBTG_OK;
             }

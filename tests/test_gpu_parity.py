@@ -1269,18 +1269,19 @@ def test_min_dist2poly_robust(capi, synth, golden_dir, host_gjk):
     assert d_rob <= d_ref * (1 + 1e-9) and pt.shape == (3,)
 
 
-@pytest.mark.parametrize("shape", ["C3", "deg7_ragged", "elevated_fallback"])
+@pytest.mark.parametrize("shape", ["C3", "deg7_ragged", "elevated_fallback", "tiled_256x15"])
 def test_constraint_sweep_equals_separate_calls(capi, synth, shape):
     """obtg_constraint_sweep_dev: all four families of a batch in one call, against the separate entry points (pair
     sweep + fused dynamics), bit for bit; on a materialised batch and inside an FD view."""
     import torch
-    N, n, R, M, B = {"C3": (64, 10, 0, 8, 700), "deg7_ragged": (40, 7, 0, 3, 11), "elevated_fallback": (8, 10, 5, 2, 9)}[shape]
+    N, n, R, M, B = {"C3": (64, 10, 0, 8, 700), "deg7_ragged": (40, 7, 0, 3, 11), "elevated_fallback": (8, 10, 5, 2, 9),
+                     "tiled_256x15": (256, 15, 0, 0, 3)}[shape]
     Y = synth.swarm_control_points(N, 2, n, seed=21)
     polys = synth.polygon_obstacles(M, seed=21)
     pa, pb = synth.swarm_pairs(N, M)
     ctx = capi.Context(N, 2, n, R)
     ctx.set_stream(torch.cuda.current_stream().cuda_stream)
-    ctx.set_polygons(*synth.pack_polys(polys))
+    ctx.set_polygons(*(synth.pack_polys(polys) if M else (None, [0])))
     ctx.set_hull_pairs(pa, pb)
     h = 1e-3
     d0 = torch.from_numpy(Y).cuda()
@@ -1321,7 +1322,7 @@ def test_constraint_sweep_equals_separate_calls(capi, synth, shape):
         torch.cuda.synchronize()
         ks = ctx.kernel_stats()
         ctx.set_profiling(False)
-        if shape == "C3":       # the whole step is ONE launch: the dynamics groups are the grid's last workgroups
+        if shape in ("C3", "tiled_256x15"):       # the whole step is ONE launch: the dynamics groups are the grid's last workgroups
             assert ks.get("pair_sweep", (0.0, 0))[1] == 2 and ks.get("ang_rate", (0.0, 0))[1] == 0, ks
         for key in a:
             assert torch.equal(a[key].view(torch.uint8), b[key].view(torch.uint8)), (key, view)
