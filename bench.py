@@ -59,6 +59,9 @@ def parse():
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline and parity_check legs")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-gjk", action="store_true", help="Bernstein sweeps only")
+    ap.add_argument("--no-variants", action="store_true",
+                    help="skip the `variants` legs after the timed region (history off, moving x, structured FD step): "
+                         "profile runs, where their launches of the same kernel would blur its average")
     ap.add_argument("--fd-dedup", action="store_true",
                     help="reuse row 0's gjkNew results for bit-identical hull pairs (obtg_ctx_set_fd_dedup); "
                          "NOT the headline number")
@@ -398,7 +401,7 @@ def main():
     variants = None
     _sumK = N * (n + 1) + (int(poff[-1]) if M else 0)
     total_bytes_ = algorithmic_bytes(N, d, n, R, P_t, P_s, _sumK)[1]
-    if use_view and use_gjk and args.mode == "batch":
+    if use_view and use_gjk and args.mode == "batch" and not args.no_variants:
         def timed(nsteps, fn):
             for _ in range(10):
                 fn(0)

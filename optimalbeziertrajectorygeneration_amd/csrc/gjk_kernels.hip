@@ -412,8 +412,12 @@ constexpr int kSweepWavesPerSimd = 5;
 // workgroups per C3 row: 128 VGPRs (no spills, also none in the dynamics groups), a third fewer stagings and sorts per
 // row, 32-row transposition passes.  Interleaved runs on one box: 5 waves / 864-pair chunks 0.1872 ms, 4 / 864
 // 0.1855, 4 / 1280 0.1819 -- while the plain gjkNew sweep still prefers five (0.129 against 0.142 ms).
+// (Round 3 measured the one-launch form at five waves per SIMD again, now with 14-byte records so that 1264-pair
+// chunks fit five times into a CU's LDS and ONE workgroup per row in two passes is one round of the chip: 0.183 - 0.187
+// ms, the same as four waves -- but under the 96-VGPR bound the speed / angular-rate groups spill, and the PMC traffic
+// of the launch goes from 630 MB to 722 MB against 647 MB algorithmic (profiles/r03_a_*).  Same speed, cleaner traffic: four.)
 #ifndef OBTG_PS_WAVES
-#define OBTG_PS_WAVES 5
+#define OBTG_PS_WAVES 4
 #endif
 constexpr int kPairSweepWavesPerSimd = OBTG_PS_WAVES;
 // packed support indices (i1 | i2 << 16) as the 10-bit record form i1 | i2 << 5 (indices < 32 in the fixed-count sweeps)
@@ -2781,9 +2785,10 @@ static int pair_sweep_tile_rows(const obtg_ctx* c, int nc, size_t& lds)
     auto tile = [&](int rows) { return (size_t)4 * rows * tpf * sizeof(double); };
     int tr = 64;                       // the largest multiple of 8 that fits
     while (tr >= 8 && objects + tile(tr) > lds) tr -= 8;
+    // up to 32 rows per pass (two passes per 64-pair group) while the workgroup keeps its place in the CU's LDS
     const size_t budget = (size_t)160 * 1024 / kPairSweepWavesPerSimd - 1280;
-    for (int want = 16; want >= 8 && tr < want; want -= 8)
-        if (objects + tile(want) <= budget) { lds = std::max(lds, objects + tile(want)); tr = want; }
+    for (int want = 32; want >= 8 && tr < want; want -= 8)
+        if (objects + tile(want) <= budget) { lds = std::max(lds, objects + tile(want)); tr = want; break; }
     return tr >= 8 ? tr : 0;
 }
 

@@ -10,7 +10,7 @@
 import csv, glob, json, os, shutil, sys
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-FAMILY = (("pair_sweep", "k_pair_sweep"), ("temporal_sep", "k_normsq_elev"), ("ang_rate", "k_dynamics"), ("ang_rate", "k_ang_rate"),
+FAMILY = (("pair_sweep", "k_pair_sweep"), ("pair_sweep", "k_step_fd_structured"), ("temporal_sep", "k_normsq_elev"), ("ang_rate", "k_dynamics"), ("ang_rate", "k_ang_rate"),
           ("speed", "k_speed"), ("gjk", "k_gjk_swarm"))
 
 
@@ -33,7 +33,8 @@ def main():
     src = os.path.join(REPO, "gpurun_out", tag)
     dst = os.path.join(REPO, "profiles")
     for sub, name in (("stats", f"{tag}_kernel_stats.csv"), ("stats_dedup", f"{tag}_fd_dedup_kernel_stats.csv"),
-                      ("stats_2s", f"{tag}_two_streams_kernel_stats.csv"), ("stats_c5", f"{tag}_C5_kernel_stats.csv")):
+                      ("stats_2s", f"{tag}_two_streams_kernel_stats.csv"), ("stats_c5", f"{tag}_C5_kernel_stats.csv"),
+                      ("stats_structured", f"{tag}_fd_structured_kernel_stats.csv")):
         hits = glob.glob(os.path.join(src, sub, "**", "*kernel_stats.csv"), recursive=True)
         if hits:
             shutil.copy(hits[0], os.path.join(dst, name))
@@ -43,7 +44,7 @@ def main():
             shutil.copy(os.path.join(src, a), os.path.join(dst, b))
     tpath = os.path.join(dst, "traffic.json")
     traffic = json.load(open(tpath)) if os.path.exists(tpath) else {}
-    for wl, suffix in ((workload, ""), ("C5", "_c5")):
+    for wl, suffix in ((workload, ""), ("C5", "_c5"), (workload + "_fd_structured", "_structured")):
         fetch = pmc_mean(os.path.join(src, "fetch" + suffix), "FETCH_SIZE")
         write = pmc_mean(os.path.join(src, "write" + suffix), "WRITE_SIZE")
         per, detail = {}, {}
