@@ -304,6 +304,9 @@ __global__ __launch_bounds__(2 * kWave) void k_dynamics2(const AngParams p)
 // against the generic kernel's degree-4m convolutions.  A workgroup is four waves on the same 64 items; each
 // repeats phase A (8 % of its work) and takes every fourth 32-column chunk, transposed through a per-wave LDS tile
 // so that stores are 256-byte runs.
+#ifndef OBTG_DYN_ELEV_WAVES
+#define OBTG_DYN_ELEV_WAVES 2
+#endif
 struct AngElevParams {
     AngParams a;
     const double* __restrict__ cv4;  // scale[4n+1] = C(4n, j) | padded row C(4R, m) 2^-e, m = -(4n) .. 4R+4n+8
@@ -312,7 +315,7 @@ struct AngElevParams {
 };
 
 template <int NC>
-__global__ __launch_bounds__(4 * kWave, (NC > 11 ? 1 : 2)) void k_dynamics_elev(const AngElevParams q)
+__global__ __launch_bounds__(4 * kWave, (NC > 11 ? 1 : OBTG_DYN_ELEV_WAVES)) void k_dynamics_elev(const AngElevParams q)
 {
     constexpr int N = NC - 1, L2 = 2 * N + 1, L4 = 4 * N + 1, TP = kElevChunk + 1;
     const AngParams& p = q.a;

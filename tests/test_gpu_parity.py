@@ -6,7 +6,7 @@ Bars (BASELINE.json north_star): float64 constraint values within 1e-9 relative
 import numpy as np
 import pytest
 
-from util import assert_close
+from util import elementwise_rel, assert_close
 
 pytestmark = pytest.mark.gpu
 
@@ -40,6 +40,7 @@ def test_constraints_golden_and_oracle(capi, oracle, golden_dir):
         ctx = capi.Context(N, dim, n, R)
         got = ctx.temporal_sep(Y, ms)[0]
         assert_close(got, c[name + "_tsep"], RTOL, name + " tsep vs golden")
+        assert elementwise_rel(got, c[name + "_tsep"]) <= 1e-9, (name, elementwise_rel(got, c[name + "_tsep"]))   # element by element too
         assert_close(got, oracle.temporal_sep(Y, N, dim, R, ms), RTOL, name + " tsep vs oracle")
         assert_close(ctx.speed(Y, tf, vmax, True)[0], c[name + "_maxspeed"], RTOL, name + " vmax")
         assert_close(ctx.speed(Y, tf, vmin, False)[0], c[name + "_minspeed"], RTOL, name + " vmin")
@@ -414,9 +415,15 @@ def test_full_size_configs_vs_oracle(capi, oracle, synth, name):
     got = ctx.temporal_sep(Yb, 0.9)
     assert got.shape == (2, N * (N - 1) // 2 * (2 * n + R + 1))
     assert_close(got, o[0], RTOL, name + " tsep")
-    assert_close(ctx.speed(Yb, 10.0, 5.0, True), o[1], RTOL, name + " speed")
+    sp = ctx.speed(Yb, 10.0, 5.0, True)
+    assert_close(sp, o[1], RTOL, name + " speed")
+    # element by element as well (the scale-aware bound above is relative to the vector's largest entry): every entry
+    # that is not tiny against its vector (> 1e-6 x the largest) agrees to 1e-9 of ITS OWN magnitude
+    assert elementwise_rel(got, o[0]) <= 1e-9 and elementwise_rel(sp, o[1]) <= 1e-9, (elementwise_rel(got, o[0]), elementwise_rel(sp, o[1]))
     if d == 2:
-        assert_close(ctx.ang_rate(Yb, 10.0, 1.0), o[2], RTOL, name + " ang")
+        an = ctx.ang_rate(Yb, 10.0, 1.0)
+        assert_close(an, o[2], RTOL, name + " ang")
+        assert elementwise_rel(an, o[2]) <= (1e-9 if R == 0 else 1e-7), elementwise_rel(an, o[2])
     L = 2 * n + R + 1
     assert_close(ctx.temporal_sep_min(Yb, 0.9), o[0].reshape(2, -1, L).min(axis=2), RTOL, name + " min")
     ctx.close()
