@@ -27,7 +27,8 @@
 #include "bern_device.h"
 #pragma clang fp contract(off)
 
-constexpr int kSweepChunk = 864;       // hull pairs per workgroup of the general sweeps (the fixed-count sweeps: sweep_shape())
+constexpr int kSweepChunk = 864;       // hull pairs per workgroup of the plain sweeps (see sweep_shape)
+constexpr int kPairSweepChunk = 1280;  // ... and of the one-launch pair sweep
 
 namespace obtg {
 
@@ -558,7 +559,7 @@ __device__ __forceinline__ void gjk_planar_body(const GjkSwarmParams& p, double2
     const int fd_veh = fd_e >= 0 ? fd_e / (2 * NC) : -1;          // the vehicle row b's advanced control point belongs to
 
     // MODE 0: a workgroup takes p.passes chunks of its row one after the other on the one staging of the row (fewer,
-    // longer workgroups: the launch is a whole number of rounds of the chip, see sweep_shape())
+    // longer workgroups; see sweep_shape() for why that is not the default shape)
     const int fix_base = (FIXUP && p.chg_from_fd && fd_veh >= 0) ? p.vp_off[fd_veh] : 0;
     const int fix_count = FIXUP ? (p.chg_from_fd ? (fd_veh >= 0 ? p.vp_off[fd_veh + 1] - fix_base : 0) : p.n_pairs) : 0;
     for (int seg0 = 0; seg0 < (FIXUP ? fix_count : (SWEEP ? p.passes * p.chunk : 1)); seg0 += p.chunk) {
@@ -2427,16 +2428,19 @@ static int build_tiles(obtg_ctx* c, int /*vp*/)
     return OBTG_OK;
 }
 
-// Shape of a MODE 0 sweep's grid: workgroups per row, chunks a workgroup takes one after the other (passes), pairs per
-// chunk.  What the workgroup timeline (OBTG_TIMELINE, tools/timeline_report.py; profiles/r03_experiments) shows at C3:
-// a workgroup lasts 55 - 60 us whether it shares its CU with three others or runs alone -- it is a chain of dependent
-// state-machine rounds, not a share of the CU's issue slots -- so a launch takes (rounds of the chip) x (duration of a
-// workgroup), and 2306 workgroups on 4 x 256 slots were THREE rounds, the last one a quarter full.  Hence:
-//  * records of 14 bytes per pair, so that five workgroups of 1264 pairs and 72 objects fit a CU's LDS (1280 slots);
-//  * fewer, longer workgroups: a workgroup stages its row once and sweeps `passes` chunks on that staging, and
-//    (wgs, passes) minimise rounds x duration with duration = F + passes x (S + chunk x t) (fitted to the timeline: fixed
-//    part 18 us, per pass 6 us, 25 ns per pair).  C3, 1153 rows: one workgroup per row, two passes -- ONE round.
-// Small batches end up with many small workgroups (one round, shortest duration), as before.
+// Shape of a MODE 0 sweep's grid: workgroups per row, pairs per chunk (and chunks a workgroup takes one after the other:
+// `passes`, 1 unless forced).  Lanes refill from their workgroup's chunk, so a chunk must hold several pairs per lane
+// (in list order 316 pairs per 256 lanes ran 0.281 ms where 1264 pairs ran 0.215 ms); with the history order ~860-pair
+// chunks do as well as 1264 for the plain sweep, while the one-launch pair sweep (a separation share and two stagings
+// fewer per row) prefers 1280.  Small batches trade chunk size for enough workgroups to fill the chip; a row whose
+// objects leave less LDS than the target chunk needs gets more, smaller chunks.
+// Round 3 tried choosing (workgroups, passes) by "rounds of the chip x duration of a workgroup" -- the workgroup timeline
+// shows a launch as rounds of ~57 us workgroups -- and measured it wrong: C3 as ONE workgroup per row in two passes (one
+// round at five workgroups per CU) is level with two per row (three rounds at four), and C5's plain sweep as one workgroup
+// per row in five passes runs 0.269 ms against 0.240 - 0.244 ms as six or seven per row (OBTG_SWEEP_WGS scan,
+// profiles/r03_experiments): when every workgroup starts at once they all stage, sort, run gjkNew and store at the
+// same time, while many staggered workgroups keep the CUs' units mixed.  The launches are bound by the chip's aggregate
+// issue rate, not by rounds.  OBTG_SWEEP_WGS / OBTG_SWEEP_PASSES force a shape for experiments.
 // OBTG_TIMELINE=<file>: the 20th (OBTG_TIMELINE_AT) instrumented launch of the process leaves its workgroup timeline
 // there (text: block, start and end in 10 ns ticks from the first start, HW_ID, XCC_ID; tools/timeline_report.py)
 struct TimelineDump {
@@ -2486,11 +2490,11 @@ struct SweepShape {
     int wgs = 1, passes = 1, chunk = 0, per_cu = 1;
     size_t lds = 0;
 };
-static SweepShape sweep_shape(const obtg_ctx* c, int B, int nc, int waves_per_simd)
+static SweepShape sweep_shape(const obtg_ctx* c, int B, int nc, int waves_per_simd, int chunk_target)
 {
     const int np = c->n_hull_pairs, n_obj = c->n_veh + c->n_poly, vpq = nc | 1;
     const size_t fixed = planar_lds_bytes<0>(n_obj, vpq, 0);
-    SweepShape best;
+    SweepShape sh;
     // workgroups per CU: what the kernel's registers allow, fewer while the row's objects leave no room for 256 pairs
     int per_cu = nc <= 11 ? waves_per_simd : 1;
     size_t budget = 0;
@@ -2499,30 +2503,22 @@ static SweepShape sweep_shape(const obtg_ctx* c, int B, int nc, int waves_per_si
         if (per_cu == 1) budget = 64 * 1024;                       // one workgroup per CU: the launch limit
         if (fixed + 14 * 256 <= budget) break;
     }
-    if (per_cu < 1) { per_cu = 1; }
-    int chunk_max = fixed + 14 * 256 <= budget ? (int)std::min<size_t>((budget - fixed) / 14, 65535) : 256;
-    if (const char* e = getenv("OBTG_SWEEP_CHUNK_MAX")) chunk_max = std::max(64, std::min(chunk_max, atoi(e)));
-    const long slots = (long)c->n_cus * per_cu;
-    double best_cost = 1e300;
-    const int force_w = getenv("OBTG_SWEEP_WGS") ? atoi(getenv("OBTG_SWEEP_WGS")) : 0;
-    for (int W = 1; W <= std::max(1, np / 64); ++W) {
-        const int per_wg = (np + W - 1) / W;
-        const int Q = (per_wg + chunk_max - 1) / chunk_max;
-        const int chunk = (per_wg + Q - 1) / Q;
-        if (W > 1 && chunk < 256 && !force_w) break;
-        const long rounds = ((long)B * W + slots - 1) / slots;
-        const double cost = (double)rounds * (18.0 + Q * (6.0 + 0.025 * chunk));
-        if ((force_w ? W == force_w : cost < best_cost - 1e-9)) {
-            best_cost = cost;
-            best.wgs = W; best.passes = Q; best.chunk = chunk;
-        }
-        if (force_w && W == force_w) break;
-    }
-    // the grid covers ceil(np / (passes * chunk)) workgroups per row
-    best.wgs = (np + best.passes * best.chunk - 1) / (best.passes * best.chunk);
-    best.per_cu = per_cu;
-    best.lds = planar_lds_bytes<0>(n_obj, vpq, best.chunk);
-    return best;
+    if (per_cu < 1) per_cu = 1;
+    const int chunk_max = fixed + 14 * 256 <= budget ? (int)std::min<size_t>((budget - fixed) / 14, 65535) : 256;
+    int W = std::max(1, (np + chunk_target - 1) / chunk_target);
+    while ((long)B * W < 2048 && (np + W - 1) / W > 256) W <<= 1;                 // small batches: fill the chip
+    while ((np + W - 1) / W > chunk_max && (np + W - 1) / W > 256) ++W;           // the row's objects leave less LDS
+    int Q = 1;
+    if (const char* e = getenv("OBTG_SWEEP_WGS")) W = std::max(1, atoi(e));
+    if (const char* e = getenv("OBTG_SWEEP_PASSES")) Q = std::max(1, atoi(e));
+    const int per_wg = (np + W - 1) / W;
+    while ((per_wg + Q - 1) / Q > chunk_max && (per_wg + Q - 1) / Q > 64) ++Q;   // (a forced shape may need passes to fit)
+    sh.passes = Q;
+    sh.chunk = (per_wg + Q - 1) / Q;
+    sh.wgs = (np + sh.passes * sh.chunk - 1) / (sh.passes * sh.chunk);
+    sh.per_cu = per_cu;
+    sh.lds = planar_lds_bytes<0>(n_obj, vpq, sh.chunk);
+    return sh;
 }
 
 int launch_gjk_swarm(obtg_ctx* c, const double* dY, int B, int max_iter, int md_cap, int* d_flag,
@@ -2555,7 +2551,7 @@ int launch_gjk_swarm(obtg_ctx* c, const double* dY, int B, int max_iter, int md_
     if (planar && c->max_poly_K <= c->deg + 1 && c->deg + 1 <= 127) {
         const int nc = c->deg + 1;
         const int vp2 = nc | 1;                    // object pitch in 16-byte points (PlanarShape<NC>::VPQ)
-        const SweepShape shape = sweep_shape(c, B, nc, kSweepWavesPerSimd);
+        const SweepShape shape = sweep_shape(c, B, nc, kSweepWavesPerSimd, kSweepChunk);
         p.chunk = shape.chunk; p.wgs_per_row = shape.wgs; p.passes = shape.passes;
         const size_t lds2 = shape.lds;
         void (*kp)(const GjkSwarmParams) = nullptr;
@@ -2798,7 +2794,7 @@ bool pair_sweep_is_one_launch(const obtg_ctx* c)
     if (!(nc == 4 || nc == 6 || nc == 8 || nc == 11 || nc == 16)) return false;
     if (!(c->dim == 2 && c->polys_planar && c->max_poly_K <= nc && c->n_hull_pairs > 0 && !c->fd_dedup && c->R == 0 &&
           c->n_obs == 0 && c->n_pairs > 0)) return false;
-    size_t lds = sweep_shape(c, 1 << 20, nc, kPairSweepWavesPerSimd).lds;
+    size_t lds = sweep_shape(c, 1 << 20, nc, kPairSweepWavesPerSimd, kPairSweepChunk).lds;
     return pair_sweep_tile_rows(c, nc, lds) > 0 && lds <= 48 * 1024;
 }
 
@@ -2830,7 +2826,7 @@ int launch_pair_sweep(obtg_ctx* c, const double* dY, int B, double max_sep, doub
         p.pa = c->d_hp_a.as<int>(); p.pb = c->d_hp_b.as<int>();
         p.n_veh = c->n_veh; p.dim = c->dim; p.nc = nc; p.n_poly = c->n_poly;
         p.n_poly_pts = c->n_poly_pts; p.n_pairs = c->n_hull_pairs;
-        const SweepShape shape = sweep_shape(c, B, nc, kPairSweepWavesPerSimd);
+        const SweepShape shape = sweep_shape(c, B, nc, kPairSweepWavesPerSimd, kPairSweepChunk);
         p.chunk = shape.chunk; p.wgs_per_row = shape.wgs; p.passes = shape.passes;
         p.max_iter = max_iter; p.md_cap = md_cap;
         p.refill_min = sweep_refill_min();
