@@ -674,6 +674,13 @@ def pairs_mode(args, ctx, dist, world, rank, dev, dY, B, max_sep, barrier, pa, p
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
+    # proof of ranks: what the process group itself reports, and the device every rank ran on
+    ranks_seen = dist.get_world_size() if use_dist else 1
+    me = "%s #%d pid %d" % (torch.cuda.get_device_name(dev), dev.index if dev.index is not None else 0, os.getpid())
+    devices = [me]
+    if use_dist:
+        devices = [None] * ranks_seen
+        dist.all_gather_object(devices, me)
     # every rank must hold the full, identical result
     chk = {"sep_min_sum": out[0].sum().item()}
     if hull is not None:
@@ -688,6 +695,7 @@ def pairs_mode(args, ctx, dist, world, rank, dev, dY, B, max_sep, barrier, pa, p
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "%s: %d temporal-separation pairs + %d gjkNew hull pairs split over %d ranks, "
                                    "B=%d rows" % (args.workload, ctx.num_pairs, len(pa) if use_gjk else 0, world, B),
+                       "ranks_seen": ranks_seen, "backend": (args.backend if use_dist else None), "devices": devices,
                        "checksum": chk}}))
     if use_dist:
         dist.destroy_process_group()
