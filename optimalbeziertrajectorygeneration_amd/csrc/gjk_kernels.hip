@@ -3036,8 +3036,10 @@ int launch_step_fd_structured(obtg_ctx* c, int B, double max_sep, double* d_out_
     s_ranges = (B + sp.sep_rows_per - 1) / sp.sep_rows_per;
     // G: chunks of ~80 hull pairs (one short gjkNew phase per workgroup), row ranges for ~512 workgroups
     sp.gjk_chunk_pairs = 80;
+    if (const char* e = getenv("OBTG_STRUCT_GJK_CHUNK")) sp.gjk_chunk_pairs = std::max(16, atoi(e));
+    static const int g_target = getenv("OBTG_STRUCT_GJK_WGS") ? std::max(1, atoi(getenv("OBTG_STRUCT_GJK_WGS"))) : 1024;
     sp.gjk_chunks = (c->n_hull_pairs + sp.gjk_chunk_pairs - 1) / sp.gjk_chunk_pairs;
-    int g_ranges = std::max(1, std::min(B, 1024 / std::max(1, sp.gjk_chunks)));
+    int g_ranges = std::max(1, std::min(B, g_target / std::max(1, sp.gjk_chunks)));
     sp.gjk_rows_per = (B + g_ranges - 1) / g_ranges;
     g_ranges = (B + sp.gjk_rows_per - 1) / sp.gjk_rows_per;
     sp.fix_chunk = 256;

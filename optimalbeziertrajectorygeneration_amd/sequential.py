@@ -65,20 +65,22 @@ def new_vs_all(ynew, traj, ndim, maxSep, degElev=10):
 def reshape(x, traj, ndim, inipt, finalpt):
     """SequentialSwarm.py:81-116: x = the interior control points of the vehicle being planned, dimension after
     dimension; returns the fixed trajectories with the new one (end points added) appended as the LAST ndim rows."""
-    x = np.asarray(x, dtype=np.float64)
-    y = np.concatenate((np.atleast_2d(inipt).reshape((-1, 1)), x.reshape((ndim, -1)),
-                        np.atleast_2d(finalpt).reshape((-1, 1))), axis=1)
-    traj = np.asarray(traj)
-    return np.concatenate((traj, y)) if traj.size > 0 else y
+    inner = np.asarray(x, dtype=np.float64).reshape(ndim, -1)
+    traj = np.asarray(traj, dtype=np.float64)
+    k = traj.shape[0] if traj.size > 0 else 0
+    y = np.empty((k + ndim, inner.shape[1] + 2))
+    if k:
+        y[:k] = traj
+    y[k:, 0] = np.ravel(inipt)
+    y[k:, 1:-1] = inner
+    y[k:, -1] = np.ravel(finalpt)
+    return y
 
 
 def initguess(vidx, params):
-    """SequentialSwarm.py:119-136: straight line between the vehicle's end points."""
-    x0 = np.empty((params.deg - 1) * params.ndim)
-    for d in range(params.ndim):
-        idx = d * (params.deg - 1)
-        x0[idx:idx + params.deg - 1] = np.linspace(params.inipts[vidx, d], params.finalpts[vidx, d], params.deg + 1)[1:-1]
-    return x0
+    """SequentialSwarm.py:119-136: the interior control points of the straight line between the vehicle's end points."""
+    line = np.linspace(params.inipts[vidx, :params.ndim], params.finalpts[vidx, :params.ndim], params.deg + 1, axis=1)
+    return np.ascontiguousarray(line[:, 1:-1]).reshape(-1)
 
 
 def cost(x, vidx, params):
