@@ -42,14 +42,38 @@ def _context(ndim, deg, deg_elev, device=0):
     return c
 
 
+_FAST_NC = (4, 6, 8, 11, 16, 21)     # control points per curve with a specialised one-vs-many kernel (include/obtg.h)
+_generic_cache = {}
+
+
+def _one_vs_many(one, many, ndim, maxSep, degElev):
+    """out[B][K].  Degrees without a specialised kernel go through the any-degree separation kernel: a context of K + 1
+    "vehicles" (candidate first) whose first K lexicographic pairs are exactly (candidate, other k)."""
+    nc = many.shape[-1]
+    if nc in _FAST_NC:
+        return _context(ndim, nc - 1, degElev).one_vs_many_min(one, many, maxSep)
+    one = np.ascontiguousarray(one, dtype=np.float64).reshape(-1, ndim, nc)
+    many = np.ascontiguousarray(many, dtype=np.float64).reshape(-1, ndim, nc)
+    B, K = one.shape[0], many.shape[0]
+    key = (K + 1, int(ndim), nc - 1, int(degElev))
+    ctx = _generic_cache.get(key)
+    if ctx is None:
+        if len(_generic_cache) > 4:
+            _generic_cache.pop(next(iter(_generic_cache))).close()
+        ctx = _generic_cache[key] = _capi.Context(K + 1, int(ndim), nc - 1, int(degElev))
+    Y = np.empty((B, (K + 1) * ndim, nc))
+    Y[:, :ndim] = one
+    Y[:, ndim:] = many.reshape(K * ndim, nc)
+    return ctx.temporal_sep_min(Y, maxSep, pair_begin=0, pair_count=K)
+
+
 def temporalSeparationConstraints(y, nveh, ndim, maxSep, degElev=10):
     """Examples/SequentialSwarm.py:43-70 (the elevation, hard-coded to 10 there, is a keyword here): trajectory 0
     (rows 0..ndim-1 of y) against trajectories 1..nveh-1 -> float64[nveh-1]."""
     if nveh <= 1:
         return np.atleast_1d(0.0)                     # SequentialSwarm.py:69-70
     y = np.ascontiguousarray(y, dtype=np.float64)
-    ctx = _context(ndim, y.shape[1] - 1, degElev)
-    return ctx.one_vs_many_min(y[0:ndim], y[ndim:nveh * ndim], maxSep)[0]
+    return _one_vs_many(y[0:ndim], y[ndim:nveh * ndim], ndim, maxSep, degElev)[0]
 
 
 def new_vs_all(ynew, traj, ndim, maxSep, degElev=10):
@@ -58,8 +82,7 @@ def new_vs_all(ynew, traj, ndim, maxSep, degElev=10):
     finite-difference batch of the new vehicle in one launch."""
     traj = np.ascontiguousarray(traj, dtype=np.float64)
     ynew = np.ascontiguousarray(ynew, dtype=np.float64)
-    ctx = _context(ndim, traj.shape[1] - 1, degElev)
-    return ctx.one_vs_many_min(ynew, traj, maxSep)
+    return _one_vs_many(ynew, traj, ndim, maxSep, degElev)
 
 
 def reshape(x, traj, ndim, inipt, finalpt):
