@@ -59,6 +59,12 @@ def parse():
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline and parity_check legs")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-gjk", action="store_true", help="Bernstein sweeps only")
+    ap.add_argument("--event-period", type=int, default=0,
+                    help="HIP events on every n-th launch of the dominant kernel inside the timed region (default 0 = every "
+                         "launch when --steps < 100, so that a 20-step run has 20 samples, every 4th otherwise).  The events ride "
+                         "on the dispatch itself (hipExtLaunchKernelGGL start / stop timestamps, no barrier packets of their "
+                         "own); a timed launch still does not overlap its neighbours: every launch 0.1886 ms per step, every "
+                         "4th 0.1865, none 0.1863 at C3")
     ap.add_argument("--no-variants", action="store_true",
                     help="skip the `variants` legs after the timed region (history off, moving x, structured FD step): "
                          "profile runs, where their launches of the same kernel would blur its average")
@@ -358,11 +364,9 @@ def main():
     wstats = kstats()
     KNAMES = ("pair_sweep", "temporal_sep", "speed", "ang_rate", "gjk", "fd_batch")
     dom_name = max(KNAMES, key=lambda k: wstats.get(k, (0.0, 0))[0])
-    # timed region: HIP events (launch stream) around the dominant kernel only, on every 4th step --
-    # an event pair drains the queue around its launch (events on all three launches of every step
-    # cost 15 % of a 0.25 ms step)
-    # (short runs -- the driver's --steps 20 -- put them on every launch, so that the average has >= 20 samples)
-    prof(True, only=dom_name, period=4 if args.steps >= 100 else 1)
+    # timed region: HIP events (launch stream) on the dominant kernel only: every launch of a short run (the driver's
+    # --steps 20 then has 20 samples), every 4th of a long one (a timed launch does not overlap its neighbours: 1 % of the step)
+    prof(True, only=dom_name, period=args.event_period or (1 if args.steps < 100 else 4))
     barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()

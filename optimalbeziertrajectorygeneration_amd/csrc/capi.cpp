@@ -58,7 +58,7 @@ int set_error(obtg_ctx* c, hipError_t e, const char* where)
     return e == hipErrorOutOfMemory ? OBTG_ERR_OOM : OBTG_ERR_DEVICE;
 }
 
-ScopedKernelTimer::ScopedKernelTimer(obtg_ctx* c_, int id_) : c(c_), id(id_)
+ScopedKernelTimer::ScopedKernelTimer(obtg_ctx* c_, int id_, bool ext_) : c(c_), id(id_), ext(ext_)
 {
     if (!c->profiling || !((c->profile_mask >> id) & 1u)) return;
     if (c->profile_period > 1 && (c->profile_seen[id]++ % c->profile_period) != 0) return;
@@ -67,13 +67,13 @@ ScopedKernelTimer::ScopedKernelTimer(obtg_ctx* c_, int id_) : c(c_), id(id_)
         return hipEventCreate(&e) == hipSuccess;
     };
     if (!take(a) || !take(b)) { a = b = nullptr; return; }
-    (void)hipEventRecord(a, c->stream);
+    if (!ext) (void)hipEventRecord(a, c->stream);
 }
 
 ScopedKernelTimer::~ScopedKernelTimer()
 {
     if (!a || !b) return;
-    (void)hipEventRecord(b, c->stream);
+    if (!ext) (void)hipEventRecord(b, c->stream);
     c->pending_events.push_back({ id, { a, b } });
 }
 

@@ -18,6 +18,8 @@
 #include <cstdlib>
 #include <vector>
 
+#include <hip/hip_ext.h>
+
 #include "gjk_device.h"
 #include "gjk_true.h"
 #include "obtg_internal.h"
@@ -2480,6 +2482,14 @@ struct TimelineDump {
     }
 };
 
+// launch with the timer's events riding on the dispatch itself (kernel start / stop timestamps), or plainly
+template <class K, class P>
+static void launch_timed(ScopedKernelTimer& t, K kern, dim3 grid, dim3 block, size_t lds, hipStream_t stream, const P& params)
+{
+    if (t.ext && t.a && t.b) hipExtLaunchKernelGGL(kern, grid, block, (unsigned)lds, stream, t.a, t.b, 0, params);
+    else hipLaunchKernelGGL(kern, grid, block, lds, stream, params);
+}
+
 static int sweep_refill_min()
 {
     static const int v = getenv("OBTG_REFILL_MIN") ? std::max(1, std::min(64, atoi(getenv("OBTG_REFILL_MIN")))) : 32;
@@ -2905,8 +2915,8 @@ int launch_pair_sweep(obtg_ctx* c, const double* dY, int B, double max_sep, doub
                 if (lds_t > 48 * 1024)
                     OBTG_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(kt),
                                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_t));
-                ScopedKernelTimer tm(c, OBTG_K_PAIR_SWEEP);
-                hipLaunchKernelGGL(kt, dim3(grid_t), dim3(256), lds_t, c->stream, q);
+                ScopedKernelTimer tm(c, OBTG_K_PAIR_SWEEP, true);
+                launch_timed(tm, kt, dim3(grid_t), dim3(256), lds_t, c->stream, q);
                 OBTG_HIP(c, hipGetLastError());
                 return OBTG_OK;
             }
@@ -2962,8 +2972,8 @@ int launch_pair_sweep(obtg_ctx* c, const double* dY, int B, double max_sep, doub
     TimelineDump tl(c, grid, p.timeline);
     if (tl.rc) return tl.rc;
     {
-        ScopedKernelTimer tm(c, OBTG_K_PAIR_SWEEP);
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(OBTG_SWEEP_THREADS), lds, c->stream, p);
+        ScopedKernelTimer tm(c, OBTG_K_PAIR_SWEEP, true);
+        launch_timed(tm, kern, dim3(grid), dim3(OBTG_SWEEP_THREADS), lds, c->stream, p);
     }
     {
         char hdr[256];
@@ -3085,8 +3095,8 @@ int launch_step_fd_structured(obtg_ctx* c, int B, double max_sep, double* d_out_
     TimelineDump tl(c, grid, p.timeline);
     if (tl.rc) return tl.rc;
     {
-        ScopedKernelTimer tm(c, OBTG_K_PAIR_SWEEP);
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, c->stream, sp);
+        ScopedKernelTimer tm(c, OBTG_K_PAIR_SWEEP, true);
+        launch_timed(tm, kern, dim3(grid), dim3(256), lds, c->stream, sp);
     }
     OBTG_HIP(c, hipGetLastError());
     char hdr[256];

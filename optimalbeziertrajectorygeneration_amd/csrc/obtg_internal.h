@@ -137,12 +137,15 @@ int set_error(obtg_ctx* c, hipError_t e, const char* where);
         if (e__ != hipSuccess) return ::obtg::set_error((c), e__, #call);   \
     } while (0)
 
-// bracket a launch with events when profiling
+// bracket a launch with events when profiling.  ext = true: the events are NOT recorded on the stream; the launch itself
+// carries them (launch_timed -> hipExtLaunchKernelGGL: the dispatch's own start / stop timestamps, no barrier packets
+// around the kernel, so events on every launch do not stretch the step).
 struct ScopedKernelTimer {
     obtg_ctx* c;
     int id;
+    bool ext;
     hipEvent_t a = nullptr, b = nullptr;
-    ScopedKernelTimer(obtg_ctx* c_, int id_);
+    ScopedKernelTimer(obtg_ctx* c_, int id_, bool ext_ = false);
     ~ScopedKernelTimer();
 };
 void flush_pending_events(obtg_ctx* c);
