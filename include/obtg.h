@@ -263,8 +263,10 @@ int obtg_constraint_sweep_dev(obtg_ctx*, const double* dY, const double* d_tf, i
  * results into all B rows, while one workgroup per row evaluates only the N-1 separation pairs, the hull pairs and the
  * vehicle its advanced control point touches.  Outputs are those of obtg_constraint_sweep_dev inside the same view,
  * bit for bit (the same device functions evaluate every pair); the launch is bound by its stores instead of by gjkNew.
- * Planar shapes of the one-launch sweep (deg + 1 in {4, 6, 8, 11}, DEG_ELEV 0, no point obstacles, angular rate wanted):
- * OBTG_ERR_UNSUPPORTED otherwise -- the brute-force call gives the same numbers.  A different evaluation strategy from
+ * Planar shapes (deg + 1 in {4, 6, 8, 11}, no point obstacles, angular rate wanted, a row's objects within 40 KB of LDS), any
+ * DEG_ELEV with 2 deg + DEG_ELEV + 1 <= 512 -- for DEG_ELEV > 0 (where the brute-force step is three launches) the separation
+ * streams are the elevated rows and the dynamics groups are the elevated kernel's: OBTG_ERR_UNSUPPORTED otherwise -- the
+ * brute-force call gives the same numbers.  A different evaluation strategy from
  * "every row in full": bench.py reports it as variants.fd_structured, never as its headline value. */
 int obtg_constraint_sweep_fd_structured_dev(obtg_ctx*, const double* dY0, int n_fixed_cols, double h, const double* d_tf,
                                             int B, double max_sep, double* d_out_sep, double speed_bound, int speed_is_max,

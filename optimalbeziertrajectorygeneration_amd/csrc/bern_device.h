@@ -292,6 +292,8 @@ struct TsepXYParams {
     double* __restrict__ out;         // [B][n_pairs][2n+1]; nullptr = no temporal work
     int n_pairs;
     double sign, offset;
+    const double* __restrict__ Tt;    // DEG_ELEV > 0 (structured step): elevation as a scaled convolution (NsParams::Tt)
+    int R;
 };
 
 template <int NC>
@@ -393,6 +395,157 @@ __device__ __forceinline__ void tsep_rows_of_vehicle(const TsepXYParams& t, cons
         double* o = t.out + ((size_t)b * t.n_pairs + q) * L;
 #pragma unroll
         for (int k = 0; k < L; ++k) o[k] = t.sign * cf[k] + t.offset;
+    }
+}
+
+// Structured finite-difference step with DEG_ELEV = R > 0 (gjk_kernels.hip k_step_fd_structured<NC, true>), row 0's part:
+// the workgroup (four waves) evaluates the 64-pair group g of the staged row -- wave 0 the products, scaled, into chT;
+// then every wave its share of the passes of rpp rows x all 2n+R+1 columns, exactly as normsq_elev_body's full-row form
+// does (lane = (row of the pass, block of 8 columns), window of the binomial row in registers, conv_block1_reg) -- and
+// streams each pass from its output tile into every batch row b0 <= b < b1, leaving out the rows of pairs that contain
+// batch row b's own vehicle (fd_element).  chT: [64][2n+1] doubles, otile_base: 4 x rpp x nb2 x 9 doubles.
+template <int NC>
+__device__ __forceinline__ void tsep_elev_group_stream(const TsepXYParams& t, const double2* xy, const int vpq, const int g,
+                                                       double* chT, double* otile_base, const int b0, const int b1,
+                                                       const int fd, const int fd_fixed)
+{
+    using S = NsShape<NC, 2>;
+    constexpr int L = S::L;
+    const int LR = L + t.R;
+    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6, n_waves = blockDim.x >> 6;
+    const int itg = g * kWave;
+    const int n_valid = min(kWave, t.n_pairs - itg);
+    const ctab_t escale = as_ctab(t.Tt);
+    if (wave == 0) {
+        const int item = min(itg + lane, t.n_pairs - 1);
+        const int2 ij = t.pairs[item];
+        const double2* vi = xy + ij.x * vpq;
+        const double2* vj = xy + ij.y * vpq;
+        double a[2][NC];
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const double2 pi = vi[c], pj = vj[c];
+            a[0][c] = pi.x - pj.x;
+            a[1][c] = pi.y - pj.y;
+        }
+        double cf[L];
+        normsq_coeffs<NC, 2>(a, as_ctab(t.W2), cf);
+        if (lane < n_valid) {
+#pragma unroll
+            for (int j = 0; j < L; ++j) chT[lane * L + j] = cf[j] * escale[j];
+        }
+    }
+    __syncthreads();
+    const double* ebin_g = t.Tt + L;
+    const double* einv_g = ebin_g + (t.R + 2 * L - 1 + kConvPad);
+    const int nblk = (LR + kElevBlock - 1) / kElevBlock;        // <= 64 (the launcher checks 2n + R + 1 <= 512)
+    int nb2 = 1;
+    while (nb2 < nblk) nb2 <<= 1;
+    const int rpp = kWave / nb2;                                 // rows per pass
+    const int cb = lane & (nb2 - 1), rs = lane / nb2;
+    constexpr int BP = kElevBlock + 1;
+    const int opitch = nb2 * BP;
+    double* otile = otile_base + wave * (rpp * opitch);
+    const bool colv = cb < nblk;
+    double w[L - 1 + kElevBlock], inv8[kElevBlock];
+#pragma unroll
+    for (int m = 0; m < L - 1 + kElevBlock; ++m) w[m] = colv ? ebin_g[cb * kElevBlock + m] : 0.0;
+#pragma unroll
+    for (int i = 0; i < kElevBlock; ++i) inv8[i] = colv ? einv_g[cb * kElevBlock + i] : 0.0;
+    for (int r0 = wave * rpp; r0 < n_valid; r0 += n_waves * rpp) {
+        const int rr = r0 + rs;
+        if (rr < n_valid && colv) {
+            double ch[L], sa[kElevBlock];
+#pragma unroll
+            for (int j = 0; j < L; ++j) ch[j] = chT[rr * L + j];
+            conv_block1_reg<L>(w, ch, sa);
+            double* o = otile + rs * opitch + cb * BP;
+#pragma unroll
+            for (int i = 0; i < kElevBlock; ++i) o[i] = t.sign * (sa[i] * inv8[i]) + t.offset;
+        }
+        wave_sync();
+        const int rows = min(rpp, n_valid - r0);
+        // the pass's rows are one contiguous run of rows x (2n+R+1) doubles in every batch row: written back to back per
+        // batch row (the L2 merges the lines neighbouring rows share), from registers (each lane keeps its columns)
+        constexpr int kMaxRows = 8, kMaxCols = 4;                                   // rpp <= 8 (LR > 56), ceil(LR / 64) <= 4 (LR <= 256); else the LDS form below
+        if (rows <= kMaxRows && LR <= kMaxCols * kWave) {
+            double v[kMaxRows][kMaxCols];
+            int pi[kMaxRows], pj[kMaxRows];
+#pragma unroll
+            for (int q = 0; q < kMaxRows; ++q) {
+                const int2 ij = q < rows ? t.pairs[itg + r0 + q] : make_int2(-2, -2);    // wave-uniform
+                pi[q] = ij.x; pj[q] = ij.y;
+#pragma unroll
+                for (int cc = 0; cc < kMaxCols; ++cc) {
+                    const int kc = lane + cc * kWave;
+                    v[q][cc] = (q < rows && kc < LR) ? otile[q * opitch + (kc >> 3) * BP + (kc & 7)] : 0.0;
+                }
+            }
+            for (int b = b0; b < b1; ++b) {
+                const int fd_e = fd_element(fd, fd_fixed, NC, b);
+                const int vb = fd_e >= 0 ? fd_e / (2 * NC) : -1;
+                double* gp = t.out + ((size_t)b * t.n_pairs + (size_t)(itg + r0)) * LR + lane;
+#pragma unroll
+                for (int q = 0; q < kMaxRows; ++q) {
+                    if (q < rows && pi[q] != vb && pj[q] != vb) {                    // (a pair of row b's own vehicle: its workgroup writes it)
+#pragma unroll
+                        for (int cc = 0; cc < kMaxCols; ++cc)
+                            if (lane + cc * kWave < LR) gp[(size_t)q * LR + cc * kWave] = v[q][cc];
+                    }
+                }
+            }
+        } else {
+            for (int b = b0; b < b1; ++b) {
+                const int fd_e = fd_element(fd, fd_fixed, NC, b);
+                const int vb = fd_e >= 0 ? fd_e / (2 * NC) : -1;
+                for (int q = 0; q < rows; ++q) {
+                    const int2 ij = t.pairs[itg + r0 + q];
+                    if (ij.x == vb || ij.y == vb) continue;
+                    double* gp = t.out + ((size_t)b * t.n_pairs + (size_t)(itg + r0 + q)) * LR;
+                    for (int kc = lane; kc < LR; kc += kWave) gp[kc] = otile[q * opitch + (kc >> 3) * BP + (kc & 7)];
+                }
+            }
+        }
+        wave_sync();
+    }
+}
+
+// ... and a perturbed row's part with DEG_ELEV > 0: the elevated separation rows of every pair that contains vehicle v of
+// row b, one pair per lane, each lane its own run (the arithmetic of k_tsep_fd's elevated form, which equals the batch's).
+template <int NC>
+__device__ __forceinline__ void tsep_elev_rows_of_vehicle(const TsepXYParams& t, const double2* xy, const int vpq, const int b,
+                                                          const int n_veh, const int v)
+{
+    using S = NsShape<NC, 2>;
+    constexpr int L = S::L;
+    const int LR = L + t.R;
+    const ctab_t escale = as_ctab(t.Tt), ebin = escale + L, einv = ebin + (t.R + 2 * L - 1 + kConvPad);
+    for (int u0 = threadIdx.x; u0 < n_veh - 1; u0 += blockDim.x) {
+        const int u = u0 < v ? u0 : u0 + 1;
+        const int i = min(u, v), j = max(u, v);
+        const int q = i * (2 * n_veh - i - 1) / 2 + (j - i - 1);
+        const double2* vi = xy + i * vpq;
+        const double2* vj = xy + j * vpq;
+        double a[2][NC];
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const double2 pi = vi[c], pj = vj[c];
+            a[0][c] = pi.x - pj.x;
+            a[1][c] = pi.y - pj.y;
+        }
+        double cf[L];
+        normsq_coeffs<NC, 2>(a, as_ctab(t.W2), cf);
+        double ch[L];
+#pragma unroll
+        for (int jj = 0; jj < L; ++jj) ch[jj] = cf[jj] * escale[jj];
+        double* o = t.out + ((size_t)b * t.n_pairs + q) * LR;
+        for (int k = 0; k < LR; k += kElevBlock) {
+            double sa[kElevBlock];
+            conv_block1<L>(ebin + k, ch, sa);
+#pragma unroll
+            for (int ii = 0; ii < kElevBlock; ++ii)
+                if (k + ii < LR) o[k + ii] = t.sign * (sa[ii] * einv[k + ii]) + t.offset;
+        }
     }
 }
 
@@ -844,6 +997,113 @@ __device__ __forceinline__ void dynamics2_group(const AngParams& p, double* lds,
         if (e0 >= 0 && e1 < total) store_nt2(p.out + grow + e0, tile[e0], tile[e1]);
         else if (e0 >= 0) store_nt(p.out + grow + e0, tile[e0]);
         else if (e1 < total) store_nt(p.out + grow + e1, tile[e1]);
+    }
+}
+
+#ifndef OBTG_DYN_ELEV_WAVES
+#define OBTG_DYN_ELEV_WAVES 2
+#endif
+struct AngElevParams {
+    AngParams a;
+    const double* __restrict__ cv4;  // scale[4n+1] = C(4n, j) | padded row C(4R, m) 2^-e, m = -(4n) .. 4R+4n+8
+    const double* __restrict__ cv2;  // scale[2n+1] = C(2n, j) | padded row C(R, m), m = -(2n) .. R+2n+8 | 1/C(2n+R, k) (+8)
+    int R;
+};
+
+template <int NC>
+__device__ __forceinline__ void dynamics_elev_group(const AngElevParams& q, double* lds, const int group)
+{
+    constexpr int N = NC - 1, L2 = 2 * N + 1, L4 = 4 * N + 1, TP = kElevChunk + 1;
+    const AngParams& p = q.a;
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform: table reads become scalar loads
+    double* tile = lds + wave * (kWave * TP);
+    const int it0 = group * kWave;
+    const int n_valid = min(kWave, p.total - it0);
+    const int item = min(it0 + lane, p.total - 1);
+    const int b = item / p.n_veh;
+    double num[L4], den[L4];
+    {   // ---- phase A: degree-4n numerator and denominator from the original control points (as k_dynamics2)
+        double x[NC], y[NC];
+        load_item_xy<NC>(p, item, b, x, y);
+        const double val = (double)N / p.tf[b];
+        double xD[NC], yD[NC], xDD[NC], yDD[NC];
+        diff_elev1<NC>(x, val, xD);
+        diff_elev1<NC>(y, val, yD);
+        diff_elev1<NC>(xD, val, xDD);
+        diff_elev1<NC>(yD, val, yDD);
+        const ctab_t Wn = as_ctab(p.Wn), W2n = as_ctab(p.W2n), W22n = as_ctab(p.W22n);
+        double num1[L2], den1[L2];
+#pragma unroll
+        for (int k = 0; k < L2; ++k) {
+            double s1 = 0.0, s2 = 0.0, sd = 0.0;
+#pragma unroll
+            for (int j = (k - N > 0 ? k - N : 0); j <= (N < k ? N : k); ++j) {
+                const double wkj = Wn[k * NC + j];
+                s1 = fma(wkj, yDD[j] * xD[k - j], s1);
+                s2 = fma(wkj, xDD[j] * yD[k - j], s2);
+            }
+#pragma unroll
+            for (int j = (k - N > 0 ? k - N : 0); 2 * j <= k; ++j)
+                sd = fma(W2n[k * NC + j], fma(xD[j], xD[k - j], yD[j] * yD[k - j]), sd);
+            num1[k] = s1 - s2;
+            den1[k] = sd;
+        }
+        // speed rows = elev(den1, R): this wave's share of their 32-column chunks, while den1 is still live
+        if (p.out_speed) {
+            const int L2R = L2 + q.R;
+            const ctab_t sc2 = as_ctab(q.cv2), row2 = sc2 + L2, inv2 = row2 + (q.R + 1 + 2 * (L2 - 1) + kElevBlock);
+            double dh[L2];
+#pragma unroll
+            for (int j = 0; j < L2; ++j) dh[j] = sc2[j] * den1[j];
+            for (int k0 = wave * kElevChunk; k0 < L2R; k0 += 4 * kElevChunk) {
+                const int kc = min(kElevChunk, L2R - k0);
+                // one pass per requested bound (the second one, obtg_ctx_set_second_speed_bound, repeats the chunk's
+                // convolution: the degree-2n curve is what the two share)
+                for (int which = 0; which < (p.out_speed2 ? 2 : 1); ++which) {
+                    const double sgn = which ? p.sp2_sign : p.sp_sign, off = which ? p.sp2_offset : p.sp_offset;
+                    for (int kb = 0; kb < kc; kb += kElevBlock) {
+                        double sa[kElevBlock];
+                        conv_block1<L2>(row2 + k0 + kb, dh, sa);
+#pragma unroll
+                        for (int i = 0; i < kElevBlock; ++i)
+                            tile[lane * TP + kb + i] = sgn * (sa[i] * inv2[k0 + kb + i]) + off;
+                    }
+                    wave_sync();
+                    elev_store_chunk<L2>(tile, which ? p.out_speed2 : p.out_speed, (size_t)it0 * L2R, L2R, k0, kc, n_valid, lane);
+                    wave_sync();
+                }
+            }
+        }
+        const ctab_t sc4 = as_ctab(q.cv4);
+#pragma unroll
+        for (int k = 0; k < L4; ++k) {
+            double sn = 0.0, sd = 0.0;
+#pragma unroll
+            for (int j = (k - 2 * N > 0 ? k - 2 * N : 0); 2 * j <= k; ++j) {
+                const double wkj = W22n[k * L2 + j];
+                sn = fma(wkj, num1[j] * num1[k - j], sn);
+                sd = fma(wkj, den1[j] * den1[k - j], sd);
+            }
+            const double sck = sc4[k];          // C(4n, k): the convolution form's pre-scaling
+            num[k] = sck * sn;
+            den[k] = sck * sd;
+        }
+    }
+    // ---- phase B: elevate both by 4R and divide, 32 output columns at a time; chunk t belongs to wave t mod 4
+    const int L4R = L4 + 4 * q.R;
+    const ctab_t row4 = as_ctab(q.cv4) + L4;
+    for (int k0 = wave * kElevChunk; k0 < L4R; k0 += 4 * kElevChunk) {
+        const int kc = min(kElevChunk, L4R - k0);
+        for (int kb = 0; kb < kc; kb += kElevBlock) {
+            double sn[kElevBlock], sd[kElevBlock];
+            conv_block2<L4>(row4 + k0 + kb, num, den, sn, sd);
+#pragma unroll
+            for (int i = 0; i < kElevBlock; ++i) tile[lane * TP + kb + i] = p.w2 - sn[i] / sd[i];
+        }
+        wave_sync();
+        elev_store_chunk<L4>(tile, p.out, (size_t)it0 * L4R, L4R, k0, kc, n_valid, lane);
+        wave_sync();
     }
 }
 

@@ -304,112 +304,11 @@ __global__ __launch_bounds__(2 * kWave) void k_dynamics2(const AngParams p)
 // against the generic kernel's degree-4m convolutions.  A workgroup is four waves on the same 64 items; each
 // repeats phase A (8 % of its work) and takes every fourth 32-column chunk, transposed through a per-wave LDS tile
 // so that stores are 256-byte runs.
-#ifndef OBTG_DYN_ELEV_WAVES
-#define OBTG_DYN_ELEV_WAVES 2
-#endif
-struct AngElevParams {
-    AngParams a;
-    const double* __restrict__ cv4;  // scale[4n+1] = C(4n, j) | padded row C(4R, m) 2^-e, m = -(4n) .. 4R+4n+8
-    const double* __restrict__ cv2;  // scale[2n+1] = C(2n, j) | padded row C(R, m), m = -(2n) .. R+2n+8 | 1/C(2n+R, k) (+8)
-    int R;
-};
-
 template <int NC>
 __global__ __launch_bounds__(4 * kWave, (NC > 11 ? 1 : OBTG_DYN_ELEV_WAVES)) void k_dynamics_elev(const AngElevParams q)
 {
-    constexpr int N = NC - 1, L2 = 2 * N + 1, L4 = 4 * N + 1, TP = kElevChunk + 1;
-    const AngParams& p = q.a;
     extern __shared__ double lds[];
-    const int lane = threadIdx.x & (kWave - 1);
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform: table reads become scalar loads
-    double* tile = lds + wave * (kWave * TP);
-    const int it0 = blockIdx.x * kWave;
-    const int n_valid = min(kWave, p.total - it0);
-    const int item = min(it0 + lane, p.total - 1);
-    const int b = item / p.n_veh;
-    double num[L4], den[L4];
-    {   // ---- phase A: degree-4n numerator and denominator from the original control points (as k_dynamics2)
-        double x[NC], y[NC];
-        load_item_xy<NC>(p, item, b, x, y);
-        const double val = (double)N / p.tf[b];
-        double xD[NC], yD[NC], xDD[NC], yDD[NC];
-        diff_elev1<NC>(x, val, xD);
-        diff_elev1<NC>(y, val, yD);
-        diff_elev1<NC>(xD, val, xDD);
-        diff_elev1<NC>(yD, val, yDD);
-        const ctab_t Wn = as_ctab(p.Wn), W2n = as_ctab(p.W2n), W22n = as_ctab(p.W22n);
-        double num1[L2], den1[L2];
-#pragma unroll
-        for (int k = 0; k < L2; ++k) {
-            double s1 = 0.0, s2 = 0.0, sd = 0.0;
-#pragma unroll
-            for (int j = (k - N > 0 ? k - N : 0); j <= (N < k ? N : k); ++j) {
-                const double wkj = Wn[k * NC + j];
-                s1 = fma(wkj, yDD[j] * xD[k - j], s1);
-                s2 = fma(wkj, xDD[j] * yD[k - j], s2);
-            }
-#pragma unroll
-            for (int j = (k - N > 0 ? k - N : 0); 2 * j <= k; ++j)
-                sd = fma(W2n[k * NC + j], fma(xD[j], xD[k - j], yD[j] * yD[k - j]), sd);
-            num1[k] = s1 - s2;
-            den1[k] = sd;
-        }
-        // speed rows = elev(den1, R): this wave's share of their 32-column chunks, while den1 is still live
-        if (p.out_speed) {
-            const int L2R = L2 + q.R;
-            const ctab_t sc2 = as_ctab(q.cv2), row2 = sc2 + L2, inv2 = row2 + (q.R + 1 + 2 * (L2 - 1) + kElevBlock);
-            double dh[L2];
-#pragma unroll
-            for (int j = 0; j < L2; ++j) dh[j] = sc2[j] * den1[j];
-            for (int k0 = wave * kElevChunk; k0 < L2R; k0 += 4 * kElevChunk) {
-                const int kc = min(kElevChunk, L2R - k0);
-                // one pass per requested bound (the second one, obtg_ctx_set_second_speed_bound, repeats the chunk's
-                // convolution: the degree-2n curve is what the two share)
-                for (int which = 0; which < (p.out_speed2 ? 2 : 1); ++which) {
-                    const double sgn = which ? p.sp2_sign : p.sp_sign, off = which ? p.sp2_offset : p.sp_offset;
-                    for (int kb = 0; kb < kc; kb += kElevBlock) {
-                        double sa[kElevBlock];
-                        conv_block1<L2>(row2 + k0 + kb, dh, sa);
-#pragma unroll
-                        for (int i = 0; i < kElevBlock; ++i)
-                            tile[lane * TP + kb + i] = sgn * (sa[i] * inv2[k0 + kb + i]) + off;
-                    }
-                    wave_sync();
-                    elev_store_chunk<L2>(tile, which ? p.out_speed2 : p.out_speed, (size_t)it0 * L2R, L2R, k0, kc, n_valid, lane);
-                    wave_sync();
-                }
-            }
-        }
-        const ctab_t sc4 = as_ctab(q.cv4);
-#pragma unroll
-        for (int k = 0; k < L4; ++k) {
-            double sn = 0.0, sd = 0.0;
-#pragma unroll
-            for (int j = (k - 2 * N > 0 ? k - 2 * N : 0); 2 * j <= k; ++j) {
-                const double wkj = W22n[k * L2 + j];
-                sn = fma(wkj, num1[j] * num1[k - j], sn);
-                sd = fma(wkj, den1[j] * den1[k - j], sd);
-            }
-            const double sck = sc4[k];          // C(4n, k): the convolution form's pre-scaling
-            num[k] = sck * sn;
-            den[k] = sck * sd;
-        }
-    }
-    // ---- phase B: elevate both by 4R and divide, 32 output columns at a time; chunk t belongs to wave t mod 4
-    const int L4R = L4 + 4 * q.R;
-    const ctab_t row4 = as_ctab(q.cv4) + L4;
-    for (int k0 = wave * kElevChunk; k0 < L4R; k0 += 4 * kElevChunk) {
-        const int kc = min(kElevChunk, L4R - k0);
-        for (int kb = 0; kb < kc; kb += kElevBlock) {
-            double sn[kElevBlock], sd[kElevBlock];
-            conv_block2<L4>(row4 + k0 + kb, num, den, sn, sd);
-#pragma unroll
-            for (int i = 0; i < kElevBlock; ++i) tile[lane * TP + kb + i] = p.w2 - sn[i] / sd[i];
-        }
-        wave_sync();
-        elev_store_chunk<L4>(tile, p.out, (size_t)it0 * L4R, L4R, k0, kc, n_valid, lane);
-        wave_sync();
-    }
+    dynamics_elev_group<NC>(q, lds, (int)blockIdx.x);
 }
 
 // =====================================================================================

@@ -967,10 +967,15 @@ struct StructuredParams {
     int n_kind[4];                     // workgroups of each kind (S, F, G, D).  The grid interleaves them: of every 16 block ids,
     int per16[4];                      // per16[k] belong to kind k, in the order pat[] (host: shares by expected work), so that
     unsigned char pat[16], rank[16];   // streams (HBM bound) and state machines (latency bound) share the CUs all along
+    const double* cv4;                 // DEG_ELEV > 0: the dynamics groups' elevation tables (AngElevParams) and DEG_ELEV
+    const double* cv2;
+    int R;
 };
 
-template <int NC>
-__global__ __launch_bounds__(256, 4) void k_step_fd_structured(const StructuredParams sp)
+// ELEV: DEG_ELEV > 0 -- the separation groups are elevated (tsep_elev_group_stream), the fix-up rows too, and the
+// dynamics groups are k_dynamics_elev's (four waves, 234 VGPRs: the launch then runs two workgroups per CU).
+template <int NC, bool ELEV>
+__global__ __launch_bounds__(256, ELEV ? 2 : 4) void k_step_fd_structured(const StructuredParams sp)
 {
     extern __shared__ double2 xy_dyn[];
     constexpr int VPQ = PlanarShape<NC>::VPQ;
@@ -985,6 +990,12 @@ __global__ __launch_bounds__(256, 4) void k_step_fd_structured(const StructuredP
     const int id = grp * sp.per16[kind] + sp.rank[slot];
     if (id >= sp.n_kind[kind]) return;
     if (kind == 3) {
+        if (ELEV) {
+            AngElevParams q;
+            q.a = p.dyn; q.cv4 = sp.cv4; q.cv2 = sp.cv2; q.R = sp.R;
+            dynamics_elev_group<NC>(q, lds, id);
+            return;
+        }
         if (threadIdx.x >= 2 * kWave) return;
         dynamics2_group<NC, true>(p.dyn, lds, id);
         return;
@@ -997,7 +1008,10 @@ __global__ __launch_bounds__(256, 4) void k_step_fd_structured(const StructuredP
         gjk_planar_body<NC, 1, false>(q, xy_dyn, b, 0);
         __syncthreads();
         const int fd_e = fd_element(p.fd, p.fd_fixed, NC, b);
-        if (fd_e >= 0) tsep_rows_of_vehicle<NC>(p.ts, xy_dyn, VPQ, b, p.n_veh, fd_e / (2 * NC));
+        if (fd_e >= 0) {
+            if (ELEV) tsep_elev_rows_of_vehicle<NC>(p.ts, xy_dyn, VPQ, b, p.n_veh, fd_e / (2 * NC));
+            else tsep_rows_of_vehicle<NC>(p.ts, xy_dyn, VPQ, b, p.n_veh, fd_e / (2 * NC));
+        }
         return;
     }
     if (kind == 2) {
@@ -1054,6 +1068,12 @@ __global__ __launch_bounds__(256, 4) void k_step_fd_structured(const StructuredP
             lds[2 * (v * VPQ + k) + qd] = p.Y[e];
         }
         __syncthreads();
+        if (ELEV) {
+            double* chT = reinterpret_cast<double*>(xy_dyn + n_obj * VPQ);   // [64][L] scaled products | 4 output tiles of a pass
+            tsep_elev_group_stream<NC>(p.ts, xy_dyn, VPQ, g, chT, chT + kWave * L, r * sp.sep_rows_per,
+                                       min(p.B, (r + 1) * sp.sep_rows_per), p.fd, p.fd_fixed);
+            return;
+        }
         double* tile = reinterpret_cast<double*>(xy_dyn + n_obj * VPQ);     // [64][L]: the output run of the group
         __shared__ int s_nv;
         if (threadIdx.x < kWave) {
@@ -2997,20 +3017,23 @@ int launch_step_fd_structured(obtg_ctx* c, int B, double max_sep, double* d_out_
     if (!c->fd.Y0) return OBTG_ERR_ARG;
     const int nc = c->deg + 1;
     void (*kern)(const StructuredParams) = nullptr;
+    const bool elev = c->R > 0;
     switch (nc) {
-        case 4: kern = k_step_fd_structured<4>; break;
-        case 6: kern = k_step_fd_structured<6>; break;
-        case 8: kern = k_step_fd_structured<8>; break;
-        case 11: kern = k_step_fd_structured<11>; break;
+        case 4: kern = elev ? k_step_fd_structured<4, true> : k_step_fd_structured<4, false>; break;
+        case 6: kern = elev ? k_step_fd_structured<6, true> : k_step_fd_structured<6, false>; break;
+        case 8: kern = elev ? k_step_fd_structured<8, true> : k_step_fd_structured<8, false>; break;
+        case 11: kern = elev ? k_step_fd_structured<11, true> : k_step_fd_structured<11, false>; break;
         default: break;
     }
     const bool ok = kern && c->dim == 2 && c->polys_planar && c->max_poly_K <= nc && c->n_hull_pairs > 0 && !c->fd_dedup &&
-                    c->R == 0 && c->n_obs == 0 && c->n_pairs > 0 && speed && speed->d_out_ang && speed->d_out_speed &&
-                    speed->d_tf && d_out_sep && c->n_veh < 65536;
+                    c->n_obs == 0 && c->n_pairs > 0 && speed && speed->d_out_ang && speed->d_out_speed &&
+                    speed->d_tf && d_out_sep && c->n_veh < 65536 && 2 * c->deg + c->R + 1 <= 512;
     if (!ok) return OBTG_ERR_UNSUPPORTED;
     int rc = ensure_tables(c);
     if (rc) return rc;
     if (c->d_ang_w22n.p == nullptr) return OBTG_ERR_UNSUPPORTED;
+    if (elev && (c->ang_elevate_first || c->d_ang_T4.p == nullptr || c->d_ang_cv2.p == nullptr || c->d_Tt.p == nullptr))
+        return OBTG_ERR_UNSUPPORTED;
     StructuredParams sp{};
     GjkSwarmParams& p = sp.g;
     p.Y = c->fd.Y0; p.fd = 1; p.fd_fixed = c->fd.fixed; p.fd_h = c->fd.h;
@@ -3023,6 +3046,8 @@ int launch_step_fd_structured(obtg_ctx* c, int B, double max_sep, double* d_out_
     p.B = B; p.chunk = 256; p.wgs_per_row = 1; p.passes = 1;
     p.ts.pairs = c->d_pairs.as<int2>(); p.ts.W2 = c->d_w2.as<double>(); p.ts.out = d_out_sep;
     p.ts.n_pairs = c->n_pairs; p.ts.sign = 1.0; p.ts.offset = -(max_sep * max_sep);
+    p.ts.Tt = c->d_Tt.as<double>(); p.ts.R = c->R;
+    sp.cv4 = c->d_ang_T4.as<double>(); sp.cv2 = c->d_ang_cv2.as<double>(); sp.R = c->R;
     {
         AngParams& d = p.dyn;
         d.Y = p.Y; d.tf = speed->d_tf; d.out = speed->d_out_ang; d.out_speed = speed->d_out_speed;
@@ -3038,7 +3063,7 @@ int launch_step_fd_structured(obtg_ctx* c, int B, double max_sep, double* d_out_
         d.W2n = c->d_ang_w2n.as<double>(); d.W22n = c->d_ang_w22n.as<double>(); d.Wn = c->d_ang_wn.as<double>();
         d.fd = 1; d.fd_fixed = p.fd_fixed; d.fd_h = p.fd_h;
     }
-    const int n_obj = c->n_veh + c->n_poly, vpq = nc | 1, L = 2 * c->deg + 1;
+    const int n_obj = c->n_veh + c->n_poly, vpq = nc | 1, L = 2 * c->deg + 1, LR = L + c->R;
     // S: one workgroup per (64-pair group, row range); about two thousand workgroups of streams
     sp.n_sep_groups = (c->n_pairs + kWave - 1) / kWave;
     int s_ranges = std::max(1, std::min(B, 2048 / std::max(1, sp.n_sep_groups)));
@@ -3061,11 +3086,19 @@ int launch_step_fd_structured(obtg_ctx* c, int B, double max_sep, double* d_out_
     unsigned grid = 0;
     {
         // shares of every 16 block ids by expected work (workgroups x duration on the C3 timeline: S 12.5, F 15.2, G 20.2, D 10.7 us)
-        const double cost[4] = { 12.5, 15.2, 20.2, 10.7 };
+        const double cost_flat[4] = { 12.5, 15.2, 20.2, 10.7 }, cost_elev[4] = { 60.0, 34.0, 40.0, 102.0 };
+        const double* cost = elev ? cost_elev : cost_flat;     // (DEG_ELEV > 0: the streams are 2n+R+1 columns wide, the dynamics groups k_dynamics_elev's)
         double w[4], tot = 0.0;
         for (int k = 0; k < 4; ++k) { w[k] = sp.n_kind[k] * cost[k]; tot += w[k]; }
         int sum = 0;
         for (int k = 0; k < 4; ++k) { sp.per16[k] = sp.n_kind[k] > 0 ? std::max(1, (int)(16.0 * w[k] / tot + 0.5)) : 0; sum += sp.per16[k]; }
+        if (const char* e = getenv("OBTG_STRUCT_PER16")) {      // (experiments: "S,F,G,D" summing to 16)
+            int v[4] = { 0, 0, 0, 0 };
+            if (sscanf(e, "%d,%d,%d,%d", &v[0], &v[1], &v[2], &v[3]) == 4 && v[0] + v[1] + v[2] + v[3] == 16) {
+                for (int k = 0; k < 4; ++k) sp.per16[k] = v[k];
+                sum = 16;
+            }
+        }
         while (sum != 16) {             // give to / take from the kind with the largest share
             int kmax = 0;
             for (int k = 1; k < 4; ++k) if (sp.per16[k] > sp.per16[kmax]) kmax = k;
@@ -3086,12 +3119,21 @@ int launch_step_fd_structured(obtg_ctx* c, int B, double max_sep, double* d_out_
         grid = (unsigned)groups * 16u;
     }
     p.dyn_first_block = 0;
-    const size_t lds_s = (size_t)16 * n_obj * vpq + sizeof(double) * kWave * L;
+    size_t lds_s = (size_t)16 * n_obj * vpq + sizeof(double) * kWave * L;
+    size_t lds_d_elev = 0;
+    if (elev) {
+        int nb2 = 1;
+        while (nb2 < (LR + kElevBlock - 1) / kElevBlock) nb2 <<= 1;
+        lds_s += sizeof(double) * 4 * (size_t)(kWave / nb2) * nb2 * (kElevBlock + 1);      // four output tiles of a pass
+        lds_d_elev = sizeof(double) * 4 * kWave * (kElevChunk + 1);
+    }
     const size_t lds_g = (planar_lds_bytes<0>(n_obj, vpq, sp.gjk_chunk_pairs) + 15) / 16 * 16 + (size_t)sp.gjk_chunk_pairs * 68 + 16;
     const size_t lds_f = planar_lds_bytes<1>(n_obj, vpq, sp.fix_chunk);
     const size_t lds_d = sizeof(double) * ((size_t)kWave * (4 * c->deg + 1) + (size_t)(kWave / 2) * L);
-    const size_t lds = std::max(std::max(lds_s, lds_g), std::max(lds_f, lds_d));
-    if (lds > 40 * 1024) return OBTG_ERR_UNSUPPORTED;
+    const size_t lds = std::max(std::max(lds_s, lds_g), std::max(lds_f, elev ? lds_d_elev : lds_d));
+    if (lds > (elev ? 76 : 40) * (size_t)1024) return OBTG_ERR_UNSUPPORTED;
+    if (lds > 48 * 1024)
+        OBTG_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     TimelineDump tl(c, grid, p.timeline);
     if (tl.rc) return tl.rc;
     {
