@@ -27,5 +27,8 @@ echo "c5 done" >> $OUT/progress.log
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_structured -o run -- python3 tools/timeline_structured_run.py > $OUT/structured.log 2> $OUT/structured.err
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/write_structured -o run -- python3 tools/timeline_structured_run.py > $OUT/structured_w.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/fetch_structured -o run -- python3 tools/timeline_structured_run.py > $OUT/structured_f.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_structured_c5 -o run -- python3 tools/timeline_structured_run.py C5 > $OUT/structured_c5.log 2> $OUT/structured_c5.err
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/write_structured_c5 -o run -- python3 tools/timeline_structured_run.py C5 > $OUT/structured_c5_w.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/fetch_structured_c5 -o run -- python3 tools/timeline_structured_run.py C5 > $OUT/structured_c5_f.log 2>&1
 echo "structured done" >> $OUT/progress.log
 cat $OUT/progress.log

@@ -34,7 +34,8 @@ def main():
     dst = os.path.join(REPO, "profiles")
     for sub, name in (("stats", f"{tag}_kernel_stats.csv"), ("stats_dedup", f"{tag}_fd_dedup_kernel_stats.csv"),
                       ("stats_2s", f"{tag}_two_streams_kernel_stats.csv"), ("stats_c5", f"{tag}_C5_kernel_stats.csv"),
-                      ("stats_structured", f"{tag}_fd_structured_kernel_stats.csv")):
+                      ("stats_structured", f"{tag}_fd_structured_kernel_stats.csv"),
+                      ("stats_structured_c5", f"{tag}_C5_fd_structured_kernel_stats.csv")):
         hits = glob.glob(os.path.join(src, sub, "**", "*kernel_stats.csv"), recursive=True)
         if hits:
             shutil.copy(hits[0], os.path.join(dst, name))
@@ -44,7 +45,8 @@ def main():
             shutil.copy(os.path.join(src, a), os.path.join(dst, b))
     tpath = os.path.join(dst, "traffic.json")
     traffic = json.load(open(tpath)) if os.path.exists(tpath) else {}
-    for wl, suffix in ((workload, ""), ("C5", "_c5"), (workload + "_fd_structured", "_structured")):
+    for wl, suffix in ((workload, ""), ("C5", "_c5"), (workload + "_fd_structured", "_structured"),
+                       ("C5_fd_structured", "_structured_c5")):
         fetch = pmc_mean(os.path.join(src, "fetch" + suffix), "FETCH_SIZE")
         write = pmc_mean(os.path.join(src, "write" + suffix), "WRITE_SIZE")
         per, detail = {}, {}
