@@ -1,0 +1,49 @@
+"""C5 step: speed / angular rate (k_dynamics_elev, VALU bound at two workgroups per CU) on a second stream beside the pair
+sweeps (separation kernel HBM bound, gjkNew sweep VALU bound) against everything on one stream."""
+import sys, time
+sys.path.insert(0, ".")
+import numpy as np, torch
+from optimalbeziertrajectorygeneration_amd import _capi as capi, synth
+cfg = synth.CONFIGS["C5"]
+N, n, R = cfg["N"], cfg["n"], cfg["R"]
+Y = synth.swarm_control_points(N, 2, n, seed=1234)
+statics, pa, pb = synth.config_hull_sweep("C5")
+B = N * 2 * (n - 1) + 1
+s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+ctxs = []
+for st in (s1, s2):
+    c = capi.Context(N, 2, n, R)
+    c.set_stream(st.cuda_stream)
+    c.set_polygons(*synth.pack_polys(statics)); c.set_hull_pairs(pa, pb)
+    ctxs.append(c)
+a, b = ctxs
+d0 = torch.from_numpy(Y).cuda(); dtf = torch.full((B,), 10.0, dtype=torch.float64, device="cuda")
+P, L, Ps = a.num_pairs, 2 * n + R + 1, len(pa)
+f64 = torch.float64
+sep = torch.empty((B, P * L), dtype=f64, device="cuda"); sp = torch.empty((B, a.len_speed), dtype=f64, device="cuda")
+an = torch.empty((B, a.len_ang_rate), dtype=f64, device="cuda"); flag = torch.empty((B, Ps), dtype=torch.int32, device="cuda")
+p1 = torch.empty((B, Ps, 3), dtype=f64, device="cuda"); p2 = torch.empty((B, Ps, 3), dtype=f64, device="cuda")
+dist = torch.empty((B, Ps), dtype=f64, device="cuda"); st_ = torch.empty((B, Ps), dtype=torch.int32, device="cuda")
+torch.cuda.synchronize()
+
+def one_stream():
+    a.fd_view_begin(d0.data_ptr(), 1, synth.FD_STEP, B)
+    a.constraint_sweep_dev(None, dtf.data_ptr(), B, 0.9, sep.data_ptr(), 5.0, True, 1.0, sp.data_ptr(), an.data_ptr(), flag.data_ptr(),
+                           p1.data_ptr(), p2.data_ptr(), dist.data_ptr(), None, st_.data_ptr(), 128, 256)
+    a.fd_view_end()
+
+def two_streams():
+    a.fd_view_begin(d0.data_ptr(), 1, synth.FD_STEP, B); b.fd_view_begin(d0.data_ptr(), 1, synth.FD_STEP, B)
+    b.dynamics_dev(None, dtf.data_ptr(), B, 5.0, True, 1.0, sp.data_ptr(), an.data_ptr())
+    a.pair_sweep_dev(None, B, 0.9, sep.data_ptr(), flag.data_ptr(), p1.data_ptr(), p2.data_ptr(), dist.data_ptr(), None, st_.data_ptr(), 128, 256)
+    a.fd_view_end(); b.fd_view_end()
+
+for name, fn in (("one stream", one_stream), ("two streams", two_streams), ("one stream", one_stream), ("two streams", two_streams)):
+    for _ in range(150):
+        fn()
+    torch.cuda.synchronize()
+    t = time.perf_counter()
+    for _ in range(100):
+        fn()
+    torch.cuda.synchronize()
+    print("%-12s %.4f ms per step" % (name, (time.perf_counter() - t) * 10))
