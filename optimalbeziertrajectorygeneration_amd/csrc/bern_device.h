@@ -879,12 +879,99 @@ __device__ __forceinline__ void diff_elev1(const double (&p)[NC], double val, do
     for (int c = 1; c < N; ++c) d[c] = t[c - 1] * ((double)c / (double)N) + t[c] * ((double)(N - c) / (double)N);
 }
 
+// Which items a dynamics group evaluates and where its rows go (the structured finite-difference step, gjk_kernels.hip
+// k_step_fd_structured: all but one vehicle of row b >= 1 repeat row 0's rows when tf[b] is tf[0]).
+//   mode 0: items [item_begin + 64 group, item_end), rows written where the items are (the plain launch);
+//   mode 1: item t of the group is (row t + 1, the vehicle that row advances), t < item_end; its rows go to that item's
+//           place -- unless tf[t + 1] differs from tf[0] (the whole row is then a mode-0 group of its own);
+//   mode 2: the group of ROW 0's vehicles, its rows copied into every row of [b0, b1) whose tf is tf[0], leaving out the
+//           vehicle that row advances.  b1 - b0 <= 64.
+// s_map: 64 ints of LDS, filled by dyn_emit_prepare.
+struct DynEmit {
+    int mode, item_begin, item_end, b0, b1;
+    int* s_map;
+};
+
+__device__ __forceinline__ bool same_bits(double a, double b) { return __double_as_longlong(a) == __double_as_longlong(b); }
+
+// item of this lane, first item and valid count of the group (mode 1: "first item" is unused)
+template <int NC>
+__device__ __forceinline__ int dyn_item_of_lane(const AngParams& p, const DynEmit* em, int group, int lane, int& it0, int& n_valid)
+{
+    if (!em) {
+        it0 = group * kWave;
+        n_valid = min(kWave, p.total - it0);
+        return min(it0 + lane, p.total - 1);
+    }
+    if (em->mode == 1) {
+        it0 = 0;
+        n_valid = min(kWave, em->item_end - group * kWave);
+        const int b = min(group * kWave + lane, em->item_end - 1) + 1;
+        return b * p.n_veh + max(fd_element(p.fd, p.fd_fixed, NC, b), 0) / (2 * NC);
+    }
+    it0 = em->item_begin + group * kWave;
+    n_valid = min(kWave, em->item_end - it0);
+    return min(it0 + lane, em->item_end - 1);
+}
+
+// the first wave fills s_map; a barrier (or, for the same wave, wave_sync) must follow before dyn_emit_* reads it
+template <int NC>
+__device__ __forceinline__ void dyn_emit_prepare(const AngParams& p, const DynEmit& em, int item, int it0, int n_valid, int lane)
+{
+    if (em.mode == 1) {
+        const int b = item / p.n_veh;
+        em.s_map[lane] = (lane < n_valid && same_bits(p.tf[b], p.tf[0])) ? item : -1;
+    } else if (em.mode == 2) {
+        const int b = em.b0 + lane;
+        if (b < em.b1) {
+            int m = -2;
+            if (same_bits(p.tf[b], p.tf[0])) {
+                const int fd_e = fd_element(p.fd, p.fd_fixed, NC, b);
+                const int local = fd_e >= 0 ? fd_e / (2 * NC) - it0 : -1;
+                m = (local >= 0 && local < n_valid) ? local : -1;
+            }
+            em.s_map[lane] = m;
+        }
+    }
+}
+
+// rows tile[r * pitch + q], r < n_valid, q < ncol  ->  columns k0 .. k0+ncol of the rows of length LROW that em names
+__device__ __forceinline__ void dyn_emit_rows(const double* __restrict__ tile, int pitch, int ncol, double* __restrict__ out,
+                                              int LROW, int k0, const AngParams& p, const DynEmit& em, int it0, int n_valid,
+                                              int tid, int nthr)
+{
+    const int total = n_valid * ncol;
+    if (em.mode == 1) {
+        for (int e = tid; e < total; e += nthr) {
+            const int r = e / ncol, q = e - r * ncol, it = em.s_map[r];
+            if (it >= 0) store_nt(out + (size_t)it * LROW + k0 + q, tile[r * pitch + q]);
+        }
+        return;
+    }
+    // the map of the range lives in one register per lane (entry j in lane j): the loop over rows reads it with
+    // v_readlane, no memory access between the stores
+    const int nb = em.b1 - em.b0;
+    const int lane = tid & (kWave - 1);
+    const int mreg = lane < nb ? em.s_map[lane] : -2;
+    const size_t row_stride = (size_t)p.n_veh * LROW;
+    for (int e = tid; e < total; e += nthr) {
+        const int r = e / ncol, q = e - r * ncol;
+        const double v = tile[r * pitch + q];
+        double* o = out + ((size_t)em.b0 * p.n_veh + it0 + r) * LROW + k0 + q;
+        for (int j = 0; j < nb; ++j, o += row_stride) {
+            const int m = __builtin_amdgcn_readlane(mreg, j);
+            if (m == -2) continue;
+            if (m != r) store_nt(o, v);
+        }
+    }
+}
+
 // Two waves (threads 0..127 of the workgroup) on the 64 items of `group`; the other waves of a larger workgroup must
 // have returned before the call (the barriers below count the surviving waves).  k_dynamics2 is this on its own grid;
 // the pair sweep runs it in workgroups of its own grid (gjk_kernels.hip k_pair_sweep<NC, true>).
 // HALF_SP: the speed rows leave through a 32-row tile in two halves (5.4 KB less LDS: the form the pair sweep's grid runs)
 template <int NC, bool HALF_SP = false>
-__device__ __forceinline__ void dynamics2_group(const AngParams& p, double* lds, const int group)
+__device__ __forceinline__ void dynamics2_group(const AngParams& p, double* lds, const int group, const DynEmit* em = nullptr)
 {
     constexpr int N = NC - 1, L2 = 2 * N + 1, L4 = 4 * N + 1;
     constexpr int KS = (L4 * 5) / 8;           // wave 0 divides k < KS, wave 1 the rest (wave 1 has the dearer products)
@@ -892,10 +979,11 @@ __device__ __forceinline__ void dynamics2_group(const AngParams& p, double* lds,
     double* tile_sp = lds + kWave * L4;        // [kWave][L2]: speed rows (wave 0)
     const int lane = threadIdx.x & (kWave - 1);
     const int role = threadIdx.x >> 6;         // wave-uniform
-    const int it0 = group * kWave;
-    const int n_valid = min(kWave, p.total - it0);
-    const int item = min(it0 + lane, p.total - 1);
+    int it0, n_valid;
+    const int item = dyn_item_of_lane<NC>(p, em, group, lane, it0, n_valid);
     const int b = item / p.n_veh;
+    const bool mapped = em && em->mode != 0;   // (the 64-row speed tile only: the structured step's form)
+    if (mapped && role == 0) dyn_emit_prepare<NC>(p, *em, item, it0, n_valid, lane);
     double x[NC], y[NC];
     load_item_xy<NC>(p, item, b, x, y);
     const double val = (double)N / p.tf[b];
@@ -922,7 +1010,8 @@ __device__ __forceinline__ void dynamics2_group(const AngParams& p, double* lds,
 #pragma unroll
                 for (int k = 0; k < L2; ++k) tile_sp[lane * L2 + k] = sgn * q1[k] + off;
                 wave_sync();
-                flush_full<L2, L2>(tile_sp, dst, (size_t)it0 * L2, n_valid, lane);
+                if (mapped) dyn_emit_rows(tile_sp, L2, L2, dst, L2, 0, p, *em, it0, n_valid, lane, kWave);
+                else flush_full<L2, L2>(tile_sp, dst, (size_t)it0 * L2, n_valid, lane);
             } else {
                 for (int h0 = 0; h0 < n_valid; h0 += kWave / 2) {
                     if (lane >= h0 && lane < h0 + kWave / 2) {
@@ -987,6 +1076,10 @@ __device__ __forceinline__ void dynamics2_group(const AngParams& p, double* lds,
         for (int k = KS; k < L4; ++k) tile[lane * L4 + k] = q[k];
     }
     __syncthreads();
+    if (mapped) {
+        dyn_emit_rows(tile, L4, L4, p.out, L4, 0, p, *em, it0, n_valid, (int)threadIdx.x, 2 * kWave);
+        return;
+    }
     // rows of consecutive items are contiguous in the output: one linear copy by both waves
     const size_t grow = (size_t)it0 * L4;
     const int total = n_valid * L4;
@@ -1011,17 +1104,21 @@ struct AngElevParams {
 };
 
 template <int NC>
-__device__ __forceinline__ void dynamics_elev_group(const AngElevParams& q, double* lds, const int group)
+__device__ __forceinline__ void dynamics_elev_group(const AngElevParams& q, double* lds, const int group, const DynEmit* em = nullptr)
 {
     constexpr int N = NC - 1, L2 = 2 * N + 1, L4 = 4 * N + 1, TP = kElevChunk + 1;
     const AngParams& p = q.a;
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform: table reads become scalar loads
     double* tile = lds + wave * (kWave * TP);
-    const int it0 = group * kWave;
-    const int n_valid = min(kWave, p.total - it0);
-    const int item = min(it0 + lane, p.total - 1);
+    int it0, n_valid;
+    const int item = dyn_item_of_lane<NC>(p, em, group, lane, it0, n_valid);
     const int b = item / p.n_veh;
+    const bool mapped = em && em->mode != 0;
+    if (mapped) {
+        if (wave == 0) dyn_emit_prepare<NC>(p, *em, item, it0, n_valid, lane);
+        __syncthreads();
+    }
     double num[L4], den[L4];
     {   // ---- phase A: degree-4n numerator and denominator from the original control points (as k_dynamics2)
         double x[NC], y[NC];
@@ -1070,7 +1167,8 @@ __device__ __forceinline__ void dynamics_elev_group(const AngElevParams& q, doub
                             tile[lane * TP + kb + i] = sgn * (sa[i] * inv2[k0 + kb + i]) + off;
                     }
                     wave_sync();
-                    elev_store_chunk<L2>(tile, which ? p.out_speed2 : p.out_speed, (size_t)it0 * L2R, L2R, k0, kc, n_valid, lane);
+                    if (mapped) dyn_emit_rows(tile, TP, kc, which ? p.out_speed2 : p.out_speed, L2R, k0, p, *em, it0, n_valid, lane, kWave);
+                    else elev_store_chunk<L2>(tile, which ? p.out_speed2 : p.out_speed, (size_t)it0 * L2R, L2R, k0, kc, n_valid, lane);
                     wave_sync();
                 }
             }
@@ -1102,7 +1200,8 @@ __device__ __forceinline__ void dynamics_elev_group(const AngElevParams& q, doub
             for (int i = 0; i < kElevBlock; ++i) tile[lane * TP + kb + i] = p.w2 - sn[i] / sd[i];
         }
         wave_sync();
-        elev_store_chunk<L4>(tile, p.out, (size_t)it0 * L4R, L4R, k0, kc, n_valid, lane);
+        if (mapped) dyn_emit_rows(tile, TP, kc, p.out, L4R, k0, p, *em, it0, n_valid, lane, kWave);
+        else elev_store_chunk<L4>(tile, p.out, (size_t)it0 * L4R, L4R, k0, kc, n_valid, lane);
         wave_sync();
     }
 }

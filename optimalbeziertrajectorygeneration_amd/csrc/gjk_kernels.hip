@@ -955,7 +955,9 @@ void k_pair_sweep(const GjkSwarmParams p)
 //       points / distance / status (/ scan count) into every row of its range, with the same exception;
 //    F  (row b >= 1): stages row b, evaluates exactly the pairs the streams left out -- the hull pairs of its vehicle
 //       (the de-duplication pass of the plain sweep, its mask computed from b) and that vehicle's separation rows;
-//    D  the speed / angular-rate groups of the whole batch, as in k_pair_sweep (36 MB of a 611 MB step: not worth a stream).
+//    D  the speed / angular-rate rows, by the same rule per vehicle: row 0's 64-vehicle groups streamed into row ranges,
+//       the advanced vehicle of every row b >= 1 (64 of them to a group), and -- tf is an input per row -- every row whose
+//       tf is not bit for bit tf[0] in full (bern_device.h DynEmit).
 //  Every output element is written exactly once, by the workgroup kind that owns it: the result equals the brute-force
 //  sweep's bit for bit (same device functions per pair), the launch is bound by its 611 MB of stores.
 // -------------------------------------------------------------------------------------
@@ -970,6 +972,7 @@ struct StructuredParams {
     const double* cv4;                 // DEG_ELEV > 0: the dynamics groups' elevation tables (AngElevParams) and DEG_ELEV
     const double* cv2;
     int R;
+    int dyn_groups_per_row, dyn_rows_per, dyn_streams, dyn_fix_groups;   // D: see the kernel
 };
 
 // ELEV: DEG_ELEV > 0 -- the separation groups are elevated (tsep_elev_group_stream), the fix-up rows too, and the
@@ -985,19 +988,47 @@ __global__ __launch_bounds__(256, ELEV ? 2 : 4) void k_step_fd_structured(const 
     const int n_obj = p.n_veh + p.n_poly;
     double* lds = reinterpret_cast<double*>(xy_dyn);
     // kind (0 S, 1 F, 2 G, 3 D) and index inside the kind from the block id
-    const int grp = (int)blockIdx.x >> 4, slot = (int)blockIdx.x & 15;
+    // (block id mod 8 is the XCD: the pattern is rotated by one slot per group of 16, or every XCD would see one or two
+    // kinds only and the XCD with the dearest kind would finish last)
+    const int grp = (int)blockIdx.x >> 4, slot = ((int)blockIdx.x + grp) & 15;
     const int kind = sp.pat[slot];
     const int id = grp * sp.per16[kind] + sp.rank[slot];
     if (id >= sp.n_kind[kind]) return;
     if (kind == 3) {
-        if (ELEV) {
-            AngElevParams q;
-            q.a = p.dyn; q.cv4 = sp.cv4; q.cv2 = sp.cv2; q.R = sp.R;
-            dynamics_elev_group<NC>(q, lds, id);
+        // ---- D: row 0's vehicle groups streamed into row ranges | the advanced vehicles, 64 rows to a group | rows whose
+        //      tf is not tf[0] (a finite-difference row of tf itself), eight rows to a workgroup, in full
+        __shared__ int s_dmap[kWave];
+        if (!ELEV && threadIdx.x >= 2 * kWave) return;      // (dynamics2_group's barriers count the surviving waves)
+        const int gd = sp.dyn_groups_per_row;
+        DynEmit em{ 0, 0, 0, 0, 0, s_dmap };
+        auto run = [&](int group) {
+            if (ELEV) {
+                AngElevParams q;
+                q.a = p.dyn; q.cv4 = sp.cv4; q.cv2 = sp.cv2; q.R = sp.R;
+                dynamics_elev_group<NC>(q, lds, group, &em);
+            } else {
+                dynamics2_group<NC, false>(p.dyn, lds, group, &em);
+            }
+        };
+        if (id < sp.dyn_streams) {
+            const int r = id / gd;
+            em.mode = 2; em.item_begin = 0; em.item_end = p.n_veh;
+            em.b0 = r * sp.dyn_rows_per; em.b1 = min(p.B, em.b0 + sp.dyn_rows_per);
+            run(id - r * gd);
             return;
         }
-        if (threadIdx.x >= 2 * kWave) return;
-        dynamics2_group<NC, true>(p.dyn, lds, id);
+        if (id < sp.dyn_streams + sp.dyn_fix_groups) {
+            em.mode = 1; em.item_end = p.B - 1;
+            run(id - sp.dyn_streams);
+            return;
+        }
+        const int x = id - sp.dyn_streams - sp.dyn_fix_groups, xr = x / gd, gv = x - xr * gd;
+        for (int b = 1 + 8 * xr; b < min(p.B, 9 + 8 * xr); ++b) {
+            if (same_bits(p.dyn.tf[b], p.dyn.tf[0])) continue;
+            em.mode = 0; em.item_begin = b * p.n_veh; em.item_end = em.item_begin + p.n_veh;
+            __syncthreads();                                 // the tile of the previous row has been read out
+            run(gv);
+        }
         return;
     }
     if (kind == 1) {
@@ -3082,14 +3113,28 @@ int launch_step_fd_structured(obtg_ctx* c, int B, double max_sep, double* d_out_
     sp.n_kind[0] = sp.n_sep_groups * s_ranges;
     sp.n_kind[1] = B - 1;
     sp.n_kind[2] = sp.gjk_chunks * g_ranges;
-    sp.n_kind[3] = (p.dyn.total + kWave - 1) / kWave;
+    // D: ~256 streams of row 0's groups (at most 64 rows each, at least 4 when there are that many: at C5 a stream of 19
+    // rows keeps its workgroup for 430 us of a 650 us launch, one of 5 rows for 190), the advanced vehicles 64 to a
+    // group, and one workgroup per 8 rows that looks for rows with their own tf
+    sp.dyn_groups_per_row = (c->n_veh + kWave - 1) / kWave;
+    sp.dyn_rows_per = std::min(64, std::max((B + 255) / 256, std::min(4, B)));
+    if (const char* e = getenv("OBTG_STRUCT_DYN_ROWS")) sp.dyn_rows_per = std::max(1, std::min(64, atoi(e)));
+    sp.dyn_streams = sp.dyn_groups_per_row * ((B + sp.dyn_rows_per - 1) / sp.dyn_rows_per);
+    sp.dyn_fix_groups = (B - 1 + kWave - 1) / kWave;
+    const int dyn_x = sp.dyn_groups_per_row * ((B - 1 + 7) / 8);
+    sp.n_kind[3] = sp.dyn_streams + sp.dyn_fix_groups + dyn_x;
     unsigned grid = 0;
     {
         // shares of every 16 block ids by expected work (workgroups x duration on the C3 timeline: S 12.5, F 15.2, G 20.2, D 10.7 us)
-        const double cost_flat[4] = { 12.5, 15.2, 20.2, 10.7 }, cost_elev[4] = { 60.0, 34.0, 40.0, 102.0 };
+        // (what decides is where each kind's ids run out: the kinds should end at about the same block id, so the D
+        // weights are those of its neighbours, not its 190 us streams: 7:3:3:3 instead of 7:4:4:1 costs C5 10 %)
+        const double cost_flat[4] = { 12.5, 15.2, 20.2, 16.0 }, cost_elev[4] = { 40.0, 36.0, 38.0, 40.0 };
         const double* cost = elev ? cost_elev : cost_flat;     // (DEG_ELEV > 0: the streams are 2n+R+1 columns wide, the dynamics groups k_dynamics_elev's)
         double w[4], tot = 0.0;
         for (int k = 0; k < 4; ++k) { w[k] = sp.n_kind[k] * cost[k]; tot += w[k]; }
+        tot -= w[3];
+        w[3] = (sp.dyn_streams + sp.dyn_fix_groups) * cost[3];      // (the workgroups that look for rows with their own tf come last and cost nothing)
+        tot += w[3];
         int sum = 0;
         for (int k = 0; k < 4; ++k) { sp.per16[k] = sp.n_kind[k] > 0 ? std::max(1, (int)(16.0 * w[k] / tot + 0.5)) : 0; sum += sp.per16[k]; }
         if (const char* e = getenv("OBTG_STRUCT_PER16")) {      // (experiments: "S,F,G,D" summing to 16)
@@ -3129,7 +3174,7 @@ int launch_step_fd_structured(obtg_ctx* c, int B, double max_sep, double* d_out_
     }
     const size_t lds_g = (planar_lds_bytes<0>(n_obj, vpq, sp.gjk_chunk_pairs) + 15) / 16 * 16 + (size_t)sp.gjk_chunk_pairs * 68 + 16;
     const size_t lds_f = planar_lds_bytes<1>(n_obj, vpq, sp.fix_chunk);
-    const size_t lds_d = sizeof(double) * ((size_t)kWave * (4 * c->deg + 1) + (size_t)(kWave / 2) * L);
+    const size_t lds_d = sizeof(double) * ((size_t)kWave * (4 * c->deg + 1) + (size_t)kWave * L);
     const size_t lds = std::max(std::max(lds_s, lds_g), std::max(lds_f, elev ? lds_d_elev : lds_d));
     if (lds > (elev ? 76 : 40) * (size_t)1024) return OBTG_ERR_UNSUPPORTED;
     if (lds > 48 * 1024)

@@ -1401,12 +1401,15 @@ def test_both_speed_bounds_from_one_pass(capi, synth, oracle, shape):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("shape", ["C3_full_batch", "deg7_two_fixed", "three_vehicles", "deg5_no_polys", "elevated_R6", "C5_like_R100", "one_row", "two_rows_elevated"])
-def test_structured_fd_step_is_bit_identical_to_the_brute_force_sweep(capi, synth, shape):
+@pytest.mark.parametrize("tf_rows", ["one_tf", "a_few_rows_with_their_own_tf", "every_row_its_own_tf"])
+def test_structured_fd_step_is_bit_identical_to_the_brute_force_sweep(capi, synth, shape, tf_rows):
     """obtg_constraint_sweep_fd_structured_dev: the finite-difference step as ONE launch that evaluates row 0 in full and
     per perturbed row only what its vehicle touches, against the brute-force one-launch sweep of the same view
     (obtg_constraint_sweep_dev, itself oracle-pinned at these shapes): every output array equal bit for bit, at C3 with
     the full SLSQP batch B = n_x + 1 = 1153, with two fixed columns per end, with an odd row length (3 vehicles) and
-    without polygons; with the second speed bound on."""
+    without polygons; with the second speed bound on.  tf: the same for every row (what a finite-difference batch over
+    control points has: the speed / angular-rate rows of row 0 are then streamed), different in a few rows (one of them by
+    one ulp: the comparison is on bits), different in every row."""
     import torch
     N, n, M, fixed, R = {"C3_full_batch": (64, 10, 8, 1, 0), "deg7_two_fixed": (20, 7, 2, 2, 0), "three_vehicles": (3, 10, 1, 1, 0),
                          "deg5_no_polys": (12, 5, 0, 1, 0), "elevated_R6": (9, 10, 3, 1, 6), "C5_like_R100": (64, 10, 32, 1, 100),
@@ -1426,7 +1429,16 @@ def test_structured_fd_step_is_bit_identical_to_the_brute_force_sweep(capi, synt
     B = {"one_row": 1, "two_rows_elevated": 2}.get(shape, B)
     h = synth.FD_STEP if shape == "C3_full_batch" else 1e-3
     d0 = torch.from_numpy(Y).cuda()
-    dtf = torch.from_numpy(np.linspace(3.0, 9.0, B)).cuda()
+    tf = np.linspace(3.0, 9.0, B)
+    if tf_rows != "every_row_its_own_tf":
+        tf[:] = 6.5
+    if tf_rows == "a_few_rows_with_their_own_tf":
+        for k in (1, 2, 9, 64, 65, 700, B - 1):
+            if 0 < k < B:
+                tf[k] = 6.5 + 1e-3 * k
+        if B > 12:
+            tf[11] = np.nextafter(6.5, 7.0)       # one ulp off is its own tf
+    dtf = torch.from_numpy(tf).cuda()
     P, L, Ps = ctx.num_pairs, 2 * n + R + 1, len(pa)
 
     def bufs():
@@ -1455,7 +1467,7 @@ def test_structured_fd_step_is_bit_identical_to_the_brute_force_sweep(capi, synt
     ctx.set_second_speed_bound(0.0, False, None)
     assert ks == {"pair_sweep": 1}, ks                                     # ONE launch
     for key in a:
-        assert torch.equal(a[key].view(torch.uint8), b[key].view(torch.uint8)), (shape, key)
+        assert torch.equal(a[key].view(torch.uint8), b[key].view(torch.uint8)), (shape, tf_rows, key)
     ctx.set_stream(0)
     ctx.close()
 

@@ -7,7 +7,7 @@ print(" ".join(hdr))
 pat = np.array([int(ch) for ch in hdr[hdr.index("pat") + 1]])
 d = np.loadtxt(path, dtype=np.int64, ndmin=2)
 blk, t0, t1 = d[:, 0], d[:, 1] * 0.01, d[:, 2] * 0.01
-kind = pat[blk & 15]
+kind = pat[(blk + (blk >> 4)) & 15]      # the pattern is rotated by one slot per group of 16 (XCD balance)
 live = (t1 - t0) > 0.5                      # blocks beyond their kind's count return at once
 print("span %.1f us" % t1.max())
 for k, name in enumerate("SFGD"):
