@@ -977,8 +977,10 @@ struct StructuredParams {
 
 // ELEV: DEG_ELEV > 0 -- the separation groups are elevated (tsep_elev_group_stream), the fix-up rows too, and the
 // dynamics groups are k_dynamics_elev's (four waves, 234 VGPRs: the launch then runs two workgroups per CU).
-template <int NC, bool ELEV>
-__global__ __launch_bounds__(256, ELEV ? 2 : 4) void k_step_fd_structured(const StructuredParams sp)
+// WPC: workgroups per CU the register budget is set for (4: rows of up to 40 KB of LDS; 1: large rows -- C4's 256 vehicles
+// of 16 points are 70 KB -- where LDS leaves room for one workgroup anyway and the streams dominate).
+template <int NC, bool ELEV, int WPC = (ELEV ? 2 : 4)>
+__global__ __launch_bounds__(256, WPC) void k_step_fd_structured(const StructuredParams sp)
 {
     extern __shared__ double2 xy_dyn[];
     constexpr int VPQ = PlanarShape<NC>::VPQ;
@@ -1105,7 +1107,9 @@ __global__ __launch_bounds__(256, ELEV ? 2 : 4) void k_step_fd_structured(const 
                                        min(p.B, (r + 1) * sp.sep_rows_per), p.fd, p.fd_fixed);
             return;
         }
-        double* tile = reinterpret_cast<double*>(xy_dyn + n_obj * VPQ);     // [64][L]: the output run of the group
+        // [64][L]: the output run of the group.  It takes the place of the staged row: only the first wave reads that,
+        // and has read it by the time it writes the tile (one wave's LDS accesses complete in order)
+        double* tile = lds;
         __shared__ int s_nv;
         if (threadIdx.x < kWave) {
             const int nv = tsep_group_to_tile<NC>(p.ts, xy_dyn, VPQ, g, tile);
@@ -3048,12 +3052,19 @@ int launch_step_fd_structured(obtg_ctx* c, int B, double max_sep, double* d_out_
     if (!c->fd.Y0) return OBTG_ERR_ARG;
     const int nc = c->deg + 1;
     void (*kern)(const StructuredParams) = nullptr;
+    void (*kern_mid)(const StructuredParams) = nullptr;      // two workgroups per CU: rows beyond 40 KB of LDS (C4: 79 KB)
+    void (*kern_big)(const StructuredParams) = nullptr;      // one: beyond 80 KB
     const bool elev = c->R > 0;
     switch (nc) {
         case 4: kern = elev ? k_step_fd_structured<4, true> : k_step_fd_structured<4, false>; break;
         case 6: kern = elev ? k_step_fd_structured<6, true> : k_step_fd_structured<6, false>; break;
         case 8: kern = elev ? k_step_fd_structured<8, true> : k_step_fd_structured<8, false>; break;
-        case 11: kern = elev ? k_step_fd_structured<11, true> : k_step_fd_structured<11, false>; break;
+        case 11: kern = elev ? k_step_fd_structured<11, true> : k_step_fd_structured<11, false>;
+                 if (!elev) { kern_mid = k_step_fd_structured<11, false, 2>; kern_big = k_step_fd_structured<11, false, 1>; }
+                 break;
+        case 16: if (!elev) { kern = k_step_fd_structured<16, false>; kern_mid = k_step_fd_structured<16, false, 2>;
+                              kern_big = k_step_fd_structured<16, false, 1>; }
+                 break;
         default: break;
     }
     const bool ok = kern && c->dim == 2 && c->polys_planar && c->max_poly_K <= nc && c->n_hull_pairs > 0 && !c->fd_dedup &&
@@ -3097,15 +3108,19 @@ int launch_step_fd_structured(obtg_ctx* c, int B, double max_sep, double* d_out_
     const int n_obj = c->n_veh + c->n_poly, vpq = nc | 1, L = 2 * c->deg + 1, LR = L + c->R;
     // S: one workgroup per (64-pair group, row range); about two thousand workgroups of streams
     sp.n_sep_groups = (c->n_pairs + kWave - 1) / kWave;
-    int s_ranges = std::max(1, std::min(B, 2048 / std::max(1, sp.n_sep_groups)));
+    // (a large step -- C4: 58 GB of separation rows -- gets more, so that a stream stays near 4 MB)
+    const double sep_stream_bytes = 8.0 * kWave * LR * (double)B * sp.n_sep_groups;
+    const int s_target = (int)std::min(32768.0, std::max(2048.0, sep_stream_bytes / (4 << 20)));
+    int s_ranges = std::max(1, std::min(B, s_target / std::max(1, sp.n_sep_groups)));
     sp.sep_rows_per = (B + s_ranges - 1) / s_ranges;
     s_ranges = (B + sp.sep_rows_per - 1) / sp.sep_rows_per;
     // G: chunks of ~80 hull pairs (one short gjkNew phase per workgroup), row ranges for ~512 workgroups
-    sp.gjk_chunk_pairs = 80;
+    sp.gjk_chunk_pairs = 16 * (size_t)n_obj * vpq > 40 * 1024 ? 64 : 80;       // (large rows: the chunk's results behind 70 KB of hulls stay under 80 KB)
     if (const char* e = getenv("OBTG_STRUCT_GJK_CHUNK")) sp.gjk_chunk_pairs = std::max(16, atoi(e));
     static const int g_target = getenv("OBTG_STRUCT_GJK_WGS") ? std::max(1, atoi(getenv("OBTG_STRUCT_GJK_WGS"))) : 1024;
     sp.gjk_chunks = (c->n_hull_pairs + sp.gjk_chunk_pairs - 1) / sp.gjk_chunk_pairs;
-    int g_ranges = std::max(1, std::min(B, g_target / std::max(1, sp.gjk_chunks)));
+    const int g_target_b = (int)std::min(32768.0, std::max((double)g_target, 68.0 * c->n_hull_pairs * (double)B / (4 << 20)));
+    int g_ranges = std::max(1, std::min(B, g_target_b / std::max(1, sp.gjk_chunks)));
     sp.gjk_rows_per = (B + g_ranges - 1) / g_ranges;
     g_ranges = (B + sp.gjk_rows_per - 1) / sp.gjk_rows_per;
     sp.fix_chunk = 256;
@@ -3164,7 +3179,8 @@ int launch_step_fd_structured(obtg_ctx* c, int B, double max_sep, double* d_out_
         grid = (unsigned)groups * 16u;
     }
     p.dyn_first_block = 0;
-    size_t lds_s = (size_t)16 * n_obj * vpq + sizeof(double) * kWave * L;
+    size_t lds_s = elev ? (size_t)16 * n_obj * vpq + sizeof(double) * kWave * L
+                        : std::max((size_t)16 * n_obj * vpq, sizeof(double) * kWave * L);      // (flat: the tile overlays the staged row)
     size_t lds_d_elev = 0;
     if (elev) {
         int nb2 = 1;
@@ -3176,7 +3192,12 @@ int launch_step_fd_structured(obtg_ctx* c, int B, double max_sep, double* d_out_
     const size_t lds_f = planar_lds_bytes<1>(n_obj, vpq, sp.fix_chunk);
     const size_t lds_d = sizeof(double) * ((size_t)kWave * (4 * c->deg + 1) + (size_t)kWave * L);
     const size_t lds = std::max(std::max(lds_s, lds_g), std::max(lds_f, elev ? lds_d_elev : lds_d));
-    if (lds > (elev ? 76 : 40) * (size_t)1024) return OBTG_ERR_UNSUPPORTED;
+    if (lds > (elev ? 76 : 40) * (size_t)1024) {
+        const size_t with_static = lds + 1536;               // (the kernel's own __shared__ variables)
+        if (kern_mid && with_static <= 80 * (size_t)1024) kern = kern_mid;
+        else if (kern_big && with_static <= 158 * (size_t)1024) kern = kern_big;
+        else return OBTG_ERR_UNSUPPORTED;
+    }
     if (lds > 48 * 1024)
         OBTG_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     TimelineDump tl(c, grid, p.timeline);

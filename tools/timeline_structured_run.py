@@ -19,7 +19,7 @@ an = torch.empty((B, ctx.len_ang_rate), dtype=f64, device="cuda"); flag = torch.
 p1 = torch.empty((B, Ps, 3), dtype=f64, device="cuda"); p2 = torch.empty((B, Ps, 3), dtype=f64, device="cuda")
 dist = torch.empty((B, Ps), dtype=f64, device="cuda"); st = torch.empty((B, Ps), dtype=torch.int32, device="cuda")
 import time
-for i in range(600 if WL == "C3" else 500):  # (the timeline, when asked for, is taken at launch OBTG_TIMELINE_AT)
+for i in range({"C3": 600, "C5": 500}.get(WL, 40)):  # (the timeline, when asked for, is taken at launch OBTG_TIMELINE_AT)
     ctx.constraint_sweep_fd_structured_dev(d0.data_ptr(), 1, synth.FD_STEP, dtf.data_ptr(), B, 0.9, sep.data_ptr(), 5.0, True, 1.0,
                                            sp.data_ptr(), an.data_ptr(), flag.data_ptr(), p1.data_ptr(), p2.data_ptr(), dist.data_ptr(), None, st.data_ptr(), 128, 256)
 torch.cuda.synchronize()
