@@ -31,4 +31,10 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_structured_c5
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/write_structured_c5 -o run -- python3 tools/timeline_structured_run.py C5 > $OUT/structured_c5_w.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/fetch_structured_c5 -o run -- python3 tools/timeline_structured_run.py C5 > $OUT/structured_c5_f.log 2>&1
 echo "structured done" >> $OUT/progress.log
+# C4 (256 vehicles, degree 15, B = 7169): the brute-force one-launch step and the structured step, stats + traffic
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_c4 -o run -- python3 bench.py --no-cpu --no-variants --workload C4 --steps 10 --warmup 2 > $OUT/bench_stats_c4.json 2> $OUT/stats_c4.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_structured_c4 -o run -- python3 tools/timeline_structured_run.py C4 > $OUT/structured_c4.log 2> $OUT/structured_c4.err
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/write_structured_c4 -o run -- python3 tools/timeline_structured_run.py C4 > $OUT/structured_c4_w.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/fetch_structured_c4 -o run -- python3 tools/timeline_structured_run.py C4 > $OUT/structured_c4_f.log 2>&1
+echo "c4 done" >> $OUT/progress.log
 cat $OUT/progress.log

@@ -35,18 +35,21 @@ def main():
     for sub, name in (("stats", f"{tag}_kernel_stats.csv"), ("stats_dedup", f"{tag}_fd_dedup_kernel_stats.csv"),
                       ("stats_2s", f"{tag}_two_streams_kernel_stats.csv"), ("stats_c5", f"{tag}_C5_kernel_stats.csv"),
                       ("stats_structured", f"{tag}_fd_structured_kernel_stats.csv"),
-                      ("stats_structured_c5", f"{tag}_C5_fd_structured_kernel_stats.csv")):
+                      ("stats_structured_c5", f"{tag}_C5_fd_structured_kernel_stats.csv"),
+                      ("stats_c4", f"{tag}_C4_kernel_stats.csv"),
+                      ("stats_structured_c4", f"{tag}_C4_fd_structured_kernel_stats.csv")):
         hits = glob.glob(os.path.join(src, sub, "**", "*kernel_stats.csv"), recursive=True)
         if hits:
             shutil.copy(hits[0], os.path.join(dst, name))
     for a, b in (("bench_stats.json", f"{tag}_bench.json"), ("bench_default.json", f"{tag}_bench_with_cpu_baseline.json"),
-                 ("bench_stats_2s.json", f"{tag}_two_streams_bench.json"), ("bench_stats_c5.json", f"{tag}_C5_bench.json")):
+                 ("bench_stats_2s.json", f"{tag}_two_streams_bench.json"), ("bench_stats_c5.json", f"{tag}_C5_bench.json"),
+                 ("bench_stats_c4.json", f"{tag}_C4_bench.json")):
         if os.path.exists(os.path.join(src, a)):
             shutil.copy(os.path.join(src, a), os.path.join(dst, b))
     tpath = os.path.join(dst, "traffic.json")
     traffic = json.load(open(tpath)) if os.path.exists(tpath) else {}
     for wl, suffix in ((workload, ""), ("C5", "_c5"), (workload + "_fd_structured", "_structured"),
-                       ("C5_fd_structured", "_structured_c5")):
+                       ("C5_fd_structured", "_structured_c5"), ("C4_fd_structured", "_structured_c4")):
         fetch = pmc_mean(os.path.join(src, "fetch" + suffix), "FETCH_SIZE")
         write = pmc_mean(os.path.join(src, "write" + suffix), "WRITE_SIZE")
         per, detail = {}, {}
