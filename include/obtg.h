@@ -265,8 +265,10 @@ int obtg_constraint_sweep_dev(obtg_ctx*, const double* dY, const double* d_tf, i
  * bit for bit (the same device functions evaluate every pair); the launch is bound by its stores instead of by gjkNew.
  * Planar shapes (deg + 1 in {4, 6, 8, 11}, no point obstacles, angular rate wanted, a row's objects within 40 KB of LDS), any
  * DEG_ELEV with 2 deg + DEG_ELEV + 1 <= 512 -- for DEG_ELEV > 0 (where the brute-force step is three launches) the separation
- * streams are the elevated rows and the dynamics groups are the elevated kernel's: OBTG_ERR_UNSUPPORTED otherwise -- the
- * brute-force call gives the same numbers.  A different evaluation strategy from
+ * streams are the elevated rows and the dynamics groups are the elevated kernel's; at DEG_ELEV = 0 also deg + 1 = 16 and, for
+ * deg + 1 in {11, 16}, rows of up to 158 KB (256 vehicles of degree 15 are 70 KB: two workgroups per CU):
+ * OBTG_ERR_UNSUPPORTED otherwise -- the brute-force call gives the same numbers.  d_tf is read per row: the speed /
+ * angular-rate rows of row 0 are copied only into rows whose tf equals tf[0] bit for bit, any other row is evaluated in full.  A different evaluation strategy from
  * "every row in full": bench.py reports it as variants.fd_structured, never as its headline value. */
 int obtg_constraint_sweep_fd_structured_dev(obtg_ctx*, const double* dY0, int n_fixed_cols, double h, const double* d_tf,
                                             int B, double max_sep, double* d_out_sep, double speed_bound, int speed_is_max,
