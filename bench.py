@@ -250,6 +250,8 @@ def main():
     max_sep, vmax, wmax, tfv = 0.9, 5.0, 1.0, 10.0
 
     ctx = _capi.Context(N, d, n, R, device=local_rank)
+    # torch's current stream; the default stream's handle is 0 = "the context's own (non-blocking) stream" to the library:
+    # every hand-over between torch's work and the library's below is a torch.cuda.synchronize()
     stream = torch.cuda.current_stream()
     ctx.set_stream(stream.cuda_stream)
     if use_gjk:

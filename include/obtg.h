@@ -94,7 +94,9 @@ int obtg_host_free(void* p);
 int obtg_ctx_create(obtg_ctx** out, int n_veh, int dim, int deg, int deg_elev,
                     int n_point_obs, const double* point_obs, int device);
 void obtg_ctx_destroy(obtg_ctx*);
-/* use an external HIP stream (e.g. torch's current stream) for every later call; NULL = own stream */
+/* use an external HIP stream (e.g. torch's current stream) for every later call; NULL = the context's own stream, which
+ * is created non-blocking: NOT ordered with the null stream.  A caller whose own work runs on the null stream (torch's
+ * default stream has handle 0) passes hipStreamLegacy, (void*)1, to have the library's launches ordered with it. */
 int obtg_ctx_set_stream(obtg_ctx*, void* hip_stream);
 /* DEG_ELEV is a module constant read at call time (optimization.py:17): allow changing it */
 int obtg_ctx_set_deg_elev(obtg_ctx*, int deg_elev);

@@ -242,6 +242,14 @@ def pinned_empty(shape, dtype=np.float64):
     return _pinned.empty(shape, dtype)
 
 
+def torch_stream():
+    """HIP handle of torch's current stream, for Context.set_stream.  torch's DEFAULT stream is the legacy null stream,
+    whose handle is 0 -- which obtg_ctx_set_stream reads as "the context's own stream"; hipStreamLegacy (1) names the null
+    stream itself, so that the library's launches are ordered with torch's kernels (fills, copies) on it."""
+    import torch
+    return torch.cuda.current_stream().cuda_stream or 1
+
+
 class Context(object):
     """One problem shape on one MI355X: wraps obtg_ctx."""
 
@@ -289,6 +297,8 @@ class Context(object):
         return self._h
 
     def set_stream(self, stream_ptr):
+        """Every later call goes to this HIP stream; 0 / None = the context's own stream (non-blocking: NOT ordered with
+        the null stream).  For torch's current stream pass torch_stream()."""
         self._check(self._lib.obtg_ctx_set_stream(self._h, _vp(stream_ptr)), "obtg_ctx_set_stream")
 
     def set_deg_elev(self, R):

@@ -27,7 +27,7 @@ def test_pair_partitioned_sweeps_with_hip_evaluators(oracle):
     polys = synth.polygon_obstacles(M, seed=5)
     pa, pb = synth.swarm_pairs(N, M)
     ctx = _capi.Context(N, d, n, 0)
-    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    ctx.set_stream((torch.cuda.current_stream().cuda_stream or 1))
     ctx.set_polygons(*synth.pack_polys(polys))
     dY = torch.from_numpy(Yb).cuda()
     P, L = ctx.num_pairs, 2 * n + 1

@@ -152,7 +152,9 @@ def test_device_pointer_path_and_pair_partition(capi, oracle, synth):
     B = 9
     Yb = synth.fd_batch(Y, B=B)
     ctx = capi.Context(N, dim, n, R)
-    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    # (torch's default stream has handle 0, which the library reads as "my own stream": 1 = hipStreamLegacy names the
+    # null stream itself, so that the launches below are ordered with torch's fills and copies; _capi.torch_stream())
+    ctx.set_stream((torch.cuda.current_stream().cuda_stream or 1))
     dY = torch.from_numpy(Yb).cuda()
     P, L = ctx.num_pairs, 2 * n + R + 1
     full = torch.empty((B, P * L), dtype=torch.float64, device="cuda")
@@ -343,7 +345,7 @@ def test_c3_full_batch_properties(capi, synth):
     N, dim, n = 64, 2, 10
     Y = synth.swarm_control_points(N, dim, n, seed=1234)
     ctx = capi.Context(N, dim, n, 0)
-    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    ctx.set_stream((torch.cuda.current_stream().cuda_stream or 1))
     B = N * dim * (n - 1) + 1
     d0 = torch.from_numpy(Y).cuda()
     dY = torch.empty((B,) + Y.shape, dtype=torch.float64, device="cuda")
@@ -381,7 +383,7 @@ def test_fused_dynamics_matches_separate_calls(capi, oracle, synth):
         Yb = synth.fd_batch(Y, B=B)
         tf = np.linspace(1.5, 8.0, B)
         ctx = capi.Context(N, 2, n, R)
-        ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+        ctx.set_stream((torch.cuda.current_stream().cuda_stream or 1))
         dY = torch.from_numpy(Yb).cuda()
         dtf = torch.from_numpy(tf).cuda()
         osp = torch.empty((B, ctx.len_speed), dtype=torch.float64, device="cuda")
@@ -437,7 +439,7 @@ def test_pair_partition_large_swarm(capi, synth):
     Y = synth.swarm_control_points(N, 2, n, seed=2)
     Yb = synth.fd_batch(Y, B=3)
     ctx = capi.Context(N, 2, n, 0)
-    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    ctx.set_stream((torch.cuda.current_stream().cuda_stream or 1))
     dY = torch.from_numpy(Yb).cuda()
     P, L = ctx.num_pairs, 21
     full = torch.empty((3, P, L), dtype=torch.float64, device="cuda")
@@ -671,7 +673,7 @@ def test_pair_sweep_one_launch_equals_separate_kernels(capi, synth, shape):
         ctx.set_polygons(*synth.pack_polys(synth.polygon_obstacles(M, seed=8)))
     ctx.set_hull_pairs(pa, pb)
     dev = torch.device("cuda")
-    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    ctx.set_stream((torch.cuda.current_stream().cuda_stream or 1))
     dY = torch.from_numpy(Yb).to(dev)
     P, L, Ps = ctx.num_pairs, 2 * n + 1, len(pa)
 
@@ -791,7 +793,7 @@ def test_pair_sweep_random_shapes(capi, synth):
             polys = [p_[:min(len(p_), n + 1)] for p_ in polys]   # the planar kernel wants <= n+1 vertices
             ctx.set_polygons(*synth.pack_polys(polys))
         ctx.set_hull_pairs(pa, pb)
-        ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+        ctx.set_stream((torch.cuda.current_stream().cuda_stream or 1))
         dY = torch.from_numpy(Yb).to(dev)
         P, L, Ps = ctx.num_pairs, 2 * n + 1, len(pa)
 
@@ -894,7 +896,7 @@ def test_c5_hull_sweep_with_curve_obstacles(capi, oracle, synth, golden_dir):
         for key in ("dist", "c1", "c2"):
             assert np.max(np.abs(r[key][b][sp] - o[key][sp]) / np.maximum(1.0, np.abs(o[key][sp]))) < 1e-12
     # device-pointer form (what bench.py --workload C5 times), second call = history-ordered schedule
-    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    ctx.set_stream((torch.cuda.current_stream().cuda_stream or 1))
     dY = torch.from_numpy(Yb).cuda()
     Ps = len(pa)
     t_flag = torch.empty((B, Ps), dtype=torch.int32, device="cuda")
@@ -956,7 +958,7 @@ def test_pair_sweep_at_bench_shape_vs_oracle(capi, oracle, synth):
     statics, pa, pb = synth.config_hull_sweep("C3", seed=1234)
     B = N * d * (n - 1) + 1
     ctx = capi.Context(N, d, n, 0)
-    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    ctx.set_stream((torch.cuda.current_stream().cuda_stream or 1))
     ctx.set_polygons(*synth.pack_polys(statics))
     ctx.set_hull_pairs(pa, pb)
     d0 = torch.from_numpy(Y).cuda()
@@ -1095,7 +1097,7 @@ def test_ang_rate_with_elevation_both_orders(capi, oracle, synth, golden_dir):
         B = 7
         Yb = synth.fd_batch(Y, B=B)
         tfs = np.linspace(2.0, 9.0, B)
-        ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+        ctx.set_stream((torch.cuda.current_stream().cuda_stream or 1))
         dY, dtf = torch.from_numpy(Yb).cuda(), torch.from_numpy(tfs).cuda()
         osp = torch.empty((B, ctx.len_speed), dtype=torch.float64, device="cuda")
         oan = torch.empty((B, ctx.len_ang_rate), dtype=torch.float64, device="cuda")
@@ -1134,7 +1136,7 @@ def test_fd_forms_equal_the_materialised_batch(capi, synth, shape):
     pa, pb = synth.swarm_pairs(N, M)
     B = N * d * (n + 1 - 2 * fixed) + 1 if shape != "C3" else 300
     ctx = capi.Context(N, d, n, R)
-    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    ctx.set_stream((torch.cuda.current_stream().cuda_stream or 1))
     ctx.set_polygons(*(synth.pack_polys(polys) if M else (None, [0])))
     ctx.set_hull_pairs(pa, pb)
     on_fly = ctx.fd_forms_on_the_fly()
@@ -1287,7 +1289,7 @@ def test_constraint_sweep_equals_separate_calls(capi, synth, shape):
     polys = synth.polygon_obstacles(M, seed=21)
     pa, pb = synth.swarm_pairs(N, M)
     ctx = capi.Context(N, 2, n, R)
-    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    ctx.set_stream((torch.cuda.current_stream().cuda_stream or 1))
     ctx.set_polygons(*(synth.pack_polys(polys) if M else (None, [0])))
     ctx.set_hull_pairs(pa, pb)
     h = 1e-3
@@ -1348,7 +1350,7 @@ def test_both_speed_bounds_from_one_pass(capi, synth, oracle, shape):
                         "space3d": (7, 3, 5, 0, 0, 6), "generic": (5, 2, 12, 2, 0, 4)}[shape]
     Y = synth.fd_batch(synth.swarm_control_points(N, d, n, seed=33), B=B, h=1e-3)
     ctx = capi.Context(N, d, n, R)
-    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    ctx.set_stream((torch.cuda.current_stream().cuda_stream or 1))
     dY = torch.from_numpy(Y).cuda()
     dtf = torch.from_numpy(np.linspace(3.0, 9.0, B)).cuda()
     vmin, vmax, wmax = 0.7, 4.0, 1.5
@@ -1418,7 +1420,7 @@ def test_structured_fd_step_is_bit_identical_to_the_brute_force_sweep(capi, synt
     Y = synth.swarm_control_points(N, 2, n, seed=41)
     B = N * 2 * (n + 1 - 2 * fixed) + 1
     ctx = capi.Context(N, 2, n, R)
-    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    ctx.set_stream((torch.cuda.current_stream().cuda_stream or 1))
     if shape == "C5_like_R100":           # BASELINE configs[4]: 32 curve obstacles as static hulls, every pair of the 96 objects
         statics, pa, pb = synth.config_hull_sweep("C5", seed=41)
         ctx.set_polygons(*synth.pack_polys(statics))
@@ -1514,7 +1516,7 @@ def test_3d_sweep_as_one_launch_equals_separate_calls(capi, synth, N, n, M, B):
     polys = [rng.uniform(0, 100, size=(1, 3)) + rng.normal(0, 6.0, size=(int(rng.integers(3, n + 2)), 3)) for _ in range(M)]
     pa, pb = synth.swarm_pairs(N, M)
     ctx = capi.Context(N, 3, n, 0)
-    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    ctx.set_stream((torch.cuda.current_stream().cuda_stream or 1))
     if M:
         ctx.set_polygons(*synth.pack_polys(polys))
     ctx.set_hull_pairs(pa, pb)

@@ -34,7 +34,7 @@ def main():
         if M:
             ctx.set_polygons(*synth.pack_polys(polys))
         ctx.set_hull_pairs(pa, pb)
-        ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+        ctx.set_stream((torch.cuda.current_stream().cuda_stream or 1))
         dY = torch.from_numpy(Yb).to(dev)
         P, L, Ps = ctx.num_pairs, 2 * n + 1, len(pa)
 
