@@ -3110,7 +3110,8 @@ int launch_step_fd_structured(obtg_ctx* c, int B, double max_sep, double* d_out_
     sp.n_sep_groups = (c->n_pairs + kWave - 1) / kWave;
     // (a large step -- C4: 58 GB of separation rows -- gets more, so that a stream stays near 4 MB)
     const double sep_stream_bytes = 8.0 * kWave * LR * (double)B * sp.n_sep_groups;
-    const int s_target = (int)std::min(32768.0, std::max(2048.0, sep_stream_bytes / (4 << 20)));
+    int s_target = (int)std::min(32768.0, std::max(2048.0, sep_stream_bytes / (4 << 20)));
+    if (const char* e = getenv("OBTG_STRUCT_SEP_WGS")) s_target = std::max(1, atoi(e));      // (experiments)
     int s_ranges = std::max(1, std::min(B, s_target / std::max(1, sp.n_sep_groups)));
     sp.sep_rows_per = (B + s_ranges - 1) / s_ranges;
     s_ranges = (B + sp.sep_rows_per - 1) / sp.sep_rows_per;
