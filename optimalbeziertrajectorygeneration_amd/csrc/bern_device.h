@@ -601,6 +601,13 @@ __device__ __forceinline__ void tsep_tile_from_xy(const TsepXYParams& t, const d
     }
 }
 
+// per-wave LDS of the elevated full-row form: the scaled products of HALF a 64-item group (the lanes keep theirs in
+// registers and hand them over 32 rows at a time) and the 64 x 9 output tile of a pass.  32 instead of 64 rows: 10 instead of
+// 15 KB per wave, three workgroups of four waves per CU instead of two at C5 (measured: the same 0.52 ms -- the kernel is
+// bound by its 968-byte rows' write rate, not by occupancy; kept for the LDS it leaves to others)
+constexpr int kElevHalfRows = 32;
+__host__ __device__ constexpr int ns_elev_tile_doubles(int L) { return kElevHalfRows * L + kWave * (kElevBlock + 1); }
+
 // (b, w) = evaluation row and workgroup index inside the row; lds = the workgroup's dynamic LDS.
 // A device function so that the pair sweep can run it next to the GJK workgroups in ONE launch
 // (gjk_kernels.hip k_pair_sweep); k_normsq_elev below is the stand-alone kernel.
@@ -617,7 +624,7 @@ __device__ __forceinline__ void normsq_elev_body(const NsParams& p, const int b,
 
     // LDS: [staged objects: stage_slots * VP][per-wave transposition tiles]
     double* vl = lds;
-    double* tile = lds + p.stage_slots * S::VP + wave * (ELEV ? kWave * (S::L + kElevBlock + 1) : p.tile_rows * S::TPF);
+    double* tile = lds + p.stage_slots * S::VP + wave * (ELEV ? ns_elev_tile_doubles(S::L) : p.tile_rows * S::TPF);
 
     // ---- stage the objects this workgroup touches
     const double* Yrow = p.fd ? p.Y : p.Y + (size_t)b * p.n_veh * S::VLEN;
@@ -772,7 +779,7 @@ __device__ __forceinline__ void normsq_elev_body(const NsParams& p, const int b,
                 while (nb2 < nblk && nb2 < kWave) nb2 <<= 1;
                 const int rpp = kWave / nb2;                       // rows per pass
                 const int cb = lane & (nb2 - 1), rs = lane / nb2;
-                double* chT = tile;                                // [64][L]
+                double* chT = tile;                                // [kElevHalfRows][L]
                 // output tile of a pass: row q, column block c, column i of the block at q * opitch + c * 9 + i -- the
                 // pitch of 9 doubles per 8-column block keeps the 16 lanes of a row on 16 different bank pairs (at
                 // pitch 8 they fall on 4: PMC showed 60 % of the LDS cycles of this loop as bank conflicts).
@@ -780,13 +787,8 @@ __device__ __forceinline__ void normsq_elev_body(const NsParams& p, const int b,
                 // store instructions share lines and the L2 has to merge them -- with non-temporal stores the same loop
                 // ran 0.65 instead of 0.55 ms at C5 (2.26 GB of output per launch).
                 constexpr int BP = kElevBlock + 1;
-                double* otile = tile + kWave * L;                  // [rpp][nb2 * 9]
+                double* otile = tile + kElevHalfRows * L;          // [rpp][nb2 * 9]
                 const int opitch = nb2 * BP;
-                if (mine) {
-#pragma unroll
-                    for (int j = 0; j < L; ++j) chT[r * L + j] = cf[j] * escale[j];
-                }
-                wave_sync();
                 for (int cg = 0; cg < nblk; cg += nb2) {            // column groups (one unless LR > 512)
                     const int blk = cg + cb;
                     const bool colv = blk < nblk;
@@ -796,9 +798,16 @@ __device__ __forceinline__ void normsq_elev_body(const NsParams& p, const int b,
 #pragma unroll
                     for (int i = 0; i < kElevBlock; ++i) inv8[i] = colv ? einv_g[blk * kElevBlock + i] : 0.0;
                     const int c_lo = cg * kElevBlock, c_n = min(LR - c_lo, nb2 * kElevBlock);   // columns of this group
-                    for (int r0 = 0; r0 < n_valid; r0 += rpp) {
+                    for (int hb = 0; hb < n_valid; hb += kElevHalfRows) {   // the group's rows, half a wave at a time
+                    const int nh = min(kElevHalfRows, n_valid - hb);
+                    if (mine && r >= hb && r < hb + kElevHalfRows) {
+#pragma unroll
+                        for (int j = 0; j < L; ++j) chT[(r - hb) * L + j] = cf[j] * escale[j];
+                    }
+                    wave_sync();
+                    for (int r0 = 0; r0 < nh; r0 += rpp) {
                         const int rr = r0 + rs;
-                        if (rr < n_valid && colv) {
+                        if (rr < nh && colv) {
                             double ch[L], sa[kElevBlock];
 #pragma unroll
                             for (int j = 0; j < L; ++j) ch[j] = chT[rr * L + j];
@@ -808,12 +817,13 @@ __device__ __forceinline__ void normsq_elev_body(const NsParams& p, const int b,
                             for (int i = 0; i < kElevBlock; ++i) o[i] = p.sign * (sa[i] * inv8[i]) + p.offset;
                         }
                         wave_sync();
-                        const int rows = min(rpp, n_valid - r0);
+                        const int rows = min(rpp, nh - r0);
                         for (int q = 0; q < rows; ++q) {            // each row: a run of c_n doubles, 512 bytes per store instruction
-                            double* g = p.out + (row + r0 + q) * LR + c_lo;
+                            double* g = p.out + (row + hb + r0 + q) * LR + c_lo;
                             for (int kc = lane; kc < c_n; kc += kWave) g[kc] = otile[q * opitch + (kc >> 3) * BP + (kc & 7)];
                         }
                         wave_sync();
+                    }
                     }
                 }
             }

@@ -829,7 +829,7 @@ static int launch_ns_t(obtg_ctx* c, NsParams p, int B, int kernel_id)
     const size_t stage = (size_t)p.stage_slots * S::VP * sizeof(double);
     size_t lds = 0;
     if (MINONLY) { p.tile_rows = 0; lds = stage; }
-    else if (p.R > 0) { p.tile_rows = kWave; lds = stage + (size_t)p.waves * kWave * (S::L + kElevBlock + 1) * sizeof(double); }
+    else if (p.R > 0) { p.tile_rows = kWave; lds = stage + (size_t)p.waves * ns_elev_tile_doubles(S::L) * sizeof(double); }
     else {
         for (int tr = kWave; tr >= 16; tr >>= 1) {
             p.tile_rows = tr;
