@@ -977,24 +977,72 @@ __device__ __forceinline__ void dyn_emit_rows(const double* __restrict__ tile, i
     }
 }
 
+// The second half of dynamics2_group for a wave that holds the coefficients K0 <= k < K1 of its side's degree-4n square:
+// square, hand the other role its share through the exchange tile (row `trow` of the item), divide, leave the quotients
+// in the tile.  Role 0 (denominator side) divides k < KS, role 1 (numerator side, the dearer products) the rest.  Three
+// workgroup barriers, the same number for every (K0, K1): waves of one workgroup may run different instances.
+template <int NC, int K0, int K1>
+__device__ __forceinline__ void dyn2_tail(const int role, const double w2, const ctab_t W22n, const double (&q1)[2 * (NC - 1) + 1],
+                                          double* trow)
+{
+    constexpr int N = NC - 1, L2 = 2 * N + 1, KS = K0 + ((K1 - K0) * 5) / 8;
+    double sq[K1 - K0];
+#pragma unroll
+    for (int k = K0; k < K1; ++k) {
+        double s = 0.0;
+#pragma unroll
+        for (int j = (k - 2 * N > 0 ? k - 2 * N : 0); 2 * j <= k; ++j) s = fma(W22n[k * L2 + j], q1[j] * q1[k - j], s);
+        sq[k - K0] = s;
+    }
+    if (role == 0) {
+#pragma unroll
+        for (int k = KS; k < K1; ++k) trow[k] = sq[k - K0];
+    } else {
+#pragma unroll
+        for (int k = K0; k < KS; ++k) trow[k] = sq[k - K0];
+    }
+    __syncthreads();
+    // constraint = w^2 - num.cpts / den.cpts (optimization.py:608), each wave its share of k
+    double q[K1 - K0];
+    if (role == 0) {
+#pragma unroll
+        for (int k = K0; k < KS; ++k) q[k - K0] = w2 - trow[k] / sq[k - K0];
+    } else {
+#pragma unroll
+        for (int k = KS; k < K1; ++k) q[k - K0] = w2 - sq[k - K0] / trow[k];
+    }
+    __syncthreads();
+    if (role == 0) {
+#pragma unroll
+        for (int k = K0; k < KS; ++k) trow[k] = q[k - K0];
+    } else {
+#pragma unroll
+        for (int k = KS; k < K1; ++k) trow[k] = q[k - K0];
+    }
+    __syncthreads();
+}
+
 // Two waves (threads 0..127 of the workgroup) on the 64 items of `group`; the other waves of a larger workgroup must
-// have returned before the call (the barriers below count the surviving waves).  k_dynamics2 is this on its own grid;
-// the pair sweep runs it in workgroups of its own grid (gjk_kernels.hip k_pair_sweep<NC, true>).
+// have returned before the call (the barriers below count the surviving waves).  k_dynamics2 is this on its own grid.
+// W4: FOUR waves on the group (the pair sweeps' grids, whose workgroups have four): wave = (role, half) -- the two roles
+// as before, each wave squaring only its half of the degree-4n coefficients (k < KH or k >= KH) and dividing its share of
+// that half; every element by the same operations as the two-wave form, so the bits are the same.
 // HALF_SP: the speed rows leave through a 32-row tile in two halves (5.4 KB less LDS: the form the pair sweep's grid runs)
-template <int NC, bool HALF_SP = false>
+template <int NC, bool HALF_SP = false, bool W4 = false>
 __device__ __forceinline__ void dynamics2_group(const AngParams& p, double* lds, const int group, const DynEmit* em = nullptr)
 {
     constexpr int N = NC - 1, L2 = 2 * N + 1, L4 = 4 * N + 1;
-    constexpr int KS = (L4 * 5) / 8;           // wave 0 divides k < KS, wave 1 the rest (wave 1 has the dearer products)
+    constexpr int KH = W4 ? (L4 + 1) / 2 : L4;                  // first coefficient of the second half
     double* tile = lds;                        // [kWave][L4]: exchange, then the output rows
     double* tile_sp = lds + kWave * L4;        // [kWave][L2]: speed rows (wave 0)
     const int lane = threadIdx.x & (kWave - 1);
-    const int role = threadIdx.x >> 6;         // wave-uniform
+    const int wave = threadIdx.x >> 6;         // wave-uniform
+    const int role = wave & 1, half = W4 ? wave >> 1 : 0;
     int it0, n_valid;
     const int item = dyn_item_of_lane<NC>(p, em, group, lane, it0, n_valid);
     const int b = item / p.n_veh;
     const bool mapped = em && em->mode != 0;   // (the 64-row speed tile only: the structured step's form)
-    if (mapped && role == 0) dyn_emit_prepare<NC>(p, *em, item, it0, n_valid, lane);
+    if (mapped && wave == 0) dyn_emit_prepare<NC>(p, *em, item, it0, n_valid, lane);
     double x[NC], y[NC];
     load_item_xy<NC>(p, item, b, x, y);
     const double val = (double)N / p.tf[b];
@@ -1002,7 +1050,7 @@ __device__ __forceinline__ void dynamics2_group(const AngParams& p, double* lds,
     diff_elev1<NC>(x, val, xD);
     diff_elev1<NC>(y, val, yD);
     const ctab_t W22n = as_ctab(p.W22n);
-    double q1[L2];                             // den1 (wave 0) or num1 (wave 1), degree 2n
+    double q1[L2];                             // den1 (role 0) or num1 (role 1), degree 2n
     if (role == 0) {
         const ctab_t W2n = as_ctab(p.W2n);
 #pragma unroll
@@ -1013,7 +1061,7 @@ __device__ __forceinline__ void dynamics2_group(const AngParams& p, double* lds,
                 sd = fma(W2n[k * NC + j], fma(xD[j], xD[k - j], yD[j] * yD[k - j]), sd);
             q1[k] = sd;
         }
-        for (int which = 0; which < (p.out_speed ? (p.out_speed2 ? 2 : 1) : 0); ++which) {
+        for (int which = 0; which < ((p.out_speed && wave == 0) ? (p.out_speed2 ? 2 : 1) : 0); ++which) {
             double* const dst = which ? p.out_speed2 : p.out_speed;
             const double sgn = which ? p.sp2_sign : p.sp_sign, off = which ? p.sp2_offset : p.sp_offset;
             if (which) wave_sync();
@@ -1052,51 +1100,22 @@ __device__ __forceinline__ void dynamics2_group(const AngParams& p, double* lds,
             q1[k] = s1 - s2;
         }
     }
-    // the square (degree 4n) of either side: one copy of the code for both waves
-    double sq[L4];
-#pragma unroll
-    for (int k = 0; k < L4; ++k) {
-        double s = 0.0;
-#pragma unroll
-        for (int j = (k - 2 * N > 0 ? k - 2 * N : 0); 2 * j <= k; ++j) s = fma(W22n[k * L2 + j], q1[j] * q1[k - j], s);
-        sq[k] = s;
-    }
-    if (role == 0) {
-#pragma unroll
-        for (int k = KS; k < L4; ++k) tile[lane * L4 + k] = sq[k];
-    } else {
-#pragma unroll
-        for (int k = 0; k < KS; ++k) tile[lane * L4 + k] = sq[k];
-    }
-    __syncthreads();
-    // constraint = w^2 - num.cpts / den.cpts (optimization.py:608), each wave its share of k
-    double q[L4];
-    if (role == 0) {
-#pragma unroll
-        for (int k = 0; k < KS; ++k) q[k] = p.w2 - tile[lane * L4 + k] / sq[k];
-    } else {
-#pragma unroll
-        for (int k = KS; k < L4; ++k) q[k] = p.w2 - sq[k] / tile[lane * L4 + k];
-    }
-    __syncthreads();
-    if (role == 0) {
-#pragma unroll
-        for (int k = 0; k < KS; ++k) tile[lane * L4 + k] = q[k];
-    } else {
-#pragma unroll
-        for (int k = KS; k < L4; ++k) tile[lane * L4 + k] = q[k];
-    }
-    __syncthreads();
+    // the square (degree 4n) of either side, this wave's coefficients; then the quotient through the exchange tile
+    // (the coefficient range is a template argument: register arrays want constant indices)
+    if (!W4) dyn2_tail<NC, 0, L4>(role, p.w2, W22n, q1, tile + lane * L4);
+    else if (half == 0) dyn2_tail<NC, 0, KH>(role, p.w2, W22n, q1, tile + lane * L4);
+    else dyn2_tail<NC, (W4 ? KH : 0), L4>(role, p.w2, W22n, q1, tile + lane * L4);
+    constexpr int NT = (W4 ? 4 : 2) * kWave;
     if (mapped) {
-        dyn_emit_rows(tile, L4, L4, p.out, L4, 0, p, *em, it0, n_valid, (int)threadIdx.x, 2 * kWave);
+        dyn_emit_rows(tile, L4, L4, p.out, L4, 0, p, *em, it0, n_valid, (int)threadIdx.x, NT);
         return;
     }
-    // rows of consecutive items are contiguous in the output: one linear copy by both waves
+    // rows of consecutive items are contiguous in the output: one linear copy by all waves
     const size_t grow = (size_t)it0 * L4;
     const int total = n_valid * L4;
     const int shift = (int)(grow & 1);
     const int npairs = (total + shift + 1) >> 1;
-    for (int m = threadIdx.x; m < npairs; m += 2 * kWave) {
+    for (int m = threadIdx.x; m < npairs; m += NT) {
         const int e0 = 2 * m - shift, e1 = e0 + 1;
         if (e0 >= 0 && e1 < total) store_nt2(p.out + grow + e0, tile[e0], tile[e1]);
         else if (e0 >= 0) store_nt(p.out + grow + e0, tile[e0]);

@@ -935,8 +935,13 @@ void k_pair_sweep(const GjkSwarmParams p)
         // block ids: they are dispatched as the sweep's workgroups drain and fill the slots the tail leaves empty
         // (on the FIRST block ids the launch takes 0.201 instead of 0.187 ms).  Under the sweep's 96-VGPR bound this
         // body spills (43 dwords); the gjkNew loop is not touched by it (no scratch access at all in this build).
-        if (threadIdx.x >= 2 * kWave) return;
-        dynamics2_group<NC, true>(p.dyn, reinterpret_cast<double*>(xy_dyn), (int)blockIdx.x - p.dyn_first_block);
+        // (two waves work, two leave: with all four on the group -- dynamics2_group<.., W4 = true>, each squaring half the
+        // coefficients -- a workgroup is shorter but the degree-2n curves are formed twice, and the launch is bound by the
+        // chip's aggregate issue rate: 0.1820 against 0.1806 ms)
+        // (16 control points: the two-wave form spills 800 bytes per lane under this kernel's 128 VGPRs, the four-wave form
+        // half of that: C4 25.9 against 26.3 ms)
+        if (NC <= 11 && threadIdx.x >= 2 * kWave) return;
+        dynamics2_group<NC, true, (NC > 11)>(p.dyn, reinterpret_cast<double*>(xy_dyn), (int)blockIdx.x - p.dyn_first_block);
         return;
     }
     gjk_planar_body<NC, 0, true>(p, xy_dyn, -1, -1);
@@ -1000,7 +1005,6 @@ __global__ __launch_bounds__(256, WPC) void k_step_fd_structured(const Structure
         // ---- D: row 0's vehicle groups streamed into row ranges | the advanced vehicles, 64 rows to a group | rows whose
         //      tf is not tf[0] (a finite-difference row of tf itself), eight rows to a workgroup, in full
         __shared__ int s_dmap[kWave];
-        if (!ELEV && threadIdx.x >= 2 * kWave) return;      // (dynamics2_group's barriers count the surviving waves)
         const int gd = sp.dyn_groups_per_row;
         DynEmit em{ 0, 0, 0, 0, 0, s_dmap };
         auto run = [&](int group) {
@@ -1009,7 +1013,7 @@ __global__ __launch_bounds__(256, WPC) void k_step_fd_structured(const Structure
                 q.a = p.dyn; q.cv4 = sp.cv4; q.cv2 = sp.cv2; q.R = sp.R;
                 dynamics_elev_group<NC>(q, lds, group, &em);
             } else {
-                dynamics2_group<NC, false>(p.dyn, lds, group, &em);
+                dynamics2_group<NC, false, true>(p.dyn, lds, group, &em);
             }
         };
         if (id < sp.dyn_streams) {
@@ -1158,8 +1162,10 @@ __global__ __launch_bounds__(256, 4) void k_pair_sweep_tiled(const GjkSwarmParam
     if (p.dyn.out != nullptr && (int)blockIdx.x >= p.dyn_first_block) {
         // the speed / angular-rate groups of the batch as the grid's last workgroups, as in k_pair_sweep: the whole
         // evaluation of a large swarm (C4) is this one launch
-        if (threadIdx.x >= 2 * kWave) return;
-        dynamics2_group<NC, true>(p.dyn, reinterpret_cast<double*>(xy_dyn), (int)blockIdx.x - p.dyn_first_block);
+        // (16 control points: the two-wave form spills 800 bytes per lane under this kernel's 128 VGPRs, the four-wave form
+        // half of that: C4 25.9 against 26.3 ms)
+        if (NC <= 11 && threadIdx.x >= 2 * kWave) return;
+        dynamics2_group<NC, true, (NC > 11)>(p.dyn, reinterpret_cast<double*>(xy_dyn), (int)blockIdx.x - p.dyn_first_block);
         return;
     }
     gjk_planar_body<NC, 2, true>(p, xy_dyn, -1, -1);
