@@ -1402,7 +1402,7 @@ def test_both_speed_bounds_from_one_pass(capi, synth, oracle, shape):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("shape", ["C3_full_batch", "deg7_two_fixed", "three_vehicles", "deg5_no_polys", "elevated_R6", "C5_like_R100", "one_row", "two_rows_elevated", "C4_like_large_rows"])
+@pytest.mark.parametrize("shape", ["C3_full_batch", "deg7_two_fixed", "three_vehicles", "deg5_no_polys", "elevated_R6", "C5_like_R100", "one_row", "two_rows_elevated", "C4_like_large_rows", "rows_of_96KB"])
 @pytest.mark.parametrize("tf_rows", ["one_tf", "a_few_rows_with_their_own_tf", "every_row_its_own_tf"])
 def test_structured_fd_step_is_bit_identical_to_the_brute_force_sweep(capi, synth, shape, tf_rows):
     """obtg_constraint_sweep_fd_structured_dev: the finite-difference step as ONE launch that evaluates row 0 in full and
@@ -1416,7 +1416,8 @@ def test_structured_fd_step_is_bit_identical_to_the_brute_force_sweep(capi, synt
     N, n, M, fixed, R = {"C3_full_batch": (64, 10, 8, 1, 0), "deg7_two_fixed": (20, 7, 2, 2, 0), "three_vehicles": (3, 10, 1, 1, 0),
                          "deg5_no_polys": (12, 5, 0, 1, 0), "elevated_R6": (9, 10, 3, 1, 6), "C5_like_R100": (64, 10, 32, 1, 100),
                          "one_row": (10, 7, 2, 1, 0), "two_rows_elevated": (6, 7, 1, 1, 3),
-                         "C4_like_large_rows": (256, 15, 0, 1, 0)}[shape]      # 70 KB of hulls per row: the one-workgroup-per-CU form
+                         "C4_like_large_rows": (256, 15, 0, 1, 0),             # 70 KB of hulls per row: two workgroups per CU
+                         "rows_of_96KB": (558, 10, 2, 1, 0)}[shape]            # one workgroup per CU (k_step_fd_structured<11, false, 1>)
     Y = synth.swarm_control_points(N, 2, n, seed=41)
     B = N * 2 * (n + 1 - 2 * fixed) + 1
     ctx = capi.Context(N, 2, n, R)
@@ -1429,7 +1430,7 @@ def test_structured_fd_step_is_bit_identical_to_the_brute_force_sweep(capi, synt
         pa, pb = synth.swarm_pairs(N, M)
         ctx.set_polygons(*(synth.pack_polys(synth.polygon_obstacles(M, seed=41)) if M else (None, [0])))
     ctx.set_hull_pairs(pa, pb)
-    B = {"one_row": 1, "two_rows_elevated": 2, "C4_like_large_rows": 130}.get(shape, B)
+    B = {"one_row": 1, "two_rows_elevated": 2, "C4_like_large_rows": 130, "rows_of_96KB": 24}.get(shape, B)
     h = synth.FD_STEP if shape == "C3_full_batch" else 1e-3
     d0 = torch.from_numpy(Y).cuda()
     tf = np.linspace(3.0, 9.0, B)
