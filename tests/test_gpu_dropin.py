@@ -474,3 +474,17 @@ def test_reduced_separation_rows_option():
     assert bo_m.temporalSeparationConstraints(s_min.x).shape == (10,)
     assert bo_a.temporalSeparationConstraints(s_min.x).min() > -1e-6          # feasible for the full constraint set too
     assert abs(s_all.fun - s_min.fun) < 1e-3 * max(1.0, abs(s_all.fun))
+
+
+@pytest.mark.gpu
+def test_whole_fd_step_in_one_launch_gives_the_providers_jacobians():
+    """examples/example5_fd_step_one_launch.py at 9 vehicles: the dense Jacobians formed on the device from ONE structured
+    launch equal the per-family `...Jacobian` providers of the drop-in class (separation, angular rate: entry for entry)."""
+    import importlib.util
+    import os
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples", "example5_fd_step_one_launch.py")
+    spec = importlib.util.spec_from_file_location("example5", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    same, _ = mod.main(N=9, n=10, M=2, verbose=False)
+    assert all(same.values()), same
