@@ -468,7 +468,8 @@ __device__ __forceinline__ void tsep_elev_group_stream(const TsepXYParams& t, co
         // the pass's rows are one contiguous run of rows x (2n+R+1) doubles in every batch row: written back to back per
         // batch row (the L2 merges the lines neighbouring rows share), from registers (each lane keeps its columns)
         // (the pass as ONE run in 16-byte pieces with a per-element pair test, the R = 0 stream's form: bit-identical, 0.90
-        // instead of 0.84 ms at C5 on the same box -- the per-piece predicates cost more than the wider stores save)
+        // instead of 0.84 ms at C5 on the same box -- the per-piece predicates cost more than the wider stores save; with
+        // non-temporal stores 0.92, and the 8-byte form below with non-temporal stores 0.89)
         constexpr int kMaxRows = 8, kMaxCols = 4;                                   // rpp <= 8 (LR > 56), ceil(LR / 64) <= 4 (LR <= 256); else the LDS form below
         if (rows <= kMaxRows && LR <= kMaxCols * kWave) {
             double v[kMaxRows][kMaxCols];
