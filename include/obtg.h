@@ -246,8 +246,10 @@ int obtg_gjk_swarm_dev(obtg_ctx*, const double* dY, int B, int max_iter, int md_
  * tiled form of the same idea when the hull pair list holds every vehicle pair: a chunk of the tiled sweep
  * stages one TA x 64 tile of the pair matrix and writes that tile's separation rows.  3-D rows: the 3-D
  * sweep's workgroups run their part of the separation block first (obtg_constraint_sweep_dev: and of the
- * speed rows), one launch as well.  Shapes without such a kernel (DEG_ELEV > 0, point obstacles,
- * de-duplication on) fall back to the two launches. */
+ * speed rows), one launch as well.  Point obstacles (constant curves in the separation pairs, optimization.py:86-98; no
+ * part of the hull sweep) are staged behind the hull objects by the planar grid: one launch too, for rows within 48 KB.
+ * Shapes without such a kernel (DEG_ELEV > 0, de-duplication on, point obstacles with large or 3-D rows) fall back to the
+ * two launches. */
 int obtg_pair_sweep_dev(obtg_ctx*, const double* dY, int B, double max_sep, double* d_out_sep,
                         int max_iter, int md_cap, int* d_flag, double* d_p1, double* d_p2,
                         double* d_dist, int* d_nsup, int* d_status);

@@ -294,7 +294,10 @@ struct TsepXYParams {
     double sign, offset;
     const double* __restrict__ Tt;    // DEG_ELEV > 0 (structured step): elevation as a scaled convolution (NsParams::Tt)
     int R;
+    int n_veh, obs_shift;             // pairs may name point obstacles (object ids >= n_veh, optimization.py:86-98): those are
+                                      // staged obs_shift slots further on (behind the polygons of the hull sweep); 0, 0: none
 };
+__device__ __forceinline__ int tsep_slot(const TsepXYParams& t, int obj) { return obj < t.n_veh ? obj : obj + t.obs_shift; }
 
 template <int NC>
 __device__ __forceinline__ void tsep_groups_from_xy(const TsepXYParams& t, const double2* xy, const int vpq,
@@ -314,8 +317,8 @@ __device__ __forceinline__ void tsep_groups_from_xy(const TsepXYParams& t, const
         const int n_valid = min(kWave, t.n_pairs - itg);
         const int item = min(itg + lane, t.n_pairs - 1);      // idle lanes recompute the last item
         const int2 ij = t.pairs[item];
-        const double2* vi = xy + ij.x * vpq;
-        const double2* vj = xy + ij.y * vpq;
+        const double2* vi = xy + (t.obs_shift ? tsep_slot(t, ij.x) : ij.x) * vpq;
+        const double2* vj = xy + (t.obs_shift ? tsep_slot(t, ij.y) : ij.y) * vpq;
         double a[2][NC];
 #pragma unroll
         for (int c = 0; c < NC; ++c) {

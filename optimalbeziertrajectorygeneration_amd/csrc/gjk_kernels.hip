@@ -279,6 +279,8 @@ struct GjkSwarmParams {
     int emit_scalar = 0;               // results may go to LDS through generic pointers: 8-byte stores only
     int refill_min = 1;                // planar sweeps: idle lanes of a wave wait until this many can refill together
     int passes = 1;                    // MODE 0: chunks a workgroup takes one after the other (w-th workgroup of a row: chunks w*passes ..)
+    const double* obs = nullptr;       // pair sweep (MODE 0): the context's point obstacles [n_obs][2], staged behind the hull
+    int n_obs = 0;                     //         objects as constant curves for the separation rows that name them
 };
 
 template <bool PLANAR>
@@ -468,7 +470,8 @@ __device__ __forceinline__ void gjk_planar_body(const GjkSwarmParams& p, double2
     int c1 = SWEEP ? 0 : (TILED ? p.chunk_off[w + 1] : min(p.n_pairs, c0 + p.chunk));
     const int obj0 = TILED ? p.cobj_off[w] : 0;
     const int n_obj = TILED ? p.cobj_off[w + 1] - obj0 : p.n_veh + p.n_poly;     // staged objects
-    const int cap_obj = TILED ? p.max_objs : n_obj;                                // LDS slots reserved
+    const int n_obs_staged = (TS && SWEEP) ? p.n_obs : 0;                          // point obstacles of the separation rows
+    const int cap_obj = TILED ? p.max_objs : n_obj + n_obs_staged;                 // LDS slots reserved
     // per-pair records of phase 1 -> phase 2 (8 bytes):  r01.x = (flag+1) | status << 2 | keys << 4 | n_support << 8,
     // r01.y = the final simplex as support indices, five bits each: A.i1 | A.i2 << 5 | B.i1 << 10 | B.i2 << 15 | C.i1 << 20 | C.i2 << 25
     static_assert(NC <= 32, "five-bit support indices in the phase-1 records");
@@ -512,6 +515,10 @@ __device__ __forceinline__ void gjk_planar_body(const GjkSwarmParams& p, double2
             const int o = e / (2 * NC), r = e - o * (2 * NC), q = r / NC, k = r - q * NC;
             const int off = p.poly_off[o], K = p.poly_off[o + 1] - off;
             lds[2 * ((p.n_veh + o) * VPQ + k) + q] = p.poly[3 * off + q * K + (k < K ? k : 0)];
+        }
+        for (int e = threadIdx.x; e < n_obs_staged * 2 * NC; e += blockDim.x) {       // constant curves (optimization.py:86-98)
+            const int o = e / (2 * NC), r = e - o * (2 * NC), q = r / NC, k = r - q * NC;
+            lds[2 * ((n_obj + o) * VPQ + k) + q] = p.obs[o * 2 + q];
         }
     }
     __syncthreads();
@@ -2563,7 +2570,7 @@ struct SweepShape {
 };
 static SweepShape sweep_shape(const obtg_ctx* c, int B, int nc, int waves_per_simd, int chunk_target)
 {
-    const int np = c->n_hull_pairs, n_obj = c->n_veh + c->n_poly, vpq = nc | 1;
+    const int np = c->n_hull_pairs, n_obj = c->n_veh + c->n_poly + c->n_obs, vpq = nc | 1;   // (point obstacles: staged by the pair sweep)
     const size_t fixed = planar_lds_bytes<0>(n_obj, vpq, 0);
     SweepShape sh;
     // workgroups per CU: what the kernel's registers allow, fewer while the row's objects leave no room for 256 pairs
@@ -2846,7 +2853,7 @@ int launch_gjk_swarm(obtg_ctx* c, const double* dY, int B, int max_iter, int md_
 // behind the staged objects; small rows get a larger allocation so that 16 rows fit.  0: no room.
 static int pair_sweep_tile_rows(const obtg_ctx* c, int nc, size_t& lds)
 {
-    const int n_obj = c->n_veh + c->n_poly, vpq = nc | 1;
+    const int n_obj = c->n_veh + c->n_poly + c->n_obs, vpq = nc | 1;
     const int L = 2 * c->deg + 1, tpf = (L % 2 == 0) ? L + 1 : L;
     const size_t objects = (size_t)16 * n_obj * vpq;
     auto tile = [&](int rows) { return (size_t)4 * rows * tpf * sizeof(double); };
@@ -2864,7 +2871,7 @@ bool pair_sweep_is_one_launch(const obtg_ctx* c)
     const int nc = c->deg + 1;
     if (!(nc == 4 || nc == 6 || nc == 8 || nc == 11 || nc == 16)) return false;
     if (!(c->dim == 2 && c->polys_planar && c->max_poly_K <= nc && c->n_hull_pairs > 0 && !c->fd_dedup && c->R == 0 &&
-          c->n_obs == 0 && c->n_pairs > 0)) return false;
+          c->n_pairs > 0)) return false;
     size_t lds = sweep_shape(c, 1 << 20, nc, kPairSweepWavesPerSimd, kPairSweepChunk).lds;
     return pair_sweep_tile_rows(c, nc, lds) > 0 && lds <= 48 * 1024;
 }
@@ -2887,7 +2894,7 @@ int launch_pair_sweep(obtg_ctx* c, const double* dY, int B, double max_sep, doub
         default: break;
     }
     bool fused = kern && c->dim == 2 && c->polys_planar && c->max_poly_K <= nc && c->n_hull_pairs > 0 &&
-                 !c->fd_dedup && c->R == 0 && c->n_obs == 0 && c->n_pairs > 0;
+                 !c->fd_dedup && c->R == 0 && c->n_pairs > 0;
     GjkSwarmParams p{};
     size_t lds = 0;
     if (fused) {
@@ -2908,6 +2915,10 @@ int launch_pair_sweep(obtg_ctx* c, const double* dY, int B, double max_sep, doub
         p.ts.pairs = c->d_pairs.as<int2>(); p.ts.W2 = c->d_w2.as<double>(); p.ts.out = d_out_sep;
         p.ts.n_pairs = c->n_pairs; p.ts.sign = 1.0; p.ts.offset = -(max_sep * max_sep);
         p.ts_tile_rows = tr;
+        if (c->n_obs > 0) {            // point obstacles: constant curves behind the hull objects, for the separation rows only
+            p.obs = c->d_obs.as<double>(); p.n_obs = c->n_obs;
+            p.ts.n_veh = c->n_veh; p.ts.obs_shift = c->n_poly;
+        }
         if (c->fd.Y0) { p.Y = c->fd.Y0; p.fd = 1; p.fd_fixed = c->fd.fixed; p.fd_h = c->fd.h; }
     }
     if (!fused && kern && c->dim == 2 && c->polys_planar && c->max_poly_K <= nc && c->n_hull_pairs > 0 && !c->fd_dedup &&

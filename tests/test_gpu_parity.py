@@ -642,13 +642,21 @@ def test_gjk_swarm_history_order_does_not_change_results(capi, oracle, synth):
     ctx.close()
 
 
-@pytest.mark.parametrize("shape", ["C3", "small_deg7", "fallback_3d", "tiled_C4", "tiled_deg5", "tiled_deg10", "tiled_partial", "tiled_dups"])
+@pytest.mark.parametrize("shape", ["C3", "small_deg7", "fallback_3d", "tiled_C4", "tiled_deg5", "tiled_deg10", "tiled_partial", "tiled_dups",
+                                   "point_obstacles", "point_obstacles_no_polygons"])
 def test_pair_sweep_one_launch_equals_separate_kernels(capi, synth, shape):
     """obtg_pair_sweep_dev (temporal separation + gjkNew sweep as ONE grid) returns what the two
-    separate entry points return, bit for bit; shapes without the fused instantiation fall back."""
+    separate entry points return, bit for bit; shapes without the fused instantiation fall back.  With pointObstacles
+    (optimization.py:86-98: constant curves in the separation pairs, no part of the hull sweep) the grid stages them
+    behind the hull objects: still one launch."""
     import torch
+    n_obs = 0
     if shape == "C3":
         N, d, n, M, B = 64, 2, 10, 8, 37
+    elif shape == "point_obstacles":
+        N, d, n, M, B, n_obs = 23, 2, 10, 3, 19, 5
+    elif shape == "point_obstacles_no_polygons":
+        N, d, n, M, B, n_obs = 7, 2, 7, 0, 9, 2
     elif shape == "small_deg7":
         N, d, n, M, B = 9, 2, 7, 3, 21
     elif shape == "tiled_C4":         # rows beyond 48 KB of LDS: the tiled sweep writes its tiles' separation rows
@@ -668,7 +676,7 @@ def test_pair_sweep_one_launch_equals_separate_kernels(capi, synth, shape):
     if shape == "tiled_partial":      # a hull pair list that misses vehicle pairs: the tiles cannot carry the separation rows
         keep = np.random.default_rng(5).random(len(pa)) < 0.7
         pa, pb = pa[keep], pb[keep]
-    ctx = capi.Context(N, d, n, 0)
+    ctx = capi.Context(N, d, n, 0, point_obs=np.random.default_rng(6).uniform(10, 90, size=(n_obs, d)) if n_obs else None)
     if M:
         ctx.set_polygons(*synth.pack_polys(synth.polygon_obstacles(M, seed=8)))
     ctx.set_hull_pairs(pa, pb)
@@ -676,6 +684,7 @@ def test_pair_sweep_one_launch_equals_separate_kernels(capi, synth, shape):
     ctx.set_stream((torch.cuda.current_stream().cuda_stream or 1))
     dY = torch.from_numpy(Yb).to(dev)
     P, L, Ps = ctx.num_pairs, 2 * n + 1, len(pa)
+    assert P == (N + n_obs) * (N + n_obs - 1) // 2
 
     def bufs():
         return dict(sep=torch.full((B, P * L), np.nan, dtype=torch.float64, device=dev),
@@ -697,6 +706,14 @@ def test_pair_sweep_one_launch_equals_separate_kernels(capi, synth, shape):
         for k in a:
             assert np.array_equal(a[k].cpu().numpy(), b[k].cpu().numpy(), equal_nan=True), k
     assert not torch.isnan(b["sep"]).any() and (b["flag"] != -7).all()
+    if n_obs or shape in ("C3", "small_deg7"):
+        ctx.reset_kernel_stats(); ctx.set_profiling(True)
+        ctx.pair_sweep_dev(dY.data_ptr(), B, 0.9, b["sep"].data_ptr(), b["flag"].data_ptr(), b["p1"].data_ptr(),
+                           b["p2"].data_ptr(), b["dist"].data_ptr(), b["nsup"].data_ptr(), b["status"].data_ptr(), 128, 500)
+        torch.cuda.synchronize()
+        ks = {k: v[1] for k, v in ctx.kernel_stats().items() if v[1]}
+        ctx.set_profiling(False)
+        assert ks == {"pair_sweep": 1}, ks                                 # ONE launch
     ctx.set_stream(0)
     ctx.close()
 
@@ -1278,17 +1295,17 @@ def test_min_dist2poly_robust(capi, synth, golden_dir, host_gjk):
     assert d_rob <= d_ref * (1 + 1e-9) and pt.shape == (3,)
 
 
-@pytest.mark.parametrize("shape", ["C3", "deg7_ragged", "elevated_fallback", "tiled_256x15"])
+@pytest.mark.parametrize("shape", ["C3", "deg7_ragged", "elevated_fallback", "tiled_256x15", "with_point_obstacles"])
 def test_constraint_sweep_equals_separate_calls(capi, synth, shape):
     """obtg_constraint_sweep_dev: all four families of a batch in one call, against the separate entry points (pair
     sweep + fused dynamics), bit for bit; on a materialised batch and inside an FD view."""
     import torch
     N, n, R, M, B = {"C3": (64, 10, 0, 8, 700), "deg7_ragged": (40, 7, 0, 3, 11), "elevated_fallback": (8, 10, 5, 2, 9),
-                     "tiled_256x15": (256, 15, 0, 0, 3)}[shape]
+                     "tiled_256x15": (256, 15, 0, 0, 3), "with_point_obstacles": (20, 10, 0, 2, 15)}[shape]
     Y = synth.swarm_control_points(N, 2, n, seed=21)
     polys = synth.polygon_obstacles(M, seed=21)
     pa, pb = synth.swarm_pairs(N, M)
-    ctx = capi.Context(N, 2, n, R)
+    ctx = capi.Context(N, 2, n, R, point_obs=np.array([[20.0, 30.0], [55.5, 41.0], [70.0, 12.5]]) if shape == "with_point_obstacles" else None)
     ctx.set_stream((torch.cuda.current_stream().cuda_stream or 1))
     ctx.set_polygons(*(synth.pack_polys(polys) if M else (None, [0])))
     ctx.set_hull_pairs(pa, pb)
@@ -1331,7 +1348,7 @@ def test_constraint_sweep_equals_separate_calls(capi, synth, shape):
         torch.cuda.synchronize()
         ks = ctx.kernel_stats()
         ctx.set_profiling(False)
-        if shape in ("C3", "tiled_256x15"):       # the whole step is ONE launch: the dynamics groups are the grid's last workgroups
+        if shape in ("C3", "tiled_256x15", "with_point_obstacles"):       # the whole step is ONE launch: the dynamics groups are the grid's last workgroups
             assert ks.get("pair_sweep", (0.0, 0))[1] == 2 and ks.get("ang_rate", (0.0, 0))[1] == 0, ks
         for key in a:
             assert torch.equal(a[key].view(torch.uint8), b[key].view(torch.uint8)), (key, view)
