@@ -495,6 +495,12 @@ def main():
         # planar rows: the speed / angular-rate groups ran as the grid's last workgroups -- the launch IS the evaluation,
         # its algorithmic bytes are SURVEY.md 8(d)'s per-eval figure (control points counted once) x B
         by["pair_sweep"] = total_bytes
+    sep_with_dynamics = (not one_launch_step and o_an is not None and stats.get("temporal_sep", (0.0, 0))[1] > 0 and
+                         stats.get("ang_rate", (0.0, 0))[1] == 0 and stats.get("speed", (0.0, 0))[1] == 0)
+    if sep_with_dynamics:
+        # DEG_ELEV > 0: the separation rows and the speed / angular-rate rows share a launch (k_sep_dynamics_elev, booked as
+        # "temporal_sep"): both families' bytes, the control points counted once
+        by["temporal_sep"] += by["ang_rate"] - 8 * N * d * (n + 1)
     for name in KNAMES:
         ms, cnt = stats.get(name, (0.0, 0))
         if cnt == 0:

@@ -255,8 +255,8 @@ int obtg_pair_sweep_dev(obtg_ctx*, const double* dY, int B, double max_sep, doub
                         double* d_dist, int* d_nsup, int* d_status);
 /* EVERY constraint family of the batch in one call: obtg_pair_sweep_dev (temporal separation + gjkNew hull sweep) and
  * obtg_dynamics_dev (max/min speed + angular rate; d_out_ang may be NULL) of the same B rows -- what one evaluation of an
- * SLSQP step needs, as the library's best launch sequence for the shape (two launches where the one-launch pair sweep
- * applies).  Outputs are those of the two separate calls, bit for bit.  dY may be NULL inside an obtg_fd_view. */
+ * SLSQP step needs, as the library's best launch sequence for the shape (ONE launch for planar DEG_ELEV = 0 rows and 3-D
+ * rows; two for planar DEG_ELEV > 0: the gjkNew sweep, and the separation rows with the speed / angular-rate groups).  Outputs are those of the two separate calls, bit for bit.  dY may be NULL inside an obtg_fd_view. */
 int obtg_constraint_sweep_dev(obtg_ctx*, const double* dY, const double* d_tf, int B, double max_sep, double* d_out_sep,
                               double speed_bound, int speed_is_max, double max_rate, double* d_out_speed,
                               double* d_out_ang, int max_iter, int md_cap, int* d_flag, double* d_p1, double* d_p2,
@@ -268,7 +268,7 @@ int obtg_constraint_sweep_dev(obtg_ctx*, const double* dY, const double* d_tf, i
  * vehicle its advanced control point touches.  Outputs are those of obtg_constraint_sweep_dev inside the same view,
  * bit for bit (the same device functions evaluate every pair); the launch is bound by its stores instead of by gjkNew.
  * Planar shapes (deg + 1 in {4, 6, 8, 11}, no point obstacles, angular rate wanted, a row's objects within 40 KB of LDS), any
- * DEG_ELEV with 2 deg + DEG_ELEV + 1 <= 512 -- for DEG_ELEV > 0 (where the brute-force step is three launches) the separation
+ * DEG_ELEV with 2 deg + DEG_ELEV + 1 <= 512 -- for DEG_ELEV > 0 (where the brute-force step is two launches) the separation
  * streams are the elevated rows and the dynamics groups are the elevated kernel's; at DEG_ELEV = 0 also deg + 1 = 16 and, for
  * deg + 1 in {11, 16}, rows of up to 158 KB (256 vehicles of degree 15 are 70 KB: two workgroups per CU):
  * OBTG_ERR_UNSUPPORTED otherwise -- the brute-force call gives the same numbers.  d_tf is read per row: the speed /

@@ -311,6 +311,33 @@ __global__ __launch_bounds__(4 * kWave, (NC > 11 ? 1 : OBTG_DYN_ELEV_WAVES)) voi
     dynamics_elev_group<NC>(q, lds, (int)blockIdx.x);
 }
 
+// DEG_ELEV > 0: the elevated separation rows and the elevated speed / angular-rate rows of a batch in ONE launch (the
+// brute-force step of such a shape is then two launches: this and the gjkNew sweep).  The separation kernel is bound by
+// its stores, the dynamics kernel by its FMAs; their workgroups are interleaved over the block ids (pattern rotated by
+// one slot per 16 ids: every XCD sees both kinds) so that each CU has one of each at most times.
+struct SepDynElevParams {
+    NsParams ts;
+    AngElevParams dyn;
+    int n_kind[2], per16[2];           // separation workgroups (row, share of the row's groups) | dynamics groups
+    unsigned char pat[16], rank[16];
+};
+
+template <int NC>
+__global__ __launch_bounds__(4 * kWave, (NC > 11 ? 1 : 2)) void k_sep_dynamics_elev(const SepDynElevParams sp)
+{
+    extern __shared__ double lds[];
+    const int grp = (int)blockIdx.x >> 4, slot = ((int)blockIdx.x + grp) & 15;
+    const int kind = sp.pat[slot];
+    const int id = grp * sp.per16[kind] + sp.rank[slot];
+    if (id >= sp.n_kind[kind]) return;
+    if (kind == 1) {
+        dynamics_elev_group<NC>(sp.dyn, lds, id);
+        return;
+    }
+    const int b = id / sp.ts.wgs_per_row;
+    normsq_elev_body<NC, 2, 0, false, true>(sp.ts, b, id - b * sp.ts.wgs_per_row, lds);
+}
+
 // =====================================================================================
 //  generic path: any degree / elevation, one wave per item, operands in LDS, products as
 //  binomially scaled convolutions:  c_k = (1/C(m+n,k)) * sum_j [C(m,j) a_j][C(n,k-j) b_{k-j}]
@@ -1153,6 +1180,74 @@ int launch_one_vs_many_min(obtg_ctx* c, const double* d_one, int B, const double
     hipLaunchKernelGGL(kern, dim3((unsigned)((items + threads - 1) / threads)), dim3(threads), 0, c->stream, p);
     OBTG_HIP(c, hipGetLastError());
     return OBTG_OK;
+}
+
+template <int NC>
+static int launch_sep_dyn_elev_t(obtg_ctx* c, SepDynElevParams& sp, int B)
+{
+    using S = NsShape<NC, 2>;
+    sp.ts.tile_rows = kWave;
+    const size_t lds_t = sizeof(double) * ((size_t)sp.ts.stage_slots * S::VP + 4 * (size_t)ns_elev_tile_doubles(S::L));
+    const size_t lds = std::max(lds_t, sizeof(double) * 4 * kWave * (kElevChunk + 1));
+    if (lds > 80 * 1024 - 512) return OBTG_ERR_UNSUPPORTED;            // two workgroups per CU
+    sp.n_kind[0] = B * sp.ts.wgs_per_row;
+    sp.n_kind[1] = (sp.dyn.a.total + kWave - 1) / kWave;
+    // shares of every 16 block ids by count: both kinds run out at about the same block id
+    const double tot = (double)sp.n_kind[0] + sp.n_kind[1];
+    sp.per16[1] = std::min(15, std::max(1, (int)(16.0 * sp.n_kind[1] / tot + 0.5)));
+    if (const char* e = getenv("OBTG_SEP_DYN_SHARE")) sp.per16[1] = std::min(15, std::max(1, atoi(e)));      // (experiments)
+    sp.per16[0] = 16 - sp.per16[1];
+    int seen[2] = { 0, 0 };
+    for (int i = 0; i < 16; ++i) {         // kind 1 in the slots where its running share crosses an integer
+        const int k = ((i + 1) * sp.per16[1]) / 16 > (i * sp.per16[1]) / 16 ? 1 : 0;
+        sp.pat[i] = (unsigned char)k; sp.rank[i] = (unsigned char)seen[k]++;
+    }
+    const int groups = std::max((sp.n_kind[0] + sp.per16[0] - 1) / sp.per16[0], (sp.n_kind[1] + sp.per16[1] - 1) / sp.per16[1]);
+    if (lds > 48 * 1024)
+        OBTG_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_sep_dynamics_elev<NC>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    ScopedKernelTimer t(c, OBTG_K_TEMPORAL_SEP);
+    hipLaunchKernelGGL(k_sep_dynamics_elev<NC>, dim3((unsigned)groups * 16u), dim3(4 * kWave), lds, c->stream, sp);
+    OBTG_HIP(c, hipGetLastError());
+    return OBTG_OK;
+}
+
+// DEG_ELEV > 0, planar: the separation rows and the speed / angular-rate rows of a batch in one launch
+// (k_sep_dynamics_elev).  OBTG_ERR_UNSUPPORTED: shape outside it, nothing launched.
+int launch_sep_dynamics_elev(obtg_ctx* c, const double* dY, int B, double max_sep, double* d_out_sep, const SweepFold& f)
+{
+    static const bool on = !(getenv("OBTG_SEP_DYN_ELEV") && getenv("OBTG_SEP_DYN_ELEV")[0] == '0');
+    const int nc = c->deg + 1;
+    if (!on || B <= 0 || c->R <= 0 || c->dim != 2 || !f.d_out_ang || !f.d_tf || !d_out_sep || c->n_pairs <= 0 ||
+        !(nc == 4 || nc == 6 || nc == 8 || nc == 11)) return OBTG_ERR_UNSUPPORTED;
+    int rc = ensure_tables(c);
+    if (rc) return rc;
+    if (!dyn_fast_elev(c) || !fast_shape(c)) return OBTG_ERR_UNSUPPORTED;
+    SepDynElevParams sp{};
+    rc = plan_temporal_sep(c, dY, B, 0, c->n_pairs, d_out_sep, sp.ts);
+    if (rc) return rc;
+    if (sp.ts.waves != 4) return OBTG_ERR_UNSUPPORTED;                 // (fewer than four 64-pair groups per row)
+    sp.ts.sign = 1.0; sp.ts.offset = -(max_sep * max_sep);
+    AngParams& p = sp.dyn.a;
+    p.Y = dY; p.tf = f.d_tf; p.out = f.d_out_ang; p.out_speed = f.d_out_speed;
+    p.n_veh = c->n_veh; p.total = B * c->n_veh;
+    p.w2 = f.max_rate * f.max_rate;
+    const double b2 = f.speed_bound * f.speed_bound;
+    p.sp_sign = f.speed_is_max ? -1.0 : 1.0; p.sp_offset = f.speed_is_max ? b2 : -b2;
+    p.W2n = c->d_ang_w2n.as<double>(); p.W22n = c->d_ang_w22n.as<double>(); p.Wn = c->d_ang_wn.as<double>();
+    second_speed_rows(c, p);
+    if (c->fd.Y0) {
+        sp.ts.Y = c->fd.Y0; sp.ts.fd = 1; sp.ts.fd_fixed = c->fd.fixed; sp.ts.fd_h = c->fd.h;
+        p.Y = c->fd.Y0; p.fd = 1; p.fd_fixed = c->fd.fixed; p.fd_h = c->fd.h;
+    }
+    sp.dyn.cv4 = c->d_ang_T4.as<double>(); sp.dyn.cv2 = c->d_ang_cv2.as<double>(); sp.dyn.R = c->R;
+    switch (nc) {
+        case 4: return launch_sep_dyn_elev_t<4>(c, sp, B);
+        case 6: return launch_sep_dyn_elev_t<6>(c, sp, B);
+        case 8: return launch_sep_dyn_elev_t<8>(c, sp, B);
+        case 11: return launch_sep_dyn_elev_t<11>(c, sp, B);
+    }
+    return OBTG_ERR_UNSUPPORTED;
 }
 
 int launch_dynamics(obtg_ctx* c, const double* dY, const double* d_tf, int B, double bound, int is_max,

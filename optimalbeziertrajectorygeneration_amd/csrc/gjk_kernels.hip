@@ -3004,6 +3004,11 @@ int launch_pair_sweep(obtg_ctx* c, const double* dY, int B, double max_sep, doub
         if (rc) return rc;
         if (speed) speed->did_speed = f.did_speed;
         if (f.did_sep) return OBTG_OK;
+        if (speed && c->R > 0) {       // DEG_ELEV > 0: the separation rows and the dynamics rows share a launch
+            rc = launch_sep_dynamics_elev(c, dY, B, max_sep, d_out_sep, *speed);
+            if (rc == OBTG_OK) { speed->did_dynamics = true; return OBTG_OK; }
+            if (rc != OBTG_ERR_UNSUPPORTED) return rc;
+        }
         return launch_temporal_sep(c, dY, B, max_sep, 0, c->n_pairs, false, d_out_sep);
     }
     const size_t np = (size_t)c->n_hull_pairs;

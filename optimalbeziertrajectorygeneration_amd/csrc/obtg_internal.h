@@ -186,6 +186,8 @@ int launch_speed(obtg_ctx* c, const double* dY, const double* d_tf, int B, doubl
                  double* d_out);
 int launch_ang_rate(obtg_ctx* c, const double* dY, const double* d_tf, int B, double max_rate,
                     double* d_out);
+// DEG_ELEV > 0, planar: separation rows + speed / angular-rate rows in one launch; OBTG_ERR_UNSUPPORTED = not this shape
+int launch_sep_dynamics_elev(obtg_ctx* c, const double* dY, int B, double max_sep, double* d_out_sep, const SweepFold& f);
 int launch_dynamics(obtg_ctx* c, const double* dY, const double* d_tf, int B, double bound, int is_max,
                     double max_rate, double* d_out_speed, double* d_out_ang);
 int launch_fd_batch(obtg_ctx* c, const double* dY0, int n_fixed_cols, double h, int B, double* dY);

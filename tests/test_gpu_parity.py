@@ -1295,13 +1295,14 @@ def test_min_dist2poly_robust(capi, synth, golden_dir, host_gjk):
     assert d_rob <= d_ref * (1 + 1e-9) and pt.shape == (3,)
 
 
-@pytest.mark.parametrize("shape", ["C3", "deg7_ragged", "elevated_fallback", "tiled_256x15", "with_point_obstacles"])
+@pytest.mark.parametrize("shape", ["C3", "deg7_ragged", "elevated_fallback", "tiled_256x15", "with_point_obstacles", "elevated_two_launches"])
 def test_constraint_sweep_equals_separate_calls(capi, synth, shape):
     """obtg_constraint_sweep_dev: all four families of a batch in one call, against the separate entry points (pair
     sweep + fused dynamics), bit for bit; on a materialised batch and inside an FD view."""
     import torch
     N, n, R, M, B = {"C3": (64, 10, 0, 8, 700), "deg7_ragged": (40, 7, 0, 3, 11), "elevated_fallback": (8, 10, 5, 2, 9),
-                     "tiled_256x15": (256, 15, 0, 0, 3), "with_point_obstacles": (20, 10, 0, 2, 15)}[shape]
+                     "tiled_256x15": (256, 15, 0, 0, 3), "with_point_obstacles": (20, 10, 0, 2, 15),
+                     "elevated_two_launches": (40, 10, 12, 2, 7)}[shape]    # DEG_ELEV > 0: separation + dynamics share a launch
     Y = synth.swarm_control_points(N, 2, n, seed=21)
     polys = synth.polygon_obstacles(M, seed=21)
     pa, pb = synth.swarm_pairs(N, M)
@@ -1350,6 +1351,8 @@ def test_constraint_sweep_equals_separate_calls(capi, synth, shape):
         ctx.set_profiling(False)
         if shape in ("C3", "tiled_256x15", "with_point_obstacles"):       # the whole step is ONE launch: the dynamics groups are the grid's last workgroups
             assert ks.get("pair_sweep", (0.0, 0))[1] == 2 and ks.get("ang_rate", (0.0, 0))[1] == 0, ks
+        if shape == "elevated_two_launches":      # gjkNew sweep + (separation rows with the dynamics groups among them)
+            assert ks.get("temporal_sep", (0.0, 0))[1] == 2 and ks.get("gjk", (0.0, 0))[1] == 2 and ks.get("ang_rate", (0.0, 0))[1] == 0, ks
         for key in a:
             assert torch.equal(a[key].view(torch.uint8), b[key].view(torch.uint8)), (key, view)
     ctx.set_stream(0)
