@@ -10,7 +10,7 @@
 import csv, glob, json, os, shutil, sys
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-FAMILY = (("pair_sweep", "k_pair_sweep"), ("pair_sweep", "k_step_fd_structured"), ("temporal_sep", "k_normsq_elev"), ("ang_rate", "k_dynamics"), ("ang_rate", "k_ang_rate"),
+FAMILY = (("pair_sweep", "k_pair_sweep"), ("pair_sweep", "k_step_fd_structured"), ("temporal_sep", "k_sep_dynamics_elev"), ("temporal_sep", "k_normsq_elev"), ("ang_rate", "k_dynamics"), ("ang_rate", "k_ang_rate"),
           ("speed", "k_speed"), ("gjk", "k_gjk_swarm"))
 
 
