@@ -539,6 +539,43 @@ def gen_mindist():
     save("mindist.npz", **d)
 
 
+def gen_mindist_script():
+    """The inputs of Examples/MinDistBez2Bez.py:42-84 (its five 3-D curves; cpts5 = cpts1 - 3 there, + 3 in bezier.py's
+    own block above) through the reference's `_minDist` on every ordered pair, and `_minDist2Poly` on its three polygons."""
+    d = {}
+    sys.setrecursionlimit(1000)
+    cpts1 = np.array([(0, 1, 2, 3, 4, 5), (1, 2, 0, 0, 2, 1), (0, 1, 2, 3, 4, 5)], dtype=float)
+    cpts2 = np.array([(0, 1, 2, 3, 4, 5), (3, 2, 0, 0, 2, 3), (5, 4, 3, 2, 1, 0)], dtype=float)
+    cpts3 = np.array([(0, 1, 2, 3, 4, 5), (0, 1, 2, 3, 4, 5), (0, 0, 0, 0, 0, 0)], dtype=float)
+    cpts4 = np.array([(5, 4, 3, 2, 1, 0), (0, 1, 2, 3, 4, 5), (0, 0, 0, 0, 0, 0)], dtype=float)
+    cpts4[1, :] -= 1
+    cpts5 = cpts1 - 3
+    polys = [np.array([(1, 3, 3), (1, 3, 2), (1, 4, 1), (3, 3, 3), (1, 5, 1)], dtype=float),
+             np.array([(1, 1, 3), (1, 1, 2), (1, 2, 1), (4, 0, 2), (1, 3, 1)], dtype=float),
+             np.array([(1, 1, 0), (1, 3, 0), (2, 5, 0), (4, 4, 0)], dtype=float)]
+    curves = [cpts1, cpts2, cpts3, cpts4, cpts5]
+    d["curves"] = np.stack(curves)
+    res, stat, pairs = [], [], []
+    for i in range(5):
+        for j in range(5):
+            if i == j:
+                continue
+            st, v, _ = run_mindist(bez.Bezier(curves[i].copy()), bez.Bezier(curves[j].copy()))
+            res.append(v); stat.append(st); pairs.append((i, j))
+    d["pairs"], d["res"], d["status"] = np.array(pairs, np.int32), np.array(res), np.array(stat, np.int32)
+    print("  script curve pairs: status", np.bincount(stat, minlength=3))
+    pts, off = synth.pack_polys(polys)
+    d["poly_pts"], d["poly_off"] = pts, off
+    r2, p2, s2, pr2 = [], [], [], []
+    for i in range(5):
+        for k, poly in enumerate(polys):
+            st, v, pt, _ = run_mindist2poly(bez.Bezier(curves[i].copy()), poly.copy())
+            r2.append(v); p2.append(pt); s2.append(st); pr2.append((i, k))
+    d["p_pairs"], d["p_res"], d["p_pt"], d["p_status"] = np.array(pr2, np.int32), np.array(r2), np.array(p2), np.array(s2, np.int32)
+    print("  script curve/poly: status", np.bincount(s2, minlength=3))
+    save("mindist_script.npz", **d)
+
+
 # ========================================================================= C5
 def gen_c5():
     """BASELINE config 5 (ComplexObstacles.py-style): 64 vehicles + 32 curve obstacles, degree 10.
@@ -725,7 +762,7 @@ def gen_spatial_fd():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["tables", "ops", "problem", "constraints", "gjk", "mindist", "c5", "spatial", "nearstop", "sequential", "spatial_fd"]
+    which = sys.argv[1:] or ["tables", "ops", "problem", "constraints", "gjk", "mindist", "c5", "spatial", "nearstop", "sequential", "spatial_fd", "mindist_script"]
     for w in which:
         if w == "none":          # import-only (exploration)
             continue

@@ -488,3 +488,29 @@ def test_whole_fd_step_in_one_launch_gives_the_providers_jacobians():
     spec.loader.exec_module(mod)
     same, _ = mod.main(N=9, n=10, M=2, verbose=False)
     assert all(same.values()), same
+
+
+@pytest.mark.gpu
+def test_min_dist_example_reproduces_the_reference_on_its_literal_curves():
+    """examples/example6_min_dist_curves.py (Examples/MinDistBez2Bez.py:42-100 without the plots): the batched calls'
+    results are the reference's own on the script's inputs wherever the reference returns (tests/golden/mindist_script.npz:
+    15 of 20 curve pairs, 11 of 15 curve / polygon pairs), the others carry a status; the true minimum is never above the
+    reference's answer."""
+    import importlib.util
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("example6", os.path.join(root, "examples", "example6_min_dist_curves.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    out = mod.main(verbose=False)
+    m = np.load(os.path.join(root, "tests", "golden", "mindist_script.npz"))
+    assert np.array_equal(np.stack(mod.curves_and_polys()[0]), m["curves"])
+    r, rr, rp = out["batch"], out["batch_robust"], out["batch_poly"]
+    ok = m["status"] == 0
+    assert np.array_equal(np.asarray(r["status"]) == 0, ok), (r["status"], m["status"])
+    np.testing.assert_allclose(np.asarray(r["res"])[ok], m["res"][ok], rtol=1e-9, atol=1e-12)
+    assert np.all(np.asarray(rr["res"])[ok, 0] <= m["res"][ok, 0] * (1 + 1e-9) + 1e-8)      # (touching curves: both are zero to 4e-9)
+    okp = m["p_status"] == 0
+    assert np.array_equal(np.asarray(rp["status"]) == 0, okp), (rp["status"], m["p_status"])
+    np.testing.assert_allclose(np.asarray(rp["res"])[okp][:, :2], m["p_res"][okp], rtol=1e-9, atol=1e-12)
+    assert abs(out["c3-c1"] - 1.0) < 1e-12

@@ -189,6 +189,28 @@ def test_min_dist(oracle, golden_dir):
                   r["res"][2:], m["c3p_pt"][k])
 
 
+def test_min_dist_on_the_example_scripts_inputs(oracle, golden_dir):
+    """Examples/MinDistBez2Bez.py:42-84's five curves (every ordered pair) and three polygons through the reference
+    (mindist_script.npz): the oracle returns the reference's numbers where the reference returns, a status elsewhere."""
+    m = _load(golden_dir, "mindist_script.npz")
+    cur, pts, off = m["curves"], m["poly_pts"], m["poly_off"]
+    for k, (i, j) in enumerate(m["pairs"]):
+        r = oracle.min_dist(cur[i], cur[j], max_nodes=300000)
+        if m["status"][k] == 0:
+            assert r["status"] == oracle.MD_OK
+            assert_close(r["res"], m["res"][k], 1e-9)
+        else:
+            assert r["status"] != oracle.MD_OK
+    for k, (i, q) in enumerate(m["p_pairs"]):
+        r = oracle.min_dist2poly(cur[i], pts[off[q]:off[q + 1]], max_nodes=300000)
+        if m["p_status"][k] == 0:
+            assert r["status"] == oracle.MD_OK
+            assert_close(r["res"][:2], m["p_res"][k], 1e-9)
+            assert_close(r["res"][2:], m["p_pt"][k], 1e-9)
+        else:
+            assert r["status"] != oracle.MD_OK
+
+
 def test_min_dist_known_answers(oracle, golden_dir):
     m = _load(golden_dir, "mindist.npz")
     c = m["lit_curves"]
