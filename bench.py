@@ -143,17 +143,17 @@ def spawn_ranks(args):
             procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                           start_new_session=True))
         live = list(procs)
-        while live:
+        while live and rc == 0:
             time.sleep(0.2)
             for p in list(live):
                 code = p.poll()
                 if code is None:
                     continue
                 live.remove(p)
-                if code != 0 and rc == 0:
-                    rc = code
+                if code != 0:
+                    rc = code               # the FIRST failing rank's code is what the launcher returns
                     stop_all()              # one rank failed: the others would wait in a barrier forever
-                    live = []
+                    break
     finally:
         stop_all()
         for sig, h in old.items():
@@ -208,6 +208,12 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if os.environ.get("OBTG_BENCH_REHEARSE_EXIT"):      # launcher rehearsal (tests/): "rank:code" -- that rank exits with
+        r_, c_ = os.environ["OBTG_BENCH_REHEARSE_EXIT"].split(":")    # the code at once, the others wait as in a barrier
+        if rank == int(r_):
+            sys.exit(int(c_))
+        time.sleep(120)
+        sys.exit(0)
     if world != args.gpus:
         raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d: refusing to print a %d-GPU line from %d rank(s)"
                          % (args.gpus, world, args.gpus, world))
@@ -250,10 +256,10 @@ def main():
     max_sep, vmax, wmax, tfv = 0.9, 5.0, 1.0, 10.0
 
     ctx = _capi.Context(N, d, n, R, device=local_rank)
-    # torch's current stream; the default stream's handle is 0 = "the context's own (non-blocking) stream" to the library:
-    # every hand-over between torch's work and the library's below is a torch.cuda.synchronize()
-    stream = torch.cuda.current_stream()
-    ctx.set_stream(stream.cuda_stream)
+    # The library stays on the context's OWN stream (created non-blocking; obtg_ctx_use_own_stream is the default after
+    # create): every hand-over between torch's work and the library's below is a torch.cuda.synchronize().
+    # (obtg_ctx_set_stream(torch.cuda.current_stream().cuda_stream) would order the launches with torch's stream instead.)
+    stream_note = "context's own non-blocking stream; hand-over by torch.cuda.synchronize()"
     if use_gjk:
         ctx.set_polygons(ppts, poff)
         ctx.set_hull_pairs(pa, pb)
@@ -572,7 +578,7 @@ def main():
                                              "once per step for the others" if use_view
                                              else "written to HBM by obtg_fd_batch_dev each step"), P_t,
                                        "max_ang_rate+" if d == 2 else "", P_s),
-                       "launches_per_step": len(kernels), "streams": 2 if two_streams else 1,
+                       "launches_per_step": len(kernels), "streams": 2 if two_streams else 1, "stream": stream_note,
                        "ranks_seen": ranks_seen, "backend": (args.backend if use_dist else None), "devices": devices,
                        "gjk_status_note": status_note,
                        "evals_per_step_per_gpu": B, "alg_bytes_per_eval": total_bytes,

@@ -184,3 +184,16 @@ def test_bench_launcher_never_prints_a_multi_gpu_line_from_one_process():
     r = _run_bench(["--gpus", "2", "--steps", "1", "--warmup", "1", "--no-cpu"])
     assert r.returncode != 0 and r.stdout.strip() == ""
     assert r.stderr.count("no HIP device visible") == 2          # both ranks were started and both refused
+
+
+def test_bench_launcher_returns_the_failing_ranks_code():
+    """A rank that exits non-zero while the others still wait (as they would in a barrier): the launcher stops them and
+    returns THAT rank's code with its message -- whichever position the rank has in the launcher's iteration order."""
+    import time
+    for failing in (0, 1, 2):
+        t0 = time.time()
+        r = _run_bench(["--gpus", "3", "--steps", "1", "--warmup", "1", "--no-cpu"],
+                       {"OBTG_BENCH_REHEARSE_EXIT": "%d:7" % failing}, timeout=60)
+        assert r.returncode == 7, (failing, r.returncode, r.stderr)
+        assert "a rank exited with code 7" in r.stderr and "Traceback" not in r.stderr
+        assert time.time() - t0 < 30          # the waiting ranks were stopped, not waited for
