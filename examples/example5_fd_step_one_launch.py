@@ -86,7 +86,7 @@ def main(N=16, n=10, M=3, verbose=True):
         print("one launch for the whole finite-difference step: %.3f ms (%.1f MB of results left in HBM)"
               % (ms, sum(t.numel() * t.element_size() for t in (sep, sp, an, flag, p1, p2, dist, st)) / 1e6))
         print("Jacobians from it equal the per-family providers' (%.1f ms for the three on host arrays): %s" % (ms_ref, same))
-    ctx.set_stream(0)
+    ctx.use_own_stream()
     ctx.close()
     return same, ms
 

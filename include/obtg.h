@@ -94,10 +94,13 @@ int obtg_host_free(void* p);
 int obtg_ctx_create(obtg_ctx** out, int n_veh, int dim, int deg, int deg_elev,
                     int n_point_obs, const double* point_obs, int device);
 void obtg_ctx_destroy(obtg_ctx*);
-/* use an external HIP stream (e.g. torch's current stream) for every later call; NULL = the context's own stream, which
- * is created non-blocking: NOT ordered with the null stream.  A caller whose own work runs on the null stream (torch's
- * default stream has handle 0) passes hipStreamLegacy, (void*)1, to have the library's launches ordered with it. */
+/* Streams.  A context starts on a stream of its own, created non-blocking: NOT ordered with the null stream.
+ * obtg_ctx_set_stream: every later call goes to the caller's HIP stream, the handle taken as given -- NULL is the null
+ * stream itself, which is torch's default stream: a torch user who passes torch.cuda.current_stream().cuda_stream gets
+ * launches ordered with torch's own work whichever stream that is.  obtg_ctx_use_own_stream: back to the private stream.
+ * (Until round 4 NULL meant "own stream", and torch's default stream, handle 0, silently un-ordered a caller's work.) */
 int obtg_ctx_set_stream(obtg_ctx*, void* hip_stream);
+int obtg_ctx_use_own_stream(obtg_ctx*);
 /* DEG_ELEV is a module constant read at call time (optimization.py:17): allow changing it */
 int obtg_ctx_set_deg_elev(obtg_ctx*, int deg_elev);
 /* Angular rate with DEG_ELEV > 0 (optimization.py:578-611).  The reference elevates the position by R first and

@@ -35,6 +35,7 @@ _SIGNATURES = {
     "obtg_ctx_create": (_i, [C.POINTER(_vp), _i, _i, _i, _i, _i, _vp, _i]),
     "obtg_ctx_destroy": (None, [_vp]),
     "obtg_ctx_set_stream": (_i, [_vp, _vp]),
+    "obtg_ctx_use_own_stream": (_i, [_vp]),
     "obtg_ctx_set_deg_elev": (_i, [_vp, _i]),
     "obtg_ctx_set_ang_rate_order": (_i, [_vp, _i]),
     "obtg_ctx_set_second_speed_bound": (_i, [_vp, _d, _i, _vp]),
@@ -243,11 +244,10 @@ def pinned_empty(shape, dtype=np.float64):
 
 
 def torch_stream():
-    """HIP handle of torch's current stream, for Context.set_stream.  torch's DEFAULT stream is the legacy null stream,
-    whose handle is 0 -- which obtg_ctx_set_stream reads as "the context's own stream"; hipStreamLegacy (1) names the null
-    stream itself, so that the library's launches are ordered with torch's kernels (fills, copies) on it."""
+    """HIP handle of torch's current stream, for Context.set_stream (0 for torch's default stream, which IS the null
+    stream: obtg_ctx_set_stream takes the handle as given, so the library's launches are ordered with torch's own)."""
     import torch
-    return torch.cuda.current_stream().cuda_stream or 1
+    return torch.cuda.current_stream().cuda_stream
 
 
 class Context(object):
@@ -297,9 +297,13 @@ class Context(object):
         return self._h
 
     def set_stream(self, stream_ptr):
-        """Every later call goes to this HIP stream; 0 / None = the context's own stream (non-blocking: NOT ordered with
-        the null stream).  For torch's current stream pass torch_stream()."""
-        self._check(self._lib.obtg_ctx_set_stream(self._h, _vp(stream_ptr)), "obtg_ctx_set_stream")
+        """Every later call goes to this HIP stream, the handle as given: 0 / None = the null stream, i.e. torch's default
+        stream (torch.cuda.current_stream().cuda_stream is the right argument whichever stream is current)."""
+        self._check(self._lib.obtg_ctx_set_stream(self._h, _vp(stream_ptr or None)), "obtg_ctx_set_stream")
+
+    def use_own_stream(self):
+        """Back to the context's private stream (created non-blocking: not ordered with the null stream)."""
+        self._check(self._lib.obtg_ctx_use_own_stream(self._h), "obtg_ctx_use_own_stream")
 
     def set_deg_elev(self, R):
         self._check(self._lib.obtg_ctx_set_deg_elev(self._h, int(R)), "obtg_ctx_set_deg_elev")

@@ -46,6 +46,7 @@ struct NsParams {
                                       //   binp[R+2L-1+8] = C(R, m) for m = -(L-1) .. R+L-1+8 (0 outside 0..R)
                                       //   inv[L+R+8]    = 1 / C(2n+R, k) (0 past the end)
     const double* __restrict__ Td;    // dense elevation table, transposed: Td[k][j] = T[j][k], [L+R][L] (R > 0)
+    const double* __restrict__ Tf;    // the same matrix as v_mfma_f64_16x16x4 B fragments (tables.cpp elev_table_frag)
     double* __restrict__ out;
     int n_veh, n_obj, R;
     int item_begin, item_count;       // items of this launch (pairs or vehicles)
@@ -183,96 +184,177 @@ __device__ __forceinline__ void flush_chunk(const double* __restrict__ tile, dou
     }
 }
 
-// ---- degree elevation as a binomially scaled convolution, lane = item -----------------------------------------
-//     elev(a, Q)_k = (1 / C(P+Q, k)) sum_j [C(P, j) a_j] C(Q, k-j)
-// All output columns share ONE weight row C(Q, .): a block of kElevBlock columns walks a window of that row with
-// one wave-uniform scalar per step (kElevBlock independent FMA chains) instead of fetching P+1 weights per column.
-// Outputs leave through a per-wave LDS tile of kElevChunk columns so that stores are 256-byte runs.
-constexpr int kConvPad = 8;           // zero entries behind the padded binomial row and the 1/C(P+Q, .) row
-constexpr int kElevChunk = 32;
-constexpr int kElevBlock = 8;
+constexpr int kElevBlock = 8;          // zero entries behind the padded binomial rows of tables.cpp elev_conv_padded
+
+// ---- degree elevation as a matrix product on v_mfma_f64_16x16x4_f64 ------------------------------------------------
+//     out[row][k] = offset + sum_j a[row][j] T[j][k],   T = elevMatrix(LIN-1, R) (bezier.py:1127-1147), a = sign * coefficients
+// At R = 100 the matrix is 83 % dense (2121 of 2541 entries) and the batch kernels multiply [64 rows x LIN] blocks by it
+// on the matrix instruction: one instruction replaces 16 v_fma_f64 and the LDS broadcasts that fed them, and keeps the
+// FP64 units busy from ONE wave per SIMD (a wave alone issues a v_fma_f64 every 9 clocks, two waves one every 4.75;
+// tools/mfma_f64_probe.hip -- which also shows that the instruction takes 64 clocks, the time of its 16 v_fma_f64, and
+// that f64 vector work of another wave on the SIMD stands still meanwhile: it runs ON the FP64 vector units, so what it
+// buys is issue slots and operand traffic, not a second pipe).  The instruction is, bit for bit, a chain of fused
+// multiply-adds in ascending k from its C operand (the same probe: 12 800 of 12 800 results), so the lane-per-item forms
+// (elev_at below: k_tsep_fd, the minima, the structured step's fix-up rows) reproduce the batch exactly by running that
+// chain over a row of the dense table; zero entries of the band and of the padding add nothing (fma(x, 0, s) = s).
+typedef double v4d_t __attribute__((ext_vector_type(4)));
 
 template <int LIN>
-__device__ __forceinline__ void elev_store_chunk(const double* __restrict__ tile, double* __restrict__ gout, size_t grow,
-                                                 int LR, int k0, int kc, int n_valid, int lane)
+struct ElevMfma {
+    static constexpr int KS = (LIN + 3) / 4;          // k-steps of one output tile
+    static constexpr int PA = 4 * KS + 2;             // row pitch of the coefficient image: PA / 2 odd => the 32 lanes of a
+                                                      // ds_read_b64 group (16 rows x 2 k) fall on 32 different bank pairs
+    static constexpr int NTG = KS <= 6 ? 8 : 4;       // output tiles (16 columns each) per column group: B fragments and
+    static constexpr int CW = 16 * NTG;               // accumulators of a group live in registers (NTG * KS, NTG * 4 doubles)
+};
+
+// per-wave LDS of elev_rows_mfma: the coefficient image [64][PA], then (same place) the output tile [16][cw]
+__host__ __device__ constexpr int elev_mfma_wave_doubles(int LIN, int R)
 {
-    constexpr int TP = kElevChunk + 1;
-    if (kc == kElevChunk && n_valid == kWave) {
-        // full tile: 32 store instructions of 2 x 256-byte runs; the LDS reads go out eight at a time (one read,
-        // one wait, one store per trip left the loop bound by the LDS latency: 32 x ~100 cycles per chunk)
-        const int q = lane & (kElevChunk - 1), half = lane >> 5;
-        const double* t = tile + half * TP + q;
-        double* g = gout + grow + (size_t)half * LR + k0 + q;
+    const int KS = (LIN + 3) / 4, PA = 4 * KS + 2, CW = 16 * (KS <= 6 ? 8 : 4);
+    const int cw = LIN + R < CW ? LIN + R : CW;
+    return kWave * PA > 16 * cw ? kWave * PA : 16 * cw;
+}
+
+// one row in one lane: out_k = offset + sum_j a_j T[j][k] as the matrix instruction forms it; Tdk = row k of the dense
+// transposed table (wave-uniform k: scalar loads)
+template <int LIN>
+__device__ __forceinline__ double elev_at(const double (&a)[LIN], const ctab_t Tdk, const double offset)
+{
+    double s = offset;
 #pragma unroll
-        for (int it0 = 0; it0 < kWave / 2; it0 += 8) {
-            double v[8];
+    for (int j = 0; j < LIN; ++j) s = fma(a[j], Tdk[j], s);
+    return s;
+}
+
+// B fragments of the column group that starts at output tile t0.  Past the last tile the last one is read again: those
+// accumulators are never stored.  One wave-uniform base, the lane's offset, constant displacements: the loads need one
+// address register between them, not one pair each.
+template <int LIN>
+__device__ __forceinline__ void elev_load_bfrag(const double* __restrict__ Tf, const int t0, const int NT, const int lane,
+                                                double (&bfr)[ElevMfma<LIN>::NTG][ElevMfma<LIN>::KS])
+{
+    using E = ElevMfma<LIN>;
 #pragma unroll
-            for (int u = 0; u < 8; ++u) v[u] = t[(it0 + u) * 2 * TP];
+    for (int t = 0; t < E::NTG; ++t) {
+        const double* ft = Tf + (size_t)__builtin_amdgcn_readfirstlane(min(t0 + t, NT - 1)) * (E::KS * kWave);
 #pragma unroll
-            for (int u = 0; u < 8; ++u) store_nt(g + (size_t)(it0 + u) * 2 * LR, v[u]);
+        for (int s = 0; s < E::KS; ++s) bfr[t][s] = ft[s * kWave + lane];
+    }
+}
+
+// one output tile: acc = offset + A-tile x B-fragments of n-tile t; lane l holds rows (l >> 4) + 4 r, column 16 t + (l & 15).
+// (a chain of dependent instructions issues at the rate of independent ones -- 64 clocks either way, mfma_f64_probe --
+// so one accumulator per tile is enough and a 16-row tile needs 8 registers of them, not 8 per column tile)
+template <int LIN>
+__device__ __forceinline__ v4d_t elev_mfma_tile(const double (&afr)[ElevMfma<LIN>::KS], const double (&bfr)[ElevMfma<LIN>::KS],
+                                                const double offset)
+{
+    using E = ElevMfma<LIN>;
+    v4d_t acc;
+    acc[0] = offset; acc[1] = offset; acc[2] = offset; acc[3] = offset;
+#pragma unroll
+    for (int s = 0; s < E::KS; ++s) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(afr[s], bfr[s], acc, 0, 0, 0);
+    return acc;
+}
+
+// A fragments of rows 16 m .. 16 m + 15 of a coefficient image [64][PA] in LDS
+template <int LIN>
+__device__ __forceinline__ void elev_load_afrag(const double* img, const int m, const int lane, double (&afr)[ElevMfma<LIN>::KS])
+{
+    using E = ElevMfma<LIN>;
+    const double* rowp = img + (16 * m + (lane & 15)) * E::PA + (lane >> 4);
+#pragma unroll
+    for (int s = 0; s < E::KS; ++s) afr[s] = rowp[4 * s];
+}
+
+// this lane's row of the coefficient image (zero padded to 4 KS entries)
+template <int LIN>
+__device__ __forceinline__ void elev_store_image_row(double* img, const int r, const double (&a)[LIN])
+{
+    using E = ElevMfma<LIN>;
+#pragma unroll
+    for (int j = 0; j < 4 * E::KS; ++j) img[r * E::PA + j] = j < LIN ? a[j] : 0.0;
+}
+
+// the accumulator of n-tile t of a 16-row tile -> LDS tile [16][cw] (the output run itself when cw is the whole row)
+__device__ __forceinline__ void elev_acc_to_tile(const v4d_t acc, const int t, double* tile, const int cw, const int lane)
+{
+    const int c = 16 * t + (lane & 15), r0 = lane >> 4;
+    if (c < cw) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) tile[(r0 + 4 * r) * cw + c] = acc[r];
+    }
+}
+
+// `total` doubles of an LDS run -> gout[e0 ..): 16-byte stores, 16-byte aligned in memory; the LDS reads go out four at
+// a time (one read, one wait, one store per trip leaves the loop bound by the LDS latency)
+template <bool NT>
+__device__ __forceinline__ void store_run(const double* __restrict__ tile, double* __restrict__ gout, const size_t e0, const int total,
+                                          const int lane)
+{
+    const int shift = (int)(e0 & 1);
+    if (shift == 0 && (total & 1) == 0 && (reinterpret_cast<size_t>(tile) & 15) == 0) {
+        const d2_t* t2 = reinterpret_cast<const d2_t*>(tile);
+        d2_t* g2 = reinterpret_cast<d2_t*>(gout + e0);
+        const int np = total >> 1;
+        for (int m0 = lane; m0 < np; m0 += 4 * kWave) {
+            d2_t v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) if (m0 + u * kWave < np) v[u] = t2[m0 + u * kWave];
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (m0 + u * kWave < np) { if (NT) __builtin_nontemporal_store(v[u], g2 + m0 + u * kWave); else g2[m0 + u * kWave] = v[u]; }
         }
         return;
     }
-    if (kc == kElevChunk) {
-        for (int e = lane; e < n_valid * kElevChunk; e += kWave) {
-            const int pr = e / kElevChunk, q = e & (kElevChunk - 1);
-            store_nt(gout + grow + (size_t)pr * LR + k0 + q, tile[pr * TP + q]);
-        }
-        return;
-    }
-    for (int e = lane; e < n_valid * kc; e += kWave) {
-        const int pr = e / kc, q = e - pr * kc;
-        store_nt(gout + grow + (size_t)pr * LR + k0 + q, tile[pr * TP + q]);
+    const int npairs = (total + shift + 1) >> 1;
+    for (int m = lane; m < npairs; m += kWave) {
+        const int a0 = 2 * m - shift, a1 = a0 + 1;
+        if (a0 >= 0 && a1 < total) {
+            if (NT) store_nt2(gout + e0 + a0, tile[a0], tile[a1]);
+            else { d2_t v; v.x = tile[a0]; v.y = tile[a1]; *reinterpret_cast<d2_t*>(gout + e0 + a0) = v; }
+        } else if (a0 >= 0) gout[e0 + a0] = tile[a0];
+        else if (a1 < total) gout[e0 + a1] = tile[a1];
     }
 }
 
-// sa[i] = sum_j a[j] c[(k0+i) - j], i < kElevBlock, with cp = (padded row) + k0: cp[m] = c[k0 - (LIN-1) + m]
+// The elevated rows of ONE wave's group: lane r < n_valid holds row r's coefficients a[] (sign applied); rows are
+// contiguous in the output from element `e_row0` on, LR = LIN + R doubles each.  wl: elev_mfma_wave_doubles of LDS.
+// Four 16-row tiles; per tile NT x KS matrix instructions, the accumulators through the LDS tile -- the tile of a
+// whole-row group (LR <= CW) IS the output run of its 16 rows, 128-byte aligned whenever the output is -- and out as
+// linear 16-byte-per-lane stores.
 template <int LIN>
-__device__ __forceinline__ void conv_block2(const ctab_t cp, const double (&a)[LIN], const double (&b)[LIN],
-                                            double (&sa)[kElevBlock], double (&sb)[kElevBlock])
+__device__ __forceinline__ void elev_rows_mfma(const double (&a)[LIN], const bool mine, const int r, const double* __restrict__ Tf,
+                                               const int LR, const double offset, double* wl, double* __restrict__ gout,
+                                               const size_t e_row0, const int n_valid, const int lane)
 {
+    using E = ElevMfma<LIN>;
+    if (mine) elev_store_image_row<LIN>(wl, r, a);
+    wave_sync();
+    double afr[4][E::KS];
 #pragma unroll
-    for (int i = 0; i < kElevBlock; ++i) sa[i] = sb[i] = 0.0;
+    for (int m = 0; m < 4; ++m) elev_load_afrag<LIN>(wl, m, lane, afr[m]);
+    wave_sync();                                       // the image is dead: its place becomes the output tile
+    const int NT = (LR + 15) >> 4;
+    for (int t0 = 0; t0 < NT; t0 += E::NTG) {
+        const int c0 = 16 * t0, cw = min(LR - c0, E::CW);
+        double bfr[E::NTG][E::KS];
+        elev_load_bfrag<LIN>(Tf, t0, NT, lane, bfr);
 #pragma unroll
-    for (int m = 0; m < LIN - 1 + kElevBlock; ++m) {
-        const double c = cp[m];
+        for (int m = 0; m < 4; ++m) {
+            const int rows = min(16, n_valid - 16 * m);        // wave-uniform
+            if (rows > 0) {
 #pragma unroll
-        for (int i = 0; i < kElevBlock; ++i) {
-            const int j = i + LIN - 1 - m;
-            if (j >= 0 && j < LIN) { sa[i] = fma(c, a[j], sa[i]); sb[i] = fma(c, b[j], sb[i]); }
-        }
-    }
-}
-
-// the same walk with the window in registers (per-lane column block): w[m] = c[k0 - (LIN-1) + m]
-template <int LIN>
-__device__ __forceinline__ void conv_block1_reg(const double (&w)[LIN - 1 + kElevBlock], const double (&a)[LIN],
-                                                double (&sa)[kElevBlock])
-{
-#pragma unroll
-    for (int i = 0; i < kElevBlock; ++i) sa[i] = 0.0;
-#pragma unroll
-    for (int m = 0; m < LIN - 1 + kElevBlock; ++m) {
-#pragma unroll
-        for (int i = 0; i < kElevBlock; ++i) {
-            const int j = i + LIN - 1 - m;
-            if (j >= 0 && j < LIN) sa[i] = fma(w[m], a[j], sa[i]);
-        }
-    }
-}
-
-template <int LIN>
-__device__ __forceinline__ void conv_block1(const ctab_t cp, const double (&a)[LIN], double (&sa)[kElevBlock])
-{
-#pragma unroll
-    for (int i = 0; i < kElevBlock; ++i) sa[i] = 0.0;
-#pragma unroll
-    for (int m = 0; m < LIN - 1 + kElevBlock; ++m) {
-        const double c = cp[m];
-#pragma unroll
-        for (int i = 0; i < kElevBlock; ++i) {
-            const int j = i + LIN - 1 - m;
-            if (j >= 0 && j < LIN) sa[i] = fma(c, a[j], sa[i]);
+                for (int t = 0; t < E::NTG; ++t) elev_acc_to_tile(elev_mfma_tile<LIN>(afr[m], bfr[t], offset), t, wl, cw, lane);
+                wave_sync();
+                if (cw == LR) store_run<false>(wl, gout, e_row0 + (size_t)(16 * m) * LR, rows * LR, lane);
+                else {
+                    for (int q = 0; q < rows; ++q)             // a run of cw doubles per row
+                        for (int kc = lane; kc < cw; kc += kWave) gout[e_row0 + (size_t)(16 * m + q) * LR + c0 + kc] = wl[q * cw + kc];
+                }
+                wave_sync();
+            }
         }
     }
 }
@@ -292,7 +374,8 @@ struct TsepXYParams {
     double* __restrict__ out;         // [B][n_pairs][2n+1]; nullptr = no temporal work
     int n_pairs;
     double sign, offset;
-    const double* __restrict__ Tt;    // DEG_ELEV > 0 (structured step): elevation as a scaled convolution (NsParams::Tt)
+    const double* __restrict__ Td;    // DEG_ELEV > 0 (structured step): the elevation matrix, dense rows and matrix-instruction
+    const double* __restrict__ Tf;    // fragments (NsParams::Td, ::Tf)
     int R;
     int n_veh, obs_shift;             // pairs may name point obstacles (object ids >= n_veh, optimization.py:86-98): those are
                                       // staged obs_shift slots further on (behind the polygons of the hull sweep); 0, 0: none
@@ -402,23 +485,24 @@ __device__ __forceinline__ void tsep_rows_of_vehicle(const TsepXYParams& t, cons
 }
 
 // Structured finite-difference step with DEG_ELEV = R > 0 (gjk_kernels.hip k_step_fd_structured<NC, true>), row 0's part:
-// the workgroup (four waves) evaluates the 64-pair group g of the staged row -- wave 0 the products, scaled, into chT;
-// then every wave its share of the passes of rpp rows x all 2n+R+1 columns, exactly as normsq_elev_body's full-row form
-// does (lane = (row of the pass, block of 8 columns), window of the binomial row in registers, conv_block1_reg) -- and
-// streams each pass from its output tile into every batch row b0 <= b < b1, leaving out the rows of pairs that contain
-// batch row b's own vehicle (fd_element).  chT: [64][2n+1] doubles, otile_base: 4 x rpp x nb2 x 9 doubles.
+// the workgroup (four waves) evaluates the 64-pair group g of the staged row -- wave 0 the products, as the coefficient
+// image of elev_rows_mfma; then wave w the elevation of rows 16 w .. 16 w + 15 on the matrix instruction, exactly as
+// normsq_elev_body's full-row form does -- and streams its 16 rows from the output tile, through registers, into every
+// batch row b0 <= b < b1, leaving out the rows of pairs that contain batch row b's own vehicle (fd_element).
+// img: [64][PA] doubles of LDS; tiles: 4 x 16 x min(LR, CW) doubles that MAY overlay img and everything before it (the
+// staged row is dead once the products exist, the image once every wave holds its fragments): two workgroup barriers.
 template <int NC>
 __device__ __forceinline__ void tsep_elev_group_stream(const TsepXYParams& t, const double2* xy, const int vpq, const int g,
-                                                       double* chT, double* otile_base, const int b0, const int b1,
+                                                       double* img, double* tiles, const int b0, const int b1,
                                                        const int fd, const int fd_fixed)
 {
     using S = NsShape<NC, 2>;
     constexpr int L = S::L;
+    using E = ElevMfma<L>;
     const int LR = L + t.R;
-    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6, n_waves = blockDim.x >> 6;
+    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
     const int itg = g * kWave;
     const int n_valid = min(kWave, t.n_pairs - itg);
-    const ctab_t escale = as_ctab(t.Tt);
     if (wave == 0) {
         const int item = min(itg + lane, t.n_pairs - 1);
         const int2 ij = t.pairs[item];
@@ -433,83 +517,52 @@ __device__ __forceinline__ void tsep_elev_group_stream(const TsepXYParams& t, co
         }
         double cf[L];
         normsq_coeffs<NC, 2>(a, as_ctab(t.W2), cf);
-        if (lane < n_valid) {
 #pragma unroll
-            for (int j = 0; j < L; ++j) chT[lane * L + j] = cf[j] * escale[j];
-        }
+        for (int j = 0; j < L; ++j) cf[j] *= t.sign;
+        if (lane < n_valid) elev_store_image_row<L>(img, lane, cf);
     }
     __syncthreads();
-    const double* ebin_g = t.Tt + L;
-    const double* einv_g = ebin_g + (t.R + 2 * L - 1 + kConvPad);
-    const int nblk = (LR + kElevBlock - 1) / kElevBlock;        // <= 64 (the launcher checks 2n + R + 1 <= 512)
-    int nb2 = 1;
-    while (nb2 < nblk) nb2 <<= 1;
-    const int rpp = kWave / nb2;                                 // rows per pass
-    const int cb = lane & (nb2 - 1), rs = lane / nb2;
-    constexpr int BP = kElevBlock + 1;
-    const int opitch = nb2 * BP;
-    double* otile = otile_base + wave * (rpp * opitch);
-    const bool colv = cb < nblk;
-    double w[L - 1 + kElevBlock], inv8[kElevBlock];
+    double afr[E::KS];
+    elev_load_afrag<L>(img, wave, lane, afr);
+    __syncthreads();
+    const int rows = min(16, n_valid - 16 * wave);                  // wave-uniform
+    if (rows <= 0) return;
+    const int NT = (LR + 15) >> 4;
+    const int cw_max = min(LR, E::CW);
+    double* tile = tiles + wave * (16 * cw_max);
+    constexpr int kMaxV = E::CW / 4;                                 // 16 x CW doubles over 64 lanes
+    const int prow0 = itg + 16 * wave;
+    for (int t0 = 0; t0 < NT; t0 += E::NTG) {
+        const int c0 = 16 * t0, cw = min(LR - c0, E::CW);
+        double bfr[E::NTG][E::KS];
+        elev_load_bfrag<L>(t.Tf, t0, NT, lane, bfr);
 #pragma unroll
-    for (int m = 0; m < L - 1 + kElevBlock; ++m) w[m] = colv ? ebin_g[cb * kElevBlock + m] : 0.0;
-#pragma unroll
-    for (int i = 0; i < kElevBlock; ++i) inv8[i] = colv ? einv_g[cb * kElevBlock + i] : 0.0;
-    for (int r0 = wave * rpp; r0 < n_valid; r0 += n_waves * rpp) {
-        const int rr = r0 + rs;
-        if (rr < n_valid && colv) {
-            double ch[L], sa[kElevBlock];
-#pragma unroll
-            for (int j = 0; j < L; ++j) ch[j] = chT[rr * L + j];
-            conv_block1_reg<L>(w, ch, sa);
-            double* o = otile + rs * opitch + cb * BP;
-#pragma unroll
-            for (int i = 0; i < kElevBlock; ++i) o[i] = t.sign * (sa[i] * inv8[i]) + t.offset;
-        }
+        for (int tt = 0; tt < E::NTG; ++tt) elev_acc_to_tile(elev_mfma_tile<L>(afr, bfr[tt], t.offset), tt, tile, cw, lane);
         wave_sync();
-        const int rows = min(rpp, n_valid - r0);
-        // the pass's rows are one contiguous run of rows x (2n+R+1) doubles in every batch row: written back to back per
-        // batch row (the L2 merges the lines neighbouring rows share), from registers (each lane keeps its columns)
-        // (the pass as ONE run in 16-byte pieces with a per-element pair test, the R = 0 stream's form: bit-identical, 0.90
-        // instead of 0.84 ms at C5 on the same box -- the per-piece predicates cost more than the wider stores save; with
-        // non-temporal stores 0.92, and the 8-byte form below with non-temporal stores 0.89)
-        constexpr int kMaxRows = 8, kMaxCols = 4;                                   // rpp <= 8 (LR > 56), ceil(LR / 64) <= 4 (LR <= 256); else the LDS form below
-        if (rows <= kMaxRows && LR <= kMaxCols * kWave) {
-            double v[kMaxRows][kMaxCols];
-            int pi[kMaxRows], pj[kMaxRows];
+        // element e = lane + 64 i of the tile's rows x cw run: value, its (row, column) and its pair, kept in registers
+        const int n_el = rows * cw;
+        double v[kMaxV];
+        int pr[kMaxV], off[kMaxV];
 #pragma unroll
-            for (int q = 0; q < kMaxRows; ++q) {
-                const int2 ij = q < rows ? t.pairs[itg + r0 + q] : make_int2(-2, -2);    // wave-uniform
-                pi[q] = ij.x; pj[q] = ij.y;
-#pragma unroll
-                for (int cc = 0; cc < kMaxCols; ++cc) {
-                    const int kc = lane + cc * kWave;
-                    v[q][cc] = (q < rows && kc < LR) ? otile[q * opitch + (kc >> 3) * BP + (kc & 7)] : 0.0;
-                }
+        for (int i = 0; i < kMaxV; ++i) {
+            const int e = lane + kWave * i;
+            v[i] = 0.0; pr[i] = -1; off[i] = 0;
+            if (e < n_el) {
+                const int q = e / cw, kc = e - q * cw;
+                const int2 ij = t.pairs[prow0 + q];
+                pr[i] = ij.x | (ij.y << 16);
+                off[i] = q * LR + c0 + kc;
+                v[i] = tile[e];
             }
-            for (int b = b0; b < b1; ++b) {
-                const int fd_e = fd_element(fd, fd_fixed, NC, b);
-                const int vb = fd_e >= 0 ? fd_e / (2 * NC) : -1;
-                double* gp = t.out + ((size_t)b * t.n_pairs + (size_t)(itg + r0)) * LR + lane;
+        }
+        for (int b = b0; b < b1; ++b) {
+            const int fd_e = fd_element(fd, fd_fixed, NC, b);
+            const int vb = fd_e >= 0 ? fd_e / (2 * NC) : -1;
+            double* gp = t.out + ((size_t)b * t.n_pairs + (size_t)prow0) * LR;
 #pragma unroll
-                for (int q = 0; q < kMaxRows; ++q) {
-                    if (q < rows && pi[q] != vb && pj[q] != vb) {                    // (a pair of row b's own vehicle: its workgroup writes it)
-#pragma unroll
-                        for (int cc = 0; cc < kMaxCols; ++cc)
-                            if (lane + cc * kWave < LR) gp[(size_t)q * LR + cc * kWave] = v[q][cc];
-                    }
-                }
-            }
-        } else {
-            for (int b = b0; b < b1; ++b) {
-                const int fd_e = fd_element(fd, fd_fixed, NC, b);
-                const int vb = fd_e >= 0 ? fd_e / (2 * NC) : -1;
-                for (int q = 0; q < rows; ++q) {
-                    const int2 ij = t.pairs[itg + r0 + q];
-                    if (ij.x == vb || ij.y == vb) continue;
-                    double* gp = t.out + ((size_t)b * t.n_pairs + (size_t)(itg + r0 + q)) * LR;
-                    for (int kc = lane; kc < LR; kc += kWave) gp[kc] = otile[q * opitch + (kc >> 3) * BP + (kc & 7)];
-                }
+            for (int i = 0; i < kMaxV; ++i) {
+                // (a pair of row b's own vehicle: its workgroup writes it)
+                if (pr[i] >= 0 && (pr[i] & 0xffff) != vb && (pr[i] >> 16) != vb) gp[off[i]] = v[i];
             }
         }
         wave_sync();
@@ -517,7 +570,7 @@ __device__ __forceinline__ void tsep_elev_group_stream(const TsepXYParams& t, co
 }
 
 // ... and a perturbed row's part with DEG_ELEV > 0: the elevated separation rows of every pair that contains vehicle v of
-// row b, one pair per lane, each lane its own run (the arithmetic of k_tsep_fd's elevated form, which equals the batch's).
+// row b, one pair per lane, each lane its own run (elev_at: the chain of the matrix instruction, hence the batch's bits).
 template <int NC>
 __device__ __forceinline__ void tsep_elev_rows_of_vehicle(const TsepXYParams& t, const double2* xy, const int vpq, const int b,
                                                           const int n_veh, const int v)
@@ -525,7 +578,7 @@ __device__ __forceinline__ void tsep_elev_rows_of_vehicle(const TsepXYParams& t,
     using S = NsShape<NC, 2>;
     constexpr int L = S::L;
     const int LR = L + t.R;
-    const ctab_t escale = as_ctab(t.Tt), ebin = escale + L, einv = ebin + (t.R + 2 * L - 1 + kConvPad);
+    const ctab_t Td = as_ctab(t.Td);
     for (int u0 = threadIdx.x; u0 < n_veh - 1; u0 += blockDim.x) {
         const int u = u0 < v ? u0 : u0 + 1;
         const int i = min(u, v), j = max(u, v);
@@ -541,17 +594,10 @@ __device__ __forceinline__ void tsep_elev_rows_of_vehicle(const TsepXYParams& t,
         }
         double cf[L];
         normsq_coeffs<NC, 2>(a, as_ctab(t.W2), cf);
-        double ch[L];
 #pragma unroll
-        for (int jj = 0; jj < L; ++jj) ch[jj] = cf[jj] * escale[jj];
+        for (int jj = 0; jj < L; ++jj) cf[jj] *= t.sign;
         double* o = t.out + ((size_t)b * t.n_pairs + q) * LR;
-        for (int k = 0; k < LR; k += kElevBlock) {
-            double sa[kElevBlock];
-            conv_block1<L>(ebin + k, ch, sa);
-#pragma unroll
-            for (int ii = 0; ii < kElevBlock; ++ii)
-                if (k + ii < LR) o[k + ii] = t.sign * (sa[ii] * einv[k + ii]) + t.offset;
-        }
+        for (int k = 0; k < LR; ++k) o[k] = elev_at<L>(cf, Td + k * L, t.offset);
     }
 }
 
@@ -607,13 +653,6 @@ __device__ __forceinline__ void tsep_tile_from_xy(const TsepXYParams& t, const d
     }
 }
 
-// per-wave LDS of the elevated full-row form: the scaled products of HALF a 64-item group (the lanes keep theirs in
-// registers and hand them over 32 rows at a time) and the 64 x 9 output tile of a pass.  32 instead of 64 rows: 10 instead of
-// 15 KB per wave, three workgroups of four waves per CU instead of two at C5 (measured: the same 0.52 ms -- the kernel is
-// bound by its 968-byte rows' write rate, not by occupancy; kept for the LDS it leaves to others)
-constexpr int kElevHalfRows = 32;
-__host__ __device__ constexpr int ns_elev_tile_doubles(int L) { return kElevHalfRows * L + kWave * (kElevBlock + 1); }
-
 // (b, w) = evaluation row and workgroup index inside the row; lds = the workgroup's dynamic LDS.
 // A device function so that the pair sweep can run it next to the GJK workgroups in ONE launch
 // (gjk_kernels.hip k_pair_sweep); k_normsq_elev below is the stand-alone kernel.
@@ -630,7 +669,8 @@ __device__ __forceinline__ void normsq_elev_body(const NsParams& p, const int b,
 
     // LDS: [staged objects: stage_slots * VP][per-wave transposition tiles]
     double* vl = lds;
-    double* tile = lds + p.stage_slots * S::VP + wave * (ELEV ? ns_elev_tile_doubles(S::L) : p.tile_rows * S::TPF);
+    double* tile = ELEV ? lds + ((p.stage_slots * S::VP + 1) & ~1) + wave * elev_mfma_wave_doubles(S::L, p.R)   // (16-byte aligned)
+                        : lds + p.stage_slots * S::VP + wave * (p.tile_rows * S::TPF);
 
     // ---- stage the objects this workgroup touches
     const double* Yrow = p.fd ? p.Y : p.Y + (size_t)b * p.n_veh * S::VLEN;
@@ -752,88 +792,168 @@ __device__ __forceinline__ void normsq_elev_body(const NsParams& p, const int b,
                 }
             }
         } else {
+            // elev(R) (bezier.py:469-495, 1127-1147) as the matrix product of the group's [64 x L] coefficients with the
+            // elevation matrix, output transform folded in: out = offset + sum_j (sign c_j) T[j][k]
+            double ch[L];
+#pragma unroll
+            for (int j = 0; j < L; ++j) ch[j] = p.sign * cf[j];
             if (MINONLY) {
-                // elev(R) as a binomially scaled convolution (bezier.py:1127-1147 written out):
-                //   out_k = (1/C(2n+R,k)) * sum_j [C(2n,j) c_j] * C(R, k-j)
-                // only the minimum over k leaves the lane
-                const ctab_t escale = as_ctab(p.Tt), ebin = escale + L, einv = ebin + (p.R + 2 * L - 1 + kConvPad);
-                double ch[L];
-#pragma unroll
-                for (int j = 0; j < L; ++j) ch[j] = cf[j] * escale[j];
+                // only the row's minimum leaves the lane: the same chain per output column, a row of the dense table
+                // as scalar operands
+                const ctab_t Td = as_ctab(p.Td);
                 double m = INFINITY;
-                for (int k = 0; k < LR; ++k) {
-                    const ctab_t win = ebin + k;              // win[L-1-j] = C(R, k-j)
-                    double s = 0.0;
-#pragma unroll
-                    for (int j = 0; j < L; ++j) s = fma(ch[j], win[L - 1 - j], s);
-                    m = fmin(m, s * einv[k]);
-                }
-                if (mine) p.out[row + r] = p.sign * m + p.offset;
+                for (int k = 0; k < LR; ++k) m = fmin(m, elev_at<L>(ch, Td + k * L, p.offset));
+                if (mine) p.out[row + r] = m;
             } else {
-                // Full elevated rows.  The wave's pre-scaled product coefficients go to LDS (64 x L); then the lane <->
-                // data mapping changes to lane = (row of a pass, block of 8 output columns): a pass covers `rpp` = 64 /
-                // nb2 rows x all columns, the lane keeps the window of the binomial row its 8 columns need in registers
-                // for the whole kernel and reads its row's L coefficients as LDS broadcasts -- 8 FMAs per LDS operand --
-                // and a pass's rows, contiguous in the output, leave through a small tile as ONE linear run of 16-byte
-                // stores.  (Earlier forms: lane = output column with 2 columns per lane was bound by the LDS pipe, 0.65 ms
-                // at C5; lane = item with 32-column chunks wrote 256-byte pieces of 968-byte rows: 0.87-1.24 ms.)
-                const ctab_t escale = as_ctab(p.Tt);
-                const double* ebin_g = p.Tt + L;
-                const double* einv_g = ebin_g + (p.R + 2 * L - 1 + kConvPad);
-                const int nblk = (LR + kElevBlock - 1) / kElevBlock;
-                int nb2 = 1;
-                while (nb2 < nblk && nb2 < kWave) nb2 <<= 1;
-                const int rpp = kWave / nb2;                       // rows per pass
-                const int cb = lane & (nb2 - 1), rs = lane / nb2;
-                double* chT = tile;                                // [kElevHalfRows][L]
-                // output tile of a pass: row q, column block c, column i of the block at q * opitch + c * 9 + i -- the
-                // pitch of 9 doubles per 8-column block keeps the 16 lanes of a row on 16 different bank pairs (at
-                // pitch 8 they fall on 4: PMC showed 60 % of the LDS cycles of this loop as bank conflicts).
-                // Ordinary write-back stores: a row is 8 LR bytes, not a multiple of the 128-byte line, so neighbouring
-                // store instructions share lines and the L2 has to merge them -- with non-temporal stores the same loop
-                // ran 0.65 instead of 0.55 ms at C5 (2.26 GB of output per launch).
-                constexpr int BP = kElevBlock + 1;
-                double* otile = tile + kElevHalfRows * L;          // [rpp][nb2 * 9]
-                const int opitch = nb2 * BP;
-                for (int cg = 0; cg < nblk; cg += nb2) {            // column groups (one unless LR > 512)
-                    const int blk = cg + cb;
-                    const bool colv = blk < nblk;
-                    double w[L - 1 + kElevBlock], inv8[kElevBlock];
+                // (history at C5, R = 100, 2.26 GB per launch: lane = output column with LDS broadcasts 0.65 ms; lane = item with
+                // 32-column chunks 0.87-1.24; lane = (row, 8 columns) with the binomial window in registers 0.52-0.55; this form: section 4.1 of DESIGN.md)
+                elev_rows_mfma<L>(ch, mine, r, p.Tf, LR, p.offset, tile, p.out, row * LR, n_valid, lane);
+            }
+        }
+    }
+}
+
+// =====================================================================================
+//  DEG_ELEV > 0, the batch form: elevated separation rows with the elevation matrix STATIONARY in the waves' registers
+// =====================================================================================
+// normsq_elev_body's elevated form gives every wave its own 64 rows and all of the matrix (NTG x KS fragments, 96
+// registers at degree 10): with the four tiles' A fragments it does not fit 256 registers, and every reload -- spilled
+// register, fragment, pair index -- is a vector-memory LOAD in a loop that streams stores: s_waitcnt vmcnt counts both, so
+// the wave drains its stores once per 16-row tile (0.445 ms at C5, matrix pipe 40 % busy).  Here a workgroup of four
+// waves works on ONE 16-row tile at a time and wave w owns output tiles t = w, w + 4, ... of it: its share of the matrix is
+// NTW x KS fragments (24 registers), loaded once.  A set is four 64-row groups: wave w forms the product coefficients of
+// group w (lane = pair, kept in its registers); then, tile after tile, the owning wave puts the tile's 16 rows into a
+// small A buffer, every wave runs its KS-instruction chains on them and writes its 16 x 16 blocks into the shared output
+// tile -- the output run of the 16 rows, 128-byte aligned when the output is -- and all 256 threads copy it out as linear
+// 16-byte stores.  A buffer and tile are double buffered: one workgroup barrier per tile.  Nothing is loaded from memory
+// inside the loop (pair indices wait in LDS), so no wave ever waits for a store.
+template <int LIN>
+struct ElevCoop {
+    using E = ElevMfma<LIN>;
+    static constexpr int ABUF = 16 * E::PA;               // doubles of one A buffer: 16 rows, pitch PA
+    static __host__ __device__ constexpr int tile_doubles(int LR) { return (16 * LR + 1) & ~1; }
+    // doubles of LDS behind the staged objects: 2 A buffers, 2 tiles; the pair indices (4 bytes each) follow
+    static __host__ __device__ constexpr int lds_doubles(int LR) { return 2 * ABUF + 2 * tile_doubles(LR); }
+};
+
+// `total` doubles of an LDS run -> gout[e0 ..), all threads of the workgroup, 16-byte stores
+__device__ __forceinline__ void store_run_wg(const double* __restrict__ tile, double* __restrict__ gout, const size_t e0, const int total)
+{
+    const int tid = threadIdx.x, nthr = blockDim.x;
+    const int shift = (int)(e0 & 1);
+    if (shift == 0 && (total & 1) == 0) {
+        const d2_t* t2 = reinterpret_cast<const d2_t*>(tile);
+        d2_t* g2 = reinterpret_cast<d2_t*>(gout + e0);
+        const int np = total >> 1;
+        for (int m0 = tid; m0 < np; m0 += 4 * nthr) {
+            d2_t v[4];
 #pragma unroll
-                    for (int m = 0; m < L - 1 + kElevBlock; ++m) w[m] = colv ? ebin_g[blk * kElevBlock + m] : 0.0;
+            for (int u = 0; u < 4; ++u) if (m0 + u * nthr < np) v[u] = t2[m0 + u * nthr];
 #pragma unroll
-                    for (int i = 0; i < kElevBlock; ++i) inv8[i] = colv ? einv_g[blk * kElevBlock + i] : 0.0;
-                    const int c_lo = cg * kElevBlock, c_n = min(LR - c_lo, nb2 * kElevBlock);   // columns of this group
-                    for (int hb = 0; hb < n_valid; hb += kElevHalfRows) {   // the group's rows, half a wave at a time
-                    const int nh = min(kElevHalfRows, n_valid - hb);
-                    if (mine && r >= hb && r < hb + kElevHalfRows) {
+            for (int u = 0; u < 4; ++u) if (m0 + u * nthr < np) g2[m0 + u * nthr] = v[u];
+        }
+        return;
+    }
+    const int npairs = (total + shift + 1) >> 1;
+    for (int m = tid; m < npairs; m += nthr) {
+        const int a0 = 2 * m - shift, a1 = a0 + 1;
+        if (a0 >= 0 && a1 < total) { d2_t v; v.x = tile[a0]; v.y = tile[a1]; *reinterpret_cast<d2_t*>(gout + e0 + a0) = v; }
+        else if (a0 >= 0) gout[e0 + a0] = tile[a0];
+        else if (a1 < total) gout[e0 + a1] = tile[a1];
+    }
+}
+
+// Keep a value that came from memory in its register, waited for HERE: a load left pending across a loop's back edge makes
+// the first use in every iteration an s_waitcnt vmcnt(0) -- which also waits for every store the wave has issued.
+__device__ __forceinline__ void pin_reg(double& x) { asm volatile("" : "+v"(x)); }
+
+// (b, w) = evaluation row and workgroup index inside the row, as normsq_elev_body; MODE 0 (pairs), every object of the row
+// staged (p.stage_all), 2n + R + 1 <= 64 NTW columns, object ids below 65536.  blockDim.x == 256.
+template <int NC, int DIM, int NTW>
+__device__ __forceinline__ void sep_elev_coop_body(const NsParams& p, const int b, const int w, double* lds)
+{
+    using S = NsShape<NC, DIM>;
+    constexpr int L = S::L;
+    using E = ElevMfma<L>;
+    using C = ElevCoop<L>;
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int LR = L + p.R, NT = (LR + 15) >> 4;
+    const int chunk = kWave * p.groups_per_wg;
+    const int it0 = p.item_begin + w * chunk;
+    const int it_end = min(p.item_begin + p.item_count, it0 + chunk);
+    if (it0 >= it_end) return;
+    const int n_items = it_end - it0;
+
+    double* vl = lds;
+    double* abuf = lds + ((p.stage_slots * S::VP + 1) & ~1);
+    double* tiles = abuf + 2 * C::ABUF;
+    const int tile_d = C::tile_doubles(LR);
+    unsigned* pr = reinterpret_cast<unsigned*>(tiles + 2 * tile_d);          // [n_items] i | j << 16
+
+    const double* Yrow = p.fd ? p.Y : p.Y + (size_t)b * p.n_veh * S::VLEN;
+    const int fd_e = fd_element(p.fd, p.fd_fixed, NC, b);
+    stage_objects<NC, DIM>(vl, Yrow, p.obs, p.n_veh, 0, p.n_obj, 0, threadIdx.x, blockDim.x, fd_e, p.fd_h);
+    for (int e = threadIdx.x; e < n_items; e += blockDim.x) {
+        const int2 ij = p.pairs[it0 + e];
+        pr[e] = (unsigned)ij.x | ((unsigned)ij.y << 16);
+    }
+    double bfr[NTW][E::KS];
 #pragma unroll
-                        for (int j = 0; j < L; ++j) chT[(r - hb) * L + j] = cf[j] * escale[j];
-                    }
-                    wave_sync();
-                    for (int r0 = 0; r0 < nh; r0 += rpp) {
-                        const int rr = r0 + rs;
-                        if (rr < nh && colv) {
-                            double ch[L], sa[kElevBlock];
+    for (int i = 0; i < NTW; ++i) {
+        const double* f = p.Tf + (size_t)min(wave + 4 * i, NT - 1) * (E::KS * kWave);
 #pragma unroll
-                            for (int j = 0; j < L; ++j) ch[j] = chT[rr * L + j];
-                            conv_block1_reg<L>(w, ch, sa);
-                            double* o = otile + rs * opitch + cb * BP;
+        for (int sx = 0; sx < E::KS; ++sx) bfr[i][sx] = f[sx * kWave + lane];
+    }
 #pragma unroll
-                            for (int i = 0; i < kElevBlock; ++i) o[i] = p.sign * (sa[i] * inv8[i]) + p.offset;
-                        }
-                        wave_sync();
-                        const int rows = min(rpp, nh - r0);
-                        // (as 16-byte pieces -- rows of an odd length start on odd elements every other time -- 0.65 instead of 0.54 ms at C5)
-                        for (int q = 0; q < rows; ++q) {            // each row: a run of c_n doubles, 512 bytes per store instruction
-                            double* g = p.out + (row + hb + r0 + q) * LR + c_lo;
-                            for (int kc = lane; kc < c_n; kc += kWave) g[kc] = otile[q * opitch + (kc >> 3) * BP + (kc & 7)];
-                        }
-                        wave_sync();
-                    }
-                    }
+    for (int i = 0; i < NTW; ++i)
+#pragma unroll
+        for (int sx = 0; sx < E::KS; ++sx) pin_reg(bfr[i][sx]);
+    __syncthreads();
+
+    const int n_groups = (n_items + kWave - 1) >> 6;
+    const size_t row0 = (size_t)b * p.item_count + (size_t)(it0 - p.item_begin);
+    int cnt = 0;                                          // tiles so far: parity of the A buffer and of the output tile
+    for (int g0 = 0; g0 < n_groups; g0 += 4) {
+        // ---- this wave's group of the set: product coefficients, sign applied, in registers
+        double ch[L];
+        {
+            const int e = min((g0 + wave) * kWave + lane, n_items - 1);      // (waves beyond the last group, lanes beyond the last pair: a valid pair, never stored)
+            const unsigned pij = pr[e];
+            const double* vi = vl + (int)(pij & 0xffffu) * S::VP;
+            const double* vj = vl + (int)(pij >> 16) * S::VP;
+            double a[DIM][NC];
+#pragma unroll
+            for (int q = 0; q < DIM; ++q)
+#pragma unroll
+                for (int c = 0; c < NC; ++c) a[q][c] = vi[q * NC + c] - vj[q * NC + c];
+            double cf[L];
+            normsq_coeffs<NC, DIM>(a, as_ctab(p.W2), cf);
+#pragma unroll
+            for (int j = 0; j < L; ++j) ch[j] = p.sign * cf[j];
+        }
+        const int set_tiles = 4 * min(4, n_groups - g0);
+        // rows of the set's first tile (group g0, rows 0..15: wave 0, lanes 0..15)
+        if (wave == 0 && lane < 16) elev_store_image_row<L>(abuf + (cnt & 1) * C::ABUF, lane, ch);
+        __syncthreads();
+        for (int mt = 0; mt < set_tiles; ++mt, ++cnt) {
+            const int gg = mt >> 2, m = mt & 3;
+            const int rows = min(16, n_items - (g0 + gg) * kWave - 16 * m);      // uniform over the workgroup
+            double* tile = tiles + (cnt & 1) * tile_d;
+            // the NEXT tile's rows into the other A buffer (its last readers passed the previous barrier)
+            if (mt + 1 < set_tiles && wave == ((mt + 1) >> 2) && (lane >> 4) == ((mt + 1) & 3))
+                elev_store_image_row<L>(abuf + ((cnt + 1) & 1) * C::ABUF, lane & 15, ch);
+            if (rows > 0) {
+                double afr[E::KS];
+                elev_load_afrag<L>(abuf + (cnt & 1) * C::ABUF, 0, lane, afr);
+#pragma unroll
+                for (int i = 0; i < NTW; ++i) {
+                    const int t = wave + 4 * i;
+                    if (t < NT) elev_acc_to_tile(elev_mfma_tile<L>(afr, bfr[i], p.offset), t, tile, LR, lane);
                 }
             }
+            __syncthreads();
+            if (rows > 0) store_run_wg(tile, p.out, (row0 + (size_t)((g0 + gg) * kWave + 16 * m)) * LR, rows * LR);
         }
     }
 }
@@ -1139,106 +1259,207 @@ struct AngElevParams {
     int R;
 };
 
+// LDS doubles of dynamics_elev_group: the two binomial rows as the matrix instruction's B operand reads them, and 1/C(2n+R, .)
+__host__ __device__ constexpr int dyn_elev_lds_doubles(int n, int R)
+{
+    const int L2 = 2 * n + 1, L4 = 4 * n + 1;
+    const int pad4 = 4 * ((L4 + 3) / 4) + 4, pad2 = 4 * ((L2 + 3) / 4) + 4;
+    const int nt4 = (L4 + 4 * R + 15) / 16, nt2 = (L2 + R + 15) / 16;
+    return (pad4 + 16 * nt4) + (pad2 + 16 * nt2) + 16 * nt2;
+}
+
+// Angular rate and speed rows with DEG_ELEV = R > 0 for the 64 items of `group`, four waves; wave w takes items 16 w ..
+// 16 w + 15.  Phase A (registers): the degree-4n numerator and denominator and the degree-2n speed curve of the lane's
+// item from the ORIGINAL control points, as k_dynamics2 forms them -- four lanes per item, lane (c, kg) = item c of the
+// tile, coefficients j = kg mod 4: exactly the A operand of v_mfma_f64_16x16x4_f64, no transposition.  Phase B: the two
+// elevations by 4R (and the speed curve's by R) as matrix products.  Elevation is a binomially scaled convolution,
+//     elev(a, Q)_k = (1 / C(P+Q, k)) sum_j [C(P, j) a_j] C(Q, k-j),
+// so with the coefficients pre-scaled by C(P, j) the B operand is a TOEPLITZ matrix, B[j][k] = C(Q, k-j): fragment
+// (k-step s, column tile t) is the table entry 16 t + c - 4 s - kg of one row of a few hundred doubles, which waits in
+// LDS -- nothing is read from memory while the wave streams its stores (a vector-memory load there would wait for every
+// store issued before it: s_waitcnt vmcnt counts both).  In the quotient num_k / den_k the factor 1 / C(P+Q, k) cancels
+// and is never applied; the row C(4R, .) is scaled by a power of two that keeps C(4R, .) x C(4n, .) x values far from
+// overflow.  22 matrix instructions per 16 x 16 block of quotients against 2 x 41 x 16 v_fma_f64 per lane before
+// (k_dynamics_elev 0.20 ms at C5); results leave straight from the accumulators, 128-byte row segments.
 template <int NC>
 __device__ __forceinline__ void dynamics_elev_group(const AngElevParams& q, double* lds, const int group, const DynEmit* em = nullptr)
 {
-    constexpr int N = NC - 1, L2 = 2 * N + 1, L4 = 4 * N + 1, TP = kElevChunk + 1;
+    constexpr int N = NC - 1, L2 = 2 * N + 1, L4 = 4 * N + 1;
+    constexpr int KS2 = (L2 + 3) / 4, KS4 = (L4 + 3) / 4, PAD2 = 4 * KS2 + 4, PAD4 = 4 * KS4 + 4;
     const AngParams& p = q.a;
     const int lane = threadIdx.x & (kWave - 1);
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform: table reads become scalar loads
-    double* tile = lds + wave * (kWave * TP);
-    int it0, n_valid;
-    const int item = dyn_item_of_lane<NC>(p, em, group, lane, it0, n_valid);
-    const int b = item / p.n_veh;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int c = lane & 15, kg = lane >> 4;
+    const int L2R = L2 + q.R, L4R = L4 + 4 * q.R, NT2 = (L2R + 15) >> 4, NT4 = (L4R + 15) >> 4;
     const bool mapped = em && em->mode != 0;
-    if (mapped) {
-        if (wave == 0) dyn_emit_prepare<NC>(p, *em, item, it0, n_valid, lane);
-        __syncthreads();
+    // ---- tables -> LDS: hl4[PAD4 + m] = C(4R, m) 2^-e, hl2[PAD2 + m] = C(R, m) (zero outside the row), inv2l[k] = 1 / C(2n+R, k)
+    double* hl4 = lds;
+    double* hl2 = hl4 + PAD4 + 16 * NT4;
+    double* inv2l = hl2 + PAD2 + 16 * NT2;
+    {
+        const int tid = threadIdx.x, nthr = blockDim.x;
+        const double* row4 = q.cv4 + L4;
+        const int rl4 = 2 * (L4 - 1) + 4 * q.R + 1 + kElevBlock;
+        for (int i = tid; i < PAD4 + 16 * NT4; i += nthr) { const int qd = i - PAD4 + (L4 - 1); hl4[i] = (qd >= 0 && qd < rl4) ? row4[qd] : 0.0; }
+        const double* row2 = q.cv2 + L2;
+        const int rl2 = 2 * (L2 - 1) + q.R + 1 + kElevBlock;
+        for (int i = tid; i < PAD2 + 16 * NT2; i += nthr) { const int qd = i - PAD2 + (L2 - 1); hl2[i] = (qd >= 0 && qd < rl2) ? row2[qd] : 0.0; }
+        const double* inv2 = row2 + rl2;
+        for (int i = tid; i < 16 * NT2; i += nthr) inv2l[i] = i < L2R ? inv2[i] : 0.0;
     }
-    double num[L4], den[L4];
-    {   // ---- phase A: degree-4n numerator and denominator from the original control points (as k_dynamics2)
+    int it0, n_valid;
+    const int item = dyn_item_of_lane<NC>(p, em, group, 16 * wave + c, it0, n_valid);
+    const int b = item / p.n_veh;
+    if (mapped && wave == 0) {
+        int it0l, nvl;
+        const int item_l = dyn_item_of_lane<NC>(p, em, group, lane, it0l, nvl);
+        dyn_emit_prepare<NC>(p, *em, item_l, it0l, nvl, lane);
+    }
+    // ---- phase A: degree-4n numerator and denominator (as k_dynamics2), pre-scaled by C(4n, k); the speed curve by C(2n, j).
+    // The denominator side first, then the numerator side, a scheduling barrier between them: interleaved, the two sides'
+    // degree-2n curves and derivatives are live together and the kernel needs 235 registers (two workgroups per CU).
+    double afn[KS4], afd[KS4], afs[KS2];
+    {
         double x[NC], y[NC];
         load_item_xy<NC>(p, item, b, x, y);
         const double val = (double)N / p.tf[b];
-        double xD[NC], yD[NC], xDD[NC], yDD[NC];
+        double xD[NC], yD[NC];
         diff_elev1<NC>(x, val, xD);
         diff_elev1<NC>(y, val, yD);
-        diff_elev1<NC>(xD, val, xDD);
-        diff_elev1<NC>(yD, val, yDD);
         const ctab_t Wn = as_ctab(p.Wn), W2n = as_ctab(p.W2n), W22n = as_ctab(p.W22n);
-        double num1[L2], den1[L2];
+        const ctab_t sc2 = as_ctab(q.cv2), sc4 = as_ctab(q.cv4);
+        // the lane's share of an operand: coefficients j = 4 s + kg (zero past the end)
+        // (the four candidates are computed by every lane and pinned: left to itself the compiler sinks each candidate's
+        // arithmetic AND its table load into a branch of its own -- vector loads with a wait each, a hundred per wave)
+        auto pick = [&](double (&v)[4]) {
 #pragma unroll
-        for (int k = 0; k < L2; ++k) {
-            double s1 = 0.0, s2 = 0.0, sd = 0.0;
+            for (int u = 0; u < 4; ++u) pin_reg(v[u]);
+            return kg == 0 ? v[0] : kg == 1 ? v[1] : kg == 2 ? v[2] : v[3];
+        };
+        {
+            double den1[L2];
 #pragma unroll
-            for (int j = (k - N > 0 ? k - N : 0); j <= (N < k ? N : k); ++j) {
-                const double wkj = Wn[k * NC + j];
-                s1 = fma(wkj, yDD[j] * xD[k - j], s1);
-                s2 = fma(wkj, xDD[j] * yD[k - j], s2);
+            for (int k = 0; k < L2; ++k) {
+                double sd = 0.0;
+#pragma unroll
+                for (int j = (k - N > 0 ? k - N : 0); 2 * j <= k; ++j)
+                    sd = fma(W2n[k * NC + j], fma(xD[j], xD[k - j], yD[j] * yD[k - j]), sd);
+                den1[k] = sd;
             }
 #pragma unroll
-            for (int j = (k - N > 0 ? k - N : 0); 2 * j <= k; ++j)
-                sd = fma(W2n[k * NC + j], fma(xD[j], xD[k - j], yD[j] * yD[k - j]), sd);
-            num1[k] = s1 - s2;
-            den1[k] = sd;
-        }
-        // speed rows = elev(den1, R): this wave's share of their 32-column chunks, while den1 is still live
-        if (p.out_speed) {
-            const int L2R = L2 + q.R;
-            const ctab_t sc2 = as_ctab(q.cv2), row2 = sc2 + L2, inv2 = row2 + (q.R + 1 + 2 * (L2 - 1) + kElevBlock);
-            double dh[L2];
+            for (int sx = 0; sx < KS2; ++sx) {
+                double v[4];
 #pragma unroll
-            for (int j = 0; j < L2; ++j) dh[j] = sc2[j] * den1[j];
-            for (int k0 = wave * kElevChunk; k0 < L2R; k0 += 4 * kElevChunk) {
-                const int kc = min(kElevChunk, L2R - k0);
-                // one pass per requested bound (the second one, obtg_ctx_set_second_speed_bound, repeats the chunk's
-                // convolution: the degree-2n curve is what the two share)
-                for (int which = 0; which < (p.out_speed2 ? 2 : 1); ++which) {
-                    const double sgn = which ? p.sp2_sign : p.sp_sign, off = which ? p.sp2_offset : p.sp_offset;
-                    for (int kb = 0; kb < kc; kb += kElevBlock) {
-                        double sa[kElevBlock];
-                        conv_block1<L2>(row2 + k0 + kb, dh, sa);
+                for (int u = 0; u < 4; ++u) { const int k = 4 * sx + u < L2 ? 4 * sx + u : 0; v[u] = (4 * sx + u < L2) ? sc2[k] * den1[k] : 0.0; }
+                afs[sx] = pick(v);
+            }
 #pragma unroll
-                        for (int i = 0; i < kElevBlock; ++i)
-                            tile[lane * TP + kb + i] = sgn * (sa[i] * inv2[k0 + kb + i]) + off;
+            for (int sx = 0; sx < KS4; ++sx) {
+                double v[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int k = 4 * sx + u;
+                    double sd = 0.0;
+                    if (k < L4) {
+#pragma unroll
+                        for (int j = (k - 2 * N > 0 ? k - 2 * N : 0); 2 * j <= k; ++j) sd = fma(W22n[k * L2 + j], den1[j] * den1[k - j], sd);
+                        sd *= sc4[k];                   // C(4n, k): the convolution form's pre-scaling
                     }
-                    wave_sync();
-                    if (mapped) dyn_emit_rows(tile, TP, kc, which ? p.out_speed2 : p.out_speed, L2R, k0, p, *em, it0, n_valid, lane, kWave);
-                    else elev_store_chunk<L2>(tile, which ? p.out_speed2 : p.out_speed, (size_t)it0 * L2R, L2R, k0, kc, n_valid, lane);
-                    wave_sync();
+                    v[u] = sd;
                 }
+                afd[sx] = pick(v);
             }
         }
-        const ctab_t sc4 = as_ctab(q.cv4);
+        __builtin_amdgcn_sched_barrier(0);
+        {
+            double xDD[NC], yDD[NC];
+            diff_elev1<NC>(xD, val, xDD);
+            diff_elev1<NC>(yD, val, yDD);
+            double num1[L2];
 #pragma unroll
-        for (int k = 0; k < L4; ++k) {
-            double sn = 0.0, sd = 0.0;
+            for (int k = 0; k < L2; ++k) {
+                double s1 = 0.0, s2 = 0.0;
 #pragma unroll
-            for (int j = (k - 2 * N > 0 ? k - 2 * N : 0); 2 * j <= k; ++j) {
-                const double wkj = W22n[k * L2 + j];
-                sn = fma(wkj, num1[j] * num1[k - j], sn);
-                sd = fma(wkj, den1[j] * den1[k - j], sd);
+                for (int j = (k - N > 0 ? k - N : 0); j <= (N < k ? N : k); ++j) {
+                    const double wkj = Wn[k * NC + j];
+                    s1 = fma(wkj, yDD[j] * xD[k - j], s1);
+                    s2 = fma(wkj, xDD[j] * yD[k - j], s2);
+                }
+                num1[k] = s1 - s2;
             }
-            const double sck = sc4[k];          // C(4n, k): the convolution form's pre-scaling
-            num[k] = sck * sn;
-            den[k] = sck * sd;
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int sx = 0; sx < KS4; ++sx) {
+                double v[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int k = 4 * sx + u;
+                    double sn = 0.0;
+                    if (k < L4) {
+#pragma unroll
+                        for (int j = (k - 2 * N > 0 ? k - 2 * N : 0); 2 * j <= k; ++j) sn = fma(W22n[k * L2 + j], num1[j] * num1[k - j], sn);
+                        sn *= sc4[k];
+                    }
+                    v[u] = sn;
+                }
+                afn[sx] = pick(v);
+            }
         }
     }
-    // ---- phase B: elevate both by 4R and divide, 32 output columns at a time; chunk t belongs to wave t mod 4
-    const int L4R = L4 + 4 * q.R;
-    const ctab_t row4 = as_ctab(q.cv4) + L4;
-    for (int k0 = wave * kElevChunk; k0 < L4R; k0 += 4 * kElevChunk) {
-        const int kc = min(kElevChunk, L4R - k0);
-        for (int kb = 0; kb < kc; kb += kElevBlock) {
-            double sn[kElevBlock], sd[kElevBlock];
-            conv_block2<L4>(row4 + k0 + kb, num, den, sn, sd);
-#pragma unroll
-            for (int i = 0; i < kElevBlock; ++i) tile[lane * TP + kb + i] = p.w2 - sn[i] / sd[i];
+    __syncthreads();                                   // the tables (and the emission map) are in LDS
+    // value of (row of the group, column) -> where the emission mode wants it
+    const size_t row_stride = (size_t)p.n_veh;
+    auto emit = [&](double* __restrict__ out, const int LROW, const int row, const int col, const double v) {
+        if (row >= n_valid || col >= LROW) return;
+        if (!mapped) { out[(size_t)(it0 + row) * LROW + col] = v; return; }
+        if (em->mode == 1) {
+            const int it = em->s_map[row];
+            if (it >= 0) out[(size_t)it * LROW + col] = v;
+            return;
         }
-        wave_sync();
-        if (mapped) dyn_emit_rows(tile, TP, kc, p.out, L4R, k0, p, *em, it0, n_valid, lane, kWave);
-        else elev_store_chunk<L4>(tile, p.out, (size_t)it0 * L4R, L4R, k0, kc, n_valid, lane);
-        wave_sync();
+        const int nb = em->b1 - em->b0;
+        double* o = out + ((size_t)em->b0 * p.n_veh + it0 + row) * LROW + col;
+        for (int j = 0; j < nb; ++j, o += row_stride * LROW) {
+            const int m = em->s_map[j];
+            if (m != -2 && m != row) *o = v;
+        }
+    };
+    const int row_base = 16 * wave + kg;               // this lane's rows: row_base + 4 r
+    // ---- speed rows = elev(den1, R), both requested bounds from the same accumulators
+    if (p.out_speed) {
+        const double* bp = hl2 + PAD2 + c - kg;
+        for (int t = 0; t < NT2; ++t) {
+            v4d_t acc;
+            acc[0] = acc[1] = acc[2] = acc[3] = 0.0;
+#pragma unroll
+            for (int sx = 0; sx < KS2; ++sx) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(afs[sx], bp[16 * t - 4 * sx], acc, 0, 0, 0);
+            const int col = 16 * t + c;
+            const double iv = inv2l[col];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const double e = acc[r] * iv;
+                emit(p.out_speed, L2R, row_base + 4 * r, col, p.sp_sign * e + p.sp_offset);
+                if (p.out_speed2) emit(p.out_speed2, L2R, row_base + 4 * r, col, p.sp2_sign * e + p.sp2_offset);
+            }
+        }
+    }
+    // ---- angular rate: elevate numerator and denominator by 4R, divide element by element (optimization.py:608)
+    if (p.out) {
+        const double* bp = hl4 + PAD4 + c - kg;
+        for (int t = 0; t < NT4; ++t) {
+            v4d_t an, ad;
+            an[0] = an[1] = an[2] = an[3] = 0.0;
+            ad[0] = ad[1] = ad[2] = ad[3] = 0.0;
+#pragma unroll
+            for (int sx = 0; sx < KS4; ++sx) {
+                const double bv = bp[16 * t - 4 * sx];
+                an = __builtin_amdgcn_mfma_f64_16x16x4f64(afn[sx], bv, an, 0, 0, 0);
+                ad = __builtin_amdgcn_mfma_f64_16x16x4f64(afd[sx], bv, ad, 0, 0, 0);
+            }
+            const int col = 16 * t + c;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) emit(p.out, L4R, row_base + 4 * r, col, p.w2 - an[r] / ad[r]);
+        }
     }
 }
 

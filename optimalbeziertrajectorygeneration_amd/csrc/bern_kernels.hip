@@ -34,12 +34,40 @@ constexpr size_t kNsLdsBudget = 76 * 1024;
 
 namespace obtg {
 
+// (the elevated full rows: B fragments, accumulators and A fragments of a group are ~210 registers, and LDS holds two
+// workgroups per CU anyway: two waves per SIMD)
 template <int NC, int DIM, int MODE /*0 = pairs, 1 = vehicles*/, bool MINONLY, bool ELEV>
-__global__ __launch_bounds__(256) void k_normsq_elev(const NsParams p)
+__global__ __launch_bounds__(256, (ELEV && !MINONLY) ? 2 : 1) void k_normsq_elev(const NsParams p)
 {
     extern __shared__ double lds[];
     const int b = blockIdx.x / p.wgs_per_row, w = blockIdx.x - b * p.wgs_per_row;
     normsq_elev_body<NC, DIM, MODE, MINONLY, ELEV>(p, b, w, lds);
+}
+
+// DEG_ELEV > 0, full separation rows of a batch whose rows stage whole (bern_device.h sep_elev_coop_body): four waves
+// share every 16-row tile, the elevation matrix stays in their registers (2 x KS fragments each).  Three workgroups
+// per CU: 53 KB of LDS each at C5, <= 168 registers.
+constexpr int kCoopNTW = 2;            // output tiles per wave: 2n + R + 1 <= 128
+template <int NC, int DIM>
+__global__ __launch_bounds__(256, (NC > 11 ? 2 : 3)) void k_sep_elev_coop(const NsParams p)
+{
+    extern __shared__ double lds[];
+    const int b = blockIdx.x / p.wgs_per_row, w = blockIdx.x - b * p.wgs_per_row;
+    sep_elev_coop_body<NC, DIM, kCoopNTW>(p, b, w, lds);
+}
+
+// LDS bytes of sep_elev_coop_body for a planned launch; 0 = the shape is outside it (normsq_elev_body's form runs)
+template <int NC, int DIM>
+static size_t sep_elev_coop_lds(const NsParams& p)
+{
+    using S = NsShape<NC, DIM>;
+    const int LR = S::L + p.R;
+    if (p.R <= 0 || !p.stage_all || p.tiling || LR > 64 * kCoopNTW || p.n_obj >= 65536) return 0;
+    static const bool on = !(getenv("OBTG_ELEV_COOP") && getenv("OBTG_ELEV_COOP")[0] == '0');      // (A/B runs)
+    if (!on) return 0;
+    const size_t lds = sizeof(double) * ((((size_t)p.stage_slots * S::VP + 1) & ~(size_t)1) + ElevCoop<S::L>::lds_doubles(LR)) +
+                       sizeof(unsigned) * kWave * (size_t)p.groups_per_wg;
+    return lds <= 160 * 1024 ? lds : 0;
 }
 
 // =====================================================================================
@@ -54,7 +82,7 @@ struct TsepFdParams {
     const double* __restrict__ Y0;     // [n_veh*DIM][NC] the evaluation row
     const double* __restrict__ obs;    // [n_obj - n_veh][DIM] point obstacles (constant curves)
     const double* __restrict__ W2;     // folded product weights
-    const double* __restrict__ Tt;     // elevation as a scaled convolution (NsParams::Tt)
+    const double* __restrict__ Td;     // the elevation matrix, dense and transposed (NsParams::Td)
     const int* __restrict__ prow;      // [n_pert] row of Y0 that perturbation t touches
     const int* __restrict__ pcol;      // [n_pert] column
     const double* __restrict__ pval;   // [n_pert] the perturbed value itself (x_k + h as the caller rounds it)
@@ -94,18 +122,12 @@ __global__ __launch_bounds__(kWave) void k_tsep_fd(const TsepFdParams p)
 #pragma unroll
         for (int k = 0; k < L; ++k) o[k] = p.sign * cf[k] + p.offset;
     } else {
-        // the elevation exactly as normsq_elev_body forms it (same pre-scaling, same window walk, same order)
-        const ctab_t escale = as_ctab(p.Tt), ebin = escale + L, einv = ebin + (p.R + 2 * L - 1 + kConvPad);
+        // the elevation exactly as normsq_elev_body's matrix instructions form it (elev_at: the same chain of fused multiply-adds)
+        const ctab_t Td = as_ctab(p.Td);
         double ch[L];
 #pragma unroll
-        for (int j = 0; j < L; ++j) ch[j] = cf[j] * escale[j];
-        for (int k = 0; k < LR; k += kElevBlock) {
-            double sa[kElevBlock];
-            conv_block1<L>(ebin + k, ch, sa);
-#pragma unroll
-            for (int i = 0; i < kElevBlock; ++i)
-                if (k + i < LR) o[k + i] = p.sign * (sa[i] * einv[k + i]) + p.offset;
-        }
+        for (int j = 0; j < L; ++j) ch[j] = p.sign * cf[j];
+        for (int k = 0; k < LR; ++k) o[k] = elev_at<L>(ch, Td + k * L, p.offset);
     }
 }
 
@@ -120,7 +142,7 @@ struct OneManyParams {
     const double* __restrict__ one;    // [B][DIM][NC]
     const double* __restrict__ many;   // [K][DIM][NC]
     const double* __restrict__ W2;     // folded product weights
-    const double* __restrict__ Tt;     // elevation as a scaled convolution (NsParams::Tt)
+    const double* __restrict__ Td;     // the elevation matrix, dense and transposed (NsParams::Td)
     double* __restrict__ out;          // [B][K]
     int B, K, R;
     double sign, offset;
@@ -148,22 +170,17 @@ __global__ __launch_bounds__(256) void k_one_vs_many(const OneManyParams p)
         mn = cf[0];
 #pragma unroll
         for (int j = 1; j < L; ++j) mn = fmin(mn, cf[j]);
+        mn = p.sign * mn + p.offset;
     } else {
         const int LR = L + p.R;
-        const ctab_t escale = as_ctab(p.Tt), ebin = escale + L, einv = ebin + (p.R + 2 * L - 1 + kConvPad);
+        const ctab_t Td = as_ctab(p.Td);
         double ch[L];
 #pragma unroll
-        for (int j = 0; j < L; ++j) ch[j] = cf[j] * escale[j];
+        for (int j = 0; j < L; ++j) ch[j] = p.sign * cf[j];
         mn = INFINITY;
-        for (int kk = 0; kk < LR; ++kk) {
-            const ctab_t win = ebin + kk;              // win[L-1-j] = C(R, kk-j)
-            double s = 0.0;
-#pragma unroll
-            for (int j = 0; j < L; ++j) s = fma(ch[j], win[L - 1 - j], s);
-            mn = fmin(mn, s * einv[kk]);
-        }
+        for (int kk = 0; kk < LR; ++kk) mn = fmin(mn, elev_at<L>(ch, Td + kk * L, p.offset));
     }
-    p.out[item] = p.sign * mn + p.offset;
+    p.out[item] = mn;
 }
 
 // =====================================================================================
@@ -305,7 +322,7 @@ __global__ __launch_bounds__(2 * kWave) void k_dynamics2(const AngParams p)
 // repeats phase A (8 % of its work) and takes every fourth 32-column chunk, transposed through a per-wave LDS tile
 // so that stores are 256-byte runs.
 template <int NC>
-__global__ __launch_bounds__(4 * kWave, (NC > 11 ? 1 : OBTG_DYN_ELEV_WAVES)) void k_dynamics_elev(const AngElevParams q)
+__global__ __launch_bounds__(4 * kWave, (NC > 11 ? 1 : 3)) void k_dynamics_elev(const AngElevParams q)
 {
     extern __shared__ double lds[];
     dynamics_elev_group<NC>(q, lds, (int)blockIdx.x);
@@ -323,7 +340,7 @@ struct SepDynElevParams {
 };
 
 template <int NC>
-__global__ __launch_bounds__(4 * kWave, (NC > 11 ? 1 : 2)) void k_sep_dynamics_elev(const SepDynElevParams sp)
+__global__ __launch_bounds__(4 * kWave, (NC > 11 ? 1 : 3)) void k_sep_dynamics_elev(const SepDynElevParams sp)
 {
     extern __shared__ double lds[];
     const int grp = (int)blockIdx.x >> 4, slot = ((int)blockIdx.x + grp) & 15;
@@ -335,7 +352,7 @@ __global__ __launch_bounds__(4 * kWave, (NC > 11 ? 1 : 2)) void k_sep_dynamics_e
         return;
     }
     const int b = id / sp.ts.wgs_per_row;
-    normsq_elev_body<NC, 2, 0, false, true>(sp.ts, b, id - b * sp.ts.wgs_per_row, lds);
+    sep_elev_coop_body<NC, 2, kCoopNTW>(sp.ts, b, id - b * sp.ts.wgs_per_row, lds);
 }
 
 // =====================================================================================
@@ -856,7 +873,7 @@ static int launch_ns_t(obtg_ctx* c, NsParams p, int B, int kernel_id)
     const size_t stage = (size_t)p.stage_slots * S::VP * sizeof(double);
     size_t lds = 0;
     if (MINONLY) { p.tile_rows = 0; lds = stage; }
-    else if (p.R > 0) { p.tile_rows = kWave; lds = stage + (size_t)p.waves * ns_elev_tile_doubles(S::L) * sizeof(double); }
+    else if (p.R > 0) { p.tile_rows = kWave; lds = ((stage + 15) & ~(size_t)15) + (size_t)p.waves * elev_mfma_wave_doubles(S::L, p.R) * sizeof(double); }
     else {
         for (int tr = kWave; tr >= 16; tr >>= 1) {
             p.tile_rows = tr;
@@ -864,9 +881,12 @@ static int launch_ns_t(obtg_ctx* c, NsParams p, int B, int kernel_id)
             if (lds <= budget) break;
         }
     }
-    if (lds > 160 * 1024) return OBTG_ERR_UNSUPPORTED;
     void (*kern)(const NsParams) = p.R > 0 ? k_normsq_elev<NC, DIM, MODE, MINONLY, true>
                                            : k_normsq_elev<NC, DIM, MODE, MINONLY, false>;
+    if (MODE == 0 && !MINONLY) {
+        if (const size_t lc = sep_elev_coop_lds<NC, DIM>(p)) { kern = k_sep_elev_coop<NC, DIM>; lds = lc; p.waves = 4; }
+    }
+    if (lds > 160 * 1024) return OBTG_ERR_UNSUPPORTED;
     if (lds > 48 * 1024)
         OBTG_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -921,6 +941,7 @@ int plan_temporal_sep(obtg_ctx* c, const double* dY, int B, int pair_begin, int 
     p = NsParams{};
     p.Y = dY; p.obs = c->d_obs.as<double>(); p.tf = nullptr;
     p.pairs = c->d_pairs.as<int2>(); p.W2 = c->d_w2.as<double>(); p.Tt = c->d_Tt.as<double>(); p.Td = c->d_Td.as<double>();
+    p.Tf = c->d_Tf.as<double>();
     p.out = d_out; p.n_veh = c->n_veh; p.n_obj = c->n_obj; p.R = c->R;
     p.item_begin = pair_begin; p.item_count = pair_count;
     // workgroup = 4 waves sharing one staging of the row's objects; each wave walks
@@ -1008,7 +1029,7 @@ int launch_temporal_sep(obtg_ctx* c, const double* dY, int B, double max_sep, in
     rc = plan_temporal_sep(c, dY, B, pair_begin, pair_count, d_out, p);
     if (rc != OBTG_OK && rc != OBTG_ERR_UNSUPPORTED) return rc;
     if (rc == OBTG_OK) {
-        p.sign = 1.0; p.offset = -(max_sep * max_sep);
+        p.sign = 1.0; p.offset = 0.0 - max_sep * max_sep;
         if (c->fd.Y0) { p.Y = c->fd.Y0; p.fd = 1; p.fd_fixed = c->fd.fixed; p.fd_h = c->fd.h; }
         rc = min_only ? dispatch_ns<0, true>(c, p, B, OBTG_K_TEMPORAL_SEP)
                       : dispatch_ns<0, false>(c, p, B, OBTG_K_TEMPORAL_SEP);
@@ -1020,7 +1041,7 @@ int launch_temporal_sep(obtg_ctx* c, const double* dY, int B, double max_sep, in
     if (rc) return rc;
     if (2 * c->deg + c->R + 1 > kMaxGenericLen) return OBTG_ERR_UNSUPPORTED;
     g.Y = dY; g.out = d_out; g.item_begin = pair_begin; g.item_count = pair_count; g.B = B;
-    g.sign = 1.0; g.offset = -(max_sep * max_sep); g.min_only = min_only ? 1 : 0;
+    g.sign = 1.0; g.offset = 0.0 - max_sep * max_sep; g.min_only = min_only ? 1 : 0;
     const int nc = c->deg + 1;
     size_t lds = sizeof(double) * ((size_t)2 * c->dim * nc + 2 * c->deg + 1);
     ScopedKernelTimer t(c, OBTG_K_TEMPORAL_SEP);
@@ -1041,6 +1062,7 @@ int launch_speed(obtg_ctx* c, const double* dY, const double* d_tf, int B, doubl
         NsParams p{};
         p.Y = dY; p.obs = nullptr; p.tf = d_tf; p.pairs = nullptr;
         p.W2 = c->d_w2.as<double>(); p.Tt = c->d_Tt.as<double>(); p.Td = c->d_Td.as<double>(); p.out = d_out;
+        p.Tf = c->d_Tf.as<double>();
         p.n_veh = c->n_veh; p.n_obj = c->n_veh; p.R = c->R;
         p.item_begin = 0; p.item_count = c->n_veh;
         p.groups_per_wg = 1;
@@ -1089,7 +1111,7 @@ static int launch_dyn_t(obtg_ctx* c, const AngParams& p, int kernel_id)
 template <int NC>
 static int launch_dyn_elev_t(obtg_ctx* c, const AngElevParams& q, int kernel_id)
 {
-    const size_t lds = sizeof(double) * 4 * kWave * (kElevChunk + 1);
+    const size_t lds = sizeof(double) * dyn_elev_lds_doubles(NC - 1, q.R);
     const unsigned groups = (unsigned)((q.a.total + kWave - 1) / kWave);
     if (lds > 48 * 1024)
         OBTG_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_dynamics_elev<NC>),
@@ -1137,10 +1159,10 @@ int launch_temporal_sep_fd(obtg_ctx* c, const double* dY0, int n_pert, const int
     if (rc) return rc;
     if (!fast_shape(c)) return OBTG_ERR_UNSUPPORTED;
     TsepFdParams p{};
-    p.Y0 = dY0; p.obs = c->d_obs.as<double>(); p.W2 = c->d_w2.as<double>(); p.Tt = c->d_Tt.as<double>();
+    p.Y0 = dY0; p.obs = c->d_obs.as<double>(); p.W2 = c->d_w2.as<double>(); p.Td = c->d_Td.as<double>();
     p.prow = d_prow; p.pcol = d_pcol; p.pval = d_pval; p.out = d_out;
     p.n_veh = c->n_veh; p.n_obj = c->n_obj; p.R = c->R; p.n_pert = n_pert;
-    p.sign = 1.0; p.offset = -(max_sep * max_sep);
+    p.sign = 1.0; p.offset = 0.0 - max_sep * max_sep;
     const long items = (long)n_pert * (c->n_obj - 1);
     const dim3 grid((unsigned)((items + kWave - 1) / kWave));
     const int nc = c->deg + 1;
@@ -1163,9 +1185,9 @@ int launch_one_vs_many_min(obtg_ctx* c, const double* d_one, int B, const double
     if (rc) return rc;
     if (!fast_shape(c)) return OBTG_ERR_UNSUPPORTED;
     OneManyParams p{};
-    p.one = d_one; p.many = d_many; p.W2 = c->d_w2.as<double>(); p.Tt = c->d_Tt.as<double>(); p.out = d_out;
+    p.one = d_one; p.many = d_many; p.W2 = c->d_w2.as<double>(); p.Td = c->d_Td.as<double>(); p.out = d_out;
     p.B = B; p.K = K; p.R = c->R;
-    p.sign = 1.0; p.offset = -(max_sep * max_sep);
+    p.sign = 1.0; p.offset = 0.0 - max_sep * max_sep;
     const long items = (long)B * K;
     const int nc = c->deg + 1;
     void (*kern)(const OneManyParams) = nullptr;
@@ -1185,11 +1207,11 @@ int launch_one_vs_many_min(obtg_ctx* c, const double* d_one, int B, const double
 template <int NC>
 static int launch_sep_dyn_elev_t(obtg_ctx* c, SepDynElevParams& sp, int B)
 {
-    using S = NsShape<NC, 2>;
     sp.ts.tile_rows = kWave;
-    const size_t lds_t = sizeof(double) * ((size_t)sp.ts.stage_slots * S::VP + 4 * (size_t)ns_elev_tile_doubles(S::L));
-    const size_t lds = std::max(lds_t, sizeof(double) * 4 * kWave * (kElevChunk + 1));
-    if (lds > 80 * 1024 - 512) return OBTG_ERR_UNSUPPORTED;            // two workgroups per CU
+    const size_t lds_t = sep_elev_coop_lds<NC, 2>(sp.ts);      // the separation workgroups are sep_elev_coop_body's
+    if (!lds_t) return OBTG_ERR_UNSUPPORTED;                   // (rows that do not stage whole, 2n + R + 1 > 128: separate launches)
+    const size_t lds = std::max(lds_t, sizeof(double) * dyn_elev_lds_doubles(NC - 1, sp.dyn.R));
+    if (lds > 80 * 1024 - 512) return OBTG_ERR_UNSUPPORTED;            // at least two workgroups per CU (three at C5: 53 KB)
     sp.n_kind[0] = B * sp.ts.wgs_per_row;
     sp.n_kind[1] = (sp.dyn.a.total + kWave - 1) / kWave;
     // shares of every 16 block ids by count: both kinds run out at about the same block id
@@ -1227,7 +1249,7 @@ int launch_sep_dynamics_elev(obtg_ctx* c, const double* dY, int B, double max_se
     rc = plan_temporal_sep(c, dY, B, 0, c->n_pairs, d_out_sep, sp.ts);
     if (rc) return rc;
     if (sp.ts.waves != 4) return OBTG_ERR_UNSUPPORTED;                 // (fewer than four 64-pair groups per row)
-    sp.ts.sign = 1.0; sp.ts.offset = -(max_sep * max_sep);
+    sp.ts.sign = 1.0; sp.ts.offset = 0.0 - max_sep * max_sep;
     AngParams& p = sp.dyn.a;
     p.Y = dY; p.tf = f.d_tf; p.out = f.d_out_ang; p.out_speed = f.d_out_speed;
     p.n_veh = c->n_veh; p.total = B * c->n_veh;

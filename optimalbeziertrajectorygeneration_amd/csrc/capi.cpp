@@ -136,17 +136,22 @@ int ensure_tables(obtg_ctx* c)
         auto Tt = elev_conv_tables(L, c->R);
         int rc = upload(c, c->d_Tt, Tt.data(), Tt.size() * sizeof(double));
         if (rc) return rc;
-        auto Td = elev_table_T(L, c->R);
+        auto Td = elev_table_T_ld(L, c->R);
         if ((rc = upload(c, c->d_Td, Td.data(), Td.size() * sizeof(double)))) return rc;
+        auto Tf = elev_table_frag(L, c->R);
+        if ((rc = upload(c, c->d_Tf, Tf.data(), Tf.size() * sizeof(double)))) return rc;
     }
     c->d_ang_T4.release();
     c->d_ang_cv2.release();
+    c->d_ang_T4f.release();
     if (c->R > 0 && c->dim == 2 && n <= 15 && 4 * c->R <= 1000) {   // C(4R, .) and C(2n+R, .) finite in binary64
         auto cv4 = elev_conv_padded(4 * n + 1, 4 * c->R, 8, true, false);
         auto cv2 = elev_conv_padded(2 * n + 1, c->R, 8, false, true);
         int rc = upload(c, c->d_ang_T4, cv4.data(), cv4.size() * sizeof(double));
         if (rc) return rc;
         if ((rc = upload(c, c->d_ang_cv2, cv2.data(), cv2.size() * sizeof(double)))) return rc;
+        auto T4f = elev_table_frag(4 * n + 1, 4 * c->R);
+        if ((rc = upload(c, c->d_ang_T4f, T4f.data(), T4f.size() * sizeof(double)))) return rc;
     }
     c->tables_R = c->R;
     return OBTG_OK;
@@ -204,7 +209,7 @@ const char* obtg_abi_symbols(void)
 {
     static const char syms[] =
         "obtg_strerror\0obtg_last_error\0obtg_device_count\0obtg_abi_symbols\0obtg_host_alloc\0obtg_host_free\0"
-        "obtg_ctx_create\0obtg_ctx_destroy\0obtg_ctx_set_stream\0obtg_ctx_set_deg_elev\0obtg_ctx_set_ang_rate_order\0obtg_ctx_set_second_speed_bound\0obtg_sync\0"
+        "obtg_ctx_create\0obtg_ctx_destroy\0obtg_ctx_set_stream\0obtg_ctx_use_own_stream\0obtg_ctx_set_deg_elev\0obtg_ctx_set_ang_rate_order\0obtg_ctx_set_second_speed_bound\0obtg_sync\0"
         "obtg_len_temporal_sep\0obtg_len_speed\0obtg_len_ang_rate\0obtg_num_pairs\0"
         "obtg_temporal_sep\0obtg_speed\0obtg_ang_rate\0obtg_temporal_sep_min\0obtg_temporal_sep_min_range\0"
         "obtg_temporal_sep_fd\0obtg_temporal_sep_fd_dev\0obtg_one_vs_many_min\0obtg_one_vs_many_min_dev\0"
@@ -264,7 +269,7 @@ void obtg_ctx_destroy(obtg_ctx* c)
     (void)hipStreamSynchronize(c->stream);
     flush_pending_events(c);
     for (hipEvent_t e : c->event_pool) (void)hipEventDestroy(e);
-    DevBuf* bufs[] = { &c->d_pairs, &c->d_obs, &c->d_w2, &c->d_Tt, &c->d_Td, &c->d_ang_w2n, &c->d_ang_w22n, &c->d_ang_wn, &c->d_ang_T4, &c->d_ang_cv2,
+    DevBuf* bufs[] = { &c->d_pairs, &c->d_obs, &c->d_w2, &c->d_Tt, &c->d_Td, &c->d_Tf, &c->d_ang_T4f, &c->d_vp_off, &c->d_vp_idx, &c->d_ang_w2n, &c->d_ang_w22n, &c->d_ang_wn, &c->d_ang_T4, &c->d_ang_cv2,
                        &c->d_binrows, &c->d_tiles, &c->d_poly_pts, &c->d_poly_off, &c->d_hp_a, &c->d_hp_b, &c->d_tile_chunk_off, &c->d_tile_order, &c->d_tile_pslots,
                        &c->d_tile_cobj_off, &c->d_tile_cobjs, &c->d_tile_ij, &c->ws_in,
                        &c->ws_in2, &c->ws_out, &c->ws_fd };
@@ -283,7 +288,15 @@ int obtg_ctx_set_stream(obtg_ctx* c, void* hip_stream)
 {
     if (!check_ctx(c)) return OBTG_ERR_ARG;
     OBTG_HIP(c, hipStreamSynchronize(c->stream));
-    c->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : c->own_stream;
+    c->stream = static_cast<hipStream_t>(hip_stream);        // as given: NULL is the null stream
+    return OBTG_OK;
+}
+
+int obtg_ctx_use_own_stream(obtg_ctx* c)
+{
+    if (!check_ctx(c)) return OBTG_ERR_ARG;
+    OBTG_HIP(c, hipStreamSynchronize(c->stream));
+    c->stream = c->own_stream;
     return OBTG_OK;
 }
 

@@ -1113,8 +1113,9 @@ __global__ __launch_bounds__(256, WPC) void k_step_fd_structured(const Structure
         }
         __syncthreads();
         if (ELEV) {
-            double* chT = reinterpret_cast<double*>(xy_dyn + n_obj * VPQ);   // [64][L] scaled products | 4 output tiles of a pass
-            tsep_elev_group_stream<NC>(p.ts, xy_dyn, VPQ, g, chT, chT + kWave * L, r * sp.sep_rows_per,
+            // the group's coefficient image behind the staged row; the waves' output tiles then take the place of both
+            double* img = reinterpret_cast<double*>(xy_dyn + n_obj * VPQ);
+            tsep_elev_group_stream<NC>(p.ts, xy_dyn, VPQ, g, img, lds, r * sp.sep_rows_per,
                                        min(p.B, (r + 1) * sp.sep_rows_per), p.fd, p.fd_fixed);
             return;
         }
@@ -2792,7 +2793,7 @@ int launch_gjk_swarm(obtg_ctx* c, const double* dY, int B, int max_iter, int md_
                 const int L = 2 * c->deg + 1, tpf = (L % 2 == 0) ? L + 1 : L, tr = 16;
                 NsParams ts{}, sp{};
                 ts.Y = p.Y; ts.obs = nullptr; ts.pairs = c->d_pairs.as<int2>(); ts.W2 = c->d_w2.as<double>();
-                ts.Tt = c->d_Tt.as<double>(); ts.Td = c->d_Td.as<double>(); ts.out = fold->d_out_sep;
+                ts.Tt = c->d_Tt.as<double>(); ts.Td = c->d_Td.as<double>(); ts.Tf = c->d_Tf.as<double>(); ts.out = fold->d_out_sep;
                 ts.n_veh = c->n_veh; ts.n_obj = c->n_obj; ts.R = 0; ts.item_begin = 0; ts.item_count = c->n_pairs;
                 const int groups_t = (c->n_pairs + kWave - 1) / kWave;
                 ts.groups_per_wg = (groups_t + W - 1) / W; ts.wgs_per_row = W; ts.waves = 4;
@@ -2913,7 +2914,7 @@ int launch_pair_sweep(obtg_ctx* c, const double* dY, int B, double max_sep, doub
         const int tr = pair_sweep_tile_rows(c, nc, lds);      // the transposition tile borrows the LDS behind the objects
         fused = tr > 0 && lds <= 48 * 1024;
         p.ts.pairs = c->d_pairs.as<int2>(); p.ts.W2 = c->d_w2.as<double>(); p.ts.out = d_out_sep;
-        p.ts.n_pairs = c->n_pairs; p.ts.sign = 1.0; p.ts.offset = -(max_sep * max_sep);
+        p.ts.n_pairs = c->n_pairs; p.ts.sign = 1.0; p.ts.offset = 0.0 - max_sep * max_sep;
         p.ts_tile_rows = tr;
         if (c->n_obs > 0) {            // point obstacles: constant curves behind the hull objects, for the separation rows only
             p.obs = c->d_obs.as<double>(); p.n_obs = c->n_obs;
@@ -3096,7 +3097,7 @@ int launch_step_fd_structured(obtg_ctx* c, int B, double max_sep, double* d_out_
     int rc = ensure_tables(c);
     if (rc) return rc;
     if (c->d_ang_w22n.p == nullptr) return OBTG_ERR_UNSUPPORTED;
-    if (elev && (c->ang_elevate_first || c->d_ang_T4.p == nullptr || c->d_ang_cv2.p == nullptr || c->d_Tt.p == nullptr))
+    if (elev && (c->ang_elevate_first || c->d_ang_T4.p == nullptr || c->d_ang_cv2.p == nullptr || c->d_Tf.p == nullptr))
         return OBTG_ERR_UNSUPPORTED;
     StructuredParams sp{};
     GjkSwarmParams& p = sp.g;
@@ -3109,8 +3110,8 @@ int launch_step_fd_structured(obtg_ctx* c, int B, double max_sep, double* d_out_
     p.flag = d_flag; p.p1 = d_p1; p.p2 = d_p2; p.dist = d_dist; p.nsup = d_nsup; p.status = d_status;
     p.B = B; p.chunk = 256; p.wgs_per_row = 1; p.passes = 1;
     p.ts.pairs = c->d_pairs.as<int2>(); p.ts.W2 = c->d_w2.as<double>(); p.ts.out = d_out_sep;
-    p.ts.n_pairs = c->n_pairs; p.ts.sign = 1.0; p.ts.offset = -(max_sep * max_sep);
-    p.ts.Tt = c->d_Tt.as<double>(); p.ts.R = c->R;
+    p.ts.n_pairs = c->n_pairs; p.ts.sign = 1.0; p.ts.offset = 0.0 - max_sep * max_sep;
+    p.ts.Td = c->d_Td.as<double>(); p.ts.Tf = c->d_Tf.as<double>(); p.ts.R = c->R;
     sp.cv4 = c->d_ang_T4.as<double>(); sp.cv2 = c->d_ang_cv2.as<double>(); sp.R = c->R;
     {
         AngParams& d = p.dyn;
@@ -3202,14 +3203,13 @@ int launch_step_fd_structured(obtg_ctx* c, int B, double max_sep, double* d_out_
         grid = (unsigned)groups * 16u;
     }
     p.dyn_first_block = 0;
-    size_t lds_s = elev ? (size_t)16 * n_obj * vpq + sizeof(double) * kWave * L
-                        : std::max((size_t)16 * n_obj * vpq, sizeof(double) * kWave * L);      // (flat: the tile overlays the staged row)
+    size_t lds_s = std::max((size_t)16 * n_obj * vpq, sizeof(double) * kWave * L);      // (flat: the tile overlays the staged row)
     size_t lds_d_elev = 0;
     if (elev) {
-        int nb2 = 1;
-        while (nb2 < (LR + kElevBlock - 1) / kElevBlock) nb2 <<= 1;
-        lds_s += sizeof(double) * 4 * (size_t)(kWave / nb2) * nb2 * (kElevBlock + 1);      // four output tiles of a pass
-        lds_d_elev = sizeof(double) * 4 * kWave * (kElevChunk + 1);
+        // staged row + the group's coefficient image [64][PA]; then, in their place, four 16-row output tiles
+        const int KS = (L + 3) / 4, PA = 4 * KS + 2, CW = 16 * (KS <= 6 ? 8 : 4);
+        lds_s = std::max((size_t)16 * n_obj * vpq + sizeof(double) * kWave * PA, sizeof(double) * 4 * 16 * (size_t)std::min(LR, CW));
+        lds_d_elev = sizeof(double) * dyn_elev_lds_doubles(c->deg, c->R);
     }
     const size_t lds_g = (planar_lds_bytes<0>(n_obj, vpq, sp.gjk_chunk_pairs) + 15) / 16 * 16 + (size_t)sp.gjk_chunk_pairs * 68 + 16;
     const size_t lds_f = planar_lds_bytes<1>(n_obj, vpq, sp.fix_chunk);

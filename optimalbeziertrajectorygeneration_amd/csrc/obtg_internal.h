@@ -17,7 +17,8 @@ constexpr int kMaxGenericLen = 1024;  // longest Bernstein coefficient vector of
 double binom(int n, int k);                         // scipy.special.binom on integers (0 outside range)
 std::vector<double> binom_row(int n);               // C(n, 0..n)
 std::vector<double> folded_product_weights(int n, int dim);  // [2n+1][n+1], see bern_kernels.hip
-std::vector<double> elev_table_T(int L_in, int R);  // transposed, zero padded: [L_in+R][L_in]
+std::vector<double> elev_table_frag(int L_in, int R);   // the same matrix as v_mfma_f64_16x16x4 B fragments: [NT][KS][64]
+std::vector<double> elev_table_T_ld(int L_in, int R);   // dense, transposed, zero padded: [L_in+R][L_in] (bit-equal to the fragments)
 std::vector<double> elev_conv_tables(int L_in, int R);  // scale | padded C(R,.) | 1/C(N+R,.)
 std::vector<double> elev_conv_padded(int L_in, int R, int extra, bool normalise, bool with_inv);
 
@@ -65,9 +66,11 @@ struct obtg_ctx {
     obtg::DevBuf d_obs;       // double[n_obs][dim]
     obtg::DevBuf d_w2;        // folded product weights for (deg, dim)
     obtg::DevBuf d_Tt;        // elevation (2*deg -> 2*deg+R) as convolution tables (elev_conv_tables)
-    obtg::DevBuf d_Td;        // the same elevation as a dense transposed matrix (elev_table_T)
+    obtg::DevBuf d_Td;        // the same elevation as a dense transposed matrix (elev_table_T_ld): rows for the lane-per-item chains
+    obtg::DevBuf d_Tf;        // ... and as matrix-instruction B fragments (elev_table_frag): the batch kernels
     obtg::DevBuf d_ang_w2n, d_ang_w22n, d_ang_wn;  // angular-rate fast path weights
     obtg::DevBuf d_ang_T4;    // angular rate, R > 0: elevation 4*deg -> 4*(deg+R) as a scaled convolution (elev_conv_padded)
+    obtg::DevBuf d_ang_T4f;   // the same elevation (4*deg -> 4*(deg+R)) as matrix-instruction B fragments (elev_table_frag)
     obtg::DevBuf d_ang_cv2;   // the same for the speed rows, 2*deg -> 2*deg+R, with the 1/C(2n+R, k) row
     bool ang_elevate_first = false;   // true: the reference's order (elevate, then products at degree n+R; generic kernel)
     // obtg_ctx_set_second_speed_bound: every dynamics pass that writes speed rows also writes the other bound's rows

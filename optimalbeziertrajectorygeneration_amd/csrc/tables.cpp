@@ -43,16 +43,43 @@ std::vector<double> folded_product_weights(int n, int dim)
     return W;
 }
 
-// Degree elevation of an L_in-coefficient curve by R (bezier.py:1127-1147), transposed and
-// dense: Tt[k][j] = C(N,j) C(R,k-j) / C(N+R,k), N = L_in-1, k = 0..N+R, j = 0..N.
-std::vector<double> elev_table_T(int L_in, int R)
+// Degree elevation of an L_in-coefficient curve by R (bezier.py:1127-1147): T[j][k] = C(N,j) C(R,k-j) / C(N+R,k),
+// N = L_in-1, k = 0..N+R, j = 0..N, in two layouts.
+// (a) in the operand order of v_mfma_f64_16x16x4_f64 (bern_device.h elev_rows_mfma): B fragment
+// (n-tile t, k-step s) = 64 doubles, lane l holds T[j = 4s + (l >> 4)][k = 16t + (l & 15)], zero outside the matrix;
+// layout [NT = ceil((L_in+R)/16)][KS = ceil(L_in/4)][64].  Entries through long double binomials: C(4n, j) C(4R, k-j)
+// of the angular rate's elevation (4R up to 1000) overflows binary64 before the division brings it back below 1.
+static long double binom_ld(int n, int k)
 {
-    int N = L_in - 1, Lr = L_in + R;
+    if (k < 0 || k > n) return 0.0L;
+    if (k > n - k) k = n - k;
+    long double r = 1.0L;
+    for (int i = 1; i <= k; ++i) r = r * (long double)(n - k + i) / (long double)i;
+    return r;
+}
+
+std::vector<double> elev_table_frag(int L_in, int R)
+{
+    const int N = L_in - 1, Lr = L_in + R, NT = (Lr + 15) / 16, KS = (L_in + 3) / 4;
+    std::vector<double> F((size_t)NT * KS * 64, 0.0);
+    for (int t = 0; t < NT; ++t)
+        for (int s = 0; s < KS; ++s)
+            for (int l = 0; l < 64; ++l) {
+                const int j = 4 * s + (l >> 4), k = 16 * t + (l & 15);
+                if (j <= N && k < Lr)
+                    F[((size_t)t * KS + s) * 64 + l] = (double)(binom_ld(N, j) * binom_ld(R, k - j) / binom_ld(N + R, k));
+            }
+    return F;
+}
+
+// (b) dense and transposed, Tt[k][j], through the same long double route (the lane-per-item forms of the same chain
+// read rows of it)
+std::vector<double> elev_table_T_ld(int L_in, int R)
+{
+    const int N = L_in - 1, Lr = L_in + R;
     std::vector<double> T((size_t)Lr * L_in, 0.0);
-    for (int k = 0; k < Lr; ++k) {
-        double den = binom(N + R, k);
-        for (int j = 0; j <= N; ++j) T[(size_t)k * L_in + j] = binom(N, j) * binom(R, k - j) / den;
-    }
+    for (int k = 0; k < Lr; ++k)
+        for (int j = 0; j <= N; ++j) T[(size_t)k * L_in + j] = (double)(binom_ld(N, j) * binom_ld(R, k - j) / binom_ld(N + R, k));
     return T;
 }
 

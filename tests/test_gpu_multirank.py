@@ -27,7 +27,7 @@ def test_pair_partitioned_sweeps_with_hip_evaluators(oracle):
     polys = synth.polygon_obstacles(M, seed=5)
     pa, pb = synth.swarm_pairs(N, M)
     ctx = _capi.Context(N, d, n, 0)
-    ctx.set_stream((torch.cuda.current_stream().cuda_stream or 1))
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
     ctx.set_polygons(*synth.pack_polys(polys))
     dY = torch.from_numpy(Yb).cuda()
     P, L = ctx.num_pairs, 2 * n + 1
@@ -57,7 +57,7 @@ def test_pair_partitioned_sweeps_with_hip_evaluators(oracle):
     ctx.set_hull_pairs(pa[b0:b0 + c], pb[b0:b0 + c])
     r = ctx.gjk_swarm(Yb, md_cap=500)
     assert np.array_equal(r["flag"], flag[:, b0:b0 + c]) and np.array_equal(r["dist"], dist_[:, b0:b0 + c], equal_nan=True)
-    ctx.set_stream(0)
+    ctx.use_own_stream()
     ctx.close()
 
 

@@ -152,9 +152,9 @@ def test_device_pointer_path_and_pair_partition(capi, oracle, synth):
     B = 9
     Yb = synth.fd_batch(Y, B=B)
     ctx = capi.Context(N, dim, n, R)
-    # (torch's default stream has handle 0, which the library reads as "my own stream": 1 = hipStreamLegacy names the
-    # null stream itself, so that the launches below are ordered with torch's fills and copies; _capi.torch_stream())
-    ctx.set_stream((torch.cuda.current_stream().cuda_stream or 1))
+    # (torch's default stream is the null stream, handle 0: obtg_ctx_set_stream takes the handle as given, so the launches
+    # below are ordered with torch's fills and copies; test_set_stream_orders_with_torchs_default_stream)
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
     dY = torch.from_numpy(Yb).cuda()
     P, L = ctx.num_pairs, 2 * n + R + 1
     full = torch.empty((B, P * L), dtype=torch.float64, device="cuda")
@@ -177,7 +177,7 @@ def test_device_pointer_path_and_pair_partition(capi, oracle, synth):
     ctx.fd_batch_dev(d0.data_ptr(), 1, synth.FD_STEP, B, dfd.data_ptr())
     torch.cuda.synchronize()
     assert np.array_equal(dfd.cpu().numpy(), Yb)
-    ctx.set_stream(0)
+    ctx.use_own_stream()
     ctx.close()
 
 
@@ -345,7 +345,7 @@ def test_c3_full_batch_properties(capi, synth):
     N, dim, n = 64, 2, 10
     Y = synth.swarm_control_points(N, dim, n, seed=1234)
     ctx = capi.Context(N, dim, n, 0)
-    ctx.set_stream((torch.cuda.current_stream().cuda_stream or 1))
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
     B = N * dim * (n - 1) + 1
     d0 = torch.from_numpy(Y).cuda()
     dY = torch.empty((B,) + Y.shape, dtype=torch.float64, device="cuda")
@@ -365,7 +365,7 @@ def test_c3_full_batch_properties(capi, synth):
         assert changed[b][involved].all()
     shifted = ctx.temporal_sep(Y + 7.25, 0.9)[0].reshape(P, L)
     assert_close(shifted, single, 1e-9)
-    ctx.set_stream(0)
+    ctx.use_own_stream()
     mins = []
     for R in (0, 5, 20):
         ctx.set_deg_elev(R)
@@ -383,7 +383,7 @@ def test_fused_dynamics_matches_separate_calls(capi, oracle, synth):
         Yb = synth.fd_batch(Y, B=B)
         tf = np.linspace(1.5, 8.0, B)
         ctx = capi.Context(N, 2, n, R)
-        ctx.set_stream((torch.cuda.current_stream().cuda_stream or 1))
+        ctx.set_stream(torch.cuda.current_stream().cuda_stream)
         dY = torch.from_numpy(Yb).cuda()
         dtf = torch.from_numpy(tf).cuda()
         osp = torch.empty((B, ctx.len_speed), dtype=torch.float64, device="cuda")
@@ -398,7 +398,7 @@ def test_fused_dynamics_matches_separate_calls(capi, oracle, synth):
         ctx.dynamics_dev(dY.data_ptr(), dtf.data_ptr(), B, 4.0, True, 1.5, only.data_ptr(), 0)
         torch.cuda.synchronize()
         assert_close(only.cpu().numpy(), o_sp, RTOL, "speed only through the fused entry")
-        ctx.set_stream(0)
+        ctx.use_own_stream()
         ctx.close()
 
 
@@ -439,7 +439,7 @@ def test_pair_partition_large_swarm(capi, synth):
     Y = synth.swarm_control_points(N, 2, n, seed=2)
     Yb = synth.fd_batch(Y, B=3)
     ctx = capi.Context(N, 2, n, 0)
-    ctx.set_stream((torch.cuda.current_stream().cuda_stream or 1))
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
     dY = torch.from_numpy(Yb).cuda()
     P, L = ctx.num_pairs, 21
     full = torch.empty((3, P, L), dtype=torch.float64, device="cuda")
@@ -451,7 +451,7 @@ def test_pair_partition_large_swarm(capi, synth):
         parts.append(o)
     torch.cuda.synchronize()
     assert torch.equal(torch.cat(parts, dim=1), full)
-    ctx.set_stream(0)
+    ctx.use_own_stream()
     ctx.close()
 
 
@@ -681,7 +681,7 @@ def test_pair_sweep_one_launch_equals_separate_kernels(capi, synth, shape):
         ctx.set_polygons(*synth.pack_polys(synth.polygon_obstacles(M, seed=8)))
     ctx.set_hull_pairs(pa, pb)
     dev = torch.device("cuda")
-    ctx.set_stream((torch.cuda.current_stream().cuda_stream or 1))
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
     dY = torch.from_numpy(Yb).to(dev)
     P, L, Ps = ctx.num_pairs, 2 * n + 1, len(pa)
     assert P == (N + n_obs) * (N + n_obs - 1) // 2
@@ -714,7 +714,7 @@ def test_pair_sweep_one_launch_equals_separate_kernels(capi, synth, shape):
         ks = {k: v[1] for k, v in ctx.kernel_stats().items() if v[1]}
         ctx.set_profiling(False)
         assert ks == {"pair_sweep": 1}, ks                                 # ONE launch
-    ctx.set_stream(0)
+    ctx.use_own_stream()
     ctx.close()
 
 
@@ -810,7 +810,7 @@ def test_pair_sweep_random_shapes(capi, synth):
             polys = [p_[:min(len(p_), n + 1)] for p_ in polys]   # the planar kernel wants <= n+1 vertices
             ctx.set_polygons(*synth.pack_polys(polys))
         ctx.set_hull_pairs(pa, pb)
-        ctx.set_stream((torch.cuda.current_stream().cuda_stream or 1))
+        ctx.set_stream(torch.cuda.current_stream().cuda_stream)
         dY = torch.from_numpy(Yb).to(dev)
         P, L, Ps = ctx.num_pairs, 2 * n + 1, len(pa)
 
@@ -833,7 +833,7 @@ def test_pair_sweep_random_shapes(capi, synth):
             torch.cuda.synchronize()
             for i, (x, y) in enumerate(zip(a, b)):
                 assert np.array_equal(x.cpu().numpy(), y.cpu().numpy(), equal_nan=True), (trial, rnd, i, N, n, M, B, Ps)
-        ctx.set_stream(0)
+        ctx.use_own_stream()
         ctx.close()
 
 
@@ -913,7 +913,7 @@ def test_c5_hull_sweep_with_curve_obstacles(capi, oracle, synth, golden_dir):
         for key in ("dist", "c1", "c2"):
             assert np.max(np.abs(r[key][b][sp] - o[key][sp]) / np.maximum(1.0, np.abs(o[key][sp]))) < 1e-12
     # device-pointer form (what bench.py --workload C5 times), second call = history-ordered schedule
-    ctx.set_stream((torch.cuda.current_stream().cuda_stream or 1))
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
     dY = torch.from_numpy(Yb).cuda()
     Ps = len(pa)
     t_flag = torch.empty((B, Ps), dtype=torch.int32, device="cuda")
@@ -929,7 +929,7 @@ def test_c5_hull_sweep_with_curve_obstacles(capi, oracle, synth, golden_dir):
         assert np.array_equal(t_flag.cpu().numpy(), r["flag"]) and np.array_equal(t_ns.cpu().numpy(), r["n_support"])
         assert np.array_equal(t_dist.cpu().numpy(), r["dist"], equal_nan=True)
         assert np.array_equal(t_p1.cpu().numpy(), r["c1"], equal_nan=True)
-    ctx.set_stream(0)
+    ctx.use_own_stream()
     ctx.close()
 
 
@@ -975,7 +975,7 @@ def test_pair_sweep_at_bench_shape_vs_oracle(capi, oracle, synth):
     statics, pa, pb = synth.config_hull_sweep("C3", seed=1234)
     B = N * d * (n - 1) + 1
     ctx = capi.Context(N, d, n, 0)
-    ctx.set_stream((torch.cuda.current_stream().cuda_stream or 1))
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
     ctx.set_polygons(*synth.pack_polys(statics))
     ctx.set_hull_pairs(pa, pb)
     d0 = torch.from_numpy(Y).cuda()
@@ -1013,7 +1013,7 @@ def test_pair_sweep_at_bench_shape_vs_oracle(capi, oracle, synth):
         sep = o["flag"] == 1
         for got, ref in ((di[k], o["dist"]), (c1[k], o["c1"]), (c2[k], o["c2"])):
             assert np.max(np.abs(got[sep] - ref[sep]) / np.maximum(1.0, np.abs(ref[sep]))) < 1e-12
-    ctx.set_stream(0)
+    ctx.use_own_stream()
     ctx.close()
 
 
@@ -1114,13 +1114,13 @@ def test_ang_rate_with_elevation_both_orders(capi, oracle, synth, golden_dir):
         B = 7
         Yb = synth.fd_batch(Y, B=B)
         tfs = np.linspace(2.0, 9.0, B)
-        ctx.set_stream((torch.cuda.current_stream().cuda_stream or 1))
+        ctx.set_stream(torch.cuda.current_stream().cuda_stream)
         dY, dtf = torch.from_numpy(Yb).cuda(), torch.from_numpy(tfs).cuda()
         osp = torch.empty((B, ctx.len_speed), dtype=torch.float64, device="cuda")
         oan = torch.empty((B, ctx.len_ang_rate), dtype=torch.float64, device="cuda")
         ctx.dynamics_dev(dY.data_ptr(), dtf.data_ptr(), B, vmax, True, wmax, osp.data_ptr(), oan.data_ptr())
         torch.cuda.synchronize()
-        ctx.set_stream(0)
+        ctx.use_own_stream()
         _, o_sp, o_an = oracle.eval_batch(Yb, tfs, N, 2, R, 0.9, vmax, wmax)
         assert_close(osp.cpu().numpy(), o_sp, RTOL, name + " fused speed")
         assert_close(oan.cpu().numpy(), o_an, RTOL, name + " fused ang")
@@ -1153,7 +1153,7 @@ def test_fd_forms_equal_the_materialised_batch(capi, synth, shape):
     pa, pb = synth.swarm_pairs(N, M)
     B = N * d * (n + 1 - 2 * fixed) + 1 if shape != "C3" else 300
     ctx = capi.Context(N, d, n, R)
-    ctx.set_stream((torch.cuda.current_stream().cuda_stream or 1))
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
     ctx.set_polygons(*(synth.pack_polys(polys) if M else (None, [0])))
     ctx.set_hull_pairs(pa, pb)
     on_fly = ctx.fd_forms_on_the_fly()
@@ -1220,7 +1220,7 @@ def test_fd_forms_equal_the_materialised_batch(capi, synth, shape):
     with pytest.raises(capi.ObtgError):
         ctx.dynamics_fd_dev(d0.data_ptr(), fixed, h, dtf.data_ptr(), N * d * (n + 1 - 2 * fixed) + 2, 4.0, True, 1.5,
                             b["sp"].data_ptr(), an_b)
-    ctx.set_stream(0)
+    ctx.use_own_stream()
     ctx.close()
 
 
@@ -1307,7 +1307,7 @@ def test_constraint_sweep_equals_separate_calls(capi, synth, shape):
     polys = synth.polygon_obstacles(M, seed=21)
     pa, pb = synth.swarm_pairs(N, M)
     ctx = capi.Context(N, 2, n, R, point_obs=np.array([[20.0, 30.0], [55.5, 41.0], [70.0, 12.5]]) if shape == "with_point_obstacles" else None)
-    ctx.set_stream((torch.cuda.current_stream().cuda_stream or 1))
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
     ctx.set_polygons(*(synth.pack_polys(polys) if M else (None, [0])))
     ctx.set_hull_pairs(pa, pb)
     h = 1e-3
@@ -1355,7 +1355,7 @@ def test_constraint_sweep_equals_separate_calls(capi, synth, shape):
             assert ks.get("temporal_sep", (0.0, 0))[1] == 2 and ks.get("gjk", (0.0, 0))[1] == 2 and ks.get("ang_rate", (0.0, 0))[1] == 0, ks
         for key in a:
             assert torch.equal(a[key].view(torch.uint8), b[key].view(torch.uint8)), (key, view)
-    ctx.set_stream(0)
+    ctx.use_own_stream()
     ctx.close()
 
 
@@ -1370,7 +1370,7 @@ def test_both_speed_bounds_from_one_pass(capi, synth, oracle, shape):
                         "space3d": (7, 3, 5, 0, 0, 6), "generic": (5, 2, 12, 2, 0, 4)}[shape]
     Y = synth.fd_batch(synth.swarm_control_points(N, d, n, seed=33), B=B, h=1e-3)
     ctx = capi.Context(N, d, n, R)
-    ctx.set_stream((torch.cuda.current_stream().cuda_stream or 1))
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
     dY = torch.from_numpy(Y).cuda()
     dtf = torch.from_numpy(np.linspace(3.0, 9.0, B)).cuda()
     vmin, vmax, wmax = 0.7, 4.0, 1.5
@@ -1417,7 +1417,7 @@ def test_both_speed_bounds_from_one_pass(capi, synth, oracle, shape):
     o_max = oracle.eval_batch(Y, np.linspace(3.0, 9.0, B), N, d, R, 0.9, vmax, wmax)[1]
     assert_close(got_max.cpu().numpy(), o_max, RTOL, shape + " max speed vs oracle")
     assert_close(got_min.cpu().numpy(), (vmax ** 2 - o_max) - vmin ** 2, 1e-9, shape + " min speed vs oracle")
-    ctx.set_stream(0)
+    ctx.use_own_stream()
     ctx.close()
 
 
@@ -1441,7 +1441,7 @@ def test_structured_fd_step_is_bit_identical_to_the_brute_force_sweep(capi, synt
     Y = synth.swarm_control_points(N, 2, n, seed=41)
     B = N * 2 * (n + 1 - 2 * fixed) + 1
     ctx = capi.Context(N, 2, n, R)
-    ctx.set_stream((torch.cuda.current_stream().cuda_stream or 1))
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
     if shape == "C5_like_R100":           # BASELINE configs[4]: 32 curve obstacles as static hulls, every pair of the 96 objects
         statics, pa, pb = synth.config_hull_sweep("C5", seed=41)
         ctx.set_polygons(*synth.pack_polys(statics))
@@ -1492,7 +1492,7 @@ def test_structured_fd_step_is_bit_identical_to_the_brute_force_sweep(capi, synt
     assert ks == {"pair_sweep": 1}, ks                                     # ONE launch
     for key in a:
         assert torch.equal(a[key].view(torch.uint8), b[key].view(torch.uint8)), (shape, tf_rows, key)
-    ctx.set_stream(0)
+    ctx.use_own_stream()
     ctx.close()
 
 
@@ -1537,7 +1537,7 @@ def test_3d_sweep_as_one_launch_equals_separate_calls(capi, synth, N, n, M, B):
     polys = [rng.uniform(0, 100, size=(1, 3)) + rng.normal(0, 6.0, size=(int(rng.integers(3, n + 2)), 3)) for _ in range(M)]
     pa, pb = synth.swarm_pairs(N, M)
     ctx = capi.Context(N, 3, n, 0)
-    ctx.set_stream((torch.cuda.current_stream().cuda_stream or 1))
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
     if M:
         ctx.set_polygons(*synth.pack_polys(polys))
     ctx.set_hull_pairs(pa, pb)
@@ -1586,5 +1586,41 @@ def test_3d_sweep_as_one_launch_equals_separate_calls(capi, synth, N, n, M, B):
         for key in a:
             assert torch.equal(a[key].view(torch.uint8), b[key].view(torch.uint8)), (key, view)
         assert not torch.isnan(b["sep"]).any() and not torch.isnan(b["sp"]).any()
-    ctx.set_stream(0)
+    ctx.use_own_stream()
+    ctx.close()
+
+
+@pytest.mark.gpu
+def test_set_stream_orders_with_torchs_default_stream(capi, synth):
+    """obtg_ctx_set_stream(torch's current stream) -- handle 0, the null stream, for torch's default -- orders the library's
+    launches with torch's own work: a large fill on that stream, a sweep into the filled buffer and a torch read of it
+    need no explicit synchronisation between them (include/obtg.h: until round 4 handle 0 meant "the context's own
+    stream" and this sequence raced).  obtg_ctx_use_own_stream goes back to the private stream."""
+    import torch
+    N, n, B = 64, 10, 600
+    Y = synth.swarm_control_points(N, 2, n, seed=8)
+    ctx = capi.Context(N, 2, n, 0)
+    P, L = ctx.num_pairs, 2 * n + 1
+    d0 = torch.from_numpy(Y).cuda()
+    dY = torch.empty((B,) + Y.shape, dtype=torch.float64, device="cuda")
+    ref = torch.empty((B, P * L), dtype=torch.float64, device="cuda")
+    ctx.use_own_stream()
+    ctx.fd_batch_dev(d0.data_ptr(), 1, synth.FD_STEP, B, dY.data_ptr())
+    ctx.temporal_sep_dev(dY.data_ptr(), B, 0.9, ref.data_ptr())
+    ctx.sync()
+    torch.cuda.synchronize()
+    assert torch.cuda.current_stream().cuda_stream == 0            # torch's default stream IS the null stream
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    for trial in range(5):
+        out = torch.full((B, P * L), float("nan"), dtype=torch.float64, device="cuda")     # 390 MB fill on torch's stream ...
+        ctx.temporal_sep_dev(dY.data_ptr(), B, 0.9, out.data_ptr())                           # ... the sweep behind it ...
+        same = torch.equal(out, ref)                                                          # ... and torch's read behind the sweep
+        assert same, "trial %d: the sweep was not ordered with torch's default stream" % trial
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):                                     # a non-default torch stream, the same way
+        ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+        out = torch.full((B, P * L), float("nan"), dtype=torch.float64, device="cuda")
+        ctx.temporal_sep_dev(dY.data_ptr(), B, 0.9, out.data_ptr())
+        assert torch.equal(out, ref)
+    ctx.use_own_stream()
     ctx.close()

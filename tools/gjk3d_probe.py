@@ -9,7 +9,7 @@ for name in ('C2', 'C2_file'):
     pa, pb = synth.swarm_pairs(N, 0)
     dev = torch.device('cuda'); f64 = torch.float64
     c = _capi.Context(N, d, n, 0); c.set_hull_pairs(pa, pb)
-    c.set_stream((torch.cuda.current_stream().cuda_stream or 1))
+    c.set_stream(torch.cuda.current_stream().cuda_stream)
     d0 = torch.from_numpy(Y).to(dev); dY = torch.empty((B, N * d, n + 1), dtype=f64, device=dev)
     c.fd_batch_dev(d0.data_ptr(), 1, 1.49e-8, B, dY.data_ptr()); torch.cuda.synchronize()
     Ps = len(pa)

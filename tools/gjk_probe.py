@@ -12,7 +12,7 @@ polys = synth.polygon_obstacles(M); ppts, poff = synth.pack_polys(polys); pa, pb
 dev = torch.device('cuda'); f64 = torch.float64
 c = _capi.Context(N, d, n, 0); c.set_polygons(ppts, poff); c.set_hull_pairs(pa, pb)
 d0 = torch.from_numpy(Y).to(dev); dY = torch.empty((B, N * d, n + 1), dtype=f64, device=dev)
-c.set_stream((torch.cuda.current_stream().cuda_stream or 1))
+c.set_stream(torch.cuda.current_stream().cuda_stream)
 c.fd_batch_dev(d0.data_ptr(), 1, 1.49e-8, B, dY.data_ptr()); torch.cuda.synchronize()
 Ps = len(pa)
 g_flag = torch.empty((B, Ps), dtype=torch.int32, device=dev); g_p1 = torch.empty((B, Ps, 3), dtype=f64, device=dev)

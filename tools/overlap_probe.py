@@ -10,7 +10,7 @@ s1=torch.cuda.Stream(); s2=torch.cuda.Stream()
 cA=_capi.Context(N,d,n,R); cB=_capi.Context(N,d,n,R)
 cA.set_polygons(ppts,poff); cA.set_hull_pairs(pa,pb)
 d0=torch.from_numpy(Y).to(dev); dY=torch.empty((B,N*d,n+1),dtype=f64,device=dev)
-cA.set_stream((torch.cuda.current_stream().cuda_stream or 1))
+cA.set_stream(torch.cuda.current_stream().cuda_stream)
 cA.fd_batch_dev(d0.data_ptr(),1,1.49e-8,B,dY.data_ptr()); torch.cuda.synchronize()
 d_tf=torch.full((B,),10.0,dtype=f64,device=dev)
 P=cA.num_pairs; L=21; Ps=len(pa)

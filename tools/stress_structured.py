@@ -36,7 +36,7 @@ def main():
             continue
         Y = synth.swarm_control_points(N, 2, n, seed=5000 + trial)
         ctx = capi.Context(N, 2, n, R)
-        ctx.set_stream((torch.cuda.current_stream().cuda_stream or 1))
+        ctx.set_stream(torch.cuda.current_stream().cuda_stream)
         pa, pb = synth.swarm_pairs(N, M)
         ctx.set_polygons(*(synth.pack_polys(synth.polygon_obstacles(M, seed=trial)) if M else (None, [0])))
         ctx.set_hull_pairs(pa, pb)
@@ -60,7 +60,7 @@ def main():
         except capi.ObtgError as e:
             skipped += 1
             print("trial %d skipped (%s): %s" % (trial, str(e)[:60], what), flush=True)
-            ctx.set_stream(0); ctx.close()
+            ctx.use_own_stream(); ctx.close()
             continue
         ctx.fd_view_begin(d0.data_ptr(), fixed, h, B)
         ctx.constraint_sweep_dev(None, dtf.data_ptr(), B, 0.9, a["sep"].data_ptr(), 4.0, True, 1.5, a["sp"].data_ptr(),
@@ -74,7 +74,7 @@ def main():
                 raise SystemExit("trial %d MISMATCH in %s (%d bytes, first at %s): %s" % (trial, key, len(bad), bad[0].tolist(), what))
         done += 1
         print("trial %d ok: %s  (%.0f s)" % (trial, what, time.time() - t0), flush=True)
-        ctx.set_stream(0); ctx.close()
+        ctx.use_own_stream(); ctx.close()
     print("stress ok: %d trials compared, %d outside the structured step's shapes" % (done, skipped))
 
 

@@ -34,7 +34,7 @@ def main():
         if M:
             ctx.set_polygons(*synth.pack_polys(polys))
         ctx.set_hull_pairs(pa, pb)
-        ctx.set_stream((torch.cuda.current_stream().cuda_stream or 1))
+        ctx.set_stream(torch.cuda.current_stream().cuda_stream)
         dY = torch.from_numpy(Yb).to(dev)
         P, L, Ps = ctx.num_pairs, 2 * n + 1, len(pa)
 
@@ -86,7 +86,7 @@ def main():
             got = a[0].cpu().numpy()
             err = np.max(np.abs(got - ref_sep) / np.maximum(1.0, np.abs(ref_sep)))
             assert err < 1e-9, ("sep", trial, err)
-        ctx.set_stream(0)
+        ctx.use_own_stream()
         ctx.close()
         print("trial %d ok: N=%d n=%d M=%d B=%d hull pairs=%d%s%s  (%.0f s)" % (trial, N, n, M, B, Ps, " tiled-size" if big else "",
               " partial" if partial else "", time.time() - t0), flush=True)

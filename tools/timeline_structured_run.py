@@ -9,7 +9,7 @@ Y = synth.swarm_control_points(N, 2, n, seed=1234)
 statics, pa, pb = synth.config_hull_sweep(WL)
 B = N * 2 * (n - 1) + 1
 ctx = capi.Context(N, 2, n, R)
-ctx.set_stream((torch.cuda.current_stream().cuda_stream or 1))
+ctx.set_stream(torch.cuda.current_stream().cuda_stream)
 ctx.set_polygons(*synth.pack_polys(statics)); ctx.set_hull_pairs(pa, pb)
 d0 = torch.from_numpy(Y).cuda(); dtf = torch.full((B,), 10.0, dtype=torch.float64, device="cuda")
 P, L, Ps = ctx.num_pairs, 2 * n + R + 1, len(pa)

@@ -7,7 +7,7 @@ cfg = synth.CONFIGS[name]
 N, d, n, R = cfg['N'], cfg['d'], cfg['n'], cfg['R']
 Y = synth.swarm_control_points(N, d, n); B = int(sys.argv[2]) if len(sys.argv) > 2 else N * d * (n - 1) + 1
 dev = torch.device('cuda'); f64 = torch.float64
-c = _capi.Context(N, d, n, R); c.set_stream((torch.cuda.current_stream().cuda_stream or 1))
+c = _capi.Context(N, d, n, R); c.set_stream(torch.cuda.current_stream().cuda_stream)
 P, L = c.num_pairs, 2 * n + R + 1
 d0 = torch.from_numpy(Y).to(dev); dY = torch.empty((B, N * d, n + 1), dtype=f64, device=dev)
 c.fd_batch_dev(d0.data_ptr(), 1, synth.FD_STEP, B, dY.data_ptr())
