@@ -71,8 +71,11 @@ def parse():
     ap.add_argument("--fd-dedup", action="store_true",
                     help="reuse row 0's gjkNew results for bit-identical hull pairs (obtg_ctx_set_fd_dedup); "
                          "NOT the headline number")
-    ap.add_argument("--mode", default="batch", choices=["batch", "pairs", "mindist"],
+    ap.add_argument("--mode", default="batch", choices=["batch", "rows", "pairs", "mindist"],
                     help="batch: every rank evaluates its own FD batch, no collective (default, the headline); "
+                         "rows: ONE swarm, ONE SLSQP iteration -- its n_x + 1 rows split over the ranks by distributed.shard_rows "
+                         "(SURVEY.md 8(e).1), every rank an obtg_fd_view_begin_rows over its range, results left per rank, no "
+                         "collective on the data path: `scaling` strong; "
                          "pairs: ONE evaluation batch, the pair lists (temporal separation AND gjkNew hull pairs) "
                          "partitioned over the ranks and the per-pair minima all-gathered (RCCL) -- the 256-vehicle "
                          "case of BASELINE.json")
@@ -88,6 +91,10 @@ def parse():
     ap.add_argument("--force-dist", action="store_true",
                     help="rehearsal: initialise torch.distributed and run the collectives even with one rank "
                          "(exercises the RCCL path on a one-GPU box)")
+    ap.add_argument("--gather-minima", action="store_true",
+                    help="--mode rows: after every step all-gather the per-(row, pair) separation minima (what a driver that "
+                         "keeps only active rows would collect: 8 bytes per row and pair)")
+    ap.add_argument("--no-proxy", action="store_true", help="skip the strong_scaling_proxy leg of a 1-GPU batch-mode run")
     ap.add_argument("--one-device", action="store_true",
                     help="rehearsal only: every rank uses device 0 (needs --backend gloo)")
     return ap.parse_args()
@@ -247,6 +254,12 @@ def main():
     N, d, n, R = cfg["N"], cfg["d"], cfg["n"], cfg["R"]
     n_x = N * d * (n - 1)
     B = args.batch or (n_x + 1)
+    B_total, row_begin = B, 0
+    if args.mode == "rows":          # one iteration's rows over the ranks: contiguous balanced blocks
+        from optimalbeziertrajectorygeneration_amd import distributed as _dd
+        row_begin, B = _dd.shard_rows(B_total, world, rank)
+        if args.materialise:
+            raise SystemExit("bench.py --mode rows evaluates row ranges of a view (obtg_fd_view_begin_rows): not with --materialise")
     seed = 1234 + (1000 * rank if args.mode == "batch" else 0)   # batch mode: every rank its own swarm instance
     Y = synth.swarm_control_points(N, d, n, seed=seed)
     statics, pa, pb = synth.config_hull_sweep(args.workload, seed=1234)
@@ -296,7 +309,7 @@ def main():
     # stages them -- an obtg_fd_view over x's control points, the sweeps called with dY = NULL; kernels without that
     # form make the library write the batch once per step (what --materialise forces for all of them)
     fly_sweep, fly_dyn = ctx.fd_forms_on_the_fly()
-    use_view = not args.materialise and B <= n_x + 1
+    use_view = not args.materialise and row_begin + B <= n_x + 1
     on_the_fly = use_view and one_launch and o_an is not None and fly_sweep and fly_dyn      # two launches, nothing written
     # the dynamics launch is latency bound (one or two wavefronts per SIMD), the pair sweep VALU bound: on two streams
     # the first hides under the second.  A context owns one stream, so the dynamics launch gets a context of its own.
@@ -310,7 +323,7 @@ def main():
 
     everything = one_launch and not two_streams       # (3-D rows: no angular rate; the 3-D sweep's launch then takes the speed rows too)
 
-    def sweeps():
+    def sweeps(B=B):
         if everything:       # all four families through one call (two launches at C3: pair sweep, dynamics)
             ctx.constraint_sweep_dev(Yp, d_tf.data_ptr(), B, max_sep, o_sep.data_ptr(), vmax, True, wmax, o_sp.data_ptr(),
                                      o_an.data_ptr() if o_an is not None else None, g_flag.data_ptr(), g_p1.data_ptr(),
@@ -330,15 +343,26 @@ def main():
             ctx.gjk_swarm_dev(Yp, B, g_flag.data_ptr(), g_p1.data_ptr(), g_p2.data_ptr(),
                               g_dist.data_ptr(), None, g_stat.data_ptr(), 128, 256)
 
+    d_min = None
+    if args.mode == "rows" and args.gather_minima:
+        counts = [c for _, c in _dd.partition(B_total, world)]
+        d_min_all = torch.empty((world, max(counts), P_t), dtype=f64, device=dev)
+        d_min = torch.zeros((max(counts), P_t), dtype=f64, device=dev)
+
     def step():
         if not use_view:
             ctx.fd_batch_dev(d0.data_ptr(), 1, synth.FD_STEP, B, dY.data_ptr())
             return sweeps()
         for cx in ([ctx, ctx_dyn] if ctx_dyn is not ctx else [ctx]):
-            cx.fd_view_begin(d0.data_ptr(), 1, synth.FD_STEP, B)
+            cx.fd_view_begin(d0.data_ptr(), 1, synth.FD_STEP, B, row_begin=row_begin)
         sweeps()
         for cx in ([ctx, ctx_dyn] if ctx_dyn is not ctx else [ctx]):
             cx.fd_view_end()
+        if d_min is not None:         # (torch's work on its own stream: hand over with the library's sync)
+            ctx.sync()
+            torch.amin(o_sep.view(B, P_t, L), dim=2, out=d_min[:B])
+            if use_dist:
+                dist.all_gather_into_tensor(d_min_all.view(-1), d_min.view(-1))
 
     # spin-up: the clocks of an idle MI355X need a few hundred ms of work to settle (at C3 a step reads 0.257 ms
     # straight after start and 0.205 ms once they have); untimed, before the W warm-up steps
@@ -409,33 +433,61 @@ def main():
     # ---- variants, beside -- never as -- `value`: the same step (a) with the trip-count history off (pairs swept in
     # list order), (b) with x MOVING between steps the way SLSQP moves it: every step evaluates the FD batch around a
     # new x, one N(0, 1e-2) step of a random walk on the free control points away from the previous one, so the history
-    # the sweep orders its pairs by comes from a different point each time (identical replays are its best case).
+    # the sweep orders its pairs by comes from a different point each time (identical replays are its best case),
+    # (c) the structured finite-difference step.  Every variant: its own 0.2 s of untimed steps, then three timed runs of
+    # max(--steps, 200) steps each; the line carries the median and the spread (max - min) / median.
     variants = None
+    proxy = None
     _sumK = N * (n + 1) + (int(poff[-1]) if M else 0)
     total_bytes_ = algorithmic_bytes(N, d, n, R, P_t, P_s, _sumK)[1]
-    if use_view and use_gjk and args.mode == "batch" and not args.no_variants:
-        def timed(nsteps, fn):
+
+    def timed(nsteps, fn, reps=3, spin=0.2):
+        t_s = time.perf_counter()
+        k = 0
+        while time.perf_counter() - t_s < spin:
             for _ in range(10):
-                fn(0)
+                fn(k)
+                k += 1
+            torch.cuda.synchronize()
+        runs = []
+        for _ in range(reps):
             torch.cuda.synchronize()
             a = time.perf_counter()
             for i in range(nsteps):
                 fn(i)
             torch.cuda.synchronize()
-            return 1e3 * (time.perf_counter() - a) / nsteps
+            runs.append(1e3 * (time.perf_counter() - a) / nsteps)
+        runs.sort()
+        med = runs[len(runs) // 2]
+        return med, (runs[-1] - runs[0]) / med
 
-        def step_at(ptr):
-            for cx in ctxs:
-                cx.fd_view_begin(ptr, 1, synth.FD_STEP, B)
-            sweeps()
-            for cx in ctxs:
-                cx.fd_view_end()
+    def entry(ms_spread, rows, **kw):
+        ms, spread = ms_spread
+        e = {"ms_per_step": round(ms, 4), "spread": round(spread, 4), "evals_per_s": round(rows / (ms * 1e-3), 1)}
+        e.update(kw)
+        return e
 
-        nv = min(args.steps, 200)
+    def step_at(ptr, Bs=B):
+        for cx in ctxs:
+            cx.fd_view_begin(ptr, 1, synth.FD_STEP, Bs, row_begin=row_begin)
+        sweeps(Bs)
+        for cx in ctxs:
+            cx.fd_view_end()
+
+    def structured(Bs=B):
+        ctx.constraint_sweep_fd_structured_dev(d0.data_ptr(), 1, synth.FD_STEP, d_tf.data_ptr(), Bs, max_sep,
+                                               o_sep.data_ptr(), vmax, True, wmax, o_sp.data_ptr(), o_an.data_ptr(),
+                                               g_flag.data_ptr(), g_p1.data_ptr(), g_p2.data_ptr(), g_dist.data_ptr(),
+                                               None, g_stat.data_ptr(), 128, 256)
+
+    nv = max(args.steps, 200)
+    nv = max(20, min(nv, int(2000.0 / max(1e3 * elapsed / args.steps, 1e-3))))      # (a 26 ms step: 76 steps per run, not 500)
+    can_structured = everything and o_an is not None and row_begin == 0
+    if use_view and use_gjk and args.mode == "batch" and not args.no_variants:
         variants = {}
         ctx.set_gjk_history(False)
-        variants["history_off"] = {"ms_per_step": round(timed(nv, lambda i: step_at(d0.data_ptr())), 4),
-                                   "what": "obtg_ctx_set_gjk_history(0): pairs swept in list order"}
+        variants["history_off"] = entry(timed(nv, lambda i: step_at(d0.data_ptr())), B,
+                                        what="obtg_ctx_set_gjk_history(0): pairs swept in list order")
         ctx.set_gjk_history(True)
         rng = np.random.default_rng(99)
         walk = [Y.copy()]
@@ -445,45 +497,75 @@ def main():
             walk.append(nxt)
         d_walk = [torch.from_numpy(w).to(dev) for w in walk]
         seq = list(range(32)) + list(range(30, 0, -1))          # there and back: consecutive steps are one move apart
-        variants["moving_x"] = {"ms_per_step": round(timed(nv, lambda i: step_at(d_walk[seq[i % len(seq)]].data_ptr())), 4),
-                                "what": "x advanced between steps by N(0, 1e-2) on every free control point (random walk, "
-                                        "32 positions there and back); history from the previous position"}
+        variants["moving_x"] = entry(timed(nv, lambda i: step_at(d_walk[seq[i % len(seq)]].data_ptr())), B,
+                                     what="x advanced between steps by N(0, 1e-2) on every free control point (random walk, "
+                                          "32 positions there and back); history from the previous position")
         ctx.set_gjk_history(False)
-        variants["moving_x_history_off"] = {
-            "ms_per_step": round(timed(nv, lambda i: step_at(d_walk[seq[i % len(seq)]].data_ptr())), 4)}
+        variants["moving_x_history_off"] = entry(timed(nv, lambda i: step_at(d_walk[seq[i % len(seq)]].data_ptr())), B)
         ctx.set_gjk_history(True)
         # (c) the structured finite-difference step: ONE launch that evaluates row 0 in full and, per perturbed row, only
         # the pairs and the vehicle its advanced control point touches (obtg_constraint_sweep_fd_structured_dev); same
-        # output buffers, bit for bit (tests/), a different evaluation strategy -- hence a variant, not `value`
-        if everything and o_an is not None:
-            def structured(_i):
-                ctx.constraint_sweep_fd_structured_dev(d0.data_ptr(), 1, synth.FD_STEP, d_tf.data_ptr(), B, max_sep,
-                                                       o_sep.data_ptr(), vmax, True, wmax, o_sp.data_ptr(), o_an.data_ptr(),
-                                                       g_flag.data_ptr(), g_p1.data_ptr(), g_p2.data_ptr(), g_dist.data_ptr(),
-                                                       None, g_stat.data_ptr(), 128, 256)
+        # output buffers, bit for bit (tests/), a different evaluation strategy -- hence a variant, not `value`.  Its own
+        # parity figure: the buffers IT left behind against the oracle, on the same sample of rows as `parity_check`.
+        if can_structured:
             try:
-                structured(0)
-                ms = timed(nv, structured)
+                for t_ in (o_sep, o_sp, o_an, g_dist):
+                    t_.fill_(float("nan"))
+                g_flag.fill_(-7)
+                torch.cuda.synchronize()
+                structured()
+                torch.cuda.synchronize()
+                s_par = None
+                if rank == 0 and not args.no_cpu and args.gpus == 1:
+                    s_snap = parity_snapshot(dict(Y=dY, sep=o_sep, speed=o_sp, ang=o_an, flag=g_flag, dist=g_dist, p1=g_p1), B)
+                    s_par = parity_check(s_snap, N, d, n, R, statics, pa, pb, use_gjk, max_sep, vmax, wmax, tfv)
+                    s_par = {k: s_par[k] for k in ("rows", "max_rel", "max_rel_elementwise", "flags_equal", "gjk_dist_max_rel", "ok")}
+                t_ms = timed(nv, lambda i: structured())
                 prof(True, only="pair_sweep")
-                for i in range(min(nv, 50)):
-                    structured(i)
+                for i in range(50):
+                    structured()
                 kms, kcnt = kstats().get("pair_sweep", (0.0, 0))
                 prof(False)
                 gbs = B * total_bytes_ / ((kms / max(kcnt, 1)) * 1e-3) / 1e9 if kcnt else None
-                variants["fd_structured"] = {
-                    "ms_per_step": round(ms, 4), "kernel_avg_ms": round(kms / max(kcnt, 1), 5), "launches_per_step": 1,
-                    "alg_bytes_per_launch": B * total_bytes_, "achieved_gbs": round(gbs, 2) if gbs else None,
-                    "frac": round(gbs / HBM_PEAK_GBS, 5) if gbs else None,
-                    "what": "row 0 evaluated in full and streamed into all rows; per row only the N-1 separation pairs, "
-                            "the hull pairs and the vehicle its advanced control point touches; outputs identical to the "
-                            "brute-force sweep"}
+                variants["fd_structured"] = entry(
+                    t_ms, B, kernel_avg_ms=round(kms / max(kcnt, 1), 5), launches_per_step=1,
+                    alg_bytes_per_launch=B * total_bytes_, achieved_gbs=round(gbs, 2) if gbs else None,
+                    frac=round(gbs / HBM_PEAK_GBS, 5) if gbs else None, parity=s_par,
+                    what="row 0 evaluated in full and streamed into all rows; per row only the N-1 separation pairs, "
+                         "the hull pairs and the vehicle its advanced control point touches; outputs identical to the "
+                         "brute-force sweep")
             except RuntimeError as e:
                 variants["fd_structured"] = {"unsupported": str(e)}
-        for v in variants.values():
-            if "ms_per_step" in v:
-                v["evals_per_s"] = round(B / (v["ms_per_step"] * 1e-3), 1)
 
-    evals = world * B * args.steps
+    # ---- strong_scaling_proxy (1 GPU): what ONE SLSQP iteration's rows cost when they are split G ways -- the step on
+    # the first ceil(B / G) rows of the same view, G = 1, 2, 4, 8 (the rows every rank of `--mode rows` would own, up to
+    # which vehicle they perturb).  efficiency = t(B) / (G t(B / G)): the speed-up G GPUs would show over one, divided by
+    # G, if nothing but the kernels' small-batch behaviour stood in the way (no collective on this path).
+    if use_view and use_gjk and args.mode == "batch" and world == 1 and not args.no_proxy and not args.no_variants:
+        proxy = {"rows": [], "what": "the step on the first ceil(B / G) rows of the view; efficiency = t(B) / (G t(B/G))"}
+        base = {}
+        for G in (1, 2, 4, 8):
+            Bg = -(-B // G)
+            e = {"G": G, "rows": Bg}
+            ms, sp = timed(nv, lambda i: step_at(d0.data_ptr(), Bg))
+            e["brute_force_ms"] = round(ms, 4)
+            if G == 1:
+                base["bf"] = ms
+            e["brute_force_efficiency"] = round(base["bf"] / (G * ms), 4)
+            if can_structured:
+                try:
+                    ms2, sp2 = timed(nv, lambda i: structured(Bg))
+                    e["structured_ms"] = round(ms2, 4)
+                    if G == 1:
+                        base["st"] = ms2
+                    e["structured_efficiency"] = round(base["st"] / (G * ms2), 4)
+                except RuntimeError:
+                    pass
+            proxy["rows"].append(e)
+        step_at(d0.data_ptr())          # leave the buffers as a full step left them
+        torch.cuda.synchronize()
+
+    evals = (B_total if args.mode == "rows" else world * B) * args.steps
     value = evals / elapsed
     ms_per_step = 1e3 * elapsed / args.steps
 
@@ -550,6 +632,19 @@ def main():
         cpu = cpu_baseline(args, N, d, n, R, Y, statics, pa, pb, use_gjk, max_sep, vmax, wmax, tfv)
         cpu_np = cpu_baseline_numpy(N, d, n, R, Y, statics, pa, pb, use_gjk, max_sep, vmax, wmax, tfv)
 
+    # --mode rows: a checksum over EVERY rank's rows (each rank sums its own, the sums travel as objects): the same figures
+    # from one rank and from G ranks say that the row ranges tile the iteration
+    checksum = None
+    if args.mode == "rows":
+        mine = {"rows": B, "sep_min_sum": float(torch.amin(o_sep.view(B, P_t, L), dim=2).sum().item()) if B else 0.0,
+                "speed_sum": float(o_sp.sum().item()) if B else 0.0,
+                "gjk_flag_sum": int(g_flag.sum().item()) if (use_gjk and B) else 0}
+        parts = [mine]
+        if use_dist:
+            parts = [None] * dist.get_world_size()
+            dist.all_gather_object(parts, mine)
+        checksum = {k: sum(q[k] for q in parts) for k in mine}
+        checksum["rows_per_rank"] = [q["rows"] for q in parts]
     # proof of ranks: what the process group itself reports, and the device every rank ran on
     ranks_seen = dist.get_world_size() if use_dist else 1
     devices = [torch.cuda.get_device_name(local_rank) + " #%d" % local_rank]
@@ -568,7 +663,7 @@ def main():
             "metric": "constraint-evals/s (full swarm pairwise min-dist + dynamics) per SLSQP iter",
             "value": round(value, 2), "unit": "constraint-evals/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "scaling": "strong" if args.mode == "rows" else "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "%s: %d vehicles, %d-D, degree %d, DEG_ELEV %d, %s; "
                                    "FD batch B=%d rows per GPU per step (%s); families: "
                                    "temporal_sep(%d pairs)+max_speed+%sgjkNew(%d hull pairs)" % (
@@ -578,6 +673,9 @@ def main():
                                              "once per step for the others" if use_view
                                              else "written to HBM by obtg_fd_batch_dev each step"), P_t,
                                        "max_ang_rate+" if d == 2 else "", P_s),
+                       "mode": args.mode, "rows_per_step_all_ranks": B_total if args.mode == "rows" else world * B,
+                       "row_range_of_rank0": [row_begin, B] if args.mode == "rows" else None,
+                       "gather_minima": bool(d_min is not None), "checksum": checksum,
                        "launches_per_step": len(kernels), "streams": 2 if two_streams else 1, "stream": stream_note,
                        "ranks_seen": ranks_seen, "backend": (args.backend if use_dist else None), "devices": devices,
                        "gjk_status_note": status_note,
@@ -586,6 +684,7 @@ def main():
             "roofline": roofline,
             "kernels": kernels,
             "variants": variants,
+            "strong_scaling_proxy": proxy,
             "parity_check": parity,
             "cpu_baseline": cpu,
             "cpu_baseline_numpy": cpu_np,

@@ -207,6 +207,11 @@ int obtg_fd_batch_dev(obtg_ctx*, const double* dY0, int n_fixed_cols, double h, 
  * view ends.  obtg_pair_sweep_fd_dev / obtg_dynamics_fd_dev are the one-call forms (a view around a single sweep);
  * obtg_fd_forms_on_the_fly: bit 0 = the pair sweep is one launch forming its rows itself, bit 1 = the dynamics launch. */
 int obtg_fd_view_begin(obtg_ctx*, const double* dY0, int n_fixed_cols, double h, int B);
+/* A RANGE of that batch's rows: the view's local row b is batch row row_begin + b (B rows).  What one of G processes
+ * opens when an SLSQP iteration's n_x + 1 rows are sharded over G GPUs (distributed.shard_rows): no rank
+ * writes or reads rows it does not own.  The structured step (obtg_constraint_sweep_fd_structured_dev) counts its
+ * workgroup kinds from the batch's row 0 and has no such form. */
+int obtg_fd_view_begin_rows(obtg_ctx*, const double* dY0, int n_fixed_cols, double h, int row_begin, int B);
 int obtg_fd_view_end(obtg_ctx*);
 int obtg_fd_forms_on_the_fly(const obtg_ctx*);
 int obtg_pair_sweep_fd_dev(obtg_ctx*, const double* dY0, int n_fixed_cols, double h, int B, double max_sep,

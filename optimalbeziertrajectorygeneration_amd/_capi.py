@@ -62,6 +62,7 @@ _SIGNATURES = {
     "obtg_dynamics_dev": (_i, [_vp, _vp, _vp, _i, _d, _i, _d, _vp, _vp]),
     "obtg_fd_batch_dev": (_i, [_vp, _vp, _i, _d, _i, _vp]),
     "obtg_fd_view_begin": (_i, [_vp, _vp, _i, _d, _i]),
+    "obtg_fd_view_begin_rows": (_i, [_vp, _vp, _i, _d, _i, _i]),
     "obtg_fd_view_end": (_i, [_vp]),
     "obtg_fd_forms_on_the_fly": (_i, [_vp]),
     "obtg_pair_sweep_fd_dev": (_i, [_vp, _vp, _i, _d, _i, _d, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
@@ -448,10 +449,15 @@ class Context(object):
                                                                _vp(d_out2) if d_out2 else None),
                     "obtg_ctx_set_second_speed_bound")
 
-    def fd_view_begin(self, dY0, n_fixed_cols, h, B):
+    def fd_view_begin(self, dY0, n_fixed_cols, h, B, row_begin=0):
         """Open a virtual finite-difference batch over the ONE device row dY0 (include/obtg.h obtg_fd_view_begin): until
-        fd_view_end() the `_dev` sweeps take dY = None."""
-        self._check(self._lib.obtg_fd_view_begin(self._h, _vp(dY0), int(n_fixed_cols), float(h), int(B)), "obtg_fd_view_begin")
+        fd_view_end the `_dev` sweeps take dY = None.  row_begin > 0: the view is rows row_begin .. row_begin + B - 1 of
+        the batch (obtg_fd_view_begin_rows: one rank's share of a row-sharded iteration)."""
+        if row_begin:
+            self._check(self._lib.obtg_fd_view_begin_rows(self._h, _vp(dY0), int(n_fixed_cols), float(h), int(row_begin), int(B)),
+                        "obtg_fd_view_begin_rows")
+        else:
+            self._check(self._lib.obtg_fd_view_begin(self._h, _vp(dY0), int(n_fixed_cols), float(h), int(B)), "obtg_fd_view_begin")
 
     def fd_view_end(self):
         self._check(self._lib.obtg_fd_view_end(self._h), "obtg_fd_view_end")

@@ -58,15 +58,17 @@ struct NsParams {
     int tiling;                       // 1: row-window tiles (large swarms), see k_normsq_elev
     const int2* __restrict__ tiles;   // [wgs_per_row] (first row, first column) of each tile
     double sign, offset;              // out = sign * value + offset
-    int fd, fd_fixed;                 // fd != 0: Y is ONE row; evaluation row b >= 1 = Y with its (b-1)-th free control point
-    double fd_h;                      //          advanced by fd_h (obtg_fd_batch_dev's rows), formed while staging
+    int fd, fd_fixed;                 // fd != 0: Y is ONE row; batch row g >= 1 = Y with its (g-1)-th free control point advanced by
+    double fd_h;                      //          fd_h (obtg_fd_batch_dev's rows), formed while staging; local row b is batch row
+                                      //          b + fd - 1 (fd = 1 + first row of the range: obtg_fd_view_begin_rows)
 };
 
-// element of an evaluation row [n_rows][nc] that row b of a virtual finite-difference batch advances (-1: none)
+// element of an evaluation row [n_rows][nc] that LOCAL row b of a virtual finite-difference batch advances (-1: none);
+// fd - 1 is the batch row of local row 0
 __device__ __forceinline__ int fd_element(int fd, int fixed, int nc, int b)
 {
-    if (!fd || b <= 0) return -1;
-    const int free_cols = nc - 2 * fixed, kq = b - 1, pr = kq / free_cols;
+    if (!fd || b + fd - 1 <= 0) return -1;
+    const int free_cols = nc - 2 * fixed, kq = b + fd - 2, pr = kq / free_cols;
     return pr * nc + fixed + (kq - pr * free_cols);
 }
 
@@ -991,8 +993,8 @@ __device__ __forceinline__ void load_item_xy(const AngParams& p, int item, int b
     const int veh = item - b * p.n_veh;
     const double* src = p.Y + (size_t)veh * 2 * NC;
     int pl = -1;                                           // perturbed element inside this vehicle's 2 NC values
-    if (b > 0) {
-        const int free_cols = NC - 2 * p.fd_fixed, kq = b - 1, pr = kq / free_cols, pc = p.fd_fixed + (kq - pr * free_cols);
+    if (b + p.fd - 1 > 0) {
+        const int free_cols = NC - 2 * p.fd_fixed, kq = b + p.fd - 2, pr = kq / free_cols, pc = p.fd_fixed + (kq - pr * free_cols);
         pl = pr * NC + pc - veh * 2 * NC;
     }
 #pragma unroll

@@ -813,15 +813,15 @@ __global__ __launch_bounds__(kWave) void k_bern_split(const BernParams p, double
 //  finite-difference batch, objectives
 // =====================================================================================
 __global__ void k_fd_batch(const double* __restrict__ Y0, double* __restrict__ Y, int rows, int nc,
-                           int fixed, double h, int B)
+                           int fixed, double h, int B, int row0)
 {
     const size_t ysz = (size_t)rows * nc;
     const size_t total = ysz * B;
     const int free_cols = nc - 2 * fixed;
     for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total;
          e += (size_t)gridDim.x * blockDim.x) {
-        const int b = (int)(e / ysz);
-        const int r = (int)(e - (size_t)b * ysz);
+        const int bl = (int)(e / ysz), b = bl + row0;          // local row, row of the batch
+        const int r = (int)(e - (size_t)bl * ysz);
         double v = Y0[r];
         if (b > 0) {
             const int k = b - 1, pr = k / free_cols, pc = fixed + (k - pr * free_cols);
@@ -1030,7 +1030,7 @@ int launch_temporal_sep(obtg_ctx* c, const double* dY, int B, double max_sep, in
     if (rc != OBTG_OK && rc != OBTG_ERR_UNSUPPORTED) return rc;
     if (rc == OBTG_OK) {
         p.sign = 1.0; p.offset = 0.0 - max_sep * max_sep;
-        if (c->fd.Y0) { p.Y = c->fd.Y0; p.fd = 1; p.fd_fixed = c->fd.fixed; p.fd_h = c->fd.h; }
+        if (c->fd.Y0) { p.Y = c->fd.Y0; p.fd = 1 + c->fd.row0; p.fd_fixed = c->fd.fixed; p.fd_h = c->fd.h; }
         rc = min_only ? dispatch_ns<0, true>(c, p, B, OBTG_K_TEMPORAL_SEP)
                       : dispatch_ns<0, false>(c, p, B, OBTG_K_TEMPORAL_SEP);
         if (rc != OBTG_ERR_UNSUPPORTED) return rc;
@@ -1071,7 +1071,7 @@ int launch_speed(obtg_ctx* c, const double* dY, const double* d_tf, int B, doubl
         p.stage_slots = std::min(c->n_veh, kWave);
         p.stage_all = 0; p.tiling = 0; p.tiles = nullptr;
         p.sign = is_max ? -1.0 : 1.0; p.offset = is_max ? b2 : -b2;
-        if (c->fd.Y0) { p.Y = c->fd.Y0; p.fd = 1; p.fd_fixed = c->fd.fixed; p.fd_h = c->fd.h; }
+        if (c->fd.Y0) { p.Y = c->fd.Y0; p.fd = 1 + c->fd.row0; p.fd_fixed = c->fd.fixed; p.fd_h = c->fd.h; }
         rc = dispatch_ns<1, false>(c, p, B, OBTG_K_SPEED);
         if (rc != OBTG_ERR_UNSUPPORTED) return rc;
     }
@@ -1259,8 +1259,8 @@ int launch_sep_dynamics_elev(obtg_ctx* c, const double* dY, int B, double max_se
     p.W2n = c->d_ang_w2n.as<double>(); p.W22n = c->d_ang_w22n.as<double>(); p.Wn = c->d_ang_wn.as<double>();
     second_speed_rows(c, p);
     if (c->fd.Y0) {
-        sp.ts.Y = c->fd.Y0; sp.ts.fd = 1; sp.ts.fd_fixed = c->fd.fixed; sp.ts.fd_h = c->fd.h;
-        p.Y = c->fd.Y0; p.fd = 1; p.fd_fixed = c->fd.fixed; p.fd_h = c->fd.h;
+        sp.ts.Y = c->fd.Y0; sp.ts.fd = 1 + c->fd.row0; sp.ts.fd_fixed = c->fd.fixed; sp.ts.fd_h = c->fd.h;
+        p.Y = c->fd.Y0; p.fd = 1 + c->fd.row0; p.fd_fixed = c->fd.fixed; p.fd_h = c->fd.h;
     }
     sp.dyn.cv4 = c->d_ang_T4.as<double>(); sp.dyn.cv2 = c->d_ang_cv2.as<double>(); sp.dyn.R = c->R;
     switch (nc) {
@@ -1290,7 +1290,7 @@ int launch_dynamics(obtg_ctx* c, const double* dY, const double* d_tf, int B, do
         p.W22n = c->d_ang_w22n.as<double>();
         p.Wn = c->d_ang_wn.as<double>();
         second_speed_rows(c, p);
-        if (c->fd.Y0) { p.Y = c->fd.Y0; p.fd = 1; p.fd_fixed = c->fd.fixed; p.fd_h = c->fd.h; }
+        if (c->fd.Y0) { p.Y = c->fd.Y0; p.fd = 1 + c->fd.row0; p.fd_fixed = c->fd.fixed; p.fd_h = c->fd.h; }
         const int kid = d_out_ang ? OBTG_K_ANG_RATE : OBTG_K_SPEED;
         switch (c->deg + 1) {
             case 4: return launch_dyn_t<4>(c, p, kid);
@@ -1312,7 +1312,7 @@ int launch_dynamics(obtg_ctx* c, const double* dY, const double* d_tf, int B, do
         p.W22n = c->d_ang_w22n.as<double>();
         p.Wn = c->d_ang_wn.as<double>();
         second_speed_rows(c, p);
-        if (c->fd.Y0) { p.Y = c->fd.Y0; p.fd = 1; p.fd_fixed = c->fd.fixed; p.fd_h = c->fd.h; }
+        if (c->fd.Y0) { p.Y = c->fd.Y0; p.fd = 1 + c->fd.row0; p.fd_fixed = c->fd.fixed; p.fd_h = c->fd.h; }
         q.cv4 = c->d_ang_T4.as<double>(); q.cv2 = c->d_ang_cv2.as<double>(); q.R = c->R;
         switch (c->deg + 1) {
             case 4: return launch_dyn_elev_t<4>(c, q, OBTG_K_ANG_RATE);
@@ -1360,15 +1360,15 @@ int launch_ang_rate(obtg_ctx* c, const double* dY, const double* d_tf, int B, do
     return OBTG_OK;
 }
 
-int launch_fd_batch(obtg_ctx* c, const double* dY0, int n_fixed_cols, double h, int B, double* dY)
+int launch_fd_batch(obtg_ctx* c, const double* dY0, int n_fixed_cols, double h, int B, double* dY, int row0)
 {
     const int rows = c->n_veh * c->dim, nc = c->deg + 1;
-    if (nc - 2 * n_fixed_cols <= 0) return OBTG_ERR_ARG;
-    if (B > rows * (nc - 2 * n_fixed_cols) + 1) return OBTG_ERR_ARG;
+    if (nc - 2 * n_fixed_cols <= 0 || row0 < 0) return OBTG_ERR_ARG;
+    if (row0 + B > rows * (nc - 2 * n_fixed_cols) + 1) return OBTG_ERR_ARG;
     const size_t total = (size_t)rows * nc * B;
     unsigned blocks = (unsigned)std::min<size_t>((total + 255) / 256, 256 * 8);
     ScopedKernelTimer t(c, OBTG_K_FD_BATCH);
-    hipLaunchKernelGGL(k_fd_batch, dim3(blocks), dim3(256), 0, c->stream, dY0, dY, rows, nc, n_fixed_cols, h, B);
+    hipLaunchKernelGGL(k_fd_batch, dim3(blocks), dim3(256), 0, c->stream, dY0, dY, rows, nc, n_fixed_cols, h, B, row0);
     OBTG_HIP(c, hipGetLastError());
     return OBTG_OK;
 }

@@ -214,7 +214,7 @@ const char* obtg_abi_symbols(void)
         "obtg_temporal_sep\0obtg_speed\0obtg_ang_rate\0obtg_temporal_sep_min\0obtg_temporal_sep_min_range\0"
         "obtg_temporal_sep_fd\0obtg_temporal_sep_fd_dev\0obtg_one_vs_many_min\0obtg_one_vs_many_min_dev\0"
         "obtg_temporal_sep_dev\0obtg_temporal_sep_min_dev\0obtg_speed_dev\0obtg_ang_rate_dev\0obtg_dynamics_dev\0"
-        "obtg_fd_batch_dev\0obtg_fd_view_begin\0obtg_fd_view_end\0obtg_fd_forms_on_the_fly\0obtg_pair_sweep_fd_dev\0obtg_dynamics_fd_dev\0obtg_gjk_pairs\0obtg_ctx_set_polygons\0obtg_ctx_set_hull_pairs\0"
+        "obtg_fd_batch_dev\0obtg_fd_view_begin\0obtg_fd_view_begin_rows\0obtg_fd_view_end\0obtg_fd_forms_on_the_fly\0obtg_pair_sweep_fd_dev\0obtg_dynamics_fd_dev\0obtg_gjk_pairs\0obtg_ctx_set_polygons\0obtg_ctx_set_hull_pairs\0"
         "obtg_ctx_set_fd_dedup\0obtg_ctx_set_gjk_history\0obtg_pair_sweep_dev\0obtg_constraint_sweep_dev\0obtg_constraint_sweep_fd_structured_dev\0obtg_gjk_swarm_dev\0obtg_gjk_swarm\0obtg_min_dist\0obtg_min_dist_robust\0obtg_min_dist2poly\0obtg_min_dist2poly_robust\0obtg_gjk_true_pairs\0"
         "obtg_bern_elev\0obtg_bern_diff\0obtg_bern_mul\0obtg_bern_normsq\0obtg_bern_split\0"
         "obtg_euclidean_obj\0obtg_accel_obj\0obtg_jerk_obj\0"
@@ -356,7 +356,7 @@ int obtg_num_pairs(const obtg_ctx* c) { return c ? c->n_pairs : 0; }
 // dY == NULL in a `_dev` sweep means "the batch of the open view" (obtg_fd_view_begin): the launcher gets the view's
 // single row with c->fd set; kernels that form the rows while staging them use it, the others answer kNeedBatch and
 // the batch is written to a context buffer -- once per view -- and handed over instead.
-static int fd_materialise(obtg_ctx* c, const double* dY0, int n_fixed_cols, double h, int B);
+static int fd_materialise(obtg_ctx* c, const double* dY0, int n_fixed_cols, double h, int B, int row0);
 
 extern "C++" {
 // can_fd: can EVERY kernel of this call form the view's rows itself?  Decided before anything is launched, so that a
@@ -383,39 +383,44 @@ static int with_batch(obtg_ctx* c, const double* dY, int B, bool can_fd, Launch 
     if (!c->view.Y0 || B != c->view.B) return OBTG_ERR_ARG;
     int rc = kNeedBatch;
     if (!c->view.materialised && can_fd) {
-        c->fd.Y0 = c->view.Y0; c->fd.h = c->view.h; c->fd.fixed = c->view.fixed;
+        c->fd.Y0 = c->view.Y0; c->fd.h = c->view.h; c->fd.fixed = c->view.fixed; c->fd.row0 = c->view.row0;
         rc = launch(c->view.Y0);
-        c->fd.Y0 = nullptr;
+        c->fd.Y0 = nullptr; c->fd.row0 = 0;
     }
     if (rc != kNeedBatch) return rc;
     if (!c->view.materialised) {
-        if ((rc = fd_materialise(c, c->view.Y0, c->view.fixed, c->view.h, c->view.B))) return rc;
+        if ((rc = fd_materialise(c, c->view.Y0, c->view.fixed, c->view.h, c->view.B, c->view.row0))) return rc;
         c->view.materialised = true;
     }
     return launch(c->ws_fd.as<double>());
 }
 }  // extern "C++"
 
-static int fd_args_ok(const obtg_ctx* c, int n_fixed_cols, int B)
+static int fd_args_ok(const obtg_ctx* c, int n_fixed_cols, int row_begin, int B)
 {
     const int rows = c->n_veh * c->dim, nc = c->deg + 1;
-    if (n_fixed_cols < 0 || nc - 2 * n_fixed_cols <= 0) return OBTG_ERR_ARG;
-    if (B < 1 || B > rows * (nc - 2 * n_fixed_cols) + 1) return OBTG_ERR_ARG;
+    if (n_fixed_cols < 0 || nc - 2 * n_fixed_cols <= 0 || row_begin < 0) return OBTG_ERR_ARG;
+    if (B < 1 || row_begin + B > rows * (nc - 2 * n_fixed_cols) + 1) return OBTG_ERR_ARG;
+    return OBTG_OK;
+}
+
+int obtg_fd_view_begin_rows(obtg_ctx* c, const double* dY0, int n_fixed_cols, double h, int row_begin, int B)
+{
+    if (!check_ctx(c) || !dY0) return OBTG_ERR_ARG;
+    if (int rc = fd_args_ok(c, n_fixed_cols, row_begin, B)) return rc;
+    c->view.Y0 = dY0; c->view.h = h; c->view.fixed = n_fixed_cols; c->view.B = B; c->view.row0 = row_begin; c->view.materialised = false;
     return OBTG_OK;
 }
 
 int obtg_fd_view_begin(obtg_ctx* c, const double* dY0, int n_fixed_cols, double h, int B)
 {
-    if (!check_ctx(c) || !dY0) return OBTG_ERR_ARG;
-    if (int rc = fd_args_ok(c, n_fixed_cols, B)) return rc;
-    c->view.Y0 = dY0; c->view.h = h; c->view.fixed = n_fixed_cols; c->view.B = B; c->view.materialised = false;
-    return OBTG_OK;
+    return obtg_fd_view_begin_rows(c, dY0, n_fixed_cols, h, 0, B);
 }
 
 int obtg_fd_view_end(obtg_ctx* c)
 {
     if (!check_ctx(c)) return OBTG_ERR_ARG;
-    c->view.Y0 = nullptr; c->view.B = 0; c->view.materialised = false;
+    c->view.Y0 = nullptr; c->view.B = 0; c->view.row0 = 0; c->view.materialised = false;
     return OBTG_OK;
 }
 
@@ -464,11 +469,11 @@ int obtg_dynamics_dev(obtg_ctx* c, const double* dY, const double* d_tf, int B, 
         return launch_dynamics(c, src, d_tf, B, speed_bound, speed_is_max, max_rate, d_out_speed, d_out_ang); });
 }
 
-static int fd_materialise(obtg_ctx* c, const double* dY0, int n_fixed_cols, double h, int B)
+static int fd_materialise(obtg_ctx* c, const double* dY0, int n_fixed_cols, double h, int B, int row0)
 {
     int rc = c->ws_fd.reserve(sizeof(double) * (size_t)B * c->n_veh * c->dim * (c->deg + 1));
     if (rc) return rc;
-    return launch_fd_batch(c, dY0, n_fixed_cols, h, B, c->ws_fd.as<double>());
+    return launch_fd_batch(c, dY0, n_fixed_cols, h, B, c->ws_fd.as<double>(), row0);
 }
 
 int obtg_fd_forms_on_the_fly(const obtg_ctx* c)

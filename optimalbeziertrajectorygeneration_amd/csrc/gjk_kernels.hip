@@ -2585,7 +2585,18 @@ static SweepShape sweep_shape(const obtg_ctx* c, int B, int nc, int waves_per_si
     if (per_cu < 1) per_cu = 1;
     const int chunk_max = fixed + 14 * 256 <= budget ? (int)std::min<size_t>((budget - fixed) / 14, 65535) : 256;
     int W = std::max(1, (np + chunk_target - 1) / chunk_target);
-    while ((long)B * W < 2048 && (np + W - 1) / W > 256) W <<= 1;                 // small batches: fill the chip
+    // Small batches (a rank's share of a row-sharded iteration, bench.py --mode rows): as many workgroups per row as ONE
+    // round of resident workgroups has room for beside the row's dynamics group -- a second round costs a whole
+    // workgroup's latency again (B = 145 at C3: 6 per row 0.040 ms, 8 per row 0.052, the old rule's 16 per row 0.068;
+    // B = 289: 3 per row 0.061, 8 per row 0.080) -- and three per row while the launch is two or three rounds
+    // (B = 577: 0.104 against 0.109 / 0.116 for 4 / 2); tools/r04_small_batch_scan.sh, profiles/r04_experiments/.
+    {
+        const long slots = (long)per_cu * std::max(1, c->n_cus);
+        if ((long)B * (W + 1) < slots) {
+            const int fill = (int)((slots - B + B / 2) / std::max(1, B));         // round((slots - B) / B)
+            W = std::max(W, std::min(fill, std::max(1, np / 128)));
+        } else if ((long)B * (W + 1) < 3 * slots) W = std::max(W, std::min(3, std::max(1, np / 128)));
+    }
     while ((np + W - 1) / W > chunk_max && (np + W - 1) / W > 256) ++W;           // the row's objects leave less LDS
     int Q = 1;
     if (const char* e = getenv("OBTG_SWEEP_WGS")) W = std::max(1, atoi(e));
@@ -2623,7 +2634,7 @@ int launch_gjk_swarm(obtg_ctx* c, const double* dY, int B, int max_iter, int md_
     p.flag = d_flag; p.p1 = d_p1; p.p2 = d_p2; p.dist = d_dist; p.nsup = d_nsup; p.status = d_status;
     if (c->fd.Y0) {
         if (c->fd_dedup) return kNeedBatch;      // the de-duplication mask compares rows in memory
-        p.Y = c->fd.Y0; p.fd = 1; p.fd_fixed = c->fd.fixed; p.fd_h = c->fd.h;
+        p.Y = c->fd.Y0; p.fd = 1 + c->fd.row0; p.fd_fixed = c->fd.fixed; p.fd_h = c->fd.h;
     }
     size_t lds = sizeof(double) * ((size_t)c->n_veh * p.vp + 3 * (size_t)c->n_poly_pts);
     const bool planar = c->dim == 2 && c->polys_planar;
@@ -2920,7 +2931,7 @@ int launch_pair_sweep(obtg_ctx* c, const double* dY, int B, double max_sep, doub
             p.obs = c->d_obs.as<double>(); p.n_obs = c->n_obs;
             p.ts.n_veh = c->n_veh; p.ts.obs_shift = c->n_poly;
         }
-        if (c->fd.Y0) { p.Y = c->fd.Y0; p.fd = 1; p.fd_fixed = c->fd.fixed; p.fd_h = c->fd.h; }
+        if (c->fd.Y0) { p.Y = c->fd.Y0; p.fd = 1 + c->fd.row0; p.fd_fixed = c->fd.fixed; p.fd_h = c->fd.h; }
     }
     if (!fused && kern && c->dim == 2 && c->polys_planar && c->max_poly_K <= nc && c->n_hull_pairs > 0 && !c->fd_dedup &&
         c->R == 0 && c->n_obs == 0 && c->n_pairs > 0 && lds > 48 * 1024) {
@@ -3073,6 +3084,7 @@ int launch_step_fd_structured(obtg_ctx* c, int B, double max_sep, double* d_out_
 {
     if (B <= 0) return OBTG_OK;
     if (!c->fd.Y0) return OBTG_ERR_ARG;
+    if (c->fd.row0 != 0) return OBTG_ERR_UNSUPPORTED;      // (a row range that does not start at the batch's row 0: its kinds count from row 0)
     const int nc = c->deg + 1;
     void (*kern)(const StructuredParams) = nullptr;
     void (*kern_mid)(const StructuredParams) = nullptr;      // two workgroups per CU: rows beyond 40 KB of LDS (C4: 79 KB)
@@ -3101,7 +3113,7 @@ int launch_step_fd_structured(obtg_ctx* c, int B, double max_sep, double* d_out_
         return OBTG_ERR_UNSUPPORTED;
     StructuredParams sp{};
     GjkSwarmParams& p = sp.g;
-    p.Y = c->fd.Y0; p.fd = 1; p.fd_fixed = c->fd.fixed; p.fd_h = c->fd.h;
+    p.Y = c->fd.Y0; p.fd = 1 + c->fd.row0; p.fd_fixed = c->fd.fixed; p.fd_h = c->fd.h;
     p.poly = c->d_poly_pts.as<double>(); p.poly_off = c->d_poly_off.as<int>();
     p.pa = c->d_hp_a.as<int>(); p.pb = c->d_hp_b.as<int>();
     p.n_veh = c->n_veh; p.dim = c->dim; p.nc = nc; p.n_poly = c->n_poly;

@@ -109,8 +109,8 @@ struct obtg_ctx {
     // row b >= 1 = Y0 with its (b-1)-th free control point advanced by h (exactly obtg_fd_batch_dev's rows).
     // `fd` is set for the duration of ONE launcher call; launchers whose kernel cannot form the rows return
     // obtg::kNeedBatch before launching anything and the caller materialises the batch (once per view) instead.
-    struct FdView { const double* Y0 = nullptr; double h = 0.0; int fixed = 0; } fd;
-    struct { const double* Y0 = nullptr; double h = 0.0; int fixed = 0; int B = 0; bool materialised = false; } view;   // obtg_fd_view_begin .. _end
+    struct FdView { const double* Y0 = nullptr; double h = 0.0; int fixed = 0; int row0 = 0; } fd;       // row0: batch row of local row 0
+    struct { const double* Y0 = nullptr; double h = 0.0; int fixed = 0; int B = 0; int row0 = 0; bool materialised = false; } view;   // obtg_fd_view_begin[_rows] .. _end
     obtg::DevBuf ws_fd;                   // the view's batch, written only when some kernel needs it
 
     // scratch for host-buffer entry points
@@ -193,7 +193,7 @@ int launch_ang_rate(obtg_ctx* c, const double* dY, const double* d_tf, int B, do
 int launch_sep_dynamics_elev(obtg_ctx* c, const double* dY, int B, double max_sep, double* d_out_sep, const SweepFold& f);
 int launch_dynamics(obtg_ctx* c, const double* dY, const double* d_tf, int B, double bound, int is_max,
                     double max_rate, double* d_out_speed, double* d_out_ang);
-int launch_fd_batch(obtg_ctx* c, const double* dY0, int n_fixed_cols, double h, int B, double* dY);
+int launch_fd_batch(obtg_ctx* c, const double* dY0, int n_fixed_cols, double h, int B, double* dY, int row0 = 0);   // rows row0 .. row0 + B - 1 of the batch
 bool dynamics_fd_on_the_fly(const obtg_ctx* c, bool want_ang);
 bool bernstein_fd_on_the_fly(const obtg_ctx* c);      // the separate temporal-separation / speed kernels form a view's rows themselves
 bool pair_sweep_is_one_launch(const obtg_ctx* c);

@@ -761,8 +761,33 @@ def gen_spatial_fd():
     save("spatial_fd.npz", **d)
 
 
+def gen_c1_text():
+    """BASELINE.json configs[0] as its TEXT has it: 1 vehicle, degree 10, 4 point obstacles ->
+    through the class path the obstacles join the pair loop as constant curves (optimization.py:86-98): P = C(5, 2) = 10
+    pairs, 210 separation values, 21 speed values, 41 angular-rate values per evaluation."""
+    d = {}
+    obs = [[3.0, 2.0], [6.0, 7.0], [2.0, 8.0], [8.0, 3.0]]
+    bo = opt.BezOptimization(numVeh=1, dimension=2, degree=10, minimizeGoal='TimeOpt', maxSep=1, maxSpeed=5, maxAngRate=1,
+                             initPoints=[(0, 0)], finalPoints=[(10, 10)], initSpeeds=[1], finalSpeeds=[1],
+                             initAngs=[0], finalAngs=[np.pi / 2], pointObstacles=obs)
+    rng = np.random.default_rng(11)
+    xg = bo.generateGuess(std=0)
+    xr = xg + rng.normal(0, 0.4, size=xg.shape)
+    xr[-1] = 4.2
+    d["obs"] = np.array(obs)
+    for tag, x in (("g", xg), ("r", xr)):
+        d["x_" + tag] = x
+        d["y_" + tag] = bo.reshapeVector(x)
+        opt.DEG_ELEV = 0
+        d["tsep_" + tag] = bo.temporalSeparationConstraints(x)
+        d["maxspeed_" + tag] = bo.maxSpeedConstraints(x)
+        d["angrate_" + tag] = bo.maxAngularRateConstraints(x)
+    assert d["tsep_r"].shape == (210,) and d["maxspeed_r"].shape == (21,) and d["angrate_r"].shape == (41,)
+    save("c1_text.npz", **d)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["tables", "ops", "problem", "constraints", "gjk", "mindist", "c5", "spatial", "nearstop", "sequential", "spatial_fd", "mindist_script"]
+    which = sys.argv[1:] or ["tables", "ops", "problem", "constraints", "gjk", "mindist", "c5", "spatial", "nearstop", "sequential", "spatial_fd", "mindist_script", "c1_text"]
     for w in which:
         if w == "none":          # import-only (exploration)
             continue

@@ -97,6 +97,25 @@ def test_bench_pairs_mode_two_ranks_equals_one_rank():
     assert c1["sep_min_sum"] == c2["sep_min_sum"] and c1["gjk_dist_nansum"] == c2["gjk_dist_nansum"]
 
 
+def test_bench_rows_mode_two_ranks_tile_the_iteration():
+    """--mode rows: ONE SLSQP iteration's n_x + 1 rows split over the ranks, each rank a row-range view
+    (obtg_fd_view_begin_rows), nothing exchanged on the data path -> `scaling` strong, value = all rows / max time; the
+    checksums over every rank's rows equal the one-rank run's."""
+    args = ["--mode", "rows", "--workload", "C3", "--batch", "301", "--steps", "3", "--warmup", "1", "--no-cpu", "--no-variants"]
+    one = _bench(["--gpus", "1"] + args)
+    two = _bench(["--gpus", "2", "--backend", "gloo", "--one-device"] + args)
+    three = _bench(["--gpus", "3", "--backend", "gloo", "--one-device", "--gather-minima"] + args)
+    for line, g in ((one, 1), (two, 2), (three, 3)):
+        c = line["config"]
+        assert line["n_gpus"] == g and line["scaling"] == "strong" and c["mode"] == "rows" and c["ranks_seen"] == g
+        assert c["rows_per_step_all_ranks"] == 301 and sum(c["checksum"]["rows_per_rank"]) == 301
+        assert abs(line["value"] - 301 / (line["ms_per_step"] * 1e-3)) < 2e-3 * line["value"]
+        assert c["checksum"]["gjk_flag_sum"] == one["config"]["checksum"]["gjk_flag_sum"]
+        for k in ("sep_min_sum", "speed_sum"):
+            assert abs(c["checksum"][k] - one["config"]["checksum"][k]) <= 1e-11 * abs(one["config"]["checksum"][k]), k
+    assert two["config"]["checksum"]["rows_per_rank"] == [151, 150] and three["config"]["gather_minima"] is True
+
+
 def test_rccl_path_with_one_rank():
     """The backend the multi-GPU runs use (`nccl` == RCCL), exercised on the one-GPU box: process-group init with a device
     id, barrier, the MAX all-reduce of the timing and -- in pairs mode -- the packed all-gather on device tensors, with a
@@ -136,3 +155,9 @@ def test_default_bench_line_keeps_the_contract():
     assert d["config"]["ranks_seen"] == 1 and len(d["config"]["devices"]) == 1
     v = d["variants"]
     assert set(v) >= {"history_off", "moving_x", "moving_x_history_off"} and all(x["ms_per_step"] > 0 for x in v.values())
+    assert all(0 <= x["spread"] < 0.5 for x in v.values())        # median of three runs, (max - min) / median beside it
+    sp = v["fd_structured"]["parity"]                              # the structured step's own buffers against the oracle
+    assert sp["ok"] is True and sp["flags_equal"] is True and sp["max_rel"] < 1e-9
+    pr = d["strong_scaling_proxy"]["rows"]
+    assert [e["G"] for e in pr] == [1, 2, 4, 8] and pr[0]["rows"] == 1153 and pr[3]["rows"] == 145
+    assert all(0.05 < e["brute_force_efficiency"] <= 1.05 and e["structured_ms"] > 0 for e in pr)

@@ -1624,3 +1624,78 @@ def test_set_stream_orders_with_torchs_default_stream(capi, synth):
         assert torch.equal(out, ref)
     ctx.use_own_stream()
     ctx.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", ["C3_one_launch", "elevated", "space3d", "tiled_large_rows", "generic_degree"])
+def test_fd_view_row_ranges_equal_the_full_batch(capi, synth, shape):
+    """obtg_fd_view_begin_rows (one SLSQP iteration's rows sharded over the GPUs): a view over rows
+    [r0, r0 + cnt) of the finite-difference batch gives, local row for local row, what the full view gives for those rows --
+    every family, bit for bit, on the one-launch shapes, the elevated ones, 3-D rows, the tiled sweep and a shape whose
+    kernels need the rows in memory (the library then writes only the range)."""
+    import torch
+    N, d, n, R, M = {"C3_one_launch": (64, 2, 10, 0, 8), "elevated": (12, 2, 10, 7, 2), "space3d": (9, 3, 5, 0, 2),
+                     "tiled_large_rows": (256, 2, 15, 0, 0), "generic_degree": (6, 2, 12, 2, 0)}[shape]
+    Y = synth.swarm_control_points(N, d, n, seed=14)
+    n_x = N * d * (n - 1)
+    B = min(n_x + 1, 230 if shape != "tiled_large_rows" else 9)
+    ctx = capi.Context(N, d, n, R)
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    polys = synth.polygon_obstacles(M, seed=14)
+    if d == 3:
+        polys = [np.concatenate([q[:, :2], 3.0 * np.arange(len(q))[:, None]], axis=1) for q in polys]
+    pa, pb = synth.swarm_pairs(N, M)
+    ctx.set_polygons(*(synth.pack_polys(polys) if M else (None, [0])))
+    ctx.set_hull_pairs(pa, pb)
+    d0 = torch.from_numpy(Y).cuda()
+    P, L, Ps = ctx.num_pairs, 2 * n + R + 1, len(pa)
+    f64, i32 = torch.float64, torch.int32
+    want_ang = d == 2
+
+    def run(r0, cnt):
+        o = dict(sep=torch.empty((cnt, P * L), dtype=f64, device="cuda"), sp=torch.empty((cnt, ctx.len_speed), dtype=f64, device="cuda"),
+                 an=torch.empty((cnt, ctx.len_ang_rate), dtype=f64, device="cuda") if want_ang else None,
+                 flag=torch.empty((cnt, Ps), dtype=i32, device="cuda"), p1=torch.empty((cnt, Ps, 3), dtype=f64, device="cuda"),
+                 p2=torch.empty((cnt, Ps, 3), dtype=f64, device="cuda"), dist=torch.empty((cnt, Ps), dtype=f64, device="cuda"),
+                 st=torch.empty((cnt, Ps), dtype=i32, device="cuda"))
+        dtf = torch.full((cnt,), 7.5, dtype=f64, device="cuda")
+        ctx.fd_view_begin(d0.data_ptr(), 1, 1e-3, cnt, row_begin=r0)
+        ctx.constraint_sweep_dev(None, dtf.data_ptr(), cnt, 0.9, o["sep"].data_ptr(), 4.0, True, 1.5, o["sp"].data_ptr(),
+                                 o["an"].data_ptr() if want_ang else None, o["flag"].data_ptr(), o["p1"].data_ptr(), o["p2"].data_ptr(),
+                                 o["dist"].data_ptr(), None, o["st"].data_ptr(), 128, 300)
+        ctx.fd_view_end()
+        torch.cuda.synchronize()
+        return o
+    full = run(0, B)
+    for r0, cnt in ((0, 3), (1, 1), (B // 3, B - B // 3), (B - 2, 2), (5, min(64, B - 5))):
+        part = run(r0, cnt)
+        for k, v in part.items():
+            if v is not None:
+                assert torch.equal(v.view(torch.uint8), full[k][r0:r0 + cnt].contiguous().view(torch.uint8)), (shape, r0, cnt, k)
+    with pytest.raises(capi.ObtgError):
+        ctx.fd_view_begin(d0.data_ptr(), 1, 1e-3, 2, row_begin=n_x)            # rows n_x, n_x + 1: one past the batch
+    ctx.use_own_stream()
+    ctx.close()
+@pytest.mark.gpu
+def test_c1_as_baseline_text_has_it(capi, golden_dir):
+    """BASELINE.json configs[0] in its text form: 1 vehicle + 4 point obstacles through the class path (P = 10: 210 / 21 /
+    41 values per evaluation), reference fixture c1_text.npz; and the same through the drop-in BezOptimization closures."""
+    from optimalbeziertrajectorygeneration_amd import optimization as opt
+    g = _load(golden_dir, "c1_text.npz")
+    ctx = capi.Context(1, 2, 10, 0, point_obs=g["obs"])
+    assert ctx.num_pairs == 10
+    bo = opt.BezOptimization(numVeh=1, dimension=2, degree=10, minimizeGoal='TimeOpt', maxSep=1, maxSpeed=5, maxAngRate=1,
+                             initPoints=[(0, 0)], finalPoints=[(10, 10)], initSpeeds=[1], finalSpeeds=[1],
+                             initAngs=[0], finalAngs=[np.pi / 2], pointObstacles=g["obs"].tolist())
+    for tag in ("g", "r"):
+        x, y = g["x_" + tag], g["y_" + tag]
+        assert_close(ctx.temporal_sep(y, 1.0)[0], g["tsep_" + tag], RTOL)
+        assert_close(ctx.speed(y, x[-1], 5.0, True)[0], g["maxspeed_" + tag], RTOL)
+        assert_close(ctx.ang_rate(y, x[-1], 1.0)[0], g["angrate_" + tag], RTOL)
+        assert np.array_equal(bo.reshapeVector(x), y)
+        assert_close(bo.temporalSeparationConstraints(x), g["tsep_" + tag], RTOL)
+        assert_close(bo.maxSpeedConstraints(x), g["maxspeed_" + tag], RTOL)
+        assert_close(bo.maxAngularRateConstraints(x), g["angrate_" + tag], RTOL)
+    ctx.close()
+
+

@@ -105,6 +105,19 @@ def test_problem_layer_constraints(oracle, golden_dir):
     assert abs(oracle.accel_obj(y, 3, 2, 0, 7.0) / float(p["fx_obj_accel"]) - 1) < 1e-12
 
 
+
+def test_c1_as_baseline_text_has_it(oracle, golden_dir):
+    """BASELINE.json configs[0] as its text reads -- 1 vehicle, degree 10, 4 point obstacles (P = 10,
+    210 / 21 / 41 values): the class path of optimization.py:86-98, fixture written by the reference."""
+    g = _load(golden_dir, "c1_text.npz")
+    assert g["tsep_r"].shape == (210,) and g["maxspeed_r"].shape == (21,) and g["angrate_r"].shape == (41,)
+    for tag in ("g", "r"):
+        x, y = g["x_" + tag], g["y_" + tag]
+        yo = np.vstack([y] + [np.full((1, 11), v) for o in g["obs"] for v in o])
+        assert_close(oracle.temporal_sep(yo, 5, 2, 0, 1.0), g["tsep_" + tag], 1e-12)
+        assert_close(oracle.speed(y, 1, 2, 0, x[-1], 5.0, 1), g["maxspeed_" + tag], 1e-12)
+        assert_close(oracle.ang_rate(y, 1, 0, x[-1], 1.0), g["angrate_" + tag], 1e-9)
+
 @pytest.mark.parametrize("grp", ["lit", "c3", "dense", "s3d"])
 def test_gjk_bit_exact(oracle, golden_dir, grp):
     """flag, support-index sequence, closest points and distance: BIT-EXACT on every
