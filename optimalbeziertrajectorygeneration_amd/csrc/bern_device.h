@@ -381,6 +381,7 @@ struct TsepXYParams {
     int R;
     int n_veh, obs_shift;             // pairs may name point obstacles (object ids >= n_veh, optimization.py:86-98): those are
                                       // staged obs_shift slots further on (behind the polygons of the hull sweep); 0, 0: none
+    int n_tobj;                       // objects of the separation pair table (vehicles + point obstacles); 0: n_veh of the caller
 };
 __device__ __forceinline__ int tsep_slot(const TsepXYParams& t, int obj) { return obj < t.n_veh ? obj : obj + t.obs_shift; }
 
@@ -465,12 +466,13 @@ __device__ __forceinline__ void tsep_rows_of_vehicle(const TsepXYParams& t, cons
 {
     using S = NsShape<NC, 2>;
     constexpr int L = S::L;
-    for (int u0 = threadIdx.x; u0 < n_veh - 1; u0 += blockDim.x) {
+    const int n_to = t.n_tobj > 0 ? t.n_tobj : n_veh;                   // partners: the other vehicles and the point obstacles
+    for (int u0 = threadIdx.x; u0 < n_to - 1; u0 += blockDim.x) {
         const int u = u0 < v ? u0 : u0 + 1;
         const int i = min(u, v), j = max(u, v);
-        const int q = i * (2 * n_veh - i - 1) / 2 + (j - i - 1);        // position of (i, j) in the lexicographic pair list
-        const double2* vi = xy + i * vpq;
-        const double2* vj = xy + j * vpq;
+        const int q = i * (2 * n_to - i - 1) / 2 + (j - i - 1);         // position of (i, j) in the lexicographic pair list
+        const double2* vi = xy + tsep_slot(t, i) * vpq;
+        const double2* vj = xy + tsep_slot(t, j) * vpq;
         double a[2][NC];
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
@@ -581,12 +583,13 @@ __device__ __forceinline__ void tsep_elev_rows_of_vehicle(const TsepXYParams& t,
     constexpr int L = S::L;
     const int LR = L + t.R;
     const ctab_t Td = as_ctab(t.Td);
-    for (int u0 = threadIdx.x; u0 < n_veh - 1; u0 += blockDim.x) {
+    const int n_to = t.n_tobj > 0 ? t.n_tobj : n_veh;
+    for (int u0 = threadIdx.x; u0 < n_to - 1; u0 += blockDim.x) {
         const int u = u0 < v ? u0 : u0 + 1;
         const int i = min(u, v), j = max(u, v);
-        const int q = i * (2 * n_veh - i - 1) / 2 + (j - i - 1);
-        const double2* vi = xy + i * vpq;
-        const double2* vj = xy + j * vpq;
+        const int q = i * (2 * n_to - i - 1) / 2 + (j - i - 1);
+        const double2* vi = xy + tsep_slot(t, i) * vpq;
+        const double2* vj = xy + tsep_slot(t, j) * vpq;
         double a[2][NC];
 #pragma unroll
         for (int c = 0; c < NC; ++c) {

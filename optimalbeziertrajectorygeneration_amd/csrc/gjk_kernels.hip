@@ -1051,6 +1051,13 @@ __global__ __launch_bounds__(256, WPC) void k_step_fd_structured(const Structure
         q.chunk = sp.fix_chunk; q.chg_from_fd = 1; q.passes = 1; q.len_in = nullptr; q.len_out = nullptr;
         gjk_planar_body<NC, 1, false>(q, xy_dyn, b, 0);
         __syncthreads();
+        if (p.n_obs > 0) {             // point obstacles: constant curves behind the hull objects, where the body's records were
+            for (int e = threadIdx.x; e < p.n_obs * 2 * NC; e += blockDim.x) {
+                const int o = e / (2 * NC), r = e - o * (2 * NC), qd = r / NC, k = r - qd * NC;
+                lds[2 * ((n_obj + o) * VPQ + k) + qd] = p.obs[o * 2 + qd];
+            }
+            __syncthreads();
+        }
         const int fd_e = fd_element(p.fd, p.fd_fixed, NC, b);
         if (fd_e >= 0) {
             if (ELEV) tsep_elev_rows_of_vehicle<NC>(p.ts, xy_dyn, VPQ, b, p.n_veh, fd_e / (2 * NC));
@@ -1111,10 +1118,14 @@ __global__ __launch_bounds__(256, WPC) void k_step_fd_structured(const Structure
             const int v = e / (2 * NC), rr = e - v * (2 * NC), qd = rr / NC, k = rr - qd * NC;
             lds[2 * (v * VPQ + k) + qd] = p.Y[e];
         }
+        for (int e = threadIdx.x; e < p.n_obs * 2 * NC; e += blockDim.x) {     // point obstacles: slot == object id here (no polygons staged)
+            const int o = e / (2 * NC), rr = e - o * (2 * NC), qd = rr / NC, k = rr - qd * NC;
+            lds[2 * ((p.n_veh + o) * VPQ + k) + qd] = p.obs[o * 2 + qd];
+        }
         __syncthreads();
         if (ELEV) {
             // the group's coefficient image behind the staged row; the waves' output tiles then take the place of both
-            double* img = reinterpret_cast<double*>(xy_dyn + n_obj * VPQ);
+            double* img = reinterpret_cast<double*>(xy_dyn + (p.n_veh + p.n_obs) * VPQ);
             tsep_elev_group_stream<NC>(p.ts, xy_dyn, VPQ, g, img, lds, r * sp.sep_rows_per,
                                        min(p.B, (r + 1) * sp.sep_rows_per), p.fd, p.fd_fixed);
             return;
@@ -3103,7 +3114,7 @@ int launch_step_fd_structured(obtg_ctx* c, int B, double max_sep, double* d_out_
         default: break;
     }
     const bool ok = kern && c->dim == 2 && c->polys_planar && c->max_poly_K <= nc && c->n_hull_pairs > 0 && !c->fd_dedup &&
-                    c->n_obs == 0 && c->n_pairs > 0 && speed && speed->d_out_ang && speed->d_out_speed &&
+                    c->n_pairs > 0 && speed && speed->d_out_ang && speed->d_out_speed &&
                     speed->d_tf && d_out_sep && c->n_veh < 65536 && 2 * c->deg + c->R + 1 <= 512;
     if (!ok) return OBTG_ERR_UNSUPPORTED;
     int rc = ensure_tables(c);
@@ -3124,6 +3135,10 @@ int launch_step_fd_structured(obtg_ctx* c, int B, double max_sep, double* d_out_
     p.ts.pairs = c->d_pairs.as<int2>(); p.ts.W2 = c->d_w2.as<double>(); p.ts.out = d_out_sep;
     p.ts.n_pairs = c->n_pairs; p.ts.sign = 1.0; p.ts.offset = 0.0 - max_sep * max_sep;
     p.ts.Td = c->d_Td.as<double>(); p.ts.Tf = c->d_Tf.as<double>(); p.ts.R = c->R;
+    if (c->n_obs > 0) {                // point obstacles (optimization.py:86-98): objects of the separation pair table only
+        p.obs = c->d_obs.as<double>(); p.n_obs = c->n_obs;
+        p.ts.n_veh = c->n_veh; p.ts.obs_shift = c->n_poly; p.ts.n_tobj = c->n_veh + c->n_obs;
+    }
     sp.cv4 = c->d_ang_T4.as<double>(); sp.cv2 = c->d_ang_cv2.as<double>(); sp.R = c->R;
     {
         AngParams& d = p.dyn;
@@ -3215,16 +3230,17 @@ int launch_step_fd_structured(obtg_ctx* c, int B, double max_sep, double* d_out_
         grid = (unsigned)groups * 16u;
     }
     p.dyn_first_block = 0;
-    size_t lds_s = std::max((size_t)16 * n_obj * vpq, sizeof(double) * kWave * L);      // (flat: the tile overlays the staged row)
+    const int n_sobj = c->n_veh + c->n_obs;                  // what an S workgroup stages: vehicles and point obstacles
+    size_t lds_s = std::max((size_t)16 * n_sobj * vpq, sizeof(double) * kWave * L);      // (flat: the tile overlays the staged row)
     size_t lds_d_elev = 0;
     if (elev) {
         // staged row + the group's coefficient image [64][PA]; then, in their place, four 16-row output tiles
         const int KS = (L + 3) / 4, PA = 4 * KS + 2, CW = 16 * (KS <= 6 ? 8 : 4);
-        lds_s = std::max((size_t)16 * n_obj * vpq + sizeof(double) * kWave * PA, sizeof(double) * 4 * 16 * (size_t)std::min(LR, CW));
+        lds_s = std::max((size_t)16 * n_sobj * vpq + sizeof(double) * kWave * PA, sizeof(double) * 4 * 16 * (size_t)std::min(LR, CW));
         lds_d_elev = sizeof(double) * dyn_elev_lds_doubles(c->deg, c->R);
     }
     const size_t lds_g = (planar_lds_bytes<0>(n_obj, vpq, sp.gjk_chunk_pairs) + 15) / 16 * 16 + (size_t)sp.gjk_chunk_pairs * 68 + 16;
-    const size_t lds_f = planar_lds_bytes<1>(n_obj, vpq, sp.fix_chunk);
+    const size_t lds_f = std::max(planar_lds_bytes<1>(n_obj, vpq, sp.fix_chunk), (size_t)16 * (n_obj + c->n_obs) * vpq);
     const size_t lds_d = sizeof(double) * ((size_t)kWave * (4 * c->deg + 1) + (size_t)kWave * L);
     const size_t lds = std::max(std::max(lds_s, lds_g), std::max(lds_f, elev ? lds_d_elev : lds_d));
     if (lds > (elev ? 76 : 40) * (size_t)1024) {

@@ -1422,7 +1422,8 @@ def test_both_speed_bounds_from_one_pass(capi, synth, oracle, shape):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("shape", ["C3_full_batch", "deg7_two_fixed", "three_vehicles", "deg5_no_polys", "elevated_R6", "C5_like_R100", "one_row", "two_rows_elevated", "C4_like_large_rows", "rows_of_96KB"])
+@pytest.mark.parametrize("shape", ["C3_full_batch", "deg7_two_fixed", "three_vehicles", "deg5_no_polys", "elevated_R6", "C5_like_R100", "one_row", "two_rows_elevated", "C4_like_large_rows", "rows_of_96KB",
+                                   "with_point_obstacles", "point_obstacles_elevated", "example1_class_path"])
 @pytest.mark.parametrize("tf_rows", ["one_tf", "a_few_rows_with_their_own_tf", "every_row_its_own_tf"])
 def test_structured_fd_step_is_bit_identical_to_the_brute_force_sweep(capi, synth, shape, tf_rows):
     """obtg_constraint_sweep_fd_structured_dev: the finite-difference step as ONE launch that evaluates row 0 in full and
@@ -1437,10 +1438,15 @@ def test_structured_fd_step_is_bit_identical_to_the_brute_force_sweep(capi, synt
                          "deg5_no_polys": (12, 5, 0, 1, 0), "elevated_R6": (9, 10, 3, 1, 6), "C5_like_R100": (64, 10, 32, 1, 100),
                          "one_row": (10, 7, 2, 1, 0), "two_rows_elevated": (6, 7, 1, 1, 3),
                          "C4_like_large_rows": (256, 15, 0, 1, 0),             # 70 KB of hulls per row: two workgroups per CU
-                         "rows_of_96KB": (558, 10, 2, 1, 0)}[shape]            # one workgroup per CU (k_step_fd_structured<11, false, 1>)
+                         "rows_of_96KB": (558, 10, 2, 1, 0),                   # one workgroup per CU (k_step_fd_structured<11, false, 1>)
+                         # pointObstacles (optimization.py:86-98): constant curves in the separation pair table only
+                         "with_point_obstacles": (20, 10, 2, 1, 0), "point_obstacles_elevated": (7, 7, 1, 1, 5),
+                         "example1_class_path": (2, 10, 1, 2, 0)}[shape]       # Example1's 2 vehicles + 2 point obstacles: P = 6
     Y = synth.swarm_control_points(N, 2, n, seed=41)
     B = N * 2 * (n + 1 - 2 * fixed) + 1
-    ctx = capi.Context(N, 2, n, R)
+    pobs = {"with_point_obstacles": [[20.0, 30.0], [55.5, 41.0], [70.0, 12.5]], "point_obstacles_elevated": [[33.0, 44.0]],
+            "example1_class_path": [[3.0, 2.0], [6.0, 7.0]]}.get(shape)
+    ctx = capi.Context(N, 2, n, R, point_obs=np.array(pobs) if pobs else None)
     ctx.set_stream(torch.cuda.current_stream().cuda_stream)
     if shape == "C5_like_R100":           # BASELINE configs[4]: 32 curve obstacles as static hulls, every pair of the 96 objects
         statics, pa, pb = synth.config_hull_sweep("C5", seed=41)
