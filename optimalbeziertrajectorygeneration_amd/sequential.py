@@ -50,7 +50,7 @@ def _one_vs_many(one, many, ndim, maxSep, degElev):
     """out[B][K].  Degrees without a specialised kernel go through the any-degree separation kernel: a context of K + 1
     "vehicles" (candidate first) whose first K lexicographic pairs are exactly (candidate, other k)."""
     nc = many.shape[-1]
-    if nc in _FAST_NC:
+    if nc in _FAST_NC and ndim in (2, 3) and degElev <= 512:       # (what the specialised kernel takes: bern_kernels.hip fast_shape)
         return _context(ndim, nc - 1, degElev).one_vs_many_min(one, many, maxSep)
     one = np.ascontiguousarray(one, dtype=np.float64).reshape(-1, ndim, nc)
     many = np.ascontiguousarray(many, dtype=np.float64).reshape(-1, ndim, nc)
@@ -166,7 +166,8 @@ class Parameters(object):
         self.finalpts = np.ascontiguousarray(finalpts[:nveh])
 
 
-def plan(params, nveh=None, pairing='reference', with_jac=True, degElev=10, maxiter=250, verbose=False, objective=None):
+def plan(params, nveh=None, pairing='reference', with_jac=True, degElev=10, maxiter=250, verbose=False, objective=None,
+         on_failure=None):
     """The loop of SequentialSwarm.py:176-192: plan vehicle i by SLSQP against the trajectories fixed so far, append
     it, go on.  -> (traj[(nveh*ndim), deg+1], per-vehicle OptimizeResult list, seconds).
     objective: 'feasibility' is the example's constant cost (SequentialSwarm.py:72-74; the default for its own pairing);
@@ -175,6 +176,12 @@ def plan(params, nveh=None, pairing='reference', with_jac=True, degElev=10, maxi
     nveh = params.nveh if nveh is None else nveh
     if objective is None:
         objective = 'feasibility' if pairing == 'reference' else 'deviation'
+    # on_failure: what joins the fixed trajectories when SLSQP does not converge.  'keep' = whatever point it stopped at
+    # (SequentialSwarm.py:186-190 appends res.x unconditionally: the default for its own pairing); 'guess' = the straight
+    # line, unless the stopping point violates the constraint less (the default for 'new_vs_all', where a vehicle whose
+    # target lies within dsafe of an earlier one has NO feasible trajectory and SLSQP's last iterate can be anywhere)
+    if on_failure is None:
+        on_failure = 'keep' if pairing == 'reference' else 'guess'
     traj = np.atleast_2d([])
     results = []
     t0 = time.time()
@@ -191,6 +198,9 @@ def plan(params, nveh=None, pairing='reference', with_jac=True, degElev=10, maxi
                            options={'maxiter': maxiter, 'disp': False, 'iprint': 0})
         results.append(res)
         xi = res.x if np.all(np.isfinite(res.x)) else x0
+        if on_failure == 'guess' and not res.success and xi is not x0:
+            if float(np.min(cons['fun'](xi))) < float(np.min(cons['fun'](x0))):
+                xi = x0
         traj = reshape(xi, traj, params.ndim, params.inipts[i, :], params.finalpts[i, :])
         if verbose:
             print('vehicle %d: nit %d, feasible margin %+.3e' % (i, res.nit, float(np.min(cons['fun'](xi)))))
