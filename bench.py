@@ -94,6 +94,9 @@ def parse():
     ap.add_argument("--gather-minima", action="store_true",
                     help="--mode rows: after every step all-gather the per-(row, pair) separation minima (what a driver that "
                          "keeps only active rows would collect: 8 bytes per row and pair)")
+    ap.add_argument("--ang-order", default="fast", choices=["fast", "reference", "exact"],
+                    help="DEG_ELEV > 0: obtg_ctx_set_ang_rate_order (fast = the headline; exact = plus the double-double "
+                         "recompute of near-stop vehicles' rows)")
     ap.add_argument("--no-proxy", action="store_true", help="skip the strong_scaling_proxy leg of a 1-GPU batch-mode run")
     ap.add_argument("--one-device", action="store_true",
                     help="rehearsal only: every rank uses device 0 (needs --backend gloo)")
@@ -273,6 +276,8 @@ def main():
     # create): every hand-over between torch's work and the library's below is a torch.cuda.synchronize().
     # (obtg_ctx_set_stream(torch.cuda.current_stream().cuda_stream) would order the launches with torch's stream instead.)
     stream_note = "context's own non-blocking stream; hand-over by torch.cuda.synchronize()"
+    if args.ang_order != "fast":
+        ctx.set_ang_rate_order({"reference": 1, "exact": 2}[args.ang_order])
     if use_gjk:
         ctx.set_polygons(ppts, poff)
         ctx.set_hull_pairs(pa, pb)
@@ -673,7 +678,7 @@ def main():
                                              "once per step for the others" if use_view
                                              else "written to HBM by obtg_fd_batch_dev each step"), P_t,
                                        "max_ang_rate+" if d == 2 else "", P_s),
-                       "mode": args.mode, "rows_per_step_all_ranks": B_total if args.mode == "rows" else world * B,
+                       "ang_rate_order": args.ang_order, "mode": args.mode, "rows_per_step_all_ranks": B_total if args.mode == "rows" else world * B,
                        "row_range_of_rank0": [row_begin, B] if args.mode == "rows" else None,
                        "gather_minima": bool(d_min is not None), "checksum": checksum,
                        "launches_per_step": len(kernels), "streams": 2 if two_streams else 1, "stream": stream_note,

@@ -108,7 +108,11 @@ int obtg_ctx_set_deg_elev(obtg_ctx*, int deg_elev);
  * Elevation commutes with diff/mul/add, so by default (elevate_first = 0) the library forms numerator and
  * denominator at degree 4n from the original control points and elevates both by 4R before the element-wise
  * quotient -- the same control points up to rounding (within the 1e-9 bar on every reference fixture), an order of
- * magnitude less arithmetic.  elevate_first = 1 keeps the reference's order of operations (generic kernel). */
+ * magnitude less arithmetic.  elevate_first = 1 keeps the reference's order of operations (generic kernel).
+ * 2 = "exact": the default order, then the rows of vehicles that nearly stop -- a control point of |v|^2 three orders
+ * below the curve's largest, where every float64 evaluation of the quotient, the reference's included, loses up to
+ * 1e-8 to cancellation -- once more in double-double arithmetic, rounded once: those rows are then within a few 1e-16
+ * of the exact rational value.  One more (small) launch behind the dynamics launch; not in the structured step. */
 int obtg_ctx_set_ang_rate_order(obtg_ctx*, int elevate_first);
 int obtg_sync(obtg_ctx*);
 
@@ -275,13 +279,16 @@ int obtg_constraint_sweep_dev(obtg_ctx*, const double* dY, const double* d_tf, i
  * results into all B rows, while one workgroup per row evaluates only the N-1 separation pairs, the hull pairs and the
  * vehicle its advanced control point touches.  Outputs are those of obtg_constraint_sweep_dev inside the same view,
  * bit for bit (the same device functions evaluate every pair); the launch is bound by its stores instead of by gjkNew.
- * Planar shapes (deg + 1 in {4, 6, 8, 11}, no point obstacles, angular rate wanted, a row's objects within 40 KB of LDS), any
+ * Planar shapes (deg + 1 in {4, 6, 8, 11}, with or without point obstacles -- constant curves of the separation pair table,
+ * optimization.py:86-98 --, angular rate wanted, a row's objects within 40 KB of LDS), any
  * DEG_ELEV with 2 deg + DEG_ELEV + 1 <= 512 -- for DEG_ELEV > 0 (where the brute-force step is two launches) the separation
  * streams are the elevated rows and the dynamics groups are the elevated kernel's; at DEG_ELEV = 0 also deg + 1 = 16 and, for
  * deg + 1 in {11, 16}, rows of up to 158 KB (256 vehicles of degree 15 are 70 KB: two workgroups per CU):
  * OBTG_ERR_UNSUPPORTED otherwise -- the brute-force call gives the same numbers.  d_tf is read per row: the speed /
  * angular-rate rows of row 0 are copied only into rows whose tf equals tf[0] bit for bit, any other row is evaluated in full.  A different evaluation strategy from
- * "every row in full": bench.py reports it as variants.fd_structured, never as its headline value. */
+ * "every row in full": bench.py reports it as variants.fd_structured, never as its headline value.  The call is a view
+ * of its own (begin .. end around its launch): with a view of the caller's open on the context it returns OBTG_ERR_ARG
+ * instead of replacing and closing that view; a row RANGE (obtg_fd_view_begin_rows) has no structured form. */
 int obtg_constraint_sweep_fd_structured_dev(obtg_ctx*, const double* dY0, int n_fixed_cols, double h, const double* d_tf,
                                             int B, double max_sep, double* d_out_sep, double speed_bound, int speed_is_max,
                                             double max_rate, double* d_out_speed, double* d_out_ang, int max_iter, int md_cap,

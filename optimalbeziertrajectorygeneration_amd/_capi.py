@@ -311,9 +311,10 @@ class Context(object):
         self.deg_elev = int(R)
 
     def set_ang_rate_order(self, elevate_first):
-        """DEG_ELEV > 0: False (default) = products at degree 4n, then elevation by 4R; True = the reference's
-        order of operations (include/obtg.h obtg_ctx_set_ang_rate_order)."""
-        self._check(self._lib.obtg_ctx_set_ang_rate_order(self._h, int(bool(elevate_first))), "obtg_ctx_set_ang_rate_order")
+        """DEG_ELEV > 0: False / 0 (default) = products at degree 4n, then elevation by 4R; True / 1 = the reference's
+        order of operations; 2 = the default order plus a double-double recompute of near-stop vehicles' rows
+        (include/obtg.h obtg_ctx_set_ang_rate_order)."""
+        self._check(self._lib.obtg_ctx_set_ang_rate_order(self._h, int(elevate_first)), "obtg_ctx_set_ang_rate_order")
 
     def sync(self):
         self._check(self._lib.obtg_sync(self._h), "obtg_sync")

@@ -1262,6 +1262,8 @@ struct AngElevParams {
     const double* __restrict__ cv4;  // scale[4n+1] = C(4n, j) | padded row C(4R, m) 2^-e, m = -(4n) .. 4R+4n+8
     const double* __restrict__ cv2;  // scale[2n+1] = C(2n, j) | padded row C(R, m), m = -(2n) .. R+2n+8 | 1/C(2n+R, k) (+8)
     int R;
+    int* flags;                      // obtg_ctx_set_ang_rate_order(2): flags[0] counts, flags[1 ..] lists the items whose speed curve
+                                     // comes near zero (their angular-rate rows are recomputed in double-double); else nullptr
 };
 
 // LDS doubles of dynamics_elev_group: the two binomial rows as the matrix instruction's B operand reads them, and 1/C(2n+R, .)
@@ -1431,8 +1433,10 @@ __device__ __forceinline__ void dynamics_elev_group(const AngElevParams& q, doub
     };
     const int row_base = 16 * wave + kg;               // this lane's rows: row_base + 4 r
     // ---- speed rows = elev(den1, R), both requested bounds from the same accumulators
-    if (p.out_speed) {
+    const bool flagging = q.flags != nullptr && p.out != nullptr && !mapped;
+    if (p.out_speed || flagging) {
         const double* bp = hl2 + PAD2 + c - kg;
+        double mn[4] = { INFINITY, INFINITY, INFINITY, INFINITY }, mx[4] = { -INFINITY, -INFINITY, -INFINITY, -INFINITY };
         for (int t = 0; t < NT2; ++t) {
             v4d_t acc;
             acc[0] = acc[1] = acc[2] = acc[3] = 0.0;
@@ -1443,8 +1447,23 @@ __device__ __forceinline__ void dynamics_elev_group(const AngElevParams& q, doub
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const double e = acc[r] * iv;
-                emit(p.out_speed, L2R, row_base + 4 * r, col, p.sp_sign * e + p.sp_offset);
-                if (p.out_speed2) emit(p.out_speed2, L2R, row_base + 4 * r, col, p.sp2_sign * e + p.sp2_offset);
+                if (col < L2R) { mn[r] = fmin(mn[r], e); mx[r] = fmax(mx[r], e); }
+                if (p.out_speed) {
+                    emit(p.out_speed, L2R, row_base + 4 * r, col, p.sp_sign * e + p.sp_offset);
+                    if (p.out_speed2) emit(p.out_speed2, L2R, row_base + 4 * r, col, p.sp2_sign * e + p.sp2_offset);
+                }
+            }
+        }
+        if (flagging) {
+            // obtg_ctx_set_ang_rate_order(2).  Near a stop: the elevated control points of |v|^2 -- tight to the curve at
+            // DEG_ELEV of any size -- fall below 2 % of their largest (or are not positive).  The elevated denominator
+            // (|v|^2)^2 is then a sum of terms ten thousand times itself; the row goes on the list of the double-double pass.
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+#pragma unroll
+                for (int m = 1; m < 16; m <<= 1) { mn[r] = fmin(mn[r], __shfl_xor(mn[r], m)); mx[r] = fmax(mx[r], __shfl_xor(mx[r], m)); }
+                const int row = row_base + 4 * r;
+                if (c == 0 && row < n_valid && !(mn[r] > 2e-2 * mx[r])) q.flags[1 + atomicAdd(q.flags, 1)] = it0 + row;
             }
         }
     }

@@ -328,6 +328,150 @@ __global__ __launch_bounds__(4 * kWave, (NC > 11 ? 1 : 3)) void k_dynamics_elev(
     dynamics_elev_group<NC>(q, lds, (int)blockIdx.x);
 }
 
+// =====================================================================================
+//  obtg_ctx_set_ang_rate_order(2): the angular-rate rows of near-stop vehicles once more, in double-double
+// =====================================================================================
+// Where a vehicle nearly stops, den = (xD^2 + yD^2)^2 falls orders of magnitude below its size elsewhere on the curve and
+// its elevated control points are sums of terms far larger than themselves: ANY float64 evaluation of
+// optimization.py:578-611 -- the reference's own included, 3e-9 from the exact value on the fixture's vehicle -- loses
+// what the cancellation takes.  The dynamics kernels list such items (a |v|^2 control point three
+// orders below the largest); this kernel evaluates the whole chain for them -- derivatives, the degree-2n curves, their
+// squares, the two elevations by 4R, the quotient -- in double-double (two_sum / fma two_prod: ~1e-31 per operation) from
+// tables held as (hi, lo) pairs, and rounds once at the end: every element within a few 1e-16 of the exact rational
+// value.  One wave per item, lane = output column; the chain up to degree 4n is computed by every lane (the items are
+// few: one in a few hundred vehicles).
+#pragma clang fp contract(off)
+struct dd_t { double hi, lo; };
+__device__ __forceinline__ dd_t dd_mk(double hi, double lo = 0.0) { dd_t r; r.hi = hi; r.lo = lo; return r; }
+__device__ __forceinline__ dd_t dd_qsum(double a, double b) { const double s = a + b; return dd_mk(s, b - (s - a)); }
+__device__ __forceinline__ dd_t dd_sum2(double a, double b)
+{
+    const double s = a + b, bb = s - a;
+    return dd_mk(s, (a - (s - bb)) + (b - bb));
+}
+__device__ __forceinline__ dd_t dd_add(dd_t a, dd_t b)
+{
+    dd_t s = dd_sum2(a.hi, b.hi);
+    const dd_t t = dd_sum2(a.lo, b.lo);
+    s.lo += t.hi;
+    s = dd_qsum(s.hi, s.lo);
+    s.lo += t.lo;
+    return dd_qsum(s.hi, s.lo);
+}
+__device__ __forceinline__ dd_t dd_neg(dd_t a) { return dd_mk(-a.hi, -a.lo); }
+__device__ __forceinline__ dd_t dd_sub(dd_t a, dd_t b) { return dd_add(a, dd_neg(b)); }
+__device__ __forceinline__ dd_t dd_mul(dd_t a, dd_t b)
+{
+    const double p = a.hi * b.hi;
+    double e = fma(a.hi, b.hi, -p);
+    e += a.hi * b.lo + a.lo * b.hi;
+    return dd_qsum(p, e);
+}
+__device__ __forceinline__ dd_t dd_div(dd_t a, dd_t b)
+{
+    if (b.hi == 0.0 || !(fabs(b.hi) < INFINITY) || !(fabs(a.hi) < INFINITY)) return dd_mk(a.hi / b.hi);   // 0/0, x/0: as float64 has them
+    const double q1 = a.hi / b.hi;
+    dd_t r = dd_sub(a, dd_mul(b, dd_mk(q1)));
+    const double q2 = r.hi / b.hi;
+    r = dd_sub(r, dd_mul(b, dd_mk(q2)));
+    const double q3 = r.hi / b.hi;
+    dd_t q = dd_qsum(q1, q2);
+    return dd_add(q, dd_mk(q3));
+}
+__device__ __forceinline__ dd_t dd_ld(const double* t, int i) { return dd_mk(t[2 * i], t[2 * i + 1]); }
+
+struct AngDdParams {
+    AngParams a;                     // the batch (or the view's row), tf, out, w2
+    const int* __restrict__ flags;   // flags[0] = count, flags[1 ..] = items
+    const double* __restrict__ tab;  // angrate_dd_tables
+    DdTables off;
+    int R, cap;
+};
+
+// d = elev(1) of the derivative of pp (Bezier.diff(), bezier.py:497-519), all in LDS, lane = control point
+template <int NC>
+__device__ __forceinline__ void dd_diff_elev1(const dd_t* pp, dd_t val, const double* ratio, dd_t* t, dd_t* d, int lane)
+{
+    constexpr int N = NC - 1;
+    if (lane < N) t[lane] = dd_mul(dd_sub(pp[lane + 1], pp[lane]), val);
+    __syncthreads();
+    if (lane == 0) d[0] = t[0];
+    else if (lane == N) d[N] = t[N - 1];
+    else if (lane < N) d[lane] = dd_add(dd_mul(t[lane - 1], dd_ld(ratio, lane)), dd_mul(t[lane], dd_ld(ratio, N - lane)));
+    __syncthreads();
+}
+
+template <int NC>
+__global__ __launch_bounds__(kWave) void k_angrate_dd(const AngDdParams q)
+{
+    constexpr int N = NC - 1, L2 = 2 * N + 1, L4 = 4 * N + 1;
+    static_assert(L2 <= kWave, "one lane per degree-2n coefficient");
+    extern __shared__ double lds[];
+    dd_t* xs = reinterpret_cast<dd_t*>(lds);            // x, y, xD, yD, xDD, yDD [NC] each, t [NC] scratch
+    dd_t* ys = xs + NC; dd_t* xD = ys + NC; dd_t* yD = xD + NC; dd_t* xDD = yD + NC; dd_t* yDD = xDD + NC; dd_t* tt = yDD + NC;
+    dd_t* num1 = tt + NC;                               // [L2] degree-2n numerator yDD xD - xDD yD
+    dd_t* den1 = num1 + L2;                             // [L2] xD^2 + yD^2
+    dd_t* numl = den1 + L2;                             // [L4] num1^2, times C(4n, k)
+    dd_t* denl = numl + L4;                             // [L4] den1^2, times C(4n, k)
+    const AngParams& p = q.a;
+    const int lane = threadIdx.x;
+    const int count = min(q.flags[0], q.cap);
+    const int L4R = L4 + 4 * q.R;
+    const double* wn = q.tab + q.off.wn; const double* w2n = q.tab + q.off.w2n; const double* w22n = q.tab + q.off.w22n;
+    const double* ratio = q.tab + q.off.ratio; const double* row4 = q.tab + q.off.row4; const double* sc4 = q.tab + q.off.sc4;
+    for (int fi = blockIdx.x; fi < count; fi += gridDim.x) {
+        const int item = q.flags[1 + fi];
+        const int b = item / p.n_veh;
+        __syncthreads();                                 // (the previous item's arrays have been read)
+        {
+            double x[NC], y[NC];
+            load_item_xy<NC>(p, item, b, x, y);
+#pragma unroll
+            for (int c = 0; c < NC; ++c) if (lane == c) { xs[c] = dd_mk(x[c]); ys[c] = dd_mk(y[c]); }
+        }
+        __syncthreads();
+        const dd_t val = dd_div(dd_mk((double)N), dd_mk(p.tf[b]));
+        dd_diff_elev1<NC>(xs, val, ratio, tt, xD, lane);
+        dd_diff_elev1<NC>(ys, val, ratio, tt, yD, lane);
+        dd_diff_elev1<NC>(xD, val, ratio, tt, xDD, lane);
+        dd_diff_elev1<NC>(yD, val, ratio, tt, yDD, lane);
+        if (lane < L2) {
+            const int k = lane;
+            dd_t s = dd_mk(0.0), sd = dd_mk(0.0);
+            for (int j = (k - N > 0 ? k - N : 0); j <= (N < k ? N : k); ++j)
+                s = dd_add(s, dd_mul(dd_ld(wn, k * NC + j), dd_sub(dd_mul(yDD[j], xD[k - j]), dd_mul(xDD[j], yD[k - j]))));
+            for (int j = (k - N > 0 ? k - N : 0); 2 * j <= k; ++j)
+                sd = dd_add(sd, dd_mul(dd_ld(w2n, k * NC + j), dd_add(dd_mul(xD[j], xD[k - j]), dd_mul(yD[j], yD[k - j]))));
+            num1[k] = s;
+            den1[k] = sd;
+        }
+        __syncthreads();
+        for (int k = lane; k < L4; k += kWave) {         // the degree-4n squares, pre-scaled by C(4n, k) for the convolution form
+            dd_t sn = dd_mk(0.0), sd = dd_mk(0.0);
+            for (int j = (k - 2 * N > 0 ? k - 2 * N : 0); 2 * j <= k; ++j) {
+                const dd_t w = dd_ld(w22n, k * L2 + j);
+                sn = dd_add(sn, dd_mul(w, dd_mul(num1[j], num1[k - j])));
+                sd = dd_add(sd, dd_mul(w, dd_mul(den1[j], den1[k - j])));
+            }
+            numl[k] = dd_mul(sn, dd_ld(sc4, k));
+            denl[k] = dd_mul(sd, dd_ld(sc4, k));
+        }
+        __syncthreads();
+        for (int k = lane; k < L4R; k += kWave) {        // elevation by 4R (the factor 1 / C(4n + 4R, k) cancels in the quotient)
+            dd_t sn = dd_mk(0.0), sd = dd_mk(0.0);
+            const int j0 = k - 4 * q.R > 0 ? k - 4 * q.R : 0, j1 = k < L4 - 1 ? k : L4 - 1;
+            for (int j = j0; j <= j1; ++j) {
+                const dd_t w = dd_ld(row4, k - j);
+                sn = dd_add(sn, dd_mul(w, numl[j]));
+                sd = dd_add(sd, dd_mul(w, denl[j]));
+            }
+            const dd_t r = dd_sub(dd_mk(p.w2), dd_div(sn, sd));
+            p.out[(size_t)item * L4R + k] = r.hi + r.lo;
+        }
+    }
+}
+#pragma clang fp contract(fast)
+
 // DEG_ELEV > 0: the elevated separation rows and the elevated speed / angular-rate rows of a batch in ONE launch (the
 // brute-force step of such a shape is then two launches: this and the gjkNew sweep).  The separation kernel is bound by
 // its stores, the dynamics kernel by its FMAs; their workgroups are interleaved over the block ids (pattern rotated by
@@ -1108,18 +1252,58 @@ static int launch_dyn_t(obtg_ctx* c, const AngParams& p, int kernel_id)
     return OBTG_OK;
 }
 
+// obtg_ctx_set_ang_rate_order(2): the list the dynamics groups fill (zeroed here) ...
+static int ang_exact_prepare(obtg_ctx* c, int total_items, int** d_flags)
+{
+    *d_flags = nullptr;
+    if (!c->ang_exact) return OBTG_OK;
+    if (c->ang_dd_R != c->R || c->d_ang_dd.p == nullptr) {
+        std::vector<double> t;
+        c->ang_dd_off = angrate_dd_tables(c->deg, c->R, t);
+        int rc = c->d_ang_dd.reserve(t.size() * sizeof(double));
+        if (rc) return rc;
+        OBTG_HIP(c, hipMemcpyAsync(c->d_ang_dd.p, t.data(), t.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
+        OBTG_HIP(c, hipStreamSynchronize(c->stream));
+        c->ang_dd_R = c->R;
+    }
+    int rc = c->d_ang_flags.reserve(sizeof(int) * ((size_t)total_items + 1));
+    if (rc) return rc;
+    OBTG_HIP(c, hipMemsetAsync(c->d_ang_flags.p, 0, sizeof(int), c->stream));
+    *d_flags = c->d_ang_flags.as<int>();
+    return OBTG_OK;
+}
+
+// ... and the double-double pass over it, behind the launch that filled it
 template <int NC>
-static int launch_dyn_elev_t(obtg_ctx* c, const AngElevParams& q, int kernel_id)
+static int ang_exact_finish(obtg_ctx* c, const AngParams& a, const int* d_flags, int total_items)
+{
+    if (!d_flags) return OBTG_OK;
+    constexpr int L2 = 2 * (NC - 1) + 1, L4 = 4 * (NC - 1) + 1;
+    AngDdParams q{};
+    q.a = a; q.flags = d_flags; q.tab = c->d_ang_dd.as<double>(); q.off = c->ang_dd_off; q.R = c->R; q.cap = total_items;
+    const size_t lds = sizeof(double) * 2 * (7 * NC + 2 * L2 + 2 * L4);
+    ScopedKernelTimer t(c, OBTG_K_ANG_RATE);
+    hipLaunchKernelGGL(k_angrate_dd<NC>, dim3((unsigned)std::max(1, std::min(total_items, 512))), dim3(kWave), lds, c->stream, q);
+    OBTG_HIP(c, hipGetLastError());
+    return OBTG_OK;
+}
+
+template <int NC>
+static int launch_dyn_elev_t(obtg_ctx* c, AngElevParams q, int kernel_id)
 {
     const size_t lds = sizeof(double) * dyn_elev_lds_doubles(NC - 1, q.R);
     const unsigned groups = (unsigned)((q.a.total + kWave - 1) / kWave);
     if (lds > 48 * 1024)
         OBTG_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_dynamics_elev<NC>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    ScopedKernelTimer t(c, kernel_id);
-    hipLaunchKernelGGL(k_dynamics_elev<NC>, dim3(groups), dim3(4 * kWave), lds, c->stream, q);
-    OBTG_HIP(c, hipGetLastError());
-    return OBTG_OK;
+    int rc = ang_exact_prepare(c, q.a.total, &q.flags);
+    if (rc) return rc;
+    {
+        ScopedKernelTimer t(c, kernel_id);
+        hipLaunchKernelGGL(k_dynamics_elev<NC>, dim3(groups), dim3(4 * kWave), lds, c->stream, q);
+        OBTG_HIP(c, hipGetLastError());
+    }
+    return ang_exact_finish<NC>(c, q.a, q.flags, q.a.total);
 }
 
 // DEG_ELEV > 0, angular rate wanted: products at degree 4n, then elevation by 4R (k_dynamics_elev).
@@ -1228,10 +1412,14 @@ static int launch_sep_dyn_elev_t(obtg_ctx* c, SepDynElevParams& sp, int B)
     if (lds > 48 * 1024)
         OBTG_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_sep_dynamics_elev<NC>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    ScopedKernelTimer t(c, OBTG_K_TEMPORAL_SEP);
-    hipLaunchKernelGGL(k_sep_dynamics_elev<NC>, dim3((unsigned)groups * 16u), dim3(4 * kWave), lds, c->stream, sp);
-    OBTG_HIP(c, hipGetLastError());
-    return OBTG_OK;
+    int rc = ang_exact_prepare(c, sp.dyn.a.total, &sp.dyn.flags);
+    if (rc) return rc;
+    {
+        ScopedKernelTimer t(c, OBTG_K_TEMPORAL_SEP);
+        hipLaunchKernelGGL(k_sep_dynamics_elev<NC>, dim3((unsigned)groups * 16u), dim3(4 * kWave), lds, c->stream, sp);
+        OBTG_HIP(c, hipGetLastError());
+    }
+    return ang_exact_finish<NC>(c, sp.dyn.a, sp.dyn.flags, sp.dyn.a.total);
 }
 
 // DEG_ELEV > 0, planar: the separation rows and the speed / angular-rate rows of a batch in one launch

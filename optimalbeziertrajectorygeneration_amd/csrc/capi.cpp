@@ -269,7 +269,7 @@ void obtg_ctx_destroy(obtg_ctx* c)
     (void)hipStreamSynchronize(c->stream);
     flush_pending_events(c);
     for (hipEvent_t e : c->event_pool) (void)hipEventDestroy(e);
-    DevBuf* bufs[] = { &c->d_pairs, &c->d_obs, &c->d_w2, &c->d_Tt, &c->d_Td, &c->d_Tf, &c->d_ang_T4f, &c->d_vp_off, &c->d_vp_idx, &c->d_ang_w2n, &c->d_ang_w22n, &c->d_ang_wn, &c->d_ang_T4, &c->d_ang_cv2,
+    DevBuf* bufs[] = { &c->d_pairs, &c->d_obs, &c->d_w2, &c->d_Tt, &c->d_Td, &c->d_Tf, &c->d_ang_T4f, &c->d_ang_dd, &c->d_ang_flags, &c->d_vp_off, &c->d_vp_idx, &c->d_ang_w2n, &c->d_ang_w22n, &c->d_ang_wn, &c->d_ang_T4, &c->d_ang_cv2,
                        &c->d_binrows, &c->d_tiles, &c->d_poly_pts, &c->d_poly_off, &c->d_hp_a, &c->d_hp_b, &c->d_tile_chunk_off, &c->d_tile_order, &c->d_tile_pslots,
                        &c->d_tile_cobj_off, &c->d_tile_cobjs, &c->d_tile_ij, &c->ws_in,
                        &c->ws_in2, &c->ws_out, &c->ws_fd };
@@ -328,7 +328,9 @@ int obtg_host_free(void* p)
 int obtg_ctx_set_ang_rate_order(obtg_ctx* c, int elevate_first)
 {
     if (!check_ctx(c)) return OBTG_ERR_ARG;
-    c->ang_elevate_first = elevate_first != 0;
+    if (elevate_first < 0 || elevate_first > 2) return OBTG_ERR_ARG;
+    c->ang_elevate_first = elevate_first == 1;
+    c->ang_exact = elevate_first == 2;
     return OBTG_OK;
 }
 
@@ -973,7 +975,8 @@ int obtg_ctx_set_hull_pairs(obtg_ctx* c, const int* pair_a, const int* pair_b, i
     if (rc) return rc;
     if ((rc = upload(c, c->d_hp_b, pair_b, sizeof(int) * (size_t)n_pairs))) return rc;
     c->n_hull_pairs = n_pairs;
-    c->hull_pairs_set = true;
+    c->hull_pairs_set = false;             // (true again once EVERY table of the list is on the device: a failed upload below
+                                           //  must not leave the previous list's per-vehicle index marked valid)
     c->h_hp_a.assign(pair_a, pair_a + n_pairs);
     c->h_hp_b.assign(pair_b, pair_b + n_pairs);
     {   // which pairs contain vehicle v (list order): what a finite-difference row that moves v has to re-evaluate
@@ -999,6 +1002,7 @@ int obtg_ctx_set_hull_pairs(obtg_ctx* c, const int* pair_a, const int* pair_b, i
         if ((rc = upload(c, c->d_poly_off, &zero, sizeof(int)))) return rc;
     }
     if (c->d_poly_pts.p == nullptr && (rc = c->d_poly_pts.reserve(8))) return rc;
+    c->hull_pairs_set = true;
     return OBTG_OK;
 }
 
@@ -1050,6 +1054,7 @@ int obtg_constraint_sweep_fd_structured_dev(obtg_ctx* c, const double* dY0, int 
     if (!check_ctx(c) || !dY0 || !d_tf || !d_out_sep || !d_out_speed || !d_out_ang || !d_flag || !d_p1 || !d_p2 || !d_dist ||
         B < 1 || max_iter < 1 || md_cap < 1) return OBTG_ERR_ARG;
     if (!c->hull_pairs_set || c->dim != 2) return OBTG_ERR_ARG;
+    if (c->view.Y0) return OBTG_ERR_ARG;       // a view of the caller's is open: this call is a view of its own and would replace and close it
     int rc = obtg_fd_view_begin(c, dY0, n_fixed_cols, h, B);
     if (rc) return rc;
     (void)hipSetDevice(c->device);

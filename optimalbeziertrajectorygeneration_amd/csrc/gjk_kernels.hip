@@ -1017,7 +1017,7 @@ __global__ __launch_bounds__(256, WPC) void k_step_fd_structured(const Structure
         auto run = [&](int group) {
             if (ELEV) {
                 AngElevParams q;
-                q.a = p.dyn; q.cv4 = sp.cv4; q.cv2 = sp.cv2; q.R = sp.R;
+                q.a = p.dyn; q.cv4 = sp.cv4; q.cv2 = sp.cv2; q.R = sp.R; q.flags = nullptr;
                 dynamics_elev_group<NC>(q, lds, group, &em);
             } else {
                 dynamics2_group<NC, false, true>(p.dyn, lds, group, &em);
@@ -3096,6 +3096,7 @@ int launch_step_fd_structured(obtg_ctx* c, int B, double max_sep, double* d_out_
     if (B <= 0) return OBTG_OK;
     if (!c->fd.Y0) return OBTG_ERR_ARG;
     if (c->fd.row0 != 0) return OBTG_ERR_UNSUPPORTED;      // (a row range that does not start at the batch's row 0: its kinds count from row 0)
+    if (c->ang_exact && c->R > 0) return OBTG_ERR_UNSUPPORTED;   // (obtg_ctx_set_ang_rate_order(2): the double-double pass follows the brute-force launches)
     const int nc = c->deg + 1;
     void (*kern)(const StructuredParams) = nullptr;
     void (*kern_mid)(const StructuredParams) = nullptr;      // two workgroups per CU: rows beyond 40 KB of LDS (C4: 79 KB)

@@ -19,6 +19,8 @@ std::vector<double> binom_row(int n);               // C(n, 0..n)
 std::vector<double> folded_product_weights(int n, int dim);  // [2n+1][n+1], see bern_kernels.hip
 std::vector<double> elev_table_frag(int L_in, int R);   // the same matrix as v_mfma_f64_16x16x4 B fragments: [NT][KS][64]
 std::vector<double> elev_table_T_ld(int L_in, int R);   // dense, transposed, zero padded: [L_in+R][L_in] (bit-equal to the fragments)
+struct DdTables { int wn, w2n, w22n, ratio, row4, sc4; };     // offsets (doubles) of angrate_dd_tables' parts
+DdTables angrate_dd_tables(int n, int R, std::vector<double>& t);
 std::vector<double> elev_conv_tables(int L_in, int R);  // scale | padded C(R,.) | 1/C(N+R,.)
 std::vector<double> elev_conv_padded(int L_in, int R, int extra, bool normalise, bool with_inv);
 
@@ -73,6 +75,11 @@ struct obtg_ctx {
     obtg::DevBuf d_ang_T4f;   // the same elevation (4*deg -> 4*(deg+R)) as matrix-instruction B fragments (elev_table_frag)
     obtg::DevBuf d_ang_cv2;   // the same for the speed rows, 2*deg -> 2*deg+R, with the 1/C(2n+R, k) row
     bool ang_elevate_first = false;   // true: the reference's order (elevate, then products at degree n+R; generic kernel)
+    bool ang_exact = false;           // obtg_ctx_set_ang_rate_order(2): the default order, then the rows of near-stop vehicles again in
+                                      // double-double (k_angrate_dd); tables and the flag list below, made on first use
+    obtg::DevBuf d_ang_dd, d_ang_flags;
+    obtg::DdTables ang_dd_off{};
+    int ang_dd_R = -1;
     // obtg_ctx_set_second_speed_bound: every dynamics pass that writes speed rows also writes the other bound's rows
     struct { double bound = 0.0; int is_max = 0; double* d_out = nullptr; } speed2;
     std::vector<int> h_pairs; // host copy of the pair table (2 ints per pair)

@@ -83,6 +83,56 @@ std::vector<double> elev_table_T_ld(int L_in, int R)
     return T;
 }
 
+// Tables of the double-double recompute of ill-conditioned angular-rate rows (bern_kernels.hip k_angrate_dd), every
+// entry as (hi, lo) with hi + lo = the long double value (64-bit mantissa: 5e-20 relative, against conditions of up to
+// 1e6 on those rows).  Layout, all for degree n, dim 2:
+//   wn[2n+1][n+1][2]     plain product weights C(n,j) C(n,k-j) / C(2n,k)
+//   w2n[2n+1][n+1][2]    folded weights of the square at degree n (x2 off the diagonal)
+//   w22n[4n+1][2n+1][2]  folded weights of the square at degree 2n
+//   ratio[n+1][2]        c / n                    (diff_elev1's elevation by one)
+//   row4[4R+1][2]        C(4R, m) 2^-e            (e as elev_conv_padded's normalisation)
+//   sc4[4n+1][2]         C(4n, k)                 (beyond 2^53 from degree 14 on)
+// returned back to back; offsets in DdTables.
+static void push_dd(std::vector<double>& t, long double v)
+{
+    const double hi = (double)v;
+    t.push_back(hi);
+    t.push_back((double)(v - (long double)hi));
+}
+
+DdTables angrate_dd_tables(int n, int R, std::vector<double>& t)
+{
+    DdTables o{};
+    t.clear();
+    const int L2 = 2 * n + 1, L4 = 4 * n + 1, nc = n + 1;
+    o.wn = 0;
+    for (int k = 0; k < L2; ++k)
+        for (int j = 0; j < nc; ++j) push_dd(t, (k - j >= 0 && k - j <= n) ? binom_ld(n, j) * binom_ld(n, k - j) / binom_ld(2 * n, k) : 0.0L);
+    o.w2n = (int)t.size();
+    for (int k = 0; k < L2; ++k)
+        for (int j = 0; j < nc; ++j) {
+            long double w = 0.0L;
+            if (j >= (k - n > 0 ? k - n : 0) && 2 * j <= k) { w = binom_ld(n, j) * binom_ld(n, k - j) / binom_ld(2 * n, k); if (j != k - j) w *= 2.0L; }
+            push_dd(t, w);
+        }
+    o.w22n = (int)t.size();
+    for (int k = 0; k < L4; ++k)
+        for (int j = 0; j < L2; ++j) {
+            long double w = 0.0L;
+            if (j >= (k - 2 * n > 0 ? k - 2 * n : 0) && 2 * j <= k) { w = binom_ld(2 * n, j) * binom_ld(2 * n, k - j) / binom_ld(4 * n, k); if (j != k - j) w *= 2.0L; }
+            push_dd(t, w);
+        }
+    o.ratio = (int)t.size();
+    for (int c = 0; c < nc; ++c) push_dd(t, (long double)c / (long double)n);
+    o.row4 = (int)t.size();
+    int e = 0;
+    (void)std::frexp(binom(4 * R, 2 * R), &e);
+    for (int m = 0; m <= 4 * R; ++m) push_dd(t, std::ldexp(binom_ld(4 * R, m), -e));
+    o.sc4 = (int)t.size();
+    for (int k = 0; k < L4; ++k) push_dd(t, binom_ld(4 * n, k));
+    return o;
+}
+
 // Degree elevation by R of an L_in-coefficient curve as a scaled convolution: three rows back to back
 //   scale[L_in] = C(N, j);  binp[R + 2 L_in - 1 + 8] = C(R, m), m = -(L_in-1) .. R+L_in-1+8;  inv[L_in+R+8] = 1/C(N+R, k)
 // (8 = kConvPad of bern_device.h: kernels that produce blocks of 8 output columns read that far past the end)

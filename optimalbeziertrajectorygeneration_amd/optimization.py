@@ -108,8 +108,8 @@ class BezOptimization(object):
         # DEG_ELEV > 0 only: 'fast' forms the angular rate's products at degree 4n and elevates them (0.2 ms at C5);
         # 'reference' elevates the position first as optimization.py:597 does (1.8 ms) -- closer to the exact value on
         # vehicles that nearly stop (tests/test_gpu_parity.py::test_near_stop_angular_rate_on_device)
-        if angRateOrder not in ('fast', 'reference'):
-            raise ValueError("angRateOrder must be 'fast' or 'reference', not {!r}".format(angRateOrder))
+        if angRateOrder not in ('fast', 'reference', 'exact'):
+            raise ValueError("angRateOrder must be 'fast', 'reference' or 'exact', not {!r}".format(angRateOrder))
         self.angRateOrder = angRateOrder
         self.pointObstacles = pointObstacles
         self.shapeObstacles = shapeObstacles
@@ -149,7 +149,7 @@ class BezOptimization(object):
             obs = self.pointObstacles if with_point_obs else None
             c = _capi.Context(self.model['numVeh'], self.model['dim'], self.model['deg'], int(DEG_ELEV),
                               point_obs=obs, device=self._device)
-            c.set_ang_rate_order(self.angRateOrder == 'reference')
+            c.set_ang_rate_order({'fast': 0, 'reference': 1, 'exact': 2}[self.angRateOrder])
             self._ctxs[key] = c
         if c.deg_elev != int(DEG_ELEV):
             c.set_deg_elev(int(DEG_ELEV))
@@ -161,7 +161,7 @@ class BezOptimization(object):
         c = self._ctxs.get('one')
         if c is None:
             c = _capi.Context(1, self.model['dim'], self.model['deg'], int(DEG_ELEV), device=self._device)
-            c.set_ang_rate_order(self.angRateOrder == 'reference')
+            c.set_ang_rate_order({'fast': 0, 'reference': 1, 'exact': 2}[self.angRateOrder])
             self._ctxs['one'] = c
         if c.deg_elev != int(DEG_ELEV):
             c.set_deg_elev(int(DEG_ELEV))

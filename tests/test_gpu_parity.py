@@ -1068,13 +1068,23 @@ def test_near_stop_angular_rate_on_device(capi, oracle, golden_dir, capsys):
     for tf in g["tfs"]:
         ref = g["angrate_tf%g" % tf].reshape(N, L4)
         exact = g["exact_tf%g" % tf].reshape(N, L4)
-        for order, name in ((0, "default order"), (1, "reference order")):
+        for order, name in ((0, "default order"), (1, "reference order"), (2, "exact order")):
             ctx = capi.Context(N, 2, n, R)
             ctx.set_ang_rate_order(order)
             got = ctx.ang_rate(Y, float(tf), 1.0)[0].reshape(N, L4)
             ctx.close()
             for v in (1, 2, 3):
                 assert err(got, ref, v) <= 1e-9, (name, tf, v, err(got, ref, v))
+            if order == 2:
+                # obtg_ctx_set_ang_rate_order(2): the near-stop vehicle's row recomputed in double-double -- EVERY element of every
+                # vehicle within 1e-11 of the exact rational value (element-wise where the value is not tiny, scale-aware below
+                # that); its distance from the reference is then the reference's own error
+                for v in range(N):
+                    fin = np.isfinite(exact[v])
+                    assert (np.isfinite(got[v]) == fin).all()
+                    el = np.abs(got[v][fin] - exact[v][fin]) / np.maximum(np.abs(exact[v][fin]), 1e-6 * np.abs(exact[v][fin]).max())
+                    assert el.max() <= 1e-11, (tf, v, el.max())
+                assert err(got, exact, 0) <= 1e-13 and abs(err(got, ref, 0) - err(ref, exact, 0)) <= 1e-11
             e_ref, e_exact = err(got, ref, 0), err(got, exact, 0)
             report.append("tf %g %s: near-stop vehicle %.2e from the reference, %.2e from the exact value "
                           "(the reference: %.2e from exact)" % (tf, name, e_ref, e_exact, err(ref, exact, 0)))
@@ -1087,8 +1097,9 @@ def test_near_stop_angular_rate_on_device(capi, oracle, golden_dir, capsys):
 # achieved bounds on the near-stop vehicle (scale-aware, per vehicle): [default order, reference order]
 # measured on MI355X (round 3): default order 3.1e-10 / 5.2e-10 from the exact value at tf = 10 / 14.3 (the reference
 # itself: 3.0e-9 / 7.2e-10), reference order 1.6e-9 / 3.1e-9; against the reference 3.4e-9 / 2.1e-10 and 4.6e-9 / 2.4e-9
-NEAR_STOP_BOUND_EXACT = (2e-9, 1e-8)
-NEAR_STOP_BOUND_REF = (1e-8, 1e-8)
+# exact order (round 4): within 1e-13 of the exact value; from the reference then by the reference's own error (3.1e-9 / 7.3e-10)
+NEAR_STOP_BOUND_EXACT = (2e-9, 1e-8, 1e-13)
+NEAR_STOP_BOUND_REF = (1e-8, 1e-8, 4e-9)
 
 
 def test_ang_rate_with_elevation_both_orders(capi, oracle, synth, golden_dir):
