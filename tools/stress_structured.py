@@ -35,10 +35,15 @@ def main():
         if only >= 0 and trial != only:
             continue
         Y = synth.swarm_control_points(N, 2, n, seed=5000 + trial)
-        ctx = capi.Context(N, 2, n, R)
+        n_obs = int(rng.integers(0, 4)) if trial % 4 == 3 else 0            # pointObstacles (optimization.py:86-98)
+        pobs = 10.0 + 80.0 * rng.random((n_obs, 2)) if n_obs else None
+        ctx = capi.Context(N, 2, n, R, point_obs=pobs)
         ctx.set_stream(torch.cuda.current_stream().cuda_stream)
         pa, pb = synth.swarm_pairs(N, M)
-        ctx.set_polygons(*(synth.pack_polys(synth.polygon_obstacles(M, seed=trial)) if M else (None, [0])))
+        # (hull objects of the planar sweeps hold at most n + 1 points: larger polygons take the general gjkNew kernels,
+        # brute force and structured step alike -- tools/stress_sweeps.py clips the same way)
+        polys = [q[:min(len(q), n + 1)] for q in synth.polygon_obstacles(M, seed=trial)] if M else []
+        ctx.set_polygons(*(synth.pack_polys(polys) if M else (None, [0])))
         ctx.set_hull_pairs(pa, pb)
         d0, dtf = torch.from_numpy(Y).cuda(), torch.from_numpy(tf).cuda()
         P, L, Ps = ctx.num_pairs, 2 * n + R + 1, len(pa)
@@ -52,7 +57,7 @@ def main():
                         st=torch.full((B, Ps), -7, dtype=i32, device="cuda"), sp=nan(B, ctx.len_speed), an=nan(B, ctx.len_ang_rate))
         a, b = bufs(), bufs()
         h = 1e-3
-        what = "N=%d n=%d R=%d M=%d fixed=%d B=%d tf kind %d" % (N, n, R, M, fixed, B, kind)
+        what = "N=%d n=%d R=%d M=%d obs=%d fixed=%d B=%d tf kind %d" % (N, n, R, M, n_obs, fixed, B, kind)
         try:
             ctx.constraint_sweep_fd_structured_dev(d0.data_ptr(), fixed, h, dtf.data_ptr(), B, 0.9, b["sep"].data_ptr(), 4.0, True, 1.5,
                                                    b["sp"].data_ptr(), b["an"].data_ptr(), b["flag"].data_ptr(), b["p1"].data_ptr(),
