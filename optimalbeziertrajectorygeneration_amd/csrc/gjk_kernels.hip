@@ -3161,7 +3161,12 @@ int launch_step_fd_structured(obtg_ctx* c, int B, double max_sep, double* d_out_
     sp.n_sep_groups = (c->n_pairs + kWave - 1) / kWave;
     // (a large step -- C4: 58 GB of separation rows -- gets more, so that a stream stays near 4 MB)
     const double sep_stream_bytes = 8.0 * kWave * LR * (double)B * sp.n_sep_groups;
-    int s_target = (int)std::min(32768.0, std::max(2048.0, sep_stream_bytes / (4 << 20)));
+    // (small batches -- a rank's share of a row-sharded iteration -- get fewer, longer streams: every S workgroup repeats row
+    // 0's products for its group and every G workgroup its gjkNew chunk, and 2048 + 1024 of them are three rounds of resident
+    // workgroups for a few rows each.  C3, tools/r04_struct_small_batch_scan.sh: B = 145 0.044 -> 0.027 ms with 512 / 384
+    // workgroups, B = 289 0.055 -> 0.040 with 1024 / 512; from B = 577 on the old numbers are the best)
+    const double s_floor = std::min(2048.0, std::max(256.0, 3.5 * B));
+    int s_target = (int)std::min(32768.0, std::max(s_floor, sep_stream_bytes / (4 << 20)));
     if (const char* e = getenv("OBTG_STRUCT_SEP_WGS")) s_target = std::max(1, atoi(e));      // (experiments)
     int s_ranges = std::max(1, std::min(B, s_target / std::max(1, sp.n_sep_groups)));
     sp.sep_rows_per = (B + s_ranges - 1) / s_ranges;
@@ -3169,7 +3174,8 @@ int launch_step_fd_structured(obtg_ctx* c, int B, double max_sep, double* d_out_
     // G: chunks of ~80 hull pairs (one short gjkNew phase per workgroup), row ranges for ~512 workgroups
     sp.gjk_chunk_pairs = 16 * (size_t)n_obj * vpq > 40 * 1024 ? 64 : 80;       // (large rows: the chunk's results behind 70 KB of hulls stay under 80 KB)
     if (const char* e = getenv("OBTG_STRUCT_GJK_CHUNK")) sp.gjk_chunk_pairs = std::max(16, atoi(e));
-    static const int g_target = getenv("OBTG_STRUCT_GJK_WGS") ? std::max(1, atoi(getenv("OBTG_STRUCT_GJK_WGS"))) : 1024;
+    const int g_target = getenv("OBTG_STRUCT_GJK_WGS") ? std::max(1, atoi(getenv("OBTG_STRUCT_GJK_WGS")))
+                                                       : (int)std::min(1024.0, std::max(192.0, 2.6 * B));
     sp.gjk_chunks = (c->n_hull_pairs + sp.gjk_chunk_pairs - 1) / sp.gjk_chunk_pairs;
     const int g_target_b = (int)std::min(32768.0, std::max((double)g_target, 68.0 * c->n_hull_pairs * (double)B / (4 << 20)));
     int g_ranges = std::max(1, std::min(B, g_target_b / std::max(1, sp.gjk_chunks)));

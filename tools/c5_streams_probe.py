@@ -38,7 +38,14 @@ def two_streams():
     a.pair_sweep_dev(None, B, 0.9, sep.data_ptr(), flag.data_ptr(), p1.data_ptr(), p2.data_ptr(), dist.data_ptr(), None, st_.data_ptr(), 128, 256)
     a.fd_view_end(); b.fd_view_end()
 
-for name, fn in (("one stream", one_stream), ("two streams", two_streams), ("one stream", one_stream), ("two streams", two_streams)):
+def gjk_beside():            # round 4: the gjkNew sweep on one stream, separation rows + dynamics groups on the other
+    a.fd_view_begin(d0.data_ptr(), 1, synth.FD_STEP, B); b.fd_view_begin(d0.data_ptr(), 1, synth.FD_STEP, B)
+    a.gjk_swarm_dev(None, B, flag.data_ptr(), p1.data_ptr(), p2.data_ptr(), dist.data_ptr(), None, st_.data_ptr(), 128, 256)
+    b.temporal_sep_dev(None, B, 0.9, sep.data_ptr())
+    b.dynamics_dev(None, dtf.data_ptr(), B, 5.0, True, 1.0, sp.data_ptr(), an.data_ptr())
+    a.fd_view_end(); b.fd_view_end()
+
+for name, fn in (("one stream", one_stream), ("two streams", two_streams), ("gjk beside", gjk_beside), ("one stream", one_stream), ("two streams", two_streams), ("gjk beside", gjk_beside)):
     for _ in range(150):
         fn()
     torch.cuda.synchronize()
