@@ -1,4 +1,5 @@
 #!/bin/bash
+# (the one-launch DEG_ELEV > 0 step of profiles/r04_experiments/step_elev_one_launch_mfma.patch must be applied: OBTG_STEP_ELEV_PER16 exists only there)
 mkdir -p gpurun_out; out=gpurun_out/r04_step_elev_scan.txt; : > $out
 for sh in default 4,2,10 6,2,8 7,3,6 8,3,5 3,2,11 5,3,8; do
   if [ $sh = default ]; then unset OBTG_STEP_ELEV_PER16; else export OBTG_STEP_ELEV_PER16=$sh; fi
