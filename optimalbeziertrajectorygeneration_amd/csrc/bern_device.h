@@ -536,6 +536,14 @@ __device__ __forceinline__ void tsep_elev_group_stream(const TsepXYParams& t, co
     double* tile = tiles + wave * (16 * cw_max);
     constexpr int kMaxV = E::CW / 4;                                 // 16 x CW doubles over 64 lanes
     const int prow0 = itg + 16 * wave;
+    // the 16 rows' pairs as (i | j << 16), ONE load per lane, looked up from LDS below (as `t.pairs[row of element i]` inside
+    // the per-element branch the compiler issued 31 loads one after the other, each with its own wait: 15 us per workgroup)
+    __shared__ unsigned s_rowpair[4][16];
+    if (lane < 16) {
+        const int2 ij = t.pairs[min(prow0 + lane, t.n_pairs - 1)];
+        s_rowpair[wave][lane] = (unsigned)ij.x | ((unsigned)ij.y << 16);
+    }
+    wave_sync();
     for (int t0 = 0; t0 < NT; t0 += E::NTG) {
         const int c0 = 16 * t0, cw = min(LR - c0, E::CW);
         double bfr[E::NTG][E::KS];
@@ -553,8 +561,7 @@ __device__ __forceinline__ void tsep_elev_group_stream(const TsepXYParams& t, co
             v[i] = 0.0; pr[i] = -1; off[i] = 0;
             if (e < n_el) {
                 const int q = e / cw, kc = e - q * cw;
-                const int2 ij = t.pairs[prow0 + q];
-                pr[i] = ij.x | (ij.y << 16);
+                pr[i] = (int)s_rowpair[wave][q];
                 off[i] = q * LR + c0 + kc;
                 v[i] = tile[e];
             }

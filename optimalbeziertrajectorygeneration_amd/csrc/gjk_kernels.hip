@@ -1134,9 +1134,12 @@ __global__ __launch_bounds__(256, WPC) void k_step_fd_structured(const Structure
         // and has read it by the time it writes the tile (one wave's LDS accesses complete in order)
         double* tile = lds;
         __shared__ int s_nv;
+        __shared__ unsigned s_gpair[kWave];                          // the group's pairs, i | j << 16: one load per lane, looked up below
         if (threadIdx.x < kWave) {
             const int nv = tsep_group_to_tile<NC>(p.ts, xy_dyn, VPQ, g, tile);
             if (threadIdx.x == 0) s_nv = nv;
+            const int2 ij = p.ts.pairs[min(g * kWave + (int)threadIdx.x, p.ts.n_pairs - 1)];
+            s_gpair[threadIdx.x] = (unsigned)ij.x | ((unsigned)ij.y << 16);
         }
         __syncthreads();
         const int n_el = s_nv * L;                                   // doubles in the run
@@ -1147,8 +1150,8 @@ __global__ __launch_bounds__(256, WPC) void k_step_fd_structured(const Structure
         for (int s = 0; s < kSlots; ++s) {
             const int m = (int)threadIdx.x + 256 * s, e0 = 2 * m, e1 = e0 + 1;
             v0[s] = v1[s] = 0.0; pr0[s] = pr1[s] = -1;
-            if (e0 < n_el) { const int2 ij = p.ts.pairs[g * kWave + e0 / L]; pr0[s] = ij.x | (ij.y << 16); v0[s] = tile[e0]; }
-            if (e1 < n_el) { const int2 ij = p.ts.pairs[g * kWave + e1 / L]; pr1[s] = ij.x | (ij.y << 16); v1[s] = tile[e1]; }
+            if (e0 < n_el) { pr0[s] = (int)s_gpair[e0 / L]; v0[s] = tile[e0]; }
+            if (e1 < n_el) { pr1[s] = (int)s_gpair[e1 / L]; v1[s] = tile[e1]; }
         }
         const int b0 = r * sp.sep_rows_per, b1 = min(p.B, b0 + sp.sep_rows_per);
         for (int b = b0; b < b1; ++b) {
