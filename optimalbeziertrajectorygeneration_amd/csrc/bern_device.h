@@ -256,7 +256,11 @@ __device__ __forceinline__ v4d_t elev_mfma_tile(const double (&afr)[ElevMfma<LIN
     v4d_t acc;
     acc[0] = offset; acc[1] = offset; acc[2] = offset; acc[3] = offset;
 #pragma unroll
+#ifdef OBTG_EXP_MFMA_STEPS
+    for (int s = 0; s < (E::KS < OBTG_EXP_MFMA_STEPS ? E::KS : OBTG_EXP_MFMA_STEPS); ++s) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(afr[s], bfr[s], acc, 0, 0, 0);
+#else
     for (int s = 0; s < E::KS; ++s) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(afr[s], bfr[s], acc, 0, 0, 0);
+#endif
     return acc;
 }
 
