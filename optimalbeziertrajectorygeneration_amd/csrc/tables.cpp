@@ -27,7 +27,8 @@ std::vector<double> binom_row(int n)
 // Equal-degree product weights w(k,j) = C(n,j) C(n,k-j) / C(2n,k) (bezier.py:1183-1208),
 // folded over the symmetry (j, k-j) <-> (k-j, j) and pre-multiplied by the reference's
 // normSquare factor dim/2 (bezier.py:884, 1744-1756).  Layout [2n+1][n+1]; only entries with
-// max(0,k-n) <= j <= k/2 are non-zero:  W2[k][j] = (dim/2) * w(k,j) * (2 if j != k-j else 1).
+// max(0,k-n) <= j <= k/2 are non-zero:  W2[k][j] = (dim/2) * w(k,j) * (2 if j != k-j else 1).  Behind them the separable
+// form of the same weights: C(n, .)[n+1], then S[2n+1].
 std::vector<double> folded_product_weights(int n, int dim)
 {
     int L = 2 * n + 1, nc = n + 1;
@@ -40,6 +41,9 @@ std::vector<double> folded_product_weights(int n, int dim)
             W[(size_t)k * nc + j] = w * (0.5 * dim);
         }
     }
+    // the separable form of the same weights (bern_device.h normsq_coeffs): C(n, j), then S_k = (dim/2) / C(2n, k), doubled for odd k
+    for (int j = 0; j < nc; ++j) W.push_back(binom(n, j));
+    for (int k = 0; k < L; ++k) W.push_back(((k & 1) ? 1.0 : 0.5) * dim / binom(2 * n, k));
     return W;
 }
 
