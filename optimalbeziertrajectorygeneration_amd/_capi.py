@@ -6,6 +6,7 @@ raises `RuntimeError` when the library is missing or no gfx950 device is usable.
 """
 import ctypes as C
 import os
+import threading
 import weakref
 
 import numpy as np
@@ -186,26 +187,31 @@ class _PinnedPool(object):
         if cap is None:
             cap = int(os.environ.get("OBTG_PINNED_CACHE_MB", "1024")) << 20
         self.cap, self.cached, self.free = cap, 0, {}
+        self._lock = threading.RLock()       # callers on several threads; re-entrant: a finaliser may run inside empty()
 
     def trim(self, keep_bytes=0):
         """Free cached blocks (largest first) until at most keep_bytes stay cached; returns the bytes released."""
         released = 0
-        for size in sorted(self.free, reverse=True):
-            blocks = self.free[size]
-            while blocks and self.cached > keep_bytes:
-                ptr = blocks.pop()
-                self.cached -= size
-                released += size
-                if _lib is not None:
-                    _lib.obtg_host_free(_vp(ptr))
-        self.free = {k: v for k, v in self.free.items() if v}
+        with self._lock:
+            for size in sorted(self.free, reverse=True):
+                blocks = self.free[size]
+                while blocks and self.cached > keep_bytes:
+                    ptr = blocks.pop()
+                    self.cached -= size
+                    released += size
+                    if _lib is not None:
+                        _lib.obtg_host_free(_vp(ptr))
+            for size in [k for k, v in self.free.items() if not v]:
+                del self.free[size]
         return released
 
     def _release(self, size, ptr):
-        if self.cached + size <= self.cap:
-            self.free.setdefault(size, []).append(ptr)
-            self.cached += size
-        elif _lib is not None:
+        with self._lock:
+            if self.cached + size <= self.cap:
+                self.free.setdefault(size, []).append(ptr)
+                self.cached += size
+                return
+        if _lib is not None:
             _lib.obtg_host_free(_vp(ptr))
 
     def empty(self, shape, dtype=np.float64):
@@ -217,11 +223,13 @@ class _PinnedPool(object):
         size = 1 << (nbytes - 1).bit_length()
         if size > (1 << 28):                      # above 256 MB: 64 MB granularity instead of powers of two
             size = -(-nbytes // (64 << 20)) * (64 << 20)
-        blocks = self.free.get(size)
-        if blocks:
-            ptr = blocks.pop()
-            self.cached -= size
-        else:
+        ptr = None
+        with self._lock:
+            blocks = self.free.get(size)
+            if blocks:
+                ptr = blocks.pop()
+                self.cached -= size
+        if ptr is None:
             h = _vp()
             if load().obtg_host_alloc(size, C.byref(h)) != OK or not h.value:
                 return np.empty(shape, dtype)     # no pinned memory left: a pageable array still works (staged)

@@ -1716,3 +1716,52 @@ def test_c1_as_baseline_text_has_it(capi, golden_dir):
     ctx.close()
 
 
+
+
+def test_two_contexts_from_two_threads(capi, synth):
+    """The library keeps its state in the context (no mutable globals on the compute path): two host threads, each with its
+    own context on that context's own stream, calling the host-buffer entry points and the one-launch sweep at the same time
+    (ctypes drops the GIL inside a call) get, call for call, the bits a single thread gets."""
+    import threading
+    shapes = ((24, 2, 10, 0, 3), (10, 2, 7, 4, 2))                     # (N, dim, n, DEG_ELEV, polygons)
+
+    def work(shape, reps, out):
+        N, d, n, R, M = shape
+        Y = synth.swarm_control_points(N, d, n, seed=3 + N)
+        Yb = synth.fd_batch(Y, B=17)
+        tf = np.linspace(2.0, 9.0, Yb.shape[0])
+        polys = synth.polygon_obstacles(M, seed=N)
+        pa, pb = synth.swarm_pairs(N, M)
+        ctx = capi.Context(N, d, n, R)
+        ctx.set_polygons(*synth.pack_polys(polys))
+        ctx.set_hull_pairs(pa, pb)
+        for _ in range(reps):
+            sep = ctx.temporal_sep(Yb, 0.9)
+            sp = ctx.speed(Yb, tf, 5.0, True)
+            an = ctx.ang_rate(Yb, tf, 1.0)
+            g = ctx.gjk_swarm(Yb, md_cap=500)
+            out.append((sep.copy(), sp.copy(), an.copy(), g["flag"].copy(), g["dist"].copy()))
+        ctx.close()
+
+    alone = [[], []]
+    for i, s in enumerate(shapes):
+        work(s, 1, alone[i])
+    together = [[], []]
+    errors = []
+
+    def guarded(i):
+        try:
+            work(shapes[i], 12, together[i])
+        except Exception as e:                                          # noqa: BLE001 -- reported by the assert below
+            errors.append(repr(e))
+    threads = [threading.Thread(target=guarded, args=(i,)) for i in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    for i in range(2):
+        assert len(together[i]) == 12
+        for got in together[i]:
+            for a, b in zip(got, alone[i][0]):
+                assert np.array_equal(a, b, equal_nan=True)
