@@ -1765,3 +1765,45 @@ def test_two_contexts_from_two_threads(capi, synth):
         for got in together[i]:
             for a, b in zip(got, alone[i][0]):
                 assert np.array_equal(a, b, equal_nan=True)
+
+
+def test_context_lifecycle_returns_its_device_memory(capi, synth):
+    """obtg_ctx_destroy gives back everything a context allocated on the device -- tables, pair lists, polygon and hull
+    buffers, staging areas, the FD view, streams and events: 60 create / use / destroy cycles over three shapes (every
+    family called, DEG_ELEV switched, an FD view opened) leave the device's free memory where it was."""
+    import torch
+    capi.pinned_trim()
+    torch.cuda.synchronize()
+
+    def cycle(k):
+        N, d, n, R, M = ((16, 2, 10, 0, 3), (9, 2, 7, 5, 2), (8, 3, 5, 0, 2))[k % 3]
+        Y = synth.swarm_control_points(N, d, n, seed=k)
+        Yb = synth.fd_batch(Y, B=9)
+        tf = np.linspace(2.0, 6.0, 9)
+        ctx = capi.Context(N, d, n, R)
+        if d == 2:
+            ctx.set_polygons(*synth.pack_polys(synth.polygon_obstacles(M, seed=k)))
+        else:
+            M = 0
+            ctx.set_polygons(None, [0])
+        ctx.set_hull_pairs(*synth.swarm_pairs(N, M))
+        ctx.temporal_sep(Yb, 0.9)
+        ctx.speed(Yb, tf, 5.0, True)
+        if d == 2:
+            ctx.ang_rate(Yb, tf, 1.0)
+        ctx.gjk_swarm(Yb, md_cap=300)
+        ctx.set_deg_elev(R + 2)
+        ctx.temporal_sep_min(Yb, 0.9)
+        ctx.close()
+
+    for k in range(6):                          # warm-up: the runtime's own pools, code objects, torch's context
+        cycle(k)
+    capi.pinned_trim()
+    torch.cuda.synchronize()
+    free0, _ = torch.cuda.mem_get_info()
+    for k in range(60):
+        cycle(k)
+    capi.pinned_trim()
+    torch.cuda.synchronize()
+    free1, _ = torch.cuda.mem_get_info()
+    assert free0 - free1 < (8 << 20), "device memory not returned: %.1f MiB after 60 contexts" % ((free0 - free1) / 2.0 ** 20)
