@@ -217,6 +217,10 @@ __device__ __forceinline__ void flush_chunk(const double* __restrict__ tile, dou
     }
 }
 
+// Keep a value that came from memory in its register, waited for HERE: a load left pending across a loop's back edge makes
+// the first use in every iteration an s_waitcnt vmcnt(0) -- which also waits for every store the wave has issued.
+__device__ __forceinline__ void pin_reg(double& x) { asm volatile("" : "+v"(x)); }
+
 constexpr int kElevBlock = 8;          // zero entries behind the padded binomial rows of tables.cpp elev_conv_padded
 
 // ---- degree elevation as a matrix product on v_mfma_f64_16x16x4_f64 ------------------------------------------------
@@ -523,128 +527,191 @@ __device__ __forceinline__ void tsep_rows_of_vehicle(const TsepXYParams& t, cons
     }
 }
 
-// Structured finite-difference step with DEG_ELEV = R > 0 (gjk_kernels.hip k_step_fd_structured<NC, true>), row 0's part:
-// the workgroup (four waves) evaluates the 64-pair group g of the staged row -- wave 0 the products, as the coefficient
-// image of elev_rows_mfma; then wave w the elevation of rows 16 w .. 16 w + 15 on the matrix instruction, exactly as
-// normsq_elev_body's full-row form does -- and streams its 16 rows from the output tile, through registers, into every
-// batch row b0 <= b < b1, leaving out the rows of pairs that contain batch row b's own vehicle (fd_element).
-// img: [64][PA] doubles of LDS; tiles: 4 x 16 x min(LR, CW) doubles that MAY overlay img and everything before it (the
-// staged row is dead once the products exist, the image once every wave holds its fragments): two workgroup barriers.
-template <int NC>
-__device__ __forceinline__ void tsep_elev_group_stream(const TsepXYParams& t, const double2* xy, const int vpq, const int g,
-                                                       double* img, double* tiles, const int b0, const int b1,
-                                                       const int fd, const int fd_fixed)
+// ---- Structured finite-difference step with DEG_ELEV = R > 0 (gjk_kernels.hip k_step_fd_structured<NC, true>) -----------------
+// Both kinds that write separation rows (S: row 0's groups streamed into row ranges; F: a perturbed row's own pairs) form
+// their elevated rows as sep_elev_coop_body does: the workgroup's four waves share each 16-row tile, wave w owning column
+// tiles w and w + 4 of the 128-column group with its B fragments stationary in 2 KS registers, accumulators -> an LDS tile
+// [16][cw].  (Round 3/4's form -- one wave per 16-row tile with all eight column tiles' fragments, 32 elements per lane of
+// the tile kept in registers with row and pair of each -- needed 250 VGPRs and spilled: two workgroups per CU for the whole
+// launch, and 8-byte stores.  This one stays below the dynamics groups' 168.)
+template <int L>
+__device__ __forceinline__ void coop_load_bfrag(const double* __restrict__ Tf, const int NT, const int cg, const int wave, const int lane,
+                                                double (&bfr)[2][ElevMfma<L>::KS])
 {
-    using S = NsShape<NC, 2>;
-    constexpr int L = S::L;
     using E = ElevMfma<L>;
-    const int LR = L + t.R;
-    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
-    const int itg = g * kWave;
-    const int n_valid = min(kWave, t.n_pairs - itg);
-    if (wave == 0) {
-        const int item = min(itg + lane, t.n_pairs - 1);
-        const int2 ij = t.pairs[item];
-        const double2* vi = xy + ij.x * vpq;
-        const double2* vj = xy + ij.y * vpq;
-        double a[2][NC];
 #pragma unroll
-        for (int c = 0; c < NC; ++c) {
-            const double2 pi = vi[c], pj = vj[c];
-            a[0][c] = pi.x - pj.x;
-            a[1][c] = pi.y - pj.y;
-        }
-        double cf[L];
-        normsq_coeffs<NC, 2>(a, as_ctab(t.W2), cf);
+    for (int i = 0; i < 2; ++i) {
+        const double* f = Tf + (size_t)min(8 * cg + wave + 4 * i, NT - 1) * (E::KS * kWave);
 #pragma unroll
-        for (int j = 0; j < L; ++j) cf[j] *= t.sign;
-        if (lane < n_valid) elev_store_image_row<L>(img, lane, cf);
+        for (int sx = 0; sx < E::KS; ++sx) bfr[i][sx] = f[sx * kWave + lane];
     }
-    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int sx = 0; sx < E::KS; ++sx) pin_reg(bfr[i][sx]);
+}
+
+// rows 16 m .. 16 m + 15 of the coefficient image x column group cg -> tile [16][cw] (this wave's two column tiles of it)
+template <int L>
+__device__ __forceinline__ void coop_tile(const double* img, const int m, const double (&bfr)[2][ElevMfma<L>::KS], const double offset,
+                                          double* tile, const int cw, const int cg, const int NT, const int wave, const int lane)
+{
+    using E = ElevMfma<L>;
     double afr[E::KS];
-    elev_load_afrag<L>(img, wave, lane, afr);
-    __syncthreads();
-    const int rows = min(16, n_valid - 16 * wave);                  // wave-uniform
-    if (rows <= 0) return;
-    const int NT = (LR + 15) >> 4;
-    const int cw_max = min(LR, E::CW);
-    double* tile = tiles + wave * (16 * cw_max);
-    constexpr int kMaxV = E::CW / 4;                                 // 16 x CW doubles over 64 lanes
-    const int prow0 = itg + 16 * wave;
-    // the 16 rows' pairs as (i | j << 16), ONE load per lane, looked up from LDS below (as `t.pairs[row of element i]` inside
-    // the per-element branch the compiler issued 31 loads one after the other, each with its own wait: 15 us per workgroup)
-    __shared__ unsigned s_rowpair[4][16];
-    if (lane < 16) {
-        const int2 ij = t.pairs[min(prow0 + lane, t.n_pairs - 1)];
-        s_rowpair[wave][lane] = (unsigned)ij.x | ((unsigned)ij.y << 16);
-    }
-    wave_sync();
-    for (int t0 = 0; t0 < NT; t0 += E::NTG) {
-        const int c0 = 16 * t0, cw = min(LR - c0, E::CW);
-        double bfr[E::NTG][E::KS];
-        elev_load_bfrag<L>(t.Tf, t0, NT, lane, bfr);
+    elev_load_afrag<L>(img, m, lane, afr);
 #pragma unroll
-        for (int tt = 0; tt < E::NTG; ++tt) elev_acc_to_tile(elev_mfma_tile<L>(afr, bfr[tt], t.offset), tt, tile, cw, lane);
-        wave_sync();
-        // element e = lane + 64 i of the tile's rows x cw run: value, its (row, column) and its pair, kept in registers
-        const int n_el = rows * cw;
-        double v[kMaxV];
-        int pr[kMaxV], off[kMaxV];
-#pragma unroll
-        for (int i = 0; i < kMaxV; ++i) {
-            const int e = lane + kWave * i;
-            v[i] = 0.0; pr[i] = -1; off[i] = 0;
-            if (e < n_el) {
-                const int q = e / cw, kc = e - q * cw;
-                pr[i] = (int)s_rowpair[wave][q];
-                off[i] = q * LR + c0 + kc;
-                v[i] = tile[e];
-            }
-        }
-        for (int b = b0; b < b1; ++b) {
-            const int fd_e = fd_element(fd, fd_fixed, NC, b);
-            const int vb = fd_e >= 0 ? fd_e / (2 * NC) : -1;
-            double* gp = t.out + ((size_t)b * t.n_pairs + (size_t)prow0) * LR;
-#pragma unroll
-            for (int i = 0; i < kMaxV; ++i) {
-                // (a pair of row b's own vehicle: its workgroup writes it)
-                if (pr[i] >= 0 && (pr[i] & 0xffff) != vb && (pr[i] >> 16) != vb) gp[off[i]] = v[i];
-            }
-        }
-        wave_sync();
+    for (int i = 0; i < 2; ++i) {
+        const int tl = wave + 4 * i;
+        if (8 * cg + tl < NT) elev_acc_to_tile(elev_mfma_tile<L>(afr, bfr[i], offset), tl, tile, cw, lane);
     }
 }
 
-// ... and a perturbed row's part with DEG_ELEV > 0: the elevated separation rows of every pair that contains vehicle v of
-// row b, one pair per lane, each lane its own run (elev_at: the chain of the matrix instruction, hence the batch's bits).
+// product coefficients (sign applied) of the pair of objects at LDS slots si, sj -> row r of the coefficient image
+template <int NC>
+__device__ __forceinline__ void tsep_image_row(const TsepXYParams& t, const double2* xy, const int vpq, const int si, const int sj,
+                                               double* img, const int r)
+{
+    constexpr int L = 2 * NC - 1;
+    const double2* vi = xy + si * vpq;
+    const double2* vj = xy + sj * vpq;
+    double a[2][NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        const double2 pi = vi[c], pj = vj[c];
+        a[0][c] = pi.x - pj.x;
+        a[1][c] = pi.y - pj.y;
+    }
+    double cf[L];
+    normsq_coeffs<NC, 2>(a, as_ctab(t.W2), cf);
+#pragma unroll
+    for (int j = 0; j < L; ++j) cf[j] *= t.sign;
+    elev_store_image_row<L>(img, r, cf);
+}
+
+// S: the 64-pair group g of the staged row, elevated tile by tile and streamed from registers (16-byte pieces, 256 threads:
+// four pieces each per tile) into every batch row b0 <= b < b1, leaving out the rows of pairs that contain batch row b's own
+// vehicle (fd_element) -- those are the F workgroups'.  img: [64][PA], tile: [16][min(LR, 128)] doubles of LDS, disjoint.
+template <int NC>
+__device__ __forceinline__ void tsep_elev_group_stream(const TsepXYParams& t, const double2* xy, const int vpq, const int g,
+                                                       double* img, double* tile, const int b0, const int b1,
+                                                       const int fd, const int fd_fixed)
+{
+    constexpr int L = 2 * NC - 1;
+    using E = ElevMfma<L>;
+    const int LR = L + t.R, NT = (LR + 15) >> 4;
+    const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int itg = g * kWave;
+    const int n_valid = min(kWave, t.n_pairs - itg);
+    __shared__ unsigned s_rowpair[kWave];                              // the group's pairs, i | j << 16 (0xffffffff: no such row)
+    if (wave == 0) {
+        const int2 ij = t.pairs[min(itg + lane, t.n_pairs - 1)];      // (lanes beyond the last pair: a valid pair, never streamed)
+        tsep_image_row<NC>(t, xy, vpq, ij.x, ij.y, img, lane);
+        s_rowpair[lane] = lane < n_valid ? ((unsigned)ij.x | ((unsigned)ij.y << 16)) : 0xffffffffu;
+    }
+    __syncthreads();
+    const int n_tiles = (n_valid + 15) >> 4;
+    constexpr int kSlots = 4;                                          // 16 x 128 doubles = 1024 pieces over 256 threads
+    for (int cg = 0; 8 * cg < NT; ++cg) {
+        const int c0 = 128 * cg, cw = min(LR - c0, 128);
+        double bfr[2][E::KS];
+        coop_load_bfrag<L>(t.Tf, NT, cg, wave, lane, bfr);            // (waited for here: no load is pending while the stores stream)
+        for (int m = 0; m < n_tiles; ++m) {
+            const int rows = min(16, n_valid - 16 * m);
+            coop_tile<L>(img, m, bfr, t.offset, tile, cw, cg, NT, wave, lane);
+            __syncthreads();
+            const int n_el = rows * cw;
+            double v0[kSlots], v1[kSlots];
+            int off0[kSlots], off1[kSlots], pr0[kSlots], pr1[kSlots];  // offsets in the batch row's run; (i | j << 16) of each element's pair, -1: none
+#pragma unroll
+            for (int sx = 0; sx < kSlots; ++sx) {
+                const int e0 = 2 * (tid + 256 * sx), e1 = e0 + 1;
+                v0[sx] = v1[sx] = 0.0; pr0[sx] = pr1[sx] = -1; off0[sx] = off1[sx] = 0;
+                if (e0 < n_el) { const int q = e0 / cw; off0[sx] = q * LR + c0 + (e0 - q * cw); pr0[sx] = (int)s_rowpair[16 * m + q]; v0[sx] = tile[e0]; }
+                if (e1 < n_el) { const int q = e1 / cw; off1[sx] = q * LR + c0 + (e1 - q * cw); pr1[sx] = (int)s_rowpair[16 * m + q]; v1[sx] = tile[e1]; }
+            }
+            __syncthreads();                                          // the tile is free for the next one
+            const unsigned myp = s_rowpair[16 * m + (lane & 15)];     // the tile's 16 pairs, for the test "does row b touch this tile at all"
+            const size_t prow0 = (size_t)itg + 16 * m;
+            for (int b = b0; b < b1; ++b) {
+                const int fd_e = fd_element(fd, fd_fixed, NC, b);
+                const int vb = fd_e >= 0 ? fd_e / (2 * NC) : -1;
+                const size_t ob = ((size_t)b * t.n_pairs + prow0) * LR;
+                double* gp = t.out + ob;
+                const int odd = (int)(ob & 1);
+                const bool touched = __builtin_amdgcn_ballot_w64((int)(myp & 0xffffu) == vb || (int)(myp >> 16) == vb) != 0;
+                if (!touched) {
+#pragma unroll
+                    for (int sx = 0; sx < kSlots; ++sx) {
+                        if (pr1[sx] >= 0 && off1[sx] == off0[sx] + 1 && ((off0[sx] ^ odd) & 1) == 0) store_nt2(gp + off0[sx], v0[sx], v1[sx]);
+                        else {
+                            if (pr0[sx] >= 0) store_nt(gp + off0[sx], v0[sx]);
+                            if (pr1[sx] >= 0) store_nt(gp + off1[sx], v1[sx]);
+                        }
+                    }
+                } else {
+#pragma unroll
+                    for (int sx = 0; sx < kSlots; ++sx) {
+                        const bool w0 = pr0[sx] >= 0 && (pr0[sx] & 0xffff) != vb && (pr0[sx] >> 16) != vb;
+                        const bool w1 = pr1[sx] >= 0 && (pr1[sx] & 0xffff) != vb && (pr1[sx] >> 16) != vb;
+                        if (w0 && w1 && off1[sx] == off0[sx] + 1 && ((off0[sx] ^ odd) & 1) == 0) store_nt2(gp + off0[sx], v0[sx], v1[sx]);
+                        else {
+                            if (w0) store_nt(gp + off0[sx], v0[sx]);
+                            if (w1) store_nt(gp + off1[sx], v1[sx]);
+                        }
+                    }
+                }
+            }
+        }
+    }
+}
+
+// F: a perturbed row's part -- the elevated separation rows of every pair that contains vehicle v of batch row b, 32 pairs
+// to a pass (two tiles), every finished row one 16-byte-wide store instruction of one wave.  The chain per element is the
+// matrix instruction's, as in the batch kernels and in the S kind: the brute-force sweep's bits.
+// img: [32][PA], tile: [16][min(LR, 128)] doubles of LDS behind the staged row.
 template <int NC>
 __device__ __forceinline__ void tsep_elev_rows_of_vehicle(const TsepXYParams& t, const double2* xy, const int vpq, const int b,
-                                                          const int n_veh, const int v)
+                                                          const int n_veh, const int v, double* img, double* tile)
 {
-    using S = NsShape<NC, 2>;
-    constexpr int L = S::L;
-    const int LR = L + t.R;
-    const ctab_t Td = as_ctab(t.Td);
+    constexpr int L = 2 * NC - 1;
+    using E = ElevMfma<L>;
+    const int LR = L + t.R, NT = (LR + 15) >> 4;
+    const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n_to = t.n_tobj > 0 ? t.n_tobj : n_veh;
-    for (int u0 = threadIdx.x; u0 < n_to - 1; u0 += blockDim.x) {
-        const int u = u0 < v ? u0 : u0 + 1;
-        const int i = min(u, v), j = max(u, v);
-        const int q = i * (2 * n_to - i - 1) / 2 + (j - i - 1);
-        const double2* vi = xy + tsep_slot(t, i) * vpq;
-        const double2* vj = xy + tsep_slot(t, j) * vpq;
-        double a[2][NC];
-#pragma unroll
-        for (int c = 0; c < NC; ++c) {
-            const double2 pi = vi[c], pj = vj[c];
-            a[0][c] = pi.x - pj.x;
-            a[1][c] = pi.y - pj.y;
+    const int n_rows = n_to - 1;
+    __shared__ int s_q[32];                                            // position of the pass's pairs in the lexicographic pair list
+    for (int cg = 0; 8 * cg < NT; ++cg) {
+        const int c0 = 128 * cg, cw = min(LR - c0, 128);
+        double bfr[2][E::KS];
+        coop_load_bfrag<L>(t.Tf, NT, cg, wave, lane, bfr);
+        for (int u00 = 0; u00 < n_rows; u00 += 32) {
+            __syncthreads();                                          // the image and s_q of the previous pass have been read
+            if (tid < 32) {
+                const int u0 = min(u00 + tid, n_rows - 1);            // (lanes beyond the last pair: a valid pair, never stored)
+                const int u = u0 < v ? u0 : u0 + 1;
+                const int i = min(u, v), j = max(u, v);
+                s_q[tid] = i * (2 * n_to - i - 1) / 2 + (j - i - 1);
+                tsep_image_row<NC>(t, xy, vpq, tsep_slot(t, i), tsep_slot(t, j), img, tid);
+            }
+            __syncthreads();
+            const int n_pass = min(32, n_rows - u00);
+            for (int m = 0; 16 * m < n_pass; ++m) {
+                const int rows = min(16, n_pass - 16 * m);
+                coop_tile<L>(img, m, bfr, t.offset, tile, cw, cg, NT, wave, lane);
+                __syncthreads();
+                for (int r = wave; r < rows; r += 4) {
+                    const size_t o = ((size_t)b * t.n_pairs + (size_t)s_q[16 * m + r]) * LR + c0;
+                    const double* src = tile + r * cw;
+                    const int sh = (int)(o & 1);                      // make the 16-byte stores 16-byte aligned
+                    const int e0 = 2 * lane - sh, e1 = e0 + 1;        // (cw <= 128: 64 lanes x 2 cover cw + 1 elements)
+                    if (e0 >= 0 && e1 < cw) store_nt2(t.out + o + e0, src[e0], src[e1]);
+                    else if (e0 >= 0 && e0 < cw) store_nt(t.out + o + e0, src[e0]);
+                    else if (e0 < 0 && e1 < cw) store_nt(t.out + o + e1, src[e1]);
+                    if (sh && lane == 0 && cw == 128) store_nt(t.out + o + 127, src[127]);      // the one element 64 shifted pieces do not reach
+                }
+                __syncthreads();
+            }
         }
-        double cf[L];
-        normsq_coeffs<NC, 2>(a, as_ctab(t.W2), cf);
-#pragma unroll
-        for (int jj = 0; jj < L; ++jj) cf[jj] *= t.sign;
-        double* o = t.out + ((size_t)b * t.n_pairs + q) * LR;
-        for (int k = 0; k < LR; ++k) o[k] = elev_at<L>(cf, Td + k * L, t.offset);
     }
 }
 
@@ -910,9 +977,6 @@ __device__ __forceinline__ void store_run_wg(const double* __restrict__ tile, do
     }
 }
 
-// Keep a value that came from memory in its register, waited for HERE: a load left pending across a loop's back edge makes
-// the first use in every iteration an s_waitcnt vmcnt(0) -- which also waits for every store the wave has issued.
-__device__ __forceinline__ void pin_reg(double& x) { asm volatile("" : "+v"(x)); }
 
 // (b, w) = evaluation row and workgroup index inside the row, as normsq_elev_body; MODE 0 (pairs), every object of the row
 // staged (p.stage_all), 2n + R + 1 <= 64 NTW columns, object ids below 65536.  blockDim.x == 256.

@@ -988,7 +988,9 @@ struct StructuredParams {
 };
 
 // ELEV: DEG_ELEV > 0 -- the separation groups are elevated (tsep_elev_group_stream), the fix-up rows too, and the
-// dynamics groups are k_dynamics_elev's (four waves, 234 VGPRs: the launch then runs two workgroups per CU).
+// dynamics groups are k_dynamics_elev's.  Two workgroups per CU: the S, F and G kinds need 121 / 120 / 82 registers, but the
+// dynamics groups' row-mapped emission spills 80 dwords under the 168 of three per CU, and the launch is slower for it
+// (C5, one box, interleaved: 0.699 against 0.564 ms; round 3's form of the S and F kinds at two per CU: 0.73-0.79).
 // WPC: workgroups per CU the register budget is set for (4: rows of up to 40 KB of LDS; 1: large rows -- C4's 256 vehicles
 // of 16 points are 70 KB -- where LDS leaves room for one workgroup anyway and the streams dominate).
 template <int NC, bool ELEV, int WPC = (ELEV ? 2 : 4)>
@@ -1060,8 +1062,11 @@ __global__ __launch_bounds__(256, WPC) void k_step_fd_structured(const Structure
         }
         const int fd_e = fd_element(p.fd, p.fd_fixed, NC, b);
         if (fd_e >= 0) {
-            if (ELEV) tsep_elev_rows_of_vehicle<NC>(p.ts, xy_dyn, VPQ, b, p.n_veh, fd_e / (2 * NC));
-            else tsep_rows_of_vehicle<NC>(p.ts, xy_dyn, VPQ, b, p.n_veh, fd_e / (2 * NC));
+            if (ELEV) {
+                // coefficient image [32][PA] and output tile behind the staged objects (the body's records are dead)
+                double* img = reinterpret_cast<double*>(xy_dyn + (n_obj + p.n_obs) * VPQ);
+                tsep_elev_rows_of_vehicle<NC>(p.ts, xy_dyn, VPQ, b, p.n_veh, fd_e / (2 * NC), img, img + 32 * ElevMfma<L>::PA);
+            } else tsep_rows_of_vehicle<NC>(p.ts, xy_dyn, VPQ, b, p.n_veh, fd_e / (2 * NC));
         }
         return;
     }
@@ -1124,9 +1129,9 @@ __global__ __launch_bounds__(256, WPC) void k_step_fd_structured(const Structure
         }
         __syncthreads();
         if (ELEV) {
-            // the group's coefficient image behind the staged row; the waves' output tiles then take the place of both
+            // the group's coefficient image [64][PA] behind the staged row, the 16-row output tile behind that
             double* img = reinterpret_cast<double*>(xy_dyn + (p.n_veh + p.n_obs) * VPQ);
-            tsep_elev_group_stream<NC>(p.ts, xy_dyn, VPQ, g, img, lds, r * sp.sep_rows_per,
+            tsep_elev_group_stream<NC>(p.ts, xy_dyn, VPQ, g, img, img + kWave * ElevMfma<L>::PA, r * sp.sep_rows_per,
                                        min(p.B, (r + 1) * sp.sep_rows_per), p.fd, p.fd_fixed);
             return;
         }
@@ -3244,13 +3249,17 @@ int launch_step_fd_structured(obtg_ctx* c, int B, double max_sep, double* d_out_
     size_t lds_s = std::max((size_t)16 * n_sobj * vpq, sizeof(double) * kWave * L);      // (flat: the tile overlays the staged row)
     size_t lds_d_elev = 0;
     if (elev) {
-        // staged row + the group's coefficient image [64][PA]; then, in their place, four 16-row output tiles
-        const int KS = (L + 3) / 4, PA = 4 * KS + 2, CW = 16 * (KS <= 6 ? 8 : 4);
-        lds_s = std::max((size_t)16 * n_sobj * vpq + sizeof(double) * kWave * PA, sizeof(double) * 4 * 16 * (size_t)std::min(LR, CW));
+        // staged row + the group's coefficient image [64][PA] + one 16-row output tile of up to 128 columns
+        const int KS = (L + 3) / 4, PA = 4 * KS + 2;
+        lds_s = (size_t)16 * n_sobj * vpq + sizeof(double) * (kWave * PA + 16 * (size_t)std::min(LR, 128));
         lds_d_elev = sizeof(double) * dyn_elev_lds_doubles(c->deg, c->R);
     }
     const size_t lds_g = (planar_lds_bytes<0>(n_obj, vpq, sp.gjk_chunk_pairs) + 15) / 16 * 16 + (size_t)sp.gjk_chunk_pairs * 68 + 16;
-    const size_t lds_f = std::max(planar_lds_bytes<1>(n_obj, vpq, sp.fix_chunk), (size_t)16 * (n_obj + c->n_obs) * vpq);
+    size_t lds_f = std::max(planar_lds_bytes<1>(n_obj, vpq, sp.fix_chunk), (size_t)16 * (n_obj + c->n_obs) * vpq);
+    if (elev) {                        // the fix-up rows' image [32][PA] and tile behind the staged objects
+        const int KS = (L + 3) / 4, PA = 4 * KS + 2;
+        lds_f = std::max(lds_f, (size_t)16 * (n_obj + c->n_obs) * vpq + sizeof(double) * (32 * PA + 16 * (size_t)std::min(LR, 128)));
+    }
     const size_t lds_d = sizeof(double) * ((size_t)kWave * (4 * c->deg + 1) + (size_t)kWave * L);
     const size_t lds = std::max(std::max(lds_s, lds_g), std::max(lds_f, elev ? lds_d_elev : lds_d));
     if (lds > (elev ? 76 : 40) * (size_t)1024) {
