@@ -955,7 +955,7 @@ __device__ __forceinline__ void store_run_wg(const double* __restrict__ tile, do
 {
     const int tid = threadIdx.x, nthr = blockDim.x;
     const int shift = (int)(e0 & 1);
-    if (shift == 0 && (total & 1) == 0) {
+    if (shift == 0 && (total & 1) == 0 && (reinterpret_cast<size_t>(tile) & 15) == 0) {
         const d2_t* t2 = reinterpret_cast<const d2_t*>(tile);
         d2_t* g2 = reinterpret_cast<d2_t*>(gout + e0);
         const int np = total >> 1;
@@ -968,12 +968,24 @@ __device__ __forceinline__ void store_run_wg(const double* __restrict__ tile, do
         }
         return;
     }
+    // (a run that starts on an odd element, or an LDS run that is only 8-byte aligned: 16-byte stores all the same, their halves
+    // read one by one; four pieces per trip as above)
     const int npairs = (total + shift + 1) >> 1;
-    for (int m = tid; m < npairs; m += nthr) {
-        const int a0 = 2 * m - shift, a1 = a0 + 1;
-        if (a0 >= 0 && a1 < total) { d2_t v; v.x = tile[a0]; v.y = tile[a1]; *reinterpret_cast<d2_t*>(gout + e0 + a0) = v; }
-        else if (a0 >= 0) gout[e0 + a0] = tile[a0];
-        else if (a1 < total) gout[e0 + a1] = tile[a1];
+    for (int m0 = tid; m0 < npairs; m0 += 4 * nthr) {
+        double x[4], y[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int a0 = 2 * (m0 + u * nthr) - shift, a1 = a0 + 1;
+            x[u] = (a0 >= 0 && a0 < total) ? tile[a0] : 0.0;
+            y[u] = a1 < total ? tile[a1] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int a0 = 2 * (m0 + u * nthr) - shift, a1 = a0 + 1;
+            if (a0 >= 0 && a1 < total) { d2_t v; v.x = x[u]; v.y = y[u]; *reinterpret_cast<d2_t*>(gout + e0 + a0) = v; }
+            else if (a0 >= 0 && a0 < total) gout[e0 + a0] = x[u];
+            else if (a0 < 0 && a1 < total) gout[e0 + a1] = y[u];
+        }
     }
 }
 
@@ -1135,9 +1147,13 @@ __device__ __forceinline__ void diff_elev1(const double (&p)[NC], double val, do
 //   mode 2: the group of ROW 0's vehicles, its rows copied into every row of [b0, b1) whose tf is tf[0], leaving out the
 //           vehicle that row advances.  b1 - b0 <= 64.
 // s_map: 64 ints of LDS, filled by dyn_emit_prepare.
+// sub (dynamics_elev_group, mode 2): >= 0: the workgroup's four waves share the 16 items 16 sub .. 16 sub + 15 of the group,
+//           each wave a quarter of the column tiles -- a stream workgroup then repeats row 0's matrix products for 16 vehicles
+//           and four times the rows instead of 64 vehicles; -1: wave w takes items 16 w .. 16 w + 15 (everything else).
 struct DynEmit {
     int mode, item_begin, item_end, b0, b1;
     int* s_map;
+    int sub = -1;
 };
 
 __device__ __forceinline__ bool same_bits(double a, double b) { return __double_as_longlong(a) == __double_as_longlong(b); }
@@ -1380,6 +1396,12 @@ __host__ __device__ constexpr int dyn_elev_lds_doubles(int n, int R)
     const int nt4 = (L4 + 4 * R + 15) / 16, nt2 = (L2 + R + 15) / 16;
     return (pad4 + 16 * nt4) + (pad2 + 16 * nt2) + 16 * nt2;
 }
+// ... and of the area behind them in which a shared stream workgroup (DynEmit::sub) collects its 16 items' rows
+__host__ __device__ constexpr int dyn_elev_stage_doubles(int n, int R)
+{
+    const int a = 16 * (4 * n + 1 + 4 * R), sp = 2 * 16 * (2 * n + 1 + R);
+    return a > sp ? a : sp;
+}
 
 // Angular rate and speed rows with DEG_ELEV = R > 0 for the 64 items of `group`, four waves; wave w takes items 16 w ..
 // 16 w + 15.  Phase A (registers): the degree-4n numerator and denominator and the degree-2n speed curve of the lane's
@@ -1420,8 +1442,11 @@ __device__ __forceinline__ void dynamics_elev_group(const AngElevParams& q, doub
         const double* inv2 = row2 + rl2;
         for (int i = tid; i < 16 * NT2; i += nthr) inv2l[i] = i < L2R ? inv2[i] : 0.0;
     }
+    const bool split = mapped && em->sub >= 0;          // (wave-uniform)
+    const int wi = split ? em->sub : wave;               // which 16 items of the group are this wave's
+    const int t_first = split ? wave : 0, t_step = split ? 4 : 1;
     int it0, n_valid;
-    const int item = dyn_item_of_lane<NC>(p, em, group, 16 * wave + c, it0, n_valid);
+    const int item = dyn_item_of_lane<NC>(p, em, group, 16 * wi + c, it0, n_valid);
     const int b = item / p.n_veh;
     if (mapped && wave == 0) {
         int it0l, nvl;
@@ -1537,13 +1562,33 @@ __device__ __forceinline__ void dynamics_elev_group(const AngElevParams& q, doub
             if (m != -2 && m != row) *o = v;
         }
     };
-    const int row_base = 16 * wave + kg;               // this lane's rows: row_base + 4 r
+    const int row_base = 16 * wi + kg;                 // this lane's rows: row_base + 4 r
+    // Shared stream workgroups (DynEmit::sub): the 16 items' rows are collected in LDS behind the tables -- consecutive
+    // vehicles' rows are one contiguous run of every batch row -- and leave as whole-workgroup runs of 16-byte stores, one
+    // or two per batch row (two: the row advances one of these vehicles and its own workgroup writes that one).
+    const bool staged = split && em->mode == 2;
+    double* stage = inv2l + 16 * NT2;                  // [16][L4R] doubles (the speed rows before: [16][L2R], twice)
+    const int sub_rows = staged ? min(16, n_valid - 16 * wi) : 0;
+    auto stream_staged = [&](const double* src, double* __restrict__ out, const int LROW) {
+        const int nb = em->b1 - em->b0;
+        for (int j = 0; j < nb; ++j) {
+            const int m = em->s_map[j];
+            if (m == -2) continue;                                  // (tf[b] is not tf[0]: the row has workgroups of its own)
+            const int skip = m - 16 * wi;                           // the advanced vehicle's row among these 16, if any
+            const size_t e0 = ((size_t)(em->b0 + j) * p.n_veh + it0 + 16 * wi) * LROW;
+            if (skip < 0 || skip >= sub_rows) store_run_wg(src, out, e0, sub_rows * LROW);
+            else {
+                if (skip > 0) store_run_wg(src, out, e0, skip * LROW);
+                if (skip + 1 < sub_rows) store_run_wg(src + (skip + 1) * LROW, out, e0 + (size_t)(skip + 1) * LROW, (sub_rows - skip - 1) * LROW);
+            }
+        }
+    };
     // ---- speed rows = elev(den1, R), both requested bounds from the same accumulators
     const bool flagging = q.flags != nullptr && p.out != nullptr && !mapped;
     if (p.out_speed || flagging) {
         const double* bp = hl2 + PAD2 + c - kg;
         double mn[4] = { INFINITY, INFINITY, INFINITY, INFINITY }, mx[4] = { -INFINITY, -INFINITY, -INFINITY, -INFINITY };
-        for (int t = 0; t < NT2; ++t) {
+        for (int t = t_first; t < NT2; t += t_step) {
             v4d_t acc;
             acc[0] = acc[1] = acc[2] = acc[3] = 0.0;
 #pragma unroll
@@ -1554,11 +1599,22 @@ __device__ __forceinline__ void dynamics_elev_group(const AngElevParams& q, doub
             for (int r = 0; r < 4; ++r) {
                 const double e = acc[r] * iv;
                 if (col < L2R) { mn[r] = fmin(mn[r], e); mx[r] = fmax(mx[r], e); }
-                if (p.out_speed) {
+                if (p.out_speed && staged) {
+                    if (col < L2R) {
+                        stage[(kg + 4 * r) * L2R + col] = p.sp_sign * e + p.sp_offset;
+                        if (p.out_speed2) stage[(16 + kg + 4 * r) * L2R + col] = p.sp2_sign * e + p.sp2_offset;
+                    }
+                } else if (p.out_speed) {
                     emit(p.out_speed, L2R, row_base + 4 * r, col, p.sp_sign * e + p.sp_offset);
                     if (p.out_speed2) emit(p.out_speed2, L2R, row_base + 4 * r, col, p.sp2_sign * e + p.sp2_offset);
                 }
             }
+        }
+        if (p.out_speed && staged) {
+            __syncthreads();
+            stream_staged(stage, p.out_speed, L2R);
+            if (p.out_speed2) stream_staged(stage + 16 * L2R, p.out_speed2, L2R);
+            __syncthreads();                                        // the angular-rate rows take the area over
         }
         if (flagging) {
             // obtg_ctx_set_ang_rate_order(2).  Near a stop: the elevated control points of |v|^2 -- tight to the curve at
@@ -1576,7 +1632,7 @@ __device__ __forceinline__ void dynamics_elev_group(const AngElevParams& q, doub
     // ---- angular rate: elevate numerator and denominator by 4R, divide element by element (optimization.py:608)
     if (p.out) {
         const double* bp = hl4 + PAD4 + c - kg;
-        for (int t = 0; t < NT4; ++t) {
+        for (int t = t_first; t < NT4; t += t_step) {
             v4d_t an, ad;
             an[0] = an[1] = an[2] = an[3] = 0.0;
             ad[0] = ad[1] = ad[2] = ad[3] = 0.0;
@@ -1588,7 +1644,15 @@ __device__ __forceinline__ void dynamics_elev_group(const AngElevParams& q, doub
             }
             const int col = 16 * t + c;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) emit(p.out, L4R, row_base + 4 * r, col, p.w2 - an[r] / ad[r]);
+            for (int r = 0; r < 4; ++r) {
+                const double v = p.w2 - an[r] / ad[r];
+                if (staged) { if (col < L4R) stage[(kg + 4 * r) * L4R + col] = v; }
+                else emit(p.out, L4R, row_base + 4 * r, col, v);
+            }
+        }
+        if (staged) {
+            __syncthreads();
+            stream_staged(stage, p.out, L4R);
         }
     }
 }

@@ -985,6 +985,7 @@ struct StructuredParams {
     const double* cv2;
     int R;
     int dyn_groups_per_row, dyn_rows_per, dyn_streams, dyn_fix_groups;   // D: see the kernel
+    int dyn_split;                     // D, DEG_ELEV > 0: stream workgroups of 16 vehicles (DynEmit::sub) instead of 64
 };
 
 // ELEV: DEG_ELEV > 0 -- the separation groups are elevated (tsep_elev_group_stream), the fix-up rows too, and the
@@ -1026,10 +1027,17 @@ __global__ __launch_bounds__(256, WPC) void k_step_fd_structured(const Structure
             }
         };
         if (id < sp.dyn_streams) {
-            const int r = id / gd;
+            // ELEV: a stream workgroup takes 16 of the group's vehicles (DynEmit::sub) and four times the rows
+            const bool split = ELEV && sp.dyn_split;
+            const int gs = split ? 4 * gd : gd;
+            const int r = id / gs, u = id - r * gs;
             em.mode = 2; em.item_begin = 0; em.item_end = p.n_veh;
             em.b0 = r * sp.dyn_rows_per; em.b1 = min(p.B, em.b0 + sp.dyn_rows_per);
-            run(id - r * gd);
+            if (split) {
+                em.sub = u & 3;
+                if (64 * (u >> 2) + 16 * em.sub >= p.n_veh) return;      // (a last group with fewer than 64 vehicles)
+                run(u >> 2);
+            } else run(u);
             return;
         }
         if (id < sp.dyn_streams + sp.dyn_fix_groups) {
@@ -3199,8 +3207,12 @@ int launch_step_fd_structured(obtg_ctx* c, int B, double max_sep, double* d_out_
     // group, and one workgroup per 8 rows that looks for rows with their own tf
     sp.dyn_groups_per_row = (c->n_veh + kWave - 1) / kWave;
     sp.dyn_rows_per = std::min(64, std::max((B + 255) / 256, std::min(4, B)));
+    // (DEG_ELEV > 0: stream workgroups of 16 vehicles that collect their rows in LDS -- while that area fits beside the tables)
+    sp.dyn_split = elev && !(getenv("OBTG_STRUCT_DYN_SPLIT") && getenv("OBTG_STRUCT_DYN_SPLIT")[0] == '0') &&
+                   sizeof(double) * (dyn_elev_lds_doubles(c->deg, c->R) + dyn_elev_stage_doubles(c->deg, c->R)) <= 72 * (size_t)1024;
+    if (sp.dyn_split) sp.dyn_rows_per = std::min(64, 4 * sp.dyn_rows_per);      // (16 vehicles per stream workgroup instead of 64: the same bytes)
     if (const char* e = getenv("OBTG_STRUCT_DYN_ROWS")) sp.dyn_rows_per = std::max(1, std::min(64, atoi(e)));
-    sp.dyn_streams = sp.dyn_groups_per_row * ((B + sp.dyn_rows_per - 1) / sp.dyn_rows_per);
+    sp.dyn_streams = (sp.dyn_split ? 4 : 1) * sp.dyn_groups_per_row * ((B + sp.dyn_rows_per - 1) / sp.dyn_rows_per);
     sp.dyn_fix_groups = (B - 1 + kWave - 1) / kWave;
     const int dyn_x = sp.dyn_groups_per_row * ((B - 1 + 7) / 8);
     sp.n_kind[3] = sp.dyn_streams + sp.dyn_fix_groups + dyn_x;
@@ -3252,7 +3264,7 @@ int launch_step_fd_structured(obtg_ctx* c, int B, double max_sep, double* d_out_
         // staged row + the group's coefficient image [64][PA] + one 16-row output tile of up to 128 columns
         const int KS = (L + 3) / 4, PA = 4 * KS + 2;
         lds_s = (size_t)16 * n_sobj * vpq + sizeof(double) * (kWave * PA + 16 * (size_t)std::min(LR, 128));
-        lds_d_elev = sizeof(double) * dyn_elev_lds_doubles(c->deg, c->R);
+        lds_d_elev = sizeof(double) * (dyn_elev_lds_doubles(c->deg, c->R) + (sp.dyn_split ? dyn_elev_stage_doubles(c->deg, c->R) : 0));
     }
     const size_t lds_g = (planar_lds_bytes<0>(n_obj, vpq, sp.gjk_chunk_pairs) + 15) / 16 * 16 + (size_t)sp.gjk_chunk_pairs * 68 + 16;
     size_t lds_f = std::max(planar_lds_bytes<1>(n_obj, vpq, sp.fix_chunk), (size_t)16 * (n_obj + c->n_obs) * vpq);

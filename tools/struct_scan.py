@@ -10,7 +10,7 @@ sys.argv, ARGS = sys.argv[:2], sys.argv[2:]
 exec(open("tools/timeline_structured_run.py").read().split("import time")[0])     # the workload's context and buffers (WL = argv[1])
 import numpy as np
 
-KEYS = ("OBTG_STRUCT_PER16", "OBTG_STRUCT_SEP_WGS", "OBTG_STRUCT_GJK_WGS", "OBTG_STRUCT_GJK_CHUNK", "OBTG_STRUCT_DYN_ROWS", "OBTG_STRUCT_ELEV_WPC")
+KEYS = ("OBTG_STRUCT_PER16", "OBTG_STRUCT_SEP_WGS", "OBTG_STRUCT_GJK_WGS", "OBTG_STRUCT_GJK_CHUNK", "OBTG_STRUCT_DYN_ROWS", "OBTG_STRUCT_DYN_SPLIT")
 ROUNDS, N = int(os.environ.get("SCAN_ROUNDS", "5")), int(os.environ.get("SCAN_N", "60"))
 
 
