@@ -1435,7 +1435,7 @@ def test_both_speed_bounds_from_one_pass(capi, synth, oracle, shape):
 @pytest.mark.gpu
 @pytest.mark.parametrize("shape", ["C3_full_batch", "deg7_two_fixed", "three_vehicles", "deg5_no_polys", "elevated_R6", "C5_like_R100", "one_row", "two_rows_elevated", "C4_like_large_rows", "rows_of_96KB",
                                    "with_point_obstacles", "point_obstacles_elevated", "example1_class_path",
-                                   "elevated_two_column_groups", "elevated_40_vehicles_odd_rows"])
+                                   "elevated_two_column_groups", "elevated_40_vehicles_odd_rows", "three_vehicles_elevated"])
 @pytest.mark.parametrize("tf_rows", ["one_tf", "a_few_rows_with_their_own_tf", "every_row_its_own_tf"])
 def test_structured_fd_step_is_bit_identical_to_the_brute_force_sweep(capi, synth, shape, tf_rows):
     """obtg_constraint_sweep_fd_structured_dev: the finite-difference step as ONE launch that evaluates row 0 in full and
@@ -1457,7 +1457,9 @@ def test_structured_fd_step_is_bit_identical_to_the_brute_force_sweep(capi, synt
                          # DEG_ELEV > 0, the cooperative tiles of the S and F kinds: rows of 141 columns (two column groups of the
                          # matrix product); 40 vehicles (a perturbed vehicle's 39 pairs: two passes of the F kind) with rows of
                          # 18 columns, 780 pairs (every second batch row starts on an odd element... of an even run: n_pairs * LR even)
-                         "elevated_two_column_groups": (7, 10, 2, 1, 120), "elevated_40_vehicles_odd_rows": (40, 7, 2, 2, 3)}[shape]
+                         "elevated_two_column_groups": (7, 10, 2, 1, 120), "elevated_40_vehicles_odd_rows": (40, 7, 2, 2, 3),
+                         # 3 pairs x 25 columns: every second batch row's run starts on an odd element (the streams' 8-byte paths)
+                         "three_vehicles_elevated": (3, 10, 1, 1, 4)}[shape]
     Y = synth.swarm_control_points(N, 2, n, seed=41)
     B = N * 2 * (n + 1 - 2 * fixed) + 1
     pobs = {"with_point_obstacles": [[20.0, 30.0], [55.5, 41.0], [70.0, 12.5]], "point_obstacles_elevated": [[33.0, 44.0]],
