@@ -45,7 +45,22 @@ def gjk_beside():            # round 4: the gjkNew sweep on one stream, separati
     b.dynamics_dev(None, dtf.data_ptr(), B, 5.0, True, 1.0, sp.data_ptr(), an.data_ptr())
     a.fd_view_end(); b.fd_view_end()
 
-for name, fn in (("one stream", one_stream), ("two streams", two_streams), ("gjk beside", gjk_beside), ("one stream", one_stream), ("two streams", two_streams), ("gjk beside", gjk_beside)):
+def sep_alone():             # late round 4: the store-bound separation rows on one stream, dynamics then gjkNew (both FP64 / VALU bound) on the other
+    a.fd_view_begin(d0.data_ptr(), 1, synth.FD_STEP, B); b.fd_view_begin(d0.data_ptr(), 1, synth.FD_STEP, B)
+    b.temporal_sep_dev(None, B, 0.9, sep.data_ptr())
+    a.dynamics_dev(None, dtf.data_ptr(), B, 5.0, True, 1.0, sp.data_ptr(), an.data_ptr())
+    a.gjk_swarm_dev(None, B, flag.data_ptr(), p1.data_ptr(), p2.data_ptr(), dist.data_ptr(), None, st_.data_ptr(), 128, 256)
+    a.fd_view_end(); b.fd_view_end()
+
+def sep_alone_gjk_first():
+    a.fd_view_begin(d0.data_ptr(), 1, synth.FD_STEP, B); b.fd_view_begin(d0.data_ptr(), 1, synth.FD_STEP, B)
+    a.gjk_swarm_dev(None, B, flag.data_ptr(), p1.data_ptr(), p2.data_ptr(), dist.data_ptr(), None, st_.data_ptr(), 128, 256)
+    b.temporal_sep_dev(None, B, 0.9, sep.data_ptr())
+    a.dynamics_dev(None, dtf.data_ptr(), B, 5.0, True, 1.0, sp.data_ptr(), an.data_ptr())
+    a.fd_view_end(); b.fd_view_end()
+
+for name, fn in (("one stream", one_stream), ("two streams", two_streams), ("gjk beside", gjk_beside), ("sep alone", sep_alone), ("sep alone, gjk first", sep_alone_gjk_first),
+                 ("one stream", one_stream), ("two streams", two_streams), ("gjk beside", gjk_beside), ("sep alone", sep_alone), ("sep alone, gjk first", sep_alone_gjk_first)):
     for _ in range(150):
         fn()
     torch.cuda.synchronize()
@@ -53,4 +68,4 @@ for name, fn in (("one stream", one_stream), ("two streams", two_streams), ("gjk
     for _ in range(100):
         fn()
     torch.cuda.synchronize()
-    print("%-12s %.4f ms per step" % (name, (time.perf_counter() - t) * 10))
+    print("%-22s %.4f ms per step" % (name, (time.perf_counter() - t) * 10))
