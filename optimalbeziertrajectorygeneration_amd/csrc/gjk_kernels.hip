@@ -3132,7 +3132,7 @@ int launch_step_fd_structured(obtg_ctx* c, int B, double max_sep, double* d_out_
     }
     const bool ok = kern && c->dim == 2 && c->polys_planar && c->max_poly_K <= nc && c->n_hull_pairs > 0 && !c->fd_dedup &&
                     c->n_pairs > 0 && speed && speed->d_out_ang && speed->d_out_speed &&
-                    speed->d_tf && d_out_sep && c->n_veh < 65536 && 2 * c->deg + c->R + 1 <= 512;
+                    speed->d_tf && d_out_sep && c->n_veh + c->n_obs < 65535 && 2 * c->deg + c->R + 1 <= 512;      // (object ids as 16-bit halves of a word)
     if (!ok) return OBTG_ERR_UNSUPPORTED;
     int rc = ensure_tables(c);
     if (rc) return rc;
