@@ -650,6 +650,48 @@ def main():
             dist.all_gather_object(parts, mine)
         checksum = {k: sum(q[k] for q in parts) for k in mine}
         checksum["rows_per_rank"] = [q["rows"] for q in parts]
+    # --mode rows, the same ranges through the STRUCTURED step (obtg_constraint_sweep_fd_structured_rows_dev: every rank
+    # evaluates the unperturbed row, the source of its streams, and per row of its range only what that row's vehicle
+    # touches): same barrier + MAX-over-ranks timing, the checksums over every rank's rows must be the brute-force ones
+    rows_structured = None
+    if args.mode == "rows" and everything and o_an is not None and use_view and use_gjk and not args.no_variants and B > 0:
+        try:
+            def structured_rows():
+                ctx.constraint_sweep_fd_structured_dev(d0.data_ptr(), 1, synth.FD_STEP, d_tf.data_ptr(), B, max_sep,
+                                                       o_sep.data_ptr(), vmax, True, wmax, o_sp.data_ptr(), o_an.data_ptr(),
+                                                       g_flag.data_ptr(), g_p1.data_ptr(), g_p2.data_ptr(), g_dist.data_ptr(),
+                                                       None, g_stat.data_ptr(), 128, 256, row_begin=row_begin)
+            for t_ in (o_sep, o_sp):
+                t_.fill_(float("nan"))
+            g_flag.fill_(-7)
+            for _ in range(max(args.warmup, 3)):
+                structured_rows()
+            barrier()
+            torch.cuda.synchronize()
+            ts0 = time.perf_counter()
+            for _ in range(args.steps):
+                structured_rows()
+            torch.cuda.synchronize()
+            barrier()
+            el_s = time.perf_counter() - ts0
+            if use_dist:
+                tt = torch.tensor([el_s], dtype=f64, device=dev)
+                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                el_s = float(tt.item())
+            mine_s = {"sep_min_sum": float(torch.amin(o_sep.view(B, P_t, L), dim=2).sum().item()), "speed_sum": float(o_sp.sum().item()),
+                      "gjk_flag_sum": int(g_flag.sum().item())}
+            parts_s = [mine_s]
+            if use_dist:
+                parts_s = [None] * dist.get_world_size()
+                dist.all_gather_object(parts_s, mine_s)
+            sums = {k: sum(q[k] for q in parts_s) for k in mine_s}
+            ms_s = 1e3 * el_s / args.steps
+            rows_structured = {"ms_per_step": round(ms_s, 4), "evals_per_s": round(B_total / (ms_s * 1e-3), 1), "checksum": sums,
+                               "checksum_equals_brute_force": all(sums[k] == checksum[k] for k in sums),
+                               "what": "every rank's row range through the structured step (row 0 of the view evaluated by every "
+                                       "rank, per row only what its vehicle touches); never `value`"}
+        except RuntimeError as e:
+            rows_structured = {"unsupported": str(e)}
     # proof of ranks: what the process group itself reports, and the device every rank ran on
     ranks_seen = dist.get_world_size() if use_dist else 1
     devices = [torch.cuda.get_device_name(local_rank) + " #%d" % local_rank]
@@ -679,7 +721,7 @@ def main():
                                              else "written to HBM by obtg_fd_batch_dev each step"), P_t,
                                        "max_ang_rate+" if d == 2 else "", P_s),
                        "ang_rate_order": args.ang_order, "mode": args.mode, "rows_per_step_all_ranks": B_total if args.mode == "rows" else world * B,
-                       "row_range_of_rank0": [row_begin, B] if args.mode == "rows" else None,
+                       "row_range_of_rank0": [row_begin, B] if args.mode == "rows" else None, "rows_structured": rows_structured,
                        "gather_minima": bool(d_min is not None), "checksum": checksum,
                        "launches_per_step": len(kernels), "streams": 2 if two_streams else 1, "stream": stream_note,
                        "ranks_seen": ranks_seen, "backend": (args.backend if use_dist else None), "devices": devices,

@@ -213,8 +213,7 @@ int obtg_fd_batch_dev(obtg_ctx*, const double* dY0, int n_fixed_cols, double h, 
 int obtg_fd_view_begin(obtg_ctx*, const double* dY0, int n_fixed_cols, double h, int B);
 /* A RANGE of that batch's rows: the view's local row b is batch row row_begin + b (B rows).  What one of G processes
  * opens when an SLSQP iteration's n_x + 1 rows are sharded over G GPUs (distributed.shard_rows): no rank
- * writes or reads rows it does not own.  The structured step (obtg_constraint_sweep_fd_structured_dev) counts its
- * workgroup kinds from the batch's row 0 and has no such form. */
+ * writes or reads rows it does not own.  The structured step's form of it: obtg_constraint_sweep_fd_structured_rows_dev. */
 int obtg_fd_view_begin_rows(obtg_ctx*, const double* dY0, int n_fixed_cols, double h, int row_begin, int B);
 int obtg_fd_view_end(obtg_ctx*);
 int obtg_fd_forms_on_the_fly(const obtg_ctx*);
@@ -288,12 +287,21 @@ int obtg_constraint_sweep_dev(obtg_ctx*, const double* dY, const double* d_tf, i
  * angular-rate rows of row 0 are copied only into rows whose tf equals tf[0] bit for bit, any other row is evaluated in full.  A different evaluation strategy from
  * "every row in full": bench.py reports it as variants.fd_structured, never as its headline value.  The call is a view
  * of its own (begin .. end around its launch): with a view of the caller's open on the context it returns OBTG_ERR_ARG
- * instead of replacing and closing that view; a row RANGE (obtg_fd_view_begin_rows) has no structured form. */
+ * instead of replacing and closing that view.
+ * ..._rows_dev: the same for the row RANGE [row_begin, row_begin + B) of the batch (what obtg_fd_view_begin_rows views; d_tf and
+ * every output hold the range's B rows): what one of G processes calls when an SLSQP iteration's n_x + 1 rows are sharded over
+ * G GPUs.  The unperturbed row is evaluated by every rank (it is the source of the streams); a range that
+ * does not hold the batch's row 0 has a perturbed row as its local row 0.  Bit for bit the rows of the whole-batch call. */
 int obtg_constraint_sweep_fd_structured_dev(obtg_ctx*, const double* dY0, int n_fixed_cols, double h, const double* d_tf,
                                             int B, double max_sep, double* d_out_sep, double speed_bound, int speed_is_max,
                                             double max_rate, double* d_out_speed, double* d_out_ang, int max_iter, int md_cap,
                                             int* d_flag, double* d_p1, double* d_p2, double* d_dist, int* d_nsup,
                                             int* d_status);
+int obtg_constraint_sweep_fd_structured_rows_dev(obtg_ctx*, const double* dY0, int n_fixed_cols, double h, int row_begin,
+                                                 const double* d_tf, int B, double max_sep, double* d_out_sep, double speed_bound,
+                                                 int speed_is_max, double max_rate, double* d_out_speed, double* d_out_ang,
+                                                 int max_iter, int md_cap, int* d_flag, double* d_p1, double* d_p2, double* d_dist,
+                                                 int* d_nsup, int* d_status);
 /* Finite-difference de-duplication (off by default).  The rows of one
  * SLSQP Jacobian differ from row 0 in ONE vehicle, so all pairs not involving it have row 0's
  * inputs bit for bit.  When on, obtg_gjk_swarm[_dev] compares every row with row 0 (bitwise, per

@@ -42,6 +42,8 @@ _SIGNATURES = {
     "obtg_ctx_set_second_speed_bound": (_i, [_vp, _d, _i, _vp]),
     "obtg_constraint_sweep_fd_structured_dev": (_i, [_vp, _vp, _i, _d, _vp, _i, _d, _vp, _d, _i, _d, _vp, _vp, _i, _i, _vp, _vp,
                                                      _vp, _vp, _vp, _vp]),
+    "obtg_constraint_sweep_fd_structured_rows_dev": (_i, [_vp, _vp, _i, _d, _i, _vp, _i, _d, _vp, _d, _i, _d, _vp, _vp, _i, _i, _vp,
+                                                          _vp, _vp, _vp, _vp, _vp]),
     "obtg_one_vs_many_min": (_i, [_vp, _vp, _i, _vp, _i, _d, _vp]),
     "obtg_one_vs_many_min_dev": (_i, [_vp, _vp, _i, _vp, _i, _d, _vp]),
     "obtg_sync": (_i, [_vp]),
@@ -579,15 +581,17 @@ class Context(object):
 
     def constraint_sweep_fd_structured_dev(self, dY0, n_fixed_cols, h, d_tf, B, max_sep, d_out_sep, speed_bound, speed_is_max,
                                            max_rate, d_out_speed, d_out_ang, d_flag, d_p1, d_p2, d_dist, d_nsup=None,
-                                           d_status=None, max_iter=128, md_cap=4096):
+                                           d_status=None, max_iter=128, md_cap=4096, row_begin=0):
         """The FD step as one launch that evaluates row 0 in full and per row only what its vehicle touches
-        (obtg_constraint_sweep_fd_structured_dev); raises for shapes it does not cover (OBTG_ERR_UNSUPPORTED)."""
+        (obtg_constraint_sweep_fd_structured_dev); raises for shapes it does not cover (OBTG_ERR_UNSUPPORTED).
+        row_begin > 0: the B rows [row_begin, row_begin + B) of the batch (obtg_constraint_sweep_fd_structured_rows_dev):
+        d_tf and the outputs hold those B rows."""
         self._need_hull_pairs("constraint_sweep_fd_structured_dev")
-        self._check(self._lib.obtg_constraint_sweep_fd_structured_dev(
-            self._h, _vp(dY0), int(n_fixed_cols), float(h), _vp(d_tf), int(B), float(max_sep), _vp(d_out_sep),
+        self._check(self._lib.obtg_constraint_sweep_fd_structured_rows_dev(
+            self._h, _vp(dY0), int(n_fixed_cols), float(h), int(row_begin), _vp(d_tf), int(B), float(max_sep), _vp(d_out_sep),
             float(speed_bound), int(bool(speed_is_max)), float(max_rate), _vp(d_out_speed), _vp(d_out_ang), max_iter, md_cap,
             _vp(d_flag), _vp(d_p1), _vp(d_p2), _vp(d_dist), _vp(d_nsup) if d_nsup else None,
-            _vp(d_status) if d_status else None), "obtg_constraint_sweep_fd_structured_dev")
+            _vp(d_status) if d_status else None), "obtg_constraint_sweep_fd_structured_rows_dev")
 
     def min_dist(self, curves, pair_a, pair_b, eps=1e-9, max_iter=128, md_cap=4096, max_depth=64,
                  max_nodes=200000):

@@ -1150,10 +1150,14 @@ __device__ __forceinline__ void diff_elev1(const double (&p)[NC], double val, do
 // sub (dynamics_elev_group, mode 2): >= 0: the workgroup's four waves share the 16 items 16 sub .. 16 sub + 15 of the group,
 //           each wave a quarter of the column tiles -- a stream workgroup then repeats row 0's matrix products for 16 vehicles
 //           and four times the rows instead of 64 vehicles; -1: wave w takes items 16 w .. 16 w + 15 (everything else).
+// fd_map (mode 2): >= 0: the AngParams::fd that names the rows of the emission map when the group's items are read with
+//           fd = 0 (the view's unperturbed row as a one-row batch -- a row range whose local row 0 is a perturbed row).
+// mode 1: item_begin = the first perturbed local row (1, or 0 in such a range), item_end = how many there are.
 struct DynEmit {
     int mode, item_begin, item_end, b0, b1;
     int* s_map;
     int sub = -1;
+    int fd_map = -1;
 };
 
 __device__ __forceinline__ bool same_bits(double a, double b) { return __double_as_longlong(a) == __double_as_longlong(b); }
@@ -1170,7 +1174,7 @@ __device__ __forceinline__ int dyn_item_of_lane(const AngParams& p, const DynEmi
     if (em->mode == 1) {
         it0 = 0;
         n_valid = min(kWave, em->item_end - group * kWave);
-        const int b = min(group * kWave + lane, em->item_end - 1) + 1;
+        const int b = min(group * kWave + lane, em->item_end - 1) + em->item_begin;
         return b * p.n_veh + max(fd_element(p.fd, p.fd_fixed, NC, b), 0) / (2 * NC);
     }
     it0 = em->item_begin + group * kWave;
@@ -1190,7 +1194,7 @@ __device__ __forceinline__ void dyn_emit_prepare(const AngParams& p, const DynEm
         if (b < em.b1) {
             int m = -2;
             if (same_bits(p.tf[b], p.tf[0])) {
-                const int fd_e = fd_element(p.fd, p.fd_fixed, NC, b);
+                const int fd_e = fd_element(em.fd_map >= 0 ? em.fd_map : p.fd, p.fd_fixed, NC, b);
                 const int local = fd_e >= 0 ? fd_e / (2 * NC) - it0 : -1;
                 m = (local >= 0 && local < n_valid) ? local : -1;
             }

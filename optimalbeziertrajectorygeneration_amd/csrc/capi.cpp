@@ -215,7 +215,7 @@ const char* obtg_abi_symbols(void)
         "obtg_temporal_sep_fd\0obtg_temporal_sep_fd_dev\0obtg_one_vs_many_min\0obtg_one_vs_many_min_dev\0"
         "obtg_temporal_sep_dev\0obtg_temporal_sep_min_dev\0obtg_speed_dev\0obtg_ang_rate_dev\0obtg_dynamics_dev\0"
         "obtg_fd_batch_dev\0obtg_fd_view_begin\0obtg_fd_view_begin_rows\0obtg_fd_view_end\0obtg_fd_forms_on_the_fly\0obtg_pair_sweep_fd_dev\0obtg_dynamics_fd_dev\0obtg_gjk_pairs\0obtg_ctx_set_polygons\0obtg_ctx_set_hull_pairs\0"
-        "obtg_ctx_set_fd_dedup\0obtg_ctx_set_gjk_history\0obtg_pair_sweep_dev\0obtg_constraint_sweep_dev\0obtg_constraint_sweep_fd_structured_dev\0obtg_gjk_swarm_dev\0obtg_gjk_swarm\0obtg_min_dist\0obtg_min_dist_robust\0obtg_min_dist2poly\0obtg_min_dist2poly_robust\0obtg_gjk_true_pairs\0"
+        "obtg_ctx_set_fd_dedup\0obtg_ctx_set_gjk_history\0obtg_pair_sweep_dev\0obtg_constraint_sweep_dev\0obtg_constraint_sweep_fd_structured_dev\0obtg_constraint_sweep_fd_structured_rows_dev\0obtg_gjk_swarm_dev\0obtg_gjk_swarm\0obtg_min_dist\0obtg_min_dist_robust\0obtg_min_dist2poly\0obtg_min_dist2poly_robust\0obtg_gjk_true_pairs\0"
         "obtg_bern_elev\0obtg_bern_diff\0obtg_bern_mul\0obtg_bern_normsq\0obtg_bern_split\0"
         "obtg_euclidean_obj\0obtg_accel_obj\0obtg_jerk_obj\0"
         "obtg_set_profiling\0obtg_set_profile_period\0obtg_kernel_stats\0obtg_reset_kernel_stats\0obtg_kernel_name\0";
@@ -1046,26 +1046,37 @@ int obtg_constraint_sweep_dev(obtg_ctx* c, const double* dY, const double* d_tf,
     });
 }
 
-int obtg_constraint_sweep_fd_structured_dev(obtg_ctx* c, const double* dY0, int n_fixed_cols, double h, const double* d_tf, int B,
-                                            double max_sep, double* d_out_sep, double speed_bound, int speed_is_max, double max_rate,
-                                            double* d_out_speed, double* d_out_ang, int max_iter, int md_cap, int* d_flag,
-                                            double* d_p1, double* d_p2, double* d_dist, int* d_nsup, int* d_status)
+int obtg_constraint_sweep_fd_structured_rows_dev(obtg_ctx* c, const double* dY0, int n_fixed_cols, double h, int row_begin,
+                                                 const double* d_tf, int B, double max_sep, double* d_out_sep, double speed_bound,
+                                                 int speed_is_max, double max_rate, double* d_out_speed, double* d_out_ang,
+                                                 int max_iter, int md_cap, int* d_flag, double* d_p1, double* d_p2, double* d_dist,
+                                                 int* d_nsup, int* d_status)
 {
     if (!check_ctx(c) || !dY0 || !d_tf || !d_out_sep || !d_out_speed || !d_out_ang || !d_flag || !d_p1 || !d_p2 || !d_dist ||
-        B < 1 || max_iter < 1 || md_cap < 1) return OBTG_ERR_ARG;
+        B < 1 || row_begin < 0 || max_iter < 1 || md_cap < 1) return OBTG_ERR_ARG;
     if (!c->hull_pairs_set || c->dim != 2) return OBTG_ERR_ARG;
     if (c->view.Y0) return OBTG_ERR_ARG;       // a view of the caller's is open: this call is a view of its own and would replace and close it
-    int rc = obtg_fd_view_begin(c, dY0, n_fixed_cols, h, B);
+    int rc = obtg_fd_view_begin_rows(c, dY0, n_fixed_cols, h, row_begin, B);
     if (rc) return rc;
     (void)hipSetDevice(c->device);
     SweepFold sp;
     sp.d_tf = d_tf; sp.speed_bound = speed_bound; sp.speed_is_max = speed_is_max;
     sp.d_out_speed = d_out_speed; sp.d_out_ang = d_out_ang; sp.max_rate = max_rate;
-    c->fd.Y0 = c->view.Y0; c->fd.h = c->view.h; c->fd.fixed = c->view.fixed;
+    c->fd.Y0 = c->view.Y0; c->fd.h = c->view.h; c->fd.fixed = c->view.fixed; c->fd.row0 = c->view.row0;
     rc = launch_step_fd_structured(c, B, max_sep, d_out_sep, max_iter, md_cap, d_flag, d_p1, d_p2, d_dist, d_nsup, d_status, &sp);
-    c->fd.Y0 = nullptr;
+    c->fd.Y0 = nullptr; c->fd.row0 = 0;
     (void)obtg_fd_view_end(c);
     return rc;
+}
+
+int obtg_constraint_sweep_fd_structured_dev(obtg_ctx* c, const double* dY0, int n_fixed_cols, double h, const double* d_tf, int B,
+                                            double max_sep, double* d_out_sep, double speed_bound, int speed_is_max, double max_rate,
+                                            double* d_out_speed, double* d_out_ang, int max_iter, int md_cap, int* d_flag,
+                                            double* d_p1, double* d_p2, double* d_dist, int* d_nsup, int* d_status)
+{
+    return obtg_constraint_sweep_fd_structured_rows_dev(c, dY0, n_fixed_cols, h, 0, d_tf, B, max_sep, d_out_sep, speed_bound, speed_is_max,
+                                                        max_rate, d_out_speed, d_out_ang, max_iter, md_cap, d_flag, d_p1, d_p2, d_dist,
+                                                        d_nsup, d_status);
 }
 
 int obtg_ctx_set_gjk_history(obtg_ctx* c, int on)

@@ -986,6 +986,7 @@ struct StructuredParams {
     int R;
     int dyn_groups_per_row, dyn_rows_per, dyn_streams, dyn_fix_groups;   // D: see the kernel
     int dyn_split;                     // D, DEG_ELEV > 0: stream workgroups of 16 vehicles (DynEmit::sub) instead of 64
+    int first_pert;                    // the view's first perturbed local row: 1 (the view starts at the batch's row 0) or 0 (a later row range)
 };
 
 // ELEV: DEG_ELEV > 0 -- the separation groups are elevated (tsep_elev_group_stream), the fix-up rows too, and the
@@ -1017,13 +1018,19 @@ __global__ __launch_bounds__(256, WPC) void k_step_fd_structured(const Structure
         __shared__ int s_dmap[kWave];
         const int gd = sp.dyn_groups_per_row;
         DynEmit em{ 0, 0, 0, 0, 0, s_dmap };
-        auto run = [&](int group) {
+        // base_row: the group's items are the vehicles of the view's UNPERTURBED row (the streams' source) -- inside a row
+        // range that is not the view's local row 0, so the items are read as a materialised one-row batch (fd = 0) while the
+        // emission maps keep the view's rows (DynEmit::fd_map)
+        auto run = [&](int group, bool base_row = false) {
             if (ELEV) {
                 AngElevParams q;
                 q.a = p.dyn; q.cv4 = sp.cv4; q.cv2 = sp.cv2; q.R = sp.R; q.flags = nullptr;
+                if (base_row) { em.fd_map = q.a.fd; q.a.fd = 0; }
                 dynamics_elev_group<NC>(q, lds, group, &em);
             } else {
-                dynamics2_group<NC, false, true>(p.dyn, lds, group, &em);
+                AngParams a = p.dyn;
+                if (base_row) { em.fd_map = a.fd; a.fd = 0; }
+                dynamics2_group<NC, false, true>(a, lds, group, &em);
             }
         };
         if (id < sp.dyn_streams) {
@@ -1036,12 +1043,12 @@ __global__ __launch_bounds__(256, WPC) void k_step_fd_structured(const Structure
             if (split) {
                 em.sub = u & 3;
                 if (64 * (u >> 2) + 16 * em.sub >= p.n_veh) return;      // (a last group with fewer than 64 vehicles)
-                run(u >> 2);
-            } else run(u);
+                run(u >> 2, true);
+            } else run(u, true);
             return;
         }
         if (id < sp.dyn_streams + sp.dyn_fix_groups) {
-            em.mode = 1; em.item_end = p.B - 1;
+            em.mode = 1; em.item_begin = sp.first_pert; em.item_end = p.B - sp.first_pert;
             run(id - sp.dyn_streams);
             return;
         }
@@ -1056,7 +1063,7 @@ __global__ __launch_bounds__(256, WPC) void k_step_fd_structured(const Structure
     }
     if (kind == 1) {
         // ---- F: row b's own pairs
-        const int b = id + 1;
+        const int b = id + sp.first_pert;
         GjkSwarmParams q = p;
         q.chunk = sp.fix_chunk; q.chg_from_fd = 1; q.passes = 1; q.len_in = nullptr; q.len_out = nullptr;
         gjk_planar_body<NC, 1, false>(q, xy_dyn, b, 0);
@@ -3111,7 +3118,6 @@ int launch_step_fd_structured(obtg_ctx* c, int B, double max_sep, double* d_out_
 {
     if (B <= 0) return OBTG_OK;
     if (!c->fd.Y0) return OBTG_ERR_ARG;
-    if (c->fd.row0 != 0) return OBTG_ERR_UNSUPPORTED;      // (a row range that does not start at the batch's row 0: its kinds count from row 0)
     if (c->ang_exact && c->R > 0) return OBTG_ERR_UNSUPPORTED;   // (obtg_ctx_set_ang_rate_order(2): the double-double pass follows the brute-force launches)
     const int nc = c->deg + 1;
     void (*kern)(const StructuredParams) = nullptr;
@@ -3170,7 +3176,7 @@ int launch_step_fd_structured(obtg_ctx* c, int B, double max_sep, double* d_out_
             d.sp2_sign = c->speed2.is_max ? -1.0 : 1.0; d.sp2_offset = c->speed2.is_max ? c2 : -c2;
         }
         d.W2n = c->d_ang_w2n.as<double>(); d.W22n = c->d_ang_w22n.as<double>(); d.Wn = c->d_ang_wn.as<double>();
-        d.fd = 1; d.fd_fixed = p.fd_fixed; d.fd_h = p.fd_h;
+        d.fd = p.fd; d.fd_fixed = p.fd_fixed; d.fd_h = p.fd_h;
     }
     const int n_obj = c->n_veh + c->n_poly, vpq = nc | 1, L = 2 * c->deg + 1, LR = L + c->R;
     // S: one workgroup per (64-pair group, row range); about two thousand workgroups of streams
@@ -3200,7 +3206,8 @@ int launch_step_fd_structured(obtg_ctx* c, int B, double max_sep, double* d_out_
     sp.fix_chunk = 256;
     p.vp_off = c->d_vp_off.as<int>(); p.vp_idx = c->d_vp_idx.as<int>();
     sp.n_kind[0] = sp.n_sep_groups * s_ranges;
-    sp.n_kind[1] = B - 1;
+    sp.first_pert = c->fd.row0 > 0 ? 0 : 1;            // (a range that starts later: its local row 0 is a perturbed row too)
+    sp.n_kind[1] = B - sp.first_pert;
     sp.n_kind[2] = sp.gjk_chunks * g_ranges;
     // D: ~256 streams of row 0's groups (at most 64 rows each, at least 4 when there are that many: at C5 a stream of 19
     // rows keeps its workgroup for 430 us of a 650 us launch, one of 5 rows for 190), the advanced vehicles 64 to a
@@ -3213,7 +3220,7 @@ int launch_step_fd_structured(obtg_ctx* c, int B, double max_sep, double* d_out_
     if (sp.dyn_split) sp.dyn_rows_per = std::min(64, 4 * sp.dyn_rows_per);      // (16 vehicles per stream workgroup instead of 64: the same bytes)
     if (const char* e = getenv("OBTG_STRUCT_DYN_ROWS")) sp.dyn_rows_per = std::max(1, std::min(64, atoi(e)));
     sp.dyn_streams = (sp.dyn_split ? 4 : 1) * sp.dyn_groups_per_row * ((B + sp.dyn_rows_per - 1) / sp.dyn_rows_per);
-    sp.dyn_fix_groups = (B - 1 + kWave - 1) / kWave;
+    sp.dyn_fix_groups = (B - sp.first_pert + kWave - 1) / kWave;
     const int dyn_x = sp.dyn_groups_per_row * ((B - 1 + 7) / 8);
     sp.n_kind[3] = sp.dyn_streams + sp.dyn_fix_groups + dyn_x;
     unsigned grid = 0;

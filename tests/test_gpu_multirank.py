@@ -114,6 +114,15 @@ def test_bench_rows_mode_two_ranks_tile_the_iteration():
         for k in ("sep_min_sum", "speed_sum"):
             assert abs(c["checksum"][k] - one["config"]["checksum"][k]) <= 1e-11 * abs(one["config"]["checksum"][k]), k
     assert two["config"]["checksum"]["rows_per_rank"] == [151, 150] and three["config"]["gather_minima"] is True
+    # the same ranges through the structured step (obtg_constraint_sweep_fd_structured_rows_dev): bit-identical rows, so
+    # the sums over all ranks' rows are the brute-force sums exactly
+    assert one["config"]["rows_structured"] is None                        # (--no-variants)
+    args_v = [a for a in args if a != "--no-variants"]
+    for g in (1, 2, 3):
+        line = _bench(["--gpus", str(g)] + (["--backend", "gloo", "--one-device"] if g > 1 else []) + args_v)
+        rs = line["config"]["rows_structured"]
+        assert rs["checksum_equals_brute_force"] is True and rs["ms_per_step"] > 0, rs
+        assert rs["checksum"]["gjk_flag_sum"] == one["config"]["checksum"]["gjk_flag_sum"]
 
 
 def test_rccl_path_with_one_rank():

@@ -1814,3 +1814,55 @@ def test_context_lifecycle_returns_its_device_memory(capi, synth):
     torch.cuda.synchronize()
     free1, _ = torch.cuda.mem_get_info()
     assert free0 - free1 < (8 << 20), "device memory not returned: %.1f MiB after 60 contexts" % ((free0 - free1) / 2.0 ** 20)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", ["C3_like", "elevated", "point_obstacles", "elevated_two_groups_of_vehicles"])
+def test_structured_fd_step_over_row_ranges(capi, synth, shape):
+    """obtg_constraint_sweep_fd_structured_rows_dev: the structured step of the rows [r0, r0 + cnt) of the batch -- a rank's
+    share of one SLSQP iteration -- gives, local row for local row, the whole-batch call's rows bit for bit:
+    ranges that hold the batch's row 0 and ranges that do not (their local row 0 is a perturbed row: the fix-up kinds start at
+    it, the streams still come from the unperturbed row), with one tf for all rows and with tf differing in some rows --
+    the local row 0 of a later range among them (the streams then copy into the rows that share ITS tf)."""
+    import torch
+    N, n, M, R, pobs = {"C3_like": (40, 10, 4, 0, None), "elevated": (11, 10, 2, 6, None),
+                        "point_obstacles": (9, 7, 1, 0, [[20.0, 30.0], [61.0, 44.5]]),
+                        "elevated_two_groups_of_vehicles": (70, 7, 1, 3, None)}[shape]
+    Y = synth.swarm_control_points(N, 2, n, seed=23)
+    n_x = N * 2 * (n - 1)
+    B = min(n_x + 1, 300)
+    ctx = capi.Context(N, 2, n, R, point_obs=np.array(pobs) if pobs else None)
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    pa, pb = synth.swarm_pairs(N, M)
+    ctx.set_polygons(*synth.pack_polys(synth.polygon_obstacles(M, seed=23)))
+    ctx.set_hull_pairs(pa, pb)
+    d0 = torch.from_numpy(Y).cuda()
+    P, L, Ps = ctx.num_pairs, 2 * n + R + 1, len(pa)
+    f64, i32 = torch.float64, torch.int32
+    for tf_kind in ("one_tf", "some_rows_their_own"):
+        tf = np.full(B, 6.5)
+        if tf_kind == "some_rows_their_own":
+            for k in (2, 7, B // 3, B // 3 + 1, B - 2):
+                tf[k] = 6.5 + 1e-3 * k
+
+        def run(r0, cnt):
+            def nan(*sh):
+                return torch.full(sh, float("nan"), dtype=f64, device="cuda")
+            o = dict(sep=nan(cnt, P * L), sp=nan(cnt, ctx.len_speed), an=nan(cnt, ctx.len_ang_rate),
+                     flag=torch.full((cnt, Ps), -7, dtype=i32, device="cuda"), p1=nan(cnt, Ps, 3), p2=nan(cnt, Ps, 3),
+                     dist=nan(cnt, Ps), ns=torch.full((cnt, Ps), -7, dtype=i32, device="cuda"),
+                     st=torch.full((cnt, Ps), -7, dtype=i32, device="cuda"))
+            dtf = torch.from_numpy(np.ascontiguousarray(tf[r0:r0 + cnt])).cuda()
+            ctx.constraint_sweep_fd_structured_dev(d0.data_ptr(), 1, 1e-3, dtf.data_ptr(), cnt, 0.9, o["sep"].data_ptr(), 4.0, True, 1.5,
+                                                   o["sp"].data_ptr(), o["an"].data_ptr(), o["flag"].data_ptr(), o["p1"].data_ptr(),
+                                                   o["p2"].data_ptr(), o["dist"].data_ptr(), o["ns"].data_ptr(), o["st"].data_ptr(),
+                                                   128, 300, row_begin=r0)
+            torch.cuda.synchronize()
+            return o
+        full = run(0, B)
+        for r0, cnt in ((0, 5), (1, 1), (B // 3, B - B // 3), (B - 2, 2), (5, min(130, B - 5)), (B // 3 + 1, 9)):
+            part = run(r0, cnt)
+            for k, v in part.items():
+                assert torch.equal(v.view(torch.uint8), full[k][r0:r0 + cnt].contiguous().view(torch.uint8)), (shape, tf_kind, r0, cnt, k)
+    ctx.use_own_stream()
+    ctx.close()
