@@ -77,6 +77,28 @@ def main():
             if not torch.equal(a[key].view(torch.uint8), b[key].view(torch.uint8)):
                 bad = (a[key].view(torch.uint8) != b[key].view(torch.uint8)).nonzero()
                 raise SystemExit("trial %d MISMATCH in %s (%d bytes, first at %s): %s" % (trial, key, len(bad), bad[0].tolist(), what))
+        # ... and a random row RANGE of it (obtg_constraint_sweep_fd_structured_rows_dev): the whole-batch call's rows
+        if B >= 2:
+            rng2 = np.random.default_rng(7000 + trial)
+            r0 = int(rng2.integers(0, B))
+            cnt = int(rng2.integers(1, B - r0 + 1))
+            dtf_r = dtf[r0:r0 + cnt].contiguous()
+
+            def nanr(*sh):
+                return torch.full(sh, float("nan"), dtype=f64, device="cuda")
+            c_ = dict(sep=nanr(cnt, P * L), flag=torch.full((cnt, Ps), -7, dtype=i32, device="cuda"), p1=nanr(cnt, Ps, 3), p2=nanr(cnt, Ps, 3),
+                      dist=nanr(cnt, Ps), ns=torch.full((cnt, Ps), -7, dtype=i32, device="cuda"),
+                      st=torch.full((cnt, Ps), -7, dtype=i32, device="cuda"), sp=nanr(cnt, ctx.len_speed), an=nanr(cnt, ctx.len_ang_rate))
+            ctx.constraint_sweep_fd_structured_dev(d0.data_ptr(), fixed, h, dtf_r.data_ptr(), cnt, 0.9, c_["sep"].data_ptr(), 4.0, True, 1.5,
+                                                   c_["sp"].data_ptr(), c_["an"].data_ptr(), c_["flag"].data_ptr(), c_["p1"].data_ptr(),
+                                                   c_["p2"].data_ptr(), c_["dist"].data_ptr(), c_["ns"].data_ptr(), c_["st"].data_ptr(), 128, 500,
+                                                   row_begin=r0)
+            torch.cuda.synchronize()
+            # (rows with their own tf are compared too: a range whose local row 0 has its own tf streams into the rows that share
+            # THAT tf and evaluates the others in full -- the same numbers either way)
+            for key in c_:
+                if not torch.equal(c_[key].view(torch.uint8), b[key][r0:r0 + cnt].contiguous().view(torch.uint8)):
+                    raise SystemExit("trial %d MISMATCH in %s of the row range [%d, %d): %s" % (trial, key, r0, r0 + cnt, what))
         done += 1
         print("trial %d ok: %s  (%.0f s)" % (trial, what, time.time() - t0), flush=True)
         ctx.use_own_stream(); ctx.close()
