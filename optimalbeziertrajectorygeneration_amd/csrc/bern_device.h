@@ -1234,6 +1234,83 @@ __device__ __forceinline__ void dyn_emit_rows(const double* __restrict__ tile, i
     }
 }
 
+// ---- angular rate / speed arithmetic in separable form (late round 4) -----------------------------------------------------
+// u_j = C(n, j) a_j turns the product of two degree-n Bernstein curves into a plain convolution of the u's,
+//     C(2n, k) (a b)_k = sum_j ua_j ub_{k-j},
+// so the degree-2n curves of optimization.py:603-605 are kept as raw_k = C(2n, k) x coefficient, their squares at degree
+// 4n are plain folded convolutions of the raws, and the quotient num.cpts / den.cpts (optimization.py:608) needs no binomial
+// at all -- the same 1 / C(4n, k) stands on both sides -- while DEG_ELEV > 0 wants exactly C(4n, k) x coefficient as the
+// operand of its convolution form.  One fused multiply-add per term where the weighted sums took two to four instructions.
+// Used by the DEG_ELEV > 0 groups (dynamics_elev_group: phase A 2000 -> 1100 instructions per lane; C5's fused launch 0.594 ->
+// 0.559 ms, same box, interleaved).  The DEG_ELEV = 0 groups keep the weighted sums: there the same change bought C3 nothing
+// (its dynamics groups fill the sweep's tail) and cost C4 1.6 % (16 control points: the four scaled derivative arrays on top
+// of a body that already spills under the tiled sweep's 128 registers).  C(n, .) and 1 / C(2n, .) sit behind the plain
+// product weights (capi.cpp plain_product_weights).
+template <int NC>
+__device__ __forceinline__ void ang_scale(const double (&a)[NC], const ctab_t Cn, double (&u)[NC])
+{
+#pragma unroll
+    for (int j = 0; j < NC; ++j) u[j] = Cn[j] * a[j];
+}
+
+// raw_k = C(2n, k) (xD^2 + yD^2)_k from the scaled derivatives
+template <int NC>
+__device__ __forceinline__ void ang_raw_den(const double (&ux)[NC], const double (&uy)[NC], double (&raw)[2 * NC - 1])
+{
+    constexpr int N = NC - 1, L2 = 2 * N + 1;
+#pragma unroll
+    for (int k = 0; k < L2; ++k) {
+        const int jlo = k - N > 0 ? k - N : 0;
+        double so = 0.0;
+#pragma unroll
+        for (int j = jlo; 2 * j < k; ++j) {
+            so = j == jlo ? ux[j] * ux[k - j] : fma(ux[j], ux[k - j], so);
+            so = fma(uy[j], uy[k - j], so);
+        }
+        if ((k & 1) == 0) {
+            const int h = k >> 1;
+            const double dg = fma(uy[h], uy[h], ux[h] * ux[h]);
+            raw[k] = (2 * jlo < k) ? fma(2.0, so, dg) : dg;
+        } else raw[k] = so + so;
+    }
+}
+
+// raw_k = C(2n, k) (yDD xD - xDD yD)_k
+template <int NC>
+__device__ __forceinline__ void ang_raw_num(const double (&uyDD)[NC], const double (&uxD)[NC], const double (&uxDD)[NC],
+                                            const double (&uyD)[NC], double (&raw)[2 * NC - 1])
+{
+    constexpr int N = NC - 1, L2 = 2 * N + 1;
+#pragma unroll
+    for (int k = 0; k < L2; ++k) {
+        const int jlo = k - N > 0 ? k - N : 0, jhi = N < k ? N : k;
+        double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+        for (int j = jlo; j <= jhi; ++j) {
+            s1 = j == jlo ? uyDD[j] * uxD[k - j] : fma(uyDD[j], uxD[k - j], s1);
+            s2 = j == jlo ? uxDD[j] * uyD[k - j] : fma(uxDD[j], uyD[k - j], s2);
+        }
+        raw[k] = s1 - s2;
+    }
+}
+
+// coefficient k of the square of a raw curve of LIN coefficients: C(2 (LIN - 1), k) x (the curve's square)_k
+template <int LIN>
+__device__ __forceinline__ double fold_square_at(const double (&u)[LIN], const int k)
+{
+    constexpr int M = LIN - 1;
+    const int jlo = k - M > 0 ? k - M : 0;
+    double so = 0.0;
+#pragma unroll
+    for (int j = jlo; 2 * j < k; ++j) so = j == jlo ? u[j] * u[k - j] : fma(u[j], u[k - j], so);
+    if ((k & 1) == 0) {
+        const int h = k >> 1;
+        const double dg = u[h] * u[h];
+        return (2 * jlo < k) ? fma(2.0, so, dg) : dg;
+    }
+    return so + so;
+}
+
 // The second half of dynamics2_group for a wave that holds the coefficients K0 <= k < K1 of its side's degree-4n square:
 // square, hand the other role its share through the exchange tile (row `trow` of the item), divide, leave the quotients
 // in the tile.  Role 0 (denominator side) divides k < KS, role 1 (numerator side, the dearer products) the rest.  Three
@@ -1468,8 +1545,7 @@ __device__ __forceinline__ void dynamics_elev_group(const AngElevParams& q, doub
         double xD[NC], yD[NC];
         diff_elev1<NC>(x, val, xD);
         diff_elev1<NC>(y, val, yD);
-        const ctab_t Wn = as_ctab(p.Wn), W2n = as_ctab(p.W2n), W22n = as_ctab(p.W22n);
-        const ctab_t sc2 = as_ctab(q.cv2), sc4 = as_ctab(q.cv4);
+        const ctab_t Cn = as_ctab(p.Wn) + L2 * NC;             // C(n, .) behind the plain product weights
         // the lane's share of an operand: coefficients j = 4 s + kg (zero past the end)
         // (the four candidates are computed by every lane and pinned: left to itself the compiler sinks each candidate's
         // arithmetic AND its table load into a branch of its own -- vector loads with a wait each, a hundred per wave)
@@ -1478,37 +1554,25 @@ __device__ __forceinline__ void dynamics_elev_group(const AngElevParams& q, doub
             for (int u = 0; u < 4; ++u) pin_reg(v[u]);
             return kg == 0 ? v[0] : kg == 1 ? v[1] : kg == 2 ? v[2] : v[3];
         };
+        double uxD[NC], uyD[NC];
+        ang_scale<NC>(xD, Cn, uxD);
+        ang_scale<NC>(yD, Cn, uyD);
         {
+            // C(2n, k) x den1_k IS the speed curve's operand of the convolution form, its folded square C(4n, k) x den_k the denominator's
             double den1[L2];
-#pragma unroll
-            for (int k = 0; k < L2; ++k) {
-                double sd = 0.0;
-#pragma unroll
-                for (int j = (k - N > 0 ? k - N : 0); 2 * j <= k; ++j)
-                    sd = fma(W2n[k * NC + j], fma(xD[j], xD[k - j], yD[j] * yD[k - j]), sd);
-                den1[k] = sd;
-            }
+            ang_raw_den<NC>(uxD, uyD, den1);
 #pragma unroll
             for (int sx = 0; sx < KS2; ++sx) {
                 double v[4];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) { const int k = 4 * sx + u < L2 ? 4 * sx + u : 0; v[u] = (4 * sx + u < L2) ? sc2[k] * den1[k] : 0.0; }
+                for (int u = 0; u < 4; ++u) v[u] = (4 * sx + u < L2) ? den1[4 * sx + u < L2 ? 4 * sx + u : 0] : 0.0;
                 afs[sx] = pick(v);
             }
 #pragma unroll
             for (int sx = 0; sx < KS4; ++sx) {
                 double v[4];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int k = 4 * sx + u;
-                    double sd = 0.0;
-                    if (k < L4) {
-#pragma unroll
-                        for (int j = (k - 2 * N > 0 ? k - 2 * N : 0); 2 * j <= k; ++j) sd = fma(W22n[k * L2 + j], den1[j] * den1[k - j], sd);
-                        sd *= sc4[k];                   // C(4n, k): the convolution form's pre-scaling
-                    }
-                    v[u] = sd;
-                }
+                for (int u = 0; u < 4; ++u) v[u] = (4 * sx + u < L4) ? fold_square_at<L2>(den1, 4 * sx + u < L4 ? 4 * sx + u : 0) : 0.0;
                 afd[sx] = pick(v);
             }
         }
@@ -1517,33 +1581,17 @@ __device__ __forceinline__ void dynamics_elev_group(const AngElevParams& q, doub
             double xDD[NC], yDD[NC];
             diff_elev1<NC>(xD, val, xDD);
             diff_elev1<NC>(yD, val, yDD);
+            double uxDD[NC], uyDD[NC];
+            ang_scale<NC>(xDD, Cn, uxDD);
+            ang_scale<NC>(yDD, Cn, uyDD);
             double num1[L2];
-#pragma unroll
-            for (int k = 0; k < L2; ++k) {
-                double s1 = 0.0, s2 = 0.0;
-#pragma unroll
-                for (int j = (k - N > 0 ? k - N : 0); j <= (N < k ? N : k); ++j) {
-                    const double wkj = Wn[k * NC + j];
-                    s1 = fma(wkj, yDD[j] * xD[k - j], s1);
-                    s2 = fma(wkj, xDD[j] * yD[k - j], s2);
-                }
-                num1[k] = s1 - s2;
-            }
+            ang_raw_num<NC>(uyDD, uxD, uxDD, uyD, num1);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int sx = 0; sx < KS4; ++sx) {
                 double v[4];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int k = 4 * sx + u;
-                    double sn = 0.0;
-                    if (k < L4) {
-#pragma unroll
-                        for (int j = (k - 2 * N > 0 ? k - 2 * N : 0); 2 * j <= k; ++j) sn = fma(W22n[k * L2 + j], num1[j] * num1[k - j], sn);
-                        sn *= sc4[k];
-                    }
-                    v[u] = sn;
-                }
+                for (int u = 0; u < 4; ++u) v[u] = (4 * sx + u < L4) ? fold_square_at<L2>(num1, 4 * sx + u < L4 ? 4 * sx + u : 0) : 0.0;
                 afn[sx] = pick(v);
             }
         }

@@ -112,6 +112,9 @@ static std::vector<double> plain_product_weights(int n)
         for (int j = (k - n > 0 ? k - n : 0); j <= (n < k ? n : k); ++j)
             W[(size_t)k * nc + j] = binom(n, j) * binom(n, k - j) / den;
     }
+    // behind them, for the separable form of the speed / angular-rate arithmetic (bern_device.h ang_raw_*): C(n, .), 1 / C(2n, .)
+    for (int j = 0; j < nc; ++j) W.push_back(binom(n, j));
+    for (int k = 0; k < L; ++k) W.push_back(1.0 / binom(2 * n, k));
     return W;
 }
 
