@@ -1096,6 +1096,7 @@ int plan_temporal_sep(obtg_ctx* c, const double* dY, int B, int pair_begin, int 
     if (row_bytes <= 24 * 1024 || c->n_obj <= 2 * kWave) {
         p.waves = groups_total >= 4 ? 4 : groups_total;
         int gpw = 16;   // groups per workgroup
+        if (const char* e = getenv("OBTG_SEP_GPW")) gpw = std::max(4, std::min(64, atoi(e)));      // (experiments)
         while (gpw > p.waves && (long)B * ((groups_total + gpw - 1) / gpw) < 4096) gpw >>= 1;
         if (gpw < p.waves) gpw = p.waves;
         p.groups_per_wg = gpw;
