@@ -290,10 +290,11 @@ __device__ __forceinline__ v4d_t elev_mfma_tile(const double (&afr)[ElevMfma<LIN
     using E = ElevMfma<LIN>;
     v4d_t acc;
     acc[0] = offset; acc[1] = offset; acc[2] = offset; acc[3] = offset;
+#ifdef OBTG_EXP_MFMA_STEPS     // TIMING builds only (tools/build_variant.sh): a truncated chain, WRONG results -- what the launch costs with fewer matrix instructions
 #pragma unroll
-#ifdef OBTG_EXP_MFMA_STEPS
     for (int s = 0; s < (E::KS < OBTG_EXP_MFMA_STEPS ? E::KS : OBTG_EXP_MFMA_STEPS); ++s) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(afr[s], bfr[s], acc, 0, 0, 0);
 #else
+#pragma unroll
     for (int s = 0; s < E::KS; ++s) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(afr[s], bfr[s], acc, 0, 0, 0);
 #endif
     return acc;
