@@ -5,7 +5,8 @@ Two independent ways to shard:
 
   * batch sharding (default, NO collective): the B = n_x + 1 evaluation rows of one SLSQP
     Jacobian are independent; rank r takes a contiguous block of rows.  Results go back to
-    the host as Jacobian column blocks.  `shard_rows`.
+    the host as Jacobian column blocks.  `shard_rows`; `RowShardedFdStep` runs a rank's block of one
+    finite-difference step (structured or brute force) on the GPU.
   * pair partitioning (one evaluation across GPUs, the 256-vehicle case): every rank holds
     all control points (65 KB), owns a contiguous balanced block of the lexicographic pair
     list -- and of the gjkNew hull pair list, "GJK pairs partition the same way" -- and ONE
@@ -157,3 +158,55 @@ class GpuHullPairSweep(object):
 
     def run(self, dY, B):
         return all_gather_pair_blocks(self.parts(dY, B), group=self.group)
+
+
+class RowShardedFdStep(object):
+    """Batch sharding of ONE finite-difference step (optimization.py:83-187 under SciPy's
+    approx_derivative): the B = n_x + 1 rows formed from x's control points are split into contiguous balanced blocks,
+    rank r evaluates rows [begin, begin + count) -- through the structured step (one launch: the unperturbed row, the source
+    of the streams, is evaluated by every rank; per row only what its vehicle touches) or through the brute-force sweep on a
+    row-range view -- and keeps its rows: Jacobian row blocks, no collective on the data path.  world / rank default to the
+    process group's (1 / 0 without one); pass them to lay out a step by hand."""
+
+    def __init__(self, B, group=None, world=None, rank=None):
+        w, r = _world_rank(group)
+        self.world = w if world is None else int(world)
+        self.rank = r if rank is None else int(rank)
+        self.B = int(B)
+        self.begin, self.count = shard_rows(self.B, self.world, self.rank)
+
+    def buffers(self, ctx, n_hull_pairs, device):
+        """Output tensors of this rank's rows (what `run` fills)."""
+        f64, i32 = torch.float64, torch.int32
+        c = self.count
+        return dict(sep=torch.empty((c, ctx.len_temporal_sep), dtype=f64, device=device),
+                    speed=torch.empty((c, ctx.len_speed), dtype=f64, device=device),
+                    ang=torch.empty((c, ctx.len_ang_rate), dtype=f64, device=device),
+                    flag=torch.empty((c, n_hull_pairs), dtype=i32, device=device),
+                    p1=torch.empty((c, n_hull_pairs, 3), dtype=f64, device=device),
+                    p2=torch.empty((c, n_hull_pairs, 3), dtype=f64, device=device),
+                    dist=torch.empty((c, n_hull_pairs), dtype=f64, device=device),
+                    status=torch.empty((c, n_hull_pairs), dtype=i32, device=device))
+
+    def run(self, ctx, dY0, n_fixed_cols, h, d_tf_rows, max_sep, speed_bound, speed_is_max, max_rate, out, structured=True,
+            max_iter=128, md_cap=256):
+        """dY0: device pointer of x's control points; d_tf_rows: device pointer of THIS rank's `count` final times;
+        out: `buffers(...)`.  structured=False: the brute-force sweep on obtg_fd_view_begin_rows (the same numbers)."""
+        if self.count == 0:
+            return out
+        if structured:
+            ctx.constraint_sweep_fd_structured_dev(dY0, n_fixed_cols, h, d_tf_rows, self.count, max_sep, out["sep"].data_ptr(),
+                                                   speed_bound, speed_is_max, max_rate, out["speed"].data_ptr(), out["ang"].data_ptr(),
+                                                   out["flag"].data_ptr(), out["p1"].data_ptr(), out["p2"].data_ptr(),
+                                                   out["dist"].data_ptr(), None, out["status"].data_ptr(), max_iter, md_cap,
+                                                   row_begin=self.begin)
+        else:
+            ctx.fd_view_begin(dY0, n_fixed_cols, h, self.count, row_begin=self.begin)
+            try:
+                ctx.constraint_sweep_dev(None, d_tf_rows, self.count, max_sep, out["sep"].data_ptr(), speed_bound, speed_is_max,
+                                         max_rate, out["speed"].data_ptr(), out["ang"].data_ptr(), out["flag"].data_ptr(),
+                                         out["p1"].data_ptr(), out["p2"].data_ptr(), out["dist"].data_ptr(), None,
+                                         out["status"].data_ptr(), max_iter, md_cap)
+            finally:
+                ctx.fd_view_end()
+        return out

@@ -170,3 +170,38 @@ def test_default_bench_line_keeps_the_contract():
     pr = d["strong_scaling_proxy"]["rows"]
     assert [e["G"] for e in pr] == [1, 2, 4, 8] and pr[0]["rows"] == 1153 and pr[3]["rows"] == 145
     assert all(0.05 < e["brute_force_efficiency"] <= 1.05 and e["structured_ms"] > 0 for e in pr)
+
+
+def test_row_sharded_fd_step_helper():
+    """distributed.RowShardedFdStep: the rows of three hand-laid ranks, structured and brute force, glue to the one-rank
+    step bit for bit (no process group needed: world / rank passed in; what the ranks of `bench.py --mode rows` do)."""
+    import torch
+    from optimalbeziertrajectorygeneration_amd import _capi, synth
+    from optimalbeziertrajectorygeneration_amd.distributed import RowShardedFdStep
+    N, n, M = 20, 10, 3
+    Y = synth.swarm_control_points(N, 2, n, seed=8)
+    B = N * 2 * (n - 1) + 1
+    ctx = _capi.Context(N, 2, n, 0)
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    ctx.set_polygons(*synth.pack_polys(synth.polygon_obstacles(M, seed=8)))
+    pa, pb = synth.swarm_pairs(N, M)
+    ctx.set_hull_pairs(pa, pb)
+    d0 = torch.from_numpy(Y).cuda()
+    tf = torch.full((B,), 7.0, dtype=torch.float64, device="cuda")
+    whole = RowShardedFdStep(B)
+    assert (whole.world, whole.rank, whole.begin, whole.count) == (1, 0, 0, B)
+    ref = whole.run(ctx, d0.data_ptr(), 1, synth.FD_STEP, tf.data_ptr(), 0.9, 5.0, True, 1.0, whole.buffers(ctx, len(pa), "cuda"))
+    torch.cuda.synchronize()
+    for structured in (True, False):
+        parts = []
+        for r in range(3):
+            st = RowShardedFdStep(B, world=3, rank=r)
+            o = st.run(ctx, d0.data_ptr(), 1, synth.FD_STEP, tf[st.begin:st.begin + st.count].contiguous().data_ptr(), 0.9, 5.0, True, 1.0,
+                       st.buffers(ctx, len(pa), "cuda"), structured=structured)
+            torch.cuda.synchronize()
+            parts.append(o)
+        for k in ref:
+            glued = torch.cat([p[k] for p in parts], dim=0)
+            assert torch.equal(glued.view(torch.uint8), ref[k].view(torch.uint8)), (structured, k)
+    ctx.use_own_stream()
+    ctx.close()
