@@ -612,6 +612,69 @@ __device__ __forceinline__ void tsep_elev_group_stream(const TsepXYParams& t, co
     __syncthreads();
     const int n_tiles = (n_valid + 15) >> 4;
     constexpr int kSlots = 4;                                          // 16 x 128 doubles = 1024 pieces over 256 threads
+#ifndef OBTG_STRUCT_S_TILE_MAJOR
+    if (NT <= 8) {
+        // Rows of up to 128 columns (one column group): all four tiles of the group wait in registers and the stream goes batch
+        // row by batch row -- the workgroup writes its 64 pairs' rows (up to 62 KB, contiguous) of batch row b, while the
+        // workgroups of the neighbouring groups write theirs: together one dense run per batch row, which is what the memory
+        // system rewards (tools/store_pattern_probe2.hip: a dense advancing write front).  Tile after tile across the batch
+        // rows, as below (and with -DOBTG_STRUCT_S_TILE_MAJOR, the A/B build), every workgroup leaves a quarter of each row for later:
+        // C5 0.545 against 0.528 ms over four interleaved pairs of runs on one box.
+        double bfr[2][E::KS];
+        coop_load_bfrag<L>(t.Tf, NT, 0, wave, lane, bfr);
+        double v0[4][kSlots], v1[4][kSlots];
+        int qrow[4][kSlots];                                           // row (inside its tile) of the piece's first element | 16 if the second one is the next row's
+        unsigned myp[4];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            const int rows = m < n_tiles ? min(16, n_valid - 16 * m) : 0;      // (workgroup-uniform)
+            if (m < n_tiles) coop_tile<L>(img, m, bfr, t.offset, tile, LR, 0, NT, wave, lane);
+            __syncthreads();
+            const int n_el = rows * LR;
+#pragma unroll
+            for (int sx = 0; sx < kSlots; ++sx) {
+                const int e0 = 2 * (tid + 256 * sx), e1 = e0 + 1;
+                v0[m][sx] = e0 < n_el ? tile[e0] : 0.0;
+                v1[m][sx] = e1 < n_el ? tile[e1] : 0.0;
+                const int q0 = e0 / LR;
+                qrow[m][sx] = q0 | ((e1 - q0 * LR >= LR) ? 16 : 0);
+            }
+            myp[m] = s_rowpair[16 * m + (lane & 15)];
+            __syncthreads();                                          // the tile is free for the next one
+        }
+        for (int b = b0; b < b1; ++b) {
+            const int fd_e = fd_element(fd, fd_fixed, NC, b);
+            const int vb = fd_e >= 0 ? fd_e / (2 * NC) : -1;
+            const size_t ob = ((size_t)b * t.n_pairs + (size_t)itg) * LR;
+            double* gp = t.out + ob;
+            const bool aligned = (ob & 1) == 0;                       // (16 LR doubles per tile: every tile of the run starts as the run does)
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                if (m >= n_tiles) break;
+                const int n_el = min(16, n_valid - 16 * m) * LR;
+                double* gm = gp + m * 16 * LR;
+                const bool touched = __builtin_amdgcn_ballot_w64((int)(myp[m] & 0xffffu) == vb || (int)(myp[m] >> 16) == vb) != 0;
+#pragma unroll
+                for (int sx = 0; sx < kSlots; ++sx) {
+                    const int e0 = 2 * (tid + 256 * sx), e1 = e0 + 1;
+                    bool w0 = e0 < n_el, w1 = e1 < n_el;
+                    if (touched) {                                    // (the pieces' pairs: looked up in LDS, only in the batch rows that need it)
+                        const int q0 = qrow[m][sx] & 15, q1 = min(15, q0 + (qrow[m][sx] >> 4));
+                        const unsigned pa_ = s_rowpair[16 * m + q0], pb_ = s_rowpair[16 * m + q1];
+                        w0 = w0 && (int)(pa_ & 0xffffu) != vb && (int)(pa_ >> 16) != vb;
+                        w1 = w1 && (int)(pb_ & 0xffffu) != vb && (int)(pb_ >> 16) != vb;
+                    }
+                    if (w0 && w1 && aligned) store_nt2(gm + e0, v0[m][sx], v1[m][sx]);
+                    else {
+                        if (w0) store_nt(gm + e0, v0[m][sx]);
+                        if (w1) store_nt(gm + e1, v1[m][sx]);
+                    }
+                }
+            }
+        }
+        return;
+    }
+#endif
     for (int cg = 0; 8 * cg < NT; ++cg) {
         const int c0 = 128 * cg, cw = min(LR - c0, 128);
         double bfr[2][E::KS];
