@@ -5,6 +5,11 @@ synthetic crossing swarm instead of the image-derived targets.  Solved twice: wi
 differences over the callback, and with the structured Jacobian provider (one `jac` key more).
 
     python examples/example2_swarm_3d.py [numVeh]
+
+The start is the straight lines plus N(0, 0.2) noise (seed 2).  SLSQP on these sufficient-condition constraints is touchy about
+its start: of ten (seed, std) pairs tried at 5 vehicles eight converge in 44-282 iterations to 57.6037, two (seed 1 std 0.2, seed 3
+std 0.5) are still moving at 400 iterations, 2e-5 from feasibility -- which ones depends on the last bits of the callback's
+values (tests/test_gpu_dropin.py holds feasibility and objective, not the iteration count).
 """
 import os
 import sys
@@ -26,11 +31,11 @@ def crossing_swarm(numVeh, seed=3):
     return init + rng.normal(0, 0.05, init.shape), final + rng.normal(0, 0.05, final.shape)
 
 
-def solve(numVeh=5, with_jac=True, maxiter=400, separationRows='all'):
+def solve(numVeh=5, with_jac=True, maxiter=400, separationRows='all', seed=2):
     init, final = crossing_swarm(numVeh)
     bezopt = BezOptimization(numVeh=numVeh, dimension=3, degree=5, minimizeGoal='Euclidean', maxSep=0.9,
                              initPoints=init, finalPoints=final, separationRows=separationRows)
-    x0 = bezopt.generateGuess(std=0.2, seed=1)
+    x0 = bezopt.generateGuess(std=0.2, seed=seed)
     con = {'type': 'ineq', 'fun': bezopt.temporalSeparationConstraints}
     if with_jac:
         con['jac'] = bezopt.temporalSeparationJacobian

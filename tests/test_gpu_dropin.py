@@ -401,7 +401,7 @@ def test_swarm_3d_driver_flow():
     # conditioning, not the kernels); status 9 = iteration limit is accepted beside 0.
     assert r_fd.status in (0, 9) and r_j.status in (0, 9), (r_fd.message, r_j.message)
     # Feasible to 1e-4 on constraint values of order 10 (squared metres): at the cap SLSQP has been seen to stop 1.8e-5
-    # short (separable product weights, rounding differences of 1e-16 in the callback's values), 1e-12 when it converges.
+    # short (separable product weights, rounding differences of 1e-16 in the callback's values, the example's former start), 1e-12 when it converges.
     assert bo.temporalSeparationConstraints(r_fd.x).min() > -1e-4 and bo.temporalSeparationConstraints(r_j.x).min() > -1e-4
     assert abs(r_fd.fun - r_j.fun) < 1e-3 * max(1.0, abs(r_fd.fun))
     guess_fun = bo.objectiveFunction(bo.generateGuess(std=0))
