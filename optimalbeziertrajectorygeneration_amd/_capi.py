@@ -170,7 +170,14 @@ def _i32(a):
 
 
 class ObtgError(RuntimeError):
-    pass
+    """A non-zero return of the C ABI; `.code` is the OBTG_ERR_* value (-5: the shape has no kernel of that kind)."""
+
+    def __init__(self, msg, code=None):
+        RuntimeError.__init__(self, msg)
+        self.code = code
+
+
+ERR_UNSUPPORTED = -5
 
 
 class _PinnedPool(object):
@@ -301,7 +308,7 @@ class Context(object):
             extra = self._lib.obtg_last_error(self._h)
             if extra:
                 msg += " (" + extra.decode() + ")"
-            raise ObtgError("%s: %s" % (what, msg))
+            raise ObtgError("%s: %s" % (what, msg), rc)
 
     @property
     def handle(self):

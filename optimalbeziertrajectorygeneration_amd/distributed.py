@@ -181,32 +181,44 @@ class RowShardedFdStep(object):
         c = self.count
         return dict(sep=torch.empty((c, ctx.len_temporal_sep), dtype=f64, device=device),
                     speed=torch.empty((c, ctx.len_speed), dtype=f64, device=device),
-                    ang=torch.empty((c, ctx.len_ang_rate), dtype=f64, device=device),
+                    ang=torch.empty((c, ctx.len_ang_rate), dtype=f64, device=device) if ctx.dim == 2 else None,   # (optimization.py:171-187: planar only)
                     flag=torch.empty((c, n_hull_pairs), dtype=i32, device=device),
                     p1=torch.empty((c, n_hull_pairs, 3), dtype=f64, device=device),
                     p2=torch.empty((c, n_hull_pairs, 3), dtype=f64, device=device),
                     dist=torch.empty((c, n_hull_pairs), dtype=f64, device=device),
                     status=torch.empty((c, n_hull_pairs), dtype=i32, device=device))
 
-    def run(self, ctx, dY0, n_fixed_cols, h, d_tf_rows, max_sep, speed_bound, speed_is_max, max_rate, out, structured=True,
+    def run(self, ctx, dY0, n_fixed_cols, h, d_tf_rows, max_sep, speed_bound, speed_is_max, max_rate, out, structured="auto",
             max_iter=128, md_cap=256):
         """dY0: device pointer of x's control points; d_tf_rows: device pointer of THIS rank's `count` final times;
-        out: `buffers(...)`.  structured=False: the brute-force sweep on obtg_fd_view_begin_rows (the same numbers)."""
+        out: `buffers(...)`.  structured: True (raises ObtgError where the shape has no structured step: 3-D rows, degree 20,
+        rows beyond 158 KB), False (the brute-force sweep on obtg_fd_view_begin_rows: the same numbers), "auto" (the
+        structured step where there is one, else brute force).  Sets `self.strategy` to what ran."""
+        from . import _capi
+        self.strategy = None
         if self.count == 0:
             return out
-        if structured:
-            ctx.constraint_sweep_fd_structured_dev(dY0, n_fixed_cols, h, d_tf_rows, self.count, max_sep, out["sep"].data_ptr(),
-                                                   speed_bound, speed_is_max, max_rate, out["speed"].data_ptr(), out["ang"].data_ptr(),
-                                                   out["flag"].data_ptr(), out["p1"].data_ptr(), out["p2"].data_ptr(),
-                                                   out["dist"].data_ptr(), None, out["status"].data_ptr(), max_iter, md_cap,
-                                                   row_begin=self.begin)
-        else:
-            ctx.fd_view_begin(dY0, n_fixed_cols, h, self.count, row_begin=self.begin)
+        if structured and out["ang"] is not None:
             try:
-                ctx.constraint_sweep_dev(None, d_tf_rows, self.count, max_sep, out["sep"].data_ptr(), speed_bound, speed_is_max,
-                                         max_rate, out["speed"].data_ptr(), out["ang"].data_ptr(), out["flag"].data_ptr(),
-                                         out["p1"].data_ptr(), out["p2"].data_ptr(), out["dist"].data_ptr(), None,
-                                         out["status"].data_ptr(), max_iter, md_cap)
-            finally:
-                ctx.fd_view_end()
+                ctx.constraint_sweep_fd_structured_dev(dY0, n_fixed_cols, h, d_tf_rows, self.count, max_sep, out["sep"].data_ptr(),
+                                                       speed_bound, speed_is_max, max_rate, out["speed"].data_ptr(),
+                                                       out["ang"].data_ptr(), out["flag"].data_ptr(), out["p1"].data_ptr(),
+                                                       out["p2"].data_ptr(), out["dist"].data_ptr(), None, out["status"].data_ptr(),
+                                                       max_iter, md_cap, row_begin=self.begin)
+                self.strategy = "structured"
+                return out
+            except _capi.ObtgError as e:
+                if structured != "auto" or e.code != _capi.ERR_UNSUPPORTED:
+                    raise
+        elif structured is True:
+            raise _capi.ObtgError("the structured step covers planar rows only", _capi.ERR_UNSUPPORTED)
+        ctx.fd_view_begin(dY0, n_fixed_cols, h, self.count, row_begin=self.begin)
+        try:
+            ctx.constraint_sweep_dev(None, d_tf_rows, self.count, max_sep, out["sep"].data_ptr(), speed_bound, speed_is_max,
+                                     max_rate, out["speed"].data_ptr(), out["ang"].data_ptr() if out["ang"] is not None else None,
+                                     out["flag"].data_ptr(), out["p1"].data_ptr(), out["p2"].data_ptr(), out["dist"].data_ptr(),
+                                     None, out["status"].data_ptr(), max_iter, md_cap)
+        finally:
+            ctx.fd_view_end()
+        self.strategy = "brute force"
         return out

@@ -192,6 +192,7 @@ def test_row_sharded_fd_step_helper():
     assert (whole.world, whole.rank, whole.begin, whole.count) == (1, 0, 0, B)
     ref = whole.run(ctx, d0.data_ptr(), 1, synth.FD_STEP, tf.data_ptr(), 0.9, 5.0, True, 1.0, whole.buffers(ctx, len(pa), "cuda"))
     torch.cuda.synchronize()
+    assert whole.strategy == "structured"
     for structured in (True, False):
         parts = []
         for r in range(3):
@@ -205,3 +206,32 @@ def test_row_sharded_fd_step_helper():
             assert torch.equal(glued.view(torch.uint8), ref[k].view(torch.uint8)), (structured, k)
     ctx.use_own_stream()
     ctx.close()
+    # 3-D rows (the SwarmOfAerialVehicles shapes): no structured step -- "auto" runs the one-launch brute-force sweep on the
+    # row-range view, structured=True says so
+    N3, n3 = 9, 5
+    Y3 = synth.swarm_control_points(N3, 3, n3, seed=8)
+    B3 = N3 * 3 * (n3 - 1) + 1
+    c3 = _capi.Context(N3, 3, n3, 0)
+    c3.set_stream(torch.cuda.current_stream().cuda_stream)
+    c3.set_polygons(None, [0])
+    pa3, pb3 = synth.swarm_pairs(N3, 0)
+    c3.set_hull_pairs(pa3, pb3)
+    d3 = torch.from_numpy(Y3).cuda()
+    tf3 = torch.full((B3,), 7.0, dtype=torch.float64, device="cuda")
+    w3 = RowShardedFdStep(B3)
+    ref3 = w3.run(c3, d3.data_ptr(), 1, synth.FD_STEP, tf3.data_ptr(), 0.9, 5.0, True, 1.0, w3.buffers(c3, len(pa3), "cuda"))
+    torch.cuda.synchronize()
+    assert w3.strategy == "brute force" and ref3["ang"] is None
+    parts = []
+    for r in range(2):
+        st = RowShardedFdStep(B3, world=2, rank=r)
+        parts.append(st.run(c3, d3.data_ptr(), 1, synth.FD_STEP, tf3[st.begin:st.begin + st.count].contiguous().data_ptr(), 0.9, 5.0, True,
+                            1.0, st.buffers(c3, len(pa3), "cuda")))
+        torch.cuda.synchronize()
+    for k in ("sep", "speed", "flag", "dist", "status"):
+        assert torch.equal(torch.cat([p[k] for p in parts], dim=0).view(torch.uint8), ref3[k].view(torch.uint8)), k
+    import pytest
+    with pytest.raises(_capi.ObtgError):
+        w3.run(c3, d3.data_ptr(), 1, synth.FD_STEP, tf3.data_ptr(), 0.9, 5.0, True, 1.0, w3.buffers(c3, len(pa3), "cuda"), structured=True)
+    c3.use_own_stream()
+    c3.close()
