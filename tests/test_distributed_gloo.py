@@ -85,6 +85,21 @@ def test_partition_helpers():
     assert shard_rows(1153, 8, 7) == (1009, 144)
 
 
+def test_row_sharded_fd_step_layout():
+    """RowShardedFdStep's host side (no GPU): the ranks' blocks tile the n_x + 1 rows, ranks beyond the rows get empty
+    blocks and `run` leaves them alone, world / rank default to "no process group"."""
+    from optimalbeziertrajectorygeneration_amd.distributed import RowShardedFdStep
+    steps = [RowShardedFdStep(1153, world=8, rank=r) for r in range(8)]
+    assert [s.count for s in steps] == [145] + [144] * 7 and steps[0].begin == 0
+    assert all(a.begin + a.count == b.begin for a, b in zip(steps, steps[1:])) and steps[-1].begin + steps[-1].count == 1153
+    lone = RowShardedFdStep(7)
+    assert (lone.world, lone.rank, lone.begin, lone.count) == (1, 0, 0, 7)
+    empty = RowShardedFdStep(3, world=5, rank=4)
+    assert empty.count == 0
+    sentinel = {"ang": None}
+    assert empty.run(None, 0, 1, 1e-3, 0, 0.9, 5.0, True, 1.0, sentinel) is sentinel and empty.strategy is None
+
+
 def test_pair_partition_and_batch_sharding_world2():
     world = 2
     ctx = mp.get_context("spawn")
