@@ -23,22 +23,50 @@ def _ctx():
     return _capi.scratch_context()
 
 
+class _Grid(object):
+    """Time span of a curve: its two ends and, on demand only, the sampling grid over them (the
+    accelerated path never samples; drivers that plot do)."""
+    __slots__ = ('ends', 'samples')
+    POINTS = 1001                                          # the reference's grid size (bezier.py:118)
+
+    def __init__(self, t0, tf, samples=None):
+        if samples is None:
+            self.ends = [float(t0), float(tf)]
+        else:                                              # a grid that is handed in decides the span
+            self.ends = [samples[0], samples[-1]]
+        self.samples = samples
+
+    def move_end(self, which, value):
+        self.ends[which] = float(value)
+        self.samples = None                                # a stale grid must not outlive its span
+
+    def grid(self):
+        if not isinstance(self.samples, np.ndarray):
+            self.samples = (np.linspace(self.ends[0], self.ends[1], self.POINTS) if self.samples is None
+                            else np.array(self.samples))
+        return self.samples
+
+
+def _span_end(which, name):
+    return property(lambda self: self._span.ends[which], lambda self, v: self._span.move_end(which, v),
+                    doc='%s of the span; assigning drops a cached tau grid' % name)
+
+
+def _shape_field(axis, off, name):
+    return property(lambda self: None if self._cpts is None else self._cpts.shape[axis] - off, doc=name)
+
+
 class BezierParams(object):
-    """Control points d x (n+1), time span [t0, tf] (reference bezier.py:34-145)."""
+    """Container half of the reference's curve type (bezier.py:34-145): control points d x (n+1) plus the
+    time span.  The reference keeps `_dim` / `_deg` / `_t0` / `_tf` / `_tau` slots side by side and
+    updates them in every setter; here the shape IS dim and deg (read off the array) and the span is
+    one `_Grid`, so there is nothing to keep in step."""
+    _cpts = None
 
     def __init__(self, cpts=None, tau=None, t0=0.0, tf=1.0):
-        self._cpts = None
-        self._dim = None
-        self._deg = None
         if cpts is not None:
             self.cpts = cpts
-        if tau is not None:
-            self._t0 = tau[0]
-            self._tf = tau[-1]
-        else:
-            self._t0 = float(t0)
-            self._tf = float(tf)
-        self._tau = tau
+        self._span = _Grid(t0, tf, tau)
 
     @property
     def cpts(self):
@@ -46,57 +74,23 @@ class BezierParams(object):
 
     @cpts.setter
     def cpts(self, value):
-        if isinstance(value, np.ndarray) and value.ndim == 2 and value.dtype == np.float64:
-            new = value
-        else:
-            new = np.array(value, ndmin=2, dtype=float)   # bezier.py:92
-        self._dim = new.shape[0]
-        self._deg = new.shape[1] - 1
-        self._cpts = new
+        # float64 matrices are taken as they are (the kernels' results arrive that way); anything else --
+        # lists, 1-D arrays, integer arrays -- is promoted the way the reference's setter does (bezier.py:92)
+        ready = isinstance(value, np.ndarray) and value.ndim == 2 and value.dtype == np.float64
+        self._cpts = value if ready else np.array(value, ndmin=2, dtype=float)
 
-    @property
-    def deg(self):
-        return self._deg
-
-    degree = deg
-
-    @property
-    def dim(self):
-        return self._dim
-
-    dimension = dim
-
-    @property
-    def t0(self):
-        return self._t0
-
-    @t0.setter
-    def t0(self, value):
-        self._t0 = float(value)
-        self._tau = None
-
-    @property
-    def tf(self):
-        return self._tf
-
-    @tf.setter
-    def tf(self, value):
-        self._tf = float(value)
-        self._tau = None
+    dim = dimension = _shape_field(0, 0, 'rows of cpts')
+    deg = degree = _shape_field(1, 1, 'columns of cpts, less one')
+    t0 = _span_end(0, 't0')
+    tf = _span_end(1, 'tf')
 
     @property
     def tau(self):
-        if self._tau is None:
-            self._tau = np.linspace(self._t0, self._tf, 1001)
-        elif not isinstance(self._tau, np.ndarray):
-            self._tau = np.array(self._tau)
-        return self._tau
+        return self._span.grid()
 
     @tau.setter
     def tau(self, val):
-        self._t0 = val[0]
-        self._tf = val[-1]
-        self._tau = np.array(val)
+        self._span = _Grid(0.0, 0.0, np.array(val))
 
 
 class Bezier(BezierParams):

@@ -504,92 +504,61 @@ class BezOptimization(object):
     def reshapeVector(self, x):
         """x -> y[(numVeh*dim) x (deg+1)] (optimization.py:242-285).
 
-        SLSQP calls this once per callback, and at Example1's size the fifteen small NumPy operations of the batched
-        form (31 us) cost more than the device call they feed (23 us).  The one-row form copies a template that holds
-        the constant columns and fills in the rest with the same element-wise arithmetic (same bits): 8 us."""
-        m = self.model
-        arrs = (m['initPoints'], m['finalPoints'], m['initSpeeds'], m['finalSpeeds'], m['initAngs'], m['finalAngs'])
-        key = (m['numVeh'], m['dim'], m['deg'], self._numCols) + tuple(a.tobytes() if a.dtype != object else None for a in arrs)
-        t = getattr(self, '_rv_template', None)
-        if t is None or t[0] != key:
-            if any(a.dtype == object for a in arrs[:2]) or (arrs[2][0] is not None and any(a.dtype == object for a in arrs[2:])):
-                return self.reshapeVectors(np.asarray(x, dtype=float)[None])[0]       # unusual inputs: the general form
-            t = (key,) + self._make_rv_template()
-            self._rv_template = t
-        _, Y0, offset, speeds = t
-        x = np.asarray(x, dtype=float)
-        deg = m['deg']
-        if self._timeopt():
-            tf = x[-1]
-            x = x[:-1]
-        else:
-            tf = float(m['tf'])
-        Y = Y0.copy()
-        if speeds is not None:
-            iS, fS, p0x, p0y, pfx, pfy, cI, sI, cF, sF = speeds
-            initMag = iS * tf / deg
-            finalMag = fS * tf / deg
-            Y[::2, 1] = p0x + initMag * cI
-            Y[1::2, 1] = p0y + initMag * sI
-            Y[::2, -2] = pfx - finalMag * cF
-            Y[1::2, -2] = pfy - finalMag * sF
-        Y[:, offset:-offset] = x.reshape((Y.shape[0], self._numCols))
-        return Y
-
-    def _make_rv_template(self):
-        """(constant part of y, first free column, speed-dependent ingredients or None) for reshapeVector."""
-        m = self.model
-        dim, deg, numVeh = m['dim'], m['deg'], m['numVeh']
-        Y0 = np.empty((dim * numVeh, deg + 1))
-        offset = 0
-        if m['initPoints'] is not None and m['initPoints'].dtype != object:
-            offset += 1
-            for i in range(m['initPoints'].shape[0]):
-                Y0[i * dim:(i + 1) * dim, 0] = m['initPoints'][i]
-                Y0[i * dim:(i + 1) * dim, -1] = m['finalPoints'][i]
-        speeds = None
-        if m['initSpeeds'][0] is not None:
-            offset += 1
-            iP, fP = m['initPoints'], m['finalPoints']
-            speeds = (m['initSpeeds'].astype(float), m['finalSpeeds'].astype(float), iP[:, 0].copy(), iP[:, 1].copy(),
-                      fP[:, 0].copy(), fP[:, 1].copy(), np.cos(m['initAngs']), np.sin(m['initAngs']),
-                      np.cos(m['finalAngs']), np.sin(m['finalAngs']))
-        return Y0, offset, speeds
+        SLSQP calls this once per callback, and at Example1's size a dozen small NumPy operations cost more than the
+        device call they feed (23 us).  Everything that does not depend on x -- end points, the headings' sines and
+        cosines -- is worked out once per problem (`_rv_parts`); a call copies that template, sets the two speed
+        columns from tf and drops x into the free columns: 8 us.  `reshapeVectors` is the same thing with a leading
+        batch axis (one row per finite-difference neighbour of x)."""
+        return self.reshapeVectors(x)
 
     def reshapeVectors(self, X):
-        """Batched reshapeVector: X[B][n_x] -> Y[B][(numVeh*dim)][deg+1]."""
-        dim = self.model['dim']
-        deg = self.model['deg']
-        numVeh = self.model['numVeh']
-        initPoints = self.model['initPoints']
-        finalPoints = self.model['finalPoints']
-        initSpeeds = self.model['initSpeeds']
-        finalSpeeds = self.model['finalSpeeds']
-        initAngs = self.model['initAngs']
-        finalAngs = self.model['finalAngs']
-        numCols = self._numCols
-        numRows = dim * numVeh
+        """X[B][n_x] -> Y[B][numVeh*dim][deg+1] (any number of leading axes, none included): the template broadcast
+        over the rows."""
+        template, first_free, headings = self._rv_parts()
         X = np.asarray(X, dtype=float)
-        B = X.shape[0]
-        if self._timeopt():
-            tf = X[:, -1]
-            X = X[:, :-1]
+        if self._timeopt():                                   # time-optimal problems carry tf as the last variable
+            tf, X = (X[..., -1:] if X.ndim > 1 else X[-1]), X[..., :-1]
         else:
-            tf = np.full(B, float(self.model['tf']))
-        Y = np.empty((B, numRows, deg + 1))
-        offset = 0
-        if initPoints is not None:
-            offset += 1
-            for i in range(initPoints.shape[0]):
-                Y[:, i * dim:(i + 1) * dim, 0] = initPoints[i]
-                Y[:, i * dim:(i + 1) * dim, -1] = finalPoints[i]
-        if initSpeeds[0] is not None:
-            offset += 1
-            initMag = initSpeeds[None, :] * tf[:, None] / deg
-            finalMag = finalSpeeds[None, :] * tf[:, None] / deg
-            Y[:, ::2, 1] = initPoints[:, 0] + initMag * np.cos(initAngs)        # X
-            Y[:, 1::2, 1] = initPoints[:, 1] + initMag * np.sin(initAngs)       # Y
-            Y[:, ::2, -2] = finalPoints[:, 0] - finalMag * np.cos(finalAngs)    # X
-            Y[:, 1::2, -2] = finalPoints[:, 1] - finalMag * np.sin(finalAngs)   # Y
-        Y[:, :, offset:-offset] = X.reshape((B, numRows, numCols))
+            tf = float(self.model['tf'])
+        lead = X.shape[:-1]
+        if lead:
+            Y = np.empty(lead + template.shape)
+            Y[...] = template
+        else:
+            Y = template.copy()
+        if headings is not None:
+            # the second / second-to-last control points realise the prescribed speeds: p0 + (v0 tf / deg) (cos, sin)
+            # and pf - (vf tf / deg) (cos, sin); even rows of y are x coordinates, odd rows y coordinates
+            deg = self.model['deg']
+            for col, (speed, px, py, c, s) in ((1, headings[0]), (-2, headings[1])):
+                reach = speed * tf / deg                      # [...][numVeh]; the final end's cos / sin carry the minus
+                Y[..., 0::2, col] = px + reach * c
+                Y[..., 1::2, col] = py + reach * s
+        Y[..., first_free:template.shape[1] - first_free] = X.reshape(lead + (template.shape[0], self._numCols))
         return Y
+
+    def _rv_parts(self):
+        """(template of y with its constant columns set, index of the first free column, per end of the curve
+        (speed, x, y, cos, sin) or None) -- rebuilt when the problem's `model` entries change."""
+        m = self.model
+        fields = [m[k] for k in ('initPoints', 'finalPoints', 'initSpeeds', 'finalSpeeds', 'initAngs', 'finalAngs')]
+        key = (m['numVeh'], m['dim'], m['deg']) + tuple(a.tobytes() if a.dtype != object else id(a) for a in fields)
+        cached = getattr(self, '_rv_cache', None)
+        if cached is not None and cached[0] == key:
+            return cached[1]
+        p0, pf, v0, vf, a0, af = fields
+        dim = m['dim']
+        # atleast_2d(None) is an object array: like the reference, a problem without end points fails on its first
+        # reshape (optimization.py:267-271 assigns None into y) -- float() raises the same TypeError here
+        p0, pf = p0.astype(float), pf.astype(float)
+        template = np.empty((dim * m['numVeh'], m['deg'] + 1))
+        rows = p0.shape[0] * dim
+        template[:rows, 0] = p0.reshape(-1)[:rows]
+        template[:rows, -1] = pf.reshape(-1)[:rows]
+        first_free, headings = 1, None
+        if v0[0] is not None:
+            first_free = 2
+            headings = ((v0.astype(float), p0[:, 0].copy(), p0[:, 1].copy(), np.cos(a0), np.sin(a0)),
+                        (vf.astype(float), pf[:, 0].copy(), pf[:, 1].copy(), -np.cos(af), -np.sin(af)))
+        self._rv_cache = (key, (template, first_free, headings))
+        return self._rv_cache[1]
