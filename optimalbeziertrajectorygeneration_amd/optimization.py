@@ -75,6 +75,18 @@ def _maxAngularRateConstraints(y, nVeh, dim, tf, maxAngRate):
     return _shape_ctx(nVeh, dim, y.shape[1] - 1, DEG_ELEV).ang_rate(y, tf, maxAngRate)[0]
 
 
+# (key of BezOptimization.model, constructor keyword, container) -- optimization.py:49-63 defines the keys
+_MODEL_FIELDS = (
+    ('numVeh', 'numVeh', None), ('dim', 'dimension', None), ('deg', 'degree', None), ('minGoal', 'minimizeGoal', None),
+    ('maxSep', 'maxSep', None), ('minSpeed', 'minSpeed', None), ('maxSpeed', 'maxSpeed', None),
+    ('maxAngRate', 'maxAngRate', None),
+    ('initPoints', 'initPoints', np.atleast_2d), ('finalPoints', 'finalPoints', np.atleast_2d),
+    ('initSpeeds', 'initSpeeds', np.atleast_1d), ('finalSpeeds', 'finalSpeeds', np.atleast_1d),
+    ('initAngs', 'initAngs', np.atleast_1d), ('finalAngs', 'finalAngs', np.atleast_1d),
+    ('tf', 'tf', None),
+)
+
+
 class BezOptimization(object):
     def __init__(self,
                  numVeh=1,
@@ -116,27 +128,13 @@ class BezOptimization(object):
         self._device = device
         self.separationRows = separationRows
 
-        self._numCols = degree + 1
-        if initPoints is not None:
-            self._numCols -= 2
-        if initSpeeds is not None:
-            self._numCols -= 2
-
-        self.model = {'numVeh': numVeh,
-                      'dim': dimension,
-                      'deg': degree,
-                      'minGoal': minimizeGoal,
-                      'maxSep': maxSep,
-                      'minSpeed': minSpeed,
-                      'maxSpeed': maxSpeed,
-                      'maxAngRate': maxAngRate,
-                      'initPoints': np.atleast_2d(initPoints),
-                      'finalPoints': np.atleast_2d(finalPoints),
-                      'initSpeeds': np.atleast_1d(initSpeeds),
-                      'finalSpeeds': np.atleast_1d(finalSpeeds),
-                      'initAngs': np.atleast_1d(initAngs),
-                      'finalAngs': np.atleast_1d(finalAngs),
-                      'tf': tf}
+        given = locals()
+        # `model` keeps the reference's keys (drivers read and edit them, Examples/*.py); what each holds is decided by
+        # _MODEL_FIELDS: scalars as given, per-vehicle data as arrays with a vehicle axis
+        self.model = {key: (given[kw] if shape is None else shape(given[kw])) for key, kw, shape in _MODEL_FIELDS}
+        # free control points per coordinate row: the end points, and with prescribed speeds their neighbours, are
+        # not variables (two columns each)
+        self._numCols = degree + 1 - 2 * sum(given[kw] is not None for kw in ('initPoints', 'initSpeeds'))
         self._ctxs = {}
 
     # ------------------------------------------------------------------ device contexts

@@ -786,8 +786,39 @@ def gen_c1_text():
     save("c1_text.npz", **d)
 
 
+def gen_fullsize():
+    """BASELINE configs 4 and 5 at their FULL shapes through the reference's own closures
+    (optimization.py:311-459): until round 5 the reference had seen these degrees / elevations only on
+    8- and 12-vehicle swarms (`c3s_R100`, `c4s` in constraints.npz) and the full shapes were held to the
+    oracle alone.  C5 (64 vehicles, degree 10, DEG_ELEV 100): every output in full (2.2 MB).  C4 (256
+    vehicles, degree 15): speed and angular-rate rows in full; of the 1 011 840 separation values the
+    per-pair minimum, the per-pair sum (both over a pair's 31 control points, so every value is
+    pinned through one of them) and every 7th value."""
+    import time
+    d = {}
+    for name, N, n, R in (("c5", 64, 10, 100), ("c4", 256, 15, 0)):
+        Y = synth.swarm_control_points(N, 2, n, seed=1234)
+        t0 = time.perf_counter()
+        r = ref_constraints(Y, N, 2, 10.0, 0.9, 5.0, 0.3, 1.0, R)
+        print("  %s: reference closures %.2f s, tsep %d, speed %d, angrate %d values" % (
+            name, time.perf_counter() - t0, r["tsep"].size, r["maxspeed"].size, r["angrate"].size))
+        d[name + "_Y"] = Y
+        d[name + "_par"] = np.array([N, 2, n, R, 10.0, 0.9, 5.0, 0.3, 1.0])
+        d[name + "_maxspeed"], d[name + "_minspeed"], d[name + "_angrate"] = r["maxspeed"], r["minspeed"], r["angrate"]
+        if name == "c5":
+            d[name + "_tsep"] = r["tsep"]
+        else:
+            L = 2 * n + R + 1
+            blk = r["tsep"].reshape(-1, L)
+            d[name + "_tsep_min"] = blk.min(axis=1)
+            d[name + "_tsep_sum"] = blk.sum(axis=1)
+            d[name + "_tsep_every7"] = r["tsep"][::7].copy()
+            d[name + "_tsep_absmax"] = np.array(np.abs(r["tsep"]).max())
+    save("fullsize.npz", **d)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["tables", "ops", "problem", "constraints", "gjk", "mindist", "c5", "spatial", "nearstop", "sequential", "spatial_fd", "mindist_script", "c1_text"]
+    which = sys.argv[1:] or ["tables", "ops", "problem", "constraints", "gjk", "mindist", "c5", "spatial", "nearstop", "sequential", "spatial_fd", "mindist_script", "c1_text", "fullsize"]
     for w in which:
         if w == "none":          # import-only (exploration)
             continue

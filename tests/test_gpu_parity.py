@@ -425,10 +425,93 @@ def test_full_size_configs_vs_oracle(capi, oracle, synth, name):
     if d == 2:
         an = ctx.ang_rate(Yb, 10.0, 1.0)
         assert_close(an, o[2], RTOL, name + " ang")
-        assert elementwise_rel(an, o[2]) <= (1e-9 if R == 0 else 1e-7), elementwise_rel(an, o[2])
+        # element-wise: 1e-9 like every other family (until round 5 C5 was admitted 1e-7 here; measured 3.0e-10)
+        assert elementwise_rel(an, o[2]) <= 1e-9, elementwise_rel(an, o[2])
     L = 2 * n + R + 1
     assert_close(ctx.temporal_sep_min(Yb, 0.9), o[0].reshape(2, -1, L).min(axis=2), RTOL, name + " min")
     ctx.close()
+
+
+def _err_table(got, ref, N=None):
+    """(scale-aware max, element-wise max over values above 1e-6 of the vector's largest, count beyond 1e-9 in each measure,
+    worst per-row scale-aware error when the vector is N rows)"""
+    got, ref = np.asarray(got, np.float64).reshape(-1), np.asarray(ref, np.float64).reshape(-1)
+    fin = np.isfinite(ref)
+    assert (np.isfinite(got) == fin).all()
+    scale = np.abs(ref[fin]).max()
+    e = np.abs(got - ref)[fin]
+    sa = e / np.maximum(np.abs(ref[fin]), scale)
+    big = np.abs(ref[fin]) > 1e-6 * scale
+    ew = e[big] / np.abs(ref[fin][big])
+    out = dict(scale_aware=float(sa.max()), elementwise=float(ew.max()), n_beyond_scale_aware=int((sa > 1e-9).sum()),
+               n_beyond_elementwise=int((ew > 1e-9).sum()), n=int(ref.size))
+    if N:
+        g2, r2 = got.reshape(N, -1), ref.reshape(N, -1)
+        pr = np.abs(g2 - r2) / np.maximum(np.abs(r2), np.abs(r2).max(axis=1, keepdims=True))
+        out["per_row"] = float(np.nanmax(pr))
+        out["n_beyond_per_row"] = int((pr > 1e-9).sum())
+    return out
+
+
+@pytest.mark.parametrize("name", ["c5", "c4"])
+def test_full_size_c4_c5_against_the_reference(capi, golden_dir, name, capsys):
+    """BASELINE configs 4 and 5 at FULL size against the REFERENCE's own closures (tests/golden/fullsize.npz; gen_golden.py
+    `fullsize` ran optimization.py:311-459 on the seeded swarms): C5 -- 64 vehicles, degree 10, DEG_ELEV 100 -- every one of
+    its 243 936 separation, 7 744 speed and 28 224 angular-rate values, the angular rate in all three orders of
+    operations; C4 -- 256 vehicles, degree 15 -- speed / angular rate in full and the 1 011 840 separation values through
+    per-pair minimum (also from the device's own reduction, obtg_temporal_sep_min), per-pair sum and every 7th value.
+    For each family the table printed below counts the values beyond 1e-9 (scale-aware; element-wise over values above
+    1e-6 of their vector's largest; per vehicle row): the bar is ZERO for every family and every order at these shapes --
+    the near-stop exception (test_near_stop_angular_rate_on_device) is a property of that stress shape, not of C5."""
+    import json
+    import os
+    g = _load(golden_dir, "fullsize.npz")
+    N, d, n, R, tf, ms, vmax, vmin, wmax = g[name + "_par"]
+    N, d, n, R = int(N), int(d), int(n), int(R)
+    Y = g[name + "_Y"][None]
+    report = {}
+    ctx = capi.Context(N, d, n, R)
+    sep = ctx.temporal_sep(Y, ms)[0]
+    L = 2 * n + R + 1
+    if name == "c5":
+        report["separation"] = _err_table(sep, g["c5_tsep"])
+        assert_close(sep, g["c5_tsep"], 1e-12, "C5 separation rows vs the reference")
+        assert_close(ctx.temporal_sep_min(Y, ms)[0], g["c5_tsep"].reshape(-1, L).min(axis=1), 1e-12, "C5 per-pair minima")
+    else:
+        blk = sep.reshape(-1, L)
+        report["separation_every7"] = _err_table(sep[::7], g["c4_tsep_every7"])
+        report["separation_pair_min"] = _err_table(blk.min(axis=1), g["c4_tsep_min"])
+        assert_close(sep[::7], g["c4_tsep_every7"], 1e-12, "C4 every 7th separation value vs the reference")
+        assert_close(blk.min(axis=1), g["c4_tsep_min"], 1e-12, "C4 per-pair minima vs the reference")
+        assert_close(ctx.temporal_sep_min(Y, ms)[0], g["c4_tsep_min"], 1e-12, "C4 per-pair minima, reduced on the device")
+        assert np.abs(blk.sum(axis=1) - g["c4_tsep_sum"]).max() <= 31 * 1e-12 * float(g["c4_tsep_absmax"])
+    sp = ctx.speed(Y, tf, vmax, True)[0]
+    report["max_speed"] = _err_table(sp, g[name + "_maxspeed"], N)
+    assert_close(sp, g[name + "_maxspeed"], 1e-12, name + " max-speed rows vs the reference")
+    assert_close(ctx.speed(Y, tf, vmin, False)[0], g[name + "_minspeed"], 1e-12, name + " min-speed rows vs the reference")
+    for order, oname in ((0, "fast"), (1, "reference"), (2, "exact")):
+        if R == 0 and order:
+            continue                                       # DEG_ELEV = 0 has one order of operations
+        ctx.set_ang_rate_order(order)
+        an = ctx.ang_rate(Y, tf, wmax)[0]
+        t = _err_table(an, g[name + "_angrate"], N)
+        report["ang_rate_" + oname] = t
+        assert t["n_beyond_scale_aware"] == 0 and t["n_beyond_elementwise"] == 0 and t["n_beyond_per_row"] == 0, (oname, t)
+    ctx.close()
+    for k, t in report.items():
+        assert t["n_beyond_scale_aware"] == 0 and t["n_beyond_elementwise"] == 0, (k, t)
+    with capsys.disabled():
+        print("\n%s at full size against the reference (values beyond 1e-9: scale-aware / element-wise / per row)" % name.upper())
+        for k, t in report.items():
+            print("  %-22s n=%-7d max %.2e / %.2e / %s   beyond 1e-9: %d / %d / %s" % (
+                k, t["n"], t["scale_aware"], t["elementwise"], "%.2e" % t["per_row"] if "per_row" in t else "-",
+                t["n_beyond_scale_aware"], t["n_beyond_elementwise"], t.get("n_beyond_per_row", "-")))
+    try:
+        os.makedirs("gpurun_out", exist_ok=True)
+        with open("gpurun_out/fullsize_parity_%s.json" % name, "w") as f:
+            json.dump(report, f, indent=1)
+    except OSError:
+        pass
 
 
 def test_pair_partition_large_swarm(capi, synth):
@@ -1084,7 +1167,7 @@ def test_near_stop_angular_rate_on_device(capi, oracle, golden_dir, capsys):
                     assert (np.isfinite(got[v]) == fin).all()
                     el = np.abs(got[v][fin] - exact[v][fin]) / np.maximum(np.abs(exact[v][fin]), 1e-6 * np.abs(exact[v][fin]).max())
                     assert el.max() <= 1e-11, (tf, v, el.max())
-                assert err(got, exact, 0) <= 1e-13 and abs(err(got, ref, 0) - err(ref, exact, 0)) <= 1e-11
+                assert err(got, exact, 0) <= NEAR_STOP_BOUND_EXACT[2] and abs(err(got, ref, 0) - err(ref, exact, 0)) <= 1e-11
             e_ref, e_exact = err(got, ref, 0), err(got, exact, 0)
             report.append("tf %g %s: near-stop vehicle %.2e from the reference, %.2e from the exact value "
                           "(the reference: %.2e from exact)" % (tf, name, e_ref, e_exact, err(ref, exact, 0)))
@@ -1098,8 +1181,10 @@ def test_near_stop_angular_rate_on_device(capi, oracle, golden_dir, capsys):
 # measured on MI355X (round 3): default order 3.1e-10 / 5.2e-10 from the exact value at tf = 10 / 14.3 (the reference
 # itself: 3.0e-9 / 7.2e-10), reference order 1.6e-9 / 3.1e-9; against the reference 3.4e-9 / 2.1e-10 and 4.6e-9 / 2.4e-9
 # exact order (round 4): within 1e-13 of the exact value; from the reference then by the reference's own error (3.1e-9 / 7.3e-10)
-NEAR_STOP_BOUND_EXACT = (2e-9, 1e-8, 1e-13)
-NEAR_STOP_BOUND_REF = (1e-8, 1e-8, 4e-9)
+# round 5: the bounds are 1.5 x the worst of the two tf values as measured in GPUTEST_r04 (from the exact value 5.50e-10 /
+# 3.14e-9 / 5.75e-15; from the reference 3.43e-9 / 4.64e-9 / 3.04e-9) -- until then they were 2-17 x looser than measured
+NEAR_STOP_BOUND_EXACT = (8.3e-10, 4.7e-9, 8.7e-15)
+NEAR_STOP_BOUND_REF = (5.2e-9, 7.0e-9, 4.6e-9)
 
 
 def test_ang_rate_with_elevation_both_orders(capi, oracle, synth, golden_dir):
@@ -1516,6 +1601,32 @@ def test_structured_fd_step_is_bit_identical_to_the_brute_force_sweep(capi, synt
     assert ks == {"pair_sweep": 1}, ks                                     # ONE launch
     for key in a:
         assert torch.equal(a[key].view(torch.uint8), b[key].view(torch.uint8)), (shape, tf_rows, key)
+    if shape in ("C5_like_R100", "C4_like_large_rows") and tf_rows != "every_row_its_own_tf":
+        # round 5: the structured launch's OWN buffers against the oracle, directly (until then only C3's were, through
+        # bench.py's fd_structured.parity; here the comparison above made the oracle evidence transitive): the elevated
+        # cooperative kinds (C5-like) and the two-workgroups-per-CU form on 70 KB rows (C4-like).  Rows: the
+        # unperturbed one, first / last perturbed, rows whose tf differs (where the D kind evaluates in full), one per XCD residue.
+        from oracle import oracle as O
+        O.build()
+        rows = sorted(set([0, 1, 2, 9, 11, B - 1] + [B // 2 + k for k in range(8)]) & set(range(B)))
+        n_x = N * 2 * (n + 1 - 2 * fixed)
+        ncol = n + 1 - 2 * fixed
+        Yr = np.repeat(Y[None], len(rows), axis=0)
+        for i, r in enumerate(rows):
+            if r:
+                rr, cc = divmod((r - 1) % n_x, ncol)
+                Yr[i, rr, fixed + cc] = Y[rr, fixed + cc] + h          # the view's row r (obtg_fd_view_begin: x + h e_r)
+        for i, r in enumerate(rows):
+            o_sep, o_sp, o_an = O.eval_batch(Yr[i:i + 1], float(tf[r]), N, 2, R, 0.9, 4.0, 1.5, nthreads=8)
+            assert_close(b["sep"][r].cpu().numpy(), o_sep[0], RTOL, "%s: structured step, separation rows of batch row %d vs oracle" % (shape, r))
+            assert_close(b["sp"][r].cpu().numpy(), o_sp[0], RTOL, "structured step, speed rows of batch row %d" % r)
+            assert_close(b["an"][r].cpu().numpy(), o_an[0], RTOL, "structured step, angular rate of batch row %d" % r)
+            if Ps:
+                hp, ho = synth.pack_polys(synth.hulls_from_Y(Yr[i], 2) + (statics if shape == "C5_like_R100" else synth.polygon_obstacles(M, seed=41) if M else []))
+                og = O.gjk_pairs(hp, ho, pa, pb, md_cap=500)
+                assert (b["flag"][r].cpu().numpy() == og["flag"]).all() and (b["ns"][r].cpu().numpy() == og["n_support"]).all(), (shape, r)
+                sepd = og["flag"] == 1
+                assert np.abs(b["dist"][r].cpu().numpy()[sepd] - og["dist"][sepd]).max() <= 1e-12 * max(1.0, np.abs(og["dist"][sepd]).max())
     ctx.use_own_stream()
     ctx.close()
 
