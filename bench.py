@@ -261,6 +261,8 @@ def main():
     if args.mode == "rows":          # one iteration's rows over the ranks: contiguous balanced blocks
         from optimalbeziertrajectorygeneration_amd import distributed as _dd
         row_begin, B = _dd.shard_rows(B_total, world, rank)
+        if B_total < world:          # (every rank decides alike: nobody is left waiting in a barrier)
+            raise SystemExit("bench.py --mode rows: %d rows over %d ranks would leave ranks without a row" % (B_total, world))
         if args.materialise:
             raise SystemExit("bench.py --mode rows evaluates row ranges of a view (obtg_fd_view_begin_rows): not with --materialise")
     seed = 1234 + (1000 * rank if args.mode == "batch" else 0)   # batch mode: every rank its own swarm instance
@@ -664,6 +666,7 @@ def main():
             for t_ in (o_sep, o_sp):
                 t_.fill_(float("nan"))
             g_flag.fill_(-7)
+            torch.cuda.synchronize()      # torch filled on ITS stream; the library launches on the context's own
             for _ in range(max(args.warmup, 3)):
                 structured_rows()
             barrier()
@@ -720,7 +723,7 @@ def main():
                                              "once per step for the others" if use_view
                                              else "written to HBM by obtg_fd_batch_dev each step"), P_t,
                                        "max_ang_rate+" if d == 2 else "", P_s),
-                       "ang_rate_order": args.ang_order, "mode": args.mode, "rows_per_step_all_ranks": B_total if args.mode == "rows" else world * B,
+                       "ang_rate_order": args.ang_order, "ang_rate_order_in_effect": (("fast", "reference", "exact")[ctx.ang_rate_order_in_effect()] if d == 2 else None), "mode": args.mode, "rows_per_step_all_ranks": B_total if args.mode == "rows" else world * B,
                        "row_range_of_rank0": [row_begin, B] if args.mode == "rows" else None, "rows_structured": rows_structured,
                        "gather_minima": bool(d_min is not None), "checksum": checksum,
                        "launches_per_step": len(kernels), "streams": 2 if two_streams else 1, "stream": stream_note,

@@ -71,6 +71,25 @@ enum {
 };
 
 const char* obtg_strerror(int code);
+
+/* ABI revision.  Bumped whenever an EXISTING symbol changes meaning (new symbols alone do not bump it), so that a caller
+ * bound against an older header can notice at load time.
+ *   4  round 4: obtg_ctx_set_stream(ctx, NULL) selects the NULL (legacy default) stream -- the handle is taken as given.
+ *      Until then NULL meant "the context's own non-blocking stream"; that meaning moved to obtg_ctx_use_own_stream.
+ *      A caller written against revision <= 3 that passes NULL to get the private stream back still links and runs, but
+ *      now serialises with the legacy stream: call obtg_ctx_use_own_stream instead.
+ *   5  round 5: nothing changed meaning; new: obtg_abi_version, obtg_fast_kernels, obtg_ctx_ang_rate_order_in_effect, obtg_temporal_sep_active[_dev],
+ *      obtg_rank_gather_* (the collective behind the C ABI); 9 control points (degree 8) joined the specialised counts. */
+#define OBTG_ABI_VERSION 5
+int obtg_abi_version(void);
+
+/* Which specialised (template-instantiated) kernel families exist for curves of `deg` in `dim` dimensions -- a bit mask:
+ *   1  separation / speed rows, one-vs-many, structured separation Jacobian blocks (2-D and 3-D)
+ *   2  angular rate at DEG_ELEV = 0, the hull sweeps on deg + 1 points per object, the one-launch steps
+ *   4  DEG_ELEV > 0: separation + dynamics in one launch, the elevated structured step
+ * 0: every family of that shape runs on the any-degree kernels (one wave per item).  The list itself lives in ONE place,
+ * csrc/obtg_internal.h (OBTG_NC_*); callers that pick a code path by degree ask here instead of repeating it. */
+int obtg_fast_kernels(int dim, int deg);
 /* last HIP error string seen by this context (empty when none) */
 const char* obtg_last_error(const obtg_ctx*);
 /* number of usable gfx950 devices (0 when none / no HIP runtime) */
@@ -114,6 +133,11 @@ int obtg_ctx_set_deg_elev(obtg_ctx*, int deg_elev);
  * 1e-8 to cancellation -- once more in double-double arithmetic, rounded once: those rows are then within a few 1e-16
  * of the exact rational value.  One more (small) launch behind the dynamics launch; not in the structured step. */
 int obtg_ctx_set_ang_rate_order(obtg_ctx*, int elevate_first);
+/* The order that is IN EFFECT for the context's present shape -- 0, 1 or 2 as above, negative = error.  A request holds
+ * only where its kernels exist: DEG_ELEV = 0 has one order (0); without a products-then-elevation kernel for (deg, R) --
+ * deg + 1 outside obtg_fast_kernels & 2, deg > 15, 4 R > 1000 -- the any-degree kernel runs, which elevates first (1),
+ * and the double-double pass of order 2 is not run.  Callers that report which order produced their numbers ask here. */
+int obtg_ctx_ang_rate_order_in_effect(obtg_ctx*);
 int obtg_sync(obtg_ctx*);
 
 /* sizes of one evaluation row's outputs, in doubles */
@@ -166,7 +190,7 @@ int obtg_temporal_sep_fd_dev(obtg_ctx*, const double* dY0, int n_pert, const int
  * callback, n_x + 1 for a finite-difference batch of the vehicle being planned), many[K][dim][deg+1] the curves it is
  * checked against.  No pair table: the context fixes (dim, deg, DEG_ELEV) only -- its vehicle count is not used -- and K
  * may differ from call to call (the planner's K grows by one per vehicle).  Degrees with a specialised kernel
- * (deg + 1 in {4, 6, 8, 11, 16, 21}), others OBTG_ERR_UNSUPPORTED. */
+ * (obtg_fast_kernels(dim, deg) & 1), others OBTG_ERR_UNSUPPORTED. */
 int obtg_one_vs_many_min(obtg_ctx*, const double* one, int B, const double* many, int K, double max_sep, double* out /*[B][K]*/);
 int obtg_one_vs_many_min_dev(obtg_ctx*, const double* d_one, int B, const double* d_many, int K, double max_sep, double* d_out);
 
@@ -278,7 +302,7 @@ int obtg_constraint_sweep_dev(obtg_ctx*, const double* dY, const double* d_tf, i
  * results into all B rows, while one workgroup per row evaluates only the N-1 separation pairs, the hull pairs and the
  * vehicle its advanced control point touches.  Outputs are those of obtg_constraint_sweep_dev inside the same view,
  * bit for bit (the same device functions evaluate every pair); the launch is bound by its stores instead of by gjkNew.
- * Planar shapes (deg + 1 in {4, 6, 8, 11}, with or without point obstacles -- constant curves of the separation pair table,
+ * Planar shapes (obtg_fast_kernels & 4: deg + 1 in {4, 6, 8, 9, 11}, with or without point obstacles -- constant curves of the separation pair table,
  * optimization.py:86-98 --, angular rate wanted, a row's objects within 40 KB of LDS), any
  * DEG_ELEV with 2 deg + DEG_ELEV + 1 <= 512 -- for DEG_ELEV > 0 (where the brute-force step is two launches) the separation
  * streams are the elevated rows and the dynamics groups are the elevated kernel's; at DEG_ELEV = 0 also deg + 1 = 16 and, for

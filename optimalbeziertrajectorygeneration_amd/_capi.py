@@ -29,6 +29,8 @@ _d = C.c_double
 _SIGNATURES = {
     "obtg_strerror": (C.c_char_p, [_i]),
     "obtg_last_error": (C.c_char_p, [_vp]),
+    "obtg_abi_version": (_i, []),
+    "obtg_fast_kernels": (_i, [_i, _i]),
     "obtg_device_count": (_i, []),
     "obtg_abi_symbols": (_vp, []),
     "obtg_host_alloc": (_i, [C.c_size_t, C.POINTER(_vp)]),
@@ -39,6 +41,7 @@ _SIGNATURES = {
     "obtg_ctx_use_own_stream": (_i, [_vp]),
     "obtg_ctx_set_deg_elev": (_i, [_vp, _i]),
     "obtg_ctx_set_ang_rate_order": (_i, [_vp, _i]),
+    "obtg_ctx_ang_rate_order_in_effect": (_i, [_vp]),
     "obtg_ctx_set_second_speed_bound": (_i, [_vp, _d, _i, _vp]),
     "obtg_constraint_sweep_fd_structured_dev": (_i, [_vp, _vp, _i, _d, _vp, _i, _d, _vp, _d, _i, _d, _vp, _vp, _i, _i, _vp, _vp,
                                                      _vp, _vp, _vp, _vp]),
@@ -155,6 +158,15 @@ def load():
 
 def device_count():
     return load().obtg_device_count()
+
+
+def abi_version():
+    return load().obtg_abi_version()
+
+
+def fast_kernels(dim, deg):
+    """obtg_fast_kernels: bit 0 separation / speed rows, bit 1 angular rate + one-launch steps, bit 2 the DEG_ELEV > 0 forms."""
+    return load().obtg_fast_kernels(int(dim), int(deg))
 
 
 def _ptr(a):
@@ -332,6 +344,14 @@ class Context(object):
         order of operations; 2 = the default order plus a double-double recompute of near-stop vehicles' rows
         (include/obtg.h obtg_ctx_set_ang_rate_order)."""
         self._check(self._lib.obtg_ctx_set_ang_rate_order(self._h, int(elevate_first)), "obtg_ctx_set_ang_rate_order")
+
+    def ang_rate_order_in_effect(self):
+        """0 / 1 / 2 = the order of operations the angular rate of this shape really runs in (a request for 'exact' or
+        'fast' holds only where those kernels exist: include/obtg.h obtg_ctx_ang_rate_order_in_effect)."""
+        rc = self._lib.obtg_ctx_ang_rate_order_in_effect(self._h)
+        if rc < 0:
+            self._check(rc, "obtg_ctx_ang_rate_order_in_effect")
+        return rc
 
     def sync(self):
         self._check(self._lib.obtg_sync(self._h), "obtg_sync")

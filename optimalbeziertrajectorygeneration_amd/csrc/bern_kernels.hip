@@ -1047,8 +1047,9 @@ static int dispatch_ns(obtg_ctx* c, const NsParams& p, int B, int kernel_id)
     const int nc = c->deg + 1;
 #define OBTG_CASE(NC_, D_) \
     if (nc == NC_ && c->dim == D_) return launch_ns_t<NC_, D_, MODE, MINONLY>(c, p, B, kernel_id);
-    OBTG_CASE(4, 2) OBTG_CASE(4, 3) OBTG_CASE(6, 2) OBTG_CASE(6, 3) OBTG_CASE(8, 2) OBTG_CASE(8, 3)
-    OBTG_CASE(11, 2) OBTG_CASE(11, 3) OBTG_CASE(16, 2) OBTG_CASE(16, 3) OBTG_CASE(21, 2) OBTG_CASE(21, 3)
+#define OBTG_CASE_D(NC_) OBTG_CASE(NC_, 2) OBTG_CASE(NC_, 3)
+    OBTG_NC_SEP(OBTG_CASE_D)
+#undef OBTG_CASE_D
 #undef OBTG_CASE
     return OBTG_ERR_UNSUPPORTED;
 }
@@ -1056,8 +1057,7 @@ static int dispatch_ns(obtg_ctx* c, const NsParams& p, int B, int kernel_id)
 static bool fast_shape(const obtg_ctx* c)
 {
     const int nc = c->deg + 1;
-    const bool ncok = nc == 4 || nc == 6 || nc == 8 || nc == 11 || nc == 16 || nc == 21;
-    return ncok && (c->dim == 2 || c->dim == 3) && c->R <= 512;
+    return nc_in_sep(nc) && (c->dim == 2 || c->dim == 3) && c->R <= 512;
 }
 
 static int gen_common(obtg_ctx* c, GenParams& g)
@@ -1312,14 +1312,26 @@ static int launch_dyn_elev_t(obtg_ctx* c, AngElevParams q, int kernel_id)
 static bool dyn_fast_elev(const obtg_ctx* c)
 {
     const int nc = c->deg + 1;
-    return c->dim == 2 && c->R > 0 && !c->ang_elevate_first && c->d_ang_T4.p != nullptr && c->d_ang_cv2.p != nullptr &&
-           (nc == 4 || nc == 6 || nc == 8 || nc == 11 || nc == 16);
+    return c->dim == 2 && c->R > 0 && !c->ang_elevate_first && c->d_ang_T4.p != nullptr && c->d_ang_cv2.p != nullptr && nc_in_dyn(nc);
 }
 
 static bool dyn_fast(const obtg_ctx* c)
 {
     const int nc = c->deg + 1;
-    return c->dim == 2 && c->R == 0 && (nc == 4 || nc == 6 || nc == 8 || nc == 11 || nc == 16);
+    return c->dim == 2 && c->R == 0 && nc_in_dyn(nc);
+}
+
+// Which order of operations the angular rate of this context's shape REALLY runs in (obtg_ctx_ang_rate_order_in_effect):
+// the request of obtg_ctx_set_ang_rate_order holds only where the kernels it names exist.
+int ang_rate_order_in_effect(obtg_ctx* c)
+{
+    if (c->dim != 2) return OBTG_ERR_ARG;
+    if (c->R == 0) return 0;                       // one order of operations: nothing to choose
+    if (c->ang_elevate_first) return 1;
+    int rc = ensure_tables(c);
+    if (rc) return rc;
+    if (!dyn_fast_elev(c)) return 1;               // no products-then-elevation kernel for this (deg, R): the any-degree kernel elevates first
+    return c->ang_exact ? 2 : 0;
 }
 
 // shapes whose dynamics kernels form a virtual finite-difference batch on the fly (see obtg_ctx::fd)
@@ -1353,8 +1365,9 @@ int launch_temporal_sep_fd(obtg_ctx* c, const double* dY0, int n_pert, const int
     const int nc = c->deg + 1;
     void (*kern)(const TsepFdParams) = nullptr;
 #define OBTG_CASE(NC_, D_) if (nc == NC_ && c->dim == D_) kern = k_tsep_fd<NC_, D_>;
-    OBTG_CASE(4, 2) OBTG_CASE(4, 3) OBTG_CASE(6, 2) OBTG_CASE(6, 3) OBTG_CASE(8, 2) OBTG_CASE(8, 3)
-    OBTG_CASE(11, 2) OBTG_CASE(11, 3) OBTG_CASE(16, 2) OBTG_CASE(16, 3) OBTG_CASE(21, 2) OBTG_CASE(21, 3)
+#define OBTG_CASE_D(NC_) OBTG_CASE(NC_, 2) OBTG_CASE(NC_, 3)
+    OBTG_NC_SEP(OBTG_CASE_D)
+#undef OBTG_CASE_D
 #undef OBTG_CASE
     if (!kern) return OBTG_ERR_UNSUPPORTED;
     ScopedKernelTimer t(c, OBTG_K_TEMPORAL_SEP);
@@ -1377,8 +1390,9 @@ int launch_one_vs_many_min(obtg_ctx* c, const double* d_one, int B, const double
     const int nc = c->deg + 1;
     void (*kern)(const OneManyParams) = nullptr;
 #define OBTG_CASE(NC_, D_) if (nc == NC_ && c->dim == D_) kern = k_one_vs_many<NC_, D_>;
-    OBTG_CASE(4, 2) OBTG_CASE(4, 3) OBTG_CASE(6, 2) OBTG_CASE(6, 3) OBTG_CASE(8, 2) OBTG_CASE(8, 3)
-    OBTG_CASE(11, 2) OBTG_CASE(11, 3) OBTG_CASE(16, 2) OBTG_CASE(16, 3) OBTG_CASE(21, 2) OBTG_CASE(21, 3)
+#define OBTG_CASE_D(NC_) OBTG_CASE(NC_, 2) OBTG_CASE(NC_, 3)
+    OBTG_NC_SEP(OBTG_CASE_D)
+#undef OBTG_CASE_D
 #undef OBTG_CASE
     if (!kern) return OBTG_ERR_UNSUPPORTED;
     // small problems: 64-lane workgroups spread a few hundred items over more CUs
@@ -1430,7 +1444,7 @@ int launch_sep_dynamics_elev(obtg_ctx* c, const double* dY, int B, double max_se
     static const bool on = !(getenv("OBTG_SEP_DYN_ELEV") && getenv("OBTG_SEP_DYN_ELEV")[0] == '0');
     const int nc = c->deg + 1;
     if (!on || B <= 0 || c->R <= 0 || c->dim != 2 || !f.d_out_ang || !f.d_tf || !d_out_sep || c->n_pairs <= 0 ||
-        !(nc == 4 || nc == 6 || nc == 8 || nc == 11)) return OBTG_ERR_UNSUPPORTED;
+        !nc_in_elev(nc)) return OBTG_ERR_UNSUPPORTED;
     int rc = ensure_tables(c);
     if (rc) return rc;
     if (!dyn_fast_elev(c) || !fast_shape(c)) return OBTG_ERR_UNSUPPORTED;
@@ -1453,10 +1467,9 @@ int launch_sep_dynamics_elev(obtg_ctx* c, const double* dY, int B, double max_se
     }
     sp.dyn.cv4 = c->d_ang_T4.as<double>(); sp.dyn.cv2 = c->d_ang_cv2.as<double>(); sp.dyn.R = c->R;
     switch (nc) {
-        case 4: return launch_sep_dyn_elev_t<4>(c, sp, B);
-        case 6: return launch_sep_dyn_elev_t<6>(c, sp, B);
-        case 8: return launch_sep_dyn_elev_t<8>(c, sp, B);
-        case 11: return launch_sep_dyn_elev_t<11>(c, sp, B);
+#define OBTG_CASE(NC_) case NC_: return launch_sep_dyn_elev_t<NC_>(c, sp, B);
+        OBTG_NC_ELEV(OBTG_CASE)
+#undef OBTG_CASE
     }
     return OBTG_ERR_UNSUPPORTED;
 }
@@ -1482,11 +1495,9 @@ int launch_dynamics(obtg_ctx* c, const double* dY, const double* d_tf, int B, do
         if (c->fd.Y0) { p.Y = c->fd.Y0; p.fd = 1 + c->fd.row0; p.fd_fixed = c->fd.fixed; p.fd_h = c->fd.h; }
         const int kid = d_out_ang ? OBTG_K_ANG_RATE : OBTG_K_SPEED;
         switch (c->deg + 1) {
-            case 4: return launch_dyn_t<4>(c, p, kid);
-            case 6: return launch_dyn_t<6>(c, p, kid);
-            case 8: return launch_dyn_t<8>(c, p, kid);
-            case 11: return launch_dyn_t<11>(c, p, kid);
-            case 16: return launch_dyn_t<16>(c, p, kid);
+#define OBTG_CASE(NC_) case NC_: return launch_dyn_t<NC_>(c, p, kid);
+            OBTG_NC_DYN(OBTG_CASE)
+#undef OBTG_CASE
         }
     }
     if (d_out_ang && dyn_fast_elev(c)) {
@@ -1504,11 +1515,9 @@ int launch_dynamics(obtg_ctx* c, const double* dY, const double* d_tf, int B, do
         if (c->fd.Y0) { p.Y = c->fd.Y0; p.fd = 1 + c->fd.row0; p.fd_fixed = c->fd.fixed; p.fd_h = c->fd.h; }
         q.cv4 = c->d_ang_T4.as<double>(); q.cv2 = c->d_ang_cv2.as<double>(); q.R = c->R;
         switch (c->deg + 1) {
-            case 4: return launch_dyn_elev_t<4>(c, q, OBTG_K_ANG_RATE);
-            case 6: return launch_dyn_elev_t<6>(c, q, OBTG_K_ANG_RATE);
-            case 8: return launch_dyn_elev_t<8>(c, q, OBTG_K_ANG_RATE);
-            case 11: return launch_dyn_elev_t<11>(c, q, OBTG_K_ANG_RATE);
-            case 16: return launch_dyn_elev_t<16>(c, q, OBTG_K_ANG_RATE);
+#define OBTG_CASE(NC_) case NC_: return launch_dyn_elev_t<NC_>(c, q, OBTG_K_ANG_RATE);
+            OBTG_NC_DYN(OBTG_CASE)
+#undef OBTG_CASE
         }
     }
     if (d_out_speed && (rc = launch_speed(c, dY, d_tf, B, bound, is_max, d_out_speed))) return rc;

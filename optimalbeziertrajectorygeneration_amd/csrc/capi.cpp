@@ -135,6 +135,11 @@ int ensure_tables(obtg_ctx* c)
             if ((rc = upload(c, c->d_ang_wn, w.data(), w.size() * sizeof(double)))) return rc;
         }
     }
+    // the elevation tables belong to ONE R: a context that moves to R = 0 or beyond 512 must not keep the previous R's
+    // (the launchers' `d_Tf.p == nullptr` guards mean "no table for this R")
+    c->d_Tt.release();
+    c->d_Td.release();
+    c->d_Tf.release();
     if (c->R > 0 && c->R <= 512) {
         auto Tt = elev_conv_tables(L, c->R);
         int rc = upload(c, c->d_Tt, Tt.data(), Tt.size() * sizeof(double));
@@ -146,15 +151,12 @@ int ensure_tables(obtg_ctx* c)
     }
     c->d_ang_T4.release();
     c->d_ang_cv2.release();
-    c->d_ang_T4f.release();
     if (c->R > 0 && c->dim == 2 && n <= 15 && 4 * c->R <= 1000) {   // C(4R, .) and C(2n+R, .) finite in binary64
         auto cv4 = elev_conv_padded(4 * n + 1, 4 * c->R, 8, true, false);
         auto cv2 = elev_conv_padded(2 * n + 1, c->R, 8, false, true);
         int rc = upload(c, c->d_ang_T4, cv4.data(), cv4.size() * sizeof(double));
         if (rc) return rc;
         if ((rc = upload(c, c->d_ang_cv2, cv2.data(), cv2.size() * sizeof(double)))) return rc;
-        auto T4f = elev_table_frag(4 * n + 1, 4 * c->R);
-        if ((rc = upload(c, c->d_ang_T4f, T4f.data(), T4f.size() * sizeof(double)))) return rc;
     }
     c->tables_R = c->R;
     return OBTG_OK;
@@ -201,6 +203,18 @@ const char* obtg_strerror(int code)
 
 const char* obtg_last_error(const obtg_ctx* c) { return c ? c->last_error.c_str() : ""; }
 
+int obtg_abi_version(void) { return OBTG_ABI_VERSION; }
+
+int obtg_fast_kernels(int dim, int deg)
+{
+    const int nc = deg + 1;
+    int mask = 0;
+    if ((dim == 2 || dim == 3) && nc_in_sep(nc)) mask |= 1;
+    if (nc_in_dyn(nc)) mask |= 2;
+    if (dim == 2 && nc_in_elev(nc)) mask |= 4;
+    return mask;
+}
+
 int obtg_device_count(void)
 {
     int n = 0;
@@ -211,8 +225,8 @@ int obtg_device_count(void)
 const char* obtg_abi_symbols(void)
 {
     static const char syms[] =
-        "obtg_strerror\0obtg_last_error\0obtg_device_count\0obtg_abi_symbols\0obtg_host_alloc\0obtg_host_free\0"
-        "obtg_ctx_create\0obtg_ctx_destroy\0obtg_ctx_set_stream\0obtg_ctx_use_own_stream\0obtg_ctx_set_deg_elev\0obtg_ctx_set_ang_rate_order\0obtg_ctx_set_second_speed_bound\0obtg_sync\0"
+        "obtg_strerror\0obtg_last_error\0obtg_abi_version\0obtg_fast_kernels\0obtg_device_count\0obtg_abi_symbols\0obtg_host_alloc\0obtg_host_free\0"
+        "obtg_ctx_create\0obtg_ctx_destroy\0obtg_ctx_set_stream\0obtg_ctx_use_own_stream\0obtg_ctx_set_deg_elev\0obtg_ctx_set_ang_rate_order\0obtg_ctx_ang_rate_order_in_effect\0obtg_ctx_set_second_speed_bound\0obtg_sync\0"
         "obtg_len_temporal_sep\0obtg_len_speed\0obtg_len_ang_rate\0obtg_num_pairs\0"
         "obtg_temporal_sep\0obtg_speed\0obtg_ang_rate\0obtg_temporal_sep_min\0obtg_temporal_sep_min_range\0"
         "obtg_temporal_sep_fd\0obtg_temporal_sep_fd_dev\0obtg_one_vs_many_min\0obtg_one_vs_many_min_dev\0"
@@ -272,7 +286,7 @@ void obtg_ctx_destroy(obtg_ctx* c)
     (void)hipStreamSynchronize(c->stream);
     flush_pending_events(c);
     for (hipEvent_t e : c->event_pool) (void)hipEventDestroy(e);
-    DevBuf* bufs[] = { &c->d_pairs, &c->d_obs, &c->d_w2, &c->d_Tt, &c->d_Td, &c->d_Tf, &c->d_ang_T4f, &c->d_ang_dd, &c->d_ang_flags, &c->d_vp_off, &c->d_vp_idx, &c->d_ang_w2n, &c->d_ang_w22n, &c->d_ang_wn, &c->d_ang_T4, &c->d_ang_cv2,
+    DevBuf* bufs[] = { &c->d_pairs, &c->d_obs, &c->d_w2, &c->d_Tt, &c->d_Td, &c->d_Tf, &c->d_ang_dd, &c->d_ang_flags, &c->d_vp_off, &c->d_vp_idx, &c->d_ang_w2n, &c->d_ang_w22n, &c->d_ang_wn, &c->d_ang_T4, &c->d_ang_cv2,
                        &c->d_binrows, &c->d_tiles, &c->d_poly_pts, &c->d_poly_off, &c->d_hp_a, &c->d_hp_b, &c->d_tile_chunk_off, &c->d_tile_order, &c->d_tile_pslots,
                        &c->d_tile_cobj_off, &c->d_tile_cobjs, &c->d_tile_ij, &c->ws_in,
                        &c->ws_in2, &c->ws_out, &c->ws_fd };
@@ -335,6 +349,12 @@ int obtg_ctx_set_ang_rate_order(obtg_ctx* c, int elevate_first)
     c->ang_elevate_first = elevate_first == 1;
     c->ang_exact = elevate_first == 2;
     return OBTG_OK;
+}
+
+int obtg_ctx_ang_rate_order_in_effect(obtg_ctx* c)
+{
+    if (!check_ctx(c)) return OBTG_ERR_ARG;
+    return ang_rate_order_in_effect(c);
 }
 
 int obtg_ctx_set_second_speed_bound(obtg_ctx* c, double bound, int is_max, double* d_out)

@@ -2684,7 +2684,7 @@ int launch_gjk_swarm(obtg_ctx* c, const double* dY, int B, int max_iter, int md_
 #define OBTG_GJK_CASE(NC_) \
     case NC_: kp = k_gjk_swarm_planar<NC_, 0>; kf = k_gjk_swarm_planar<NC_, 1>; kt = k_gjk_swarm_planar<NC_, 2>; break;
         switch (nc) {
-            OBTG_GJK_CASE(4) OBTG_GJK_CASE(6) OBTG_GJK_CASE(8) OBTG_GJK_CASE(11) OBTG_GJK_CASE(16) OBTG_GJK_CASE(21)
+            OBTG_NC_SEP(OBTG_GJK_CASE)
             default: break;
         }
 #undef OBTG_GJK_CASE
@@ -2781,11 +2781,9 @@ int launch_gjk_swarm(obtg_ctx* c, const double* dY, int B, int max_iter, int md_
         const int nc = c->deg + 1, n_obj = c->n_veh + c->n_poly;
         void (*k3)(const GjkSwarmParams) = nullptr;
         switch (nc) {
-            case 4: k3 = k_gjk_swarm_3d<4>; break;
-            case 6: k3 = k_gjk_swarm_3d<6>; break;
-            case 8: k3 = k_gjk_swarm_3d<8>; break;
-            case 11: k3 = k_gjk_swarm_3d<11>; break;
-            case 16: k3 = k_gjk_swarm_3d<16>; break;
+#define OBTG_CASE(NC_) case NC_: k3 = k_gjk_swarm_3d<NC_>; break;
+            OBTG_NC_DYN(OBTG_CASE)
+#undef OBTG_CASE
             default: break;
         }
         // Chunks: a pair of the 3-D machine can take 50 scans (cycling pairs run until the detector fires), and a
@@ -2825,11 +2823,9 @@ int launch_gjk_swarm(obtg_ctx* c, const double* dY, int B, int max_iter, int md_
             if (fold && fold->d_out_sep && c->dim == 3 && c->R == 0 && c->n_obs == 0 && c->n_pairs > 0 && !c->fd_dedup) {
                 void (*kf3)(const GjkSwarmParams, const NsParams, const NsParams, int) = nullptr;
                 switch (nc) {
-                    case 4: kf3 = k_pair_sweep_3d<4>; break;
-                    case 6: kf3 = k_pair_sweep_3d<6>; break;
-                    case 8: kf3 = k_pair_sweep_3d<8>; break;
-                    case 11: kf3 = k_pair_sweep_3d<11>; break;
-                    case 16: kf3 = k_pair_sweep_3d<16>; break;
+#define OBTG_CASE(NC_) case NC_: kf3 = k_pair_sweep_3d<NC_>; break;
+                    OBTG_NC_DYN(OBTG_CASE)
+#undef OBTG_CASE
                     default: break;
                 }
                 int rc2 = ensure_tables(c);
@@ -2915,7 +2911,7 @@ static int pair_sweep_tile_rows(const obtg_ctx* c, int nc, size_t& lds)
 bool pair_sweep_is_one_launch(const obtg_ctx* c)
 {
     const int nc = c->deg + 1;
-    if (!(nc == 4 || nc == 6 || nc == 8 || nc == 11 || nc == 16)) return false;
+    if (!nc_in_dyn(nc)) return false;
     if (!(c->dim == 2 && c->polys_planar && c->max_poly_K <= nc && c->n_hull_pairs > 0 && !c->fd_dedup && c->R == 0 &&
           c->n_pairs > 0)) return false;
     size_t lds = sweep_shape(c, 1 << 20, nc, kPairSweepWavesPerSimd, kPairSweepChunk).lds;
@@ -2932,11 +2928,9 @@ int launch_pair_sweep(obtg_ctx* c, const double* dY, int B, double max_sep, doub
     const int nc = c->deg + 1;
     void (*kern)(const GjkSwarmParams) = nullptr;
     switch (nc) {
-        case 4: kern = k_pair_sweep<4>; break;
-        case 6: kern = k_pair_sweep<6>; break;
-        case 8: kern = k_pair_sweep<8>; break;
-        case 11: kern = k_pair_sweep<11>; break;
-        case 16: kern = k_pair_sweep<16>; break;
+#define OBTG_CASE(NC_) case NC_: kern = k_pair_sweep<NC_>; break;
+        OBTG_NC_DYN(OBTG_CASE)
+#undef OBTG_CASE
         default: break;
     }
     bool fused = kern && c->dim == 2 && c->polys_planar && c->max_poly_K <= nc && c->n_hull_pairs > 0 &&
@@ -2972,11 +2966,9 @@ int launch_pair_sweep(obtg_ctx* c, const double* dY, int B, double max_sep, doub
         // large rows: the tiled sweep, its chunks writing their tile's separation rows
         void (*kt)(const GjkSwarmParams) = nullptr;
         switch (nc) {
-            case 4: kt = k_pair_sweep_tiled<4>; break;
-            case 6: kt = k_pair_sweep_tiled<6>; break;
-            case 8: kt = k_pair_sweep_tiled<8>; break;
-            case 11: kt = k_pair_sweep_tiled<11>; break;
-            case 16: kt = k_pair_sweep_tiled<16>; break;
+#define OBTG_CASE(NC_) case NC_: kt = k_pair_sweep_tiled<NC_>; break;
+            OBTG_NC_DYN(OBTG_CASE)
+#undef OBTG_CASE
             default: break;
         }
         const int vpq = nc | 1;
@@ -3128,6 +3120,7 @@ int launch_step_fd_structured(obtg_ctx* c, int B, double max_sep, double* d_out_
         case 4: kern = elev ? k_step_fd_structured<4, true> : k_step_fd_structured<4, false>; break;
         case 6: kern = elev ? k_step_fd_structured<6, true> : k_step_fd_structured<6, false>; break;
         case 8: kern = elev ? k_step_fd_structured<8, true> : k_step_fd_structured<8, false>; break;
+        case 9: kern = elev ? k_step_fd_structured<9, true> : k_step_fd_structured<9, false>; break;
         case 11: kern = elev ? k_step_fd_structured<11, true> : k_step_fd_structured<11, false>;
                  if (!elev) { kern_mid = k_step_fd_structured<11, false, 2>; kern_big = k_step_fd_structured<11, false, 1>; }
                  break;

@@ -9,6 +9,20 @@
 
 namespace obtg {
 
+// ---- Specialised control-point counts (degree + 1).  The batch kernels are templates on the count; these lists are the
+// ONLY place that says which counts are instantiated -- every dispatch below expands one of them, so a new degree is one
+// entry here (round 5: 9 = the degree-8 drivers, Examples/DubinsCarTimeOptimal.py:72, DubinsCarExample2.py:83).
+//   OBTG_NC_SEP : separation / speed rows (k_normsq_elev, k_tsep_fd, k_one_vs_many; 2-D and 3-D), planar hull sweep
+//   OBTG_NC_DYN : angular rate (k_dynamics*), 3-D sweeps, the one-launch steps (k_pair_sweep*, k_step_fd_structured)
+//   OBTG_NC_ELEV: DEG_ELEV > 0 separation + dynamics in one launch (k_sep_dynamics_elev) and the elevated structured step
+#define OBTG_NC_ELEV(X) X(4) X(6) X(8) X(9) X(11)
+#define OBTG_NC_DYN(X)  OBTG_NC_ELEV(X) X(16)
+#define OBTG_NC_SEP(X)  OBTG_NC_DYN(X) X(21)
+#define OBTG_NC_EQ_(N) || nc == N
+static inline bool nc_in_sep(int nc)  { return false OBTG_NC_SEP(OBTG_NC_EQ_); }
+static inline bool nc_in_dyn(int nc)  { return false OBTG_NC_DYN(OBTG_NC_EQ_); }
+static inline bool nc_in_elev(int nc) { return false OBTG_NC_ELEV(OBTG_NC_EQ_); }
+
 constexpr int kWave = 64;
 constexpr int kNeedBatch = 1077;      // internal launcher result: "this kernel needs the finite-difference batch in memory"
 constexpr int kMaxGenericLen = 1024;  // longest Bernstein coefficient vector of the generic kernels
@@ -72,7 +86,6 @@ struct obtg_ctx {
     obtg::DevBuf d_Tf;        // ... and as matrix-instruction B fragments (elev_table_frag): the batch kernels
     obtg::DevBuf d_ang_w2n, d_ang_w22n, d_ang_wn;  // angular-rate fast path weights
     obtg::DevBuf d_ang_T4;    // angular rate, R > 0: elevation 4*deg -> 4*(deg+R) as a scaled convolution (elev_conv_padded)
-    obtg::DevBuf d_ang_T4f;   // the same elevation (4*deg -> 4*(deg+R)) as matrix-instruction B fragments (elev_table_frag)
     obtg::DevBuf d_ang_cv2;   // the same for the speed rows, 2*deg -> 2*deg+R, with the 1/C(2n+R, k) row
     bool ang_elevate_first = false;   // true: the reference's order (elevate, then products at degree n+R; generic kernel)
     bool ang_exact = false;           // obtg_ctx_set_ang_rate_order(2): the default order, then the rows of near-stop vehicles again in
@@ -202,6 +215,7 @@ int launch_dynamics(obtg_ctx* c, const double* dY, const double* d_tf, int B, do
                     double max_rate, double* d_out_speed, double* d_out_ang);
 int launch_fd_batch(obtg_ctx* c, const double* dY0, int n_fixed_cols, double h, int B, double* dY, int row0 = 0);   // rows row0 .. row0 + B - 1 of the batch
 bool dynamics_fd_on_the_fly(const obtg_ctx* c, bool want_ang);
+int ang_rate_order_in_effect(obtg_ctx* c);
 bool bernstein_fd_on_the_fly(const obtg_ctx* c);      // the separate temporal-separation / speed kernels form a view's rows themselves
 bool pair_sweep_is_one_launch(const obtg_ctx* c);
 int launch_bern_elev(obtg_ctx* c, const double* d_in, int rows, int n, int R, double* d_out);

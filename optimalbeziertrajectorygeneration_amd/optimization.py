@@ -165,6 +165,13 @@ class BezOptimization(object):
             c.set_deg_elev(int(DEG_ELEV))
         return c
 
+    @property
+    def angRateOrderInEffect(self):
+        """'fast' / 'reference' / 'exact': the order the angular rate of this problem REALLY runs in at the current DEG_ELEV
+        (the constructor's `angRateOrder` is a request: DEG_ELEV = 0 has one order, and degrees or elevations without a
+        products-then-elevation kernel run in the reference's order, without the double-double pass)."""
+        return ('fast', 'reference', 'exact')[self._ctx(False).ang_rate_order_in_effect()]
+
     def _timeopt(self):
         return self.model['minGoal'].lower() == 'timeopt'
 
@@ -256,7 +263,13 @@ class BezOptimization(object):
                        'instead it is {} dimensional'.format(self.model['dim']))
                 raise ValueError(msg)            # optimization.py:590-593
             y = self.reshapeVector(x)
-            return self._ctx(False).ang_rate(y, self._tf_of(x), self.model['maxAngRate'])[0]
+            tf = self._tf_of(x)
+            if not tf > 0:
+                # an SLSQP step to tf <= 0 (time-optimal drivers without a lower bound on tf): the reference's curve
+                # arithmetic returns None for an empty span (bezier.py:340-343, 365-368) and optimization.py:603-604
+                # multiplies it -- the driver dies with this TypeError.  Same exception, same text, no device call.
+                raise TypeError("unsupported operand type(s) for *: 'NoneType' and 'NoneType'")
+            return self._ctx(False).ang_rate(y, tf, self.model['maxAngRate'])[0]
         return wrapper
 
     def spatialSeparationConstraints(self, x, robust=False):

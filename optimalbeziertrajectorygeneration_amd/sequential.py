@@ -42,7 +42,6 @@ def _context(ndim, deg, deg_elev, device=0):
     return c
 
 
-_FAST_NC = (4, 6, 8, 11, 16, 21)     # control points per curve with a specialised one-vs-many kernel (include/obtg.h)
 _generic_cache = {}
 
 
@@ -50,7 +49,7 @@ def _one_vs_many(one, many, ndim, maxSep, degElev):
     """out[B][K].  Degrees without a specialised kernel go through the any-degree separation kernel: a context of K + 1
     "vehicles" (candidate first) whose first K lexicographic pairs are exactly (candidate, other k)."""
     nc = many.shape[-1]
-    if nc in _FAST_NC and ndim in (2, 3) and degElev <= 512:       # (what the specialised kernel takes: bern_kernels.hip fast_shape)
+    if (_capi.fast_kernels(ndim, nc - 1) & 1) and degElev <= 512:  # (a specialised kernel exists: obtg_fast_kernels, bern_kernels.hip fast_shape)
         return _context(ndim, nc - 1, degElev).one_vs_many_min(one, many, maxSep)
     one = np.ascontiguousarray(one, dtype=np.float64).reshape(-1, ndim, nc)
     many = np.ascontiguousarray(many, dtype=np.float64).reshape(-1, ndim, nc)

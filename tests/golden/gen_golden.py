@@ -817,8 +817,103 @@ def gen_fullsize():
     save("fullsize.npz", **d)
 
 
+def _slsqp_attempts(bo, cons, bounds=None, max_retries=8):
+    """The drivers' `results = minimize(...); while not results.success: xGuess = generateGuess(std=std); ...` loop
+    (Examples/DubinsCarTimeOptimal.py:109-137) with SEEDED retries (seed 100 + std; the examples draw unseeded).  One
+    record per attempt: start, outcome (1 success, 0 SLSQP gave up, -1 the reference raised TypeError -- SLSQP stepped to
+    tf <= 0, where Bezier.sub returns None, bezier.py:365-368, and optimization.py:604 multiplies None by None), fun, nit, x."""
+    import scipy.optimize as sop
+    kw = dict(method='SLSQP', constraints=cons, options={'maxiter': 250, 'disp': False})
+    if bounds is not None:
+        kw['bounds'] = bounds
+    x0s, outcome, funs, nits, xs = [], [], [], [], []
+    x0 = bo.generateGuess(std=0)
+    std = 0
+    while True:
+        x0s.append(x0)
+        try:
+            with np.errstate(all='ignore'):
+                r = sop.minimize(bo.objectiveFunction, x0=x0, **kw)
+            outcome.append(1 if r.success else 0); funs.append(r.fun); nits.append(r.nit); xs.append(r.x)
+        except TypeError:
+            outcome.append(-1); funs.append(np.nan); nits.append(-1); xs.append(np.full_like(x0, np.nan))
+        if outcome[-1] == 1 or std >= max_retries:
+            break
+        std += 1
+        x0 = bo.generateGuess(std=std, seed=100 + std)
+    return dict(x0=np.array(x0s), outcome=np.array(outcome, np.int32), fun=np.array(funs), nit=np.array(nits, np.int32),
+                x=np.array(xs))
+
+
+def gen_drivers():
+    """The three example drivers the package had no fixtures for (round 5): Examples/DubinsCarTimeOptimal.py:60-137 and
+    Examples/DubinsCarExample2.py:83-140 (degree 8: 9 control points, speeds and angles prescribed, point obstacles,
+    time-optimal, retry-with-noisier-guess loop; the second one with bounds and DEG_ELEV) and
+    Examples/DrivingOnATrack.py:18-50 (scalar constructor arguments, list-built Bezier tracks as shapeObstacles).
+    Constraint vectors at the drivers' own guess and at a noisy one, DEG_ELEV 0 and 10, and the outcome of every
+    attempt of the SLSQP loops."""
+    d = {}
+
+    def dubins_time_optimal():
+        return opt.BezOptimization(numVeh=1, dimension=2, degree=8, minimizeGoal='TimeOpt', maxSep=1, maxSpeed=5,
+                                   maxAngRate=1, initPoints=[(3, 0)], finalPoints=[(7, 10)], initSpeeds=[1], finalSpeeds=[1],
+                                   initAngs=[np.pi / 2], finalAngs=[np.pi / 2], pointObstacles=[[3, 2], [6, 7]])
+
+    def dubins_example2():
+        return opt.BezOptimization(numVeh=1, dimension=2, degree=8, minimizeGoal='TimeOpt', maxSep=1, maxSpeed=3,
+                                   maxAngRate=np.pi / 2, initPoints=[(0, 0)], finalPoints=[(12, 8)], initSpeeds=[1],
+                                   finalSpeeds=[1], tf=8, initAngs=[np.pi / 2], finalAngs=[0],
+                                   pointObstacles=[(3, 2), (7, 6), (9, 9), (4, 5), (5, 8), (3, 7), (7, 3)])
+
+    import scipy.optimize as sop
+    for pre, make, bounds in (("tt", dubins_time_optimal, None),
+                              ("e2", dubins_example2, sop.Bounds([-100] * 10 + [0.0001], [100] * 10 + [50], [False] * 10 + [True]))):
+        for R in (0, 10):
+            opt.DEG_ELEV = R
+            bo = make()
+            cons = [{'type': 'ineq', 'fun': bo.temporalSeparationConstraints}, {'type': 'ineq', 'fun': bo.maxSpeedConstraints},
+                    {'type': 'ineq', 'fun': bo.maxAngularRateConstraints}, {'type': 'ineq', 'fun': lambda x: x[-1]}]
+            xs = np.array([bo.generateGuess(std=0), bo.generateGuess(std=0.3, seed=7)])
+            d["%s_x" % pre] = xs
+            d["%s_y" % pre] = np.array([bo.reshapeVector(x) for x in xs])
+            with np.errstate(all="ignore"):
+                d["%s_R%d_tsep" % (pre, R)] = np.array([bo.temporalSeparationConstraints(x) for x in xs])
+                d["%s_R%d_maxspeed" % (pre, R)] = np.array([bo.maxSpeedConstraints(x) for x in xs])
+                d["%s_R%d_angrate" % (pre, R)] = np.array([bo.maxAngularRateConstraints(x) for x in xs])
+            a = _slsqp_attempts(bo, cons, bounds)
+            for k, v in a.items():
+                d["%s_R%d_flow_%s" % (pre, R, k)] = v
+            print("  %s DEG_ELEV %d: attempts %s, fun %s, nit %s" % (pre, R, a["outcome"], np.round(a["fun"], 6), a["nit"]))
+    opt.DEG_ELEV = 0
+    # DrivingOnATrack.py: the constructor takes scalars / one tuple, the tracks are Beziers built from lists
+    tracks = [[[0, 0, 0, 3, 4, 5, 6, 7, 10, 10, 10], [0, 3, 4, 5, 6, 6, 6, 6, 7, 8, 10]],
+              [[4, 4, 4, 7, 8, 9, 10, 11, 14, 14, 14], [0, 3, 4, 4, 4, 5, 5, 5, 7, 8, 10]]]
+    bo = opt.BezOptimization(numVeh=1, dimension=2, degree=10, minimizeGoal='TimeOpt', maxSep=0.5, maxSpeed=5,
+                             maxAngRate=0.5, initPoints=(2, 1), finalPoints=(12, 9), initSpeeds=1, finalSpeeds=1,
+                             initAngs=np.pi / 2, finalAngs=np.pi / 2, shapeObstacles=[bez.Bezier(t) for t in tracks])
+    xg = bo.generateGuess()
+    xg[-1] = 10
+    d["tr_tracks"] = np.array(tracks, dtype=float)
+    d["tr_x"] = xg
+    d["tr_y"] = bo.reshapeVector(xg)
+    d["tr_maxspeed"] = bo.maxSpeedConstraints(xg)
+    d["tr_angrate"] = bo.maxAngularRateConstraints(xg)
+    sys.setrecursionlimit(1000)
+    curves = [bez.Bezier(d["tr_y"][0:2, :])] + list(bo.shapeObstacles)
+    st = []
+    for i in range(3):
+        for j in range(i + 1, 3):
+            s_, v = guarded(curves[i].minDist, 30.0, curves[j])
+            st.append(s_)
+    d["tr_mindist_status"] = np.array(st, np.int32)          # 2 = RecursionError in the reference (all three pairs)
+    s_, v = guarded(bo.spatialSeparationConstraints, 60.0, xg)
+    d["tr_spatial_status"] = np.array(s_, np.int32)
+    print("  track: minDist status per pair %s, spatialSeparationConstraints status %d" % (st, s_))
+    save("drivers.npz", **d)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["tables", "ops", "problem", "constraints", "gjk", "mindist", "c5", "spatial", "nearstop", "sequential", "spatial_fd", "mindist_script", "c1_text", "fullsize"]
+    which = sys.argv[1:] or ["tables", "ops", "problem", "constraints", "gjk", "mindist", "c5", "spatial", "nearstop", "sequential", "spatial_fd", "mindist_script", "c1_text", "fullsize", "drivers"]
     for w in which:
         if w == "none":          # import-only (exploration)
             continue

@@ -395,19 +395,138 @@ def test_swarm_3d_driver_flow():
     spec.loader.exec_module(ex)
     bo, r_fd, _ = ex.solve(5, with_jac=False)
     _, r_j, _ = ex.solve(5, with_jac=True)
-    # What is held: both runs END feasible and at the same objective.  Not that SLSQP reports convergence inside its
-    # iteration cap -- whether it does turns on the last bits of the constraint values (a kernel change of 1e-16 once made
-    # this test fail at the 400-iteration cap with a feasible, equally good point in hand: that measures SLSQP's
-    # conditioning, not the kernels); status 9 = iteration limit is accepted beside 0.
-    assert r_fd.status in (0, 9) and r_j.status in (0, 9), (r_fd.message, r_j.message)
-    # Feasible to 1e-4 on constraint values of order 10 (squared metres): at the cap SLSQP has been seen to stop 1.8e-5
-    # short (separable product weights, rounding differences of 1e-16 in the callback's values, the example's former start), 1e-12 when it converges.
-    assert bo.temporalSeparationConstraints(r_fd.x).min() > -1e-4 and bo.temporalSeparationConstraints(r_j.x).min() > -1e-4
-    assert abs(r_fd.fun - r_j.fun) < 1e-3 * max(1.0, abs(r_fd.fun))
+    # The example's own start (seed 2, std 0.2) is a deterministic configuration on which SLSQP converges well inside its
+    # cap with either Jacobian: it is held to the ORIGINAL bounds -- convergence reported, feasible to 1e-6, the two runs'
+    # objectives within 1e-4 -- so that an end-to-end loss of convergence is caught (round 4 had widened these bounds for
+    # every configuration when one start began to stop at the cap; that start is the second block below).
+    assert r_fd.success and r_j.success, (r_fd.message, r_j.message)
+    assert bo.temporalSeparationConstraints(r_fd.x).min() > -1e-6 and bo.temporalSeparationConstraints(r_j.x).min() > -1e-6
+    assert abs(r_fd.fun - r_j.fun) < 1e-4 * max(1.0, abs(r_fd.fun))
     guess_fun = bo.objectiveFunction(bo.generateGuess(std=0))
     assert r_fd.fun < 1.25 * guess_fun and r_j.fun < 1.25 * guess_fun        # (the straight lines are the infeasible lower bound)
     # the straight-line guess is infeasible (the paths cross): the constraint did real work
     assert bo.temporalSeparationConstraints(bo.generateGuess(std=0)).min() < 0
+    # The documented cap case, and only it, gets the wide bounds: from seed 1 / std 0.2 SLSQP is still moving at 400
+    # iterations (whether it is turns on the last bits of the callback's values: DESIGN.md 4.9); given 1200 iterations
+    # the same start must converge, strictly feasible, to the same objective.
+    bo1, r_cap, _ = ex.solve(5, with_jac=True, seed=1)
+    assert r_cap.status in (0, 9), r_cap.message
+    assert bo1.temporalSeparationConstraints(r_cap.x).min() > -1e-4
+    _, r_long, _ = ex.solve(5, with_jac=True, seed=1, maxiter=1200)
+    assert r_long.success, r_long.message
+    assert bo1.temporalSeparationConstraints(r_long.x).min() > -1e-6
+    assert abs(r_long.fun - r_j.fun) < 1e-3 * max(1.0, abs(r_j.fun))
+
+
+def _load_example(name):
+    import importlib.util
+    import os
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples", name + ".py")
+    spec = importlib.util.spec_from_file_location(name, path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+@pytest.mark.parametrize("which,pre", [("time_optimal", "tt"), ("example2", "e2")])
+@pytest.mark.parametrize("R", [0, 10])
+def test_degree8_driver_flows(golden_dir, which, pre, R, capsys):
+    """Examples/DubinsCarTimeOptimal.py:60-137 and Examples/DubinsCarExample2.py:83-140 (degree 8 = 9 control points, the
+    count round 5 added to the specialised kernels): constraint vectors at the drivers' guess and at a noisy point equal the
+    reference's, and the SLSQP loop -- `while not results.success: xGuess = generateGuess(std)` -- replayed from the
+    reference's own (seeded) starts ends every attempt as the reference's did (tests/golden/drivers.npz): gives up,
+    dies in TypeError on a step to tf <= 0 (optimization.py:604), or converges to the same tf* (1e-6: SLSQP's path
+    depends on the last bits of the callbacks, as for Example1)."""
+    from optimalbeziertrajectorygeneration_amd import _capi
+    from optimalbeziertrajectorygeneration_amd import optimization as opt
+    g = np.load(golden_dir + "/drivers.npz")
+    ex = _load_example("example7_dubins_degree8")
+    assert _capi.fast_kernels(2, 8) == 7                     # every family of this degree runs on specialised kernels
+    opt.DEG_ELEV = R
+    try:
+        bo, _ = ex.problem(which)
+        for k in range(2):
+            x = g[pre + "_x"][k]
+            assert_close(bo.temporalSeparationConstraints(x), g["%s_R%d_tsep" % (pre, R)][k], what="tsep")
+            assert_close(bo.maxSpeedConstraints(x), g["%s_R%d_maxspeed" % (pre, R)][k], what="max speed")
+            assert_close(bo.maxAngularRateConstraints(x), g["%s_R%d_angrate" % (pre, R)][k], what="ang rate")
+        # structured Jacobian providers at degree 8 = SciPy's own differences of the closures
+        from scipy.optimize._numdiff import approx_derivative
+        x = g[pre + "_x"][1]
+        for fun, jac in ((bo.temporalSeparationConstraints, bo.temporalSeparationJacobian), (bo.maxSpeedConstraints, bo.maxSpeedJacobian),
+                         (bo.maxAngularRateConstraints, bo.maxAngularRateJacobian)):
+            J, Jn = jac(x), approx_derivative(fun, x, method='2-point', abs_step=1.4901161193847656e-08)
+            assert J.shape == Jn.shape and np.allclose(J, Jn, rtol=0, atol=2e-6 * max(1.0, np.abs(Jn).max()))
+        starts = list(g["%s_R%d_flow_x0" % (pre, R)])
+        want = g["%s_R%d_flow_outcome" % (pre, R)]
+        _, attempts = ex.solve(which, starts=starts)
+        got = [(-1 if isinstance(r, TypeError) else int(r.success)) for _, r in attempts]
+        with capsys.disabled():
+            print("\n%s DEG_ELEV %d: attempts here %s, in the reference %s; tf %s vs %s" % (
+                which, R, got, want.tolist(), [None if isinstance(r, TypeError) else round(float(r.fun), 6) for _, r in attempts],
+                np.round(g["%s_R%d_flow_fun" % (pre, R)], 6).tolist()))
+        assert got == want.tolist()
+        for a, (_, r) in enumerate(attempts):
+            if want[a] == 1:
+                ref_fun = float(g["%s_R%d_flow_fun" % (pre, R)][a])
+                assert abs(r.fun - ref_fun) <= 1e-6 * ref_fun, (a, r.fun, ref_fun)
+                assert bo.temporalSeparationConstraints(r.x).min() > -1e-6 and bo.maxSpeedConstraints(r.x).min() > -1e-6
+                assert bo.maxAngularRateConstraints(r.x).min() > -1e-6
+    finally:
+        opt.DEG_ELEV = 0
+
+
+def test_degree8_callback_latency_is_that_of_degree7():
+    """One-row callbacks at degree 8 (9 control points, specialised since round 5) cost what degree 7's do -- until then
+    they ran on the one-wave-per-item any-degree kernels.  Median of 300 calls of each closure, 2 vehicles + 2 point
+    obstacles; bound: within 10 % (+ 2 us of timer noise)."""
+    import time
+    from optimalbeziertrajectorygeneration_amd.optimization import BezOptimization
+    med = {}
+    for deg in (7, 8):
+        bo = BezOptimization(numVeh=2, dimension=2, degree=deg, minimizeGoal='TimeOpt', maxSep=1, maxSpeed=5, maxAngRate=1,
+                             initPoints=[(0, 5), (3, 0)], finalPoints=[(8, 4), (7, 10)], initSpeeds=[1] * 2, finalSpeeds=[1] * 2,
+                             initAngs=[0, np.pi / 2], finalAngs=[0, np.pi / 2], pointObstacles=[[3, 2], [6, 7]])
+        x = bo.generateGuess(std=0.1, seed=1)
+        for f in (bo.temporalSeparationConstraints, bo.maxSpeedConstraints, bo.maxAngularRateConstraints):
+            for _ in range(50):
+                f(x)
+            ts = []
+            for _ in range(300):
+                t0 = time.perf_counter()
+                f(x)
+                ts.append(time.perf_counter() - t0)
+            med[(deg, f.__qualname__.split('.')[1])] = float(np.median(ts)) * 1e6
+    for fam in ("temporalSeparationConstraints", "maxSpeedConstraints", "maxAngularRateConstraints"):
+        assert med[(8, fam)] <= 1.10 * med[(7, fam)] + 2.0, med
+
+
+def test_driving_on_a_track_flow(golden_dir):
+    """Examples/DrivingOnATrack.py:18-60: scalar / bare-tuple constructor arguments, tracks built from lists, speed and
+    angular-rate rows equal to the reference's at the script's guess; `spatialSeparationConstraints` raises RecursionError
+    on this problem exactly as the reference does (drivers.npz: all three pairs overflow its stack); the script's +inf
+    lower bounds end SLSQP at once under today's SciPy, as they do for the reference; with the robust search the
+    constraint goes to SLSQP RAW -- the (P, 3) array -- and, as the distance column, to a feasible time-optimal solution."""
+    g = np.load(golden_dir + "/drivers.npz")
+    ex = _load_example("example8_driving_on_a_track")
+    bo, xg = ex.problem()
+    assert np.array_equal(xg, g["tr_x"]) and np.array_equal(bo.reshapeVector(xg), g["tr_y"])
+    assert_close(bo.maxSpeedConstraints(xg), g["tr_maxspeed"], what="track speed")
+    assert_close(bo.maxAngularRateConstraints(xg), g["tr_angrate"], what="track ang rate")
+    assert int(g["tr_spatial_status"]) == 2
+    with pytest.raises(RecursionError):
+        bo.spatialSeparationConstraints(xg)
+    raw = bo.spatialSeparationConstraints(xg, robust=True)
+    assert raw.shape == (3, 3) and np.isfinite(raw).all()
+    _, r_inf, _ = ex.solve(robust=True, raw=True, reference_bounds=True)
+    assert not r_inf.success and not np.isfinite(r_inf.x[:-1]).any()          # x0 clipped to [inf, inf]
+    _, r_raw, _ = ex.solve(robust=True, raw=True, maxiter=60)                  # the reference's wiring runs (t1, t2 rows included)
+    assert r_raw.x.shape == xg.shape and r_raw.nit >= 1
+    bo2, r, _ = ex.solve(robust=True, raw=False)
+    assert r.success, r.message
+    d = bo2.spatialSeparationConstraints(r.x, robust=True)[:, 0]
+    assert d.min() > -1e-6 and bo2.maxSpeedConstraints(r.x).min() > -1e-6 and bo2.maxAngularRateConstraints(r.x).min() > -1e-6
+    assert 1e-3 < r.x[-1] < xg[-1]                                            # faster than the guess's tf = 10
 
 
 def test_integration_md_binding_stub_runs(golden_dir):

@@ -91,3 +91,30 @@ def test_bezier_container_semantics():
         d.minDist(d)
     r = RationalBezier(np.ones((1, 3)), np.ones((1, 3)))
     assert r.deg == 2
+
+
+def test_example_drivers_constructor_forms(golden_dir):
+    """The constructor forms of the three drivers added in round 5 (drivers.npz, written by the reference): degree 8 with
+    one-element lists (Examples/DubinsCarTimeOptimal.py:70-96, DubinsCarExample2.py:83-104 with a fixed-tf keyword that the
+    time-optimal goal overrides) and DrivingOnATrack.py:25-39's scalars / bare tuples (atleast_1d / atleast_2d promote them)."""
+    from optimalbeziertrajectorygeneration_amd.optimization import BezOptimization
+    g = np.load(golden_dir + "/drivers.npz")
+    tt = BezOptimization(numVeh=1, dimension=2, degree=8, minimizeGoal='TimeOpt', maxSep=1, maxSpeed=5, maxAngRate=1,
+                         initPoints=[(3, 0)], finalPoints=[(7, 10)], initSpeeds=[1], finalSpeeds=[1], initAngs=[np.pi / 2],
+                         finalAngs=[np.pi / 2], pointObstacles=[[3, 2], [6, 7]])
+    e2 = BezOptimization(numVeh=1, dimension=2, degree=8, minimizeGoal='TimeOpt', maxSep=1, maxSpeed=3, maxAngRate=np.pi / 2,
+                         initPoints=[(0, 0)], finalPoints=[(12, 8)], initSpeeds=[1], finalSpeeds=[1], tf=8, initAngs=[np.pi / 2],
+                         finalAngs=[0], pointObstacles=[(3, 2), (7, 6), (9, 9), (4, 5), (5, 8), (3, 7), (7, 3)])
+    for pre, bo in (("tt", tt), ("e2", e2)):
+        assert np.array_equal(bo.generateGuess(std=0), g[pre + "_x"][0])
+        assert np.array_equal(bo.generateGuess(std=0.3, seed=7), g[pre + "_x"][1])
+        for k in range(2):
+            assert np.array_equal(bo.reshapeVector(g[pre + "_x"][k]), g[pre + "_y"][k])
+        for a in range(1, len(g[pre + "_R0_flow_x0"])):            # the retry loop's seeded, noisier guesses
+            assert np.array_equal(bo.generateGuess(std=a, seed=100 + a), g[pre + "_R0_flow_x0"][a])
+    tr = BezOptimization(numVeh=1, dimension=2, degree=10, minimizeGoal='TimeOpt', maxSep=0.5, maxSpeed=5, maxAngRate=0.5,
+                         initPoints=(2, 1), finalPoints=(12, 9), initSpeeds=1, finalSpeeds=1, initAngs=np.pi / 2,
+                         finalAngs=np.pi / 2, shapeObstacles=[])
+    xg = tr.generateGuess()
+    xg[-1] = 10
+    assert np.array_equal(xg, g["tr_x"]) and np.array_equal(tr.reshapeVector(xg), g["tr_y"])

@@ -396,3 +396,29 @@ def test_full_size_c4_c5_against_the_reference(oracle, golden_dir):
         a2, r2 = an.reshape(N, L4), ref.reshape(N, L4)
         per_row = np.abs(a2 - r2) / np.maximum(np.abs(r2), np.abs(r2).max(axis=1, keepdims=True))
         assert per_row.max() <= b["ang_row"], per_row.max()
+
+
+DRIVERS = {   # prefix -> (degree, maxSep, maxSpeed, maxAngRate, point obstacles): Examples/DubinsCarTimeOptimal.py:70-96, DubinsCarExample2.py:60-104
+    "tt": (8, 1.0, 5.0, 1.0, [[3, 2], [6, 7]]),
+    "e2": (8, 1.0, 3.0, np.pi / 2, [(3, 2), (7, 6), (9, 9), (4, 5), (5, 8), (3, 7), (7, 3)]),
+}
+
+
+def test_degree8_drivers_constraint_vectors(oracle, golden_dir):
+    """drivers.npz (gen_golden.py `drivers`): the two degree-8 example drivers' constraint vectors through the REFERENCE's class
+    path -- one vehicle with prescribed speeds / angles, 2 and 7 point obstacles, DEG_ELEV 0 and 10, at the drivers' own
+    straight-line guess and at a noisy one -- and DrivingOnATrack.py's speed / angular-rate rows at its guess."""
+    g = _load(golden_dir, "drivers.npz")
+    for pre, (deg, max_sep, vmax, wmax, obs) in DRIVERS.items():
+        for R in (0, 10):
+            for k in range(2):
+                x, y = g[pre + "_x"][k], g[pre + "_y"][k]
+                yo = np.vstack([y] + [np.full((1, deg + 1), float(v)) for o in obs for v in o])
+                nobj = 1 + len(obs)
+                assert_close(oracle.temporal_sep(yo, nobj, 2, R, max_sep), g["%s_R%d_tsep" % (pre, R)][k], 1e-12, pre + " tsep")
+                assert_close(oracle.speed(y, 1, 2, R, x[-1], vmax, 1), g["%s_R%d_maxspeed" % (pre, R)][k], 1e-12, pre + " speed")
+                assert_close(oracle.ang_rate(y, 1, R, x[-1], wmax), g["%s_R%d_angrate" % (pre, R)][k], 1e-9, pre + " ang rate")
+    x, y = g["tr_x"], g["tr_y"]
+    assert_close(oracle.speed(y, 1, 2, 0, x[-1], 5.0, 1), g["tr_maxspeed"], 1e-12, "track speed")
+    assert_close(oracle.ang_rate(y, 1, 0, x[-1], 0.5), g["tr_angrate"], 1e-9, "track ang rate")
+    assert (g["tr_mindist_status"] == 2).all() and int(g["tr_spatial_status"]) == 2      # the reference overflows its stack on every pair
