@@ -76,9 +76,11 @@ def parse():
                          "rows: ONE swarm, ONE SLSQP iteration -- its n_x + 1 rows split over the ranks by distributed.shard_rows "
                          "(SURVEY.md 8(e).1), every rank an obtg_fd_view_begin_rows over its range, results left per rank, no "
                          "collective on the data path: `scaling` strong; "
-                         "pairs: ONE evaluation batch, the pair lists (temporal separation AND gjkNew hull pairs) "
-                         "partitioned over the ranks and the per-pair minima all-gathered (RCCL) -- the 256-vehicle "
-                         "case of BASELINE.json")
+                         "pairs: ONE evaluation (B = 1 unless --batch says otherwise: a line-search / callback evaluation of a swarm "
+                         "too large for one GPU's latency budget), the pair lists (temporal separation AND gjkNew hull pairs) "
+                         "partitioned over the ranks and the per-pair separation minima all-gathered (RCCL; --gather-gjk adds "
+                         "gjkNew's dist / flag) -- the partitioned form of BASELINE.json's 256-vehicle case; an iteration's FD "
+                         "batch of that swarm shards by ROWS (--mode rows), DESIGN.md 6")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for rehearsals)")
     ap.add_argument("--materialise", action="store_true",
                     help="write the finite-difference batch to HBM every step (obtg_fd_batch_dev) even when the sweeps "
@@ -91,9 +93,14 @@ def parse():
     ap.add_argument("--force-dist", action="store_true",
                     help="rehearsal: initialise torch.distributed and run the collectives even with one rank "
                          "(exercises the RCCL path on a one-GPU box)")
-    ap.add_argument("--gather-minima", action="store_true",
-                    help="--mode rows: after every step all-gather the per-(row, pair) separation minima (what a driver that "
-                         "keeps only active rows would collect: 8 bytes per row and pair)")
+    ap.add_argument("--gather-minima", nargs="?", const="sparse", default=None, choices=["sparse", "dense"],
+                    help="--mode rows: after every step all-gather the per-(row, pair) separation minima to every rank.  sparse "
+                         "(default when the flag is given): per row only the N-1 pairs of the vehicle that row advances, plus row "
+                         "0's minima broadcast once -- B x (N-1) x 8 bytes per step (C4: 14.6 MB; distributed.SparseMinimaGather); "
+                         "dense: the whole [rows][P] block (C4: 1.87 GB per step)")
+    ap.add_argument("--gather-gjk", action="store_true",
+                    help="--mode pairs: all-gather gjkNew's (dist, flag) of the partitioned hull pair list as well (12 bytes per "
+                         "hull pair and row); the default gathers what north_star names, the separation minima (8 bytes per pair and row)")
     ap.add_argument("--ang-order", default="fast", choices=["fast", "reference", "exact"],
                     help="DEG_ELEV > 0: obtg_ctx_set_ang_rate_order (fast = the headline; exact = plus the double-double "
                          "recompute of near-stop vehicles' rows)")
@@ -256,7 +263,7 @@ def main():
     cfg = dict(synth.CONFIGS[args.workload])
     N, d, n, R = cfg["N"], cfg["d"], cfg["n"], cfg["R"]
     n_x = N * d * (n - 1)
-    B = args.batch or (n_x + 1)
+    B = args.batch or (1 if args.mode == "pairs" else n_x + 1)
     B_total, row_begin = B, 0
     if args.mode == "rows":          # one iteration's rows over the ranks: contiguous balanced blocks
         from optimalbeziertrajectorygeneration_amd import distributed as _dd
@@ -351,10 +358,18 @@ def main():
                               g_dist.data_ptr(), None, g_stat.data_ptr(), 128, 256)
 
     d_min = None
+    sparse_gather, gather_bytes = None, None
     if args.mode == "rows" and args.gather_minima:
         counts = [c for _, c in _dd.partition(B_total, world)]
-        d_min_all = torch.empty((world, max(counts), P_t), dtype=f64, device=dev)
         d_min = torch.zeros((max(counts), P_t), dtype=f64, device=dev)
+        if args.gather_minima == "dense":
+            d_min_all = torch.empty((world, max(counts), P_t), dtype=f64, device=dev)
+            gather_bytes = 8 * world * max(counts) * P_t
+        else:
+            sparse_gather = _dd.SparseMinimaGather(B_total, N, ctx.n_veh + ctx.n_obs, d, n - 1, world=world, rank=rank)
+            gather_bytes = sparse_gather.bytes_per_step
+
+    gathered = {}
 
     def step():
         if not use_view:
@@ -368,7 +383,9 @@ def main():
         if d_min is not None:         # (torch's work on its own stream: hand over with the library's sync)
             ctx.sync()
             torch.amin(o_sep.view(B, P_t, L), dim=2, out=d_min[:B])
-            if use_dist:
+            if sparse_gather is not None:
+                gathered["sparse"], gathered["row0"] = sparse_gather.exchange(d_min[:B], force=args.force_dist)
+            elif use_dist:
                 dist.all_gather_into_tensor(d_min_all.view(-1), d_min.view(-1))
 
     # spin-up: the clocks of an idle MI355X need a few hundred ms of work to settle (at C3 a step reads 0.257 ms
@@ -652,6 +669,13 @@ def main():
             dist.all_gather_object(parts, mine)
         checksum = {k: sum(q[k] for q in parts) for k in mine}
         checksum["rows_per_rank"] = [q["rows"] for q in parts]
+    gather_check = None
+    if sparse_gather is not None and B and "sparse" in gathered:
+        # what the exchange returned rebuilds the dense minima: this rank's first / last rows against its own reduction
+        mine_rows = [row_begin, row_begin + B - 1]
+        rebuilt = sparse_gather.dense_rows(gathered["sparse"], gathered["row0"], mine_rows)
+        own = torch.amin(o_sep.view(B, P_t, L), dim=2)[[0, B - 1]]
+        gather_check = bool(torch.equal(rebuilt, own)) and tuple(gathered["sparse"].shape) == (B_total, ctx.n_veh + ctx.n_obs - 1)
     # --mode rows, the same ranges through the STRUCTURED step (obtg_constraint_sweep_fd_structured_rows_dev: every rank
     # evaluates the unperturbed row, the source of its streams, and per row of its range only what that row's vehicle
     # touches): same barrier + MAX-over-ranks timing, the checksums over every rank's rows must be the brute-force ones
@@ -725,7 +749,8 @@ def main():
                                        "max_ang_rate+" if d == 2 else "", P_s),
                        "ang_rate_order": args.ang_order, "ang_rate_order_in_effect": (("fast", "reference", "exact")[ctx.ang_rate_order_in_effect()] if d == 2 else None), "mode": args.mode, "rows_per_step_all_ranks": B_total if args.mode == "rows" else world * B,
                        "row_range_of_rank0": [row_begin, B] if args.mode == "rows" else None, "rows_structured": rows_structured,
-                       "gather_minima": bool(d_min is not None), "checksum": checksum,
+                       "gather_minima": args.gather_minima if d_min is not None else None, "allgather_bytes": gather_bytes,
+                       "gather_check": gather_check, "checksum": checksum,
                        "launches_per_step": len(kernels), "streams": 2 if two_streams else 1, "stream": stream_note,
                        "ranks_seen": ranks_seen, "backend": (args.backend if use_dist else None), "devices": devices,
                        "gjk_status_note": status_note,
@@ -821,11 +846,22 @@ def pairs_mode(args, ctx, dist, world, rank, dev, dY, B, max_sep, barrier, pa, p
     evaluate = gpu_temporal_sep_evaluator(ctx, dY, B, max_sep, min_only=True)
     hull = GpuHullPairSweep(ctx, pa, pb) if use_gjk else None
 
+    gather_gjk = hull is not None and args.gather_gjk
+
     def step():
         parts = [(evaluate(*sweep.my_block), sweep.blocks, 1)]
         if hull is not None:
-            parts += hull.parts(dY, B)
+            hp = hull.parts(dY, B)              # the rank's block of the hull sweep runs either way; its results travel on request
+            if gather_gjk:
+                parts += hp
         return all_gather_pair_blocks(parts, force=args.force_dist)
+
+    # bytes one step's all-gather delivers to EVERY rank (blocks padded to the largest), per evaluation row and in all
+    per_eval = 8 * world * max(c for _, c in sweep.blocks)
+    if gather_gjk:
+        per_eval += 12 * world * max(c for _, c in hull.blocks)
+    allgather_bytes = {"per_evaluation": per_eval, "per_step": per_eval * B, "sent_per_rank_per_step": per_eval * B // world,
+                       "what": "separation minima (8 B per pair)" + (" + gjkNew dist, flag (12 B per hull pair)" if gather_gjk else "")}
 
     for _ in range(max(args.warmup, 1)):
         out = step()
@@ -850,20 +886,29 @@ def pairs_mode(args, ctx, dist, world, rank, dev, dY, B, max_sep, barrier, pa, p
         dist.all_gather_object(devices, me)
     # every rank must hold the full, identical result
     chk = {"sep_min_sum": out[0].sum().item()}
-    if hull is not None:
+    if gather_gjk:
         chk["gjk_dist_nansum"] = torch.nansum(out[1]).item()
         chk["gjk_flag_sum"] = int(out[2].sum().item())
+    elif hull is not None:                    # not gathered: the sums over every rank's own block must still be the one-rank figures
+        d_dist, d_flag = hull._buf[0], hull._buf[1]
+        mine = [float(torch.nansum(d_dist).item()), int(d_flag.sum().item())]
+        allm = [mine]
+        if use_dist:
+            allm = [None] * dist.get_world_size()
+            dist.all_gather_object(allm, mine)
+        chk["gjk_dist_nansum"] = sum(m[0] for m in allm)
+        chk["gjk_flag_sum"] = sum(m[1] for m in allm)
     if rank == 0:
         print(json.dumps({
-            "metric": "pair-partitioned evals/s (one batch across all GPUs: separation minima + gjkNew dist/flag, "
-                      "one RCCL all-gather)",
+            "metric": "pair-partitioned evals/s (one evaluation batch across all GPUs: pair lists split over the ranks, "
+                      "separation minima in one RCCL all-gather)",
             "value": round(B * args.steps / elapsed, 2), "unit": "constraint-evals/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 4),
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "%s: %d temporal-separation pairs + %d gjkNew hull pairs split over %d ranks, "
                                    "B=%d rows" % (args.workload, ctx.num_pairs, len(pa) if use_gjk else 0, world, B),
                        "ranks_seen": ranks_seen, "backend": (args.backend if use_dist else None), "devices": devices,
-                       "checksum": chk}}))
+                       "allgather_bytes": allgather_bytes, "checksum": chk}}))
     if use_dist:
         dist.destroy_process_group()
 
@@ -882,8 +927,18 @@ def mindist_mode(args, rank):
     pa, pb = synth.all_pairs(N + M)
     ctx = _capi.scratch_context()
     out = {}
+    pmc = {}
+    ppath = os.path.join(REPO, "profiles", "mindist_pmc.json")      # VALU-busy fractions from the committed counter passes
+    if os.path.exists(ppath):
+        try:
+            pmc = json.load(open(ppath))
+        except Exception:
+            pmc = {}
     for name, f in (("reference_algorithm", lambda: ctx.min_dist(curves, pa, pb, eps=1e-9, max_depth=128, max_nodes=2000)),
                     ("robust", lambda: ctx.min_dist_robust(curves, pa, pb, eps=1e-9, max_nodes=400000))):
+        t0 = time.perf_counter()
+        r = f()                                    # the first evaluation of this pair list: no node-count history yet
+        first_ms = 1e3 * (time.perf_counter() - t0)
         for _ in range(max(args.warmup // 10, 2)):
             r = f()
         reps = max(args.steps // 50, 5)
@@ -891,12 +946,24 @@ def mindist_mode(args, rank):
         for _ in range(reps):
             r = f()
         ms = 1e3 * (time.perf_counter() - t0) / reps
-        out[name] = dict(ms_per_eval=round(ms, 3), evals_per_s=round(1e3 / ms, 2), pairs_per_s=round(len(pa) * 1e3 / ms, 1),
-                         status_counts=np.bincount(r["status"], minlength=4).tolist())
+        nodes = int(r["nodes"].sum())
+        out[name] = dict(ms_per_eval=round(ms, 3), first_eval_ms=round(first_ms, 3), evals_per_s=round(1e3 / ms, 2),
+                         pairs_per_s=round(len(pa) * 1e3 / ms, 1), nodes_per_eval=nodes, nodes_per_s=round(nodes * 1e3 / ms, 1),
+                         status_counts=np.bincount(r["status"], minlength=4).tolist(),
+                         result_checksum=float(np.nansum(r["res"][:, 0])))
+        if "gjk_calls" in r:
+            calls = int(r["gjk_calls"].sum())
+            out[name]["gjk_calls_per_eval"] = calls
+            out[name]["gjk_calls_per_s"] = round(calls * 1e3 / ms, 1)
+        if name in pmc:
+            out[name]["valu_busy"] = pmc[name].get("valu_busy")
+            out[name]["valu_busy_source"] = pmc[name].get("source")
     if rank == 0:
         print(json.dumps({"metric": "spatial-separation (_minDist) evals/s, host buffers in and out", "value": out["reference_algorithm"]["evals_per_s"],
                           "unit": "constraint-evals/s", "n_gpus": 1, "higher_is_better": True, "dtype": "f64", "data": "synthetic",
-                          "vs_baseline": None, "config": {"workload": "C5-style: 64 vehicles + 32 curve obstacles, degree 10, 4560 curve pairs per evaluation"},
+                          "vs_baseline": None, "config": {"workload": "C5-style: 64 vehicles + 32 curve obstacles, degree 10, 4560 curve pairs per evaluation",
+                                                          "note": "a branch-and-bound search per pair: bound by VALU issue and by the longest pair, not by HBM -- "
+                                                                  "nodes/s, gjkNew calls/s and the VALU-busy fraction of the launch stand in for a roofline"},
                           "variants": out}))
 
 

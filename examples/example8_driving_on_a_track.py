@@ -1,20 +1,24 @@
 #!/usr/bin/env python3
 """Examples/DrivingOnATrack.py:18-60 on the MI355X path: one car, degree 10, time optimal, driving between two Bezier
-"tracks" (shapeObstacles built from plain lists), constructor arguments as scalars / bare tuples, and
-`bezopt.spatialSeparationConstraints` handed to SLSQP AS IT IS -- the (P, 3) array of (distance, t1, t2) - maxSep.
+"tracks" (shapeObstacles built from plain lists), constructor arguments as scalars / bare tuples, and the SPATIAL
+separation constraint (`_minDist` on every pair of vehicle and tracks) next to max speed and max angular rate.
 
-    python examples/example8_driving_on_a_track.py
+    python examples/example8_driving_on_a_track.py [--raw]
 
-What the reference's script does at its HEAD, and what this one does instead (tests/golden/drivers.npz records the first
-two from the reference itself):
+The reference's script cannot run at its HEAD, for four independent reasons; tests/golden/drivers.npz records the first two
+from the reference itself, tests/test_gpu_dropin.py::test_driving_on_a_track_flow holds this script to all of them:
   * `_minDist` overflows Python's stack on EVERY pair of this problem (vehicle-track1, vehicle-track2, track1-track2):
-    the reference's script ends in RecursionError at its first constraint evaluation.  Here the same call raises the same
-    exception (status OBTG depth cap -> RecursionError), and the script then switches to the robust search;
-  * its lower bounds are +inf for every control point (DrivingOnATrack.py:44-46); SciPy >= 1.5 clips the start to the bounds,
-    x becomes inf and SLSQP stops with "Inequality constraints incompatible".  `--bounds reference` reproduces that; the
-    default bounds only tf (>= 1e-3), the evident intent;
-  * handed over raw, the constraint also demands t1 - maxSep >= 0 and t2 - maxSep >= 0 of the closest-approach parameters
-    -- `--raw` keeps that (the reference's wiring); the default hands SLSQP the distance column.
+    RecursionError at the first constraint evaluation.  Here the same call raises the same exception (depth cap ->
+    RecursionError), and the script goes on with the robust search (obtg_min_dist_robust);
+  * `bezopt.spatialSeparationConstraints` returns the (P, 3) array of (distance, t1, t2) - maxSep, and SLSQP's wrapper
+    concatenates it with the 1-D speed / angular-rate vectors: SciPy raises "all the input arrays must have same number of
+    dimensions" (SciPy 1.15, scipy/optimize/_slsqp_py.py `_eval_constraint`).  `--raw` shows it; what goes to SLSQP
+    otherwise is the distance column;
+  * its lower bounds are +inf for every control point (DrivingOnATrack.py:44-46): SciPy treats lb == ub as "fixed" and
+    pins every control point at inf -- with these bounds and the two constraints that do evaluate, the reference's own
+    closures end SLSQP after one iteration with "Inequality constraints incompatible" (SciPy 1.15, run in the build
+    container).  Here only tf is bounded (>= 1e-3), the evident intent;
+  * `bezier.py` never imports gjkNew (bezier.py:21-22), so `minDist` raises NameError before any of the above.
 """
 import os
 import sys
@@ -42,18 +46,13 @@ def problem():
     return bezopt, xGuess
 
 
-def solve(robust=True, raw=False, reference_bounds=False, maxiter=250):
+def solve(robust=True, raw=False, maxiter=250):
     bezopt, xGuess = problem()
-    if reference_bounds:
-        infs = [np.inf] * (bezopt.model['deg'] + 1 - 4) * bezopt.model['dim']
-        infs.append(1e-3)
-        bounds = sop.Bounds(np.array(infs), np.inf)
-    else:
-        lb = np.full(xGuess.size, -np.inf)
-        lb[-1] = 1e-3
-        bounds = sop.Bounds(lb, np.inf)
-    if raw:
-        spatial = (lambda x: bezopt.spatialSeparationConstraints(x, robust=True)) if robust else bezopt.spatialSeparationConstraints
+    lb = np.full(xGuess.size, -np.inf)
+    lb[-1] = 1e-3
+    bounds = sop.Bounds(lb, np.inf)
+    if raw:                      # the reference's wiring: the (P, 3) array as it is -- SciPy's concatenate refuses it
+        spatial = lambda x: bezopt.spatialSeparationConstraints(x, robust=robust)         # noqa: E731
     else:
         spatial = lambda x: bezopt.spatialSeparationConstraints(x, robust=robust)[:, 0]   # noqa: E731
     ineqCons = [{'type': 'ineq', 'fun': bezopt.maxSpeedConstraints},
@@ -66,21 +65,23 @@ def solve(robust=True, raw=False, reference_bounds=False, maxiter=250):
 
 
 def main():
-    raw = '--raw' in sys.argv
-    ref_bounds = 'reference' in sys.argv
     try:
-        solve(robust=False, raw=raw, reference_bounds=ref_bounds, maxiter=1)
+        solve(robust=False, maxiter=1)
         robust = False
     except (RecursionError, RuntimeError) as e:
         print("the reference's search: %s: %s -> the robust search" % (type(e).__name__, e))
         robust = True
-    bezopt, results, dt = solve(robust=robust, raw=raw, reference_bounds=ref_bounds)
+    if '--raw' in sys.argv:
+        try:
+            solve(robust=robust, raw=True, maxiter=1)
+        except ValueError as e:
+            print("the (P, 3) array handed to SLSQP as it is: ValueError: %s -> the distance column" % e)
+    bezopt, results, dt = solve(robust=robust)
     print('---\nComputation Time: {}\n---'.format(dt))
     print('success %s (%s), %d iterations, tf = %s' % (results.success, results.message, results.nit, results.x[-1]))
-    if np.isfinite(results.x).all():
-        d = bezopt.spatialSeparationConstraints(results.x, robust=True)
-        print('distance margins to (track1, track2) and between the tracks: %s; speed / angular-rate margins %.2e / %.2e'
-              % (np.round(d[:, 0], 4), bezopt.maxSpeedConstraints(results.x).min(), bezopt.maxAngularRateConstraints(results.x).min()))
+    d = bezopt.spatialSeparationConstraints(results.x, robust=True)
+    print('distance margins to (track1, track2) and between the tracks: %s; speed / angular-rate margins %.2e / %.2e'
+          % (np.round(d[:, 0], 4), bezopt.maxSpeedConstraints(results.x).min(), bezopt.maxAngularRateConstraints(results.x).min()))
 
 
 if __name__ == '__main__':

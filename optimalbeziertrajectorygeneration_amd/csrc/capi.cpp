@@ -1171,11 +1171,35 @@ int obtg_min_dist(obtg_ctx* c, const double* curves, int n_curves, int K, const 
     if ((rc = m[5].reserve(sizeof(double) * min_dist_stack_doubles(K, max_depth) * n_pairs))) return rc;
     if ((rc = c->ws_out.reserve(sizeof(double) * 3 * (size_t)n_pairs))) return rc;
     if ((rc = m[3].reserve(sizeof(int) * 4 * (size_t)n_pairs))) return rc;
+    // the order the worker waves take the pairs in: by the previous evaluation's node counts, longest search first, when
+    // this very pair list was evaluated before (an SLSQP run evaluates one list over and over at nearby x); list order else
+    unsigned long long sig = 1469598103934665603ull ^ (unsigned long long)n_pairs;
+    for (int k = 0; k < n_pairs; ++k) {
+        sig = (sig ^ (unsigned)pair_a[k]) * 1099511628211ull;
+        sig = (sig ^ (unsigned)pair_b[k]) * 1099511628211ull;
+    }
+    static const bool use_hist = !(getenv("OBTG_MD_HISTORY") && getenv("OBTG_MD_HISTORY")[0] == '0');
+    std::vector<int> qbuf((size_t)n_pairs + 1, 0);           // [0] the queue counter, [1..] the order
+    int slot = -1;
+    for (size_t h = 0; h < c->md_hist.size(); ++h)
+        if (c->md_hist[h].sig == sig && (int)c->md_hist[h].nodes.size() == n_pairs) slot = (int)h;
+    const bool have = use_hist && slot >= 0;
+    for (int k = 0; k < n_pairs; ++k) qbuf[1 + k] = k;
+    if (have) {
+        const std::vector<int>& hn = c->md_hist[slot].nodes;
+        std::stable_sort(qbuf.begin() + 1, qbuf.end(), [&](int a, int b) { return hn[a] > hn[b]; });
+    }
+    if ((rc = h2d(c, m[6], qbuf.data(), sizeof(int) * qbuf.size()))) return rc;
     rc = launch_min_dist(c, c->ws_in.as<double>(), K, m[1].as<int>(), m[2].as<int>(), n_pairs, eps, max_iter,
-                         md_cap, max_depth, max_nodes, m[5].as<double>(), c->ws_out.as<double>(), m[3].as<int>());
+                         md_cap, max_depth, max_nodes, m[5].as<double>(), c->ws_out.as<double>(), m[3].as<int>(),
+                         have ? m[6].as<int>() + 1 : nullptr, m[6].as<int>());
     if (rc) return rc;
     std::vector<int> hinfo((size_t)4 * n_pairs);
     if ((rc = d2h_copy(c, hinfo.data(), m[3].p, sizeof(int) * 4 * n_pairs))) return rc;
+    if (slot >= 0) c->md_hist.erase(c->md_hist.begin() + slot);
+    if (c->md_hist.size() >= 4) c->md_hist.erase(c->md_hist.begin());
+    c->md_hist.push_back({ sig, std::vector<int>((size_t)n_pairs) });
+    for (int k = 0; k < n_pairs; ++k) c->md_hist.back().nodes[k] = hinfo[4 * k];
     rc = d2h(c, res, c->ws_out.p, sizeof(double) * 3 * n_pairs);
     if (rc) return rc;
     if (info) std::memcpy(info, hinfo.data(), sizeof(int) * 4 * n_pairs);

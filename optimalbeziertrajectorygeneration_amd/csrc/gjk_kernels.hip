@@ -1629,9 +1629,11 @@ struct MdParams {
     const int* __restrict__ pb;
     int n_pairs, K, max_iter, md_cap, max_depth, max_nodes;
     double eps;
-    double* stack;                        // [n_pairs][max_depth][frame]
+    double* stack;                        // [n_pairs][max_depth][frame] (the wave form: one per WORKER wave)
     double* __restrict__ res;             // [n_pairs][3]
     int* __restrict__ info;               // [n_pairs][4]
+    const int* __restrict__ order;        // wave form: the pairs in the order they are handed out (nullptr = list order)
+    int* queue;                           // wave form: the next slot of `order` (zeroed before the launch)
 };
 
 __global__ __launch_bounds__(64) void k_min_dist(const MdParams p)
@@ -1808,17 +1810,31 @@ __device__ __forceinline__ double hull_param_wave(const double* c, int K, const 
     return np_sum(sh_q, K);
 }
 
+// Round 5: the waves are WORKERS.  A pair's search costs anything from one gjkNew call to max_nodes nodes of four, and a
+// launch of one single-wave workgroup per pair, all resident at once, lasts as long as the SIMD that happened to receive the
+// most long pairs (C5-sized sweep, PMC: VALU 23 % busy over the launch, profiles/r05_mindist_pmc_before.txt).  Now a fixed
+// number of waves per SIMD pull pairs from a queue -- in the order of `order`: the previous evaluation's node counts,
+// descending (the host keeps them per pair list), so the long searches start first, spread over the chip, and the short ones
+// fill in behind them.  Pairs are independent and every result is written per pair: which wave evaluates a pair, and when,
+// changes nothing in res / info.
 __global__ __launch_bounds__(64) void k_min_dist_wave(const MdParams p)
 {
     extern __shared__ double md_lds[];
-    const int k = blockIdx.x, lane = threadIdx.x, half = lane >> 5, li = lane & 31;
+    const int lane = threadIdx.x, half = lane >> 5, li = lane & 31;
     const int K = p.K, FR = 6 * K + F_NSCAL;
+    double* st = p.stack + (size_t)blockIdx.x * p.max_depth * FR;
+  for (;;) {
+    int slot = 0;
+    if (lane == 0) slot = atomicAdd(p.queue, 1);
+    slot = __shfl(slot, 0);
+    if (slot >= p.n_pairs) break;                // every worker ends here: the queue only grows
+    const int k = p.order ? p.order[slot] : slot;
+    __syncthreads();                             // (one wave per workgroup: the previous pair's LDS reads are done)
     double* cur = md_lds;                       // [6K] curves of the node being evaluated
     double* nxt = cur + 6 * K;                  // [6K] curves of the child being built
     double* sh_e = nxt + 6 * K;                 // [2][kMdMaxK]; with sh_q also the six scratch rows of a split
     double* sh_q = sh_e + 2 * kMdMaxK;          // [2][kMdMaxK] (+ 2 more rows so that 6 K doubles fit)
     double* scs = sh_q + 4 * kMdMaxK;           // [max_depth][F_NSCAL] frame scalars
-    double* st = p.stack + (size_t)k * p.max_depth * FR;
     const double* ca = p.curves + (size_t)p.pa[k] * 3 * K;
     const double* cb = p.curves + (size_t)p.pb[k] * 3 * K;
     for (int i = lane; i < 3 * K; i += kWave) {
@@ -1945,6 +1961,7 @@ __global__ __launch_bounds__(64) void k_min_dist_wave(const MdParams p)
         p.res[3 * k] = r0; p.res[3 * k + 1] = r1; p.res[3 * k + 2] = r2;
         if (p.info) { p.info[4 * k] = nodes; p.info[4 * k + 1] = calls; p.info[4 * k + 2] = dmax; p.info[4 * k + 3] = status; }
     }
+  }
 }
 
 // -------------------------------------------------------------------------------------
@@ -3300,18 +3317,31 @@ int launch_step_fd_structured(obtg_ctx* c, int B, double max_sep, double* d_out_
 size_t min_dist_stack_doubles(int K, int max_depth) { return (size_t)max_depth * (6 * K + F_NSCAL); }
 size_t min_dist2poly_stack_doubles(int K, int max_depth) { return (size_t)max_depth * (3 * K + G_NSCAL); }
 
+// worker waves of the wave-per-pair searches: waves per SIMD x 4 SIMDs x CUs, never more than pairs (OBTG_MD_WAVES_PER_SIMD)
+int min_dist_workers(const obtg_ctx* c, int n_pairs, size_t lds_per_wave)
+{
+    static const int env = getenv("OBTG_MD_WAVES_PER_SIMD") ? atoi(getenv("OBTG_MD_WAVES_PER_SIMD")) : 0;
+    int per_simd = env > 0 ? env : 2;
+    const int by_lds = (int)((size_t)160 * 1024 / (lds_per_wave ? lds_per_wave : 1)) / 4;   // a CU's LDS over its four SIMDs
+    if (per_simd > by_lds) per_simd = by_lds > 0 ? by_lds : 1;
+    const long w = (long)per_simd * 4 * (c->n_cus > 0 ? c->n_cus : 256);
+    return (int)(w < n_pairs ? w : n_pairs);
+}
+
 int launch_min_dist(obtg_ctx* c, const double* d_curves, int K, const int* d_pa, const int* d_pb,
                     int n_pairs, double eps, int max_iter, int md_cap, int max_depth, int max_nodes,
-                    double* d_stack, double* d_res, int* d_info)
+                    double* d_stack, double* d_res, int* d_info, const int* d_order, int* d_queue)
 {
     if (n_pairs <= 0) return OBTG_OK;
     if (K < 2 || K > kMdMaxK || max_depth < 1) return OBTG_ERR_UNSUPPORTED;
-    MdParams p{ d_curves, d_pa, d_pb, n_pairs, K, max_iter, md_cap, max_depth, max_nodes, eps, d_stack, d_res, d_info };
+    MdParams p{ d_curves, d_pa, d_pb, n_pairs, K, max_iter, md_cap, max_depth, max_nodes, eps, d_stack, d_res, d_info,
+                d_order, d_queue };
     ScopedKernelTimer t(c, OBTG_K_MIN_DIST);
     const size_t lds_w = sizeof(double) * ((size_t)12 * K + 6 * kMdMaxK + (size_t)max_depth * F_NSCAL);
-    if (lds_w <= 48 * 1024)    // one pair per wavefront
-        hipLaunchKernelGGL(k_min_dist_wave, dim3((unsigned)n_pairs), dim3(kWave), lds_w, c->stream, p);
-    else
+    if (lds_w <= 48 * 1024 && d_queue) {   // one pair per wavefront at a time, the waves as workers on a queue
+        OBTG_HIP(c, hipMemsetAsync(d_queue, 0, sizeof(int), c->stream));
+        hipLaunchKernelGGL(k_min_dist_wave, dim3((unsigned)min_dist_workers(c, n_pairs, lds_w)), dim3(kWave), lds_w, c->stream, p);
+    } else
         hipLaunchKernelGGL(k_min_dist, dim3((n_pairs + 63) / 64), dim3(64), 0, c->stream, p);
     OBTG_HIP(c, hipGetLastError());
     return OBTG_OK;

@@ -135,6 +135,11 @@ struct obtg_ctx {
 
     // scratch for host-buffer entry points
     obtg::DevBuf ws_in, ws_in2, ws_out, ws_misc[8];
+    // obtg_min_dist: node counts of the previous evaluation of the SAME pair list (signature = count + hash of the lists):
+    // the next evaluation hands its pairs to the worker waves in descending order of them (k_min_dist_wave)
+    // (up to four lists, least recently used dropped: a driver alternates the constraint's list with its Jacobian's longer one)
+    struct MdHist { unsigned long long sig; std::vector<int> nodes; };
+    std::vector<MdHist> md_hist;
     void* ring = nullptr;                 // pinned staging ring for pageable caller buffers (capi.cpp h2d / d2h)
     hipEvent_t ring_ev[4] = {};
     bool ring_pending[4] = {};            // slot's event recorded and not waited for yet
@@ -236,7 +241,7 @@ int launch_gjk_swarm(obtg_ctx* c, const double* dY, int B, int max_iter, int md_
                      double* d_p1, double* d_p2, double* d_dist, int* d_nsup, int* d_status, SweepFold* fold = nullptr);
 int launch_min_dist(obtg_ctx* c, const double* d_curves, int K, const int* d_pa, const int* d_pb,
                     int n_pairs, double eps, int max_iter, int md_cap, int max_depth, int max_nodes,
-                    double* d_stack, double* d_res, int* d_info);
+                    double* d_stack, double* d_res, int* d_info, const int* d_order = nullptr, int* d_queue = nullptr);
 int launch_min_dist_robust(obtg_ctx* c, const double* d_curves, int K, const int* d_pa, const int* d_pb, int n_pairs,
                            double eps, int max_nodes, int max_level, int cap, double* d_frontier, double* d_res, int* d_info);
 int launch_min_dist2poly(obtg_ctx* c, const double* d_curves, int K, const double* d_soa,

@@ -81,6 +81,81 @@ def all_gather_pair_blocks(parts, group=None, force=False):
     return out
 
 
+def fd_row_vehicle(rows, n_veh, dim, n_free_cols):
+    """Which vehicle batch row b of a finite-difference batch advances (obtg_fd_view_begin: row 0 is x, row b >= 1 advances free
+    control point b - 1, numbered row-major over (coordinate row, free column) as x.reshape(numRows, numCols) in
+    optimization.py:283): -> int64 tensor, -1 for row 0."""
+    rows = torch.as_tensor(rows, dtype=torch.int64)
+    k = (rows - 1) % (n_veh * dim * n_free_cols)
+    veh = k // (dim * n_free_cols)
+    return torch.where(rows > 0, veh, torch.full_like(veh, -1))
+
+
+def pairs_of_vehicle(n_obj):
+    """[n_obj][n_obj - 1] lexicographic pair indices of the pairs that contain object v (partners ascending) -- the only
+    separation pairs a control point of vehicle v moves."""
+    v = torch.arange(n_obj)[:, None]
+    q = torch.arange(n_obj - 1)[None, :]
+    partner = q + (q >= v).long()
+    lo, hi = torch.minimum(v, partner), torch.maximum(v, partner)
+    return lo * n_obj - lo * (lo + 1) // 2 + (hi - lo - 1)
+
+
+class SparseMinimaGather(object):
+    """What the ranks of a row-sharded finite-difference step exchange when rank 0's SLSQP wants the per-pair separation
+    minima of EVERY row (north_star: "an all-gather of inter-vehicle separation minima"): batch row b differs from row 0 only
+    in the n_obj - 1 pairs of the vehicle it advances, so a rank sends, per owned row, those n_obj - 1 minima -- B x (n_obj - 1)
+    doubles in all (C4: 7169 x 255 x 8 B = 14.6 MB; the dense [B][P] block would be 1.87 GB) -- and the owner of row 0
+    broadcasts that row's P minima (C4: 261 KB).  `dense_rows()` rebuilds any rows of the dense block on demand.
+    ONE `all_gather_into_tensor` (ragged row blocks padded to the largest) + one broadcast."""
+
+    def __init__(self, B, n_veh, n_obj, dim, n_free_cols, group=None, world=None, rank=None):
+        w, r = _world_rank(group)
+        self.group = group
+        self.world = w if world is None else int(world)
+        self.rank = r if rank is None else int(rank)
+        self.B, self.n_obj = int(B), int(n_obj)
+        self.blocks = partition(self.B, self.world)
+        self.begin, self.count = self.blocks[self.rank]
+        self.max_count = max(c for _, c in self.blocks)
+        self.veh = fd_row_vehicle(torch.arange(self.B), n_veh, dim, n_free_cols)         # [B]
+        self.pair_idx = pairs_of_vehicle(self.n_obj)                                      # [n_obj][n_obj - 1]
+        self.bytes_per_step = 8 * (self.world * self.max_count * (self.n_obj - 1) + self.n_obj * (self.n_obj - 1) // 2)
+
+    def compact(self, minima_rows):
+        """minima_rows: this rank's [count][P] per-pair minima -> [count][n_obj - 1]: per row the pairs of its vehicle
+        (row 0, which advances nothing, carries its first n_obj - 1 pairs: never read back)."""
+        veh = self.veh[self.begin:self.begin + self.count].clamp(min=0).to(minima_rows.device)
+        idx = self.pair_idx.to(minima_rows.device)[veh]                                   # [count][n_obj - 1]
+        return torch.gather(minima_rows, 1, idx)
+
+    def exchange(self, minima_rows, force=False):
+        """-> (sparse[B][n_obj - 1], row0[P]) identical on every rank."""
+        mine = self.compact(minima_rows)
+        row0 = minima_rows[0].clone() if self.begin == 0 and self.count else torch.empty(minima_rows.shape[1], dtype=minima_rows.dtype,
+                                                                                        device=minima_rows.device)
+        live = dist.is_available() and dist.is_initialized() and (self.world > 1 or force)
+        if not live:
+            return mine, row0
+        send = torch.zeros((self.max_count, self.n_obj - 1), dtype=mine.dtype, device=mine.device)
+        send[:self.count] = mine
+        recv = torch.empty((self.world,) + tuple(send.shape), dtype=mine.dtype, device=mine.device)
+        dist.all_gather_into_tensor(recv.view(-1), send.view(-1), group=self.group)
+        dist.broadcast(row0, src=0, group=self.group)                                     # rank 0 owns the batch's row 0
+        sparse = torch.cat([recv[r, :c] for r, (_, c) in enumerate(self.blocks)], dim=0)
+        return sparse, row0
+
+    def dense_rows(self, sparse, row0, rows):
+        """Rows `rows` of the dense [B][P] minima block, rebuilt from what `exchange` returned."""
+        rows = torch.as_tensor(rows, dtype=torch.int64)
+        out = row0[None, :].repeat(len(rows), 1)
+        for i, b in enumerate(rows.tolist()):
+            v = int(self.veh[b])
+            if v >= 0:
+                out[i, self.pair_idx[v].to(out.device)] = sparse[b]
+        return out
+
+
 class PairPartitionedSweep(object):
     """All-gather of per-rank pair blocks into the full [B, n_pairs*width] result."""
 

@@ -264,7 +264,7 @@ class BezOptimization(object):
                 raise ValueError(msg)            # optimization.py:590-593
             y = self.reshapeVector(x)
             tf = self._tf_of(x)
-            if not tf > 0:
+            if tf <= 0:
                 # an SLSQP step to tf <= 0 (time-optimal drivers without a lower bound on tf): the reference's curve
                 # arithmetic returns None for an empty span (bezier.py:340-343, 365-368) and optimization.py:603-604
                 # multiplies it -- the driver dies with this TypeError.  Same exception, same text, no device call.

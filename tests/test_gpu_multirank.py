@@ -94,7 +94,20 @@ def test_bench_pairs_mode_two_ranks_equals_one_rank():
     assert two["n_gpus"] == 2 and two["scaling"] == "strong"
     c1, c2 = one["config"]["checksum"], two["config"]["checksum"]
     assert c1["gjk_flag_sum"] == c2["gjk_flag_sum"]
-    assert c1["sep_min_sum"] == c2["sep_min_sum"] and c1["gjk_dist_nansum"] == c2["gjk_dist_nansum"]
+    assert c1["sep_min_sum"] == c2["sep_min_sum"] and abs(c1["gjk_dist_nansum"] - c2["gjk_dist_nansum"]) <= 1e-12 * abs(c1["gjk_dist_nansum"])
+    # round 5: what travels is what north_star names -- the separation minima, 8 bytes per pair and evaluation; gjkNew's
+    # (dist, flag) stay with the rank that computed them unless --gather-gjk asks (then one packed all-gather carries all three)
+    ab = two["config"]["allgather_bytes"]
+    assert ab["per_evaluation"] == 8 * 2 * 1008 and ab["per_step"] == 9 * ab["per_evaluation"] and "gjkNew" not in ab["what"]
+    full = _bench(["--gpus", "2", "--backend", "gloo", "--one-device", "--gather-gjk"] + args)
+    assert full["config"]["allgather_bytes"]["per_evaluation"] == 8 * 2 * 1008 + 12 * 2 * 1264
+    cf = full["config"]["checksum"]
+    assert cf["gjk_flag_sum"] == c1["gjk_flag_sum"] and cf["gjk_dist_nansum"] == c1["gjk_dist_nansum"] and cf["sep_min_sum"] == c1["sep_min_sum"]
+    # B = 1, the mode's default: ONE evaluation (a line-search / callback evaluation) with its pair lists over the ranks
+    one1 = _bench(["--gpus", "1"] + [a for a in args if a not in ("--batch", "9")])
+    two1 = _bench(["--gpus", "2", "--backend", "gloo", "--one-device"] + [a for a in args if a not in ("--batch", "9")])
+    assert "B=1 rows" in two1["config"]["workload"] and two1["config"]["allgather_bytes"]["per_step"] == 8 * 2 * 1008
+    assert one1["config"]["checksum"]["sep_min_sum"] == two1["config"]["checksum"]["sep_min_sum"]
 
 
 def test_bench_rows_mode_two_ranks_tile_the_iteration():
@@ -113,7 +126,14 @@ def test_bench_rows_mode_two_ranks_tile_the_iteration():
         assert c["checksum"]["gjk_flag_sum"] == one["config"]["checksum"]["gjk_flag_sum"]
         for k in ("sep_min_sum", "speed_sum"):
             assert abs(c["checksum"][k] - one["config"]["checksum"][k]) <= 1e-11 * abs(one["config"]["checksum"][k]), k
-    assert two["config"]["checksum"]["rows_per_rank"] == [151, 150] and three["config"]["gather_minima"] is True
+    assert two["config"]["checksum"]["rows_per_rank"] == [151, 150]
+    # the reduced gather (distributed.SparseMinimaGather): per row the 71 pairs of its vehicle + row 0's 2016 minima once;
+    # every rank rebuilds dense rows from it and finds its own reduction bit for bit
+    c3 = three["config"]
+    assert c3["gather_minima"] == "sparse" and c3["gather_check"] is True
+    assert c3["allgather_bytes"] == 8 * (3 * 101 * 63 + 2016)              # against 8 x 301 x 2016 = 4.9 MB dense
+    dense = _bench(["--gpus", "2", "--backend", "gloo", "--one-device", "--gather-minima", "dense"] + args)
+    assert dense["config"]["gather_minima"] == "dense" and dense["config"]["allgather_bytes"] == 8 * 2 * 151 * 2016
     # the same ranges through the structured step (obtg_constraint_sweep_fd_structured_rows_dev): bit-identical rows, so
     # the sums over all ranks' rows are the brute-force sums exactly
     assert one["config"]["rows_structured"] is None                        # (--no-variants)
@@ -135,6 +155,13 @@ def test_rccl_path_with_one_rank():
     assert plain["config"]["checksum"] == rccl["config"]["checksum"]
     line = _bench(["--gpus", "1", "--force-dist", "--backend", "nccl", "--steps", "4", "--warmup", "2", "--no-cpu", "--workload", "C2"])
     assert line["n_gpus"] == 1 and line["value"] > 0
+    # --mode rows over RCCL (one rank): the row-range view, the reduced gather's all_gather_into_tensor + broadcast on device
+    # tensors, the MAX all-reduce of the timing -- the collectives of that mode have now run on the backend the 8-GPU run uses
+    rargs = ["--mode", "rows", "--workload", "C3", "--batch", "301", "--steps", "3", "--warmup", "1", "--no-cpu", "--no-variants"]
+    r_plain = _bench(["--gpus", "1"] + rargs)
+    r_rccl = _bench(["--gpus", "1", "--force-dist", "--backend", "nccl", "--gather-minima"] + rargs)
+    assert r_rccl["config"]["backend"] == "nccl" and r_rccl["config"]["gather_check"] is True
+    assert r_rccl["config"]["checksum"] == r_plain["config"]["checksum"]
 
 
 def test_default_bench_line_keeps_the_contract():
