@@ -1824,9 +1824,16 @@ __global__ __launch_bounds__(64) void k_min_dist_wave(const MdParams p)
     const int K = p.K, FR = 6 * K + F_NSCAL;
     double* st = p.stack + (size_t)blockIdx.x * p.max_depth * FR;
   for (;;) {
-    int slot = 0;
-    if (lane == 0) slot = atomicAdd(p.queue, 1);
-    slot = __shfl(slot, 0);
+    // The pull must not hang on a lane-dependent branch.  The first form -- `if (lane == 0) slot = atomicAdd(queue, 1);
+    // slot = __shfl(slot, 0);`, with `if (lane == 0) { write the results }` as the loop's last statement -- was compiled
+    // into a loop in which the two lane-0 regions on either side of the back edge are ONE region and lanes 1..63 go round
+    // without lane 0: their ds_bpermute reads an inactive lane (0), they start pair 0 again on their own, and the search,
+    // which relies on lane 0's writes, never ends (ISA of that build: the depth-2 loop under BB2_3; the GPU suite hung in
+    // its first minDist call).  So: every lane issues the atomic, lane 0 with the increment and the others with 0 -- correct
+    // whether or not the compiler folds the 64 into one -- and the results below are stored by every lane (the values are
+    // wave-uniform): no lane-dependent control flow at either end of the loop body.
+    const int ticket = atomicAdd(p.queue, lane == 0 ? 1 : 0);
+    const int slot = __builtin_amdgcn_readfirstlane(ticket);
     if (slot >= p.n_pairs) break;                // every worker ends here: the queue only grows
     const int k = p.order ? p.order[slot] : slot;
     __syncthreads();                             // (one wave per workgroup: the previous pair's LDS reads are done)
@@ -1957,10 +1964,9 @@ __global__ __launch_bounds__(64) void k_min_dist_wave(const MdParams p)
             wave_sync();
         }
     }
-    if (lane == 0) {
-        p.res[3 * k] = r0; p.res[3 * k + 1] = r1; p.res[3 * k + 2] = r2;
-        if (p.info) { p.info[4 * k] = nodes; p.info[4 * k + 1] = calls; p.info[4 * k + 2] = dmax; p.info[4 * k + 3] = status; }
-    }
+    // (every lane, the same values to the same addresses: see the pull above)
+    p.res[3 * k] = r0; p.res[3 * k + 1] = r1; p.res[3 * k + 2] = r2;
+    if (p.info) { p.info[4 * k] = nodes; p.info[4 * k + 1] = calls; p.info[4 * k + 2] = dmax; p.info[4 * k + 3] = status; }
   }
 }
 

@@ -3,6 +3,10 @@
 set -o pipefail
 export TMPDIR=/tmp
 OUT=gpurun_out/r05_c; mkdir -p $OUT
+# the queue-fed _minDist kernel first, alone and under a short limit (its first build hung: see the kernel's comment)
+timeout -k 5 90 python -m pytest tests/test_gpu_dropin.py -m gpu -q -k "mindist_known_answers" > $OUT/mindist_first.log 2>&1; rc0=$?
+tail -3 $OUT/mindist_first.log
+if [ $rc0 -ne 0 ]; then echo "minDist test failed or timed out (rc=$rc0): stopping here"; exit $rc0; fi
 timeout -k 10 1000 python -m pytest tests -m gpu -q > $OUT/gpu_tests.log 2>&1; rc=$?
 tail -25 $OUT/gpu_tests.log
 echo "pytest rc=$rc"
