@@ -1785,6 +1785,34 @@ __device__ __forceinline__ void split_row_lds(const double* src, int K, double t
     if (half == 0) dst[K - 1] = work[0]; else dst[0] = work[0];
 }
 
+// The lane above's value (lane 63: zero): one DPP move per half of the double, no LDS round trip.
+__device__ __forceinline__ double wave_next_lane(double v)
+{
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, 0x130 /* wave_shl:1 */, 0xf, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(0, hi, 0x130, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+
+// deCasteljauSplit (bezier.py:985-1027) of three coordinate rows at once, LEVEL-parallel: lane (r, i) = r * K + i holds
+// control point i of row r; a level is one neighbour exchange and the reference's `(1 - t) * w[i] + t * w[i + 1]` in every
+// lane, K - 1 levels in all -- the same operation per element as split_row_lds, so the same bits, but a chain of K - 1
+// dependent steps instead of K (K - 1) / 2 LDS round trips in ONE lane (round 5: the splits were a fifth of a node's
+// latency, and a pair's search is a serial chain of up to max_nodes nodes).  Left piece: point L is lane 0's value at
+// level L; right piece (stored reversed, bezier.py:563): point i is lane i's value at the last level it takes part in.
+// Needs 3 K <= 64; rl / il = lane / K, lane % K (rl >= 3: the lane idles).
+__device__ __forceinline__ void split_rows3_wave(const double* src, int K, double t, int half, double* dst, int rl, int il)
+{
+    const bool valid = rl < 3;
+    double w = valid ? src[rl * K + il] : 0.0;
+    for (int L = 0; L < K - 1; ++L) {
+        if (valid && (half == 0 ? il == 0 : il == K - 1 - L)) dst[rl * K + (half == 0 ? L : il)] = w;
+        const double up = wave_next_lane(w);
+        w = (1 - t) * w + t * up;
+    }
+    if (valid && il == 0) dst[rl * K + (half == 0 ? K - 1 : 0)] = w;
+}
+
 __device__ __forceinline__ double hull_param_wave(const double* c, int K, const V3& cl, double* sh_e, double* sh_q, int li)
 {
     // exact row match first (bezier.py:1320-1333): lowest matching index
@@ -1817,11 +1845,15 @@ __device__ __forceinline__ double hull_param_wave(const double* c, int K, const 
 // descending (the host keeps them per pair list), so the long searches start first, spread over the chip, and the short ones
 // fill in behind them.  Pairs are independent and every result is written per pair: which wave evaluates a pair, and when,
 // changes nothing in res / info.
-__global__ __launch_bounds__(64) void k_min_dist_wave(const MdParams p)
+#ifndef OBTG_MD_MIN_WAVES
+#define OBTG_MD_MIN_WAVES 2     // worker waves per SIMD the register allocation is held to (launch bound's second argument)
+#endif
+__global__ __launch_bounds__(64, OBTG_MD_MIN_WAVES) void k_min_dist_wave(const MdParams p)
 {
     extern __shared__ double md_lds[];
     const int lane = threadIdx.x, half = lane >> 5, li = lane & 31;
     const int K = p.K, FR = 6 * K + F_NSCAL;
+    const int rl = lane / K, il = lane - rl * K;          // (row, point) of the lane in the level-parallel splits
     double* st = p.stack + (size_t)blockIdx.x * p.max_depth * FR;
   for (;;) {
     // The pull must not hang on a lane-dependent branch.  The first form -- `if (lane == 0) slot = atomicAdd(queue, 1);
@@ -1939,7 +1971,10 @@ __global__ __launch_bounds__(64) void k_min_dist_wave(const MdParams p)
             const int ch = state - 1, h1 = ch >> 1, h2 = ch & 1;
             const double t1 = sc[F_T1], t2 = sc[F_T2];
             double* nf = f + FR;
-            if (lane < 6) {                       // rows 0..2: curve 1 (x, y, z), rows 3..5: curve 2
+            if (3 * K <= kWave) {                 // rows 0..2: curve 1 (x, y, z), rows 3..5: curve 2; level-parallel
+                split_rows3_wave(cur, K, t1, h1, nxt, rl, il);
+                split_rows3_wave(cur + 3 * K, K, t2, h2, nxt + 3 * K, rl, il);
+            } else if (lane < 6) {
                 const bool second = lane >= 3;
                 split_row_lds(cur + lane * K, K, second ? t2 : t1, second ? h2 : h1, nxt + lane * K, sh_e + lane * K);
             }
