@@ -31,10 +31,10 @@ def crossing_swarm(numVeh, seed=3):
     return init + rng.normal(0, 0.05, init.shape), final + rng.normal(0, 0.05, final.shape)
 
 
-def solve(numVeh=5, with_jac=True, maxiter=400, separationRows='all', seed=2):
+def solve(numVeh=5, with_jac=True, maxiter=400, separationRows='all', seed=2, activeRows=2):
     init, final = crossing_swarm(numVeh)
     bezopt = BezOptimization(numVeh=numVeh, dimension=3, degree=5, minimizeGoal='Euclidean', maxSep=0.9,
-                             initPoints=init, finalPoints=final, separationRows=separationRows)
+                             initPoints=init, finalPoints=final, separationRows=separationRows, activeRows=activeRows)
     x0 = bezopt.generateGuess(std=0.2, seed=seed)
     con = {'type': 'ineq', 'fun': bezopt.temporalSeparationConstraints}
     if with_jac:
@@ -47,10 +47,11 @@ def solve(numVeh=5, with_jac=True, maxiter=400, separationRows='all', seed=2):
 
 def main():
     numVeh = int(sys.argv[1]) if len(sys.argv) > 1 else 5
-    for with_jac, rows in ((False, 'all'), (True, 'all'), (True, 'min')):
-        bezopt, res, dt = solve(numVeh, with_jac, separationRows=rows)
+    k = 2 if numVeh <= 5 else 4             # rows per pair of the 'active' run (profiles/r05_experiments/active_rows_scan.txt)
+    for with_jac, rows in ((False, 'all'), (True, 'all'), (True, 'min'), (True, 'active')):
+        bezopt, res, dt = solve(numVeh, with_jac, separationRows=rows, activeRows=k)
         sep = bezopt.temporalSeparationConstraints(res.x)
-        what = ('structured Jacobian provider' if with_jac else 'SciPy finite differences') + (', one row per pair' if rows == 'min' else '')
+        what = ('structured Jacobian provider' if with_jac else 'SciPy finite differences') + (', one row per pair' if rows == 'min' else ', the %d smallest rows per pair' % k if rows == 'active' else '')
         print('%-46s objective %.6f  nit %3d  nfev %5d  converged %s  min separation margin %+.2e  %4d rows  %.2f s'
               % (what, res.fun, res.nit, res.nfev, res.success, sep.min(), sep.size, dt))
 

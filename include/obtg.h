@@ -163,6 +163,17 @@ int obtg_ang_rate(obtg_ctx*, const double* Y, const double* tf, int B, double ma
  * (the `dv.normSquare().min()` variant commented at optimization.py:338 and used by
  * Examples/SequentialSwarm.py:65): out[B][C(N+M,2)]. */
 int obtg_temporal_sep_min(obtg_ctx*, const double* Y, int B, double max_sep, double* out);
+/* SURVEY.md 8(f) item 4 as the survey words it -- "feed SLSQP only active / near-active constraint rows": per pair the k
+ * SMALLEST of its 2n+R+1 elevated separation control points (minus max_sep^2) -- among equal values the lower
+ * control-point index is taken first --, listed in ascending control-point INDEX.  1 <= k <= 4 (and k <= 2n+R+1):
+ * out_val[B][P][k], out_idx[B][P][k] (nullable) = which control points they are.  k is fixed, so the constraint vector
+ * has a constant length P k -- what SLSQP needs -- and in index order a row follows one control point, a polynomial in
+ * x, for as long as the membership of the set stands: the rows kink only where the k-th and (k+1)-th smallest cross (in
+ * value order they would kink at every crossing inside the set as well).  k = 1 is obtg_temporal_sep_min.  The specialised kernels select in the epilogue of their reduced form (one lane holds a pair's
+ * control points: a branch-free insertion into four registers per value); other degrees write the rows to a workspace and
+ * select in a second launch.  Same values as the corresponding entries of obtg_temporal_sep, bit for bit.
+ * optimization.py:337-338 is where the reference builds the full rows / leaves the minimum commented out. */
+int obtg_temporal_sep_active(obtg_ctx*, const double* Y, int B, double max_sep, int k, double* out_val, int* out_idx);
 /* the same restricted to pairs [pair_begin, pair_begin+pair_count) of the lexicographic list:
  * out[B][pair_count].  With pair_begin = 0, pair_count = N-1 this is the one-vs-many constraint
  * of Examples/SequentialSwarm.py:43-70 (vehicle 0 against every other one). */
@@ -202,6 +213,8 @@ int obtg_temporal_sep_dev(obtg_ctx*, const double* dY, int B, double max_sep,
                           int pair_begin, int pair_count, double* d_out);
 int obtg_temporal_sep_min_dev(obtg_ctx*, const double* dY, int B, double max_sep,
                               int pair_begin, int pair_count, double* d_out);
+int obtg_temporal_sep_active_dev(obtg_ctx*, const double* dY, int B, double max_sep, int k,
+                                 int pair_begin, int pair_count, double* d_out_val, int* d_out_idx /*nullable*/);
 int obtg_speed_dev(obtg_ctx*, const double* dY, const double* d_tf, int B, double bound, int is_max,
                    double* d_out);
 int obtg_ang_rate_dev(obtg_ctx*, const double* dY, const double* d_tf, int B, double max_rate,

@@ -58,6 +58,8 @@ _SIGNATURES = {
     "obtg_speed": (_i, [_vp, _vp, _vp, _i, _d, _i, _vp]),
     "obtg_ang_rate": (_i, [_vp, _vp, _vp, _i, _d, _vp]),
     "obtg_temporal_sep_min": (_i, [_vp, _vp, _i, _d, _vp]),
+    "obtg_temporal_sep_active": (_i, [_vp, _vp, _i, _d, _i, _vp, _vp]),
+    "obtg_temporal_sep_active_dev": (_i, [_vp, _vp, _i, _d, _i, _i, _i, _vp, _vp]),
     "obtg_temporal_sep_min_range": (_i, [_vp, _vp, _i, _d, _i, _i, _vp]),
     "obtg_temporal_sep_fd": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _d, _vp]),
     "obtg_temporal_sep_fd_dev": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _d, _vp]),
@@ -397,6 +399,22 @@ class Context(object):
         self._check(self._lib.obtg_temporal_sep_min_range(self._h, _ptr(Y), B, float(max_sep), int(pair_begin),
                                                           int(pair_count), _ptr(out)), "obtg_temporal_sep_min_range")
         return out
+
+    def temporal_sep_active(self, Y, max_sep, k, with_index=False):
+        """Per pair its k smallest elevated separation control points, in control-point order (obtg_temporal_sep_active): [B][P * k]
+        (and, with_index, the int32 control-point indices of the same shape)."""
+        Y, B = self._rows(Y)
+        out = pinned_empty((B, self.num_pairs * int(k)))
+        idx = np.empty((B, self.num_pairs * int(k)), np.int32) if with_index else None
+        self._check(self._lib.obtg_temporal_sep_active(self._h, _ptr(Y), B, float(max_sep), int(k), _ptr(out), _ptr(idx)),
+                    "obtg_temporal_sep_active")
+        return (out, idx) if with_index else out
+
+    def temporal_sep_active_dev(self, dY, B, max_sep, k, d_out_val, d_out_idx=None, pair_begin=0, pair_count=None):
+        if pair_count is None:
+            pair_count = self.num_pairs - pair_begin
+        self._check(self._lib.obtg_temporal_sep_active_dev(self._h, _vp(dY), B, float(max_sep), int(k), pair_begin, pair_count,
+                                                           _vp(d_out_val), _vp(d_out_idx)), "obtg_temporal_sep_active_dev")
 
     def speed(self, Y, tf, bound, is_max):
         Y, B = self._rows(Y)

@@ -61,6 +61,48 @@ struct NsParams {
     int fd, fd_fixed;                 // fd != 0: Y is ONE row; batch row g >= 1 = Y with its (g-1)-th free control point advanced by
     double fd_h;                      //          fd_h (obtg_fd_batch_dev's rows), formed while staging; local row b is batch row
                                       //          b + fd - 1 (fd = 1 + first row of the range: obtg_fd_view_begin_rows)
+    int sel_k;                        // MINONLY kernels: 0 = the item's minimum; 1..4 = its sel_k SMALLEST values, ascending
+    int* __restrict__ sel_idx;        //   (obtg_temporal_sep_active): out[item][sel_k], sel_idx[item][sel_k] = their columns (nullable)
+};
+
+// The four smallest of a stream of values with their positions, ascending in value while they are collected; ties keep
+// the earlier position first (the order numpy's stable argsort gives).  Branch-free insertion: v[] is sorted, so x < v[j] implies x < v[j + 1].
+struct Smallest4 {
+    double v[4];
+    int i[4];
+    __device__ __forceinline__ Smallest4()
+    {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { v[j] = INFINITY; i[j] = -1; }
+    }
+    __device__ __forceinline__ void put(double x, int k)
+    {
+        const bool l0 = x < v[0], l1 = x < v[1], l2 = x < v[2], l3 = x < v[3];
+        v[3] = l2 ? v[2] : (l3 ? x : v[3]); i[3] = l2 ? i[2] : (l3 ? k : i[3]);
+        v[2] = l1 ? v[1] : (l2 ? x : v[2]); i[2] = l1 ? i[1] : (l2 ? k : i[2]);
+        v[1] = l0 ? v[0] : (l1 ? x : v[1]); i[1] = l0 ? i[0] : (l1 ? k : i[1]);
+        v[0] = l0 ? x : v[0];               i[0] = l0 ? k : i[0];
+    }
+    // the n smallest to out[base .. base + n), positions to idx (nullable) -- in ascending POSITION, not ascending value:
+    // a row then follows ONE control point for as long as the set's membership stands, and two members whose values cross
+    // do not swap rows (in value order every such crossing is a kink in both rows; SLSQP's quasi-Newton update sees each)
+    __device__ __forceinline__ void store(double* out, int* idx, size_t base, int n) const
+    {
+        double w[4];
+        int q[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { w[j] = v[j]; q[j] = j < n ? i[j] : 0x7fffffff; }   // the others sort behind the n
+        auto cswap = [&](int a, int b) {
+            const bool s = q[b] < q[a];
+            const int qa = s ? q[b] : q[a], qb = s ? q[a] : q[b];
+            const double wa = s ? w[b] : w[a], wb = s ? w[a] : w[b];
+            q[a] = qa; q[b] = qb; w[a] = wa; w[b] = wb;
+        };
+        cswap(0, 1); cswap(2, 3); cswap(0, 2); cswap(1, 3); cswap(1, 2);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (j < n) { out[base + j] = w[j]; if (idx) idx[base + j] = q[j]; }
+    }
 };
 
 // element of an evaluation row [n_rows][nc] that LOCAL row b of a virtual finite-difference batch advances (-1: none);
@@ -953,10 +995,17 @@ __device__ __forceinline__ void normsq_elev_body(const NsParams& p, const int b,
         if (!ELEV) {
             // elevMatrix(2n, 0) is the identity (bezier.py:1141-1147): the product IS the output
             if (MINONLY) {
-                double m = cf[0];
+                if (p.sel_k > 0) {              // the item's sel_k smallest control points (separationRows='active')
+                    Smallest4 sm;
 #pragma unroll
-                for (int k = 1; k < L; ++k) m = fmin(m, cf[k]);
-                if (mine) p.out[row + r] = p.sign * m + p.offset;
+                    for (int k = 0; k < L; ++k) sm.put(p.sign * cf[k] + p.offset, k);
+                    if (mine) sm.store(p.out, p.sel_idx, (row + r) * p.sel_k, p.sel_k);
+                } else {
+                    double m = cf[0];
+#pragma unroll
+                    for (int k = 1; k < L; ++k) m = fmin(m, cf[k]);
+                    if (mine) p.out[row + r] = p.sign * m + p.offset;
+                }
             } else {
                 // transpose TR rows at a time through the wave's tile
                 for (int r0 = 0; r0 < n_valid; r0 += TR) {
@@ -979,9 +1028,15 @@ __device__ __forceinline__ void normsq_elev_body(const NsParams& p, const int b,
                 // only the row's minimum leaves the lane: the same chain per output column, a row of the dense table
                 // as scalar operands
                 const ctab_t Td = as_ctab(p.Td);
-                double m = INFINITY;
-                for (int k = 0; k < LR; ++k) m = fmin(m, elev_at<L>(ch, Td + k * L, p.offset));
-                if (mine) p.out[row + r] = m;
+                if (p.sel_k > 0) {
+                    Smallest4 sm;
+                    for (int k = 0; k < LR; ++k) sm.put(elev_at<L>(ch, Td + k * L, p.offset), k);
+                    if (mine) sm.store(p.out, p.sel_idx, (row + r) * p.sel_k, p.sel_k);
+                } else {
+                    double m = INFINITY;
+                    for (int k = 0; k < LR; ++k) m = fmin(m, elev_at<L>(ch, Td + k * L, p.offset));
+                    if (mine) p.out[row + r] = m;
+                }
             } else {
                 // (history at C5, R = 100, 2.26 GB per launch: lane = output column with LDS broadcasts 0.65 ms; lane = item with
                 // 32-column chunks 0.87-1.24; lane = (row, 8 columns) with the binomial window in registers 0.52-0.55; this form: section 4.1 of DESIGN.md)

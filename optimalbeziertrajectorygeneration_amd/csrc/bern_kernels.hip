@@ -1164,10 +1164,25 @@ size_t temporal_sep_lds_bytes(const obtg_ctx* c, NsParams& p, size_t budget)
     return 0;
 }
 
+// items x L values -> per item the k smallest, ascending, with their positions (the any-degree shapes' route to
+// obtg_temporal_sep_active: their kernels write whole rows; the specialised kernels select in their own epilogue)
+__global__ __launch_bounds__(256) void k_select_smallest(const double* __restrict__ rows, long items, int L, int k,
+                                                         double* __restrict__ out, int* __restrict__ idx)
+{
+    const long it = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (it >= items) return;
+    const double* r = rows + it * L;
+    Smallest4 sm;
+    for (int j = 0; j < L; ++j) sm.put(r[j], j);
+    sm.store(out, idx, (size_t)it * k, k);
+}
+
 int launch_temporal_sep(obtg_ctx* c, const double* dY, int B, double max_sep, int pair_begin,
-                        int pair_count, bool min_only, double* d_out)
+                        int pair_count, bool min_only, double* d_out, int sel_k, int* d_sel_idx)
 {
     if (B <= 0 || pair_count <= 0) return OBTG_OK;
+    if (sel_k < 0 || sel_k > 4) return OBTG_ERR_ARG;
+    if (sel_k > 0) min_only = true;           // the selection lives in the reduced kernels' epilogue
     int rc = ensure_tables(c);
     if (rc) return rc;
     NsParams p{};
@@ -1175,12 +1190,25 @@ int launch_temporal_sep(obtg_ctx* c, const double* dY, int B, double max_sep, in
     if (rc != OBTG_OK && rc != OBTG_ERR_UNSUPPORTED) return rc;
     if (rc == OBTG_OK) {
         p.sign = 1.0; p.offset = 0.0 - max_sep * max_sep;
+        p.sel_k = sel_k; p.sel_idx = d_sel_idx;
         if (c->fd.Y0) { p.Y = c->fd.Y0; p.fd = 1 + c->fd.row0; p.fd_fixed = c->fd.fixed; p.fd_h = c->fd.h; }
         rc = min_only ? dispatch_ns<0, true>(c, p, B, OBTG_K_TEMPORAL_SEP)
                       : dispatch_ns<0, false>(c, p, B, OBTG_K_TEMPORAL_SEP);
         if (rc != OBTG_ERR_UNSUPPORTED) return rc;
     }
     if (c->fd.Y0) return kNeedBatch;          // the generic kernel reads its rows from memory
+    if (sel_k > 0) {
+        // any-degree shapes: whole rows into a workspace, then the selection as a launch of its own
+        const int L = 2 * c->deg + c->R + 1;
+        const long items = (long)B * pair_count;
+        DevBuf& ws = c->ws_misc[7];
+        if ((rc = ws.reserve(sizeof(double) * (size_t)items * L))) return rc;
+        if ((rc = launch_temporal_sep(c, dY, B, max_sep, pair_begin, pair_count, false, ws.as<double>(), 0, nullptr))) return rc;
+        hipLaunchKernelGGL(k_select_smallest, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, c->stream,
+                           ws.as<double>(), items, L, sel_k, d_out, d_sel_idx);
+        OBTG_HIP(c, hipGetLastError());
+        return OBTG_OK;
+    }
     GenParams g{};
     rc = gen_common(c, g);
     if (rc) return rc;

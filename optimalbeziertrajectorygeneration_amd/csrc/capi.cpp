@@ -228,7 +228,7 @@ const char* obtg_abi_symbols(void)
         "obtg_strerror\0obtg_last_error\0obtg_abi_version\0obtg_fast_kernels\0obtg_device_count\0obtg_abi_symbols\0obtg_host_alloc\0obtg_host_free\0"
         "obtg_ctx_create\0obtg_ctx_destroy\0obtg_ctx_set_stream\0obtg_ctx_use_own_stream\0obtg_ctx_set_deg_elev\0obtg_ctx_set_ang_rate_order\0obtg_ctx_ang_rate_order_in_effect\0obtg_ctx_set_second_speed_bound\0obtg_sync\0"
         "obtg_len_temporal_sep\0obtg_len_speed\0obtg_len_ang_rate\0obtg_num_pairs\0"
-        "obtg_temporal_sep\0obtg_speed\0obtg_ang_rate\0obtg_temporal_sep_min\0obtg_temporal_sep_min_range\0"
+        "obtg_temporal_sep\0obtg_speed\0obtg_ang_rate\0obtg_temporal_sep_min\0obtg_temporal_sep_min_range\0obtg_temporal_sep_active\0obtg_temporal_sep_active_dev\0"
         "obtg_temporal_sep_fd\0obtg_temporal_sep_fd_dev\0obtg_one_vs_many_min\0obtg_one_vs_many_min_dev\0"
         "obtg_temporal_sep_dev\0obtg_temporal_sep_min_dev\0obtg_speed_dev\0obtg_ang_rate_dev\0obtg_dynamics_dev\0"
         "obtg_fd_batch_dev\0obtg_fd_view_begin\0obtg_fd_view_begin_rows\0obtg_fd_view_end\0obtg_fd_forms_on_the_fly\0obtg_pair_sweep_fd_dev\0obtg_dynamics_fd_dev\0obtg_gjk_pairs\0obtg_ctx_set_polygons\0obtg_ctx_set_hull_pairs\0"
@@ -470,6 +470,16 @@ int obtg_temporal_sep_min_dev(obtg_ctx* c, const double* dY, int B, double max_s
         return launch_temporal_sep(c, src, B, max_sep, pair_begin, pair_count, true, d_out); });
 }
 
+int obtg_temporal_sep_active_dev(obtg_ctx* c, const double* dY, int B, double max_sep, int k, int pair_begin,
+                                 int pair_count, double* d_out_val, int* d_out_idx)
+{
+    if (!check_ctx(c) || !d_out_val || B < 0 || k < 1 || k > 4 || k > 2 * c->deg + c->R + 1) return OBTG_ERR_ARG;
+    if (pair_begin < 0 || pair_count < 0 || pair_begin + pair_count > c->n_pairs) return OBTG_ERR_ARG;
+    (void)hipSetDevice(c->device);
+    return with_batch(c, dY, B, true, [&](const double* src) {
+        return launch_temporal_sep(c, src, B, max_sep, pair_begin, pair_count, true, d_out_val, k, d_out_idx); });
+}
+
 int obtg_speed_dev(obtg_ctx* c, const double* dY, const double* d_tf, int B, double bound, int is_max,
                    double* d_out)
 {
@@ -692,6 +702,23 @@ static int host_sep(obtg_ctx* c, const double* Y, int B, double max_sep, bool mi
                              c->ws_out.as<double>());
     if (rc) return rc;
     return d2h(c, out, c->ws_out.p, sizeof(double) * per * B);
+}
+
+int obtg_temporal_sep_active(obtg_ctx* c, const double* Y, int B, double max_sep, int k, double* out_val, int* out_idx)
+{
+    if (!check_ctx(c) || !Y || !out_val || B < 0 || k < 1 || k > 4 || k > 2 * c->deg + c->R + 1) return OBTG_ERR_ARG;
+    if (B == 0 || c->n_pairs == 0) return OBTG_OK;
+    (void)hipSetDevice(c->device);
+    const size_t n = (size_t)c->n_pairs * k * B;
+    int rc = h2d(c, c->ws_in, Y, sizeof(double) * ysize(c) * B, true);
+    if (rc) return rc;
+    if ((rc = c->ws_out.reserve(sizeof(double) * n))) return rc;
+    DevBuf& di = c->ws_misc[4];
+    if ((rc = di.reserve(sizeof(int) * n))) return rc;
+    rc = launch_temporal_sep(c, c->ws_in.as<double>(), B, max_sep, 0, c->n_pairs, true, c->ws_out.as<double>(), k, di.as<int>());
+    if (rc) return rc;
+    if (out_idx && (rc = d2h_copy(c, out_idx, di.p, sizeof(int) * n))) return rc;
+    return d2h(c, out_val, c->ws_out.p, sizeof(double) * n);
 }
 
 int obtg_temporal_sep_min_range(obtg_ctx* c, const double* Y, int B, double max_sep, int pair_begin,

@@ -183,7 +183,7 @@ int binrow_offset(obtg_ctx* c, int n);  // ensures row C(n,.) is resident; retur
 
 // ---------------------------------------------------------------- launchers (bern_kernels.hip)
 int launch_temporal_sep(obtg_ctx* c, const double* dY, int B, double max_sep, int pair_begin,
-                        int pair_count, bool min_only, double* d_out);
+                        int pair_count, bool min_only, double* d_out, int sel_k = 0, int* d_sel_idx = nullptr);
 struct NsParams;
 // What launch_gjk_swarm may fold into its 3-D sweep launch (k_pair_sweep_3d): the row's temporal-separation block and,
 // when d_out_speed is set, its speed rows.  did_* report what the launch took over.

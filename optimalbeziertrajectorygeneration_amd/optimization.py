@@ -108,15 +108,22 @@ class BezOptimization(object):
                  shapeObstacles=None,
                  device=0,
                  separationRows='all',
-                 angRateOrder='fast'):
+                 angRateOrder='fast',
+                 activeRows=2):
         """Beyond the reference's keywords: `device` (HIP ordinal) and `separationRows` --
         'all': temporalSeparationConstraints returns every elevated control point of every pair, as the
         reference does (optimization.py:337); 'min': one row per pair, the smallest of them -- the
         `dv.normSquare().min()` form the reference leaves commented at optimization.py:338 and uses in
         Examples/SequentialSwarm.py:65 -- which hands SLSQP 2n+R+1 times fewer rows (SURVEY.md 8(f) item 4:
         its dense least-squares step is what dominates an iteration once the callbacks are fast)."""
-        if separationRows not in ('all', 'min'):
-            raise ValueError("separationRows must be 'all' or 'min', not {!r}".format(separationRows))
+        # 'active' (round 5; SURVEY.md 8(f) item 4 as worded: "only active / near-active constraint rows"): per pair its
+        # `activeRows` SMALLEST elevated control points, in control-point order (1..4; obtg_temporal_sep_active) -- a fixed number of rows, so
+        # SLSQP's constraint count is constant, but more than the single piecewise-smooth minimum that makes it stall.
+        if separationRows not in ('all', 'min', 'active'):
+            raise ValueError("separationRows must be 'all', 'min' or 'active', not {!r}".format(separationRows))
+        if separationRows == 'active' and not 1 <= int(activeRows) <= 4:
+            raise ValueError("activeRows must be 1..4, not {!r}".format(activeRows))
+        self.activeRows = int(activeRows)
         # DEG_ELEV > 0 only: 'fast' forms the angular rate's products at degree 4n and elevates them (0.2 ms at C5);
         # 'reference' elevates the position first as optimization.py:597 does (1.8 ms) -- closer to the exact value on
         # vehicles that nearly stop (tests/test_gpu_parity.py::test_near_stop_angular_rate_on_device, DESIGN.md 4.2b)
@@ -171,6 +178,10 @@ class BezOptimization(object):
         (the constructor's `angRateOrder` is a request: DEG_ELEV = 0 has one order, and degrees or elevations without a
         products-then-elevation kernel run in the reference's order, without the double-double pass)."""
         return ('fast', 'reference', 'exact')[self._ctx(False).ang_rate_order_in_effect()]
+
+    def _active_k(self):
+        """rows per pair of separationRows='active': never more than a pair has control points"""
+        return min(self.activeRows, 2 * self.model['deg'] + int(DEG_ELEV) + 1)
 
     def _timeopt(self):
         return self.model['minGoal'].lower() == 'timeopt'
@@ -238,6 +249,8 @@ class BezOptimization(object):
             y = self.reshapeVector(x)
             if self.separationRows == 'min':     # per-pair minimum, reduced on the device (obtg_temporal_sep_min)
                 return self._ctx(with_obs).temporal_sep_min(y, self.model['maxSep'])[0]
+            if self.separationRows == 'active':  # per pair its k smallest control points, selected on the device
+                return self._ctx(with_obs).temporal_sep_active(y, self.model['maxSep'], self._active_k())[0]
             return self._ctx(with_obs).temporal_sep(y, self.model['maxSep'])[0]
         return wrapper
 
@@ -374,6 +387,8 @@ class BezOptimization(object):
             with_obs = self.pointObstacles is not None
             if self.separationRows == 'min':
                 F = self._ctx(with_obs).temporal_sep_min(Y, self.model['maxSep'])
+            elif self.separationRows == 'active':
+                F = self._ctx(with_obs).temporal_sep_active(Y, self.model['maxSep'], self._active_k())
             else:
                 F = self._ctx(with_obs).temporal_sep(Y, self.model['maxSep'])
         else:
@@ -395,7 +410,9 @@ class BezOptimization(object):
         matrix is assembled from them; every entry equals the brute-force batch's
         (structured=False) bit for bit.  Variables that move every vehicle (tf with prescribed
         speeds) and shapes outside the specialised kernels take the batch path."""
-        if not structured:
+        if not structured or self.separationRows == 'active':
+            # 'active': the forward differences of the order statistics themselves -- what SciPy builds from n_x + 1 calls
+            # of the closure -- from one batched call (k values per pair and row leave the device, not 2n+R+1)
             return self._jac(x, 'tsep')
         x = np.asarray(x, dtype=float)
         X, dx = self._fd_rows(x)
