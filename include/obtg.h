@@ -79,7 +79,8 @@ const char* obtg_strerror(int code);
  *      A caller written against revision <= 3 that passes NULL to get the private stream back still links and runs, but
  *      now serialises with the legacy stream: call obtg_ctx_use_own_stream instead.
  *   5  round 5: nothing changed meaning; new: obtg_abi_version, obtg_fast_kernels, obtg_ctx_ang_rate_order_in_effect, obtg_temporal_sep_active[_dev],
- *      obtg_rank_gather_* (the collective behind the C ABI); 9 control points (degree 8) joined the specialised counts. */
+ *      obtg_comm_* and obtg_temporal_sep_min_gather_dev (the collective behind the C ABI); 9 control points (degree 8)
+ *      joined the specialised counts. */
 #define OBTG_ABI_VERSION 5
 int obtg_abi_version(void);
 
@@ -309,6 +310,35 @@ int obtg_constraint_sweep_dev(obtg_ctx*, const double* dY, const double* d_tf, i
                               double speed_bound, int speed_is_max, double max_rate, double* d_out_speed,
                               double* d_out_ang, int max_iter, int md_cap, int* d_flag, double* d_p1, double* d_p2,
                               double* d_dist, int* d_nsup, int* d_status);
+/* ---- the collective behind the C ABI: one process per GPU, RCCL over xGMI ------------------------
+ * For callers that bind this library without PyTorch (INTEGRATION.md route 2); the Python layer's distributed.py does the
+ * same through torch.distributed.  RCCL is loaded at run time (librccl.so.1, or the file OBTG_RCCL_LIB names): without it
+ * these calls return OBTG_ERR_UNSUPPORTED and nothing else in the library is affected.
+ *   rank 0:      obtg_comm_unique_id(id)             -- 128 bytes, handed to the other ranks by the caller's own means
+ *                                                       (a file, a socket, MPI: the library opens no connection of its own)
+ *   every rank:  obtg_comm_create(&comm, n_ranks, rank, id, device)      (collective: returns when all ranks have called)
+ * obtg_comm_all_gather_dev: bytes_per_rank bytes of d_send from every rank into d_recv[n_ranks][bytes_per_rank], on the
+ * CONTEXT's stream (ordered with its launches; obtg_sync completes it).
+ * obtg_temporal_sep_min_gather_dev: what north_star names -- the swarm's pair list partitioned over the ranks (contiguous
+ * balanced blocks of the lexicographic list, the first P mod G ranks one pair more), each rank evaluating the per-pair
+ * separation minima of ITS block for the B rows (every rank holds all control points: dY, or an open view with dY = NULL),
+ * ONE all-gather of 8 B P bytes in all, and d_min_all[B][P] complete on every rank.  The reference loops over every pair
+ * in one process (optimization.py:311-346); the minimum per pair is its commented form at optimization.py:338. */
+typedef struct obtg_comm obtg_comm;
+int obtg_comm_unique_id(unsigned char* id /*[128]*/);
+int obtg_comm_create(obtg_comm** out, int n_ranks, int rank, const unsigned char* id /*[128]*/, int device);
+void obtg_comm_destroy(obtg_comm*);
+int obtg_comm_size(const obtg_comm*);
+int obtg_comm_rank(const obtg_comm*);
+const char* obtg_comm_last_error(const obtg_comm*);
+int obtg_comm_all_gather_dev(obtg_comm*, obtg_ctx*, const void* d_send, void* d_recv, size_t bytes_per_rank);
+int obtg_temporal_sep_min_gather_dev(obtg_ctx*, obtg_comm*, const double* dY, int B, double max_sep, double* d_min_all /*[B][P]*/);
+/* The two pieces of it for callers with a collective of their own (MPI, a host-staged exchange): rank's block of the pair
+ * list, and rank blocks [n_ranks][B * ceil(P / n_ranks)] (rank r's `count_r` minima of row 0, then of row 1, ...: what
+ * obtg_temporal_sep_min_dev(pair_begin, pair_count) writes, padded to the largest block) -> rows d_rows[B][P]. */
+int obtg_pair_block(const obtg_ctx*, int n_ranks, int rank, int* begin, int* count);
+int obtg_unpack_pair_blocks_dev(obtg_ctx*, const double* d_blocks, int B, int n_ranks, double* d_rows);
+
 /* The whole finite-difference step as ONE launch that does not repeat row 0's work (SURVEY.md 8(f) item 1 for every
  * family; what SciPy's approx_derivative needs from optimization.py:83-187 per SLSQP iteration).  The rows of the view
  * (dY0, n_fixed_cols, h, B) differ from row 0 in ONE vehicle each: the launch evaluates row 0 in full and streams its

@@ -60,6 +60,16 @@ _SIGNATURES = {
     "obtg_temporal_sep_min": (_i, [_vp, _vp, _i, _d, _vp]),
     "obtg_temporal_sep_active": (_i, [_vp, _vp, _i, _d, _i, _vp, _vp]),
     "obtg_temporal_sep_active_dev": (_i, [_vp, _vp, _i, _d, _i, _i, _i, _vp, _vp]),
+    "obtg_temporal_sep_min_gather_dev": (_i, [_vp, _vp, _vp, _i, _d, _vp]),
+    "obtg_comm_unique_id": (_i, [_vp]),
+    "obtg_comm_create": (_i, [C.POINTER(_vp), _i, _i, _vp, _i]),
+    "obtg_comm_destroy": (None, [_vp]),
+    "obtg_comm_size": (_i, [_vp]),
+    "obtg_comm_rank": (_i, [_vp]),
+    "obtg_comm_last_error": (C.c_char_p, [_vp]),
+    "obtg_comm_all_gather_dev": (_i, [_vp, _vp, _vp, _vp, C.c_size_t]),
+    "obtg_pair_block": (_i, [_vp, _i, _i, C.POINTER(_i), C.POINTER(_i)]),
+    "obtg_unpack_pair_blocks_dev": (_i, [_vp, _vp, _i, _i, _vp]),
     "obtg_temporal_sep_min_range": (_i, [_vp, _vp, _i, _d, _i, _i, _vp]),
     "obtg_temporal_sep_fd": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _d, _vp]),
     "obtg_temporal_sep_fd_dev": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _d, _vp]),
@@ -181,6 +191,64 @@ def _f64(a):
 
 def _i32(a):
     return np.ascontiguousarray(a, dtype=np.int32)
+
+
+def _prefer_torch_rccl():
+    """One RCCL per process, as for the HIP runtime: PyTorch bundles a librccl.so; when it is there and the caller has not
+    chosen a file, comm.cpp is told to open that one (OBTG_RCCL_LIB) so that obtg_comm_* and torch.distributed share it."""
+    if os.environ.get("OBTG_RCCL_LIB"):
+        return
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is not None and spec.submodule_search_locations:
+        cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "librccl.so")
+        if os.path.exists(cand):
+            os.environ["OBTG_RCCL_LIB"] = cand
+
+
+class Comm(object):
+    """obtg_comm: this process's membership of a group of n_ranks processes, one per GPU (RCCL).  Rank 0 creates the id
+    (`Comm.unique_id()`, 128 bytes) and hands it to the others by any means; every rank then constructs its Comm --
+    collectively."""
+
+    @staticmethod
+    def unique_id():
+        _prefer_torch_rccl()
+        buf = (C.c_ubyte * 128)()
+        rc = load().obtg_comm_unique_id(buf)
+        if rc:
+            raise ObtgError("obtg_comm_unique_id: %s" % load().obtg_strerror(rc).decode(), rc)
+        return bytes(buf)
+
+    def __init__(self, n_ranks, rank, unique_id, device=0):
+        _prefer_torch_rccl()
+        self._lib = load()
+        self._h = _vp()
+        buf = (C.c_ubyte * 128).from_buffer_copy(unique_id)
+        rc = self._lib.obtg_comm_create(C.byref(self._h), int(n_ranks), int(rank), buf, int(device))
+        if rc:
+            raise ObtgError("obtg_comm_create: %s" % self._lib.obtg_strerror(rc).decode(), rc)
+        self.n_ranks, self.rank = int(n_ranks), int(rank)
+
+    def all_gather_dev(self, ctx, d_send, d_recv, bytes_per_rank):
+        rc = self._lib.obtg_comm_all_gather_dev(self._h, ctx._h, _vp(d_send), _vp(d_recv), int(bytes_per_rank))
+        if rc:
+            raise ObtgError("obtg_comm_all_gather_dev: %s (%s)" % (self._lib.obtg_strerror(rc).decode(),
+                                                                     (self._lib.obtg_comm_last_error(self._h) or b"").decode()), rc)
+
+    def close(self):
+        if self._h:
+            self._lib.obtg_comm_destroy(self._h)
+            self._h = _vp()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class ObtgError(RuntimeError):
@@ -415,6 +483,24 @@ class Context(object):
             pair_count = self.num_pairs - pair_begin
         self._check(self._lib.obtg_temporal_sep_active_dev(self._h, _vp(dY), B, float(max_sep), int(k), pair_begin, pair_count,
                                                            _vp(d_out_val), _vp(d_out_idx)), "obtg_temporal_sep_active_dev")
+
+    # ---- pair partition + collective behind the C ABI (include/obtg.h obtg_comm_*)
+    def pair_block(self, n_ranks, rank):
+        b, c = _i(0), _i(0)
+        self._check(self._lib.obtg_pair_block(self._h, int(n_ranks), int(rank), C.byref(b), C.byref(c)), "obtg_pair_block")
+        return b.value, c.value
+
+    def unpack_pair_blocks_dev(self, d_blocks, B, n_ranks, d_rows):
+        self._check(self._lib.obtg_unpack_pair_blocks_dev(self._h, _vp(d_blocks), int(B), int(n_ranks), _vp(d_rows)),
+                    "obtg_unpack_pair_blocks_dev")
+
+    def temporal_sep_min_gather_dev(self, comm, dY, B, max_sep, d_min_all):
+        """This rank's block of the per-pair minima + ONE RCCL all-gather on the context's stream: d_min_all[B][P] on every
+        rank (obtg_temporal_sep_min_gather_dev)."""
+        rc = self._lib.obtg_temporal_sep_min_gather_dev(self._h, comm._h, _vp(dY), int(B), float(max_sep), _vp(d_min_all))
+        if rc:
+            raise ObtgError("obtg_temporal_sep_min_gather_dev: %s (%s)" % (self._lib.obtg_strerror(rc).decode(),
+                            (self._lib.obtg_comm_last_error(comm._h) or self._lib.obtg_last_error(self._h) or b"").decode()), rc)
 
     def speed(self, Y, tf, bound, is_max):
         Y, B = self._rows(Y)

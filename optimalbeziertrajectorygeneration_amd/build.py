@@ -22,6 +22,7 @@ UNITS = [
     ("gjk_kernels.hip", ["-ffp-contract=off"]),
     ("capi.cpp", []),
     ("tables.cpp", []),
+    ("comm.cpp", []),
 ]
 COMMON = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=" + ARCH, "-fno-fast-math",
           "-Wall", "-Wno-unused-function", "-fvisibility=hidden", "-fgpu-rdc" if False else "-fno-gpu-rdc"]
@@ -64,7 +65,7 @@ def build(force=False, verbose=False):
     if failed:
         raise RuntimeError("libobtg_hip.so: compilation failed")
     if force or procs or _mtime(LIB) < max(_mtime(o) for o in objs):
-        cmd = [_hipcc(), "-shared", "-fPIC", "--offload-arch=" + ARCH, "-o", LIB] + objs
+        cmd = [_hipcc(), "-shared", "-fPIC", "--offload-arch=" + ARCH, "-o", LIB] + objs + ["-ldl"]
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)

@@ -228,7 +228,8 @@ const char* obtg_abi_symbols(void)
         "obtg_strerror\0obtg_last_error\0obtg_abi_version\0obtg_fast_kernels\0obtg_device_count\0obtg_abi_symbols\0obtg_host_alloc\0obtg_host_free\0"
         "obtg_ctx_create\0obtg_ctx_destroy\0obtg_ctx_set_stream\0obtg_ctx_use_own_stream\0obtg_ctx_set_deg_elev\0obtg_ctx_set_ang_rate_order\0obtg_ctx_ang_rate_order_in_effect\0obtg_ctx_set_second_speed_bound\0obtg_sync\0"
         "obtg_len_temporal_sep\0obtg_len_speed\0obtg_len_ang_rate\0obtg_num_pairs\0"
-        "obtg_temporal_sep\0obtg_speed\0obtg_ang_rate\0obtg_temporal_sep_min\0obtg_temporal_sep_min_range\0obtg_temporal_sep_active\0obtg_temporal_sep_active_dev\0"
+        "obtg_temporal_sep\0obtg_speed\0obtg_ang_rate\0obtg_temporal_sep_min\0obtg_temporal_sep_min_range\0obtg_temporal_sep_active\0obtg_temporal_sep_active_dev\0obtg_temporal_sep_min_gather_dev\0"
+        "obtg_comm_unique_id\0obtg_comm_create\0obtg_comm_destroy\0obtg_comm_size\0obtg_comm_rank\0obtg_comm_last_error\0obtg_comm_all_gather_dev\0obtg_pair_block\0obtg_unpack_pair_blocks_dev\0"
         "obtg_temporal_sep_fd\0obtg_temporal_sep_fd_dev\0obtg_one_vs_many_min\0obtg_one_vs_many_min_dev\0"
         "obtg_temporal_sep_dev\0obtg_temporal_sep_min_dev\0obtg_speed_dev\0obtg_ang_rate_dev\0obtg_dynamics_dev\0"
         "obtg_fd_batch_dev\0obtg_fd_view_begin\0obtg_fd_view_begin_rows\0obtg_fd_view_end\0obtg_fd_forms_on_the_fly\0obtg_pair_sweep_fd_dev\0obtg_dynamics_fd_dev\0obtg_gjk_pairs\0obtg_ctx_set_polygons\0obtg_ctx_set_hull_pairs\0"
@@ -478,6 +479,14 @@ int obtg_temporal_sep_active_dev(obtg_ctx* c, const double* dY, int B, double ma
     (void)hipSetDevice(c->device);
     return with_batch(c, dY, B, true, [&](const double* src) {
         return launch_temporal_sep(c, src, B, max_sep, pair_begin, pair_count, true, d_out_val, k, d_out_idx); });
+}
+
+int obtg_temporal_sep_min_gather_dev(obtg_ctx* c, obtg_comm* m, const double* dY, int B, double max_sep, double* d_min_all)
+{
+    if (!check_ctx(c) || !m || !d_min_all || B < 0) return OBTG_ERR_ARG;
+    if (B == 0 || c->n_pairs == 0) return OBTG_OK;
+    (void)hipSetDevice(c->device);
+    return with_batch(c, dY, B, true, [&](const double* src) { return comm_gather_pair_minima(m, c, src, B, max_sep, d_min_all); });
 }
 
 int obtg_speed_dev(obtg_ctx* c, const double* dY, const double* d_tf, int B, double bound, int is_max,

@@ -182,6 +182,9 @@ int ensure_tables(obtg_ctx* c);
 int binrow_offset(obtg_ctx* c, int n);  // ensures row C(n,.) is resident; returns offset (doubles)
 
 // ---------------------------------------------------------------- launchers (bern_kernels.hip)
+// comm.cpp: this rank's block of the per-pair minima (contiguous balanced partition of the lexicographic pair list), ONE
+// RCCL all-gather on the context's stream, rows [B][P] on every rank
+int comm_gather_pair_minima(::obtg_comm* m, obtg_ctx* c, const double* dY, int B, double max_sep, double* d_min_all);
 int launch_temporal_sep(obtg_ctx* c, const double* dY, int B, double max_sep, int pair_begin,
                         int pair_count, bool min_only, double* d_out, int sel_k = 0, int* d_sel_idx = nullptr);
 struct NsParams;

@@ -262,3 +262,59 @@ def test_row_sharded_fd_step_helper():
         w3.run(c3, d3.data_ptr(), 1, synth.FD_STEP, tf3.data_ptr(), 0.9, 5.0, True, 1.0, w3.buffers(c3, len(pa3), "cuda"), structured=True)
     c3.use_own_stream()
     c3.close()
+
+
+def test_collective_behind_the_c_abi():
+    """include/obtg.h obtg_comm_*: the RCCL all-gather a caller without PyTorch uses (comm.cpp binds librccl at run time).
+    On the one-GPU box: a communicator of ONE rank -- ncclGetUniqueId, ncclCommInitRank and ncclAllGather on the context's
+    stream really run -- whose obtg_temporal_sep_min_gather_dev equals the plain per-pair minima bit for bit, inside a
+    finite-difference view as well; and, because RCCL refuses two ranks on one device, the partition and the unpacking of
+    rank blocks for 3 and 8 ranks with the blocks evaluated one after the other (obtg_pair_block,
+    obtg_temporal_sep_min_dev(pair_begin, pair_count), obtg_unpack_pair_blocks_dev): what the G ranks' all-gather delivers."""
+    import torch
+    from optimalbeziertrajectorygeneration_amd import _capi, synth
+    from optimalbeziertrajectorygeneration_amd.distributed import partition
+    N, d, n, R, B = 23, 2, 10, 3, 5                      # 253 pairs: ragged over 3 and over 8 ranks
+    Y = synth.swarm_control_points(N, d, n, seed=11)
+    Yb = synth.fd_batch(Y, B=B, h=1e-3)
+    ctx = _capi.Context(N, d, n, R)
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    P = ctx.num_pairs
+    want = ctx.temporal_sep_min(Yb, 0.9)
+    dY = torch.from_numpy(Yb).cuda()
+    uid = _capi.Comm.unique_id()
+    assert len(uid) == 128
+    comm = _capi.Comm(1, 0, uid, device=0)
+    out = torch.full((B, P), float("nan"), dtype=torch.float64, device="cuda")
+    ctx.temporal_sep_min_gather_dev(comm, dY.data_ptr(), B, 0.9, out.data_ptr())
+    torch.cuda.synchronize()
+    assert np.array_equal(out.cpu().numpy(), want)
+    # inside a view (dY = NULL): the rows are formed from x's control points while staging
+    d0 = torch.from_numpy(Y).cuda()
+    out.fill_(float("nan"))
+    ctx.fd_view_begin(d0.data_ptr(), 1, 1e-3, B)
+    ctx.temporal_sep_min_gather_dev(comm, None, B, 0.9, out.data_ptr())
+    ctx.fd_view_end()
+    torch.cuda.synchronize()
+    assert np.array_equal(out.cpu().numpy(), want)
+    # the byte-typed primitive
+    send = torch.arange(1000, dtype=torch.int32, device="cuda")
+    recv = torch.zeros_like(send)
+    comm.all_gather_dev(ctx, send.data_ptr(), recv.data_ptr(), send.numel() * 4)
+    torch.cuda.synchronize()
+    assert torch.equal(send, recv)
+    comm.close()
+    # G ranks' blocks, evaluated here one after the other, in the layout their all-gather delivers
+    for G in (3, 8):
+        blocks = [ctx.pair_block(G, r) for r in range(G)]
+        assert blocks == partition(P, G)
+        cmax = max(c for _, c in blocks)
+        recv = torch.full((G, B * cmax), float("nan"), dtype=torch.float64, device="cuda")
+        for r, (b0, cnt) in enumerate(blocks):
+            ctx.temporal_sep_min_dev(dY.data_ptr(), B, 0.9, recv[r].data_ptr(), b0, cnt)
+        rows = torch.full((B, P), float("nan"), dtype=torch.float64, device="cuda")
+        ctx.unpack_pair_blocks_dev(recv.data_ptr(), B, G, rows.data_ptr())
+        torch.cuda.synchronize()
+        assert np.array_equal(rows.cpu().numpy(), want), G
+    ctx.use_own_stream()
+    ctx.close()
