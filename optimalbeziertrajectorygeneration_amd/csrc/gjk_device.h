@@ -153,14 +153,27 @@ __device__ __forceinline__ void support_pts_wave(Ctx<Mem>& g, const V3& dir, Ver
     const double v0 = __shfl(v, half << 5);                // value of point 0 of this half
     if (v != v) v = -__builtin_inf();                      // `cur > maxd` is false for NaN: never selected
     int idx = have ? li : 0x7fffffff;
-#pragma unroll
-    for (int m = 16; m >= 1; m >>= 1) {
-        const double ov = __shfl_xor(v, m);
-        const int oi = __shfl_xor(idx, m);
+    // "largest value, lowest index" over the 32 lanes of the half.  The combination is commutative and associative, so any
+    // exchange pattern gives the scan's answer; four of the five rounds stay inside a 16-lane row and are DPP moves (quad
+    // permutes, then the half-row and the row mirrored: each lane meets the lanes it has not met yet), only the last one
+    // crosses rows through the LDS crossbar.  (Round 5: five ds_bpermute rounds of three transfers each were ~0.9 k clocks of
+    // a scan, and a pair's search is a serial chain of scans.)
+    auto meet = [&](double ov, int oi) {
         const bool take = ov > v || (ov == v && oi < idx);
         v = take ? ov : v;
         idx = take ? oi : idx;
-    }
+    };
+#define OBTG_DPP_MEET(CTRL) \
+    { const int lo_ = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, false); \
+      const int hi_ = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, false); \
+      const int oi_ = __builtin_amdgcn_update_dpp(0, idx, CTRL, 0xf, 0xf, false); \
+      meet(__hiloint2double(hi_, lo_), oi_); }
+    OBTG_DPP_MEET(0xB1)      // quad_perm:[1,0,3,2]
+    OBTG_DPP_MEET(0x4E)      // quad_perm:[2,3,0,1]
+    OBTG_DPP_MEET(0x141)     // row_half_mirror
+    OBTG_DPP_MEET(0x140)     // row_mirror
+#undef OBTG_DPP_MEET
+    meet(__shfl_xor(v, 16), __shfl_xor(idx, 16));
     if (v0 != v0) idx = 0;                                 // maxd starts as NaN: nothing is ever greater
     const int i1 = __shfl(idx, 0), i2 = __shfl(idx, 32);
     out.i1 = i1; out.i2 = i2;
