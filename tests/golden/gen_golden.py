@@ -331,6 +331,10 @@ def gen_constraints():
         ("d1", 5, 1, 6, 2, 3.0, 5),
         ("n20", 4, 2, 20, 5, 4.0, 6),
         ("n3", 7, 3, 3, 0, 4.0, 8),
+        # degree 8 (9 control points: Examples/DubinsCarTimeOptimal.py:72, DubinsCarExample2.py:83), specialised since round 5
+        ("d8", 10, 2, 8, 0, 6.0, 31),
+        ("d8_R7", 6, 2, 8, 7, 3.5, 32),
+        ("d8_3d", 5, 3, 8, 0, 2.0, 33),
     ]
     names = []
     for (name, N, dim, n, R, tf, seed) in cases:

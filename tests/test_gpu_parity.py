@@ -725,7 +725,7 @@ def test_gjk_swarm_history_order_does_not_change_results(capi, oracle, synth):
     ctx.close()
 
 
-@pytest.mark.parametrize("shape", ["C3", "small_deg7", "fallback_3d", "tiled_C4", "tiled_deg5", "tiled_deg10", "tiled_partial", "tiled_dups",
+@pytest.mark.parametrize("shape", ["C3", "small_deg7", "deg8", "tiled_deg8", "fallback_3d", "tiled_C4", "tiled_deg5", "tiled_deg10", "tiled_partial", "tiled_dups",
                                    "point_obstacles", "point_obstacles_no_polygons"])
 def test_pair_sweep_one_launch_equals_separate_kernels(capi, synth, shape):
     """obtg_pair_sweep_dev (temporal separation + gjkNew sweep as ONE grid) returns what the two
@@ -742,6 +742,10 @@ def test_pair_sweep_one_launch_equals_separate_kernels(capi, synth, shape):
         N, d, n, M, B, n_obs = 7, 2, 7, 0, 9, 2
     elif shape == "small_deg7":
         N, d, n, M, B = 9, 2, 7, 3, 21
+    elif shape == "deg8":             # 9 control points (the degree-8 drivers): specialised since round 5
+        N, d, n, M, B = 31, 2, 8, 4, 17
+    elif shape == "tiled_deg8":
+        N, d, n, M, B = 420, 2, 8, 3, 2
     elif shape == "tiled_C4":         # rows beyond 48 KB of LDS: the tiled sweep writes its tiles' separation rows
         N, d, n, M, B = 256, 2, 15, 5, 3
     elif shape in ("tiled_deg5", "tiled_partial", "tiled_dups"):       # taller tiles, a ragged last row / column block
@@ -789,7 +793,7 @@ def test_pair_sweep_one_launch_equals_separate_kernels(capi, synth, shape):
         for k in a:
             assert np.array_equal(a[k].cpu().numpy(), b[k].cpu().numpy(), equal_nan=True), k
     assert not torch.isnan(b["sep"]).any() and (b["flag"] != -7).all()
-    if n_obs or shape in ("C3", "small_deg7"):
+    if n_obs or shape in ("C3", "small_deg7", "deg8"):
         ctx.reset_kernel_stats(); ctx.set_profiling(True)
         ctx.pair_sweep_dev(dY.data_ptr(), B, 0.9, b["sep"].data_ptr(), b["flag"].data_ptr(), b["p1"].data_ptr(),
                            b["p2"].data_ptr(), b["dist"].data_ptr(), b["nsup"].data_ptr(), b["status"].data_ptr(), 128, 500)
@@ -1235,7 +1239,7 @@ def test_ang_rate_with_elevation_both_orders(capi, oracle, synth, golden_dir):
     ctx.close()
 
 
-@pytest.mark.parametrize("shape", ["C3", "deg7", "elevated", "space3d", "generic"])
+@pytest.mark.parametrize("shape", ["C3", "deg7", "deg8", "deg8_elevated", "elevated", "space3d", "generic"])
 def test_fd_forms_equal_the_materialised_batch(capi, synth, shape):
     """obtg_pair_sweep_fd_dev / obtg_dynamics_fd_dev take ONE row of control points and form the finite-difference
     rows while staging them (C3, deg7: on the fly; elevated: dynamics on the fly, pair sweep through the fallback;
@@ -1243,6 +1247,7 @@ def test_fd_forms_equal_the_materialised_batch(capi, synth, shape):
     obtg_fd_batch_dev + obtg_pair_sweep_dev / obtg_dynamics_dev produce."""
     import torch
     N, d, n, R, M, fixed = {"C3": (64, 2, 10, 0, 8, 1), "deg7": (20, 2, 7, 0, 2, 2), "elevated": (8, 2, 10, 6, 3, 1),
+                            "deg8": (17, 2, 8, 0, 3, 2), "deg8_elevated": (9, 2, 8, 10, 2, 1),
                             "space3d": (7, 3, 5, 0, 0, 1), "generic": (5, 2, 12, 2, 2, 1)}[shape]
     Y = synth.swarm_control_points(N, d, n, seed=12)
     polys = synth.polygon_obstacles(M, seed=12)
@@ -1253,7 +1258,8 @@ def test_fd_forms_equal_the_materialised_batch(capi, synth, shape):
     ctx.set_polygons(*(synth.pack_polys(polys) if M else (None, [0])))
     ctx.set_hull_pairs(pa, pb)
     on_fly = ctx.fd_forms_on_the_fly()
-    assert on_fly == {"C3": (True, True), "deg7": (True, True), "elevated": (False, True), "space3d": (False, False),
+    assert on_fly == {"C3": (True, True), "deg7": (True, True), "deg8": (True, True), "deg8_elevated": (False, True),
+                      "elevated": (False, True), "space3d": (False, False),
                       "generic": (False, False)}[shape]      # generic: degree 12 has no specialised kernel at all
     h = 1e-3
     d0 = torch.from_numpy(Y).cuda()
@@ -1391,12 +1397,13 @@ def test_min_dist2poly_robust(capi, synth, golden_dir, host_gjk):
     assert d_rob <= d_ref * (1 + 1e-9) and pt.shape == (3,)
 
 
-@pytest.mark.parametrize("shape", ["C3", "deg7_ragged", "elevated_fallback", "tiled_256x15", "with_point_obstacles", "elevated_two_launches"])
+@pytest.mark.parametrize("shape", ["C3", "deg7_ragged", "deg8", "deg8_elevated", "elevated_fallback", "tiled_256x15", "with_point_obstacles", "elevated_two_launches"])
 def test_constraint_sweep_equals_separate_calls(capi, synth, shape):
     """obtg_constraint_sweep_dev: all four families of a batch in one call, against the separate entry points (pair
     sweep + fused dynamics), bit for bit; on a materialised batch and inside an FD view."""
     import torch
     N, n, R, M, B = {"C3": (64, 10, 0, 8, 700), "deg7_ragged": (40, 7, 0, 3, 11), "elevated_fallback": (8, 10, 5, 2, 9),
+                     "deg8": (33, 8, 0, 3, 13), "deg8_elevated": (40, 8, 10, 2, 7),
                      "tiled_256x15": (256, 15, 0, 0, 3), "with_point_obstacles": (20, 10, 0, 2, 15),
                      "elevated_two_launches": (40, 10, 12, 2, 7)}[shape]    # DEG_ELEV > 0: separation + dynamics share a launch
     Y = synth.swarm_control_points(N, 2, n, seed=21)
@@ -1445,9 +1452,9 @@ def test_constraint_sweep_equals_separate_calls(capi, synth, shape):
         torch.cuda.synchronize()
         ks = ctx.kernel_stats()
         ctx.set_profiling(False)
-        if shape in ("C3", "tiled_256x15", "with_point_obstacles"):       # the whole step is ONE launch: the dynamics groups are the grid's last workgroups
+        if shape in ("C3", "deg8", "tiled_256x15", "with_point_obstacles"):       # the whole step is ONE launch: the dynamics groups are the grid's last workgroups
             assert ks.get("pair_sweep", (0.0, 0))[1] == 2 and ks.get("ang_rate", (0.0, 0))[1] == 0, ks
-        if shape == "elevated_two_launches":      # gjkNew sweep + (separation rows with the dynamics groups among them)
+        if shape in ("elevated_two_launches", "deg8_elevated"):      # gjkNew sweep + (separation rows with the dynamics groups among them)
             assert ks.get("temporal_sep", (0.0, 0))[1] == 2 and ks.get("gjk", (0.0, 0))[1] == 2 and ks.get("ang_rate", (0.0, 0))[1] == 0, ks
         for key in a:
             assert torch.equal(a[key].view(torch.uint8), b[key].view(torch.uint8)), (key, view)
@@ -1518,7 +1525,7 @@ def test_both_speed_bounds_from_one_pass(capi, synth, oracle, shape):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("shape", ["C3_full_batch", "deg7_two_fixed", "three_vehicles", "deg5_no_polys", "elevated_R6", "C5_like_R100", "one_row", "two_rows_elevated", "C4_like_large_rows", "rows_of_96KB",
+@pytest.mark.parametrize("shape", ["C3_full_batch", "deg7_two_fixed", "deg8_two_fixed", "deg8_elevated_R10", "three_vehicles", "deg5_no_polys", "elevated_R6", "C5_like_R100", "one_row", "two_rows_elevated", "C4_like_large_rows", "rows_of_96KB",
                                    "with_point_obstacles", "point_obstacles_elevated", "example1_class_path",
                                    "elevated_two_column_groups", "elevated_40_vehicles_odd_rows", "three_vehicles_elevated"])
 @pytest.mark.parametrize("tf_rows", ["one_tf", "a_few_rows_with_their_own_tf", "every_row_its_own_tf"])
@@ -1532,6 +1539,7 @@ def test_structured_fd_step_is_bit_identical_to_the_brute_force_sweep(capi, synt
     one ulp: the comparison is on bits), different in every row."""
     import torch
     N, n, M, fixed, R = {"C3_full_batch": (64, 10, 8, 1, 0), "deg7_two_fixed": (20, 7, 2, 2, 0), "three_vehicles": (3, 10, 1, 1, 0),
+                         "deg8_two_fixed": (21, 8, 3, 2, 0), "deg8_elevated_R10": (12, 8, 2, 1, 10),       # 9 control points (round 5)
                          "deg5_no_polys": (12, 5, 0, 1, 0), "elevated_R6": (9, 10, 3, 1, 6), "C5_like_R100": (64, 10, 32, 1, 100),
                          "one_row": (10, 7, 2, 1, 0), "two_rows_elevated": (6, 7, 1, 1, 3),
                          "C4_like_large_rows": (256, 15, 0, 1, 0),             # 70 KB of hulls per row: two workgroups per CU
