@@ -484,7 +484,7 @@ def test_degree8_driver_flows(golden_dir, which, pre, R, capsys):
         opt.DEG_ELEV = 0
 
 
-def test_degree8_callback_latency_is_that_of_degree7():
+def test_degree8_callback_latency_is_that_of_degree7(capsys):
     """One-row callbacks at degree 8 (9 control points, specialised since round 5) cost what degree 7's do -- until then
     they ran on the one-wave-per-item any-degree kernels.  Median of 300 calls of each closure, 2 vehicles + 2 point
     obstacles; bound: within 10 % (+ 2 us of timer noise)."""
@@ -505,6 +505,9 @@ def test_degree8_callback_latency_is_that_of_degree7():
                 f(x)
                 ts.append(time.perf_counter() - t0)
             med[(deg, f.__qualname__.split('.')[1])] = float(np.median(ts)) * 1e6
+    with capsys.disabled():
+        print("\none-row callback medians (us): " + ", ".join("%s deg7 %.1f deg8 %.1f" % (f[:12], med[(7, f)], med[(8, f)])
+                                                             for f in ("temporalSeparationConstraints", "maxSpeedConstraints", "maxAngularRateConstraints")))
     for fam in ("temporalSeparationConstraints", "maxSpeedConstraints", "maxAngularRateConstraints"):
         assert med[(8, fam)] <= 1.10 * med[(7, fam)] + 2.0, med
 
