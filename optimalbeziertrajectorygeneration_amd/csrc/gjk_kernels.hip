@@ -3395,6 +3395,7 @@ __global__ __launch_bounds__(64) void k_min_dist2poly_wave(const Md2Params p)
     extern __shared__ double m2_lds[];
     const int k = blockIdx.x, lane = threadIdx.x, li = lane & 31;
     const int K = p.K, FR = 3 * K + G_NSCAL;
+    const int rl = lane / K, il = lane - rl * K;          // (row, point) of the lane in the level-parallel splits
     const int po = p.off[p.pp[k]], PK = p.off[p.pp[k] + 1] - po;
     double* cur = m2_lds;                       // [3K] curve of the node being evaluated
     double* nxt = cur + 3 * K;                  // [3K] the child being built
@@ -3485,7 +3486,8 @@ __global__ __launch_bounds__(64) void k_min_dist2poly_wave(const Md2Params p)
             const int h1 = state - 1;
             const double t1 = sc[G_T1];
             double* nf = f + FR;
-            if (lane < 3) split_row_lds(cur + lane * K, K, t1, h1, nxt + lane * K, sh_e + lane * kMdMaxK);
+            if (3 * K <= kWave) split_rows3_wave(cur, K, t1, h1, nxt, rl, il);        // level-parallel (see k_min_dist_wave)
+            else if (lane < 3) split_row_lds(cur + lane * K, K, t1, h1, nxt + lane * K, sh_e + lane * kMdMaxK);
             wave_sync();
             for (int i = lane; i < 3 * K; i += kWave) nf[i] = nxt[i];
             const double t1len = sc[G_T1H] - sc[G_T1L];
