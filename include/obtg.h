@@ -443,6 +443,9 @@ int obtg_bern_diff(obtg_ctx*, const double* in, int rows, int n, double T, doubl
 int obtg_bern_mul(obtg_ctx*, const double* a, const double* b, int rows, int m, int n, double* out);
 int obtg_bern_normsq(obtg_ctx*, const double* x, int d, int n, double* out);
 int obtg_bern_split(obtg_ctx*, const double* in, int rows, int n, double z, double* left, double* right);
+/* Bezier.__call__ / Bezier.curve (bezier.py:184-199, 233-258) -> deCasteljauCurve (bezier.py:945-982): every row of
+ * cpts[rows][n+1] at every tau[k]: out[rows][n_tau], T = (tau - t0) / (tf - t0), the de Casteljau triangle per sample. */
+int obtg_bern_eval(obtg_ctx*, const double* cpts, int rows, int n, const double* tau, int n_tau, double t0, double tf, double* out);
 
 /* ---- objectives (optimization.py:462-489 _euclideanObjective, 503-519 _minAccelObjective,
  * 522-539 _minJerkObjective): sums over vehicles of the elevated |d^k pos/dt^k|^2 control

@@ -104,6 +104,7 @@ _SIGNATURES = {
     "obtg_bern_mul": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),
     "obtg_bern_normsq": (_i, [_vp, _vp, _i, _i, _vp]),
     "obtg_bern_split": (_i, [_vp, _vp, _i, _i, _d, _vp, _vp]),
+    "obtg_bern_eval": (_i, [_vp, _vp, _i, _i, _vp, _i, _d, _d, _vp]),
     "obtg_euclidean_obj": (_i, [_vp, _vp, _i, _vp]),
     "obtg_accel_obj": (_i, [_vp, _vp, _vp, _i, _vp]),
     "obtg_jerk_obj": (_i, [_vp, _vp, _vp, _i, _vp]),
@@ -841,6 +842,16 @@ class Context(object):
         self._check(self._lib.obtg_bern_split(self._h, _ptr(a), rows, nc - 1, float(z), _ptr(left), _ptr(right)),
                     "obtg_bern_split")
         return left, right
+
+    def bern_eval(self, cpts, tau, t0, tf):
+        """Every row of control points at every tau (obtg_bern_eval: de Casteljau per sample) -> rows x len(tau)."""
+        a = np.atleast_2d(_f64(cpts))
+        tau = np.atleast_1d(_f64(tau)).reshape(-1)
+        rows, nc = a.shape
+        out = np.empty((rows, tau.size))
+        self._check(self._lib.obtg_bern_eval(self._h, _ptr(a), rows, nc - 1, _ptr(tau), tau.size, float(t0), float(tf), _ptr(out)),
+                    "obtg_bern_eval")
+        return out
 
     # -- instrumentation
     def temporal_sep_fd(self, Y0, pert_row, pert_col, pert_val, max_sep):

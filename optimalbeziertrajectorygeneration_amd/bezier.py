@@ -11,8 +11,9 @@ Differences from the reference, on purpose:
   * `minDist` / `minDist2Poly` work (at the reference's HEAD they raise because `gjkNew` is
     never imported, bezier.py:21-22) and report the reference's non-terminating inputs as
     exceptions instead of hanging;
-  * plotting, sampling on `tau` and temporal alignment of curves with different [t0, tf]
-    are outside the accelerated path and are not provided.
+  * plotting (`plot`, matplotlib) and temporal alignment of curves with different [t0, tf] are outside the
+    accelerated path and are not provided; `curve` / `__call__` -- what the drivers' own
+    plotting code reads after a solve -- are (obtg_bern_eval).
 """
 import numpy as np
 
@@ -125,6 +126,17 @@ class Bezier(BezierParams):
     @property
     def z(self):
         return Bezier(self.cpts[2], t0=self.t0, tf=self.tf) if self.dim > 2 else None
+
+    def __call__(self, t):
+        """The curve at the value(s) t, dim x len(t) (bezier.py:184-199); not cached."""
+        return _ctx().bern_eval(self.cpts, np.atleast_1d(t), self.t0, self.tf)
+
+    @property
+    def curve(self):
+        """The curve at every value of `tau` (1001 samples over [t0, tf] unless a grid was given), dim x len(tau)
+        (bezier.py:233-258): what the drivers plot after a solve.  Sampled on the device on every access -- the
+        reference caches it until cpts / tau change; a sample set is 24 KB and one launch."""
+        return _ctx().bern_eval(self.cpts, self.tau, self.t0, self.tf)
 
     def copy(self):
         return Bezier(self.cpts, self.t0, self.tf)

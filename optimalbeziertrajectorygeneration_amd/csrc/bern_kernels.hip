@@ -953,6 +953,27 @@ __global__ __launch_bounds__(kWave) void k_bern_split(const BernParams p, double
     if (lane == 0) { L[n] = cur[0]; Rt[0] = cur[0]; }
 }
 
+// Bezier.__call__ / Bezier.curve (bezier.py:184-199, 233-258) -> deCasteljauCurve (bezier.py:945-982): every row of control
+// points at every value of tau.  T = (tau - t0) / (tf - t0), then the triangle `(1 - t) c_i + t c_{i+1}` per sample: one
+// lane per (row, sample), the row's control points in LDS (all lanes read the same address: a broadcast), the lane's
+// working copy in LDS as well (pitch nc | 1: conflict-free).
+__global__ __launch_bounds__(kWave) void k_bern_eval(const double* __restrict__ cpts, const double* __restrict__ tau, int n_tau,
+                                                     int nc, double t0, double tf, double* __restrict__ out)
+{
+    extern __shared__ double lds[];
+    const int lane = threadIdx.x, r = blockIdx.y, k = blockIdx.x * kWave + lane, pitch = nc | 1;
+    double* row = lds;                         // [nc]
+    double* w = lds + nc + lane * pitch;       // [nc] per lane
+    for (int e = lane; e < nc; e += kWave) row[e] = cpts[(size_t)r * nc + e];
+    __syncthreads();
+    if (k >= n_tau) return;
+    const double t = (tau[k] - t0) / (tf - t0), u = 1.0 - t;
+    for (int i = 0; i < nc; ++i) w[i] = row[i];
+    for (int len = nc; len > 1; --len)
+        for (int i = 0; i < len - 1; ++i) w[i] = u * w[i] + t * w[i + 1];
+    out[(size_t)r * n_tau + k] = w[0];
+}
+
 // =====================================================================================
 //  finite-difference batch, objectives
 // =====================================================================================
@@ -1644,6 +1665,21 @@ int launch_bern_split(obtg_ctx* c, const double* d_in, int rows, int n, double z
     p.a = d_in; p.out = d_left; p.rows = rows; p.n = n; p.T = z;
     ScopedKernelTimer t(c, OBTG_K_BERN);
     hipLaunchKernelGGL(k_bern_split, dim3(rows), dim3(kWave), sizeof(double) * 2 * (n + 1), c->stream, p, d_right);
+    OBTG_HIP(c, hipGetLastError());
+    return OBTG_OK;
+}
+
+int launch_bern_eval(obtg_ctx* c, const double* d_cpts, int rows, int n, const double* d_tau, int n_tau, double t0, double tf,
+                     double* d_out)
+{
+    if (rows <= 0 || n_tau <= 0) return OBTG_OK;
+    if (n < 0 || n + 1 > kMaxGenericLen) return OBTG_ERR_UNSUPPORTED;
+    const int nc = n + 1;
+    const size_t lds = sizeof(double) * ((size_t)nc + (size_t)kWave * (nc | 1));
+    if (lds > 64 * 1024) return OBTG_ERR_UNSUPPORTED;
+    ScopedKernelTimer t(c, OBTG_K_BERN);
+    hipLaunchKernelGGL(k_bern_eval, dim3((unsigned)((n_tau + kWave - 1) / kWave), (unsigned)rows), dim3(kWave), lds, c->stream,
+                       d_cpts, d_tau, n_tau, nc, t0, tf, d_out);
     OBTG_HIP(c, hipGetLastError());
     return OBTG_OK;
 }

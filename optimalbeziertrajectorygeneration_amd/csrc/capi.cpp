@@ -234,7 +234,7 @@ const char* obtg_abi_symbols(void)
         "obtg_temporal_sep_dev\0obtg_temporal_sep_min_dev\0obtg_speed_dev\0obtg_ang_rate_dev\0obtg_dynamics_dev\0"
         "obtg_fd_batch_dev\0obtg_fd_view_begin\0obtg_fd_view_begin_rows\0obtg_fd_view_end\0obtg_fd_forms_on_the_fly\0obtg_pair_sweep_fd_dev\0obtg_dynamics_fd_dev\0obtg_gjk_pairs\0obtg_ctx_set_polygons\0obtg_ctx_set_hull_pairs\0"
         "obtg_ctx_set_fd_dedup\0obtg_ctx_set_gjk_history\0obtg_pair_sweep_dev\0obtg_constraint_sweep_dev\0obtg_constraint_sweep_fd_structured_dev\0obtg_constraint_sweep_fd_structured_rows_dev\0obtg_gjk_swarm_dev\0obtg_gjk_swarm\0obtg_min_dist\0obtg_min_dist_robust\0obtg_min_dist2poly\0obtg_min_dist2poly_robust\0obtg_gjk_true_pairs\0"
-        "obtg_bern_elev\0obtg_bern_diff\0obtg_bern_mul\0obtg_bern_normsq\0obtg_bern_split\0"
+        "obtg_bern_elev\0obtg_bern_diff\0obtg_bern_mul\0obtg_bern_normsq\0obtg_bern_split\0obtg_bern_eval\0"
         "obtg_euclidean_obj\0obtg_accel_obj\0obtg_jerk_obj\0"
         "obtg_set_profiling\0obtg_set_profile_period\0obtg_kernel_stats\0obtg_reset_kernel_stats\0obtg_kernel_name\0";
     return syms;
@@ -1351,6 +1351,20 @@ int obtg_bern_split(obtg_ctx* c, const double* in, int rows, int n, double z, do
     if ((rc = launch_bern_split(c, c->ws_in.as<double>(), rows, n, z, dl, dl + len))) return rc;
     if ((rc = d2h_copy(c, left, dl, sizeof(double) * len))) return rc;
     return d2h(c, right, dl + len, sizeof(double) * len);
+}
+
+int obtg_bern_eval(obtg_ctx* c, const double* cpts, int rows, int n, const double* tau, int n_tau, double t0, double tf, double* out)
+{
+    if (!check_ctx(c) || !cpts || !tau || !out || rows < 0 || n < 0 || n_tau < 0) return OBTG_ERR_ARG;
+    if (rows == 0 || n_tau == 0) return OBTG_OK;
+    (void)hipSetDevice(c->device);
+    int rc = h2d(c, c->ws_in, cpts, sizeof(double) * (size_t)rows * (n + 1));
+    if (rc) return rc;
+    if ((rc = h2d(c, c->ws_in2, tau, sizeof(double) * (size_t)n_tau))) return rc;
+    if ((rc = c->ws_out.reserve(sizeof(double) * (size_t)rows * n_tau))) return rc;
+    if ((rc = launch_bern_eval(c, c->ws_in.as<double>(), rows, n, c->ws_in2.as<double>(), n_tau, t0, tf, c->ws_out.as<double>())))
+        return rc;
+    return d2h(c, out, c->ws_out.p, sizeof(double) * (size_t)rows * n_tau);
 }
 
 int obtg_bern_mul(obtg_ctx* c, const double* a, const double* b, int rows, int m, int n, double* out)

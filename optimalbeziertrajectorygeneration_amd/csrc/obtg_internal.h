@@ -229,6 +229,8 @@ bool pair_sweep_is_one_launch(const obtg_ctx* c);
 int launch_bern_elev(obtg_ctx* c, const double* d_in, int rows, int n, int R, double* d_out);
 int launch_bern_diff(obtg_ctx* c, const double* d_in, int rows, int n, double T, double* d_out);
 int launch_bern_split(obtg_ctx* c, const double* d_in, int rows, int n, double z, double* d_left, double* d_right);
+int launch_bern_eval(obtg_ctx* c, const double* d_cpts, int rows, int n, const double* d_tau, int n_tau, double t0, double tf,
+                     double* d_out);
 int launch_bern_mul(obtg_ctx* c, const double* d_a, const double* d_b, int rows, int m, int n,
                     double* d_out);
 int launch_bern_normsq(obtg_ctx* c, const double* d_x, int d, int n, double* d_out);

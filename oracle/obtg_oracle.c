@@ -726,6 +726,22 @@ EXPORT void obtg_oracle_split(const double *cpts, int rows, int n, double z, dou
     }
 }
 
+/* bezier.py:945-982 deCasteljauCurve (behind Bezier.__call__ and Bezier.curve, bezier.py:184-199, 233-258): every row
+ * of cpts[rows][n+1] at every tau; T = (tau - t0) / (tf - t0); out[rows][ntau] */
+EXPORT void obtg_oracle_eval(const double *cpts, int rows, int n, const double *tau, int ntau, double t0, double tf, double *out)
+{
+    int K = n + 1;
+    double w[K];
+    for (int r = 0; r < rows; ++r)
+        for (int k = 0; k < ntau; ++k) {
+            double t = (tau[k] - t0) / (tf - t0);
+            for (int i = 0; i < K; ++i) w[i] = cpts[(long)r * K + i];
+            for (int len = K; len > 1; --len)
+                for (int i = 0; i < len - 1; ++i) w[i] = (1 - t) * w[i] + t * w[i + 1];
+            out[(long)r * ntau + k] = w[0];
+        }
+}
+
 /* bezier.py:1320-1351: curve parameter of a hull closest point */
 static double hull_param(const double *poly, int K, const double *closest)
 {

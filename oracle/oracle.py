@@ -100,6 +100,15 @@ def split(cpts, z):
     return left, right
 
 
+def curve_eval(cpts, tau, t0, tf):
+    cpts = np.atleast_2d(_f64(cpts))
+    tau = np.atleast_1d(_f64(tau)).reshape(-1)
+    rows, nc = cpts.shape
+    out = np.empty((rows, tau.size))
+    lib().obtg_oracle_eval(_p(cpts), C.c_int(rows), C.c_int(nc - 1), _p(tau), C.c_int(tau.size), C.c_double(t0), C.c_double(tf), _p(out))
+    return out
+
+
 def normsq(x):
     x = np.atleast_2d(_f64(x))
     d, nc = x.shape

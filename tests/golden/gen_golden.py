@@ -211,6 +211,10 @@ def gen_ops():
                 d[pre + "split%d_t" % q] = np.array(frac * tf)
                 d[pre + "split%d_l" % q], d[pre + "split%d_r" % q] = np.asarray(c1.cpts), np.asarray(c2.cpts)
                 d[pre + "split%d_span" % q] = np.array([c1.t0, c1.tf, c2.t0, c2.tf])
+            # Bezier.__call__ and Bezier.curve (bezier.py:184-199, 233-258; deCasteljauCurve): a few samples incl. the ends
+            ts = np.array([0.0, 0.125 * tf, 0.5 * tf, 0.77 * tf, tf])
+            d[pre + "call_t"], d[pre + "call_v"] = ts, A(ts)
+            d[pre + "curve_head"], d[pre + "curve_tail"] = A.curve[:, :3].copy(), A.curve[:, -3:].copy()
             case += 1
     d["n_cases"] = np.array(case)
     save("bezier_ops.npz", **d)
@@ -821,6 +825,25 @@ def gen_fullsize():
     save("fullsize.npz", **d)
 
 
+def gen_c4_hulls():
+    """BASELINE config 4's hull sweep through the reference: gjkNew on all C(256, 2) = 32 640 pairs of the seeded
+    256-vehicle degree-15 swarm (16-point control polygons), with the support-index trace of every pair.  Closest
+    points are left out (1.5 MB); flag, distance, status and traces are what the bit-exactness bar is about."""
+    import time
+    N, n = 256, 15
+    Y = synth.swarm_control_points(N, 2, n, seed=1234)
+    polys = synth.hulls_from_Y(Y, 2)
+    pa, pb = synth.swarm_pairs(N, 0)
+    t0 = time.perf_counter()
+    g = gjk_group(polys, pa, pb)
+    ok = g["status"] == 0
+    print("  c4 hulls: %d pairs in %.1f s, flags(-1,0,1) %s, timeouts %d, mean supports %.2f" % (
+        len(pa), time.perf_counter() - t0, np.bincount(g["flag"][ok] + 1, minlength=3), (~ok).sum(), np.diff(g["trace_off"])[ok].mean()))
+    d = {"c4_" + k: v for k, v in g.items() if k not in ("c1", "c2")}
+    d["Y"] = Y
+    save("c4_hulls.npz", **d)
+
+
 def _slsqp_attempts(bo, cons, bounds=None, max_retries=8):
     """The drivers' `results = minimize(...); while not results.success: xGuess = generateGuess(std=std); ...` loop
     (Examples/DubinsCarTimeOptimal.py:109-137) with SEEDED retries (seed 100 + std; the examples draw unseeded).  One
@@ -917,7 +940,7 @@ def gen_drivers():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["tables", "ops", "problem", "constraints", "gjk", "mindist", "c5", "spatial", "nearstop", "sequential", "spatial_fd", "mindist_script", "c1_text", "fullsize", "drivers"]
+    which = sys.argv[1:] or ["tables", "ops", "problem", "constraints", "gjk", "mindist", "c5", "spatial", "nearstop", "sequential", "spatial_fd", "mindist_script", "c1_text", "fullsize", "drivers", "c4_hulls"]
     for w in which:
         if w == "none":          # import-only (exploration)
             continue

@@ -42,6 +42,14 @@ def test_bezier_methods_match_reference(golden_dir):
         assert_close(ns.cpts, o[pre + "normsq"])
         assert_close((A * B).cpts, o[pre + "mul"])
         assert np.array_equal((A - B).cpts, o[pre + "sub"]) and np.array_equal((A + B).cpts, o[pre + "add"])
+        # Bezier.__call__ / Bezier.curve (bezier.py:184-199, 233-258): what the drivers' plotting code reads after a solve
+        assert_close(A(o[pre + "call_t"]), o[pre + "call_v"], 1e-12, "curve at given values")
+        assert A(float(o[pre + "call_t"][2])).shape == (A.dim, 1)
+        cv = A.curve
+        assert cv.shape == (A.dim, 1001)
+        assert_close(cv[:, :3], o[pre + "curve_head"], 1e-12, "curve head")
+        assert_close(cv[:, -3:], o[pre + "curve_tail"], 1e-12, "curve tail")
+        assert np.array_equal(cv[:, 0], a[:, 0]) and np.array_equal(cv[:, -1], a[:, -1])     # the end points exactly
         for q in range(3):                                     # Bezier.split (bezier.py:533-572)
             c1, c2 = A.split(float(o[pre + "split%d_t" % q]))
             assert_close(c1.cpts, o[pre + "split%d_l" % q])

@@ -43,6 +43,11 @@ def test_bezier_ops(oracle, golden_dir):
         assert_close(oracle.normsq(a), o[pre + "normsq"], 1e-13, pre + "normsq")
         assert_close(oracle.mul(a, b), o[pre + "mul"], 1e-13, pre + "mul")
         assert (a - b == o[pre + "sub"]).all() and (a + b == o[pre + "add"]).all()
+        # Bezier.__call__ / Bezier.curve (deCasteljauCurve, bezier.py:945-982): the same operations in the same order
+        assert np.array_equal(oracle.curve_eval(a, o[pre + "call_t"], 0.0, tf), o[pre + "call_v"])
+        grid = np.linspace(0.0, tf, 1001)
+        cv = oracle.curve_eval(a, grid, 0.0, tf)
+        assert np.array_equal(cv[:, :3], o[pre + "curve_head"]) and np.array_equal(cv[:, -3:], o[pre + "curve_tail"])
         for q in range(3):
             left, right = oracle.split(a, float(o[pre + "split%d_t" % q]) / tf)
             assert_close(left, o[pre + "split%d_l" % q], 1e-13, pre + "split left")
@@ -118,12 +123,13 @@ def test_c1_as_baseline_text_has_it(oracle, golden_dir):
         assert_close(oracle.speed(y, 1, 2, 0, x[-1], 5.0, 1), g["maxspeed_" + tag], 1e-12)
         assert_close(oracle.ang_rate(y, 1, 0, x[-1], 1.0), g["angrate_" + tag], 1e-9)
 
-@pytest.mark.parametrize("grp", ["lit", "c3", "dense", "s3d"])
+@pytest.mark.parametrize("grp", ["lit", "c3", "dense", "s3d", "c4"])
 def test_gjk_bit_exact(oracle, golden_dir, grp):
     """flag, support-index sequence, closest points and distance: BIT-EXACT on every
     input where the reference terminates; on the others (the generator's timer fired) the cycle
     detector proves that minimumDistance's loop can never exit."""
-    g = _load(golden_dir, "gjk.npz")
+    # c4 (round 5): all 32 640 hull pairs of BASELINE config 4's 256-vehicle degree-15 swarm (closest points left out of the fixture)
+    g = _load(golden_dir, "c4_hulls.npz" if grp == "c4" else "gjk.npz")
     pa, pb = g[grp + "_pair_a"], g[grp + "_pair_b"]
     r = oracle.gjk_pairs(g[grp + "_pts"], g[grp + "_off"], pa, pb, trace_cap=64, md_cap=2000)
     ok = g[grp + "_status"] == 0
@@ -142,8 +148,9 @@ def test_gjk_bit_exact(oracle, golden_dir, grp):
         assert (r["trace"][k, :n] == tr[toff[k]:toff[k + 1]]).all(), "support trace of pair %d" % k
     sep = ok & (g[grp + "_flag"] == 1)
     assert (r["dist"][sep] == g[grp + "_dist"][sep]).all()
-    assert (r["c1"][sep] == g[grp + "_c1"][sep]).all()
-    assert (r["c2"][sep] == g[grp + "_c2"][sep]).all()
+    if grp != "c4":
+        assert (r["c1"][sep] == g[grp + "_c1"][sep]).all()
+        assert (r["c2"][sep] == g[grp + "_c2"][sep]).all()
 
 
 def test_gjk_known_answers(oracle):
