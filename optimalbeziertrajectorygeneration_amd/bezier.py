@@ -113,7 +113,7 @@ class Bezier(BezierParams):
         return self.div(curve)
 
     def __repr__(self):
-        return 'Bezier({}, {}, {})'.format(self.cpts, self.t0, self.tf)
+        return 'Bezier({}, {}, {}, {})'.format(self.cpts, self.tau, self.t0, self.tf)       # (bezier.py:180-182: tau is printed too)
 
     @property
     def x(self):

@@ -75,6 +75,41 @@ def _maxAngularRateConstraints(y, nVeh, dim, tf, maxAngRate):
     return _shape_ctx(nVeh, dim, y.shape[1] - 1, DEG_ELEV).ang_rate(y, tf, maxAngRate)[0]
 
 
+def _euclideanObjective(y, nVeh, dim):
+    """optimization.py:463-490: summed distances between neighbouring control points, every vehicle (obtg_euclidean_obj)."""
+    y = np.ascontiguousarray(y, dtype=np.float64)
+    return float(_shape_ctx(nVeh, dim, y.shape[1] - 1, 0).euclidean_obj(y)[0])
+
+
+def _minAccelObjective(y, nVeh, dim, tf):
+    """optimization.py:503-520: sum of the elevated control points of |acceleration|^2 (obtg_accel_obj)."""
+    y = np.ascontiguousarray(y, dtype=np.float64)
+    return float(_shape_ctx(nVeh, dim, y.shape[1] - 1, DEG_ELEV).deriv_energy_obj(y, tf, 2)[0])
+
+
+def _minJerkObjective(y, nVeh, dim, tf):
+    """optimization.py:523-540: the same for the jerk (obtg_jerk_obj)."""
+    y = np.ascontiguousarray(y, dtype=np.float64)
+    return float(_shape_ctx(nVeh, dim, y.shape[1] - 1, DEG_ELEV).deriv_energy_obj(y, tf, 3)[0])
+
+
+def _angularRateSqr(bezTraj):
+    """optimization.py:578-611: the squared angular rate of ONE planar trajectory as a rational curve -- control points
+    num / den (inf / nan kept), weights den = (|v|^2)^2.  The quotient is obtg_ang_rate's (bound 0: the kernel returns
+    0 - num/den), the weights two device products of the speed curve; the trajectory is taken at the degree it has."""
+    if bezTraj.dim != 2:
+        raise ValueError('The input curve must be two dimensional,\n'
+                         'instead it is {} dimensional'.format(bezTraj.dim))
+    cpts = np.ascontiguousarray(bezTraj.cpts, dtype=np.float64)
+    ctx = _capi.Context(1, 2, bezTraj.deg, 0)
+    try:
+        quotient = 0.0 - ctx.ang_rate(cpts, bezTraj.tf - bezTraj.t0, 0.0)[0]
+    finally:
+        ctx.close()
+    speed2 = bezTraj.diff().normSquare()              # (d / 2) |v|^2 with d = 2
+    return bez.RationalBezier(quotient[None, :], (speed2 * speed2).cpts)
+
+
 # (key of BezOptimization.model, constructor keyword, container) -- optimization.py:49-63 defines the keys
 _MODEL_FIELDS = (
     ('numVeh', 'numVeh', None), ('dim', 'dimension', None), ('deg', 'degree', None), ('minGoal', 'minimizeGoal', None),
