@@ -2049,11 +2049,40 @@ __device__ __forceinline__ void subcurve_row(double* x, int K, double a, double 
     }
 }
 
+// the same with the row in registers (K a compile-time constant): the loops of subcurve_row, element for element
+template <int KC>
+__device__ __forceinline__ void subcurve_row_reg(double (&x)[KC], double a, double w)
+{
+    const double b = a + w;
+    if (b < 1.0) {
+#pragma unroll
+        for (int sz = KC; sz > 1; --sz)
+#pragma unroll
+            for (int i = KC - 1; i >= KC - sz + 1; --i) x[i] = (1 - b) * x[i - 1] + b * x[i];
+    }
+    if (a > 0.0) {
+        const double u = a / b;
+#pragma unroll
+        for (int sz = KC; sz > 1; --sz)
+#pragma unroll
+            for (int i = 0; i < sz - 1; ++i) x[i] = (1 - u) * x[i] + u * x[i + 1];
+    }
+}
+
+// KC > 0: the control-point count is a compile-time constant and a node's six sub-curve rows live in REGISTERS (round 5).
+// The generic form (KC = 0) keeps every lane's rows in LDS: a sub-curve is K (K - 1) dependent multiply-adds, each an LDS
+// round trip, twelve rows per node (six per pass) -- ~95 us per 64-node step of a wave that has its SIMD to itself, and the
+// longest pair of the C5-sized sweep (13 945 nodes, 27 levels) WAS the launch: 20.8 ms alone, 20.8 ms with the other 4559
+// pairs beside it (tools/robust_stats_probe.py).  In registers the same loops are register arithmetic with the elements of a
+// level independent of one another, and pass B reuses the rows pass A formed.  The operations per element and their order
+// are those of the LDS form (this unit is compiled with -ffp-contract=off): identical results, node and level counts
+// (test_min_dist_robust_register_form_is_the_lds_form; OBTG_MDR_GENERIC=1 selects the LDS form).
+template <int KC>
 __global__ __launch_bounds__(64) void k_min_dist_robust(const MdrParams p)
 {
     extern __shared__ double mr_lds[];
     __shared__ int s_count;
-    const int k = blockIdx.x, lane = threadIdx.x, K = p.K;
+    const int k = blockIdx.x, lane = threadIdx.x, K = KC > 0 ? KC : p.K;
     const int pitch = (3 * K) | 1;
     double* orig = mr_lds;                         // [2][3][K]
     double* work = orig + 6 * K + lane * pitch;    // per lane: row scratch [K], projections [2][K]
@@ -2085,13 +2114,27 @@ __global__ __launch_bounds__(64) void k_min_dist_robust(const MdrParams p)
             const double w = __builtin_ldexp(1.0, -lev);
             // pass A: end points and a middle control point of both sub-curves
             double e[2][2][3], mid[2][3];
-            for (int cv = 0; cv < 2; ++cv)
-                for (int q = 0; q < 3; ++q) {
-                    for (int i = 0; i < K; ++i) work[i] = orig[(cv * 3 + q) * K + i];
-                    subcurve_row(work, K, cv ? t2 : t1, w);
-                    e[cv][0][q] = work[0]; e[cv][1][q] = work[K - 1];
-                    mid[cv][q] = 0.5 * (work[0] + work[K - 1]);
-                }
+            double sub[2][3][KC > 0 ? KC : 1];          // KC > 0: the node's six sub-curve rows, kept for pass B
+            if constexpr (KC > 0) {
+#pragma unroll
+                for (int cv = 0; cv < 2; ++cv)
+#pragma unroll
+                    for (int q = 0; q < 3; ++q) {
+#pragma unroll
+                        for (int i = 0; i < KC; ++i) sub[cv][q][i] = orig[(cv * 3 + q) * KC + i];
+                        subcurve_row_reg<KC>(sub[cv][q], cv ? t2 : t1, w);
+                        e[cv][0][q] = sub[cv][q][0]; e[cv][1][q] = sub[cv][q][KC - 1];
+                        mid[cv][q] = 0.5 * (sub[cv][q][0] + sub[cv][q][KC - 1]);
+                    }
+            } else {
+                for (int cv = 0; cv < 2; ++cv)
+                    for (int q = 0; q < 3; ++q) {
+                        for (int i = 0; i < K; ++i) work[i] = orig[(cv * 3 + q) * K + i];
+                        subcurve_row(work, K, cv ? t2 : t1, w);
+                        e[cv][0][q] = work[0]; e[cv][1][q] = work[K - 1];
+                        mid[cv][q] = 0.5 * (work[0] + work[K - 1]);
+                    }
+            }
             double best = INFINITY, b1 = -1, b2 = -1;
             for (int i1 = 0; i1 < 2; ++i1)
                 for (int i2 = 0; i2 < 2; ++i2) {
@@ -2114,17 +2157,28 @@ __global__ __launch_bounds__(64) void k_min_dist_robust(const MdrParams p)
             const double dn = __builtin_sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
             double lb = 0.0;
             if (dn > 0.0) {
-                double* pr = work + K;                  // [2][K]
-                for (int i = 0; i < 2 * K; ++i) pr[i] = 0.0;
-                for (int cv = 0; cv < 2; ++cv)
-                    for (int q = 0; q < 3; ++q) {
-                        for (int i = 0; i < K; ++i) work[i] = orig[(cv * 3 + q) * K + i];
-                        subcurve_row(work, K, cv ? t2 : t1, w);
-                        const double dq = d[q] / dn;
-                        for (int i = 0; i < K; ++i) pr[cv * K + i] += dq * work[i];
-                    }
                 double lo1 = INFINITY, hi2 = -INFINITY;
-                for (int i = 0; i < K; ++i) { lo1 = fmin(lo1, pr[i]); hi2 = fmax(hi2, pr[K + i]); }
+                if constexpr (KC > 0) {
+                    const double dq0 = d[0] / dn, dq1 = d[1] / dn, dq2 = d[2] / dn;
+#pragma unroll
+                    for (int i = 0; i < KC; ++i) {            // (the LDS form's pr[] += dq * row, q = 0, 1, 2, from 0.0)
+                        double s1 = 0.0, s2 = 0.0;
+                        s1 += dq0 * sub[0][0][i]; s1 += dq1 * sub[0][1][i]; s1 += dq2 * sub[0][2][i];
+                        s2 += dq0 * sub[1][0][i]; s2 += dq1 * sub[1][1][i]; s2 += dq2 * sub[1][2][i];
+                        lo1 = fmin(lo1, s1); hi2 = fmax(hi2, s2);
+                    }
+                } else {
+                    double* pr = work + K;                  // [2][K]
+                    for (int i = 0; i < 2 * K; ++i) pr[i] = 0.0;
+                    for (int cv = 0; cv < 2; ++cv)
+                        for (int q = 0; q < 3; ++q) {
+                            for (int i = 0; i < K; ++i) work[i] = orig[(cv * 3 + q) * K + i];
+                            subcurve_row(work, K, cv ? t2 : t1, w);
+                            const double dq = d[q] / dn;
+                            for (int i = 0; i < K; ++i) pr[cv * K + i] += dq * work[i];
+                        }
+                    for (int i = 0; i < K; ++i) { lo1 = fmin(lo1, pr[i]); hi2 = fmax(hi2, pr[K + i]); }
+                }
                 lb = fmax(0.0, (lo1 - hi2) * (1.0 - 1e-12));
             }
             const bool keep = valid && lb < alpha * (1 - p.eps) && alpha > abs_tol;
@@ -2258,11 +2312,14 @@ struct OnePoint {
     __device__ __forceinline__ tgjk::P3 operator()(int) const { return q; }
 };
 
+// KC > 0: the node's three sub-curve rows are formed in registers (subcurve_row_reg: see k_min_dist_robust) and then put into
+// the lane's LDS rows, where the two true-distance searches read them by support index; KC = 0: formed in the LDS rows.
+template <int KC>
 __global__ __launch_bounds__(64) void k_min_dist2poly_robust(const Md2rParams p)
 {
     extern __shared__ double mr_lds[];
     __shared__ int s_count;
-    const int k = blockIdx.x, lane = threadIdx.x, K = p.K;
+    const int k = blockIdx.x, lane = threadIdx.x, K = KC > 0 ? KC : p.K;
     const int pitch = (3 * K) | 1;
     const int po = p.off[p.pp[k]], Kp = p.off[p.pp[k] + 1] - po;
     double* orig = mr_lds;                         // [3][K]
@@ -2291,9 +2348,21 @@ __global__ __launch_bounds__(64) void k_min_dist2poly_robust(const Md2rParams p)
             const double t = fa[2 * ni];
             const int lev = (int)fa[2 * ni + 1];
             const double w = __builtin_ldexp(1.0, -lev);
-            for (int q = 0; q < 3; ++q) {
-                for (int i = 0; i < K; ++i) work[q * K + i] = orig[q * K + i];
-                subcurve_row(work + q * K, K, t, w);
+            if constexpr (KC > 0) {
+#pragma unroll
+                for (int q = 0; q < 3; ++q) {
+                    double x[KC];
+#pragma unroll
+                    for (int i = 0; i < KC; ++i) x[i] = orig[q * KC + i];
+                    subcurve_row_reg<KC>(x, t, w);
+#pragma unroll
+                    for (int i = 0; i < KC; ++i) work[q * KC + i] = x[i];
+                }
+            } else {
+                for (int q = 0; q < 3; ++q) {
+                    for (int i = 0; i < K; ++i) work[q * K + i] = orig[q * K + i];
+                    subcurve_row(work + q * K, K, t, w);
+                }
             }
             // upper bounds: the sub-curve's end points against the polygon's hull
             double best = INFINITY, bt_l = -1;
@@ -3518,9 +3587,21 @@ int launch_min_dist_robust(obtg_ctx* c, const double* d_curves, int K, const int
     if (n_pairs <= 0) return OBTG_OK;
     if (K < 2 || K > kMdMaxK || cap < 4 || max_level < 1 || max_level > 50) return OBTG_ERR_UNSUPPORTED;
     MdrParams p{ d_curves, d_pa, d_pb, n_pairs, K, max_nodes, max_level, cap, eps, d_frontier, d_res, d_info };
-    const size_t lds = sizeof(double) * ((size_t)6 * K + (size_t)kWave * ((3 * K) | 1));
+    size_t lds = sizeof(double) * ((size_t)6 * K + (size_t)kWave * ((3 * K) | 1));
+    // the specialised control-point counts keep a node's rows in registers (and need only the curves in LDS)
+    const char* env_generic = getenv("OBTG_MDR_GENERIC");                  // (read per launch: the A/B test flips it in-process)
+    const bool generic = env_generic && env_generic[0] == '1';
+    void (*kern)(const MdrParams) = k_min_dist_robust<0>;
+    if (!generic) {
+        switch (K) {
+#define OBTG_CASE(NC_) case NC_: kern = k_min_dist_robust<NC_>; lds = sizeof(double) * 6 * NC_; break;
+            OBTG_NC_DYN(OBTG_CASE)
+#undef OBTG_CASE
+            default: break;
+        }
+    }
     ScopedKernelTimer t(c, OBTG_K_MIN_DIST);
-    hipLaunchKernelGGL(k_min_dist_robust, dim3((unsigned)n_pairs), dim3(kWave), lds, c->stream, p);
+    hipLaunchKernelGGL(kern, dim3((unsigned)n_pairs), dim3(kWave), lds, c->stream, p);
     OBTG_HIP(c, hipGetLastError());
     return OBTG_OK;
 }
@@ -3546,11 +3627,20 @@ int launch_min_dist2poly_robust(obtg_ctx* c, const double* d_curves, int K, cons
     Md2rParams p{ d_curves, d_soa, d_off, d_pc, d_pp, n_pairs, K, max_nodes, max_level, cap, eps, d_frontier, d_res, d_info };
     const size_t lds = sizeof(double) * ((size_t)3 * K + (size_t)3 * max_poly_K + (size_t)kWave * ((3 * K) | 1));
     if (lds > 64 * 1024) return OBTG_ERR_UNSUPPORTED;
+    const char* env_generic = getenv("OBTG_MDR_GENERIC");
+    void (*kern)(const Md2rParams) = k_min_dist2poly_robust<0>;
+    if (!(env_generic && env_generic[0] == '1')) {
+        switch (K) {
+#define OBTG_CASE(NC_) case NC_: kern = k_min_dist2poly_robust<NC_>; break;
+            OBTG_NC_DYN(OBTG_CASE)
+#undef OBTG_CASE
+            default: break;
+        }
+    }
     if (lds > 48 * 1024)
-        OBTG_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_min_dist2poly_robust),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        OBTG_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     ScopedKernelTimer t(c, OBTG_K_MIN_DIST);
-    hipLaunchKernelGGL(k_min_dist2poly_robust, dim3((unsigned)n_pairs), dim3(kWave), lds, c->stream, p);
+    hipLaunchKernelGGL(kern, dim3((unsigned)n_pairs), dim3(kWave), lds, c->stream, p);
     OBTG_HIP(c, hipGetLastError());
     return OBTG_OK;
 }

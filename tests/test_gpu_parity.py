@@ -808,6 +808,41 @@ def test_pair_sweep_one_launch_equals_separate_kernels(capi, synth, shape):
     ctx.close()
 
 
+
+def test_min_dist_robust_register_form_is_the_lds_form(capi, synth, monkeypatch):
+    """obtg_min_dist_robust, round 5: for the specialised control-point counts a node's six sub-curve rows live in registers
+    (k_min_dist_robust<K>); the any-degree form keeps them in per-lane LDS rows.  Same operations per element in the same
+    order: results, node counts, level counts and largest frontiers identical on the C5-sized pair list (degree 10) and on
+    degree-5 and degree-8 curves in 3-D."""
+    for (ncurves, dim, n, seed) in ((96, 2, 10, 1234), (20, 3, 5, 3), (14, 3, 8, 4)):
+        Yc = synth.swarm_control_points(ncurves, dim, n, seed=seed)
+        curves = np.zeros((ncurves, 3, n + 1))
+        curves[:, :dim, :] = Yc.reshape(ncurves, dim, n + 1)
+        pa, pb = synth.all_pairs(ncurves)
+        ctx = capi.scratch_context()
+        fast = ctx.min_dist_robust(curves, pa, pb, eps=1e-9, max_nodes=400000)
+        monkeypatch.setenv("OBTG_MDR_GENERIC", "1")
+        slow = ctx.min_dist_robust(curves, pa, pb, eps=1e-9, max_nodes=400000)
+        monkeypatch.delenv("OBTG_MDR_GENERIC")
+        for key in ("res", "nodes", "levels", "frontier", "status"):
+            assert np.array_equal(fast[key], slow[key], equal_nan=True), (n, key)
+    # curve <-> polygon (obtg_min_dist2poly_robust): the sub-curve rows formed in registers, then used from LDS
+    polys = synth.polygon_obstacles(6, seed=9)
+    ppts, poff = synth.pack_polys(polys)
+    for (ncurves, n, seed) in ((40, 10, 5), (12, 8, 6), (9, 12, 7)):          # degree 12: no register form, both runs the same kernel
+        Yc = synth.swarm_control_points(ncurves, 2, n, seed=seed)
+        curves = np.zeros((ncurves, 3, n + 1))
+        curves[:, :2, :] = Yc.reshape(ncurves, 2, n + 1)
+        pc = np.repeat(np.arange(ncurves), len(polys)).astype(np.int32)
+        pp = np.tile(np.arange(len(polys)), ncurves).astype(np.int32)
+        ctx = capi.scratch_context()
+        fast = ctx.min_dist2poly_robust(curves, ppts, poff, pc, pp, eps=1e-9, max_nodes=200000)
+        monkeypatch.setenv("OBTG_MDR_GENERIC", "1")
+        slow = ctx.min_dist2poly_robust(curves, ppts, poff, pc, pp, eps=1e-9, max_nodes=200000)
+        monkeypatch.delenv("OBTG_MDR_GENERIC")
+        for key in ("res", "nodes", "levels", "frontier", "status"):
+            assert np.array_equal(fast[key], slow[key], equal_nan=True), (n, key)
+
 @pytest.mark.parametrize("R", [0, 7])
 def test_temporal_sep_is_the_sampled_squared_distance(capi, synth, R):
     """The reference's own eyeball check (temp.py:20-37), made numerical and independent of the oracle:
