@@ -368,6 +368,8 @@ def main():
         else:
             sparse_gather = _dd.SparseMinimaGather(B_total, N, ctx.n_veh + ctx.n_obs, d, n - 1, world=world, rank=rank)
             gather_bytes = sparse_gather.bytes_per_step
+            sg_send = sparse_gather.send_rows(dev)
+            sg_row0 = sparse_gather.send_row0(dev)
 
     gathered = {}
 
@@ -378,23 +380,48 @@ def main():
         for cx in ([ctx, ctx_dyn] if ctx_dyn is not ctx else [ctx]):
             cx.fd_view_begin(d0.data_ptr(), 1, synth.FD_STEP, B, row_begin=row_begin)
         sweeps()
+        if sparse_gather is not None:
+            # what this rank sends, straight from x's control points: per owned row the minima of the N - 1 pairs its vehicle
+            # touches (obtg_temporal_sep_fd_min_rows_dev: B (N - 1) pair evaluations, no [B][P] block is formed or read back),
+            # and, on the rank that owns it, row 0's P minima
+            first = max(row_begin, 1)
+            if row_begin == 0:
+                ctx.temporal_sep_min_dev(d0.data_ptr(), 1, max_sep, sg_row0.data_ptr())
+            if row_begin + B > first:
+                ctx.temporal_sep_fd_min_rows_dev(d0.data_ptr(), 1, synth.FD_STEP, first, row_begin + B - first, max_sep,
+                                                 sg_send[first - row_begin:].data_ptr())
+        elif d_min is not None:
+            # dense: the per-pair minima of this rank's rows from the library's reduced kernel, inside the same view (8 B P
+            # bytes written instead of the 8 B P L of the full block read back by torch.amin: 58 GB at C4)
+            ctx.temporal_sep_min_dev(None, B, max_sep, d_min.data_ptr())
         for cx in ([ctx, ctx_dyn] if ctx_dyn is not ctx else [ctx]):
             cx.fd_view_end()
-        if d_min is not None:         # (torch's work on its own stream: hand over with the library's sync)
+        if d_min is not None:         # (torch's collectives on its own stream: hand over with the library's sync)
             ctx.sync()
-            torch.amin(o_sep.view(B, P_t, L), dim=2, out=d_min[:B])
             if sparse_gather is not None:
-                gathered["sparse"], gathered["row0"] = sparse_gather.exchange(d_min[:B], force=args.force_dist)
+                gathered["sparse"], gathered["row0"] = sparse_gather.exchange_compact(sg_send[:B], sg_row0 if row_begin == 0 else None,
+                                                                                            force=args.force_dist)
             elif use_dist:
                 dist.all_gather_into_tensor(d_min_all.view(-1), d_min.view(-1))
 
     # spin-up: the clocks of an idle MI355X need a few hundred ms of work to settle (at C3 a step reads 0.257 ms
     # straight after start and 0.205 ms once they have); untimed, before the W warm-up steps
+    # (with a collective inside step() -- the rows mode's gathers -- every rank must run the SAME number of steps: the ranks
+    # agree after each batch whether to go on.  A time-based loop per rank deadlocks as soon as two ranks read the clock on
+    # either side of the limit: round 5 met it with three gloo ranks, two in the all-gather of a 21st batch and one in the
+    # barrier behind the loop.)
     t_spin = time.perf_counter()
-    while time.perf_counter() - t_spin < 0.4:
+    while True:
         for _ in range(20):
             step()
         torch.cuda.synchronize()
+        more = time.perf_counter() - t_spin < 0.4
+        if use_dist:
+            flag = torch.tensor([1 if more else 0], dtype=torch.int32, device=dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+            more = bool(flag.item())
+        if not more:
+            break
     ctxs = [ctx] + ([ctx_dyn] if ctx_dyn is not ctx else [])
 
     def prof(on, only=None, period=1):

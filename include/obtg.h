@@ -336,6 +336,14 @@ int obtg_temporal_sep_min_gather_dev(obtg_ctx*, obtg_comm*, const double* dY, in
 /* The two pieces of it for callers with a collective of their own (MPI, a host-staged exchange): rank's block of the pair
  * list, and rank blocks [n_ranks][B * ceil(P / n_ranks)] (rank r's `count_r` minima of row 0, then of row 1, ...: what
  * obtg_temporal_sep_min_dev(pair_begin, pair_count) writes, padded to the largest block) -> rows d_rows[B][P]. */
+/* What a rank of a ROW-sharded finite-difference step sends when the per-pair minima of every row are wanted in one place
+ * (distributed.SparseMinimaGather): batch row b >= 1 differs from row 0 only in the n_obj - 1 pairs of the vehicle
+ * it advances, so for the rows [row_begin, row_begin + n_rows) of the batch over dY0 (obtg_fd_view_begin's rows, row_begin >= 1)
+ * d_out[n_rows][n_obj - 1] holds, per row, the minima of exactly those pairs, partners ascending -- evaluated from dY0
+ * directly (n_rows (n_obj - 1) pair evaluations; no [B][P] block is formed), the same bits as the corresponding entries of
+ * obtg_temporal_sep_min_dev inside the view.  Row 0's P minima are obtg_temporal_sep_min_dev(dY0, 1, ...). */
+int obtg_temporal_sep_fd_min_rows_dev(obtg_ctx*, const double* dY0, int n_fixed_cols, double h, int row_begin, int n_rows,
+                                      double max_sep, double* d_out);
 int obtg_pair_block(const obtg_ctx*, int n_ranks, int rank, int* begin, int* count);
 int obtg_unpack_pair_blocks_dev(obtg_ctx*, const double* d_blocks, int B, int n_ranks, double* d_rows);
 

@@ -61,6 +61,7 @@ _SIGNATURES = {
     "obtg_temporal_sep_active": (_i, [_vp, _vp, _i, _d, _i, _vp, _vp]),
     "obtg_temporal_sep_active_dev": (_i, [_vp, _vp, _i, _d, _i, _i, _i, _vp, _vp]),
     "obtg_temporal_sep_min_gather_dev": (_i, [_vp, _vp, _vp, _i, _d, _vp]),
+    "obtg_temporal_sep_fd_min_rows_dev": (_i, [_vp, _vp, _i, _d, _i, _i, _d, _vp]),
     "obtg_comm_unique_id": (_i, [_vp]),
     "obtg_comm_create": (_i, [C.POINTER(_vp), _i, _i, _vp, _i]),
     "obtg_comm_destroy": (None, [_vp]),
@@ -484,6 +485,13 @@ class Context(object):
             pair_count = self.num_pairs - pair_begin
         self._check(self._lib.obtg_temporal_sep_active_dev(self._h, _vp(dY), B, float(max_sep), int(k), pair_begin, pair_count,
                                                            _vp(d_out_val), _vp(d_out_idx)), "obtg_temporal_sep_active_dev")
+
+    def temporal_sep_fd_min_rows_dev(self, dY0, n_fixed_cols, h, row_begin, n_rows, max_sep, d_out):
+        """Per finite-difference row only the minima of the pairs its vehicle touches: d_out[n_rows][n_obj - 1]
+        (obtg_temporal_sep_fd_min_rows_dev)."""
+        self._check(self._lib.obtg_temporal_sep_fd_min_rows_dev(self._h, _vp(dY0), int(n_fixed_cols), float(h), int(row_begin),
+                                                                int(n_rows), float(max_sep), _vp(d_out)),
+                    "obtg_temporal_sep_fd_min_rows_dev")
 
     # ---- pair partition + collective behind the C ABI (include/obtg.h obtg_comm_*)
     def pair_block(self, n_ranks, rank):

@@ -86,9 +86,12 @@ struct TsepFdParams {
     const int* __restrict__ prow;      // [n_pert] row of Y0 that perturbation t touches
     const int* __restrict__ pcol;      // [n_pert] column
     const double* __restrict__ pval;   // [n_pert] the perturbed value itself (x_k + h as the caller rounds it)
-    double* __restrict__ out;          // [n_pert][n_obj-1][L+R]
+    double* __restrict__ out;          // [n_pert][n_obj-1][L+R]; min_only: [n_pert][n_obj-1]
     int n_veh, n_obj, R, n_pert;
     double sign, offset;
+    int min_only;                      // 1: per item only the smallest of its L+R values (obtg_temporal_sep_fd_min_rows_dev)
+    int fd_row0, fd_fixed;             // prow == nullptr: perturbation t IS row fd_row0 + t (>= 1) of the finite-difference batch
+    double fd_h;                       //   over Y0 (obtg_fd_view_begin's rows: free control point (row - 1) advanced by fd_h)
 };
 
 template <int NC, int DIM>
@@ -100,8 +103,14 @@ __global__ __launch_bounds__(kWave) void k_tsep_fd(const TsepFdParams p)
     const int partners = p.n_obj - 1;
     if (item >= (long)p.n_pert * partners) return;
     const int t = (int)(item / partners), uu = (int)(item - (long)t * partners);
-    const int r = p.prow[t], cc = p.pcol[t];
-    const double val = p.pval[t];
+    int r, cc;
+    double val;
+    if (p.prow) { r = p.prow[t]; cc = p.pcol[t]; val = p.pval[t]; }
+    else {
+        const int free_cols = NC - 2 * p.fd_fixed, kq = p.fd_row0 + t - 1;
+        r = kq / free_cols; cc = p.fd_fixed + (kq - r * free_cols);
+        val = p.Y0[(size_t)r * NC + cc] + p.fd_h;              // (as k_fd_batch and the views form it)
+    }
     const int v = r / DIM, rq = r - v * DIM;
     const int u = uu < v ? uu : uu + 1;
     double a[DIM][NC];
@@ -117,6 +126,21 @@ __global__ __launch_bounds__(kWave) void k_tsep_fd(const TsepFdParams p)
     double cf[L];
     normsq_coeffs<NC, DIM>(a, as_ctab(p.W2), cf);
     const int LR = L + p.R;
+    if (p.min_only) {
+        double m = INFINITY;
+        if (p.R == 0) {
+#pragma unroll
+            for (int k = 0; k < L; ++k) m = fmin(m, p.sign * cf[k] + p.offset);
+        } else {
+            const ctab_t Td = as_ctab(p.Td);
+            double ch[L];
+#pragma unroll
+            for (int j = 0; j < L; ++j) ch[j] = p.sign * cf[j];
+            for (int k = 0; k < LR; ++k) m = fmin(m, elev_at<L>(ch, Td + k * L, p.offset));
+        }
+        p.out[item] = m;
+        return;
+    }
     double* o = p.out + (size_t)item * LR;
     if (p.R == 0) {
 #pragma unroll
@@ -1398,7 +1422,7 @@ static void second_speed_rows(const obtg_ctx* c, AngParams& p)
 
 // speed and/or angular rate in one launch (either output may be null)
 int launch_temporal_sep_fd(obtg_ctx* c, const double* dY0, int n_pert, const int* d_prow, const int* d_pcol,
-                           const double* d_pval, double max_sep, double* d_out)
+                           const double* d_pval, double max_sep, double* d_out, int min_only, int fd_row0, int fd_fixed, double fd_h)
 {
     if (n_pert <= 0 || c->n_obj < 2) return OBTG_OK;
     int rc = ensure_tables(c);
@@ -1407,6 +1431,7 @@ int launch_temporal_sep_fd(obtg_ctx* c, const double* dY0, int n_pert, const int
     TsepFdParams p{};
     p.Y0 = dY0; p.obs = c->d_obs.as<double>(); p.W2 = c->d_w2.as<double>(); p.Td = c->d_Td.as<double>();
     p.prow = d_prow; p.pcol = d_pcol; p.pval = d_pval; p.out = d_out;
+    p.min_only = min_only; p.fd_row0 = fd_row0; p.fd_fixed = fd_fixed; p.fd_h = fd_h;
     p.n_veh = c->n_veh; p.n_obj = c->n_obj; p.R = c->R; p.n_pert = n_pert;
     p.sign = 1.0; p.offset = 0.0 - max_sep * max_sep;
     const long items = (long)n_pert * (c->n_obj - 1);

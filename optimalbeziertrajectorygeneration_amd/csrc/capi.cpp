@@ -228,7 +228,7 @@ const char* obtg_abi_symbols(void)
         "obtg_strerror\0obtg_last_error\0obtg_abi_version\0obtg_fast_kernels\0obtg_device_count\0obtg_abi_symbols\0obtg_host_alloc\0obtg_host_free\0"
         "obtg_ctx_create\0obtg_ctx_destroy\0obtg_ctx_set_stream\0obtg_ctx_use_own_stream\0obtg_ctx_set_deg_elev\0obtg_ctx_set_ang_rate_order\0obtg_ctx_ang_rate_order_in_effect\0obtg_ctx_set_second_speed_bound\0obtg_sync\0"
         "obtg_len_temporal_sep\0obtg_len_speed\0obtg_len_ang_rate\0obtg_num_pairs\0"
-        "obtg_temporal_sep\0obtg_speed\0obtg_ang_rate\0obtg_temporal_sep_min\0obtg_temporal_sep_min_range\0obtg_temporal_sep_active\0obtg_temporal_sep_active_dev\0obtg_temporal_sep_min_gather_dev\0"
+        "obtg_temporal_sep\0obtg_speed\0obtg_ang_rate\0obtg_temporal_sep_min\0obtg_temporal_sep_min_range\0obtg_temporal_sep_active\0obtg_temporal_sep_active_dev\0obtg_temporal_sep_min_gather_dev\0obtg_temporal_sep_fd_min_rows_dev\0"
         "obtg_comm_unique_id\0obtg_comm_create\0obtg_comm_destroy\0obtg_comm_size\0obtg_comm_rank\0obtg_comm_last_error\0obtg_comm_all_gather_dev\0obtg_pair_block\0obtg_unpack_pair_blocks_dev\0"
         "obtg_temporal_sep_fd\0obtg_temporal_sep_fd_dev\0obtg_one_vs_many_min\0obtg_one_vs_many_min_dev\0"
         "obtg_temporal_sep_dev\0obtg_temporal_sep_min_dev\0obtg_speed_dev\0obtg_ang_rate_dev\0obtg_dynamics_dev\0"
@@ -479,6 +479,16 @@ int obtg_temporal_sep_active_dev(obtg_ctx* c, const double* dY, int B, double ma
     (void)hipSetDevice(c->device);
     return with_batch(c, dY, B, true, [&](const double* src) {
         return launch_temporal_sep(c, src, B, max_sep, pair_begin, pair_count, true, d_out_val, k, d_out_idx); });
+}
+
+int obtg_temporal_sep_fd_min_rows_dev(obtg_ctx* c, const double* dY0, int n_fixed_cols, double h, int row_begin, int n_rows,
+                                      double max_sep, double* d_out)
+{
+    if (!check_ctx(c) || !dY0 || !d_out || n_rows < 0 || row_begin < 1) return OBTG_ERR_ARG;
+    if (int rc = fd_args_ok(c, n_fixed_cols, row_begin, n_rows > 0 ? n_rows : 1)) return rc;
+    if (n_rows == 0 || c->n_obj < 2) return OBTG_OK;
+    (void)hipSetDevice(c->device);
+    return launch_temporal_sep_fd(c, dY0, n_rows, nullptr, nullptr, nullptr, max_sep, d_out, 1, row_begin, n_fixed_cols, h);
 }
 
 int obtg_temporal_sep_min_gather_dev(obtg_ctx* c, obtg_comm* m, const double* dY, int B, double max_sep, double* d_min_all)

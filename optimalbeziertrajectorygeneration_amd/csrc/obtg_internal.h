@@ -211,7 +211,8 @@ int launch_pair_sweep(obtg_ctx* c, const double* dY, int B, double max_sep, doub
 int launch_step_fd_structured(obtg_ctx* c, int B, double max_sep, double* d_out_sep, int max_iter, int md_cap, int* d_flag,
                               double* d_p1, double* d_p2, double* d_dist, int* d_nsup, int* d_status, SweepFold* speed);
 int launch_temporal_sep_fd(obtg_ctx* c, const double* dY0, int n_pert, const int* d_prow, const int* d_pcol,
-                           const double* d_pval, double max_sep, double* d_out);
+                           const double* d_pval, double max_sep, double* d_out, int min_only = 0, int fd_row0 = 0,
+                           int fd_fixed = 0, double fd_h = 0.0);
 int launch_one_vs_many_min(obtg_ctx* c, const double* d_one, int B, const double* d_many, int K, double max_sep, double* d_out);
 int launch_speed(obtg_ctx* c, const double* dY, const double* d_tf, int B, double bound, int is_max,
                  double* d_out);

@@ -105,9 +105,10 @@ class SparseMinimaGather(object):
     """What the ranks of a row-sharded finite-difference step exchange when rank 0's SLSQP wants the per-pair separation
     minima of EVERY row (north_star: "an all-gather of inter-vehicle separation minima"): batch row b differs from row 0 only
     in the n_obj - 1 pairs of the vehicle it advances, so a rank sends, per owned row, those n_obj - 1 minima -- B x (n_obj - 1)
-    doubles in all (C4: 7169 x 255 x 8 B = 14.6 MB; the dense [B][P] block would be 1.87 GB) -- and the owner of row 0
-    broadcasts that row's P minima (C4: 261 KB).  `dense_rows()` rebuilds any rows of the dense block on demand.
-    ONE `all_gather_into_tensor` (ragged row blocks padded to the largest) + one broadcast."""
+    doubles in all (C4: 7169 x 255 x 8 B = 14.6 MB; the dense [B][P] block would be 1.87 GB) -- and row 0's P minima travel in
+    the tail of every rank's block (meaningful in rank 0's: C4 261 KB per rank).  ONE `all_gather_into_tensor` of persistent
+    buffers, nothing else: at C3 a second collective and an assembly copy cost more than the step they followed.
+    `dense_rows()` rebuilds any rows of the dense block on demand."""
 
     def __init__(self, B, n_veh, n_obj, dim, n_free_cols, group=None, world=None, rank=None):
         w, r = _world_rank(group)
@@ -115,12 +116,30 @@ class SparseMinimaGather(object):
         self.world = w if world is None else int(world)
         self.rank = r if rank is None else int(rank)
         self.B, self.n_obj = int(B), int(n_obj)
+        self.P = self.n_obj * (self.n_obj - 1) // 2
         self.blocks = partition(self.B, self.world)
         self.begin, self.count = self.blocks[self.rank]
         self.max_count = max(c for _, c in self.blocks)
         self.veh = fd_row_vehicle(torch.arange(self.B), n_veh, dim, n_free_cols)         # [B]
         self.pair_idx = pairs_of_vehicle(self.n_obj)                                      # [n_obj][n_obj - 1]
-        self.bytes_per_step = 8 * (self.world * self.max_count * (self.n_obj - 1) + self.n_obj * (self.n_obj - 1) // 2)
+        self.block_len = self.max_count * (self.n_obj - 1) + self.P                       # doubles a rank sends
+        self.bytes_per_step = 8 * self.world * self.block_len
+        self._send = self._recv = None
+
+    def _buffers(self, device, dtype=torch.float64):
+        if self._send is None or self._send.device != torch.device(device) or self._send.dtype != dtype:
+            self._send = torch.zeros(self.block_len, dtype=dtype, device=device)
+            self._recv = torch.zeros((self.world, self.block_len), dtype=dtype, device=device)
+        return self._send, self._recv
+
+    def send_rows(self, device, dtype=torch.float64):
+        """[max_count][n_obj - 1], a view of the persistent send block: a kernel may write this rank's rows straight into its
+        first `count` rows (obtg_temporal_sep_fd_min_rows_dev) and pass `send_rows()[:count]` to exchange_compact."""
+        return self._buffers(device, dtype)[0][:self.max_count * (self.n_obj - 1)].view(self.max_count, self.n_obj - 1)
+
+    def send_row0(self, device, dtype=torch.float64):
+        """[P], the tail of the send block: row 0's minima on the rank that owns the batch's row 0."""
+        return self._buffers(device, dtype)[0][self.max_count * (self.n_obj - 1):]
 
     def compact(self, minima_rows):
         """minima_rows: this rank's [count][P] per-pair minima -> [count][n_obj - 1]: per row the pairs of its vehicle
@@ -130,20 +149,30 @@ class SparseMinimaGather(object):
         return torch.gather(minima_rows, 1, idx)
 
     def exchange(self, minima_rows, force=False):
-        """-> (sparse[B][n_obj - 1], row0[P]) identical on every rank."""
-        mine = self.compact(minima_rows)
-        row0 = minima_rows[0].clone() if self.begin == 0 and self.count else torch.empty(minima_rows.shape[1], dtype=minima_rows.dtype,
-                                                                                        device=minima_rows.device)
+        """-> (sparse[B][n_obj - 1], row0[P]) identical on every rank, from this rank's DENSE rows [count][P]."""
+        row0 = minima_rows[0] if self.begin == 0 and self.count else None
+        return self.exchange_compact(self.compact(minima_rows), row0, force)
+
+    def exchange_compact(self, mine, row0, force=False):
+        """The same from rows that are compact already -- what `obtg_temporal_sep_fd_min_rows_dev` writes: mine[count][n_obj - 1]
+        (the owner of the batch's row 0 passes anything in ITS row 0 slot), row0[P] (rank 0; None elsewhere)."""
+        rows, tail = self.send_rows(mine.device, mine.dtype), self.send_row0(mine.device, mine.dtype)
+        if mine.data_ptr() != rows.data_ptr():                 # (a caller that wrote into send_rows() itself skips the copy)
+            rows[:self.count] = mine
+        if row0 is not None and row0.data_ptr() != tail.data_ptr():
+            tail.copy_(row0)
+        send, recv = self._buffers(mine.device, mine.dtype)
         live = dist.is_available() and dist.is_initialized() and (self.world > 1 or force)
-        if not live:
-            return mine, row0
-        send = torch.zeros((self.max_count, self.n_obj - 1), dtype=mine.dtype, device=mine.device)
-        send[:self.count] = mine
-        recv = torch.empty((self.world,) + tuple(send.shape), dtype=mine.dtype, device=mine.device)
-        dist.all_gather_into_tensor(recv.view(-1), send.view(-1), group=self.group)
-        dist.broadcast(row0, src=0, group=self.group)                                     # rank 0 owns the batch's row 0
-        sparse = torch.cat([recv[r, :c] for r, (_, c) in enumerate(self.blocks)], dim=0)
-        return sparse, row0
+        if live:
+            dist.all_gather_into_tensor(recv.view(-1), send, group=self.group)
+        else:
+            recv[self.rank].copy_(send)
+        w = self.n_obj - 1
+        if self.world == 1:
+            sparse = recv[0, :self.count * w].view(self.count, w)
+        else:
+            sparse = torch.cat([recv[r, :c * w].view(c, w) for r, (_, c) in enumerate(self.blocks)], dim=0)
+        return sparse, recv[0, self.max_count * w:]
 
     def dense_rows(self, sparse, row0, rows):
         """Rows `rows` of the dense [B][P] minima block, rebuilt from what `exchange` returned."""

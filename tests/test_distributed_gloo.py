@@ -209,7 +209,7 @@ def _worker_sparse(rank, world, port, q):
         ok = ok and bool(np.array_equal(rebuilt, dense))         # every row of the dense block, on every rank
         # and it really is reduced: what travelled is B x (n_obj - 1) (+ padding) + P doubles, the dense block B x P
         P = n_obj * (n_obj - 1) // 2
-        ok = ok and g.bytes_per_step == 8 * (world * g.max_count * (n_obj - 1) + P) and g.bytes_per_step < 8 * B * P / 3
+        ok = ok and g.bytes_per_step == 8 * world * (g.max_count * (n_obj - 1) + P) and g.bytes_per_step < 8 * B * P / 2
         q.put((rank, ok, (g.begin, g.count)))
     finally:
         dist.destroy_process_group()

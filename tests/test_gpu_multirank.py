@@ -131,7 +131,7 @@ def test_bench_rows_mode_two_ranks_tile_the_iteration():
     # every rank rebuilds dense rows from it and finds its own reduction bit for bit
     c3 = three["config"]
     assert c3["gather_minima"] == "sparse" and c3["gather_check"] is True
-    assert c3["allgather_bytes"] == 8 * (3 * 101 * 63 + 2016)              # against 8 x 301 x 2016 = 4.9 MB dense
+    assert c3["allgather_bytes"] == 8 * 3 * (101 * 63 + 2016)              # against 8 x 301 x 2016 = 4.9 MB dense
     dense = _bench(["--gpus", "2", "--backend", "gloo", "--one-device", "--gather-minima", "dense"] + args)
     assert dense["config"]["gather_minima"] == "dense" and dense["config"]["allgather_bytes"] == 8 * 2 * 151 * 2016
     # the same ranges through the structured step (obtg_constraint_sweep_fd_structured_rows_dev): bit-identical rows, so
@@ -297,6 +297,20 @@ def test_collective_behind_the_c_abi():
     ctx.fd_view_end()
     torch.cuda.synchronize()
     assert np.array_equal(out.cpu().numpy(), want)
+    # what a rank of a ROW-sharded step sends (obtg_temporal_sep_fd_min_rows_dev): per row the minima of the pairs its vehicle
+    # touches, straight from x's control points -- the entries SparseMinimaGather.compact picks out of the dense block
+    from optimalbeziertrajectorygeneration_amd.distributed import SparseMinimaGather
+    Bx = N * d * (n - 1) + 1
+    dense = ctx.temporal_sep_min(synth.fd_batch(Y, B=Bx, h=1e-3), 0.9)
+    for (r0, cnt, world, rank) in ((1, Bx - 1, 1, 0), (150, 57, 3, 1)):
+        comp = torch.full((cnt, N - 1), float("nan"), dtype=torch.float64, device="cuda")
+        ctx.temporal_sep_fd_min_rows_dev(d0.data_ptr(), 1, 1e-3, r0, cnt, 0.9, comp.data_ptr())
+        torch.cuda.synchronize()
+        g = SparseMinimaGather(Bx, N, N, d, n - 1, world=1, rank=0)
+        ref = g.compact(torch.from_numpy(dense))[r0:r0 + cnt]
+        assert np.array_equal(comp.cpu().numpy(), ref.numpy()), (r0, cnt)
+    with pytest.raises(_capi.ObtgError):
+        ctx.temporal_sep_fd_min_rows_dev(d0.data_ptr(), 1, 1e-3, 0, 3, 0.9, comp.data_ptr())      # row 0 advances nothing
     # the byte-typed primitive
     send = torch.arange(1000, dtype=torch.int32, device="cuda")
     recv = torch.zeros_like(send)
