@@ -1801,16 +1801,47 @@ __device__ __forceinline__ double wave_next_lane(double v)
 // latency, and a pair's search is a serial chain of up to max_nodes nodes).  Left piece: point L is lane 0's value at
 // level L; right piece (stored reversed, bezier.py:563): point i is lane i's value at the last level it takes part in.
 // Needs 3 K <= 64; rl / il = lane / K, lane % K (rl >= 3: the lane idles).
-__device__ __forceinline__ void split_rows3_wave(const double* src, int K, double t, int half, double* dst, int rl, int il)
+// One level: every lane stores -- the lane whose value is a point of the piece at this level to its place, the others to a
+// slot of their own in `dump` (64 doubles of scratch) -- so that a level has no divergent region: a select on the address,
+// one ds_write, two DPP moves, two multiplies and an add.
+template <int KC>          // KC > 0: K is that constant and the levels are unrolled
+__device__ __forceinline__ void split_rows3_wave_t(const double* src, int K, double t, int half, double* dst, int rl, int il,
+                                                   double* dump)
 {
+    if (KC > 0) K = KC;
     const bool valid = rl < 3;
     double w = valid ? src[rl * K + il] : 0.0;
-    for (int L = 0; L < K - 1; ++L) {
-        if (valid && (half == 0 ? il == 0 : il == K - 1 - L)) dst[rl * K + (half == 0 ? L : il)] = w;
+    const double u = 1 - t;
+    // who records at level L: the left piece's point L is lane 0's value, the right piece's point i is lane i's value at
+    // level K - 1 - i; the last level's value (lane 0) is point K - 1 of the left piece / point 0 of the right one
+    const bool every = valid && half == 0 && il == 0;
+    const int my_level = (valid && half != 0) ? K - 1 - il : -1;
+    double* out = dst + rl * K + (half == 0 ? 0 : il);
+    double* mine = dump + (threadIdx.x & 63);
+    auto level = [&](int L) {
+        double* a = every ? out + L : (my_level == L ? out : mine);
+        *a = w;
         const double up = wave_next_lane(w);
-        w = (1 - t) * w + t * up;
+        w = u * w + t * up;
+    };
+    if constexpr (KC > 0) {
+#pragma unroll
+        for (int L = 0; L < KC - 1; ++L) level(L);
+    } else {
+        for (int L = 0; L < K - 1; ++L) level(L);
     }
     if (valid && il == 0) dst[rl * K + (half == 0 ? K - 1 : 0)] = w;
+}
+
+__device__ __forceinline__ void split_rows3_wave(const double* src, int K, double t, int half, double* dst, int rl, int il,
+                                                 double* dump)
+{
+    switch (K) {        // (wave-uniform)
+#define OBTG_CASE(NC_) case NC_: split_rows3_wave_t<NC_>(src, K, t, half, dst, rl, il, dump); return;
+        OBTG_NC_DYN(OBTG_CASE)
+#undef OBTG_CASE
+        default: split_rows3_wave_t<0>(src, K, t, half, dst, rl, il, dump);
+    }
 }
 
 __device__ __forceinline__ double hull_param_wave(const double* c, int K, const V3& cl, double* sh_e, double* sh_q, int li)
@@ -1889,6 +1920,12 @@ __global__ __launch_bounds__(64, OBTG_MD_MIN_WAVES) void k_min_dist_wave(const M
     int nodes = 0, calls = 0, dmax = 0, status = OBTG_MD_OK;
     double r0 = INFINITY, r1 = -1, r2 = -1;
     bool returning = false;
+#ifdef OBTG_MD_TIMING      // (variant builds: where a node's clocks go -- info[] then carries phase totals in units of 1024 clocks)
+    unsigned long long tm_gjk = 0, tm_eval = 0, tm_desc = 0, tm_fetch = 0, tm_t;
+#define OBTG_TM(acc, t0) acc += __builtin_readcyclecounter() - (t0)
+#else
+#define OBTG_TM(acc, t0)
+#endif
     for (;;) {
         double* f = st + (size_t)depth * FR;
         double* sc = scs + depth * F_NSCAL;
@@ -1905,7 +1942,14 @@ __global__ __launch_bounds__(64, OBTG_MD_MIN_WAVES) void k_min_dist_wave(const M
             g.P2 = Poly{ 3 * K, K, K, 1 };
             g.trace = nullptr; g.trace_cap = 0; g.n_support = 0;
             Result gr;
+#ifdef OBTG_MD_TIMING
+            tm_t = __builtin_readcyclecounter();
+#endif
             gjk::run<MemLds, false, true>(g, p.max_iter, p.md_cap, gr);
+            OBTG_TM(tm_gjk, tm_t);
+#ifdef OBTG_MD_TIMING
+            tm_t = __builtin_readcyclecounter();
+#endif
             calls++;
             if (gr.status == OBTG_ST_MD_CAP || gr.status == OBTG_ST_CYCLE) { status = OBTG_MD_GJK_CAP; break; }
             double lb, t1, t2;
@@ -1945,6 +1989,7 @@ __global__ __launch_bounds__(64, OBTG_MD_MIN_WAVES) void k_min_dist_wave(const M
             }
             wave_sync();
             state = 1;
+            OBTG_TM(tm_eval, tm_t);
         }
         if (returning) {
             if (r0 < sc[F_ALPHA]) {
@@ -1962,18 +2007,25 @@ __global__ __launch_bounds__(64, OBTG_MD_MIN_WAVES) void k_min_dist_wave(const M
         }
         // ---- descend into child state-1: (c3,c5) (c3,c6) (c4,c5) (c4,c6)
         {
+#ifdef OBTG_MD_TIMING
+            tm_t = __builtin_readcyclecounter();
+#endif
             if (cur_depth != depth) {            // the walk came back up: fetch this frame's curves again
                 __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");   // other lanes' stores of this frame have landed
                 for (int i = lane; i < 6 * K; i += kWave) cur[i] = f[i];
                 cur_depth = depth;
                 wave_sync();
+#ifdef OBTG_MD_TIMING
+                if (cur[0] != cur[0]) tm_fetch += 1;      // (keeps the loads ahead of the stamp)
+                OBTG_TM(tm_fetch, tm_t);
+#endif
             }
             const int ch = state - 1, h1 = ch >> 1, h2 = ch & 1;
             const double t1 = sc[F_T1], t2 = sc[F_T2];
             double* nf = f + FR;
             if (3 * K <= kWave) {                 // rows 0..2: curve 1 (x, y, z), rows 3..5: curve 2; level-parallel
-                split_rows3_wave(cur, K, t1, h1, nxt, rl, il);
-                split_rows3_wave(cur + 3 * K, K, t2, h2, nxt + 3 * K, rl, il);
+                split_rows3_wave(cur, K, t1, h1, nxt, rl, il, sh_e);                 // (sh_e: 64 doubles, idle here)
+                split_rows3_wave(cur + 3 * K, K, t2, h2, nxt + 3 * K, rl, il, sh_e);
             } else if (lane < 6) {
                 const bool second = lane >= 3;
                 split_row_lds(cur + lane * K, K, second ? t2 : t1, second ? h2 : h1, nxt + lane * K, sh_e + lane * K);
@@ -1997,8 +2049,12 @@ __global__ __launch_bounds__(64, OBTG_MD_MIN_WAVES) void k_min_dist_wave(const M
             depth++;
             cur_depth = depth;
             wave_sync();
+            OBTG_TM(tm_desc, tm_t);
         }
     }
+#ifdef OBTG_MD_TIMING
+    calls = (int)(tm_gjk >> 10); dmax = (int)(tm_eval >> 10); status = (int)(tm_desc >> 10) | ((int)(tm_fetch >> 10) << 16);
+#endif
     // (every lane, the same values to the same addresses: see the pull above)
     p.res[3 * k] = r0; p.res[3 * k + 1] = r1; p.res[3 * k + 2] = r2;
     if (p.info) { p.info[4 * k] = nodes; p.info[4 * k + 1] = calls; p.info[4 * k + 2] = dmax; p.info[4 * k + 3] = status; }
@@ -3555,7 +3611,7 @@ __global__ __launch_bounds__(64) void k_min_dist2poly_wave(const Md2Params p)
             const int h1 = state - 1;
             const double t1 = sc[G_T1];
             double* nf = f + FR;
-            if (3 * K <= kWave) split_rows3_wave(cur, K, t1, h1, nxt, rl, il);        // level-parallel (see k_min_dist_wave)
+            if (3 * K <= kWave) split_rows3_wave(cur, K, t1, h1, nxt, rl, il, sh_e);  // level-parallel (see k_min_dist_wave); sh_e + sh_q: 64 idle doubles
             else if (lane < 3) split_row_lds(cur + lane * K, K, t1, h1, nxt + lane * K, sh_e + lane * kMdMaxK);
             wave_sync();
             for (int i = lane; i < 3 * K; i += kWave) nf[i] = nxt[i];
