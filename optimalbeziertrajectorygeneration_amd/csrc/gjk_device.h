@@ -185,6 +185,47 @@ __device__ __forceinline__ void support_pts_wave(Ctx<Mem>& g, const V3& dir, Ver
     g.n_support++;
 }
 
+// supportPts for FOUR calls at a time, one per 16-lane row of the wavefront (K <= 16 points per set): the lanes of a row
+// hold that row's call (its own two point sets, direction and simplex), lane l of the row takes point l of BOTH sets, and
+// the two "largest value, lowest index" reductions run side by side over the row -- quad permutes, the half row mirrored,
+// the row mirrored: all DPP moves, after which every lane of the row holds both answers (no cross-row transfer at all).
+// Same products, same tie rule as the serial scan (see support_pts_wave).
+template <class Mem>
+__device__ __forceinline__ void support_pts_quarter(Ctx<Mem>& g, const V3& dir, Vert& out)
+{
+    const int lane = threadIdx.x & 63, l = lane & 15;
+    const V3 nd = neg(dir);
+    const bool have1 = l < g.P1.K, have2 = l < g.P2.K;
+    double v1 = have1 ? sdot<Mem, false>(g.mem, g.P1, l, dir) : -__builtin_inf();
+    double v2 = have2 ? sdot<Mem, false>(g.mem, g.P2, l, nd) : -__builtin_inf();
+    // point 0's value NaN: maxd starts as NaN and nothing is ever greater (the row's lane 0 holds point 0)
+    const unsigned long long nan1 = __ballot(v1 != v1), nan2 = __ballot(v2 != v2);
+    const int row0 = lane & 48;
+    if (v1 != v1) v1 = -__builtin_inf();                   // `cur > maxd` is false for NaN: never selected
+    if (v2 != v2) v2 = -__builtin_inf();
+    int i1 = have1 ? l : 0x7fffffff, i2 = have2 ? l : 0x7fffffff;
+#define OBTG_DPP_MEET2(CTRL) \
+    { const int lo1_ = __builtin_amdgcn_update_dpp(0, __double2loint(v1), CTRL, 0xf, 0xf, false); \
+      const int hi1_ = __builtin_amdgcn_update_dpp(0, __double2hiint(v1), CTRL, 0xf, 0xf, false); \
+      const int oi1_ = __builtin_amdgcn_update_dpp(0, i1, CTRL, 0xf, 0xf, false); \
+      const int lo2_ = __builtin_amdgcn_update_dpp(0, __double2loint(v2), CTRL, 0xf, 0xf, false); \
+      const int hi2_ = __builtin_amdgcn_update_dpp(0, __double2hiint(v2), CTRL, 0xf, 0xf, false); \
+      const int oi2_ = __builtin_amdgcn_update_dpp(0, i2, CTRL, 0xf, 0xf, false); \
+      const double ov1_ = __hiloint2double(hi1_, lo1_), ov2_ = __hiloint2double(hi2_, lo2_); \
+      const bool t1_ = ov1_ > v1 || (ov1_ == v1 && oi1_ < i1), t2_ = ov2_ > v2 || (ov2_ == v2 && oi2_ < i2); \
+      v1 = t1_ ? ov1_ : v1; i1 = t1_ ? oi1_ : i1; v2 = t2_ ? ov2_ : v2; i2 = t2_ ? oi2_ : i2; }
+    OBTG_DPP_MEET2(0xB1)      // quad_perm:[1,0,3,2]
+    OBTG_DPP_MEET2(0x4E)      // quad_perm:[2,3,0,1]
+    OBTG_DPP_MEET2(0x141)     // row_half_mirror
+    OBTG_DPP_MEET2(0x140)     // row_mirror
+#undef OBTG_DPP_MEET2
+    if ((nan1 >> row0) & 1) i1 = 0;
+    if ((nan2 >> row0) & 1) i2 = 0;
+    out.i1 = i1; out.i2 = i2;
+    out.v = sub(point(g.mem, g.P1, i1), point(g.mem, g.P2, i2));
+    g.n_support++;
+}
+
 // gjk.py:397-437 weightedOriginToLine
 __device__ __forceinline__ double origin_to_line(const V3& A, const V3& B, double& dist)
 {
@@ -282,11 +323,13 @@ __device__ __forceinline__ bool simplex_update(Simplex& s, V3& dir)
     return true;
 }
 
-template <class Mem, bool PLANAR = false, bool WAVE = false>
+// WAVE: 0 = a call per lane, 1 = one call per wavefront (support_pts_wave), 2 = one call per 16-lane row (support_pts_quarter)
+template <class Mem, bool PLANAR = false, int WAVE = 0>
 __device__ __forceinline__ void do_simplex(Ctx<Mem>& g, Simplex& s, V3& dir)
 {
     if (simplex_update(s, dir)) {
-        if (WAVE) support_pts_wave<Mem>(g, dir, s.A);
+        if (WAVE == 2) support_pts_quarter<Mem>(g, dir, s.A);
+        else if (WAVE == 1) support_pts_wave<Mem>(g, dir, s.A);
         else support_pts<Mem, PLANAR>(g, dir, s.A);
         s.keys |= kA;
     }
@@ -366,7 +409,7 @@ __device__ __forceinline__ void closest_from_simplex(const Ctx<Mem>& g, const Si
 
 // gjk.py:230-270 gjkNew + 273-360 minimumDistance
 // WAVE: one pair per wavefront, see support_pts_wave
-template <class Mem, bool PLANAR = false, bool WAVE = false>
+template <class Mem, bool PLANAR = false, int WAVE = 0>
 __device__ __forceinline__ void run(Ctx<Mem>& g, int max_iter, int md_cap, Result& r)
 {
     Simplex s;
@@ -397,6 +440,47 @@ __device__ __forceinline__ void run(Ctx<Mem>& g, int max_iter, int md_cap, Resul
             closest_from_simplex(g, old, r);
             break;
         }
+    }
+    r.n_support = g.n_support;
+}
+
+// gjkNew + minimumDistance for four calls at a time, one per 16-lane row (support_pts_quarter).  `run` above has two loops
+// -- the sign search of gjkNew and, entered from inside it, minimumDistance's `while True` -- and rows that are in different
+// loops would take turns (a row inside the inner loop runs it to the end while the others wait).  Here the two are ONE loop
+// with a phase per row, so that every trip is one doSimplex of every live row: the four calls cost about as many trips as
+// the longest of them.  Per row the sequence of operations is `run`'s, hence the same bits.
+template <class Mem>
+__device__ __forceinline__ void run_quarter(Ctx<Mem>& g, int max_iter, int md_cap, Result& r)
+{
+    Simplex s;
+    s.keys = 0;
+    s.A = Vert{ V3{ 0, 0, 0 }, 0, 0 };
+    s.B = s.A; s.C = s.A; s.D = s.A;
+    Simplex old = s;
+    Checkpoint chk;
+    chk.start(s, V3{ 0, 0, 0 });
+    V3 dir{ 1.0, 0.0, 0.0 };
+    const double qnan = __builtin_nan("");
+    r.flag = -1; r.status = OBTG_ST_MAXITER;
+    r.c1 = V3{ qnan, qnan, qnan }; r.c2 = r.c1; r.dist = qnan;
+    int phase = 0, it = 0, rr = 0;
+    bool live = max_iter > 0, conv = false;
+    while (live) {
+        if (phase) old = s;
+        do_simplex<Mem, false, 2>(g, s, dir);
+        if (!phase) {
+            if (s.keys & kColl) { r.flag = 0; r.status = OBTG_ST_OK; live = false; }
+            else if (dotb(s.A.v, dir) < 0) { phase = 1; chk.start(s, dir); }
+            else if (++it >= max_iter) live = false;
+        } else {
+            if (matches_old(g, old, s.A.v)) { conv = true; live = false; }
+            else if (chk.step(s, dir)) { r.flag = 1; r.status = OBTG_ST_CYCLE; live = false; }
+            else if (++rr >= md_cap) { r.flag = 1; r.status = OBTG_ST_MD_CAP; live = false; }
+        }
+    }
+    if (conv) {
+        r.flag = 1; r.status = OBTG_ST_OK;
+        closest_from_simplex(g, old, r);
     }
     r.n_support = g.n_support;
 }

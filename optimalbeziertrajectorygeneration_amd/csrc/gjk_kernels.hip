@@ -16,6 +16,7 @@
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <vector>
 
 #include <hip/hip_ext.h>
@@ -2061,6 +2062,270 @@ __global__ __launch_bounds__(64, OBTG_MD_MIN_WAVES) void k_min_dist_wave(const M
   }
 }
 
+// ---- _minDist, four children at a time (round 5) -------------------------------------------------------------------
+// bezier.py:1283-1408 calls itself on ALL four children of a node it does not cut off -- the cut (lb >= alpha (1 - eps)) is
+// taken inside the child, after the child's own gjkNew call and end-point distances -- so a child's gjkNew result, its split
+// parameters and its end-point bound depend on the child's curves alone, never on alpha: the four can be worked out
+// together when their parent is split, and the depth-first walk (which does depend on alpha, child after child) then only
+// reads them.  k_min_dist_wave spends a whole wavefront on one gjkNew call at a time and a pair's search is a serial chain
+// of them (8.9 k of a node's 14.8 k clocks, profiles/r05_experiments); here one 16-lane row of the wavefront takes each
+// child (K <= 16), the four state machines advance in lockstep (gjk::run_quarter), and a node's two splits produce BOTH
+// pieces of both curves in one level-parallel pass.  The walk visits the same nodes in the same order with the same
+// values: res and info are those of k_min_dist_wave (test_min_dist_quad_form_is_the_wave_form and the reference fixtures).
+//
+// A frame's blob: the four half curves of an EXPANDED node, c3 c4 (curve 1 left, right) c5 c6 (curve 2), then the records
+// of its four children (c3,c5) (c3,c6) (c4,c5) (c4,c6).
+enum { R_CAP = 0, R_LB, R_T1, R_T2, R_UB, R_AM, R_NREC };
+enum { Q_CH = F_NSCAL, Q_NSCAL };          // frame scalars: k_min_dist_wave's + which child of its parent the node is
+__host__ __device__ constexpr int md_quad_blob(int K) { return 12 * K + 4 * R_NREC; }
+constexpr int kMdQuadMaxK = 16;
+
+// deCasteljauSplit of rows [row0, row0 + nrows) of a node's six coordinate rows (rows 0..2: curve 1 at t1, rows 3..5:
+// curve 2 at t2), BOTH pieces kept: as split_rows3_wave_t, where the left piece's point L is lane (r, 0)'s value at level L
+// and the right piece's point i is lane (r, i)'s value at level K - 1 - i -- never the same lane at the same level before
+// the last one, so a level is still one store per lane.
+template <int KC>
+__device__ __forceinline__ void split_both_t(const double* c1, const double* c2, int K, double t1, double t2, double* blob,
+                                             int row0, int nrows, double* dump)
+{
+    if (KC > 0) K = KC;
+    const int lane = threadIdx.x & 63;
+    const int rq = lane / K, il = lane - rq * K, row = row0 + rq;
+    const bool valid = rq < nrows;
+    const bool second = row >= 3;
+    const int r3 = second ? row - 3 : row;
+    double w = valid ? (second ? c2 : c1)[r3 * K + il] : 0.0;
+    const double t = second ? t2 : t1, u = 1 - t;
+    double* outL = blob + (second ? 6 * K : 0) + r3 * K;          // left piece's row; the right piece's is 3 K further
+    double* outR = outL + 3 * K + il;
+    const bool first = valid && il == 0;
+    const int my_level = valid ? K - 1 - il : -1;
+    double* mine = dump + lane;
+    auto level = [&](int L) {
+        double* a = first ? outL + L : (my_level == L ? outR : mine);
+        *a = w;
+        const double up = wave_next_lane(w);
+        w = u * w + t * up;
+    };
+    if constexpr (KC > 0) {
+#pragma unroll
+        for (int L = 0; L < KC - 1; ++L) level(L);
+    } else {
+        for (int L = 0; L < K - 1; ++L) level(L);
+    }
+    // the last level's value: point K - 1 of the left piece and point 0 of the right one
+    double* a = first ? outL + (K - 1) : mine;
+    double* b = first ? outR : mine;
+    *a = w; *b = w;
+}
+
+__device__ __forceinline__ void split_both(const double* c1, const double* c2, int K, double t1, double t2, double* blob,
+                                           double* dump)
+{
+    const bool one_pass = 6 * K <= kWave;
+    switch (K) {        // (wave-uniform)
+#define OBTG_CASE(NC_) \
+    case NC_: \
+        if (NC_ <= kMdQuadMaxK) { \
+            if (one_pass) split_both_t<NC_>(c1, c2, K, t1, t2, blob, 0, 6, dump); \
+            else { split_both_t<NC_>(c1, c2, K, t1, t2, blob, 0, 3, dump); split_both_t<NC_>(c1, c2, K, t1, t2, blob, 3, 3, dump); } \
+            return; \
+        } \
+        break;
+        OBTG_NC_DYN(OBTG_CASE)
+#undef OBTG_CASE
+        default: break;
+    }
+    if (one_pass) split_both_t<0>(c1, c2, K, t1, t2, blob, 0, 6, dump);
+    else { split_both_t<0>(c1, c2, K, t1, t2, blob, 0, 3, dump); split_both_t<0>(c1, c2, K, t1, t2, blob, 3, 3, dump); }
+}
+
+// hull_param_wave for the call of one 16-lane row: c = the row's curve, sh_e / sh_q = 16 doubles of the row's own
+__device__ __forceinline__ double hull_param_quarter(const double* c, int K, const V3& cl, double* sh_e, double* sh_q)
+{
+    const int lane = threadIdx.x & 63, l = lane & 15;
+    const bool hit = l < K && c[l] == cl.x && c[K + l] == cl.y && c[2 * K + l] == cl.z;
+    const unsigned m = (unsigned)(__ballot(hit) >> (lane & 48)) & 0xffffu;
+    if (m) return (double)(__ffs((int)m) - 1) / (double)(K - 1);
+    if (l < K) {
+        const double dx = cl.x - c[l], dy = cl.y - c[K + l], dz = cl.z - c[2 * K + l];
+        double s = 0.0;
+        s += dx * dx; s += dy * dy; s += dz * dz;
+        sh_e[l] = __builtin_sqrt(s);
+    }
+    wave_sync();
+    if (l < K) {
+        const double ei = sh_e[l];
+        const double s1 = np_sum_f(l, [&](int j) { return ei / sh_e[j]; });
+        const double s2 = np_sum_f(K - l - 1, [&](int j) { return ei / sh_e[l + 1 + j]; });
+        const double W = 1 / (1 + s1 + s2);
+        sh_q[l] = W * (double)l / (double)K;
+    }
+    wave_sync();
+    return np_sum(sh_q, K);
+}
+
+// What a node's visit needs of it, for the four (curve 1, curve 2) pairs the rows of the wavefront name: the gjkNew call,
+// the split parameters of its closest points (bezier.py:1313-1351), the end-point bound (_upperbound, bezier.py:1255-1280).
+// o1 / o2: offsets of the row's two curves in `lds`; rec: the row's record.  Every lane of a row stores the row's (equal)
+// values: no lane-dependent region (see the queue pull of k_min_dist_wave).
+__device__ __forceinline__ void md_eval_rows(const double* lds, int o1, int o2, int K, double eps, int max_iter, int md_cap,
+                                             double* rec, double* sh_e, double* sh_q)
+{
+    Ctx<MemLds> g;
+    g.mem = MemLds{ lds };
+    g.P1 = Poly{ o1, K, K, 1 };
+    g.P2 = Poly{ o2, K, K, 1 };
+    g.trace = nullptr; g.trace_cap = 0; g.n_support = 0;
+    Result gr;
+    gjk::run_quarter<MemLds>(g, max_iter, md_cap, gr);
+    const bool cap = gr.status == OBTG_ST_MD_CAP || gr.status == OBTG_ST_CYCLE;
+    double lb = eps, t1 = 0.5, t2 = 0.5;
+    const double* c1 = lds + o1; const double* c2 = lds + o2;
+    if (gr.flag > 0 && !cap) {
+        lb = gr.dist;
+        t1 = hull_param_quarter(c1, K, gr.c1, sh_e, sh_q);
+        t2 = hull_param_quarter(c2, K, gr.c2, sh_e + 16, sh_q + 16);
+    }
+    double dd[4];
+    dd[0] = norm_seq(c1[0], c1[K], c1[2 * K], c2[0], c2[K], c2[2 * K]);
+    dd[1] = norm_seq(c1[0], c1[K], c1[2 * K], c2[K - 1], c2[2 * K - 1], c2[3 * K - 1]);
+    dd[2] = norm_seq(c1[K - 1], c1[2 * K - 1], c1[3 * K - 1], c2[0], c2[K], c2[2 * K]);
+    dd[3] = norm_seq(c1[K - 1], c1[2 * K - 1], c1[3 * K - 1], c2[K - 1], c2[2 * K - 1], c2[3 * K - 1]);
+    int am = 0;
+    for (int i = 1; i < 4; ++i) if (dd[i] < dd[am]) am = i;
+    for (int i = 0; i < 4; ++i) if (dd[i] != dd[i]) { am = i; break; }
+    rec[R_CAP] = cap ? 1.0 : 0.0; rec[R_LB] = lb; rec[R_T1] = t1; rec[R_T2] = t2; rec[R_UB] = dd[am]; rec[R_AM] = (double)am;
+}
+
+__global__ __launch_bounds__(64, OBTG_MD_MIN_WAVES) void k_min_dist_quad(const MdParams p)
+{
+    extern __shared__ double md_lds[];
+    const int lane = threadIdx.x, q = lane >> 4;
+    const int K = p.K, BL = md_quad_blob(K);
+    double* st = p.stack + (size_t)blockIdx.x * p.max_depth * BL;
+    double* sh_e = md_lds + 2 * BL;             // [4][2][16]
+    double* sh_q = sh_e + 128;                  // [4][2][16]
+    double* dump = sh_q + 128;                  // [64]
+    double* scs = dump + 64;                    // [max_depth][Q_NSCAL] frame scalars
+  for (;;) {
+    const int ticket = atomicAdd(p.queue, lane == 0 ? 1 : 0);      // (see k_min_dist_wave)
+    const int slot = __builtin_amdgcn_readfirstlane(ticket);
+    if (slot >= p.n_pairs) break;
+    const int k = p.order ? p.order[slot] : slot;
+    wave_sync();
+    double* cur = md_lds;                       // [BL] blob of the frame `cur_depth`
+    double* nxt = cur + BL;                     // [BL] blob being built
+    // The pair's own curves as the blob of a frame "-1" whose four children are all the root: pieces c1 c1 c2 c2.  The
+    // root is then visited like every other node (its record is child 0's), and the kernel has ONE copy of the evaluation.
+    const double* ca = p.curves + (size_t)p.pa[k] * 3 * K;
+    const double* cb = p.curves + (size_t)p.pb[k] * 3 * K;
+    for (int i = lane; i < 3 * K; i += kWave) {
+        const double a = ca[i], bq = cb[i];
+        nxt[i] = a; nxt[3 * K + i] = a; nxt[6 * K + i] = bq; nxt[9 * K + i] = bq;
+    }
+    scs[F_T1L] = 0; scs[F_T1H] = 1; scs[F_T2L] = 0; scs[F_T2H] = 1; scs[F_ALPHA] = INFINITY; scs[F_STATE] = 0; scs[Q_CH] = 0;
+    int depth = 0, cur_depth = -1;    // cur_depth: which frame's blob `cur` holds
+    int eval_depth = -1;              // which frame's blob `nxt` is about to become
+    int nodes = 0, calls = 0, dmax = 0, status = OBTG_MD_OK;
+    double r0 = INFINITY, r1 = -1, r2 = -1;
+    bool returning = false, done = false;
+    while (!done) {
+        // ---- the four children of the blob in `nxt`, a row of the wavefront each
+        wave_sync();
+        md_eval_rows(md_lds, (int)(nxt - md_lds) + (q >> 1) * 3 * K, (int)(nxt - md_lds) + (2 + (q & 1)) * 3 * K, K, p.eps,
+                     p.max_iter, p.md_cap, nxt + 12 * K + q * R_NREC, sh_e + q * 32, sh_q + q * 32);
+        wave_sync();
+        if (eval_depth >= 0) {
+            double* f = st + (size_t)eval_depth * BL;
+            for (int i = lane; i < BL; i += kWave) f[i] = nxt[i];
+        }
+        { double* tsw = cur; cur = nxt; nxt = tsw; }
+        cur_depth = eval_depth;
+        // ---- the depth-first walk, until a node has to be expanded (its pieces go to `nxt`) or the search ends
+        for (;;) {
+            double* sc = scs + depth * Q_NSCAL;
+            int state = (int)sc[F_STATE];
+            if (!returning && state == 0) {
+                if (depth + 1 > 1000) { r0 = r1 = r2 = -1; returning = true; depth--; if (depth < 0) { done = true; break; } continue; }
+                if (nodes >= p.max_nodes) { status = OBTG_MD_NODE_CAP; done = true; break; }
+                nodes++;
+                if (depth + 1 > dmax) dmax = depth + 1;
+                const int ch = (int)sc[Q_CH];
+                // the node's record and curves: in its parent's blob, which is `cur` (the parent descended into it just now)
+                const double* rec = cur + 12 * K + ch * R_NREC;
+                calls++;
+                if (rec[R_CAP] != 0.0) { status = OBTG_MD_GJK_CAP; done = true; break; }
+                const double lb = rec[R_LB];
+                double t1 = rec[R_T1], t2 = rec[R_T2];
+                const int am = (int)rec[R_AM];
+                const double ub = rec[R_UB], t1loc = (am >> 1) ? 1.0 : 0.0, t2loc = (am & 1) ? 1.0 : 0.0;
+                double alpha = sc[F_ALPHA], nT1, nT2;
+                if (ub <= alpha) {
+                    alpha = ub;
+                    nT1 = (1 - t1loc) * sc[F_T1L] + t1loc * sc[F_T1H];
+                    nT2 = (1 - t2loc) * sc[F_T2L] + t2loc * sc[F_T2H];
+                } else { nT1 = -1; nT2 = -1; }
+                if (lb >= alpha * (1 - p.eps)) {
+                    r0 = alpha; r1 = nT1; r2 = nT2; returning = true; depth--;
+                    if (depth < 0) { done = true; break; }
+                    continue;
+                }
+                if (depth + 1 >= p.max_depth) { status = OBTG_MD_DEPTH_CAP; r0 = alpha; r1 = nT1; r2 = nT2; done = true; break; }
+                if (t1 != t1) t1 = 0;
+                if (t2 != t2) t2 = 0;
+                // expand: both pieces of both curves; the evaluation of the four children is the next trip's
+                split_both(cur + (ch >> 1) * 3 * K, cur + (2 + (ch & 1)) * 3 * K, K, t1, t2, nxt, dump);
+                wave_sync();
+                sc[F_T1] = t1; sc[F_T2] = t2; sc[F_ALPHA] = alpha; sc[F_RT1] = nT1; sc[F_RT2] = nT2; sc[F_STATE] = 1;
+                wave_sync();
+                eval_depth = depth;
+                break;
+            }
+            if (returning) {
+                if (r0 < sc[F_ALPHA]) {
+                    wave_sync();
+                    sc[F_ALPHA] = r0; sc[F_RT1] = r1; sc[F_RT2] = r2;
+                    wave_sync();
+                }
+                returning = false;
+                state = (int)sc[F_STATE];
+            }
+            if (state >= 5) {
+                r0 = sc[F_ALPHA]; r1 = sc[F_RT1]; r2 = sc[F_RT2]; returning = true; depth--;
+                if (depth < 0) { done = true; break; }
+                continue;
+            }
+            // ---- descend into child state-1: (c3,c5) (c3,c6) (c4,c5) (c4,c6); its record (and, if it is expanded, its
+            //      curves) are in this frame's blob
+            if (cur_depth != depth) {            // the walk came back up: fetch this frame's blob again
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+                const double* f = st + (size_t)depth * BL;
+                for (int i = lane; i < BL; i += kWave) cur[i] = f[i];
+                cur_depth = depth;
+            }
+            const int ch = state - 1, h1 = ch >> 1, h2 = ch & 1;
+            const double t1 = sc[F_T1], t2 = sc[F_T2];
+            const double t1len = sc[F_T1H] - sc[F_T1L], t2len = sc[F_T2H] - sc[F_T2L];
+            const double m1 = sc[F_T1L] + t1 * t1len, m2 = sc[F_T2L] + t2 * t2len;
+            const double a_in = sc[F_ALPHA];
+            const double n1l = h1 ? m1 : sc[F_T1L], n1h = h1 ? sc[F_T1H] : m1;
+            const double n2l = h2 ? m2 : sc[F_T2L], n2h = h2 ? sc[F_T2H] : m2;
+            wave_sync();
+            double* ns = sc + Q_NSCAL;
+            ns[F_T1L] = n1l; ns[F_T1H] = n1h; ns[F_T2L] = n2l; ns[F_T2H] = n2h;
+            ns[F_ALPHA] = a_in; ns[F_STATE] = 0; ns[Q_CH] = (double)ch;
+            sc[F_STATE] = state + 1;
+            depth++;
+            wave_sync();
+        }
+    }
+    // (every lane, the same values to the same addresses)
+    p.res[3 * k] = r0; p.res[3 * k + 1] = r1; p.res[3 * k + 2] = r2;
+    if (p.info) { p.info[4 * k] = nodes; p.info[4 * k + 1] = calls; p.info[4 * k + 2] = dmax; p.info[4 * k + 3] = status; }
+  }
+}
+
 // -------------------------------------------------------------------------------------
 //  Robust curve <-> curve minimum distance: an opt-in replacement for
 //  _minDist that does not inherit gjkNew's non-minimal distances and unbounded loops (SURVEY.md 8(a)
@@ -3480,7 +3745,11 @@ int launch_step_fd_structured(obtg_ctx* c, int B, double max_sep, double* d_out_
     return tl.finish(hdr);
 }
 
-size_t min_dist_stack_doubles(int K, int max_depth) { return (size_t)max_depth * (6 * K + F_NSCAL); }
+size_t min_dist_stack_doubles(int K, int max_depth)     // per pair (lane form) / per worker wave: the larger of the frame forms
+{
+    const int fr = 6 * K + F_NSCAL, bl = K <= kMdQuadMaxK ? md_quad_blob(K) : 0;
+    return (size_t)max_depth * (fr > bl ? fr : bl);
+}
 size_t min_dist2poly_stack_doubles(int K, int max_depth) { return (size_t)max_depth * (3 * K + G_NSCAL); }
 
 // worker waves of the wave-per-pair searches: waves per SIMD x 4 SIMDs x CUs, never more than pairs (OBTG_MD_WAVES_PER_SIMD)
@@ -3504,7 +3773,13 @@ int launch_min_dist(obtg_ctx* c, const double* d_curves, int K, const int* d_pa,
                 d_order, d_queue };
     ScopedKernelTimer t(c, OBTG_K_MIN_DIST);
     const size_t lds_w = sizeof(double) * ((size_t)12 * K + 6 * kMdMaxK + (size_t)max_depth * F_NSCAL);
-    if (lds_w <= 48 * 1024 && d_queue) {   // one pair per wavefront at a time, the waves as workers on a queue
+    const size_t lds_q = sizeof(double) * ((size_t)2 * md_quad_blob(K) + 320 + (size_t)max_depth * Q_NSCAL);
+    const char* env_form = getenv("OBTG_MD_FORM");          // "wave": a wavefront per gjkNew call (read per launch: the A/B test flips it)
+    const bool quad = K <= kMdQuadMaxK && lds_q <= 48 * 1024 && d_queue && !(env_form && !strcmp(env_form, "wave"));
+    if (quad) {                            // a 16-lane row per child: four gjkNew calls of a node's children in lockstep
+        OBTG_HIP(c, hipMemsetAsync(d_queue, 0, sizeof(int), c->stream));
+        hipLaunchKernelGGL(k_min_dist_quad, dim3((unsigned)min_dist_workers(c, n_pairs, lds_q)), dim3(kWave), lds_q, c->stream, p);
+    } else if (lds_w <= 48 * 1024 && d_queue) {   // one pair per wavefront at a time, the waves as workers on a queue
         OBTG_HIP(c, hipMemsetAsync(d_queue, 0, sizeof(int), c->stream));
         hipLaunchKernelGGL(k_min_dist_wave, dim3((unsigned)min_dist_workers(c, n_pairs, lds_w)), dim3(kWave), lds_w, c->stream, p);
     } else

@@ -843,6 +843,29 @@ def test_min_dist_robust_register_form_is_the_lds_form(capi, synth, monkeypatch)
         for key in ("res", "nodes", "levels", "frontier", "status"):
             assert np.array_equal(fast[key], slow[key], equal_nan=True), (n, key)
 
+def test_min_dist_quad_form_is_the_wave_form(capi, synth, monkeypatch):
+    """obtg_min_dist, round 5: up to 16 control points a node's four children are evaluated together, a 16-lane row of the
+    wavefront each, the four gjkNew state machines in lockstep (k_min_dist_quad); OBTG_MD_FORM=wave selects the form that
+    spends the wavefront on one call at a time (k_min_dist_wave, which also serves 17..32 points).  The walk is the same
+    walk: results, node counts, call counts, depths and statuses identical -- on the C5-sized pair list, on 3-D curves of
+    degree 3..15, with a node budget that ends searches early, with a depth cap, and with a one-node budget."""
+    cases = [(96, 2, 10, 1234), (30, 3, 3, 2), (20, 3, 5, 3), (14, 3, 8, 4), (12, 2, 12, 5), (10, 3, 15, 6), (24, 2, 7, 7)]
+    for (ncurves, dim, n, seed) in cases:
+        Yc = synth.swarm_control_points(ncurves, dim, n, seed=seed)
+        curves = np.zeros((ncurves, 3, n + 1))
+        curves[:, :dim, :] = Yc.reshape(ncurves, dim, n + 1)
+        pa, pb = synth.all_pairs(ncurves)
+        ctx = capi.scratch_context()
+        for kw in (dict(max_depth=64, max_nodes=2000), dict(max_depth=7, max_nodes=2000), dict(max_depth=64, max_nodes=1),
+                   dict(max_depth=64, max_nodes=37), dict(max_depth=1, max_nodes=50)):
+            quad = ctx.min_dist(curves, pa, pb, **kw)
+            monkeypatch.setenv("OBTG_MD_FORM", "wave")
+            wave = ctx.min_dist(curves, pa, pb, **kw)
+            monkeypatch.delenv("OBTG_MD_FORM")
+            for key in ("res", "nodes", "gjk_calls", "depth", "status"):
+                assert np.array_equal(quad[key], wave[key], equal_nan=True), (n, kw, key)
+
+
 @pytest.mark.parametrize("R", [0, 7])
 def test_temporal_sep_is_the_sampled_squared_distance(capi, synth, R):
     """The reference's own eyeball check (temp.py:20-37), made numerical and independent of the oracle:
@@ -1706,7 +1729,7 @@ def test_small_host_calls_through_mapped_memory_equal_the_staged_path(capi, synt
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("N,n,M,B", [(8, 10, 0, 217), (36, 5, 2, 40), (70, 7, 3, 3), (130, 3, 0, 2)])
+@pytest.mark.parametrize("N,n,M,B", [(8, 10, 0, 217), (36, 5, 2, 40), (70, 7, 3, 3), (130, 3, 0, 2), (14, 8, 2, 9)])
 def test_3d_sweep_as_one_launch_equals_separate_calls(capi, synth, N, n, M, B):
     """3-D rows: obtg_constraint_sweep_dev is ONE launch (k_pair_sweep_3d: the sweep's workgroups first run their part of
     the row's temporal-separation block and speed rows with the stand-alone kernels' code) -- the same bits as
