@@ -2076,7 +2076,7 @@ __global__ __launch_bounds__(64, OBTG_MD_MIN_WAVES) void k_min_dist_wave(const M
 // A frame's blob: the four half curves of an EXPANDED node, c3 c4 (curve 1 left, right) c5 c6 (curve 2), then the records
 // of its four children (c3,c5) (c3,c6) (c4,c5) (c4,c6).
 enum { R_CAP = 0, R_LB, R_T1, R_T2, R_UB, R_AM, R_NREC };
-enum { Q_CH = F_NSCAL, Q_NSCAL };          // frame scalars: k_min_dist_wave's + which child of its parent the node is
+enum { Q_NSCAL = F_NSCAL };               // frame scalars: k_min_dist_wave's (F_STATE: the next child, 0..4)
 __host__ __device__ constexpr int md_quad_blob(int K) { return 12 * K + 4 * R_NREC; }
 constexpr int kMdQuadMaxK = 16;
 
@@ -2140,29 +2140,158 @@ __device__ __forceinline__ void split_both(const double* c1, const double* c2, i
     else { split_both_t<0>(c1, c2, K, t1, t2, blob, 0, 3, dump); split_both_t<0>(c1, c2, K, t1, t2, blob, 3, 3, dump); }
 }
 
-// hull_param_wave for the call of one 16-lane row: c = the row's curve, sh_e / sh_q = 16 doubles of the row's own
-__device__ __forceinline__ double hull_param_quarter(const double* c, int K, const V3& cl, double* sh_e, double* sh_q)
+// np_sum_f of two sequences side by side (their quotients are independent chains: the two divisions of a step overlap)
+template <class FA, class FB>
+__device__ __forceinline__ void np_sum_f2(int n, FA qa, FB qb, double& sa, double& sb)
+{
+    if (n < 8) {
+        double ra = 0.0, rb = 0.0;
+        for (int i = 0; i < n; ++i) { ra += qa(i); rb += qb(i); }
+        sa = ra; sb = rb;
+        return;
+    }
+    double a0 = qa(0), a1 = qa(1), a2 = qa(2), a3 = qa(3), a4 = qa(4), a5 = qa(5), a6 = qa(6), a7 = qa(7);
+    double b0 = qb(0), b1 = qb(1), b2 = qb(2), b3 = qb(3), b4 = qb(4), b5 = qb(5), b6 = qb(6), b7 = qb(7);
+    int i;
+    for (i = 8; i < n - (n % 8); i += 8) {
+        a0 += qa(i); a1 += qa(i + 1); a2 += qa(i + 2); a3 += qa(i + 3); a4 += qa(i + 4); a5 += qa(i + 5); a6 += qa(i + 6); a7 += qa(i + 7);
+        b0 += qb(i); b1 += qb(i + 1); b2 += qb(i + 2); b3 += qb(i + 3); b4 += qb(i + 4); b5 += qb(i + 5); b6 += qb(i + 6); b7 += qb(i + 7);
+    }
+    double ra = ((a0 + a1) + (a2 + a3)) + ((a4 + a5) + (a6 + a7));
+    double rb = ((b0 + b1) + (b2 + b3)) + ((b4 + b5) + (b6 + b7));
+    for (; i < n; ++i) { ra += qa(i); rb += qb(i); }
+    sa = ra; sb = rb;
+}
+
+// hull_param_wave for the call of one 16-lane row, both curves at once: lane l of the row takes control point l of c1 AND of
+// c2 (the weights of a point are a chain of K - 1 divisions; the two curves' chains overlap); sh_e / sh_q: 32 doubles of
+// the row's own.  Per curve the operations are hull_param's (bezier.py:1320-1351).
+__device__ __forceinline__ void hull_param_quarter2(const double* c1, const double* c2, int K, const V3& cl1, const V3& cl2,
+                                                    double* sh_e, double* sh_q, double& t1, double& t2)
 {
     const int lane = threadIdx.x & 63, l = lane & 15;
-    const bool hit = l < K && c[l] == cl.x && c[K + l] == cl.y && c[2 * K + l] == cl.z;
-    const unsigned m = (unsigned)(__ballot(hit) >> (lane & 48)) & 0xffffu;
-    if (m) return (double)(__ffs((int)m) - 1) / (double)(K - 1);
+    // exact row match first: lowest matching index
+    const bool hit1 = l < K && c1[l] == cl1.x && c1[K + l] == cl1.y && c1[2 * K + l] == cl1.z;
+    const bool hit2 = l < K && c2[l] == cl2.x && c2[K + l] == cl2.y && c2[2 * K + l] == cl2.z;
+    const unsigned m1 = (unsigned)(__ballot(hit1) >> (lane & 48)) & 0xffffu;
+    const unsigned m2 = (unsigned)(__ballot(hit2) >> (lane & 48)) & 0xffffu;
+    if (m1) t1 = (double)(__ffs((int)m1) - 1) / (double)(K - 1);
+    if (m2) t2 = (double)(__ffs((int)m2) - 1) / (double)(K - 1);
+    if (m1 && m2) return;
     if (l < K) {
-        const double dx = cl.x - c[l], dy = cl.y - c[K + l], dz = cl.z - c[2 * K + l];
+        const double dx = cl1.x - c1[l], dy = cl1.y - c1[K + l], dz = cl1.z - c1[2 * K + l];
         double s = 0.0;
         s += dx * dx; s += dy * dy; s += dz * dz;
         sh_e[l] = __builtin_sqrt(s);
+        const double ex = cl2.x - c2[l], ey = cl2.y - c2[K + l], ez = cl2.z - c2[2 * K + l];
+        double u = 0.0;
+        u += ex * ex; u += ey * ey; u += ez * ez;
+        sh_e[16 + l] = __builtin_sqrt(u);
     }
     wave_sync();
     if (l < K) {
-        const double ei = sh_e[l];
-        const double s1 = np_sum_f(l, [&](int j) { return ei / sh_e[j]; });
-        const double s2 = np_sum_f(K - l - 1, [&](int j) { return ei / sh_e[l + 1 + j]; });
-        const double W = 1 / (1 + s1 + s2);
-        sh_q[l] = W * (double)l / (double)K;
+        const double ea = sh_e[l], eb = sh_e[16 + l];
+        double a1, b1, a2, b2;
+        np_sum_f2(l, [&](int j) { return ea / sh_e[j]; }, [&](int j) { return eb / sh_e[16 + j]; }, a1, b1);
+        np_sum_f2(K - l - 1, [&](int j) { return ea / sh_e[l + 1 + j]; }, [&](int j) { return eb / sh_e[16 + l + 1 + j]; }, a2, b2);
+        const double Wa = 1 / (1 + a1 + a2), Wb = 1 / (1 + b1 + b2);
+        sh_q[l] = Wa * (double)l / (double)K;
+        sh_q[16 + l] = Wb * (double)l / (double)K;
     }
     wave_sync();
-    return np_sum(sh_q, K);
+    if (!m1) t1 = np_sum(sh_q, K);
+    if (!m2) t2 = np_sum(sh_q + 16, K);
+}
+
+// hull_param_quarter2 for a control-point count known at compile time.  The weights of point l are 1 / (1 + sum_{j<l} e_l/e_j
+// + sum_{j>l} e_l/e_j) with numpy's association of each sum (np_sum_f: left to right below eight terms, else the first eight
+// pairwise and the rest left to right) -- K - 1 divisions per lane.  As loops of lane-dependent length (hull_param_quarter2)
+// the wavefront walks through the longest of every kind, a division at a time, and the two calls were 11.6 k clocks of an
+// evaluation's 33 k (profiles/r05_experiments/mindist_quad_phases.txt).  Here every lane forms ALL K quotients of both curves
+// -- 2 K independent divisions, unrolled -- and the sums pick their terms by predicate in the order numpy adds them.
+template <int K>
+__device__ __forceinline__ void hull_param_quarter2_t(const double* c1, const double* c2, const V3& cl1, const V3& cl2,
+                                                      double* sh_e, double* sh_q, double& t1, double& t2)
+{
+    static_assert(K >= 2 && K <= 16, "a 16-lane row per curve pair");
+    const int lane = threadIdx.x & 63, l = lane & 15;
+    const int li = l < K ? l : 0;                        // (lanes past the curve repeat point 0; nothing of theirs is used)
+    const double ax = c1[li], ay = c1[K + li], az = c1[2 * K + li];
+    const double bx = c2[li], by = c2[K + li], bz = c2[2 * K + li];
+    const bool hit1 = l < K && ax == cl1.x && ay == cl1.y && az == cl1.z;
+    const bool hit2 = l < K && bx == cl2.x && by == cl2.y && bz == cl2.z;
+    const unsigned m1 = (unsigned)(__ballot(hit1) >> (lane & 48)) & 0xffffu;
+    const unsigned m2 = (unsigned)(__ballot(hit2) >> (lane & 48)) & 0xffffu;
+    if (m1) t1 = (double)(__ffs((int)m1) - 1) / (double)(K - 1);
+    if (m2) t2 = (double)(__ffs((int)m2) - 1) / (double)(K - 1);
+    if (m1 && m2) return;
+    double ea, eb;
+    {
+        const double dx = cl1.x - ax, dy = cl1.y - ay, dz = cl1.z - az;
+        double s = 0.0;
+        s += dx * dx; s += dy * dy; s += dz * dz;
+        ea = __builtin_sqrt(s);
+        const double ex = cl2.x - bx, ey = cl2.y - by, ez = cl2.z - bz;
+        double u = 0.0;
+        u += ex * ex; u += ey * ey; u += ez * ez;
+        eb = __builtin_sqrt(u);
+    }
+    sh_e[l] = ea; sh_e[16 + l] = eb;
+    wave_sync();
+    double qa[K], qb[K];
+#pragma unroll
+    for (int j = 0; j < K; ++j) { qa[j] = ea / sh_e[j]; qb[j] = eb / sh_e[16 + j]; }
+    // terms j < l (l of them)
+    auto sum_lo = [&](const double (&q)[K]) {
+        double r = 0.0;
+#pragma unroll
+        for (int j = 0; j < (K < 8 ? K : 7); ++j) r = j < l ? r + q[j] : r;
+        if constexpr (K > 8) {
+            double P = ((q[0] + q[1]) + (q[2] + q[3])) + ((q[4] + q[5]) + (q[6] + q[7]));
+#pragma unroll
+            for (int j = 8; j < K - 1; ++j) P = j < l ? P + q[j] : P;
+            r = l >= 8 ? P : r;
+        }
+        return r;
+    };
+    // terms j > l (K - 1 - l of them)
+    auto sum_hi = [&](const double (&q)[K]) {
+        double r = 0.0;
+#pragma unroll
+        for (int j = 1; j < K; ++j) r = j > l ? r + q[j] : r;
+        if constexpr (K > 8) {                            // eight or more terms: lanes l <= K - 9, the first eight start at l + 1
+            double x[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                x[k] = q[1 + k];
+#pragma unroll
+                for (int l0 = 1; l0 <= K - 9; ++l0) x[k] = l == l0 ? q[l0 + 1 + k] : x[k];
+            }
+            double P = ((x[0] + x[1]) + (x[2] + x[3])) + ((x[4] + x[5]) + (x[6] + x[7]));
+#pragma unroll
+            for (int j = 9; j < K; ++j) P = j >= l + 9 ? P + q[j] : P;
+            r = K - 1 - l >= 8 ? P : r;
+        }
+        return r;
+    };
+    const double a1 = sum_lo(qa), a2 = sum_hi(qa), b1 = sum_lo(qb), b2 = sum_hi(qb);
+    const double Wa = 1 / (1 + a1 + a2), Wb = 1 / (1 + b1 + b2);
+    sh_q[l] = Wa * (double)l / (double)K;
+    sh_q[16 + l] = Wb * (double)l / (double)K;
+    wave_sync();
+    if (!m1) t1 = np_sum(sh_q, K);
+    if (!m2) t2 = np_sum(sh_q + 16, K);
+}
+
+__device__ __forceinline__ void hull_param_rows(const double* c1, const double* c2, int K, const V3& cl1, const V3& cl2,
+                                                double* sh_e, double* sh_q, double& t1, double& t2)
+{
+    switch (K) {        // (wave-uniform)
+#define OBTG_CASE(NC_) case NC_: hull_param_quarter2_t<NC_>(c1, c2, cl1, cl2, sh_e, sh_q, t1, t2); return;
+        OBTG_NC_DYN(OBTG_CASE)
+#undef OBTG_CASE
+        default: hull_param_quarter2(c1, c2, K, cl1, cl2, sh_e, sh_q, t1, t2);
+    }
 }
 
 // What a node's visit needs of it, for the four (curve 1, curve 2) pairs the rows of the wavefront name: the gjkNew call,
@@ -2170,7 +2299,11 @@ __device__ __forceinline__ double hull_param_quarter(const double* c, int K, con
 // o1 / o2: offsets of the row's two curves in `lds`; rec: the row's record.  Every lane of a row stores the row's (equal)
 // values: no lane-dependent region (see the queue pull of k_min_dist_wave).
 __device__ __forceinline__ void md_eval_rows(const double* lds, int o1, int o2, int K, double eps, int max_iter, int md_cap,
-                                             double* rec, double* sh_e, double* sh_q)
+                                             double* rec, double* sh_e, double* sh_q
+#ifdef OBTG_MD_TIMING
+                                             , unsigned long long* tm      // [0] the lockstep gjkNew, [1] the split parameters, [2] bound + record
+#endif
+)
 {
     Ctx<MemLds> g;
     g.mem = MemLds{ lds };
@@ -2178,15 +2311,27 @@ __device__ __forceinline__ void md_eval_rows(const double* lds, int o1, int o2, 
     g.P2 = Poly{ o2, K, K, 1 };
     g.trace = nullptr; g.trace_cap = 0; g.n_support = 0;
     Result gr;
+#ifdef OBTG_MD_TIMING
+    const unsigned long long tq0 = __builtin_readcyclecounter();
+#endif
     gjk::run_quarter<MemLds>(g, max_iter, md_cap, gr);
+#ifdef OBTG_MD_TIMING
+    if (gr.dist == -1.0) rec[R_CAP] = 0.0;      // (keeps the call ahead of the stamp)
+    tm[0] += __builtin_readcyclecounter() - tq0;
+    const unsigned long long tq1 = __builtin_readcyclecounter();
+#endif
     const bool cap = gr.status == OBTG_ST_MD_CAP || gr.status == OBTG_ST_CYCLE;
     double lb = eps, t1 = 0.5, t2 = 0.5;
     const double* c1 = lds + o1; const double* c2 = lds + o2;
     if (gr.flag > 0 && !cap) {
         lb = gr.dist;
-        t1 = hull_param_quarter(c1, K, gr.c1, sh_e, sh_q);
-        t2 = hull_param_quarter(c2, K, gr.c2, sh_e + 16, sh_q + 16);
+        hull_param_rows(c1, c2, K, gr.c1, gr.c2, sh_e, sh_q, t1, t2);
     }
+#ifdef OBTG_MD_TIMING
+    if (t1 == -1.0) rec[R_CAP] = 0.0;
+    tm[1] += __builtin_readcyclecounter() - tq1;
+    const unsigned long long tq2 = __builtin_readcyclecounter();
+#endif
     double dd[4];
     dd[0] = norm_seq(c1[0], c1[K], c1[2 * K], c2[0], c2[K], c2[2 * K]);
     dd[1] = norm_seq(c1[0], c1[K], c1[2 * K], c2[K - 1], c2[2 * K - 1], c2[3 * K - 1]);
@@ -2196,6 +2341,11 @@ __device__ __forceinline__ void md_eval_rows(const double* lds, int o1, int o2, 
     for (int i = 1; i < 4; ++i) if (dd[i] < dd[am]) am = i;
     for (int i = 0; i < 4; ++i) if (dd[i] != dd[i]) { am = i; break; }
     rec[R_CAP] = cap ? 1.0 : 0.0; rec[R_LB] = lb; rec[R_T1] = t1; rec[R_T2] = t2; rec[R_UB] = dd[am]; rec[R_AM] = (double)am;
+#ifdef OBTG_MD_TIMING
+    wave_sync();
+    if (rec[R_UB] == -1.0) rec[R_CAP] = 0.0;
+    tm[2] += __builtin_readcyclecounter() - tq2;
+#endif
 }
 
 __global__ __launch_bounds__(64, OBTG_MD_MIN_WAVES) void k_min_dist_quad(const MdParams p)
@@ -2224,102 +2374,137 @@ __global__ __launch_bounds__(64, OBTG_MD_MIN_WAVES) void k_min_dist_quad(const M
         const double a = ca[i], bq = cb[i];
         nxt[i] = a; nxt[3 * K + i] = a; nxt[6 * K + i] = bq; nxt[9 * K + i] = bq;
     }
-    scs[F_T1L] = 0; scs[F_T1H] = 1; scs[F_T2L] = 0; scs[F_T2H] = 1; scs[F_ALPHA] = INFINITY; scs[F_STATE] = 0; scs[Q_CH] = 0;
-    int depth = 0, cur_depth = -1;    // cur_depth: which frame's blob `cur` holds
+    // The frame whose children the walk is going through lives in registers (the values are wave-uniform); `scs` holds the
+    // frames below it.  Frame -1: the parameter square itself, split "at (1, 1)", whose child 0 is the root.
+    double f_t1l = 0, f_t1h = 1, f_t2l = 0, f_t2h = 1, f_t1 = 1, f_t2 = 1, f_alpha = INFINITY, f_rt1 = -1, f_rt2 = -1;
+    int f_next = 0;
+    int depth = -1, cur_depth = -1;   // depth: the frame in registers; cur_depth: which frame's blob `cur` holds
     int eval_depth = -1;              // which frame's blob `nxt` is about to become
     int nodes = 0, calls = 0, dmax = 0, status = OBTG_MD_OK;
     double r0 = INFINITY, r1 = -1, r2 = -1;
-    bool returning = false, done = false;
+    bool done = false;
+#ifdef OBTG_MD_TIMING      // (variant builds: info[] then carries phase totals in units of 1024 clocks)
+    unsigned long long tm_ev[3] = { 0, 0, 0 }, tm_eval = 0, tm_split = 0, tm_walk = 0, tm_store = 0, tm_fetch = 0;
+#endif
     while (!done) {
         // ---- the four children of the blob in `nxt`, a row of the wavefront each
         wave_sync();
+#ifdef OBTG_MD_TIMING
+        unsigned long long tq = __builtin_readcyclecounter();
+        md_eval_rows(md_lds, (int)(nxt - md_lds) + (q >> 1) * 3 * K, (int)(nxt - md_lds) + (2 + (q & 1)) * 3 * K, K, p.eps,
+                     p.max_iter, p.md_cap, nxt + 12 * K + q * R_NREC, sh_e + q * 32, sh_q + q * 32, tm_ev);
+#else
         md_eval_rows(md_lds, (int)(nxt - md_lds) + (q >> 1) * 3 * K, (int)(nxt - md_lds) + (2 + (q & 1)) * 3 * K, K, p.eps,
                      p.max_iter, p.md_cap, nxt + 12 * K + q * R_NREC, sh_e + q * 32, sh_q + q * 32);
+#endif
         wave_sync();
+#ifdef OBTG_MD_TIMING
+        const unsigned long long tq3 = __builtin_readcyclecounter();
+#endif
         if (eval_depth >= 0) {
             double* f = st + (size_t)eval_depth * BL;
             for (int i = lane; i < BL; i += kWave) f[i] = nxt[i];
         }
         { double* tsw = cur; cur = nxt; nxt = tsw; }
         cur_depth = eval_depth;
-        // ---- the depth-first walk, until a node has to be expanded (its pieces go to `nxt`) or the search ends
+#ifdef OBTG_MD_TIMING
+        if (cur[12 * K] == -1.0) tm_eval += 1;      // (keeps the records ahead of the stamp)
+        tm_store += __builtin_readcyclecounter() - tq3;
+        tm_eval += __builtin_readcyclecounter() - tq;
+        tq = __builtin_readcyclecounter();
+#endif
+        // ---- the depth-first walk (bezier.py:1283-1408 unrolled onto the frames), until a node has to be expanded -- its
+        //      pieces go to `nxt`, the evaluation of its children is the next trip's -- or the search ends.
+        //      A value returned to a frame: `if newAlpha < retval[0]: retval = ...` (bezier.py:1383-1406); to frame -1: the answer.
+#define OBTG_MD_RETURN() \
+    { if (depth < 0) { done = true; break; } \
+      if (r0 < f_alpha) { f_alpha = r0; f_rt1 = r1; f_rt2 = r2; } \
+      continue; }
         for (;;) {
-            double* sc = scs + depth * Q_NSCAL;
-            int state = (int)sc[F_STATE];
-            if (!returning && state == 0) {
-                if (depth + 1 > 1000) { r0 = r1 = r2 = -1; returning = true; depth--; if (depth < 0) { done = true; break; } continue; }
-                if (nodes >= p.max_nodes) { status = OBTG_MD_NODE_CAP; done = true; break; }
-                nodes++;
-                if (depth + 1 > dmax) dmax = depth + 1;
-                const int ch = (int)sc[Q_CH];
-                // the node's record and curves: in its parent's blob, which is `cur` (the parent descended into it just now)
-                const double* rec = cur + 12 * K + ch * R_NREC;
-                calls++;
-                if (rec[R_CAP] != 0.0) { status = OBTG_MD_GJK_CAP; done = true; break; }
-                const double lb = rec[R_LB];
-                double t1 = rec[R_T1], t2 = rec[R_T2];
-                const int am = (int)rec[R_AM];
-                const double ub = rec[R_UB], t1loc = (am >> 1) ? 1.0 : 0.0, t2loc = (am & 1) ? 1.0 : 0.0;
-                double alpha = sc[F_ALPHA], nT1, nT2;
-                if (ub <= alpha) {
-                    alpha = ub;
-                    nT1 = (1 - t1loc) * sc[F_T1L] + t1loc * sc[F_T1H];
-                    nT2 = (1 - t2loc) * sc[F_T2L] + t2loc * sc[F_T2H];
-                } else { nT1 = -1; nT2 = -1; }
-                if (lb >= alpha * (1 - p.eps)) {
-                    r0 = alpha; r1 = nT1; r2 = nT2; returning = true; depth--;
-                    if (depth < 0) { done = true; break; }
-                    continue;
-                }
-                if (depth + 1 >= p.max_depth) { status = OBTG_MD_DEPTH_CAP; r0 = alpha; r1 = nT1; r2 = nT2; done = true; break; }
-                if (t1 != t1) t1 = 0;
-                if (t2 != t2) t2 = 0;
-                // expand: both pieces of both curves; the evaluation of the four children is the next trip's
-                split_both(cur + (ch >> 1) * 3 * K, cur + (2 + (ch & 1)) * 3 * K, K, t1, t2, nxt, dump);
-                wave_sync();
-                sc[F_T1] = t1; sc[F_T2] = t2; sc[F_ALPHA] = alpha; sc[F_RT1] = nT1; sc[F_RT2] = nT2; sc[F_STATE] = 1;
-                wave_sync();
-                eval_depth = depth;
-                break;
-            }
-            if (returning) {
-                if (r0 < sc[F_ALPHA]) {
-                    wave_sync();
-                    sc[F_ALPHA] = r0; sc[F_RT1] = r1; sc[F_RT2] = r2;
-                    wave_sync();
-                }
-                returning = false;
-                state = (int)sc[F_STATE];
-            }
-            if (state >= 5) {
-                r0 = sc[F_ALPHA]; r1 = sc[F_RT1]; r2 = sc[F_RT2]; returning = true; depth--;
+            if (f_next >= 4) {                   // the four children are done: this frame's value goes to its parent
+                r0 = f_alpha; r1 = f_rt1; r2 = f_rt2;
+                depth--;
                 if (depth < 0) { done = true; break; }
-                continue;
+                const double* sc = scs + depth * Q_NSCAL;
+                f_t1 = sc[F_T1]; f_t2 = sc[F_T2]; f_t1l = sc[F_T1L]; f_t1h = sc[F_T1H]; f_t2l = sc[F_T2L]; f_t2h = sc[F_T2H];
+                f_alpha = sc[F_ALPHA]; f_rt1 = sc[F_RT1]; f_rt2 = sc[F_RT2]; f_next = (int)sc[F_STATE];
+                OBTG_MD_RETURN()
             }
-            // ---- descend into child state-1: (c3,c5) (c3,c6) (c4,c5) (c4,c6); its record (and, if it is expanded, its
-            //      curves) are in this frame's blob
+            // ---- child f_next of the frame: (c3,c5) (c3,c6) (c4,c5) (c4,c6), a node at depth + 1
+            const int ch = f_next++, h1 = ch >> 1, h2 = ch & 1;
+            if (depth + 2 > 1000) { r0 = r1 = r2 = -1; OBTG_MD_RETURN() }
+            if (nodes >= p.max_nodes) { status = OBTG_MD_NODE_CAP; done = true; break; }
+            nodes++;
+            if (depth + 2 > dmax) dmax = depth + 2;
             if (cur_depth != depth) {            // the walk came back up: fetch this frame's blob again
+#ifdef OBTG_MD_TIMING
+                const unsigned long long tf0 = __builtin_readcyclecounter();
+#endif
                 __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
                 const double* f = st + (size_t)depth * BL;
                 for (int i = lane; i < BL; i += kWave) cur[i] = f[i];
                 cur_depth = depth;
+                wave_sync();
+#ifdef OBTG_MD_TIMING
+                if (cur[0] == -1.0) tm_fetch += 1;
+                tm_fetch += __builtin_readcyclecounter() - tf0;
+#endif
             }
-            const int ch = state - 1, h1 = ch >> 1, h2 = ch & 1;
-            const double t1 = sc[F_T1], t2 = sc[F_T2];
-            const double t1len = sc[F_T1H] - sc[F_T1L], t2len = sc[F_T2H] - sc[F_T2L];
-            const double m1 = sc[F_T1L] + t1 * t1len, m2 = sc[F_T2L] + t2 * t2len;
-            const double a_in = sc[F_ALPHA];
-            const double n1l = h1 ? m1 : sc[F_T1L], n1h = h1 ? sc[F_T1H] : m1;
-            const double n2l = h2 ? m2 : sc[F_T2L], n2h = h2 ? sc[F_T2H] : m2;
+            const double* rec = cur + 12 * K + ch * R_NREC;
+            calls++;
+            if (rec[R_CAP] != 0.0) { status = OBTG_MD_GJK_CAP; done = true; break; }
+            const double t1len = f_t1h - f_t1l, t2len = f_t2h - f_t2l;
+            const double m1 = f_t1l + f_t1 * t1len, m2 = f_t2l + f_t2 * t2len;
+            const double n1l = h1 ? m1 : f_t1l, n1h = h1 ? f_t1h : m1;
+            const double n2l = h2 ? m2 : f_t2l, n2h = h2 ? f_t2h : m2;
+            const double lb = rec[R_LB];
+            double t1 = rec[R_T1], t2 = rec[R_T2];
+            const int am = (int)rec[R_AM];
+            const double ub = rec[R_UB], t1loc = (am >> 1) ? 1.0 : 0.0, t2loc = (am & 1) ? 1.0 : 0.0;
+            double alpha = f_alpha, nT1, nT2;
+            if (ub <= alpha) {
+                alpha = ub;
+                nT1 = (1 - t1loc) * n1l + t1loc * n1h;
+                nT2 = (1 - t2loc) * n2l + t2loc * n2h;
+            } else { nT1 = -1; nT2 = -1; }
+            if (lb >= alpha * (1 - p.eps)) { r0 = alpha; r1 = nT1; r2 = nT2; OBTG_MD_RETURN() }
+            if (depth + 2 >= p.max_depth) { status = OBTG_MD_DEPTH_CAP; r0 = alpha; r1 = nT1; r2 = nT2; done = true; break; }
+            if (t1 != t1) t1 = 0;
+            if (t2 != t2) t2 = 0;
+            // ---- expand the child: both pieces of both its curves to `nxt`; this frame goes to `scs`, the child's into the registers
+#ifdef OBTG_MD_TIMING
+            const unsigned long long ts0 = __builtin_readcyclecounter();
+#endif
+            split_both(cur + h1 * 3 * K, cur + (2 + h2) * 3 * K, K, t1, t2, nxt, dump);
+#ifdef OBTG_MD_TIMING
             wave_sync();
-            double* ns = sc + Q_NSCAL;
-            ns[F_T1L] = n1l; ns[F_T1H] = n1h; ns[F_T2L] = n2l; ns[F_T2H] = n2h;
-            ns[F_ALPHA] = a_in; ns[F_STATE] = 0; ns[Q_CH] = (double)ch;
-            sc[F_STATE] = state + 1;
+            if (nxt[0] == -1.0) tm_split += 1;
+            tm_split += __builtin_readcyclecounter() - ts0;
+#endif
+            if (depth >= 0) {
+                double* sc = scs + depth * Q_NSCAL;
+                sc[F_T1] = f_t1; sc[F_T2] = f_t2; sc[F_T1L] = f_t1l; sc[F_T1H] = f_t1h; sc[F_T2L] = f_t2l; sc[F_T2H] = f_t2h;
+                sc[F_ALPHA] = f_alpha; sc[F_RT1] = f_rt1; sc[F_RT2] = f_rt2; sc[F_STATE] = (double)f_next;
+            }
+            f_t1 = t1; f_t2 = t2; f_t1l = n1l; f_t1h = n1h; f_t2l = n2l; f_t2h = n2h;
+            f_alpha = alpha; f_rt1 = nT1; f_rt2 = nT2; f_next = 0;
             depth++;
-            wave_sync();
+            eval_depth = depth;
+            break;
         }
+#undef OBTG_MD_RETURN
+#ifdef OBTG_MD_TIMING
+        tm_walk += __builtin_readcyclecounter() - tq;      // (includes the split)
+#endif
     }
+#ifdef OBTG_MD_TIMING
+    // gjk_calls <- the lockstep gjkNew loops, depth <- a trip's evaluation in all (gjkNew included), status <- split | walk << 16
+#if OBTG_MD_TIMING == 2     // split parameters, bound + record, blob store, blob re-fetch
+    calls = (int)(tm_ev[1] >> 10); dmax = (int)(tm_ev[2] >> 10); status = (int)(tm_store >> 10) | ((int)(tm_fetch >> 10) << 16);
+#else
+    calls = (int)(tm_ev[0] >> 10); dmax = (int)(tm_eval >> 10); status = (int)(tm_split >> 10) | ((int)(tm_walk >> 10) << 16);
+#endif
+#endif
     // (every lane, the same values to the same addresses)
     p.res[3 * k] = r0; p.res[3 * k + 1] = r1; p.res[3 * k + 2] = r2;
     if (p.info) { p.info[4 * k] = nodes; p.info[4 * k + 1] = calls; p.info[4 * k + 2] = dmax; p.info[4 * k + 3] = status; }
