@@ -1214,7 +1214,7 @@ int obtg_min_dist(obtg_ctx* c, const double* curves, int n_curves, int K, const 
     if (rc) return rc;
     if ((rc = h2d(c, m[1], pair_a, sizeof(int) * n_pairs))) return rc;
     if ((rc = h2d(c, m[2], pair_b, sizeof(int) * n_pairs))) return rc;
-    if ((rc = m[5].reserve(sizeof(double) * min_dist_stack_doubles(K, max_depth) * n_pairs))) return rc;
+    if ((rc = m[5].reserve(sizeof(double) * min_dist_stack_doubles(c, K, max_depth, n_pairs)))) return rc;
     if ((rc = c->ws_out.reserve(sizeof(double) * 3 * (size_t)n_pairs))) return rc;
     if ((rc = m[3].reserve(sizeof(int) * 4 * (size_t)n_pairs))) return rc;
     // the order the worker waves take the pairs in: by the previous evaluation's node counts, longest search first, when

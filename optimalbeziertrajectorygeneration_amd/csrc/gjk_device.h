@@ -98,6 +98,7 @@ template <class Mem>
 struct Ctx {
     Mem mem;
     Poly P1, P2;
+    V3 own1, own2;     // support_pts_quarter only: the lane's own point of each set (run_quarter loads them once per call)
     short* trace;      // nullable, [trace_cap][2]
     int trace_cap;
     int n_support;
@@ -196,8 +197,9 @@ __device__ __forceinline__ void support_pts_quarter(Ctx<Mem>& g, const V3& dir, 
     const int lane = threadIdx.x & 63, l = lane & 15;
     const V3 nd = neg(dir);
     const bool have1 = l < g.P1.K, have2 = l < g.P2.K;
-    double v1 = have1 ? sdot<Mem, false>(g.mem, g.P1, l, dir) : -__builtin_inf();
-    double v2 = have2 ? sdot<Mem, false>(g.mem, g.P2, l, nd) : -__builtin_inf();
+    // (sdot's expression on the lane's own points, which do not change during a call)
+    double v1 = have1 ? g.own1.x * dir.x + g.own1.y * dir.y + g.own1.z * dir.z : -__builtin_inf();
+    double v2 = have2 ? g.own2.x * nd.x + g.own2.y * nd.y + g.own2.z * nd.z : -__builtin_inf();
     // point 0's value NaN: maxd starts as NaN and nothing is ever greater (the row's lane 0 holds point 0)
     const unsigned long long nan1 = __ballot(v1 != v1), nan2 = __ballot(v2 != v2);
     const int row0 = lane & 48;
@@ -212,7 +214,7 @@ __device__ __forceinline__ void support_pts_quarter(Ctx<Mem>& g, const V3& dir, 
       const int hi2_ = __builtin_amdgcn_update_dpp(0, __double2hiint(v2), CTRL, 0xf, 0xf, false); \
       const int oi2_ = __builtin_amdgcn_update_dpp(0, i2, CTRL, 0xf, 0xf, false); \
       const double ov1_ = __hiloint2double(hi1_, lo1_), ov2_ = __hiloint2double(hi2_, lo2_); \
-      const bool t1_ = ov1_ > v1 || (ov1_ == v1 && oi1_ < i1), t2_ = ov2_ > v2 || (ov2_ == v2 && oi2_ < i2); \
+      const bool t1_ = (ov1_ > v1) | ((ov1_ == v1) & (oi1_ < i1)), t2_ = (ov2_ > v2) | ((ov2_ == v2) & (oi2_ < i2)); \
       v1 = t1_ ? ov1_ : v1; i1 = t1_ ? oi1_ : i1; v2 = t2_ ? ov2_ : v2; i2 = t2_ ? oi2_ : i2; }
     OBTG_DPP_MEET2(0xB1)      // quad_perm:[1,0,3,2]
     OBTG_DPP_MEET2(0x4E)      // quad_perm:[2,3,0,1]
@@ -463,6 +465,11 @@ __device__ __forceinline__ void run_quarter(Ctx<Mem>& g, int max_iter, int md_ca
     const double qnan = __builtin_nan("");
     r.flag = -1; r.status = OBTG_ST_MAXITER;
     r.c1 = V3{ qnan, qnan, qnan }; r.c2 = r.c1; r.dist = qnan;
+    {
+        const int l = threadIdx.x & 15;
+        g.own1 = point(g.mem, g.P1, l < g.P1.K ? l : 0);
+        g.own2 = point(g.mem, g.P2, l < g.P2.K ? l : 0);
+    }
     int phase = 0, it = 0, rr = 0;
     bool live = max_iter > 0, conv = false;
     while (live) {

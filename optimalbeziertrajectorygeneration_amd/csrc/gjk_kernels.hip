@@ -3930,11 +3930,6 @@ int launch_step_fd_structured(obtg_ctx* c, int B, double max_sep, double* d_out_
     return tl.finish(hdr);
 }
 
-size_t min_dist_stack_doubles(int K, int max_depth)     // per pair (lane form) / per worker wave: the larger of the frame forms
-{
-    const int fr = 6 * K + F_NSCAL, bl = K <= kMdQuadMaxK ? md_quad_blob(K) : 0;
-    return (size_t)max_depth * (fr > bl ? fr : bl);
-}
 size_t min_dist2poly_stack_doubles(int K, int max_depth) { return (size_t)max_depth * (3 * K + G_NSCAL); }
 
 // worker waves of the wave-per-pair searches: waves per SIMD x 4 SIMDs x CUs, never more than pairs (OBTG_MD_WAVES_PER_SIMD)
@@ -3948,6 +3943,36 @@ int min_dist_workers(const obtg_ctx* c, int n_pairs, size_t lds_per_wave)
     return (int)(w < n_pairs ? w : n_pairs);
 }
 
+// which forms of the curve <-> curve search the LDS budget allows for (K, max_depth), and what each asks per worker wave
+struct MdPlan {
+    size_t lds_w, lds_q;
+    bool wave_ok, quad_ok;
+};
+static MdPlan md_plan(int K, int max_depth)
+{
+    MdPlan pl;
+    pl.lds_w = sizeof(double) * ((size_t)12 * K + 6 * kMdMaxK + (size_t)max_depth * F_NSCAL);
+    pl.lds_q = sizeof(double) * ((size_t)2 * md_quad_blob(K) + 320 + (size_t)max_depth * Q_NSCAL);
+    pl.wave_ok = pl.lds_w <= 48 * 1024;
+    pl.quad_ok = K <= kMdQuadMaxK && pl.lds_q <= 48 * 1024;
+    return pl;
+}
+
+// doubles of frame stack obtg_min_dist has to provide: a stack per WORKER wave for the forms that run as workers on the queue
+// (either may be chosen at launch), a stack per pair only when neither fits and the one-lane form runs
+size_t min_dist_stack_doubles(const obtg_ctx* c, int K, int max_depth, int n_pairs)
+{
+    const MdPlan pl = md_plan(K, max_depth);
+    size_t need = 0;
+    if (pl.quad_ok) need = (size_t)min_dist_workers(c, n_pairs, pl.lds_q) * max_depth * md_quad_blob(K);
+    if (pl.wave_ok) {
+        const size_t w = (size_t)min_dist_workers(c, n_pairs, pl.lds_w) * max_depth * (6 * K + F_NSCAL);
+        if (w > need) need = w;
+    }
+    if (!pl.quad_ok && !pl.wave_ok) need = (size_t)n_pairs * max_depth * (6 * K + F_NSCAL);
+    return need;
+}
+
 int launch_min_dist(obtg_ctx* c, const double* d_curves, int K, const int* d_pa, const int* d_pb,
                     int n_pairs, double eps, int max_iter, int md_cap, int max_depth, int max_nodes,
                     double* d_stack, double* d_res, int* d_info, const int* d_order, int* d_queue)
@@ -3957,14 +3982,14 @@ int launch_min_dist(obtg_ctx* c, const double* d_curves, int K, const int* d_pa,
     MdParams p{ d_curves, d_pa, d_pb, n_pairs, K, max_iter, md_cap, max_depth, max_nodes, eps, d_stack, d_res, d_info,
                 d_order, d_queue };
     ScopedKernelTimer t(c, OBTG_K_MIN_DIST);
-    const size_t lds_w = sizeof(double) * ((size_t)12 * K + 6 * kMdMaxK + (size_t)max_depth * F_NSCAL);
-    const size_t lds_q = sizeof(double) * ((size_t)2 * md_quad_blob(K) + 320 + (size_t)max_depth * Q_NSCAL);
+    const MdPlan pl = md_plan(K, max_depth);
+    const size_t lds_w = pl.lds_w, lds_q = pl.lds_q;
     const char* env_form = getenv("OBTG_MD_FORM");          // "wave": a wavefront per gjkNew call (read per launch: the A/B test flips it)
-    const bool quad = K <= kMdQuadMaxK && lds_q <= 48 * 1024 && d_queue && !(env_form && !strcmp(env_form, "wave"));
+    const bool quad = pl.quad_ok && d_queue && !(env_form && !strcmp(env_form, "wave"));
     if (quad) {                            // a 16-lane row per child: four gjkNew calls of a node's children in lockstep
         OBTG_HIP(c, hipMemsetAsync(d_queue, 0, sizeof(int), c->stream));
         hipLaunchKernelGGL(k_min_dist_quad, dim3((unsigned)min_dist_workers(c, n_pairs, lds_q)), dim3(kWave), lds_q, c->stream, p);
-    } else if (lds_w <= 48 * 1024 && d_queue) {   // one pair per wavefront at a time, the waves as workers on a queue
+    } else if (pl.wave_ok && d_queue) {    // one pair per wavefront at a time, the waves as workers on a queue
         OBTG_HIP(c, hipMemsetAsync(d_queue, 0, sizeof(int), c->stream));
         hipLaunchKernelGGL(k_min_dist_wave, dim3((unsigned)min_dist_workers(c, n_pairs, lds_w)), dim3(kWave), lds_w, c->stream, p);
     } else

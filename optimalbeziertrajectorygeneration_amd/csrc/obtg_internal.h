@@ -260,7 +260,7 @@ int launch_gjk_true_pairs(obtg_ctx* c, const double* d_soa, const int* d_off, co
 int launch_min_dist2poly_robust(obtg_ctx* c, const double* d_curves, int K, const double* d_soa, const int* d_off,
                                 const int* d_pc, const int* d_pp, int n_pairs, double eps, int max_nodes, int max_level,
                                 int cap, int max_poly_K, double* d_frontier, double* d_res, int* d_info);
-size_t min_dist_stack_doubles(int K, int max_depth);
+size_t min_dist_stack_doubles(const obtg_ctx* c, int K, int max_depth, int n_pairs);   // whole launch
 size_t min_dist2poly_stack_doubles(int K, int max_depth);
 
 }  // namespace obtg

@@ -6,8 +6,8 @@ timeout -k 10 120 python -m pytest tests/test_gpu_parity.py -m gpu -x -q -k "tes
 tail -1 gpurun_out/z_first.log
 timeout -k 10 600 python -m pytest tests -m gpu -x -q -k "min_dist or minDist or mindist or 3d_sweep_as_one_launch" > gpurun_out/z_md.log 2>&1 || { tail -40 gpurun_out/z_md.log; exit 1; }
 tail -1 gpurun_out/z_md.log
-OBTG_LIB=optimalbeziertrajectorygeneration_amd/exp_mdtm.so timeout -k 10 120 python tools/mindist_quad_probe.py > gpurun_out/z_probe.log 2>&1 || { tail -20 gpurun_out/z_probe.log; exit 1; }
-cat gpurun_out/z_probe.log; OBTG_PROBE_SET=2 OBTG_LIB=optimalbeziertrajectorygeneration_amd/exp_mdtm2.so timeout -k 10 120 python tools/mindist_quad_probe.py 2>/dev/null
+true
+true
 timeout -k 10 300 python bench.py --mode mindist --steps 10 --warmup 3 > gpurun_out/z_bench_quad.log 2>&1 || { tail -20 gpurun_out/z_bench_quad.log; exit 1; }
 python3 -c "
 import json
