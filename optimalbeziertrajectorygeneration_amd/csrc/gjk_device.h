@@ -357,6 +357,22 @@ __device__ __forceinline__ bool matches_old(const Ctx<Mem>& g, const Simplex& o,
     return false;
 }
 
+// matches_old with ONE LDS round trip in the usual case: a vertex's "pts" clause needs A == its poly1 point, whose first test
+// is A.x == that point's x -- the four x are fetched together, and only if one of them is equal (A is a Minkowski difference:
+// hardly ever) the clause-by-clause form above decides.  Same truth value in every case.
+template <class Mem>
+__device__ __forceinline__ bool matches_old_batched(const Ctx<Mem>& g, const Simplex& o, const V3& A)
+{
+    const bool hA = o.keys & kA, hB = o.keys & kB, hC = o.keys & kC, hD = o.keys & kD, pD = o.keys & kDpts;
+    // (the indices of absent entries are stale or zero, always in range)
+    const double xa = g.mem(g.P1.base + o.A.i1), xb = g.mem(g.P1.base + o.B.i1), xc = g.mem(g.P1.base + o.C.i1),
+                 xd = g.mem(g.P1.base + o.D.i1);
+    const bool maybe = (hA & (A.x == xa)) | (hB & (A.x == xb)) | (hC & (A.x == xc)) | (pD & (A.x == xd));
+    if (maybe) return matches_old(g, o, A);
+    return (hA && eq(A, o.A.v)) || (hB && eq(A, o.B.v)) || (hC && eq(A, o.C.v)) || (hD && eq(A, o.D.v)) ||
+           ((o.keys & kColl) && A.x == 1.0 && A.y == 1.0 && A.z == 1.0);
+}
+
 // Brent cycle detector for minimumDistance's `while True` (gjk.py:277): the loop body is a function
 // of (live simplex entries, search direction) alone, so an exact return to a checkpointed state
 // proves that the reference never exits.  One checkpoint, refreshed after 1, 2, 4, ... rounds.
@@ -480,7 +496,7 @@ __device__ __forceinline__ void run_quarter(Ctx<Mem>& g, int max_iter, int md_ca
             else if (dotb(s.A.v, dir) < 0) { phase = 1; chk.start(s, dir); }
             else if (++it >= max_iter) live = false;
         } else {
-            if (matches_old(g, old, s.A.v)) { conv = true; live = false; }
+            if (matches_old_batched(g, old, s.A.v)) { conv = true; live = false; }
             else if (chk.step(s, dir)) { r.flag = 1; r.status = OBTG_ST_CYCLE; live = false; }
             else if (++rr >= md_cap) { r.flag = 1; r.status = OBTG_ST_MD_CAP; live = false; }
         }
