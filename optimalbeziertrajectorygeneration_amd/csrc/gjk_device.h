@@ -449,7 +449,7 @@ __device__ __forceinline__ void run(Ctx<Mem>& g, int max_iter, int md_cap, Resul
             for (int rr = 0; rr < md_cap; ++rr) {
                 old = s;
                 do_simplex<Mem, PLANAR, WAVE>(g, s, dir);
-                if (matches_old(g, old, s.A.v)) { conv = true; break; }
+                if (matches_old_batched(g, old, s.A.v)) { conv = true; break; }
                 if (chk.step(s, dir)) { cycle = true; break; }
             }
             r.flag = 1;

@@ -101,7 +101,7 @@ __device__ __forceinline__ void gjk_sweep(int c_end, int* s_next, int max_iter, 
                 else if (it >= max_iter) { r.flag = -1; r.status = OBTG_ST_MAXITER; done = true; }
             } else {
                 ++rr;
-                if (gjk::matches_old(g, old, s.A.v)) {
+                if (gjk::matches_old_batched(g, old, s.A.v)) {
                     gjk::closest_from_simplex(g, old, r);
                     r.flag = 1; done = true;
                 } else if (chk.step(s, dir)) { r.flag = 1; r.status = OBTG_ST_CYCLE; done = true; }
