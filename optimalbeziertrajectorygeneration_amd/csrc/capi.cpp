@@ -121,6 +121,7 @@ static std::vector<double> plain_product_weights(int n)
 int ensure_tables(obtg_ctx* c)
 {
     if (c->tables_R == c->R) return OBTG_OK;
+    (void)hipSetDevice(c->device);                 // (obtg_ctx_set_deg_elev comes here from whatever device the caller was on)
     const int n = c->deg, L = 2 * n + 1;
     if (c->tables_R < 0) {
         auto W2 = folded_product_weights(n, c->dim);
@@ -368,6 +369,7 @@ int obtg_ctx_set_second_speed_bound(obtg_ctx* c, double bound, int is_max, doubl
 int obtg_sync(obtg_ctx* c)
 {
     if (!check_ctx(c)) return OBTG_ERR_ARG;
+    (void)hipSetDevice(c->device);
     OBTG_HIP(c, hipStreamSynchronize(c->stream));
     flush_pending_events(c);
     return OBTG_OK;
