@@ -911,5 +911,16 @@ def scratch_context():
     (gjkNew on raw point sets, minDist, single-curve Bernstein algebra)."""
     global _scratch_ctx
     if _scratch_ctx is None:
-        _scratch_ctx = Context(1, 2, 1, 0)
+        _scratch_ctx = Context(1, 2, 1, 0, device=default_device())
     return _scratch_ctx
+
+
+def default_device():
+    """The GPU of this process when nothing names one: OBTG_DEVICE, else the launcher's LOCAL_RANK (one process per GPU),
+    wrapped to the devices present (a rehearsal of several ranks on one card), else 0."""
+    n = max(load().obtg_device_count(), 1)
+    for key in ("OBTG_DEVICE", "LOCAL_RANK"):
+        v = os.environ.get(key)
+        if v is not None and v.strip().lstrip("-").isdigit():
+            return int(v) % n
+    return 0

@@ -33,9 +33,12 @@ _CTX_CACHE_MAX = 8              # device contexts kept; the least recently used 
 _ctx_cache = collections.OrderedDict()
 
 
-def _shape_ctx(nVeh, dim, deg, R, device=0):
+def _shape_ctx(nVeh, dim, deg, R, device=None):
     """A device context per (shape, DEG_ELEV): least-recently-used eviction, so that a driver sweeping degElev or the
-    degree (Examples/Example1_DubinsCarTimeOptimal.py:19-52 takes degElev as an argument) does not pile up contexts."""
+    degree (Examples/Example1_DubinsCarTimeOptimal.py:19-52 takes degElev as an argument) does not pile up contexts.
+    device None: this process's GPU (_capi.default_device: OBTG_DEVICE, else the launcher's LOCAL_RANK, else 0)."""
+    if device is None:
+        device = _capi.default_device()
     key = (int(nVeh), int(dim), int(deg), int(R), int(device))
     c = _ctx_cache.get(key)
     if c is None:
@@ -141,11 +144,11 @@ class BezOptimization(object):
                  tf=1.0,
                  pointObstacles=None,
                  shapeObstacles=None,
-                 device=0,
+                 device=None,
                  separationRows='all',
                  angRateOrder='fast',
                  activeRows=2):
-        """Beyond the reference's keywords: `device` (HIP ordinal) and `separationRows` --
+        """Beyond the reference's keywords: `device` (HIP ordinal; None: this process's, see _capi.default_device) and `separationRows` --
         'all': temporalSeparationConstraints returns every elevated control point of every pair, as the
         reference does (optimization.py:337); 'min': one row per pair, the smallest of them -- the
         `dv.normSquare().min()` form the reference leaves commented at optimization.py:338 and uses in
@@ -167,7 +170,7 @@ class BezOptimization(object):
         self.angRateOrder = angRateOrder
         self.pointObstacles = pointObstacles
         self.shapeObstacles = shapeObstacles
-        self._device = device
+        self._device = _capi.default_device() if device is None else int(device)
         self.separationRows = separationRows
 
         given = locals()

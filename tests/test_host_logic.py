@@ -118,3 +118,19 @@ def test_example_drivers_constructor_forms(golden_dir):
     xg = tr.generateGuess()
     xg[-1] = 10
     assert np.array_equal(xg, g["tr_x"]) and np.array_equal(tr.reshapeVector(xg), g["tr_y"])
+
+
+def test_default_device_follows_the_launcher(monkeypatch):
+    """One process per GPU: when nothing names a device, the scratch context, the shape contexts and BezOptimization take
+    OBTG_DEVICE, else torchrun's LOCAL_RANK (wrapped to the devices present, so that several ranks can rehearse on one card)."""
+    from optimalbeziertrajectorygeneration_amd import _capi
+    n = max(_capi.device_count(), 1)
+    monkeypatch.delenv("OBTG_DEVICE", raising=False)
+    monkeypatch.delenv("LOCAL_RANK", raising=False)
+    assert _capi.default_device() == 0
+    monkeypatch.setenv("LOCAL_RANK", "5")
+    assert _capi.default_device() == 5 % n
+    monkeypatch.setenv("OBTG_DEVICE", "3")
+    assert _capi.default_device() == 3 % n
+    monkeypatch.setenv("OBTG_DEVICE", "not a number")
+    assert _capi.default_device() == 5 % n
