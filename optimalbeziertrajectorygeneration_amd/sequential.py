@@ -32,8 +32,11 @@ FD_STEP = 1.4901161193847656e-08   # SciPy '2-point' abs_step
 _ctx_cache = {}
 
 
-def _context(ndim, deg, deg_elev, device=0):
-    """One context per (dimension, degree, elevation): the number of trajectories is an argument of every call."""
+def _context(ndim, deg, deg_elev, device=None):
+    """One context per (dimension, degree, elevation): the number of trajectories is an argument of every call.
+    device None: this process's GPU (_capi.default_device)."""
+    if device is None:
+        device = _capi.default_device()
     key = (int(ndim), int(deg), int(deg_elev), int(device))
     c = _ctx_cache.get(key)
     if c is None:
