@@ -62,7 +62,7 @@ def _one_vs_many(one, many, ndim, maxSep, degElev):
     if ctx is None:
         if len(_generic_cache) > 4:
             _generic_cache.pop(next(iter(_generic_cache))).close()
-        ctx = _generic_cache[key] = _capi.Context(K + 1, int(ndim), nc - 1, int(degElev))
+        ctx = _generic_cache[key] = _capi.Context(K + 1, int(ndim), nc - 1, int(degElev), device=_capi.default_device())
     Y = np.empty((B, (K + 1) * ndim, nc))
     Y[:, :ndim] = one
     Y[:, ndim:] = many.reshape(K * ndim, nc)
