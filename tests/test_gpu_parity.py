@@ -847,9 +847,11 @@ def test_min_dist_quad_form_is_the_wave_form(capi, synth, monkeypatch):
     """obtg_min_dist, round 5: up to 16 control points a node's four children are evaluated together, a 16-lane row of the
     wavefront each, the four gjkNew state machines in lockstep (k_min_dist_quad); OBTG_MD_FORM=wave selects the form that
     spends the wavefront on one call at a time (k_min_dist_wave, which also serves 17..32 points).  The walk is the same
-    walk: results, node counts, call counts, depths and statuses identical -- on the C5-sized pair list, on 3-D curves of
-    degree 3..15, with a node budget that ends searches early, with a depth cap, and with a one-node budget."""
-    cases = [(96, 2, 10, 1234), (30, 3, 3, 2), (20, 3, 5, 3), (14, 3, 8, 4), (12, 2, 12, 5), (10, 3, 15, 6), (24, 2, 7, 7)]
+    walk: results, node counts, call counts, depths and statuses identical -- on the C5-sized pair list, on curves of
+    degree 1..15 in 2-D and 3-D, with a node budget that ends searches early, with a depth cap, and with a one-node budget."""
+    cases = [(96, 2, 10, 1234), (30, 3, 3, 2), (20, 3, 5, 3), (14, 3, 8, 4), (12, 2, 12, 5), (10, 3, 15, 6), (24, 2, 7, 7),
+             # control-point counts without an unrolled form (2, 3, 5, 7, 14, 15): the any-count splits and split parameters
+             (12, 3, 1, 8), (12, 2, 2, 9), (10, 3, 4, 10), (10, 2, 6, 11), (8, 3, 13, 12), (8, 2, 14, 13)]
     for (ncurves, dim, n, seed) in cases:
         Yc = synth.swarm_control_points(ncurves, dim, n, seed=seed)
         curves = np.zeros((ncurves, 3, n + 1))
