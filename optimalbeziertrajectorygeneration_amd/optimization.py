@@ -125,6 +125,65 @@ _MODEL_FIELDS = (
 )
 
 
+def _raise_first_md(status):
+    """The exception of the first pair, in list order, whose search did not end (bezier._raise_md): what the reference
+    would hit first in its pair loop (optimization.py:127-131)."""
+    bad = np.nonzero(np.asarray(status) != _capi.MD_OK)[0]
+    if bad.size:
+        bez._raise_md(int(status[bad[0]]))
+
+
+def _spatial_jac_plan(Y, numVeh, dim, obstacle_curves):
+    """The curve and pair lists of ONE `obtg_min_dist` call that yields the 2-point Jacobian of
+    spatialSeparationConstraints (optimization.py:109-133): the base evaluation's C(n, 2) pairs of the n = numVeh +
+    obstacles curves of row 0 of Y, then, for every finite-difference row k + 1, the pairs that contain a vehicle whose
+    control points differ from row 0's, with that vehicle's perturbed curve appended to the curve list.
+    Y: [n_x + 1][numVeh * dim][deg + 1]; obstacle_curves: padded [3][deg + 1] arrays.
+    Returns (stack [n_curves][3][deg + 1], pa, pb, P, col, row, pos): entry e of the call's extra pairs is base pair
+    row[e] re-evaluated for variable col[e] at position pos[e] of the pair list.  Pairs of a column come in base-pair
+    order, columns in order (array form of the loops it replaced: tests/test_host_logic.py holds it to them)."""
+    nx = Y.shape[0] - 1
+    K = Y.shape[2]
+    n = numVeh + len(obstacle_curves)
+    Yv = Y.reshape(nx + 1, numVeh, dim, K)
+    base = np.zeros((n, 3, K))
+    base[:numVeh, :dim, :] = Yv[0]
+    for o, c in enumerate(obstacle_curves):
+        base[numVeh + o] = c
+    pa0, pb0 = np.triu_indices(n, 1)                            # i < j, lexicographic: the reference's pair loop
+    P = pa0.size
+    changed = np.any(Yv[1:] != Yv[0], axis=(2, 3))              # [n_x][numVeh]
+    ck, cv = np.nonzero(changed)                                # (column, vehicle), columns ascending, vehicles ascending
+    extra = np.zeros((ck.size, 3, K))
+    extra[:, :dim, :] = Yv[ck + 1, cv]
+    new_id = np.full((nx, n), -1, dtype=np.int64)               # curve index of vehicle v's perturbed copy in column k
+    new_id[ck, cv] = n + np.arange(ck.size)
+    # per column, the base pairs touched: those with an end among the column's changed vehicles.  A column that moves ONE
+    # vehicle (all but a trailing tf) touches that vehicle's n - 1 pairs; the others go through a mask over the pair list.
+    nchg = changed.sum(axis=1)
+    pairs_of = np.empty((numVeh, n - 1), dtype=np.int64)        # base pairs containing vehicle v, ascending
+    for v in range(numVeh):
+        pairs_of[v] = np.nonzero((pa0 == v) | (pb0 == v))[0]
+    k1 = np.nonzero(nchg == 1)[0]
+    col = [np.repeat(k1, n - 1)]
+    row = [pairs_of[np.argmax(changed[k1], axis=1)].ravel()] if k1.size else [np.zeros(0, dtype=np.int64)]
+    for k in np.nonzero(nchg > 1)[0]:
+        m = np.zeros(n, dtype=bool)
+        m[:numVeh] = changed[k]
+        q = np.nonzero(m[pa0] | m[pb0])[0]
+        col.append(np.full(q.size, k))
+        row.append(q)
+    col, row = np.concatenate(col).astype(np.int64), np.concatenate(row)
+    order = np.lexsort((row, col))                              # column-major, base-pair order within a column
+    col, row = col[order], row[order]
+    ia, ib = pa0[row], pb0[row]
+    na, nb = new_id[col, ia], new_id[col, ib]
+    pa = np.concatenate((pa0, np.where(na >= 0, na, ia))).astype(np.int32)
+    pb = np.concatenate((pb0, np.where(nb >= 0, nb, ib))).astype(np.int32)
+    pos = P + np.arange(col.size)
+    return np.concatenate((base, extra)), pa, pb, P, col, row, pos
+
+
 class BezOptimization(object):
     def __init__(self,
                  numVeh=1,
@@ -341,8 +400,7 @@ class BezOptimization(object):
         if robust:
             return _capi.scratch_context().min_dist_robust(stack, pa, pb, eps=1e-9, max_nodes=400000)['res'] - maxSep
         r = _capi.scratch_context().min_dist(stack, pa, pb, eps=1e-9, max_depth=128, max_nodes=4000000)
-        for st in r['status']:
-            bez._raise_md(st)
+        _raise_first_md(r['status'])
         return r['res'] - maxSep
 
     def spatialSeparationJacobian(self, x, robust=False, column=None, on_cap='raise'):
@@ -362,32 +420,7 @@ class BezOptimization(object):
         Y = self.reshapeVectors(X)                                  # [n_x + 1][numVeh*dim][deg+1]
         nx = X.shape[1]
         obstacles = list(self.shapeObstacles) if self.shapeObstacles is not None else []
-        n = numVeh + len(obstacles)
-        base = [bez.Bezier(Y[0, i * dim:(i + 1) * dim, :])._padded() for i in range(numVeh)] + [c._padded() for c in obstacles]
-        curves = list(base)
-        pa, pb = [], []
-        for i in range(n):
-            for j in range(i + 1, n):
-                pa.append(i)
-                pb.append(j)
-        P = len(pa)
-        pair_index = {(pa[q], pb[q]): q for q in range(P)}
-        touched = []                                               # per variable: (row of the base list, position in the call)
-        Yv = Y.reshape(nx + 1, numVeh, dim, -1)
-        changed = np.any(Yv[1:] != Yv[0], axis=(2, 3))             # [n_x][numVeh]
-        for k in range(nx):
-            mine = {}
-            for v in np.nonzero(changed[k])[0]:
-                mine[int(v)] = len(curves)
-                curves.append(bez.Bezier(Y[k + 1, v * dim:(v + 1) * dim, :])._padded())
-            rows = []
-            for (i, j), q in pair_index.items():
-                if i in mine or j in mine:
-                    rows.append((q, len(pa)))
-                    pa.append(mine.get(i, i))
-                    pb.append(mine.get(j, j))
-            touched.append(rows)
-        stack = np.stack(curves)
+        stack, pa, pb, P, t_col, t_row, t_pos = _spatial_jac_plan(Y, numVeh, dim, [c._padded() for c in obstacles])
         if robust:
             res = _capi.scratch_context().min_dist_robust(stack, pa, pb, eps=1e-9, max_nodes=400000)['res']
         else:
@@ -396,13 +429,10 @@ class BezOptimization(object):
             if on_cap == 'nan':
                 res = np.where((r['status'] != 0)[:, None], np.nan, res)
             else:
-                for st in r['status']:
-                    bez._raise_md(st)
+                _raise_first_md(r['status'])
         F0 = res[:P] - maxSep
         J = np.zeros((P, 3, nx))
-        for k in range(nx):
-            for q, pos in touched[k]:
-                J[q, :, k] = ((res[pos] - maxSep) - F0[q]) / dx[k]
+        J[t_row, :, t_col] = ((res[t_pos] - maxSep) - F0[t_row]) / dx[t_col][:, None]
         if column is not None:
             return J[:, column, :]
         return J.reshape(3 * P, nx)

@@ -134,3 +134,53 @@ def test_default_device_follows_the_launcher(monkeypatch):
     assert _capi.default_device() == 3 % n
     monkeypatch.setenv("OBTG_DEVICE", "not a number")
     assert _capi.default_device() == 5 % n
+
+
+def test_spatial_jacobian_call_plan_is_the_loop_form():
+    """BezOptimization.spatialSeparationJacobian's one-call plan (optimization._spatial_jac_plan, array form) against the
+    loops it replaced: same curve list, same pair list, same (variable, base pair, position) triples -- for rows that move one
+    vehicle each, a row that moves all of them (a trailing tf) and a row that moves none."""
+    from optimalbeziertrajectorygeneration_amd.optimization import _spatial_jac_plan
+    rng = np.random.default_rng(5)
+    for (numVeh, dim, K, nobs) in ((5, 2, 6, 3), (4, 3, 4, 0), (1, 2, 11, 2), (7, 2, 9, 1)):
+        nvar = numVeh * dim * K
+        Y0 = rng.normal(size=(numVeh * dim, K))
+        rows = [Y0]
+        for k in range(nvar):                        # one coefficient of one vehicle each
+            Yk = Y0.copy(); Yk.reshape(-1)[k] += 1e-8
+            rows.append(Yk)
+        rows.append(Y0 + 1e-8)                       # every vehicle moves
+        rows.append(Y0.copy())                       # nothing moves
+        two = Y0.copy(); two[0, 0] += 1e-8; two[-1, -1] += 1e-8
+        rows.append(two)                             # the first and the last vehicle (the same one when numVeh == 1)
+        Y = np.stack(rows)
+        obs = [np.vstack((rng.normal(size=(dim, K)), np.zeros((3 - dim, K)))) for _ in range(nobs)]
+        stack, pa, pb, P, col, row, pos = _spatial_jac_plan(Y, numVeh, dim, obs)
+        # the loop form
+        def pad(c):
+            out = np.zeros((3, K)); out[:dim] = c
+            return out
+        n = numVeh + nobs
+        curves = [pad(Y[0, i * dim:(i + 1) * dim]) for i in range(numVeh)] + obs
+        lpa, lpb = [], []
+        for i in range(n):
+            for j in range(i + 1, n):
+                lpa.append(i); lpb.append(j)
+        LP = len(lpa)
+        pair_index = {(lpa[q], lpb[q]): q for q in range(LP)}
+        trip = []
+        Yv = Y.reshape(Y.shape[0], numVeh, dim, K)
+        changed = np.any(Yv[1:] != Yv[0], axis=(2, 3))
+        for k in range(Y.shape[0] - 1):
+            mine = {}
+            for v in np.nonzero(changed[k])[0]:
+                mine[int(v)] = len(curves)
+                curves.append(pad(Y[k + 1, v * dim:(v + 1) * dim]))
+            for (i, j), q in pair_index.items():
+                if i in mine or j in mine:
+                    trip.append((k, q, len(lpa)))
+                    lpa.append(mine.get(i, i)); lpb.append(mine.get(j, j))
+        assert P == LP
+        assert np.array_equal(stack, np.stack(curves))
+        assert np.array_equal(pa, lpa) and np.array_equal(pb, lpb)
+        assert [tuple(t) for t in zip(col.tolist(), row.tolist(), pos.tolist())] == trip
