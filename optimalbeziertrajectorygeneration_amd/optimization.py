@@ -392,11 +392,7 @@ class BezOptimization(object):
         curves = [bez.Bezier(y[i * dim:(i + 1) * dim, :]) for i in range(numVeh)] + list(self.shapeObstacles)
         n = len(curves)
         stack = np.stack([c._padded() for c in curves])
-        pa, pb = [], []
-        for i in range(n):
-            for j in range(i + 1, n):
-                pa.append(i)
-                pb.append(j)
+        pa, pb = np.triu_indices(n, 1)                              # i < j, lexicographic: the reference's pair loop
         if robust:
             return _capi.scratch_context().min_dist_robust(stack, pa, pb, eps=1e-9, max_nodes=400000)['res'] - maxSep
         r = _capi.scratch_context().min_dist(stack, pa, pb, eps=1e-9, max_depth=128, max_nodes=4000000)
