@@ -2079,6 +2079,9 @@ enum { R_CAP = 0, R_LB, R_T1, R_T2, R_UB, R_AM, R_NREC };
 enum { Q_NSCAL = F_NSCAL };               // frame scalars: k_min_dist_wave's (F_STATE: the next child, 0..4)
 __host__ __device__ constexpr int md_quad_blob(int K) { return 12 * K + 4 * R_NREC; }
 constexpr int kMdQuadMaxK = 16;
+// doubles of split-parameter scratch per 16-lane row: 2 x 16 used; 34 (not 32 = 64 banks) so that the four rows' broadcast
+// reads of the same element fall into four banks (PMC: a quarter of the LDS cycles were conflicts with 32)
+constexpr int kMdShRow = 34;
 
 // deCasteljauSplit of rows [row0, row0 + nrows) of a node's six coordinate rows (rows 0..2: curve 1 at t1, rows 3..5:
 // curve 2 at t2), BOTH pieces kept: as split_rows3_wave_t, where the left piece's point L is lane (r, 0)'s value at level L
@@ -2354,9 +2357,9 @@ __global__ __launch_bounds__(64, OBTG_MD_MIN_WAVES) void k_min_dist_quad(const M
     const int lane = threadIdx.x, q = lane >> 4;
     const int K = p.K, BL = md_quad_blob(K);
     double* st = p.stack + (size_t)blockIdx.x * p.max_depth * BL;
-    double* sh_e = md_lds + 2 * BL;             // [4][2][16]
-    double* sh_q = sh_e + 128;                  // [4][2][16]
-    double* dump = sh_q + 128;                  // [64]
+    double* sh_e = md_lds + 2 * BL;             // [4][kMdShRow]: [2][16] per row of the wavefront, the rows' banks apart
+    double* sh_q = sh_e + 4 * kMdShRow;         // the same
+    double* dump = sh_q + 4 * kMdShRow;         // [64]
     double* scs = dump + 64;                    // [max_depth][Q_NSCAL] frame scalars
   for (;;) {
     const int ticket = atomicAdd(p.queue, lane == 0 ? 1 : 0);      // (see k_min_dist_wave)
@@ -2392,10 +2395,10 @@ __global__ __launch_bounds__(64, OBTG_MD_MIN_WAVES) void k_min_dist_quad(const M
 #ifdef OBTG_MD_TIMING
         unsigned long long tq = __builtin_readcyclecounter();
         md_eval_rows(md_lds, (int)(nxt - md_lds) + (q >> 1) * 3 * K, (int)(nxt - md_lds) + (2 + (q & 1)) * 3 * K, K, p.eps,
-                     p.max_iter, p.md_cap, nxt + 12 * K + q * R_NREC, sh_e + q * 32, sh_q + q * 32, tm_ev);
+                     p.max_iter, p.md_cap, nxt + 12 * K + q * R_NREC, sh_e + q * kMdShRow, sh_q + q * kMdShRow, tm_ev);
 #else
         md_eval_rows(md_lds, (int)(nxt - md_lds) + (q >> 1) * 3 * K, (int)(nxt - md_lds) + (2 + (q & 1)) * 3 * K, K, p.eps,
-                     p.max_iter, p.md_cap, nxt + 12 * K + q * R_NREC, sh_e + q * 32, sh_q + q * 32);
+                     p.max_iter, p.md_cap, nxt + 12 * K + q * R_NREC, sh_e + q * kMdShRow, sh_q + q * kMdShRow);
 #endif
         wave_sync();
 #ifdef OBTG_MD_TIMING
@@ -3952,7 +3955,7 @@ static MdPlan md_plan(int K, int max_depth)
 {
     MdPlan pl;
     pl.lds_w = sizeof(double) * ((size_t)12 * K + 6 * kMdMaxK + (size_t)max_depth * F_NSCAL);
-    pl.lds_q = sizeof(double) * ((size_t)2 * md_quad_blob(K) + 320 + (size_t)max_depth * Q_NSCAL);
+    pl.lds_q = sizeof(double) * ((size_t)2 * md_quad_blob(K) + 8 * kMdShRow + 64 + (size_t)max_depth * Q_NSCAL);
     pl.wave_ok = pl.lds_w <= 48 * 1024;
     pl.quad_ok = K <= kMdQuadMaxK && pl.lds_q <= 48 * 1024;
     return pl;
