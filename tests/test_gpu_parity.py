@@ -859,7 +859,11 @@ def test_min_dist_quad_form_is_the_wave_form(capi, synth, monkeypatch):
         pa, pb = synth.all_pairs(ncurves)
         ctx = capi.scratch_context()
         for kw in (dict(max_depth=64, max_nodes=2000), dict(max_depth=7, max_nodes=2000), dict(max_depth=64, max_nodes=1),
-                   dict(max_depth=64, max_nodes=37), dict(max_depth=1, max_nodes=50)):
+                   dict(max_depth=64, max_nodes=37), dict(max_depth=1, max_nodes=50),
+                   # gjkNew's own limits (sign search cut after one / three doSimplex steps, minimumDistance after one / two
+                   # rounds: the GJK_CAP and MAXITER exits of every row) and a coarse eps
+                   dict(max_depth=32, max_nodes=300, max_iter=1), dict(max_depth=32, max_nodes=300, max_iter=3, md_cap=1),
+                   dict(max_depth=32, max_nodes=300, md_cap=2), dict(max_depth=32, max_nodes=500, eps=1e-3)):
             quad = ctx.min_dist(curves, pa, pb, **kw)
             monkeypatch.setenv("OBTG_MD_FORM", "wave")
             wave = ctx.min_dist(curves, pa, pb, **kw)
