@@ -26,7 +26,7 @@ UNITS = [
 ]
 COMMON = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=" + ARCH, "-fno-fast-math",
           "-Wall", "-Wno-unused-function", "-fvisibility=hidden", "-fgpu-rdc" if False else "-fno-gpu-rdc"]
-HEADERS = ["obtg_internal.h", "gjk_device.h", "gjk_true.h", "bern_device.h", os.path.join("..", "..", "include", "obtg.h")]
+HEADERS = ["obtg_internal.h", "gjk_device.h", "gjk_true.h", "bern_device.h", "libm_pow2.h", "libm_pow2_tables.h", os.path.join("..", "..", "include", "obtg.h")]
 
 
 def _hipcc():

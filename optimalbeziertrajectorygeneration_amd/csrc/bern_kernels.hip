@@ -1234,7 +1234,7 @@ int launch_temporal_sep(obtg_ctx* c, const double* dY, int B, double max_sep, in
     rc = plan_temporal_sep(c, dY, B, pair_begin, pair_count, d_out, p);
     if (rc != OBTG_OK && rc != OBTG_ERR_UNSUPPORTED) return rc;
     if (rc == OBTG_OK) {
-        p.sign = 1.0; p.offset = 0.0 - max_sep * max_sep;
+        p.sign = 1.0; p.offset = 0.0 - square_as_python(max_sep);
         p.sel_k = sel_k; p.sel_idx = d_sel_idx;
         if (c->fd.Y0) { p.Y = c->fd.Y0; p.fd = 1 + c->fd.row0; p.fd_fixed = c->fd.fixed; p.fd_h = c->fd.h; }
         rc = min_only ? dispatch_ns<0, true>(c, p, B, OBTG_K_TEMPORAL_SEP)
@@ -1259,7 +1259,7 @@ int launch_temporal_sep(obtg_ctx* c, const double* dY, int B, double max_sep, in
     if (rc) return rc;
     if (2 * c->deg + c->R + 1 > kMaxGenericLen) return OBTG_ERR_UNSUPPORTED;
     g.Y = dY; g.out = d_out; g.item_begin = pair_begin; g.item_count = pair_count; g.B = B;
-    g.sign = 1.0; g.offset = 0.0 - max_sep * max_sep; g.min_only = min_only ? 1 : 0;
+    g.sign = 1.0; g.offset = 0.0 - square_as_python(max_sep); g.min_only = min_only ? 1 : 0;
     const int nc = c->deg + 1;
     size_t lds = sizeof(double) * ((size_t)2 * c->dim * nc + 2 * c->deg + 1);
     ScopedKernelTimer t(c, OBTG_K_TEMPORAL_SEP);
@@ -1275,7 +1275,7 @@ int launch_speed(obtg_ctx* c, const double* dY, const double* d_tf, int B, doubl
     if (B <= 0) return OBTG_OK;
     int rc = ensure_tables(c);
     if (rc) return rc;
-    const double b2 = bound * bound;
+    const double b2 = square_as_python(bound);
     if (fast_shape(c)) {
         NsParams p{};
         p.Y = dY; p.obs = nullptr; p.tf = d_tf; p.pairs = nullptr;
@@ -1415,7 +1415,7 @@ bool bernstein_fd_on_the_fly(const obtg_ctx* c) { return fast_shape(c); }
 static void second_speed_rows(const obtg_ctx* c, AngParams& p)
 {
     if (!c->speed2.d_out || !p.out_speed) return;
-    const double b2 = c->speed2.bound * c->speed2.bound;
+    const double b2 = square_as_python(c->speed2.bound);
     p.out_speed2 = c->speed2.d_out;
     p.sp2_sign = c->speed2.is_max ? -1.0 : 1.0; p.sp2_offset = c->speed2.is_max ? b2 : -b2;
 }
@@ -1433,7 +1433,7 @@ int launch_temporal_sep_fd(obtg_ctx* c, const double* dY0, int n_pert, const int
     p.prow = d_prow; p.pcol = d_pcol; p.pval = d_pval; p.out = d_out;
     p.min_only = min_only; p.fd_row0 = fd_row0; p.fd_fixed = fd_fixed; p.fd_h = fd_h;
     p.n_veh = c->n_veh; p.n_obj = c->n_obj; p.R = c->R; p.n_pert = n_pert;
-    p.sign = 1.0; p.offset = 0.0 - max_sep * max_sep;
+    p.sign = 1.0; p.offset = 0.0 - square_as_python(max_sep);
     const long items = (long)n_pert * (c->n_obj - 1);
     const dim3 grid((unsigned)((items + kWave - 1) / kWave));
     const int nc = c->deg + 1;
@@ -1459,7 +1459,7 @@ int launch_one_vs_many_min(obtg_ctx* c, const double* d_one, int B, const double
     OneManyParams p{};
     p.one = d_one; p.many = d_many; p.W2 = c->d_w2.as<double>(); p.Td = c->d_Td.as<double>(); p.out = d_out;
     p.B = B; p.K = K; p.R = c->R;
-    p.sign = 1.0; p.offset = 0.0 - max_sep * max_sep;
+    p.sign = 1.0; p.offset = 0.0 - square_as_python(max_sep);
     const long items = (long)B * K;
     const int nc = c->deg + 1;
     void (*kern)(const OneManyParams) = nullptr;
@@ -1526,12 +1526,12 @@ int launch_sep_dynamics_elev(obtg_ctx* c, const double* dY, int B, double max_se
     rc = plan_temporal_sep(c, dY, B, 0, c->n_pairs, d_out_sep, sp.ts);
     if (rc) return rc;
     if (sp.ts.waves != 4) return OBTG_ERR_UNSUPPORTED;                 // (fewer than four 64-pair groups per row)
-    sp.ts.sign = 1.0; sp.ts.offset = 0.0 - max_sep * max_sep;
+    sp.ts.sign = 1.0; sp.ts.offset = 0.0 - square_as_python(max_sep);
     AngParams& p = sp.dyn.a;
     p.Y = dY; p.tf = f.d_tf; p.out = f.d_out_ang; p.out_speed = f.d_out_speed;
     p.n_veh = c->n_veh; p.total = B * c->n_veh;
-    p.w2 = f.max_rate * f.max_rate;
-    const double b2 = f.speed_bound * f.speed_bound;
+    p.w2 = square_as_python(f.max_rate);
+    const double b2 = square_as_python(f.speed_bound);
     p.sp_sign = f.speed_is_max ? -1.0 : 1.0; p.sp_offset = f.speed_is_max ? b2 : -b2;
     p.W2n = c->d_ang_w2n.as<double>(); p.W22n = c->d_ang_w22n.as<double>(); p.Wn = c->d_ang_wn.as<double>();
     second_speed_rows(c, p);
@@ -1559,8 +1559,8 @@ int launch_dynamics(obtg_ctx* c, const double* dY, const double* d_tf, int B, do
         AngParams p{};
         p.Y = dY; p.tf = d_tf; p.out = d_out_ang; p.out_speed = d_out_speed;
         p.n_veh = c->n_veh; p.total = B * c->n_veh;
-        p.w2 = max_rate * max_rate;
-        const double b2 = bound * bound;
+        p.w2 = square_as_python(max_rate);
+        const double b2 = square_as_python(bound);
         p.sp_sign = is_max ? -1.0 : 1.0; p.sp_offset = is_max ? b2 : -b2;
         p.W2n = c->d_ang_w2n.as<double>();
         p.W22n = c->d_ang_w22n.as<double>();
@@ -1579,8 +1579,8 @@ int launch_dynamics(obtg_ctx* c, const double* dY, const double* d_tf, int B, do
         AngParams& p = q.a;
         p.Y = dY; p.tf = d_tf; p.out = d_out_ang; p.out_speed = d_out_speed;
         p.n_veh = c->n_veh; p.total = B * c->n_veh;
-        p.w2 = max_rate * max_rate;
-        const double b2 = bound * bound;
+        p.w2 = square_as_python(max_rate);
+        const double b2 = square_as_python(bound);
         p.sp_sign = is_max ? -1.0 : 1.0; p.sp_offset = is_max ? b2 : -b2;
         p.W2n = c->d_ang_w2n.as<double>();
         p.W22n = c->d_ang_w22n.as<double>();
@@ -1615,7 +1615,7 @@ int launch_ang_rate(obtg_ctx* c, const double* dY, const double* d_tf, int B, do
     if (rc) return rc;
     const int m = c->deg + c->R, mc = m + 1, L2 = 2 * m + 1;
     if (m > 250) return OBTG_ERR_UNSUPPORTED;   // C(4m,2m) must stay finite in binary64
-    g.Y = dY; g.tf = d_tf; g.out = d_out; g.B = B; g.offset = max_rate * max_rate;
+    g.Y = dY; g.tf = d_tf; g.out = d_out; g.B = B; g.offset = square_as_python(max_rate);
     const int mc8 = (mc + 7) & ~7, L28 = (L2 + 7) & ~7;
     const bool bal = angrate_balanced(m), bal2 = angrate_balanced2(m);
     const int padf = bal ? 8 : L28, padm = bal2 ? 8 : mc8;

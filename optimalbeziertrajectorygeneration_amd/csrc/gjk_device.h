@@ -15,6 +15,11 @@
 
 #include "../../include/obtg.h"
 
+// `a**2` of gjk.py:460 as the reference's libm forms it (see libm_pow2.h)
+#define OBTG_P2_TABLE static __device__ const
+#define OBTG_P2_FUNC __device__ __forceinline__
+#include "libm_pow2.h"
+
 namespace obtg {
 namespace gjk {
 
@@ -519,13 +524,13 @@ __device__ __forceinline__ void closest_from_simplex(const Ctx<Mem>& g, const Si
         } else if (dotb(cross(AB, ABC), A0) >= 0) {
             seg_result(g, s.A, s.B, r);
         } else {
-            // gjk.py:440-477 weightedOriginToPlane (a**2 taken as a*a: the reference's
-            // libm pow(a, 2.0) can differ from it by one ulp of the denominator)
+            // gjk.py:440-477 weightedOriginToPlane; `a**2` (gjk.py:460) is libm's pow(a, 2.0), one ulp away from a * a now and
+            // then: restated in libm_pow2.h, so that closest points and distance are the reference's to the bit
             const V3 N = cross(sub(s.B.v, s.A.v), sub(s.C.v, s.A.v));
             const double nn = normb(N);
             const V3 n{ N.x / nn, N.y / nn, N.z / nn };
             const double tq = (n.x * s.A.v.x + n.y * s.A.v.y + n.z * s.A.v.z) /
-                              (n.x * n.x + n.y * n.y + n.z * n.z);
+                              (obtg_square_as_libm_pow(n.x) + obtg_square_as_libm_pow(n.y) + obtg_square_as_libm_pow(n.z));
             const V3 cp{ tq * n.x, tq * n.y, tq * n.z };
             r.dist = __builtin_sqrt(dot3(cp, cp));
             const V3 PA = sub(s.A.v, cp), PB = sub(s.B.v, cp), PC = sub(s.C.v, cp);

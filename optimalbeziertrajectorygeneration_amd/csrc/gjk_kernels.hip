@@ -3475,7 +3475,7 @@ int launch_gjk_swarm(obtg_ctx* c, const double* dY, int B, int max_iter, int md_
                 const int groups_t = (c->n_pairs + kWave - 1) / kWave;
                 ts.groups_per_wg = (groups_t + W - 1) / W; ts.wgs_per_row = W; ts.waves = 4;
                 ts.stage_all = 1; ts.stage_slots = c->n_obj; ts.tile_rows = tr; ts.tiling = 0; ts.tiles = nullptr;
-                ts.sign = 1.0; ts.offset = -(fold->max_sep * fold->max_sep);
+                ts.sign = 1.0; ts.offset = -square_as_python(fold->max_sep);
                 ts.fd = p.fd; ts.fd_fixed = p.fd_fixed; ts.fd_h = p.fd_h;
                 size_t ns_bytes = sizeof(double) * ((size_t)ts.stage_slots * vp3 + (size_t)4 * tr * tpf);
                 if (fold->d_out_speed && fold->d_tf && !c->speed2.d_out) {      // (a second speed bound: the dynamics launch writes both)
@@ -3485,7 +3485,7 @@ int launch_gjk_swarm(obtg_ctx* c, const double* dY, int B, int max_iter, int md_
                     const int groups_s = (c->n_veh + kWave - 1) / kWave;
                     sp.groups_per_wg = (groups_s + W - 1) / W;
                     sp.stage_all = 0; sp.stage_slots = std::min(c->n_veh, kWave * sp.groups_per_wg);
-                    const double b2 = fold->speed_bound * fold->speed_bound;
+                    const double b2 = square_as_python(fold->speed_bound);
                     sp.sign = fold->speed_is_max ? -1.0 : 1.0; sp.offset = fold->speed_is_max ? b2 : -b2;
                     ns_bytes = std::max(ns_bytes, sizeof(double) * ((size_t)sp.stage_slots * vp3 + (size_t)4 * tr * tpf));
                 }
@@ -3589,7 +3589,7 @@ int launch_pair_sweep(obtg_ctx* c, const double* dY, int B, double max_sep, doub
         const int tr = pair_sweep_tile_rows(c, nc, lds);      // the transposition tile borrows the LDS behind the objects
         fused = tr > 0 && lds <= 48 * 1024;
         p.ts.pairs = c->d_pairs.as<int2>(); p.ts.W2 = c->d_w2.as<double>(); p.ts.out = d_out_sep;
-        p.ts.n_pairs = c->n_pairs; p.ts.sign = 1.0; p.ts.offset = 0.0 - max_sep * max_sep;
+        p.ts.n_pairs = c->n_pairs; p.ts.sign = 1.0; p.ts.offset = 0.0 - square_as_python(max_sep);
         p.ts_tile_rows = tr;
         if (c->n_obs > 0) {            // point obstacles: constant curves behind the hull objects, for the separation rows only
             p.obs = c->d_obs.as<double>(); p.n_obs = c->n_obs;
@@ -3642,11 +3642,11 @@ int launch_pair_sweep(obtg_ctx* c, const double* dY, int B, double max_sep, doub
                         AngParams& d = q.dyn;
                         d.Y = q.Y; d.tf = speed->d_tf; d.out = speed->d_out_ang; d.out_speed = speed->d_out_speed;
                         d.n_veh = c->n_veh; d.total = B * c->n_veh;
-                        d.w2 = speed->max_rate * speed->max_rate;
-                        const double b2 = speed->speed_bound * speed->speed_bound;
+                        d.w2 = square_as_python(speed->max_rate);
+                        const double b2 = square_as_python(speed->speed_bound);
                         d.sp_sign = speed->speed_is_max ? -1.0 : 1.0; d.sp_offset = speed->speed_is_max ? b2 : -b2;
                         if (c->speed2.d_out) {
-                            const double c2 = c->speed2.bound * c->speed2.bound;
+                            const double c2 = square_as_python(c->speed2.bound);
                             d.out_speed2 = c->speed2.d_out;
                             d.sp2_sign = c->speed2.is_max ? -1.0 : 1.0; d.sp2_offset = c->speed2.is_max ? c2 : -c2;
                         }
@@ -3704,11 +3704,11 @@ int launch_pair_sweep(obtg_ctx* c, const double* dY, int B, double max_sep, doub
             AngParams& d = p.dyn;
             d.Y = p.Y; d.tf = speed->d_tf; d.out = speed->d_out_ang; d.out_speed = speed->d_out_speed;
             d.n_veh = c->n_veh; d.total = B * c->n_veh;
-            d.w2 = speed->max_rate * speed->max_rate;
-            const double b2 = speed->speed_bound * speed->speed_bound;
+            d.w2 = square_as_python(speed->max_rate);
+            const double b2 = square_as_python(speed->speed_bound);
             d.sp_sign = speed->speed_is_max ? -1.0 : 1.0; d.sp_offset = speed->speed_is_max ? b2 : -b2;
             if (c->speed2.d_out) {
-                const double c2 = c->speed2.bound * c->speed2.bound;
+                const double c2 = square_as_python(c->speed2.bound);
                 d.out_speed2 = c->speed2.d_out;
                 d.sp2_sign = c->speed2.is_max ? -1.0 : 1.0; d.sp2_offset = c->speed2.is_max ? c2 : -c2;
             }
@@ -3785,7 +3785,7 @@ int launch_step_fd_structured(obtg_ctx* c, int B, double max_sep, double* d_out_
     p.flag = d_flag; p.p1 = d_p1; p.p2 = d_p2; p.dist = d_dist; p.nsup = d_nsup; p.status = d_status;
     p.B = B; p.chunk = 256; p.wgs_per_row = 1; p.passes = 1;
     p.ts.pairs = c->d_pairs.as<int2>(); p.ts.W2 = c->d_w2.as<double>(); p.ts.out = d_out_sep;
-    p.ts.n_pairs = c->n_pairs; p.ts.sign = 1.0; p.ts.offset = 0.0 - max_sep * max_sep;
+    p.ts.n_pairs = c->n_pairs; p.ts.sign = 1.0; p.ts.offset = 0.0 - square_as_python(max_sep);
     p.ts.Td = c->d_Td.as<double>(); p.ts.Tf = c->d_Tf.as<double>(); p.ts.R = c->R;
     if (c->n_obs > 0) {                // point obstacles (optimization.py:86-98): objects of the separation pair table only
         p.obs = c->d_obs.as<double>(); p.n_obs = c->n_obs;
@@ -3796,11 +3796,11 @@ int launch_step_fd_structured(obtg_ctx* c, int B, double max_sep, double* d_out_
         AngParams& d = p.dyn;
         d.Y = p.Y; d.tf = speed->d_tf; d.out = speed->d_out_ang; d.out_speed = speed->d_out_speed;
         d.n_veh = c->n_veh; d.total = B * c->n_veh;
-        d.w2 = speed->max_rate * speed->max_rate;
-        const double b2 = speed->speed_bound * speed->speed_bound;
+        d.w2 = square_as_python(speed->max_rate);
+        const double b2 = square_as_python(speed->speed_bound);
         d.sp_sign = speed->speed_is_max ? -1.0 : 1.0; d.sp_offset = speed->speed_is_max ? b2 : -b2;
         if (c->speed2.d_out) {
-            const double c2 = c->speed2.bound * c->speed2.bound;
+            const double c2 = square_as_python(c->speed2.bound);
             d.out_speed2 = c->speed2.d_out;
             d.sp2_sign = c->speed2.is_max ? -1.0 : 1.0; d.sp2_offset = c->speed2.is_max ? c2 : -c2;
         }

@@ -260,6 +260,9 @@ int launch_gjk_true_pairs(obtg_ctx* c, const double* d_soa, const int* d_off, co
 int launch_min_dist2poly_robust(obtg_ctx* c, const double* d_curves, int K, const double* d_soa, const int* d_off,
                                 const int* d_pc, const int* d_pp, int n_pairs, double eps, int max_nodes, int max_level,
                                 int cap, int max_poly_K, double* d_frontier, double* d_res, int* d_info);
+// x**2 as Python forms it for the constraint offsets (optimization.py:343, 384, 422, 459: maxSep**2, minSpeed**2, maxSpeed**2,
+// maxAngRate**2 on Python floats): the host libm's pow(x, 2.0), which is not always x * x (tables.cpp)
+double square_as_python(double x);
 size_t min_dist_stack_doubles(const obtg_ctx* c, int K, int max_depth, int n_pairs);   // whole launch
 size_t min_dist2poly_stack_doubles(int K, int max_depth);
 

@@ -164,3 +164,13 @@ std::vector<double> elev_conv_padded(int L_in, int R, int extra, bool normalise,
 }
 
 }  // namespace obtg
+
+// pow through a volatile pointer: clang folds a literal pow(x, 2.0) into x * x, and the two are one ulp apart on 0.09 % of inputs
+// with glibc 2.35 (libm_pow2.h)
+namespace obtg {
+double square_as_python(double x)
+{
+    static double (*volatile libm_pow)(double, double) = std::pow;
+    return libm_pow(x, 2.0);
+}
+}  // namespace obtg

@@ -22,8 +22,9 @@ MD_OK, MD_NODE_CAP, MD_DEPTH_CAP, MD_GJK_CAP = 0, 1, 2, 3
 
 
 def build(force=False):
-    src = os.path.join(HERE, "obtg_oracle.c")
-    if force or not os.path.exists(LIB_PATH) or os.path.getmtime(LIB_PATH) < os.path.getmtime(src):
+    csrc = os.path.join(HERE, "..", "optimalbeziertrajectorygeneration_amd", "csrc")
+    srcs = [os.path.join(HERE, "obtg_oracle.c"), os.path.join(csrc, "libm_pow2.h"), os.path.join(csrc, "libm_pow2_tables.h")]
+    if force or not os.path.exists(LIB_PATH) or os.path.getmtime(LIB_PATH) < max(os.path.getmtime(f) for f in srcs):
         subprocess.check_call(["make", "-C", HERE, "-s", "-B", "libobtg_oracle.so"])
     return LIB_PATH
 
@@ -242,3 +243,17 @@ def min_dist2poly(c1, poly, eps=1e-6, max_iter=128, md_cap=4096, max_depth=900, 
 
 def num_threads():
     return lib().obtg_oracle_num_threads()
+
+
+def set_square_by_pow(on):
+    """Diagnostics: False = the squares of gjk.py:460 (`a**2`, libm pow on NumPy scalars) as a * a, the way the device forms them;
+    True (the default) = as the reference.  Tells whether a device / oracle difference comes from that step alone."""
+    lib().obtg_oracle_set_square_by_pow(1 if on else 0)
+
+
+def pow2_both(x):
+    """(csrc/libm_pow2.h's restatement of pow(x, 2.0) -- what the device runs --, this machine's libm pow(x, 2.0)) for every x."""
+    x = _f64(x).ravel()
+    a, b = np.empty_like(x), np.empty_like(x)
+    lib().obtg_oracle_pow2_both(_p(x), C.c_long(x.size), _p(a), _p(b))
+    return a, b

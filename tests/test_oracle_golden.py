@@ -429,3 +429,32 @@ def test_degree8_drivers_constraint_vectors(oracle, golden_dir):
     assert_close(oracle.speed(y, 1, 2, 0, x[-1], 5.0, 1), g["tr_maxspeed"], 1e-12, "track speed")
     assert_close(oracle.ang_rate(y, 1, 0, x[-1], 0.5), g["tr_angrate"], 1e-9, "track ang rate")
     assert (g["tr_mindist_status"] == 2).all() and int(g["tr_spatial_status"]) == 2      # the reference overflows its stack on every pair
+
+
+def test_pow2_restated(oracle):
+    """gjk.py:460 squares with `a**2` on NumPy scalars = libm's pow(a, 2.0), which is not always a * a.  The device restates
+    that pow for y = 2 (csrc/libm_pow2.h: glibc 2.35's algorithm in the operation order of this image's `__pow_fma`, with the
+    library's own tables, tools/gen_libm_pow2_tables.py); here the restatement, compiled for the host, is held to THIS machine's
+    pow(x, 2.0) bit for bit -- on components of unit vectors (what gjk.py:460 feeds it), on magnitudes across the restated range
+    and beyond it, around 1, and on the special values.  A different libm would fail here instead of silently changing parity."""
+    rng = np.random.default_rng(20251005)
+    v = rng.normal(size=(300000, 3))
+    v /= np.linalg.norm(v, axis=1)[:, None]
+    x = np.concatenate([
+        v.ravel(), rng.uniform(-1, 1, 400000),
+        np.ldexp(1 + rng.random(300000), rng.integers(-420, 420, 300000)) * rng.choice([-1.0, 1.0], 300000),
+        1 + np.arange(-3000, 3000) * 2.0 ** -52, -1 + np.arange(-3000, 3000) * 2.0 ** -53,
+        [0.0, -0.0, 1.0, -1.0, 0.5, 2.0, np.inf, -np.inf, np.nan, 5e-324, 1e-300, 1e300, 2.0 ** -359, 2.0 ** 359, 2.0 ** -361, 2.0 ** 361],
+    ])
+    restated, libm = oracle.pow2_both(x)
+    same = (restated.view(np.int64) == libm.view(np.int64)) | (np.isnan(restated) & np.isnan(libm))
+    # the restated range (2^-360, 2^360) and the special values: bit for bit; beyond it the restatement returns x * x
+    inside = ((np.abs(x) > 2.0 ** -360) & (np.abs(x) < 2.0 ** 360)) | (x == 0) | ~np.isfinite(x)
+    assert same[inside].all(), "pow(x, 2.0) restated differs from this machine's libm on %d of %d inputs, e.g. x = %r" % (
+        (~same[inside]).sum(), inside.sum(), x[inside][~same[inside]][:3].tolist())
+    with np.errstate(over="ignore", under="ignore", invalid="ignore"):
+        assert np.array_equal(restated[~inside], (x * x)[~inside])
+    with np.errstate(over="ignore", under="ignore", invalid="ignore"):
+        prod = x * x
+    one_ulp = (libm.view(np.int64) != prod.view(np.int64)) & ~np.isnan(libm)
+    assert 0 < one_ulp.sum() < 0.01 * x.size        # the reason it is restated at all: pow(x, 2.0) is not x * x

@@ -37,3 +37,16 @@ def elementwise_rel(got, ref, floor=1e-6):
         return 0.0
     m = fin & (np.abs(ref) > floor * np.abs(ref[fin]).max())
     return float((np.abs(got[m] - ref[m]) / np.abs(ref[m])).max()) if m.any() else 0.0
+
+
+def assert_identical(got, ref, what=""):
+    """The same float64 values, element for element (NaN matches NaN; +0 and -0 compare equal): what the GJK closest points and
+    distances are held to since round 5 -- gjkNew's last non-bit-exact step, `a**2` of gjk.py:460 as libm's pow, is restated on the
+    device (csrc/libm_pow2.h)."""
+    got = np.asarray(got, dtype=np.float64)
+    ref = np.asarray(ref, dtype=np.float64)
+    assert got.shape == ref.shape, "%s shape %s vs %s" % (what, got.shape, ref.shape)
+    if not np.array_equal(got, ref, equal_nan=True):
+        bad = ~((got == ref) | (np.isnan(got) & np.isnan(ref)))
+        rel = np.abs(got[bad] - ref[bad]) / np.maximum(1.0, np.abs(ref[bad]))
+        raise AssertionError("%s: %d of %d values differ (largest relative difference %.3e)" % (what, int(bad.sum()), got.size, float(np.nanmax(rel))))
