@@ -530,7 +530,11 @@ __device__ __forceinline__ void closest_from_simplex(const Ctx<Mem>& g, const Si
             const double nn = normb(N);
             const V3 n{ N.x / nn, N.y / nn, N.z / nn };
             const double tq = (n.x * s.A.v.x + n.y * s.A.v.y + n.z * s.A.v.z) /
+#ifdef OBTG_SQUARE_AS_PRODUCT      // (A/B builds only: rounds 1-4's a * a)
+                              (n.x * n.x + n.y * n.y + n.z * n.z);
+#else
                               (obtg_square_as_libm_pow(n.x) + obtg_square_as_libm_pow(n.y) + obtg_square_as_libm_pow(n.z));
+#endif
             const V3 cp{ tq * n.x, tq * n.y, tq * n.z };
             r.dist = __builtin_sqrt(dot3(cp, cp));
             const V3 PA = sub(s.A.v, cp), PB = sub(s.B.v, cp), PC = sub(s.C.v, cp);
