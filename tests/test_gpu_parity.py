@@ -288,7 +288,7 @@ def test_min_dist_golden(capi, oracle, golden_dir):
         if m["lit_status"][k] == 0:
             assert r["status"][k] == capi.MD_OK
             assert r["gjk_calls"][k] == m["lit_calls"][k]
-            assert_close(r["res"][k], m["lit_res"][k], RTOL)
+            assert_identical(r["res"][k], m["lit_res"][k], "lit pair %d" % k)      # the reference's float64 values
         else:
             assert r["status"][k] != capi.MD_OK
     Y = m["c3_Y"]
@@ -300,10 +300,10 @@ def test_min_dist_golden(capi, oracle, golden_dir):
         assert r["status"][k] == o["status"]
         if o["status"] == oracle.MD_OK:
             assert r["gjk_calls"][k] == o["gjk_calls"] and r["depth"][k] == o["depth"]
-            assert_close(r["res"][k], o["res"], RTOL)
+            assert_identical(r["res"][k], o["res"], "pair %d vs oracle" % k)
         if m["c3_status"][k] == 0:
             assert r["status"][k] == capi.MD_OK and r["gjk_calls"][k] == m["c3_calls"][k]
-            assert_close(r["res"][k], m["c3_res"][k], RTOL)
+            assert_identical(r["res"][k], m["c3_res"][k], "c3 pair %d" % k)
             n_ok += 1
     assert n_ok >= 30
 
@@ -320,8 +320,8 @@ def test_min_dist2poly_golden(capi, golden_dir):
     for k in range(len(pr)):
         if m["litp_status"][k] == 0:
             assert r["status"][k] == capi.MD_OK and r["gjk_calls"][k] == m["litp_calls"][k]
-            assert_close(r["res"][k][:2], m["litp_res"][k], RTOL)
-            assert_close(r["res"][k][2:], m["litp_pt"][k], RTOL)
+            assert_identical(r["res"][k][:2], m["litp_res"][k], "litp %d" % k)
+            assert_identical(r["res"][k][2:], m["litp_pt"][k], "litp point %d" % k)
         else:
             assert r["status"][k] != capi.MD_OK
     Y = m["c3_Y"]
@@ -331,8 +331,8 @@ def test_min_dist2poly_golden(capi, golden_dir):
     for k in range(len(pr)):
         if m["c3p_status"][k] == 0:
             assert r["status"][k] == capi.MD_OK and r["gjk_calls"][k] == m["c3p_calls"][k]
-            assert_close(r["res"][k][:2], m["c3p_res"][k], RTOL)
-            assert_close(r["res"][k][2:], m["c3p_pt"][k], RTOL)
+            assert_identical(r["res"][k][:2], m["c3p_res"][k], "c3p %d" % k)
+            assert_identical(r["res"][k][2:], m["c3p_pt"][k], "c3p point %d" % k)
         else:
             assert r["status"][k] != capi.MD_OK
 
@@ -1098,7 +1098,7 @@ def test_c5_min_dist_pairs(capi, oracle, synth, golden_dir):
     for k in range(len(g["md_pa"])):
         if g["md_status"][k] == 0:
             assert r["status"][k] == capi.MD_OK and r["gjk_calls"][k] == g["md_calls"][k]
-            assert_close(r["res"][k], g["md_res"][k], RTOL)
+            assert_identical(r["res"][k], g["md_res"][k], "C5 pair %d vs the reference" % k)
             n_ok += 1
         elif g["md_status"][k] == 2:
             assert r["status"][k] != capi.MD_OK      # RecursionError in the reference
@@ -1111,7 +1111,7 @@ def test_c5_min_dist_pairs(capi, oracle, synth, golden_dir):
         assert r["status"][k] == o["status"], k
         if o["status"] == oracle.MD_OK:
             assert r["gjk_calls"][k] == o["gjk_calls"] and r["nodes"][k] == o["nodes"] and r["depth"][k] == o["depth"]
-            assert_close(r["res"][k], o["res"], RTOL)
+            assert_identical(r["res"][k], o["res"], "pair %d vs oracle" % k)
             n_fin += 1
     assert n_fin > 300
 
