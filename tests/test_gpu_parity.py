@@ -871,6 +871,37 @@ def test_min_dist_quad_form_is_the_wave_form(capi, synth, monkeypatch):
                 assert np.array_equal(quad[key], wave[key], equal_nan=True), (n, kw, key)
 
 
+def test_min_dist_random_sets_identical_to_the_oracle(capi, oracle, synth):
+    """A slice of tools/mindist_campaign.py as a test: random curve sets in 2-D and 3-D, degrees 1..15 (straight lines plus noise, and
+    curves drawn in a small box so that many cross), node budgets 60 / 400 / 1500 -- every pair's status, and where the search ends its
+    gjkNew-call count, depth and (distance, t1, t2), IDENTICAL to the CPU oracle's.  Before csrc/libm_pow2.h one 3-D pair in ~8000
+    left the oracle's path (a**2 of gjk.py:460 as a * a instead of libm's pow); the full campaign's record is
+    profiles/r05_experiments/mindist_campaign.txt."""
+    ctx = capi.scratch_context()
+    rng = np.random.default_rng(2025)
+    n_pairs = 0
+    for s in range(260):
+        dim = 2 + (s & 1)
+        n = int(rng.integers(1, 16))
+        nc = int(rng.integers(5, 15))
+        curves = np.zeros((nc, 3, n + 1))
+        if s % 3 == 0:
+            curves[:, :dim, :] = rng.uniform(0, 10, size=(nc, dim, n + 1))
+        else:
+            curves[:, :dim, :] = synth.swarm_control_points(nc, dim, n, seed=1000 + s).reshape(nc, dim, n + 1)
+        pa, pb = synth.all_pairs(nc)
+        kw = dict(max_depth=64, max_nodes=int(rng.choice([60, 400, 1500])))
+        q = ctx.min_dist(curves, pa, pb, **kw)
+        for k in range(len(pa)):
+            o = oracle.min_dist(curves[pa[k]], curves[pb[k]], **kw)
+            assert q["status"][k] == o["status"], (s, k)
+            if o["status"] == oracle.MD_OK:
+                assert q["gjk_calls"][k] == o["gjk_calls"] and q["depth"][k] == o["depth"] and q["nodes"][k] == o["nodes"], (s, k)
+                assert_identical(q["res"][k], o["res"], "set %d pair %d (dim %d, degree %d)" % (s, k, dim, n))
+        n_pairs += len(pa)
+    assert n_pairs > 9000
+
+
 @pytest.mark.parametrize("R", [0, 7])
 def test_temporal_sep_is_the_sampled_squared_distance(capi, synth, R):
     """The reference's own eyeball check (temp.py:20-37), made numerical and independent of the oracle:
