@@ -989,8 +989,8 @@ def mindist_mode(args, rank):
         print(json.dumps({"metric": "spatial-separation (_minDist) evals/s, host buffers in and out", "value": out["reference_algorithm"]["evals_per_s"],
                           "unit": "constraint-evals/s", "n_gpus": 1, "higher_is_better": True, "dtype": "f64", "data": "synthetic",
                           "vs_baseline": None, "config": {"workload": "C5-style: 64 vehicles + 32 curve obstacles, degree 10, 4560 curve pairs per evaluation",
-                                                          "note": "a branch-and-bound search per pair: bound by VALU issue and by the longest pair, not by HBM -- "
-                                                                  "nodes/s, gjkNew calls/s and the VALU-busy fraction of the launch stand in for a roofline"},
+                                                          "note": "a branch-and-bound search per pair, not an HBM stream: the launch lasts as long as the dependent chain of its slowest pair "
+                                                                  "(profiles/r05_experiments/mindist_quad_phases.txt) -- nodes/s, gjkNew calls/s and the VALU-busy fraction of the launch stand in for a roofline"},
                           "variants": out}))
 
 
