@@ -961,8 +961,15 @@ def mindist_mode(args, rank):
             pmc = json.load(open(ppath))
         except Exception:
             pmc = {}
+    # curve <-> polygon (`_minDist2Poly`, bezier.py:1411-1496): the 64 vehicles against 64 polygon obstacles, 4096 pairs
+    polys = synth.polygon_obstacles(64, seed=1234)
+    ppts, poff = synth.pack_polys(polys)
+    pc = np.repeat(np.arange(N), len(polys)).astype(np.int32)
+    pp = np.tile(np.arange(len(polys)), N).astype(np.int32)
     for name, f in (("reference_algorithm", lambda: ctx.min_dist(curves, pa, pb, eps=1e-9, max_depth=128, max_nodes=2000)),
-                    ("robust", lambda: ctx.min_dist_robust(curves, pa, pb, eps=1e-9, max_nodes=400000))):
+                    ("robust", lambda: ctx.min_dist_robust(curves, pa, pb, eps=1e-9, max_nodes=400000)),
+                    ("curve_polygon_reference_algorithm", lambda: ctx.min_dist2poly(curves[:N], ppts, poff, pc, pp, eps=1e-6, max_depth=128, max_nodes=2000)),
+                    ("curve_polygon_robust", lambda: ctx.min_dist2poly_robust(curves[:N], ppts, poff, pc, pp, eps=1e-9, max_nodes=200000))):
         t0 = time.perf_counter()
         r = f()                                    # the first evaluation of this pair list: no node-count history yet
         first_ms = 1e3 * (time.perf_counter() - t0)
@@ -974,8 +981,9 @@ def mindist_mode(args, rank):
             r = f()
         ms = 1e3 * (time.perf_counter() - t0) / reps
         nodes = int(r["nodes"].sum())
-        out[name] = dict(ms_per_eval=round(ms, 3), first_eval_ms=round(first_ms, 3), evals_per_s=round(1e3 / ms, 2),
-                         pairs_per_s=round(len(pa) * 1e3 / ms, 1), nodes_per_eval=nodes, nodes_per_s=round(nodes * 1e3 / ms, 1),
+        npairs = len(pc) if name.startswith("curve_polygon") else len(pa)
+        out[name] = dict(ms_per_eval=round(ms, 3), first_eval_ms=round(first_ms, 3), evals_per_s=round(1e3 / ms, 2), pairs=npairs,
+                         pairs_per_s=round(npairs * 1e3 / ms, 1), nodes_per_eval=nodes, nodes_per_s=round(nodes * 1e3 / ms, 1),
                          status_counts=np.bincount(r["status"], minlength=4).tolist(),
                          result_checksum=float(np.nansum(r["res"][:, 0])))
         if "gjk_calls" in r:

@@ -2212,7 +2212,7 @@ __device__ __forceinline__ void hull_param_quarter2(const double* c1, const doub
 // the wavefront walks through the longest of every kind, a division at a time, and the two calls were 11.6 k clocks of an
 // evaluation's 33 k (profiles/r05_experiments/mindist_quad_phases.txt).  Here every lane forms ALL K quotients of both curves
 // -- 2 K independent divisions, unrolled -- and the sums pick their terms by predicate in the order numpy adds them.
-template <int K>
+template <int K, bool TWO = true>      // TWO = false: curve 1 only (c2 / cl2 / t2 unused: the curve <-> polygon search)
 __device__ __forceinline__ void hull_param_quarter2_t(const double* c1, const double* c2, const V3& cl1, const V3& cl2,
                                                       double* sh_e, double* sh_q, double& t1, double& t2)
 {
@@ -2220,13 +2220,13 @@ __device__ __forceinline__ void hull_param_quarter2_t(const double* c1, const do
     const int lane = threadIdx.x & 63, l = lane & 15;
     const int li = l < K ? l : 0;                        // (lanes past the curve repeat point 0; nothing of theirs is used)
     const double ax = c1[li], ay = c1[K + li], az = c1[2 * K + li];
-    const double bx = c2[li], by = c2[K + li], bz = c2[2 * K + li];
+    const double bx = TWO ? c2[li] : 0.0, by = TWO ? c2[K + li] : 0.0, bz = TWO ? c2[2 * K + li] : 0.0;
     const bool hit1 = l < K && ax == cl1.x && ay == cl1.y && az == cl1.z;
-    const bool hit2 = l < K && bx == cl2.x && by == cl2.y && bz == cl2.z;
+    const bool hit2 = TWO && l < K && bx == cl2.x && by == cl2.y && bz == cl2.z;
     const unsigned m1 = (unsigned)(__ballot(hit1) >> (lane & 48)) & 0xffffu;
-    const unsigned m2 = (unsigned)(__ballot(hit2) >> (lane & 48)) & 0xffffu;
+    const unsigned m2 = TWO ? (unsigned)(__ballot(hit2) >> (lane & 48)) & 0xffffu : 1u;
     if (m1) t1 = (double)(__ffs((int)m1) - 1) / (double)(K - 1);
-    if (m2) t2 = (double)(__ffs((int)m2) - 1) / (double)(K - 1);
+    if (TWO && m2) t2 = (double)(__ffs((int)m2) - 1) / (double)(K - 1);
     if (m1 && m2) return;
     double ea, eb;
     {
@@ -2234,16 +2234,20 @@ __device__ __forceinline__ void hull_param_quarter2_t(const double* c1, const do
         double s = 0.0;
         s += dx * dx; s += dy * dy; s += dz * dz;
         ea = __builtin_sqrt(s);
-        const double ex = cl2.x - bx, ey = cl2.y - by, ez = cl2.z - bz;
-        double u = 0.0;
-        u += ex * ex; u += ey * ey; u += ez * ez;
-        eb = __builtin_sqrt(u);
+        eb = 1.0;
+        if constexpr (TWO) {
+            const double ex = cl2.x - bx, ey = cl2.y - by, ez = cl2.z - bz;
+            double u = 0.0;
+            u += ex * ex; u += ey * ey; u += ez * ez;
+            eb = __builtin_sqrt(u);
+        }
     }
-    sh_e[l] = ea; sh_e[16 + l] = eb;
+    sh_e[l] = ea;
+    if constexpr (TWO) sh_e[16 + l] = eb;
     wave_sync();
     double qa[K], qb[K];
 #pragma unroll
-    for (int j = 0; j < K; ++j) { qa[j] = ea / sh_e[j]; qb[j] = eb / sh_e[16 + j]; }
+    for (int j = 0; j < K; ++j) { qa[j] = ea / sh_e[j]; qb[j] = TWO ? eb / sh_e[16 + j] : 0.0; }
     // terms j < l (l of them)
     auto sum_lo = [&](const double (&q)[K]) {
         double r = 0.0;
@@ -2277,13 +2281,30 @@ __device__ __forceinline__ void hull_param_quarter2_t(const double* c1, const do
         }
         return r;
     };
-    const double a1 = sum_lo(qa), a2 = sum_hi(qa), b1 = sum_lo(qb), b2 = sum_hi(qb);
-    const double Wa = 1 / (1 + a1 + a2), Wb = 1 / (1 + b1 + b2);
+    const double a1 = sum_lo(qa), a2 = sum_hi(qa);
+    const double Wa = 1 / (1 + a1 + a2);
     sh_q[l] = Wa * (double)l / (double)K;
-    sh_q[16 + l] = Wb * (double)l / (double)K;
+    if constexpr (TWO) {
+        const double b1 = sum_lo(qb), b2 = sum_hi(qb);
+        const double Wb = 1 / (1 + b1 + b2);
+        sh_q[16 + l] = Wb * (double)l / (double)K;
+    }
     wave_sync();
     if (!m1) t1 = np_sum(sh_q, K);
-    if (!m2) t2 = np_sum(sh_q + 16, K);
+    if (TWO && !m2) t2 = np_sum(sh_q + 16, K);
+}
+
+// the curve's parameter alone (curve <-> polygon search)
+__device__ __forceinline__ double hull_param_row(const double* c1, int K, const V3& cl1, double* sh_e, double* sh_q)
+{
+    double t1 = 0.0, t2 = 0.0;
+    switch (K) {        // (wave-uniform)
+#define OBTG_CASE(NC_) case NC_: hull_param_quarter2_t<NC_, false>(c1, c1, cl1, cl1, sh_e, sh_q, t1, t2); return t1;
+        OBTG_NC_DYN(OBTG_CASE)
+#undef OBTG_CASE
+        default: hull_param_quarter2(c1, c1, K, cl1, cl1, sh_e, sh_q, t1, t2);
+    }
+    return t1;
 }
 
 __device__ __forceinline__ void hull_param_rows(const double* c1, const double* c2, int K, const V3& cl1, const V3& cl2,
@@ -2932,6 +2953,9 @@ __global__ __launch_bounds__(64) void k_min_dist2poly_robust(const Md2rParams p)
 
 // frame layout for the polygon form: c1[3K] then scalars
 enum { G_T1 = 0, G_T1L, G_T1H, G_ALPHA, G_RT1, G_PX, G_PY, G_PZ, G_STATE, G_NSCAL };
+// a child's record / the blob of a frame in k_min_dist2poly_quad (further down)
+enum { P_CAP = 0, P_POS, P_LB, P_T1, P_UB, P_AM, P_CX, P_CY, P_CZ, P_NREC };
+__host__ __device__ constexpr int md2_quad_blob(int K) { return 6 * K + 2 * P_NREC; }
 
 struct Md2Params {
     const double* __restrict__ curves;   // [n_curves][3][K]
@@ -2940,7 +2964,7 @@ struct Md2Params {
     const int* __restrict__ pc;
     const int* __restrict__ pp;
     int n_pairs, K, max_iter, md_cap, max_depth, max_nodes;
-    double eps;
+    double eps, eps3;                     // eps3 = eps**3 as Python forms it (bezier.py:1468: libm pow, on the host)
     double* stack;
     double* __restrict__ res;             // [n_pairs][5]
     int* __restrict__ info;
@@ -3005,7 +3029,7 @@ __global__ __launch_bounds__(64) void k_min_dist2poly(const Md2Params p)
                 if (ub <= alpha) { alpha = ub; nT1 = (1 - t1loc) * sc[G_T1L] + t1loc * sc[G_T1H]; }
                 else nT1 = -1;
             } else {
-                t1 = 0.5; nT1 = -1; cx = cy = cz = -1; lb = p.eps * p.eps * p.eps;
+                t1 = 0.5; nT1 = -1; cx = cy = cz = -1; lb = p.eps3;
             }
             if (lb >= alpha * (1 - p.eps)) {
                 r0 = alpha; r1 = nT1; rx = cx; ry = cy; rz = cz; returning = true; depth--;
@@ -3933,7 +3957,11 @@ int launch_step_fd_structured(obtg_ctx* c, int B, double max_sep, double* d_out_
     return tl.finish(hdr);
 }
 
-size_t min_dist2poly_stack_doubles(int K, int max_depth) { return (size_t)max_depth * (3 * K + G_NSCAL); }
+size_t min_dist2poly_stack_doubles(int K, int max_depth)      // per pair: the larger of the frame forms
+{
+    const int fr = 3 * K + G_NSCAL, bl = K <= kMdQuadMaxK ? md2_quad_blob(K) : 0;
+    return (size_t)max_depth * (fr > bl ? fr : bl);
+}
 
 // worker waves of the wave-per-pair searches: waves per SIMD x 4 SIMDs x CUs, never more than pairs (OBTG_MD_WAVES_PER_SIMD)
 int min_dist_workers(const obtg_ctx* c, int n_pairs, size_t lds_per_wave)
@@ -4058,7 +4086,7 @@ __global__ __launch_bounds__(64) void k_min_dist2poly_wave(const Md2Params p)
                 if (ub <= alpha) { alpha = ub; nT1 = (1 - t1loc) * sc[G_T1L] + t1loc * sc[G_T1H]; }
                 else nT1 = -1;
             } else {
-                t1 = 0.5; nT1 = -1; cx = cy = cz = -1; lb = p.eps * p.eps * p.eps;
+                t1 = 0.5; nT1 = -1; cx = cy = cz = -1; lb = p.eps3;
             }
             if (lb >= alpha * (1 - p.eps)) {
                 r0 = alpha; r1 = nT1; rx = cx; ry = cy; rz = cz; returning = true; depth--;
@@ -4123,6 +4151,153 @@ __global__ __launch_bounds__(64) void k_min_dist2poly_wave(const Md2Params p)
         p.res[5 * k] = r0; p.res[5 * k + 1] = r1; p.res[5 * k + 2] = rx; p.res[5 * k + 3] = ry; p.res[5 * k + 4] = rz;
         if (p.info) { p.info[4 * k] = nodes; p.info[4 * k + 1] = calls; p.info[4 * k + 2] = dmax; p.info[4 * k + 3] = status; }
     }
+}
+
+// ---- _minDist2Poly, both children at a time (round 5): k_min_dist_quad's arrangement for bezier.py:1411-1496, whose nodes have TWO
+// children (the curve's pieces against the same polygon), both always visited, the cut taken inside the child -- so the children's
+// gjkNew calls, split parameters and end-point bounds are worked out when the parent is split, a 16-lane row of the wavefront each
+// (curve and polygon of at most 16 points; rows 2 and 3 repeat rows 0 and 1), in lockstep.  Why it matters here: a launch of the
+// wave form lasts as long as the pair whose inner gjkNew never converges (md_cap rounds of minimumDistance: 3 such pairs among the
+// 4096 of bench.py --mode mindist took 5.3 ms), and a lockstep trip of 16-lane rows is a third of a wavefront-wide one.
+// A frame's blob: the curve's two pieces (left, right), then the two children's records.
+
+__device__ __forceinline__ void split_one_both(const double* c, int K, double t, double* blob, double* dump)
+{
+    switch (K) {        // (wave-uniform; 3 K <= 48 lanes)
+#define OBTG_CASE(NC_) case NC_: if (NC_ <= kMdQuadMaxK) { split_both_t<NC_>(c, c, K, t, t, blob, 0, 3, dump); return; } break;
+        OBTG_NC_DYN(OBTG_CASE)
+#undef OBTG_CASE
+        default: break;
+    }
+    split_both_t<0>(c, c, K, t, t, blob, 0, 3, dump);
+}
+
+// the record of the (curve piece, polygon) pair a row of the wavefront names: gjkNew, the curve's split parameter (bezier.py:
+// 1436-1452), _upperboundPoly (the curve's end points against the polygon's closest point)
+__device__ __forceinline__ void md2_eval_rows(const double* lds, int oc, int K, int op, int PK, int max_iter, int md_cap,
+                                              double* rec, double* sh_e, double* sh_q)
+{
+    Ctx<MemLds> g;
+    g.mem = MemLds{ lds };
+    g.P1 = Poly{ oc, K, K, 1 };
+    g.P2 = Poly{ op, 16, PK, 1 };
+    g.trace = nullptr; g.trace_cap = 0; g.n_support = 0;
+    Result gr;
+    gjk::run_quarter<MemLds>(g, max_iter, md_cap, gr);
+    const bool cap = gr.status == OBTG_ST_MD_CAP || gr.status == OBTG_ST_CYCLE;
+    const bool pos = gr.flag > 0 && !cap;
+    const double* c1 = lds + oc;
+    double t1 = 0.5, ub = INFINITY;
+    int am = 0;
+    if (pos) {
+        t1 = hull_param_row(c1, K, gr.c1, sh_e, sh_q);
+        const double d0 = norm_seq(c1[0], c1[K], c1[2 * K], gr.c2.x, gr.c2.y, gr.c2.z);
+        const double d1 = norm_seq(c1[K - 1], c1[2 * K - 1], c1[3 * K - 1], gr.c2.x, gr.c2.y, gr.c2.z);
+        am = (d1 < d0) ? 1 : 0;
+        if (d0 != d0) am = 0; else if (d1 != d1) am = 1;
+        ub = am ? d1 : d0;
+    }
+    rec[P_CAP] = cap ? 1.0 : 0.0; rec[P_POS] = pos ? 1.0 : 0.0; rec[P_LB] = gr.dist; rec[P_T1] = t1; rec[P_UB] = ub;
+    rec[P_AM] = (double)am; rec[P_CX] = gr.c2.x; rec[P_CY] = gr.c2.y; rec[P_CZ] = gr.c2.z;
+}
+
+__global__ __launch_bounds__(64, OBTG_MD_MIN_WAVES) void k_min_dist2poly_quad(const Md2Params p)
+{
+    extern __shared__ double m2q_lds[];
+    const int k = blockIdx.x, lane = threadIdx.x, q = (lane >> 4) & 1;        // rows 2, 3 repeat rows 0, 1
+    const int K = p.K, BL = md2_quad_blob(K);
+    const int po = p.off[p.pp[k]], PK = p.off[p.pp[k] + 1] - po;
+    double* st = p.stack + (size_t)k * p.max_depth * BL;
+    double* cur = m2q_lds;                      // [BL] blob of the frame `cur_depth`
+    double* nxt = cur + BL;                     // [BL] blob being built
+    double* pol = nxt + BL;                     // [3][16] polygon, SoA
+    double* sh_e = pol + 48;                    // [4][kMdShRow]
+    double* sh_q = sh_e + 4 * kMdShRow;
+    double* dump = sh_q + 4 * kMdShRow;         // [64]
+    double* scs = dump + 64;                    // [max_depth][G_NSCAL] frame scalars
+    const double* ca = p.curves + (size_t)p.pc[k] * 3 * K;
+    for (int i = lane; i < 3 * K; i += kWave) { const double a = ca[i]; nxt[i] = a; nxt[3 * K + i] = a; }      // frame "-1": pieces c, c
+    for (int i = lane; i < 3 * PK; i += kWave) pol[(i / PK) * 16 + (i % PK)] = p.soa[3 * po + i];
+    // the frame whose children the walk is going through, in registers (see k_min_dist_quad); frame -1: [0, 1] split "at 1"
+    double f_t1l = 0, f_t1h = 1, f_t1 = 1, f_alpha = INFINITY, f_rt1 = -1, f_px = -1, f_py = -1, f_pz = -1;
+    int f_next = 0;
+    int depth = -1, cur_depth = -1, eval_depth = -1;
+    int nodes = 0, calls = 0, dmax = 0, status = OBTG_MD_OK;
+    double r0 = INFINITY, r1 = -1, rx = -1, ry = -1, rz = -1;
+    bool done = false;
+    while (!done) {
+        wave_sync();
+        md2_eval_rows(m2q_lds, (int)(nxt - m2q_lds) + q * 3 * K, K, (int)(pol - m2q_lds), PK, p.max_iter, p.md_cap,
+                      nxt + 6 * K + q * P_NREC, sh_e + (lane >> 4) * kMdShRow, sh_q + (lane >> 4) * kMdShRow);
+        wave_sync();
+        if (eval_depth >= 0) {
+            double* f = st + (size_t)eval_depth * BL;
+            for (int i = lane; i < BL; i += kWave) f[i] = nxt[i];
+        }
+        { double* tsw = cur; cur = nxt; nxt = tsw; }
+        cur_depth = eval_depth;
+#define OBTG_MD2_RETURN() \
+    { if (depth < 0) { done = true; break; } \
+      if (r0 < f_alpha) { f_alpha = r0; f_rt1 = r1; f_px = rx; f_py = ry; f_pz = rz; } \
+      continue; }
+        for (;;) {
+            if (f_next >= 2) {                   // both children done: this frame's value goes to its parent
+                r0 = f_alpha; r1 = f_rt1; rx = f_px; ry = f_py; rz = f_pz;
+                depth--;
+                if (depth < 0) { done = true; break; }
+                const double* sc = scs + depth * G_NSCAL;
+                f_t1 = sc[G_T1]; f_t1l = sc[G_T1L]; f_t1h = sc[G_T1H]; f_alpha = sc[G_ALPHA]; f_rt1 = sc[G_RT1];
+                f_px = sc[G_PX]; f_py = sc[G_PY]; f_pz = sc[G_PZ]; f_next = (int)sc[G_STATE];
+                OBTG_MD2_RETURN()
+            }
+            const int h1 = f_next++;             // child: the left (0) / right (1) piece, a node at depth + 1
+            if (depth + 2 > 1000) { r0 = r1 = rx = -1; ry = rz = -1; OBTG_MD2_RETURN() }
+            if (nodes >= p.max_nodes) { status = OBTG_MD_NODE_CAP; done = true; break; }
+            nodes++;
+            if (depth + 2 > dmax) dmax = depth + 2;
+            if (cur_depth != depth) {            // the walk came back up: fetch this frame's blob again
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+                const double* f = st + (size_t)depth * BL;
+                for (int i = lane; i < BL; i += kWave) cur[i] = f[i];
+                cur_depth = depth;
+                wave_sync();
+            }
+            const double* rec = cur + 6 * K + h1 * P_NREC;
+            calls++;
+            if (rec[P_CAP] != 0.0) { status = OBTG_MD_GJK_CAP; done = true; break; }
+            const double t1len = f_t1h - f_t1l;
+            const double m1 = f_t1l + f_t1 * t1len;
+            const double n1l = h1 ? m1 : f_t1l, n1h = h1 ? f_t1h : m1;
+            double lb, t1, nT1, alpha = f_alpha, cx, cy, cz;
+            if (rec[P_POS] != 0.0) {
+                lb = rec[P_LB]; t1 = rec[P_T1];
+                cx = rec[P_CX]; cy = rec[P_CY]; cz = rec[P_CZ];
+                const double ub = rec[P_UB], t1loc = rec[P_AM] != 0.0 ? 1.0 : 0.0;
+                if (ub <= alpha) { alpha = ub; nT1 = (1 - t1loc) * n1l + t1loc * n1h; }
+                else nT1 = -1;
+            } else {
+                t1 = 0.5; nT1 = -1; cx = cy = cz = -1; lb = p.eps3;
+            }
+            if (lb >= alpha * (1 - p.eps)) { r0 = alpha; r1 = nT1; rx = cx; ry = cy; rz = cz; OBTG_MD2_RETURN() }
+            if (depth + 2 >= p.max_depth) { status = OBTG_MD_DEPTH_CAP; r0 = alpha; r1 = nT1; rx = cx; ry = cy; rz = cz; done = true; break; }
+            if (t1 != t1) t1 = 0;
+            // expand the child: both its pieces to `nxt`; this frame goes to `scs`, the child's into the registers
+            split_one_both(cur + h1 * 3 * K, K, t1, nxt, dump);
+            if (depth >= 0) {
+                double* sc = scs + depth * G_NSCAL;
+                sc[G_T1] = f_t1; sc[G_T1L] = f_t1l; sc[G_T1H] = f_t1h; sc[G_ALPHA] = f_alpha; sc[G_RT1] = f_rt1;
+                sc[G_PX] = f_px; sc[G_PY] = f_py; sc[G_PZ] = f_pz; sc[G_STATE] = (double)f_next;
+            }
+            f_t1 = t1; f_t1l = n1l; f_t1h = n1h; f_alpha = alpha; f_rt1 = nT1; f_px = cx; f_py = cy; f_pz = cz; f_next = 0;
+            depth++;
+            eval_depth = depth;
+            break;
+        }
+#undef OBTG_MD2_RETURN
+    }
+    // (every lane, the same values to the same addresses)
+    p.res[5 * k] = r0; p.res[5 * k + 1] = r1; p.res[5 * k + 2] = rx; p.res[5 * k + 3] = ry; p.res[5 * k + 4] = rz;
+    if (p.info) { p.info[4 * k] = nodes; p.info[4 * k + 1] = calls; p.info[4 * k + 2] = dmax; p.info[4 * k + 3] = status; }
 }
 
 int launch_min_dist_robust(obtg_ctx* c, const double* d_curves, int K, const int* d_pa, const int* d_pb, int n_pairs,
@@ -4196,11 +4371,15 @@ int launch_min_dist2poly(obtg_ctx* c, const double* d_curves, int K, const doubl
 {
     if (n_pairs <= 0) return OBTG_OK;
     if (K < 2 || K > kMdMaxK || max_depth < 1) return OBTG_ERR_UNSUPPORTED;
-    Md2Params p{ d_curves, d_soa, d_off, d_pc, d_pp, n_pairs, K, max_iter, md_cap, max_depth, max_nodes, eps,
+    Md2Params p{ d_curves, d_soa, d_off, d_pc, d_pp, n_pairs, K, max_iter, md_cap, max_depth, max_nodes, eps, cube_as_python(eps),
                  d_stack, d_res, d_info };
     ScopedKernelTimer t(c, OBTG_K_MIN_DIST);
     const size_t lds_w = sizeof(double) * ((size_t)6 * K + 8 * kMdMaxK + (size_t)max_depth * G_NSCAL);
-    if (lds_w <= 48 * 1024 && max_poly_K <= kMdMaxK)      // one pair per wavefront
+    const size_t lds_q = sizeof(double) * ((size_t)2 * md2_quad_blob(K) + 48 + 8 * kMdShRow + 64 + (size_t)max_depth * G_NSCAL);
+    const char* env_form = getenv("OBTG_MD_FORM");          // "wave": a wavefront per gjkNew call (read per launch: the A/B test flips it)
+    if (K <= kMdQuadMaxK && max_poly_K <= 16 && lds_q <= 48 * 1024 && !(env_form && !strcmp(env_form, "wave")))
+        hipLaunchKernelGGL(k_min_dist2poly_quad, dim3((unsigned)n_pairs), dim3(kWave), lds_q, c->stream, p);   // both children side by side
+    else if (lds_w <= 48 * 1024 && max_poly_K <= kMdMaxK)      // one pair per wavefront
         hipLaunchKernelGGL(k_min_dist2poly_wave, dim3((unsigned)n_pairs), dim3(kWave), lds_w, c->stream, p);
     else
         hipLaunchKernelGGL(k_min_dist2poly, dim3((n_pairs + 63) / 64), dim3(64), 0, c->stream, p);

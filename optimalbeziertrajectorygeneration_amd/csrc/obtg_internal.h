@@ -263,6 +263,7 @@ int launch_min_dist2poly_robust(obtg_ctx* c, const double* d_curves, int K, cons
 // x**2 as Python forms it for the constraint offsets (optimization.py:343, 384, 422, 459: maxSep**2, minSpeed**2, maxSpeed**2,
 // maxAngRate**2 on Python floats): the host libm's pow(x, 2.0), which is not always x * x (tables.cpp)
 double square_as_python(double x);
+double cube_as_python(double x);       // x**3 likewise (bezier.py:1468: eps**3)
 size_t min_dist_stack_doubles(const obtg_ctx* c, int K, int max_depth, int n_pairs);   // whole launch
 size_t min_dist2poly_stack_doubles(int K, int max_depth);
 

@@ -173,4 +173,9 @@ double square_as_python(double x)
     static double (*volatile libm_pow)(double, double) = std::pow;
     return libm_pow(x, 2.0);
 }
+double cube_as_python(double x)
+{
+    static double (*volatile libm_pow)(double, double) = std::pow;
+    return libm_pow(x, 3.0);
+}
 }  // namespace obtg

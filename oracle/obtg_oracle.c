@@ -913,7 +913,7 @@ static void min_dist_poly_rec(md_ctx_t *m, const double *c1, const double *poly2
         if (ub <= alpha) { alpha = ub; nT1 = (1 - t1loc) * t1_l + t1loc * t1_h; }
         else nT1 = -1;
     } else {
-        t1 = 0.5; nT1 = -1; cl2[0] = cl2[1] = cl2[2] = -1; lb = m->eps * m->eps * m->eps;
+        t1 = 0.5; nT1 = -1; cl2[0] = cl2[1] = cl2[2] = -1; lb = libm_pow(m->eps, 3.0);      /* eps**3 on a Python float (bezier.py:1468) */
     }
     double t1len = t1_h - t1_l;
     ret[0] = alpha; ret[1] = nT1; ret[2] = cl2[0]; ret[3] = cl2[1]; ret[4] = cl2[2];

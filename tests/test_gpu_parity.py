@@ -871,6 +871,40 @@ def test_min_dist_quad_form_is_the_wave_form(capi, synth, monkeypatch):
                 assert np.array_equal(quad[key], wave[key], equal_nan=True), (n, kw, key)
 
 
+def test_min_dist2poly_quad_form_is_the_wave_form(capi, synth, monkeypatch):
+    """obtg_min_dist2poly, round 5: with at most 16 control points and polygons of at most 16 vertices a node's two children are
+    evaluated together, a 16-lane row each (k_min_dist2poly_quad); OBTG_MD_FORM=wave selects the wavefront-per-call form.  The
+    same walk: (alpha, t1, closest point), node counts, gjkNew-call counts, depths and statuses identical -- 2-D and 3-D curves of
+    degree 1..15 against polygons of 3..16 vertices (planar ones, and point sets in space), under node, depth and gjkNew limits."""
+    rng = np.random.default_rng(77)
+    for (ncurves, dim, n, seed) in ((40, 2, 10, 5), (12, 3, 8, 6), (9, 2, 12, 7), (10, 3, 3, 8), (8, 2, 1, 9), (8, 3, 15, 10), (10, 2, 6, 11)):
+        Yc = synth.swarm_control_points(ncurves, dim, n, seed=seed)
+        curves = np.zeros((ncurves, 3, n + 1))
+        curves[:, :dim, :] = Yc.reshape(ncurves, dim, n + 1)
+        polys = synth.polygon_obstacles(5, seed=seed)
+        for kv in (3, 11, 16):                                     # up to the 16 vertices a row takes
+            ang = np.sort(rng.uniform(0, 2 * np.pi, kv))
+            P = np.zeros((kv, 3))
+            P[:, 0] = 50 + 20 * np.cos(ang); P[:, 1] = 50 + 12 * np.sin(ang)
+            if dim == 3:
+                P[:, 2] = rng.uniform(0, 30, kv)                   # a point set in space (gjkNew takes any)
+            polys.append(P)
+        ppts, poff = synth.pack_polys(polys)
+        pc = np.repeat(np.arange(ncurves), len(polys)).astype(np.int32)
+        pp = np.tile(np.arange(len(polys)), ncurves).astype(np.int32)
+        ctx = capi.scratch_context()
+        for kw in (dict(max_depth=64, max_nodes=2000), dict(max_depth=6, max_nodes=2000), dict(max_depth=64, max_nodes=1),
+                   dict(max_depth=64, max_nodes=23), dict(max_depth=1, max_nodes=50), dict(max_depth=32, max_nodes=200, max_iter=1),
+                   dict(max_depth=32, max_nodes=200, max_iter=3, md_cap=1), dict(max_depth=32, max_nodes=200, md_cap=2),
+                   dict(max_depth=32, max_nodes=300, eps=1e-3)):
+            quad = ctx.min_dist2poly(curves, ppts, poff, pc, pp, **kw)
+            monkeypatch.setenv("OBTG_MD_FORM", "wave")
+            wave = ctx.min_dist2poly(curves, ppts, poff, pc, pp, **kw)
+            monkeypatch.delenv("OBTG_MD_FORM")
+            for key in ("res", "nodes", "gjk_calls", "depth", "status"):
+                assert np.array_equal(quad[key], wave[key], equal_nan=True), (n, dim, kw, key)
+
+
 def test_min_dist_random_sets_identical_to_the_oracle(capi, oracle, synth):
     """A slice of tools/mindist_campaign.py as a test: random curve sets in 2-D and 3-D, degrees 1..15 (straight lines plus noise, and
     curves drawn in a small box so that many cross), node budgets 60 / 400 / 1500 -- every pair's status, and where the search ends its
