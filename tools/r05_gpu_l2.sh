@@ -16,7 +16,7 @@ for d in ("mindist_pmc", "mindist_pmc2"):
     for f in glob.glob("gpurun_out/r05_l2/%s/*counter_collection.csv" % d):
         for r in csv.DictReader(open(f)):
             k = r["Kernel_Name"].split("(")[0].split("::")[-1]
-            if "min_dist" in k or "Md" in k: acc[(k, r["Counter_Name"])].append(float(r["Counter_Value"]))
+            if "min_dist" in k: acc[(k, r["Counter_Name"])].append(float(r["Counter_Value"]))
     for (k, c), v in sorted(acc.items()):
         print("%-20s %-22s launches=%d mean=%.5g" % (k, c, len(v), sum(v) / len(v)))
 PY
