@@ -905,6 +905,45 @@ def test_min_dist2poly_quad_form_is_the_wave_form(capi, synth, monkeypatch):
                 assert np.array_equal(quad[key], wave[key], equal_nan=True), (n, dim, kw, key)
 
 
+def test_min_dist2poly_random_sets_identical_to_the_oracle(capi, oracle, synth):
+    """Curve <-> polygon searches on random sets (2-D and 3-D curves of degree 1..15; planar polygons of 3..16 vertices and point sets
+    in space): status, and where the search ends gjkNew-call count, depth, (alpha, t1) and the polygon's closest point, IDENTICAL to
+    the CPU oracle's."""
+    ctx = capi.scratch_context()
+    rng = np.random.default_rng(4242)
+    n_pairs = 0
+    for s in range(120):
+        dim = 2 + (s & 1)
+        n = int(rng.integers(1, 16))
+        nc = int(rng.integers(4, 10))
+        curves = np.zeros((nc, 3, n + 1))
+        if s % 3 == 0:
+            curves[:, :dim, :] = rng.uniform(20, 80, size=(nc, dim, n + 1))
+        else:
+            curves[:, :dim, :] = synth.swarm_control_points(nc, dim, n, seed=3000 + s).reshape(nc, dim, n + 1)
+        polys = synth.polygon_obstacles(3, seed=500 + s)
+        for kv in (int(rng.integers(3, 17)), 16):
+            ang = np.sort(rng.uniform(0, 2 * np.pi, kv))
+            P = np.zeros((kv, 3))
+            P[:, 0] = 50 + 25 * np.cos(ang); P[:, 1] = 50 + 15 * np.sin(ang)
+            if dim == 3:
+                P[:, 2] = rng.uniform(0, 40, kv)
+            polys.append(P)
+        ppts, poff = synth.pack_polys(polys)
+        pc = np.repeat(np.arange(nc), len(polys)).astype(np.int32)
+        pp = np.tile(np.arange(len(polys)), nc).astype(np.int32)
+        kw = dict(max_depth=64, max_nodes=int(rng.choice([60, 400, 1500])))
+        q = ctx.min_dist2poly(curves, ppts, poff, pc, pp, **kw)
+        for k in range(len(pc)):
+            o = oracle.min_dist2poly(curves[pc[k]], polys[pp[k]], **kw)
+            assert q["status"][k] == o["status"], (s, k)
+            if o["status"] == oracle.MD_OK:
+                assert q["gjk_calls"][k] == o["gjk_calls"] and q["depth"][k] == o["depth"] and q["nodes"][k] == o["nodes"], (s, k)
+                assert_identical(q["res"][k], o["res"], "set %d pair %d (dim %d, degree %d)" % (s, k, dim, n))
+        n_pairs += len(pc)
+    assert n_pairs > 3000
+
+
 def test_min_dist_random_sets_identical_to_the_oracle(capi, oracle, synth):
     """A slice of tools/mindist_campaign.py as a test: random curve sets in 2-D and 3-D, degrees 1..15 (straight lines plus noise, and
     curves drawn in a small box so that many cross), node budgets 60 / 400 / 1500 -- every pair's status, and where the search ends its
