@@ -142,7 +142,7 @@ def test_spatial_jacobian_call_plan_is_the_loop_form():
     vehicle each, a row that moves all of them (a trailing tf) and a row that moves none."""
     from optimalbeziertrajectorygeneration_amd.optimization import _spatial_jac_plan
     rng = np.random.default_rng(5)
-    for (numVeh, dim, K, nobs) in ((5, 2, 6, 3), (4, 3, 4, 0), (1, 2, 11, 2), (7, 2, 9, 1)):
+    for (numVeh, dim, K, nobs) in ((5, 2, 6, 3), (4, 3, 4, 0), (1, 2, 11, 2), (7, 2, 9, 1), (1, 2, 5, 0)):      # (the last: no pair at all)
         nvar = numVeh * dim * K
         Y0 = rng.normal(size=(numVeh * dim, K))
         rows = [Y0]
