@@ -28,6 +28,7 @@ FD_STEP = 1.4901161193847656e-08   # SciPy '2-point' abs_step (sqrt of machine e
 # the first one with a `degElev` argument), so they exist here too; contexts are cached per shape.
 # ---------------------------------------------------------------------------------------------
 import collections
+import os
 
 _CTX_CACHE_MAX = 8              # device contexts kept; the least recently used one is closed beyond that
 _ctx_cache = collections.OrderedDict()
@@ -206,7 +207,8 @@ class BezOptimization(object):
                  device=None,
                  separationRows='all',
                  angRateOrder='fast',
-                 activeRows=2):
+                 activeRows=2,
+                 fdBatching=True):
         """Beyond the reference's keywords: `device` (HIP ordinal; None: this process's, see _capi.default_device) and `separationRows` --
         'all': temporalSeparationConstraints returns every elevated control point of every pair, as the
         reference does (optimization.py:337); 'min': one row per pair, the smallest of them -- the
@@ -231,6 +233,10 @@ class BezOptimization(object):
         self.shapeObstacles = shapeObstacles
         self._device = _capi.default_device() if device is None else int(device)
         self.separationRows = separationRows
+        # SciPy's own finite differences, served from one batched evaluation (see _serve); OBTG_FD_BATCHING=0 turns it off everywhere
+        self.fdBatching = bool(fdBatching) and os.environ.get("OBTG_FD_BATCHING", "1") != "0"
+        self.fdBatchingStats = {'batches': 0, 'served': 0, 'direct': 0}
+        self._fd_state = None
 
         given = locals()
         # `model` keeps the reference's keys (drivers read and edit them, Examples/*.py); what each holds is decided by
@@ -304,13 +310,13 @@ class BezOptimization(object):
             raise ValueError(err)
 
     def euclideanObjective(self, x):
-        return float(self._ctx(False).euclidean_obj(self.reshapeVector(x))[0])
+        return float(self._serve('obj_euclidean', x, lambda x_: self._ctx(False).euclidean_obj(self.reshapeVector(x_))[:1])[0])
 
     def accelObjective(self, x):
-        return float(self._ctx(False).deriv_energy_obj(self.reshapeVector(x), self.model['tf'], 2)[0])
+        return float(self._serve('obj_accel', x, lambda x_: self._ctx(False).deriv_energy_obj(self.reshapeVector(x_), self.model['tf'], 2)[:1])[0])
 
     def jerkObjective(self, x):
-        return float(self._ctx(False).deriv_energy_obj(self.reshapeVector(x), self.model['tf'], 3)[0])
+        return float(self._serve('obj_jerk', x, lambda x_: self._ctx(False).deriv_energy_obj(self.reshapeVector(x_), self.model['tf'], 3)[:1])[0])
 
     def objectiveGradient(self, x):
         """Gradient of `objectiveFunction` the way SciPy would difference it (2-point, abs_step = sqrt(eps)), but from ONE
@@ -343,6 +349,9 @@ class BezOptimization(object):
         def wrapper(x):
             if nobj <= 1:
                 return None                      # optimization.py:345-346
+            return self._serve('tsep', x, direct)
+
+        def direct(x):
             y = self.reshapeVector(x)
             if self.separationRows == 'min':     # per-pair minimum, reduced on the device (obtg_temporal_sep_min)
                 return self._ctx(with_obs).temporal_sep_min(y, self.model['maxSep'])[0]
@@ -353,17 +362,17 @@ class BezOptimization(object):
 
     @property
     def minSpeedConstraints(self):
-        def wrapper(x):
+        def direct(x):
             y = self.reshapeVector(x)
             return self._ctx(False).speed(y, self._tf_of(x), self.model['minSpeed'], False)[0]
-        return wrapper
+        return lambda x: self._serve('vmin', x, direct)
 
     @property
     def maxSpeedConstraints(self):
-        def wrapper(x):
+        def direct(x):
             y = self.reshapeVector(x)
             return self._ctx(False).speed(y, self._tf_of(x), self.model['maxSpeed'], True)[0]
-        return wrapper
+        return lambda x: self._serve('vmax', x, direct)
 
     @property
     def maxAngularRateConstraints(self):
@@ -379,7 +388,7 @@ class BezOptimization(object):
                 # arithmetic returns None for an empty span (bezier.py:340-343, 365-368) and optimization.py:603-604
                 # multiplies it -- the driver dies with this TypeError.  Same exception, same text, no device call.
                 raise TypeError("unsupported operand type(s) for *: 'NoneType' and 'NoneType'")
-            return self._ctx(False).ang_rate(y, tf, self.model['maxAngRate'])[0]
+            return self._serve('ang', x, lambda x_: self._ctx(False).ang_rate(self.reshapeVector(x_), self._tf_of(x_), self.model['maxAngRate'])[0])
         return wrapper
 
     def spatialSeparationConstraints(self, x, robust=False):
@@ -444,9 +453,81 @@ class BezOptimization(object):
         dx = X[idx + 1, idx] - x
         return X, dx
 
+    def _serve(self, family, x, direct):
+        """A constraint closure's value at x -- from ONE batched evaluation when x is a row of SciPy's finite differences.
+
+        The reference hands SLSQP bare closures (Examples/*.py: `{'type': 'ineq', 'fun': bezopt.temporalSeparationConstraints}`),
+        so SciPy differentiates each of them itself: n_x calls at x0 + h e_k per closure and iteration, each a device launch of
+        one row (Example2's five vehicles: 3112 calls per solve).  The driver stays as it is; this notices the pattern instead.
+        The first call that differs from the last base point x0 in ONE variable by exactly SciPy's step is taken for row k of a
+        forward difference: the closure's whole batch F(x0), F(x0 + h e_1), ... is evaluated in one launch (the rows `_jac`
+        forms, formed on the device from x0), kept, and this and the following calls are answered from it.  A call at any other
+        point is a new base (a line-search step, the next iterate) and drops the batches.  Values are those of the one-row call,
+        element for element (tests/test_gpu_dropin.py::test_scipy_finite_differences_served_from_one_batch: SLSQP takes the same
+        iterates either way).  Batches above OBTG_FD_BATCH_MB (256) per closure are not formed; steps SciPy turned around at a
+        bound (x0 - h) are evaluated directly."""
+        if not self.fdBatching:
+            return direct(x)
+        x = np.asarray(x, dtype=float)
+        key = (int(DEG_ELEV), self.separationRows, self.activeRows, self._rv_parts_key(), self.model['maxSep'], self.model['maxSpeed'],
+               self.model['minSpeed'], self.model['maxAngRate'], None if self._timeopt() else self.model['tf'],
+               None if self.pointObstacles is None else np.asarray(self.pointObstacles, dtype=float).tobytes())
+        st = self._fd_state
+        if st is None or st['key'] != key or st['x0'].shape != x.shape:
+            st = self._fd_state = {'key': key, 'x0': x.copy(), 'base': {}, 'rows': {}}
+        d = np.flatnonzero(x != st['x0'])
+        if d.size == 0:
+            if family not in st['base']:
+                self.fdBatchingStats['direct'] += 1
+                st['base'][family] = direct(x)
+            v = st['base'][family]
+            return None if v is None else v.copy()
+        if d.size == 1:
+            k = int(d[0])
+            if x[k] != st['x0'][k] + FD_STEP:
+                self.fdBatchingStats['direct'] += 1          # (a step turned around at a bound, or not SciPy's at all)
+                return direct(x)
+            rows = st['rows'].get(family)
+            if rows is None:
+                base = st['base'].get(family)
+                if base is None:
+                    base = st['base'][family] = direct(st['x0'])
+                    self.fdBatchingStats['direct'] += 1
+                limit = float(os.environ.get("OBTG_FD_BATCH_MB", "256")) * 2.0 ** 20
+                if base is None or 8.0 * base.size * (x.size + 1) > limit:
+                    rows = st['rows'][family] = False        # (too large, or a closure without rows: evaluate directly)
+                else:
+                    rows = st['rows'][family] = self._fd_values(st['x0'], family)[0]
+                    self.fdBatchingStats['batches'] += 1
+            if rows is False:
+                self.fdBatchingStats['direct'] += 1
+                return direct(x)
+            self.fdBatchingStats['served'] += 1
+            return rows[k + 1].copy()
+        # a new base point
+        st = self._fd_state = {'key': key, 'x0': x.copy(), 'base': {}, 'rows': {}}
+        self.fdBatchingStats['direct'] += 1
+        st['base'][family] = direct(x)
+        v = st['base'][family]
+        return None if v is None else v.copy()
+
+    def _rv_parts_key(self):
+        self._rv_parts()
+        return self._rv_cache[0]
+
     def _jac(self, x, family):
+        F, dx = self._fd_values(x, family)
+        return ((F[1:] - F[0:1]) / dx[:, None]).T
+
+    def _fd_values(self, x, family):
+        """(F, dx): the closure `family` on x and its n_x forward-difference neighbours, F[k + 1] = closure(x + h e_k), in one
+        batched device call."""
         X, dx = self._fd_rows(x)
         Y = self.reshapeVectors(X)
+        if family.startswith('obj_'):      # the objectives (one value per row; a column here)
+            c = self._ctx(False)
+            F = c.euclidean_obj(Y) if family == 'obj_euclidean' else c.deriv_energy_obj(Y, self.model['tf'], 2 if family == 'obj_accel' else 3)
+            return np.asarray(F, dtype=float).reshape(-1, 1), dx
         if family == 'tsep':
             with_obs = self.pointObstacles is not None
             if self.separationRows == 'min':
@@ -464,7 +545,7 @@ class BezOptimization(object):
                 F = c.speed(Y, tf, self.model['minSpeed'], False)
             else:
                 F = c.ang_rate(Y, tf, self.model['maxAngRate'])
-        return ((F[1:] - F[0:1]) / dx[:, None]).T
+        return F, dx
 
     def temporalSeparationJacobian(self, x, structured=True):
         """d(temporalSeparationConstraints)/dx by SciPy-style forward differences.

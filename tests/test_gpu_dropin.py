@@ -757,3 +757,79 @@ def test_active_separation_rows_option(golden_dir):
         assert r8.success and ex.solve(8, with_jac=True, maxiter=1)[0].temporalSeparationConstraints(r8.x).min() > -1e-6
     finally:
         opt.DEG_ELEV = 0
+
+
+@pytest.mark.gpu
+def test_scipy_finite_differences_served_from_one_batch(monkeypatch):
+    """The reference's drivers hand SLSQP bare closures, so SciPy differences every one of them itself -- n_x calls at x0 + h e_k
+    per closure and iteration.  BezOptimization._serve notices the first such call and answers it and the rest of the sweep from
+    ONE batched evaluation of the closure's n_x + 1 rows (and drops the batch at the next base point).  Nothing a driver can see
+    may change: the served rows equal the one-row evaluation element for element, and SLSQP -- which amplifies last bits --
+    takes the same iterates, the same number of function evaluations and ends at the same x with the switch on and off;
+    3-D swarm ('all' / 'min' / 'active' rows), the two degree-8 Dubins drivers (time-optimal: tf is a variable and moves every
+    vehicle's speed columns; point obstacles; bounds) at DEG_ELEV 0 and 10."""
+    import scipy.optimize as sop
+    from optimalbeziertrajectorygeneration_amd import optimization as opt
+    from optimalbeziertrajectorygeneration_amd.optimization import BezOptimization, FD_STEP
+    e2 = _load_example("example2_swarm_3d")
+    e7 = _load_example("example7_dubins_degree8")
+
+    def build(kind, on):
+        if on:
+            monkeypatch.delenv("OBTG_FD_BATCHING", raising=False)
+        else:
+            monkeypatch.setenv("OBTG_FD_BATCHING", "0")
+        if kind[0] == 'swarm':
+            init, final = e2.crossing_swarm(5)
+            bo = BezOptimization(numVeh=5, dimension=3, degree=5, minimizeGoal='Euclidean', maxSep=0.9, initPoints=init,
+                                 finalPoints=final, separationRows=kind[1], activeRows=2)
+            cons, bounds = [{'type': 'ineq', 'fun': bo.temporalSeparationConstraints}], None
+            x0 = bo.generateGuess(std=0.2, seed=2)
+        else:
+            bo, bounds = e7.problem(kind[1])
+            cons = [{'type': 'ineq', 'fun': bo.temporalSeparationConstraints}, {'type': 'ineq', 'fun': bo.maxSpeedConstraints},
+                    {'type': 'ineq', 'fun': bo.maxAngularRateConstraints}, {'type': 'ineq', 'fun': lambda x: x[-1]}]
+            x0 = bo.generateGuess(std=0.3, seed=4)
+        assert bo.fdBatching == on
+        return bo, cons, bounds, x0
+
+    try:
+        for kind, R in ((('swarm', 'all'), 0), (('swarm', 'min'), 0), (('swarm', 'active'), 0), (('dubins', 'time_optimal'), 0),
+                        (('dubins', 'example2'), 0), (('dubins', 'time_optimal'), 10), (('dubins', 'example2'), 10)):
+            opt.DEG_ELEV = R
+            out = {}
+            for on in (True, False):
+                bo, cons, bounds, x0 = build(kind, on)
+                kw = dict(method='SLSQP', constraints=cons, options={'maxiter': 12, 'disp': False})
+                if bounds is not None:
+                    kw['bounds'] = bounds
+                try:
+                    res = sop.minimize(bo.objectiveFunction, x0=x0, **kw)
+                    out[on] = (res.x.copy(), res.nfev, res.nit, float(res.fun), res.status)
+                except TypeError:                        # the drivers' own death at tf <= 0 (optimization.py:604): both must die
+                    out[on] = 'TypeError'
+                if on:
+                    stats = dict(bo.fdBatchingStats)
+                    # the rows the batch holds against the closure evaluated on its own
+                    x = bo.generateGuess(std=0.2, seed=9)
+                    plain, _, _, _ = build(kind, False)
+                    monkeypatch.delenv("OBTG_FD_BATCHING", raising=False)
+                    pairs = [(bo.temporalSeparationConstraints, plain.temporalSeparationConstraints),
+                             (bo.objectiveFunction, plain.objectiveFunction)]
+                    if kind[0] != 'swarm':
+                        pairs += [(bo.maxSpeedConstraints, plain.maxSpeedConstraints),
+                                  (bo.maxAngularRateConstraints, plain.maxAngularRateConstraints)]
+                    for f_on, f_off in pairs:
+                        assert np.array_equal(f_on(x), f_off(x))
+                        for k in range(x.size):
+                            xk = x.copy()
+                            xk[k] += FD_STEP
+                            assert np.array_equal(f_on(xk), f_off(xk)), (kind, R, k)
+            if isinstance(out[True], str) or isinstance(out[False], str):
+                assert out[True] == out[False], (kind, R)
+                continue
+            assert np.array_equal(out[True][0], out[False][0]), (kind, R, "SLSQP ended at another x")
+            assert out[True][1:] == out[False][1:], (kind, R, out[True][1:], out[False][1:])
+            assert stats['served'] > 5 * stats['batches'] > 0, (kind, R, stats)
+    finally:
+        opt.DEG_ELEV = 0
