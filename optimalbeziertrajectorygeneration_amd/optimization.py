@@ -396,6 +396,9 @@ class BezOptimization(object):
         returns shape (P, 3): (dist, t1, t2) - maxSep, as the reference does.
         robust=True: true minimum distances (obtg_min_dist_robust) instead of the reference's `_minDist`;
         pairs whose search budget runs out (curves coinciding over a stretch) report their best upper bound."""
+        return self._serve('spatial_robust' if robust else 'spatial', x, lambda x_: self._spatial_direct(x_, robust))
+
+    def _spatial_direct(self, x, robust):
         numVeh, dim, maxSep = self.model['numVeh'], self.model['dim'], self.model['maxSep']
         y = self.reshapeVector(x)
         curves = [bez.Bezier(y[i * dim:(i + 1) * dim, :]) for i in range(numVeh)] + list(self.shapeObstacles)
@@ -407,6 +410,26 @@ class BezOptimization(object):
         r = _capi.scratch_context().min_dist(stack, pa, pb, eps=1e-9, max_depth=128, max_nodes=4000000)
         _raise_first_md(r['status'])
         return r['res'] - maxSep
+
+    def _spatial_fd_values(self, x, robust):
+        """F[k + 1] = spatialSeparationConstraints(x + h e_k), F[0] at x, from ONE device call (spatialSeparationJacobian's plan:
+        the base pairs and, per variable, the pairs its vehicle touches); None when a search of the call does not end -- the
+        closure's own calls then say which, as they always did."""
+        numVeh, dim, maxSep = self.model['numVeh'], self.model['dim'], self.model['maxSep']
+        X, _ = self._fd_rows(x)
+        Y = self.reshapeVectors(X)
+        obstacles = list(self.shapeObstacles) if self.shapeObstacles is not None else []
+        stack, pa, pb, P, t_col, t_row, t_pos = _spatial_jac_plan(Y, numVeh, dim, [c._padded() for c in obstacles])
+        if robust:
+            res = _capi.scratch_context().min_dist_robust(stack, pa, pb, eps=1e-9, max_nodes=400000)['res']
+        else:
+            r = _capi.scratch_context().min_dist(stack, pa, pb, eps=1e-9, max_depth=128, max_nodes=4000000)
+            if np.any(r['status'] != _capi.MD_OK):
+                return None
+            res = r['res']
+        F = np.repeat((res[:P] - maxSep)[None], X.shape[0], axis=0)          # [n_x + 1][P][3]
+        F[t_col + 1, t_row] = res[t_pos] - maxSep
+        return F
 
     def spatialSeparationJacobian(self, x, robust=False, column=None, on_cap='raise'):
         """SciPy's 2-point Jacobian of `spatialSeparationConstraints` from ONE device call.  The reference hands the
@@ -471,7 +494,8 @@ class BezOptimization(object):
         x = np.asarray(x, dtype=float)
         key = (int(DEG_ELEV), self.separationRows, self.activeRows, self._rv_parts_key(), self.model['maxSep'], self.model['maxSpeed'],
                self.model['minSpeed'], self.model['maxAngRate'], None if self._timeopt() else self.model['tf'],
-               None if self.pointObstacles is None else np.asarray(self.pointObstacles, dtype=float).tobytes())
+               None if self.pointObstacles is None else np.asarray(self.pointObstacles, dtype=float).tobytes(),
+               None if self.shapeObstacles is None else tuple(np.asarray(c.cpts, dtype=float).tobytes() for c in self.shapeObstacles))
         st = self._fd_state
         if st is None or st['key'] != key or st['x0'].shape != x.shape:
             st = self._fd_state = {'key': key, 'x0': x.copy(), 'base': {}, 'rows': {}}
@@ -496,6 +520,10 @@ class BezOptimization(object):
                 limit = float(os.environ.get("OBTG_FD_BATCH_MB", "256")) * 2.0 ** 20
                 if base is None or 8.0 * base.size * (x.size + 1) > limit:
                     rows = st['rows'][family] = False        # (too large, or a closure without rows: evaluate directly)
+                elif family.startswith('spatial'):
+                    rows = self._spatial_fd_values(st['x0'], family == 'spatial_robust')
+                    rows = st['rows'][family] = False if rows is None else rows
+                    self.fdBatchingStats['batches'] += rows is not False
                 else:
                     rows = st['rows'][family] = self._fd_values(st['x0'], family)[0]
                     self.fdBatchingStats['batches'] += 1

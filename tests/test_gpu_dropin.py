@@ -234,7 +234,7 @@ def test_spatial_separation_jacobian(golden_dir):
         nveh, dim, deg, max_sep = s[name + "_par"]
         bo = BezOptimization(numVeh=2, dimension=int(dim), degree=int(deg), minimizeGoal='Euclidean', maxSep=float(max_sep),
                              initPoints=s[name + "_init"], finalPoints=s[name + "_final"],
-                             shapeObstacles=[Bezier(s[name + "_obs"].copy())])
+                             shapeObstacles=[Bezier(s[name + "_obs"].copy())], fdBatching=False)   # (the closure on its own, row by row)
         x = s[name + "_x"]
         J = bo.spatialSeparationJacobian(x, on_cap='nan')
         F0 = bo.spatialSeparationConstraints(x)
@@ -831,5 +831,36 @@ def test_scipy_finite_differences_served_from_one_batch(monkeypatch):
             assert np.array_equal(out[True][0], out[False][0]), (kind, R, "SLSQP ended at another x")
             assert out[True][1:] == out[False][1:], (kind, R, out[True][1:], out[False][1:])
             assert stats['served'] > 5 * stats['batches'] > 0, (kind, R, stats)
+        # the shape-obstacle constraint (Examples/DrivingOnATrack.py hands spatialSeparationConstraints to SLSQP as it is)
+        opt.DEG_ELEV = 0
+        from optimalbeziertrajectorygeneration_amd.bezier import Bezier
+        rng = np.random.default_rng(3)
+        for dim in (2, 3):
+            obs = [Bezier(np.vstack([np.linspace(0, 10, 6) + rng.normal(0, 0.3, 6), np.full(6, 4.0 + o) + rng.normal(0, 0.3, 6)] +
+                                    ([np.linspace(1, 3, 6)] if dim == 3 else []))) for o in (0.0, 3.0)]
+            kws = dict(numVeh=2, dimension=dim, degree=5, minimizeGoal='Euclidean', maxSep=0.5,
+                       initPoints=[[0.0, 0.0] + [0.0] * (dim - 2), [0.0, 9.0] + [1.0] * (dim - 2)],
+                       finalPoints=[[10.0, 9.0] + [2.0] * (dim - 2), [10.0, 0.0] + [0.0] * (dim - 2)], shapeObstacles=obs)
+            monkeypatch.delenv("OBTG_FD_BATCHING", raising=False)
+            b_on, b_off = BezOptimization(**kws), BezOptimization(fdBatching=False, **kws)
+            x = b_on.generateGuess(std=0.4, seed=6)
+            try:
+                F_off = b_off.spatialSeparationConstraints(x)
+            except (RuntimeError, RecursionError):
+                continue
+            assert np.array_equal(b_on.spatialSeparationConstraints(x), F_off)
+            n_ok = 0
+            for k in range(x.size):
+                xk = x.copy()
+                xk[k] += FD_STEP
+                try:
+                    ref = b_off.spatialSeparationConstraints(xk)
+                except (RuntimeError, RecursionError):
+                    with pytest.raises((RuntimeError, RecursionError)):
+                        b_on.spatialSeparationConstraints(xk)
+                    continue
+                assert np.array_equal(b_on.spatialSeparationConstraints(xk), ref), (dim, k)
+                n_ok += 1
+            assert n_ok > x.size // 2
     finally:
         opt.DEG_ELEV = 0
