@@ -487,7 +487,7 @@ class BezOptimization(object):
         forms, formed on the device from x0), kept, and this and the following calls are answered from it.  A call at any other
         point is a new base (a line-search step, the next iterate) and drops the batches.  Values are those of the one-row call,
         element for element (tests/test_gpu_dropin.py::test_scipy_finite_differences_served_from_one_batch: SLSQP takes the same
-        iterates either way).  Batches above OBTG_FD_BATCH_MB (256) per closure are not formed; steps SciPy turned around at a
+        iterates either way).  Batches above OBTG_FD_BATCH_MB (512) per closure are not formed; steps SciPy turned around at a
         bound (x0 - h) are evaluated directly."""
         if not self.fdBatching:
             return direct(x)
@@ -517,7 +517,7 @@ class BezOptimization(object):
                 if base is None:
                     base = st['base'][family] = direct(st['x0'])
                     self.fdBatchingStats['direct'] += 1
-                limit = float(os.environ.get("OBTG_FD_BATCH_MB", "256")) * 2.0 ** 20
+                limit = float(os.environ.get("OBTG_FD_BATCH_MB", "512")) * 2.0 ** 20
                 if base is None or 8.0 * base.size * (x.size + 1) > limit:
                     rows = st['rows'][family] = False        # (too large, or a closure without rows: evaluate directly)
                 elif family.startswith('spatial'):
