@@ -184,3 +184,66 @@ def test_spatial_jacobian_call_plan_is_the_loop_form():
         assert np.array_equal(stack, np.stack(curves))
         assert np.array_equal(pa, lpa) and np.array_equal(pb, lpb)
         assert [tuple(t) for t in zip(col.tolist(), row.tolist(), pos.tolist())] == trip
+
+
+def test_fd_serving_logic_without_a_device(monkeypatch):
+    """BezOptimization._serve on the host alone (the closure and its batch are stand-ins): a sweep of SciPy's forward differences is
+    answered from one batch; a step SciPy turned around at a bound, or any other one-variable change, is evaluated directly without
+    dropping the batch; a point that differs in several variables is a new base; a changed model entry drops everything; the
+    switch and the size limit are honoured."""
+    from optimalbeziertrajectorygeneration_amd import optimization as opt
+    from optimalbeziertrajectorygeneration_amd.optimization import BezOptimization, FD_STEP
+    monkeypatch.delenv("OBTG_FD_BATCHING", raising=False)
+    kws = dict(numVeh=2, dimension=2, degree=5, minimizeGoal='Euclidean', maxSep=0.9, initPoints=[[0, 0], [1, 5]], finalPoints=[[9, 9], [8, 0]])
+    bo = BezOptimization(**kws)
+    calls = {'direct': 0, 'batch': 0}
+
+    def direct(x):
+        calls['direct'] += 1
+        return np.array([x.sum(), (x * x).sum(), x[0] - x[-1]])
+
+    def fake_fd_values(x, family):
+        calls['batch'] += 1
+        X, dx = bo._fd_rows(x)
+        return np.stack([np.array([r.sum(), (r * r).sum(), r[0] - r[-1]]) for r in X]), dx
+    monkeypatch.setattr(bo, "_fd_values", fake_fd_values)
+    x0 = bo.generateGuess(std=0.1, seed=1)
+    nx = x0.size
+    assert np.array_equal(bo._serve('tsep', x0, direct), direct(x0))
+    calls['direct'] = 0
+    for k in range(nx):                                      # the sweep: one batch, no direct call
+        xk = x0.copy(); xk[k] += FD_STEP
+        want = np.array([xk.sum(), (xk * xk).sum(), xk[0] - xk[-1]])
+        assert np.array_equal(bo._serve('tsep', xk, direct), want)
+    assert calls == {'direct': 0, 'batch': 1} and bo.fdBatchingStats['served'] == nx
+    got = bo._serve('tsep', x0, direct)                      # the base again: kept
+    got[0] = 1e9                                             # (a caller may scribble on what it gets)
+    assert calls['direct'] == 0 and bo._serve('tsep', x0, direct)[0] != 1e9
+    xb = x0.copy(); xb[3] -= FD_STEP                         # a step turned around at a bound: direct, the batch stays
+    bo._serve('tsep', xb, direct)
+    xk = x0.copy(); xk[2] += FD_STEP
+    bo._serve('tsep', xk, direct)
+    assert calls == {'direct': 1, 'batch': 1}
+    x1 = x0 + 0.01                                           # the next iterate: a new base, then its own batch
+    bo._serve('tsep', x1, direct)
+    xk = x1.copy(); xk[0] += FD_STEP
+    bo._serve('tsep', xk, direct)
+    assert calls == {'direct': 2, 'batch': 2}
+    bo.model['maxSep'] = 1.1                                 # a driver edits the model between solves: nothing stale is served
+    bo._serve('tsep', xk, direct)
+    assert calls['direct'] == 3
+    # the limit: a batch that would be too large is not formed
+    monkeypatch.setenv("OBTG_FD_BATCH_MB", "0.00001")
+    bo2 = BezOptimization(**kws)
+    monkeypatch.setattr(bo2, "_fd_values", fake_fd_values)
+    bo2._serve('tsep', x0, direct)
+    n0 = calls['batch']
+    for k in range(3):
+        xk = x0.copy(); xk[k] += FD_STEP
+        bo2._serve('tsep', xk, direct)
+    assert calls['batch'] == n0 and bo2.fdBatchingStats['served'] == 0
+    # the switch
+    monkeypatch.setenv("OBTG_FD_BATCHING", "0")
+    assert BezOptimization(**kws).fdBatching is False and BezOptimization(fdBatching=True, **kws).fdBatching is False
+    monkeypatch.delenv("OBTG_FD_BATCHING")
+    assert BezOptimization(fdBatching=False, **kws).fdBatching is False
