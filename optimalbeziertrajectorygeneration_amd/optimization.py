@@ -492,56 +492,61 @@ class BezOptimization(object):
         if not self.fdBatching:
             return direct(x)
         x = np.asarray(x, dtype=float)
-        key = (int(DEG_ELEV), self.separationRows, self.activeRows, self._rv_parts_key(), self.model['maxSep'], self.model['maxSpeed'],
-               self.model['minSpeed'], self.model['maxAngRate'], None if self._timeopt() else self.model['tf'],
-               None if self.pointObstacles is None else np.asarray(self.pointObstacles, dtype=float).tobytes(),
-               None if self.shapeObstacles is None else tuple(np.asarray(c.cpts, dtype=float).tobytes() for c in self.shapeObstacles))
         st = self._fd_state
-        if st is None or st['key'] != key or st['x0'].shape != x.shape:
-            st = self._fd_state = {'key': key, 'x0': x.copy(), 'base': {}, 'rows': {}}
-        d = np.flatnonzero(x != st['x0'])
+        d = None
+        if st is not None and st['x0'].shape == x.shape:
+            d = np.flatnonzero(x != st['x0'])
+            if d.size > 1 or st['key'] != self._serve_key(True):      # several variables moved, or the problem was edited: a new base
+                st = None
+        else:
+            st = None
+        if st is None:
+            self.fdBatchingStats['direct'] += 1
+            v = direct(x)
+            # (the key after the evaluation: reshapeVector has just refreshed the model's byte key, nothing is computed twice)
+            self._fd_state = {'key': self._serve_key(False), 'x0': x.copy(), 'base': {family: v}, 'rows': {}}
+            return None if v is None else v.copy()
         if d.size == 0:
             if family not in st['base']:
                 self.fdBatchingStats['direct'] += 1
                 st['base'][family] = direct(x)
             v = st['base'][family]
             return None if v is None else v.copy()
-        if d.size == 1:
-            k = int(d[0])
-            if x[k] != st['x0'][k] + FD_STEP:
-                self.fdBatchingStats['direct'] += 1          # (a step turned around at a bound, or not SciPy's at all)
-                return direct(x)
-            rows = st['rows'].get(family)
-            if rows is None:
-                base = st['base'].get(family)
-                if base is None:
-                    base = st['base'][family] = direct(st['x0'])
-                    self.fdBatchingStats['direct'] += 1
-                limit = float(os.environ.get("OBTG_FD_BATCH_MB", "512")) * 2.0 ** 20
-                if base is None or 8.0 * base.size * (x.size + 1) > limit:
-                    rows = st['rows'][family] = False        # (too large, or a closure without rows: evaluate directly)
-                elif family.startswith('spatial'):
-                    rows = self._spatial_fd_values(st['x0'], family == 'spatial_robust')
-                    rows = st['rows'][family] = False if rows is None else rows
-                    self.fdBatchingStats['batches'] += rows is not False
-                else:
-                    rows = st['rows'][family] = self._fd_values(st['x0'], family)[0]
-                    self.fdBatchingStats['batches'] += 1
-            if rows is False:
+        k = int(d[0])
+        if x[k] != st['x0'][k] + FD_STEP:
+            self.fdBatchingStats['direct'] += 1              # (a step turned around at a bound, or not SciPy's at all)
+            return direct(x)
+        rows = st['rows'].get(family)
+        if rows is None:
+            base = st['base'].get(family)
+            if base is None:
+                base = st['base'][family] = direct(st['x0'])
                 self.fdBatchingStats['direct'] += 1
-                return direct(x)
-            self.fdBatchingStats['served'] += 1
-            return rows[k + 1].copy()
-        # a new base point
-        st = self._fd_state = {'key': key, 'x0': x.copy(), 'base': {}, 'rows': {}}
-        self.fdBatchingStats['direct'] += 1
-        st['base'][family] = direct(x)
-        v = st['base'][family]
-        return None if v is None else v.copy()
+            limit = float(os.environ.get("OBTG_FD_BATCH_MB", "512")) * 2.0 ** 20
+            if base is None or 8.0 * base.size * (x.size + 1) > limit:
+                rows = st['rows'][family] = False            # (too large, or a closure without rows: evaluate directly)
+            elif family.startswith('spatial'):
+                rows = self._spatial_fd_values(st['x0'], family == 'spatial_robust')
+                rows = st['rows'][family] = False if rows is None else rows
+                self.fdBatchingStats['batches'] += rows is not False
+            else:
+                rows = st['rows'][family] = self._fd_values(st['x0'], family)[0]
+                self.fdBatchingStats['batches'] += 1
+        if rows is False:
+            self.fdBatchingStats['direct'] += 1
+            return direct(x)
+        self.fdBatchingStats['served'] += 1
+        return rows[k + 1].copy()
 
-    def _rv_parts_key(self):
-        self._rv_parts()
-        return self._rv_cache[0]
+    def _serve_key(self, refresh):
+        """What a kept batch depends on besides x: DEG_ELEV, the row options, the model (its arrays by their bytes: the key
+        reshapeVector keeps; refresh = recompute it now), the bounds' values, the obstacles."""
+        if refresh or getattr(self, '_rv_cache', None) is None:
+            self._rv_parts()
+        return (int(DEG_ELEV), self.separationRows, self.activeRows, self._rv_cache[0], self.model['maxSep'], self.model['maxSpeed'],
+                self.model['minSpeed'], self.model['maxAngRate'], None if self._timeopt() else self.model['tf'],
+                None if self.pointObstacles is None else np.asarray(self.pointObstacles, dtype=float).tobytes(),
+                None if self.shapeObstacles is None else tuple(np.asarray(c.cpts, dtype=float).tobytes() for c in self.shapeObstacles))
 
     def _jac(self, x, family):
         F, dx = self._fd_values(x, family)
