@@ -71,7 +71,7 @@ def parse():
     ap.add_argument("--fd-dedup", action="store_true",
                     help="reuse row 0's gjkNew results for bit-identical hull pairs (obtg_ctx_set_fd_dedup); "
                          "NOT the headline number")
-    ap.add_argument("--mode", default="batch", choices=["batch", "rows", "pairs", "mindist"],
+    ap.add_argument("--mode", default="batch", choices=["batch", "rows", "pairs", "mindist", "c1text"],
                     help="batch: every rank evaluates its own FD batch, no collective (default, the headline); "
                          "rows: ONE swarm, ONE SLSQP iteration -- its n_x + 1 rows split over the ranks by distributed.shard_rows "
                          "(SURVEY.md 8(e).1), every rank an obtg_fd_view_begin_rows over its range, results left per rank, no "
@@ -107,6 +107,17 @@ def parse():
     ap.add_argument("--no-proxy", action="store_true", help="skip the strong_scaling_proxy leg of a 1-GPU batch-mode run")
     ap.add_argument("--one-device", action="store_true",
                     help="rehearsal only: every rank uses device 0 (needs --backend gloo)")
+    ap.add_argument("--no-configs", action="store_true",
+                    help="1-GPU C3 batch-mode run: skip the `configs` block (every other BASELINE.json configuration measured by a "
+                         "child process of this run: C1_text, C2, C2_file, C4, C5, C5_mindist -- ms per step, the dominant kernel's "
+                         "HIP-event duration, algorithmic bytes, fraction of the HBM peak, parity against the oracle on sampled rows)")
+    ap.add_argument("--config-leg", action="store_true",
+                    help="this process IS one leg of another run's `configs` block: no variants, no proxy, no NumPy baseline, no "
+                         "measured-peaks leg, bounded CPU legs")
+    ap.add_argument("--all-modes", action="store_true", default=os.environ.get("OBTG_BENCH_ALL_MODES") == "1",
+                    help="batch mode with --gpus > 1: after the weak line's own timed region, run `--mode rows --gather-minima` (ONE "
+                         "SLSQP iteration's rows over the ranks, sparse minima all-gather: `scaling` strong) for C3 and for C4 in the "
+                         "same processes and carry both in the line's `modes` -- one command, both curves (also OBTG_BENCH_ALL_MODES=1)")
     return ap.parse_args()
 
 
@@ -195,6 +206,45 @@ def algorithmic_bytes(N, d, n, R, P_t, P_s, sumK):
     return by, total
 
 
+COUNTERS_PATH = os.path.join(REPO, "profiles", "counters.json")
+_KERNEL_UNIT = {"pair_sweep": "gjk_kernels", "gjk": "gjk_kernels", "min_dist": "gjk_kernels", "temporal_sep": "bern_kernels",
+                "speed": "bern_kernels", "ang_rate": "bern_kernels", "fd_batch": "bern_kernels"}
+
+
+def _source_hash(_capi, unit):
+    """obtg_source_hash of the LOADED library for a compile unit (what the running kernels were built from)."""
+    try:
+        return _capi.source_hash(unit)
+    except Exception:
+        return None
+
+
+def counters_for(workload, kernel, running_hash, path=None):
+    """The committed hardware-counter figures of (workload, kernel) -- HBM bytes per launch from the FETCH_SIZE / WRITE_SIZE
+    passes, VALU wave-instructions and busy fraction from the SQ passes (profiles/counters.json, written by
+    tools/r06_counters.py from rocprofv3 --pmc output) -- IF they were taken on the kernels that are running now: every
+    entry records the obtg_source_hash of its compile unit, the tree it was taken on and the file the raw pass is kept in.
+    An entry whose hash is not `running_hash` is NOT reported: {"stale": True, ...} without figures (the line then says
+    that counters exist but belong to other kernels); no entry at all: None."""
+    path = path or COUNTERS_PATH
+    try:
+        entries = json.load(open(path)).get("entries", [])
+    except (OSError, ValueError):
+        return None
+    hits = [e for e in entries if e.get("workload") == workload and e.get("kernel") == kernel]
+    if not hits:
+        return None
+    for e in hits:
+        if running_hash is not None and e.get("source_hash") == running_hash:
+            out = dict(e)
+            out["matches_running_library"] = True
+            return out
+    e = hits[-1]
+    return {"stale": True, "matches_running_library": False, "taken_on_source_hash": e.get("source_hash"), "running_source_hash": running_hash,
+            "tree": e.get("tree"), "source": e.get("source"),
+            "note": "counter figures exist but were taken on other kernel sources: not reported"}
+
+
 def measured_peaks(torch, dev):
     """This box's achievable HBM rates with stock kernels (tools/bw_probe.py): device copy (read + write
     bytes) and fill (write only), 1 GiB each -- well past the 256 MB Infinity Cache."""
@@ -237,7 +287,6 @@ def main():
 
     import torch
     import torch.distributed as dist
-    from optimalbeziertrajectorygeneration_amd import _capi, synth
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
@@ -256,9 +305,53 @@ def main():
             dist.init_process_group(args.backend)
         if dist.get_world_size() != args.gpus:
             raise SystemExit("bench.py: process group of %d ranks for --gpus %d" % (dist.get_world_size(), args.gpus))
+    env = dict(rank=rank, world=world, local_rank=local_rank, use_dist=use_dist)
 
     if args.mode == "mindist":
-        return mindist_mode(args, rank)
+        mindist_mode(args, rank)
+    elif args.mode == "c1text":
+        c1_text_mode(args, rank)
+    else:
+        line = step_bench(args, env)
+        if line is not None and args.mode == "batch" and args.all_modes and world > 1:
+            # the other curve, in the same processes: ONE iteration's rows over the ranks with the sparse minima gather, C3 and C4.
+            # Every rank takes part (the step has a collective); only rank 0 holds the lines.
+            import copy
+            modes = {}
+            for wl in ("C3", "C4"):
+                a2 = copy.copy(args)
+                a2.mode, a2.workload, a2.gather_minima, a2.no_cpu, a2.batch = "rows", wl, "sparse", True, 0
+                a2.steps = args.steps if wl == "C3" else max(3, min(args.steps, 10))
+                a2.warmup = args.warmup if wl == "C3" else max(1, min(args.warmup, 2))
+                l2 = step_bench(a2, env)
+                if l2 is not None and l2.get("value") is not None:
+                    modes["rows_" + wl] = {k: l2.get(k) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "scaling",
+                                                                  "config", "roofline", "kernels")}
+            if rank == 0:
+                line["modes"] = modes
+        if rank == 0 and line is not None and line.get("value") is not None:
+            if (args.workload == "C3" and args.mode == "batch" and world == 1 and not args.no_configs and not args.config_leg
+                    and not args.no_cpu and not args.batch):
+                line["configs"] = config_legs(args)
+            print(json.dumps(line))
+            sys.stdout.flush()
+        if use_dist:
+            dist.destroy_process_group()
+        par = (line or {}).get("parity_check")
+        if par is not None and not par["ok"]:
+            raise SystemExit("bench.py: the timed step's device buffers DISAGREE with the oracle: %s" % json.dumps(par))
+        return
+    if use_dist:
+        dist.destroy_process_group()
+
+
+def step_bench(args, env):
+    """One timed run of the step (modes batch / rows / pairs) inside the process group main() set up; rank 0 gets the line
+    (a dict), the other ranks None."""
+    import torch
+    import torch.distributed as dist
+    from optimalbeziertrajectorygeneration_amd import _capi, synth
+    rank, world, local_rank, use_dist = env["rank"], env["world"], env["local_rank"], env["use_dist"]
 
     cfg = dict(synth.CONFIGS[args.workload])
     N, d, n, R = cfg["N"], cfg["d"], cfg["n"], cfg["R"]
@@ -306,6 +399,7 @@ def main():
 
     if args.mode == "pairs":
         return pairs_mode(args, ctx, dist, world, rank, dev, dY, B, max_sep, barrier, pa, pb, use_gjk, use_dist)
+    lean = args.config_leg          # a leg of another run's `configs` block: the headline figures only
 
     d_tf = torch.full((B,), tfv, dtype=f64, device=dev)
     o_sep = torch.empty((B, P_t * L), dtype=f64, device=dev)
@@ -534,7 +628,7 @@ def main():
     nv = max(args.steps, 200)
     nv = max(20, min(nv, int(2000.0 / max(1e3 * elapsed / args.steps, 1e-3))))      # (a 26 ms step: 76 steps per run, not 500)
     can_structured = everything and o_an is not None and row_begin == 0
-    if use_view and use_gjk and args.mode == "batch" and not args.no_variants:
+    if use_view and use_gjk and args.mode == "batch" and not args.no_variants and not lean:
         variants = {}
         ctx.set_gjk_history(False)
         variants["history_off"] = entry(timed(nv, lambda i: step_at(d0.data_ptr())), B,
@@ -578,8 +672,10 @@ def main():
                 kms, kcnt = kstats().get("pair_sweep", (0.0, 0))
                 prof(False)
                 gbs = B * total_bytes_ / ((kms / max(kcnt, 1)) * 1e-3) / 1e9 if kcnt else None
+                s_cnt = counters_for(args.workload + "_fd_structured", "pair_sweep", _source_hash(_capi, "gjk_kernels"))
                 variants["fd_structured"] = entry(
-                    t_ms, B, kernel_avg_ms=round(kms / max(kcnt, 1), 5), launches_per_step=1,
+                    t_ms, B, kernel_avg_ms=round(kms / max(kcnt, 1), 5), launches_per_step=1, counters=s_cnt,
+                    bound="hbm (stores): the launch moves its bytes at the box's write-only rate, DESIGN.md 4.10",
                     alg_bytes_per_launch=B * total_bytes_, achieved_gbs=round(gbs, 2) if gbs else None,
                     frac=round(gbs / HBM_PEAK_GBS, 5) if gbs else None, parity=s_par,
                     what="row 0 evaluated in full and streamed into all rows; per row only the N-1 separation pairs, "
@@ -592,7 +688,7 @@ def main():
     # the first ceil(B / G) rows of the same view, G = 1, 2, 4, 8 (the rows every rank of `--mode rows` would own, up to
     # which vehicle they perturb).  efficiency = t(B) / (G t(B / G)): the speed-up G GPUs would show over one, divided by
     # G, if nothing but the kernels' small-batch behaviour stood in the way (no collective on this path).
-    if use_view and use_gjk and args.mode == "batch" and world == 1 and not args.no_proxy and not args.no_variants:
+    if use_view and use_gjk and args.mode == "batch" and world == 1 and not args.no_proxy and not args.no_variants and not lean:
         proxy = {"rows": [], "what": "the step on the first ceil(B / G) rows of the view; efficiency = t(B) / (G t(B/G))"}
         base = {}
         for G in (1, 2, 4, 8):
@@ -650,13 +746,24 @@ def main():
                             alg_bytes_per_launch=B * by[name], achieved_gbs=round(gbs, 2),
                             frac=round(gbs / HBM_PEAK_GBS, 5)))
     dom = max(kernels, key=lambda k: k["avg_ms"])
-    traffic = None
-    tpath = os.path.join(REPO, "profiles", "traffic.json")   # PMC-derived HBM bytes per launch (see profiles/README.md)
-    if os.path.exists(tpath):
-        try:
-            traffic = json.load(open(tpath)).get(args.workload, {}).get(dom["kernel"])
-        except Exception:
-            traffic = None
+    # hardware counters of the dominant kernel, from the committed passes -- only when they were taken on THESE kernels
+    cnt = counters_for(args.workload, dom["kernel"], _source_hash(_capi, _KERNEL_UNIT.get(dom["kernel"], "all")))
+    traffic = traffic_source = issue = None
+    bound = "hbm"
+    if cnt is not None and not cnt.get("stale"):
+        traffic = cnt.get("hbm_bytes_per_launch")
+        traffic_source = {k: cnt.get(k) for k in ("source", "tree", "unit", "source_hash", "matches_running_library", "kernel_symbol")}
+        if cnt.get("valu_wave_insts") is not None:
+            issue = {"valu_wave_insts": cnt.get("valu_wave_insts"), "busy_frac": cnt.get("valu_busy_frac"),
+                     "lds_bank_conflict_frac": cnt.get("lds_bank_conflict_frac"),
+                     "busy_frac_what": "SQ_INSTS_VALU x 4 clocks / (1024 SIMDs x the launch's clocks): the share of the chip's FP64-rate issue slots the launch fills",
+                     "source": cnt.get("source_issue", cnt.get("source")), "tree": cnt.get("tree"), "source_hash": cnt.get("source_hash")}
+            # which roof binds: the counters decide.  A launch that fills more of its issue slots than of the HBM peak is
+            # bound by issue (the bit-exact gjkNew state machine), not by bytes
+            if cnt.get("valu_busy_frac") is not None and cnt["valu_busy_frac"] > max(dom["frac"], 0.5):
+                bound = "valu_issue"
+    elif cnt is not None:
+        traffic_source = cnt
     note = None
     if dom["kernel"] == "pair_sweep":
         note = ("one launch: the gjkNew sweep's workgroups (VALU bound) also write their row's temporal-separation "
@@ -668,11 +775,15 @@ def main():
     if dom["kernel"] == "gjk":
         note = ("gjkNew sweep: VALU-issue bound by nature (PMC at C3: ~85 % VALU busy, LDS 34 %), reported against "
                 "HBM as the contract asks; see DESIGN.md 4.3")
-    copy_gbs, fill_gbs = measured_peaks(torch, dev)
-    roofline = dict(bound="hbm", kernel=dom["kernel"], achieved=dom["achieved_gbs"], peak=HBM_PEAK_GBS,
-                    unit="GB/s", frac=dom["frac"], traffic=traffic,
-                    peak_measured=round(copy_gbs, 1), frac_measured=round(dom["achieved_gbs"] / copy_gbs, 5),
-                    peak_measured_write_only=round(fill_gbs, 1),
+    copy_gbs, fill_gbs = measured_peaks(torch, dev) if not lean else (float("nan"), float("nan"))
+    roofline = dict(bound=bound, kernel=dom["kernel"], achieved=dom["achieved_gbs"], peak=HBM_PEAK_GBS,
+                    unit="GB/s", frac=dom["frac"], traffic=traffic, traffic_source=traffic_source, issue=issue,
+                    bound_note=("achieved / peak / frac are the HBM figures the contract asks for; `bound` names the roof the "
+                                "counters say binds this launch (valu_issue: the launch fills a larger share of the chip's VALU "
+                                "issue slots than of the HBM peak -- DESIGN.md 4.7)"),
+                    peak_measured=round(copy_gbs, 1) if not lean else None,
+                    frac_measured=round(dom["achieved_gbs"] / copy_gbs, 5) if not lean else None,
+                    peak_measured_write_only=round(fill_gbs, 1) if not lean else None,
                     peak_measured_note="this box, torch copy_ (read+write bytes) / fill_ of 1 GiB, HIP events",
                     note=note, step_achieved=round(B * total_bytes / (ms_per_step * 1e-3) / 1e9, 2))
 
@@ -681,7 +792,8 @@ def main():
         parity = parity_check(snap, N, d, n, R, statics, pa, pb, use_gjk, max_sep, vmax, wmax, tfv)
         parity["status_nonok"] = status_nonok
         cpu = cpu_baseline(args, N, d, n, R, Y, statics, pa, pb, use_gjk, max_sep, vmax, wmax, tfv)
-        cpu_np = cpu_baseline_numpy(N, d, n, R, Y, statics, pa, pb, use_gjk, max_sep, vmax, wmax, tfv)
+        if not lean:
+            cpu_np = cpu_baseline_numpy(N, d, n, R, Y, statics, pa, pb, use_gjk, max_sep, vmax, wmax, tfv)
 
     # --mode rows: a checksum over EVERY rank's rows (each rank sums its own, the sums travel as objects): the same figures
     # from one rank and from G ranks say that the row ranges tile the iteration
@@ -791,12 +903,12 @@ def main():
             "cpu_baseline": cpu,
             "cpu_baseline_numpy": cpu_np,
         }
-        print(json.dumps(line))
-        sys.stdout.flush()
-    if use_dist:
-        dist.destroy_process_group()
-    if parity is not None and not parity["ok"]:
-        raise SystemExit("bench.py: the timed step's device buffers DISAGREE with the oracle: %s" % json.dumps(parity))
+        for cx in ctxs:
+            cx.close()
+        return line
+    for cx in ctxs:
+        cx.close()
+    return None
 
 
 def parity_snapshot(dev_out, B):
@@ -926,7 +1038,7 @@ def pairs_mode(args, ctx, dist, world, rank, dev, dY, B, max_sep, barrier, pa, p
         chk["gjk_dist_nansum"] = sum(m[0] for m in allm)
         chk["gjk_flag_sum"] = sum(m[1] for m in allm)
     if rank == 0:
-        print(json.dumps({
+        return ({
             "metric": "pair-partitioned evals/s (one evaluation batch across all GPUs: pair lists split over the ranks, "
                       "separation minima in one RCCL all-gather)",
             "value": round(B * args.steps / elapsed, 2), "unit": "constraint-evals/s", "n_gpus": world,
@@ -935,9 +1047,67 @@ def pairs_mode(args, ctx, dist, world, rank, dev, dY, B, max_sep, barrier, pa, p
             "config": {"workload": "%s: %d temporal-separation pairs + %d gjkNew hull pairs split over %d ranks, "
                                    "B=%d rows" % (args.workload, ctx.num_pairs, len(pa) if use_gjk else 0, world, B),
                        "ranks_seen": ranks_seen, "backend": (args.backend if use_dist else None), "devices": devices,
-                       "allgather_bytes": allgather_bytes, "checksum": chk}}))
-    if use_dist:
-        dist.destroy_process_group()
+                       "allgather_bytes": allgather_bytes, "checksum": chk}})
+    return None
+
+
+def mindist_jacobian_plan(N=64, M=32, n=10, seed=1234):
+    """The ONE `obtg_min_dist` call spatialSeparationJacobian makes for a C5-sized problem (64 vehicles + 32 curve obstacles,
+    degree 10, n_x = 1152): the C(96, 2) = 4560 base pairs plus, per variable, the N + M - 1 = 95 pairs of the vehicle it
+    advances -- 1152 x 95 + 4560 = 114 000 searches on 96 + 1152 curves (optimization._spatial_jac_plan, the provider's own
+    plan; Examples/ComplexObstacles.py:49-63 hands the bare constraint to SLSQP: n_x + 1 all-pairs sweeps per iteration)."""
+    from optimalbeziertrajectorygeneration_amd import synth
+    from optimalbeziertrajectorygeneration_amd.optimization import _spatial_jac_plan
+    Y = synth.swarm_control_points(N, 2, n, seed=seed)
+    Yb = synth.fd_batch(Y)                                      # [n_x + 1][N * 2][n + 1]
+    obs = synth.curve_obstacles(M, 2, n, seed=seed).reshape(M, 2, n + 1)
+    obs3 = np.zeros((M, 3, n + 1))
+    obs3[:, :2, :] = obs
+    stack, pa, pb, P, col, row, pos = _spatial_jac_plan(Yb, N, 2, list(obs3))
+    return dict(curves=stack, pa=pa, pb=pb, P=P, col=col, row=row, pos=pos, n_x=Yb.shape[0] - 1)
+
+
+def mindist_parity(O, curves, pa, pb, r, sample, kw):
+    """Sampled pairs of the device's call against the oracle's search of the same pair: (distance, t1, t2) IDENTICAL (bit for
+    bit; NaN where NaN), node counts, gjkNew-call counts, depths and statuses equal."""
+    o = O.min_dist_pairs(curves, pa[sample], pb[sample], nthreads=1, **kw)
+    same_res = bool(np.array_equal(r["res"][sample].view(np.int64), o["res"].view(np.int64)))
+    if not same_res:                                            # (NaN payloads aside)
+        same_res = bool(np.array_equal(r["res"][sample], o["res"], equal_nan=True))
+    eq = {k: bool(np.array_equal(np.asarray(r[k])[sample], np.asarray(o[k]))) for k in ("nodes", "gjk_calls", "depth", "status")}
+    return {"pairs": int(len(sample)), "results_identical": same_res, "node_counts_equal": eq["nodes"],
+            "gjk_call_counts_equal": eq["gjk_calls"], "depths_equal": eq["depth"], "statuses_equal": eq["status"],
+            "ok": bool(same_res and all(eq.values())),
+            "against": "oracle/obtg_oracle.c min_dist_rec (bezier.py:1283-1408) on the same curves, same budgets"}
+
+
+def mindist_cpu_baseline(O, curves, pa, pb, kw, seconds, what):
+    """The oracle's pair loop on a bounded, strided sample of the same pair list: 1 core, then OpenMP on the box's share."""
+    n = len(pa)
+    probe = np.arange(0, n, max(1, n // 64))[:64]
+    t0 = time.perf_counter()
+    O.min_dist_pairs(curves, pa[probe], pb[probe], nthreads=1, **kw)
+    per = (time.perf_counter() - t0) / len(probe)
+    take = int(max(64, min(n, seconds / max(per, 1e-9))))
+    samp = np.arange(0, n, max(1, n // take))[:take]
+    t0 = time.perf_counter()
+    o = O.min_dist_pairs(curves, pa[samp], pb[samp], nthreads=1, **kw)
+    dt = time.perf_counter() - t0
+    out = {"value": round(len(samp) / dt, 2), "unit": "pair searches/s", "evals_per_s": round(len(samp) / dt / n, 5), "cores": 1, "kind": "port",
+           "nodes_per_s": round(float(o["nodes"].sum()) / dt, 1),
+           "sample": "%d of the %d pairs of %s (every %d-th), %.2f s, oracle/obtg_oracle.c -O2" % (len(samp), n, what, max(1, n // take), dt)}
+    try:
+        ncores = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        ncores = os.cpu_count() or 1
+    ncores = max(1, min(ncores, 16))
+    if ncores > 1:
+        t0 = time.perf_counter()
+        O.min_dist_pairs(curves, pa[samp], pb[samp], nthreads=ncores, **kw)
+        dtm = time.perf_counter() - t0
+        out["all_cores"] = {"value": round(len(samp) / dtm, 2), "evals_per_s": round(len(samp) / dtm / n, 5), "cores": ncores,
+                            "sample": "the same %d pairs, OpenMP (dynamic over pairs), %.2f s" % (len(samp), dtm)}
+    return out
 
 
 def mindist_mode(args, rank):
@@ -945,7 +1115,19 @@ def mindist_mode(args, rank):
     spatialSeparationConstraints (optimization.py:109-133) at the ComplexObstacles-style size of C5 -- all
     C(96, 2) pairs of 64 vehicles and 32 curve obstacles -- through the host-buffer entry points, in the
     reference's own algorithm (obtg_min_dist, node budget 2000 per pair: a fifth of the pairs would not
-    finish in the reference either) and in the robust one (obtg_min_dist_robust)."""
+    finish in the reference either) and in the robust one (obtg_min_dist_robust); and, since round 6, at the size an SLSQP
+    ITERATION asks for: the one call of spatialSeparationJacobian (`jacobian_list`: 114 000 searches)."""
+    legs = ("reference_algorithm", "jacobian_list", "curve_polygon_reference_algorithm") if args.config_leg else None
+    line = mindist_line(args, cpu=not args.no_cpu, legs=legs)
+    if rank == 0:
+        print(json.dumps(line))
+        sys.stdout.flush()
+    bad = [k for k, v in line["variants"].items() if isinstance(v, dict) and v.get("parity_check") and not v["parity_check"]["ok"]]
+    if bad:
+        raise SystemExit("bench.py --mode mindist: the device's searches DISAGREE with the oracle's: %s" % bad)
+
+
+def mindist_line(args, cpu=True, legs=None, cpu_seconds=None):
     from optimalbeziertrajectorygeneration_amd import _capi, synth
     N, M, n = 64, 32, 10
     Yc = np.vstack((synth.swarm_control_points(N, 2, n, seed=1234), synth.curve_obstacles(M, 2, n, seed=1234)))
@@ -954,35 +1136,48 @@ def mindist_mode(args, rank):
     pa, pb = synth.all_pairs(N + M)
     ctx = _capi.scratch_context()
     out = {}
-    pmc = {}
-    ppath = os.path.join(REPO, "profiles", "mindist_pmc.json")      # VALU-busy fractions from the committed counter passes
-    if os.path.exists(ppath):
-        try:
-            pmc = json.load(open(ppath))
-        except Exception:
-            pmc = {}
+    cpu_seconds = cpu_seconds if cpu_seconds is not None else args.cpu_seconds
+    # VALU-busy fractions from the committed counter passes -- only those taken on THIS tree's kernels (counters_for)
     # curve <-> polygon (`_minDist2Poly`, bezier.py:1411-1496): the 64 vehicles against 64 polygon obstacles, 4096 pairs
     polys = synth.polygon_obstacles(64, seed=1234)
     ppts, poff = synth.pack_polys(polys)
     pc = np.repeat(np.arange(N), len(polys)).astype(np.int32)
     pp = np.tile(np.arange(len(polys)), N).astype(np.int32)
-    for name, f in (("reference_algorithm", lambda: ctx.min_dist(curves, pa, pb, eps=1e-9, max_depth=128, max_nodes=2000)),
-                    ("robust", lambda: ctx.min_dist_robust(curves, pa, pb, eps=1e-9, max_nodes=400000)),
-                    ("curve_polygon_reference_algorithm", lambda: ctx.min_dist2poly(curves[:N], ppts, poff, pc, pp, eps=1e-6, max_depth=128, max_nodes=2000)),
-                    ("curve_polygon_robust", lambda: ctx.min_dist2poly_robust(curves[:N], ppts, poff, pc, pp, eps=1e-9, max_nodes=200000))):
+    kw_ref = dict(eps=1e-9, max_depth=128, max_nodes=2000)
+    plan = mindist_jacobian_plan(N, M, n)
+    all_legs = (("reference_algorithm", lambda: ctx.min_dist(curves, pa, pb, **kw_ref)),
+                ("jacobian_list", lambda: ctx.min_dist(plan["curves"], plan["pa"], plan["pb"], **kw_ref)),
+                ("robust", lambda: ctx.min_dist_robust(curves, pa, pb, eps=1e-9, max_nodes=400000)),
+                ("jacobian_list_robust", lambda: ctx.min_dist_robust(plan["curves"], plan["pa"], plan["pb"], eps=1e-9, max_nodes=400000)),
+                ("curve_polygon_reference_algorithm", lambda: ctx.min_dist2poly(curves[:N], ppts, poff, pc, pp, eps=1e-6, max_depth=128, max_nodes=2000)),
+                ("curve_polygon_robust", lambda: ctx.min_dist2poly_robust(curves[:N], ppts, poff, pc, pp, eps=1e-9, max_nodes=200000)))
+    O = None
+    if cpu:
+        from oracle import oracle as O
+        O.build()
+    for name, f in all_legs:
+        if legs is not None and name not in legs:
+            continue
+        big = name.startswith("jacobian_list")
+        ctx.set_profiling(True, only="min_dist")
+        ctx.reset_kernel_stats()
         t0 = time.perf_counter()
         r = f()                                    # the first evaluation of this pair list: no node-count history yet
         first_ms = 1e3 * (time.perf_counter() - t0)
-        for _ in range(max(args.warmup // 10, 2)):
+        for _ in range(1 if big else max(args.warmup // 10, 2)):
             r = f()
-        reps = max(args.steps // 50, 5)
+        ctx.reset_kernel_stats()
+        reps = max(args.steps // 100, 3) if big else max(args.steps // 50, 5)
         t0 = time.perf_counter()
         for _ in range(reps):
             r = f()
         ms = 1e3 * (time.perf_counter() - t0) / reps
+        kms, kcnt = ctx.kernel_stats().get("min_dist", (0.0, 0))
+        ctx.set_profiling(False)
         nodes = int(r["nodes"].sum())
-        npairs = len(pc) if name.startswith("curve_polygon") else len(pa)
+        npairs = len(r["status"])
         out[name] = dict(ms_per_eval=round(ms, 3), first_eval_ms=round(first_ms, 3), evals_per_s=round(1e3 / ms, 2), pairs=npairs,
+                         kernel_avg_ms=round(kms / kcnt, 4) if kcnt else None,
                          pairs_per_s=round(npairs * 1e3 / ms, 1), nodes_per_eval=nodes, nodes_per_s=round(nodes * 1e3 / ms, 1),
                          status_counts=np.bincount(r["status"], minlength=4).tolist(),
                          result_checksum=float(np.nansum(r["res"][:, 0])))
@@ -990,16 +1185,188 @@ def mindist_mode(args, rank):
             calls = int(r["gjk_calls"].sum())
             out[name]["gjk_calls_per_eval"] = calls
             out[name]["gjk_calls_per_s"] = round(calls * 1e3 / ms, 1)
-        if name in pmc:
-            out[name]["valu_busy"] = pmc[name].get("valu_busy")
-            out[name]["valu_busy_source"] = pmc[name].get("source")
+        if big:
+            out[name]["what"] = ("the ONE call of spatialSeparationJacobian at C5 size: %d base pairs + %d variables x %d pairs of the advanced "
+                                 "vehicle = %d searches on %d curves" % (plan["P"], plan["n_x"], N + M - 1, npairs, len(plan["curves"])))
+            out[name]["iteration_equivalent"] = ("one SLSQP iteration of Examples/ComplexObstacles.py:49-63 (the bare constraint, n_x + 1 = %d "
+                                                 "all-pairs sweeps = %d searches) from %d" % (plan["n_x"] + 1, (plan["n_x"] + 1) * plan["P"], npairs))
+        cnt = counters_for("C5_mindist", name, _source_hash(_capi, "gjk_kernels"))
+        if cnt is not None:
+            out[name]["counters"] = cnt
+        if O is not None and name in ("reference_algorithm", "jacobian_list"):
+            cs, pas, pbs = (plan["curves"], plan["pa"], plan["pb"]) if big else (curves, pa, pb)
+            rng = np.random.default_rng(5)
+            # sampled pairs: a stride through the list plus the longest searches that END (capped ones are budget-bound in the oracle too)
+            ok_ids = np.nonzero(r["status"] == 0)[0]
+            longest = ok_ids[np.argsort(r["nodes"][ok_ids])[-40:]]
+            samp = np.unique(np.concatenate((rng.choice(npairs, size=min(npairs, 260), replace=False), longest)))
+            out[name]["parity_check"] = mindist_parity(O, cs, pas, pbs, r, samp, kw_ref)
+            out[name]["cpu_baseline"] = mindist_cpu_baseline(O, cs, pas, pbs, kw_ref, cpu_seconds, name)
+    head = out.get("jacobian_list") or out.get("reference_algorithm") or next(iter(out.values()))
+    return {"metric": "spatial-separation (_minDist) evals/s, host buffers in and out", "value": (out.get("reference_algorithm") or head)["evals_per_s"],
+            "unit": "constraint-evals/s", "n_gpus": 1, "higher_is_better": True, "dtype": "f64", "data": "synthetic",
+            "vs_baseline": None, "config": {"workload": "C5-style: 64 vehicles + 32 curve obstacles, degree 10, 4560 curve pairs per evaluation; jacobian_list: the 114 000-search call of one SLSQP iteration",
+                                            "note": "a branch-and-bound search per pair, not an HBM stream: the launch lasts as long as the dependent chain of its slowest pair "
+                                                    "(profiles/r05_experiments/mindist_quad_phases.txt) -- nodes/s, gjkNew calls/s and the VALU-busy fraction of the launch stand in for a roofline"},
+            "variants": out}
+
+
+def c1_text_mode(args, rank):
+    """BASELINE.json configs[0] as its text reads -- Examples/Example1: ONE vehicle, degree 10, 4 point obstacles, time-optimal,
+    through the class path (optimization.py:86-98: the obstacles join the pair loop as constant curves: P = C(5, 2) = 10 pairs,
+    210 / 21 / 41 values per evaluation) -- at the reference's own point x_r of tests/golden/c1_text.npz.  One step = what ONE
+    SLSQP iteration asks of the three constraint closures: each family on x and its n_x = 15 forward-difference neighbours
+    (16 rows, the trailing tf among the variables), through the drop-in BezOptimization's host-buffer path (three calls, three
+    launches).  Launch-latency sized: the figure of interest is ms per iteration against the reference's, not bytes."""
+    from optimalbeziertrajectorygeneration_amd import optimization as opt
+    g = np.load(os.path.join(REPO, "tests", "golden", "c1_text.npz"))
+    bo = opt.BezOptimization(numVeh=1, dimension=2, degree=10, minimizeGoal='TimeOpt', maxSep=1, maxSpeed=5, maxAngRate=1,
+                             initPoints=[(0, 0)], finalPoints=[(10, 10)], initSpeeds=[1], finalSpeeds=[1],
+                             initAngs=[0], finalAngs=[np.pi / 2], pointObstacles=g["obs"].tolist())
+    x = g["x_r"]
+    fams = ("tsep", "vmax", "ang")
+
+    def step():
+        return [bo._fd_values(x, f)[0] for f in fams]
+
+    t_s = time.perf_counter()
+    while time.perf_counter() - t_s < 0.3:
+        step()
+    for _ in range(max(args.warmup, 1)):
+        step()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        F = step()
+    elapsed = time.perf_counter() - t0
+    B = x.size + 1
+    ms = 1e3 * elapsed / args.steps
+    # the kernels behind it: HIP events on every launch of a replay
+    ctxs = [bo._ctx(True), bo._ctx(False)]
+    for cx in ctxs:
+        cx.set_profiling(True)
+        cx.reset_kernel_stats()
+    for _ in range(args.steps):
+        step()
+    kernels = []
+    N, d, n, R, P, L = 1, 2, 10, 0, 10, 21
+    by = {"temporal_sep": 8 * 5 * d * (n + 1) + 8 * P * L, "speed": 8 * N * d * (n + 1) + 8 * N * L,
+          "ang_rate": 8 * N * d * (n + 1) + 8 * N * (4 * n + 1)}
+    for cx in ctxs:
+        cx.sync()
+        for kname, (kms, cnt) in cx.kernel_stats().items():
+            if cnt and kname in by:
+                avg = kms / cnt
+                gbs = B * by[kname] / (avg * 1e-3) / 1e9
+                kernels.append(dict(kernel=kname, launches=cnt, avg_ms=round(avg, 5), alg_bytes_per_launch=B * by[kname],
+                                    achieved_gbs=round(gbs, 3), frac=round(gbs / HBM_PEAK_GBS, 7)))
+        cx.set_profiling(False)
+    dom = max(kernels, key=lambda k: k["avg_ms"]) if kernels else None
+    parity = cpu = None
+    if not args.no_cpu:
+        from oracle import oracle as O
+        O.build()
+        X, _ = bo._fd_rows(x)
+        Yr = bo.reshapeVectors(X)
+        tfr = X[:, -1]
+
+        def rel(got, ref):
+            return float((np.abs(got - ref) / np.maximum(np.abs(ref), np.abs(ref).max())).max())
+        ref_fix = {"tsep": g["tsep_r"], "vmax": g["maxspeed_r"], "ang": g["angrate_r"]}
+        vs_reference = {f: rel(F[i][0], ref_fix[f]) for i, f in enumerate(fams)}       # row 0 against the REFERENCE's own values
+        orc = {"tsep": [], "vmax": [], "ang": []}
+        for b in range(B):
+            yo = np.vstack([Yr[b]] + [np.full((1, n + 1), v) for o in g["obs"] for v in o])
+            orc["tsep"].append(O.temporal_sep(yo, 5, 2, 0, 1.0))
+            orc["vmax"].append(O.speed(Yr[b], 1, 2, 0, tfr[b], 5.0, 1))
+            orc["ang"].append(O.ang_rate(Yr[b], 1, 0, tfr[b], 1.0))
+        vs_oracle = {f: max(rel(F[i][b], orc[f][b]) for b in range(B)) for i, f in enumerate(fams)}
+        worst = max(max(vs_reference.values()), max(vs_oracle.values()))
+        parity = {"rows": B, "max_rel": worst, "row0_vs_reference_fixture": vs_reference, "all_rows_vs_oracle": vs_oracle, "ok": bool(worst <= 1e-9),
+                  "against": "tests/golden/c1_text.npz (written by the reference's own closures) on row 0; oracle/obtg_oracle.c on all %d rows" % B}
+        t0 = time.perf_counter()
+        reps = 0
+        while time.perf_counter() - t0 < min(args.cpu_seconds, 2.0):
+            for b in range(B):
+                yo = np.vstack([Yr[b]] + [np.full((1, n + 1), v) for o in g["obs"] for v in o])
+                O.temporal_sep(yo, 5, 2, 0, 1.0); O.speed(Yr[b], 1, 2, 0, tfr[b], 5.0, 1); O.ang_rate(Yr[b], 1, 0, tfr[b], 1.0)
+            reps += 1
+        dt = time.perf_counter() - t0
+        cpu = {"value": round(B * reps / dt, 1), "unit": "constraint-evals/s", "cores": 1, "kind": "port",
+               "sample": "the same %d rows x %d passes through the oracle's one-row calls (ctypes overhead included), %.2f s" % (B, reps, dt)}
     if rank == 0:
-        print(json.dumps({"metric": "spatial-separation (_minDist) evals/s, host buffers in and out", "value": out["reference_algorithm"]["evals_per_s"],
-                          "unit": "constraint-evals/s", "n_gpus": 1, "higher_is_better": True, "dtype": "f64", "data": "synthetic",
-                          "vs_baseline": None, "config": {"workload": "C5-style: 64 vehicles + 32 curve obstacles, degree 10, 4560 curve pairs per evaluation",
-                                                          "note": "a branch-and-bound search per pair, not an HBM stream: the launch lasts as long as the dependent chain of its slowest pair "
-                                                                  "(profiles/r05_experiments/mindist_quad_phases.txt) -- nodes/s, gjkNew calls/s and the VALU-busy fraction of the launch stand in for a roofline"},
-                          "variants": out}))
+        print(json.dumps({
+            "metric": "constraint-evals/s (full swarm pairwise min-dist + dynamics) per SLSQP iter", "value": round(B * args.steps / elapsed, 1),
+            "unit": "constraint-evals/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "reference fixture point (tests/golden/c1_text.npz)",
+            "config": {"workload": "C1_text: 1 vehicle, 2-D, degree 10, 4 point obstacles (class path: 10 pairs), time-optimal; one step = the three "
+                                   "constraint closures on x and its 15 forward-difference neighbours (B=16 rows) through the host-buffer path",
+                       "launches_per_step": 3, "evals_per_step_per_gpu": B,
+                       "note": "launch-latency bound: a step is three host calls of one launch each; the reference takes 0.45 s for its whole "
+                               "22-iteration solve (BASELINE.md 2)"},
+            "roofline": (dict(bound="launch latency", kernel=dom["kernel"], achieved=dom["achieved_gbs"], peak=HBM_PEAK_GBS, unit="GB/s",
+                              frac=dom["frac"], traffic=None) if dom else None),
+            "kernels": kernels, "parity_check": parity, "cpu_baseline": cpu}))
+        sys.stdout.flush()
+    if parity is not None and not parity["ok"]:
+        raise SystemExit("bench.py --mode c1text: the closures DISAGREE with the reference fixture / the oracle: %s" % json.dumps(parity))
+
+
+def config_legs(args):
+    """`configs`: every other BASELINE.json configuration, each measured by a child process of this run (fresh process, the
+    same script with --config-leg: its own context, spin-up, timed region with HIP events on the dominant kernel, parity of
+    the timed step's buffers against the oracle, bounded CPU legs) -- so that the ONE line the driver records carries them
+    all.  The parent has finished its own timing; parent + one child use the GPU at a time."""
+    legs = (("C1_text", ["--mode", "c1text", "--steps", "200", "--warmup", "20"]),
+            ("C2", ["--workload", "C2", "--steps", "300", "--warmup", "30"]),
+            ("C2_file", ["--workload", "C2_file", "--steps", "300", "--warmup", "30"]),
+            ("C4", ["--workload", "C4", "--steps", "5", "--warmup", "2"]),
+            ("C5", ["--workload", "C5", "--steps", "60", "--warmup", "10"]),
+            ("C5_mindist", ["--mode", "mindist", "--steps", "100", "--warmup", "20"]))
+    out = {}
+    t_all = time.perf_counter()
+    for name, extra in legs:
+        cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--config-leg", "--cpu-seconds", "2.5"] + extra
+        t0 = time.perf_counter()
+        try:
+            p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=150, text=True)
+        except subprocess.TimeoutExpired:
+            out[name] = {"error": "timed out after 150 s"}
+            continue
+        wall = time.perf_counter() - t0
+        lines = [ln for ln in p.stdout.strip().splitlines() if ln.startswith("{")]
+        if not lines:
+            out[name] = {"error": "exit code %d, no line" % p.returncode, "stderr_tail": p.stderr[-400:]}
+            continue
+        ln = json.loads(lines[-1])
+        e = {"exit_code": p.returncode, "wall_s": round(wall, 1), "value": ln.get("value"), "unit": ln.get("unit"),
+             "ms_per_step": ln.get("ms_per_step"), "workload": (ln.get("config") or {}).get("workload")}
+        if name == "C5_mindist":
+            v = ln["variants"]
+            for leg in ("reference_algorithm", "jacobian_list", "curve_polygon_reference_algorithm"):
+                if leg in v:
+                    e[leg] = {k: v[leg].get(k) for k in ("ms_per_eval", "kernel_avg_ms", "pairs", "pairs_per_s", "nodes_per_s", "gjk_calls_per_s",
+                                                         "status_counts", "counters", "parity_check", "cpu_baseline")}
+            e["ms_per_step"] = v["jacobian_list"]["ms_per_eval"] if "jacobian_list" in v else v["reference_algorithm"]["ms_per_eval"]
+            e["parity"] = {"ok": all((v[leg].get("parity_check") or {"ok": True})["ok"] for leg in v)}
+        else:
+            rf = ln.get("roofline") or {}
+            dom = next((k for k in (ln.get("kernels") or []) if k["kernel"] == rf.get("kernel")), None)
+            e["kernel"] = {"name": rf.get("kernel"), "avg_ms": dom["avg_ms"] if dom else None, "launches": dom["launches"] if dom else None,
+                           "alg_bytes_per_launch": dom["alg_bytes_per_launch"] if dom else None, "frac": rf.get("frac"), "bound": rf.get("bound"),
+                           "traffic": rf.get("traffic"), "timing": "HIP events on the launch stream, inside the leg's timed region"}
+            e["launches_per_step"] = (ln.get("config") or {}).get("launches_per_step")
+            pc = ln.get("parity_check") or {}
+            e["parity"] = {k: pc.get(k) for k in ("rows", "max_rel", "max_rel_elementwise", "flags_equal", "gjk_dist_max_rel", "ok", "against")}
+            cb = ln.get("cpu_baseline") or {}
+            e["cpu_baseline"] = {"value": cb.get("value"), "cores": cb.get("cores"), "kind": cb.get("kind"), "sample": cb.get("sample"),
+                                 "all_cores": cb.get("all_cores")}
+            if (ln.get("config") or {}).get("gjk_status_note"):
+                e["gjk_status_note"] = ln["config"]["gjk_status_note"]
+        out[name] = e
+    out["_wall_s"] = round(time.perf_counter() - t_all, 1)
+    out["_what"] = ("each entry: a child process of this run (python bench.py --config-leg ...), its own timed region; kernel.avg_ms from "
+                    "HIP events on the launch stream; parity against oracle/ on rows sampled from the timed step's buffers")
+    return out
 
 
 def cpu_baseline(args, N, d, n, R, Y, statics, pa, pb, use_gjk, max_sep, vmax, wmax, tfv):

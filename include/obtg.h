@@ -80,9 +80,23 @@ const char* obtg_strerror(int code);
  *      now serialises with the legacy stream: call obtg_ctx_use_own_stream instead.
  *   5  round 5: nothing changed meaning; new: obtg_abi_version, obtg_fast_kernels, obtg_ctx_ang_rate_order_in_effect, obtg_temporal_sep_active[_dev],
  *      obtg_comm_* and obtg_temporal_sep_min_gather_dev (the collective behind the C ABI); 9 control points (degree 8)
- *      joined the specialised counts. */
-#define OBTG_ABI_VERSION 5
+ *      joined the specialised counts.
+ *   6  round 6: nothing changed meaning; new: obtg_source_hash, obtg_libm_pow_matches. */
+#define OBTG_ABI_VERSION 6
 int obtg_abi_version(void);
+
+/* Which sources this library was built from: the first 16 hex digits of a sha256 over a compile unit's source, the headers of
+ * csrc/ and its compiler flags.  unit: "gjk_kernels", "bern_kernels", "capi", "tables", "comm", "libm_check", or "all" (NULL =
+ * "all"); NULL is returned for a name that is none of these.  Counter files under profiles/ record the hash of the kernels they
+ * were taken on; bench.py drops a counter whose hash is not the running library's instead of reporting it as measured. */
+const char* obtg_source_hash(const char* unit);
+
+/* 1 when this host's libm rounds pow(x, 2.0) exactly as the device's restatement of it does (csrc/libm_pow2.h: glibc 2.35,
+ * the FMA build) on a few thousand inputs, 0 when not.  `a**2` in the reference (gjk/gjk.py:460; optimization.py:343-459 on the
+ * bounds) is libm's pow; with 0 the device's closest points / distances can differ from a reference run on THIS host by one
+ * ulp (and `_minDist` searches that feed them back can take another path), although they still equal the committed fixtures.
+ * Evaluated once per process, no device needed. */
+int obtg_libm_pow_matches(void);
 
 /* Which specialised (template-instantiated) kernel families exist for curves of `deg` in `dim` dimensions -- a bit mask:
  *   1  separation / speed rows, one-vs-many, structured separation Jacobian blocks (2-D and 3-D)
@@ -330,7 +344,7 @@ int obtg_comm_create(obtg_comm** out, int n_ranks, int rank, const unsigned char
 void obtg_comm_destroy(obtg_comm*);
 int obtg_comm_size(const obtg_comm*);
 int obtg_comm_rank(const obtg_comm*);
-const char* obtg_comm_last_error(const obtg_comm*);
+const char* obtg_comm_last_error(const obtg_comm*);   /* NULL: the calling thread's last failure without a communicator (obtg_comm_unique_id, obtg_comm_create) */
 int obtg_comm_all_gather_dev(obtg_comm*, obtg_ctx*, const void* d_send, void* d_recv, size_t bytes_per_rank);
 int obtg_temporal_sep_min_gather_dev(obtg_ctx*, obtg_comm*, const double* dY, int B, double max_sep, double* d_min_all /*[B][P]*/);
 /* The two pieces of it for callers with a collective of their own (MPI, a host-staged exchange): rank's block of the pair

@@ -30,6 +30,8 @@ _SIGNATURES = {
     "obtg_strerror": (C.c_char_p, [_i]),
     "obtg_last_error": (C.c_char_p, [_vp]),
     "obtg_abi_version": (_i, []),
+    "obtg_source_hash": (C.c_char_p, [C.c_char_p]),
+    "obtg_libm_pow_matches": (_i, []),
     "obtg_fast_kernels": (_i, [_i, _i]),
     "obtg_device_count": (_i, []),
     "obtg_abi_symbols": (_vp, []),
@@ -176,6 +178,17 @@ def device_count():
 
 def abi_version():
     return load().obtg_abi_version()
+
+
+def source_hash(unit="all"):
+    """obtg_source_hash: which sources the loaded library was built from (16 hex digits; None for an unknown unit name)."""
+    h = load().obtg_source_hash(unit.encode() if unit is not None else None)
+    return h.decode() if h is not None else None
+
+
+def libm_pow_matches():
+    """obtg_libm_pow_matches: does this host's pow(x, 2.0) round as the device's restatement of glibc 2.35's does."""
+    return bool(load().obtg_libm_pow_matches())
 
 
 def fast_kernels(dim, deg):

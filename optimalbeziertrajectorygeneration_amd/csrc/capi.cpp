@@ -226,7 +226,7 @@ int obtg_device_count(void)
 const char* obtg_abi_symbols(void)
 {
     static const char syms[] =
-        "obtg_strerror\0obtg_last_error\0obtg_abi_version\0obtg_fast_kernels\0obtg_device_count\0obtg_abi_symbols\0obtg_host_alloc\0obtg_host_free\0"
+        "obtg_strerror\0obtg_last_error\0obtg_abi_version\0obtg_source_hash\0obtg_libm_pow_matches\0obtg_fast_kernels\0obtg_device_count\0obtg_abi_symbols\0obtg_host_alloc\0obtg_host_free\0"
         "obtg_ctx_create\0obtg_ctx_destroy\0obtg_ctx_set_stream\0obtg_ctx_use_own_stream\0obtg_ctx_set_deg_elev\0obtg_ctx_set_ang_rate_order\0obtg_ctx_ang_rate_order_in_effect\0obtg_ctx_set_second_speed_bound\0obtg_sync\0"
         "obtg_len_temporal_sep\0obtg_len_speed\0obtg_len_ang_rate\0obtg_num_pairs\0"
         "obtg_temporal_sep\0obtg_speed\0obtg_ang_rate\0obtg_temporal_sep_min\0obtg_temporal_sep_min_range\0obtg_temporal_sep_active\0obtg_temporal_sep_active_dev\0obtg_temporal_sep_min_gather_dev\0obtg_temporal_sep_fd_min_rows_dev\0"

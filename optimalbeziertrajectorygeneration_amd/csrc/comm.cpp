@@ -85,12 +85,15 @@ struct obtg_comm {
     std::string last_error;
 };
 
+// (failures before a communicator exists -- ncclGetUniqueId, ncclCommInitRank -- keep their text per thread:
+// obtg_comm_last_error(NULL) returns it)
+static thread_local std::string t_last_error;
+
 static int comm_fail(obtg_comm* m, int nccl_rc, const char* where)
 {
-    if (m) {
-        const char* txt = rccl().error_string ? rccl().error_string(nccl_rc) : "RCCL error";
-        m->last_error = std::string(where) + ": " + (txt ? txt : "RCCL error");
-    }
+    const char* txt = rccl().error_string ? rccl().error_string(nccl_rc) : "RCCL error";
+    std::string& dst = m ? m->last_error : t_last_error;
+    dst = std::string(where) + ": " + (txt ? txt : "RCCL error");
     return OBTG_ERR_DEVICE;
 }
 
@@ -136,7 +139,7 @@ void obtg_comm_destroy(obtg_comm* m)
 
 int obtg_comm_size(const obtg_comm* m) { return m ? m->n_ranks : 0; }
 int obtg_comm_rank(const obtg_comm* m) { return m ? m->rank : -1; }
-const char* obtg_comm_last_error(const obtg_comm* m) { return m ? m->last_error.c_str() : ""; }
+const char* obtg_comm_last_error(const obtg_comm* m) { return m ? m->last_error.c_str() : t_last_error.c_str(); }
 
 int obtg_comm_all_gather_dev(obtg_comm* m, obtg_ctx* c, const void* d_send, void* d_recv, size_t bytes_per_rank)
 {
@@ -187,6 +190,7 @@ namespace obtg {
 
 int comm_gather_pair_minima(::obtg_comm* m, obtg_ctx* c, const double* dY, int B, double max_sep, double* d_min_all)
 {
+    if (c->device != m->device) return OBTG_ERR_ARG;      // (the buffers live on the context's device, the communicator is bound to its own)
     const int P = c->n_pairs, G = m->n_ranks;
     int b0, cnt;
     pair_block(P, G, m->rank, &b0, &cnt);

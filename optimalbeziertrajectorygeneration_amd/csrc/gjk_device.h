@@ -369,7 +369,8 @@ template <class Mem>
 __device__ __forceinline__ bool matches_old_batched(const Ctx<Mem>& g, const Simplex& o, const V3& A)
 {
     const bool hA = o.keys & kA, hB = o.keys & kB, hC = o.keys & kC, hD = o.keys & kD, pD = o.keys & kDpts;
-    // (the indices of absent entries are stale or zero, always in range)
+    // (the indices of absent entries are zero or left from an earlier round of the SAME pair -- the sweeps reset them when a lane
+    // takes a new pair --, so always in range of this pair's first hull)
     const double xa = g.mem(g.P1.base + o.A.i1), xb = g.mem(g.P1.base + o.B.i1), xc = g.mem(g.P1.base + o.C.i1),
                  xd = g.mem(g.P1.base + o.D.i1);
     const bool maybe = (hA & (A.x == xa)) | (hB & (A.x == xb)) | (hC & (A.x == xc)) | (pD & (A.x == xd));

@@ -79,6 +79,9 @@ __device__ __forceinline__ void gjk_sweep(int c_end, int* s_next, int max_iter, 
                     setup(k, g);
                     g.n_support = 0;
                     s.keys = 0; dir = V3{ 1.0, 0.0, 0.0 };
+                    // (matches_old_batched fetches poly-1 points at the indices of absent entries too: none may be left from
+                    // the previous pair, whose first hull can have had more points than this one's)
+                    s.A.i1 = 0; s.B.i1 = 0; s.C.i1 = 0; s.D.i1 = 0;
                     phase = 0; it = 0; rr = 0;
                 } else exhausted = true;
             }

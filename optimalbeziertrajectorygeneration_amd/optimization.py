@@ -343,15 +343,16 @@ class BezOptimization(object):
     # ------------------------------------------------------------------ constraints
     @property
     def temporalSeparationConstraints(self):
-        with_obs = self.pointObstacles is not None
-        nobj = self.model['numVeh'] + (len(self.pointObstacles) if with_obs else 0)
-
+        # (pointObstacles is read when the closure is CALLED, here as in _fd_values: a driver that sets the obstacles after
+        # taking the closure gets the served rows and the one-row calls from the same context)
         def wrapper(x):
-            if nobj <= 1:
+            with_obs = self.pointObstacles is not None
+            if self.model['numVeh'] + (len(self.pointObstacles) if with_obs else 0) <= 1:
                 return None                      # optimization.py:345-346
             return self._serve('tsep', x, direct)
 
         def direct(x):
+            with_obs = self.pointObstacles is not None
             y = self.reshapeVector(x)
             if self.separationRows == 'min':     # per-pair minimum, reduced on the device (obtg_temporal_sep_min)
                 return self._ctx(with_obs).temporal_sep_min(y, self.model['maxSep'])[0]
@@ -540,7 +541,10 @@ class BezOptimization(object):
 
     def _serve_key(self, refresh):
         """What a kept batch depends on besides x: DEG_ELEV, the row options, the model (its arrays by their bytes: the key
-        reshapeVector keeps; refresh = recompute it now), the bounds' values, the obstacles."""
+        reshapeVector keeps; refresh = recompute it now), the bounds' values, the obstacles.  The obstacles by their BYTES on
+        every call, on purpose: drivers edit `pointObstacles` / a track's control points in place between solves, which a key of
+        object identities would not see (4 point obstacles: 1 us; 32 curve obstacles: 30 us beside a `_minDist` sweep of
+        milliseconds); _serve asks for the key only when at most one variable moved."""
         if refresh or getattr(self, '_rv_cache', None) is None:
             self._rv_parts()
         return (int(DEG_ELEV), self.separationRows, self.activeRows, self._rv_cache[0], self.model['maxSep'], self.model['maxSpeed'],

@@ -28,12 +28,12 @@
 
 #ifdef _OPENMP
 #include <omp.h>
+#endif
 
 /* `a**2` on np.float64 scalars (gjk.py:460) and on Python floats (optimization.py:343, 384, 422, 459: maxSep**2, minSpeed**2,
  * maxSpeed**2, maxAngRate**2) is libm pow(a, 2.0), which is NOT always a*a (one ulp apart on 0.09 % of inputs with this glibc);
  * the volatile pointer keeps gcc from folding it into a product. */
 static double (*volatile libm_pow)(double, double) = pow;
-#endif
 
 #define EXPORT __attribute__((visibility("default")))
 
@@ -882,6 +882,26 @@ EXPORT int obtg_oracle_min_dist(const double *c1, int dim1, int K1, const double
     min_dist_rec(&m, a, b, 0, INFINITY, 0, 1, 0, 1, res);
     if (info) { info[0] = m.nodes; info[1] = m.gjk_calls; info[2] = m.depth_seen; info[3] = m.status; }
     return m.status;
+}
+
+/* The pair loop of spatialSeparationConstraints (optimization.py:127-131) -- or the one-call list of its finite-difference
+ * Jacobian -- over packed curves[n][3][K]: pair k = (pa[k], pb[k]) through min_dist_rec exactly as obtg_oracle_min_dist runs it.
+ * res[n_pairs][3], info[n_pairs][4] = (nodes, gjk_calls, max depth, status).  nthreads > 1: OpenMP over pairs (the pairs are
+ * independent; dynamic schedule: their searches differ by four orders of magnitude). */
+EXPORT int obtg_oracle_min_dist_pairs(const double *curves, int K, const int *pa, const int *pb, long n_pairs,
+                                      double eps, int max_iter, int md_cap, int max_depth, long max_nodes,
+                                      double *res, long *info, int nthreads)
+{
+    (void)nthreads;
+#ifdef _OPENMP
+#pragma omp parallel for schedule(dynamic, 4) num_threads(nthreads > 0 ? nthreads : 1)
+#endif
+    for (long k = 0; k < n_pairs; ++k) {
+        md_ctx_t m = { K, K, max_iter, md_cap, max_depth, 0, max_nodes, 0, 0, MD_OK, eps };
+        min_dist_rec(&m, curves + (size_t)pa[k] * 3 * K, curves + (size_t)pb[k] * 3 * K, 0, INFINITY, 0, 1, 0, 1, res + 3 * k);
+        if (info) { info[4 * k] = m.nodes; info[4 * k + 1] = m.gjk_calls; info[4 * k + 2] = m.depth_seen; info[4 * k + 3] = m.status; }
+    }
+    return 0;
 }
 
 /* bezier.py:1411-1496 _minDist2Poly */

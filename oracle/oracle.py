@@ -229,6 +229,23 @@ def min_dist(c1, c2, eps=1e-9, max_iter=128, md_cap=4096, max_depth=900, max_nod
     return dict(res=res, nodes=int(info[0]), gjk_calls=int(info[1]), depth=int(info[2]), status=st)
 
 
+def min_dist_pairs(curves, pair_a, pair_b, eps=1e-9, max_iter=128, md_cap=4096, max_depth=900, max_nodes=2000000, nthreads=1):
+    """`min_dist` over a pair list on packed curves[n][3][K] (the layout obtg_min_dist takes): the pair loop of
+    spatialSeparationConstraints (optimization.py:127-131), OpenMP over pairs when nthreads > 1."""
+    curves = _f64(curves)
+    n, three, K = curves.shape
+    assert three == 3
+    pa = np.ascontiguousarray(pair_a, dtype=np.int32)
+    pb = np.ascontiguousarray(pair_b, dtype=np.int32)
+    assert pa.shape == pb.shape and (pa.size == 0 or (0 <= min(pa.min(), pb.min()) and max(pa.max(), pb.max()) < n))
+    res = np.empty((pa.size, 3))
+    info = np.zeros((pa.size, 4), dtype=np.int64)
+    lib().obtg_oracle_min_dist_pairs(_p(curves), C.c_int(K), _p(pa), _p(pb), C.c_long(pa.size), C.c_double(eps),
+                                     C.c_int(max_iter), C.c_int(md_cap), C.c_int(max_depth), C.c_long(max_nodes),
+                                     _p(res), _p(info), C.c_int(nthreads))
+    return dict(res=res, nodes=info[:, 0], gjk_calls=info[:, 1], depth=info[:, 2], status=info[:, 3].astype(np.int32))
+
+
 def min_dist2poly(c1, poly, eps=1e-6, max_iter=128, md_cap=4096, max_depth=900, max_nodes=2000000):
     c1 = np.atleast_2d(_f64(c1))
     poly = _f64(poly)

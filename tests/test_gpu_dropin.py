@@ -760,6 +760,55 @@ def test_active_separation_rows_option(golden_dir):
 
 
 @pytest.mark.gpu
+def test_fd_serving_on_the_any_degree_kernels_and_the_exact_order(monkeypatch):
+    """the served rows are right only if the BATCHED kernels give the one-row call's bits.  The test below covers the
+    specialised shapes in the default order; here the shapes that run elsewhere: degree 6 (no specialised count: every family on the
+    any-degree, one-wave-per-item kernels) at DEG_ELEV 0 and 3, 2-D with point obstacles and 3-D, and angRateOrder='exact' /
+    'reference' at DEG_ELEV 10 (the double-double pass over the near-stop vehicles' rows; the elevate-first order).  Every closure
+    at x and at every x + h e_k: served == evaluated on its own, element for element."""
+    from optimalbeziertrajectorygeneration_amd import optimization as opt
+    from optimalbeziertrajectorygeneration_amd.optimization import BezOptimization, FD_STEP
+    rng = np.random.default_rng(21)
+
+    def swarm(nveh, dim, deg, order, obstacles):
+        init = rng.uniform(0, 10, size=(nveh, dim))
+        final = rng.uniform(0, 10, size=(nveh, dim))
+        kw = dict(numVeh=nveh, dimension=dim, degree=deg, minimizeGoal='Euclidean', maxSep=0.9, maxSpeed=5, maxAngRate=1,
+                  initPoints=init, finalPoints=final, tf=6.0, angRateOrder=order,
+                  pointObstacles=[[3.0, 2.0], [6.0, 7.0]] if obstacles else None)
+        monkeypatch.delenv("OBTG_FD_BATCHING", raising=False)
+        return BezOptimization(**kw), BezOptimization(fdBatching=False, **kw)
+
+    try:
+        for nveh, dim, deg, R, order, obstacles in ((3, 2, 6, 0, 'fast', True), (3, 2, 6, 3, 'fast', False), (4, 3, 6, 0, 'fast', False),
+                                                   (3, 2, 10, 10, 'exact', False), (3, 2, 10, 10, 'reference', True),
+                                                   (2, 2, 7, 4, 'exact', False)):
+            opt.DEG_ELEV = R
+            b_on, b_off = swarm(nveh, dim, deg, order, obstacles)
+            x = b_on.generateGuess(std=0.3, seed=8)
+            if order == 'exact':                          # a vehicle that nearly stops mid-way, so that the double-double pass has rows to redo
+                y = b_on.reshapeVector(x)
+                mid = y.shape[1] // 2
+                y[0:2, mid - 1:mid + 2] = y[0:2, mid:mid + 1] + 1e-3 * rng.normal(size=(2, 3))
+                x = y[:, 1:-1].reshape(-1).copy()
+                assert np.array_equal(b_on.reshapeVector(x), y)
+            pairs = [(b_on.temporalSeparationConstraints, b_off.temporalSeparationConstraints),
+                     (b_on.maxSpeedConstraints, b_off.maxSpeedConstraints), (b_on.objectiveFunction, b_off.objectiveFunction)]
+            if dim == 2:
+                pairs.append((b_on.maxAngularRateConstraints, b_off.maxAngularRateConstraints))
+            for f_on, f_off in pairs:
+                assert np.array_equal(f_on(x), f_off(x), equal_nan=True)
+                for k in range(x.size):
+                    xk = x.copy()
+                    xk[k] += FD_STEP
+                    assert np.array_equal(f_on(xk), f_off(xk), equal_nan=True), (nveh, dim, deg, R, order, k)
+            st = b_on.fdBatchingStats
+            assert st['served'] >= len(pairs) * (x.size - 1) and st['batches'] == len(pairs), (deg, R, order, st)
+    finally:
+        opt.DEG_ELEV = 0
+
+
+@pytest.mark.gpu
 def test_scipy_finite_differences_served_from_one_batch(monkeypatch):
     """The reference's drivers hand SLSQP bare closures, so SciPy differences every one of them itself -- n_x calls at x0 + h e_k
     per closure and iteration.  BezOptimization._serve notices the first such call and answers it and the rest of the sweep from
