@@ -107,6 +107,9 @@ def parse():
     ap.add_argument("--no-proxy", action="store_true", help="skip the strong_scaling_proxy leg of a 1-GPU batch-mode run")
     ap.add_argument("--one-device", action="store_true",
                     help="rehearsal only: every rank uses device 0 (needs --backend gloo)")
+    ap.add_argument("--mindist-legs", default=None,
+                    help="--mode mindist: comma-separated legs to run (reference_algorithm, jacobian_list, robust, jacobian_list_robust, "
+                         "curve_polygon_reference_algorithm, curve_polygon_robust); default all (profile runs pick the kernels they want)")
     ap.add_argument("--no-configs", action="store_true",
                     help="1-GPU C3 batch-mode run: skip the `configs` block (every other BASELINE.json configuration measured by a "
                          "child process of this run: C1_text, C2, C2_file, C4, C5, C5_mindist -- ms per step, the dominant kernel's "
@@ -1071,11 +1074,13 @@ def mindist_parity(O, curves, pa, pb, r, sample, kw):
     """Sampled pairs of the device's call against the oracle's search of the same pair: (distance, t1, t2) IDENTICAL (bit for
     bit; NaN where NaN), node counts, gjkNew-call counts, depths and statuses equal."""
     o = O.min_dist_pairs(curves, pa[sample], pb[sample], nthreads=1, **kw)
-    same_res = bool(np.array_equal(r["res"][sample].view(np.int64), o["res"].view(np.int64)))
-    if not same_res:                                            # (NaN payloads aside)
-        same_res = bool(np.array_equal(r["res"][sample], o["res"], equal_nan=True))
+    # (distance, t1, t2) of the searches that END; a search stopped by a budget (node / depth / inner-gjkNew cap: inputs on which
+    # the reference itself does not return) has no result to compare -- its status and its counts up to the stop are compared
+    ended = o["status"] == 0
+    got, ref = r["res"][sample][ended], o["res"][ended]
+    same_res = bool(np.array_equal(got, ref, equal_nan=True))
     eq = {k: bool(np.array_equal(np.asarray(r[k])[sample], np.asarray(o[k]))) for k in ("nodes", "gjk_calls", "depth", "status")}
-    return {"pairs": int(len(sample)), "results_identical": same_res, "node_counts_equal": eq["nodes"],
+    return {"pairs": int(len(sample)), "pairs_that_end": int(ended.sum()), "results_identical": same_res, "node_counts_equal": eq["nodes"],
             "gjk_call_counts_equal": eq["gjk_calls"], "depths_equal": eq["depth"], "statuses_equal": eq["status"],
             "ok": bool(same_res and all(eq.values())),
             "against": "oracle/obtg_oracle.c min_dist_rec (bezier.py:1283-1408) on the same curves, same budgets"}
@@ -1118,6 +1123,8 @@ def mindist_mode(args, rank):
     finish in the reference either) and in the robust one (obtg_min_dist_robust); and, since round 6, at the size an SLSQP
     ITERATION asks for: the one call of spatialSeparationJacobian (`jacobian_list`: 114 000 searches)."""
     legs = ("reference_algorithm", "jacobian_list", "curve_polygon_reference_algorithm") if args.config_leg else None
+    if args.mindist_legs:
+        legs = tuple(x.strip() for x in args.mindist_legs.split(",") if x.strip())
     line = mindist_line(args, cpu=not args.no_cpu, legs=legs)
     if rank == 0:
         print(json.dumps(line))

@@ -1238,9 +1238,15 @@ int obtg_min_dist(obtg_ctx* c, const double* curves, int n_curves, int K, const 
         std::stable_sort(qbuf.begin() + 1, qbuf.end(), [&](int a, int b) { return hn[a] > hn[b]; });
     }
     if ((rc = h2d(c, m[6], qbuf.data(), sizeof(int) * qbuf.size()))) return rc;
+    // 2-D curves arrive padded with a zero z row (bezier.py:1294-1308): then the planar gjkNew machine runs (the same bits)
+    bool planar = true;
+    for (int i = 0; i < n_curves && planar; ++i) {
+        const double* z = curves + ((size_t)i * 3 + 2) * K;
+        for (int j = 0; j < K; ++j) if (z[j] != 0.0) { planar = false; break; }
+    }
     rc = launch_min_dist(c, c->ws_in.as<double>(), K, m[1].as<int>(), m[2].as<int>(), n_pairs, eps, max_iter,
                          md_cap, max_depth, max_nodes, m[5].as<double>(), c->ws_out.as<double>(), m[3].as<int>(),
-                         have ? m[6].as<int>() + 1 : nullptr, m[6].as<int>());
+                         have ? m[6].as<int>() + 1 : nullptr, m[6].as<int>(), planar);
     if (rc) return rc;
     std::vector<int> hinfo((size_t)4 * n_pairs);
     if ((rc = d2h_copy(c, hinfo.data(), m[3].p, sizeof(int) * 4 * n_pairs))) return rc;
@@ -1312,9 +1318,15 @@ int obtg_min_dist2poly(obtg_ctx* c, const double* curves, int n_curves, int K, c
     if ((rc = m[5].reserve(sizeof(double) * min_dist2poly_stack_doubles(K, max_depth) * n_pairs))) return rc;
     if ((rc = c->ws_out.reserve(sizeof(double) * 5 * (size_t)n_pairs))) return rc;
     if ((rc = m[3].reserve(sizeof(int) * 4 * (size_t)n_pairs))) return rc;
+    bool planar = true;             // 2-D curves against polygons in the plane (bezier.py:1416-1430 pads both with z = 0)
+    for (int i = 0; i < n_curves && planar; ++i) {
+        const double* z = curves + ((size_t)i * 3 + 2) * K;
+        for (int j = 0; j < K; ++j) if (z[j] != 0.0) { planar = false; break; }
+    }
+    for (int i = 0; i < n_pts && planar; ++i) if (pts[3 * (size_t)i + 2] != 0.0) planar = false;
     rc = launch_min_dist2poly(c, c->ws_in.as<double>(), K, c->ws_in2.as<double>(), m[0].as<int>(), m[1].as<int>(),
                               m[2].as<int>(), n_pairs, eps, max_iter, md_cap, max_depth, max_nodes,
-                              m[5].as<double>(), c->ws_out.as<double>(), m[3].as<int>(), max_K);
+                              m[5].as<double>(), c->ws_out.as<double>(), m[3].as<int>(), max_K, planar);
     if (rc) return rc;
     std::vector<int> hinfo((size_t)4 * n_pairs);
     if ((rc = d2h_copy(c, hinfo.data(), m[3].p, sizeof(int) * 4 * n_pairs))) return rc;

@@ -191,6 +191,28 @@ __device__ __forceinline__ void support_pts_wave(Ctx<Mem>& g, const V3& dir, Ver
     g.n_support++;
 }
 
+// "largest value, lowest index" of two sequences side by side over the 16 lanes of a row: quad permutes, the half row
+// mirrored, the row mirrored -- all DPP moves, after which every lane of the row holds both answers.  The combination is
+// commutative and associative, so any exchange pattern gives the serial scan's answer (strict '>' from index 0).
+__device__ __forceinline__ void row_argmax_pair(double& v1, int& i1, double& v2, int& i2)
+{
+#define OBTG_DPP_MEET2(CTRL) \
+    { const int lo1_ = __builtin_amdgcn_update_dpp(0, __double2loint(v1), CTRL, 0xf, 0xf, false); \
+      const int hi1_ = __builtin_amdgcn_update_dpp(0, __double2hiint(v1), CTRL, 0xf, 0xf, false); \
+      const int oi1_ = __builtin_amdgcn_update_dpp(0, i1, CTRL, 0xf, 0xf, false); \
+      const int lo2_ = __builtin_amdgcn_update_dpp(0, __double2loint(v2), CTRL, 0xf, 0xf, false); \
+      const int hi2_ = __builtin_amdgcn_update_dpp(0, __double2hiint(v2), CTRL, 0xf, 0xf, false); \
+      const int oi2_ = __builtin_amdgcn_update_dpp(0, i2, CTRL, 0xf, 0xf, false); \
+      const double ov1_ = __hiloint2double(hi1_, lo1_), ov2_ = __hiloint2double(hi2_, lo2_); \
+      const bool t1_ = (ov1_ > v1) | ((ov1_ == v1) & (oi1_ < i1)), t2_ = (ov2_ > v2) | ((ov2_ == v2) & (oi2_ < i2)); \
+      v1 = t1_ ? ov1_ : v1; i1 = t1_ ? oi1_ : i1; v2 = t2_ ? ov2_ : v2; i2 = t2_ ? oi2_ : i2; }
+    OBTG_DPP_MEET2(0xB1)      // quad_perm:[1,0,3,2]
+    OBTG_DPP_MEET2(0x4E)      // quad_perm:[2,3,0,1]
+    OBTG_DPP_MEET2(0x141)     // row_half_mirror
+    OBTG_DPP_MEET2(0x140)     // row_mirror
+#undef OBTG_DPP_MEET2
+}
+
 // supportPts for FOUR calls at a time, one per 16-lane row of the wavefront (K <= 16 points per set): the lanes of a row
 // hold that row's call (its own two point sets, direction and simplex), lane l of the row takes point l of BOTH sets, and
 // the two "largest value, lowest index" reductions run side by side over the row -- quad permutes, the half row mirrored,
@@ -211,21 +233,7 @@ __device__ __forceinline__ void support_pts_quarter(Ctx<Mem>& g, const V3& dir, 
     if (v1 != v1) v1 = -__builtin_inf();                   // `cur > maxd` is false for NaN: never selected
     if (v2 != v2) v2 = -__builtin_inf();
     int i1 = have1 ? l : 0x7fffffff, i2 = have2 ? l : 0x7fffffff;
-#define OBTG_DPP_MEET2(CTRL) \
-    { const int lo1_ = __builtin_amdgcn_update_dpp(0, __double2loint(v1), CTRL, 0xf, 0xf, false); \
-      const int hi1_ = __builtin_amdgcn_update_dpp(0, __double2hiint(v1), CTRL, 0xf, 0xf, false); \
-      const int oi1_ = __builtin_amdgcn_update_dpp(0, i1, CTRL, 0xf, 0xf, false); \
-      const int lo2_ = __builtin_amdgcn_update_dpp(0, __double2loint(v2), CTRL, 0xf, 0xf, false); \
-      const int hi2_ = __builtin_amdgcn_update_dpp(0, __double2hiint(v2), CTRL, 0xf, 0xf, false); \
-      const int oi2_ = __builtin_amdgcn_update_dpp(0, i2, CTRL, 0xf, 0xf, false); \
-      const double ov1_ = __hiloint2double(hi1_, lo1_), ov2_ = __hiloint2double(hi2_, lo2_); \
-      const bool t1_ = (ov1_ > v1) | ((ov1_ == v1) & (oi1_ < i1)), t2_ = (ov2_ > v2) | ((ov2_ == v2) & (oi2_ < i2)); \
-      v1 = t1_ ? ov1_ : v1; i1 = t1_ ? oi1_ : i1; v2 = t2_ ? ov2_ : v2; i2 = t2_ ? oi2_ : i2; }
-    OBTG_DPP_MEET2(0xB1)      // quad_perm:[1,0,3,2]
-    OBTG_DPP_MEET2(0x4E)      // quad_perm:[2,3,0,1]
-    OBTG_DPP_MEET2(0x141)     // row_half_mirror
-    OBTG_DPP_MEET2(0x140)     // row_mirror
-#undef OBTG_DPP_MEET2
+    row_argmax_pair(v1, i1, v2, i2);
     if ((nan1 >> row0) & 1) i1 = 0;
     if ((nan2 >> row0) & 1) i2 = 0;
     out.i1 = i1; out.i2 = i2;
@@ -710,6 +718,104 @@ __device__ __forceinline__ Simplex lift(const Simplex2& s)
     r.D = r.A;
     r.keys = s.keys;
     return r;
+}
+
+// ---- the planar machine for FOUR calls at a time, one per 16-lane row (round 6: `_minDist` on 2-D curves, which is every
+//      driver that uses it -- Examples/ComplexObstacles.py, DrivingOnATrack.py; bezier.py:1294-1308 pads them with z = 0).
+//      run_quarter spends its trips on the 3-D expressions although, with every z zero, two thirds of their terms are exact
+//      zeros and the tetrahedron cases cannot occur; this is run_quarter on simplex_update2 / matches_old2: per row the
+//      operations that survive, in the reference's order, hence run_quarter's bits on such inputs (the planar sweeps have
+//      held simplex_update2 to the 3-D machine and to the reference's traces since round 1).
+
+// supportPts of a row's planar call (see support_pts_quarter; sdot<PLANAR>'s two-term products)
+template <class Mem>
+__device__ __forceinline__ void support_pts_quarter2(Ctx<Mem>& g, const V2& dir, Vert2& out)
+{
+    const int lane = threadIdx.x & 63, l = lane & 15;
+    const V2 nd = neg2(dir);
+    const bool have1 = l < g.P1.K, have2 = l < g.P2.K;
+    double v1 = have1 ? g.own1.x * dir.x + g.own1.y * dir.y : -__builtin_inf();
+    double v2 = have2 ? g.own2.x * nd.x + g.own2.y * nd.y : -__builtin_inf();
+    const unsigned long long nan1 = __ballot(v1 != v1), nan2 = __ballot(v2 != v2);
+    const int row0 = lane & 48;
+    if (v1 != v1) v1 = -__builtin_inf();
+    if (v2 != v2) v2 = -__builtin_inf();
+    int i1 = have1 ? l : 0x7fffffff, i2 = have2 ? l : 0x7fffffff;
+    row_argmax_pair(v1, i1, v2, i2);
+    if ((nan1 >> row0) & 1) i1 = 0;
+    if ((nan2 >> row0) & 1) i2 = 0;
+    out.ii = pack_ii(i1, i2);
+    out.v = sub2(point2(g.mem, g.P1, i1), point2(g.mem, g.P2, i2));
+    g.n_support++;
+}
+
+// Checkpoint for planar states: (live simplex entries, direction); the kD / kDpts entries of the 3-D state never exist here
+// and a direction's z is an exact zero, so `same` is true exactly when Checkpoint::same is on the lifted state -- the cycle
+// is reported at the same round.
+struct Checkpoint2 {
+    int keys, power, lam, a, b, c;
+    V2 dir;
+    __device__ __forceinline__ void take(const Simplex2& s, const V2& d) { keys = s.keys; dir = d; a = s.A.ii; b = s.B.ii; c = s.C.ii; }
+    __device__ __forceinline__ void start(const Simplex2& s, const V2& d) { take(s, d); power = 1; lam = 0; }
+    __device__ __forceinline__ bool same(const Simplex2& s, const V2& d) const
+    {
+        if (s.keys != keys || !eq2(d, dir)) return false;
+        if ((keys & kA) && s.A.ii != a) return false;
+        if ((keys & kB) && s.B.ii != b) return false;
+        if ((keys & kC) && s.C.ii != c) return false;
+        return true;
+    }
+    __device__ __forceinline__ bool step(const Simplex2& s, const V2& d)
+    {
+        if (same(s, d)) return true;
+        if (++lam == power) { take(s, d); power *= 2; lam = 0; }
+        return false;
+    }
+};
+
+// run_quarter for point sets whose z are all zero (the caller has checked)
+template <class Mem>
+__device__ __forceinline__ void run_quarter2(Ctx<Mem>& g, int max_iter, int md_cap, Result& r)
+{
+    Simplex2 s;
+    s.keys = 0;
+    s.A = Vert2{ V2{ 0, 0 }, 0 };
+    s.B = s.A; s.C = s.A;
+    Simplex2 old = s;
+    Checkpoint2 chk;
+    chk.start(s, V2{ 0, 0 });
+    V2 dir{ 1.0, 0.0 };
+    const double qnan = __builtin_nan("");
+    r.flag = -1; r.status = OBTG_ST_MAXITER;
+    r.c1 = V3{ qnan, qnan, qnan }; r.c2 = r.c1; r.dist = qnan;
+    {
+        const int l = threadIdx.x & 15;
+        const V2 p1 = point2(g.mem, g.P1, l < g.P1.K ? l : 0), p2 = point2(g.mem, g.P2, l < g.P2.K ? l : 0);
+        g.own1 = V3{ p1.x, p1.y, 0.0 };
+        g.own2 = V3{ p2.x, p2.y, 0.0 };
+    }
+    int phase = 0, it = 0, rr = 0;
+    bool live = max_iter > 0, conv = false;
+    while (live) {
+        if (phase) old = s;
+        simplex_update2(s, dir);
+        support_pts_quarter2<Mem>(g, dir, s.A);
+        s.keys |= kA;
+        if (!phase) {
+            if (s.keys & kColl) { r.flag = 0; r.status = OBTG_ST_OK; live = false; }
+            else if (dotb2(s.A.v, dir) < 0) { phase = 1; chk.start(s, dir); }
+            else if (++it >= max_iter) live = false;
+        } else {
+            if (matches_old2(g, old, s.A.v)) { conv = true; live = false; }
+            else if (chk.step(s, dir)) { r.flag = 1; r.status = OBTG_ST_CYCLE; live = false; }
+            else if (++rr >= md_cap) { r.flag = 1; r.status = OBTG_ST_MD_CAP; live = false; }
+        }
+    }
+    if (conv) {
+        r.flag = 1; r.status = OBTG_ST_OK;
+        closest_from_simplex(g, lift(old), r);
+    }
+    r.n_support = g.n_support;
 }
 
 }  // namespace gjk

@@ -2082,6 +2082,11 @@ enum { R_CAP = 0, R_LB, R_T1, R_T2, R_UB, R_AM, R_NREC };
 enum { Q_NSCAL = F_NSCAL };               // frame scalars: k_min_dist_wave's (F_STATE: the next child, 0..4)
 __host__ __device__ constexpr int md_quad_blob(int K) { return 12 * K + 4 * R_NREC; }
 constexpr int kMdQuadMaxK = 16;
+// The scalars of the frames below the walk's: the first kMdScsLds levels in LDS, deeper ones behind their frame's blob in the
+// global stack (round 6: at max_depth 128 the scalars were 10 of a worker's 15.4 KB of LDS and held a CU to ten workers;
+// a search that ends is a few levels deep, one that runs into the depth cap pays two global round trips per level below 32).
+constexpr int kMdScsLds = 32;
+__host__ __device__ constexpr int md_quad_frame(int K) { return md_quad_blob(K) + Q_NSCAL; }     // doubles of a frame in the global stack
 // doubles of split-parameter scratch per 16-lane row: 2 x 16 used; 34 (not 32 = 64 banks) so that the four rows' broadcast
 // reads of the same element fall into four banks (PMC: a quarter of the LDS cycles were conflicts with 32)
 constexpr int kMdShRow = 34;
@@ -2215,17 +2220,19 @@ __device__ __forceinline__ void hull_param_quarter2(const double* c1, const doub
 // the wavefront walks through the longest of every kind, a division at a time, and the two calls were 11.6 k clocks of an
 // evaluation's 33 k (profiles/r05_experiments/mindist_quad_phases.txt).  Here every lane forms ALL K quotients of both curves
 // -- 2 K independent divisions, unrolled -- and the sums pick their terms by predicate in the order numpy adds them.
-template <int K, bool TWO = true>      // TWO = false: curve 1 only (c2 / cl2 / t2 unused: the curve <-> polygon search)
+// PLANAR: every z of both curves and of both closest points is an exact zero (2-D curves, bezier.py:1294-1308): the z loads,
+// the z clause of the row match (0 == 0) and the `+= dz * dz` (s + 0 = s) are dropped -- the same values.
+template <int K, bool TWO = true, bool PLANAR = false>      // TWO = false: curve 1 only (c2 / cl2 / t2 unused: the curve <-> polygon search)
 __device__ __forceinline__ void hull_param_quarter2_t(const double* c1, const double* c2, const V3& cl1, const V3& cl2,
                                                       double* sh_e, double* sh_q, double& t1, double& t2)
 {
     static_assert(K >= 2 && K <= 16, "a 16-lane row per curve pair");
     const int lane = threadIdx.x & 63, l = lane & 15;
     const int li = l < K ? l : 0;                        // (lanes past the curve repeat point 0; nothing of theirs is used)
-    const double ax = c1[li], ay = c1[K + li], az = c1[2 * K + li];
-    const double bx = TWO ? c2[li] : 0.0, by = TWO ? c2[K + li] : 0.0, bz = TWO ? c2[2 * K + li] : 0.0;
-    const bool hit1 = l < K && ax == cl1.x && ay == cl1.y && az == cl1.z;
-    const bool hit2 = TWO && l < K && bx == cl2.x && by == cl2.y && bz == cl2.z;
+    const double ax = c1[li], ay = c1[K + li], az = PLANAR ? 0.0 : c1[2 * K + li];
+    const double bx = TWO ? c2[li] : 0.0, by = TWO ? c2[K + li] : 0.0, bz = (TWO && !PLANAR) ? c2[2 * K + li] : 0.0;
+    const bool hit1 = l < K && ax == cl1.x && ay == cl1.y && (PLANAR || az == cl1.z);
+    const bool hit2 = TWO && l < K && bx == cl2.x && by == cl2.y && (PLANAR || bz == cl2.z);
     const unsigned m1 = (unsigned)(__ballot(hit1) >> (lane & 48)) & 0xffffu;
     const unsigned m2 = TWO ? (unsigned)(__ballot(hit2) >> (lane & 48)) & 0xffffu : 1u;
     if (m1) t1 = (double)(__ffs((int)m1) - 1) / (double)(K - 1);
@@ -2235,13 +2242,15 @@ __device__ __forceinline__ void hull_param_quarter2_t(const double* c1, const do
     {
         const double dx = cl1.x - ax, dy = cl1.y - ay, dz = cl1.z - az;
         double s = 0.0;
-        s += dx * dx; s += dy * dy; s += dz * dz;
+        s += dx * dx; s += dy * dy;
+        if constexpr (!PLANAR) s += dz * dz;
         ea = __builtin_sqrt(s);
         eb = 1.0;
         if constexpr (TWO) {
             const double ex = cl2.x - bx, ey = cl2.y - by, ez = cl2.z - bz;
             double u = 0.0;
-            u += ex * ex; u += ey * ey; u += ez * ez;
+            u += ex * ex; u += ey * ey;
+            if constexpr (!PLANAR) u += ez * ez;
             eb = __builtin_sqrt(u);
         }
     }
@@ -2298,11 +2307,12 @@ __device__ __forceinline__ void hull_param_quarter2_t(const double* c1, const do
 }
 
 // the curve's parameter alone (curve <-> polygon search)
+template <bool PLANAR = false>
 __device__ __forceinline__ double hull_param_row(const double* c1, int K, const V3& cl1, double* sh_e, double* sh_q)
 {
     double t1 = 0.0, t2 = 0.0;
     switch (K) {        // (wave-uniform)
-#define OBTG_CASE(NC_) case NC_: hull_param_quarter2_t<NC_, false>(c1, c1, cl1, cl1, sh_e, sh_q, t1, t2); return t1;
+#define OBTG_CASE(NC_) case NC_: hull_param_quarter2_t<NC_, false, PLANAR>(c1, c1, cl1, cl1, sh_e, sh_q, t1, t2); return t1;
         OBTG_NC_DYN(OBTG_CASE)
 #undef OBTG_CASE
         default: hull_param_quarter2(c1, c1, K, cl1, cl1, sh_e, sh_q, t1, t2);
@@ -2310,11 +2320,12 @@ __device__ __forceinline__ double hull_param_row(const double* c1, int K, const 
     return t1;
 }
 
+template <bool PLANAR = false>
 __device__ __forceinline__ void hull_param_rows(const double* c1, const double* c2, int K, const V3& cl1, const V3& cl2,
                                                 double* sh_e, double* sh_q, double& t1, double& t2)
 {
     switch (K) {        // (wave-uniform)
-#define OBTG_CASE(NC_) case NC_: hull_param_quarter2_t<NC_>(c1, c2, cl1, cl2, sh_e, sh_q, t1, t2); return;
+#define OBTG_CASE(NC_) case NC_: hull_param_quarter2_t<NC_, true, PLANAR>(c1, c2, cl1, cl2, sh_e, sh_q, t1, t2); return;
         OBTG_NC_DYN(OBTG_CASE)
 #undef OBTG_CASE
         default: hull_param_quarter2(c1, c2, K, cl1, cl2, sh_e, sh_q, t1, t2);
@@ -2325,6 +2336,7 @@ __device__ __forceinline__ void hull_param_rows(const double* c1, const double* 
 // the split parameters of its closest points (bezier.py:1313-1351), the end-point bound (_upperbound, bezier.py:1255-1280).
 // o1 / o2: offsets of the row's two curves in `lds`; rec: the row's record.  Every lane of a row stores the row's (equal)
 // values: no lane-dependent region (see the queue pull of k_min_dist_wave).
+template <bool PLANAR = false>
 __device__ __forceinline__ void md_eval_rows(const double* lds, int o1, int o2, int K, double eps, int max_iter, int md_cap,
                                              double* rec, double* sh_e, double* sh_q
 #ifdef OBTG_MD_TIMING
@@ -2341,7 +2353,8 @@ __device__ __forceinline__ void md_eval_rows(const double* lds, int o1, int o2, 
 #ifdef OBTG_MD_TIMING
     const unsigned long long tq0 = __builtin_readcyclecounter();
 #endif
-    gjk::run_quarter<MemLds>(g, max_iter, md_cap, gr);
+    if constexpr (PLANAR) gjk::run_quarter2<MemLds>(g, max_iter, md_cap, gr);
+    else gjk::run_quarter<MemLds>(g, max_iter, md_cap, gr);
 #ifdef OBTG_MD_TIMING
     if (gr.dist == -1.0) rec[R_CAP] = 0.0;      // (keeps the call ahead of the stamp)
     tm[0] += __builtin_readcyclecounter() - tq0;
@@ -2352,7 +2365,7 @@ __device__ __forceinline__ void md_eval_rows(const double* lds, int o1, int o2, 
     const double* c1 = lds + o1; const double* c2 = lds + o2;
     if (gr.flag > 0 && !cap) {
         lb = gr.dist;
-        hull_param_rows(c1, c2, K, gr.c1, gr.c2, sh_e, sh_q, t1, t2);
+        hull_param_rows<PLANAR>(c1, c2, K, gr.c1, gr.c2, sh_e, sh_q, t1, t2);
     }
 #ifdef OBTG_MD_TIMING
     if (t1 == -1.0) rec[R_CAP] = 0.0;
@@ -2360,10 +2373,23 @@ __device__ __forceinline__ void md_eval_rows(const double* lds, int o1, int o2, 
     const unsigned long long tq2 = __builtin_readcyclecounter();
 #endif
     double dd[4];
-    dd[0] = norm_seq(c1[0], c1[K], c1[2 * K], c2[0], c2[K], c2[2 * K]);
-    dd[1] = norm_seq(c1[0], c1[K], c1[2 * K], c2[K - 1], c2[2 * K - 1], c2[3 * K - 1]);
-    dd[2] = norm_seq(c1[K - 1], c1[2 * K - 1], c1[3 * K - 1], c2[0], c2[K], c2[2 * K]);
-    dd[3] = norm_seq(c1[K - 1], c1[2 * K - 1], c1[3 * K - 1], c2[K - 1], c2[2 * K - 1], c2[3 * K - 1]);
+    if constexpr (PLANAR) {          // (norm_seq with dz = 0: s + 0 * 0 = s)
+        auto n2 = [](double ax, double ay, double bx, double by) {
+            const double dx = ax - bx, dy = ay - by;
+            double s = 0.0;
+            s += dx * dx; s += dy * dy;
+            return __builtin_sqrt(s);
+        };
+        dd[0] = n2(c1[0], c1[K], c2[0], c2[K]);
+        dd[1] = n2(c1[0], c1[K], c2[K - 1], c2[2 * K - 1]);
+        dd[2] = n2(c1[K - 1], c1[2 * K - 1], c2[0], c2[K]);
+        dd[3] = n2(c1[K - 1], c1[2 * K - 1], c2[K - 1], c2[2 * K - 1]);
+    } else {
+        dd[0] = norm_seq(c1[0], c1[K], c1[2 * K], c2[0], c2[K], c2[2 * K]);
+        dd[1] = norm_seq(c1[0], c1[K], c1[2 * K], c2[K - 1], c2[2 * K - 1], c2[3 * K - 1]);
+        dd[2] = norm_seq(c1[K - 1], c1[2 * K - 1], c1[3 * K - 1], c2[0], c2[K], c2[2 * K]);
+        dd[3] = norm_seq(c1[K - 1], c1[2 * K - 1], c1[3 * K - 1], c2[K - 1], c2[2 * K - 1], c2[3 * K - 1]);
+    }
     int am = 0;
     for (int i = 1; i < 4; ++i) if (dd[i] < dd[am]) am = i;
     for (int i = 0; i < 4; ++i) if (dd[i] != dd[i]) { am = i; break; }
@@ -2375,16 +2401,25 @@ __device__ __forceinline__ void md_eval_rows(const double* lds, int o1, int o2, 
 #endif
 }
 
-__global__ __launch_bounds__(64, OBTG_MD_MIN_WAVES) void k_min_dist_quad(const MdParams p)
+#ifndef OBTG_MD_MIN_WAVES_PLANAR
+#define OBTG_MD_MIN_WAVES_PLANAR 3     // the planar form's simplices, checkpoint and own points are two thirds the size
+#endif
+// PLANAR: every curve of the call has z == 0 in every control point (the host has looked): the planar gjkNew machine per row.
+// W: worker waves per SIMD the registers are held to.  The planar form has two builds: W = 2 (223 registers, nothing spilled) for
+// calls that are bound by the chain of their longest search (a few pairs per worker: one evaluation's 4560 pairs, 6.4 ms
+// against 7.7), W = 3 (168 registers, 44 spilled) for calls bound by the chip's issue rate (the Jacobian's 114 000: 76 ms
+// against 94) -- launch_min_dist picks by pairs per worker.
+template <bool PLANAR, int W>
+__global__ __launch_bounds__(64, W) void k_min_dist_quad(const MdParams p)
 {
     extern __shared__ double md_lds[];
     const int lane = threadIdx.x, q = lane >> 4;
-    const int K = p.K, BL = md_quad_blob(K);
-    double* st = p.stack + (size_t)blockIdx.x * p.max_depth * BL;
+    const int K = p.K, BL = md_quad_blob(K), FRM = md_quad_frame(K);
+    double* st = p.stack + (size_t)blockIdx.x * p.max_depth * FRM;
     double* sh_e = md_lds + 2 * BL;             // [4][kMdShRow]: [2][16] per row of the wavefront, the rows' banks apart
     double* sh_q = sh_e + 4 * kMdShRow;         // the same
     double* dump = sh_q + 4 * kMdShRow;         // [64]
-    double* scs = dump + 64;                    // [max_depth][Q_NSCAL] frame scalars
+    double* scs = dump + 64;                    // [min(max_depth, kMdScsLds)][Q_NSCAL] frame scalars; deeper frames: st + d * FRM + BL
   for (;;) {
     const int ticket = atomicAdd(p.queue, lane == 0 ? 1 : 0);      // (see k_min_dist_wave)
     const int slot = __builtin_amdgcn_readfirstlane(ticket);
@@ -2418,10 +2453,10 @@ __global__ __launch_bounds__(64, OBTG_MD_MIN_WAVES) void k_min_dist_quad(const M
         wave_sync();
 #ifdef OBTG_MD_TIMING
         unsigned long long tq = __builtin_readcyclecounter();
-        md_eval_rows(md_lds, (int)(nxt - md_lds) + (q >> 1) * 3 * K, (int)(nxt - md_lds) + (2 + (q & 1)) * 3 * K, K, p.eps,
+        md_eval_rows<PLANAR>(md_lds, (int)(nxt - md_lds) + (q >> 1) * 3 * K, (int)(nxt - md_lds) + (2 + (q & 1)) * 3 * K, K, p.eps,
                      p.max_iter, p.md_cap, nxt + 12 * K + q * R_NREC, sh_e + q * kMdShRow, sh_q + q * kMdShRow, tm_ev);
 #else
-        md_eval_rows(md_lds, (int)(nxt - md_lds) + (q >> 1) * 3 * K, (int)(nxt - md_lds) + (2 + (q & 1)) * 3 * K, K, p.eps,
+        md_eval_rows<PLANAR>(md_lds, (int)(nxt - md_lds) + (q >> 1) * 3 * K, (int)(nxt - md_lds) + (2 + (q & 1)) * 3 * K, K, p.eps,
                      p.max_iter, p.md_cap, nxt + 12 * K + q * R_NREC, sh_e + q * kMdShRow, sh_q + q * kMdShRow);
 #endif
         wave_sync();
@@ -2429,7 +2464,7 @@ __global__ __launch_bounds__(64, OBTG_MD_MIN_WAVES) void k_min_dist_quad(const M
         const unsigned long long tq3 = __builtin_readcyclecounter();
 #endif
         if (eval_depth >= 0) {
-            double* f = st + (size_t)eval_depth * BL;
+            double* f = st + (size_t)eval_depth * FRM;
             for (int i = lane; i < BL; i += kWave) f[i] = nxt[i];
         }
         { double* tsw = cur; cur = nxt; nxt = tsw; }
@@ -2452,7 +2487,9 @@ __global__ __launch_bounds__(64, OBTG_MD_MIN_WAVES) void k_min_dist_quad(const M
                 r0 = f_alpha; r1 = f_rt1; r2 = f_rt2;
                 depth--;
                 if (depth < 0) { done = true; break; }
-                const double* sc = scs + depth * Q_NSCAL;
+                const bool deep = depth >= kMdScsLds;
+                if (deep) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+                const double* sc = deep ? st + (size_t)depth * FRM + BL : scs + depth * Q_NSCAL;
                 f_t1 = sc[F_T1]; f_t2 = sc[F_T2]; f_t1l = sc[F_T1L]; f_t1h = sc[F_T1H]; f_t2l = sc[F_T2L]; f_t2h = sc[F_T2H];
                 f_alpha = sc[F_ALPHA]; f_rt1 = sc[F_RT1]; f_rt2 = sc[F_RT2]; f_next = (int)sc[F_STATE];
                 OBTG_MD_RETURN()
@@ -2468,7 +2505,7 @@ __global__ __launch_bounds__(64, OBTG_MD_MIN_WAVES) void k_min_dist_quad(const M
                 const unsigned long long tf0 = __builtin_readcyclecounter();
 #endif
                 __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-                const double* f = st + (size_t)depth * BL;
+                const double* f = st + (size_t)depth * FRM;
                 for (int i = lane; i < BL; i += kWave) cur[i] = f[i];
                 cur_depth = depth;
                 wave_sync();
@@ -2509,7 +2546,7 @@ __global__ __launch_bounds__(64, OBTG_MD_MIN_WAVES) void k_min_dist_quad(const M
             tm_split += __builtin_readcyclecounter() - ts0;
 #endif
             if (depth >= 0) {
-                double* sc = scs + depth * Q_NSCAL;
+                double* sc = depth >= kMdScsLds ? st + (size_t)depth * FRM + BL : scs + depth * Q_NSCAL;
                 sc[F_T1] = f_t1; sc[F_T2] = f_t2; sc[F_T1L] = f_t1l; sc[F_T1H] = f_t1h; sc[F_T2L] = f_t2l; sc[F_T2H] = f_t2h;
                 sc[F_ALPHA] = f_alpha; sc[F_RT1] = f_rt1; sc[F_RT2] = f_rt2; sc[F_STATE] = (double)f_next;
             }
@@ -2959,6 +2996,7 @@ enum { G_T1 = 0, G_T1L, G_T1H, G_ALPHA, G_RT1, G_PX, G_PY, G_PZ, G_STATE, G_NSCA
 // a child's record / the blob of a frame in k_min_dist2poly_quad (further down)
 enum { P_CAP = 0, P_POS, P_LB, P_T1, P_UB, P_AM, P_CX, P_CY, P_CZ, P_NREC };
 __host__ __device__ constexpr int md2_quad_blob(int K) { return 6 * K + 2 * P_NREC; }
+__host__ __device__ constexpr int md2_quad_frame(int K) { return md2_quad_blob(K) + G_NSCAL; }   // a frame in the global stack: blob, then (below level kMdScsLds) its scalars
 
 struct Md2Params {
     const double* __restrict__ curves;   // [n_curves][3][K]
@@ -2971,6 +3009,7 @@ struct Md2Params {
     double* stack;
     double* __restrict__ res;             // [n_pairs][5]
     int* __restrict__ info;
+    int quad_frame;                       // k_min_dist2poly_quad: doubles per frame of `stack` (what min_dist2poly_stack_doubles sized it by)
 };
 
 constexpr int kPolyBias = 1 << 24;
@@ -3962,15 +4001,15 @@ int launch_step_fd_structured(obtg_ctx* c, int B, double max_sep, double* d_out_
 
 size_t min_dist2poly_stack_doubles(int K, int max_depth)      // per pair: the larger of the frame forms
 {
-    const int fr = 3 * K + G_NSCAL, bl = K <= kMdQuadMaxK ? md2_quad_blob(K) : 0;
+    const int fr = 3 * K + G_NSCAL, bl = K <= kMdQuadMaxK ? md2_quad_frame(K) : 0;
     return (size_t)max_depth * (fr > bl ? fr : bl);
 }
 
 // worker waves of the wave-per-pair searches: waves per SIMD x 4 SIMDs x CUs, never more than pairs (OBTG_MD_WAVES_PER_SIMD)
-int min_dist_workers(const obtg_ctx* c, int n_pairs, size_t lds_per_wave)
+int min_dist_workers(const obtg_ctx* c, int n_pairs, size_t lds_per_wave, int waves_per_simd)
 {
     static const int env = getenv("OBTG_MD_WAVES_PER_SIMD") ? atoi(getenv("OBTG_MD_WAVES_PER_SIMD")) : 0;
-    int per_simd = env > 0 ? env : 2;
+    int per_simd = env > 0 ? env : waves_per_simd;
     const int by_lds = (int)((size_t)160 * 1024 / (lds_per_wave ? lds_per_wave : 1)) / 4;   // a CU's LDS over its four SIMDs
     if (per_simd > by_lds) per_simd = by_lds > 0 ? by_lds : 1;
     const long w = (long)per_simd * 4 * (c->n_cus > 0 ? c->n_cus : 256);
@@ -3986,7 +4025,7 @@ static MdPlan md_plan(int K, int max_depth)
 {
     MdPlan pl;
     pl.lds_w = sizeof(double) * ((size_t)12 * K + 6 * kMdMaxK + (size_t)max_depth * F_NSCAL);
-    pl.lds_q = sizeof(double) * ((size_t)2 * md_quad_blob(K) + 8 * kMdShRow + 64 + (size_t)max_depth * Q_NSCAL);
+    pl.lds_q = sizeof(double) * ((size_t)2 * md_quad_blob(K) + 8 * kMdShRow + 64 + (size_t)(max_depth < kMdScsLds ? max_depth : kMdScsLds) * Q_NSCAL);
     pl.wave_ok = pl.lds_w <= 48 * 1024;
     pl.quad_ok = K <= kMdQuadMaxK && pl.lds_q <= 48 * 1024;
     return pl;
@@ -3998,9 +4037,9 @@ size_t min_dist_stack_doubles(const obtg_ctx* c, int K, int max_depth, int n_pai
 {
     const MdPlan pl = md_plan(K, max_depth);
     size_t need = 0;
-    if (pl.quad_ok) need = (size_t)min_dist_workers(c, n_pairs, pl.lds_q) * max_depth * md_quad_blob(K);
+    if (pl.quad_ok) need = (size_t)min_dist_workers(c, n_pairs, pl.lds_q, OBTG_MD_MIN_WAVES_PLANAR) * max_depth * md_quad_frame(K);
     if (pl.wave_ok) {
-        const size_t w = (size_t)min_dist_workers(c, n_pairs, pl.lds_w) * max_depth * (6 * K + F_NSCAL);
+        const size_t w = (size_t)min_dist_workers(c, n_pairs, pl.lds_w, OBTG_MD_MIN_WAVES) * max_depth * (6 * K + F_NSCAL);
         if (w > need) need = w;
     }
     if (!pl.quad_ok && !pl.wave_ok) need = (size_t)n_pairs * max_depth * (6 * K + F_NSCAL);
@@ -4009,7 +4048,7 @@ size_t min_dist_stack_doubles(const obtg_ctx* c, int K, int max_depth, int n_pai
 
 int launch_min_dist(obtg_ctx* c, const double* d_curves, int K, const int* d_pa, const int* d_pb,
                     int n_pairs, double eps, int max_iter, int md_cap, int max_depth, int max_nodes,
-                    double* d_stack, double* d_res, int* d_info, const int* d_order, int* d_queue)
+                    double* d_stack, double* d_res, int* d_info, const int* d_order, int* d_queue, bool planar)
 {
     if (n_pairs <= 0) return OBTG_OK;
     if (K < 2 || K > kMdMaxK || max_depth < 1) return OBTG_ERR_UNSUPPORTED;
@@ -4022,10 +4061,19 @@ int launch_min_dist(obtg_ctx* c, const double* d_curves, int K, const int* d_pa,
     const bool quad = pl.quad_ok && d_queue && !(env_form && !strcmp(env_form, "wave"));
     if (quad) {                            // a 16-lane row per child: four gjkNew calls of a node's children in lockstep
         OBTG_HIP(c, hipMemsetAsync(d_queue, 0, sizeof(int), c->stream));
-        hipLaunchKernelGGL(k_min_dist_quad, dim3((unsigned)min_dist_workers(c, n_pairs, lds_q)), dim3(kWave), lds_q, c->stream, p);
+        static const bool no_planar = getenv("OBTG_MD_PLANAR") && getenv("OBTG_MD_PLANAR")[0] == '0';      // (A/B runs: the 3-D machine on planar curves)
+        static const int many_env = getenv("OBTG_MD_MANY") ? atoi(getenv("OBTG_MD_MANY")) : 0;             // pairs per worker from which a call counts as issue bound
+        const int w3 = min_dist_workers(c, n_pairs, lds_q, OBTG_MD_MIN_WAVES_PLANAR);
+        const bool many = (long)n_pairs >= (long)(many_env > 0 ? many_env : 8) * w3;
+        if (planar && !no_planar && many)
+            hipLaunchKernelGGL((k_min_dist_quad<true, OBTG_MD_MIN_WAVES_PLANAR>), dim3((unsigned)w3), dim3(kWave), lds_q, c->stream, p);
+        else if (planar && !no_planar)
+            hipLaunchKernelGGL((k_min_dist_quad<true, OBTG_MD_MIN_WAVES>), dim3((unsigned)min_dist_workers(c, n_pairs, lds_q, OBTG_MD_MIN_WAVES)), dim3(kWave), lds_q, c->stream, p);
+        else
+            hipLaunchKernelGGL((k_min_dist_quad<false, OBTG_MD_MIN_WAVES>), dim3((unsigned)min_dist_workers(c, n_pairs, lds_q, OBTG_MD_MIN_WAVES)), dim3(kWave), lds_q, c->stream, p);
     } else if (pl.wave_ok && d_queue) {    // one pair per wavefront at a time, the waves as workers on a queue
         OBTG_HIP(c, hipMemsetAsync(d_queue, 0, sizeof(int), c->stream));
-        hipLaunchKernelGGL(k_min_dist_wave, dim3((unsigned)min_dist_workers(c, n_pairs, lds_w)), dim3(kWave), lds_w, c->stream, p);
+        hipLaunchKernelGGL(k_min_dist_wave, dim3((unsigned)min_dist_workers(c, n_pairs, lds_w, OBTG_MD_MIN_WAVES)), dim3(kWave), lds_w, c->stream, p);
     } else
         hipLaunchKernelGGL(k_min_dist, dim3((n_pairs + 63) / 64), dim3(64), 0, c->stream, p);
     OBTG_HIP(c, hipGetLastError());
@@ -4177,6 +4225,7 @@ __device__ __forceinline__ void split_one_both(const double* c, int K, double t,
 
 // the record of the (curve piece, polygon) pair a row of the wavefront names: gjkNew, the curve's split parameter (bezier.py:
 // 1436-1452), _upperboundPoly (the curve's end points against the polygon's closest point)
+template <bool PLANAR = false>
 __device__ __forceinline__ void md2_eval_rows(const double* lds, int oc, int K, int op, int PK, int max_iter, int md_cap,
                                               double* rec, double* sh_e, double* sh_q)
 {
@@ -4186,16 +4235,18 @@ __device__ __forceinline__ void md2_eval_rows(const double* lds, int oc, int K, 
     g.P2 = Poly{ op, 16, PK, 1 };
     g.trace = nullptr; g.trace_cap = 0; g.n_support = 0;
     Result gr;
-    gjk::run_quarter<MemLds>(g, max_iter, md_cap, gr);
+    if constexpr (PLANAR) gjk::run_quarter2<MemLds>(g, max_iter, md_cap, gr);
+    else gjk::run_quarter<MemLds>(g, max_iter, md_cap, gr);
     const bool cap = gr.status == OBTG_ST_MD_CAP || gr.status == OBTG_ST_CYCLE;
     const bool pos = gr.flag > 0 && !cap;
     const double* c1 = lds + oc;
     double t1 = 0.5, ub = INFINITY;
     int am = 0;
     if (pos) {
-        t1 = hull_param_row(c1, K, gr.c1, sh_e, sh_q);
-        const double d0 = norm_seq(c1[0], c1[K], c1[2 * K], gr.c2.x, gr.c2.y, gr.c2.z);
-        const double d1 = norm_seq(c1[K - 1], c1[2 * K - 1], c1[3 * K - 1], gr.c2.x, gr.c2.y, gr.c2.z);
+        t1 = hull_param_row<PLANAR>(c1, K, gr.c1, sh_e, sh_q);
+        // (PLANAR: the curve's z row and the closest point's z are exact zeros; norm_seq's `+= dz * dz` adds 0)
+        const double d0 = norm_seq(c1[0], c1[K], PLANAR ? 0.0 : c1[2 * K], gr.c2.x, gr.c2.y, PLANAR ? 0.0 : gr.c2.z);
+        const double d1 = norm_seq(c1[K - 1], c1[2 * K - 1], PLANAR ? 0.0 : c1[3 * K - 1], gr.c2.x, gr.c2.y, PLANAR ? 0.0 : gr.c2.z);
         am = (d1 < d0) ? 1 : 0;
         if (d0 != d0) am = 0; else if (d1 != d1) am = 1;
         ub = am ? d1 : d0;
@@ -4204,20 +4255,25 @@ __device__ __forceinline__ void md2_eval_rows(const double* lds, int oc, int K, 
     rec[P_AM] = (double)am; rec[P_CX] = gr.c2.x; rec[P_CY] = gr.c2.y; rec[P_CZ] = gr.c2.z;
 }
 
-__global__ __launch_bounds__(64, OBTG_MD_MIN_WAVES) void k_min_dist2poly_quad(const Md2Params p)
+#ifndef OBTG_MD2_MIN_WAVES_PLANAR
+#define OBTG_MD2_MIN_WAVES_PLANAR 4
+#endif
+// PLANAR: the curves and the polygons of the call all have z == 0 (the host has looked): the planar gjkNew machine per row
+template <bool PLANAR>
+__global__ __launch_bounds__(64, PLANAR ? OBTG_MD2_MIN_WAVES_PLANAR : OBTG_MD_MIN_WAVES) void k_min_dist2poly_quad(const Md2Params p)
 {
     extern __shared__ double m2q_lds[];
     const int k = blockIdx.x, lane = threadIdx.x, q = (lane >> 4) & 1;        // rows 2, 3 repeat rows 0, 1
-    const int K = p.K, BL = md2_quad_blob(K);
+    const int K = p.K, BL = md2_quad_blob(K), FRM = p.quad_frame;             // FRM: doubles per frame of this call's stack (>= md2_quad_frame(K))
     const int po = p.off[p.pp[k]], PK = p.off[p.pp[k] + 1] - po;
-    double* st = p.stack + (size_t)k * p.max_depth * BL;
+    double* st = p.stack + (size_t)k * p.max_depth * FRM;
     double* cur = m2q_lds;                      // [BL] blob of the frame `cur_depth`
     double* nxt = cur + BL;                     // [BL] blob being built
     double* pol = nxt + BL;                     // [3][16] polygon, SoA
     double* sh_e = pol + 48;                    // [4][kMdShRow]
     double* sh_q = sh_e + 4 * kMdShRow;
     double* dump = sh_q + 4 * kMdShRow;         // [64]
-    double* scs = dump + 64;                    // [max_depth][G_NSCAL] frame scalars
+    double* scs = dump + 64;                    // [min(max_depth, kMdScsLds)][G_NSCAL] frame scalars; deeper frames: st + d * FRM + BL
     const double* ca = p.curves + (size_t)p.pc[k] * 3 * K;
     for (int i = lane; i < 3 * K; i += kWave) { const double a = ca[i]; nxt[i] = a; nxt[3 * K + i] = a; }      // frame "-1": pieces c, c
     for (int i = lane; i < 3 * PK; i += kWave) pol[(i / PK) * 16 + (i % PK)] = p.soa[3 * po + i];
@@ -4230,11 +4286,11 @@ __global__ __launch_bounds__(64, OBTG_MD_MIN_WAVES) void k_min_dist2poly_quad(co
     bool done = false;
     while (!done) {
         wave_sync();
-        md2_eval_rows(m2q_lds, (int)(nxt - m2q_lds) + q * 3 * K, K, (int)(pol - m2q_lds), PK, p.max_iter, p.md_cap,
+        md2_eval_rows<PLANAR>(m2q_lds, (int)(nxt - m2q_lds) + q * 3 * K, K, (int)(pol - m2q_lds), PK, p.max_iter, p.md_cap,
                       nxt + 6 * K + q * P_NREC, sh_e + (lane >> 4) * kMdShRow, sh_q + (lane >> 4) * kMdShRow);
         wave_sync();
         if (eval_depth >= 0) {
-            double* f = st + (size_t)eval_depth * BL;
+            double* f = st + (size_t)eval_depth * FRM;
             for (int i = lane; i < BL; i += kWave) f[i] = nxt[i];
         }
         { double* tsw = cur; cur = nxt; nxt = tsw; }
@@ -4248,7 +4304,9 @@ __global__ __launch_bounds__(64, OBTG_MD_MIN_WAVES) void k_min_dist2poly_quad(co
                 r0 = f_alpha; r1 = f_rt1; rx = f_px; ry = f_py; rz = f_pz;
                 depth--;
                 if (depth < 0) { done = true; break; }
-                const double* sc = scs + depth * G_NSCAL;
+                const bool deep = depth >= kMdScsLds;
+                if (deep) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+                const double* sc = deep ? st + (size_t)depth * FRM + BL : scs + depth * G_NSCAL;
                 f_t1 = sc[G_T1]; f_t1l = sc[G_T1L]; f_t1h = sc[G_T1H]; f_alpha = sc[G_ALPHA]; f_rt1 = sc[G_RT1];
                 f_px = sc[G_PX]; f_py = sc[G_PY]; f_pz = sc[G_PZ]; f_next = (int)sc[G_STATE];
                 OBTG_MD2_RETURN()
@@ -4260,7 +4318,7 @@ __global__ __launch_bounds__(64, OBTG_MD_MIN_WAVES) void k_min_dist2poly_quad(co
             if (depth + 2 > dmax) dmax = depth + 2;
             if (cur_depth != depth) {            // the walk came back up: fetch this frame's blob again
                 __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-                const double* f = st + (size_t)depth * BL;
+                const double* f = st + (size_t)depth * FRM;
                 for (int i = lane; i < BL; i += kWave) cur[i] = f[i];
                 cur_depth = depth;
                 wave_sync();
@@ -4287,7 +4345,7 @@ __global__ __launch_bounds__(64, OBTG_MD_MIN_WAVES) void k_min_dist2poly_quad(co
             // expand the child: both its pieces to `nxt`; this frame goes to `scs`, the child's into the registers
             split_one_both(cur + h1 * 3 * K, K, t1, nxt, dump);
             if (depth >= 0) {
-                double* sc = scs + depth * G_NSCAL;
+                double* sc = depth >= kMdScsLds ? st + (size_t)depth * FRM + BL : scs + depth * G_NSCAL;
                 sc[G_T1] = f_t1; sc[G_T1L] = f_t1l; sc[G_T1H] = f_t1h; sc[G_ALPHA] = f_alpha; sc[G_RT1] = f_rt1;
                 sc[G_PX] = f_px; sc[G_PY] = f_py; sc[G_PZ] = f_pz; sc[G_STATE] = (double)f_next;
             }
@@ -4370,18 +4428,23 @@ int launch_min_dist2poly_robust(obtg_ctx* c, const double* d_curves, int K, cons
 int launch_min_dist2poly(obtg_ctx* c, const double* d_curves, int K, const double* d_soa,
                          const int* d_off, const int* d_pc, const int* d_pp, int n_pairs, double eps,
                          int max_iter, int md_cap, int max_depth, int max_nodes, double* d_stack,
-                         double* d_res, int* d_info, int max_poly_K)
+                         double* d_res, int* d_info, int max_poly_K, bool planar)
 {
     if (n_pairs <= 0) return OBTG_OK;
     if (K < 2 || K > kMdMaxK || max_depth < 1) return OBTG_ERR_UNSUPPORTED;
     Md2Params p{ d_curves, d_soa, d_off, d_pc, d_pp, n_pairs, K, max_iter, md_cap, max_depth, max_nodes, eps, cube_as_python(eps),
-                 d_stack, d_res, d_info };
+                 d_stack, d_res, d_info, (int)(min_dist2poly_stack_doubles(K, max_depth) / (size_t)max_depth) };
     ScopedKernelTimer t(c, OBTG_K_MIN_DIST);
     const size_t lds_w = sizeof(double) * ((size_t)6 * K + 8 * kMdMaxK + (size_t)max_depth * G_NSCAL);
-    const size_t lds_q = sizeof(double) * ((size_t)2 * md2_quad_blob(K) + 48 + 8 * kMdShRow + 64 + (size_t)max_depth * G_NSCAL);
+    const size_t lds_q = sizeof(double) * ((size_t)2 * md2_quad_blob(K) + 48 + 8 * kMdShRow + 64 +
+                                           (size_t)(max_depth < kMdScsLds ? max_depth : kMdScsLds) * G_NSCAL);
     const char* env_form = getenv("OBTG_MD_FORM");          // "wave": a wavefront per gjkNew call (read per launch: the A/B test flips it)
-    if (K <= kMdQuadMaxK && max_poly_K <= 16 && lds_q <= 48 * 1024 && !(env_form && !strcmp(env_form, "wave")))
-        hipLaunchKernelGGL(k_min_dist2poly_quad, dim3((unsigned)n_pairs), dim3(kWave), lds_q, c->stream, p);   // both children side by side
+    static const bool no_planar = getenv("OBTG_MD_PLANAR") && getenv("OBTG_MD_PLANAR")[0] == '0';          // (A/B runs)
+    if (K <= kMdQuadMaxK && max_poly_K <= 16 && lds_q <= 48 * 1024 && !(env_form && !strcmp(env_form, "wave"))) {
+        // both children side by side
+        if (planar && !no_planar) hipLaunchKernelGGL(k_min_dist2poly_quad<true>, dim3((unsigned)n_pairs), dim3(kWave), lds_q, c->stream, p);
+        else hipLaunchKernelGGL(k_min_dist2poly_quad<false>, dim3((unsigned)n_pairs), dim3(kWave), lds_q, c->stream, p);
+    }
     else if (lds_w <= 48 * 1024 && max_poly_K <= kMdMaxK)      // one pair per wavefront
         hipLaunchKernelGGL(k_min_dist2poly_wave, dim3((unsigned)n_pairs), dim3(kWave), lds_w, c->stream, p);
     else

@@ -247,13 +247,14 @@ int launch_gjk_swarm(obtg_ctx* c, const double* dY, int B, int max_iter, int md_
                      double* d_p1, double* d_p2, double* d_dist, int* d_nsup, int* d_status, SweepFold* fold = nullptr);
 int launch_min_dist(obtg_ctx* c, const double* d_curves, int K, const int* d_pa, const int* d_pb,
                     int n_pairs, double eps, int max_iter, int md_cap, int max_depth, int max_nodes,
-                    double* d_stack, double* d_res, int* d_info, const int* d_order = nullptr, int* d_queue = nullptr);
+                    double* d_stack, double* d_res, int* d_info, const int* d_order = nullptr, int* d_queue = nullptr,
+                    bool planar = false);      // planar: every control point of every curve has z == 0 (the caller has looked)
 int launch_min_dist_robust(obtg_ctx* c, const double* d_curves, int K, const int* d_pa, const int* d_pb, int n_pairs,
                            double eps, int max_nodes, int max_level, int cap, double* d_frontier, double* d_res, int* d_info);
 int launch_min_dist2poly(obtg_ctx* c, const double* d_curves, int K, const double* d_soa,
                          const int* d_off, const int* d_pc, const int* d_pp, int n_pairs, double eps,
                          int max_iter, int md_cap, int max_depth, int max_nodes, double* d_stack,
-                         double* d_res, int* d_info, int max_poly_K);
+                         double* d_res, int* d_info, int max_poly_K, bool planar = false);     // planar: curves AND polygons have z == 0 throughout
 int launch_gjk_true_pairs(obtg_ctx* c, const double* d_soa, const int* d_off, const int* d_pa, const int* d_pb, int n_pairs,
                           double eps, int max_iter, int* d_flag, double* d_p1, double* d_p2, double* d_dist, double* d_lower,
                           int* d_iters, int* d_status);

@@ -939,8 +939,97 @@ def gen_drivers():
     save("drivers.npz", **d)
 
 
+def gen_trajectories():
+    """Teacher-forced trajectory fixtures (round 6): the reference's OWN drivers run with an SLSQP `callback` that records
+    every iterate x_k, and every constraint closure's value there.  SLSQP amplifies the last bits of its callbacks, so two
+    float64 implementations do not stay on one trajectory (drivers.npz pins only outcomes); the iterates the REFERENCE
+    visited are data, and a replacement can be held to the reference's values at each of them with no SLSQP in the loop.
+      ex1_R{0,30}   Examples/Example1_DubinsCarTimeOptimal.py:94-148 (2 vehicles, degree 10, its own separation function
+                    with degElev, speed / angular rate at DEG_ELEV 0)
+      tt_R{0,10}    Examples/DubinsCarTimeOptimal.py:60-137, the attempt of its retry loop that converges (seeded guesses
+                    as in drivers.npz)
+      e2_R{0,10}    Examples/DubinsCarExample2.py:83-140, likewise (bounds)
+      sw            Examples/SwarmOfAerialVehicles.py:137-170 with the first 8 vehicles of its image (3-D, degree 5; the
+                    example's own initial guess; at most 40 iterations are kept)"""
+    import scipy.optimize as sop
+    import Example1_DubinsCarTimeOptimal as ex1
+    import SwarmOfAerialVehicles as swm
+    d = {}
+    names = []
+
+    def record(tag, bo, cons_named, x0, bounds=None, maxiter=250, keep=400):
+        xs = [np.array(x0, dtype=float)]
+        kw = dict(method='SLSQP', constraints=[{'type': 'ineq', 'fun': f} for _, f in cons_named] + [{'type': 'ineq', 'fun': lambda x: x[-1]}]
+                  if bo.model['minGoal'].lower() == 'timeopt' else [{'type': 'ineq', 'fun': f} for _, f in cons_named],
+                  options={'maxiter': maxiter, 'disp': False}, callback=lambda xk: xs.append(np.array(xk, dtype=float)))
+        if bounds is not None:
+            kw['bounds'] = bounds
+        try:
+            with np.errstate(all='ignore'):
+                r = sop.minimize(bo.objectiveFunction, x0=x0, **kw)
+            outcome = (1 if r.success else 0, r.nit, float(r.fun))
+        except TypeError:
+            outcome = (-1, -1, float('nan'))
+        xs = np.array(xs[:keep])
+        d[tag + "_x"] = xs
+        d[tag + "_y"] = np.array([bo.reshapeVector(x) for x in xs])
+        with np.errstate(all='ignore'):
+            for cname, f in cons_named:
+                d["%s_%s" % (tag, cname)] = np.array([f(x) for x in xs])
+            d[tag + "_obj"] = np.array([bo.objectiveFunction(x) for x in xs])
+        d[tag + "_outcome"] = np.array(outcome, dtype=float)
+        names.append(tag)
+        print("  %s: %d iterates kept, outcome %s" % (tag, len(xs), outcome))
+
+    # Example1: two Dubins cars
+    for elev in (0, 30):
+        opt.DEG_ELEV = 0
+        bo = opt.BezOptimization(numVeh=2, dimension=2, degree=10, minimizeGoal='TimeOpt', maxSep=1, maxSpeed=5, maxAngRate=1,
+                                 initPoints=[(0, 5), (3, 0)], finalPoints=[(8, 4), (7, 10)], initSpeeds=[1] * 2, finalSpeeds=[1] * 2,
+                                 initAngs=[0, np.pi / 2], finalAngs=[0, np.pi / 2], pointObstacles=[[3, 2], [6, 7]])
+        sep = (lambda e: (lambda x: ex1._temporalSeparationConstraints(bo.reshapeVector(x), 2, 2, 1, e)))(elev)
+        record("ex1_R%d" % elev, bo, [("tsep", sep), ("maxspeed", bo.maxSpeedConstraints), ("angrate", bo.maxAngularRateConstraints)],
+               bo.generateGuess(std=0))
+
+    # the two degree-8 Dubins drivers: the attempt that converges in the reference
+    def dubins_time_optimal():
+        return opt.BezOptimization(numVeh=1, dimension=2, degree=8, minimizeGoal='TimeOpt', maxSep=1, maxSpeed=5,
+                                   maxAngRate=1, initPoints=[(3, 0)], finalPoints=[(7, 10)], initSpeeds=[1], finalSpeeds=[1],
+                                   initAngs=[np.pi / 2], finalAngs=[np.pi / 2], pointObstacles=[[3, 2], [6, 7]])
+
+    def dubins_example2():
+        return opt.BezOptimization(numVeh=1, dimension=2, degree=8, minimizeGoal='TimeOpt', maxSep=1, maxSpeed=3,
+                                   maxAngRate=np.pi / 2, initPoints=[(0, 0)], finalPoints=[(12, 8)], initSpeeds=[1],
+                                   finalSpeeds=[1], tf=8, initAngs=[np.pi / 2], finalAngs=[0],
+                                   pointObstacles=[(3, 2), (7, 6), (9, 9), (4, 5), (5, 8), (3, 7), (7, 3)])
+
+    drv = np.load(os.path.join(HERE, "drivers.npz"))
+    for pre, make, bounds in (("tt", dubins_time_optimal, None),
+                              ("e2", dubins_example2, sop.Bounds([-100] * 10 + [0.0001], [100] * 10 + [50], [False] * 10 + [True]))):
+        for R in (0, 10):
+            opt.DEG_ELEV = R
+            bo = make()
+            outc = drv["%s_R%d_flow_outcome" % (pre, R)]
+            win = int(np.nonzero(outc == 1)[0][0])
+            x0 = drv["%s_R%d_flow_x0" % (pre, R)][win]
+            record("%s_R%d" % (pre, R), bo, [("tsep", bo.temporalSeparationConstraints), ("maxspeed", bo.maxSpeedConstraints),
+                                             ("angrate", bo.maxAngularRateConstraints)], x0, bounds)
+            d["%s_R%d_attempt" % (pre, R)] = np.array(win)
+    # the 3-D swarm, 8 vehicles
+    opt.DEG_ELEV = 0
+    nveh_all, initPts, finalPts = swm.generatePointsFromImage(swm.CAS_IMG)
+    sel = np.arange(8)
+    bo = opt.BezOptimization(numVeh=8, dimension=3, degree=5, minimizeGoal='Euclidean', maxSep=0.9,
+                             initPoints=initPts[sel], finalPoints=finalPts[sel])
+    d["sw_init"], d["sw_final"] = initPts[sel], finalPts[sel]
+    record("sw", bo, [("tsep", bo.temporalSeparationConstraints)], swm.generate3DGuess(initPts[sel], finalPts[sel], 5), maxiter=40, keep=41)
+    opt.DEG_ELEV = 0
+    d["names"] = np.array(names)
+    save("trajectories.npz", **d)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["tables", "ops", "problem", "constraints", "gjk", "mindist", "c5", "spatial", "nearstop", "sequential", "spatial_fd", "mindist_script", "c1_text", "fullsize", "drivers", "c4_hulls"]
+    which = sys.argv[1:] or ["trajectories", "tables", "ops", "problem", "constraints", "gjk", "mindist", "c5", "spatial", "nearstop", "sequential", "spatial_fd", "mindist_script", "c1_text", "fullsize", "drivers", "c4_hulls"]
     for w in which:
         if w == "none":          # import-only (exploration)
             continue

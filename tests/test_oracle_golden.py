@@ -459,3 +459,39 @@ def test_pow2_restated(oracle):
         prod = x * x
     one_ulp = (libm.view(np.int64) != prod.view(np.int64)) & ~np.isnan(libm)
     assert 0 < one_ulp.sum() < 0.01 * x.size        # the reason it is restated at all: pow(x, 2.0) is not x * x
+
+
+# (tag, vehicles, dim, degree, DEG_ELEV of the separation rows, DEG_ELEV of the speed / angular-rate rows, point obstacles in the
+#  pair loop, maxSep, maxSpeed, maxAngRate)
+TRAJECTORY_PROBLEMS = {
+    "ex1_R0": (2, 2, 10, 0, 0, None, 1.0, 5.0, 1.0), "ex1_R30": (2, 2, 10, 30, 0, None, 1.0, 5.0, 1.0),
+    "tt_R0": (1, 2, 8, 0, 0, [[3, 2], [6, 7]], 1.0, 5.0, 1.0), "tt_R10": (1, 2, 8, 10, 10, [[3, 2], [6, 7]], 1.0, 5.0, 1.0),
+    "e2_R0": (1, 2, 8, 0, 0, [(3, 2), (7, 6), (9, 9), (4, 5), (5, 8), (3, 7), (7, 3)], 1.0, 3.0, np.pi / 2),
+    "e2_R10": (1, 2, 8, 10, 10, [(3, 2), (7, 6), (9, 9), (4, 5), (5, 8), (3, 7), (7, 3)], 1.0, 3.0, np.pi / 2),
+    "sw": (8, 3, 5, 0, 0, None, 0.9, None, None),
+}
+
+
+def test_reference_trajectories_teacher_forced(oracle, golden_dir):
+    """trajectories.npz (round 6): every iterate x_k the REFERENCE's own SLSQP runs visited -- Example1 (DEG_ELEV 0 / 30),
+    the converging attempts of the two degree-8 Dubins drivers (DEG_ELEV 0 / 10), the 8-vehicle 3-D swarm -- with every
+    closure's value there.  The oracle at each of them, no SLSQP in the loop: 1e-12 on the separation and speed rows, 1e-9 on
+    the angular rate (as everywhere)."""
+    g = _load(golden_dir, "trajectories.npz")
+    assert sorted(g["names"].tolist()) == sorted(TRAJECTORY_PROBLEMS)
+    total = 0
+    for tag, (nveh, dim, deg, R_sep, R_dyn, obs, max_sep, vmax, wmax) in TRAJECTORY_PROBLEMS.items():
+        X, Y = g[tag + "_x"], g[tag + "_y"]
+        assert len(X) >= 16 and Y.shape == (len(X), nveh * dim, deg + 1)
+        for k in range(len(X)):
+            y = Y[k]
+            yo = y if obs is None else np.vstack([y] + [np.full((1, deg + 1), float(v)) for o in obs for v in o])
+            nobj = nveh + (0 if obs is None else len(obs))
+            assert_close(oracle.temporal_sep(yo, nobj, dim, R_sep, max_sep), g[tag + "_tsep"][k], 1e-12, what="%s[%d] tsep" % (tag, k))
+            if vmax is not None:
+                tf = X[k][-1]
+                assert_close(oracle.speed(y, nveh, dim, R_dyn, tf, vmax, 1), g[tag + "_maxspeed"][k], 1e-12, what="%s[%d] speed" % (tag, k))
+                assert_close(oracle.ang_rate(y, nveh, R_dyn, tf, wmax), g[tag + "_angrate"][k], 1e-9, what="%s[%d] ang" % (tag, k))
+                assert g[tag + "_obj"][k] == tf
+            total += 1
+    assert total == sum(len(g[t + "_x"]) for t in TRAJECTORY_PROBLEMS) >= 170

@@ -11,5 +11,5 @@ F="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -fno-fast-math -Wall -Wno-unused-f
 /opt/rocm/bin/hipcc $F "$@" -x hip -c $C/bern_kernels.hip -o $O/bern.o &
 /opt/rocm/bin/hipcc $F -ffp-contract=off "$@" -x hip -c $C/gjk_kernels.hip -o $O/gjk.o &
 wait
-/opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -o $PKG/exp_$NAME.so $O/bern.o $O/gjk.o $C/build/capi.o $C/build/tables.o $C/build/comm.o -ldl
+/opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -o $PKG/exp_$NAME.so $O/bern.o $O/gjk.o $C/build/capi.o $C/build/tables.o $C/build/comm.o $C/build/libm_check.o $C/build/source_hash.o -ldl
 echo $PKG/exp_$NAME.so
