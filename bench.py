@@ -101,7 +101,7 @@ def parse():
     ap.add_argument("--gather-gjk", action="store_true",
                     help="--mode pairs: all-gather gjkNew's (dist, flag) of the partitioned hull pair list as well (12 bytes per "
                          "hull pair and row); the default gathers what north_star names, the separation minima (8 bytes per pair and row)")
-    ap.add_argument("--ang-order", default="fast", choices=["fast", "reference", "exact"],
+    ap.add_argument("--ang-order", default="fast", choices=["fast", "elevate_first", "reference", "exact"],
                     help="DEG_ELEV > 0: obtg_ctx_set_ang_rate_order (fast = the headline; exact = plus the double-double "
                          "recompute of near-stop vehicles' rows)")
     ap.add_argument("--no-proxy", action="store_true", help="skip the strong_scaling_proxy leg of a 1-GPU batch-mode run")
@@ -382,7 +382,7 @@ def step_bench(args, env):
     # (obtg_ctx_set_stream(torch.cuda.current_stream().cuda_stream) would order the launches with torch's stream instead.)
     stream_note = "context's own non-blocking stream; hand-over by torch.cuda.synchronize()"
     if args.ang_order != "fast":
-        ctx.set_ang_rate_order({"reference": 1, "exact": 2}[args.ang_order])
+        ctx.set_ang_rate_order({"elevate_first": 1, "reference": 1, "exact": 2}[args.ang_order])      # ("reference": the old name of elevate_first)
     if use_gjk:
         ctx.set_polygons(ppts, poff)
         ctx.set_hull_pairs(pa, pb)
@@ -889,7 +889,7 @@ def step_bench(args, env):
                                              "once per step for the others" if use_view
                                              else "written to HBM by obtg_fd_batch_dev each step"), P_t,
                                        "max_ang_rate+" if d == 2 else "", P_s),
-                       "ang_rate_order": args.ang_order, "ang_rate_order_in_effect": (("fast", "reference", "exact")[ctx.ang_rate_order_in_effect()] if d == 2 else None), "mode": args.mode, "rows_per_step_all_ranks": B_total if args.mode == "rows" else world * B,
+                       "ang_rate_order": args.ang_order, "ang_rate_order_in_effect": (("fast", "elevate_first", "exact")[ctx.ang_rate_order_in_effect()] if d == 2 else None), "mode": args.mode, "rows_per_step_all_ranks": B_total if args.mode == "rows" else world * B,
                        "row_range_of_rank0": [row_begin, B] if args.mode == "rows" else None, "rows_structured": rows_structured,
                        "gather_minima": args.gather_minima if d_min is not None else None, "allgather_bytes": gather_bytes,
                        "gather_check": gather_check, "checksum": checksum,

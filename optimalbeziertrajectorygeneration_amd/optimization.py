@@ -224,10 +224,17 @@ class BezOptimization(object):
             raise ValueError("activeRows must be 1..4, not {!r}".format(activeRows))
         self.activeRows = int(activeRows)
         # DEG_ELEV > 0 only: 'fast' forms the angular rate's products at degree 4n and elevates them (0.2 ms at C5);
-        # 'reference' elevates the position first as optimization.py:597 does (1.8 ms) -- closer to the exact value on
-        # vehicles that nearly stop (tests/test_gpu_parity.py::test_near_stop_angular_rate_on_device)
-        if angRateOrder not in ('fast', 'reference', 'exact'):
-            raise ValueError("angRateOrder must be 'fast', 'reference' or 'exact', not {!r}".format(angRateOrder))
+        # 'elevate_first' elevates the position first, the sequence of optimization.py:597 (1.8 ms); 'exact' = 'fast' plus a
+        # double-double recompute of the rows of vehicles that nearly stop.  Until round 6 'elevate_first' was called
+        # 'reference' (still accepted): it follows the reference's SEQUENCE of operations, but where a vehicle nearly stops it
+        # is no closer to the reference's values than the other orders (nearstop.npz's worst vehicle: 4.6e-9 against 3.4e-9
+        # for 'fast' and 3.0e-9 for 'exact' -- the reference itself is 3.0e-9 from the exact rational value there, and its
+        # own sums run through OpenBLAS in an order no restatement short of that library's kernels reproduces): the name
+        # promised what no float64 order delivers (tests/test_gpu_parity.py::test_near_stop_angular_rate_on_device)
+        if angRateOrder == 'reference':
+            angRateOrder = 'elevate_first'
+        if angRateOrder not in ('fast', 'elevate_first', 'exact'):
+            raise ValueError("angRateOrder must be 'fast', 'elevate_first' or 'exact', not {!r}".format(angRateOrder))
         self.angRateOrder = angRateOrder
         self.pointObstacles = pointObstacles
         self.shapeObstacles = shapeObstacles
@@ -257,7 +264,7 @@ class BezOptimization(object):
             obs = self.pointObstacles if with_point_obs else None
             c = _capi.Context(self.model['numVeh'], self.model['dim'], self.model['deg'], int(DEG_ELEV),
                               point_obs=obs, device=self._device)
-            c.set_ang_rate_order({'fast': 0, 'reference': 1, 'exact': 2}[self.angRateOrder])
+            c.set_ang_rate_order({'fast': 0, 'elevate_first': 1, 'exact': 2}[self.angRateOrder])
             self._ctxs[key] = c
         if c.deg_elev != int(DEG_ELEV):
             c.set_deg_elev(int(DEG_ELEV))
@@ -269,7 +276,7 @@ class BezOptimization(object):
         c = self._ctxs.get('one')
         if c is None:
             c = _capi.Context(1, self.model['dim'], self.model['deg'], int(DEG_ELEV), device=self._device)
-            c.set_ang_rate_order({'fast': 0, 'reference': 1, 'exact': 2}[self.angRateOrder])
+            c.set_ang_rate_order({'fast': 0, 'elevate_first': 1, 'exact': 2}[self.angRateOrder])
             self._ctxs['one'] = c
         if c.deg_elev != int(DEG_ELEV):
             c.set_deg_elev(int(DEG_ELEV))
@@ -277,10 +284,10 @@ class BezOptimization(object):
 
     @property
     def angRateOrderInEffect(self):
-        """'fast' / 'reference' / 'exact': the order the angular rate of this problem REALLY runs in at the current DEG_ELEV
+        """'fast' / 'elevate_first' / 'exact': the order the angular rate of this problem REALLY runs in at the current DEG_ELEV
         (the constructor's `angRateOrder` is a request: DEG_ELEV = 0 has one order, and degrees or elevations without a
         products-then-elevation kernel run in the reference's order, without the double-double pass)."""
-        return ('fast', 'reference', 'exact')[self._ctx(False).ang_rate_order_in_effect()]
+        return ('fast', 'elevate_first', 'exact')[self._ctx(False).ang_rate_order_in_effect()]
 
     def _active_k(self):
         """rows per pair of separationRows='active': never more than a pair has control points"""

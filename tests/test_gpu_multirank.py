@@ -164,6 +164,32 @@ def test_rccl_path_with_one_rank():
     assert r_rccl["config"]["checksum"] == r_plain["config"]["checksum"]
 
 
+def k_bytes(d):
+    return d["config"]["alg_bytes_per_eval"] * d["config"]["evals_per_step_per_gpu"]
+
+
+def test_bench_all_modes_two_ranks():
+    """`bench.py --gpus N --all-modes` -- beside the weak line (every rank its own swarm), the strong lines of
+    ONE SLSQP iteration's rows over the ranks with the sparse minima gather, for C3 and for C4, in the same processes and the same
+    ONE JSON line (`modes`): one driver command, both curves.  Rehearsed with two gloo ranks sharing the one GPU: each mode's
+    checksums over all ranks' rows equal a one-rank run's."""
+    two = _bench(["--gpus", "2", "--backend", "gloo", "--one-device", "--all-modes", "--steps", "3", "--warmup", "1", "--no-cpu", "--no-variants"],
+                 timeout=900)
+    assert two["n_gpus"] == 2 and two["scaling"] == "weak" and set(two["modes"]) == {"rows_C3", "rows_C4"}
+    for wl, rows in (("C3", 1153), ("C4", 7169)):
+        m = two["modes"]["rows_" + wl]
+        c = m["config"]
+        assert m["scaling"] == "strong" and m["n_gpus"] == 2 and c["mode"] == "rows" and c["ranks_seen"] == 2
+        assert c["rows_per_step_all_ranks"] == rows and sum(c["checksum"]["rows_per_rank"]) == rows
+        assert c["gather_minima"] == "sparse" and c["gather_check"] is True and c["allgather_bytes"] > 0
+        assert abs(m["value"] - rows / (m["ms_per_step"] * 1e-3)) < 2e-3 * m["value"]
+    one = _bench(["--gpus", "1", "--mode", "rows", "--workload", "C3", "--steps", "3", "--warmup", "1", "--no-cpu", "--no-variants"])
+    c1, c2 = one["config"]["checksum"], two["modes"]["rows_C3"]["config"]["checksum"]
+    assert c1["gjk_flag_sum"] == c2["gjk_flag_sum"]
+    for k in ("sep_min_sum", "speed_sum"):
+        assert abs(c1[k] - c2[k]) <= 1e-11 * abs(c1[k]), k
+
+
 def test_default_bench_line_keeps_the_contract():
     """`python bench.py` as the driver runs it (shortened): ONE JSON line with the contract's keys, the C3 workload as one
     launch per step, `roofline` and `cpu_baseline` objects complete, and the bench's own check of its device buffers
@@ -177,8 +203,26 @@ def test_default_bench_line_keeps_the_contract():
     assert d["config"]["workload"].startswith("C3") and d["config"]["launches_per_step"] == 1
     assert abs(d["value"] - d["config"]["evals_per_step_per_gpu"] / (d["ms_per_step"] * 1e-3)) < 2e-3 * d["value"]
     r = d["roofline"]
-    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0 and r["kernel"] == "pair_sweep"
+    assert r["bound"] in ("hbm", "valu_issue") and r["unit"] == "GB/s" and r["peak"] == 8000.0 and r["kernel"] == "pair_sweep"
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-4 and 0.2 < r["frac"] < 1.0 and "traffic" in r
+    # round 6: counters only with their provenance, and only when taken on the kernels that run (bench.counters_for)
+    if r["traffic"] is not None:
+        ts = r["traffic_source"]
+        assert ts["matches_running_library"] is True and ts["source_hash"] and ts["source"].startswith("profiles/")
+        assert 0.5 < r["traffic"] / k_bytes(d) < 1.5
+    if r["bound"] == "valu_issue":
+        assert r["issue"]["busy_frac"] > r["frac"] and r["issue"]["valu_wave_insts"] > 1e6
+    # round 6: every other BASELINE configuration in the same line, each a child process with its own timed region
+    cf = d["configs"]
+    assert set(cf) >= {"C1_text", "C2", "C2_file", "C4", "C5", "C5_mindist"}
+    for name in ("C1_text", "C2", "C2_file", "C4", "C5"):
+        e = cf[name]
+        assert e.get("exit_code") == 0 and e["ms_per_step"] > 0 and e["parity"]["ok"] is True, (name, e)
+        assert e["kernel"]["avg_ms"] > 0 and e["kernel"]["alg_bytes_per_launch"] > 0 and e["cpu_baseline"]["value"] > 0, (name, e)
+    md = cf["C5_mindist"]
+    assert md["exit_code"] == 0 and md["parity"]["ok"] is True
+    assert md["jacobian_list"]["pairs"] == 114000 and md["jacobian_list"]["parity_check"]["ok"] is True
+    assert md["jacobian_list"]["cpu_baseline"]["value"] > 0 and md["jacobian_list"]["cpu_baseline"]["all_cores"]["cores"] >= 1
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] == 1 and c["value"] > 0 and c["unit"] == d["unit"] and c["sample"]
     p = d["parity_check"]
