@@ -316,7 +316,7 @@ def main():
         c1_text_mode(args, rank)
     else:
         line = step_bench(args, env)
-        if line is not None and args.mode == "batch" and args.all_modes and world > 1:
+        if args.mode == "batch" and args.all_modes and world > 1:          # (every rank: only rank 0 holds a line)
             # the other curve, in the same processes: ONE iteration's rows over the ranks with the sparse minima gather, C3 and C4.
             # Every rank takes part (the step has a collective); only rank 0 holds the lines.
             import copy
@@ -330,7 +330,7 @@ def main():
                 if l2 is not None and l2.get("value") is not None:
                     modes["rows_" + wl] = {k: l2.get(k) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "scaling",
                                                                   "config", "roofline", "kernels")}
-            if rank == 0:
+            if rank == 0 and line is not None:
                 line["modes"] = modes
         if rank == 0 and line is not None and line.get("value") is not None:
             if (args.workload == "C3" and args.mode == "batch" and world == 1 and not args.no_configs and not args.config_leg

@@ -1242,7 +1242,7 @@ int obtg_min_dist(obtg_ctx* c, const double* curves, int n_curves, int K, const 
     bool planar = true;
     for (int i = 0; i < n_curves && planar; ++i) {
         const double* z = curves + ((size_t)i * 3 + 2) * K;
-        for (int j = 0; j < K; ++j) if (z[j] != 0.0) { planar = false; break; }
+        for (int j = 0; j < K; ++j) if (z[j] != 0.0 || std::signbit(z[j])) { planar = false; break; }      // (+0 only: a -0 would show in a returned closest point)
     }
     rc = launch_min_dist(c, c->ws_in.as<double>(), K, m[1].as<int>(), m[2].as<int>(), n_pairs, eps, max_iter,
                          md_cap, max_depth, max_nodes, m[5].as<double>(), c->ws_out.as<double>(), m[3].as<int>(),
@@ -1321,9 +1321,9 @@ int obtg_min_dist2poly(obtg_ctx* c, const double* curves, int n_curves, int K, c
     bool planar = true;             // 2-D curves against polygons in the plane (bezier.py:1416-1430 pads both with z = 0)
     for (int i = 0; i < n_curves && planar; ++i) {
         const double* z = curves + ((size_t)i * 3 + 2) * K;
-        for (int j = 0; j < K; ++j) if (z[j] != 0.0) { planar = false; break; }
+        for (int j = 0; j < K; ++j) if (z[j] != 0.0 || std::signbit(z[j])) { planar = false; break; }      // (+0 only: a -0 would show in a returned closest point)
     }
-    for (int i = 0; i < n_pts && planar; ++i) if (pts[3 * (size_t)i + 2] != 0.0) planar = false;
+    for (int i = 0; i < n_pts && planar; ++i) if (pts[3 * (size_t)i + 2] != 0.0 || std::signbit(pts[3 * (size_t)i + 2])) planar = false;
     rc = launch_min_dist2poly(c, c->ws_in.as<double>(), K, c->ws_in2.as<double>(), m[0].as<int>(), m[1].as<int>(),
                               m[2].as<int>(), n_pairs, eps, max_iter, md_cap, max_depth, max_nodes,
                               m[5].as<double>(), c->ws_out.as<double>(), m[3].as<int>(), max_K, planar);

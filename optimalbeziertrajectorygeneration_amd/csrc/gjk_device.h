@@ -191,26 +191,33 @@ __device__ __forceinline__ void support_pts_wave(Ctx<Mem>& g, const V3& dir, Ver
     g.n_support++;
 }
 
-// "largest value, lowest index" of two sequences side by side over the 16 lanes of a row: quad permutes, the half row
-// mirrored, the row mirrored -- all DPP moves, after which every lane of the row holds both answers.  The combination is
-// commutative and associative, so any exchange pattern gives the serial scan's answer (strict '>' from index 0).
-__device__ __forceinline__ void row_argmax_pair(double& v1, int& i1, double& v2, int& i2)
+// The largest of a value per lane over the 16 lanes of a row, in every lane of the row: two DPP moves and one v_max_f64 per
+// exchange (quad permutes, half row mirrored, row mirrored).  No NaN among the inputs (the callers have replaced them).
+__device__ __forceinline__ double row_max(double v)
 {
-#define OBTG_DPP_MEET2(CTRL) \
-    { const int lo1_ = __builtin_amdgcn_update_dpp(0, __double2loint(v1), CTRL, 0xf, 0xf, false); \
-      const int hi1_ = __builtin_amdgcn_update_dpp(0, __double2hiint(v1), CTRL, 0xf, 0xf, false); \
-      const int oi1_ = __builtin_amdgcn_update_dpp(0, i1, CTRL, 0xf, 0xf, false); \
-      const int lo2_ = __builtin_amdgcn_update_dpp(0, __double2loint(v2), CTRL, 0xf, 0xf, false); \
-      const int hi2_ = __builtin_amdgcn_update_dpp(0, __double2hiint(v2), CTRL, 0xf, 0xf, false); \
-      const int oi2_ = __builtin_amdgcn_update_dpp(0, i2, CTRL, 0xf, 0xf, false); \
-      const double ov1_ = __hiloint2double(hi1_, lo1_), ov2_ = __hiloint2double(hi2_, lo2_); \
-      const bool t1_ = (ov1_ > v1) | ((ov1_ == v1) & (oi1_ < i1)), t2_ = (ov2_ > v2) | ((ov2_ == v2) & (oi2_ < i2)); \
-      v1 = t1_ ? ov1_ : v1; i1 = t1_ ? oi1_ : i1; v2 = t2_ ? ov2_ : v2; i2 = t2_ ? oi2_ : i2; }
-    OBTG_DPP_MEET2(0xB1)      // quad_perm:[1,0,3,2]
-    OBTG_DPP_MEET2(0x4E)      // quad_perm:[2,3,0,1]
-    OBTG_DPP_MEET2(0x141)     // row_half_mirror
-    OBTG_DPP_MEET2(0x140)     // row_mirror
-#undef OBTG_DPP_MEET2
+#define OBTG_DPP_MAX(CTRL) \
+    { const int lo_ = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, false); \
+      const int hi_ = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, false); \
+      v = __builtin_fmax(v, __hiloint2double(hi_, lo_)); }
+    OBTG_DPP_MAX(0xB1)
+    OBTG_DPP_MAX(0x4E)
+    OBTG_DPP_MAX(0x141)
+    OBTG_DPP_MAX(0x140)
+#undef OBTG_DPP_MAX
+    return v;
+}
+
+// "largest value, lowest index" of a row (the serial scan with its strict '>' from index 0, gjk.py:87-114) as: the row's
+// largest value, then the lowest lane of the row that holds it -- a ballot and a find-first-set instead of carrying the index
+// through the exchanges (round 6: 3 instructions per exchange and sequence where row_argmax_pair needs 10).  +0 and -0 compare
+// equal here as they do under '>'; lanes past the set hold -inf and sit above the set's lanes, so they never win a tie; a NaN at
+// point 0 (nothing is ever greater than a NaN maximum) is the caller's `nan0`.
+__device__ __forceinline__ int row_argmax(double v, bool nan0)
+{
+    const int lane = threadIdx.x & 63;
+    const double m = row_max(v);
+    const unsigned bits = (unsigned)(__ballot(v == m) >> (lane & 48)) & 0xffffu;
+    return nan0 ? 0 : __ffs((int)bits) - 1;
 }
 
 // supportPts for FOUR calls at a time, one per 16-lane row of the wavefront (K <= 16 points per set): the lanes of a row
@@ -232,10 +239,7 @@ __device__ __forceinline__ void support_pts_quarter(Ctx<Mem>& g, const V3& dir, 
     const int row0 = lane & 48;
     if (v1 != v1) v1 = -__builtin_inf();                   // `cur > maxd` is false for NaN: never selected
     if (v2 != v2) v2 = -__builtin_inf();
-    int i1 = have1 ? l : 0x7fffffff, i2 = have2 ? l : 0x7fffffff;
-    row_argmax_pair(v1, i1, v2, i2);
-    if ((nan1 >> row0) & 1) i1 = 0;
-    if ((nan2 >> row0) & 1) i2 = 0;
+    const int i1 = row_argmax(v1, (nan1 >> row0) & 1), i2 = row_argmax(v2, (nan2 >> row0) & 1);
     out.i1 = i1; out.i2 = i2;
     out.v = sub(point(g.mem, g.P1, i1), point(g.mem, g.P2, i2));
     g.n_support++;
@@ -720,6 +724,49 @@ __device__ __forceinline__ Simplex lift(const Simplex2& s)
     return r;
 }
 
+// gjk.py:299-360 on a planar simplex: which feature is closest -- point A, segment A-B, segment A-C, or the triangle's
+// interior -- decided with the planar forms of closest_from_simplex's expressions (the ones simplex_update2 uses), then ONE
+// segment evaluation (weightedOriginToLine, gjk.py:397-437, dot's two-term sums; np.linalg.norm(A) = sqrt(dotb(A, A)) for the
+// point).  The interior case (about one call in a hundred) takes the general evaluation on the lifted simplex.  The planar sweeps'
+// phase 2 has evaluated their records this way since round 1; same values as closest_from_simplex(lift(s)).
+template <class Mem>
+__device__ __forceinline__ void closest_from_simplex2(const Ctx<Mem>& g, const Simplex2& s, Result& r)
+{
+    const V2 a1 = point2(g.mem, g.P1, s.A.i1()), a2 = point2(g.mem, g.P2, s.A.i2());
+    const V2 A = s.A.v;
+    int which = 0;                    // 0: point A, 1: segment A-B, 2: segment A-C, 3: the triangle's interior
+    if (s.keys & kC) {
+        const V2 A0 = neg2(A), AB = sub2(s.B.v, A), AC = sub2(s.C.v, A);
+        const double w = cz(AB, AC);
+        const V2 t1{ -(w * AC.y), w * AC.x };
+        const V2 t2{ AB.y * w, -(AB.x * w) };
+        which = (dotb2(t1, A0) >= 0) ? 2 : ((dotb2(t2, A0) >= 0) ? 1 : 3);
+    } else if (s.keys & kB) which = 1;
+    if (which == 3) { closest_from_simplex(g, lift(s), r); return; }
+    double t = 0.0, rad = dotb2(A, A);
+    V2 o1 = a1, o2 = a2;
+    if (which != 0) {
+        const Vert2& O = which == 2 ? s.C : s.B;
+        o1 = point2(g.mem, g.P1, O.i1()); o2 = point2(g.mem, g.P2, O.i2());
+        rad = dot2(A, A);                                           // identical points (gjk.py:417-419)
+        if (!eq2(A, O.v)) {
+            const V2 v = sub2(O.v, A);
+            t = -dot2(v, A) / dot2(v, v);
+            if (t > 1) t = 1; else if (t < 0) t = 0;
+            const V2 cp{ (1 - t) * A.x + t * O.v.x, (1 - t) * A.y + t * O.v.y };
+            rad = dot2(cp, cp);
+        }
+    }
+    r.dist = __builtin_sqrt(rad);
+    if (which == 0) {
+        r.c1 = V3{ a1.x, a1.y, 0.0 };
+        r.c2 = V3{ a2.x, a2.y, 0.0 };
+    } else {
+        r.c1 = V3{ (1 - t) * a1.x + t * o1.x, (1 - t) * a1.y + t * o1.y, 0.0 };
+        r.c2 = V3{ (1 - t) * a2.x + t * o2.x, (1 - t) * a2.y + t * o2.y, 0.0 };
+    }
+}
+
 // ---- the planar machine for FOUR calls at a time, one per 16-lane row (round 6: `_minDist` on 2-D curves, which is every
 //      driver that uses it -- Examples/ComplexObstacles.py, DrivingOnATrack.py; bezier.py:1294-1308 pads them with z = 0).
 //      run_quarter spends its trips on the 3-D expressions although, with every z zero, two thirds of their terms are exact
@@ -736,14 +783,12 @@ __device__ __forceinline__ void support_pts_quarter2(Ctx<Mem>& g, const V2& dir,
     const bool have1 = l < g.P1.K, have2 = l < g.P2.K;
     double v1 = have1 ? g.own1.x * dir.x + g.own1.y * dir.y : -__builtin_inf();
     double v2 = have2 ? g.own2.x * nd.x + g.own2.y * nd.y : -__builtin_inf();
+    // point 0's value NaN: maxd starts as NaN and nothing is ever greater (the row's lane 0 holds point 0)
     const unsigned long long nan1 = __ballot(v1 != v1), nan2 = __ballot(v2 != v2);
     const int row0 = lane & 48;
-    if (v1 != v1) v1 = -__builtin_inf();
+    if (v1 != v1) v1 = -__builtin_inf();                   // `cur > maxd` is false for NaN: never selected
     if (v2 != v2) v2 = -__builtin_inf();
-    int i1 = have1 ? l : 0x7fffffff, i2 = have2 ? l : 0x7fffffff;
-    row_argmax_pair(v1, i1, v2, i2);
-    if ((nan1 >> row0) & 1) i1 = 0;
-    if ((nan2 >> row0) & 1) i2 = 0;
+    const int i1 = row_argmax(v1, (nan1 >> row0) & 1), i2 = row_argmax(v2, (nan2 >> row0) & 1);
     out.ii = pack_ii(i1, i2);
     out.v = sub2(point2(g.mem, g.P1, i1), point2(g.mem, g.P2, i2));
     g.n_support++;
@@ -796,6 +841,54 @@ __device__ __forceinline__ void run_quarter2(Ctx<Mem>& g, int max_iter, int md_c
     }
     int phase = 0, it = 0, rr = 0;
     bool live = max_iter > 0, conv = false;
+    // ---- the first two doSimplex steps as straight-line code.  They always happen (unless max_iter stops the call after
+    //      one) and always with the directions (1, 0) and (-1, -0) (gjk.py:247, 544): zero points -- keep the direction,
+    //      fetch A --, then one point -- B <- A, turn the direction round, fetch A.  Their four support scans are ONE pass: with
+    //      these directions sdot's products are x * 1 + y * 0 and x * -1 + y * -0, so the supports are "first index of the
+    //      largest x" / "of the largest -x" of each set.  An average call has 3.7 steps; as trips of the loop below these two
+    //      cost what the others cost (simplex update, scan, convergence test, checkpoint: ~500 instructions each).  State after
+    //      them: exactly the loop's (same keys, vertices, direction, counters, phase, checkpoint).
+    if (live) {
+        const int lane = threadIdx.x & 63, l = lane & 15, row0 = lane & 48;
+        const bool have1 = l < g.P1.K, have2 = l < g.P2.K;
+        const V2 nd = neg2(dir);                                  // (-1, -0)
+        double a_hi = have1 ? g.own1.x * dir.x + g.own1.y * dir.y : -__builtin_inf();      // step 1, set 1: direction
+        double b_lo = have2 ? g.own2.x * nd.x + g.own2.y * nd.y : -__builtin_inf();        // step 1, set 2: -direction
+        double a_lo = have1 ? g.own1.x * nd.x + g.own1.y * nd.y : -__builtin_inf();        // step 2, set 1: the direction turned round
+        double b_hi = have2 ? g.own2.x * dir.x + g.own2.y * dir.y : -__builtin_inf();      // step 2, set 2
+        const unsigned long long n_ah = __ballot(a_hi != a_hi), n_bl = __ballot(b_lo != b_lo), n_al = __ballot(a_lo != a_lo),
+                                 n_bh = __ballot(b_hi != b_hi);
+        if (a_hi != a_hi) a_hi = -__builtin_inf();
+        if (b_lo != b_lo) b_lo = -__builtin_inf();
+        if (a_lo != a_lo) a_lo = -__builtin_inf();
+        if (b_hi != b_hi) b_hi = -__builtin_inf();
+        const int i_ah = row_argmax(a_hi, (n_ah >> row0) & 1), i_bl = row_argmax(b_lo, (n_bl >> row0) & 1);
+        const int i_al = row_argmax(a_lo, (n_al >> row0) & 1), i_bh = row_argmax(b_hi, (n_bh >> row0) & 1);
+        // step 1 (no point yet): A
+        s.A.ii = pack_ii(i_ah, i_bl);
+        s.A.v = sub2(point2(g.mem, g.P1, i_ah), point2(g.mem, g.P2, i_bl));
+        s.keys = kA;
+        g.n_support++;
+        if (dotb2(s.A.v, dir) < 0) { phase = 1; chk.start(s, dir); }
+        else if (++it >= max_iter) live = false;
+        if (live) {
+            // step 2 (one point): B <- A, the direction turned round, A
+            if (phase) old = s;
+            s.B = s.A; s.keys |= kB;
+            dir = nd;
+            s.A.ii = pack_ii(i_al, i_bh);
+            s.A.v = sub2(point2(g.mem, g.P1, i_al), point2(g.mem, g.P2, i_bh));
+            g.n_support++;
+            if (!phase) {
+                if (dotb2(s.A.v, dir) < 0) { phase = 1; chk.start(s, dir); }
+                else if (++it >= max_iter) live = false;
+            } else {
+                if (matches_old2(g, old, s.A.v)) { conv = true; live = false; }
+                else if (chk.step(s, dir)) { r.flag = 1; r.status = OBTG_ST_CYCLE; live = false; }
+                else if (++rr >= md_cap) { r.flag = 1; r.status = OBTG_ST_MD_CAP; live = false; }
+            }
+        }
+    }
     while (live) {
         if (phase) old = s;
         simplex_update2(s, dir);
@@ -813,7 +906,7 @@ __device__ __forceinline__ void run_quarter2(Ctx<Mem>& g, int max_iter, int md_c
     }
     if (conv) {
         r.flag = 1; r.status = OBTG_ST_OK;
-        closest_from_simplex(g, lift(old), r);
+        closest_from_simplex2(g, old, r);
     }
     r.n_support = g.n_support;
 }

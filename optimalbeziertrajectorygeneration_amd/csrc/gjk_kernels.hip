@@ -2336,7 +2336,7 @@ __device__ __forceinline__ void hull_param_rows(const double* c1, const double* 
 // the split parameters of its closest points (bezier.py:1313-1351), the end-point bound (_upperbound, bezier.py:1255-1280).
 // o1 / o2: offsets of the row's two curves in `lds`; rec: the row's record.  Every lane of a row stores the row's (equal)
 // values: no lane-dependent region (see the queue pull of k_min_dist_wave).
-template <bool PLANAR = false>
+template <bool PLANAR = false, int KC = 0>      // KC: the control-point count when the kernel is built for one (0: any count up to 16)
 __device__ __forceinline__ void md_eval_rows(const double* lds, int o1, int o2, int K, double eps, int max_iter, int md_cap,
                                              double* rec, double* sh_e, double* sh_q
 #ifdef OBTG_MD_TIMING
@@ -2365,7 +2365,8 @@ __device__ __forceinline__ void md_eval_rows(const double* lds, int o1, int o2, 
     const double* c1 = lds + o1; const double* c2 = lds + o2;
     if (gr.flag > 0 && !cap) {
         lb = gr.dist;
-        hull_param_rows<PLANAR>(c1, c2, K, gr.c1, gr.c2, sh_e, sh_q, t1, t2);
+        if constexpr (KC > 0) hull_param_quarter2_t<KC, true, PLANAR>(c1, c2, gr.c1, gr.c2, sh_e, sh_q, t1, t2);
+        else hull_param_rows<PLANAR>(c1, c2, K, gr.c1, gr.c2, sh_e, sh_q, t1, t2);
     }
 #ifdef OBTG_MD_TIMING
     if (t1 == -1.0) rec[R_CAP] = 0.0;
@@ -2409,12 +2410,15 @@ __device__ __forceinline__ void md_eval_rows(const double* lds, int o1, int o2, 
 // calls that are bound by the chain of their longest search (a few pairs per worker: one evaluation's 4560 pairs, 6.4 ms
 // against 7.7), W = 3 (168 registers, 44 spilled) for calls bound by the chip's issue rate (the Jacobian's 114 000: 76 ms
 // against 94) -- launch_min_dist picks by pairs per worker.
-template <bool PLANAR, int W>
+// KC: the control-point count the kernel is built for (0: any up to 16, the count-dependent parts behind wave-uniform switches).
+// One kernel for every count took the registers of its largest case -- the split parameters' 2 K quotients per lane at K = 16 --
+// and the degree-10 searches (K = 11) spilled for it.
+template <bool PLANAR, int W, int KC>
 __global__ __launch_bounds__(64, W) void k_min_dist_quad(const MdParams p)
 {
     extern __shared__ double md_lds[];
     const int lane = threadIdx.x, q = lane >> 4;
-    const int K = p.K, BL = md_quad_blob(K), FRM = md_quad_frame(K);
+    const int K = KC > 0 ? KC : p.K, BL = md_quad_blob(K), FRM = md_quad_frame(K);
     double* st = p.stack + (size_t)blockIdx.x * p.max_depth * FRM;
     double* sh_e = md_lds + 2 * BL;             // [4][kMdShRow]: [2][16] per row of the wavefront, the rows' banks apart
     double* sh_q = sh_e + 4 * kMdShRow;         // the same
@@ -2453,10 +2457,10 @@ __global__ __launch_bounds__(64, W) void k_min_dist_quad(const MdParams p)
         wave_sync();
 #ifdef OBTG_MD_TIMING
         unsigned long long tq = __builtin_readcyclecounter();
-        md_eval_rows<PLANAR>(md_lds, (int)(nxt - md_lds) + (q >> 1) * 3 * K, (int)(nxt - md_lds) + (2 + (q & 1)) * 3 * K, K, p.eps,
+        md_eval_rows<PLANAR, KC>(md_lds, (int)(nxt - md_lds) + (q >> 1) * 3 * K, (int)(nxt - md_lds) + (2 + (q & 1)) * 3 * K, K, p.eps,
                      p.max_iter, p.md_cap, nxt + 12 * K + q * R_NREC, sh_e + q * kMdShRow, sh_q + q * kMdShRow, tm_ev);
 #else
-        md_eval_rows<PLANAR>(md_lds, (int)(nxt - md_lds) + (q >> 1) * 3 * K, (int)(nxt - md_lds) + (2 + (q & 1)) * 3 * K, K, p.eps,
+        md_eval_rows<PLANAR, KC>(md_lds, (int)(nxt - md_lds) + (q >> 1) * 3 * K, (int)(nxt - md_lds) + (2 + (q & 1)) * 3 * K, K, p.eps,
                      p.max_iter, p.md_cap, nxt + 12 * K + q * R_NREC, sh_e + q * kMdShRow, sh_q + q * kMdShRow);
 #endif
         wave_sync();
@@ -2539,7 +2543,13 @@ __global__ __launch_bounds__(64, W) void k_min_dist_quad(const MdParams p)
 #ifdef OBTG_MD_TIMING
             const unsigned long long ts0 = __builtin_readcyclecounter();
 #endif
-            split_both(cur + h1 * 3 * K, cur + (2 + h2) * 3 * K, K, t1, t2, nxt, dump);
+            if constexpr (KC > 0) {
+                if constexpr (6 * KC <= kWave) split_both_t<KC>(cur + h1 * 3 * K, cur + (2 + h2) * 3 * K, K, t1, t2, nxt, 0, 6, dump);
+                else {
+                    split_both_t<KC>(cur + h1 * 3 * K, cur + (2 + h2) * 3 * K, K, t1, t2, nxt, 0, 3, dump);
+                    split_both_t<KC>(cur + h1 * 3 * K, cur + (2 + h2) * 3 * K, K, t1, t2, nxt, 3, 3, dump);
+                }
+            } else split_both(cur + h1 * 3 * K, cur + (2 + h2) * 3 * K, K, t1, t2, nxt, dump);
 #ifdef OBTG_MD_TIMING
             wave_sync();
             if (nxt[0] == -1.0) tm_split += 1;
@@ -4063,14 +4073,22 @@ int launch_min_dist(obtg_ctx* c, const double* d_curves, int K, const int* d_pa,
         OBTG_HIP(c, hipMemsetAsync(d_queue, 0, sizeof(int), c->stream));
         static const bool no_planar = getenv("OBTG_MD_PLANAR") && getenv("OBTG_MD_PLANAR")[0] == '0';      // (A/B runs: the 3-D machine on planar curves)
         static const int many_env = getenv("OBTG_MD_MANY") ? atoi(getenv("OBTG_MD_MANY")) : 0;             // pairs per worker from which a call counts as issue bound
-        const int w3 = min_dist_workers(c, n_pairs, lds_q, OBTG_MD_MIN_WAVES_PLANAR);
+        const int w3 = min_dist_workers(c, n_pairs, lds_q, OBTG_MD_MIN_WAVES_PLANAR), w2 = min_dist_workers(c, n_pairs, lds_q, OBTG_MD_MIN_WAVES);
         const bool many = (long)n_pairs >= (long)(many_env > 0 ? many_env : 8) * w3;
-        if (planar && !no_planar && many)
-            hipLaunchKernelGGL((k_min_dist_quad<true, OBTG_MD_MIN_WAVES_PLANAR>), dim3((unsigned)w3), dim3(kWave), lds_q, c->stream, p);
-        else if (planar && !no_planar)
-            hipLaunchKernelGGL((k_min_dist_quad<true, OBTG_MD_MIN_WAVES>), dim3((unsigned)min_dist_workers(c, n_pairs, lds_q, OBTG_MD_MIN_WAVES)), dim3(kWave), lds_q, c->stream, p);
-        else
-            hipLaunchKernelGGL((k_min_dist_quad<false, OBTG_MD_MIN_WAVES>), dim3((unsigned)min_dist_workers(c, n_pairs, lds_q, OBTG_MD_MIN_WAVES)), dim3(kWave), lds_q, c->stream, p);
+        const int form = (planar && !no_planar) ? (many ? 2 : 1) : 0;      // 0: the 3-D machine, 1: planar, chain bound, 2: planar, issue bound
+        void (*kern)(const MdParams) = form == 2 ? k_min_dist_quad<true, OBTG_MD_MIN_WAVES_PLANAR, 0>
+                                                 : (form == 1 ? k_min_dist_quad<true, OBTG_MD_MIN_WAVES, 0> : k_min_dist_quad<false, OBTG_MD_MIN_WAVES, 0>);
+        switch (K) {        // the counts with a build of their own
+#define OBTG_CASE(NC_) \
+        case NC_: \
+            kern = form == 2 ? k_min_dist_quad<true, OBTG_MD_MIN_WAVES_PLANAR, NC_> \
+                             : (form == 1 ? k_min_dist_quad<true, OBTG_MD_MIN_WAVES, NC_> : k_min_dist_quad<false, OBTG_MD_MIN_WAVES, NC_>); \
+            break;
+            OBTG_NC_DYN(OBTG_CASE)
+#undef OBTG_CASE
+            default: break;
+        }
+        hipLaunchKernelGGL(kern, dim3((unsigned)(form == 2 ? w3 : w2)), dim3(kWave), lds_q, c->stream, p);
     } else if (pl.wave_ok && d_queue) {    // one pair per wavefront at a time, the waves as workers on a queue
         OBTG_HIP(c, hipMemsetAsync(d_queue, 0, sizeof(int), c->stream));
         hipLaunchKernelGGL(k_min_dist_wave, dim3((unsigned)min_dist_workers(c, n_pairs, lds_w, OBTG_MD_MIN_WAVES)), dim3(kWave), lds_w, c->stream, p);
@@ -4225,7 +4243,7 @@ __device__ __forceinline__ void split_one_both(const double* c, int K, double t,
 
 // the record of the (curve piece, polygon) pair a row of the wavefront names: gjkNew, the curve's split parameter (bezier.py:
 // 1436-1452), _upperboundPoly (the curve's end points against the polygon's closest point)
-template <bool PLANAR = false>
+template <bool PLANAR = false, int KC = 0>
 __device__ __forceinline__ void md2_eval_rows(const double* lds, int oc, int K, int op, int PK, int max_iter, int md_cap,
                                               double* rec, double* sh_e, double* sh_q)
 {
@@ -4243,7 +4261,8 @@ __device__ __forceinline__ void md2_eval_rows(const double* lds, int oc, int K, 
     double t1 = 0.5, ub = INFINITY;
     int am = 0;
     if (pos) {
-        t1 = hull_param_row<PLANAR>(c1, K, gr.c1, sh_e, sh_q);
+        if constexpr (KC > 0) { double t2u = 0.0; hull_param_quarter2_t<KC, false, PLANAR>(c1, c1, gr.c1, gr.c1, sh_e, sh_q, t1, t2u); }
+        else t1 = hull_param_row<PLANAR>(c1, K, gr.c1, sh_e, sh_q);
         // (PLANAR: the curve's z row and the closest point's z are exact zeros; norm_seq's `+= dz * dz` adds 0)
         const double d0 = norm_seq(c1[0], c1[K], PLANAR ? 0.0 : c1[2 * K], gr.c2.x, gr.c2.y, PLANAR ? 0.0 : gr.c2.z);
         const double d1 = norm_seq(c1[K - 1], c1[2 * K - 1], PLANAR ? 0.0 : c1[3 * K - 1], gr.c2.x, gr.c2.y, PLANAR ? 0.0 : gr.c2.z);
@@ -4256,15 +4275,15 @@ __device__ __forceinline__ void md2_eval_rows(const double* lds, int oc, int K, 
 }
 
 #ifndef OBTG_MD2_MIN_WAVES_PLANAR
-#define OBTG_MD2_MIN_WAVES_PLANAR 4
+#define OBTG_MD2_MIN_WAVES_PLANAR 3     // 4096 curve-polygon pairs: 2 / 3 / 4 workers per SIMD 2.82 / 2.70 / 2.85 ms -- the launch is its deepest search's chain
 #endif
 // PLANAR: the curves and the polygons of the call all have z == 0 (the host has looked): the planar gjkNew machine per row
-template <bool PLANAR>
+template <bool PLANAR, int KC>        // KC: the curve's control-point count when the kernel is built for one (see k_min_dist_quad)
 __global__ __launch_bounds__(64, PLANAR ? OBTG_MD2_MIN_WAVES_PLANAR : OBTG_MD_MIN_WAVES) void k_min_dist2poly_quad(const Md2Params p)
 {
     extern __shared__ double m2q_lds[];
     const int k = blockIdx.x, lane = threadIdx.x, q = (lane >> 4) & 1;        // rows 2, 3 repeat rows 0, 1
-    const int K = p.K, BL = md2_quad_blob(K), FRM = p.quad_frame;             // FRM: doubles per frame of this call's stack (>= md2_quad_frame(K))
+    const int K = KC > 0 ? KC : p.K, BL = md2_quad_blob(K), FRM = p.quad_frame;   // FRM: doubles per frame of this call's stack (>= md2_quad_frame(K))
     const int po = p.off[p.pp[k]], PK = p.off[p.pp[k] + 1] - po;
     double* st = p.stack + (size_t)k * p.max_depth * FRM;
     double* cur = m2q_lds;                      // [BL] blob of the frame `cur_depth`
@@ -4286,7 +4305,7 @@ __global__ __launch_bounds__(64, PLANAR ? OBTG_MD2_MIN_WAVES_PLANAR : OBTG_MD_MI
     bool done = false;
     while (!done) {
         wave_sync();
-        md2_eval_rows<PLANAR>(m2q_lds, (int)(nxt - m2q_lds) + q * 3 * K, K, (int)(pol - m2q_lds), PK, p.max_iter, p.md_cap,
+        md2_eval_rows<PLANAR, KC>(m2q_lds, (int)(nxt - m2q_lds) + q * 3 * K, K, (int)(pol - m2q_lds), PK, p.max_iter, p.md_cap,
                       nxt + 6 * K + q * P_NREC, sh_e + (lane >> 4) * kMdShRow, sh_q + (lane >> 4) * kMdShRow);
         wave_sync();
         if (eval_depth >= 0) {
@@ -4343,7 +4362,8 @@ __global__ __launch_bounds__(64, PLANAR ? OBTG_MD2_MIN_WAVES_PLANAR : OBTG_MD_MI
             if (depth + 2 >= p.max_depth) { status = OBTG_MD_DEPTH_CAP; r0 = alpha; r1 = nT1; rx = cx; ry = cy; rz = cz; done = true; break; }
             if (t1 != t1) t1 = 0;
             // expand the child: both its pieces to `nxt`; this frame goes to `scs`, the child's into the registers
-            split_one_both(cur + h1 * 3 * K, K, t1, nxt, dump);
+            if constexpr (KC > 0) split_both_t<KC>(cur + h1 * 3 * K, cur + h1 * 3 * K, K, t1, t1, nxt, 0, 3, dump);
+            else split_one_both(cur + h1 * 3 * K, K, t1, nxt, dump);
             if (depth >= 0) {
                 double* sc = depth >= kMdScsLds ? st + (size_t)depth * FRM + BL : scs + depth * G_NSCAL;
                 sc[G_T1] = f_t1; sc[G_T1L] = f_t1l; sc[G_T1H] = f_t1h; sc[G_ALPHA] = f_alpha; sc[G_RT1] = f_rt1;
@@ -4442,8 +4462,15 @@ int launch_min_dist2poly(obtg_ctx* c, const double* d_curves, int K, const doubl
     static const bool no_planar = getenv("OBTG_MD_PLANAR") && getenv("OBTG_MD_PLANAR")[0] == '0';          // (A/B runs)
     if (K <= kMdQuadMaxK && max_poly_K <= 16 && lds_q <= 48 * 1024 && !(env_form && !strcmp(env_form, "wave"))) {
         // both children side by side
-        if (planar && !no_planar) hipLaunchKernelGGL(k_min_dist2poly_quad<true>, dim3((unsigned)n_pairs), dim3(kWave), lds_q, c->stream, p);
-        else hipLaunchKernelGGL(k_min_dist2poly_quad<false>, dim3((unsigned)n_pairs), dim3(kWave), lds_q, c->stream, p);
+        const bool pl2 = planar && !no_planar;
+        void (*kern)(const Md2Params) = pl2 ? k_min_dist2poly_quad<true, 0> : k_min_dist2poly_quad<false, 0>;
+        switch (K) {        // the counts with a build of their own
+#define OBTG_CASE(NC_) case NC_: kern = pl2 ? k_min_dist2poly_quad<true, NC_> : k_min_dist2poly_quad<false, NC_>; break;
+            OBTG_NC_DYN(OBTG_CASE)
+#undef OBTG_CASE
+            default: break;
+        }
+        hipLaunchKernelGGL(kern, dim3((unsigned)n_pairs), dim3(kWave), lds_q, c->stream, p);
     }
     else if (lds_w <= 48 * 1024 && max_poly_K <= kMdMaxK)      // one pair per wavefront
         hipLaunchKernelGGL(k_min_dist2poly_wave, dim3((unsigned)n_pairs), dim3(kWave), lds_w, c->stream, p);
