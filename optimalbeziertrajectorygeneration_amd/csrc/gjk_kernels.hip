@@ -2256,10 +2256,54 @@ __device__ __forceinline__ void hull_param_quarter2_t(const double* c1, const do
     }
     sh_e[l] = ea;
     if constexpr (TWO) sh_e[16 + l] = eb;
-    wave_sync();
+    // The 2 K quotients e_l / e_j of a lane are IEEE divisions, which the compiler expands (v_div_scale x 2, v_rcp, two Newton steps
+    // on the reciprocal, q0 = n r, rem = n - d q0, q = q0 + rem r through v_div_fmas, v_div_fixup: 11 instructions).  Everything up
+    // to the refined reciprocal depends on the DENOMINATOR alone, and when numerator and denominator are ordinary numbers
+    // (v_div_scale scales nothing, v_div_fmas is a plain fused multiply-add, v_div_fixup passes its operand) the quotient is
+    // fma(fma(-d, n r, n), r, n r) with that reciprocal: the same instructions on the same values, so the same bits.  The lane
+    // that owns e_j refines 1 / e_j once (5 instructions) and leaves it beside e_j; every quotient is then 3 instructions
+    // instead of 11 (round 6: this block was 727 of the ~2200 instructions of an expansion, and a call of the Jacobian's
+    // size is issue bound).  Distances outside [2^-300, 2^300] (v_div_scale leaves operands alone while their exponents are less than
+    // 768 apart and neither is near the ends of the range) -- a zero where the closest point IS a control point of a curve
+    // whose parameter comes from the sums, an overflow, a NaN -- send the whole wavefront through the divisions as written.
+    bool fast = true;
+#ifndef OBTG_MD_PLAIN_DIVISIONS
+    {
+        const bool ok_a = ea >= 0x1p-300 && ea <= 0x1p300, ok_b = !TWO || (eb >= 0x1p-300 && eb <= 0x1p300);
+        fast = __ballot(l < K && ((!m1 && !ok_a) || (TWO && !m2 && !ok_b))) == 0ull;
+    }
+#else
+    fast = false;
+#endif
     double qa[K], qb[K];
+    if (fast) {
+        auto refined_rcp = [](double d) {
+            double r = __builtin_amdgcn_rcp(d);
+            double e = __builtin_fma(-d, r, 1.0);
+            r = __builtin_fma(r, e, r);
+            e = __builtin_fma(-d, r, 1.0);
+            return __builtin_fma(r, e, r);
+        };
+        sh_q[l] = refined_rcp(ea);
+        if constexpr (TWO) sh_q[16 + l] = refined_rcp(eb);
+        wave_sync();
 #pragma unroll
-    for (int j = 0; j < K; ++j) { qa[j] = ea / sh_e[j]; qb[j] = TWO ? eb / sh_e[16 + j] : 0.0; }
+        for (int j = 0; j < K; ++j) {
+            const double da = sh_e[j], ra = sh_q[j];
+            const double q0 = ea * ra;
+            qa[j] = __builtin_fma(__builtin_fma(-da, q0, ea), ra, q0);
+            if constexpr (TWO) {
+                const double db = sh_e[16 + j], rb = sh_q[16 + j];
+                const double p0 = eb * rb;
+                qb[j] = __builtin_fma(__builtin_fma(-db, p0, eb), rb, p0);
+            } else qb[j] = 0.0;
+        }
+        wave_sync();                                    // (the reciprocals have been read: sh_q takes the weights below)
+    } else {
+        wave_sync();
+#pragma unroll
+        for (int j = 0; j < K; ++j) { qa[j] = ea / sh_e[j]; qb[j] = TWO ? eb / sh_e[16 + j] : 0.0; }
+    }
     // terms j < l (l of them)
     auto sum_lo = [&](const double (&q)[K]) {
         double r = 0.0;
@@ -2403,7 +2447,7 @@ __device__ __forceinline__ void md_eval_rows(const double* lds, int o1, int o2, 
 }
 
 #ifndef OBTG_MD_MIN_WAVES_PLANAR
-#define OBTG_MD_MIN_WAVES_PLANAR 3     // the planar form's simplices, checkpoint and own points are two thirds the size
+#define OBTG_MD_MIN_WAVES_PLANAR 4     // workers per SIMD of an issue-bound planar call (K = 11: 128 registers + 116 B of scratch; 3: 63.2 ms, 4: 61.0 on the Jacobian list)
 #endif
 // PLANAR: every curve of the call has z == 0 in every control point (the host has looked): the planar gjkNew machine per row.
 // W: worker waves per SIMD the registers are held to.  The planar form has two builds: W = 2 (223 registers, nothing spilled) for
