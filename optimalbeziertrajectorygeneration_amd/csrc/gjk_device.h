@@ -192,13 +192,17 @@ __device__ __forceinline__ void support_pts_wave(Ctx<Mem>& g, const V3& dir, Ver
 }
 
 // The largest of a value per lane over the 16 lanes of a row, in every lane of the row: two DPP moves and one v_max_f64 per
-// exchange (quad permutes, half row mirrored, row mirrored).  No NaN among the inputs (the callers have replaced them).
+// exchange (quad permutes, half row mirrored, row mirrored).  v_max_f64 is IEEE maxNum: a quiet NaN operand loses against a
+// number (the products below are arithmetic results, so their NaNs are quiet); all NaN gives NaN.  (The instruction is written
+// out: through fmax() the compiler first canonicalises the moved operand -- a second v_max_f64 per exchange -- and through
+// update_dpp it zeroes the destination registers first: 6 instructions per exchange where 3 do.)
 __device__ __forceinline__ double row_max(double v)
 {
 #define OBTG_DPP_MAX(CTRL) \
-    { const int lo_ = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, false); \
-      const int hi_ = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, false); \
-      v = __builtin_fmax(v, __hiloint2double(hi_, lo_)); }
+    { const int lo_ = __builtin_amdgcn_mov_dpp(__double2loint(v), CTRL, 0xf, 0xf, true); \
+      const int hi_ = __builtin_amdgcn_mov_dpp(__double2hiint(v), CTRL, 0xf, 0xf, true); \
+      const double o_ = __hiloint2double(hi_, lo_); \
+      asm("v_max_f64 %0, %1, %2" : "=v"(v) : "v"(v), "v"(o_)); }
     OBTG_DPP_MAX(0xB1)
     OBTG_DPP_MAX(0x4E)
     OBTG_DPP_MAX(0x141)
@@ -209,9 +213,10 @@ __device__ __forceinline__ double row_max(double v)
 
 // "largest value, lowest index" of a row (the serial scan with its strict '>' from index 0, gjk.py:87-114) as: the row's
 // largest value, then the lowest lane of the row that holds it -- a ballot and a find-first-set instead of carrying the index
-// through the exchanges (round 6: 3 instructions per exchange and sequence where row_argmax_pair needs 10).  +0 and -0 compare
-// equal here as they do under '>'; lanes past the set hold -inf and sit above the set's lanes, so they never win a tie; a NaN at
-// point 0 (nothing is ever greater than a NaN maximum) is the caller's `nan0`.
+// through the exchanges.  +0 and -0 compare equal here as they do under '>'; lanes past the set hold -inf and sit above the
+// set's lanes, so they never win a tie.  NaN: `cur > maxd` is false for a NaN `cur` -- never selected: v_max_f64 drops it and
+// `v == m` is false for it -- and for a NaN `maxd`, which the scan starts with when point 0's value is one -- nothing is ever
+// greater: the caller's `nan0` (the row's lane 0 holds point 0), which also covers the all-NaN row (m is NaN, no lane equal).
 __device__ __forceinline__ int row_argmax(double v, bool nan0)
 {
     const int lane = threadIdx.x & 63;
@@ -237,8 +242,6 @@ __device__ __forceinline__ void support_pts_quarter(Ctx<Mem>& g, const V3& dir, 
     // point 0's value NaN: maxd starts as NaN and nothing is ever greater (the row's lane 0 holds point 0)
     const unsigned long long nan1 = __ballot(v1 != v1), nan2 = __ballot(v2 != v2);
     const int row0 = lane & 48;
-    if (v1 != v1) v1 = -__builtin_inf();                   // `cur > maxd` is false for NaN: never selected
-    if (v2 != v2) v2 = -__builtin_inf();
     const int i1 = row_argmax(v1, (nan1 >> row0) & 1), i2 = row_argmax(v2, (nan2 >> row0) & 1);
     out.i1 = i1; out.i2 = i2;
     out.v = sub(point(g.mem, g.P1, i1), point(g.mem, g.P2, i2));
@@ -786,8 +789,6 @@ __device__ __forceinline__ void support_pts_quarter2(Ctx<Mem>& g, const V2& dir,
     // point 0's value NaN: maxd starts as NaN and nothing is ever greater (the row's lane 0 holds point 0)
     const unsigned long long nan1 = __ballot(v1 != v1), nan2 = __ballot(v2 != v2);
     const int row0 = lane & 48;
-    if (v1 != v1) v1 = -__builtin_inf();                   // `cur > maxd` is false for NaN: never selected
-    if (v2 != v2) v2 = -__builtin_inf();
     const int i1 = row_argmax(v1, (nan1 >> row0) & 1), i2 = row_argmax(v2, (nan2 >> row0) & 1);
     out.ii = pack_ii(i1, i2);
     out.v = sub2(point2(g.mem, g.P1, i1), point2(g.mem, g.P2, i2));
@@ -852,16 +853,12 @@ __device__ __forceinline__ void run_quarter2(Ctx<Mem>& g, int max_iter, int md_c
         const int lane = threadIdx.x & 63, l = lane & 15, row0 = lane & 48;
         const bool have1 = l < g.P1.K, have2 = l < g.P2.K;
         const V2 nd = neg2(dir);                                  // (-1, -0)
-        double a_hi = have1 ? g.own1.x * dir.x + g.own1.y * dir.y : -__builtin_inf();      // step 1, set 1: direction
-        double b_lo = have2 ? g.own2.x * nd.x + g.own2.y * nd.y : -__builtin_inf();        // step 1, set 2: -direction
-        double a_lo = have1 ? g.own1.x * nd.x + g.own1.y * nd.y : -__builtin_inf();        // step 2, set 1: the direction turned round
-        double b_hi = have2 ? g.own2.x * dir.x + g.own2.y * dir.y : -__builtin_inf();      // step 2, set 2
+        const double a_hi = have1 ? g.own1.x * dir.x + g.own1.y * dir.y : -__builtin_inf();      // step 1, set 1: direction
+        const double b_lo = have2 ? g.own2.x * nd.x + g.own2.y * nd.y : -__builtin_inf();        // step 1, set 2: -direction
+        const double a_lo = have1 ? g.own1.x * nd.x + g.own1.y * nd.y : -__builtin_inf();        // step 2, set 1: the direction turned round
+        const double b_hi = have2 ? g.own2.x * dir.x + g.own2.y * dir.y : -__builtin_inf();      // step 2, set 2
         const unsigned long long n_ah = __ballot(a_hi != a_hi), n_bl = __ballot(b_lo != b_lo), n_al = __ballot(a_lo != a_lo),
                                  n_bh = __ballot(b_hi != b_hi);
-        if (a_hi != a_hi) a_hi = -__builtin_inf();
-        if (b_lo != b_lo) b_lo = -__builtin_inf();
-        if (a_lo != a_lo) a_lo = -__builtin_inf();
-        if (b_hi != b_hi) b_hi = -__builtin_inf();
         const int i_ah = row_argmax(a_hi, (n_ah >> row0) & 1), i_bl = row_argmax(b_lo, (n_bl >> row0) & 1);
         const int i_al = row_argmax(a_lo, (n_al >> row0) & 1), i_bh = row_argmax(b_hi, (n_bh >> row0) & 1);
         // step 1 (no point yet): A
