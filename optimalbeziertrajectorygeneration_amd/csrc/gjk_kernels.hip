@@ -282,6 +282,7 @@ struct GjkSwarmParams {
     const int* vp_idx = nullptr;
     int emit_scalar = 0;               // results may go to LDS through generic pointers: 8-byte stores only
     int refill_min = 1;                // planar sweeps: idle lanes of a wave wait until this many can refill together
+    int hist_shift = 0;                // planar sweeps: the history order's bins hold scan counts c with equal c >> hist_shift (0: one count per bin)
     int passes = 1;                    // MODE 0: chunks a workgroup takes one after the other (w-th workgroup of a row: chunks w*passes ..)
     const double* obs = nullptr;       // pair sweep (MODE 0): the context's point obstacles [n_obs][2], staged behind the hull
     int n_obs = 0;                     //         objects as constant curves for the separation rows that name them
@@ -613,7 +614,7 @@ __device__ __forceinline__ void gjk_planar_body(const GjkSwarmParams& p, double2
             const unsigned char* len = p.len_in + (size_t)b * p.len_in_stride;
             if (threadIdx.x < 256) s_hist[threadIdx.x] = 0;
             __syncthreads();
-            for (int l = threadIdx.x; l < n_loc; l += blockDim.x) atomicAdd(&s_hist[255 - len[pair_of(l)]], 1);
+            for (int l = threadIdx.x; l < n_loc; l += blockDim.x) atomicAdd(&s_hist[255 - (len[pair_of(l)] >> p.hist_shift)], 1);
             __syncthreads();
             if (threadIdx.x < kWave) {
                 const int lane = threadIdx.x;
@@ -632,7 +633,7 @@ __device__ __forceinline__ void gjk_planar_body(const GjkSwarmParams& p, double2
             __syncthreads();
             for (int l = threadIdx.x; l < n_loc; l += blockDim.x) {
                 const int kq = pair_of(l);
-                const int pos = atomicAdd(&s_hist[255 - len[kq]], 1);
+                const int pos = atomicAdd(&s_hist[255 - (len[kq] >> p.hist_shift)], 1);
                 ord[pos] = (unsigned short)l;
                 plist[pos] = slots_of(l, kq);
             }
@@ -3349,6 +3350,14 @@ static void launch_timed(ScopedKernelTimer& t, K kern, dim3 grid, dim3 block, si
     else hipLaunchKernelGGL(kern, grid, block, lds, stream, params);
 }
 
+// (experiment, profiles/r06_experiments: coarser bins keep more of a tile row's pairs next to each other in the sorted order --
+// lanes of a wave then share object A in LDS -- at the price of mixing trip counts within a wave)
+static int sweep_hist_shift()
+{
+    static const int v = getenv("OBTG_HIST_SHIFT") ? std::max(0, std::min(7, atoi(getenv("OBTG_HIST_SHIFT")))) : 0;
+    return v;
+}
+
 static int sweep_refill_min()
 {
     static const int v = getenv("OBTG_REFILL_MIN") ? std::max(1, std::min(64, atoi(getenv("OBTG_REFILL_MIN")))) : 32;
@@ -3420,7 +3429,7 @@ int launch_gjk_swarm(obtg_ctx* c, const double* dY, int B, int max_iter, int md_
     p.chunk = (c->n_hull_pairs + wgs - 1) / wgs;
     p.wgs_per_row = (c->n_hull_pairs + p.chunk - 1) / p.chunk;
     p.max_iter = max_iter; p.md_cap = md_cap;
-    p.refill_min = sweep_refill_min();
+    p.refill_min = sweep_refill_min(); p.hist_shift = sweep_hist_shift();
     p.flag = d_flag; p.p1 = d_p1; p.p2 = d_p2; p.dist = d_dist; p.nsup = d_nsup; p.status = d_status;
     if (c->fd.Y0) {
         if (c->fd_dedup) return kNeedBatch;      // the de-duplication mask compares rows in memory
@@ -3703,7 +3712,7 @@ int launch_pair_sweep(obtg_ctx* c, const double* dY, int B, double max_sep, doub
         const SweepShape shape = sweep_shape(c, B, nc, kPairSweepWavesPerSimd, kPairSweepChunk);
         p.chunk = shape.chunk; p.wgs_per_row = shape.wgs; p.passes = shape.passes;
         p.max_iter = max_iter; p.md_cap = md_cap;
-        p.refill_min = sweep_refill_min();
+        p.refill_min = sweep_refill_min(); p.hist_shift = sweep_hist_shift();
         p.flag = d_flag; p.p1 = d_p1; p.p2 = d_p2; p.dist = d_dist; p.nsup = d_nsup; p.status = d_status;
         lds = shape.lds;
         const int tr = pair_sweep_tile_rows(c, nc, lds);      // the transposition tile borrows the LDS behind the objects
@@ -3901,7 +3910,7 @@ int launch_step_fd_structured(obtg_ctx* c, int B, double max_sep, double* d_out_
     p.pa = c->d_hp_a.as<int>(); p.pb = c->d_hp_b.as<int>();
     p.n_veh = c->n_veh; p.dim = c->dim; p.nc = nc; p.n_poly = c->n_poly;
     p.n_poly_pts = c->n_poly_pts; p.n_pairs = c->n_hull_pairs;
-    p.max_iter = max_iter; p.md_cap = md_cap; p.refill_min = sweep_refill_min();
+    p.max_iter = max_iter; p.md_cap = md_cap; p.refill_min = sweep_refill_min(); p.hist_shift = sweep_hist_shift();
     p.flag = d_flag; p.p1 = d_p1; p.p2 = d_p2; p.dist = d_dist; p.nsup = d_nsup; p.status = d_status;
     p.B = B; p.chunk = 256; p.wgs_per_row = 1; p.passes = 1;
     p.ts.pairs = c->d_pairs.as<int2>(); p.ts.W2 = c->d_w2.as<double>(); p.ts.out = d_out_sep;
