@@ -1200,6 +1200,24 @@ def mindist_line(args, cpu=True, legs=None, cpu_seconds=None):
         cnt = counters_for("C5_mindist", name, _source_hash(_capi, "gjk_kernels"))
         if cnt is not None:
             out[name]["counters"] = cnt
+        if O is not None and name == "curve_polygon_reference_algorithm":
+            # sampled (curve, polygon) pairs against the oracle's search (bezier.py:1411-1496): (alpha, t1, closest point) identical where the
+            # search ends, node / call counts, depths and statuses equal; and the oracle's pair loop timed on the same sample
+            rng = np.random.default_rng(6)
+            samp = np.sort(rng.choice(npairs, size=min(npairs, 400), replace=False))
+            kw2 = dict(eps=1e-6, max_depth=128, max_nodes=2000, md_cap=4096)
+            t0 = time.perf_counter()
+            oo = [O.min_dist2poly(curves[pc[k]], polys[pp[k]], **kw2) for k in samp]
+            dt = time.perf_counter() - t0
+            ended = np.array([o_["status"] == 0 for o_ in oo])
+            same = all(np.array_equal(r["res"][k], o_["res"], equal_nan=True) for k, o_, e_ in zip(samp, oo, ended) if e_)
+            cnt_ok = all(r["nodes"][k] == o_["nodes"] and r["gjk_calls"][k] == o_["gjk_calls"] and r["depth"][k] == o_["depth"] and r["status"][k] == o_["status"]
+                         for k, o_ in zip(samp, oo))
+            out[name]["parity_check"] = {"pairs": int(len(samp)), "pairs_that_end": int(ended.sum()), "results_identical": bool(same),
+                                         "counts_and_statuses_equal": bool(cnt_ok), "ok": bool(same and cnt_ok),
+                                         "against": "oracle/obtg_oracle.c min_dist_poly_rec (bezier.py:1411-1496), same budgets"}
+            out[name]["cpu_baseline"] = {"value": round(len(samp) / dt, 1), "unit": "pair searches/s", "cores": 1, "kind": "port",
+                                         "sample": "%d of the %d pairs, one ctypes call each (call overhead included), %.2f s" % (len(samp), npairs, dt)}
         if O is not None and name in ("reference_algorithm", "jacobian_list"):
             cs, pas, pbs = (plan["curves"], plan["pa"], plan["pb"]) if big else (curves, pa, pb)
             rng = np.random.default_rng(5)

@@ -288,6 +288,30 @@ def test_c5_min_dist_subset(oracle, golden_dir):
     assert n_ok >= 25
 
 
+def test_min_dist_pair_loop_is_the_single_call(oracle, golden_dir):
+    """oracle.min_dist_pairs (round 6: the pair loop of spatialSeparationConstraints over packed curves, what bench.py's
+    `_minDist` legs check the device against and time as cpu_baseline): pair for pair the single call -- results, node and
+    gjkNew-call counts, depths, statuses -- on C5's reference fixture pairs, serial and with OpenMP over pairs."""
+    g = _load(golden_dir, "c5.npz")
+    Yall = np.vstack((g["Y"], g["Yobs"]))
+    n = Yall.shape[0] // 2
+    curves = np.zeros((n, 3, Yall.shape[1]))
+    curves[:, :2, :] = Yall.reshape(n, 2, -1)
+    pa, pb = g["md_pa"].astype(np.int32), g["md_pb"].astype(np.int32)
+    kw = dict(max_depth=128, max_nodes=5000)
+    one = oracle.min_dist_pairs(curves, pa, pb, nthreads=1, **kw)
+    many = oracle.min_dist_pairs(curves, pa, pb, nthreads=4, **kw)
+    for k in ("res", "nodes", "gjk_calls", "depth", "status"):
+        assert np.array_equal(one[k], many[k], equal_nan=True), k
+    for k in range(len(pa)):
+        r = oracle.min_dist(Yall[2 * pa[k]:2 * pa[k] + 2], Yall[2 * pb[k]:2 * pb[k] + 2], **kw)
+        assert r["status"] == one["status"][k] and r["nodes"] == one["nodes"][k] and r["gjk_calls"] == one["gjk_calls"][k]
+        assert np.array_equal(r["res"], one["res"][k], equal_nan=True)
+        if g["md_status"][k] == 0 and r["status"] == oracle.MD_OK:          # and, where both end, the REFERENCE's own result
+            assert_close(one["res"][k], g["md_res"][k], 1e-12)
+    assert (one["status"] == oracle.MD_OK).sum() >= 25
+
+
 def spatial_from_oracle(O, y, obs, dim, max_sep):
     """spatialSeparationConstraints (optimization.py:109-133) restated over the oracle's _minDist:
     vehicles then obstacles, all pairs i<j, np.array(list of 3-tuples) - maxSep."""
