@@ -4124,8 +4124,11 @@ int launch_min_dist(obtg_ctx* c, const double* d_curves, int K, const int* d_pa,
     const bool quad = pl.quad_ok && d_queue && !(env_form && !strcmp(env_form, "wave"));
     if (quad) {                            // a 16-lane row per child: four gjkNew calls of a node's children in lockstep
         OBTG_HIP(c, hipMemsetAsync(d_queue, 0, sizeof(int), c->stream));
-        static const bool no_planar = getenv("OBTG_MD_PLANAR") && getenv("OBTG_MD_PLANAR")[0] == '0';      // (A/B runs: the 3-D machine on planar curves)
-        static const int many_env = getenv("OBTG_MD_MANY") ? atoi(getenv("OBTG_MD_MANY")) : 0;             // pairs per worker from which a call counts as issue bound
+        // (both read per launch: the tests flip them in-process)
+        const char* env_planar = getenv("OBTG_MD_PLANAR");                       // "0": the 3-D machine on planar curves too (A/B runs)
+        const bool no_planar = env_planar && env_planar[0] == '0';
+        const char* env_many = getenv("OBTG_MD_MANY");                           // pairs per worker from which a call counts as issue bound
+        const int many_env = env_many ? atoi(env_many) : 0;
         const int w3 = min_dist_workers(c, n_pairs, lds_q, OBTG_MD_MIN_WAVES_PLANAR), w2 = min_dist_workers(c, n_pairs, lds_q, OBTG_MD_MIN_WAVES);
         const bool many = (long)n_pairs >= (long)(many_env > 0 ? many_env : 8) * w3;
         const int form = (planar && !no_planar) ? (many ? 2 : 1) : 0;      // 0: the 3-D machine, 1: planar, chain bound, 2: planar, issue bound
@@ -4512,7 +4515,8 @@ int launch_min_dist2poly(obtg_ctx* c, const double* d_curves, int K, const doubl
     const size_t lds_q = sizeof(double) * ((size_t)2 * md2_quad_blob(K) + 48 + 8 * kMdShRow + 64 +
                                            (size_t)(max_depth < kMdScsLds ? max_depth : kMdScsLds) * G_NSCAL);
     const char* env_form = getenv("OBTG_MD_FORM");          // "wave": a wavefront per gjkNew call (read per launch: the A/B test flips it)
-    static const bool no_planar = getenv("OBTG_MD_PLANAR") && getenv("OBTG_MD_PLANAR")[0] == '0';          // (A/B runs)
+    const char* env_planar = getenv("OBTG_MD_PLANAR");                           // (A/B runs and tests; read per launch)
+    const bool no_planar = env_planar && env_planar[0] == '0';
     if (K <= kMdQuadMaxK && max_poly_K <= 16 && lds_q <= 48 * 1024 && !(env_form && !strcmp(env_form, "wave"))) {
         // both children side by side
         const bool pl2 = planar && !no_planar;

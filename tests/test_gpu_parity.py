@@ -871,6 +871,60 @@ def test_min_dist_quad_form_is_the_wave_form(capi, synth, monkeypatch):
                 assert np.array_equal(quad[key], wave[key], equal_nan=True), (n, kw, key)
 
 
+def test_min_dist_planar_builds_are_the_3d_machine(capi, synth, monkeypatch):
+    """Round 6: 2-D curves (a zero z row, bezier.py:1294-1308) take the planar gjkNew machine per 16-lane row -- two builds of it,
+    picked by pairs per worker (two workers per SIMD for calls bound by their longest search, four for calls bound by the issue
+    rate; OBTG_MD_MANY=1 forces the second) -- with the first two doSimplex steps as one pass, max-only row reductions, the split
+    parameters' quotients from refined reciprocals and the closest points evaluated in the plane; OBTG_MD_PLANAR=0 sends the same
+    curves through the 3-D machine.  One search: results, node counts, gjkNew-call counts, depths and statuses identical, for
+    every control-point count with a kernel of its own (4, 6, 8, 9, 11, 16) and without (3, 13), under node, depth and gjkNew
+    limits (sign search cut after one / three steps -- inside and right behind the merged steps --, minimumDistance after one /
+    two rounds); the same for curve <-> polygon.  A curve whose z row holds a -0.0 is not planar to the host (its closest points
+    would show the sign)."""
+    ctx = capi.scratch_context()
+    kws = (dict(max_depth=64, max_nodes=2000), dict(max_depth=7, max_nodes=2000), dict(max_depth=64, max_nodes=1),
+           dict(max_depth=64, max_nodes=37), dict(max_depth=32, max_nodes=300, max_iter=1), dict(max_depth=32, max_nodes=300, max_iter=2),
+           dict(max_depth=32, max_nodes=300, max_iter=3, md_cap=1), dict(max_depth=32, max_nodes=300, md_cap=2),
+           dict(max_depth=32, max_nodes=500, eps=1e-3))
+    rng = np.random.default_rng(31)
+    for (ncurves, n, seed, box) in ((40, 10, 1234, False), (16, 3, 2, False), (14, 5, 3, True), (12, 7, 4, False), (12, 8, 5, True),
+                                    (10, 15, 6, False), (12, 2, 7, True), (8, 12, 8, False)):
+        if box:                                            # curves at random in a small box: many pairs cross (collisions, cycles, caps)
+            Yc = rng.uniform(0, 10, size=(ncurves * 2, n + 1))
+        else:
+            Yc = synth.swarm_control_points(ncurves, 2, n, seed=seed)
+        curves = np.zeros((ncurves, 3, n + 1))
+        curves[:, :2, :] = Yc.reshape(ncurves, 2, n + 1)
+        pa, pb = synth.all_pairs(ncurves)
+        polys = synth.polygon_obstacles(6, seed=seed)
+        ppts, poff = synth.pack_polys(polys)
+        pc = np.repeat(np.arange(ncurves), len(polys)).astype(np.int32)
+        pp = np.tile(np.arange(len(polys)), ncurves).astype(np.int32)
+        for kw in kws:
+            chain = ctx.min_dist(curves, pa, pb, **kw)
+            c2 = ctx.min_dist2poly(curves, ppts, poff, pc, pp, **kw)
+            monkeypatch.setenv("OBTG_MD_MANY", "1")
+            issue = ctx.min_dist(curves, pa, pb, **kw)
+            monkeypatch.delenv("OBTG_MD_MANY")
+            monkeypatch.setenv("OBTG_MD_PLANAR", "0")
+            space = ctx.min_dist(curves, pa, pb, **kw)
+            s2 = ctx.min_dist2poly(curves, ppts, poff, pc, pp, **kw)
+            monkeypatch.delenv("OBTG_MD_PLANAR")
+            for key in ("res", "nodes", "gjk_calls", "depth", "status"):
+                assert np.array_equal(chain[key], space[key], equal_nan=True), (n, kw, key, "planar, two workers per SIMD")
+                assert np.array_equal(issue[key], space[key], equal_nan=True), (n, kw, key, "planar, four workers per SIMD")
+                assert np.array_equal(c2[key], s2[key], equal_nan=True), (n, kw, key, "curve <-> polygon")
+    # -0.0 in a z row: the 3-D machine (the only visible difference would be the sign of a returned closest point's z)
+    curves = np.zeros((6, 3, 6))
+    curves[:, :2, :] = synth.swarm_control_points(6, 2, 5, seed=9).reshape(6, 2, 6)
+    neg = curves.copy()
+    neg[2, 2, 3] = -0.0
+    pa, pb = synth.all_pairs(6)
+    a, b = ctx.min_dist(curves, pa, pb, max_depth=32, max_nodes=500), ctx.min_dist(neg, pa, pb, max_depth=32, max_nodes=500)
+    for key in ("res", "nodes", "gjk_calls", "depth", "status"):
+        assert np.array_equal(a[key], b[key], equal_nan=True), key
+
+
 def test_min_dist2poly_quad_form_is_the_wave_form(capi, synth, monkeypatch):
     """obtg_min_dist2poly, round 5: with at most 16 control points and polygons of at most 16 vertices a node's two children are
     evaluated together, a 16-lane row each (k_min_dist2poly_quad); OBTG_MD_FORM=wave selects the wavefront-per-call form.  The
