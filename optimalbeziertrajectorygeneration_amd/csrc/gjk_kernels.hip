@@ -2448,13 +2448,13 @@ __device__ __forceinline__ void md_eval_rows(const double* lds, int o1, int o2, 
 }
 
 #ifndef OBTG_MD_MIN_WAVES_PLANAR
-#define OBTG_MD_MIN_WAVES_PLANAR 4     // workers per SIMD of an issue-bound planar call (K = 11: 128 registers + 116 B of scratch; 3: 63.2 ms, 4: 61.0 on the Jacobian list)
+#define OBTG_MD_MIN_WAVES_PLANAR 3     // workers per SIMD of an issue-bound planar call (K = 11: 162 registers, nothing spilled; four -- 128 registers + 116 B of scratch -- are no faster: 59.8 against 59.6 ms on the Jacobian list)
 #endif
 // PLANAR: every curve of the call has z == 0 in every control point (the host has looked): the planar gjkNew machine per row.
-// W: worker waves per SIMD the registers are held to.  The planar form has two builds: W = 2 (223 registers, nothing spilled) for
-// calls that are bound by the chain of their longest search (a few pairs per worker: one evaluation's 4560 pairs, 6.4 ms
-// against 7.7), W = 3 (168 registers, 44 spilled) for calls bound by the chip's issue rate (the Jacobian's 114 000: 76 ms
-// against 94) -- launch_min_dist picks by pairs per worker.
+// W: worker waves per SIMD the registers are held to.  The planar form has two builds: W = 2 for calls that are bound by the chain
+// of their longest search (a few pairs per worker: one evaluation's 4560 pairs; K = 11 takes 162 registers either way, but 2048
+// workers leave each chain more of its SIMD), W = OBTG_MD_MIN_WAVES_PLANAR for calls bound by the chip's issue rate (the Jacobian's
+// 114 000 searches) -- launch_min_dist picks by pairs per worker (OBTG_MD_MANY).  History: profiles/r06_experiments/mindist_steps.txt.
 // KC: the control-point count the kernel is built for (0: any up to 16, the count-dependent parts behind wave-uniform switches).
 // One kernel for every count took the registers of its largest case -- the split parameters' 2 K quotients per lane at K = 16 --
 // and the degree-10 searches (K = 11) spilled for it.

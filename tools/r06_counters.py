@@ -36,7 +36,7 @@ KERNELS = (
     ("C5_fd_structured", "C5_fd_structured", "pair_sweep", "k_step_fd_structured<11, true", "gjk_kernels"),
     ("C4_fd_structured", "C4_fd_structured", "pair_sweep", "k_step_fd_structured<16, false", "gjk_kernels"),
     ("C5_mindist", "C5_mindist", "reference_algorithm", "k_min_dist_quad<true, 2, 11>", "gjk_kernels"),
-    ("C5_mindist", "C5_mindist", "jacobian_list", "k_min_dist_quad<true, 4, 11>", "gjk_kernels"),
+    ("C5_mindist", "C5_mindist", "jacobian_list", "k_min_dist_quad<true, 3, 11>", "gjk_kernels"),
     ("C5_mindist", "C5_mindist", "curve_polygon_reference_algorithm", "k_min_dist2poly_quad<true, 11>", "gjk_kernels"),
 )
 
