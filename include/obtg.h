@@ -58,8 +58,9 @@ enum {
     OBTG_ST_MAXITER = 2, /* gjkNew exhausted maxIter (flag = -1, gjk/gjk.py:269-270) */
     OBTG_ST_CYCLE = 3    /* minimumDistance returned exactly to an earlier (simplex, direction) state: the
                           * reference's loop depends on nothing else, so it never exits on this input.
-                          * Reported by the 3-D state machine (any z != 0, and the curve-distance entry
-                          * points); all-z-zero input runs on the 2-D machine, guarded by md_cap alone. */
+                          * Reported by the 3-D state machine (any z != 0) and by the curve-distance entry points
+                          * (obtg_min_dist, obtg_min_dist2poly: inner calls, seen as OBTG_MD_GJK_CAP; since round 6 their
+                          * planar calls carry the checkpoint too); the planar hull SWEEPS are guarded by md_cap alone. */
 };
 
 /* per-item minDist status */
@@ -67,7 +68,7 @@ enum {
     OBTG_MD_OK = 0,
     OBTG_MD_NODE_CAP = 1,  /* node budget exhausted (reference: runs for seconds / forever) */
     OBTG_MD_DEPTH_CAP = 2, /* deeper than max_depth (reference: RecursionError / cnt > 1000, bezier.py:1310) */
-    OBTG_MD_GJK_CAP = 3    /* an inner gjkNew hit md_cap */
+    OBTG_MD_GJK_CAP = 3    /* an inner gjkNew never returns: a proven cycle of its minimumDistance loop, or md_cap rounds */
 };
 
 const char* obtg_strerror(int code);
