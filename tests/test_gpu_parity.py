@@ -925,6 +925,38 @@ def test_min_dist_planar_builds_are_the_3d_machine(capi, synth, monkeypatch):
         assert np.array_equal(a[key], b[key], equal_nan=True), key
 
 
+def test_min_dist_split_parameter_quotients_at_extreme_scales(capi, oracle, synth):
+    """Round 6: the split parameters' quotients e_l / e_j come from per-denominator refined reciprocals while every distance of
+    the call lies in [2^-300, 2^300] -- where the compiler's division expansion scales nothing and is the same instruction
+    sequence -- and from the divisions as written otherwise (the whole wavefront).  Curves scaled by powers of two far outside and
+    just inside that window (both paths, and the boundary), against the oracle: status, and where the search ends node counts,
+    gjkNew-call counts, depths and (distance, t1, t2) identical -- including the scales at which gjkNew's own products overflow
+    or vanish (NaN directions, NaN support values: `cur > maxd` semantics of the row reductions).  (Scaling by a power of two is
+    exact, so at 2^+-100 t1 / t2 are those of the unscaled search.)"""
+    ctx = capi.scratch_context()
+    for (ncurves, n, seed) in ((10, 10, 3), (8, 5, 4), (8, 15, 5)):
+        Yc = synth.swarm_control_points(ncurves, 2, n, seed=seed)
+        base = np.zeros((ncurves, 3, n + 1))
+        base[:, :2, :] = Yc.reshape(ncurves, 2, n + 1)
+        pa, pb = synth.all_pairs(ncurves)
+        ref_t = None
+        for e in (0, -100, 100, -290, 290, -310, 310, -400, 400, -306, 294):
+            curves = np.ldexp(base, e)
+            got = ctx.min_dist(curves, pa, pb, max_depth=48, max_nodes=600)
+            o = oracle.min_dist_pairs(curves, pa, pb, max_depth=48, max_nodes=600)
+            assert np.array_equal(got["status"], o["status"]), (n, e)
+            ended = o["status"] == 0
+            for key in ("nodes", "gjk_calls", "depth"):
+                assert np.array_equal(np.asarray(got[key])[ended], np.asarray(o[key])[ended]), (n, e, key)
+            assert np.array_equal(got["res"][ended], o["res"][ended], equal_nan=True), (n, e)
+            if e == 0:
+                ref_t = (got["res"][:, 1:].copy(), ended.copy())
+            elif abs(e) <= 100:                            # no under- / overflow anywhere: the same search, the distance scaled
+                both = ended & ref_t[1]                    # (beyond 2^+-256 gjkNew's fourth-order products leave the range: inf / NaN / 0
+                                                           # paths, which the device must walk exactly as the oracle does)
+                assert np.array_equal(got["res"][both, 1:], ref_t[0][both]), (n, e)
+
+
 def test_min_dist2poly_quad_form_is_the_wave_form(capi, synth, monkeypatch):
     """obtg_min_dist2poly, round 5: with at most 16 control points and polygons of at most 16 vertices a node's two children are
     evaluated together, a 16-lane row each (k_min_dist2poly_quad); OBTG_MD_FORM=wave selects the wavefront-per-call form.  The
