@@ -53,12 +53,48 @@ def _shape_ctx(nVeh, dim, deg, R, device=None):
     return c
 
 
+# The private separation evaluator under SciPy's finite differences (round 6).  Examples/Example1_DubinsCarTimeOptimal.py:124-125
+# hands SLSQP `lambda x: _temporalSeparationConstraints(bezopt.reshapeVector(x), ...)`: the function sees y, not x, and SciPy
+# differences the lambda with n_x one-row calls per iteration.  As BezOptimization._serve does for the class closures: a call
+# whose y differs from the last base in ONE element by exactly SciPy's step is taken for a row of that sweep -- the rows for
+# every element of y are evaluated in one launch, kept, and this and the following calls are answered from them (a variable
+# that moves several elements -- tf with prescribed speeds -- and any other point are evaluated directly and become the new
+# base).  Values are those of the one-row call (the batch kernels' rows are its bits: tests/test_gpu_dropin.py).
+_ysep_state = {}
+
+
 def _temporalSeparationConstraints(y, nVeh, dim, maxSep, degElev=None):
     if nVeh <= 1:
         return None
     y = np.ascontiguousarray(y, dtype=np.float64)
     R = DEG_ELEV if degElev is None else degElev
-    return _shape_ctx(nVeh, dim, y.shape[1] - 1, R).temporal_sep(y, maxSep)[0]
+    ctx = _shape_ctx(nVeh, dim, y.shape[1] - 1, R)
+    if os.environ.get("OBTG_FD_BATCHING", "1") == "0":
+        return ctx.temporal_sep(y, maxSep)[0]
+    key = (int(nVeh), int(dim), y.shape, int(R), float(maxSep))
+    st = _ysep_state.get(key)
+    if st is not None and st['ctx'] is ctx:
+        d = np.flatnonzero(y.ravel() != st['y0'].ravel())
+        if d.size == 0:
+            return st['base'].copy()
+        if d.size == 1 and y.ravel()[d[0]] == st['y0'].ravel()[d[0]] + FD_STEP:
+            if st['rows'] is None:
+                E = y.size
+                limit = float(os.environ.get("OBTG_FD_BATCH_MB", "512")) * 2.0 ** 20
+                if 8.0 * E * st['base'].size > limit:
+                    st['rows'] = False
+                else:
+                    Yb = np.repeat(st['y0'][None], E, axis=0)
+                    Yb.reshape(E, E)[np.arange(E), np.arange(E)] += FD_STEP
+                    st['rows'] = ctx.temporal_sep(Yb, maxSep)
+            if st['rows'] is not False:
+                return st['rows'][d[0]].copy()
+            return ctx.temporal_sep(y, maxSep)[0]
+    v = ctx.temporal_sep(y, maxSep)[0]
+    if len(_ysep_state) > 8:
+        _ysep_state.clear()
+    _ysep_state[key] = {'ctx': ctx, 'y0': y.copy(), 'base': v.copy(), 'rows': None}
+    return v
 
 
 def _minSpeedConstraints(y, nVeh, dim, tf, minSpeed):

@@ -815,6 +815,62 @@ def test_reference_trajectories_teacher_forced(golden_dir):
 
 
 @pytest.mark.gpu
+def test_private_separation_evaluator_serves_scipys_differences(monkeypatch):
+    """Examples/Example1_DubinsCarTimeOptimal.py:124-125 hands SLSQP a lambda over the PRIVATE evaluator
+    `_temporalSeparationConstraints(bezopt.reshapeVector(x), nVeh, dim, maxSep, elev)`; round 6 serves SciPy's differences of it
+    from one batched launch per sweep as `_serve` does for the class closures.  Nothing a driver can see may change: at x and at
+    every x + h e_k the served value equals the one-row call's (DEG_ELEV 0 / 30 / 100, the trailing tf -- which moves four
+    control points at once -- included), and Example1's own solve takes the same iterates with the switch on and off."""
+    import scipy.optimize as sop
+    from optimalbeziertrajectorygeneration_amd import optimization as opt
+    from optimalbeziertrajectorygeneration_amd.optimization import BezOptimization, FD_STEP
+
+    def problem():
+        return BezOptimization(numVeh=2, dimension=2, degree=10, minimizeGoal='TimeOpt', maxSep=1, maxSpeed=5, maxAngRate=1,
+                               initPoints=[(0, 5), (3, 0)], finalPoints=[(8, 4), (7, 10)], initSpeeds=[1] * 2, finalSpeeds=[1] * 2,
+                               initAngs=[0, np.pi / 2], finalAngs=[0, np.pi / 2])
+    bo = problem()
+    x = bo.generateGuess(std=0.2, seed=3)
+    for elev in (0, 30, 100):
+        f = lambda v: opt._temporalSeparationConstraints(bo.reshapeVector(v), 2, 2, 1, elev)      # noqa: E731
+        rows = []
+        for on in (True, False):
+            if on:
+                monkeypatch.delenv("OBTG_FD_BATCHING", raising=False)
+            else:
+                monkeypatch.setenv("OBTG_FD_BATCHING", "0")
+            opt._ysep_state.clear()
+            out = [f(x)]
+            for k in range(x.size):
+                xk = x.copy()
+                xk[k] += FD_STEP
+                out.append(f(xk))
+            out.append(f(x))                              # back at the base
+            rows.append(out)
+        for a, b in zip(*rows):
+            assert np.array_equal(a, b), elev
+        monkeypatch.delenv("OBTG_FD_BATCHING", raising=False)
+    # the example's solve, both ways: same iterates
+    res = {}
+    for on in (True, False):
+        if on:
+            monkeypatch.delenv("OBTG_FD_BATCHING", raising=False)
+        else:
+            monkeypatch.setenv("OBTG_FD_BATCHING", "0")
+        opt._ysep_state.clear()
+        b2 = problem()
+        cons = [{'type': 'ineq', 'fun': lambda v, b2=b2: opt._temporalSeparationConstraints(b2.reshapeVector(v), 2, 2, 1, 30)},
+                {'type': 'ineq', 'fun': b2.maxSpeedConstraints}, {'type': 'ineq', 'fun': b2.maxAngularRateConstraints},
+                {'type': 'ineq', 'fun': lambda v: v[-1]}]
+        r = sop.minimize(b2.objectiveFunction, x0=b2.generateGuess(std=0), method='SLSQP', constraints=cons,
+                         options={'maxiter': 250, 'disp': False})
+        res[on] = (r.x.copy(), r.nit, r.nfev, float(r.fun))
+    monkeypatch.delenv("OBTG_FD_BATCHING", raising=False)
+    assert np.array_equal(res[True][0], res[False][0]) and res[True][1:] == res[False][1:]
+    assert abs(res[True][3] - 2.427643188386696) < 1e-6          # the reference's optimum at DEG_ELEV 30 (trajectories.npz: ex1_R30)
+
+
+@pytest.mark.gpu
 def test_fd_serving_on_the_any_degree_kernels_and_the_exact_order(monkeypatch):
     """the served rows are right only if the BATCHED kernels give the one-row call's bits.  The test below covers the
     specialised shapes in the default order; here the shapes that run elsewhere: degree 6 (no specialised count: every family on the
