@@ -1122,7 +1122,7 @@ def mindist_mode(args, rank):
     reference's own algorithm (obtg_min_dist, node budget 2000 per pair: a fifth of the pairs would not
     finish in the reference either) and in the robust one (obtg_min_dist_robust); and, since round 6, at the size an SLSQP
     ITERATION asks for: the one call of spatialSeparationJacobian (`jacobian_list`: 114 000 searches)."""
-    legs = ("reference_algorithm", "jacobian_list", "curve_polygon_reference_algorithm") if args.config_leg else None
+    legs = ("reference_algorithm", "jacobian_list", "curve_polygon_reference_algorithm", "provider_end_to_end") if args.config_leg else None
     if args.mindist_legs:
         legs = tuple(x.strip() for x in args.mindist_legs.split(",") if x.strip())
     line = mindist_line(args, cpu=not args.no_cpu, legs=legs)
@@ -1227,6 +1227,36 @@ def mindist_line(args, cpu=True, legs=None, cpu_seconds=None):
             samp = np.unique(np.concatenate((rng.choice(npairs, size=min(npairs, 260), replace=False), longest)))
             out[name]["parity_check"] = mindist_parity(O, cs, pas, pbs, r, samp, kw_ref)
             out[name]["cpu_baseline"] = mindist_cpu_baseline(O, cs, pas, pbs, kw_ref, cpu_seconds, name)
+    # The PROVIDER end to end: BezOptimization.spatialSeparationJacobian(x, robust=True, column=0) on the same problem -- the 1-D
+    # distance constraint's (P, n_x) Jacobian a driver hands to SLSQP as `jac`: the host's plan of the one call, the call, the
+    # assembly of the dense matrix.  With the robust search, whose every pair ends (the reference's own search raises on this
+    # swarm's crossing pairs, as the reference does: optimization.py:127-131 never comes back from them).
+    if legs is None or "provider_end_to_end" in legs:
+        from optimalbeziertrajectorygeneration_amd import optimization as opt, bezier as bez
+        Yv = synth.swarm_control_points(N, 2, n, seed=1234)
+        Yo = synth.curve_obstacles(M, 2, n, seed=1234).reshape(M, 2, n + 1)
+        bo = opt.BezOptimization(numVeh=N, dimension=2, degree=n, minimizeGoal='Euclidean', maxSep=0.9,
+                                 initPoints=Yv.reshape(N, 2, n + 1)[:, :, 0], finalPoints=Yv.reshape(N, 2, n + 1)[:, :, -1],
+                                 shapeObstacles=[bez.Bezier(np.ascontiguousarray(o)) for o in Yo])
+        x = np.ascontiguousarray(Yv[:, 1:-1]).reshape(-1)
+        assert np.array_equal(bo.reshapeVector(x), Yv)
+        t0 = time.perf_counter()
+        J = bo.spatialSeparationJacobian(x, robust=True, column=0)
+        first_ms = 1e3 * (time.perf_counter() - t0)
+        reps = 3
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            J = bo.spatialSeparationJacobian(x, robust=True, column=0)
+        ms = 1e3 * (time.perf_counter() - t0) / reps
+        t0 = time.perf_counter()
+        F = bo.spatialSeparationConstraints(x, robust=True)
+        ms_f = 1e3 * (time.perf_counter() - t0)
+        out["provider_end_to_end"] = dict(
+            ms_per_jacobian=round(ms, 2), first_ms=round(first_ms, 2), ms_per_constraint_evaluation=round(ms_f, 2),
+            jacobian_shape=list(J.shape), nonzeros=int(np.count_nonzero(J)), finite=bool(np.isfinite(J).all() and np.isfinite(F).all()),
+            what="BezOptimization.spatialSeparationJacobian(x, robust=True, column=0) at C5 size, host arrays in and out: plan of the ONE "
+                 "call (114 000 searches), obtg_min_dist_robust, dense (4560 x 1152) matrix; and one spatialSeparationConstraints(x, robust=True); "
+                 "what ONE SLSQP iteration of Examples/ComplexObstacles.py:49-63 costs through the provider instead of n_x + 1 sweeps")
     head = out.get("jacobian_list") or out.get("reference_algorithm") or next(iter(out.values()))
     return {"metric": "spatial-separation (_minDist) evals/s, host buffers in and out", "value": (out.get("reference_algorithm") or head)["evals_per_s"],
             "unit": "constraint-evals/s", "n_gpus": 1, "higher_is_better": True, "dtype": "f64", "data": "synthetic",
@@ -1371,8 +1401,10 @@ def config_legs(args):
                 if leg in v:
                     e[leg] = {k: v[leg].get(k) for k in ("ms_per_eval", "kernel_avg_ms", "pairs", "pairs_per_s", "nodes_per_s", "gjk_calls_per_s",
                                                          "status_counts", "counters", "parity_check", "cpu_baseline")}
+            if "provider_end_to_end" in v:
+                e["provider_end_to_end"] = v["provider_end_to_end"]
             e["ms_per_step"] = v["jacobian_list"]["ms_per_eval"] if "jacobian_list" in v else v["reference_algorithm"]["ms_per_eval"]
-            e["parity"] = {"ok": all((v[leg].get("parity_check") or {"ok": True})["ok"] for leg in v)}
+            e["parity"] = {"ok": all((v[leg].get("parity_check") or {"ok": True})["ok"] for leg in v if isinstance(v[leg], dict))}
         else:
             rf = ln.get("roofline") or {}
             dom = next((k for k in (ln.get("kernels") or []) if k["kernel"] == rf.get("kernel")), None)
