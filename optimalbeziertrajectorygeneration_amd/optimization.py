@@ -187,12 +187,19 @@ def _spatial_jac_plan(Y, numVeh, dim, obstacle_curves):
     base[:numVeh, :dim, :] = Yv[0]
     for o, c in enumerate(obstacle_curves):
         base[numVeh + o] = c
-    pa0, pb0 = np.triu_indices(n, 1)                            # i < j, lexicographic: the reference's pair loop
-    P = pa0.size
     changed = np.any(Yv[1:] != Yv[0], axis=(2, 3))              # [n_x][numVeh]
     ck, cv = np.nonzero(changed)                                # (column, vehicle), columns ascending, vehicles ascending
     extra = np.zeros((ck.size, 3, K))
     extra[:, :dim, :] = Yv[ck + 1, cv]
+    # The pair lists depend on WHICH vehicles every column moves, not on the values: an SLSQP run asks for the same pattern at
+    # every iterate, so the lists of the last pattern are kept (round 6: building them was 16 of the provider's 35 ms at C5 size).
+    memo = _spatial_jac_plan.memo
+    pattern = (n, numVeh, changed.shape, changed.tobytes())
+    if memo.get('pattern') == pattern:
+        pa, pb, P, col, row, pos = memo['lists']
+        return np.concatenate((base, extra)), pa, pb, P, col, row, pos
+    pa0, pb0 = np.triu_indices(n, 1)                            # i < j, lexicographic: the reference's pair loop
+    P = pa0.size
     new_id = np.full((nx, n), -1, dtype=np.int64)               # curve index of vehicle v's perturbed copy in column k
     new_id[ck, cv] = n + np.arange(ck.size)
     # per column, the base pairs touched: those with an end among the column's changed vehicles.  A column that moves ONE
@@ -218,7 +225,11 @@ def _spatial_jac_plan(Y, numVeh, dim, obstacle_curves):
     pa = np.concatenate((pa0, np.where(na >= 0, na, ia))).astype(np.int32)
     pb = np.concatenate((pb0, np.where(nb >= 0, nb, ib))).astype(np.int32)
     pos = P + np.arange(col.size)
+    memo['pattern'], memo['lists'] = pattern, (pa, pb, P, col, row, pos)
     return np.concatenate((base, extra)), pa, pb, P, col, row, pos
+
+
+_spatial_jac_plan.memo = {}
 
 
 class BezOptimization(object):
@@ -503,10 +514,12 @@ class BezOptimization(object):
             else:
                 _raise_first_md(r['status'])
         F0 = res[:P] - maxSep
+        if column is not None:           # the one column a driver hands to SLSQP: its (P, n_x) matrix alone (a third of the zeros to write)
+            J1 = np.zeros((P, nx))
+            J1[t_row, t_col] = ((res[t_pos, column] - maxSep) - F0[t_row, column]) / dx[t_col]
+            return J1
         J = np.zeros((P, 3, nx))
         J[t_row, :, t_col] = ((res[t_pos] - maxSep) - F0[t_row]) / dx[t_col][:, None]
-        if column is not None:
-            return J[:, column, :]
         return J.reshape(3 * P, nx)
 
     # ------------------------------------------------------------------ batched Jacobians (new)
